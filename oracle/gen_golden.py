@@ -1,0 +1,185 @@
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE'S OWN modules.
+
+Run in the build container only (needs /root/reference):
+
+    python oracle/gen_golden.py
+
+For every fixture the reference module is built with a fixed seed, run in fp32 on the CPU on
+seeded inputs, and {config, state_dict, inputs, outputs, grads} are frozen to a `.pt` file.
+Before writing, the CPU restatement in `oracle/vit_oracle.py` is checked against the reference
+output on the same inputs (max-abs tolerance printed and asserted), so a committed fixture is
+also a record that the oracle was pinned when it was made.
+"""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import vit_oracle as O  # noqa: E402
+from refharness import load_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+ATOL = 2.0e-5
+
+
+def _check(name: str, a: torch.Tensor, b: torch.Tensor, atol: float = ATOL) -> None:
+    err = (a - b).abs().max().item()
+    scale = b.abs().max().item()
+    print(f"  oracle vs reference [{name}]: max|diff| = {err:.3e} (max|ref| = {scale:.3e})")
+    assert err <= atol * max(1.0, scale), name
+
+
+def gen_linear(ref) -> None:
+    torch.manual_seed(11)
+    m = ref.Linear(96, 40)
+    with torch.no_grad():
+        m.linear.bias.normal_()
+    x = torch.randn(5, 7, 96, requires_grad=True)
+    y = m(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    _check("linear", O.linear(x.detach(), sd["linear.weight"], sd["linear.bias"]), y.detach())
+    torch.save(
+        dict(
+            sd=sd, x=x.detach(), y=y.detach(), gy=gy, gx=x.grad.clone(),
+            gw=m.linear.weight.grad.clone(), gb=m.linear.bias.grad.clone(),
+        ),
+        os.path.join(OUT, "linear.pt"),
+    )
+
+
+def gen_layernorm(ref) -> None:
+    torch.manual_seed(12)
+    m = ref.NormFactory("layer").make(128)
+    with torch.no_grad():
+        m.weight.normal_(1.0, 0.2)
+        m.bias.normal_(0.0, 0.2)
+    x = (torch.randn(6, 9, 128) * 2.0 + 0.5).requires_grad_(True)
+    y = m(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    _check("layer_norm", O.layer_norm(x.detach(), m.weight.detach(), m.bias.detach(), m.eps), y.detach())
+    torch.save(
+        dict(
+            eps=m.eps, w=m.weight.detach().clone(), b=m.bias.detach().clone(), x=x.detach(),
+            y=y.detach(), gy=gy, gx=x.grad.clone(), gw=m.weight.grad.clone(), gb=m.bias.grad.clone(),
+        ),
+        os.path.join(OUT, "layernorm.pt"),
+    )
+
+
+def gen_attention(ref) -> None:
+    """Self-attention with and without the 3-D bool mask (mask quirk, attentions.py:246-253)."""
+    torch.manual_seed(13)
+    heads = 2
+    m = ref.Attention(128, heads, is_self_attention=True)
+    with torch.no_grad():
+        m.qkv_bias.normal_(0.0, 0.1)
+        m.in_w.mul_(8.0)  # larger logits than the 0.02-std init: a peaky softmax
+        m.out_linear.linear.bias.normal_(0.0, 0.1)
+    b, t = 3, 21
+    x = torch.randn(b, t, 128, requires_grad=True)
+    mask = torch.rand(b, t, t) < 0.3
+    mask[:, torch.arange(t), torch.arange(t)] = False  # no fully-masked rows
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    out = {}
+    for tag, mk in (("r_nomask", None), ("r_mask", mask)):
+        if x.grad is not None:
+            x.grad = None
+        m.zero_grad()
+        y = m(x, x, x, mask=mk).output
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+        y.backward(gy)
+        _check(f"attention/{tag}", O.self_attention(x.detach(), sd, "", heads, mk), y.detach())
+        out[tag] = dict(
+            y=y.detach().clone(), gy=gy, gx=x.grad.clone(),
+            grads={k: p.grad.clone() for k, p in m.named_parameters()},
+        )
+    torch.save(dict(sd=sd, x=x.detach(), mask=mask, heads=heads, **out), os.path.join(OUT, "attention.pt"))
+
+
+def gen_sdp(ref) -> None:
+    """`sdp_attn` core on [B,H,T,dh] incl. a causal keep-mask (the CLIP text tower's use)."""
+    torch.manual_seed(14)
+    b, h, t, dh = 2, 3, 37, 64
+    q, k, v = (torch.randn(b, h, t, dh) for _ in range(3))
+    causal_keep = ~torch.triu(torch.ones(t, t, dtype=torch.bool), diagonal=1)
+    y0 = ref.sdp_attn(q, k, v, False)
+    y1 = ref.sdp_attn(q, k, v, False, causal_keep)
+    _check("sdp/nomask", O.sdp_attention(q, k, v), y0)
+    _check("sdp/causal", O.sdp_attention(q, k, v, causal_keep), y1)
+    torch.save(dict(q=q, k=k, v=v, keep=causal_keep, y_nomask=y0, y_causal=y1), os.path.join(OUT, "sdp.pt"))
+
+
+def gen_feedforward(ref) -> None:
+    torch.manual_seed(15)
+    m = ref.FeedForward(128, 256, 0.0)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.normal_(0.0, 0.1)
+    x = torch.randn(4, 10, 128, requires_grad=True)
+    y = m(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    _check("feed_forward", O.feed_forward(x.detach(), sd, ""), y.detach())
+    torch.save(
+        dict(sd=sd, x=x.detach(), y=y.detach(), gy=gy, gx=x.grad.clone(),
+             grads={k: p.grad.clone() for k, p in m.named_parameters()}),
+        os.path.join(OUT, "feedforward.pt"),
+    )
+
+
+def gen_vit(ref) -> None:
+    """Small ViT classifier = head(ViTEncoder(x)), CE loss, all grads."""
+    torch.manual_seed(16)
+    cfg = dict(img_size=32, patch_size=8, in_channels=3, latent_dim=128, num_layers=2,
+               feedforward_dim_ratio=2.0)
+    num_classes, heads = 10, 2
+    enc = ref.ViTEncoder(**cfg)
+    head = ref.Linear(cfg["latent_dim"], num_classes)
+    with torch.no_grad():  # perturb the zero / unit inits so every gradient path is exercised
+        for n, p in list(enc.named_parameters()) + list(head.named_parameters()):
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.05)
+    b = 4
+    img = torch.randn(b, 3, 32, 32)
+    labels = torch.randint(0, num_classes, (b, 1))
+    logits = head(enc(img))
+    loss = torch.nn.functional.cross_entropy(logits, labels.view(-1))
+    loss.backward()
+    sd = {f"encoder.{k}": v.detach().clone() for k, v in enc.state_dict().items()}
+    sd.update({f"head.{k}": v.detach().clone() for k, v in head.state_dict().items()})
+    grads = {f"encoder.{k}": p.grad.clone() for k, p in enc.named_parameters()}
+    grads.update({f"head.{k}": p.grad.clone() for k, p in head.named_parameters()})
+    o_loss, o_logits, o_grads = O.loss_and_grads(img, labels, sd, heads, cfg["num_layers"])
+    _check("vit/logits", o_logits, logits.detach())
+    _check("vit/loss", o_loss, loss.detach())
+    for k in grads:
+        _check(f"vit/grad/{k}", o_grads[k], grads[k], atol=5.0e-5)
+
+    torch.save(
+        dict(cfg=cfg, num_classes=num_classes, heads=heads, sd=sd, img=img, labels=labels,
+             logits=logits.detach(), loss=loss.detach(), grads=grads),
+        os.path.join(OUT, "vit_small.pt"),
+    )
+
+
+def main() -> None:
+    os.makedirs(OUT, exist_ok=True)
+    ref = load_reference()
+    torch.set_num_threads(4)
+    for fn in (gen_linear, gen_layernorm, gen_sdp, gen_attention, gen_feedforward, gen_vit):
+        print(fn.__name__)
+        fn(ref)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
