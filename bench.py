@@ -1,0 +1,246 @@
+"""bench.py — ViT-B/16 224^2 bf16 training step on N MI355X (one process per GPU, RCCL all-reduce).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one synthetic batch that is already resident in HBM:
+patch embedding -> 12 pre-norm transformer blocks -> head LN + Linear -> softmax-CE -> full backward
+-> (N > 1: bucketed gradient all-reduce) -> fused AdamW update of all 86.6 M parameters.
+Rank 0 prints ONE JSON line (metric = BASELINE.json's: train samples/sec + step ms).
+
+Extra objects:
+  roofline      dominant kernel family = the MFMA GEMM (`gemm_bf16_kernel<*>`, 96 % of the step's
+                FLOPs).  achieved = algorithmic FLOPs of every GEMM launch of one step (2*M*N*K each,
+                the per-sample figure of SURVEY §8d x the batch) / sum of their durations, each shape
+                timed live with HIP events on the launch stream; peak = 2500 TFLOP/s dense bf16.
+  cpu_baseline  the CPU oracle (oracle/vit_oracle.py, a port of the reference's PyTorch-CPU path) doing
+                the same step (fwd + CE + bwd + AdamW) in fp32 on the host cores, on a bounded sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOP_PER_SAMPLE = 105.38e9  # fwd + bwd, SURVEY §8d (17 563 828 224 MAC fwd x 2 x 3)
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def gemm_shapes(batch: int, t: int = 197, d: int = 768, dff: int = 3072, layers: int = 12, classes: int = 1000):
+    """(count, layout, M, N, K, epilogue) of every GEMM launch in one training step."""
+    m = batch * t
+    mp = batch * (t - 1)
+    L = layers
+    return [
+        # forward (k-major x k-major)
+        (L, "nt", m, 3 * d, d, "bias"), (L, "nt", m, d, d, "residual"), (L, "nt", m, dff, d, "gelu"),
+        (L, "nt", m, d, dff, "residual"), (1, "nt", mp, d, d, "bias"), (1, "nt", batch, classes, d, "bias"),
+        # backward dX = dY W (W read n-major through the transposing LDS read)
+        (L, "nn", m, dff, d, "dgelu"), (L, "nn", m, d, dff, "none"), (L, "nn", m, d, d, "none"),
+        (L, "nn", m, d, 3 * d, "none"), (1, "nn", batch, d, classes, "none"),
+        # backward dW = dY^T X (both operands token-major), split-K
+        (L, "tn", d, dff, m, "none"), (L, "tn", dff, d, m, "none"), (L, "tn", d, d, m, "none"),
+        (L, "tn", 3 * d, d, m, "none"), (1, "tn", d, d, mp, "none"), (1, "tn", classes, d, batch, "none"),
+    ]
+
+
+def time_gemms(batch: int, reps: int):
+    """Event-timed duration of every GEMM shape of the step (steady state, same stream)."""
+    from cflearn_amd import ops
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rows = []
+    tot_flops = tot_time = 0.0
+    for count, layout, m, n, k, epi in gemm_shapes(batch):
+        bf = torch.bfloat16
+        g = torch.Generator(device=dev).manual_seed(m + n + k)
+        rnd = lambda *s: (torch.randn(*s, generator=g, device=dev) * 0.5).to(bf)  # noqa: E731
+        if layout == "nt":
+            a, b, kw = rnd(m, k), rnd(n, k), {}
+        elif layout == "nn":
+            a, b, kw = rnd(m, k), rnd(k, n), dict(b_trans=True)
+        else:
+            a, b, kw = rnd(k, m), rnd(k, n), dict(a_trans=True, b_trans=True, out_dtype=torch.float32,
+                                                  split_k=ops.pick_split_k(m, n, k))
+        bias = torch.zeros(n, device=dev) if epi in ("bias", "residual", "gelu") else None
+        aux = rnd(m, n) if epi in ("residual", "dgelu") else None
+        if epi == "gelu":
+            kw.update(epilogue=ops.EPI_GELU, aux_out=torch.empty(m, n, dtype=bf, device=dev))
+        elif epi == "residual":
+            kw.update(epilogue=ops.EPI_RESIDUAL, aux_in=aux)
+        elif epi == "dgelu":
+            kw.update(epilogue=ops.EPI_DGELU, aux_in=aux)
+        out = torch.empty(m, n, dtype=kw.pop("out_dtype", bf), device=dev)
+        for _ in range(2):
+            ops.gemm(a, b, bias=bias, out=out, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.gemm(a, b, bias=bias, out=out, **kw)
+        e1.record()
+        e1.synchronize()
+        dur = e0.elapsed_time(e1) * 1e-3 / reps
+        flops = 2.0 * m * n * k
+        rows.append(dict(layout=layout, M=m, N=n, K=k, epilogue=epi, count=count, us=round(dur * 1e6, 1),
+                         tflops=round(flops / dur / 1e12, 1)))
+        tot_flops += count * flops
+        tot_time += count * dur
+    return tot_flops, tot_time, rows
+
+
+def cpu_baseline(batch: int, steps: int):
+    """The oracle's step on the host cores: fwd + CE + bwd (autograd over the restatement) + AdamW."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vit_oracle as O
+
+    import cflearn_amd as C
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = C.vit_b16_classifier(1000)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    del model
+    g = torch.Generator().manual_seed(1234)
+    img = torch.randn(batch, 3, 224, 224, generator=g)
+    labels = torch.randint(0, 1000, (batch, 1), generator=g)
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in sd.items()}
+
+    def one(step: int) -> None:
+        _, _, grads = O.loss_and_grads(img, labels, sd, 12, 12)
+        for k in sd:
+            O.adamw_step(sd[k], grads[k], m[k], v2[k], step, 1e-4, weight_decay=0.0)
+
+    one(1)
+    t0 = time.perf_counter()
+    for s in range(steps):
+        one(s + 2)
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch * steps / dt, 3), unit="samples/s", cores=cores, kind="port",
+                sample=f"{steps} timed steps (+1 warm-up) of fwd+CE+bwd+AdamW, fp32, batch {batch}, "
+                       f"torch CPU with {cores} threads, ViT-B/16 224^2",
+                ms_per_step=round(dt / steps * 1e3, 1))
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--gemm-reps", type=int, default=10)
+    ap.add_argument("--bucket-mb", type=int, default=64)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" == RCCL on ROCm
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+
+    import cflearn_amd as C
+    from cflearn_amd.engine import TrainStep
+
+    torch.manual_seed(0)  # identical init on every rank (and rank 0 is broadcast anyway)
+    model = C.vit_b16_classifier(1000).to(dev)
+    ts = TrainStep(model, lr=1.0e-4, weight_decay=0.0, decoupled=True, use_graph=not args.no_graph,
+                   distributed=distributed, bucket_bytes=args.bucket_mb << 20)
+    g = torch.Generator().manual_seed(1234 + rank)
+    img = torch.randn(args.batch, 3, 224, 224, generator=g).to(dev)
+    labels = torch.randint(0, 1000, (args.batch,), generator=g).to(dev)
+
+    def sync() -> None:
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    first_loss = None
+    for i in range(args.warmup):
+        loss = ts.step(img, labels)
+        if i == 0:
+            first_loss = loss.item() / args.batch
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = ts.step(img, labels)
+    sync()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    last_loss = loss.item() / args.batch
+    samples_per_s = world * args.batch * args.steps / dt
+
+    result = {
+        "metric": "train samples/sec + step ms, ViT-B/16 bf16 DDP at 1/2/4/8 MI355X",
+        "value": round(samples_per_s, 2),
+        "unit": "samples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": "ViT-B/16 224^2 classifier (1000 classes), fwd + softmax-CE + bwd + AdamW, bf16 "
+                        "activations / MFMA operands, fp32 master weights, grads and optimizer state",
+            "per_gpu_batch": args.batch,
+            "global_batch": world * args.batch,
+            "seq_len": 197,
+            "parallelism": f"dp{world}",
+            "launch": "hipGraph replay" if ts.use_graph else "eager",
+            "grad_exchange": "none" if not distributed else f"bucketed RCCL all-reduce fp32, {args.bucket_mb} MB buckets, side stream",
+            "loss_first_step": None if first_loss is None else round(first_loss, 4),
+            "loss_last_step": round(last_loss, 4),
+        },
+        "mfma_frac_whole_step": round(samples_per_s * FLOP_PER_SAMPLE / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+    }
+    if rank == 0 and not args.no_roofline:
+        flops, tsec, rows = time_gemms(args.batch, args.gemm_reps)
+        achieved = flops / tsec / 1e12
+        result["roofline"] = {
+            "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "kernel": "gemm_bf16_kernel<AT,BT,EPI> (all GEMM launches of one step, weighted by count)",
+            "gemm_ms_per_step": round(tsec * 1e3, 3),
+            "shapes": rows,
+        }
+    if distributed:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
+    if rank == 0:
+        print(json.dumps(result))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Build libcfhip.so (gfx950 only) in-tree: carefree-learn_amd/libcfhip.so
+set -e
+cd "$(dirname "$0")/carefree-learn_amd/csrc"
+OUT=../libcfhip.so
+mkdir -p ../_build
+pids=()
+for f in errors gemm attn norm elementwise; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c $f.hip -o ../_build/$f.o &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../_build/*.o
+echo "built $(realpath $OUT)"

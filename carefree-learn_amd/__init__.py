@@ -1,0 +1,39 @@
+"""carefree-learn_amd — MI355X-native (gfx950) implementation of carefree-learn's data-parallel
+training hot path: the `cflearn.modules` building blocks behind ViT (Linear / Attention /
+FeedForward / LayerNorm / patch embedding), the fused Adam step and the bucketed RCCL gradient
+exchange, behind the reference's module-registry surface.
+
+Importable as `cflearn_amd` (the directory name `carefree-learn_amd` is not a Python identifier;
+`cflearn_amd.py` at the repository root is the alias loader).
+
+Importing the package never touches the GPU; the first kernel call loads `libcfhip.so`
+(built by `__graft_entry__.build()`), and raises if it is missing — there is no CPU fallback.
+"""
+from . import _lib, ops, functional, fused, registry, modules, optim, ddp  # noqa: F401
+from .registry import (  # noqa: F401
+    PrefixModules,
+    build_module,
+    module_dict,
+    register_module,
+)
+from .modules import (  # noqa: F401
+    Attention,
+    AttentionTokenMixer,
+    Conv2d,
+    FeedForward,
+    HijackCustomLinear,
+    HijackLinear,
+    LayerNorm,
+    Linear,
+    MixedStackedEncoder,
+    MixingBlock,
+    NormFactory,
+    VanillaClassifier,
+    VanillaPatchEmbed,
+    ViTEncoder,
+    vit_b16_classifier,
+)
+from .optim import FusedAdam, ParamArena, clip_grad_norm_  # noqa: F401
+from .ddp import BucketedAllReduce, RcclDDPCallback, get_ddp_info  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,93 @@
+"""ctypes binding of libcfhip.so (the C-ABI declared in include/cfhip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `build_lib.sh` and must sit next to
+this file.  There is NO fallback: if it is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcfhip.so")
+
+_lib: Optional[ctypes.CDLL] = None
+
+# name -> (restype, argtypes); mirrors include/cfhip.h line by line
+_P = c_void_p
+SIGNATURES = {
+    "cfhip_version": (c_int, []),
+    "cfhip_last_error": (c_char_p, []),
+    "cfhip_gemm_bf16": (
+        c_int,
+        [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int,
+         c_int, c_int, c_int, _P, c_size_t, _P],
+    ),
+    "cfhip_colsum_workspace": (c_size_t, [c_int, c_int]),
+    "cfhip_colsum_bf16": (c_int, [_P, _P, c_int, c_int, c_int64, c_int, _P, c_size_t, _P]),
+    "cfhip_layernorm_fwd": (
+        c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int64, c_int64, c_float, _P]
+    ),
+    "cfhip_layernorm_bwd_workspace": (c_size_t, [c_int, c_int]),
+    "cfhip_layernorm_bwd": (
+        c_int,
+        [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int64, c_int64, c_int64, c_int, _P,
+         c_size_t, _P],
+    ),
+    "cfhip_attn_fwd": (
+        c_int,
+        [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
+         c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, _P],
+    ),
+    "cfhip_attn_bwd": (
+        c_int,
+        [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64,
+         c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, _P],
+    ),
+    "cfhip_im2row": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cfhip_assemble_tokens_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "cfhip_assemble_tokens_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "cfhip_cast_f32_to_bf16": (c_int, [_P, _P, c_int64, _P]),
+    "cfhip_cast_bf16_to_f32": (c_int, [_P, _P, c_int64, _P]),
+    "cfhip_gelu_fwd": (c_int, [_P, _P, c_int64, _P]),
+    "cfhip_gelu_bwd": (c_int, [_P, _P, _P, c_int64, _P]),
+    "cfhip_add_bf16": (c_int, [_P, _P, _P, c_int64, _P]),
+    "cfhip_transpose_bf16": (c_int, [_P, _P, c_int, c_int, c_int64, c_int64, _P]),
+    "cfhip_adam_step": (
+        c_int,
+        [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_int,
+         c_float, _P],
+    ),
+    "cfhip_adam_step_dev": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, c_int, _P]),
+    "cfhip_sumsq_f32": (c_int, [_P, _P, c_int64, _P]),
+    "cfhip_softmax_xent": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P]),
+}
+
+
+def lib_exists() -> bool:
+    return os.path.isfile(LIB_PATH)
+
+
+def load() -> ctypes.CDLL:
+    """Load libcfhip.so once; raises if it has not been built (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not lib_exists():
+        raise RuntimeError(
+            f"libcfhip.so not found at {LIB_PATH}: run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or ./build_lib.sh) first — the HIP path has no fallback"
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().cfhip_last_error()
+        raise RuntimeError(f"cfhip {what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,485 @@
+// K3/K4: fused scaled-dot-product attention (forward + backward) for gfx950, head_dim 64,
+// sequence lengths up to 256 (the whole K / V of one head is resident in LDS: ViT-B/16 has T = 197).
+//
+// Replaces F.scaled_dot_product_attention reached through sdp_attn (reference toolkit.py:953-963)
+// from Attention.forward (attentions.py:254), including the head split / merge permute copies
+// (attentions.py:180-185, 270-275): q / k / v are read in place from the packed [B,T,3,H,64]
+// projection output and o is written directly as [B,T,H*64].
+//
+// Structure (all on v_mfma_f32_16x16x32_bf16, one 16-row tile per wave):
+//   * "swapped" products: S^T = K Q^T, so that a lane holds 4 consecutive kv positions of ONE query
+//     row (row = lane & 15) -> the row softmax is lane-local plus two xor-shuffles (16, 32), and the
+//     bf16-packed probabilities are directly the register operand of the P·V MFMA (the k-slot
+//     permutation this implies is matched on the V side, a dot product does not care about order).
+//   * K / V / Q / dO tiles sit in LDS as [rows][64] bf16 with an XOR swizzle of the 16-byte slots;
+//     row-operand fragments are ds_read_b128, column-operand fragments (V in P·V, K in dS·K,
+//     dO and Q in the dK/dV pass) are ds_read_b64_tr_b16 hardware-transpose reads.
+//   * backward = two passes without atomics: pass A (wave = query tile) recomputes S and dP and
+//     accumulates dQ; pass B (wave = kv tile) recomputes them transposed and accumulates dK, dV.
+//     Deterministic; costs 7 instead of 5 GEMM units, attention is 3.4 % of the ViT FLOPs.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int DH = CFHIP_ATTN_HEAD_DIM;  // 64
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct AttnParams {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v;
+  bf16_t* o; const bf16_t* o_in; const bf16_t* d_o;
+  float* lse; float* delta;
+  const uint8_t* mask;
+  bf16_t* dq; bf16_t* dk; bf16_t* dv;
+  int B, H, Tq, Tk;
+  long q_sb, q_st, kv_sb, kv_st, o_sb, o_st;
+  long ms_b, ms_h, ms_q;
+  float scale;
+  int causal;
+};
+
+// byte offset of element (row, col) in a swizzled [rows][64] bf16 tile (128 B per row)
+__device__ __forceinline__ int tile_off(int row, int col) {
+  return row * 128 + ((((col >> 3) ^ ((row >> 1) & 7))) << 4) + ((col & 7) << 1);
+}
+
+// cooperative load of `rows_pad` rows (zero beyond rows_valid) of one head into a swizzled tile
+__device__ __forceinline__ void load_tile(char* tile, const bf16_t* base, long stride_t, int rows_valid,
+                                          int rows_pad) {
+  for (int idx = threadIdx.x; idx < rows_pad * 8; idx += blockDim.x) {
+    const int row = idx >> 3, slot = idx & 7;
+    u32x4 val = {0u, 0u, 0u, 0u};
+    if (row < rows_valid) val = *reinterpret_cast<const u32x4*>(base + (long)row * stride_t + slot * 8);
+    *reinterpret_cast<u32x4*>(tile + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = val;
+  }
+}
+
+// row-operand fragment: lane (i = l&15, g = l>>4) <- tile[row0 + i][ks*32 + 8g .. +8]
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int row0, int ks, int lane) {
+  const int row = row0 + (lane & 15);
+  const int slot = ks * 4 + (lane >> 4);
+  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+}
+
+// column-operand fragment over the 32-row block starting at `r32`, columns c0..c0+15:
+// lane (n = l&15, g = l>>4) <- { tile[r32 + 4g + e][c0 + n], e = 0..3 ; tile[r32 + 16 + 4g + e][c0 + n] }
+// (the k-slot order that the packed S^T / P registers have).
+__device__ __forceinline__ bf16x8 frag_cols(const char* tile, int r32, int c0, int lane) {
+  const int g = lane >> 4, s = lane & 15;
+  const int r_lo = r32 + 4 * g + (s >> 2);
+  const int col = c0 + 4 * (s & 3);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)LDS_PTR(tile + tile_off(r_lo, col)));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)LDS_PTR(tile + tile_off(r_lo + 16, col)));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+// row-operand fragment straight from global memory (one 16-row tile owned by this wave)
+__device__ __forceinline__ bf16x8 frag_global(const bf16_t* base, long stride_t, int row0, int rows_valid,
+                                              int ks, int lane) {
+  const int row = row0 + (lane & 15);
+  bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (row < rows_valid)
+    r = *reinterpret_cast<const bf16x8*>(base + (long)row * stride_t + ks * 32 + (lane >> 4) * 8);
+  return r;
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  union { bf16x8 v; unsigned w[4]; } u;
+  u.w[0] = pack_bf16x2(a[0], a[1]); u.w[1] = pack_bf16x2(a[2], a[3]);
+  u.w[2] = pack_bf16x2(b[0], b[1]); u.w[3] = pack_bf16x2(b[2], b[3]);
+  return u.v;
+}
+
+__device__ __forceinline__ bool keep_at(const AttnParams& p, int b, int h, int i, int j) {
+  if (j >= p.Tk) return false;
+  if (p.causal && j > i) return false;
+  if (p.mask != nullptr) return p.mask[(long)b * p.ms_b + (long)h * p.ms_h + (long)i * p.ms_q + j] != 0;
+  return true;
+}
+
+__device__ __forceinline__ float group_max(float v) {  // across the 4 lanes sharing l & 15
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: workgroup = (query chunk of nwaves*16 rows, head, batch); NB = ceil(Tk / 32)
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + NB * 32 * 128;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const bf16_t* kb = p.k + (long)b * p.kv_sb + h * DH;
+  const bf16_t* vb = p.v + (long)b * p.kv_sb + h * DH;
+  load_tile(Ks, kb, p.kv_st, p.Tk, NB * 32);
+  load_tile(Vs, vb, p.kv_st, p.Tk, NB * 32);
+  __syncthreads();
+
+  const int row0 = (blockIdx.x * nwaves + wave) * 16;
+  if (row0 >= p.Tq) return;
+  const int i = lane & 15, g = lane >> 4;
+  const int qi = row0 + i;
+  const bf16_t* qb = p.q + (long)b * p.q_sb + h * DH;
+  const bf16x8 qf0 = frag_global(qb, p.q_st, row0, p.Tq, 0, lane);
+  const bf16x8 qf1 = frag_global(qb, p.q_st, row0, p.Tq, 1, lane);
+
+  f32x4 st[2 * NB];
+#pragma unroll
+  for (int jt = 0; jt < 2 * NB; ++jt) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 0, lane), qf0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 1, lane), qf1, acc, 0, 0, 0);
+    st[jt] = acc;
+  }
+  // scaled scores in the log2 domain, masked; row max / sum
+  const float sl2 = p.scale * LOG2E;
+  const bool plain = (p.mask == nullptr) && !p.causal;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int jt = 0; jt < 2 * NB; ++jt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = jt * 16 + 4 * g + r;
+      const bool keep = plain ? (j < p.Tk) : keep_at(p, b, h, qi < p.Tq ? qi : p.Tq - 1, j);
+      const float x = keep ? st[jt][r] * sl2 : -INFINITY;
+      st[jt][r] = x;
+      mx = fmaxf(mx, x);
+    }
+  }
+  mx = group_max(mx);
+  float l = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < 2 * NB; ++jt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = exp2f(st[jt][r] - mx);
+      st[jt][r] = e;
+      l += e;
+    }
+  }
+  l = group_sum(l);
+
+  // O^T[d][i] = sum_j V^T[d][j] P^T[j][i]   (operands swapped: lane ends with 4 consecutive d of row i)
+  f32x4 ot[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < NB; ++a) {
+    const bf16x8 pa = pack8(st[2 * a], st[2 * a + 1]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Vs, a * 32, dt * 16, lane), pa, ot[dt], 0, 0, 0);
+  }
+  if (qi < p.Tq) {
+    const float inv = 1.0f / l;
+    bf16_t* orow = p.o + (long)b * p.o_sb + (long)qi * p.o_st + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const f32x4 v = ot[dt] * inv;
+      *reinterpret_cast<u32x2*>(orow + dt * 16 + 4 * g) =
+          u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+    if (g == 0 && p.lse != nullptr)
+      p.lse[((long)b * p.H + h) * p.Tq + qi] = (mx + log2f(l)) * (1.0f / LOG2E);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass A: dQ (and delta = rowsum(dO * O)).  workgroup as in forward; K, V in LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p, int nb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + nb * 32 * 128;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  load_tile(Ks, p.k + (long)b * p.kv_sb + h * DH, p.kv_st, p.Tk, nb * 32);
+  load_tile(Vs, p.v + (long)b * p.kv_sb + h * DH, p.kv_st, p.Tk, nb * 32);
+  __syncthreads();
+
+  const int row0 = (blockIdx.x * nwaves + wave) * 16;
+  if (row0 >= p.Tq) return;
+  const int i = lane & 15, g = lane >> 4;
+  const int qi = row0 + i;
+  const bool qvalid = qi < p.Tq;
+  const bf16_t* qb = p.q + (long)b * p.q_sb + h * DH;
+  const bf16_t* dob = p.d_o + (long)b * p.o_sb + h * DH;
+  const bf16_t* ob = p.o_in + (long)b * p.o_sb + h * DH;
+  const bf16x8 qf0 = frag_global(qb, p.q_st, row0, p.Tq, 0, lane);
+  const bf16x8 qf1 = frag_global(qb, p.q_st, row0, p.Tq, 1, lane);
+  const bf16x8 dof0 = frag_global(dob, p.o_st, row0, p.Tq, 0, lane);
+  const bf16x8 dof1 = frag_global(dob, p.o_st, row0, p.Tq, 1, lane);
+  // delta_i = sum_d dO[i][d] * O[i][d]
+  float delta;
+  {
+    const bf16x8 of0 = frag_global(ob, p.o_st, row0, p.Tq, 0, lane);
+    const bf16x8 of1 = frag_global(ob, p.o_st, row0, p.Tq, 1, lane);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s += bf16_to_f32((bf16_t)dof0[e]) * bf16_to_f32((bf16_t)of0[e]);
+      s += bf16_to_f32((bf16_t)dof1[e]) * bf16_to_f32((bf16_t)of1[e]);
+    }
+    delta = group_sum(s);
+  }
+  const long stat = ((long)b * p.H + h) * p.Tq + qi;
+  if (qvalid && g == 0) p.delta[stat] = delta;
+  const float lse2 = qvalid ? p.lse[stat] * LOG2E : INFINITY;  // +inf -> p = 0 for padded rows
+  const float sl2 = p.scale * LOG2E;
+  const bool plain = (p.mask == nullptr) && !p.causal;
+
+  f32x4 dqt[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dqt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < nb; ++a) {
+    f32x4 ds[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int jt = 2 * a + t;
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 0, lane), qf0, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 1, lane), qf1, s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vs, jt * 16, 0, lane), dof0, dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vs, jt * 16, 1, lane), dof1, dp, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = jt * 16 + 4 * g + r;
+        const bool keep = plain ? (j < p.Tk) : keep_at(p, b, h, qvalid ? qi : p.Tq - 1, j);
+        const float pr = keep ? exp2f(s[r] * sl2 - lse2) : 0.f;
+        ds[t][r] = pr * (dp[r] - delta);
+      }
+    }
+    const bf16x8 dsp = pack8(ds[0], ds[1]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Ks, a * 32, dt * 16, lane), dsp, dqt[dt], 0, 0, 0);
+  }
+  if (qvalid) {
+    bf16_t* dqrow = p.dq + (long)b * p.q_sb + (long)qi * p.q_st + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const f32x4 v = dqt[dt] * p.scale;
+      *reinterpret_cast<u32x2*>(dqrow + dt * 16 + 4 * g) =
+          u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass B: dK, dV.  workgroup = (kv chunk of nwaves*16 rows, head, batch); Q, dO, lse,
+// delta of the whole head in LDS; nbq = ceil(Tq / 32).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p, int nbq) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* dOs = smem + nbq * 32 * 128;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * nbq * 32 * 128);
+  float* delta_s = lse_s + nbq * 32;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  load_tile(Qs, p.q + (long)b * p.q_sb + h * DH, p.q_st, p.Tq, nbq * 32);
+  load_tile(dOs, p.d_o + (long)b * p.o_sb + h * DH, p.o_st, p.Tq, nbq * 32);
+  for (int t = threadIdx.x; t < nbq * 32; t += blockDim.x) {
+    const long stat = ((long)b * p.H + h) * p.Tq + t;
+    lse_s[t] = t < p.Tq ? p.lse[stat] * LOG2E : INFINITY;
+    delta_s[t] = t < p.Tq ? p.delta[stat] : 0.f;
+  }
+  __syncthreads();
+
+  const int row0 = (blockIdx.x * nwaves + wave) * 16;  // kv rows of this wave
+  if (row0 >= p.Tk) return;
+  const int n = lane & 15, g = lane >> 4;
+  const int kj = row0 + n;
+  const bf16_t* kb = p.k + (long)b * p.kv_sb + h * DH;
+  const bf16_t* vb = p.v + (long)b * p.kv_sb + h * DH;
+  const bf16x8 kf0 = frag_global(kb, p.kv_st, row0, p.Tk, 0, lane);
+  const bf16x8 kf1 = frag_global(kb, p.kv_st, row0, p.Tk, 1, lane);
+  const bf16x8 vf0 = frag_global(vb, p.kv_st, row0, p.Tk, 0, lane);
+  const bf16x8 vf1 = frag_global(vb, p.kv_st, row0, p.Tk, 1, lane);
+  const float sl2 = p.scale * LOG2E;
+  const bool plain = (p.mask == nullptr) && !p.causal;
+
+  f32x4 dkt[4], dvt[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { dkt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int a = 0; a < nbq; ++a) {
+    f32x4 pp[2], ds[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int it = 2 * a + t;
+      // S[i][j] with lane <- rows i = it*16 + 4g + r, column j = kj
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs, it * 16, 0, lane), kf0, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs, it * 16, 1, lane), kf1, s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dOs, it * 16, 0, lane), vf0, dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dOs, it * 16, 1, lane), vf1, dp, 0, 0, 0);
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + it * 16 + 4 * g);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + it * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = it * 16 + 4 * g + r;
+        const bool keep = plain ? (kj < p.Tk) : (qi < p.Tq && keep_at(p, b, h, qi, kj));
+        const float pr = keep ? exp2f(s[r] * sl2 - l4[r]) : 0.f;
+        pp[t][r] = pr;
+        ds[t][r] = pr * (dp[r] - d4[r]);
+      }
+    }
+    const bf16x8 ppk = pack8(pp[0], pp[1]);
+    const bf16x8 dsk = pack8(ds[0], ds[1]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(dOs, a * 32, dt * 16, lane), ppk, dvt[dt], 0, 0, 0);
+      dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Qs, a * 32, dt * 16, lane), dsk, dkt[dt], 0, 0, 0);
+    }
+  }
+  if (kj < p.Tk) {
+    bf16_t* dkrow = p.dk + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH;
+    bf16_t* dvrow = p.dv + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const f32x4 kk = dkt[dt] * p.scale;
+      const f32x4 vv = dvt[dt];
+      *reinterpret_cast<u32x2*>(dkrow + dt * 16 + 4 * g) =
+          u32x2{pack_bf16x2(kk[0], kk[1]), pack_bf16x2(kk[2], kk[3])};
+      *reinterpret_cast<u32x2*>(dvrow + dt * 16 + 4 * g) =
+          u32x2{pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3])};
+    }
+  }
+}
+
+// waves per workgroup: cover the tiles with the fewest idle wave slots (at most 8 waves)
+inline int pick_waves(int T) {
+  const int tiles = (T + 15) / 16;
+  const int groups = (tiles + 7) / 8;
+  return (tiles + groups - 1) / groups;
+}
+
+int check_common(const char* who, const void* q, const void* k, const void* v, int B, int H, int Tq, int Tk,
+                 int64_t q_sb, int64_t q_st, int64_t kv_sb, int64_t kv_st, int64_t o_sb, int64_t o_st) {
+  CFHIP_REQUIRE(q && k && v, "%s: null q/k/v", who);
+  CFHIP_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "%s: empty problem", who);
+  CFHIP_REQUIRE(Tq <= CFHIP_ATTN_MAX_T && Tk <= CFHIP_ATTN_MAX_T,
+                "%s: sequence length (Tq=%d, Tk=%d) exceeds the LDS-resident limit %d", who, Tq, Tk,
+                CFHIP_ATTN_MAX_T);
+  CFHIP_REQUIRE(q_sb % 8 == 0 && q_st % 8 == 0 && kv_sb % 8 == 0 && kv_st % 8 == 0 && o_sb % 8 == 0 &&
+                    o_st % 8 == 0,
+                "%s: strides must be multiples of 8 elements", who);
+  CFHIP_REQUIRE(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0,
+                "%s: q/k/v must be 16-byte aligned", who);
+  return CFHIP_OK;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes, const char* who) {
+  if (bytes > 65536) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+      cfhip_set_error("%s: cannot reserve %zu bytes of LDS: %s", who, bytes, hipGetErrorString(e));
+      return CFHIP_ERR_LAUNCH;
+    }
+  }
+  return CFHIP_OK;
+}
+
+}  // namespace
+
+extern "C" int cfhip_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                              const uint8_t* mask, int B, int H, int Tq, int Tk, int64_t q_stride_b,
+                              int64_t q_stride_t, int64_t kv_stride_b, int64_t kv_stride_t,
+                              int64_t o_stride_b, int64_t o_stride_t, int64_t ms_b, int64_t ms_h,
+                              int64_t ms_q, float scale, int causal, void* stream) {
+  int rc = check_common("attn_fwd", q, k, v, B, H, Tq, Tk, q_stride_b, q_stride_t, kv_stride_b,
+                        kv_stride_t, o_stride_b, o_stride_t);
+  if (rc != CFHIP_OK) return rc;
+  CFHIP_REQUIRE(o && ((uintptr_t)o & 7) == 0, "attn_fwd: o must be non-null and 8-byte aligned");
+  AttnParams p = {};
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
+  p.lse = lse; p.mask = mask;
+  p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
+  p.q_sb = q_stride_b; p.q_st = q_stride_t; p.kv_sb = kv_stride_b; p.kv_st = kv_stride_t;
+  p.o_sb = o_stride_b; p.o_st = o_stride_t;
+  p.ms_b = ms_b; p.ms_h = ms_h; p.ms_q = ms_q;
+  p.scale = scale; p.causal = causal;
+  const int nb = (Tk + 31) / 32;
+  const int nw = pick_waves(Tq);
+  const int tiles = (Tq + 15) / 16;
+  dim3 grid((tiles + nw - 1) / nw, H, B), block(nw * 64);
+  const size_t lds = (size_t)2 * nb * 32 * 128;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define CFHIP_ATTN_FWD(NB_) \
+  case NB_: hipLaunchKernelGGL((attn_fwd_kernel<NB_>), grid, block, lds, s, p); break;
+  switch (nb) {
+    CFHIP_ATTN_FWD(1) CFHIP_ATTN_FWD(2) CFHIP_ATTN_FWD(3) CFHIP_ATTN_FWD(4)
+    CFHIP_ATTN_FWD(5) CFHIP_ATTN_FWD(6) CFHIP_ATTN_FWD(7) CFHIP_ATTN_FWD(8)
+    default: cfhip_set_error("attn_fwd: bad nb %d", nb); return CFHIP_ERR_INVALID;
+  }
+#undef CFHIP_ATTN_FWD
+  CFHIP_CHECK_LAUNCH("attn_fwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                              const float* lse, float* delta, const uint8_t* mask, void* dq, void* dk,
+                              void* dv, int B, int H, int Tq, int Tk, int64_t q_stride_b,
+                              int64_t q_stride_t, int64_t kv_stride_b, int64_t kv_stride_t,
+                              int64_t o_stride_b, int64_t o_stride_t, int64_t ms_b, int64_t ms_h,
+                              int64_t ms_q, float scale, int causal, void* stream) {
+  int rc = check_common("attn_bwd", q, k, v, B, H, Tq, Tk, q_stride_b, q_stride_t, kv_stride_b,
+                        kv_stride_t, o_stride_b, o_stride_t);
+  if (rc != CFHIP_OK) return rc;
+  CFHIP_REQUIRE(o && d_o && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
+  CFHIP_REQUIRE(((uintptr_t)o & 15) == 0 && ((uintptr_t)d_o & 15) == 0 && ((uintptr_t)dq & 7) == 0 &&
+                    ((uintptr_t)dk & 7) == 0 && ((uintptr_t)dv & 7) == 0,
+                "attn_bwd: misaligned tensors");
+  AttnParams p = {};
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v;
+  p.o_in = (const bf16_t*)o; p.d_o = (const bf16_t*)d_o;
+  p.lse = const_cast<float*>(lse); p.delta = delta; p.mask = mask;
+  p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
+  p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
+  p.q_sb = q_stride_b; p.q_st = q_stride_t; p.kv_sb = kv_stride_b; p.kv_st = kv_stride_t;
+  p.o_sb = o_stride_b; p.o_st = o_stride_t;
+  p.ms_b = ms_b; p.ms_h = ms_h; p.ms_q = ms_q;
+  p.scale = scale; p.causal = causal;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  {
+    const int nb = (Tk + 31) / 32;
+    const int nw = pick_waves(Tq);
+    const int tiles = (Tq + 15) / 16;
+    dim3 grid((tiles + nw - 1) / nw, H, B), block(nw * 64);
+    const size_t lds = (size_t)2 * nb * 32 * 128;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, lds, s, p, nb);
+    CFHIP_CHECK_LAUNCH("attn_bwd_dq");
+  }
+  {
+    const int nbq = (Tq + 31) / 32;
+    const int nw = pick_waves(Tk);
+    const int tiles = (Tk + 15) / 16;
+    dim3 grid((tiles + nw - 1) / nw, H, B), block(nw * 64);
+    const size_t lds = (size_t)2 * nbq * 32 * 128 + (size_t)2 * nbq * 32 * sizeof(float);
+    rc = set_lds(attn_bwd_dkv_kernel, lds, "attn_bwd_dkv");
+    if (rc != CFHIP_OK) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, lds, s, p, nbq);
+    CFHIP_CHECK_LAUNCH("attn_bwd_dkv");
+  }
+  return CFHIP_OK;
+}

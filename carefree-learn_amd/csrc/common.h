@@ -1,0 +1,74 @@
+// Shared helpers for the gfx950 kernels of libcfhip.so (wave = 64 lanes, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/cfhip.h"
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+void cfhip_set_error(const char* fmt, ...);
+
+#define CFHIP_REQUIRE(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      cfhip_set_error(__VA_ARGS__);       \
+      return CFHIP_ERR_INVALID;           \
+    }                                     \
+  } while (0)
+
+#define CFHIP_CHECK_LAUNCH(name)                                                \
+  do {                                                                          \
+    hipError_t e__ = hipGetLastError();                                         \
+    if (e__ != hipSuccess) {                                                    \
+      cfhip_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));   \
+      return CFHIP_ERR_LAUNCH;                                                  \
+    }                                                                           \
+  } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((unsigned)v) << 16);
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float bf16lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+// ---- exact-erf GELU and its derivative ---------------------------------------------------------
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- wave-level reductions over all 64 lanes ----------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}

@@ -1,0 +1,547 @@
+// HBM-bound helpers of the ViT training path for gfx950: casts, stand-alone GELU, residual add,
+// transpose, column sums (bias gradients), ViT patch im2row, token assembly (head token +
+// positional encoding), fused Adam(W) over the flat parameter arena, gradient sum-of-squares and
+// softmax cross-entropy.  All kernels use 16-byte (or 8-byte bf16x4) coalesced accesses and
+// grid-stride loops capped at ~8 workgroups per CU.
+#include "common.h"
+
+int cfhip_internal_colreduce_f32(const float* partials, int R, int D, float* out, int accumulate,
+                                 hipStream_t s);
+
+namespace {
+
+inline int grid_for(long work_items, int per_block, int cap = 2048) {
+  long b = (work_items + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---- column reduce of a dense f32 [R][D] matrix: out[d] (+)= sum_r p[r][d] ---------------------
+// workgroup = 32 columns x 8 row-lanes; every thread keeps several independent loads in flight.
+__global__ void colreduce_f32_kernel(const float* __restrict__ p, int R, int D, float* __restrict__ out,
+                                     int accumulate) {
+  __shared__ float red[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cx;
+  float acc = 0.f;
+  if (col < D) {
+    for (int r = ry; r < R; r += 8) acc += p[(long)r * D + col];
+  }
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && col < D) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][cx];
+    out[col] = accumulate ? out[col] + s : s;
+  }
+}
+
+// ---- column sums of a bf16 [M][N] matrix, stage 1: partial[y][n] = sum over the rows of slice y
+// wave = one 512-column strip (64 lanes x 8 columns), waves of a workgroup take different rows.
+constexpr int CS_WAVES = 4;
+__global__ __launch_bounds__(CS_WAVES * 64) void colsum_partial_kernel(const bf16_t* __restrict__ x,
+                                                                        float* __restrict__ partial,
+                                                                        int M, int N, long ldx,
+                                                                        int rows_per_slice) {
+  __shared__ float red[CS_WAVES][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 512 + lane * 8;
+  const int r0 = blockIdx.y * rows_per_slice;
+  const int r1 = min(M, r0 + rows_per_slice);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < N) {  // N % 8 == 0
+    for (int r = r0 + wave; r < r1; r += CS_WAVES) {
+      const u32x4 w = *reinterpret_cast<const u32x4*>(x + (long)r * ldx + col);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[2 * e] += bf16lo(w[e]);
+        acc[2 * e + 1] += bf16hi(w[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = acc[e];
+  __syncthreads();
+  if (wave == 0 && col < N) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < CS_WAVES; ++k) s += red[k][lane * 8 + e];
+      partial[(long)blockIdx.y * N + col + e] = s;
+    }
+  }
+}
+// generic (any N, any alignment) variant: thread per column
+__global__ void colsum_generic_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int M, int N,
+                                      long ldx, int accumulate) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N) return;
+  float s = 0.f;
+  for (int r = 0; r < M; ++r) s += bf16_to_f32(x[(long)r * ldx + col]);
+  out[col] = accumulate ? out[col] + s : s;
+}
+
+inline int colsum_slices(int M) {
+  int slices = (M + 31) / 32;  // >= 32 rows per slice
+  if (slices > 256) slices = 256;
+  if (slices < 1) slices = 1;
+  return slices;
+}
+
+// ---- casts / element-wise ------------------------------------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+    reinterpret_cast<u32x2*>(dst)[i] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  }
+  for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = f32_to_bf16(src[i]);
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long n) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const u32x2 w = reinterpret_cast<const u32x2*>(src)[i];
+    reinterpret_cast<f32x4*>(dst)[i] = f32x4{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
+  }
+  for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = bf16_to_f32(src[i]);
+}
+// MODE 0: y = gelu(x); 1: dx = dy * gelu'(x); 2: out = a + b
+template <int MODE>
+__global__ void ew_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                               bf16_t* __restrict__ out, long n) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const u32x2 wa = reinterpret_cast<const u32x2*>(a)[i];
+    float va[4] = {bf16lo(wa[0]), bf16hi(wa[0]), bf16lo(wa[1]), bf16hi(wa[1])};
+    float vb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE != 0) {
+      const u32x2 wb = reinterpret_cast<const u32x2*>(b)[i];
+      vb[0] = bf16lo(wb[0]); vb[1] = bf16hi(wb[0]); vb[2] = bf16lo(wb[1]); vb[3] = bf16hi(wb[1]);
+    }
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = MODE == 0 ? gelu_erf_f(va[e]) : MODE == 1 ? va[e] * gelu_erf_grad_f(vb[e]) : va[e] + vb[e];
+    reinterpret_cast<u32x2*>(out)[i] = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+  }
+  for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float x = bf16_to_f32(a[i]);
+    const float y = MODE != 0 ? bf16_to_f32(b[i]) : 0.f;
+    out[i] = f32_to_bf16(MODE == 0 ? gelu_erf_f(x) : MODE == 1 ? x * gelu_erf_grad_f(y) : x + y);
+  }
+}
+
+// ---- bf16 transpose through a padded 64x64 LDS tile -----------------------------------------------
+__global__ void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R,
+                                      int C, long lds_, long ldd) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 256 threads: 4 rows per pass
+  for (int r = ty; r < 64; r += 4) {
+    const int rr = r0 + r, cc = c0 + tx;
+    tile[r][tx] = (rr < R && cc < C) ? src[(long)rr * lds_ + cc] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    const int cc = c0 + c, rr = r0 + tx;
+    if (cc < C && rr < R) dst[(long)cc * ldd + rr] = tile[tx][c];
+  }
+}
+
+// ---- ViT patch im2row: img [B,C,H,W] -> rows [B*gh*gw][C*P*P] (c, ph, pw) -------------------------
+// one thread = 4 consecutive pw (P % 4 == 0): 16-byte f32 read (or 8-byte bf16), 8-byte bf16 write.
+template <bool IN_BF16>
+__global__ void im2row_kernel(const void* __restrict__ img, bf16_t* __restrict__ rows, int B, int C,
+                              int Hh, int Ww, int P) {
+  const int gh = Hh / P, gw = Ww / P;
+  const int kdim = C * P * P;
+  const long total4 = (long)B * gh * gw * kdim / 4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += stride) {
+    const long e = i * 4;
+    const long rowi = e / kdim;
+    const int kk = (int)(e - rowi * kdim);
+    const int c = kk / (P * P);
+    const int ph = (kk - c * P * P) / P;
+    const int pw = kk - c * P * P - ph * P;
+    const int b = (int)(rowi / (gh * gw));
+    const int pi = (int)(rowi - (long)b * gh * gw);
+    const int py = pi / gw, px = pi - py * gw;
+    const long src = (((long)b * C + c) * Hh + (py * P + ph)) * Ww + (px * P + pw);
+    u32x2 o;
+    if (IN_BF16) {
+      o = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(img) + src);
+    } else {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(img) + src);
+      o = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+    *reinterpret_cast<u32x2*>(rows + e) = o;
+  }
+}
+
+// ---- token assembly --------------------------------------------------------------------------------
+__global__ void assemble_fwd_kernel(const bf16_t* __restrict__ patches, const float* __restrict__ head,
+                                    const float* __restrict__ pos, bf16_t* __restrict__ x0, int B, int Np,
+                                    int D) {
+  const int T = Np + 1;
+  const int d4 = D >> 2;
+  const long total = (long)B * T * d4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int dd = (int)(i % d4) * 4;
+    const long bt = i / d4;
+    const int t = (int)(bt % T);
+    const int b = (int)(bt / T);
+    const f32x4 pe = *reinterpret_cast<const f32x4*>(pos + (long)t * D + dd);
+    f32x4 v;
+    if (t == 0) {
+      v = *reinterpret_cast<const f32x4*>(head + dd);
+    } else {
+      const u32x2 w = *reinterpret_cast<const u32x2*>(patches + ((long)b * Np + (t - 1)) * D + dd);
+      v = f32x4{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
+    }
+    v += pe;
+    *reinterpret_cast<u32x2*>(x0 + bt * D + dd) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  }
+}
+// backward: dpatches = dx0[:, 1:], dpos[t] = sum_b dx0[b, t], dhead = dpos-row-0 sum.
+// one thread per (t, d): loops over the batch (coalesced across d).
+__global__ void assemble_bwd_kernel(const bf16_t* __restrict__ dx0, bf16_t* __restrict__ dpatches,
+                                    float* __restrict__ dhead, float* __restrict__ dpos, int B, int Np,
+                                    int D, int accumulate) {
+  const int T = Np + 1;
+  const long total = (long)T * D;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int t = (int)(i / D), d = (int)(i - (long)t * D);
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const bf16_t w = dx0[((long)b * T + t) * D + d];
+      s += bf16_to_f32(w);
+      if (t > 0 && dpatches != nullptr) dpatches[((long)b * Np + (t - 1)) * D + d] = w;
+    }
+    if (dpos != nullptr) dpos[i] = accumulate ? dpos[i] + s : s;
+    if (t == 0 && dhead != nullptr) dhead[d] = accumulate ? dhead[d] + s : s;
+  }
+}
+
+// ---- fused Adam / AdamW over the flat arena --------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, bf16_t* __restrict__ pb, long n, float lr, float b1,
+                            float b2, float eps, float wd, int decoupled, float bc1, float bc2_rsqrt,
+                            float gscale) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float step_size = lr / bc1;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gg = gv[e] * gscale;
+      float pp = pv[e];
+      if (wd != 0.f) {
+        if (decoupled) pp *= (1.f - lr * wd);
+        else gg += wd * pp;
+      }
+      const float mm = b1 * mv[e] + (1.f - b1) * gg;
+      const float v2 = b2 * vv[e] + (1.f - b2) * gg * gg;
+      const float denom = sqrtf(v2) * bc2_rsqrt + eps;
+      pp -= step_size * (mm / denom);
+      pv[e] = pp; mv[e] = mm; vv[e] = v2;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (pb != nullptr)
+      reinterpret_cast<u32x2*>(pb)[i] = u32x2{pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+  }
+  for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
+    float gg = g[i] * gscale, pp = p[i];
+    if (wd != 0.f) {
+      if (decoupled) pp *= (1.f - lr * wd);
+      else gg += wd * pp;
+    }
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float v2 = b2 * v[i] + (1.f - b2) * gg * gg;
+    pp -= step_size * (mm / (sqrtf(v2) * bc2_rsqrt + eps));
+    p[i] = pp; m[i] = mm; v[i] = v2;
+    if (pb != nullptr) pb[i] = f32_to_bf16(pp);
+  }
+}
+
+// Same update with the step-dependent scalars read from device memory (hyper[0..7] = lr, beta1,
+// beta2, eps, weight_decay, bias_corr1, 1/sqrt(bias_corr2), grad_scale): the launch is then
+// replayable from a captured hipGraph while the host refreshes the 32-byte record each step.
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, bf16_t* __restrict__ pb, long n,
+                                const float* __restrict__ hyper, int decoupled) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+  const float bc1 = hyper[5], bc2_rsqrt = hyper[6], gscale = hyper[7];
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float step_size = lr / bc1;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gg = gv[e] * gscale;
+      float pp = pv[e];
+      if (wd != 0.f) {
+        if (decoupled) pp *= (1.f - lr * wd);
+        else gg += wd * pp;
+      }
+      const float mm = b1 * mv[e] + (1.f - b1) * gg;
+      const float v2 = b2 * vv[e] + (1.f - b2) * gg * gg;
+      pp -= step_size * (mm / (sqrtf(v2) * bc2_rsqrt + eps));
+      pv[e] = pp; mv[e] = mm; vv[e] = v2;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (pb != nullptr)
+      reinterpret_cast<u32x2*>(pb)[i] = u32x2{pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+  }
+  for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
+    float gg = g[i] * gscale, pp = p[i];
+    if (wd != 0.f) {
+      if (decoupled) pp *= (1.f - lr * wd);
+      else gg += wd * pp;
+    }
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float v2 = b2 * v[i] + (1.f - b2) * gg * gg;
+    pp -= step_size * (mm / (sqrtf(v2) * bc2_rsqrt + eps));
+    p[i] = pp; m[i] = mm; v[i] = v2;
+    if (pb != nullptr) pb[i] = f32_to_bf16(pp);
+  }
+}
+
+__global__ void sumsq_kernel(const float* __restrict__ g, float* __restrict__ out, long n) {
+  __shared__ float red[4];
+  const long stride = (long)gridDim.x * blockDim.x;
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---- softmax cross-entropy: one wave per sample ----------------------------------------------------
+__global__ void softmax_xent_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                    float* __restrict__ loss_sum, float* __restrict__ dlogits, int B, int C,
+                                    float gscale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float* lr = logits + (long)row * C;
+  float mx = -INFINITY;
+  for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lr[c]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int c = lane; c < C; c += 64) se += __expf(lr[c] - mx);
+  se = wave_sum(se);
+  const int y = (int)labels[row];
+  const float lse = mx + __logf(se);
+  if (lane == 0) atomicAdd(loss_sum, lse - lr[y]);
+  if (dlogits != nullptr) {
+    float* dr = dlogits + (long)row * C;
+    const float inv = 1.f / se;
+    for (int c = lane; c < C; c += 64) {
+      const float pr = __expf(lr[c] - mx) * inv;
+      dr[c] = (pr - (c == y ? 1.f : 0.f)) * gscale;
+    }
+  }
+}
+
+}  // namespace
+
+int cfhip_internal_colreduce_f32(const float* partials, int R, int D, float* out, int accumulate,
+                                 hipStream_t s) {
+  hipLaunchKernelGGL(colreduce_f32_kernel, dim3((D + 31) / 32), dim3(256), 0, s, partials, R, D, out,
+                     accumulate);
+  CFHIP_CHECK_LAUNCH("colreduce_f32");
+  return CFHIP_OK;
+}
+
+extern "C" size_t cfhip_colsum_workspace(int M, int N) {
+  return (size_t)colsum_slices(M) * (size_t)N * sizeof(float);
+}
+
+extern "C" int cfhip_colsum_bf16(const void* X, float* out, int M, int N, int64_t ldx, int accumulate,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  CFHIP_REQUIRE(X && out && M > 0 && N > 0, "colsum: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const bool fast = (N % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)X & 15) == 0);
+  if (!fast) {
+    hipLaunchKernelGGL(colsum_generic_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const bf16_t*)X,
+                       out, M, N, (long)ldx, accumulate);
+    CFHIP_CHECK_LAUNCH("colsum_generic");
+    return CFHIP_OK;
+  }
+  const int slices = colsum_slices(M);
+  const size_t need = (size_t)slices * N * sizeof(float);
+  if (workspace == nullptr || workspace_bytes < need) {
+    cfhip_set_error("colsum: needs %zu workspace bytes, got %zu", need, workspace_bytes);
+    return CFHIP_ERR_WORKSPACE;
+  }
+  const int rows_per_slice = (M + slices - 1) / slices;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 511) / 512, slices), dim3(CS_WAVES * 64), 0, s,
+                     (const bf16_t*)X, (float*)workspace, M, N, (long)ldx, rows_per_slice);
+  CFHIP_CHECK_LAUNCH("colsum_partial");
+  return cfhip_internal_colreduce_f32((const float*)workspace, slices, N, out, accumulate, s);
+}
+
+extern "C" int cfhip_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  CFHIP_REQUIRE(src && dst && n >= 0, "cast_f32_to_bf16: bad arguments");
+  if (n == 0) return CFHIP_OK;
+  CFHIP_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0, "cast_f32_to_bf16: misaligned");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, (bf16_t*)dst, (long)n);
+  CFHIP_CHECK_LAUNCH("cast_f32_to_bf16");
+  return CFHIP_OK;
+}
+extern "C" int cfhip_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+  CFHIP_REQUIRE(src && dst && n >= 0, "cast_bf16_to_f32: bad arguments");
+  if (n == 0) return CFHIP_OK;
+  CFHIP_REQUIRE(((uintptr_t)src & 7) == 0 && ((uintptr_t)dst & 15) == 0, "cast_bf16_to_f32: misaligned");
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)src, dst, (long)n);
+  CFHIP_CHECK_LAUNCH("cast_bf16_to_f32");
+  return CFHIP_OK;
+}
+
+#define CFHIP_EW(NAME, MODE, A_, B_, OUT_)                                                         \
+  CFHIP_REQUIRE(A_ && OUT_ && n >= 0, NAME ": bad arguments");                                      \
+  if (n == 0) return CFHIP_OK;                                                                      \
+  CFHIP_REQUIRE(((uintptr_t)(A_)&7) == 0 && ((uintptr_t)(B_)&7) == 0 && ((uintptr_t)(OUT_)&7) == 0, \
+                NAME ": misaligned");                                                               \
+  hipLaunchKernelGGL((ew_bf16_kernel<MODE>), dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0,          \
+                     (hipStream_t)stream, (const bf16_t*)(A_), (const bf16_t*)(B_), (bf16_t*)(OUT_), \
+                     (long)n);                                                                      \
+  CFHIP_CHECK_LAUNCH(NAME);                                                                         \
+  return CFHIP_OK;
+
+extern "C" int cfhip_gelu_fwd(const void* x, void* y, int64_t n, void* stream) {
+  CFHIP_EW("gelu_fwd", 0, x, (const void*)nullptr, y)
+}
+extern "C" int cfhip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream) {
+  CFHIP_REQUIRE(x, "gelu_bwd: null x");
+  CFHIP_EW("gelu_bwd", 1, dy, x, dx)
+}
+extern "C" int cfhip_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+  CFHIP_REQUIRE(b, "add_bf16: null b");
+  CFHIP_EW("add_bf16", 2, a, b, out)
+}
+
+extern "C" int cfhip_transpose_bf16(const void* src, void* dst, int R, int C, int64_t ld_src,
+                                    int64_t ld_dst, void* stream) {
+  CFHIP_REQUIRE(src && dst && R > 0 && C > 0, "transpose: bad arguments");
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, R, C, (long)ld_src,
+                     (long)ld_dst);
+  CFHIP_CHECK_LAUNCH("transpose_bf16");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_im2row(const void* img, int img_is_bf16, void* rows, int B, int C, int Hh, int Ww,
+                            int P, void* stream) {
+  CFHIP_REQUIRE(img && rows && B > 0 && C > 0 && P > 0, "im2row: bad arguments");
+  CFHIP_REQUIRE(Hh % P == 0 && Ww % P == 0, "im2row: image %dx%d not divisible by patch %d", Hh, Ww, P);
+  CFHIP_REQUIRE(P % 4 == 0 && Ww % 4 == 0, "im2row: patch size and width must be multiples of 4");
+  CFHIP_REQUIRE(((uintptr_t)img & 15) == 0 && ((uintptr_t)rows & 7) == 0, "im2row: misaligned");
+  const long total4 = (long)B * C * Hh * Ww / 4;
+  if (img_is_bf16)
+    hipLaunchKernelGGL((im2row_kernel<true>), dim3(grid_for(total4, 256)), dim3(256), 0,
+                       (hipStream_t)stream, img, (bf16_t*)rows, B, C, Hh, Ww, P);
+  else
+    hipLaunchKernelGGL((im2row_kernel<false>), dim3(grid_for(total4, 256)), dim3(256), 0,
+                       (hipStream_t)stream, img, (bf16_t*)rows, B, C, Hh, Ww, P);
+  CFHIP_CHECK_LAUNCH("im2row");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_assemble_tokens_fwd(const void* patches, const float* head_token, const float* pos,
+                                         void* x0, int B, int Np, int D, void* stream) {
+  CFHIP_REQUIRE(patches && head_token && pos && x0, "assemble_tokens_fwd: null pointer");
+  CFHIP_REQUIRE(B > 0 && Np > 0 && D > 0 && D % 4 == 0, "assemble_tokens_fwd: D must be a multiple of 4");
+  CFHIP_REQUIRE(((uintptr_t)patches & 7) == 0 && ((uintptr_t)x0 & 7) == 0 &&
+                    ((uintptr_t)head_token & 15) == 0 && ((uintptr_t)pos & 15) == 0,
+                "assemble_tokens_fwd: misaligned");
+  const long total = (long)B * (Np + 1) * (D / 4);
+  hipLaunchKernelGGL(assemble_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)patches, head_token, pos, (bf16_t*)x0, B, Np, D);
+  CFHIP_CHECK_LAUNCH("assemble_tokens_fwd");
+  return CFHIP_OK;
+}
+extern "C" int cfhip_assemble_tokens_bwd(const void* dx0, void* dpatches, float* dhead_token,
+                                         float* dpos, int B, int Np, int D, int accumulate,
+                                         void* stream) {
+  CFHIP_REQUIRE(dx0 && B > 0 && Np > 0 && D > 0, "assemble_tokens_bwd: bad arguments");
+  const long total = (long)(Np + 1) * D;
+  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dx0, (bf16_t*)dpatches, dhead_token, dpos, B, Np, D, accumulate);
+  CFHIP_CHECK_LAUNCH("assemble_tokens_bwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n,
+                               float lr, float beta1, float beta2, float eps, float weight_decay,
+                               int decoupled, int step, float grad_scale, void* stream) {
+  CFHIP_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "adam_step: bad arguments");
+  if (n == 0) return CFHIP_OK;
+  CFHIP_REQUIRE(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)m & 15) == 0 &&
+                    ((uintptr_t)v & 15) == 0 && ((uintptr_t)p_bf16 & 7) == 0,
+                "adam_step: arena pointers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, p, g,
+                     m, v, (bf16_t*)p_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, decoupled,
+                     (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+  CFHIP_CHECK_LAUNCH("adam_step");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_adam_step_dev(float* p, const float* g, float* m, float* v, void* p_bf16,
+                                   int64_t n, const float* hyper, int decoupled, void* stream) {
+  CFHIP_REQUIRE(p && g && m && v && hyper && n >= 0, "adam_step_dev: bad arguments");
+  if (n == 0) return CFHIP_OK;
+  CFHIP_REQUIRE(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)m & 15) == 0 &&
+                    ((uintptr_t)v & 15) == 0 && ((uintptr_t)p_bf16 & 7) == 0,
+                "adam_step_dev: arena pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                     p, g, m, v, (bf16_t*)p_bf16, (long)n, hyper, decoupled);
+  CFHIP_CHECK_LAUNCH("adam_step_dev");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_sumsq_f32(const float* g, float* out, int64_t n, void* stream) {
+  CFHIP_REQUIRE(g && out && n >= 0, "sumsq: bad arguments");
+  if (n == 0) return CFHIP_OK;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 8, 1024)), dim3(256), 0, (hipStream_t)stream, g,
+                     out, (long)n);
+  CFHIP_CHECK_LAUNCH("sumsq");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_softmax_xent(const float* logits, const int64_t* labels, float* loss_sum,
+                                  float* dlogits, int B, int C, float grad_scale, void* stream) {
+  CFHIP_REQUIRE(logits && labels && loss_sum && B > 0 && C > 0, "softmax_xent: bad arguments");
+  hipLaunchKernelGGL(softmax_xent_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits,
+                     (const long long*)labels, loss_sum, dlogits, B, C, grad_scale);
+  CFHIP_CHECK_LAUNCH("softmax_xent");
+  return CFHIP_OK;
+}

@@ -1,0 +1,179 @@
+"""Data-parallel gradient exchange: bucketed all-reduce on RCCL over xGMI, overlapped with backward.
+
+What it replaces: the torch-DDP reducer that `accelerator.prepare` installs in the reference
+(trainer.py:268-272) — and which the reference then bypasses (`model_for_training` is
+never called, so its autograd hooks never arm).  The reference's intent is DDP-mean semantics
+(g <- sum_r g_r / W once per optimizer step); this module implements that intent by hooking
+PARAMETERS (gradient-ready notifications from the HIP backward kernels, plus autograd
+post-accumulate hooks for everything else), never a wrapper in the forward path.
+
+MI355X specifics: one process per GPU; the buckets are zero-copy slices of the gradient arena
+(`optim.ParamArena.flat_g`), built in reverse registration order (≈ backward completion order) and
+sized >= 32 MB so that an xGMI link (≈153 GB/s, point-to-point, 7 per GPU) is bandwidth- rather
+than latency-bound; each bucket's all-reduce is issued on a side HIP stream as soon as its last
+gradient lands and the optimizer waits on the events.  The 1/W averaging costs nothing: it is the
+`grad_scale` of the fused Adam kernel.  `torch.distributed` (backend "nccl" == RCCL on ROCm; "gloo"
+in the CPU tests) is used for rendezvous and the collective launch.
+"""
+import contextlib
+from typing import Any, Iterator, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from . import functional as HF
+from .optim import FusedAdam, ParamArena
+
+
+class _Bucket:
+    __slots__ = ("start", "end", "param_ids", "pending", "work", "launched")
+
+    def __init__(self, start: int, end: int, param_ids: List[int]):
+        self.start, self.end, self.param_ids = start, end, param_ids
+        self.pending = len(param_ids)
+        self.work: Any = None
+        self.launched = False
+
+
+def get_ddp_info() -> Optional[dict]:
+    """RANK / WORLD_SIZE / LOCAL_RANK from the launcher's environment (reference toolkit.py:1902-1921)."""
+    import os
+
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ and "LOCAL_RANK" in os.environ:
+        return dict(rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]),
+                    local_rank=int(os.environ["LOCAL_RANK"]))
+    return None
+
+
+class BucketedAllReduce:
+    def __init__(self, arena: ParamArena, *, process_group: Any = None, bucket_bytes: int = 64 << 20,
+                 overlap: bool = True, optimizer: Optional[FusedAdam] = None):
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("BucketedAllReduce needs an initialised torch.distributed process group")
+        self.arena = arena
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group)
+        self.overlap = overlap
+        self.sync_enabled = True
+        self.optimizer = optimizer
+        self.is_cuda = arena.flat_g.is_cuda
+        self.comm_stream = torch.cuda.Stream() if self.is_cuda else None
+        # buckets: walk the parameters from LAST to FIRST (backward produces them in that order)
+        self.buckets: List[_Bucket] = []
+        ids: List[int] = []
+        end = arena.total
+        acc = 0
+        n = len(arena.params)
+        for i in range(n - 1, -1, -1):
+            ids.append(i)
+            acc += arena.params[i].numel() * 4
+            if acc >= bucket_bytes or i == 0:
+                start = arena.offsets[i]
+                self.buckets.append(_Bucket(start, end, ids))
+                end, ids, acc = start, [], 0
+        self.bucket_of = [0] * n
+        for bi, b in enumerate(self.buckets):
+            for i in b.param_ids:
+                self.bucket_of[i] = bi
+        self._ready = [False] * n
+        self._index = {id(p): i for i, p in enumerate(arena.params)}
+        HF.grad_ready_callbacks.append(self._on_ready)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_ready) for p in arena.params]
+        if optimizer is not None:
+            optimizer.grad_scale = 1.0 / self.world_size
+
+    # -- life cycle ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if self._on_ready in HF.grad_ready_callbacks:
+            HF.grad_ready_callbacks.remove(self._on_ready)
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """What the DDP constructor used to do: every rank starts from rank `src`."""
+        dist.broadcast(self.arena.flat_p, src=src, group=self.group)
+        self.arena.refresh_shadow()
+
+    @contextlib.contextmanager
+    def no_sync(self) -> Iterator[None]:
+        """Gradient accumulation: steps inside do not reduce (reference schema.py:1277-1282 — only
+        the update step synchronises)."""
+        prev, self.sync_enabled = self.sync_enabled, False
+        try:
+            yield
+        finally:
+            self.sync_enabled = prev
+
+    # -- backward-time notifications ----------------------------------------------------------
+    def _on_ready(self, p: Tensor) -> None:
+        if not self.sync_enabled or not self.overlap:
+            return
+        i = self._index.get(id(p))
+        if i is None:
+            return
+        b = self.buckets[self.bucket_of[i]]
+        if self._ready[i]:
+            if b.launched:
+                raise RuntimeError(
+                    "a parameter's gradient was written again after its bucket was reduced (shared "
+                    "weights): construct BucketedAllReduce(overlap=False) for such models"
+                )
+            return
+        self._ready[i] = True
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def _launch(self, b: _Bucket) -> None:
+        view = self.arena.flat_g[b.start:b.end]
+        if self.is_cuda:
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(done)
+            with torch.cuda.stream(self.comm_stream):
+                b.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            b.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        b.launched = True
+
+    # -- before the optimizer step ----------------------------------------------------------------
+    def finish(self) -> None:
+        """Issue whatever has not been issued (unused parameters, overlap=False), then make the
+        compute stream wait for every bucket.  Gradients hold the SUM over ranks afterwards; the
+        1/W factor is applied by the optimizer's grad_scale (or here when there is none)."""
+        if not self.sync_enabled:
+            return
+        self.arena.finalize_grads()
+        for b in self.buckets:  # fixed order on every rank
+            if not b.launched:
+                self._launch(b)
+        for b in self.buckets:
+            b.work.wait()
+            b.work, b.launched, b.pending = None, False, len(b.param_ids)
+        self._ready = [False] * len(self._ready)
+        if self.optimizer is None and self.world_size > 1:
+            self.arena.flat_g.mul_(1.0 / self.world_size)
+
+
+class RcclDDPCallback:
+    """Trainer-side seam (no trainer edits): duck-typed `TrainerCallback` whose `before_loop(trainer)`
+    (reference trainer.py:312-313, schema.py:1755) re-homes the model's parameters into an arena,
+    installs the bucketed all-reduce and broadcasts rank 0's weights; the optimizer pre-step hook
+    waits for the exchange.  Registration under the reference: see INTEGRATION.md."""
+
+    def __init__(self, bucket_bytes: int = 64 << 20):
+        self.bucket_bytes = bucket_bytes
+        self.reducer: Optional[BucketedAllReduce] = None
+
+    def before_loop(self, trainer: Any) -> None:
+        if get_ddp_info() is None or not dist.is_initialized():
+            return
+        params = [p for p in trainer.model.m.parameters() if p.requires_grad]
+        arena = ParamArena(params, with_shadow=True)
+        self.reducer = BucketedAllReduce(arena, bucket_bytes=self.bucket_bytes)
+        self.reducer.broadcast_parameters(0)
+        for opt in trainer.optimizers.values():
+            inner = getattr(opt, "optimizer", opt)  # accelerate's AcceleratedOptimizer wraps the torch one
+            inner.register_step_pre_hook(lambda *_a, **_k: self.reducer.finish())

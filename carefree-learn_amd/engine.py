@@ -1,0 +1,88 @@
+"""One optimisation step of a classifier on the HIP path, optionally replayed from a hipGraph.
+
+This is the MI355X-side equivalent of what the reference's step engine does per batch
+(`IDLModel.train`, schema.py:1174-1294: forward -> loss -> `accelerator.backward` ->
+`optimizer.step` -> `zero_grad`), minus its per-step host synchronisations (`.item()` per loss
+key, models/common.py:40-43): the loss stays on the device until somebody asks for it.
+
+Single GPU: the whole step (zero-grad marking, forward, softmax-CE, backward, fused Adam) is
+captured once into a hipGraph (through torch's CUDAGraph plumbing — our kernels launch on torch's
+current stream, so the capture picks them up) and replayed, which removes ~300 kernel-launch
+round trips of Python / ctypes overhead per step.  Only the 32-byte Adam hyper-parameter record is
+refreshed from the host before each replay.
+
+Multi GPU (one process per GPU): eager launches; every gradient bucket is all-reduced on the side
+stream as soon as the backward kernels have produced it (`ddp.BucketedAllReduce`), the optimizer
+waits for the events, 1/W is folded into the Adam kernel.
+"""
+from typing import Any, Dict, Optional
+
+import torch
+from torch import Tensor
+
+from . import ops
+from .ddp import BucketedAllReduce
+from .optim import FusedAdam, ParamArena
+
+
+class TrainStep:
+    def __init__(self, model: torch.nn.Module, *, lr: float = 1.0e-4, betas: Any = (0.9, 0.999),
+                 eps: float = 1.0e-8, weight_decay: float = 0.0, decoupled: bool = True,
+                 use_graph: bool = False, distributed: bool = False, bucket_bytes: int = 64 << 20,
+                 output_key: str = "predictions"):
+        self.model = model
+        self.output_key = output_key
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.arena = ParamArena(params, with_shadow=True)
+        self.optimizer = FusedAdam(None, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                   decoupled=decoupled, arena=self.arena)
+        self.optimizer.lazy_zero = True  # every ViT parameter gradient is written by a HIP backward kernel
+        self.reducer: Optional[BucketedAllReduce] = None
+        if distributed:
+            self.reducer = BucketedAllReduce(self.arena, bucket_bytes=bucket_bytes, optimizer=self.optimizer)
+            self.reducer.broadcast_parameters(0)
+        self.use_graph = use_graph and not distributed
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._static: Dict[str, Tensor] = {}
+        self.loss_sum: Optional[Tensor] = None  # device scalar (sum over the local batch)
+
+    # -- the step body (all device work, no host sync) ---------------------------------------------
+    def _body(self, img: Tensor, labels: Tensor) -> Tensor:
+        self.optimizer.zero_grad()
+        out = self.model(img)
+        logits = out[self.output_key] if isinstance(out, dict) else out
+        loss_sum, dlogits = ops.softmax_xent(logits, labels, 1.0 / logits.shape[0])
+        logits.backward(dlogits)
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.launch_step()
+        return loss_sum
+
+    def _capture(self, img: Tensor, labels: Tensor) -> None:
+        self._static = dict(img=img.clone(), labels=labels.clone())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up off the capture stream (allocator, lazy inits)
+            for _ in range(2):
+                self.optimizer.prepare_step()
+                self._body(self._static["img"], self._static["labels"])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):  # records, does not execute
+            self.loss_sum = self._body(self._static["img"], self._static["labels"])
+
+    def step(self, img: Tensor, labels: Tensor) -> Tensor:
+        """Runs one step; returns the device tensor holding the summed CE loss of the batch."""
+        if self.use_graph:
+            if self._graph is None:
+                self._capture(img, labels)  # 2 eager warm-up steps (real updates), then the recording
+            if img.data_ptr() != self._static["img"].data_ptr():
+                self._static["img"].copy_(img, non_blocking=True)
+                self._static["labels"].copy_(labels, non_blocking=True)
+            self.optimizer.prepare_step()
+            self._graph.replay()
+            return self.loss_sum
+        self.optimizer.prepare_step()
+        self.loss_sum = self._body(img, labels)
+        return self.loss_sum

@@ -1,0 +1,416 @@
+"""torch.autograd.Function wrappers: the operator seam of the drop-in.
+
+Each Function replaces one ATen call of the reference's hot path with calls into libcfhip.so and
+provides the matching hand-written backward.  Activations are bf16 (what the reference computes
+under `mixed_precision="bf16"` autocast), parameters stay fp32 masters with a cached bf16 shadow,
+parameter gradients are produced in fp32.
+
+Parameter gradients are written by the backward kernels STRAIGHT into `param.grad` (allocated on
+first use, accumulated afterwards) instead of being returned to autograd: that removes one full
+read-modify-write pass per parameter and lets the gradient arena / DDP bucket views
+(`optim.ParamArena`, `ddp.BucketedAllReduce`) be the kernels' destination.  Because autograd's own
+post-accumulate hooks do not fire for such parameters, `grad_ready_callbacks` is invoked instead.
+"""
+from typing import Any, Callable, List, Optional, Tuple
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from . import ops
+
+bf16 = torch.bfloat16
+f32 = torch.float32
+
+# called as cb(param) right after a parameter's gradient has been written by a HIP backward
+grad_ready_callbacks: List[Callable[[Tensor], None]] = []
+
+
+# ---------------------------------------------------------------------------------------------
+# bf16 shadows of fp32 master parameters
+# ---------------------------------------------------------------------------------------------
+
+
+def shadow_bf16(param: Tensor) -> Tensor:
+    """bf16 copy of an fp32 parameter, re-cast only when the parameter changed.
+
+    `optim.ParamArena` installs arena-backed shadows that its fused Adam kernel refreshes in the
+    same pass that updates the master weights; otherwise the copy is keyed on `param._version`.
+    """
+    if param.dtype == bf16:
+        return param.detach()
+    sh = getattr(param, "_cfhip_shadow", None)
+    ver = param._version
+    if sh is not None and getattr(param, "_cfhip_shadow_version", None) == ver and sh.device == param.device:
+        return sh
+    src = param.detach()
+    if sh is None or sh.shape != src.shape or sh.device != src.device:
+        sh = torch.empty(src.shape, dtype=bf16, device=src.device)
+    ops.to_bf16(src.contiguous(), out=sh)
+    try:
+        param._cfhip_shadow = sh
+        param._cfhip_shadow_version = ver
+    except Exception:  # non-leaf views etc.: just do not cache
+        pass
+    return sh
+
+
+def _is_direct(param: Optional[Tensor]) -> bool:
+    return param is not None and param.is_leaf and param.requires_grad and param.dtype == f32
+
+
+def write_param_grad(param: Tensor, compute: Callable[[Tensor, bool], None]) -> None:
+    """`compute(out, accumulate)` must write (accumulate=False) or add (True) the f32 gradient."""
+    g = param.grad
+    if g is None:
+        buf = torch.empty(param.shape, dtype=f32, device=param.device)
+        compute(buf, False)
+        param.grad = buf
+    else:
+        fresh = getattr(param, "_cfhip_fresh", False)
+        compute(g, not fresh)
+        if fresh:
+            param._cfhip_fresh = False
+    for cb in grad_ready_callbacks:
+        cb(param)
+
+
+def _as_bf16_2d(x: Tensor) -> Tensor:
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.dtype != bf16:
+        x2 = ops.to_bf16(x2.float() if x2.dtype != f32 else x2)
+    if x2.stride(-1) != 1 or (x2.dim() == 2 and x2.stride(0) % 8 != 0 and x2.shape[0] > 1):
+        x2 = x2.contiguous()
+    return x2
+
+
+# ---------------------------------------------------------------------------------------------
+# Linear (K1): y = x W^T + b, optional fused GELU / residual-add epilogue
+# ---------------------------------------------------------------------------------------------
+
+ACT_NONE, ACT_GELU = 0, 1
+
+
+def _linear_param_grads(dy2: Tensor, x2: Tensor, weight: Tensor, bias: Optional[Tensor],
+                        weight_direct: bool, bias_direct: bool) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """dW = dy^T x, db = colsum(dy): direct-to-.grad when possible, returned otherwise."""
+    gw = gb = None
+    n, k, m = weight.shape[0], weight.shape[1], x2.shape[0]
+    split = ops.pick_split_k(n, k, m)
+
+    def dw_into(out: Tensor, acc: bool) -> None:
+        ops.gemm(dy2, x2, a_trans=True, b_trans=True, out=out, accumulate=acc, split_k=split)
+
+    if weight.requires_grad:
+        if weight_direct:
+            write_param_grad(weight, dw_into)
+        else:
+            gw = torch.empty(weight.shape, dtype=f32, device=dy2.device)
+            dw_into(gw, False)
+    if bias is not None and bias.requires_grad:
+        if bias_direct:
+            write_param_grad(bias, lambda out, acc: ops.colsum(dy2, out=out.view(-1), accumulate=acc))
+        else:
+            gb = ops.colsum(dy2).view(bias.shape)
+    return gw, gb
+
+
+class LinearFn(Function):
+    """Replaces F.linear (reference customs.py:89, attentions.py:214) incl. backward."""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int,
+                residual: Optional[Tensor], out_f32: bool) -> Tensor:
+        x2 = _as_bf16_2d(x)
+        w16 = shadow_bf16(weight)
+        bias_f = None if bias is None else bias.detach().reshape(-1).contiguous()
+        m, n = x2.shape[0], weight.shape[0]
+        pre = None
+        if act == ACT_GELU:
+            pre = torch.empty((m, n), dtype=bf16, device=x2.device)
+            y = ops.gemm(x2, w16, bias=bias_f, epilogue=ops.EPI_GELU, aux_out=pre)
+        elif residual is not None:
+            r2 = _as_bf16_2d(residual)
+            if not r2.is_contiguous():
+                r2 = r2.contiguous()
+            y = ops.gemm(x2, w16, bias=bias_f, epilogue=ops.EPI_RESIDUAL, aux_in=r2)
+        else:
+            y = ops.gemm(x2, w16, bias=bias_f, out_dtype=f32 if out_f32 else bf16)
+        ctx.save_for_backward(x2, w16, pre)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.has_residual = residual is not None
+        ctx.x_shape = x.shape
+        ctx.in_dtype = x.dtype
+        return y.view(*x.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        x2, w16, pre = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        dy2 = _as_bf16_2d(dy)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        d_res = dy2.view(*ctx.x_shape[:-1], weight.shape[0]) if ctx.has_residual and ctx.needs_input_grad[4] else None
+        if pre is not None:
+            dy2 = ops.gelu_bwd(dy2, pre)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dy2, w16, b_trans=True).view(ctx.x_shape)
+            if ctx.in_dtype != bf16:
+                dx = ops.to_f32(dx).to(ctx.in_dtype)
+        gw, gb = _linear_param_grads(dy2, x2, weight, bias, _is_direct(weight), _is_direct(bias))
+        return dx, gw, gb, None, d_res, None
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,
+           residual: Optional[Tensor] = None, out_f32: bool = False) -> Tensor:
+    return LinearFn.apply(x, weight, bias, act, residual, out_f32)
+
+
+# ---------------------------------------------------------------------------------------------
+# LayerNorm (K5)
+# ---------------------------------------------------------------------------------------------
+
+
+class LayerNormFn(Function):
+    """Replaces nn.LayerNorm.forward (reference norms.py:88-89 via NormFactory)."""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
+        x2 = _as_bf16_2d(x)
+        gamma = weight.detach().contiguous()
+        beta = bias.detach().contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x2, gamma, beta, eps)
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.x_shape, ctx.in_dtype = x.shape, x.dtype
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        dy2 = _as_bf16_2d(dy)
+        wd, bd = _is_direct(weight), _is_direct(bias)
+        gw = gb = None
+        if wd and bd and weight.grad is None and bias.grad is None:
+            dx, dg, db = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd)
+            write_param_grad(weight, lambda out, acc: out.copy_(dg.view(out.shape)))
+            write_param_grad(bias, lambda out, acc: out.copy_(db.view(out.shape)))
+        else:
+            dx, dg, db = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd)
+            if wd:
+                write_param_grad(weight, lambda out, acc: out.add_(dg.view(out.shape)) if acc else out.copy_(dg.view(out.shape)))
+            elif weight.requires_grad:
+                gw = dg.view(weight.shape)
+            if bd:
+                write_param_grad(bias, lambda out, acc: out.add_(db.view(out.shape)) if acc else out.copy_(db.view(out.shape)))
+            elif bias.requires_grad:
+                gb = db.view(bias.shape)
+        dx = dx.view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        if dx is not None and ctx.in_dtype != bf16:
+            dx = ops.to_f32(dx).to(ctx.in_dtype)
+        return dx, gw, gb, None
+
+
+def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
+    return LayerNormFn.apply(x, weight, bias, eps)
+
+
+# ---------------------------------------------------------------------------------------------
+# attention core (K3/K4)
+# ---------------------------------------------------------------------------------------------
+
+
+class PackedSelfAttentionFn(Function):
+    """softmax(q k^T / sqrt(dh) [mask]) v on the packed projection output qkv [B, T, 3*D]
+    (q | k | v along the last dim, head h = channels [h*64, (h+1)*64) of each third — the layout of
+    reference attentions.py:214-216,180-185).  Output [B, T, D], heads already merged."""
+
+    @staticmethod
+    def forward(ctx: Any, qkv: Tensor, num_heads: int, keep_mask: Optional[Tensor], causal: bool) -> Tensor:
+        if qkv.dtype != bf16:
+            qkv = ops.to_bf16(qkv.float().contiguous())
+        if not qkv.is_contiguous():
+            qkv = qkv.contiguous()
+        d = qkv.shape[-1] // 3
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        o, lse = ops.attn_fwd(q, k, v, num_heads, mask=keep_mask, causal=causal)
+        ctx.save_for_backward(qkv, o, lse, keep_mask)
+        ctx.num_heads, ctx.causal = num_heads, causal
+        return o
+
+    @staticmethod
+    def backward(ctx: Any, d_o: Tensor):  # type: ignore
+        qkv, o, lse, keep_mask = ctx.saved_tensors
+        d = qkv.shape[-1] // 3
+        if d_o.dtype != bf16:
+            d_o = ops.to_bf16(d_o.float())
+        d_o = d_o.contiguous()
+        dqkv = torch.empty_like(qkv)
+        ops.attn_bwd(
+            qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, d_o, lse, ctx.num_heads,
+            dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], mask=keep_mask,
+            causal=ctx.causal,
+        )
+        return dqkv, None, None, None
+
+
+class AttentionCoreFn(Function):
+    """Same computation for separately projected q [B,Tq,D], k / v [B,Tk,D] (cross attention)."""
+
+    @staticmethod
+    def forward(ctx: Any, q: Tensor, k: Tensor, v: Tensor, num_heads: int, keep_mask: Optional[Tensor],
+                causal: bool) -> Tensor:
+        q, k, v = (t if t.dtype == bf16 else ops.to_bf16(t.float().contiguous()) for t in (q, k, v))
+        q = q.contiguous()
+        kv = torch.stack([k, v], dim=2)  # [B, Tk, 2, D]: k and v share strides
+        k, v = kv[:, :, 0], kv[:, :, 1]
+        o, lse = ops.attn_fwd(q, k, v, num_heads, mask=keep_mask, causal=causal)
+        ctx.save_for_backward(q, kv, o, lse, keep_mask)
+        ctx.num_heads, ctx.causal = num_heads, causal
+        return o
+
+    @staticmethod
+    def backward(ctx: Any, d_o: Tensor):  # type: ignore
+        q, kv, o, lse, keep_mask = ctx.saved_tensors
+        if d_o.dtype != bf16:
+            d_o = ops.to_bf16(d_o.float())
+        d_o = d_o.contiguous()
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        ops.attn_bwd(q, kv[:, :, 0], kv[:, :, 1], o, d_o, lse, ctx.num_heads, dq=dq, dk=dkv[:, :, 0],
+                     dv=dkv[:, :, 1], mask=keep_mask, causal=ctx.causal)
+        return dq, dkv[:, :, 0], dkv[:, :, 1], None, None, None
+
+
+def packed_self_attention(qkv: Tensor, num_heads: int, keep_mask: Optional[Tensor] = None,
+                          causal: bool = False) -> Tensor:
+    return PackedSelfAttentionFn.apply(qkv, num_heads, keep_mask, causal)
+
+
+def attention_core(q: Tensor, k: Tensor, v: Tensor, num_heads: int, keep_mask: Optional[Tensor] = None,
+                   causal: bool = False) -> Tensor:
+    return AttentionCoreFn.apply(q, k, v, num_heads, keep_mask, causal)
+
+
+# ---------------------------------------------------------------------------------------------
+# small element-wise Functions used by the composed (non-fused) module paths
+# ---------------------------------------------------------------------------------------------
+
+
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx: Any, a: Tensor, b: Tensor) -> Tensor:
+        a2 = a if a.dtype == bf16 else ops.to_bf16(a.float().contiguous())
+        b2 = b if b.dtype == bf16 else ops.to_bf16(b.float().contiguous())
+        return ops.add(a2.contiguous(), b2.contiguous())
+
+    @staticmethod
+    def backward(ctx: Any, g: Tensor):  # type: ignore
+        return g, g
+
+
+class GeluFn(Function):
+    @staticmethod
+    def forward(ctx: Any, x: Tensor) -> Tensor:
+        x2 = (x if x.dtype == bf16 else ops.to_bf16(x.float().contiguous())).contiguous()
+        ctx.save_for_backward(x2)
+        return ops.gelu_fwd(x2)
+
+    @staticmethod
+    def backward(ctx: Any, g: Tensor):  # type: ignore
+        (x2,) = ctx.saved_tensors
+        g2 = (g if g.dtype == bf16 else ops.to_bf16(g.float().contiguous())).contiguous()
+        return ops.gelu_bwd(g2, x2)
+
+
+def add(a: Tensor, b: Tensor) -> Tensor:
+    return AddFn.apply(a, b)
+
+
+def gelu(x: Tensor) -> Tensor:
+    return GeluFn.apply(x)
+
+
+# ---------------------------------------------------------------------------------------------
+# ViT input stage (K8 as GEMM + K7 glue)
+# ---------------------------------------------------------------------------------------------
+
+
+class PatchTokensFn(Function):
+    """VanillaPatchEmbed (stride == kernel Conv2d, reference high_level.py:172-188) + head-token
+    concat + positional-encoding add (mixed_stacks/api.py:419-438,209-228) in three launches:
+    im2row -> GEMM(+bias) -> assemble.  img [B,C,H,W] -> tokens bf16 [B, Np+1, D]."""
+
+    @staticmethod
+    def forward(ctx: Any, img: Tensor, conv_w: Tensor, conv_b: Optional[Tensor], head_token: Tensor,
+                pos: Tensor) -> Tensor:
+        b = img.shape[0]
+        patch = conv_w.shape[-1]
+        src = img if img.dtype in (f32, bf16) else img.float()
+        rows = ops.im2row(src.contiguous(), patch)
+        w16 = shadow_bf16(conv_w).view(conv_w.shape[0], -1)
+        bias_f = None if conv_b is None else conv_b.detach().contiguous()
+        patches = ops.gemm(rows, w16, bias=bias_f)
+        x0 = ops.assemble_tokens_fwd(patches, head_token.detach().reshape(-1).contiguous(),
+                                     pos.detach().reshape(-1).contiguous(), b)
+        ctx.save_for_backward(rows)
+        ctx.params = (conv_w, conv_b, head_token, pos)
+        return x0
+
+    @staticmethod
+    def backward(ctx: Any, dx0: Tensor):  # type: ignore
+        (rows,) = ctx.saved_tensors
+        conv_w, conv_b, head_token, pos = ctx.params
+        dx0 = (dx0 if dx0.dtype == bf16 else ops.to_bf16(dx0.float())).contiguous()
+        d = dx0.shape[-1]
+        direct = all(_is_direct(p) for p in (head_token, pos))
+        g_head = g_pos = None
+        if direct:
+            # both written by one kernel: hand it the two destinations
+            for prm in (head_token, pos):
+                if prm.grad is None:
+                    prm.grad = torch.zeros(prm.shape, dtype=f32, device=prm.device)
+                    prm._cfhip_fresh = False
+            acc_h = not getattr(head_token, "_cfhip_fresh", False)
+            acc_p = not getattr(pos, "_cfhip_fresh", False)
+            if acc_h != acc_p:  # keep one accumulate flag for the single launch
+                for prm in (head_token, pos):
+                    if getattr(prm, "_cfhip_fresh", False):
+                        prm.grad.zero_()
+                acc_h = acc_p = True
+            dpatches = ops.assemble_tokens_bwd(dx0, head_token.grad.view(-1), pos.grad.view(-1), acc_h)
+            for prm in (head_token, pos):
+                prm._cfhip_fresh = False
+                for cb in grad_ready_callbacks:
+                    cb(prm)
+        else:
+            g_head = torch.empty((d,), dtype=f32, device=dx0.device)
+            g_pos = torch.empty((dx0.shape[1] * d,), dtype=f32, device=dx0.device)
+            dpatches = ops.assemble_tokens_bwd(dx0, g_head, g_pos, False)
+            g_head, g_pos = g_head.view(head_token.shape), g_pos.view(pos.shape)
+        w2 = conv_w.view(conv_w.shape[0], -1) if not _is_direct(conv_w) else conv_w
+        gw, gb = None, None
+        n, k, m = conv_w.shape[0], rows.shape[1], rows.shape[0]
+        split = ops.pick_split_k(n, k, m)
+        if conv_w.requires_grad:
+            def dw_into(out: Tensor, acc: bool) -> None:
+                ops.gemm(dpatches, rows, a_trans=True, b_trans=True, out=out.view(n, k), accumulate=acc,
+                         split_k=split)
+            if _is_direct(conv_w):
+                write_param_grad(conv_w, dw_into)
+            else:
+                gw = torch.empty(conv_w.shape, dtype=f32, device=dx0.device)
+                dw_into(gw, False)
+        if conv_b is not None and conv_b.requires_grad:
+            if _is_direct(conv_b):
+                write_param_grad(conv_b, lambda out, acc: ops.colsum(dpatches, out=out.view(-1), accumulate=acc))
+            else:
+                gb = ops.colsum(dpatches).view(conv_b.shape)
+        return None, gw, gb, g_head, g_pos
+
+
+def patch_tokens(img: Tensor, conv_w: Tensor, conv_b: Optional[Tensor], head_token: Tensor,
+                 pos: Tensor) -> Tensor:
+    return PatchTokensFn.apply(img, conv_w, conv_b, head_token, pos)

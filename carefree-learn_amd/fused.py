@@ -1,0 +1,136 @@
+"""Fused pre-norm transformer block: ONE autograd node per `MixingBlock`.
+
+Forward (reference mixed_stacks/api.py:130-158 with attention token mixer + FeedForward channel
+mixer, dropout = drop_path = 0):
+
+    x1 = x  + out_linear(attn(split_heads(LN1(x) in_w^T + qkv_bias)))
+    x2 = x1 + W2 gelu(W1 LN2(x1) + b1) + b2
+
+8 launches forward: LN, GEMM(+bias), flash attention (reads the packed qkv in place, writes merged
+heads), GEMM(+bias +residual), LN, GEMM(+bias +GELU, also stores the pre-activation),
+GEMM(+bias +residual).  Backward: every dX GEMM reads W row-major through the transposing LDS read
+(no W^T copies), every dW GEMM reads dY and X token-major the same way (no activation transposes),
+GELU' is the epilogue of the FF2 dX GEMM, both residual-gradient adds are folded into the LayerNorm
+backward kernels, and all parameter gradients are written directly into `param.grad`.
+"""
+from typing import Any, Optional
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from . import ops
+from .functional import bf16, f32, shadow_bf16, write_param_grad
+
+
+def _dw(param: Tensor, dy2: Tensor, x2: Tensor) -> None:
+    n, k = param.shape[0], x2.shape[1]
+    split = ops.pick_split_k(n, k, x2.shape[0])
+    write_param_grad(
+        param,
+        lambda out, acc: ops.gemm(dy2, x2, a_trans=True, b_trans=True, out=out.view(n, k),
+                                  accumulate=acc, split_k=split),
+    )
+
+
+def _db(param: Optional[Tensor], dy2: Tensor) -> None:
+    if param is not None and param.requires_grad:
+        write_param_grad(param, lambda out, acc: ops.colsum(dy2, out=out.view(-1), accumulate=acc))
+
+
+def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: Tensor,
+            dx_add: Optional[Tensor]) -> Tensor:
+    """LayerNorm backward with the residual-gradient add fused; dgamma / dbeta go to `.grad`."""
+    gamma = w.detach()
+    for prm in (w, b):
+        if prm.grad is None:
+            prm.grad = torch.empty(prm.shape, dtype=f32, device=prm.device)
+            prm._cfhip_fresh = True
+    acc_w = not getattr(w, "_cfhip_fresh", False)
+    acc_b = not getattr(b, "_cfhip_fresh", False)
+    if acc_w != acc_b:
+        for prm in (w, b):
+            if getattr(prm, "_cfhip_fresh", False):
+                prm.grad.zero_()
+        acc_w = True
+    dx, _, _ = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dx_add=dx_add, dgamma=w.grad.view(-1),
+                                 dbeta=b.grad.view(-1), accumulate=acc_w)
+    from .functional import grad_ready_callbacks
+
+    for prm in (w, b):
+        prm._cfhip_fresh = False
+        for cb in grad_ready_callbacks:
+            cb(prm)
+    return dx
+
+
+class MixingBlockFn(Function):
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, ln1_w: Tensor, ln1_b: Tensor, in_w: Tensor, qkv_b: Optional[Tensor],
+                out_w: Tensor, out_b: Optional[Tensor], ln2_w: Tensor, ln2_b: Tensor, w1: Tensor,
+                b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], num_heads: int, eps1: float,
+                eps2: float, keep_mask: Optional[Tensor], causal: bool) -> Tensor:
+        bsz, t, d = x.shape
+        if x.dtype != bf16:
+            x = ops.to_bf16(x.float().contiguous())
+        x = x.contiguous()
+        x2 = x.view(bsz * t, d)
+        fb = lambda p: None if p is None else p.detach().reshape(-1)  # noqa: E731
+        in_w16, out_w16 = shadow_bf16(in_w), shadow_bf16(out_w)
+        w1_16, w2_16 = shadow_bf16(w1), shadow_bf16(w2)
+
+        ln1, mean1, rstd1 = ops.layernorm_fwd(x2, ln1_w.detach(), ln1_b.detach(), eps1)
+        qkv = ops.gemm(ln1, in_w16, bias=fb(qkv_b))
+        qkv3 = qkv.view(bsz, t, 3 * d)
+        o, lse = ops.attn_fwd(qkv3[..., :d], qkv3[..., d:2 * d], qkv3[..., 2 * d:], num_heads,
+                              mask=keep_mask, causal=causal)
+        o2 = o.view(bsz * t, d)
+        x1 = ops.gemm(o2, out_w16, bias=fb(out_b), epilogue=ops.EPI_RESIDUAL, aux_in=x2)
+        ln2, mean2, rstd2 = ops.layernorm_fwd(x1, ln2_w.detach(), ln2_b.detach(), eps2)
+        pre = torch.empty((bsz * t, w1.shape[0]), dtype=bf16, device=x.device)
+        h = ops.gemm(ln2, w1_16, bias=fb(b1), epilogue=ops.EPI_GELU, aux_out=pre)
+        y = ops.gemm(h, w2_16, bias=fb(b2), epilogue=ops.EPI_RESIDUAL, aux_in=x1)
+
+        ctx.save_for_backward(x2, mean1, rstd1, ln1, qkv, o2, lse, x1, mean2, rstd2, ln2, pre, h,
+                              in_w16, out_w16, w1_16, w2_16, keep_mask)
+        ctx.params = (ln1_w, ln1_b, in_w, qkv_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2)
+        ctx.meta = (bsz, t, d, num_heads, causal)
+        return y.view(bsz, t, d)
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        (x2, mean1, rstd1, ln1, qkv, o2, lse, x1, mean2, rstd2, ln2, pre, h, in_w16, out_w16, w1_16,
+         w2_16, keep_mask) = ctx.saved_tensors
+        ln1_w, ln1_b, in_w, qkv_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2 = ctx.params
+        bsz, t, d, num_heads, causal = ctx.meta
+        if dy.dtype != bf16:
+            dy = ops.to_bf16(dy.float().contiguous())
+        d2 = dy.contiguous().view(bsz * t, d)
+
+        # channel mixing
+        dpre = ops.gemm(d2, w2_16, b_trans=True, epilogue=ops.EPI_DGELU, aux_in=pre)
+        _dw(w2, d2, h)
+        _db(b2, d2)
+        dln2 = ops.gemm(dpre, w1_16, b_trans=True)
+        _dw(w1, dpre, ln2)
+        _db(b1, dpre)
+        dx1 = _ln_bwd(dln2, x1, ln2_w, ln2_b, mean2, rstd2, dx_add=d2)
+
+        # token mixing
+        d_o = ops.gemm(dx1, out_w16, b_trans=True)
+        _dw(out_w, dx1, o2)
+        _db(out_b, dx1)
+        dqkv = torch.empty_like(qkv)
+        qkv3, dqkv3 = qkv.view(bsz, t, 3 * d), dqkv.view(bsz, t, 3 * d)
+        ops.attn_bwd(qkv3[..., :d], qkv3[..., d:2 * d], qkv3[..., 2 * d:], o2.view(bsz, t, d),
+                     d_o.view(bsz, t, d), lse, num_heads, dq=dqkv3[..., :d], dk=dqkv3[..., d:2 * d],
+                     dv=dqkv3[..., 2 * d:], mask=keep_mask, causal=causal)
+        dln1 = ops.gemm(dqkv, in_w16, b_trans=True)
+        _dw(in_w, dqkv, ln1)
+        _db(qkv_b, dqkv)
+        dx = _ln_bwd(dln1, x2, ln1_w, ln1_b, mean1, rstd1, dx_add=dx1)
+        return (dx.view(bsz, t, d),) + (None,) * 17
+
+
+def mixing_block(x: Tensor, *args: Any) -> Tensor:
+    return MixingBlockFn.apply(x, *args)

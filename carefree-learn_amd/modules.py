@@ -1,0 +1,690 @@
+"""Drop-in `nn.Module`s mirroring `cflearn.modules` for the ViT training path.
+
+Same constructor keywords, attribute names and state_dict keys as the reference classes (cited per
+class), so reference checkpoints load and `build_module(name, config=...)` configs are unchanged;
+the arithmetic runs on the HIP kernels through `functional` / `fused`.  Features of the reference
+classes that are outside the hot path (pruners, style-modulated convs, spatial reduction, custom
+softmax callbacks...) raise NotImplementedError instead of silently doing something else.
+"""
+import math
+from typing import Any, Callable, Dict, List, NamedTuple, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+from torch.nn import Module
+
+from . import functional as HF
+from . import fused
+from .registry import (
+    attentions,
+    channel_mixers,
+    encoders,
+    register_module,
+    shallow_copy_dict,
+    token_mixers,
+    update_dict,
+)
+
+LATENT_KEY = "latent"  # reference constants.py:3-7
+PREDICTIONS_KEY = "predictions"
+
+
+class Lambda(Module):
+    """reference modules/common.py:89-100"""
+
+    def __init__(self, fn: Callable, name: Optional[str] = None):
+        super().__init__()
+        self.name, self.fn = name, fn
+
+    def extra_repr(self) -> str:
+        return "" if self.name is None else self.name
+
+    def forward(self, *args: Any, **kwargs: Any) -> Any:
+        return self.fn(*args, **kwargs)
+
+
+# ---------------------------------------------------------------------------------------------
+# Linear family
+# ---------------------------------------------------------------------------------------------
+
+
+class Linear(Module):
+    """reference modules/core/customs.py:23-114 — state keys `linear.weight`, `linear.bias`
+    (or `w1`, `w2`, `b` for the low-rank form)."""
+
+    def __init__(self, in_dim: int, out_dim: int, *, bias: bool = True,
+                 pruner_config: Optional[Dict[str, Any]] = None, init_method: Optional[str] = None,
+                 rank: Optional[int] = None, rank_ratio: Optional[float] = None, hook: Any = None):
+        super().__init__()
+        if pruner_config is not None:
+            raise NotImplementedError("`pruner_config` is outside the accelerated hot path")
+        full_rank = min(in_dim, out_dim)
+        if rank is None and rank_ratio is not None:
+            rank = round(full_rank * rank_ratio)
+        if rank is None:
+            self.w1 = self.w2 = self.b = None
+            self.linear = nn.Linear(in_dim, out_dim, bias)
+        else:
+            self.w1 = nn.Parameter(torch.zeros(rank, in_dim))
+            self.w2 = nn.Parameter(torch.zeros(out_dim, rank))
+            self.b = nn.Parameter(torch.zeros(1, out_dim)) if bias else None
+            self.linear = None
+        self.pruner = self.pruner1 = self.pruner2 = None
+        init_fn = getattr(nn.init, f"{init_method or 'xavier_normal'}_", nn.init.xavier_normal_)
+        self.init_weights_with(lambda t: init_fn(t, 1.0 / math.sqrt(2.0)))
+        self.hook = hook
+        self.out_f32 = False  # set by classifiers: emit fp32 logits straight from the GEMM epilogue
+
+    @property
+    def weight(self) -> Tensor:
+        return self.linear.weight if self.linear is not None else torch.matmul(self.w2, self.w1)
+
+    @property
+    def bias(self) -> Optional[Tensor]:
+        return self.b if self.linear is None else self.linear.bias
+
+    def forward(self, net: Tensor, *, act: int = HF.ACT_NONE, residual: Optional[Tensor] = None) -> Tensor:
+        inp = net
+        if self.hook is not None:
+            inp = self.hook.before_forward(inp)
+        if self.linear is not None:
+            net = HF.linear(net, self.linear.weight, self.linear.bias, act=act, residual=residual,
+                            out_f32=self.out_f32)
+        else:
+            net = HF.linear(net, self.w1, None)
+            net = HF.linear(net, self.w2, self.b, act=act, residual=residual, out_f32=self.out_f32)
+        if self.hook is not None:
+            net = self.hook.after_forward(inp, net)
+        return net
+
+    def init_weights_with(self, w_init_fn: Callable[[Tensor], None]) -> None:
+        with torch.no_grad():
+            if self.linear is not None:
+                w_init_fn(self.linear.weight.data)
+                if self.linear.bias is not None:
+                    self.linear.bias.data.zero_()
+            else:
+                w_init_fn(self.w1.data)
+                w_init_fn(self.w2.data)
+                if self.b is not None:
+                    self.b.data.zero_()
+
+
+class _HijackMixin:
+    """reference hijacks.py:33-49: keeps ctor args for LoRA cloning, optional before/after hook."""
+
+    def __init__(self, *args: Any, hook: Any = None, **kwargs: Any):
+        self.args = args
+        self.kwargs = shallow_copy_dict(kwargs)
+        super().__init__(*args, **kwargs)
+        self.hook = hook
+
+
+class HijackLinear(_HijackMixin, nn.Linear):
+    """reference hijacks.py:52-53 — state keys `weight`, `bias`."""
+
+    def forward(self, net: Tensor) -> Tensor:  # type: ignore
+        inp = net
+        if self.hook is not None:
+            inp = self.hook.before_forward(inp)
+        net = HF.linear(net, self.weight, self.bias)
+        if self.hook is not None:
+            net = self.hook.after_forward(inp, net)
+        return net
+
+
+class HijackCustomLinear(_HijackMixin, Linear):
+    """reference hijacks.py:56-57 (the out_linear of Attention, the two layers of FeedForward)."""
+
+
+class LayerNorm(nn.LayerNorm):
+    """`NormFactory("layer").make(dim)` (reference norms.py:88-89,118-119): nn.LayerNorm with
+    eps defaulting to 1e-6; state keys `weight`, `bias`."""
+
+    def forward(self, net: Tensor) -> Tensor:  # type: ignore
+        if not self.elementwise_affine or len(self.normalized_shape) != 1:
+            raise NotImplementedError("only affine LayerNorm over the last dim is on the hot path")
+        return HF.layer_norm(net, self.weight, self.bias, self.eps)
+
+
+class NormFactory:
+    """reference norms.py:70-140 restricted to what the transformer path uses."""
+
+    def __init__(self, norm_type: Optional[str]):
+        self.norm_type = norm_type
+
+    @property
+    def use_bias(self) -> bool:
+        return self.norm_type is None or not self.norm_type.startswith("batch")
+
+    def make(self, *args: Any, **kwargs: Any) -> Module:
+        if self.norm_type is None:
+            return nn.Identity()
+        if self.norm_type == "layer":
+            kw = update_dict(kwargs, {"eps": 1.0e-6})
+            return LayerNorm(*args, **kw)
+        raise NotImplementedError(f"normalization '{self.norm_type}' is not on the accelerated hot path")
+
+
+# ---------------------------------------------------------------------------------------------
+# Attention
+# ---------------------------------------------------------------------------------------------
+
+
+class AttentionOutput(NamedTuple):
+    output: Tensor
+    weights: Optional[Tensor]
+
+
+def expand_module_mask(mask: Tensor, num_heads: int) -> Tensor:
+    """Reference mask quirk (attentions.py:246-253): the [B, Tq, Tk] `True = zeroed` mask is
+    `repeat(H,1,1).view(-1,H,Tq,Tk)`-ed, i.e. (b, h) uses mask[(b*H + h) % B].  Integer index
+    arithmetic -> bit-exact.  Returns the uint8 KEEP mask [B, H, Tq, Tk]."""
+    if mask.dim() == 2:  # [Tq, Tk] broadcast (causal masks of the text tower)
+        return (~mask).to(torch.uint8)[None, None]
+    b = mask.shape[0]
+    idx = (torch.arange(b * num_heads, device=mask.device) % b).view(b, num_heads)
+    return (~mask)[idx].to(torch.uint8)
+
+
+@attentions.register("basic")
+class Attention(Module):
+    """reference modules/core/attentions.py:57-279.  Parameters: `in_w` [3D, Din] + `qkv_bias`
+    (self attention), or `q_w` + `kv_w` / `q_w`,`k_w`,`v_w` with their biases; `out_linear`."""
+
+    customize_sdp: bool = False
+
+    def __init__(self, input_dim: int, num_heads: int = 1, *, bias: bool = True, dropout: float = 0.0,
+                 qk_scale: Optional[float] = None, kv_same: Optional[bool] = None,
+                 qkv_bias_same: bool = True, is_self_attention: bool = False, k_dim: Optional[int] = None,
+                 v_dim: Optional[int] = None, embed_dim: Optional[int] = None,
+                 activation: Optional[str] = None, activation_config: Optional[Dict[str, Any]] = None,
+                 out_linear_config: Optional[Dict[str, Any]] = None, reduction_ratio: Optional[int] = None,
+                 hook: Any = None):
+        super().__init__()
+        if reduction_ratio is not None and reduction_ratio > 1:
+            raise NotImplementedError("spatial `reduction_ratio` is outside the accelerated hot path")
+        if activation is not None:
+            raise NotImplementedError("`activation` on q/k/v is outside the accelerated hot path")
+        self.input_dim = input_dim
+        if kv_same is None:
+            kv_same = not (k_dim is not None and v_dim is not None and k_dim != v_dim)
+        self.kv_same = kv_same
+        self.qkv_same = is_self_attention
+        if not is_self_attention:
+            self.k_dim = k_dim or input_dim
+            self.v_dim = v_dim or self.k_dim
+        else:
+            if k_dim is not None and k_dim != input_dim:
+                raise ValueError("self attention is used but `k_dim` != `input_dim`")
+            if v_dim is not None and v_dim != input_dim:
+                raise ValueError("self attention is used but `v_dim` != `input_dim`")
+            self.k_dim = self.v_dim = input_dim
+        self.embed_dim = embed_dim or input_dim
+        self.num_heads = num_heads
+        self.head_dim = self.embed_dim // num_heads
+        self.scaling = qk_scale or float(self.head_dim) ** 0.5
+        if self.head_dim * num_heads != self.embed_dim:
+            raise ValueError("`embed_dim` must be divisible by `num_heads`")
+        e = self.embed_dim
+        P = nn.Parameter
+        self.in_w = self.q_w = self.k_w = self.v_w = self.kv_w = None
+        if self.qkv_same:
+            self.in_w = P(torch.empty(3 * e, input_dim))
+            nn.init.trunc_normal_(self.in_w, std=0.02)
+        elif kv_same:
+            self.q_w = P(torch.empty(e, input_dim))
+            self.kv_w = P(torch.empty(2 * e, input_dim))
+            nn.init.trunc_normal_(self.q_w, std=0.02)
+            nn.init.trunc_normal_(self.kv_w, std=0.02)
+        else:
+            self.q_w = P(torch.empty(e, input_dim))
+            self.k_w = P(torch.empty(e, self.k_dim))
+            self.v_w = P(torch.empty(e, self.v_dim))
+            for w in (self.q_w, self.k_w, self.v_w):
+                nn.init.xavier_uniform_(w)
+        self.q_bias = self.k_bias = self.v_bias = self.kv_bias = self.qkv_bias = None
+        if bias:
+            if not qkv_bias_same:
+                self.q_bias, self.k_bias, self.v_bias = (P(torch.zeros(e)) for _ in range(3))
+            elif self.qkv_same or not kv_same:
+                self.qkv_bias = P(torch.zeros(3 * e))
+            else:
+                self.q_bias = P(torch.zeros(e))
+                self.kv_bias = P(torch.zeros(2 * e))
+        self.out_linear = HijackCustomLinear(e, input_dim, **(out_linear_config or {}))
+        self.dropout = dropout
+        self.activation = nn.Identity()
+        self.reduction = None
+        self.hook = hook
+
+    # -- projections --------------------------------------------------------------------------
+    def _project(self, q: Tensor, k: Tensor, v: Tensor) -> Tuple[Optional[Tensor], Tensor, Tensor, Tensor]:
+        """returns (packed qkv or None, q, k, v)"""
+        e = self.embed_dim
+        if self.qkv_same:
+            qkv = HF.linear(q, self.in_w, self.qkv_bias)
+            return qkv, qkv[..., :e], qkv[..., e:2 * e], qkv[..., 2 * e:]
+        if self.kv_same:
+            qq = HF.linear(q, self.q_w, self.q_bias)
+            kv = HF.linear(k, self.kv_w, self.kv_bias)
+            return None, qq, kv[..., :e], kv[..., e:]
+        if self.qkv_bias is not None:
+            qb, kb, vb = self.qkv_bias.chunk(3)
+        else:
+            qb, kb, vb = self.q_bias, self.k_bias, self.v_bias
+        return None, HF.linear(q, self.q_w, qb), HF.linear(k, self.k_w, kb), HF.linear(v, self.v_w, vb)
+
+    def forward(self, q: Tensor, k: Tensor, v: Tensor, *, hw: Optional[Tuple[int, int]] = None,
+                mask: Optional[Tensor] = None, require_weights: bool = False,
+                deterministic: bool = False, residual: Optional[Tensor] = None) -> AttentionOutput:
+        if require_weights or self.customize_sdp:
+            raise NotImplementedError("attention weights / custom softmax need the un-fused slow path")
+        if self.training and self.dropout > 0.0:
+            raise NotImplementedError("attention dropout is outside the accelerated hot path")
+        if self.head_dim != 64:
+            raise NotImplementedError(f"HIP attention kernel is built for head_dim 64, got {self.head_dim}")
+        qkv_inp = q, k, v
+        if self.hook is not None:
+            qkv_inp = self.hook.before_forward(qkv_inp)
+        packed, qq, kk, vv = self._project(q, k, v)
+        if self.hook is not None:
+            qq, kk, vv = self.hook.after_forward(qkv_inp, (qq, kk, vv))
+            packed = None
+        keep = None if mask is None else expand_module_mask(mask, self.num_heads)
+        if packed is not None:
+            out = HF.packed_self_attention(packed, self.num_heads, keep, False)
+        else:
+            out = HF.attention_core(qq, kk, vv, self.num_heads, keep, False)
+        net = self.out_linear(out, residual=residual)
+        return AttentionOutput(net, None)
+
+
+# ---------------------------------------------------------------------------------------------
+# mixers
+# ---------------------------------------------------------------------------------------------
+
+
+class ITokenMixer(Module):
+    def __init__(self, in_dim: int, num_tokens: int):
+        super().__init__()
+        self.in_dim, self.num_tokens = in_dim, num_tokens
+
+
+class IChannelMixer(Module):
+    def __init__(self, in_dim: int, latent_dim: int, dropout: float):
+        super().__init__()
+        self.in_dim, self.latent_dim, self.dropout = in_dim, latent_dim, dropout
+
+
+@token_mixers.register("attention")
+class AttentionTokenMixer(ITokenMixer):
+    """reference mixed_stacks/token_mixers.py:57-83"""
+
+    def __init__(self, in_dim: int, num_tokens: int, *, attention_type: str = "basic",
+                 **attention_kwargs: Any):
+        super().__init__(in_dim, num_tokens)
+        attention_kwargs.setdefault("bias", False)
+        attention_kwargs.setdefault("num_heads", 8)
+        attention_kwargs["input_dim"] = in_dim
+        attention_kwargs.setdefault("is_self_attention", True)
+        self.net = attentions.build(attention_type, config=attention_kwargs)
+
+    def forward(self, net: Tensor, hw: Optional[Tuple[int, int]] = None, *, deterministic: bool = False,
+                mask: Optional[Tensor] = None, residual: Optional[Tensor] = None) -> Tensor:
+        return self.net(net, net, net, hw=hw, mask=mask, deterministic=deterministic,
+                        residual=residual).output
+
+
+class _Act(Module):
+    def __init__(self, name: str):
+        super().__init__()
+        self.name = name
+
+    def forward(self, net: Tensor) -> Tensor:
+        return HF.gelu(net)
+
+
+@channel_mixers.register("ff")
+class FeedForward(IChannelMixer):
+    """reference mixed_stacks/channel_mixers.py:15-43 — `net.0` Linear, `net.1` act, `net.2`
+    Dropout, `net.3` Linear, (`net.4` Dropout); state keys `net.0.linear.*`, `net.3.linear.*`."""
+
+    def __init__(self, in_dim: int, latent_dim: int, dropout: float, activation: str = "GELU",
+                 add_last_dropout: bool = True):
+        super().__init__(in_dim, latent_dim, dropout)
+        if activation != "GELU":
+            raise NotImplementedError(f"activation '{activation}' is not on the accelerated hot path yet")
+        blocks: List[Module] = [HijackCustomLinear(in_dim, latent_dim), _Act(activation),
+                                nn.Dropout(dropout), HijackCustomLinear(latent_dim, in_dim)]
+        if add_last_dropout:
+            blocks.append(nn.Dropout(dropout))
+        self.net = nn.Sequential(*blocks)
+
+    @property
+    def need_2d(self) -> bool:
+        return False
+
+    def forward(self, net: Tensor, *, residual: Optional[Tensor] = None) -> Tensor:
+        if self.training and self.dropout > 0.0:
+            raise NotImplementedError("dropout > 0 is outside the accelerated hot path")
+        h = self.net[0](net, act=HF.ACT_GELU)  # bias + exact-erf GELU fused in the GEMM epilogue
+        return self.net[3](h, residual=residual)
+
+
+class PreNorm(Module):
+    """reference high_level.py:26-60 (non-attention use: norm then module)."""
+
+    def __init__(self, *dims: int, module: Module, norm_type: Optional[str] = "layer",
+                 norm_kwargs: Optional[Dict[str, Any]] = None):
+        super().__init__()
+        self.norms = nn.ModuleList([NormFactory(norm_type).make(dim, **(norm_kwargs or {})) for dim in dims])
+        self.module = module
+
+    def forward(self, *xs: Tensor, **kwargs: Any) -> Tensor:
+        return self.module(*[norm(x) for x, norm in zip(xs, self.norms)], **kwargs)
+
+
+# ---------------------------------------------------------------------------------------------
+# MixingBlock / MixedStackedEncoder
+# ---------------------------------------------------------------------------------------------
+
+
+class MixingBlock(Module):
+    """reference mixed_stacks/api.py:41-185 — `token_norm`, `token_mixing`, `channel_norm`,
+    `channel_mixing`."""
+
+    def __init__(self, layer_idx: int, num_layers: int, num_tokens: int, in_dim: int, latent_dim: int, *,
+                 norm_position: str = "pre_norm", token_mixing_type: str,
+                 token_mixing_config: Optional[Dict[str, Any]] = None,
+                 token_mixing_dropout: Optional[float] = None, channel_mixing_type: str = "ff",
+                 channel_mixing_config: Optional[Dict[str, Any]] = None, dropout: float = 0.0,
+                 drop_path: float = 0.0, norm_type: Optional[str] = "batch_norm",
+                 norm_kwargs: Optional[Dict[str, Any]] = None, residual_after_norm: bool = False):
+        super().__init__()
+        if norm_position != "pre_norm":
+            raise NotImplementedError("only `pre_norm` blocks are on the accelerated hot path")
+        if drop_path > 0.0 or dropout > 0.0 or residual_after_norm:
+            raise NotImplementedError("dropout / drop_path / residual_after_norm are outside the hot path")
+        self.norm_position = norm_position
+        self.drop_path = nn.Identity()
+        tm = dict(token_mixing_config or {})
+        tm.update(layer_idx=layer_idx, num_layers=num_layers, num_tokens=num_tokens, in_dim=in_dim,
+                  latent_dim=latent_dim, dropout=dropout)
+        self.token_norm = NormFactory(norm_type).make(in_dim, **(norm_kwargs or {}))
+        self.token_mixing = token_mixers.build(token_mixing_type, config=tm)
+        self.token_mixing_dropout = nn.Dropout(dropout if token_mixing_dropout is None else token_mixing_dropout)
+        cm = dict(channel_mixing_config or {})
+        cm.update(layer_idx=layer_idx, num_layers=num_layers, in_dim=in_dim, latent_dim=latent_dim,
+                  dropout=dropout)
+        self.residual_after_norm = residual_after_norm
+        self.channel_norm = NormFactory(norm_type).make(in_dim, **(norm_kwargs or {}))
+        self.channel_mixing = channel_mixers.build(channel_mixing_type, config=cm)
+        self.use_fused = True
+
+    def _fusable(self) -> bool:
+        tmix, cmix = self.token_mixing, self.channel_mixing
+        if not (isinstance(tmix, AttentionTokenMixer) and isinstance(cmix, FeedForward)):
+            return False
+        att = tmix.net
+        if not (isinstance(att, Attention) and att.qkv_same and att.hook is None and att.head_dim == 64):
+            return False
+        if not (isinstance(self.token_norm, LayerNorm) and isinstance(self.channel_norm, LayerNorm)):
+            return False
+        lins = (att.out_linear, cmix.net[0], cmix.net[3])
+        if any(l.linear is None or l.hook is not None for l in lins):
+            return False
+        params = [att.in_w, att.out_linear.linear.weight, cmix.net[0].linear.weight, cmix.net[3].linear.weight]
+        return all(HF._is_direct(p) for p in params)
+
+    def forward(self, net: Tensor, hw: Optional[Tuple[int, int]] = None, *, deterministic: bool = False,
+                mask: Optional[Tensor] = None, **kwargs: Any) -> Tensor:
+        if self.use_fused and not kwargs and net.dim() == 3 and self._fusable():
+            att, ff = self.token_mixing.net, self.channel_mixing
+            keep = None if mask is None else expand_module_mask(mask, att.num_heads)
+            return fused.mixing_block(
+                net, self.token_norm.weight, self.token_norm.bias, att.in_w, att.qkv_bias,
+                att.out_linear.linear.weight, att.out_linear.linear.bias, self.channel_norm.weight,
+                self.channel_norm.bias, ff.net[0].linear.weight, ff.net[0].linear.bias,
+                ff.net[3].linear.weight, ff.net[3].linear.bias, att.num_heads, self.token_norm.eps,
+                self.channel_norm.eps, keep, False,
+            )
+        # composed path: same kernels, one autograd node per op
+        tkw = dict(hw=hw, deterministic=deterministic, residual=net)
+        if mask is not None:
+            tkw["mask"] = mask
+        tkw.update(kwargs)
+        net = self.token_mixing(self.token_norm(net), **tkw)
+        return self.channel_mixing(self.channel_norm(net), residual=net)
+
+
+class PositionalEncoding(Module):
+    """reference mixed_stacks/api.py:188-267 — parameter `pos_encoding` [1, T, D]."""
+
+    def __init__(self, dim: int, num_tokens: int, dropout: float = 0.0, *, num_head_tokens: int,
+                 is_vision: bool, enable: bool = True):
+        super().__init__()
+        self.pos_drop = None
+        self.pos_encoding = None
+        if enable:
+            self.pos_drop = nn.Dropout(p=dropout)
+            self.pos_encoding = nn.Parameter(torch.zeros(1, num_tokens, dim))
+            nn.init.trunc_normal_(self.pos_encoding, std=0.02)
+        self.num_head_tokens = num_head_tokens
+        self.is_vision = is_vision
+
+
+class MixedStackedEncoder(Module):
+    """reference mixed_stacks/api.py:270-458 (head token + learned positional encoding at native
+    resolution + pre-norm blocks + `PreNorm(LN) -> x[:, 0]` head, the ViT configuration)."""
+
+    def __init__(self, in_dim: int, num_tokens: int, *, token_mixing_type: str,
+                 token_mixing_config: Optional[Dict[str, Any]] = None, channel_mixing_type: str = "ff",
+                 channel_mixing_config: Optional[Dict[str, Any]] = None, num_layers: int = 4,
+                 dropout: float = 0.0, dpr_list: Optional[List[float]] = None, drop_path_rate: float = 0.1,
+                 norm_position: str = "pre_norm", norm_type: Optional[str] = "batch_norm",
+                 norm_kwargs: Optional[Dict[str, Any]] = None, embedding_norm: Optional[Module] = None,
+                 embedding_dropout: Optional[float] = None, residual_after_norm: bool = False,
+                 latent_dim: Optional[int] = None, latent_dim_ratio: float = 1.0,
+                 use_head_token: bool = False, head_pooler: Optional[str] = "mean",
+                 use_positional_encoding: bool = False,
+                 is_vision_positional_encoding: Optional[bool] = None,
+                 positional_encoding_dropout: float = 0.0, no_head_norm: Optional[bool] = None,
+                 norm_after_head: bool = False, aux_heads: Optional[List[str]] = None):
+        super().__init__()
+        if aux_heads is not None or embedding_norm is not None or embedding_dropout is not None:
+            raise NotImplementedError("aux heads / embedding norm / dropout are outside the hot path")
+        if not use_head_token or not use_positional_encoding or norm_after_head or no_head_norm:
+            raise NotImplementedError("only the head-token + positional-encoding + PreNorm head "
+                                      "configuration (ViT) is on the accelerated hot path")
+        self.aux_heads = None
+        self.head_token = nn.Parameter(torch.zeros(1, 1, in_dim))
+        self.num_heads = 1
+        num_tokens += 1
+        self.pos_encoding = PositionalEncoding(in_dim, num_tokens, positional_encoding_dropout,
+                                               num_head_tokens=1, is_vision=bool(is_vision_positional_encoding),
+                                               enable=True)
+        self.embedding_norm = None
+        self.embedding_dropout = None
+        if dpr_list is None:
+            dpr_list = [x.item() for x in torch.linspace(0, drop_path_rate, num_layers)]
+        if latent_dim is None:
+            latent_dim = int(round(in_dim * latent_dim_ratio))
+        self.mixing_blocks = nn.ModuleList([
+            MixingBlock(i, num_layers, num_tokens, in_dim, latent_dim, norm_position=norm_position,
+                        token_mixing_type=token_mixing_type,
+                        token_mixing_config=shallow_copy_dict(token_mixing_config or {}),
+                        channel_mixing_type=channel_mixing_type,
+                        channel_mixing_config=shallow_copy_dict(channel_mixing_config or {}),
+                        dropout=dropout, drop_path=dp, norm_type=norm_type, norm_kwargs=norm_kwargs,
+                        residual_after_norm=residual_after_norm)
+            for i, dp in enumerate(dpr_list)
+        ])
+        self.head_norm = None
+        self.head = PreNorm(in_dim, module=Lambda(lambda x: x[:, 0], name="head_token"),
+                            norm_type=norm_type, norm_kwargs=norm_kwargs)
+        nn.init.trunc_normal_(self.head_token, std=0.02)
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m: Module) -> None:
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0.0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0.0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def post_process(self, net: Tensor) -> Tensor:
+        # LayerNorm is row-wise, so LN(x)[:, 0] == LN(x[:, 0]): normalise token 0 only (1/197 of
+        # the reference's work, identical result) by handing the kernel a strided row view.
+        return self.head.norms[0](net[:, 0])
+
+    def forward_tokens(self, tokens: Tensor, *, hw: Optional[Tuple[int, int]] = None,
+                       deterministic: bool = False) -> Tensor:
+        net = tokens
+        for block in self.mixing_blocks:
+            net = block(net, hw, deterministic=deterministic)
+        return self.post_process(net)
+
+
+# ---------------------------------------------------------------------------------------------
+# patch embedding / ViT encoder / classifier
+# ---------------------------------------------------------------------------------------------
+
+
+class Conv2d(Module):
+    """reference convs/basic.py:41-184 — parameters `weight` [out, in, k, k], `bias`.  Only the
+    stride == kernel_size, padding 0 form (the ViT patch embedding, a GEMM) is on the hot path."""
+
+    def __init__(self, in_channels: int, out_channels: int, *, kernel_size: int, groups: int = 1,
+                 stride: int = 1, dilation: int = 1, padding: Any = "same", bias: bool = True,
+                 gain: float = math.sqrt(2.0)):
+        super().__init__()
+        if padding == "same":
+            padding = kernel_size // 2
+        if groups != 1 or dilation != 1 or stride != kernel_size or padding != 0:
+            raise NotImplementedError("general convolutions are a later hot-path row; only the "
+                                      "patch-embedding form (stride == kernel, padding 0) is built")
+        self.in_c, self.out_c, self.kernel_size = in_channels, out_channels, kernel_size
+        self.groups, self.stride, self.dilation, self.padding = groups, stride, dilation, padding
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        with torch.no_grad():
+            nn.init.xavier_normal_(self.weight.data, gain / math.sqrt(2.0))
+            if self.bias is not None:
+                self.bias.zero_()
+
+
+class VanillaPatchEmbed(Module):
+    """reference high_level.py:153-188 — `projection` Conv2d(k = stride = patch)."""
+
+    def __init__(self, img_size: int, patch_size: int, in_channels: int, latent_dim: int = 128,
+                 **conv_kwargs: Any):
+        super().__init__()
+        if img_size % patch_size != 0:
+            raise ValueError(f"`img_size` ({img_size}) should be divisible by `patch_size` ({patch_size})")
+        self.img_size, self.patch_size = img_size, patch_size
+        self.in_channels, self.latent_dim = in_channels, latent_dim
+        self.projection = Conv2d(in_channels, latent_dim, kernel_size=patch_size, stride=patch_size,
+                                 padding=0, **conv_kwargs)
+
+    @property
+    def num_patches(self) -> int:
+        return (self.img_size // self.patch_size) ** 2
+
+
+to_patches: Dict[str, Any] = {"vanilla": VanillaPatchEmbed}
+
+
+@encoders.register("vit")
+class ViTEncoder(Module):
+    """reference cv/encoder/transformer.py:17-100, made `IEncoder`-conformant (`encode`,
+    `in_channels`, `latent_dim`) so that `cv_clf(encoder="vit")` works — it crashes in the
+    reference.  State keys: `to_patches.projection.*`, `encoder.*`, `output_projection`."""
+
+    def __init__(self, *, img_size: int, patch_size: int, in_channels: int, latent_dim: int = 384,
+                 to_patches_type: str = "vanilla", to_patches_config: Optional[Dict[str, Any]] = None,
+                 num_layers: int = 12, dropout: float = 0.0, drop_path_rate: float = 0.0,
+                 norm_type: Optional[str] = "layer", norm_kwargs: Optional[Dict[str, Any]] = None,
+                 embedding_norm: Optional[Module] = None, residual_after_norm: bool = False,
+                 feedforward_dim_ratio: float = 4.0, attention_kwargs: Optional[Dict[str, Any]] = None,
+                 feedforward_kwargs: Optional[Dict[str, Any]] = None, use_head_token: bool = True,
+                 head_pooler: Optional[str] = "mean", use_positional_encoding: bool = True,
+                 norm_after_head: bool = False, output_dim: Optional[int] = None):
+        super().__init__()
+        cfg = dict(to_patches_config or {})
+        cfg.update(img_size=img_size, patch_size=patch_size, in_channels=in_channels, latent_dim=latent_dim)
+        self.to_patches = to_patches[to_patches_type](**cfg)
+        attention_kwargs = dict(attention_kwargs or {})
+        attention_kwargs.setdefault("bias", True)
+        attention_kwargs.setdefault("num_heads", latent_dim // 64)
+        self.encoder = MixedStackedEncoder(
+            latent_dim, self.to_patches.num_patches, token_mixing_type="attention",
+            token_mixing_config=attention_kwargs, channel_mixing_config=feedforward_kwargs,
+            num_layers=num_layers, dropout=dropout, drop_path_rate=drop_path_rate, norm_type=norm_type,
+            norm_kwargs=norm_kwargs, embedding_norm=embedding_norm, residual_after_norm=residual_after_norm,
+            latent_dim_ratio=feedforward_dim_ratio, head_pooler=head_pooler, use_head_token=use_head_token,
+            use_positional_encoding=use_positional_encoding, is_vision_positional_encoding=True,
+            norm_after_head=norm_after_head,
+        )
+        self.in_channels, self.latent_dim, self.img_size = in_channels, latent_dim, img_size
+        if output_dim is None:
+            self.output_projection = None
+        else:
+            self.output_projection = nn.Parameter((latent_dim ** -0.5) * torch.randn(latent_dim, output_dim))
+
+    def forward(self, net: Tensor, *, hw: Optional[Tuple[int, int]] = None, hwp: Any = None,
+                deterministic: bool = False) -> Tensor:
+        if net.shape[-1] != self.img_size or net.shape[-2] != self.img_size:
+            raise NotImplementedError("positional-encoding interpolation (non-native resolution) is "
+                                      "outside the accelerated hot path")
+        conv = self.to_patches.projection
+        enc = self.encoder
+        tokens = HF.patch_tokens(net, conv.weight, conv.bias, enc.head_token, enc.pos_encoding.pos_encoding)
+        g = self.img_size // self.to_patches.patch_size
+        out = enc.forward_tokens(tokens, hw=(g, g), deterministic=deterministic)
+        if self.output_projection is not None:
+            out = HF.linear(out, self.output_projection.t(), None)
+        return out
+
+    def encode(self, net: Tensor) -> Tensor:
+        return self(net)
+
+
+@register_module("cv_clf")
+class VanillaClassifier(Module):
+    """reference cv/classifier/vanilla.py:16-66 — `encoder` + `head` Linear; returns
+    {"predictions": logits} (fp32 logits, what accelerate's bf16 wrapper hands the loss)."""
+
+    def __init__(self, in_channels: int, num_classes: int, img_size: Optional[int] = None,
+                 latent_dim: int = 128, aux_num_classes: Optional[Dict[str, int]] = None, *,
+                 encoder: str = "vanilla_1d", encoder_config: Optional[Dict[str, Any]] = None):
+        super().__init__()
+        if aux_num_classes is not None:
+            raise NotImplementedError("auxiliary heads are outside the accelerated hot path")
+        self.img_size = img_size
+        cfg = dict(encoder_config or {})
+        cfg.setdefault("img_size", img_size)
+        cfg.setdefault("in_channels", in_channels)
+        cfg.setdefault("latent_dim", latent_dim)
+        self.encoder = encoders.build(encoder, config=cfg)
+        self.head = Linear(latent_dim, num_classes)
+        self.head.out_f32 = True
+        self.aux_keys = None
+
+    def forward(self, net: Tensor, *, return_latent: bool = False) -> Dict[str, Tensor]:
+        latent = self.encoder.encode(net)
+        if return_latent:
+            return {LATENT_KEY: latent}
+        return {PREDICTIONS_KEY: self.head(latent)}
+
+
+def vit_b16_classifier(num_classes: int = 1000, img_size: int = 224, **encoder_overrides: Any) -> VanillaClassifier:
+    """ViT-B/16: latent 768, 12 layers, 12 heads (latent // 64), FF ratio 4, patch 16 — the
+    configuration BASELINE.json's metric is quoted on."""
+    cfg: Dict[str, Any] = dict(patch_size=16, latent_dim=768, num_layers=12)
+    cfg.update(encoder_overrides)
+    return VanillaClassifier(3, num_classes, img_size, cfg["latent_dim"], encoder="vit", encoder_config=cfg)

@@ -1,0 +1,426 @@
+"""Tensor-level wrappers over the C-ABI (include/cfhip.h).  No autograd here.
+
+Every function takes / returns torch tensors that live on the HIP device, launches on torch's
+current stream and never synchronises.  PyTorch is used only as the owner of device memory.
+"""
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU = 0, 1, 2, 3
+
+bf16 = torch.bfloat16
+f32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: Tensor, dtype: torch.dtype, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"cfhip: `{name}` must live on the HIP device (got {t.device})")
+    if t.dtype != dtype:
+        raise TypeError(f"cfhip: `{name}` must be {dtype}, got {t.dtype}")
+
+
+def _mat(t: Tensor, name: str) -> Tuple[int, int, int]:
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"cfhip: `{name}` must be 2-D with a contiguous last dim, got {tuple(t.shape)} / {t.stride()}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------
+
+
+def pick_split_k(m: int, n: int, k: int) -> int:
+    """Split the reduction when the output has too few 128x128 tiles to fill 256 CUs."""
+    tiles = ((m + 127) // 128) * ((n + 127) // 128)
+    steps = (k + 63) // 64
+    if tiles >= 256 or steps < 8:
+        return 1
+    return max(1, min(steps // 4, (512 + tiles - 1) // tiles))
+
+
+def gemm(
+    a: Tensor,
+    b: Tensor,
+    *,
+    a_trans: bool = False,
+    b_trans: bool = False,
+    bias: Optional[Tensor] = None,
+    epilogue: int = EPI_NONE,
+    aux_in: Optional[Tensor] = None,
+    aux_out: Optional[Tensor] = None,
+    out: Optional[Tensor] = None,
+    out_dtype: torch.dtype = bf16,
+    accumulate: bool = False,
+    split_k: int = 1,
+) -> Tensor:
+    """C[m,n] = epilogue(sum_k A(m,k) B(n,k)); see cfhip_gemm_bf16 in include/cfhip.h."""
+    _need(a, bf16, "a")
+    _need(b, bf16, "b")
+    ra, ca, lda = _mat(a, "a")
+    rb, cb, ldb = _mat(b, "b")
+    m, k = (ca, ra) if a_trans else (ra, ca)
+    n, kb = (cb, rb) if b_trans else (rb, cb)
+    if k != kb:
+        raise ValueError(f"cfhip gemm: reduction dims differ ({k} vs {kb})")
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    else:
+        _need(out, out.dtype, "out")
+        if out.dtype not in (bf16, f32) or tuple(out.shape) != (m, n) or out.stride(1) != 1:
+            raise ValueError("cfhip gemm: bad `out`")
+    ldc = out.stride(0)
+    if bias is not None:
+        _need(bias, f32, "bias")
+        if bias.numel() != n or not bias.is_contiguous():
+            raise ValueError("cfhip gemm: bias must be a contiguous f32 [N]")
+    for t, nm in ((aux_in, "aux_in"), (aux_out, "aux_out")):
+        if t is not None:
+            _need(t, bf16, nm)
+            if tuple(t.shape) != (m, n) or t.stride(1) != 1 or t.stride(0) != ldc:
+                raise ValueError(f"cfhip gemm: `{nm}` must match the output layout")
+    ws, ws_bytes = None, 0
+    if split_k > 1:
+        ws = torch.empty((split_k * m * n,), dtype=f32, device=a.device)
+        ws_bytes = ws.numel() * 4
+    rc = _lib.load().cfhip_gemm_bf16(
+        a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(bias), _p(aux_in), _p(aux_out), m, n, k, lda,
+        ldb, ldc, int(a_trans), int(b_trans), epilogue, 1 if out.dtype == f32 else 0,
+        int(accumulate), split_k, _p(ws), ws_bytes, _stream(),
+    )
+    _lib.check(rc, "gemm")
+    return out
+
+
+def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """out[n] (f32) (+)= sum_m x[m, n]   (bias gradient)."""
+    _need(x, bf16, "x")
+    m, n, ldx = _mat(x, "x")
+    if out is None:
+        out = torch.empty((n,), dtype=f32, device=x.device)
+        accumulate = False
+    _need(out, f32, "out")
+    lib = _lib.load()
+    nbytes = lib.cfhip_colsum_workspace(m, n)
+    ws = torch.empty((max(nbytes, 4) // 4,), dtype=f32, device=x.device)
+    rc = lib.cfhip_colsum_bf16(x.data_ptr(), out.data_ptr(), m, n, ldx, int(accumulate), ws.data_ptr(),
+                               ws.numel() * 4, _stream())
+    _lib.check(rc, "colsum")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# LayerNorm
+# ---------------------------------------------------------------------------------------------
+
+
+def layernorm_fwd(
+    x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out: Optional[Tensor] = None
+) -> Tuple[Tensor, Tensor, Tensor]:
+    """x: bf16 [M, D] (row stride free) -> y bf16 [M, D], mean f32 [M], rstd f32 [M]."""
+    _need(x, bf16, "x")
+    _need(gamma, f32, "gamma")
+    _need(beta, f32, "beta")
+    m, d, xs = _mat(x, "x")
+    y = torch.empty((m, d), dtype=bf16, device=x.device) if out is None else out
+    mean = torch.empty((m,), dtype=f32, device=x.device)
+    rstd = torch.empty((m,), dtype=f32, device=x.device)
+    rc = _lib.load().cfhip_layernorm_fwd(
+        x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+        rstd.data_ptr(), m, d, xs, y.stride(0), float(eps), _stream(),
+    )
+    _lib.check(rc, "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(
+    dy: Tensor,
+    x: Tensor,
+    gamma: Tensor,
+    mean: Tensor,
+    rstd: Tensor,
+    *,
+    dx_add: Optional[Tensor] = None,
+    dgamma: Optional[Tensor] = None,
+    dbeta: Optional[Tensor] = None,
+    accumulate: bool = False,
+) -> Tuple[Tensor, Tensor, Tensor]:
+    """Returns (dx bf16 [M, D] (+ dx_add), dgamma f32 [D], dbeta f32 [D])."""
+    _need(dy, bf16, "dy")
+    _need(x, bf16, "x")
+    m, d, xs = _mat(x, "x")
+    _, _, dys = _mat(dy, "dy")
+    dx = torch.empty((m, d), dtype=bf16, device=x.device)
+    if dx_add is not None:
+        _need(dx_add, bf16, "dx_add")
+        if tuple(dx_add.shape) != (m, d) or dx_add.stride(0) != dx.stride(0) or dx_add.stride(1) != 1:
+            raise ValueError("cfhip layernorm_bwd: dx_add must be a dense [M, D] bf16 tensor")
+    if dgamma is None:
+        dgamma = torch.empty((d,), dtype=f32, device=x.device)
+        dbeta = torch.empty((d,), dtype=f32, device=x.device)
+        accumulate = False
+    lib = _lib.load()
+    nbytes = lib.cfhip_layernorm_bwd_workspace(m, d)
+    ws = torch.empty((nbytes // 4,), dtype=f32, device=x.device)
+    rc = lib.cfhip_layernorm_bwd(
+        dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add),
+        dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), m, d, dys, xs, dx.stride(0),
+        int(accumulate), ws.data_ptr(), nbytes, _stream(),
+    )
+    _lib.check(rc, "layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+# ---------------------------------------------------------------------------------------------
+# attention (head_dim 64).  q / k / v / o are [B, T, H*64] views (any batch / token strides).
+# ---------------------------------------------------------------------------------------------
+
+
+def _bth(t: Tensor, name: str) -> Tuple[int, int, int, int, int]:
+    _need(t, bf16, name)
+    if t.dim() != 3 or t.stride(2) != 1:
+        raise ValueError(f"cfhip attention: `{name}` must be [B, T, H*64] with a contiguous last dim")
+    return t.shape[0], t.shape[1], t.shape[2], t.stride(0), t.stride(1)
+
+
+def _mask_args(mask: Optional[Tensor], b: int, h: int, tq: int, tk: int):
+    """mask: bool/uint8 'keep' mask broadcastable to [B, H, Tq, Tk] (True = attend)."""
+    if mask is None:
+        return None, None, 0, 0, 0
+    if mask.dtype == torch.bool:
+        mask = mask.to(torch.uint8)
+    if mask.dtype != torch.uint8:
+        raise TypeError("cfhip attention: mask must be bool or uint8")
+    while mask.dim() < 4:
+        mask = mask.unsqueeze(0)
+    mask = mask.expand(b, h, tq, tk)
+    if mask.stride(3) != 1:
+        mask = mask.contiguous()
+    return mask, mask.data_ptr(), mask.stride(0), mask.stride(1), mask.stride(2)
+
+
+def attn_fwd(
+    q: Tensor, k: Tensor, v: Tensor, num_heads: int, *, mask: Optional[Tensor] = None,
+    causal: bool = False, scale: Optional[float] = None,
+) -> Tuple[Tensor, Tensor]:
+    """Returns (o bf16 [B, Tq, H*64] contiguous, lse f32 [B, H, Tq])."""
+    b, tq, d, q_sb, q_st = _bth(q, "q")
+    _, tk, _, k_sb, k_st = _bth(k, "k")
+    _, _, _, v_sb, v_st = _bth(v, "v")
+    if d != num_heads * 64:
+        raise ValueError(f"cfhip attention: head_dim must be 64 (embed {d}, heads {num_heads})")
+    if (k_sb, k_st) != (v_sb, v_st):
+        raise ValueError("cfhip attention: k and v must share batch / token strides")
+    if scale is None:
+        scale = 1.0 / math.sqrt(64.0)
+    o = torch.empty((b, tq, d), dtype=bf16, device=q.device)
+    lse = torch.empty((b, num_heads, tq), dtype=f32, device=q.device)
+    keep, mp, ms_b, ms_h, ms_q = _mask_args(mask, b, num_heads, tq, tk)
+    rc = _lib.load().cfhip_attn_fwd(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), mp, b, num_heads, tq,
+        tk, q_sb, q_st, k_sb, k_st, o.stride(0), o.stride(1), ms_b, ms_h, ms_q, float(scale),
+        int(causal), _stream(),
+    )
+    _lib.check(rc, "attn_fwd")
+    return o, lse
+
+
+def attn_bwd(
+    q: Tensor, k: Tensor, v: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, num_heads: int, *,
+    dq: Tensor, dk: Tensor, dv: Tensor, mask: Optional[Tensor] = None, causal: bool = False,
+    scale: Optional[float] = None,
+) -> None:
+    """Writes dq / dk / dv (bf16, SAME strides as q / k / v — e.g. views of one packed buffer)."""
+    b, tq, d, q_sb, q_st = _bth(q, "q")
+    _, tk, _, k_sb, k_st = _bth(k, "k")
+    _bth(v, "v")
+    _, _, _, o_sb, o_st = _bth(o, "o")
+    _, _, _, do_sb, do_st = _bth(d_o, "d_o")
+    if (o_sb, o_st) != (do_sb, do_st):
+        raise ValueError("cfhip attention: o and d_o must share strides")
+    for t, ref, nm in ((dq, q, "dq"), (dk, k, "dk"), (dv, v, "dv")):
+        _need(t, bf16, nm)
+        if t.shape != ref.shape or t.stride() != ref.stride():
+            raise ValueError(f"cfhip attention: `{nm}` must have the shape and strides of its primal")
+    if scale is None:
+        scale = 1.0 / math.sqrt(64.0)
+    delta = torch.empty((b, num_heads, tq), dtype=f32, device=q.device)
+    keep, mp, ms_b, ms_h, ms_q = _mask_args(mask, b, num_heads, tq, tk)
+    rc = _lib.load().cfhip_attn_bwd(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
+        delta.data_ptr(), mp, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), b, num_heads, tq, tk, q_sb,
+        q_st, k_sb, k_st, o_sb, o_st, ms_b, ms_h, ms_q, float(scale), int(causal), _stream(),
+    )
+    _lib.check(rc, "attn_bwd")
+
+
+# ---------------------------------------------------------------------------------------------
+# ViT glue
+# ---------------------------------------------------------------------------------------------
+
+
+def im2row(img: Tensor, patch: int) -> Tensor:
+    """img [B, C, H, W] (f32 or bf16, contiguous) -> bf16 [B*gh*gw, C*P*P] in (c, ph, pw) order."""
+    if img.dtype not in (f32, bf16) or not img.is_cuda or not img.is_contiguous() or img.dim() != 4:
+        raise ValueError("cfhip im2row: img must be a contiguous f32/bf16 [B, C, H, W] device tensor")
+    b, c, hh, ww = img.shape
+    rows = torch.empty((b * (hh // patch) * (ww // patch), c * patch * patch), dtype=bf16, device=img.device)
+    rc = _lib.load().cfhip_im2row(img.data_ptr(), int(img.dtype == bf16), rows.data_ptr(), b, c, hh, ww,
+                                  patch, _stream())
+    _lib.check(rc, "im2row")
+    return rows
+
+
+def assemble_tokens_fwd(patches: Tensor, head_token: Tensor, pos: Tensor, b: int) -> Tensor:
+    """patches bf16 [B*Np, D]; head_token f32 [D]; pos f32 [(Np+1)*D] -> x0 bf16 [B, Np+1, D]."""
+    _need(patches, bf16, "patches")
+    _need(head_token, f32, "head_token")
+    _need(pos, f32, "pos")
+    d = patches.shape[-1]
+    np_ = patches.numel() // (b * d)
+    x0 = torch.empty((b, np_ + 1, d), dtype=bf16, device=patches.device)
+    rc = _lib.load().cfhip_assemble_tokens_fwd(patches.data_ptr(), head_token.data_ptr(), pos.data_ptr(),
+                                               x0.data_ptr(), b, np_, d, _stream())
+    _lib.check(rc, "assemble_tokens_fwd")
+    return x0
+
+
+def assemble_tokens_bwd(
+    dx0: Tensor, dhead: Optional[Tensor], dpos: Optional[Tensor], accumulate: bool,
+    want_dpatches: bool = True,
+) -> Optional[Tensor]:
+    """dx0 bf16 [B, Np+1, D] contiguous -> dpatches bf16 [B*Np, D]; dhead / dpos f32 (+)=."""
+    _need(dx0, bf16, "dx0")
+    if not dx0.is_contiguous():
+        raise ValueError("cfhip assemble_tokens_bwd: dx0 must be contiguous")
+    b, t, d = dx0.shape
+    dpatches = torch.empty((b * (t - 1), d), dtype=bf16, device=dx0.device) if want_dpatches else None
+    rc = _lib.load().cfhip_assemble_tokens_bwd(dx0.data_ptr(), _p(dpatches), _p(dhead), _p(dpos), b, t - 1,
+                                               d, int(accumulate), _stream())
+    _lib.check(rc, "assemble_tokens_bwd")
+    return dpatches
+
+
+# ---------------------------------------------------------------------------------------------
+# element-wise
+# ---------------------------------------------------------------------------------------------
+
+
+def to_bf16(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """f32 -> bf16 (round-to-nearest-even) through the HIP cast kernel; bf16 passes through."""
+    if x.dtype == bf16 and out is None:
+        return x
+    _need(x, f32, "x")
+    if not x.is_contiguous():
+        x = x.contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=bf16, device=x.device)
+    rc = _lib.load().cfhip_cast_f32_to_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream())
+    _lib.check(rc, "cast_f32_to_bf16")
+    return out
+
+
+def to_f32(x: Tensor) -> Tensor:
+    if x.dtype == f32:
+        return x
+    _need(x, bf16, "x")
+    if not x.is_contiguous():
+        x = x.contiguous()
+    out = torch.empty(x.shape, dtype=f32, device=x.device)
+    rc = _lib.load().cfhip_cast_bf16_to_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream())
+    _lib.check(rc, "cast_bf16_to_f32")
+    return out
+
+
+def _ew(fn_name: str, *tensors: Tensor) -> Tensor:
+    for i, t in enumerate(tensors):
+        _need(t, bf16, f"arg{i}")
+        if not t.is_contiguous():
+            raise ValueError(f"cfhip {fn_name}: tensors must be contiguous")
+    out = torch.empty_like(tensors[0])
+    fn = getattr(_lib.load(), fn_name)
+    rc = fn(*[t.data_ptr() for t in tensors], out.data_ptr(), out.numel(), _stream())
+    _lib.check(rc, fn_name)
+    return out
+
+
+def gelu_fwd(x: Tensor) -> Tensor:
+    return _ew("cfhip_gelu_fwd", x)
+
+
+def gelu_bwd(dy: Tensor, x: Tensor) -> Tensor:
+    return _ew("cfhip_gelu_bwd", dy, x)
+
+
+def add(a: Tensor, b: Tensor) -> Tensor:
+    return _ew("cfhip_add_bf16", a, b)
+
+
+def transpose(x: Tensor) -> Tensor:
+    _need(x, bf16, "x")
+    r, c, ld = _mat(x, "x")
+    out = torch.empty((c, r), dtype=bf16, device=x.device)
+    rc = _lib.load().cfhip_transpose_bf16(x.data_ptr(), out.data_ptr(), r, c, ld, out.stride(0), _stream())
+    _lib.check(rc, "transpose")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# optimiser / loss
+# ---------------------------------------------------------------------------------------------
+
+
+def adam_step(
+    p: Tensor, g: Tensor, m: Tensor, v: Tensor, p_bf16: Optional[Tensor], *, lr: float, beta1: float,
+    beta2: float, eps: float, weight_decay: float, decoupled: bool, step: int, grad_scale: float = 1.0,
+) -> None:
+    for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _need(t, f32, nm)
+        if not t.is_contiguous() or t.numel() != p.numel():
+            raise ValueError("cfhip adam_step: flat contiguous f32 buffers of equal length expected")
+    if p_bf16 is not None:
+        _need(p_bf16, bf16, "p_bf16")
+    rc = _lib.load().cfhip_adam_step(
+        p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), p.numel(), float(lr),
+        float(beta1), float(beta2), float(eps), float(weight_decay), int(decoupled), int(step),
+        float(grad_scale), _stream(),
+    )
+    _lib.check(rc, "adam_step")
+
+
+def sumsq(g: Tensor) -> Tensor:
+    _need(g, f32, "g")
+    out = torch.zeros((1,), dtype=f32, device=g.device)
+    rc = _lib.load().cfhip_sumsq_f32(g.data_ptr(), out.data_ptr(), g.numel(), _stream())
+    _lib.check(rc, "sumsq")
+    return out
+
+
+def softmax_xent(logits: Tensor, labels: Tensor, grad_scale: float, want_grad: bool = True):
+    """Returns (loss_sum f32 [1], dlogits f32 [B, C] = (softmax - onehot) * grad_scale)."""
+    _need(logits, f32, "logits")
+    if labels.dtype != torch.int64 or not labels.is_cuda:
+        raise TypeError("cfhip softmax_xent: labels must be int64 on the device")
+    if not logits.is_contiguous():
+        logits = logits.contiguous()
+    labels = labels.reshape(-1).contiguous()
+    b, c = logits.shape
+    loss = torch.zeros((1,), dtype=f32, device=logits.device)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    rc = _lib.load().cfhip_softmax_xent(logits.data_ptr(), labels.data_ptr(), loss.data_ptr(), _p(dlogits),
+                                        b, c, float(grad_scale), _stream())
+    _lib.check(rc, "softmax_xent")
+    return loss, dlogits

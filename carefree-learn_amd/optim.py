@@ -1,0 +1,185 @@
+"""Flat parameter / gradient arenas in HBM and the fused Adam(W) step over them.
+
+Layout (sized for 288 GB HBM3E: full fp32 replica + fp32 grads + Adam moments + bf16 shadow =
+18 B / parameter, 1.56 GB for ViT-B/16): every parameter of the model is a VIEW into one flat fp32
+buffer, every `.grad` a view into a second one, every bf16 forward-pass copy a view into a third.
+Consequences:
+  * the optimiser step is ONE HBM-bound kernel over the arena (reads p, g, m, v; writes p, m, v and
+    the bf16 shadow used by the next forward — no separate cast pass, no per-tensor launches);
+  * DDP buckets are plain slices of the gradient arena (zero-copy all-reduce, `ddp.py`);
+  * the backward kernels' fp32 outputs land directly in their final place.
+
+The reference selects `torch.optim.Adam` / `AdamW` by name (optimizers.py:29-33) and steps it from
+`get_update_fn` (schema.py:977-986); `FusedAdam` keeps that class's constructor / `step()` /
+`zero_grad()` / `state_dict()` surface.
+"""
+import math
+from typing import Any, Dict, Iterable, List, Optional
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+f32 = torch.float32
+bf16 = torch.bfloat16
+_ALIGN = 8  # elements: keeps every bf16 shadow view 16-byte aligned (MFMA GEMM operand rule)
+
+
+class ParamArena:
+    """Re-homes `params` (fp32, same device) into flat param / grad / bf16-shadow buffers."""
+
+    def __init__(self, params: Iterable[Tensor], *, with_shadow: bool = True):
+        self.params: List[Tensor] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("ParamArena: no trainable parameters")
+        dev = self.params[0].device
+        for p in self.params:
+            if p.dtype != f32 or p.device != dev:
+                raise ValueError("ParamArena: parameters must be fp32 and on one device")
+        self.offsets: List[int] = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.total = off
+        self.flat_p = torch.zeros(off, dtype=f32, device=dev)
+        self.flat_g = torch.zeros(off, dtype=f32, device=dev)
+        self.flat_p16 = torch.zeros(off, dtype=bf16, device=dev) if with_shadow else None
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                n = p.numel()
+                self.flat_p[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[o:o + n].view(p.shape)
+                p.grad = self.flat_g[o:o + n].view(p.shape)
+                p._cfhip_fresh = False  # the arena starts zeroed: accumulate into it
+                if self.flat_p16 is not None:
+                    p._cfhip_shadow = self.flat_p16[o:o + n].view(p.shape)
+                    p._cfhip_shadow_version = None  # filled by refresh_shadow()
+        self.refresh_shadow()
+
+    def refresh_shadow(self) -> None:
+        """bf16 shadow <- fp32 masters (after construction / load_state_dict)."""
+        if self.flat_p16 is None:
+            return
+        if self.flat_p.is_cuda:
+            ops.to_bf16(self.flat_p, out=self.flat_p16)
+        else:
+            self.flat_p16.copy_(self.flat_p)
+        for p in self.params:
+            p._cfhip_shadow_version = p._version
+
+    def zero_grad(self, lazy: bool = False) -> None:
+        """Default: one memset over the gradient arena (autograd accumulates INTO `.grad`, so stale
+        values must be gone).  `lazy=True` skips the memset and marks every gradient 'fresh' instead:
+        the first HIP backward kernel that writes a parameter's gradient then OVERWRITES it and
+        whatever nobody wrote is zeroed by `finalize_grads()`.  Only valid when every parameter's
+        gradient is produced by the direct-write HIP backward kernels (true for the ViT modules)."""
+        if not lazy:
+            self.flat_g.zero_()
+        for p in self.params:
+            if p.grad is None:  # somebody ran a set_to_none zero_grad: point it back into the arena
+                self._rebind_grad(p)
+            p._cfhip_fresh = lazy
+
+    def _index(self, p: Tensor) -> int:
+        idx = getattr(p, "_cfhip_arena_index", None)
+        if idx is None:
+            for i, q in enumerate(self.params):
+                q._cfhip_arena_index = i
+            idx = p._cfhip_arena_index
+        return idx
+
+    def _rebind_grad(self, p: Tensor) -> None:
+        o = self.offsets[self._index(p)]
+        p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+
+    def finalize_grads(self) -> None:
+        """Zero the gradient slots no backward kernel touched this step (unused parameters)."""
+        for p in self.params:
+            if getattr(p, "_cfhip_fresh", False):
+                p.grad.zero_()
+                p._cfhip_fresh = False
+
+
+class FusedAdam:
+    """Adam / AdamW over a `ParamArena` in one kernel launch (K14)."""
+
+    def __init__(self, params: Any, lr: float = 1.0e-3, betas: Any = (0.9, 0.999), eps: float = 1.0e-8,
+                 weight_decay: float = 0.0, *, decoupled: bool = False, arena: Optional[ParamArena] = None):
+        self.arena = arena if arena is not None else ParamArena(params)
+        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
+        self.param_groups = [dict(params=self.arena.params, **self.defaults)]
+        self.decoupled = decoupled
+        self.step_count = 0
+        self.grad_scale = 1.0
+        self.lazy_zero = False  # see ParamArena.zero_grad
+        a = self.arena
+        self.exp_avg = torch.zeros_like(a.flat_p)
+        self.exp_avg_sq = torch.zeros_like(a.flat_p)
+        self._hyper_host = torch.zeros(8, dtype=f32, pin_memory=a.flat_p.is_cuda)
+        self._hyper_dev = torch.zeros(8, dtype=f32, device=a.flat_p.device)
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        self.arena.zero_grad(lazy=self.lazy_zero)
+
+    def _fill_hyper(self) -> None:
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        t = self.step_count
+        h = self._hyper_host
+        h[0], h[1], h[2], h[3], h[4] = g["lr"], b1, b2, g["eps"], g["weight_decay"]
+        h[5] = 1.0 - b1 ** t
+        h[6] = 1.0 / math.sqrt(1.0 - b2 ** t)
+        h[7] = self.grad_scale
+
+    def prepare_step(self) -> None:
+        """Host side of a step: advance t and upload the 32-byte hyper-parameter record.  Kept
+        separate from `launch_step()` so the launch itself can live inside a captured hipGraph."""
+        self.step_count += 1
+        self._fill_hyper()
+        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+
+    def launch_step(self) -> None:
+        a = self.arena
+        a.finalize_grads()
+        if not a.flat_p.is_cuda:
+            raise RuntimeError("FusedAdam: the arena must live on the HIP device (no CPU fallback)")
+        from . import _lib
+
+        rc = _lib.load().cfhip_adam_step_dev(
+            a.flat_p.data_ptr(), a.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+            None if a.flat_p16 is None else a.flat_p16.data_ptr(), a.total, self._hyper_dev.data_ptr(),
+            int(self.decoupled), torch.cuda.current_stream().cuda_stream,
+        )
+        _lib.check(rc, "adam_step_dev")
+
+    def step(self, closure: Any = None) -> None:
+        self.prepare_step()
+        self.launch_step()
+
+    def state_dict(self) -> Dict[str, Any]:
+        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq,
+                    param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])
+
+    def load_state_dict(self, sd: Dict[str, Any]) -> None:
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
+
+
+def clip_grad_norm_(arena: ParamArena, max_norm: float, optimizer: Optional[FusedAdam] = None) -> Tensor:
+    """Global L2 clipping on the gradient arena (reference trainer.py:170-176 semantics).  With an
+    optimizer the clip coefficient is folded into the Adam kernel's grad_scale (needs one host
+    read of the norm, like accelerate's clip_grad_norm_)."""
+    arena.finalize_grads()
+    total = ops.sumsq(arena.flat_g).sqrt()
+    coef = float(max_norm) / (float(total) + 1.0e-6)
+    if coef < 1.0:
+        if optimizer is not None:
+            optimizer.grad_scale *= coef
+        else:
+            arena.flat_g.mul_(coef)
+    return total

@@ -1,0 +1,182 @@
+/*
+ * cfhip.h — C-ABI of libcfhip.so: the MI355X (gfx950 / CDNA4) kernels behind carefree-learn's
+ * data-parallel training hot path (ViT building blocks).
+ *
+ * The reference (carefree-learn v0.5.0, /root/reference) is 100 % Python and has no FFI of its
+ * own: all arithmetic on this path is delegated to PyTorch ATen ops.  The "reference interface"
+ * each entry point replaces is therefore the ATen call site inside the reference module, cited
+ * per function below as file:line relative to /root/reference.
+ *
+ * Conventions
+ *   - plain C types only; every tensor is a raw device pointer + explicit sizes / leading dims
+ *     (in ELEMENTS of the tensor's dtype); row-major, last dimension contiguous.
+ *   - bf16 = 16-bit brain float stored as uint16_t; "f32" = IEEE float.
+ *   - every call takes the HIP stream (hipStream_t as void*); nothing synchronises the device,
+ *     nothing allocates or frees device memory, no pointer is retained after return: the caller
+ *     (PyTorch caching allocator) owns every buffer, scratch is passed in as `workspace`.
+ *   - return 0 on success, negative on error; cfhip_last_error() gives the thread-local message.
+ *   - re-entrant: callable from the Python main thread and the autograd worker thread.
+ */
+#ifndef CFHIP_H
+#define CFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFHIP_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define CFHIP_OK 0
+#define CFHIP_ERR_INVALID (-1)   /* bad argument / unsupported shape */
+#define CFHIP_ERR_LAUNCH (-2)    /* HIP launch failure */
+#define CFHIP_ERR_WORKSPACE (-3) /* workspace too small */
+
+int cfhip_version(void);
+const char* cfhip_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1/K2  GEMM  (replaces F.linear at modules/core/customs.py:89, attentions.py:214,
+ *              nn.Linear.forward via hijacks.py:42-57, and its autograd backward)
+ *
+ *   C[m][n] = epilogue( sum_k A(m,k) * B(n,k) )          bf16 operands, fp32 accumulate (MFMA)
+ *
+ *   a_trans = 0: A(m,k) = A[m*lda + k]      a_trans = 1: A(m,k) = A[k*lda + m]
+ *   b_trans = 0: B(n,k) = B[n*ldb + k]      b_trans = 1: B(n,k) = B[k*ldb + n]
+ *   (forward  y = x W^T      : a_trans 0, b_trans 0, A = x [M,K],  B = W  [N,K])
+ *   (backward dx = dy W      : a_trans 0, b_trans 1, A = dy [M,Kd], B = W  [Kd,N])
+ *   (backward dW = dy^T x    : a_trans 1, b_trans 1, A = dy [Kd,M], B = x  [Kd,N])
+ *
+ *   epilogue (bias is fp32 [N] or NULL in every mode):
+ *     CFHIP_EPI_NONE        C = acc + bias
+ *     CFHIP_EPI_GELU        aux_out (bf16 [M,ldc], may be NULL) = acc + bias ; C = gelu_erf(acc + bias)
+ *     CFHIP_EPI_RESIDUAL    C = acc + bias + aux_in (bf16 [M,ldc])
+ *     CFHIP_EPI_DGELU       C = acc * gelu_erf'(aux_in)   (aux_in = saved pre-activation, bf16)
+ *   out_dtype: 0 = bf16, 1 = f32.   accumulate != 0 (f32 output only): C += result.
+ *   split_k > 1: the K range is cut in `split_k` slices, partial tiles go to `workspace`
+ *     (needs split_k*M*N*4 bytes) and a second kernel reduces them (epilogue NONE only).
+ * ------------------------------------------------------------------------------------------ */
+#define CFHIP_EPI_NONE 0
+#define CFHIP_EPI_GELU 1
+#define CFHIP_EPI_RESIDUAL 2
+#define CFHIP_EPI_DGELU 3
+
+int cfhip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, const void* aux_in,
+                    void* aux_out, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                    int a_trans, int b_trans, int epilogue, int out_dtype, int accumulate,
+                    int split_k, void* workspace, size_t workspace_bytes, void* stream);
+
+/* column sums of a bf16 matrix: out[n] (f32) (+)= sum_m X[m*ldx + n]   (bias gradients)
+ * workspace: >= cfhip_colsum_workspace(M, N) bytes. */
+size_t cfhip_colsum_workspace(int M, int N);
+int cfhip_colsum_bf16(const void* X, float* out, int M, int N, int64_t ldx, int accumulate,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5  LayerNorm over the last dim (replaces nn.LayerNorm built by NormFactory("layer"),
+ *     modules/core/norms.py:88-89,118-119; call sites mixed_stacks/api.py:141,155,397-402)
+ *   biased variance, eps inside the sqrt, fp32 statistics; x / y are bf16, gamma / beta fp32.
+ *   D % 4 == 0 and D <= 2048 (a row lives in the registers of one wave).
+ *   x_row_stride / y_row_stride in elements (lets the head LN read token 0 of every sample).
+ *   fwd saves mean / rstd (f32 [M]) for bwd.
+ *   bwd: dx (bf16) = LN'(dy) [+ dx_add (bf16) if not NULL]; dgamma / dbeta (f32 [D]) (+)= ...
+ *        workspace >= cfhip_layernorm_bwd_workspace(M, D) bytes.
+ * ------------------------------------------------------------------------------------------ */
+int cfhip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                        float* rstd, int M, int D, int64_t x_row_stride, int64_t y_row_stride,
+                        float eps, void* stream);
+size_t cfhip_layernorm_bwd_workspace(int M, int D);
+int cfhip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                        const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta,
+                        int M, int D, int64_t dy_row_stride, int64_t x_row_stride,
+                        int64_t dx_row_stride, int accumulate_param_grads, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3/K4  fused scaled-dot-product attention (replaces F.scaled_dot_product_attention reached
+ *     through sdp_attn, toolkit.py:953-963, from Attention.forward, attentions.py:254, and the
+ *     head split / merge copies at attentions.py:180-185,270-275)
+ *
+ *   o[b,t,h,:] = softmax_j( q[b,t,h,:] . k[b,j,h,:] * scale  [+ mask] ) v[b,j,h,:]
+ *
+ *   q, k, v, o, dq, dk, dv, do: bf16, addressed as  ptr[b*stride_b + t*stride_t + h*DH + d]
+ *   (so the packed [B,T,3,H,DH] projection output is consumed in place and o is written
+ *   directly as [B,T,H*DH]).  head_dim DH must be 64.  Tq, Tk <= CFHIP_ATTN_MAX_T (whole K/V of
+ *   one head is LDS-resident).  lse: f32 [B,H,Tq] (natural-log sum-exp of the scaled scores).
+ *   mask: optional uint8 "keep" mask (1 = attend), addressed mask[b*ms_b + h*ms_h + i*ms_q + j]
+ *   (strides may be 0 for broadcasting), or NULL.  causal != 0 additionally masks j > i.
+ *   bwd needs delta: f32 [B,H,Tq] scratch (rowsum(do * o), computed inside).
+ * ------------------------------------------------------------------------------------------ */
+#define CFHIP_ATTN_MAX_T 256
+#define CFHIP_ATTN_HEAD_DIM 64
+
+int cfhip_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                   const uint8_t* mask, int B, int H, int Tq, int Tk, int64_t q_stride_b,
+                   int64_t q_stride_t, int64_t kv_stride_b, int64_t kv_stride_t, int64_t o_stride_b,
+                   int64_t o_stride_t, int64_t ms_b, int64_t ms_h, int64_t ms_q, float scale,
+                   int causal, void* stream);
+
+int cfhip_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                   const float* lse, float* delta, const uint8_t* mask, void* dq, void* dk, void* dv,
+                   int B, int H, int Tq, int Tk, int64_t q_stride_b, int64_t q_stride_t,
+                   int64_t kv_stride_b, int64_t kv_stride_t, int64_t o_stride_b, int64_t o_stride_t,
+                   int64_t ms_b, int64_t ms_h, int64_t ms_q, float scale, int causal, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K8 (ViT patch embedding) + K7 glue
+ *   im2row: img f32/bf16 [B,C,Hh,Ww] -> rows bf16 [B*gh*gw, C*P*P] in (c, ph, pw) order, so the
+ *     stride==kernel Conv2d of VanillaPatchEmbed (high_level.py:172-188) becomes one K1 GEMM with
+ *     the conv weight viewed as [out, C*P*P].
+ *   assemble_tokens: x0[b,0,:] = head_token + pos[0]; x0[b,1+p,:] = patches[b,p,:] + pos[1+p]
+ *     (mixed_stacks/api.py:419-438,209-228).  bwd: dpatches (bf16), dhead_token, dpos (f32, (+)=).
+ * ------------------------------------------------------------------------------------------ */
+int cfhip_im2row(const void* img, int img_is_bf16, void* rows, int B, int C, int Hh, int Ww, int P,
+                 void* stream);
+int cfhip_assemble_tokens_fwd(const void* patches, const float* head_token, const float* pos,
+                              void* x0, int B, int Np, int D, void* stream);
+int cfhip_assemble_tokens_bwd(const void* dx0, void* dpatches, float* dhead_token, float* dpos,
+                              int B, int Np, int D, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * element-wise helpers (K6 stand-alone forms, casts)
+ * ------------------------------------------------------------------------------------------ */
+int cfhip_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int cfhip_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+int cfhip_gelu_fwd(const void* x, void* y, int64_t n, void* stream);              /* bf16 */
+int cfhip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
+int cfhip_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+/* bf16 [R,C] -> bf16 [C,R] */
+int cfhip_transpose_bf16(const void* src, void* dst, int R, int C, int64_t ld_src, int64_t ld_dst,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K14  fused Adam / AdamW over a flat fp32 parameter arena (next-row §8f; replaces
+ *     torch.optim.Adam(W).step() selected by optimizers.py:29-33)
+ *   p, g, m, v: f32 [n].  p_bf16 (may be NULL): refreshed bf16 copy of the parameters for the
+ *   next forward.  grad_scale multiplies g first (1/world_size for DDP-mean, clip coefficient).
+ *   step >= 1 (bias correction).  decoupled != 0 -> AdamW.
+ * ------------------------------------------------------------------------------------------ */
+int cfhip_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int decoupled, int step,
+                    float grad_scale, void* stream);
+/* same update, step-dependent scalars read from device memory so the launch can be replayed from a
+ * captured hipGraph: hyper[0..7] = lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1/sqrt(1-beta2^t),
+ * grad_scale (f32, device). */
+int cfhip_adam_step_dev(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n,
+                        const float* hyper, int decoupled, void* stream);
+/* sum of squares of g (f32 [n]) into out[0] (+= ; caller zeroes) — gradient-norm clipping */
+int cfhip_sumsq_f32(const float* g, float* out, int64_t n, void* stream);
+
+/* softmax cross-entropy on f32 logits [B,C] with int64 labels [B]: loss_sum (f32[1], caller
+ * zeroes) += sum_b CE_b ; dlogits (f32 [B,C]) = (softmax - onehot) * grad_scale.
+ * (losses/basic.py:126-141; integer label gather is exact.) */
+int cfhip_softmax_xent(const float* logits, const int64_t* labels, float* loss_sum, float* dlogits,
+                       int B, int C, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFHIP_H */

@@ -1,0 +1,75 @@
+"""The C-ABI library: loads, exports every symbol include/cfhip.h declares, the ctypes table matches
+the header, and argument validation returns errors (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import cflearn_amd
+from cflearn_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "cfhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cfhip_\w+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"libcfhip.so does not export {n}"
+
+
+def test_ctypes_table_matches_header():
+    assert sorted(_lib.SIGNATURES) == _declared()
+
+
+def test_version_and_error_string():
+    lib = _lib.load()
+    assert lib.cfhip_version() == 100
+    # invalid arguments are rejected before any launch, with a message
+    rc = lib.cfhip_gemm_bf16(None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1, None, 0, None)
+    assert rc == -1
+    assert b"null" in lib.cfhip_last_error()
+    rc = lib.cfhip_layernorm_fwd(1, 1, 1, 1, None, None, 4, 6, 8, 8, 1e-6, None)
+    assert rc == -1 and b"multiple of 4" in lib.cfhip_last_error()
+    rc = lib.cfhip_attn_fwd(16, 16, 16, 16, None, None, 1, 1, 300, 300, 64, 64, 64, 64, 64, 64, 0, 0, 0, 0.125, 0, None)
+    assert rc == -1 and b"exceeds" in lib.cfhip_last_error()
+    with pytest.raises(RuntimeError, match="exceeds"):
+        _lib.check(rc, "attn_fwd")
+
+
+def test_workspace_queries():
+    lib = _lib.load()
+    assert lib.cfhip_colsum_workspace(12608, 768) >= 768 * 4
+    assert lib.cfhip_layernorm_bwd_workspace(12608, 768) >= 2 * 768 * 4
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libcfhip.so"))
+    with pytest.raises(RuntimeError, match="no fallback"):
+        _lib.load()
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+
+    a = torch.zeros(8, 8, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        cflearn_amd.ops.gemm(a, a)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "carefree-learn_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "vit_oracle" not in src and "refharness" not in src and "import oracle" not in src, f

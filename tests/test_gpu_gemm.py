@@ -1,0 +1,159 @@
+"""K1/K2 GEMM kernel vs a plain fp32 matmul of the SAME bf16-rounded operands (so the only
+differences are accumulation order and the final bf16 rounding of the output).
+
+Tolerances: bf16 output -> half an ulp = 2^-9 relative per element, rel-L2 bound 4e-3;
+fp32 output -> accumulation order only, rel-L2 bound 2e-5."""
+import pytest
+import torch
+
+from helpers import assert_close, bf16_round
+
+pytestmark = pytest.mark.gpu
+
+import cflearn_amd as C  # noqa: E402
+from cflearn_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def _mk(rows, cols, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(rows, cols, generator=g) * scale).to(torch.bfloat16)
+
+
+def _ref(a, b, a_trans, b_trans):
+    A = a.float().t() if a_trans else a.float()
+    B = b.float() if b_trans else b.float().t()
+    return A.double() @ B.double()
+
+
+SHAPES = [
+    # M, N, K
+    (128, 128, 64), (256, 384, 128), (64, 128, 64), (197, 768, 768), (1576, 2304, 768),
+    (130, 136, 72), (100, 1000, 768), (4, 8, 8), (333, 260, 200), (1024, 768, 3072),
+]
+
+
+@pytest.mark.parametrize("m,n,k", SHAPES)
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_layouts(m, n, k, layout):
+    a_trans = layout == "tn"
+    b_trans = layout in ("nn", "tn")
+    if a_trans and m % 8:
+        pytest.skip("m-major A needs M % 8 == 0 on the MFMA path (covered by test_generic_path)")
+    if b_trans and n % 8:
+        pytest.skip("n-major B needs N % 8 == 0 on the MFMA path")
+    a = _mk(k, m, 1) if a_trans else _mk(m, k, 1)
+    b = _mk(k, n, 2) if b_trans else _mk(n, k, 2)
+    want = _ref(a, b, a_trans, b_trans)
+    got32 = ops.gemm(a.to(DEV), b.to(DEV), a_trans=a_trans, b_trans=b_trans, out_dtype=torch.float32)
+    assert_close(got32, want, 2e-5, f"{layout} f32 {m}x{n}x{k}")
+    got16 = ops.gemm(a.to(DEV), b.to(DEV), a_trans=a_trans, b_trans=b_trans)
+    assert got16.dtype == torch.bfloat16
+    assert_close(got16, want, 4e-3, f"{layout} bf16 {m}x{n}x{k}")
+
+
+def test_asymmetric_identity_detects_transposes():
+    """A = I with an asymmetric B: a swapped row/col C-write cannot pass (guide rule G9)."""
+    n = 128
+    eye = torch.eye(n).to(torch.bfloat16)
+    b = (torch.arange(n * n).reshape(n, n) % 251).float().sub(125).div(16).to(torch.bfloat16)
+    got = ops.gemm(eye.to(DEV), b.to(DEV), out_dtype=torch.float32)  # C = I B^T = B^T
+    assert torch.equal(got.cpu(), b.float().t())
+    got = ops.gemm(eye.to(DEV), b.to(DEV), b_trans=True, out_dtype=torch.float32)  # C = I B
+    assert torch.equal(got.cpu(), b.float())
+    got = ops.gemm(b.to(DEV), eye.to(DEV), a_trans=True, b_trans=True, out_dtype=torch.float32)  # C = B^T I
+    assert torch.equal(got.cpu(), b.float().t())
+
+
+def test_epilogues():
+    m, n, k = 300, 256, 192
+    a, w = _mk(m, k, 3).to(DEV), _mk(n, k, 4, 0.1).to(DEV)
+    bias = torch.randn(n, generator=torch.Generator().manual_seed(5)).to(DEV)
+    res = _mk(m, n, 6).to(DEV)
+    base = (a.float() @ w.float().t()) + bias
+    got = ops.gemm(a, w, bias=bias)
+    assert_close(got, base, 4e-3, "bias")
+    got = ops.gemm(a, w, bias=bias, epilogue=ops.EPI_RESIDUAL, aux_in=res)
+    assert_close(got, base + res.float(), 4e-3, "residual")
+    pre = torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+    got = ops.gemm(a, w, bias=bias, epilogue=ops.EPI_GELU, aux_out=pre)
+    assert_close(pre, base, 4e-3, "pre-activation")
+    assert_close(got, torch.nn.functional.gelu(pre.float()), 4e-3, "gelu(pre)")
+    # dGELU epilogue: C = (dY W) * gelu'(pre)
+    dy = _mk(m, n, 7).to(DEV)
+    w2 = _mk(n, k, 8, 0.1).to(DEV)  # [Kd = n, N = k] as a b_trans operand
+    prek = _mk(m, k, 9).to(DEV)
+    x = prek.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).backward(torch.ones_like(x))
+    want = (dy.float() @ w2.float()) * x.grad
+    got = ops.gemm(dy, w2, b_trans=True, epilogue=ops.EPI_DGELU, aux_in=prek)
+    assert_close(got, want, 5e-3, "dgelu")
+
+
+def test_split_k_and_accumulate():
+    kd, n, k = 4000, 256, 384  # dW[n, k] = dY[kd, n]^T X[kd, k]
+    dy, x = _mk(kd, n, 10).to(DEV), _mk(kd, k, 11).to(DEV)
+    want = dy.float().t().double() @ x.float().double()
+    for split in (1, 2, 7, 16):
+        got = ops.gemm(dy, x, a_trans=True, b_trans=True, out_dtype=torch.float32, split_k=split)
+        assert_close(got, want, 2e-5, f"split_k={split}")
+    out = torch.full((n, k), 2.0, dtype=torch.float32, device=DEV)
+    ops.gemm(dy, x, a_trans=True, b_trans=True, out=out, accumulate=True, split_k=5)
+    assert_close(out, want + 2.0, 2e-5, "accumulate split")
+    out = torch.full((n, k), -1.0, dtype=torch.float32, device=DEV)
+    ops.gemm(dy, x, a_trans=True, b_trans=True, out=out, accumulate=True)
+    assert_close(out, want - 1.0, 2e-5, "accumulate direct")
+
+
+def test_k_tail_zero_fill_not_neighbour_rows():
+    """K not a multiple of the 64-deep step: the tail must be zero-filled (buffer range check), not
+    read from the next row.  Poison everything outside the logical operand."""
+    m, n, k, ld = 64, 64, 72, 136
+    big_a = torch.full((m, ld), float("nan"), dtype=torch.bfloat16)
+    big_b = torch.full((n, ld), float("nan"), dtype=torch.bfloat16)
+    a, b = _mk(m, k, 12), _mk(n, k, 13)
+    big_a[:, :k], big_b[:, :k] = a, b
+    got = ops.gemm(big_a.to(DEV)[:, :k], big_b.to(DEV)[:, :k], out_dtype=torch.float32)
+    assert torch.isfinite(got).all()
+    assert_close(got, a.float() @ b.float().t(), 2e-5, "k-tail")
+
+
+def test_generic_path_odd_shapes():
+    """Shapes the MFMA path rejects (K, N not multiples of 8 / 4) run on the scalar kernel."""
+    for (m, n, k) in ((7, 3, 10), (33, 5, 17)):
+        a, b = _mk(m, k, 14), _mk(n, k, 15)
+        bias = torch.randn(n).to(DEV)
+        got = ops.gemm(a.to(DEV), b.to(DEV), bias=bias, out_dtype=torch.float32)
+        assert_close(got, a.float() @ b.float().t() + bias.cpu(), 1e-5, f"generic {m}x{n}x{k}")
+        xt, wt = _mk(k, m, 16), _mk(k, n, 17)
+        got = ops.gemm(xt.to(DEV), wt.to(DEV), a_trans=True, b_trans=True, out_dtype=torch.float32)
+        assert_close(got, xt.float().t() @ wt.float(), 1e-5, "generic tn")
+
+
+def test_linearity_at_full_size():
+    """Size-independent property at the ViT-B/16 bench shape (B=64: M = 12608):
+    gemm(a1 + a2, w) == gemm(a1, w) + gemm(a2, w) up to fp32 accumulation order, and against a
+    torch fp32 matmul on a random sample of rows."""
+    m, n, k = 12608, 3072, 768
+    g = torch.Generator(device=DEV).manual_seed(0)
+    # values on a coarse grid so that a1 + a2 is exactly representable in bf16
+    a1 = (torch.randint(-8, 9, (m, k), generator=g, device=DEV).float() / 8).to(torch.bfloat16)
+    a2 = (torch.randint(-8, 9, (m, k), generator=g, device=DEV).float() / 8).to(torch.bfloat16)
+    w = (torch.randn(n, k, generator=g, device=DEV) * 0.05).to(torch.bfloat16)
+    s = (a1.float() + a2.float()).to(torch.bfloat16)
+    y = ops.gemm(s, w, out_dtype=torch.float32)
+    y12 = ops.gemm(a1, w, out_dtype=torch.float32) + ops.gemm(a2, w, out_dtype=torch.float32)
+    assert_close(y, y12, 1e-5, "linearity")
+    rows = torch.randint(0, m, (257,), generator=torch.Generator().manual_seed(1)).to(DEV)
+    assert_close(y[rows], s[rows].float() @ w.float().t(), 2e-5, "row sample")
+
+
+def test_colsum():
+    for (m, n) in ((1000, 768), (12608, 2304), (5, 8), (77, 13)):
+        x = _mk(m, n, 20).to(DEV)
+        assert_close(ops.colsum(x), x.float().sum(0), 1e-5, f"colsum {m}x{n}")
+    out = torch.ones(768, device=DEV)
+    x = _mk(300, 768, 21).to(DEV)
+    ops.colsum(x, out=out, accumulate=True)
+    assert_close(out, x.float().sum(0) + 1, 1e-5, "colsum acc")

@@ -1,0 +1,175 @@
+"""Drop-in modules on the MI355X vs (a) the golden fixtures frozen from the reference's own
+modules and (b) the CPU oracle.  Weights are always COPIED from the fixture / oracle state_dict
+(never RNG-matched), as SURVEY §8a' prescribes.
+
+Tolerances (bf16 activations & GEMM operands, fp32 accumulate / stats / param grads):
+outputs rel-L2 <= 1e-2, gradients rel-L2 <= 3e-2, loss |rel| <= 3e-3 on the small perturbed model
+and <= 1e-3 on ViT-B/16 at init (the north-star bound)."""
+import math
+
+import pytest
+import torch
+
+import vit_oracle as O
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+import cflearn_amd as C  # noqa: E402
+
+DEV = "cuda"
+
+
+def _grads(module):
+    return {k: p.grad.detach().float().cpu() for k, p in module.named_parameters() if p.grad is not None}
+
+
+def test_linear_golden(golden):
+    g = golden("linear.pt")
+    m = C.Linear(96, 40).to(DEV)
+    m.load_state_dict(g["sd"])
+    x = g["x"].to(DEV).requires_grad_(True)
+    y = m(x)
+    assert y.dtype == torch.bfloat16
+    assert_close(y, g["y"], 1e-2, "linear y")
+    y.backward(g["gy"].to(DEV).to(torch.bfloat16))
+    assert_close(x.grad, g["gx"], 1.5e-2, "linear gx")
+    assert_close(m.linear.weight.grad, g["gw"], 1.5e-2, "linear gw")
+    assert_close(m.linear.bias.grad, g["gb"], 1e-2, "linear gb")
+    assert m.linear.weight.grad.dtype == torch.float32
+
+
+def test_layernorm_golden(golden):
+    g = golden("layernorm.pt")
+    m = C.NormFactory("layer").make(128).to(DEV)
+    assert m.eps == g["eps"]
+    with torch.no_grad():
+        m.weight.copy_(g["w"]); m.bias.copy_(g["b"])
+    x = g["x"].to(DEV).requires_grad_(True)
+    y = m(x)
+    assert_close(y, g["y"], 1e-2, "ln y")
+    y.backward(g["gy"].to(DEV).to(torch.bfloat16))
+    assert_close(x.grad, g["gx"], 2e-2, "ln gx")
+    assert_close(m.weight.grad, g["gw"], 1e-2, "ln gw")
+    assert_close(m.bias.grad, g["gb"], 1e-2, "ln gb")
+
+
+@pytest.mark.parametrize("tag", ["r_nomask", "r_mask"])
+def test_attention_golden(golden, tag):
+    """incl. the reference's 3-D mask layout quirk (attentions.py:246-253)."""
+    g = golden("attention.pt")
+    m = C.Attention(128, g["heads"], is_self_attention=True).to(DEV)
+    m.load_state_dict(g["sd"])
+    x = g["x"].to(DEV).requires_grad_(True)
+    mask = g["mask"].to(DEV) if tag == "r_mask" else None
+    out = m(x, x, x, mask=mask)
+    assert out.weights is None
+    assert_close(out.output, g[tag]["y"], 1.5e-2, "attention y")
+    out.output.backward(g[tag]["gy"].to(DEV).to(torch.bfloat16))
+    assert_close(x.grad, g[tag]["gx"], 3e-2, "attention gx")
+    for k, v in _grads(m).items():
+        assert_close(v, g[tag]["grads"][k], 3e-2, f"attention grad {k}")
+
+
+def test_feedforward_golden(golden):
+    g = golden("feedforward.pt")
+    m = C.FeedForward(128, 256, 0.0).to(DEV)
+    m.load_state_dict(g["sd"])
+    x = g["x"].to(DEV).requires_grad_(True)
+    y = m(x)
+    assert_close(y, g["y"], 1e-2, "ff y")
+    y.backward(g["gy"].to(DEV).to(torch.bfloat16))
+    assert_close(x.grad, g["gx"], 2e-2, "ff gx")
+    for k, v in _grads(m).items():
+        assert_close(v, g["grads"][k], 2e-2, f"ff grad {k}")
+
+
+def _small_vit(g):
+    cfg = dict(g["cfg"])
+    m = C.build_module("cv_clf", config=dict(in_channels=3, num_classes=g["num_classes"], img_size=cfg.pop("img_size"),
+                                             latent_dim=cfg["latent_dim"], encoder="vit", encoder_config=cfg))
+    m.load_state_dict(g["sd"])
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_vit_small_golden(golden, fused):
+    """head(ViTEncoder(x)) logits / CE loss / every parameter gradient vs the reference run."""
+    g = golden("vit_small.pt")
+    m = _small_vit(g)
+    for blk in m.encoder.encoder.mixing_blocks:
+        blk.use_fused = fused
+    logits = m(g["img"].to(DEV))["predictions"]
+    assert logits.dtype == torch.float32
+    assert_close(logits, g["logits"], 1e-2, "logits")
+    loss = torch.nn.functional.cross_entropy(logits, g["labels"].view(-1).to(DEV))
+    assert abs(loss.item() - g["loss"].item()) <= 3e-3 * abs(g["loss"].item())
+    loss.backward()
+    grads = _grads(m)
+    assert set(grads) == set(g["grads"])
+    worst = 0.0
+    for k, v in grads.items():
+        worst = max(worst, assert_close(v, g["grads"][k], 3e-2, f"grad {k}", abs_floor=2e-4))
+    print(f"fused={fused}: worst grad rel-L2 {worst:.3e}")
+
+
+def test_fused_equals_composed(golden):
+    g = golden("vit_small.pt")
+    outs = []
+    for fused in (True, False):
+        m = _small_vit(g)
+        for blk in m.encoder.encoder.mixing_blocks:
+            blk.use_fused = fused
+        logits = m(g["img"].to(DEV))["predictions"]
+        logits.sum().backward()
+        outs.append((logits.detach(), _grads(m)))
+    assert_close(outs[0][0], outs[1][0], 2e-3, "fused vs composed logits")
+    for k in outs[0][1]:
+        assert_close(outs[0][1][k], outs[1][1][k], 1e-2, f"fused vs composed {k}", abs_floor=1e-4)
+
+
+def test_hook_contract_and_lowrank():
+    """IBasicHook before/after_forward (LoRA contract, hijacks.py:33-49) and the low-rank Linear."""
+
+    class Hook(torch.nn.Module):
+        def before_forward(self, inp, index=None):
+            return inp * 2
+
+        def after_forward(self, inp, out):
+            return out + 1
+
+    torch.manual_seed(0)
+    m = C.HijackCustomLinear(64, 32, hook=Hook()).to(DEV)
+    assert m.kwargs == {} and m.args == (64, 32)
+    x = torch.randn(10, 64, device=DEV)
+    y = m(x)
+    want = torch.nn.functional.linear(x, m.linear.weight, m.linear.bias) + 1
+    assert_close(y, want, 1e-2, "hooked linear")
+    lr = C.Linear(64, 32, rank=8).to(DEV)
+    with torch.no_grad():
+        lr.w1.normal_(); lr.w2.normal_()
+    want = torch.nn.functional.linear(torch.nn.functional.linear(x, lr.w1), lr.w2, lr.b)
+    assert_close(lr(x), want, 1.5e-2, "low-rank linear")
+
+
+def test_vit_b16_loss_within_1e3_of_cpu_reference():
+    """North-star bound: ViT-B/16 224^2 logits / loss vs the fp32 CPU reference on the same inputs
+    and the same (reference-initialised) weights.  Loss within 1e-3 relative; logits are compared
+    in rel-L2 with the documented bf16 bound (the reference's own bf16-autocast run differs from its
+    fp32 run by 8e-3 on this metric)."""
+    torch.manual_seed(0)
+    m = C.vit_b16_classifier(num_classes=1000)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    img = torch.randn(2, 3, 224, 224, generator=g)
+    labels = torch.randint(0, 1000, (2, 1), generator=g)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    with torch.no_grad():
+        want = O.vit_classifier(img, sd, 12, 12)
+    want_loss = O.cross_entropy(want, labels).item()
+    m = m.to(DEV)
+    logits = m(img.to(DEV))["predictions"]
+    loss, _ = C.ops.softmax_xent(logits, labels.to(DEV), 1.0, want_grad=False)
+    got_loss = loss.item() / 2
+    assert abs(got_loss - want_loss) <= 1e-3 * abs(want_loss), (got_loss, want_loss)
+    assert_close(logits, want, 2e-2, "ViT-B/16 logits")

@@ -1,0 +1,132 @@
+"""LayerNorm + element-wise / glue kernels vs fp32 torch references and the CPU oracle."""
+import math
+
+import pytest
+import torch
+
+import vit_oracle as O
+from helpers import assert_close, bf16_round, max_abs
+
+pytestmark = pytest.mark.gpu
+
+from cflearn_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("m,d", [(12608, 768), (64, 768), (5, 128), (1000, 1024), (33, 2048), (17, 4), (300, 520)])
+def test_layernorm_fwd_bwd(m, d):
+    g = torch.Generator().manual_seed(m + d)
+    x = (torch.randn(m, d, generator=g) * 2 + 0.5).to(torch.bfloat16)
+    w = torch.randn(d, generator=g) * 0.2 + 1
+    b = torch.randn(d, generator=g) * 0.2
+    dy = torch.randn(m, d, generator=g).to(torch.bfloat16)
+    xf = x.float().requires_grad_(True)
+    wf, bf = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = O.layer_norm(xf, wf, bf, 1e-6)
+    y_ref.backward(dy.float())
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6)
+    assert_close(y, y_ref, 4e-3, "ln y")
+    assert_close(mean, x.float().mean(1), 1e-5, "mean", abs_floor=1e-6)
+    dx, dg, db = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd)
+    assert_close(dx, xf.grad, 5e-3, "ln dx")
+    assert_close(dg, wf.grad, 2e-4, "ln dgamma")
+    assert_close(db, bf.grad, 2e-4, "ln dbeta")
+    # fused residual-gradient add + accumulation into existing (adjacent) param grads
+    add = torch.randn(m, d, generator=g).to(torch.bfloat16)
+    pg = torch.ones(2 * d, device=DEV)
+    dx2, _, _ = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, dx_add=add.to(DEV),
+                                  dgamma=pg[:d], dbeta=pg[d:], accumulate=True)
+    assert_close(dx2, xf.grad + add.float(), 5e-3, "ln dx + add")
+    assert_close(pg[:d], wf.grad + 1, 2e-4, "dgamma acc")
+    assert_close(pg[d:], bf.grad + 1, 2e-4, "dbeta acc")
+
+
+def test_layernorm_strided_rows():
+    """head LN reads token 0 of every sample: row stride T*D."""
+    b, t, d = 16, 197, 768
+    x = torch.randn(b, t, d).to(torch.bfloat16).to(DEV)
+    w, bb = torch.ones(d, device=DEV), torch.zeros(d, device=DEV)
+    y, _, _ = ops.layernorm_fwd(x[:, 0], w, bb, 1e-6)
+    assert_close(y, O.layer_norm(x[:, 0].float().cpu(), w.cpu(), bb.cpu()), 4e-3, "strided ln")
+
+
+def test_casts_gelu_add_transpose():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1000003, generator=g) * 3
+    xb = ops.to_bf16(x.to(DEV))
+    assert torch.equal(xb.cpu(), x.to(torch.bfloat16))  # round-to-nearest-even, bit exact
+    assert torch.equal(ops.to_f32(xb).cpu(), x.to(torch.bfloat16).float())
+    v = (torch.randn(4099, 33, generator=g) * 2).to(torch.bfloat16)
+    assert_close(ops.gelu_fwd(v.to(DEV)), O.gelu_erf(v.float()), 4e-3, "gelu")
+    vf = v.float().requires_grad_(True)
+    dy = torch.randn(4099, 33, generator=g).to(torch.bfloat16)
+    O.gelu_erf(vf).backward(dy.float())
+    assert_close(ops.gelu_bwd(dy.to(DEV), v.to(DEV)), vf.grad, 4e-3, "gelu bwd")
+    assert_close(ops.add(v.to(DEV), dy.to(DEV)), v.float() + dy.float(), 4e-3, "add")
+    t = torch.randn(197, 130, generator=g).to(torch.bfloat16)
+    assert torch.equal(ops.transpose(t.to(DEV)).cpu(), t.t().contiguous())
+
+
+def test_im2row_and_patch_gemm_match_conv():
+    g = torch.Generator().manual_seed(1)
+    img = torch.randn(3, 3, 64, 64, generator=g)
+    w = torch.randn(32, 3, 16, 16, generator=g) * 0.05
+    bias = torch.randn(32, generator=g)
+    rows = ops.im2row(img.to(DEV), 16)
+    assert rows.shape == (3 * 16, 768)
+    want_rows = img.reshape(3, 3, 4, 16, 4, 16).permute(0, 2, 4, 1, 3, 5).reshape(48, 768)
+    assert torch.equal(rows.cpu(), want_rows.to(torch.bfloat16))
+    out = ops.gemm(rows, w.reshape(32, -1).to(torch.bfloat16).to(DEV), bias=bias.to(DEV), out_dtype=torch.float32)
+    conv = torch.nn.functional.conv2d(bf16_round(img), bf16_round(w), bias, stride=16)
+    assert_close(out, conv.flatten(2).transpose(1, 2).reshape(48, 32), 1e-4, "patch embed == conv")
+    rows_b = ops.im2row(img.to(torch.bfloat16).to(DEV), 16)
+    assert torch.equal(rows_b.cpu(), rows.cpu())
+
+
+def test_assemble_tokens():
+    b, np_, d = 5, 16, 128
+    g = torch.Generator().manual_seed(2)
+    patches = torch.randn(b * np_, d, generator=g).to(torch.bfloat16)
+    head, pos = torch.randn(d, generator=g), torch.randn((np_ + 1) * d, generator=g)
+    x0 = ops.assemble_tokens_fwd(patches.to(DEV), head.to(DEV), pos.to(DEV), b)
+    want = torch.cat([head.view(1, 1, d).expand(b, 1, d), patches.float().view(b, np_, d)], 1) + pos.view(1, np_ + 1, d)
+    assert_close(x0, want, 4e-3, "assemble fwd")
+    dx0 = torch.randn(b, np_ + 1, d, generator=g).to(torch.bfloat16)
+    dhead, dpos = torch.zeros(d, device=DEV), torch.zeros((np_ + 1) * d, device=DEV)
+    dp = ops.assemble_tokens_bwd(dx0.to(DEV), dhead, dpos, False)
+    assert torch.equal(dp.cpu(), dx0[:, 1:].reshape(b * np_, d))
+    assert_close(dpos, dx0.float().sum(0).reshape(-1), 1e-5, "dpos")
+    assert_close(dhead, dx0.float()[:, 0].sum(0), 1e-5, "dhead")
+
+
+def test_adam_matches_oracle():
+    n = 100003
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    for decoupled in (False, True):
+        p, m, v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        p16 = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+        q, mq, vq = p0.clone(), torch.zeros(n), torch.zeros(n)
+        for t in range(1, 5):
+            grad = torch.randn(n, generator=g)
+            ops.adam_step(p, (grad * 2).to(DEV), m, v, p16, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8,
+                          weight_decay=0.05, decoupled=decoupled, step=t, grad_scale=0.5)
+            O.adamw_step(q, grad, mq, vq, t, 1e-2, weight_decay=0.05, decoupled=decoupled)
+        assert max_abs(p, q) < 2e-6
+        assert torch.equal(p16.cpu(), p.cpu().to(torch.bfloat16))
+
+
+def test_sumsq_and_xent():
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1234567, generator=g)
+    got = ops.sumsq(x.to(DEV)).item()
+    assert abs(got - (x.double() ** 2).sum().item()) / got < 1e-5
+    logits = torch.randn(64, 1000, generator=g) * 3
+    labels = torch.randint(0, 1000, (64, 1), generator=g)
+    loss, dl = ops.softmax_xent(logits.to(DEV), labels.to(DEV), 1.0 / 64)
+    lf = logits.clone().requires_grad_(True)
+    ref = O.cross_entropy(lf, labels)
+    ref.backward()
+    assert abs(loss.item() / 64 - ref.item()) < 1e-5 * abs(ref.item()) + 1e-6
+    assert_close(dl, lf.grad, 1e-5, "dlogits")

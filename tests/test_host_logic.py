@@ -1,0 +1,127 @@
+"""Host-side logic that needs no GPU: registry semantics, state_dict compatibility with the
+reference (through the golden fixture keys), mask-layout quirk (bit-exact), arenas, split-K policy."""
+import pytest
+import torch
+
+import cflearn_amd as C
+import vit_oracle as O
+
+
+def test_registry_build_module_drops_unknown_kwargs():
+    @C.register_module("unit.dummy")
+    class Dummy(torch.nn.Module):
+        def __init__(self, a: int, b: int = 2):
+            super().__init__()
+            self.a, self.b = a, b
+
+    m = C.build_module("unit.dummy", config=dict(a=1, zzz=3))
+    assert (m.a, m.b) == (1, 2)
+    m = C.build_module("unit.dummy", config=dict(a=1), b=5)
+    assert m.b == 5
+    with pytest.raises(TypeError):
+        C.build_module("unit.dummy", config=dict(b=1))
+    with pytest.raises(KeyError):
+        C.build_module("unit.nope")
+    pm = C.PrefixModules("unit")
+    assert pm.has("dummy") and pm.get("dummy") is Dummy and "unit.dummy" in pm.all
+
+
+def test_reference_names_registered():
+    for name in ("attention.basic", "token_mixer.attention", "channel_mixer.ff", "encoders.vit", "cv_clf"):
+        assert name in C.module_dict
+
+
+def test_state_dict_keys_match_reference(golden):
+    g = golden("vit_small.pt")
+    cfg = dict(g["cfg"])
+    m = C.build_module("cv_clf", config=dict(in_channels=3, num_classes=g["num_classes"], img_size=cfg.pop("img_size"),
+                                             latent_dim=cfg["latent_dim"], encoder="vit", encoder_config=cfg))
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["sd"].keys())  # same names AND same registration order
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(g["sd"][k].shape), k
+    m.load_state_dict(g["sd"])  # reference checkpoint loads as is
+
+
+def test_vit_b16_parameter_count():
+    m = C.vit_b16_classifier()
+    assert sum(p.numel() for p in m.parameters()) == 86_567_656  # SURVEY §6 probe of the reference
+    assert len(m.state_dict()) == 152
+    att = m.encoder.encoder.mixing_blocks[0].token_mixing.net
+    assert att.num_heads == 12 and att.head_dim == 64 and tuple(att.in_w.shape) == (2304, 768)
+    assert m.encoder.encoder.mixing_blocks[0].token_norm.eps == 1.0e-6
+
+
+def test_attention_module_parameter_layouts():
+    a = C.Attention(128, 2, is_self_attention=True)
+    assert set(dict(a.named_parameters())) == {"in_w", "qkv_bias", "out_linear.linear.weight", "out_linear.linear.bias"}
+    a = C.Attention(128, 2, k_dim=64, v_dim=32)
+    assert {"q_w", "k_w", "v_w", "qkv_bias"} <= set(dict(a.named_parameters()))
+    a = C.Attention(128, 2)
+    assert {"q_w", "kv_w", "q_bias", "kv_bias"} <= set(dict(a.named_parameters()))
+    with pytest.raises(ValueError):
+        C.Attention(100, 3)
+
+
+def test_mask_quirk_is_bit_exact():
+    torch.manual_seed(0)
+    for b, h in ((3, 2), (4, 3), (2, 5)):
+        mask = torch.rand(b, 7, 9) < 0.4
+        keep = C.modules.expand_module_mask(mask, h)
+        want = O.expand_module_mask(mask, h)
+        assert keep.dtype == torch.uint8 and torch.equal(keep.bool(), want)
+        # and it is what the reference's repeat/view produces (attentions.py:246-249)
+        ref = (~mask).repeat(h, 1, 1).view(-1, h, 7, 9)
+        assert torch.equal(keep.bool(), ref)
+
+
+def test_unsupported_features_raise():
+    with pytest.raises(NotImplementedError):
+        C.Linear(8, 8, pruner_config={})
+    with pytest.raises(NotImplementedError):
+        C.Attention(128, 2, reduction_ratio=2)
+    with pytest.raises(NotImplementedError):
+        C.FeedForward(8, 16, 0.0, activation="geglu")
+    with pytest.raises(NotImplementedError):
+        C.Conv2d(3, 8, kernel_size=3)
+
+
+def test_param_arena_views_and_lazy_zero():
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    before = [p.detach().clone() for p in lin.parameters()]
+    arena = C.ParamArena(lin.parameters(), with_shadow=True)
+    for p, b, off in zip(lin.parameters(), before, arena.offsets):
+        assert torch.equal(p.detach(), b)
+        assert off % 8 == 0
+        assert p.data_ptr() == arena.flat_p.data_ptr() + 4 * off
+        assert p.grad.data_ptr() == arena.flat_g.data_ptr() + 4 * off
+        assert torch.equal(p._cfhip_shadow.float(), b.to(torch.bfloat16).float())
+    # autograd accumulates in place into the arena views
+    arena.zero_grad()
+    lin(torch.randn(4, 5)).sum().backward()
+    g0 = arena.flat_g.clone()
+    assert g0.abs().sum() > 0
+    # lazy zeroing: nothing written -> finalize zeroes the stale values
+    arena.zero_grad(lazy=True)
+    assert arena.flat_g.abs().sum() > 0
+    arena.finalize_grads()
+    assert arena.flat_g.abs().sum() == 0
+
+
+def test_fused_adam_is_gpu_only():
+    lin = torch.nn.Linear(4, 4)
+    opt = C.FusedAdam(lin.parameters(), lr=1e-3)
+    lin(torch.randn(2, 4)).sum().backward()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        opt.step()
+
+
+def test_split_k_policy():
+    from cflearn_amd.ops import pick_split_k
+
+    assert pick_split_k(12608, 3072, 768) == 1           # forward GEMM: plenty of tiles
+    assert pick_split_k(768, 768, 12608) >= 8            # dW of a 768x768 layer: 36 tiles only
+    s = pick_split_k(2304, 768, 12608)
+    assert 2 <= s <= 8
+    assert pick_split_k(1000, 768, 64) == 1
