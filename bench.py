@@ -103,7 +103,7 @@ def cpu_baseline(batch: int, steps: int):
 
     import cflearn_amd as C
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)  # more threads than this only adds OpenMP overhead here
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = C.vit_b16_classifier(1000)
@@ -131,6 +131,14 @@ def cpu_baseline(batch: int, steps: int):
                 ms_per_step=round(dt / steps * 1e3, 1))
 
 
+_T0 = time.perf_counter()
+
+
+def note(msg: str) -> None:
+    """progress line on stderr (stdout carries only the JSON result)"""
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,7 +152,12 @@ def main() -> None:
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--gemm-reps", type=int, default=10)
     ap.add_argument("--bucket-mb", type=int, default=64)
+    ap.add_argument("--watchdog", type=int, default=0, help="dump all Python stacks every N seconds")
     args = ap.parse_args()
+    if args.watchdog > 0:
+        import faulthandler
+
+        faulthandler.dump_traceback_later(args.watchdog, repeat=True, file=sys.stderr)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -176,12 +189,15 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    note(f"model + arena ready on {dev}, launch={'graph' if ts.use_graph else 'eager'}")
     first_loss = None
     for i in range(args.warmup):
         loss = ts.step(img, labels)
         if i == 0:
             first_loss = loss.item() / args.batch
+            note(f"first step done, loss {first_loss:.4f}")
     sync()
+    note("warm-up done, timing")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = ts.step(img, labels)
@@ -192,6 +208,7 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
     last_loss = loss.item() / args.batch
+    note(f"timed region: {dt / args.steps * 1e3:.3f} ms/step")
     samples_per_s = world * args.batch * args.steps / dt
 
     result = {
@@ -224,6 +241,7 @@ def main() -> None:
     if rank == 0 and not args.no_roofline:
         flops, tsec, rows = time_gemms(args.batch, args.gemm_reps)
         achieved = flops / tsec / 1e12
+        note(f"GEMM roofline pass: {achieved:.1f} TFLOP/s over {tsec * 1e3:.2f} ms of GEMM per step")
         result["roofline"] = {
             "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
@@ -234,7 +252,9 @@ def main() -> None:
     if distributed:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        note("cpu baseline (oracle on the host cores) ...")
         result["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
+        note("cpu baseline done")
     if rank == 0:
         print(json.dumps(result))
     if distributed:

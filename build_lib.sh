@@ -6,7 +6,7 @@ OUT=../libcfhip.so
 mkdir -p ../_build
 pids=()
 for f in errors gemm attn norm elementwise; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c $f.hip -o ../_build/$f.o &
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -c $f.hip -o ../_build/$f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done

@@ -18,6 +18,7 @@ _P = c_void_p
 SIGNATURES = {
     "cfhip_version": (c_int, []),
     "cfhip_last_error": (c_char_p, []),
+    "cfhip_set_option": (c_int, [c_char_p, c_int]),
     "cfhip_gemm_bf16": (
         c_int,
         [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int,
@@ -26,12 +27,12 @@ SIGNATURES = {
     "cfhip_colsum_workspace": (c_size_t, [c_int, c_int]),
     "cfhip_colsum_bf16": (c_int, [_P, _P, c_int, c_int, c_int64, c_int, _P, c_size_t, _P]),
     "cfhip_layernorm_fwd": (
-        c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int64, c_int64, c_float, _P]
+        c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int64, c_int64, c_float, _P]
     ),
     "cfhip_layernorm_bwd_workspace": (c_size_t, [c_int, c_int]),
     "cfhip_layernorm_bwd": (
         c_int,
-        [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int64, c_int64, c_int64, c_int, _P,
+        [_P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int64, c_int64, c_int64, c_int, _P,
          c_size_t, _P],
     ),
     "cfhip_attn_fwd": (
@@ -45,7 +46,7 @@ SIGNATURES = {
          c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, _P],
     ),
     "cfhip_im2row": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "cfhip_assemble_tokens_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "cfhip_assemble_tokens_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "cfhip_assemble_tokens_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "cfhip_cast_f32_to_bf16": (c_int, [_P, _P, c_int64, _P]),
     "cfhip_cast_bf16_to_f32": (c_int, [_P, _P, c_int64, _P]),

@@ -18,15 +18,11 @@
 // ends up with 4 CONSECUTIVE output columns of one row: 8-byte bf16 / 16-byte f32 stores.
 // Workgroup ids are remapped so that each XCD (private L2) owns a contiguous range of tiles.
 #include "common.h"
+#include <string.h>
 
 namespace {
 
-constexpr int BM = 128;
-constexpr int BN = 128;
-constexpr int BK = 64;
-constexpr int NTHREADS = 256;
-constexpr int TILE_BYTES = 128 * 64 * 2;  // one operand tile, either orientation
-constexpr unsigned OOB = 0x80000000u;     // any offset >= num_records reads as zero
+constexpr unsigned OOB = 0x80000000u;  // any offset >= num_records reads as zero
 
 struct GemmParams {
   const bf16_t* A;
@@ -41,6 +37,24 @@ struct GemmParams {
   int k_chunk;   // K range per z-slice (multiple of BK), == K rounded up when no split
   float* slabs;  // split-K partials [z][M][N] or nullptr
   int tiles_m, tiles_n;
+  int ablate;  // benchmarking only: bit0 skip in-loop DMA, bit1 skip MFMA/LDS reads, bit2 skip stores
+};
+
+// Tile configuration.  BM x BN x 64 workgroup tile, WM x WN waves (each a (BM/WM) x (BN/WN) sub-tile of
+// 16x16 MFMA tiles), NSTAGE-deep LDS ring (prefetch distance NSTAGE-1 K-steps).
+template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_, int BK_>
+struct Cfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_, BK = BK_;
+  static constexpr int NW = WM * WN, NT = NW * 64;
+  static constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = STAGE_BYTES * NSTAGE;
+  static constexpr int A_INSTR = A_BYTES / 1024 / NW, B_INSTR = B_BYTES / 1024 / NW;  // LDS-DMA instr / wave / K-step
+  static constexpr int LPS = A_INSTR + B_INSTR;                        // "loads per stage" for vmcnt
+  static constexpr int WGS_PER_CU = (160 * 1024 / LDS_BYTES) > (16 / NW) ? (16 / NW) : (160 * 1024 / LDS_BYTES);
+  static constexpr int WAVES_PER_SIMD = WGS_PER_CU * NW / 4 < 1 ? 1 : WGS_PER_CU * NW / 4;
+  static_assert(BK == 32 || BK == 64, "K-step must be 32 or 64");
+  static_assert(A_BYTES % (1024 * NW) == 0 && B_BYTES % (1024 * NW) == 0, "tiles must split evenly over the waves");
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long bytes) {
@@ -49,29 +63,48 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, lo
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-// Per-lane staging plan for one operand tile: 4 LDS-DMA instructions per wave per K-step.
+// Per-lane staging plan for one operand tile (R rows or columns): NI LDS-DMA instructions per wave
+// per K-step, each moving 1 KiB (64 lanes x 16 B) into a lane-linear LDS image.
+template <int NI>
 struct StagePlan {
-  unsigned voff[4];  // byte offset from the tile base at k-step 0 (OOB when statically invalid)
-  unsigned kpos[4];  // k-major only: k index (elements) of this lane's 16-B chunk inside a K-step
+  unsigned voff[NI];  // byte offset from the tile base at k-step 0 (OOB when statically invalid)
+  unsigned kpos[NI];  // k index (elements) this lane's 16 bytes start at, inside a K-step
 };
 
-template <bool TRANS>
-__device__ __forceinline__ StagePlan make_plan(int wave, int lane, long ld, int extent_valid) {
-  StagePlan p;
+// 16-byte slot swizzle of a k-major tile row (row pitch BK*2 bytes): conflict-free ds_read_b128
+template <int BK>
+__device__ __forceinline__ int kswz(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+
+// 32-byte chunk swizzle key of k-row `krow` of an m-major tile with R columns: the 8 k-rows a
+// half-wave touches in one ds_read_b64_tr_b16 must land on distinct chunks modulo the 256-B bank
+// row.  R >= 128 (row pitch >= 256 B): 8 distinct keys; R == 64 (pitch 128 B): even / odd rows are
+// already on different bank halves, 4 keys suffice.  mkey(krow) == mkey(krow + 4) for krow % 8 < 4.
+template <int R>
+__device__ __forceinline__ int mkey(int krow) {
+  return R >= 128 ? ((krow & 3) | (((krow >> 3) & 1) << 2)) : (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1));
+}
+
+template <bool TRANS, int R, int NI, int BK>
+__device__ __forceinline__ StagePlan<NI> make_plan(int wave, int lane, long ld, int extent_valid) {
+  StagePlan<NI> p;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NI; ++j) {
+    const int inst = wave * NI + j;
     if (!TRANS) {
-      // tile [128 rows][64 k]: one instruction = 8 rows x 128 B
-      const int row = (wave * 4 + j) * 8 + (lane >> 3);
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      // k-major tile [R rows][BK k]: SPR 16-B slots per row; slot s of row r holds source chunk
+      // s ^ kswz(r)
+      constexpr int SPR = BK / 8;
+      const int row = inst * (64 / SPR) + lane / SPR;
+      const int chunk = (lane % SPR) ^ kswz<BK>(row);
       p.kpos[j] = chunk * 8;
       p.voff[j] = (row < extent_valid) ? (unsigned)(row * ld * 2 + chunk * 16) : OOB;
     } else {
-      // tile [64 k][128 cols]: one instruction = 4 k-rows x 256 B
-      const int krow = (wave * 4 + j) * 4 + (lane >> 4);
-      const int s = lane & 15;
-      const int key = (krow & 3) | (((krow >> 3) & 1) << 2);
-      const int col = (((s >> 1) ^ key) << 4) + ((s & 1) << 3);
+      // m-major tile [BK k][R cols]: one k-row = R/8 slots of 16 B; 32-B chunk c of k-row kr holds
+      // source chunk c ^ mkey(kr)
+      constexpr int SLOTS = R / 8;
+      const int krow = inst * (64 / SLOTS) + lane / SLOTS;
+      const int s = lane % SLOTS;
+      const int col = (((s >> 1) ^ mkey<R>(krow)) << 4) + ((s & 1) << 3);
       p.kpos[j] = krow;
       p.voff[j] = (col < extent_valid) ? (unsigned)(krow * ld * 2 + col * 2) : OOB;
     }
@@ -79,80 +112,82 @@ __device__ __forceinline__ StagePlan make_plan(int wave, int lane, long ld, int 
   return p;
 }
 
-template <bool TRANS>
+template <bool TRANS, int NI>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int wave,
-                                           const StagePlan& p, long ld, int k0, int klen) {
+                                           const StagePlan<NI>& p, long ld, int k0, int klen) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    unsigned off;
-    if (!TRANS) {
-      off = p.voff[j] + (unsigned)(k0 * 2);
-      off = ((int)(k0 + p.kpos[j]) < klen && p.voff[j] != OOB) ? off : OOB;
-    } else {
-      off = p.voff[j] + (unsigned)((long)k0 * ld * 2);
-      off = ((int)(k0 + p.kpos[j]) < klen && p.voff[j] != OOB) ? off : OOB;
-    }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + (wave * 4 + j) * 1024), 16, off,
-                                             0, 0, 0);
+  for (int j = 0; j < NI; ++j) {
+    unsigned off = TRANS ? p.voff[j] + (unsigned)((long)k0 * ld * 2) : p.voff[j] + (unsigned)(k0 * 2);
+    off = ((int)(k0 + p.kpos[j]) < klen && p.voff[j] != OOB) ? off : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + (wave * NI + j) * 1024), 16, off, 0, 0, 0);
   }
 }
 
 // Fragment of a k-major tile: rows r0..r0+15, k-substep ks (32 deep).  lane (i = l&15, g = l>>4)
 // gets the 8 bf16 at [r0 + i][ks*32 + g*8 ..].
+template <int BK>
 __device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int r0, int ks, int i, int g) {
   const int row = r0 + i;
-  const int slot = (ks * 4 + g) ^ ((row >> 1) & 7);
-  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + slot * 16);
+  const int slot = (ks * 4 + g) ^ kswz<BK>(row);
+  return *reinterpret_cast<const bf16x8*>(tile + row * (BK * 2) + slot * 16);
 }
 
-// Fragment of an m-major tile ([64 k][128 cols]): columns c0..c0+15, k-substep ks.  Two hardware
+// Fragment of an m-major tile ([64 k][R cols]): columns c0..c0+15, k-substep ks.  Two hardware
 // transpose reads; within a 16-lane group, lane s supplies the address of k-row (s>>2), columns
 // 4*(s&3).. and receives column (s) of the 4 rows.
+template <int R>
 __device__ __forceinline__ bf16x8 frag_mmajor(const char* tile, int c0, int ks, int lane) {
   const int g = lane >> 4;
   const int j = (lane & 15) >> 2;
   const int q = lane & 3;
-  const int krow = ks * 32 + g * 8 + j;
-  const int key = (krow & 3) | (((krow >> 3) & 1) << 2);
-  const char* p = tile + krow * 256 + ((((c0 >> 4) ^ key)) << 5) + q * 8;
+  const int krow = ks * 32 + g * 8 + j;  // mkey<R>(krow) == mkey<R>(krow + 4)
+  const char* p = tile + krow * (R * 2) + (((c0 >> 4) ^ mkey<R>(krow)) << 5) + q * 8;
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (__attribute__((address_space(3))) s16x4*)LDS_PTR(p));
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4*)LDS_PTR(p + 4 * 256));
+      (__attribute__((address_space(3))) s16x4*)LDS_PTR(p + 4 * (R * 2)));
   bf16x8 r;
   r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
   r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
   return r;
 }
 
-template <bool AT, bool BT>
+template <bool AT, bool BT, class C>
 __device__ __forceinline__ void compute_tile(const char* a_tile, const char* b_tile, int wm, int wn,
-                                             int lane, f32x4 (&acc)[4][4]) {
+                                             int lane, f32x4 (&acc)[C::FM][C::FN]) {
   const int i = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    bf16x8 af[4], bfr[4];
+  for (int ks = 0; ks < C::BK / 32; ++ks) {
+    bf16x8 af[C::FM], bfr[C::FN];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      af[t] = AT ? frag_mmajor(a_tile, wm * 64 + t * 16, ks, lane)
-                 : frag_kmajor(a_tile, wm * 64 + t * 16, ks, i, g);
-      bfr[t] = BT ? frag_mmajor(b_tile, wn * 64 + t * 16, ks, lane)
-                  : frag_kmajor(b_tile, wn * 64 + t * 16, ks, i, g);
-    }
+    for (int t = 0; t < C::FM; ++t)
+      af[t] = AT ? frag_mmajor<C::BM>(a_tile, wm * (C::FM * 16) + t * 16, ks, lane)
+                 : frag_kmajor<C::BK>(a_tile, wm * (C::FM * 16) + t * 16, ks, i, g);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int t = 0; t < C::FN; ++t)
+      bfr[t] = BT ? frag_mmajor<C::BN>(b_tile, wn * (C::FN * 16) + t * 16, ks, lane)
+                  : frag_kmajor<C::BK>(b_tile, wn * (C::FN * 16) + t * 16, ks, i, g);
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+    for (int mi = 0; mi < C::FM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::FN; ++ni)
         // swapped operands: D[n][m] -> lane holds row m = l&15, cols n = 4*(l>>4) + 0..3
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
   }
 }
 
-// EPI is a template parameter so that each instantiation carries exactly one epilogue (the erf
-// code is large; a runtime switch multiplied it by the 16 unrolled output tiles).
-template <bool AT, bool BT, int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+#define CFHIP_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+// K loop = NSTAGE-deep LDS ring fed by LDS-DMA.  The DMA of K-step t + NSTAGE - 1 is issued right
+// after the barrier of step t and stays in flight ACROSS the following barriers: waits are counted
+// (`s_waitcnt vmcnt(N)` with N = loads of the younger stages), the barrier is the raw s_barrier
+// (a `__syncthreads()` would drain vmcnt to 0).  One barrier per K-step:
+//   RAW: a wave passes barrier(t) only after its own DMA for step t has landed  -> all of step t is in LDS;
+//   WAR: the DMA issued after barrier(t) overwrites the buffer read in step t-1 -> every wave is past it.
+template <bool AT, bool BT, int EPI, class C>
+__global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD)
+void gemm_bf16_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // XCD-aware, bijective workgroup remap: XCD x (= bid % 8) owns a contiguous tile range.
   const int nwg = gridDim.x;
@@ -162,7 +197,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
   const int tile_m = wg / p.tiles_n;
   const int tile_n = wg - tile_m * p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
   const int z = blockIdx.y;
   const int kb = z * p.k_chunk;
   const int klen = min(p.K - kb, p.k_chunk);
@@ -170,7 +205,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / C::WN, wn = wave % C::WN;
 
   // buffer descriptors relative to this tile's origin (small 32-bit offsets, range-checked)
   const int rows_a = p.M - m0, rows_b = p.N - n0;
@@ -180,86 +215,129 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
   const long b_bytes = BT ? ((long)(klen - 1) * p.ldb + rows_b) * 2 : ((long)(rows_b - 1) * p.ldb + klen) * 2;
   const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(a_base, a_bytes);
   const __amdgpu_buffer_rsrc_t b_rsrc = make_rsrc(b_base, b_bytes);
-  const StagePlan pa = make_plan<AT>(wave, lane, p.lda, rows_a);
-  const StagePlan pb = make_plan<BT>(wave, lane, p.ldb, rows_b);
+  const StagePlan<C::A_INSTR> pa = make_plan<AT, C::BM, C::A_INSTR, C::BK>(wave, lane, p.lda, rows_a);
+  const StagePlan<C::B_INSTR> pb = make_plan<BT, C::BN, C::B_INSTR, C::BK>(wave, lane, p.ldb, rows_b);
 
-  char* a0 = smem;
-  char* b0 = smem + TILE_BYTES;
-  char* a1 = smem + 2 * TILE_BYTES;
-  char* b1 = smem + 3 * TILE_BYTES;
-
-  f32x4 acc[4][4];
+  f32x4 acc[C::FM][C::FN];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < C::FM; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ni = 0; ni < C::FN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  constexpr int BK = C::BK;
   const int nk = (klen + BK - 1) / BK;
-  if (nk > 0) {
-    stage_tile<AT>(a_rsrc, a0, wave, pa, p.lda, 0, klen);
-    stage_tile<BT>(b_rsrc, b0, wave, pb, p.ldb, 0, klen);
+  constexpr int D = C::NSTAGE - 1;  // prefetch distance
+#pragma unroll
+  for (int s = 0; s < D; ++s) {
+    if (s < nk) {
+      char* st = smem + s * C::STAGE_BYTES;
+      stage_tile<AT>(a_rsrc, st, wave, pa, p.lda, s * BK, klen);
+      stage_tile<BT>(b_rsrc, st + C::A_BYTES, wave, pb, p.ldb, s * BK, klen);
+    }
   }
-  __syncthreads();
-  for (int t = 0; t < nk; t += 2) {
-    if (t + 1 < nk) {
-      stage_tile<AT>(a_rsrc, a1, wave, pa, p.lda, (t + 1) * BK, klen);
-      stage_tile<BT>(b_rsrc, b1, wave, pb, p.ldb, (t + 1) * BK, klen);
+  int rd = 0, wr = D % C::NSTAGE;  // ring slots of step t and of step t + D
+  for (int t = 0; t < nk; ++t) {
+    const int younger = min(D - 1, nk - 1 - t);  // stages allowed to stay in flight
+    if (D >= 3 && younger >= 2) CFHIP_WAIT_VMCNT(2 * C::LPS);
+    else if (D >= 2 && younger == 1) CFHIP_WAIT_VMCNT(1 * C::LPS);
+    else CFHIP_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    if (t + D < nk && !(p.ablate & 1)) {
+      char* st = smem + wr * C::STAGE_BYTES;
+      stage_tile<AT>(a_rsrc, st, wave, pa, p.lda, (t + D) * BK, klen);
+      stage_tile<BT>(b_rsrc, st + C::A_BYTES, wave, pb, p.ldb, (t + D) * BK, klen);
     }
-    compute_tile<AT, BT>(a0, b0, wm, wn, lane, acc);
-    __syncthreads();
-    if (t + 1 < nk) {
-      if (t + 2 < nk) {
-        stage_tile<AT>(a_rsrc, a0, wave, pa, p.lda, (t + 2) * BK, klen);
-        stage_tile<BT>(b_rsrc, b0, wave, pb, p.ldb, (t + 2) * BK, klen);
-      }
-      compute_tile<AT, BT>(a1, b1, wm, wn, lane, acc);
-      __syncthreads();
-    }
+    const char* cur = smem + rd * C::STAGE_BYTES;
+    if (!(p.ablate & 2)) compute_tile<AT, BT, C>(cur, cur + C::A_BYTES, wm, wn, lane, acc);
+    rd = rd + 1 == C::NSTAGE ? 0 : rd + 1;
+    wr = wr + 1 == C::NSTAGE ? 0 : wr + 1;
   }
 
-  // ---- epilogue: lane owns row (l&15), 4 consecutive columns 4*(l>>4).. of each 16x16 tile ----
+  // ---- epilogue ----------------------------------------------------------------------------------
+  // The MFMA result layout (lane = row l&15, 4 consecutive columns per 16x16 tile) would give 8-byte
+  // stores scattered over 16 rows per instruction (measured: 1.8 TB/s, 40 % of the kernel).  Instead
+  // every wave transposes its sub-tile through a private LDS strip, 16 rows at a time, so that a
+  // lane ends up with 8 CONSECUTIVE columns of one row: residual / pre-activation traffic becomes
+  // 16-byte coalesced loads and every store instruction writes whole 128-byte row segments.
+  if (p.ablate & 4) return;
+  __syncthreads();  // all waves are done reading the ring buffers (no DMA in flight any more)
+  constexpr int WCOLS = C::FN * 16;           // columns of the wave's sub-tile
+  constexpr int SW = WCOLS + 4;               // padded LDS row stride (floats): conflict-free b128 writes
+  constexpr int LPR = WCOLS / 8;              // lanes per row when every lane takes 8 columns
+  constexpr int RPP = 64 / LPR;               // rows covered by one pass of the wave
+  float* stg = reinterpret_cast<float*>(smem) + wave * (16 * SW);
   const int i = lane & 15, g = lane >> 4;
+  const int rr = lane / LPR, cc = (lane % LPR) * 8;
   const bool to_slab = p.slabs != nullptr;
+  const int col = n0 + wn * WCOLS + cc;
+  const bool c_lo = col < p.N, c_hi = col + 4 < p.N;  // N % 4 == 0 on this path
+  f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias != nullptr && !to_slab) {
+    if (c_lo) b_lo = *reinterpret_cast<const f32x4*>(p.bias + col);
+    if (c_hi) b_hi = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+  }
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int row = m0 + wm * 64 + mi * 16 + i;
-    if (row >= p.M) continue;
+  for (int mi = 0; mi < C::FM; ++mi) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int col = n0 + wn * 64 + ni * 16 + g * 4;
-      if (col >= p.N) continue;  // N % 4 == 0 is required by the fast path
-      f32x4 v = acc[mi][ni];
+    for (int ni = 0; ni < C::FN; ++ni)
+      *reinterpret_cast<f32x4*>(stg + i * SW + ni * 16 + g * 4) = acc[mi][ni];
+#pragma unroll
+    for (int ps = 0; ps < 16 / RPP; ++ps) {
+      const int r = ps * RPP + rr;
+      f32x4 lo = *reinterpret_cast<const f32x4*>(stg + r * SW + cc);
+      f32x4 hi = *reinterpret_cast<const f32x4*>(stg + r * SW + cc + 4);
+      const int row = m0 + wm * (C::FM * 16) + mi * 16 + r;
+      if (row >= p.M || !c_lo) continue;
       if (to_slab) {
         float* dst = p.slabs + ((long)z * p.M + row) * p.N + col;
-        *reinterpret_cast<f32x4*>(dst) = v;
+        *reinterpret_cast<f32x4*>(dst) = lo;
+        if (c_hi) *reinterpret_cast<f32x4*>(dst + 4) = hi;
         continue;
       }
-      if (p.bias != nullptr) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + col);
-        v += bv;
-      }
+      lo += b_lo;
+      hi += b_hi;
       const long off = (long)row * p.ldc + col;
       if (EPI == CFHIP_EPI_GELU) {
-        const unsigned w0 = pack_bf16x2(v[0], v[1]), w1 = pack_bf16x2(v[2], v[3]);
-        if (p.aux_out != nullptr) *reinterpret_cast<u32x2*>(p.aux_out + off) = u32x2{w0, w1};
         // GELU of the bf16-rounded pre-activation (what the saved tensor holds for backward)
-        v[0] = gelu_erf_f(bf16lo(w0)); v[1] = gelu_erf_f(bf16hi(w0));
-        v[2] = gelu_erf_f(bf16lo(w1)); v[3] = gelu_erf_f(bf16hi(w1));
-      } else if (EPI == CFHIP_EPI_RESIDUAL) {
-        const u32x2 r = *reinterpret_cast<const u32x2*>(p.aux_in + off);
-        v[0] += bf16lo(r[0]); v[1] += bf16hi(r[0]); v[2] += bf16lo(r[1]); v[3] += bf16hi(r[1]);
-      } else if (EPI == CFHIP_EPI_DGELU) {
-        const u32x2 r = *reinterpret_cast<const u32x2*>(p.aux_in + off);
-        v[0] *= gelu_erf_grad_f(bf16lo(r[0])); v[1] *= gelu_erf_grad_f(bf16hi(r[0]));
-        v[2] *= gelu_erf_grad_f(bf16lo(r[1])); v[3] *= gelu_erf_grad_f(bf16hi(r[1]));
+        const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                         pack_bf16x2(hi[2], hi[3])};
+        if (p.aux_out != nullptr) {
+          if (c_hi) *reinterpret_cast<u32x4*>(p.aux_out + off) = w;
+          else *reinterpret_cast<u32x2*>(p.aux_out + off) = u32x2{w[0], w[1]};
+        }
+        lo = f32x4{gelu_erf_f(bf16lo(w[0])), gelu_erf_f(bf16hi(w[0])), gelu_erf_f(bf16lo(w[1])), gelu_erf_f(bf16hi(w[1]))};
+        hi = f32x4{gelu_erf_f(bf16lo(w[2])), gelu_erf_f(bf16hi(w[2])), gelu_erf_f(bf16lo(w[3])), gelu_erf_f(bf16hi(w[3]))};
+      } else if (EPI == CFHIP_EPI_RESIDUAL && p.out_f32) {
+        // f32 residual stream: aux_in is f32 with the output's layout
+        const float* r = reinterpret_cast<const float*>(p.aux_in) + off;
+        lo += *reinterpret_cast<const f32x4*>(r);
+        if (c_hi) hi += *reinterpret_cast<const f32x4*>(r + 4);
+      } else if (EPI == CFHIP_EPI_RESIDUAL || EPI == CFHIP_EPI_DGELU) {
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if (c_hi) w = *reinterpret_cast<const u32x4*>(p.aux_in + off);
+        else { const u32x2 h2 = *reinterpret_cast<const u32x2*>(p.aux_in + off); w[0] = h2[0]; w[1] = h2[1]; }
+        if (EPI == CFHIP_EPI_RESIDUAL) {
+          lo += f32x4{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
+          hi += f32x4{bf16lo(w[2]), bf16hi(w[2]), bf16lo(w[3]), bf16hi(w[3])};
+        } else {
+          lo *= f32x4{gelu_erf_grad_f(bf16lo(w[0])), gelu_erf_grad_f(bf16hi(w[0])), gelu_erf_grad_f(bf16lo(w[1])), gelu_erf_grad_f(bf16hi(w[1]))};
+          hi *= f32x4{gelu_erf_grad_f(bf16lo(w[2])), gelu_erf_grad_f(bf16hi(w[2])), gelu_erf_grad_f(bf16lo(w[3])), gelu_erf_grad_f(bf16hi(w[3]))};
+        }
       }
       if (p.out_f32) {
         float* dst = reinterpret_cast<float*>(p.C) + off;
-        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
-        *reinterpret_cast<f32x4*>(dst) = v;
+        if (p.accumulate) {
+          lo += *reinterpret_cast<const f32x4*>(dst);
+          if (c_hi) hi += *reinterpret_cast<const f32x4*>(dst + 4);
+        }
+        *reinterpret_cast<f32x4*>(dst) = lo;
+        if (c_hi) *reinterpret_cast<f32x4*>(dst + 4) = hi;
       } else {
         bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + off;
-        *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                         pack_bf16x2(hi[2], hi[3])};
+        if (c_hi) *reinterpret_cast<u32x4*>(dst) = w;
+        else *reinterpret_cast<u32x2*>(dst) = u32x2{w[0], w[1]};
       }
     }
   }
@@ -311,7 +389,7 @@ __global__ void gemm_bf16_generic_kernel(GemmParams p, int a_trans, int b_trans)
       if (p.aux_out != nullptr) p.aux_out[off] = f32_to_bf16(acc);
       acc = gelu_erf_f(pre);
     } else if (p.epilogue == CFHIP_EPI_RESIDUAL) {
-      acc += bf16_to_f32(p.aux_in[off]);
+      acc += p.out_f32 ? reinterpret_cast<const float*>(p.aux_in)[off] : bf16_to_f32(p.aux_in[off]);
     } else if (p.epilogue == CFHIP_EPI_DGELU) {
       acc *= gelu_erf_grad_f(bf16_to_f32(p.aux_in[off]));
     }
@@ -326,7 +404,91 @@ __global__ void gemm_bf16_generic_kernel(GemmParams p, int a_trans, int b_trans)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// tile configurations (see Cfg): index = value of the "gemm_config" option (-1 = heuristic)
+using CfgA = Cfg<128, 128, 2, 2, 2, 64>;  //  64 KiB LDS, 4 waves, 2 WG / CU, prefetch 1
+using CfgB = Cfg<128, 128, 2, 2, 2, 32>;  //  32 KiB LDS, 4 waves, 4 WG / CU, prefetch 1
+using CfgC = Cfg<128, 128, 2, 2, 3, 32>;  //  48 KiB LDS, 4 waves, 3 WG / CU, prefetch 2
+using CfgD = Cfg<128, 64, 2, 2, 2, 64>;   //  48 KiB LDS, 4 waves (64x32 each), 3 WG / CU, prefetch 1
+using CfgE = Cfg<128, 128, 2, 2, 4, 32>;  //  64 KiB LDS, 4 waves, 2 WG / CU, prefetch 3
+using CfgF = Cfg<128, 64, 2, 2, 2, 32>;   //  24 KiB LDS, 4 waves (64x32 each), 4 WG / CU, prefetch 1
+using CfgG = Cfg<128, 64, 2, 2, 3, 32>;   //  36 KiB LDS, 4 waves (64x32 each), 4 WG / CU, prefetch 2
+constexpr int NUM_CFG = 7;
+constexpr int BK_MAX = 64;
+
+int g_gemm_config = -1;
+int g_gemm_ablate = 0;
+
+template <bool AT, bool BT, int EPI, class C>
+int launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
+  auto kern = gemm_bf16_kernel<AT, BT, EPI, C>;
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done && C::LDS_BYTES > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) {
+      cfhip_set_error("gemm: cannot reserve %d bytes of LDS: %s", C::LDS_BYTES, hipGetErrorString(e));
+      return CFHIP_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::LDS_BYTES, s, p);
+  return CFHIP_OK;
+}
+
+template <class C>
+int launch_layout(GemmParams p, int a_trans, int b_trans, int epilogue, int split_k, hipStream_t s) {
+  p.tiles_m = (p.M + C::BM - 1) / C::BM;
+  p.tiles_n = (p.N + C::BN - 1) / C::BN;
+  const long a_span = a_trans ? (long)p.k_chunk * p.lda * 2 : (long)C::BM * p.lda * 2;
+  const long b_span = b_trans ? (long)p.k_chunk * p.ldb * 2 : (long)C::BN * p.ldb * 2;
+  CFHIP_REQUIRE(a_span < 0x7fffffffL && b_span < 0x7fffffffL,
+                "gemm: operand tile span exceeds 2 GiB (lda=%ld ldb=%ld K=%d)", p.lda, p.ldb, p.K);
+  dim3 grid(p.tiles_m * p.tiles_n, split_k);
+  if (!a_trans && !b_trans) {
+    switch (epilogue) {
+      case CFHIP_EPI_NONE: return launch_cfg<false, false, CFHIP_EPI_NONE, C>(p, grid, s);
+      case CFHIP_EPI_GELU: return launch_cfg<false, false, CFHIP_EPI_GELU, C>(p, grid, s);
+      case CFHIP_EPI_RESIDUAL: return launch_cfg<false, false, CFHIP_EPI_RESIDUAL, C>(p, grid, s);
+      default: break;
+    }
+  } else if (!a_trans && b_trans) {
+    switch (epilogue) {
+      case CFHIP_EPI_NONE: return launch_cfg<false, true, CFHIP_EPI_NONE, C>(p, grid, s);
+      case CFHIP_EPI_DGELU: return launch_cfg<false, true, CFHIP_EPI_DGELU, C>(p, grid, s);
+      default: break;
+    }
+  } else if (epilogue == CFHIP_EPI_NONE) {
+    return launch_cfg<true, true, CFHIP_EPI_NONE, C>(p, grid, s);
+  }
+  cfhip_set_error("gemm: epilogue %d is not provided for layout (%d,%d)", epilogue, a_trans, b_trans);
+  return CFHIP_ERR_INVALID;
+}
+
+// Shape-aware tile choice, from the measured A/B table of tools/gemm_bench.py on the ViT-B/16 shapes
+// (profiles/): the kernels are bound by how well DMA, MFMA and the store tail of co-resident
+// workgroups overlap, so the small-LDS configurations (3-4 workgroups / CU) win whenever the
+// operand is read through the transposing LDS path or the output is narrow.
+int pick_config(int M, int N, int a_trans, int b_trans) {
+  if (g_gemm_config >= 0 && g_gemm_config < NUM_CFG) return g_gemm_config;
+  if (a_trans || b_trans) return 1;   // 128x128x32, 4 WG / CU
+  if (N <= 1024) return 3;            // 128x64x64, 3 WG / CU
+  return 0;                           // 128x128x64, 2 WG / CU
+}
+
 }  // namespace
+
+extern "C" int cfhip_set_option(const char* name, int value) {
+  if (name != nullptr && strcmp(name, "gemm_config") == 0) {
+    g_gemm_config = value;
+    return CFHIP_OK;
+  }
+  if (name != nullptr && strcmp(name, "gemm_ablate") == 0) {
+    g_gemm_ablate = value;
+    return CFHIP_OK;
+  }
+  cfhip_set_error("set_option: unknown option '%s'", name ? name : "(null)");
+  return CFHIP_ERR_INVALID;
+}
 
 extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const float* bias,
                                const void* aux_in, void* aux_out, int M, int N, int K, int64_t lda,
@@ -354,13 +516,10 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.epilogue = epilogue; p.out_f32 = out_dtype; p.accumulate = accumulate;
   p.slabs = nullptr;
-  p.tiles_m = (M + BM - 1) / BM;
-  p.tiles_n = (N + BN - 1) / BN;
-  p.k_chunk = ((K + BK - 1) / BK) * BK;
+  p.tiles_m = p.tiles_n = 0;
+  p.ablate = g_gemm_ablate;
+  p.k_chunk = ((K + BK_MAX - 1) / BK_MAX) * BK_MAX;
 
-  // operand extents must keep 32-bit tile-relative offsets below 2 GiB
-  const long a_span = a_trans ? (long)K * lda * 2 : (long)BM * lda * 2;
-  const long b_span = b_trans ? (long)K * ldb * 2 : (long)BN * ldb * 2;
   const bool fast = (K % 8 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (N % 4 == 0) &&
                     (ldc % 4 == 0) && (!a_trans || M % 8 == 0) && (!b_trans || N % 8 == 0) &&
                     aligned16(A) && aligned16(B) && aligned16(C) &&
@@ -377,11 +536,11 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
 
   if (split_k > 1) {
     CFHIP_REQUIRE(epilogue == CFHIP_EPI_NONE, "gemm: split_k supports epilogue NONE only");
-    const int steps = (K + BK - 1) / BK;
+    const int steps = (K + BK_MAX - 1) / BK_MAX;
     if (split_k > steps) split_k = steps;
     const int per = (steps + split_k - 1) / split_k;
     split_k = (steps + per - 1) / per;
-    p.k_chunk = per * BK;
+    p.k_chunk = per * BK_MAX;
   }
   if (split_k > 1) {
     const size_t need = (size_t)split_k * M * N * sizeof(float);
@@ -391,36 +550,18 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
     }
     p.slabs = reinterpret_cast<float*>(workspace);
   }
-  const long max_span = p.slabs ? (long)p.k_chunk : (long)K;
-  CFHIP_REQUIRE((a_trans ? max_span * lda * 2 : a_span) < 0x7fffffffL &&
-                    (b_trans ? max_span * ldb * 2 : b_span) < 0x7fffffffL,
-                "gemm: operand tile span exceeds 2 GiB (lda=%ld ldb=%ld K=%d)", (long)lda, (long)ldb, K);
 
-  dim3 grid(p.tiles_m * p.tiles_n, split_k);
-#define CFHIP_LAUNCH_GEMM(AT_, BT_, EPI_) \
-  hipLaunchKernelGGL((gemm_bf16_kernel<AT_, BT_, EPI_>), grid, dim3(NTHREADS), 0, s, p)
-  if (!a_trans && !b_trans) {
-    switch (epilogue) {
-      case CFHIP_EPI_NONE: CFHIP_LAUNCH_GEMM(false, false, CFHIP_EPI_NONE); break;
-      case CFHIP_EPI_GELU: CFHIP_LAUNCH_GEMM(false, false, CFHIP_EPI_GELU); break;
-      case CFHIP_EPI_RESIDUAL: CFHIP_LAUNCH_GEMM(false, false, CFHIP_EPI_RESIDUAL); break;
-      default:
-        cfhip_set_error("gemm: epilogue %d is not provided for layout (0,0)", epilogue);
-        return CFHIP_ERR_INVALID;
-    }
-  } else if (!a_trans && b_trans) {
-    switch (epilogue) {
-      case CFHIP_EPI_NONE: CFHIP_LAUNCH_GEMM(false, true, CFHIP_EPI_NONE); break;
-      case CFHIP_EPI_DGELU: CFHIP_LAUNCH_GEMM(false, true, CFHIP_EPI_DGELU); break;
-      default:
-        cfhip_set_error("gemm: epilogue %d is not provided for layout (0,1)", epilogue);
-        return CFHIP_ERR_INVALID;
-    }
-  } else {
-    CFHIP_REQUIRE(epilogue == CFHIP_EPI_NONE, "gemm: epilogue %d is not provided for layout (1,1)", epilogue);
-    CFHIP_LAUNCH_GEMM(true, true, CFHIP_EPI_NONE);
+  int rc;
+  switch (pick_config(M, N, a_trans, b_trans)) {
+    case 1: rc = launch_layout<CfgB>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 2: rc = launch_layout<CfgC>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 3: rc = launch_layout<CfgD>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 4: rc = launch_layout<CfgE>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 5: rc = launch_layout<CfgF>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 6: rc = launch_layout<CfgG>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    default: rc = launch_layout<CfgA>(p, a_trans, b_trans, epilogue, split_k, s); break;
   }
-#undef CFHIP_LAUNCH_GEMM
+  if (rc != CFHIP_OK) return rc;
   CFHIP_CHECK_LAUNCH("gemm_bf16");
 
   if (split_k > 1) {

@@ -28,9 +28,46 @@ __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
   *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
 }
 
-template <int NCH>
+// 64-lane sum without the LDS pipe: 4 DPP steps inside each 16-lane row (quad swaps, half-row mirror,
+// row mirror), then the 4 row totals are read through v_readlane.  (A __shfl_xor chain lowers to 6
+// dependent ds_bpermute round trips, which made the reductions the latency of every row.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+  return v + __int_as_float(o);
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror -> every lane holds its 16-lane row total
+  const int iv = __float_as_int(v);
+  return (__int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48)));
+}
+
+// EXACT: D == NCH * 256 (no column masks).  The next row's loads are issued before the current row
+// is reduced (register double buffer), so two rows per wave are in flight.
+// 4 consecutive elements of a row as f32, from a bf16 (8-byte load) or an f32 (16-byte load) tensor
+template <typename XT> struct Row4;
+template <> struct Row4<bf16_t> {
+  u32x2 w;
+  __device__ __forceinline__ void load(const bf16_t* p) { w = *reinterpret_cast<const u32x2*>(p); }
+  __device__ __forceinline__ void zero() { w = u32x2{0u, 0u}; }
+  __device__ __forceinline__ void get(float (&v)[4]) const {
+    v[0] = bf16lo(w[0]); v[1] = bf16hi(w[0]); v[2] = bf16lo(w[1]); v[3] = bf16hi(w[1]);
+  }
+};
+template <> struct Row4<float> {
+  f32x4 w;
+  __device__ __forceinline__ void load(const float* p) { w = *reinterpret_cast<const f32x4*>(p); }
+  __device__ __forceinline__ void zero() { w = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ __forceinline__ void get(float (&v)[4]) const { v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3]; }
+};
+
+template <int NCH, bool EXACT, typename XT>
 __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
-    const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const XT* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     bf16_t* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int D,
     long xs, long ys, float eps) {
   const int lane = threadIdx.x & 63;
@@ -43,38 +80,50 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
     const int col = c * 256 + lane * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      gm[c][e] = (col + e < D) ? gamma[col + e] : 0.f;
-      bt[c][e] = (col + e < D) ? beta[col + e] : 0.f;
+      gm[c][e] = (EXACT || col + e < D) ? gamma[col + e] : 0.f;
+      bt[c][e] = (EXACT || col + e < D) ? beta[col + e] : 0.f;
     }
   }
   const float inv_d = 1.0f / (float)D;
+  Row4<XT> nxt[NCH];
+  if (gw < M) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (EXACT || col < D) nxt[c].load(x + (long)gw * xs + col); else nxt[c].zero();
+    }
+  }
   for (int row = gw; row < M; row += nw) {
-    const bf16_t* xr = x + (long)row * xs;
     float v[NCH][4];
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const int col = c * 256 + lane * 4;
-      if (col < D) load4(xr + col, v[c]);
-      else { v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f; }
+      nxt[c].get(v[c]);
       s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
     }
-    const float mean = wave_sum(s) * inv_d;
+    if (row + nw < M) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (EXACT || col < D) nxt[c].load(x + (long)(row + nw) * xs + col); else nxt[c].zero();
+      }
+    }
+    const float mean = wave_sum_dpp(s) * inv_d;
     float sq = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
-      if (col < D) {
+      if (EXACT || col < D) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float d = v[c][e] - mean; sq += d * d; }
       }
     }
-    const float rstd = rsqrtf(wave_sum(sq) * inv_d + eps);
+    const float rstd = rsqrtf(wave_sum_dpp(sq) * inv_d + eps);
     bf16_t* yr = y + (long)row * ys;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
-      if (col < D) {
+      if (EXACT || col < D) {
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * gm[c][e] + bt[c][e];
@@ -88,9 +137,9 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
   }
 }
 
-template <int NCH>
+template <int NCH, bool EXACT, typename XT>
 __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
-    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+    const bf16_t* __restrict__ dy, const XT* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     const bf16_t* __restrict__ dx_add, bf16_t* __restrict__ dx, float* __restrict__ partials, int M,
     int D, long dys, long xs, long dxs) {
@@ -108,68 +157,91 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
     const int col = c * 256 + lane * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      gm[c][e] = (col + e < D) ? gamma[col + e] : 0.f;
+      gm[c][e] = (EXACT || col + e < D) ? gamma[col + e] : 0.f;
       dg[c][e] = 0.f;
       db[c][e] = 0.f;
     }
   }
   const float inv_d = 1.0f / (float)D;
+  Row4<XT> nx[NCH];
+  u32x2 ny[NCH];
+  float nmean = 0.f, nrstd = 0.f;
+  if (gw < M) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      const bool ok = EXACT || col < D;
+      if (ok) nx[c].load(x + (long)gw * xs + col); else nx[c].zero();
+      ny[c] = ok ? *reinterpret_cast<const u32x2*>(dy + (long)gw * dys + col) : u32x2{0u, 0u};
+    }
+    nmean = mean_in[gw];
+    nrstd = rstd_in[gw];
+  }
   for (int row = gw; row < M; row += nw) {
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    const bf16_t* xr = x + (long)row * xs;
-    const bf16_t* dyr = dy + (long)row * dys;
+    const float mean = nmean, rstd = nrstd;
     float xh[NCH][4], g[NCH][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
+      float xv[4];
+      nx[c].get(xv);
+      const float dv[4] = {bf16lo(ny[c][0]), bf16hi(ny[c][0]), bf16lo(ny[c][1]), bf16hi(ny[c][1])};
       const int col = c * 256 + lane * 4;
-      if (col < D) {
-        float xv[4], dv[4];
-        load4(xr + col, xv);
-        load4(dyr + col, dv);
+      const bool ok = EXACT || col < D;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xh[c][e] = (xv[e] - mean) * rstd;
-          g[c][e] = dv[e] * gm[c][e];
-          s1 += g[c][e];
-          s2 += g[c][e] * xh[c][e];
-          dg[c][e] += dv[e] * xh[c][e];
-          db[c][e] += dv[e];
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { xh[c][e] = 0.f; g[c][e] = 0.f; }
+      for (int e = 0; e < 4; ++e) {
+        xh[c][e] = ok ? (xv[e] - mean) * rstd : 0.f;
+        g[c][e] = dv[e] * gm[c][e];
+        s1 += g[c][e];
+        s2 += g[c][e] * xh[c][e];
+        dg[c][e] += dv[e] * xh[c][e];
+        db[c][e] += dv[e];
       }
     }
-    s1 = wave_sum(s1) * inv_d;
-    s2 = wave_sum(s2) * inv_d;
+    // residual-gradient rows of THIS row and the operands of the NEXT row: all in flight together
+    u32x2 addv[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      addv[c] = (dx_add != nullptr && (EXACT || col < D))
+                    ? *reinterpret_cast<const u32x2*>(dx_add + (long)row * dxs + col) : u32x2{0u, 0u};
+    }
+    if (row + nw < M) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        const bool ok = EXACT || col < D;
+        if (ok) nx[c].load(x + (long)(row + nw) * xs + col); else nx[c].zero();
+        ny[c] = ok ? *reinterpret_cast<const u32x2*>(dy + (long)(row + nw) * dys + col) : u32x2{0u, 0u};
+      }
+      nmean = mean_in[row + nw];
+      nrstd = rstd_in[row + nw];
+    }
+    s1 = wave_sum_dpp(s1) * inv_d;
+    s2 = wave_sum_dpp(s2) * inv_d;
     bf16_t* dxr = dx + (long)row * dxs;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
-      if (col < D) {
+      if (EXACT || col < D) {
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rstd * (g[c][e] - s1 - xh[c][e] * s2);
-        if (dx_add != nullptr) {
-          float a[4];
-          load4(dx_add + (long)row * dxs + col, a);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] += a[e];
-        }
+        o[0] += bf16lo(addv[c][0]); o[1] += bf16hi(addv[c][0]);
+        o[2] += bf16lo(addv[c][1]); o[3] += bf16hi(addv[c][1]);
         store4(dxr + col, o);
       }
     }
   }
-  // fold the workgroup's waves through LDS, then one partial row per workgroup
+  // fold the workgroup's waves through LDS float atomics (ds_add_f32), one partial row per workgroup
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = c * 256 + lane * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (col + e < D) {
-        atomicAdd(&red[col + e], dg[c][e]);
-        atomicAdd(&red[D + col + e], db[c][e]);
+      if (EXACT || col + e < D) {
+        __hip_atomic_fetch_add(&red[col + e], dg[c][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&red[D + col + e], db[c][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
@@ -178,40 +250,49 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
   for (int i = threadIdx.x; i < 2 * D; i += LN_THREADS) out[i] = red[i];
 }
 
-inline int ln_grid(int M) {
+inline int ln_grid(int M, int cap = 512) {
   int blocks = (M + LN_WAVES - 1) / LN_WAVES;
-  if (blocks > 512) blocks = 512;  // 2 workgroups of 8 waves per CU
+  if (blocks > cap) blocks = cap;  // 512 = 2 workgroups of 8 waves per CU
   if (blocks < 1) blocks = 1;
   return blocks;
 }
 
 }  // namespace
 
-#define LN_DISPATCH(KERNEL, nch, ...)                                      \
+#define LN_DISPATCH(KERNEL, nch, ...) /* KERNEL(NCH, EXACT) */                                      \
   switch (nch) {                                                           \
-    case 1: KERNEL(1, __VA_ARGS__); break;                                 \
-    case 2: KERNEL(2, __VA_ARGS__); break;                                 \
-    case 3: KERNEL(3, __VA_ARGS__); break;                                 \
-    case 4: KERNEL(4, __VA_ARGS__); break;                                 \
-    case 5: case 6: KERNEL(6, __VA_ARGS__); break;                         \
-    default: KERNEL(8, __VA_ARGS__); break;                                \
+    case 1: if (exact) { KERNEL(1, true); } else { KERNEL(1, false); } break;      \
+    case 2: if (exact) { KERNEL(2, true); } else { KERNEL(2, false); } break;      \
+    case 3: if (exact) { KERNEL(3, true); } else { KERNEL(3, false); } break;      \
+    case 4: if (exact) { KERNEL(4, true); } else { KERNEL(4, false); } break;      \
+    case 5: case 6: if (exact && nch == 6) { KERNEL(6, true); } else { KERNEL(6, false); } break; \
+    default: if (exact && nch == 8) { KERNEL(8, true); } else { KERNEL(8, false); } break;        \
   }
 
-extern "C" int cfhip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
-                                   float* mean, float* rstd, int M, int D, int64_t x_row_stride,
-                                   int64_t y_row_stride, float eps, void* stream) {
+extern "C" int cfhip_layernorm_fwd(const void* x, int x_is_f32, const float* gamma, const float* beta,
+                                   void* y, float* mean, float* rstd, int M, int D,
+                                   int64_t x_row_stride, int64_t y_row_stride, float eps, void* stream) {
   CFHIP_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
   CFHIP_REQUIRE(M > 0 && D > 0, "layernorm_fwd: empty problem");
   CFHIP_REQUIRE(D % 4 == 0 && D <= 2048, "layernorm_fwd: D=%d must be a multiple of 4 and <= 2048", D);
   CFHIP_REQUIRE(x_row_stride % 4 == 0 && y_row_stride % 4 == 0, "layernorm_fwd: row strides must be multiples of 4");
-  CFHIP_REQUIRE(((uintptr_t)x & 7) == 0 && ((uintptr_t)y & 7) == 0, "layernorm_fwd: x / y must be 8-byte aligned");
+  CFHIP_REQUIRE(((uintptr_t)x & (x_is_f32 ? 15 : 7)) == 0 && ((uintptr_t)y & 7) == 0,
+                "layernorm_fwd: x / y must be 8-byte (bf16) / 16-byte (f32) aligned");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int nch = (D + 255) / 256;
-  const int blocks = ln_grid(M);
-#define LN_FWD(N_, ...)                                                                          \
-  hipLaunchKernelGGL((layernorm_fwd_kernel<N_>), dim3(blocks), dim3(LN_THREADS), 0, s,            \
-                     (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, (long)x_row_stride, \
-                     (long)y_row_stride, eps)
+  const bool exact = (D % 256) == 0;
+  const int blocks = ln_grid(M, 1024);
+#define LN_FWD(N_, EX_)                                                                           \
+  do {                                                                                             \
+    if (x_is_f32)                                                                                  \
+      hipLaunchKernelGGL((layernorm_fwd_kernel<N_, EX_, float>), dim3(blocks), dim3(LN_THREADS), 0, s, \
+                         (const float*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D,                \
+                         (long)x_row_stride, (long)y_row_stride, eps);                              \
+    else                                                                                           \
+      hipLaunchKernelGGL((layernorm_fwd_kernel<N_, EX_, bf16_t>), dim3(blocks), dim3(LN_THREADS), 0, s, \
+                         (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D,               \
+                         (long)x_row_stride, (long)y_row_stride, eps);                              \
+  } while (0)
   LN_DISPATCH(LN_FWD, nch, 0)
 #undef LN_FWD
   CFHIP_CHECK_LAUNCH("layernorm_fwd");
@@ -222,7 +303,7 @@ extern "C" size_t cfhip_layernorm_bwd_workspace(int M, int D) {
   return (size_t)ln_grid(M) * 2 * (size_t)D * sizeof(float);
 }
 
-extern "C" int cfhip_layernorm_bwd(const void* dy, const void* x, const float* gamma,
+extern "C" int cfhip_layernorm_bwd(const void* dy, const void* x, int x_is_f32, const float* gamma,
                                    const float* mean, const float* rstd, const void* dx_add, void* dx,
                                    float* dgamma, float* dbeta, int M, int D, int64_t dy_row_stride,
                                    int64_t x_row_stride, int64_t dx_row_stride,
@@ -233,7 +314,7 @@ extern "C" int cfhip_layernorm_bwd(const void* dy, const void* x, const float* g
   CFHIP_REQUIRE(D % 4 == 0 && D <= 2048, "layernorm_bwd: D=%d must be a multiple of 4 and <= 2048", D);
   CFHIP_REQUIRE(dy_row_stride % 4 == 0 && x_row_stride % 4 == 0 && dx_row_stride % 4 == 0,
                 "layernorm_bwd: row strides must be multiples of 4");
-  CFHIP_REQUIRE(((uintptr_t)dy & 7) == 0 && ((uintptr_t)x & 7) == 0 && ((uintptr_t)dx & 7) == 0 &&
+  CFHIP_REQUIRE(((uintptr_t)dy & 7) == 0 && ((uintptr_t)x & (x_is_f32 ? 15 : 7)) == 0 && ((uintptr_t)dx & 7) == 0 &&
                     ((uintptr_t)dx_add & 7) == 0,
                 "layernorm_bwd: tensors must be 8-byte aligned");
   const size_t need = cfhip_layernorm_bwd_workspace(M, D);
@@ -243,14 +324,23 @@ extern "C" int cfhip_layernorm_bwd(const void* dy, const void* x, const float* g
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int nch = (D + 255) / 256;
+  const bool exact = (D % 256) == 0;
   const int blocks = ln_grid(M);
   float* partials = reinterpret_cast<float*>(workspace);
   const size_t lds = (size_t)2 * D * sizeof(float);
-#define LN_BWD(N_, ...)                                                                            \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<N_>), dim3(blocks), dim3(LN_THREADS), lds, s,            \
-                     (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dx_add, \
-                     (bf16_t*)dx, partials, M, D, (long)dy_row_stride, (long)x_row_stride,          \
-                     (long)dx_row_stride)
+#define LN_BWD(N_, EX_)                                                                               \
+  do {                                                                                                 \
+    if (x_is_f32)                                                                                      \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<N_, EX_, float>), dim3(blocks), dim3(LN_THREADS), lds, s, \
+                         (const bf16_t*)dy, (const float*)x, gamma, mean, rstd, (const bf16_t*)dx_add,   \
+                         (bf16_t*)dx, partials, M, D, (long)dy_row_stride, (long)x_row_stride,          \
+                         (long)dx_row_stride);                                                          \
+    else                                                                                               \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<N_, EX_, bf16_t>), dim3(blocks), dim3(LN_THREADS), lds, s, \
+                         (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dx_add, \
+                         (bf16_t*)dx, partials, M, D, (long)dy_row_stride, (long)x_row_stride,          \
+                         (long)dx_row_stride);                                                          \
+  } while (0)
   LN_DISPATCH(LN_BWD, nch, 0)
 #undef LN_BWD
   CFHIP_CHECK_LAUNCH("layernorm_bwd");

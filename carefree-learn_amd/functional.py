@@ -75,6 +75,16 @@ def write_param_grad(param: Tensor, compute: Callable[[Tensor, bool], None]) -> 
         cb(param)
 
 
+def _as_rows(x: Tensor) -> Tensor:
+    """[..., D] -> 2-D view with a contiguous last dim, keeping f32 or bf16 as is."""
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.dtype not in (bf16, f32):
+        x2 = x2.float()
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    return x2
+
+
 def _as_bf16_2d(x: Tensor) -> Tensor:
     x2 = x.reshape(-1, x.shape[-1])
     if x2.dtype != bf16:
@@ -130,10 +140,11 @@ class LinearFn(Function):
             pre = torch.empty((m, n), dtype=bf16, device=x2.device)
             y = ops.gemm(x2, w16, bias=bias_f, epilogue=ops.EPI_GELU, aux_out=pre)
         elif residual is not None:
-            r2 = _as_bf16_2d(residual)
+            # the residual operand keeps its dtype: an f32 residual stream gives an f32 sum
+            r2 = _as_rows(residual)
             if not r2.is_contiguous():
                 r2 = r2.contiguous()
-            y = ops.gemm(x2, w16, bias=bias_f, epilogue=ops.EPI_RESIDUAL, aux_in=r2)
+            y = ops.gemm(x2, w16, bias=bias_f, epilogue=ops.EPI_RESIDUAL, aux_in=r2, out_dtype=r2.dtype)
         else:
             y = ops.gemm(x2, w16, bias=bias_f, out_dtype=f32 if out_f32 else bf16)
         ctx.save_for_backward(x2, w16, pre)
@@ -151,13 +162,12 @@ class LinearFn(Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         d_res = dy2.view(*ctx.x_shape[:-1], weight.shape[0]) if ctx.has_residual and ctx.needs_input_grad[4] else None
+        # (autograd casts d_res to the residual's dtype; the gradient stream itself stays bf16)
         if pre is not None:
             dy2 = ops.gelu_bwd(dy2, pre)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm(dy2, w16, b_trans=True).view(ctx.x_shape)
-            if ctx.in_dtype != bf16:
-                dx = ops.to_f32(dx).to(ctx.in_dtype)
+            dx = ops.gemm(dy2, w16, b_trans=True).view(ctx.x_shape)  # bf16; autograd casts if needed
         gw, gb = _linear_param_grads(dy2, x2, weight, bias, _is_direct(weight), _is_direct(bias))
         return dx, gw, gb, None, d_res, None
 
@@ -177,7 +187,7 @@ class LayerNormFn(Function):
 
     @staticmethod
     def forward(ctx: Any, x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
-        x2 = _as_bf16_2d(x)
+        x2 = _as_rows(x)
         gamma = weight.detach().contiguous()
         beta = bias.detach().contiguous()
         y, mean, rstd = ops.layernorm_fwd(x2, gamma, beta, eps)
@@ -207,9 +217,7 @@ class LayerNormFn(Function):
                 write_param_grad(bias, lambda out, acc: out.add_(db.view(out.shape)) if acc else out.copy_(db.view(out.shape)))
             elif bias.requires_grad:
                 gb = db.view(bias.shape)
-        dx = dx.view(ctx.x_shape) if ctx.needs_input_grad[0] else None
-        if dx is not None and ctx.in_dtype != bf16:
-            dx = ops.to_f32(dx).to(ctx.in_dtype)
+        dx = dx.view(ctx.x_shape) if ctx.needs_input_grad[0] else None  # bf16; autograd casts if needed
         return dx, gw, gb, None
 
 

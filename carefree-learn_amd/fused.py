@@ -71,10 +71,10 @@ class MixingBlockFn(Function):
                 b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], num_heads: int, eps1: float,
                 eps2: float, keep_mask: Optional[Tensor], causal: bool) -> Tensor:
         bsz, t, d = x.shape
-        if x.dtype != bf16:
-            x = ops.to_bf16(x.float().contiguous())
+        if x.dtype not in (bf16, f32):
+            x = x.float()
         x = x.contiguous()
-        x2 = x.view(bsz * t, d)
+        x2 = x.view(bsz * t, d)  # residual stream: f32 (reference autocast semantics) or bf16
         fb = lambda p: None if p is None else p.detach().reshape(-1)  # noqa: E731
         in_w16, out_w16 = shadow_bf16(in_w), shadow_bf16(out_w)
         w1_16, w2_16 = shadow_bf16(w1), shadow_bf16(w2)
@@ -85,11 +85,11 @@ class MixingBlockFn(Function):
         o, lse = ops.attn_fwd(qkv3[..., :d], qkv3[..., d:2 * d], qkv3[..., 2 * d:], num_heads,
                               mask=keep_mask, causal=causal)
         o2 = o.view(bsz * t, d)
-        x1 = ops.gemm(o2, out_w16, bias=fb(out_b), epilogue=ops.EPI_RESIDUAL, aux_in=x2)
+        x1 = ops.gemm(o2, out_w16, bias=fb(out_b), epilogue=ops.EPI_RESIDUAL, aux_in=x2, out_dtype=x2.dtype)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, ln2_w.detach(), ln2_b.detach(), eps2)
         pre = torch.empty((bsz * t, w1.shape[0]), dtype=bf16, device=x.device)
         h = ops.gemm(ln2, w1_16, bias=fb(b1), epilogue=ops.EPI_GELU, aux_out=pre)
-        y = ops.gemm(h, w2_16, bias=fb(b2), epilogue=ops.EPI_RESIDUAL, aux_in=x1)
+        y = ops.gemm(h, w2_16, bias=fb(b2), epilogue=ops.EPI_RESIDUAL, aux_in=x1, out_dtype=x1.dtype)
 
         ctx.save_for_backward(x2, mean1, rstd1, ln1, qkv, o2, lse, x1, mean2, rstd2, ln2, pre, h,
                               in_w16, out_w16, w1_16, w2_16, keep_mask)

@@ -38,6 +38,11 @@ def _mat(t: Tensor, name: str) -> Tuple[int, int, int]:
     return t.shape[0], t.shape[1], t.stride(0)
 
 
+def set_option(name: str, value: int) -> None:
+    """process-wide tuning knob of libcfhip.so (see cfhip_set_option in include/cfhip.h)"""
+    _lib.check(_lib.load().cfhip_set_option(name.encode(), int(value)), "set_option")
+
+
 # ---------------------------------------------------------------------------------------------
 # GEMM
 # ---------------------------------------------------------------------------------------------
@@ -89,7 +94,8 @@ def gemm(
             raise ValueError("cfhip gemm: bias must be a contiguous f32 [N]")
     for t, nm in ((aux_in, "aux_in"), (aux_out, "aux_out")):
         if t is not None:
-            _need(t, bf16, nm)
+            # the residual operand follows the output dtype (f32 residual stream); everything else is bf16
+            _need(t, f32 if (nm == "aux_in" and epilogue == EPI_RESIDUAL and out.dtype == f32) else bf16, nm)
             if tuple(t.shape) != (m, n) or t.stride(1) != 1 or t.stride(0) != ldc:
                 raise ValueError(f"cfhip gemm: `{nm}` must match the output layout")
     ws, ws_bytes = None, 0
@@ -130,8 +136,8 @@ def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) ->
 def layernorm_fwd(
     x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out: Optional[Tensor] = None
 ) -> Tuple[Tensor, Tensor, Tensor]:
-    """x: bf16 [M, D] (row stride free) -> y bf16 [M, D], mean f32 [M], rstd f32 [M]."""
-    _need(x, bf16, "x")
+    """x: bf16 or f32 [M, D] (row stride free) -> y bf16 [M, D], mean f32 [M], rstd f32 [M]."""
+    _need(x, x.dtype if x.dtype in (bf16, f32) else bf16, "x")
     _need(gamma, f32, "gamma")
     _need(beta, f32, "beta")
     m, d, xs = _mat(x, "x")
@@ -139,7 +145,7 @@ def layernorm_fwd(
     mean = torch.empty((m,), dtype=f32, device=x.device)
     rstd = torch.empty((m,), dtype=f32, device=x.device)
     rc = _lib.load().cfhip_layernorm_fwd(
-        x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+        x.data_ptr(), int(x.dtype == f32), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
         rstd.data_ptr(), m, d, xs, y.stride(0), float(eps), _stream(),
     )
     _lib.check(rc, "layernorm_fwd")
@@ -158,9 +164,9 @@ def layernorm_bwd(
     dbeta: Optional[Tensor] = None,
     accumulate: bool = False,
 ) -> Tuple[Tensor, Tensor, Tensor]:
-    """Returns (dx bf16 [M, D] (+ dx_add), dgamma f32 [D], dbeta f32 [D])."""
+    """x bf16 or f32.  Returns (dx bf16 [M, D] (+ dx_add), dgamma f32 [D], dbeta f32 [D])."""
     _need(dy, bf16, "dy")
-    _need(x, bf16, "x")
+    _need(x, x.dtype if x.dtype in (bf16, f32) else bf16, "x")
     m, d, xs = _mat(x, "x")
     _, _, dys = _mat(dy, "dy")
     dx = torch.empty((m, d), dtype=bf16, device=x.device)
@@ -176,7 +182,8 @@ def layernorm_bwd(
     nbytes = lib.cfhip_layernorm_bwd_workspace(m, d)
     ws = torch.empty((nbytes // 4,), dtype=f32, device=x.device)
     rc = lib.cfhip_layernorm_bwd(
-        dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add),
+        dy.data_ptr(), x.data_ptr(), int(x.dtype == f32), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+        _p(dx_add),
         dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), m, d, dys, xs, dx.stride(0),
         int(accumulate), ws.data_ptr(), nbytes, _stream(),
     )
@@ -284,16 +291,18 @@ def im2row(img: Tensor, patch: int) -> Tensor:
     return rows
 
 
-def assemble_tokens_fwd(patches: Tensor, head_token: Tensor, pos: Tensor, b: int) -> Tensor:
-    """patches bf16 [B*Np, D]; head_token f32 [D]; pos f32 [(Np+1)*D] -> x0 bf16 [B, Np+1, D]."""
+def assemble_tokens_fwd(patches: Tensor, head_token: Tensor, pos: Tensor, b: int,
+                        out_dtype: torch.dtype = f32) -> Tensor:
+    """patches bf16 [B*Np, D]; head_token f32 [D]; pos f32 [(Np+1)*D] -> x0 [B, Np+1, D] (f32 residual
+    stream by default: head_token / pos are f32 parameters, the reference's sum type-promotes)."""
     _need(patches, bf16, "patches")
     _need(head_token, f32, "head_token")
     _need(pos, f32, "pos")
     d = patches.shape[-1]
     np_ = patches.numel() // (b * d)
-    x0 = torch.empty((b, np_ + 1, d), dtype=bf16, device=patches.device)
+    x0 = torch.empty((b, np_ + 1, d), dtype=out_dtype, device=patches.device)
     rc = _lib.load().cfhip_assemble_tokens_fwd(patches.data_ptr(), head_token.data_ptr(), pos.data_ptr(),
-                                               x0.data_ptr(), b, np_, d, _stream())
+                                               x0.data_ptr(), int(out_dtype == f32), b, np_, d, _stream())
     _lib.check(rc, "assemble_tokens_fwd")
     return x0
 

@@ -37,6 +37,9 @@ extern "C" {
 
 int cfhip_version(void);
 const char* cfhip_last_error(void);
+/* tuning knobs (process-wide): "gemm_config" = -1 (shape heuristic, default) or 0..3 to force one
+ * tile configuration of the GEMM kernel (used by the benchmarks' A/B runs). */
+int cfhip_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------
  * K1/K2  GEMM  (replaces F.linear at modules/core/customs.py:89, attentions.py:214,
@@ -53,7 +56,7 @@ const char* cfhip_last_error(void);
  *   epilogue (bias is fp32 [N] or NULL in every mode):
  *     CFHIP_EPI_NONE        C = acc + bias
  *     CFHIP_EPI_GELU        aux_out (bf16 [M,ldc], may be NULL) = acc + bias ; C = gelu_erf(acc + bias)
- *     CFHIP_EPI_RESIDUAL    C = acc + bias + aux_in (bf16 [M,ldc])
+ *     CFHIP_EPI_RESIDUAL    C = acc + bias + aux_in (bf16 [M,ldc]; f32 when out_dtype == 1)
  *     CFHIP_EPI_DGELU       C = acc * gelu_erf'(aux_in)   (aux_in = saved pre-activation, bf16)
  *   out_dtype: 0 = bf16, 1 = f32.   accumulate != 0 (f32 output only): C += result.
  *   split_k > 1: the K range is cut in `split_k` slices, partial tiles go to `workspace`
@@ -78,18 +81,20 @@ int cfhip_colsum_bf16(const void* X, float* out, int M, int N, int64_t ldx, int 
 /* ------------------------------------------------------------------------------------------
  * K5  LayerNorm over the last dim (replaces nn.LayerNorm built by NormFactory("layer"),
  *     modules/core/norms.py:88-89,118-119; call sites mixed_stacks/api.py:141,155,397-402)
- *   biased variance, eps inside the sqrt, fp32 statistics; x / y are bf16, gamma / beta fp32.
+ *   biased variance, eps inside the sqrt, fp32 statistics; y is bf16, gamma / beta fp32; x is bf16 or
+ *   (x_is_f32 != 0) f32 — the residual stream is kept in f32, as it is in the reference's autocast run
+ *   (head_token / pos_encoding are f32 parameters, so `x + f(LN(x))` type-promotes to f32).
  *   D % 4 == 0 and D <= 2048 (a row lives in the registers of one wave).
  *   x_row_stride / y_row_stride in elements (lets the head LN read token 0 of every sample).
  *   fwd saves mean / rstd (f32 [M]) for bwd.
  *   bwd: dx (bf16) = LN'(dy) [+ dx_add (bf16) if not NULL]; dgamma / dbeta (f32 [D]) (+)= ...
  *        workspace >= cfhip_layernorm_bwd_workspace(M, D) bytes.
  * ------------------------------------------------------------------------------------------ */
-int cfhip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                        float* rstd, int M, int D, int64_t x_row_stride, int64_t y_row_stride,
-                        float eps, void* stream);
+int cfhip_layernorm_fwd(const void* x, int x_is_f32, const float* gamma, const float* beta, void* y,
+                        float* mean, float* rstd, int M, int D, int64_t x_row_stride,
+                        int64_t y_row_stride, float eps, void* stream);
 size_t cfhip_layernorm_bwd_workspace(int M, int D);
-int cfhip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+int cfhip_layernorm_bwd(const void* dy, const void* x, int x_is_f32, const float* gamma, const float* mean,
                         const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta,
                         int M, int D, int64_t dy_row_stride, int64_t x_row_stride,
                         int64_t dx_row_stride, int accumulate_param_grads, void* workspace,
@@ -136,7 +141,7 @@ int cfhip_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
 int cfhip_im2row(const void* img, int img_is_bf16, void* rows, int B, int C, int Hh, int Ww, int P,
                  void* stream);
 int cfhip_assemble_tokens_fwd(const void* patches, const float* head_token, const float* pos,
-                              void* x0, int B, int Np, int D, void* stream);
+                              void* x0, int x0_is_f32, int B, int Np, int D, void* stream);
 int cfhip_assemble_tokens_bwd(const void* dx0, void* dpatches, float* dhead_token, float* dpos,
                               int B, int Np, int D, int accumulate, void* stream);
 

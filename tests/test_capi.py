@@ -37,7 +37,7 @@ def test_version_and_error_string():
     rc = lib.cfhip_gemm_bf16(None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1, None, 0, None)
     assert rc == -1
     assert b"null" in lib.cfhip_last_error()
-    rc = lib.cfhip_layernorm_fwd(1, 1, 1, 1, None, None, 4, 6, 8, 8, 1e-6, None)
+    rc = lib.cfhip_layernorm_fwd(1, 0, 1, 1, 1, None, None, 4, 6, 8, 8, 1e-6, None)
     assert rc == -1 and b"multiple of 4" in lib.cfhip_last_error()
     rc = lib.cfhip_attn_fwd(16, 16, 16, 16, None, None, 1, 1, 300, 300, 64, 64, 64, 64, 64, 64, 0, 0, 0, 0.125, 0, None)
     assert rc == -1 and b"exceeds" in lib.cfhip_last_error()
