@@ -22,7 +22,7 @@ SIGNATURES = {
     "cfhip_gemm_bf16": (
         c_int,
         [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int,
-         c_int, c_int, c_int, _P, c_size_t, _P],
+         c_int, c_int, c_int, _P, c_size_t, _P, c_int, _P],
     ),
     "cfhip_colsum_workspace": (c_size_t, [c_int, c_int]),
     "cfhip_colsum_bf16": (c_int, [_P, _P, c_int, c_int, c_int64, c_int, _P, c_size_t, _P]),

@@ -37,6 +37,9 @@ struct GemmParams {
   int k_chunk;   // K range per z-slice (multiple of BK), == K rounded up when no split
   float* slabs;  // split-K partials [z][M][N] or nullptr
   int tiles_m, tiles_n;
+  float* bgrad;        // (1,1) layout only: out[m] (+)= sum_k A(m,k)  — the bias gradient of a dW GEMM
+  float* bgrad_slabs;  // split-K partials [z][M] of the above
+  int bgrad_acc;
   int ablate;  // benchmarking only: bit0 skip in-loop DMA, bit1 skip MFMA/LDS reads, bit2 skip stores
 };
 
@@ -176,6 +179,23 @@ __device__ __forceinline__ void compute_tile(const char* a_tile, const char* b_t
   }
 }
 
+// Bias gradient on the side of a dW GEMM: the m-major A tile is dY^T, so its row sums over k are
+// colsum(dY).  Run only by the waves (first tile column, wn == 0) that own the result: they re-read
+// their A fragments from LDS and add them up on the VALU — kept out of compute_tile so that the
+// MFMA loop of every other wave stays branch-free and within its register budget.
+template <class C>
+__device__ __forceinline__ void bias_rows(const char* a_tile, int wm, int lane, float (&accb)[C::FM]) {
+#pragma unroll
+  for (int ks = 0; ks < C::BK / 32; ++ks)
+#pragma unroll
+    for (int mi = 0; mi < C::FM; ++mi) {
+      union { bf16x8 v; unsigned w[4]; } u;
+      u.v = frag_mmajor<C::BM>(a_tile, wm * (C::FM * 16) + mi * 16, ks, lane);
+      accb[mi] += ((bf16lo(u.w[0]) + bf16hi(u.w[0])) + (bf16lo(u.w[1]) + bf16hi(u.w[1]))) +
+                  ((bf16lo(u.w[2]) + bf16hi(u.w[2])) + (bf16lo(u.w[3]) + bf16hi(u.w[3])));
+    }
+}
+
 #define CFHIP_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 // K loop = NSTAGE-deep LDS ring fed by LDS-DMA.  The DMA of K-step t + NSTAGE - 1 is issued right
@@ -223,6 +243,10 @@ void gemm_bf16_kernel(GemmParams p) {
   for (int mi = 0; mi < C::FM; ++mi)
 #pragma unroll
     for (int ni = 0; ni < C::FN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float accb[C::FM];
+#pragma unroll
+  for (int mi = 0; mi < C::FM; ++mi) accb[mi] = 0.f;
+  const bool do_bg = AT && p.bgrad != nullptr && tile_n == 0 && wn == 0;
 
   constexpr int BK = C::BK;
   const int nk = (klen + BK - 1) / BK;
@@ -249,6 +273,7 @@ void gemm_bf16_kernel(GemmParams p) {
     }
     const char* cur = smem + rd * C::STAGE_BYTES;
     if (!(p.ablate & 2)) compute_tile<AT, BT, C>(cur, cur + C::A_BYTES, wm, wn, lane, acc);
+    if (AT && do_bg) bias_rows<C>(cur, wm, lane, accb);
     rd = rd + 1 == C::NSTAGE ? 0 : rd + 1;
     wr = wr + 1 == C::NSTAGE ? 0 : wr + 1;
   }
@@ -260,6 +285,19 @@ void gemm_bf16_kernel(GemmParams p) {
   // lane ends up with 8 CONSECUTIVE columns of one row: residual / pre-activation traffic becomes
   // 16-byte coalesced loads and every store instruction writes whole 128-byte row segments.
   if (p.ablate & 4) return;
+  if (AT && do_bg) {
+#pragma unroll
+    for (int mi = 0; mi < C::FM; ++mi) {
+      float v = accb[mi];  // lane (i, g) holds the k-slots of group g: fold the 4 groups
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int m = m0 + wm * (C::FM * 16) + mi * 16 + (lane & 15);
+      if ((lane >> 4) == 0 && m < p.M) {
+        if (p.bgrad_slabs != nullptr) p.bgrad_slabs[(long)z * p.M + m] = v;
+        else p.bgrad[m] = p.bgrad_acc ? p.bgrad[m] + v : v;
+      }
+    }
+  }
   __syncthreads();  // all waves are done reading the ring buffers (no DMA in flight any more)
   constexpr int WCOLS = C::FN * 16;           // columns of the wave's sub-tile
   constexpr int SW = WCOLS + 4;               // padded LDS row stride (floats): conflict-free b128 writes
@@ -345,11 +383,17 @@ void gemm_bf16_kernel(GemmParams p) {
 
 // split-K second pass: C = sum_z slab[z] (+ bias) (+ C)
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, void* C, const float* bias,
-                                     int M, int N, long ldc, int splits, int out_f32, int accumulate) {
+                                     int M, int N, long ldc, int splits, int out_f32, int accumulate,
+                                     const float* __restrict__ bgrad_slabs, float* bgrad, int bgrad_acc) {
   const long n4 = N >> 2;
   const long total = (long)M * n4;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
        idx += (long)gridDim.x * blockDim.x) {
+    if (bgrad != nullptr && idx < M) {  // the dW GEMM's fused bias gradient: reduce its slabs too
+      float b = 0.f;
+      for (int z = 0; z < splits; ++z) b += bgrad_slabs[(long)z * M + idx];
+      bgrad[idx] = bgrad_acc ? bgrad[idx] + b : b;
+    }
     const int row = (int)(idx / n4);
     const int col = (int)(idx - (long)row * n4) * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -376,12 +420,14 @@ __global__ void gemm_bf16_generic_kernel(GemmParams p, int a_trans, int b_trans)
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
        idx += (long)gridDim.x * blockDim.x) {
     const int m = (int)(idx / p.N), n = (int)(idx - (long)m * p.N);
-    float acc = 0.f;
+    float acc = 0.f, asum = 0.f;
     for (int k = 0; k < p.K; ++k) {
       const float a = bf16_to_f32(a_trans ? p.A[(long)k * p.lda + m] : p.A[(long)m * p.lda + k]);
       const float b = bf16_to_f32(b_trans ? p.B[(long)k * p.ldb + n] : p.B[(long)n * p.ldb + k]);
       acc = fmaf(a, b, acc);
+      asum += a;
     }
+    if (p.bgrad != nullptr && n == 0) p.bgrad[m] = p.bgrad_acc ? p.bgrad[m] + asum : asum;
     if (p.bias != nullptr) acc += p.bias[n];
     const long off = (long)m * p.ldc + n;
     if (p.epilogue == CFHIP_EPI_GELU) {
@@ -494,8 +540,11 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
                                const void* aux_in, void* aux_out, int M, int N, int K, int64_t lda,
                                int64_t ldb, int64_t ldc, int a_trans, int b_trans, int epilogue,
                                int out_dtype, int accumulate, int split_k, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               size_t workspace_bytes, float* bias_grad, int bias_grad_accumulate,
+                               void* stream) {
   CFHIP_REQUIRE(A && B && C, "gemm: null operand");
+  CFHIP_REQUIRE(bias_grad == nullptr || (a_trans && b_trans),
+                "gemm: the fused bias gradient exists for layout (1,1) only");
   CFHIP_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
   CFHIP_REQUIRE(epilogue >= 0 && epilogue <= 3, "gemm: bad epilogue %d", epilogue);
   CFHIP_REQUIRE(!(epilogue == CFHIP_EPI_RESIDUAL || epilogue == CFHIP_EPI_DGELU) || aux_in,
@@ -518,6 +567,9 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
   p.slabs = nullptr;
   p.tiles_m = p.tiles_n = 0;
   p.ablate = g_gemm_ablate;
+  p.bgrad = bias_grad;
+  p.bgrad_acc = bias_grad_accumulate;
+  p.bgrad_slabs = nullptr;
   p.k_chunk = ((K + BK_MAX - 1) / BK_MAX) * BK_MAX;
 
   const bool fast = (K % 8 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (N % 4 == 0) &&
@@ -543,12 +595,13 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
     p.k_chunk = per * BK_MAX;
   }
   if (split_k > 1) {
-    const size_t need = (size_t)split_k * M * N * sizeof(float);
+    const size_t need = (size_t)split_k * M * N * sizeof(float) + (bias_grad ? (size_t)split_k * M * sizeof(float) : 0);
     if (workspace == nullptr || workspace_bytes < need) {
       cfhip_set_error("gemm: split_k=%d needs %zu workspace bytes, got %zu", split_k, need, workspace_bytes);
       return CFHIP_ERR_WORKSPACE;
     }
     p.slabs = reinterpret_cast<float*>(workspace);
+    if (bias_grad) p.bgrad_slabs = p.slabs + (size_t)split_k * M * N;
   }
 
   int rc;
@@ -569,7 +622,7 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slabs, C, bias, M, N,
-                       (long)ldc, split_k, out_dtype, accumulate);
+                       (long)ldc, split_k, out_dtype, accumulate, p.bgrad_slabs, p.bgrad, p.bgrad_acc);
     CFHIP_CHECK_LAUNCH("splitk_reduce");
   }
   return CFHIP_OK;

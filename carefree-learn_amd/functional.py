@@ -111,6 +111,13 @@ def _linear_param_grads(dy2: Tensor, x2: Tensor, weight: Tensor, bias: Optional[
     def dw_into(out: Tensor, acc: bool) -> None:
         ops.gemm(dy2, x2, a_trans=True, b_trans=True, out=out, accumulate=acc, split_k=split)
 
+    fast_ok = dy2.shape[1] % 8 == 0 and x2.shape[1] % 8 == 0 and dy2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0
+    if (weight.requires_grad and weight_direct and bias is not None and bias.requires_grad and bias_direct
+            and fast_ok):
+        from .fused import _dw_db  # one launch for dW and db
+
+        _dw_db(weight, bias, dy2, x2)
+        return None, None
     if weight.requires_grad:
         if weight_direct:
             write_param_grad(weight, dw_into)

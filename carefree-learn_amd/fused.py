@@ -20,22 +20,40 @@ from torch import Tensor
 from torch.autograd import Function
 
 from . import ops
-from .functional import bf16, f32, shadow_bf16, write_param_grad
+from .functional import bf16, f32, shadow_bf16
 
 
-def _dw(param: Tensor, dy2: Tensor, x2: Tensor) -> None:
-    n, k = param.shape[0], x2.shape[1]
+# The dW GEMM can also produce db = colsum(dy) (cfhip_gemm_bf16's `bias_grad`).  Measured on ViT-B/16
+# (profiles/r01): the waves that own the extra row sums slow their whole workgroup down by more than
+# the two small column-sum kernels cost (+0.7 ms vs -0.65 ms per step), so the stand-alone kernels
+# stay the default.
+FUSE_BIAS_GRAD = False
+
+
+def _dw_db(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> None:
+    """dW = dy^T x and db = colsum(dy) from ONE split-K GEMM launch (the bias gradient rides on a
+    ones-operand MFMA inside the dW kernel), both written straight into `.grad`."""
+    from .functional import grad_ready_callbacks
+
+    n, k = w.shape[0], x2.shape[1]
     split = ops.pick_split_k(n, k, x2.shape[0])
-    write_param_grad(
-        param,
-        lambda out, acc: ops.gemm(dy2, x2, a_trans=True, b_trans=True, out=out.view(n, k),
-                                  accumulate=acc, split_k=split),
-    )
-
-
-def _db(param: Optional[Tensor], dy2: Tensor) -> None:
-    if param is not None and param.requires_grad:
-        write_param_grad(param, lambda out, acc: ops.colsum(dy2, out=out.view(-1), accumulate=acc))
+    prms = [w] + ([b] if (b is not None and b.requires_grad) else [])
+    for prm in prms:
+        if prm.grad is None:
+            prm.grad = torch.empty(prm.shape, dtype=f32, device=prm.device)
+            prm._cfhip_fresh = True
+    acc_w = not getattr(w, "_cfhip_fresh", False)
+    kw = {}
+    if len(prms) == 2:
+        if FUSE_BIAS_GRAD:
+            kw = dict(bias_grad=b.grad.view(-1), bias_grad_accumulate=not getattr(b, "_cfhip_fresh", False))
+        else:
+            ops.colsum(dy2, out=b.grad.view(-1), accumulate=not getattr(b, "_cfhip_fresh", False))
+    ops.gemm(dy2, x2, a_trans=True, b_trans=True, out=w.grad.view(n, k), accumulate=acc_w, split_k=split, **kw)
+    for prm in prms:
+        prm._cfhip_fresh = False
+        for cb in grad_ready_callbacks:
+            cb(prm)
 
 
 def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: Tensor,
@@ -109,25 +127,21 @@ class MixingBlockFn(Function):
 
         # channel mixing
         dpre = ops.gemm(d2, w2_16, b_trans=True, epilogue=ops.EPI_DGELU, aux_in=pre)
-        _dw(w2, d2, h)
-        _db(b2, d2)
+        _dw_db(w2, b2, d2, h)
         dln2 = ops.gemm(dpre, w1_16, b_trans=True)
-        _dw(w1, dpre, ln2)
-        _db(b1, dpre)
+        _dw_db(w1, b1, dpre, ln2)
         dx1 = _ln_bwd(dln2, x1, ln2_w, ln2_b, mean2, rstd2, dx_add=d2)
 
         # token mixing
         d_o = ops.gemm(dx1, out_w16, b_trans=True)
-        _dw(out_w, dx1, o2)
-        _db(out_b, dx1)
+        _dw_db(out_w, out_b, dx1, o2)
         dqkv = torch.empty_like(qkv)
         qkv3, dqkv3 = qkv.view(bsz, t, 3 * d), dqkv.view(bsz, t, 3 * d)
         ops.attn_bwd(qkv3[..., :d], qkv3[..., d:2 * d], qkv3[..., 2 * d:], o2.view(bsz, t, d),
                      d_o.view(bsz, t, d), lse, num_heads, dq=dqkv3[..., :d], dk=dqkv3[..., d:2 * d],
                      dv=dqkv3[..., 2 * d:], mask=keep_mask, causal=causal)
         dln1 = ops.gemm(dqkv, in_w16, b_trans=True)
-        _dw(in_w, dqkv, ln1)
-        _db(qkv_b, dqkv)
+        _dw_db(in_w, qkv_b, dqkv, ln1)
         dx = _ln_bwd(dln1, x2, ln1_w, ln1_b, mean1, rstd1, dx_add=dx1)
         return (dx.view(bsz, t, d),) + (None,) * 17
 

@@ -71,8 +71,11 @@ def gemm(
     out_dtype: torch.dtype = bf16,
     accumulate: bool = False,
     split_k: int = 1,
+    bias_grad: Optional[Tensor] = None,
+    bias_grad_accumulate: bool = False,
 ) -> Tensor:
-    """C[m,n] = epilogue(sum_k A(m,k) B(n,k)); see cfhip_gemm_bf16 in include/cfhip.h."""
+    """C[m,n] = epilogue(sum_k A(m,k) B(n,k)); see cfhip_gemm_bf16 in include/cfhip.h.
+    `bias_grad` (f32 [M], layout a_trans & b_trans only): (+)= sum_k A(m,k), i.e. colsum(dY) of a dW GEMM."""
     _need(a, bf16, "a")
     _need(b, bf16, "b")
     ra, ca, lda = _mat(a, "a")
@@ -98,14 +101,18 @@ def gemm(
             _need(t, f32 if (nm == "aux_in" and epilogue == EPI_RESIDUAL and out.dtype == f32) else bf16, nm)
             if tuple(t.shape) != (m, n) or t.stride(1) != 1 or t.stride(0) != ldc:
                 raise ValueError(f"cfhip gemm: `{nm}` must match the output layout")
+    if bias_grad is not None:
+        _need(bias_grad, f32, "bias_grad")
+        if bias_grad.numel() != m or not bias_grad.is_contiguous():
+            raise ValueError("cfhip gemm: bias_grad must be a contiguous f32 [M]")
     ws, ws_bytes = None, 0
     if split_k > 1:
-        ws = torch.empty((split_k * m * n,), dtype=f32, device=a.device)
+        ws = torch.empty((split_k * m * (n + (1 if bias_grad is not None else 0)),), dtype=f32, device=a.device)
         ws_bytes = ws.numel() * 4
     rc = _lib.load().cfhip_gemm_bf16(
         a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(bias), _p(aux_in), _p(aux_out), m, n, k, lda,
         ldb, ldc, int(a_trans), int(b_trans), epilogue, 1 if out.dtype == f32 else 0,
-        int(accumulate), split_k, _p(ws), ws_bytes, _stream(),
+        int(accumulate), split_k, _p(ws), ws_bytes, _p(bias_grad), int(bias_grad_accumulate), _stream(),
     )
     _lib.check(rc, "gemm")
     return out

@@ -61,6 +61,9 @@ int cfhip_set_option(const char* name, int value);
  *   out_dtype: 0 = bf16, 1 = f32.   accumulate != 0 (f32 output only): C += result.
  *   split_k > 1: the K range is cut in `split_k` slices, partial tiles go to `workspace`
  *     (needs split_k*M*N*4 bytes) and a second kernel reduces them (epilogue NONE only).
+ *   bias_grad (layout (1,1) only, else NULL): f32 [M], (+)= sum_k A(m,k) — for dW = dY^T X this is
+ *     the bias gradient colsum(dY), produced by the same kernel with a ones-operand MFMA
+ *     (workspace then needs split_k*M*4 more bytes).
  * ------------------------------------------------------------------------------------------ */
 #define CFHIP_EPI_NONE 0
 #define CFHIP_EPI_GELU 1
@@ -70,7 +73,8 @@ int cfhip_set_option(const char* name, int value);
 int cfhip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, const void* aux_in,
                     void* aux_out, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                     int a_trans, int b_trans, int epilogue, int out_dtype, int accumulate,
-                    int split_k, void* workspace, size_t workspace_bytes, void* stream);
+                    int split_k, void* workspace, size_t workspace_bytes, float* bias_grad,
+                    int bias_grad_accumulate, void* stream);
 
 /* column sums of a bf16 matrix: out[n] (f32) (+)= sum_m X[m*ldx + n]   (bias gradients)
  * workspace: >= cfhip_colsum_workspace(M, N) bytes. */

@@ -34,7 +34,7 @@ def test_version_and_error_string():
     lib = _lib.load()
     assert lib.cfhip_version() == 100
     # invalid arguments are rejected before any launch, with a message
-    rc = lib.cfhip_gemm_bf16(None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1, None, 0, None)
+    rc = lib.cfhip_gemm_bf16(None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1, None, 0, None, 0, None)
     assert rc == -1
     assert b"null" in lib.cfhip_last_error()
     rc = lib.cfhip_layernorm_fwd(1, 0, 1, 1, 1, None, None, 4, 6, 8, 8, 1e-6, None)

@@ -157,3 +157,39 @@ def test_colsum():
     x = _mk(300, 768, 21).to(DEV)
     ops.colsum(x, out=out, accumulate=True)
     assert_close(out, x.float().sum(0) + 1, 1e-5, "colsum acc")
+
+
+def test_fused_bias_gradient_of_dw_gemm():
+    """dW = dY^T X with bias_grad: the ones-operand MFMA must give colsum(dY) for every split / tail."""
+    for (kd, n, k) in ((4000, 256, 384), (12608, 768, 768), (200, 136, 72), (64, 1000, 768)):
+        dy, x = _mk(kd, n, 30).to(DEV), _mk(kd, k, 31).to(DEV)
+        want_w = dy.float().t().double() @ x.float().double()
+        want_b = dy.float().sum(0)
+        for split in (1, 3, ops.pick_split_k(n, k, kd)):
+            gw = torch.empty(n, k, dtype=torch.float32, device=DEV)
+            gb = torch.full((n,), 7.0, dtype=torch.float32, device=DEV)
+            ops.gemm(dy, x, a_trans=True, b_trans=True, out=gw, split_k=split, bias_grad=gb)
+            assert_close(gw, want_w, 2e-5, f"dW {kd}x{n}x{k} split {split}")
+            assert_close(gb, want_b, 2e-5, f"db {kd}x{n}x{k} split {split}")
+            ops.gemm(dy, x, a_trans=True, b_trans=True, out=gw, accumulate=True, split_k=split, bias_grad=gb,
+                     bias_grad_accumulate=True)
+            assert_close(gb, 2 * want_b, 2e-5, "db accumulate")
+            assert_close(gw, 2 * want_w, 2e-5, "dW accumulate")
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+def test_every_tile_config(cfg):
+    """all tile configurations of the kernel on ragged shapes, all three layouts"""
+    try:
+        ops.set_option("gemm_config", cfg)
+        for (m, n, k) in ((333, 264, 200), (128, 64, 32), (520, 1000, 72)):
+            for layout in ("nt", "nn", "tn"):
+                a_trans, b_trans = layout == "tn", layout in ("nn", "tn")
+                if a_trans and m % 8:
+                    continue
+                a = _mk(k, m, 40) if a_trans else _mk(m, k, 40)
+                b = _mk(k, n, 41) if b_trans else _mk(n, k, 41)
+                got = ops.gemm(a.to(DEV), b.to(DEV), a_trans=a_trans, b_trans=b_trans, out_dtype=torch.float32)
+                assert_close(got, _ref(a, b, a_trans, b_trans), 2e-5, f"cfg{cfg} {layout} {m}x{n}x{k}")
+    finally:
+        ops.set_option("gemm_config", -1)
