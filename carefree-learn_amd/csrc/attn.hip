@@ -43,14 +43,23 @@ __device__ __forceinline__ int tile_off(int row, int col) {
   return row * 128 + ((((col >> 3) ^ ((row >> 1) & 7))) << 4) + ((col & 7) << 1);
 }
 
-// cooperative load of `rows_pad` rows (zero beyond rows_valid) of one head into a swizzled tile
-__device__ __forceinline__ void load_tile(char* tile, const bf16_t* base, long stride_t, int rows_valid,
-                                          int rows_pad) {
-  for (int idx = threadIdx.x; idx < rows_pad * 8; idx += blockDim.x) {
-    const int row = idx >> 3, slot = idx & 7;
-    u32x4 val = {0u, 0u, 0u, 0u};
-    if (row < rows_valid) val = *reinterpret_cast<const u32x4*>(base + (long)row * stride_t + slot * 8);
-    *reinterpret_cast<u32x4*>(tile + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = val;
+// Cooperative asynchronous load of `rows_pad` rows (zero beyond rows_valid) of one head into a swizzled
+// tile: LDS-DMA (buffer_load_dwordx4 ... lds), one instruction = 8 rows x 128 B, no VGPR staging.  The
+// LDS image of the DMA is lane-linear, so the 16-byte-slot swizzle is applied to the SOURCE address;
+// rows past the end are range-checked to zero by the buffer descriptor.  Completion = the issuing
+// wave's vmcnt, then a workgroup barrier.
+__device__ __forceinline__ void dma_tile(char* tile, const bf16_t* base, long stride_t, int rows_valid,
+                                         int rows_pad, int wave, int nwaves, int lane) {
+  long bytes = ((long)(rows_valid - 1) * stride_t + DH) * 2;
+  if (bytes > 0x7fffffffL) bytes = 0x7fffffffL;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, (int)bytes, 0x00020000);
+  const int r8 = lane >> 3, slot = lane & 7;
+  for (int inst = wave; inst < rows_pad / 8; inst += nwaves) {
+    const int row = inst * 8 + r8;
+    const int chunk = slot ^ ((row >> 1) & 7);
+    const unsigned off = row < rows_valid ? (unsigned)(row * stride_t * 2 + chunk * 16) : 0x80000000u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(tile + inst * 1024), 16, off, 0, 0, 0);
   }
 }
 
@@ -125,15 +134,15 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   const int nwaves = blockDim.x >> 6;
   const bf16_t* kb = p.k + (long)b * p.kv_sb + h * DH;
   const bf16_t* vb = p.v + (long)b * p.kv_sb + h * DH;
-  load_tile(Ks, kb, p.kv_st, p.Tk, NB * 32);
-  load_tile(Vs, vb, p.kv_st, p.Tk, NB * 32);
-  __syncthreads();
+  dma_tile(Ks, kb, p.kv_st, p.Tk, NB * 32, wave, nwaves, lane);
+  dma_tile(Vs, vb, p.kv_st, p.Tk, NB * 32, wave, nwaves, lane);
+  __syncthreads();  // (drains the DMA: vmcnt(0) + barrier)
 
-  const int row0 = (blockIdx.x * nwaves + wave) * 16;
-  if (row0 >= p.Tq) return;
   const int i = lane & 15, g = lane >> 4;
-  const int qi = row0 + i;
   const bf16_t* qb = p.q + (long)b * p.q_sb + h * DH;
+  // K / V are loaded once per (batch, head); the waves walk the query tiles
+  for (int row0 = (blockIdx.x * nwaves + wave) * 16; row0 < p.Tq; row0 += gridDim.x * nwaves * 16) {
+  const int qi = row0 + i;
   const bf16x8 qf0 = frag_global(qb, p.q_st, row0, p.Tq, 0, lane);
   const bf16x8 qf1 = frag_global(qb, p.q_st, row0, p.Tq, 1, lane);
 
@@ -154,8 +163,9 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int j = jt * 16 + 4 * g + r;
-      const bool keep = plain ? (j < p.Tk) : keep_at(p, b, h, qi < p.Tq ? qi : p.Tq - 1, j);
-      const float x = keep ? st[jt][r] * sl2 : -INFINITY;
+      float x = st[jt][r] * sl2;
+      if (!plain) x = keep_at(p, b, h, qi < p.Tq ? qi : p.Tq - 1, j) ? x : -INFINITY;
+      else if (jt * 16 + 15 >= p.Tk) x = (j < p.Tk) ? x : -INFINITY;  // only the tile straddling Tk
       st[jt][r] = x;
       mx = fmaxf(mx, x);
     }
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   for (int jt = 0; jt < 2 * NB; ++jt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float e = exp2f(st[jt][r] - mx);
+      const float e = __builtin_amdgcn_exp2f(st[jt][r] - mx);  // raw v_exp_f32: arguments are <= 0
       st[jt][r] = e;
       l += e;
     }
@@ -196,6 +206,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
     if (g == 0 && p.lse != nullptr)
       p.lse[((long)b * p.H + h) * p.Tq + qi] = (mx + log2f(l)) * (1.0f / LOG2E);
   }
+  }  // query-tile loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -209,13 +220,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p, int nb) 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
-  load_tile(Ks, p.k + (long)b * p.kv_sb + h * DH, p.kv_st, p.Tk, nb * 32);
-  load_tile(Vs, p.v + (long)b * p.kv_sb + h * DH, p.kv_st, p.Tk, nb * 32);
+  dma_tile(Ks, p.k + (long)b * p.kv_sb + h * DH, p.kv_st, p.Tk, nb * 32, wave, nwaves, lane);
+  dma_tile(Vs, p.v + (long)b * p.kv_sb + h * DH, p.kv_st, p.Tk, nb * 32, wave, nwaves, lane);
   __syncthreads();
 
-  const int row0 = (blockIdx.x * nwaves + wave) * 16;
-  if (row0 >= p.Tq) return;
   const int i = lane & 15, g = lane >> 4;
+  for (int row0 = (blockIdx.x * nwaves + wave) * 16; row0 < p.Tq; row0 += gridDim.x * nwaves * 16) {
   const int qi = row0 + i;
   const bool qvalid = qi < p.Tq;
   const bf16_t* qb = p.q + (long)b * p.q_sb + h * DH;
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p, int nb) 
       for (int r = 0; r < 4; ++r) {
         const int j = jt * 16 + 4 * g + r;
         const bool keep = plain ? (j < p.Tk) : keep_at(p, b, h, qvalid ? qi : p.Tq - 1, j);
-        const float pr = keep ? exp2f(s[r] * sl2 - lse2) : 0.f;
+        const float pr = keep ? __builtin_amdgcn_exp2f(s[r] * sl2 - lse2) : 0.f;
         ds[t][r] = pr * (dp[r] - delta);
       }
     }
@@ -279,6 +289,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p, int nb) 
           u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
     }
   }
+  }  // query-tile loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -295,8 +306,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p, int nbq
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
-  load_tile(Qs, p.q + (long)b * p.q_sb + h * DH, p.q_st, p.Tq, nbq * 32);
-  load_tile(dOs, p.d_o + (long)b * p.o_sb + h * DH, p.o_st, p.Tq, nbq * 32);
+  dma_tile(Qs, p.q + (long)b * p.q_sb + h * DH, p.q_st, p.Tq, nbq * 32, wave, nwaves, lane);
+  dma_tile(dOs, p.d_o + (long)b * p.o_sb + h * DH, p.o_st, p.Tq, nbq * 32, wave, nwaves, lane);
   for (int t = threadIdx.x; t < nbq * 32; t += blockDim.x) {
     const long stat = ((long)b * p.H + h) * p.Tq + t;
     lse_s[t] = t < p.Tq ? p.lse[stat] * LOG2E : INFINITY;
@@ -304,10 +315,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p, int nbq
   }
   __syncthreads();
 
-  const int row0 = (blockIdx.x * nwaves + wave) * 16;  // kv rows of this wave
-  if (row0 >= p.Tk) return;
   const int n = lane & 15, g = lane >> 4;
-  const int kj = row0 + n;
+  for (int row0 = (blockIdx.x * nwaves + wave) * 16; row0 < p.Tk; row0 += gridDim.x * nwaves * 16) {
+  const int kj = row0 + n;  // kv rows of this wave
   const bf16_t* kb = p.k + (long)b * p.kv_sb + h * DH;
   const bf16_t* vb = p.v + (long)b * p.kv_sb + h * DH;
   const bf16x8 kf0 = frag_global(kb, p.kv_st, row0, p.Tk, 0, lane);
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p, int nbq
       for (int r = 0; r < 4; ++r) {
         const int qi = it * 16 + 4 * g + r;
         const bool keep = plain ? (kj < p.Tk) : (qi < p.Tq && keep_at(p, b, h, qi, kj));
-        const float pr = keep ? exp2f(s[r] * sl2 - l4[r]) : 0.f;
+        const float pr = keep ? __builtin_amdgcn_exp2f(s[r] * sl2 - l4[r]) : 0.f;
         pp[t][r] = pr;
         ds[t][r] = pr * (dp[r] - d4[r]);
       }
@@ -363,13 +373,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p, int nbq
           u32x2{pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3])};
     }
   }
+  }  // kv-tile loop
 }
 
-// waves per workgroup: cover the tiles with the fewest idle wave slots (at most 8 waves)
+// waves per workgroup: ONE workgroup per (batch, head) (the resident K / V — or Q / dO — tiles are
+// loaded once), its waves walk the 16-row tiles in rounds; pick the wave count that leaves the
+// fewest idle slots in the last round (at most 8 waves).
 inline int pick_waves(int T) {
   const int tiles = (T + 15) / 16;
-  const int groups = (tiles + 7) / 8;
-  return (tiles + groups - 1) / groups;
+  const int rounds = (tiles + 7) / 8;
+  return (tiles + rounds - 1) / rounds;
 }
 
 int check_common(const char* who, const void* q, const void* k, const void* v, int B, int H, int Tq, int Tk,
@@ -422,7 +435,8 @@ extern "C" int cfhip_attn_fwd(const void* q, const void* k, const void* v, void*
   const int nb = (Tk + 31) / 32;
   const int nw = pick_waves(Tq);
   const int tiles = (Tq + 15) / 16;
-  dim3 grid((tiles + nw - 1) / nw, H, B), block(nw * 64);
+  (void)tiles;
+  dim3 grid(1, H, B), block(nw * 64);
   const size_t lds = (size_t)2 * nb * 32 * 128;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define CFHIP_ATTN_FWD(NB_) \
@@ -465,7 +479,8 @@ extern "C" int cfhip_attn_bwd(const void* q, const void* k, const void* v, const
     const int nb = (Tk + 31) / 32;
     const int nw = pick_waves(Tq);
     const int tiles = (Tq + 15) / 16;
-    dim3 grid((tiles + nw - 1) / nw, H, B), block(nw * 64);
+    (void)tiles;
+    dim3 grid(1, H, B), block(nw * 64);
     const size_t lds = (size_t)2 * nb * 32 * 128;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, lds, s, p, nb);
     CFHIP_CHECK_LAUNCH("attn_bwd_dq");
@@ -474,7 +489,8 @@ extern "C" int cfhip_attn_bwd(const void* q, const void* k, const void* v, const
     const int nbq = (Tq + 31) / 32;
     const int nw = pick_waves(Tk);
     const int tiles = (Tk + 15) / 16;
-    dim3 grid((tiles + nw - 1) / nw, H, B), block(nw * 64);
+    (void)tiles;
+    dim3 grid(1, H, B), block(nw * 64);
     const size_t lds = (size_t)2 * nbq * 32 * 128 + (size_t)2 * nbq * 32 * sizeof(float);
     rc = set_lds(attn_bwd_dkv_kernel, lds, "attn_bwd_dkv");
     if (rc != CFHIP_OK) return rc;

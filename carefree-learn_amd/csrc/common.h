@@ -39,14 +39,16 @@ void cfhip_set_error(const char* fmt, ...);
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((unsigned)v) << 16);
 }
+// f32 -> bf16 goes through the native __bf16 type: hipcc lowers the cast to gfx950's
+// v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN-quieting) — one instruction per PAIR instead of
+// ~6 integer ops per element for a hand-rolled rounding.
+typedef __bf16 bf16x2_native __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
 }
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+  const bf16x2_native v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
 }
 __device__ __forceinline__ float bf16lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
