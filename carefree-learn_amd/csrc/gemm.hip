@@ -340,7 +340,7 @@ void gemm_bf16_kernel(GemmParams p) {
         const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
                          pack_bf16x2(hi[2], hi[3])};
         if (p.aux_out != nullptr) {
-          if (c_hi) *reinterpret_cast<u32x4*>(p.aux_out + off) = w;
+          if (c_hi) { if (p.ablate & 8) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p.aux_out + off)); else *reinterpret_cast<u32x4*>(p.aux_out + off) = w; }
           else *reinterpret_cast<u32x2*>(p.aux_out + off) = u32x2{w[0], w[1]};
         }
         lo = f32x4{gelu_erf_f(bf16lo(w[0])), gelu_erf_f(bf16hi(w[0])), gelu_erf_f(bf16lo(w[1])), gelu_erf_f(bf16hi(w[1]))};
@@ -374,7 +374,7 @@ void gemm_bf16_kernel(GemmParams p) {
         bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + off;
         const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
                          pack_bf16x2(hi[2], hi[3])};
-        if (c_hi) *reinterpret_cast<u32x4*>(dst) = w;
+        if (c_hi) { if (p.ablate & 8) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(dst)); else *reinterpret_cast<u32x4*>(dst) = w; }
         else *reinterpret_cast<u32x2*>(dst) = u32x2{w[0], w[1]};
       }
     }

@@ -137,7 +137,10 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
   }
 }
 
-template <int NCH, bool EXACT, typename XT>
+// DO_DX / DO_PG select what the launch produces: the input gradient (critical path of backward:
+// no per-column accumulators, high occupancy), the dgamma / dbeta partials (a pure streaming column
+// reduction that can run on the side stream), or both in one pass.
+template <int NCH, bool EXACT, typename XT, bool DO_DX, bool DO_PG>
 __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
     const bf16_t* __restrict__ dy, const XT* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
@@ -148,8 +151,10 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
   const int wave = threadIdx.x >> 6;
   const int gw = blockIdx.x * LN_WAVES + wave;
   const int nw = gridDim.x * LN_WAVES;
-  for (int i = threadIdx.x; i < 2 * D; i += LN_THREADS) red[i] = 0.f;
-  __syncthreads();
+  if (DO_PG) {
+    for (int i = threadIdx.x; i < 2 * D; i += LN_THREADS) red[i] = 0.f;
+    __syncthreads();
+  }
 
   float gm[NCH][4], dg[NCH][4], db[NCH][4];
 #pragma unroll
@@ -194,8 +199,10 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
         g[c][e] = dv[e] * gm[c][e];
         s1 += g[c][e];
         s2 += g[c][e] * xh[c][e];
-        dg[c][e] += dv[e] * xh[c][e];
-        db[c][e] += dv[e];
+        if (DO_PG) {
+          dg[c][e] += dv[e] * xh[c][e];
+          db[c][e] += dv[e];
+        }
       }
     }
     // residual-gradient rows of THIS row and the operands of the NEXT row: all in flight together
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
-      addv[c] = (dx_add != nullptr && (EXACT || col < D))
+      addv[c] = (DO_DX && dx_add != nullptr && (EXACT || col < D))
                     ? *reinterpret_cast<const u32x2*>(dx_add + (long)row * dxs + col) : u32x2{0u, 0u};
     }
     if (row + nw < M) {
@@ -217,22 +224,25 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
       nmean = mean_in[row + nw];
       nrstd = rstd_in[row + nw];
     }
-    s1 = wave_sum_dpp(s1) * inv_d;
-    s2 = wave_sum_dpp(s2) * inv_d;
-    bf16_t* dxr = dx + (long)row * dxs;
+    if (DO_DX) {
+      s1 = wave_sum_dpp(s1) * inv_d;
+      s2 = wave_sum_dpp(s2) * inv_d;
+      bf16_t* dxr = dx + (long)row * dxs;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int col = c * 256 + lane * 4;
-      if (EXACT || col < D) {
-        float o[4];
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (EXACT || col < D) {
+          float o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rstd * (g[c][e] - s1 - xh[c][e] * s2);
-        o[0] += bf16lo(addv[c][0]); o[1] += bf16hi(addv[c][0]);
-        o[2] += bf16lo(addv[c][1]); o[3] += bf16hi(addv[c][1]);
-        store4(dxr + col, o);
+          for (int e = 0; e < 4; ++e) o[e] = rstd * (g[c][e] - s1 - xh[c][e] * s2);
+          o[0] += bf16lo(addv[c][0]); o[1] += bf16hi(addv[c][0]);
+          o[2] += bf16lo(addv[c][1]); o[3] += bf16hi(addv[c][1]);
+          store4(dxr + col, o);
+        }
       }
     }
   }
+  if (!DO_PG) return;
   // fold the workgroup's waves through LDS float atomics (ds_add_f32), one partial row per workgroup
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -309,7 +319,9 @@ extern "C" int cfhip_layernorm_bwd(const void* dy, const void* x, int x_is_f32, 
                                    int64_t x_row_stride, int64_t dx_row_stride,
                                    int accumulate_param_grads, void* workspace,
                                    size_t workspace_bytes, void* stream) {
-  CFHIP_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
+  CFHIP_REQUIRE(dy && x && gamma && mean && rstd, "layernorm_bwd: null pointer");
+  const bool do_dx = dx != nullptr, do_pg = dgamma != nullptr || dbeta != nullptr;
+  CFHIP_REQUIRE(do_dx || do_pg, "layernorm_bwd: nothing to compute (dx, dgamma and dbeta are all NULL)");
   CFHIP_REQUIRE(M > 0 && D > 0, "layernorm_bwd: empty problem");
   CFHIP_REQUIRE(D % 4 == 0 && D <= 2048, "layernorm_bwd: D=%d must be a multiple of 4 and <= 2048", D);
   CFHIP_REQUIRE(dy_row_stride % 4 == 0 && x_row_stride % 4 == 0 && dx_row_stride % 4 == 0,
@@ -318,31 +330,36 @@ extern "C" int cfhip_layernorm_bwd(const void* dy, const void* x, int x_is_f32, 
                     ((uintptr_t)dx_add & 7) == 0,
                 "layernorm_bwd: tensors must be 8-byte aligned");
   const size_t need = cfhip_layernorm_bwd_workspace(M, D);
-  if (workspace == nullptr || workspace_bytes < need) {
+  if (do_pg && (workspace == nullptr || workspace_bytes < need)) {
     cfhip_set_error("layernorm_bwd: needs %zu workspace bytes, got %zu", need, workspace_bytes);
     return CFHIP_ERR_WORKSPACE;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int nch = (D + 255) / 256;
   const bool exact = (D % 256) == 0;
-  const int blocks = ln_grid(M);
+  const int blocks = ln_grid(M, do_pg ? 512 : 1024);  // dx-only: fewer registers, twice the waves
   float* partials = reinterpret_cast<float*>(workspace);
-  const size_t lds = (size_t)2 * D * sizeof(float);
-#define LN_BWD(N_, EX_)                                                                               \
-  do {                                                                                                 \
-    if (x_is_f32)                                                                                      \
-      hipLaunchKernelGGL((layernorm_bwd_kernel<N_, EX_, float>), dim3(blocks), dim3(LN_THREADS), lds, s, \
-                         (const bf16_t*)dy, (const float*)x, gamma, mean, rstd, (const bf16_t*)dx_add,   \
-                         (bf16_t*)dx, partials, M, D, (long)dy_row_stride, (long)x_row_stride,          \
-                         (long)dx_row_stride);                                                          \
-    else                                                                                               \
-      hipLaunchKernelGGL((layernorm_bwd_kernel<N_, EX_, bf16_t>), dim3(blocks), dim3(LN_THREADS), lds, s, \
-                         (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dx_add, \
-                         (bf16_t*)dx, partials, M, D, (long)dy_row_stride, (long)x_row_stride,          \
-                         (long)dx_row_stride);                                                          \
+  const size_t lds = do_pg ? (size_t)2 * D * sizeof(float) : 0;
+#define LN_BWD_ONE(N_, EX_, XT_, DX_, PG_)                                                               \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<N_, EX_, XT_, DX_, PG_>), dim3(blocks), dim3(LN_THREADS), lds, \
+                     s, (const bf16_t*)dy, (const XT_*)x, gamma, mean, rstd, (const bf16_t*)dx_add,       \
+                     (bf16_t*)dx, partials, M, D, (long)dy_row_stride, (long)x_row_stride,                \
+                     (long)dx_row_stride)
+#define LN_BWD_MODE(N_, EX_, XT_)                                     \
+  do {                                                                \
+    if (do_dx && do_pg) LN_BWD_ONE(N_, EX_, XT_, true, true);          \
+    else if (do_dx) LN_BWD_ONE(N_, EX_, XT_, true, false);             \
+    else LN_BWD_ONE(N_, EX_, XT_, false, true);                        \
+  } while (0)
+#define LN_BWD(N_, EX_)                        \
+  do {                                         \
+    if (x_is_f32) LN_BWD_MODE(N_, EX_, float); \
+    else LN_BWD_MODE(N_, EX_, bf16_t);         \
   } while (0)
   LN_DISPATCH(LN_BWD, nch, 0)
 #undef LN_BWD
+#undef LN_BWD_MODE
+#undef LN_BWD_ONE
   CFHIP_CHECK_LAUNCH("layernorm_bwd");
   if (dgamma != nullptr || dbeta != nullptr) {
     // partial rows are [2*D] wide: dgamma in the first half, dbeta in the second

@@ -21,6 +21,7 @@ import torch
 from torch import Tensor
 
 from . import ops
+from .functional import SideStream
 from .ddp import BucketedAllReduce
 from .optim import FusedAdam, ParamArena
 
@@ -53,6 +54,7 @@ class TrainStep:
         logits = out[self.output_key] if isinstance(out, dict) else out
         loss_sum, dlogits = ops.softmax_xent(logits, labels, 1.0 / logits.shape[0])
         logits.backward(dlogits)
+        SideStream.join()  # parameter-gradient kernels ran on the side stream
         if self.reducer is not None:
             self.reducer.finish()
         self.optimizer.launch_step()

@@ -27,6 +27,57 @@ grad_ready_callbacks: List[Callable[[Tensor], None]] = []
 
 
 # ---------------------------------------------------------------------------------------------
+# side HIP stream for the parameter-gradient kernels
+# ---------------------------------------------------------------------------------------------
+# In backward, dX = dY W (needed by the next layer: the critical path) and dW = dY^T X / db (needed
+# only by the optimizer) are independent.  Issuing the dW work on a second HIP stream lets the two
+# kernel queues interleave on the CUs: one kernel's store tail and partial last wave of workgroups
+# are filled by the other's MFMA work (measured in profiles/).  Inside a hipGraph capture the side
+# stream simply becomes a parallel branch of the graph.
+
+
+class SideStream:
+    enabled = True
+    stream: Optional["torch.cuda.Stream"] = None
+    keep: List[Tensor] = []  # operands produced on the main stream, alive until the join
+
+    _join_queued = False
+
+    @classmethod
+    def _end_of_backward(cls) -> None:
+        cls._join_queued = False
+        cls.join()
+
+    @classmethod
+    def run(cls, fn: Callable[[], None], keep: Tuple[Tensor, ...] = ()) -> None:
+        if not cls.enabled or not torch.cuda.is_available():
+            fn()
+            return
+        if not cls._join_queued:
+            # join automatically when the running backward pass ends, so that whoever reads `.grad`
+            # afterwards on the caller's stream is ordered after the side-stream kernels
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(cls._end_of_backward)
+                cls._join_queued = True
+            except RuntimeError:  # not inside a backward pass: stay on the current stream
+                fn()
+                return
+        if cls.stream is None:
+            cls.stream = torch.cuda.Stream()
+        cls.stream.wait_stream(torch.cuda.current_stream())  # everything issued so far is visible
+        with torch.cuda.stream(cls.stream):
+            fn()
+        cls.keep.extend(keep)
+
+    @classmethod
+    def join(cls) -> None:
+        """Make the current stream wait for the side stream (call before consuming parameter grads)."""
+        if cls.stream is not None:
+            torch.cuda.current_stream().wait_stream(cls.stream)
+        cls.keep.clear()
+
+
+# ---------------------------------------------------------------------------------------------
 # bf16 shadows of fp32 master parameters
 # ---------------------------------------------------------------------------------------------
 

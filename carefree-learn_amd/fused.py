@@ -20,7 +20,7 @@ from torch import Tensor
 from torch.autograd import Function
 
 from . import ops
-from .functional import bf16, f32, shadow_bf16
+from .functional import SideStream, bf16, f32, shadow_bf16
 
 
 # The dW GEMM can also produce db = colsum(dy) (cfhip_gemm_bf16's `bias_grad`).  Measured on ViT-B/16
@@ -58,27 +58,34 @@ def _dw_db(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> None:
 
 def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: Tensor,
             dx_add: Optional[Tensor]) -> Tensor:
-    """LayerNorm backward with the residual-gradient add fused; dgamma / dbeta go to `.grad`."""
-    gamma = w.detach()
-    for prm in (w, b):
-        if prm.grad is None:
-            prm.grad = torch.empty(prm.shape, dtype=f32, device=prm.device)
-            prm._cfhip_fresh = True
-    acc_w = not getattr(w, "_cfhip_fresh", False)
-    acc_b = not getattr(b, "_cfhip_fresh", False)
-    if acc_w != acc_b:
-        for prm in (w, b):
-            if getattr(prm, "_cfhip_fresh", False):
-                prm.grad.zero_()
-        acc_w = True
-    dx, _, _ = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dx_add=dx_add, dgamma=w.grad.view(-1),
-                                 dbeta=b.grad.view(-1), accumulate=acc_w)
+    """LayerNorm backward, split in two launches: the input gradient (with the residual-gradient add
+    fused) on the main stream — it is the critical path — and dgamma / dbeta (a streaming column
+    reduction straight into `.grad`) on the side stream."""
     from .functional import grad_ready_callbacks
 
-    for prm in (w, b):
-        prm._cfhip_fresh = False
-        for cb in grad_ready_callbacks:
-            cb(prm)
+    gamma = w.detach()
+
+    def param_grads() -> None:
+        for prm in (w, b):
+            if prm.grad is None:
+                prm.grad = torch.empty(prm.shape, dtype=f32, device=prm.device)
+                prm._cfhip_fresh = True
+        acc_w = not getattr(w, "_cfhip_fresh", False)
+        acc_b = not getattr(b, "_cfhip_fresh", False)
+        if acc_w != acc_b:
+            for prm in (w, b):
+                if getattr(prm, "_cfhip_fresh", False):
+                    prm.grad.zero_()
+            acc_w = True
+        ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dgamma=w.grad.view(-1), dbeta=b.grad.view(-1),
+                          accumulate=acc_w, want_dx=False)
+        for prm in (w, b):
+            prm._cfhip_fresh = False
+            for cb in grad_ready_callbacks:
+                cb(prm)
+
+    SideStream.run(param_grads, (dy2, x2, mean, rstd))
+    dx, _, _ = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dx_add=dx_add, want_param_grads=False)
     return dx
 
 
@@ -125,23 +132,25 @@ class MixingBlockFn(Function):
             dy = ops.to_bf16(dy.float().contiguous())
         d2 = dy.contiguous().view(bsz * t, d)
 
+        # Parameter-gradient GEMMs go to the side stream BEFORE their sibling dX GEMM is issued, so the
+        # two run concurrently; the dX chain on the main stream is the critical path.
         # channel mixing
+        SideStream.run(lambda: _dw_db(w2, b2, d2, h), (d2, h))
         dpre = ops.gemm(d2, w2_16, b_trans=True, epilogue=ops.EPI_DGELU, aux_in=pre)
-        _dw_db(w2, b2, d2, h)
+        SideStream.run(lambda: _dw_db(w1, b1, dpre, ln2), (dpre, ln2))
         dln2 = ops.gemm(dpre, w1_16, b_trans=True)
-        _dw_db(w1, b1, dpre, ln2)
         dx1 = _ln_bwd(dln2, x1, ln2_w, ln2_b, mean2, rstd2, dx_add=d2)
 
         # token mixing
+        SideStream.run(lambda: _dw_db(out_w, out_b, dx1, o2), (dx1, o2))
         d_o = ops.gemm(dx1, out_w16, b_trans=True)
-        _dw_db(out_w, out_b, dx1, o2)
         dqkv = torch.empty_like(qkv)
         qkv3, dqkv3 = qkv.view(bsz, t, 3 * d), dqkv.view(bsz, t, 3 * d)
         ops.attn_bwd(qkv3[..., :d], qkv3[..., d:2 * d], qkv3[..., 2 * d:], o2.view(bsz, t, d),
                      d_o.view(bsz, t, d), lse, num_heads, dq=dqkv3[..., :d], dk=dqkv3[..., d:2 * d],
                      dv=dqkv3[..., 2 * d:], mask=keep_mask, causal=causal)
+        SideStream.run(lambda: _dw_db(in_w, qkv_b, dqkv, ln1), (dqkv, ln1))
         dln1 = ops.gemm(dqkv, in_w16, b_trans=True)
-        _dw_db(in_w, qkv_b, dqkv, ln1)
         dx = _ln_bwd(dln1, x2, ln1_w, ln1_b, mean1, rstd1, dx_add=dx1)
         return (dx.view(bsz, t, d),) + (None,) * 17
 

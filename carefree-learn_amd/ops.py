@@ -170,28 +170,32 @@ def layernorm_bwd(
     dgamma: Optional[Tensor] = None,
     dbeta: Optional[Tensor] = None,
     accumulate: bool = False,
-) -> Tuple[Tensor, Tensor, Tensor]:
+    want_dx: bool = True,
+    want_param_grads: bool = True,
+) -> Tuple[Optional[Tensor], Optional[Tensor], Optional[Tensor]]:
     """x bf16 or f32.  Returns (dx bf16 [M, D] (+ dx_add), dgamma f32 [D], dbeta f32 [D])."""
     _need(dy, bf16, "dy")
     _need(x, x.dtype if x.dtype in (bf16, f32) else bf16, "x")
     m, d, xs = _mat(x, "x")
     _, _, dys = _mat(dy, "dy")
-    dx = torch.empty((m, d), dtype=bf16, device=x.device)
+    dx = torch.empty((m, d), dtype=bf16, device=x.device) if want_dx else None
     if dx_add is not None:
         _need(dx_add, bf16, "dx_add")
-        if tuple(dx_add.shape) != (m, d) or dx_add.stride(0) != dx.stride(0) or dx_add.stride(1) != 1:
+        if tuple(dx_add.shape) != (m, d) or dx_add.stride(0) != d or dx_add.stride(1) != 1:
             raise ValueError("cfhip layernorm_bwd: dx_add must be a dense [M, D] bf16 tensor")
-    if dgamma is None:
+    if not want_param_grads:
+        dgamma = dbeta = None
+    elif dgamma is None:
         dgamma = torch.empty((d,), dtype=f32, device=x.device)
         dbeta = torch.empty((d,), dtype=f32, device=x.device)
         accumulate = False
     lib = _lib.load()
-    nbytes = lib.cfhip_layernorm_bwd_workspace(m, d)
-    ws = torch.empty((nbytes // 4,), dtype=f32, device=x.device)
+    nbytes = lib.cfhip_layernorm_bwd_workspace(m, d) if want_param_grads else 0
+    ws = torch.empty((max(nbytes, 4) // 4,), dtype=f32, device=x.device)
     rc = lib.cfhip_layernorm_bwd(
         dy.data_ptr(), x.data_ptr(), int(x.dtype == f32), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
         _p(dx_add),
-        dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), m, d, dys, xs, dx.stride(0),
+        _p(dx), _p(dgamma), _p(dbeta), m, d, dys, xs, d,
         int(accumulate), ws.data_ptr(), nbytes, _stream(),
     )
     _lib.check(rc, "layernorm_bwd")

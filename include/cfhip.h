@@ -92,7 +92,9 @@ int cfhip_colsum_bf16(const void* X, float* out, int M, int N, int64_t ldx, int 
  *   x_row_stride / y_row_stride in elements (lets the head LN read token 0 of every sample).
  *   fwd saves mean / rstd (f32 [M]) for bwd.
  *   bwd: dx (bf16) = LN'(dy) [+ dx_add (bf16) if not NULL]; dgamma / dbeta (f32 [D]) (+)= ...
- *        workspace >= cfhip_layernorm_bwd_workspace(M, D) bytes.
+ *        workspace >= cfhip_layernorm_bwd_workspace(M, D) bytes.  dx == NULL: parameter gradients
+ *        only; dgamma == dbeta == NULL: input gradient only (two launches that can run on two
+ *        streams: dx is the critical path of backward, the parameter gradients are not).
  * ------------------------------------------------------------------------------------------ */
 int cfhip_layernorm_fwd(const void* x, int x_is_f32, const float* gamma, const float* beta, void* y,
                         float* mean, float* rstd, int M, int D, int64_t x_row_stride,

@@ -130,3 +130,22 @@ def test_sumsq_and_xent():
     ref.backward()
     assert abs(loss.item() / 64 - ref.item()) < 1e-5 * abs(ref.item()) + 1e-6
     assert_close(dl, lf.grad, 1e-5, "dlogits")
+
+
+def test_layernorm_bwd_split_modes():
+    """dx-only and parameter-gradient-only launches give the same numbers as the combined one."""
+    m, d = 1000, 768
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(m, d, generator=g).to(DEV)  # f32 residual stream
+    dy = torch.randn(m, d, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(d, generator=g) * 0.2 + 1).to(DEV)
+    b = torch.zeros(d, device=DEV)
+    _, mean, rstd = ops.layernorm_fwd(x, w, b, 1e-6)
+    dx_all, dg_all, db_all = ops.layernorm_bwd(dy, x, w, mean, rstd, dx_add=dy)
+    dx_only, none1, none2 = ops.layernorm_bwd(dy, x, w, mean, rstd, dx_add=dy, want_param_grads=False)
+    assert none1 is None and none2 is None and torch.equal(dx_only, dx_all)
+    pg = torch.zeros(2 * d, device=DEV)
+    nodx, _, _ = ops.layernorm_bwd(dy, x, w, mean, rstd, dgamma=pg[:d], dbeta=pg[d:], want_dx=False)
+    assert nodx is None
+    assert_close(pg[:d], dg_all, 1e-5, "dgamma split")
+    assert_close(pg[d:], db_all, 1e-5, "dbeta split")
