@@ -43,7 +43,7 @@ SIGNATURES = {
     "cfhip_attn_bwd": (
         c_int,
         [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64,
-         c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, _P],
+         c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_int, _P],
     ),
     "cfhip_im2row": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cfhip_assemble_tokens_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -36,6 +36,7 @@ struct AttnParams {
   long ms_b, ms_h, ms_q;
   float scale;
   int causal;
+  int delta_ready;  // dK/dV pass: p.delta was already written by the dQ pass of the same call
 };
 
 // byte offset of element (row, col) in a swizzled [rows][64] bf16 tile (128 B per row)
@@ -308,10 +309,29 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p, int nbq
   const int nwaves = blockDim.x >> 6;
   dma_tile(Qs, p.q + (long)b * p.q_sb + h * DH, p.q_st, p.Tq, nbq * 32, wave, nwaves, lane);
   dma_tile(dOs, p.d_o + (long)b * p.o_sb + h * DH, p.o_st, p.Tq, nbq * 32, wave, nwaves, lane);
-  for (int t = threadIdx.x; t < nbq * 32; t += blockDim.x) {
-    const long stat = ((long)b * p.H + h) * p.Tq + t;
-    lse_s[t] = t < p.Tq ? p.lse[stat] * LOG2E : INFINITY;
-    delta_s[t] = t < p.Tq ? p.delta[stat] : 0.f;
+  // lse and delta_i = sum_d dO[i][d] * O[i][d] of every query row (delta is recomputed here from the
+  // L2-resident dO / O rows so that this pass does not depend on the dQ pass: the two kernels run
+  // concurrently on two streams).  8 consecutive lanes own the 8 16-byte slots of one row.
+  for (int idx = threadIdx.x; idx < nbq * 32 * 8; idx += blockDim.x) {
+    const int t = idx >> 3, slot = idx & 7;
+    float s = 0.f;
+    if (p.delta_ready) {
+      if (slot == 0 && t < p.Tq) s = p.delta[((long)b * p.H + h) * p.Tq + t];
+    } else if (t < p.Tq) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(p.d_o + (long)b * p.o_sb + (long)t * p.o_st + h * DH + slot * 8);
+      const u32x4 c = *reinterpret_cast<const u32x4*>(p.o_in + (long)b * p.o_sb + (long)t * p.o_st + h * DH + slot * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += bf16lo(a[e]) * bf16lo(c[e]) + bf16hi(a[e]) * bf16hi(c[e]);
+    }
+    if (!p.delta_ready) {
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+    }
+    if (slot == 0) {
+      delta_s[t] = s;
+      lse_s[t] = t < p.Tq ? p.lse[((long)b * p.H + h) * p.Tq + t] * LOG2E : INFINITY;
+    }
   }
   __syncthreads();
 
@@ -456,7 +476,7 @@ extern "C" int cfhip_attn_bwd(const void* q, const void* k, const void* v, const
                               void* dv, int B, int H, int Tq, int Tk, int64_t q_stride_b,
                               int64_t q_stride_t, int64_t kv_stride_b, int64_t kv_stride_t,
                               int64_t o_stride_b, int64_t o_stride_t, int64_t ms_b, int64_t ms_h,
-                              int64_t ms_q, float scale, int causal, void* stream) {
+                              int64_t ms_q, float scale, int causal, int parts, void* stream) {
   int rc = check_common("attn_bwd", q, k, v, B, H, Tq, Tk, q_stride_b, q_stride_t, kv_stride_b,
                         kv_stride_t, o_stride_b, o_stride_t);
   if (rc != CFHIP_OK) return rc;
@@ -475,7 +495,9 @@ extern "C" int cfhip_attn_bwd(const void* q, const void* k, const void* v, const
   p.ms_b = ms_b; p.ms_h = ms_h; p.ms_q = ms_q;
   p.scale = scale; p.causal = causal;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  {
+  p.delta_ready = (parts & 3) == 3;
+  CFHIP_REQUIRE((parts & 3) != 0, "attn_bwd: parts must select the dQ pass (1), the dK/dV pass (2) or both (3)");
+  if (parts & 1) {
     const int nb = (Tk + 31) / 32;
     const int nw = pick_waves(Tq);
     const int tiles = (Tq + 15) / 16;
@@ -485,7 +507,7 @@ extern "C" int cfhip_attn_bwd(const void* q, const void* k, const void* v, const
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, lds, s, p, nb);
     CFHIP_CHECK_LAUNCH("attn_bwd_dq");
   }
-  {
+  if (parts & 2) {
     const int nbq = (Tq + 31) / 32;
     const int nw = pick_waves(Tk);
     const int tiles = (Tk + 15) / 16;

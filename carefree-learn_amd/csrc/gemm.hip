@@ -36,7 +36,7 @@ struct GemmParams {
   int epilogue, out_f32, accumulate;
   int k_chunk;   // K range per z-slice (multiple of BK), == K rounded up when no split
   float* slabs;  // split-K partials [z][M][N] or nullptr
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n, splits;
   float* bgrad;        // (1,1) layout only: out[m] (+)= sum_k A(m,k)  — the bias gradient of a dW GEMM
   float* bgrad_slabs;  // split-K partials [z][M] of the above
   int bgrad_acc;
@@ -198,184 +198,238 @@ __device__ __forceinline__ void bias_rows(const char* a_tile, int wm, int lane, 
 
 #define CFHIP_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
-// K loop = NSTAGE-deep LDS ring fed by LDS-DMA.  The DMA of K-step t + NSTAGE - 1 is issued right
-// after the barrier of step t and stays in flight ACROSS the following barriers: waits are counted
-// (`s_waitcnt vmcnt(N)` with N = loads of the younger stages), the barrier is the raw s_barrier
-// (a `__syncthreads()` would drain vmcnt to 0).  One barrier per K-step:
-//   RAW: a wave passes barrier(t) only after its own DMA for step t has landed  -> all of step t is in LDS;
-//   WAR: the DMA issued after barrier(t) overwrites the buffer read in step t-1 -> every wave is past it.
+// Work item = (output tile, K slice).  Everything a wave needs to stream one item.
+template <bool AT, bool BT, class C>
+struct ItemCtx {
+  int m0, n0, z, klen, nk, tile_n;
+  __amdgpu_buffer_rsrc_t a_rsrc, b_rsrc;
+  StagePlan<C::A_INSTR> pa;
+  StagePlan<C::B_INSTR> pb;
+};
+
+template <bool AT, bool BT, class C>
+__device__ __forceinline__ ItemCtx<AT, BT, C> setup_item(const GemmParams& p, int item, int wave, int lane) {
+  ItemCtx<AT, BT, C> c;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  c.z = item / ntiles;
+  const int tile = item - c.z * ntiles;
+  const int tile_m = tile / p.tiles_n;
+  c.tile_n = tile - tile_m * p.tiles_n;
+  c.m0 = tile_m * C::BM;
+  c.n0 = c.tile_n * C::BN;
+  const int kb = c.z * p.k_chunk;
+  c.klen = min(p.K - kb, p.k_chunk);
+  c.nk = (c.klen + C::BK - 1) / C::BK;
+  // buffer descriptors relative to this tile's origin (small 32-bit offsets, range-checked)
+  const int rows_a = p.M - c.m0, rows_b = p.N - c.n0;
+  const bf16_t* a_base = AT ? p.A + (long)kb * p.lda + c.m0 : p.A + (long)c.m0 * p.lda + kb;
+  const bf16_t* b_base = BT ? p.B + (long)kb * p.ldb + c.n0 : p.B + (long)c.n0 * p.ldb + kb;
+  const long a_bytes = AT ? ((long)(c.klen - 1) * p.lda + rows_a) * 2 : ((long)(rows_a - 1) * p.lda + c.klen) * 2;
+  const long b_bytes = BT ? ((long)(c.klen - 1) * p.ldb + rows_b) * 2 : ((long)(rows_b - 1) * p.ldb + c.klen) * 2;
+  c.a_rsrc = make_rsrc(a_base, a_bytes);
+  c.b_rsrc = make_rsrc(b_base, b_bytes);
+  c.pa = make_plan<AT, C::BM, C::A_INSTR, C::BK>(wave, lane, p.lda, rows_a);
+  c.pb = make_plan<BT, C::BN, C::B_INSTR, C::BK>(wave, lane, p.ldb, rows_b);
+  return c;
+}
+
+template <bool AT, bool BT, class C>
+__device__ __forceinline__ void stage_step(const ItemCtx<AT, BT, C>& c, const GemmParams& p, char* smem,
+                                           int slot, int wave, int kstep) {
+  char* st = smem + slot * C::STAGE_BYTES;
+  stage_tile<AT>(c.a_rsrc, st, wave, c.pa, p.lda, kstep * C::BK, c.klen);
+  stage_tile<BT>(c.b_rsrc, st + C::A_BYTES, wave, c.pb, p.ldb, kstep * C::BK, c.klen);
+}
+
+// PERSISTENT kernel: the grid is (#CUs x resident workgroups per CU); every workgroup walks work
+// items item, item + G, ... and treats them as ONE long K loop over an NSTAGE-deep LDS ring fed by
+// LDS-DMA:
+//   * inside an item the DMA of K-step t + D (D = NSTAGE-1) is issued right after the barrier of
+//     step t and stays in flight ACROSS barriers: waits are counted (`s_waitcnt vmcnt(N)`), the
+//     barrier is the raw s_barrier (a `__syncthreads()` would drain vmcnt to 0).  One barrier per
+//     K-step — RAW: a wave passes barrier(t) only after its own DMA of step t landed; WAR: the DMA
+//     issued after barrier(t) overwrites the slot read in step t-1, which every wave has left;
+//   * at an item boundary the first D K-steps of the NEXT item are issued BEFORE the epilogue of the
+//     current one, into the ring slots the finished item no longer needs, so the pipeline-fill
+//     latency of the next tile and the drain of this tile's stores overlap (with K = 768 a tile has
+//     only 12-24 K-steps: fill + drain per tile was a third of the kernel);
+//   * the epilogue transposes the accumulators through the one ring slot that is free (the slot
+//     of the last K-step) — see below.
 template <bool AT, bool BT, int EPI, class C>
 __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD)
 void gemm_bf16_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int D = C::NSTAGE - 1;  // prefetch distance
+  static_assert(C::NW * 16 * (C::FN * 16) * 4 <= C::STAGE_BYTES, "epilogue staging must fit in one ring slot");
 
-  // XCD-aware, bijective workgroup remap: XCD x (= bid % 8) owns a contiguous tile range.
-  const int nwg = gridDim.x;
+  // XCD-aware, bijective remap of the persistent grid: XCD x (= bid % 8) owns a contiguous range of
+  // slots, hence in every round a contiguous range of tiles (neighbours share A / B panels in its L2).
+  const int G = gridDim.x;
   const int bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int q8 = G >> 3, r8 = G & 7;
   const int xcd = bid & 7, loc = bid >> 3;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-  const int tile_m = wg / p.tiles_n;
-  const int tile_n = wg - tile_m * p.tiles_n;
-  const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
-  const int z = blockIdx.y;
-  const int kb = z * p.k_chunk;
-  const int klen = min(p.K - kb, p.k_chunk);
+  const int first = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  const int total = p.tiles_m * p.tiles_n * p.splits;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / C::WN, wn = wave % C::WN;
+  if (first >= total) return;
 
-  // buffer descriptors relative to this tile's origin (small 32-bit offsets, range-checked)
-  const int rows_a = p.M - m0, rows_b = p.N - n0;
-  const bf16_t* a_base = AT ? p.A + (long)kb * p.lda + m0 : p.A + (long)m0 * p.lda + kb;
-  const bf16_t* b_base = BT ? p.B + (long)kb * p.ldb + n0 : p.B + (long)n0 * p.ldb + kb;
-  const long a_bytes = AT ? ((long)(klen - 1) * p.lda + rows_a) * 2 : ((long)(rows_a - 1) * p.lda + klen) * 2;
-  const long b_bytes = BT ? ((long)(klen - 1) * p.ldb + rows_b) * 2 : ((long)(rows_b - 1) * p.ldb + klen) * 2;
-  const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(a_base, a_bytes);
-  const __amdgpu_buffer_rsrc_t b_rsrc = make_rsrc(b_base, b_bytes);
-  const StagePlan<C::A_INSTR> pa = make_plan<AT, C::BM, C::A_INSTR, C::BK>(wave, lane, p.lda, rows_a);
-  const StagePlan<C::B_INSTR> pb = make_plan<BT, C::BN, C::B_INSTR, C::BK>(wave, lane, p.ldb, rows_b);
+  ItemCtx<AT, BT, C> cur = setup_item<AT, BT, C>(p, first, wave, lane);
+  int rd = 0;  // ring slot of the next K-step to compute
+#pragma unroll
+  for (int st = 0; st < D; ++st)
+    if (st < cur.nk) stage_step<AT, BT, C>(cur, p, smem, st, wave, st);
 
-  f32x4 acc[C::FM][C::FN];
+  for (int item = first; item < total; item += G) {
+    f32x4 acc[C::FM][C::FN];
 #pragma unroll
-  for (int mi = 0; mi < C::FM; ++mi)
+    for (int mi = 0; mi < C::FM; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < C::FN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float accb[C::FM];
+      for (int ni = 0; ni < C::FN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float accb[C::FM];
 #pragma unroll
-  for (int mi = 0; mi < C::FM; ++mi) accb[mi] = 0.f;
-  const bool do_bg = AT && p.bgrad != nullptr && tile_n == 0 && wn == 0;
+    for (int mi = 0; mi < C::FM; ++mi) accb[mi] = 0.f;
+    const bool do_bg = AT && p.bgrad != nullptr && cur.tile_n == 0 && wn == 0;
+    const int nk = cur.nk;
 
-  constexpr int BK = C::BK;
-  const int nk = (klen + BK - 1) / BK;
-  constexpr int D = C::NSTAGE - 1;  // prefetch distance
-#pragma unroll
-  for (int s = 0; s < D; ++s) {
-    if (s < nk) {
-      char* st = smem + s * C::STAGE_BYTES;
-      stage_tile<AT>(a_rsrc, st, wave, pa, p.lda, s * BK, klen);
-      stage_tile<BT>(b_rsrc, st + C::A_BYTES, wave, pb, p.ldb, s * BK, klen);
+    for (int t = 0; t < nk; ++t) {
+      const int younger = min(D - 1, nk - 1 - t);  // stages of THIS item allowed to stay in flight
+      if (D >= 3 && younger >= 2) CFHIP_WAIT_VMCNT(2 * C::LPS);
+      else if (D >= 2 && younger == 1) CFHIP_WAIT_VMCNT(1 * C::LPS);
+      else CFHIP_WAIT_VMCNT(0);
+      __builtin_amdgcn_s_barrier();
+      if (t + D < nk && !(p.ablate & 1)) {
+        int wr = rd + D;
+        if (wr >= C::NSTAGE) wr -= C::NSTAGE;
+        stage_step<AT, BT, C>(cur, p, smem, wr, wave, t + D);
+      }
+      const char* tile = smem + rd * C::STAGE_BYTES;
+      if (!(p.ablate & 2)) compute_tile<AT, BT, C>(tile, tile + C::A_BYTES, wm, wn, lane, acc);
+      if (AT && do_bg) bias_rows<C>(tile, wm, lane, accb);
+      rd = rd + 1 == C::NSTAGE ? 0 : rd + 1;
     }
-  }
-  int rd = 0, wr = D % C::NSTAGE;  // ring slots of step t and of step t + D
-  for (int t = 0; t < nk; ++t) {
-    const int younger = min(D - 1, nk - 1 - t);  // stages allowed to stay in flight
-    if (D >= 3 && younger >= 2) CFHIP_WAIT_VMCNT(2 * C::LPS);
-    else if (D >= 2 && younger == 1) CFHIP_WAIT_VMCNT(1 * C::LPS);
-    else CFHIP_WAIT_VMCNT(0);
+
+    // ---- item boundary: start the next item's pipeline fill, then this item's epilogue -----------
+    const int m0 = cur.m0, n0 = cur.n0, z = cur.z;
+    const int nitem = item + G;
+    if (nitem < total) {
+      cur = setup_item<AT, BT, C>(p, nitem, wave, lane);
+#pragma unroll
+      for (int st = 0; st < D; ++st) {
+        if (st < cur.nk) {
+          int slot = rd + st;
+          if (slot >= C::NSTAGE) slot -= C::NSTAGE;
+          stage_step<AT, BT, C>(cur, p, smem, slot, wave, st);  // slots of steps older than the last one
+        }
+      }
+    }
+    if (p.ablate & 4) continue;
+    if (AT && do_bg) {
+#pragma unroll
+      for (int mi = 0; mi < C::FM; ++mi) {
+        float v = accb[mi];  // lane (i, g) holds the k-slots of group g: fold the 4 groups
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const int m = m0 + wm * (C::FM * 16) + mi * 16 + (lane & 15);
+        if ((lane >> 4) == 0 && m < p.M) {
+          if (p.bgrad_slabs != nullptr) p.bgrad_slabs[(long)z * p.M + m] = v;
+          else p.bgrad[m] = p.bgrad_acc ? p.bgrad[m] + v : v;
+        }
+      }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // The MFMA result layout (lane = row l&15, 4 consecutive columns per 16x16 tile) would give 8-byte
+    // stores scattered over 16 rows per instruction.  Instead every wave transposes its sub-tile
+    // through a private LDS strip, 16 rows at a time, so that a lane ends up with 8 CONSECUTIVE columns
+    // of one row: residual / pre-activation traffic becomes 16-byte coalesced loads and every store
+    // instruction writes whole 128-byte row segments.  The strip lives in the ring slot of the last
+    // K-step (free once every wave is past the raw barrier below; it is re-used by the DMA of the
+    // next item's step D only after that item's first barrier, i.e. after every wave's epilogue).
+    // 16-byte chunks are XOR-swizzled by the row (no padding: the strips of all waves fill the slot).
     __builtin_amdgcn_s_barrier();
-    if (t + D < nk && !(p.ablate & 1)) {
-      char* st = smem + wr * C::STAGE_BYTES;
-      stage_tile<AT>(a_rsrc, st, wave, pa, p.lda, (t + D) * BK, klen);
-      stage_tile<BT>(b_rsrc, st + C::A_BYTES, wave, pb, p.ldb, (t + D) * BK, klen);
+    constexpr int WCOLS = C::FN * 16;           // columns of the wave's sub-tile
+    constexpr int LPR = WCOLS / 8;              // lanes per row when every lane takes 8 columns
+    constexpr int RPP = 64 / LPR;               // rows covered by one pass of the wave
+    int eslot = rd - 1;
+    if (eslot < 0) eslot += C::NSTAGE;
+    float* stg = reinterpret_cast<float*>(smem + eslot * C::STAGE_BYTES) + wave * (16 * WCOLS);
+    const int i = lane & 15, g = lane >> 4;
+    const int rr = lane / LPR, c8 = lane % LPR;
+    const bool to_slab = p.slabs != nullptr;
+    const int col = n0 + wn * WCOLS + c8 * 8;
+    const bool c_lo = col < p.N, c_hi = col + 4 < p.N;  // N % 4 == 0 on this path
+    f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr && !to_slab) {
+      if (c_lo) b_lo = *reinterpret_cast<const f32x4*>(p.bias + col);
+      if (c_hi) b_hi = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
     }
-    const char* cur = smem + rd * C::STAGE_BYTES;
-    if (!(p.ablate & 2)) compute_tile<AT, BT, C>(cur, cur + C::A_BYTES, wm, wn, lane, acc);
-    if (AT && do_bg) bias_rows<C>(cur, wm, lane, accb);
-    rd = rd + 1 == C::NSTAGE ? 0 : rd + 1;
-    wr = wr + 1 == C::NSTAGE ? 0 : wr + 1;
-  }
-
-  // ---- epilogue ----------------------------------------------------------------------------------
-  // The MFMA result layout (lane = row l&15, 4 consecutive columns per 16x16 tile) would give 8-byte
-  // stores scattered over 16 rows per instruction (measured: 1.8 TB/s, 40 % of the kernel).  Instead
-  // every wave transposes its sub-tile through a private LDS strip, 16 rows at a time, so that a
-  // lane ends up with 8 CONSECUTIVE columns of one row: residual / pre-activation traffic becomes
-  // 16-byte coalesced loads and every store instruction writes whole 128-byte row segments.
-  if (p.ablate & 4) return;
-  if (AT && do_bg) {
 #pragma unroll
     for (int mi = 0; mi < C::FM; ++mi) {
-      float v = accb[mi];  // lane (i, g) holds the k-slots of group g: fold the 4 groups
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      const int m = m0 + wm * (C::FM * 16) + mi * 16 + (lane & 15);
-      if ((lane >> 4) == 0 && m < p.M) {
-        if (p.bgrad_slabs != nullptr) p.bgrad_slabs[(long)z * p.M + m] = v;
-        else p.bgrad[m] = p.bgrad_acc ? p.bgrad[m] + v : v;
-      }
-    }
-  }
-  __syncthreads();  // all waves are done reading the ring buffers (no DMA in flight any more)
-  constexpr int WCOLS = C::FN * 16;           // columns of the wave's sub-tile
-  constexpr int SW = WCOLS + 4;               // padded LDS row stride (floats): conflict-free b128 writes
-  constexpr int LPR = WCOLS / 8;              // lanes per row when every lane takes 8 columns
-  constexpr int RPP = 64 / LPR;               // rows covered by one pass of the wave
-  float* stg = reinterpret_cast<float*>(smem) + wave * (16 * SW);
-  const int i = lane & 15, g = lane >> 4;
-  const int rr = lane / LPR, cc = (lane % LPR) * 8;
-  const bool to_slab = p.slabs != nullptr;
-  const int col = n0 + wn * WCOLS + cc;
-  const bool c_lo = col < p.N, c_hi = col + 4 < p.N;  // N % 4 == 0 on this path
-  f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias != nullptr && !to_slab) {
-    if (c_lo) b_lo = *reinterpret_cast<const f32x4*>(p.bias + col);
-    if (c_hi) b_hi = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
-  }
 #pragma unroll
-  for (int mi = 0; mi < C::FM; ++mi) {
+      for (int ni = 0; ni < C::FN; ++ni)
+        *reinterpret_cast<f32x4*>(stg + i * WCOLS + (((ni * 4 + g) ^ (i & 7)) << 2)) = acc[mi][ni];
 #pragma unroll
-    for (int ni = 0; ni < C::FN; ++ni)
-      *reinterpret_cast<f32x4*>(stg + i * SW + ni * 16 + g * 4) = acc[mi][ni];
-#pragma unroll
-    for (int ps = 0; ps < 16 / RPP; ++ps) {
-      const int r = ps * RPP + rr;
-      f32x4 lo = *reinterpret_cast<const f32x4*>(stg + r * SW + cc);
-      f32x4 hi = *reinterpret_cast<const f32x4*>(stg + r * SW + cc + 4);
-      const int row = m0 + wm * (C::FM * 16) + mi * 16 + r;
-      if (row >= p.M || !c_lo) continue;
-      if (to_slab) {
-        float* dst = p.slabs + ((long)z * p.M + row) * p.N + col;
-        *reinterpret_cast<f32x4*>(dst) = lo;
-        if (c_hi) *reinterpret_cast<f32x4*>(dst + 4) = hi;
-        continue;
-      }
-      lo += b_lo;
-      hi += b_hi;
-      const long off = (long)row * p.ldc + col;
-      if (EPI == CFHIP_EPI_GELU) {
-        // GELU of the bf16-rounded pre-activation (what the saved tensor holds for backward)
-        const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                         pack_bf16x2(hi[2], hi[3])};
-        if (p.aux_out != nullptr) {
-          if (c_hi) { if (p.ablate & 8) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p.aux_out + off)); else *reinterpret_cast<u32x4*>(p.aux_out + off) = w; }
-          else *reinterpret_cast<u32x2*>(p.aux_out + off) = u32x2{w[0], w[1]};
+      for (int ps = 0; ps < 16 / RPP; ++ps) {
+        const int r = ps * RPP + rr;
+        f32x4 lo = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + (((2 * c8) ^ (r & 7)) << 2));
+        f32x4 hi = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + (((2 * c8 + 1) ^ (r & 7)) << 2));
+        const int row = m0 + wm * (C::FM * 16) + mi * 16 + r;
+        if (row >= p.M || !c_lo) continue;
+        if (to_slab) {
+          float* dst = p.slabs + ((long)z * p.M + row) * p.N + col;
+          *reinterpret_cast<f32x4*>(dst) = lo;
+          if (c_hi) *reinterpret_cast<f32x4*>(dst + 4) = hi;
+          continue;
         }
-        lo = f32x4{gelu_erf_f(bf16lo(w[0])), gelu_erf_f(bf16hi(w[0])), gelu_erf_f(bf16lo(w[1])), gelu_erf_f(bf16hi(w[1]))};
-        hi = f32x4{gelu_erf_f(bf16lo(w[2])), gelu_erf_f(bf16hi(w[2])), gelu_erf_f(bf16lo(w[3])), gelu_erf_f(bf16hi(w[3]))};
-      } else if (EPI == CFHIP_EPI_RESIDUAL && p.out_f32) {
-        // f32 residual stream: aux_in is f32 with the output's layout
-        const float* r = reinterpret_cast<const float*>(p.aux_in) + off;
-        lo += *reinterpret_cast<const f32x4*>(r);
-        if (c_hi) hi += *reinterpret_cast<const f32x4*>(r + 4);
-      } else if (EPI == CFHIP_EPI_RESIDUAL || EPI == CFHIP_EPI_DGELU) {
-        u32x4 w = {0u, 0u, 0u, 0u};
-        if (c_hi) w = *reinterpret_cast<const u32x4*>(p.aux_in + off);
-        else { const u32x2 h2 = *reinterpret_cast<const u32x2*>(p.aux_in + off); w[0] = h2[0]; w[1] = h2[1]; }
-        if (EPI == CFHIP_EPI_RESIDUAL) {
-          lo += f32x4{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
-          hi += f32x4{bf16lo(w[2]), bf16hi(w[2]), bf16lo(w[3]), bf16hi(w[3])};
+        lo += b_lo;
+        hi += b_hi;
+        const long off = (long)row * p.ldc + col;
+        if (EPI == CFHIP_EPI_GELU) {
+          // GELU of the bf16-rounded pre-activation (what the saved tensor holds for backward)
+          const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                           pack_bf16x2(hi[2], hi[3])};
+          if (p.aux_out != nullptr) {
+            if (c_hi) *reinterpret_cast<u32x4*>(p.aux_out + off) = w;
+            else *reinterpret_cast<u32x2*>(p.aux_out + off) = u32x2{w[0], w[1]};
+          }
+          lo = f32x4{gelu_erf_f(bf16lo(w[0])), gelu_erf_f(bf16hi(w[0])), gelu_erf_f(bf16lo(w[1])), gelu_erf_f(bf16hi(w[1]))};
+          hi = f32x4{gelu_erf_f(bf16lo(w[2])), gelu_erf_f(bf16hi(w[2])), gelu_erf_f(bf16lo(w[3])), gelu_erf_f(bf16hi(w[3]))};
+        } else if (EPI == CFHIP_EPI_RESIDUAL && p.out_f32) {
+          // f32 residual stream: aux_in is f32 with the output's layout
+          const float* r32 = reinterpret_cast<const float*>(p.aux_in) + off;
+          lo += *reinterpret_cast<const f32x4*>(r32);
+          if (c_hi) hi += *reinterpret_cast<const f32x4*>(r32 + 4);
+        } else if (EPI == CFHIP_EPI_RESIDUAL || EPI == CFHIP_EPI_DGELU) {
+          u32x4 w = {0u, 0u, 0u, 0u};
+          if (c_hi) w = *reinterpret_cast<const u32x4*>(p.aux_in + off);
+          else { const u32x2 h2 = *reinterpret_cast<const u32x2*>(p.aux_in + off); w[0] = h2[0]; w[1] = h2[1]; }
+          if (EPI == CFHIP_EPI_RESIDUAL) {
+            lo += f32x4{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
+            hi += f32x4{bf16lo(w[2]), bf16hi(w[2]), bf16lo(w[3]), bf16hi(w[3])};
+          } else {
+            lo *= f32x4{gelu_erf_grad_f(bf16lo(w[0])), gelu_erf_grad_f(bf16hi(w[0])), gelu_erf_grad_f(bf16lo(w[1])), gelu_erf_grad_f(bf16hi(w[1]))};
+            hi *= f32x4{gelu_erf_grad_f(bf16lo(w[2])), gelu_erf_grad_f(bf16hi(w[2])), gelu_erf_grad_f(bf16lo(w[3])), gelu_erf_grad_f(bf16hi(w[3]))};
+          }
+        }
+        if (p.out_f32) {
+          float* dst = reinterpret_cast<float*>(p.C) + off;
+          if (p.accumulate) {
+            lo += *reinterpret_cast<const f32x4*>(dst);
+            if (c_hi) hi += *reinterpret_cast<const f32x4*>(dst + 4);
+          }
+          *reinterpret_cast<f32x4*>(dst) = lo;
+          if (c_hi) *reinterpret_cast<f32x4*>(dst + 4) = hi;
         } else {
-          lo *= f32x4{gelu_erf_grad_f(bf16lo(w[0])), gelu_erf_grad_f(bf16hi(w[0])), gelu_erf_grad_f(bf16lo(w[1])), gelu_erf_grad_f(bf16hi(w[1]))};
-          hi *= f32x4{gelu_erf_grad_f(bf16lo(w[2])), gelu_erf_grad_f(bf16hi(w[2])), gelu_erf_grad_f(bf16lo(w[3])), gelu_erf_grad_f(bf16hi(w[3]))};
+          bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + off;
+          const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                           pack_bf16x2(hi[2], hi[3])};
+          if (c_hi) *reinterpret_cast<u32x4*>(dst) = w;
+          else *reinterpret_cast<u32x2*>(dst) = u32x2{w[0], w[1]};
         }
-      }
-      if (p.out_f32) {
-        float* dst = reinterpret_cast<float*>(p.C) + off;
-        if (p.accumulate) {
-          lo += *reinterpret_cast<const f32x4*>(dst);
-          if (c_hi) hi += *reinterpret_cast<const f32x4*>(dst + 4);
-        }
-        *reinterpret_cast<f32x4*>(dst) = lo;
-        if (c_hi) *reinterpret_cast<f32x4*>(dst + 4) = hi;
-      } else {
-        bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + off;
-        const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                         pack_bf16x2(hi[2], hi[3])};
-        if (c_hi) { if (p.ablate & 8) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(dst)); else *reinterpret_cast<u32x4*>(dst) = w; }
-        else *reinterpret_cast<u32x2*>(dst) = u32x2{w[0], w[1]};
       }
     }
   }
@@ -463,6 +517,8 @@ constexpr int BK_MAX = 64;
 
 int g_gemm_config = -1;
 int g_gemm_ablate = 0;
+int g_gemm_persistent = 0;
+int g_gemm_heuristic = 0;
 
 template <bool AT, bool BT, int EPI, class C>
 int launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
@@ -489,7 +545,21 @@ int launch_layout(GemmParams p, int a_trans, int b_trans, int epilogue, int spli
   const long b_span = b_trans ? (long)p.k_chunk * p.ldb * 2 : (long)C::BN * p.ldb * 2;
   CFHIP_REQUIRE(a_span < 0x7fffffffL && b_span < 0x7fffffffL,
                 "gemm: operand tile span exceeds 2 GiB (lda=%ld ldb=%ld K=%d)", p.lda, p.ldb, p.K);
-  dim3 grid(p.tiles_m * p.tiles_n, split_k);
+  p.splits = split_k;
+  // persistent grid: one workgroup per resident slot (or per work item when there are fewer)
+  int dev = 0, cus = 256;
+  static int cached_cus = 0;
+  if (cached_cus == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached_cus = prop.multiProcessorCount;
+    else cached_cus = 256;
+  }
+  cus = cached_cus;
+  const int items = p.tiles_m * p.tiles_n * split_k;
+  const int slots = cus * C::WGS_PER_CU;
+  // Persistence is optional: a persistent grid keeps every CU slot for the kernel's lifetime, which
+  // blocks the co-scheduling with the side-stream kernels (measured slower end-to-end on ViT-B/16).
+  dim3 grid((g_gemm_persistent && items > slots) ? slots : items);
   if (!a_trans && !b_trans) {
     switch (epilogue) {
       case CFHIP_EPI_NONE: return launch_cfg<false, false, CFHIP_EPI_NONE, C>(p, grid, s);
@@ -516,6 +586,11 @@ int launch_layout(GemmParams p, int a_trans, int b_trans, int epilogue, int spli
 // operand is read through the transposing LDS path or the output is narrow.
 int pick_config(int M, int N, int a_trans, int b_trans) {
   if (g_gemm_config >= 0 && g_gemm_config < NUM_CFG) return g_gemm_config;
+  if (g_gemm_heuristic == 1) {
+    if (a_trans && (long)M * N <= 768L * 768L) return 0;  // small dW outputs: few tiles, deep split-K
+    if (a_trans || b_trans) return 1;
+    return N <= 1024 ? 1 : 0;
+  }
   if (a_trans || b_trans) return 1;   // 128x128x32, 4 WG / CU
   if (N <= 1024) return 3;            // 128x64x64, 3 WG / CU
   return 0;                           // 128x128x64, 2 WG / CU
@@ -526,6 +601,14 @@ int pick_config(int M, int N, int a_trans, int b_trans) {
 extern "C" int cfhip_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "gemm_config") == 0) {
     g_gemm_config = value;
+    return CFHIP_OK;
+  }
+  if (name != nullptr && strcmp(name, "gemm_heuristic") == 0) {
+    g_gemm_heuristic = value;
+    return CFHIP_OK;
+  }
+  if (name != nullptr && strcmp(name, "gemm_persistent") == 0) {
+    g_gemm_persistent = value;
     return CFHIP_OK;
   }
   if (name != nullptr && strcmp(name, "gemm_ablate") == 0) {

@@ -38,7 +38,8 @@ grad_ready_callbacks: List[Callable[[Tensor], None]] = []
 
 class SideStream:
     enabled = True
-    stream: Optional["torch.cuda.Stream"] = None
+    lanes = 2  # side streams (0: dW GEMMs; 1: column sums / LayerNorm parameter grads)
+    streams: List[Optional["torch.cuda.Stream"]] = [None, None, None]
     keep: List[Tensor] = []  # operands produced on the main stream, alive until the join
 
     _join_queued = False
@@ -49,7 +50,7 @@ class SideStream:
         cls.join()
 
     @classmethod
-    def run(cls, fn: Callable[[], None], keep: Tuple[Tensor, ...] = ()) -> None:
+    def run(cls, fn: Callable[[], None], keep: Tuple[Tensor, ...] = (), lane: int = 0) -> None:
         if not cls.enabled or not torch.cuda.is_available():
             fn()
             return
@@ -62,18 +63,32 @@ class SideStream:
             except RuntimeError:  # not inside a backward pass: stay on the current stream
                 fn()
                 return
-        if cls.stream is None:
-            cls.stream = torch.cuda.Stream()
-        cls.stream.wait_stream(torch.cuda.current_stream())  # everything issued so far is visible
-        with torch.cuda.stream(cls.stream):
+        lane = lane % max(1, cls.lanes)
+        if cls.streams[lane] is None:
+            cls.streams[lane] = torch.cuda.Stream()
+        side = cls.streams[lane]
+        side.wait_stream(torch.cuda.current_stream())  # everything issued so far is visible
+        with torch.cuda.stream(side):
             fn()
         cls.keep.extend(keep)
 
     @classmethod
+    def fork(cls, lane: int = 0) -> Optional["torch.cuda.Stream"]:
+        """A side stream that has waited for the current stream (for work the caller joins itself)."""
+        if not cls.enabled or not torch.cuda.is_available():
+            return None
+        lane = lane % max(1, cls.lanes)
+        if cls.streams[lane] is None:
+            cls.streams[lane] = torch.cuda.Stream()
+        cls.streams[lane].wait_stream(torch.cuda.current_stream())
+        return cls.streams[lane]
+
+    @classmethod
     def join(cls) -> None:
         """Make the current stream wait for the side stream (call before consuming parameter grads)."""
-        if cls.stream is not None:
-            torch.cuda.current_stream().wait_stream(cls.stream)
+        for side in cls.streams:
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
         cls.keep.clear()
 
 

@@ -45,10 +45,11 @@ def _dw_db(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> None:
     acc_w = not getattr(w, "_cfhip_fresh", False)
     kw = {}
     if len(prms) == 2:
+        acc_b = not getattr(b, "_cfhip_fresh", False)
         if FUSE_BIAS_GRAD:
-            kw = dict(bias_grad=b.grad.view(-1), bias_grad_accumulate=not getattr(b, "_cfhip_fresh", False))
-        else:
-            ops.colsum(dy2, out=b.grad.view(-1), accumulate=not getattr(b, "_cfhip_fresh", False))
+            kw = dict(bias_grad=b.grad.view(-1), bias_grad_accumulate=acc_b)
+        else:  # second side stream: the column sum runs beside the dW GEMM
+            SideStream.run(lambda: ops.colsum(dy2, out=b.grad.view(-1), accumulate=acc_b), (dy2,), lane=1)
     ops.gemm(dy2, x2, a_trans=True, b_trans=True, out=w.grad.view(n, k), accumulate=acc_w, split_k=split, **kw)
     for prm in prms:
         prm._cfhip_fresh = False
@@ -84,7 +85,7 @@ def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: T
             for cb in grad_ready_callbacks:
                 cb(prm)
 
-    SideStream.run(param_grads, (dy2, x2, mean, rstd))
+    SideStream.run(param_grads, (dy2, x2, mean, rstd), lane=1)
     dx, _, _ = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dx_add=dx_add, want_param_grads=False)
     return dx
 
@@ -146,9 +147,12 @@ class MixingBlockFn(Function):
         d_o = ops.gemm(dx1, out_w16, b_trans=True)
         dqkv = torch.empty_like(qkv)
         qkv3, dqkv3 = qkv.view(bsz, t, 3 * d), dqkv.view(bsz, t, 3 * d)
-        ops.attn_bwd(qkv3[..., :d], qkv3[..., d:2 * d], qkv3[..., 2 * d:], o2.view(bsz, t, d),
-                     d_o.view(bsz, t, d), lse, num_heads, dq=dqkv3[..., :d], dk=dqkv3[..., d:2 * d],
-                     dv=dqkv3[..., 2 * d:], mask=keep_mask, causal=causal)
+        o3, do3 = o2.view(bsz, t, d), d_o.view(bsz, t, d)
+        akw = dict(dq=dqkv3[..., :d], dk=dqkv3[..., d:2 * d], dv=dqkv3[..., 2 * d:], mask=keep_mask,
+                   causal=causal)
+        # (the two passes are independent kernels — `parts` — but running them on two streams measured
+        # slower end-to-end: the main stream has to wait for both anyway)
+        ops.attn_bwd(qkv3[..., :d], qkv3[..., d:2 * d], qkv3[..., 2 * d:], o3, do3, lse, num_heads, **akw)
         SideStream.run(lambda: _dw_db(in_w, qkv_b, dqkv, ln1), (dqkv, ln1))
         dln1 = ops.gemm(dqkv, in_w16, b_trans=True)
         dx = _ln_bwd(dln1, x2, ln1_w, ln1_b, mean1, rstd1, dx_add=dx1)

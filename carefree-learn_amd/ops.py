@@ -259,7 +259,7 @@ def attn_fwd(
 def attn_bwd(
     q: Tensor, k: Tensor, v: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, num_heads: int, *,
     dq: Tensor, dk: Tensor, dv: Tensor, mask: Optional[Tensor] = None, causal: bool = False,
-    scale: Optional[float] = None,
+    scale: Optional[float] = None, parts: int = 3, delta: Optional[Tensor] = None,
 ) -> None:
     """Writes dq / dk / dv (bf16, SAME strides as q / k / v — e.g. views of one packed buffer)."""
     b, tq, d, q_sb, q_st = _bth(q, "q")
@@ -275,12 +275,13 @@ def attn_bwd(
             raise ValueError(f"cfhip attention: `{nm}` must have the shape and strides of its primal")
     if scale is None:
         scale = 1.0 / math.sqrt(64.0)
-    delta = torch.empty((b, num_heads, tq), dtype=f32, device=q.device)
+    if delta is None:
+        delta = torch.empty((b, num_heads, tq), dtype=f32, device=q.device)
     keep, mp, ms_b, ms_h, ms_q = _mask_args(mask, b, num_heads, tq, tk)
     rc = _lib.load().cfhip_attn_bwd(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
         delta.data_ptr(), mp, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), b, num_heads, tq, tk, q_sb,
-        q_st, k_sb, k_st, o_sb, o_st, ms_b, ms_h, ms_q, float(scale), int(causal), _stream(),
+        q_st, k_sb, k_st, o_sb, o_st, ms_b, ms_h, ms_q, float(scale), int(causal), int(parts), _stream(),
     )
     _lib.check(rc, "attn_bwd")
 

@@ -134,7 +134,10 @@ int cfhip_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
                    const float* lse, float* delta, const uint8_t* mask, void* dq, void* dk, void* dv,
                    int B, int H, int Tq, int Tk, int64_t q_stride_b, int64_t q_stride_t,
                    int64_t kv_stride_b, int64_t kv_stride_t, int64_t o_stride_b, int64_t o_stride_t,
-                   int64_t ms_b, int64_t ms_h, int64_t ms_q, float scale, int causal, void* stream);
+                   int64_t ms_b, int64_t ms_h, int64_t ms_q, float scale, int causal, int parts,
+                   void* stream);
+/* parts: 1 = dQ pass only, 2 = dK/dV pass only, 3 = both.  The two passes are independent kernels
+ * (each recomputes S, dP and delta) and may be launched on two streams. */
 
 /* ------------------------------------------------------------------------------------------
  * K8 (ViT patch embedding) + K7 glue

@@ -1,0 +1,47 @@
+"""Within-process A/B of whole-step variants (interleaved rounds, medians): python tools/step_ab.py"""
+import os, sys, statistics, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import cflearn_amd as C
+from cflearn_amd import ops
+from cflearn_amd.engine import TrainStep
+from cflearn_amd.functional import SideStream
+
+dev = torch.device("cuda")
+torch.manual_seed(0)
+model = C.vit_b16_classifier(1000).to(dev)
+ts = TrainStep(model, lr=1e-4, use_graph=False)
+g = torch.Generator().manual_seed(1234)
+img = torch.randn(64, 3, 224, 224, generator=g).to(dev)
+labels = torch.randint(0, 1000, (64,), generator=g).to(dev)
+
+VARIANTS = {
+    "2 side streams": dict(gemm_heuristic=0, gemm_persistent=0, side=True, lanes=2),
+    "1 side stream": dict(gemm_heuristic=0, gemm_persistent=0, side=True, lanes=1),
+    "no side stream": dict(gemm_heuristic=0, gemm_persistent=0, side=False, lanes=1),
+}
+
+def apply(v):
+    ops.set_option("gemm_heuristic", v["gemm_heuristic"])
+    ops.set_option("gemm_persistent", v["gemm_persistent"])
+    SideStream.enabled = v["side"]
+    SideStream.lanes = v["lanes"]
+
+def run(n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ts.step(img, labels)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+for v in VARIANTS.values():
+    apply(v); run(3)
+res = {k: [] for k in VARIANTS}
+for rnd in range(5):
+    for k, v in VARIANTS.items():
+        apply(v)
+        res[k].append(run(10))
+for k, v in res.items():
+    print(f"{k:28s} median {statistics.median(v):7.3f} ms  min {min(v):7.3f}  all {[round(x, 2) for x in v]}")
