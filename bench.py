@@ -144,7 +144,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (weak scaling; SURVEY §8a: 64 or 128)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (single GPU).  Default is eager multi-stream "
                          "launches: with the parameter-gradient kernels on side streams the eager step measured "
