@@ -159,23 +159,40 @@ template <bool AT, bool BT, class C>
 __device__ __forceinline__ void compute_tile(const char* a_tile, const char* b_tile, int wm, int wn,
                                              int lane, f32x4 (&acc)[C::FM][C::FN]) {
   const int i = lane & 15, g = lane >> 4;
+  constexpr int KS = C::BK / 32;
+  // Fragment loads of the WHOLE K-step are issued before the first MFMA (register double buffer when
+  // the configuration has the VGPR headroom): one exposed LDS latency per K-step instead of one per
+  // half K-substep with the compiler's own just-in-time placement.
+  constexpr bool PRELOAD = KS == 2 && C::WAVES_PER_SIMD <= 3;
+  bf16x8 af[KS][C::FM], bfr[KS][C::FN];
 #pragma unroll
-  for (int ks = 0; ks < C::BK / 32; ++ks) {
-    bf16x8 af[C::FM], bfr[C::FN];
+  for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
     for (int t = 0; t < C::FM; ++t)
-      af[t] = AT ? frag_mmajor<C::BM>(a_tile, wm * (C::FM * 16) + t * 16, ks, lane)
-                 : frag_kmajor<C::BK>(a_tile, wm * (C::FM * 16) + t * 16, ks, i, g);
+      af[ks][t] = AT ? frag_mmajor<C::BM>(a_tile, wm * (C::FM * 16) + t * 16, ks, lane)
+                     : frag_kmajor<C::BK>(a_tile, wm * (C::FM * 16) + t * 16, ks, i, g);
 #pragma unroll
     for (int t = 0; t < C::FN; ++t)
-      bfr[t] = BT ? frag_mmajor<C::BN>(b_tile, wn * (C::FN * 16) + t * 16, ks, lane)
-                  : frag_kmajor<C::BK>(b_tile, wn * (C::FN * 16) + t * 16, ks, i, g);
+      bfr[ks][t] = BT ? frag_mmajor<C::BN>(b_tile, wn * (C::FN * 16) + t * 16, ks, lane)
+                      : frag_kmajor<C::BK>(b_tile, wn * (C::FN * 16) + t * 16, ks, i, g);
+    if (!PRELOAD) {
 #pragma unroll
-    for (int mi = 0; mi < C::FM; ++mi)
+      for (int mi = 0; mi < C::FM; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < C::FN; ++ni)
-        // swapped operands: D[n][m] -> lane holds row m = l&15, cols n = 4*(l>>4) + 0..3
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < C::FN; ++ni)
+          // swapped operands: D[n][m] -> lane holds row m = l&15, cols n = 4*(l>>4) + 0..3
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0);
+    }
+  }
+  if (PRELOAD) {
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads above the MFMA block
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < C::FM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::FN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0);
   }
 }
 
