@@ -215,6 +215,97 @@ __device__ __forceinline__ void bias_rows(const char* a_tile, int wm, int lane, 
 
 #define CFHIP_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
+// ---- epilogue ----------------------------------------------------------------------------------------
+// The MFMA result layout (lane = row l&15, 4 consecutive columns per 16x16 tile) would give 8-byte
+// stores scattered over 16 rows per instruction.  Instead every wave transposes its sub-tile through
+// a private LDS strip (inside `stage`, a ring slot nobody reads any more), 16 rows at a time, so that
+// a lane ends up with 8 CONSECUTIVE columns of one row: residual / pre-activation traffic becomes
+// 16-byte coalesced loads and every store instruction writes whole 128-byte row segments.  16-byte
+// chunks are XOR-swizzled by the row (no padding: the strips of all waves exactly fill 16 KiB).
+template <int EPI, class C>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[C::FM][C::FN], char* stage,
+                                         int m0, int n0, int z, int wm, int wn, int wave, int lane) {
+  constexpr int WCOLS = C::FN * 16;           // columns of the wave's sub-tile
+  constexpr int LPR = WCOLS / 8;              // lanes per row when every lane takes 8 columns
+  constexpr int RPP = 64 / LPR;               // rows covered by one pass of the wave
+  float* stg = reinterpret_cast<float*>(stage) + wave * (16 * WCOLS);
+  const int i = lane & 15, g = lane >> 4;
+  const int rr = lane / LPR, c8 = lane % LPR;
+  const bool to_slab = p.slabs != nullptr;
+  const int col = n0 + wn * WCOLS + c8 * 8;
+  const bool c_lo = col < p.N, c_hi = col + 4 < p.N;  // N % 4 == 0 on this path
+  f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias != nullptr && !to_slab) {
+    if (c_lo) b_lo = *reinterpret_cast<const f32x4*>(p.bias + col);
+    if (c_hi) b_hi = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+  }
+#pragma unroll
+  for (int mi = 0; mi < C::FM; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < C::FN; ++ni)
+      *reinterpret_cast<f32x4*>(stg + i * WCOLS + (((ni * 4 + g) ^ (i & 7)) << 2)) = acc[mi][ni];
+#pragma unroll
+    for (int ps = 0; ps < 16 / RPP; ++ps) {
+      const int r = ps * RPP + rr;
+      f32x4 lo = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + (((2 * c8) ^ (r & 7)) << 2));
+      f32x4 hi = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + (((2 * c8 + 1) ^ (r & 7)) << 2));
+      const int row = m0 + wm * (C::FM * 16) + mi * 16 + r;
+      if (row >= p.M || !c_lo) continue;
+      if (to_slab) {
+        float* dst = p.slabs + ((long)z * p.M + row) * p.N + col;
+        *reinterpret_cast<f32x4*>(dst) = lo;
+        if (c_hi) *reinterpret_cast<f32x4*>(dst + 4) = hi;
+        continue;
+      }
+      lo += b_lo;
+      hi += b_hi;
+      const long off = (long)row * p.ldc + col;
+      if (EPI == CFHIP_EPI_GELU) {
+        // GELU of the bf16-rounded pre-activation (what the saved tensor holds for backward)
+        const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                         pack_bf16x2(hi[2], hi[3])};
+        if (p.aux_out != nullptr) {
+          if (c_hi) *reinterpret_cast<u32x4*>(p.aux_out + off) = w;
+          else *reinterpret_cast<u32x2*>(p.aux_out + off) = u32x2{w[0], w[1]};
+        }
+        lo = f32x4{gelu_erf_f(bf16lo(w[0])), gelu_erf_f(bf16hi(w[0])), gelu_erf_f(bf16lo(w[1])), gelu_erf_f(bf16hi(w[1]))};
+        hi = f32x4{gelu_erf_f(bf16lo(w[2])), gelu_erf_f(bf16hi(w[2])), gelu_erf_f(bf16lo(w[3])), gelu_erf_f(bf16hi(w[3]))};
+      } else if (EPI == CFHIP_EPI_RESIDUAL && p.out_f32) {
+        // f32 residual stream: aux_in is f32 with the output's layout
+        const float* r32 = reinterpret_cast<const float*>(p.aux_in) + off;
+        lo += *reinterpret_cast<const f32x4*>(r32);
+        if (c_hi) hi += *reinterpret_cast<const f32x4*>(r32 + 4);
+      } else if (EPI == CFHIP_EPI_RESIDUAL || EPI == CFHIP_EPI_DGELU) {
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if (c_hi) w = *reinterpret_cast<const u32x4*>(p.aux_in + off);
+        else { const u32x2 h2 = *reinterpret_cast<const u32x2*>(p.aux_in + off); w[0] = h2[0]; w[1] = h2[1]; }
+        if (EPI == CFHIP_EPI_RESIDUAL) {
+          lo += f32x4{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
+          hi += f32x4{bf16lo(w[2]), bf16hi(w[2]), bf16lo(w[3]), bf16hi(w[3])};
+        } else {
+          lo *= f32x4{gelu_erf_grad_f(bf16lo(w[0])), gelu_erf_grad_f(bf16hi(w[0])), gelu_erf_grad_f(bf16lo(w[1])), gelu_erf_grad_f(bf16hi(w[1]))};
+          hi *= f32x4{gelu_erf_grad_f(bf16lo(w[2])), gelu_erf_grad_f(bf16hi(w[2])), gelu_erf_grad_f(bf16lo(w[3])), gelu_erf_grad_f(bf16hi(w[3]))};
+        }
+      }
+      if (p.out_f32) {
+        float* dst = reinterpret_cast<float*>(p.C) + off;
+        if (p.accumulate) {
+          lo += *reinterpret_cast<const f32x4*>(dst);
+          if (c_hi) hi += *reinterpret_cast<const f32x4*>(dst + 4);
+        }
+        *reinterpret_cast<f32x4*>(dst) = lo;
+        if (c_hi) *reinterpret_cast<f32x4*>(dst + 4) = hi;
+      } else {
+        bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + off;
+        const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                         pack_bf16x2(hi[2], hi[3])};
+        if (c_hi) *reinterpret_cast<u32x4*>(dst) = w;
+        else *reinterpret_cast<u32x2*>(dst) = u32x2{w[0], w[1]};
+      }
+    }
+  }
+}
+
 // Work item = (output tile, K slice).  Everything a wave needs to stream one item.
 template <bool AT, bool BT, class C>
 struct ItemCtx {
@@ -358,98 +449,111 @@ void gemm_bf16_kernel(GemmParams p) {
       }
     }
 
-    // ---- epilogue ---------------------------------------------------------------------------------
-    // The MFMA result layout (lane = row l&15, 4 consecutive columns per 16x16 tile) would give 8-byte
-    // stores scattered over 16 rows per instruction.  Instead every wave transposes its sub-tile
-    // through a private LDS strip, 16 rows at a time, so that a lane ends up with 8 CONSECUTIVE columns
-    // of one row: residual / pre-activation traffic becomes 16-byte coalesced loads and every store
-    // instruction writes whole 128-byte row segments.  The strip lives in the ring slot of the last
-    // K-step (free once every wave is past the raw barrier below; it is re-used by the DMA of the
-    // next item's step D only after that item's first barrier, i.e. after every wave's epilogue).
-    // 16-byte chunks are XOR-swizzled by the row (no padding: the strips of all waves fill the slot).
+    // ---- epilogue (see epilogue<>): the strip lives in the ring slot of the last K-step, free once
+    // every wave is past the raw barrier below; it is re-used by the DMA of the next item's step D
+    // only after that item's first barrier, i.e. after every wave's epilogue.
     __builtin_amdgcn_s_barrier();
-    constexpr int WCOLS = C::FN * 16;           // columns of the wave's sub-tile
-    constexpr int LPR = WCOLS / 8;              // lanes per row when every lane takes 8 columns
-    constexpr int RPP = 64 / LPR;               // rows covered by one pass of the wave
     int eslot = rd - 1;
     if (eslot < 0) eslot += C::NSTAGE;
-    float* stg = reinterpret_cast<float*>(smem + eslot * C::STAGE_BYTES) + wave * (16 * WCOLS);
-    const int i = lane & 15, g = lane >> 4;
-    const int rr = lane / LPR, c8 = lane % LPR;
-    const bool to_slab = p.slabs != nullptr;
-    const int col = n0 + wn * WCOLS + c8 * 8;
-    const bool c_lo = col < p.N, c_hi = col + 4 < p.N;  // N % 4 == 0 on this path
-    f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr && !to_slab) {
-      if (c_lo) b_lo = *reinterpret_cast<const f32x4*>(p.bias + col);
-      if (c_hi) b_hi = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
-    }
-#pragma unroll
-    for (int mi = 0; mi < C::FM; ++mi) {
-#pragma unroll
-      for (int ni = 0; ni < C::FN; ++ni)
-        *reinterpret_cast<f32x4*>(stg + i * WCOLS + (((ni * 4 + g) ^ (i & 7)) << 2)) = acc[mi][ni];
-#pragma unroll
-      for (int ps = 0; ps < 16 / RPP; ++ps) {
-        const int r = ps * RPP + rr;
-        f32x4 lo = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + (((2 * c8) ^ (r & 7)) << 2));
-        f32x4 hi = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + (((2 * c8 + 1) ^ (r & 7)) << 2));
-        const int row = m0 + wm * (C::FM * 16) + mi * 16 + r;
-        if (row >= p.M || !c_lo) continue;
-        if (to_slab) {
-          float* dst = p.slabs + ((long)z * p.M + row) * p.N + col;
-          *reinterpret_cast<f32x4*>(dst) = lo;
-          if (c_hi) *reinterpret_cast<f32x4*>(dst + 4) = hi;
-          continue;
-        }
-        lo += b_lo;
-        hi += b_hi;
-        const long off = (long)row * p.ldc + col;
-        if (EPI == CFHIP_EPI_GELU) {
-          // GELU of the bf16-rounded pre-activation (what the saved tensor holds for backward)
-          const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                           pack_bf16x2(hi[2], hi[3])};
-          if (p.aux_out != nullptr) {
-            if (c_hi) *reinterpret_cast<u32x4*>(p.aux_out + off) = w;
-            else *reinterpret_cast<u32x2*>(p.aux_out + off) = u32x2{w[0], w[1]};
-          }
-          lo = f32x4{gelu_erf_f(bf16lo(w[0])), gelu_erf_f(bf16hi(w[0])), gelu_erf_f(bf16lo(w[1])), gelu_erf_f(bf16hi(w[1]))};
-          hi = f32x4{gelu_erf_f(bf16lo(w[2])), gelu_erf_f(bf16hi(w[2])), gelu_erf_f(bf16lo(w[3])), gelu_erf_f(bf16hi(w[3]))};
-        } else if (EPI == CFHIP_EPI_RESIDUAL && p.out_f32) {
-          // f32 residual stream: aux_in is f32 with the output's layout
-          const float* r32 = reinterpret_cast<const float*>(p.aux_in) + off;
-          lo += *reinterpret_cast<const f32x4*>(r32);
-          if (c_hi) hi += *reinterpret_cast<const f32x4*>(r32 + 4);
-        } else if (EPI == CFHIP_EPI_RESIDUAL || EPI == CFHIP_EPI_DGELU) {
-          u32x4 w = {0u, 0u, 0u, 0u};
-          if (c_hi) w = *reinterpret_cast<const u32x4*>(p.aux_in + off);
-          else { const u32x2 h2 = *reinterpret_cast<const u32x2*>(p.aux_in + off); w[0] = h2[0]; w[1] = h2[1]; }
-          if (EPI == CFHIP_EPI_RESIDUAL) {
-            lo += f32x4{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
-            hi += f32x4{bf16lo(w[2]), bf16hi(w[2]), bf16lo(w[3]), bf16hi(w[3])};
-          } else {
-            lo *= f32x4{gelu_erf_grad_f(bf16lo(w[0])), gelu_erf_grad_f(bf16hi(w[0])), gelu_erf_grad_f(bf16lo(w[1])), gelu_erf_grad_f(bf16hi(w[1]))};
-            hi *= f32x4{gelu_erf_grad_f(bf16lo(w[2])), gelu_erf_grad_f(bf16hi(w[2])), gelu_erf_grad_f(bf16lo(w[3])), gelu_erf_grad_f(bf16hi(w[3]))};
-          }
-        }
-        if (p.out_f32) {
-          float* dst = reinterpret_cast<float*>(p.C) + off;
-          if (p.accumulate) {
-            lo += *reinterpret_cast<const f32x4*>(dst);
-            if (c_hi) hi += *reinterpret_cast<const f32x4*>(dst + 4);
-          }
-          *reinterpret_cast<f32x4*>(dst) = lo;
-          if (c_hi) *reinterpret_cast<f32x4*>(dst + 4) = hi;
-        } else {
-          bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + off;
-          const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                           pack_bf16x2(hi[2], hi[3])};
-          if (c_hi) *reinterpret_cast<u32x4*>(dst) = w;
-          else *reinterpret_cast<u32x2*>(dst) = u32x2{w[0], w[1]};
-        }
-      }
-    }
+    epilogue<EPI, C>(p, acc, smem + eslot * C::STAGE_BYTES, m0, n0, z, wm, wn, wave, lane);
   }
+}
+
+// ---- register-pipelined variant ----------------------------------------------------------------------
+// Same tiles, ring and epilogue, different K loop (BK = 32, 4 ring slots): the MFMA operands of K-step
+// t+1 are read from LDS into a SECOND fragment register set while the MFMAs of step t run, so a wave's
+// MFMA stream never waits for an LDS round trip; the DMA runs 3-4 steps ahead.  Per iteration t:
+//   (A) ds_read fragments(t+1)  <- slot (t+1)%4   (landed + visible since the barrier of iteration t-1)
+//   (B) 16 MFMAs on fragments(t)
+//   (C) s_waitcnt vmcnt: own DMA of step t+2 landed; s_barrier
+//   (D) DMA step t+4 -> slot t%4 (its fragments were consumed in (B) by every wave that passed (C))
+template <bool AT, bool BT, class C>
+struct Frags {
+  bf16x8 a[C::FM];
+  bf16x8 b[C::FN];
+};
+
+template <bool AT, bool BT, class C>
+__device__ __forceinline__ void load_frags(const char* tile, int wm, int wn, int lane, Frags<AT, BT, C>& f) {
+  const int i = lane & 15, g = lane >> 4;
+  const char* b_tile = tile + C::A_BYTES;
+#pragma unroll
+  for (int t = 0; t < C::FM; ++t)
+    f.a[t] = AT ? frag_mmajor<C::BM>(tile, wm * (C::FM * 16) + t * 16, 0, lane)
+                : frag_kmajor<C::BK>(tile, wm * (C::FM * 16) + t * 16, 0, i, g);
+#pragma unroll
+  for (int t = 0; t < C::FN; ++t)
+    f.b[t] = BT ? frag_mmajor<C::BN>(b_tile, wn * (C::FN * 16) + t * 16, 0, lane)
+                : frag_kmajor<C::BK>(b_tile, wn * (C::FN * 16) + t * 16, 0, i, g);
+}
+
+template <bool AT, bool BT, class C>
+__device__ __forceinline__ void mfma_frags(const Frags<AT, BT, C>& f, f32x4 (&acc)[C::FM][C::FN]) {
+#pragma unroll
+  for (int mi = 0; mi < C::FM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::FN; ++ni)
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[ni], f.a[mi], acc[mi][ni], 0, 0, 0);
+}
+
+template <bool AT, bool BT, int EPI, class C>
+__global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD)
+void gemm_bf16_pipe_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(C::BK == 32 && C::NSTAGE == 4, "the register-pipelined loop is written for BK = 32, 4 ring slots");
+  static_assert(C::NW * 16 * (C::FN * 16) * 4 <= C::STAGE_BYTES, "epilogue staging must fit in one ring slot");
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / C::WN, wn = wave % C::WN;
+
+  const ItemCtx<AT, BT, C> cur = setup_item<AT, BT, C>(p, item, wave, lane);
+  const int nk = cur.nk;
+  f32x4 acc[C::FM][C::FN];
+#pragma unroll
+  for (int mi = 0; mi < C::FM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::FN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int st = 0; st < 4; ++st)
+    if (st < nk) stage_step<AT, BT, C>(cur, p, smem, st, wave, st);
+  {  // steps 0 and 1 must have landed: at most the stages beyond step 1 stay in flight
+    const int younger = min(nk, 4) - 2;
+    if (younger >= 2) CFHIP_WAIT_VMCNT(2 * C::LPS);
+    else if (younger == 1) CFHIP_WAIT_VMCNT(1 * C::LPS);
+    else CFHIP_WAIT_VMCNT(0);
+  }
+  __builtin_amdgcn_s_barrier();
+
+  Frags<AT, BT, C> f0, f1;
+  load_frags<AT, BT, C>(smem, wm, wn, lane, f0);
+
+  // (C) + (D) of iteration t
+  auto sync_and_stage = [&](int t) {
+    if (t + 3 < nk) CFHIP_WAIT_VMCNT(1 * C::LPS);  // step t+3 may stay in flight, step t+2 has landed
+    else CFHIP_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    if (t + 4 < nk) stage_step<AT, BT, C>(cur, p, smem, t & 3, wave, t + 4);
+  };
+
+  for (int t = 0; t < nk; t += 2) {
+    if (t + 1 < nk) load_frags<AT, BT, C>(smem + ((t + 1) & 3) * C::STAGE_BYTES, wm, wn, lane, f1);
+    mfma_frags<AT, BT, C>(f0, acc);
+    sync_and_stage(t);
+    if (t + 1 >= nk) break;
+    if (t + 2 < nk) load_frags<AT, BT, C>(smem + ((t + 2) & 3) * C::STAGE_BYTES, wm, wn, lane, f0);
+    mfma_frags<AT, BT, C>(f1, acc);
+    sync_and_stage(t + 1);
+  }
+  if (p.ablate & 4) return;
+  // every wave is past the last barrier and holds its last fragments in registers: the ring is free
+  epilogue<EPI, C>(p, acc, smem, cur.m0, cur.n0, cur.z, wm, wn, wave, lane);
 }
 
 // split-K second pass: C = sum_z slab[z] (+ bias) (+ C)
@@ -529,7 +633,7 @@ using CfgD = Cfg<128, 64, 2, 2, 2, 64>;   //  48 KiB LDS, 4 waves (64x32 each), 
 using CfgE = Cfg<128, 128, 2, 2, 4, 32>;  //  64 KiB LDS, 4 waves, 2 WG / CU, prefetch 3
 using CfgF = Cfg<128, 64, 2, 2, 2, 32>;   //  24 KiB LDS, 4 waves (64x32 each), 4 WG / CU, prefetch 1
 using CfgG = Cfg<128, 64, 2, 2, 3, 32>;   //  36 KiB LDS, 4 waves (64x32 each), 4 WG / CU, prefetch 2
-constexpr int NUM_CFG = 7;
+constexpr int NUM_CFG = 8;  // 7 = CfgE with the register-pipelined K loop
 constexpr int BK_MAX = 64;
 
 int g_gemm_config = -1;
@@ -537,9 +641,11 @@ int g_gemm_ablate = 0;
 int g_gemm_persistent = 0;
 int g_gemm_heuristic = 0;
 
-template <bool AT, bool BT, int EPI, class C>
+template <bool AT, bool BT, int EPI, class C, bool PIPE>
 int launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
-  auto kern = gemm_bf16_kernel<AT, BT, EPI, C>;
+  void (*kern)(GemmParams) = nullptr;
+  if constexpr (PIPE) kern = gemm_bf16_pipe_kernel<AT, BT, EPI, C>;
+  else kern = gemm_bf16_kernel<AT, BT, EPI, C>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done && C::LDS_BYTES > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -554,7 +660,7 @@ int launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
   return CFHIP_OK;
 }
 
-template <class C>
+template <class C, bool PIPE = false>
 int launch_layout(GemmParams p, int a_trans, int b_trans, int epilogue, int split_k, hipStream_t s) {
   p.tiles_m = (p.M + C::BM - 1) / C::BM;
   p.tiles_n = (p.N + C::BN - 1) / C::BN;
@@ -576,22 +682,22 @@ int launch_layout(GemmParams p, int a_trans, int b_trans, int epilogue, int spli
   const int slots = cus * C::WGS_PER_CU;
   // Persistence is optional: a persistent grid keeps every CU slot for the kernel's lifetime, which
   // blocks the co-scheduling with the side-stream kernels (measured slower end-to-end on ViT-B/16).
-  dim3 grid((g_gemm_persistent && items > slots) ? slots : items);
+  dim3 grid((!PIPE && g_gemm_persistent && items > slots) ? slots : items);
   if (!a_trans && !b_trans) {
     switch (epilogue) {
-      case CFHIP_EPI_NONE: return launch_cfg<false, false, CFHIP_EPI_NONE, C>(p, grid, s);
-      case CFHIP_EPI_GELU: return launch_cfg<false, false, CFHIP_EPI_GELU, C>(p, grid, s);
-      case CFHIP_EPI_RESIDUAL: return launch_cfg<false, false, CFHIP_EPI_RESIDUAL, C>(p, grid, s);
+      case CFHIP_EPI_NONE: return launch_cfg<false, false, CFHIP_EPI_NONE, C, PIPE>(p, grid, s);
+      case CFHIP_EPI_GELU: return launch_cfg<false, false, CFHIP_EPI_GELU, C, PIPE>(p, grid, s);
+      case CFHIP_EPI_RESIDUAL: return launch_cfg<false, false, CFHIP_EPI_RESIDUAL, C, PIPE>(p, grid, s);
       default: break;
     }
   } else if (!a_trans && b_trans) {
     switch (epilogue) {
-      case CFHIP_EPI_NONE: return launch_cfg<false, true, CFHIP_EPI_NONE, C>(p, grid, s);
-      case CFHIP_EPI_DGELU: return launch_cfg<false, true, CFHIP_EPI_DGELU, C>(p, grid, s);
+      case CFHIP_EPI_NONE: return launch_cfg<false, true, CFHIP_EPI_NONE, C, PIPE>(p, grid, s);
+      case CFHIP_EPI_DGELU: return launch_cfg<false, true, CFHIP_EPI_DGELU, C, PIPE>(p, grid, s);
       default: break;
     }
   } else if (epilogue == CFHIP_EPI_NONE) {
-    return launch_cfg<true, true, CFHIP_EPI_NONE, C>(p, grid, s);
+    return launch_cfg<true, true, CFHIP_EPI_NONE, C, PIPE>(p, grid, s);
   }
   cfhip_set_error("gemm: epilogue %d is not provided for layout (%d,%d)", epilogue, a_trans, b_trans);
   return CFHIP_ERR_INVALID;
@@ -712,6 +818,7 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
     case 4: rc = launch_layout<CfgE>(p, a_trans, b_trans, epilogue, split_k, s); break;
     case 5: rc = launch_layout<CfgF>(p, a_trans, b_trans, epilogue, split_k, s); break;
     case 6: rc = launch_layout<CfgG>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 7: rc = launch_layout<CfgE, true>(p, a_trans, b_trans, epilogue, split_k, s); break;
     default: rc = launch_layout<CfgA>(p, a_trans, b_trans, epilogue, split_k, s); break;
   }
   if (rc != CFHIP_OK) return rc;

@@ -129,9 +129,13 @@ class BucketedAllReduce:
     def _launch(self, b: _Bucket) -> None:
         view = self.arena.flat_g[b.start:b.end]
         if self.is_cuda:
-            done = torch.cuda.Event()
-            done.record(torch.cuda.current_stream())
-            self.comm_stream.wait_event(done)
+            # The bucket's gradients were written by kernels on the current stream AND on the side
+            # streams of functional.SideStream (dW GEMMs on one lane, column sums / LayerNorm parameter
+            # gradients on another): the collective must be ordered after all of them.
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            for side in HF.SideStream.streams:
+                if side is not None:
+                    self.comm_stream.wait_stream(side)
             with torch.cuda.stream(self.comm_stream):
                 b.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:

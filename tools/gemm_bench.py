@@ -58,7 +58,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--configs", default="0,1,3")
+    ap.add_argument("--configs", default="0,1,4,7")
     args = ap.parse_args()
     dev = torch.device("cuda")
     cfgs = [int(c) for c in args.configs.split(",")]
