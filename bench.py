@@ -157,6 +157,9 @@ def main() -> None:
     ap.add_argument("--gemm-reps", type=int, default=10)
     ap.add_argument("--bucket-mb", type=int, default=64)
     ap.add_argument("--watchdog", type=int, default=0, help="dump all Python stacks every N seconds")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for the "
+                                                      "single-GPU dry run of the N > 1 code path)")
+    ap.add_argument("--all-on-gpu0", action="store_true", help="dry run: every rank uses cuda:0")
     args = ap.parse_args()
     if args.watchdog > 0:
         import faulthandler
@@ -165,7 +168,7 @@ def main() -> None:
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if "--all-on-gpu0" in sys.argv else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -173,7 +176,10 @@ def main() -> None:
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" == RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
 

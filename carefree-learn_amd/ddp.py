@@ -77,16 +77,17 @@ class BucketedAllReduce:
             for i in b.param_ids:
                 self.bucket_of[i] = bi
         self._ready = [False] * n
+        self._direct = [False] * n  # notified by a HIP backward (functional.grad_ready_callbacks)
         self._index = {id(p): i for i, p in enumerate(arena.params)}
-        HF.grad_ready_callbacks.append(self._on_ready)
+        HF.grad_ready_callbacks.append(self._on_direct)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_ready) for p in arena.params]
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world_size
 
     # -- life cycle ---------------------------------------------------------------------------
     def close(self) -> None:
-        if self._on_ready in HF.grad_ready_callbacks:
-            HF.grad_ready_callbacks.remove(self._on_ready)
+        if self._on_direct in HF.grad_ready_callbacks:
+            HF.grad_ready_callbacks.remove(self._on_direct)
         for h in self._hooks:
             h.remove()
         self._hooks = []
@@ -107,18 +108,28 @@ class BucketedAllReduce:
             self.sync_enabled = prev
 
     # -- backward-time notifications ----------------------------------------------------------
-    def _on_ready(self, p: Tensor) -> None:
+    def _on_direct(self, p: Tensor) -> None:
+        self._on_ready(p, True)
+
+    def _on_ready(self, p: Tensor, direct: bool = False) -> None:
         if not self.sync_enabled or not self.overlap:
             return
         i = self._index.get(id(p))
         if i is None:
             return
         b = self.buckets[self.bucket_of[i]]
+        if direct:
+            self._direct[i] = True
+        elif self._direct[i]:
+            # autograd also runs the post-accumulate hook of a parameter whose gradient the HIP
+            # backward wrote itself (the Function returned None for it): that is the echo of the
+            # direct notification, not a second write
+            return
         if self._ready[i]:
             if b.launched:
                 raise RuntimeError(
-                    "a parameter's gradient was written again after its bucket was reduced (shared "
-                    "weights): construct BucketedAllReduce(overlap=False) for such models"
+                    f"parameter #{i} {tuple(p.shape)}: gradient written again after its bucket was reduced "
+                    "(shared weights): construct BucketedAllReduce(overlap=False) for such models"
                 )
             return
         self._ready[i] = True
@@ -157,6 +168,7 @@ class BucketedAllReduce:
             b.work.wait()
             b.work, b.launched, b.pending = None, False, len(b.param_ids)
         self._ready = [False] * len(self._ready)
+        self._direct = [False] * len(self._direct)
         if self.optimizer is None and self.world_size > 1:
             self.arena.flat_g.mul_(1.0 / self.world_size)
 
