@@ -37,7 +37,10 @@ struct AttnParams {
   float scale;
   int causal;
   int delta_ready;  // dK/dV pass: p.delta was already written by the dQ pass of the same call
+  int ablate;       // benchmarking only (forward): bit0 skip the K/V DMA, bit1 skip the tile loop, bit2 skip stores
 };
+
+int g_attn_ablate = 0;
 
 // byte offset of element (row, col) in a swizzled [rows][64] bf16 tile (128 B per row)
 __device__ __forceinline__ int tile_off(int row, int col) {
@@ -124,8 +127,10 @@ __device__ __forceinline__ float group_sum(float v) {
 // ------------------------------------------------------------------------------------------------
 // forward: workgroup = (query chunk of nwaves*16 rows, head, batch); NB = ceil(Tk / 32)
 // ------------------------------------------------------------------------------------------------
-template <int NB>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
+// PLAIN = no mask, not causal (the ViT path): the only masking is the kv tail (j >= Tk), decided per
+// 16-wide tile with wave-uniform branches — no per-element predicate registers.
+template <int NB, bool PLAIN>
+__global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + NB * 32 * 128;
@@ -135,9 +140,12 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   const int nwaves = blockDim.x >> 6;
   const bf16_t* kb = p.k + (long)b * p.kv_sb + h * DH;
   const bf16_t* vb = p.v + (long)b * p.kv_sb + h * DH;
-  dma_tile(Ks, kb, p.kv_st, p.Tk, NB * 32, wave, nwaves, lane);
-  dma_tile(Vs, vb, p.kv_st, p.Tk, NB * 32, wave, nwaves, lane);
+  if (!(p.ablate & 1)) {
+    dma_tile(Ks, kb, p.kv_st, p.Tk, NB * 32, wave, nwaves, lane);
+    dma_tile(Vs, vb, p.kv_st, p.Tk, NB * 32, wave, nwaves, lane);
+  }
   __syncthreads();  // (drains the DMA: vmcnt(0) + barrier)
+  if (p.ablate & 2) return;
 
   const int i = lane & 15, g = lane >> 4;
   const bf16_t* qb = p.q + (long)b * p.q_sb + h * DH;
@@ -154,21 +162,40 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 0, lane), qf0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 1, lane), qf1, acc, 0, 0, 0);
     st[jt] = acc;
+    if (jt & 1) __builtin_amdgcn_sched_barrier(0);  // at most 4 K fragments in flight: 128 VGPRs, 4 waves / SIMD
   }
   // scaled scores in the log2 domain, masked; row max / sum
   const float sl2 = p.scale * LOG2E;
-  const bool plain = (p.mask == nullptr) && !p.causal;
   float mx = -INFINITY;
 #pragma unroll
   for (int jt = 0; jt < 2 * NB; ++jt) {
+    if (PLAIN) {
+      // nb = ceil(Tk / 32): only the last two tiles can touch the tail
+      if (jt >= 2 * NB - 2 && jt * 16 >= p.Tk) {  // tile entirely past the end (wave-uniform)
+        st[jt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      } else if (jt >= 2 * NB - 2 && jt * 16 + 15 >= p.Tk) {  // the tile straddling Tk
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = jt * 16 + 4 * g + r;
-      float x = st[jt][r] * sl2;
-      if (!plain) x = keep_at(p, b, h, qi < p.Tq ? qi : p.Tq - 1, j) ? x : -INFINITY;
-      else if (jt * 16 + 15 >= p.Tk) x = (j < p.Tk) ? x : -INFINITY;  // only the tile straddling Tk
-      st[jt][r] = x;
-      mx = fmaxf(mx, x);
+        for (int r = 0; r < 4; ++r) {
+          const float x = (jt * 16 + 4 * g + r < p.Tk) ? st[jt][r] * sl2 : -INFINITY;
+          st[jt][r] = x;
+          mx = fmaxf(mx, x);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = st[jt][r] * sl2;
+          st[jt][r] = x;
+          mx = fmaxf(mx, x);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = jt * 16 + 4 * g + r;
+        const float x = keep_at(p, b, h, qi < p.Tq ? qi : p.Tq - 1, j) ? st[jt][r] * sl2 : -INFINITY;
+        st[jt][r] = x;
+        mx = fmaxf(mx, x);
+      }
     }
   }
   mx = group_max(mx);
@@ -194,8 +221,9 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
       ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Vs, a * 32, dt * 16, lane), pa, ot[dt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  if (qi < p.Tq) {
+  if (qi < p.Tq && !(p.ablate & 4)) {
     const float inv = 1.0f / l;
     bf16_t* orow = p.o + (long)b * p.o_sb + (long)qi * p.o_st + h * DH;
 #pragma unroll
@@ -213,7 +241,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------------
 // backward pass A: dQ (and delta = rowsum(dO * O)).  workgroup as in forward; K, V in LDS.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p, int nb) {
+// PLAIN (no mask, not causal): no predicate at all — kv rows past Tk are ZERO in LDS (DMA range check),
+// so their dS (finite: s = 0, dP = 0) meets K = 0 in the dQ product; padded query rows carry lse = +inf.
+template <bool PLAIN>
+__global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(AttnParams p, int nb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + nb * 32 * 128;
@@ -253,7 +284,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p, int nb) 
   if (qvalid && g == 0) p.delta[stat] = delta;
   const float lse2 = qvalid ? p.lse[stat] * LOG2E : INFINITY;  // +inf -> p = 0 for padded rows
   const float sl2 = p.scale * LOG2E;
-  const bool plain = (p.mask == nullptr) && !p.causal;
 
   f32x4 dqt[4];
 #pragma unroll
@@ -270,9 +300,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p, int nb) 
       dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vs, jt * 16, 1, lane), dof1, dp, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int j = jt * 16 + 4 * g + r;
-        const bool keep = plain ? (j < p.Tk) : keep_at(p, b, h, qvalid ? qi : p.Tq - 1, j);
-        const float pr = keep ? __builtin_amdgcn_exp2f(s[r] * sl2 - lse2) : 0.f;
+        float pr = __builtin_amdgcn_exp2f(s[r] * sl2 - lse2);
+        if (!PLAIN) pr = keep_at(p, b, h, qvalid ? qi : p.Tq - 1, jt * 16 + 4 * g + r) ? pr : 0.f;
         ds[t][r] = pr * (dp[r] - delta);
       }
     }
@@ -297,7 +326,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p, int nb) 
 // backward pass B: dK, dV.  workgroup = (kv chunk of nwaves*16 rows, head, batch); Q, dO, lse,
 // delta of the whole head in LDS; nbq = ceil(Tq / 32).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p, int nbq) {
+// PLAIN: no predicate — a kv row past Tk only pollutes its own (never stored) dK / dV row, padded query
+// rows carry lse = +inf (p = 0).
+template <bool PLAIN>
+__global__ __launch_bounds__(512, 4) void attn_bwd_dkv_kernel(AttnParams p, int nbq) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
   char* dOs = smem + nbq * 32 * 128;
@@ -307,6 +339,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p, int nbq
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
+  if (!(p.ablate & 1)) {
   dma_tile(Qs, p.q + (long)b * p.q_sb + h * DH, p.q_st, p.Tq, nbq * 32, wave, nwaves, lane);
   dma_tile(dOs, p.d_o + (long)b * p.o_sb + h * DH, p.o_st, p.Tq, nbq * 32, wave, nwaves, lane);
   // lse and delta_i = sum_d dO[i][d] * O[i][d] of every query row (delta is recomputed here from the
@@ -333,7 +366,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p, int nbq
       lse_s[t] = t < p.Tq ? p.lse[((long)b * p.H + h) * p.Tq + t] * LOG2E : INFINITY;
     }
   }
+  }
   __syncthreads();
+  if (p.ablate & 2) return;
 
   const int n = lane & 15, g = lane >> 4;
   for (int row0 = (blockIdx.x * nwaves + wave) * 16; row0 < p.Tk; row0 += gridDim.x * nwaves * 16) {
@@ -345,7 +380,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p, int nbq
   const bf16x8 vf0 = frag_global(vb, p.kv_st, row0, p.Tk, 0, lane);
   const bf16x8 vf1 = frag_global(vb, p.kv_st, row0, p.Tk, 1, lane);
   const float sl2 = p.scale * LOG2E;
-  const bool plain = (p.mask == nullptr) && !p.causal;
 
   f32x4 dkt[4], dvt[4];
 #pragma unroll
@@ -365,9 +399,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p, int nbq
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + it * 16 + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int qi = it * 16 + 4 * g + r;
-        const bool keep = plain ? (kj < p.Tk) : (qi < p.Tq && keep_at(p, b, h, qi, kj));
-        const float pr = keep ? __builtin_amdgcn_exp2f(s[r] * sl2 - l4[r]) : 0.f;
+        float pr = __builtin_amdgcn_exp2f(s[r] * sl2 - l4[r]);
+        if (!PLAIN) {
+          const int qi = it * 16 + 4 * g + r;
+          pr = (qi < p.Tq && keep_at(p, b, h, qi, kj)) ? pr : 0.f;
+        }
         pp[t][r] = pr;
         ds[t][r] = pr * (dp[r] - d4[r]);
       }
@@ -380,7 +416,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p, int nbq
       dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Qs, a * 32, dt * 16, lane), dsk, dkt[dt], 0, 0, 0);
     }
   }
-  if (kj < p.Tk) {
+  if (kj < p.Tk && !(p.ablate & 4)) {
     bf16_t* dkrow = p.dk + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH;
     bf16_t* dvrow = p.dv + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH;
 #pragma unroll
@@ -435,6 +471,11 @@ int set_lds(K kernel, size_t bytes, const char* who) {
 
 }  // namespace
 
+int cfhip_internal_set_attn_ablate(int v) {
+  g_attn_ablate = v;
+  return CFHIP_OK;
+}
+
 extern "C" int cfhip_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                               const uint8_t* mask, int B, int H, int Tq, int Tk, int64_t q_stride_b,
                               int64_t q_stride_t, int64_t kv_stride_b, int64_t kv_stride_t,
@@ -452,6 +493,7 @@ extern "C" int cfhip_attn_fwd(const void* q, const void* k, const void* v, void*
   p.o_sb = o_stride_b; p.o_st = o_stride_t;
   p.ms_b = ms_b; p.ms_h = ms_h; p.ms_q = ms_q;
   p.scale = scale; p.causal = causal;
+  p.ablate = g_attn_ablate;
   const int nb = (Tk + 31) / 32;
   const int nw = pick_waves(Tq);
   const int tiles = (Tq + 15) / 16;
@@ -459,8 +501,12 @@ extern "C" int cfhip_attn_fwd(const void* q, const void* k, const void* v, void*
   dim3 grid(1, H, B), block(nw * 64);
   const size_t lds = (size_t)2 * nb * 32 * 128;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define CFHIP_ATTN_FWD(NB_) \
-  case NB_: hipLaunchKernelGGL((attn_fwd_kernel<NB_>), grid, block, lds, s, p); break;
+  const bool plain = mask == nullptr && !causal;
+#define CFHIP_ATTN_FWD(NB_)                                                                         \
+  case NB_:                                                                                         \
+    if (plain) hipLaunchKernelGGL((attn_fwd_kernel<NB_, true>), grid, block, lds, s, p);            \
+    else hipLaunchKernelGGL((attn_fwd_kernel<NB_, false>), grid, block, lds, s, p);                 \
+    break;
   switch (nb) {
     CFHIP_ATTN_FWD(1) CFHIP_ATTN_FWD(2) CFHIP_ATTN_FWD(3) CFHIP_ATTN_FWD(4)
     CFHIP_ATTN_FWD(5) CFHIP_ATTN_FWD(6) CFHIP_ATTN_FWD(7) CFHIP_ATTN_FWD(8)
@@ -496,6 +542,8 @@ extern "C" int cfhip_attn_bwd(const void* q, const void* k, const void* v, const
   p.scale = scale; p.causal = causal;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   p.delta_ready = (parts & 3) == 3;
+  p.ablate = g_attn_ablate;
+  const bool plain = mask == nullptr && !causal;
   CFHIP_REQUIRE((parts & 3) != 0, "attn_bwd: parts must select the dQ pass (1), the dK/dV pass (2) or both (3)");
   if (parts & 1) {
     const int nb = (Tk + 31) / 32;
@@ -504,7 +552,8 @@ extern "C" int cfhip_attn_bwd(const void* q, const void* k, const void* v, const
     (void)tiles;
     dim3 grid(1, H, B), block(nw * 64);
     const size_t lds = (size_t)2 * nb * 32 * 128;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, lds, s, p, nb);
+    if (plain) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, block, lds, s, p, nb);
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, block, lds, s, p, nb);
     CFHIP_CHECK_LAUNCH("attn_bwd_dq");
   }
   if (parts & 2) {
@@ -514,9 +563,10 @@ extern "C" int cfhip_attn_bwd(const void* q, const void* k, const void* v, const
     (void)tiles;
     dim3 grid(1, H, B), block(nw * 64);
     const size_t lds = (size_t)2 * nbq * 32 * 128 + (size_t)2 * nbq * 32 * sizeof(float);
-    rc = set_lds(attn_bwd_dkv_kernel, lds, "attn_bwd_dkv");
+    rc = plain ? set_lds(attn_bwd_dkv_kernel<true>, lds, "attn_bwd_dkv") : set_lds(attn_bwd_dkv_kernel<false>, lds, "attn_bwd_dkv");
     if (rc != CFHIP_OK) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, lds, s, p, nbq);
+    if (plain) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, block, lds, s, p, nbq);
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, block, lds, s, p, nbq);
     CFHIP_CHECK_LAUNCH("attn_bwd_dkv");
   }
   return CFHIP_OK;

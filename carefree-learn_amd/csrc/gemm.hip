@@ -459,49 +459,38 @@ void gemm_bf16_kernel(GemmParams p) {
   }
 }
 
-// ---- register-pipelined variant ----------------------------------------------------------------------
-// Same tiles, ring and epilogue, different K loop (BK = 32, 4 ring slots): the MFMA operands of K-step
-// t+1 are read from LDS into a SECOND fragment register set while the MFMAs of step t run, so a wave's
-// MFMA stream never waits for an LDS round trip; the DMA runs 3-4 steps ahead.  Per iteration t:
-//   (A) ds_read fragments(t+1)  <- slot (t+1)%4   (landed + visible since the barrier of iteration t-1)
-//   (B) 16 MFMAs on fragments(t)
-//   (C) s_waitcnt vmcnt: own DMA of step t+2 landed; s_barrier
-//   (D) DMA step t+4 -> slot t%4 (its fragments were consumed in (B) by every wave that passed (C))
-template <bool AT, bool BT, class C>
-struct Frags {
-  bf16x8 a[C::FM];
-  bf16x8 b[C::FN];
-};
-
-template <bool AT, bool BT, class C>
-__device__ __forceinline__ void load_frags(const char* tile, int wm, int wn, int lane, Frags<AT, BT, C>& f) {
-  const int i = lane & 15, g = lane >> 4;
-  const char* b_tile = tile + C::A_BYTES;
-#pragma unroll
-  for (int t = 0; t < C::FM; ++t)
-    f.a[t] = AT ? frag_mmajor<C::BM>(tile, wm * (C::FM * 16) + t * 16, 0, lane)
-                : frag_kmajor<C::BK>(tile, wm * (C::FM * 16) + t * 16, 0, i, g);
-#pragma unroll
-  for (int t = 0; t < C::FN; ++t)
-    f.b[t] = BT ? frag_mmajor<C::BN>(b_tile, wn * (C::FN * 16) + t * 16, 0, lane)
-                : frag_kmajor<C::BK>(b_tile, wn * (C::FN * 16) + t * 16, 0, i, g);
-}
-
-template <bool AT, bool BT, class C>
-__device__ __forceinline__ void mfma_frags(const Frags<AT, BT, C>& f, f32x4 (&acc)[C::FM][C::FN]) {
-#pragma unroll
-  for (int mi = 0; mi < C::FM; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < C::FN; ++ni)
-      acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[ni], f.a[mi], acc[mi][ni], 0, 0, 0);
-}
-
+// ---- big-tile, two-group "ping-pong" variant -----------------------------------------------------------
+// 128^2 tiles move 1 byte L2 -> LDS per 64 flop: at the dense MFMA rate that is ~39 TB/s, more than the
+// eight L2s deliver (the DMA-only ablation of the kernel above tops out at ~19 TB/s), so the 128^2
+// kernels are L2-bandwidth bound at about half the MFMA peak.  This variant works on a 256 x 256 (or
+// 256 x 128) tile with 8 waves (2 x 4), one workgroup per CU, BK = 32, a 4-slot LDS ring (DMA three
+// K-steps ahead, counted vmcnt, never drained inside the loop) and splits every K-step in two PHASES
+// (upper / lower half of the wave's rows):
+//
+//     L segment: ds_read the phase's fragments        | s_barrier |
+//     M segment: 16 MFMAs (s_setprio 1)                | s_barrier |
+//
+// The two wave groups (wm = 0 / 1; waves w and w + 4 share a SIMD) run STAGGERED by one barrier: group 1
+// executes one extra barrier before the loop, group 0 one after it.  In every barrier interval one
+// group is in its M segment and the other in its L segment, so each SIMD's MFMA pipe always has a
+// wave with operands in registers while its partner's LDS reads are in flight.
+//
+// Ordering (by count, not by luck).  Intervals are numbered by barriers; group 0 runs L(t,ph) in
+// interval 4t + 2ph and M(t,ph) in 4t + 2ph + 1, group 1 one interval later.
+//   RAW: the DMA of K-step t+1 (issued in M(t-2, 1)) is retired by every wave's counted vmcnt BEFORE
+//        the barrier that ends its L(t, 1) (intervals 4t+2 / 4t+3); the first read of step t+1 is
+//        group 0's L(t+1, 0) in interval 4t+4.
+//   WAR: slot (t+3)&3 held step t-1, last read in group 1's L(t-1, 1) (interval 4t-1) and retired by
+//        the lgkmcnt waits in front of its MFMAs in interval 4t; the DMA of step t+3 is issued AFTER the barrier
+//        that ends L(t, 1), i.e. in interval 4t+3 (group 0) / 4t+4 (group 1).
 template <bool AT, bool BT, int EPI, class C>
 __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD)
-void gemm_bf16_pipe_kernel(GemmParams p) {
+void gemm_bf16_phase_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(C::BK == 32 && C::NSTAGE == 4, "the register-pipelined loop is written for BK = 32, 4 ring slots");
-  static_assert(C::NW * 16 * (C::FN * 16) * 4 <= C::STAGE_BYTES, "epilogue staging must fit in one ring slot");
+  static_assert(C::BK == 32 && (C::NSTAGE == 3 || C::NSTAGE == 4) && C::WM == 2, "phase kernel: BK = 32, 3-4 ring slots, 2 wave rows");
+  constexpr int D = C::NSTAGE - 1;  // prefetch distance (K-steps)
+  static_assert(C::NW * 16 * (C::FN * 16) * 4 <= C::LDS_BYTES, "epilogue staging must fit in the (free) ring");
+  constexpr int HM = C::FM / 2;  // row fragments per phase
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7;
@@ -511,6 +500,7 @@ void gemm_bf16_pipe_kernel(GemmParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / C::WN, wn = wave % C::WN;
+  const int i = lane & 15, g = lane >> 4;
 
   const ItemCtx<AT, BT, C> cur = setup_item<AT, BT, C>(p, item, wave, lane);
   const int nk = cur.nk;
@@ -521,38 +511,62 @@ void gemm_bf16_pipe_kernel(GemmParams p) {
     for (int ni = 0; ni < C::FN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
-  for (int st = 0; st < 4; ++st)
+  for (int st = 0; st < D; ++st)
     if (st < nk) stage_step<AT, BT, C>(cur, p, smem, st, wave, st);
-  {  // steps 0 and 1 must have landed: at most the stages beyond step 1 stay in flight
-    const int younger = min(nk, 4) - 2;
-    if (younger >= 2) CFHIP_WAIT_VMCNT(2 * C::LPS);
+  {  // K-step 0 has landed; the younger ones stay in flight
+    const int younger = min(nk, D) - 1;
+    if (D >= 3 && younger >= 2) CFHIP_WAIT_VMCNT(2 * C::LPS);
     else if (younger == 1) CFHIP_WAIT_VMCNT(1 * C::LPS);
     else CFHIP_WAIT_VMCNT(0);
   }
   __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // the stagger
 
-  Frags<AT, BT, C> f0, f1;
-  load_frags<AT, BT, C>(smem, wm, wn, lane, f0);
-
-  // (C) + (D) of iteration t
-  auto sync_and_stage = [&](int t) {
-    if (t + 3 < nk) CFHIP_WAIT_VMCNT(1 * C::LPS);  // step t+3 may stay in flight, step t+2 has landed
-    else CFHIP_WAIT_VMCNT(0);
-    __builtin_amdgcn_s_barrier();
-    if (t + 4 < nk) stage_step<AT, BT, C>(cur, p, smem, t & 3, wave, t + 4);
-  };
-
-  for (int t = 0; t < nk; t += 2) {
-    if (t + 1 < nk) load_frags<AT, BT, C>(smem + ((t + 1) & 3) * C::STAGE_BYTES, wm, wn, lane, f1);
-    mfma_frags<AT, BT, C>(f0, acc);
-    sync_and_stage(t);
-    if (t + 1 >= nk) break;
-    if (t + 2 < nk) load_frags<AT, BT, C>(smem + ((t + 2) & 3) * C::STAGE_BYTES, wm, wn, lane, f0);
-    mfma_frags<AT, BT, C>(f1, acc);
-    sync_and_stage(t + 1);
+  int rd = 0, wr = D;  // ring slots of K-steps t and t + D
+  for (int t = 0; t < nk; ++t) {
+    const char* a_tile = smem + rd * C::STAGE_BYTES;
+    const char* b_tile = a_tile + C::A_BYTES;
+    bf16x8 bfr[C::FN], af[HM];
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      // ---- L segment
+      if (ph == 0) {
+#pragma unroll
+        for (int n = 0; n < C::FN; ++n)
+          bfr[n] = BT ? frag_mmajor<C::BN>(b_tile, wn * (C::FN * 16) + n * 16, 0, lane)
+                      : frag_kmajor<C::BK>(b_tile, wn * (C::FN * 16) + n * 16, 0, i, g);
+      }
+#pragma unroll
+      for (int m = 0; m < HM; ++m)
+        af[m] = AT ? frag_mmajor<C::BM>(a_tile, wm * (C::FM * 16) + (ph * HM + m) * 16, 0, lane)
+                   : frag_kmajor<C::BK>(a_tile, wm * (C::FM * 16) + (ph * HM + m) * 16, 0, i, g);
+      if (ph == 1) {  // own DMA of K-step t+1 retired (step t+2 may still be in flight when D == 3)
+        if (D >= 3 && t + 2 < nk) CFHIP_WAIT_VMCNT(1 * C::LPS);
+        else CFHIP_WAIT_VMCNT(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- M segment
+      // (the compiler's own lgkmcnt ladder in front of the MFMAs retires the fragment reads)
+      if (ph == 1 && t + D < nk) stage_step<AT, BT, C>(cur, p, smem, wr, wave, t + D);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int m = 0; m < HM; ++m)
+#pragma unroll
+        for (int n = 0; n < C::FN; ++n)
+          acc[ph * HM + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[n], af[m], acc[ph * HM + m][n], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    rd = rd + 1 == C::NSTAGE ? 0 : rd + 1;
+    wr = wr + 1 == C::NSTAGE ? 0 : wr + 1;
   }
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // every wave has executed the same number of barriers
   if (p.ablate & 4) return;
-  // every wave is past the last barrier and holds its last fragments in registers: the ring is free
+  // all DMA retired (the last wait was vmcnt(0)), all fragment reads retired: the ring is free
   epilogue<EPI, C>(p, acc, smem, cur.m0, cur.n0, cur.z, wm, wn, wave, lane);
 }
 
@@ -633,18 +647,26 @@ using CfgD = Cfg<128, 64, 2, 2, 2, 64>;   //  48 KiB LDS, 4 waves (64x32 each), 
 using CfgE = Cfg<128, 128, 2, 2, 4, 32>;  //  64 KiB LDS, 4 waves, 2 WG / CU, prefetch 3
 using CfgF = Cfg<128, 64, 2, 2, 2, 32>;   //  24 KiB LDS, 4 waves (64x32 each), 4 WG / CU, prefetch 1
 using CfgG = Cfg<128, 64, 2, 2, 3, 32>;   //  36 KiB LDS, 4 waves (64x32 each), 4 WG / CU, prefetch 2
-constexpr int NUM_CFG = 8;  // 7 = CfgE with the register-pipelined K loop
+using CfgP = Cfg<256, 256, 2, 4, 4, 32>;  // 128 KiB LDS, 8 waves, 1 WG / CU, prefetch 3: two-group phase kernel
+using CfgQ = Cfg<256, 128, 2, 4, 3, 32>;  //  72 KiB LDS, 8 waves (128x32 each), 2 WG / CU
+using CfgR = Cfg<256, 128, 2, 2, 3, 32>;  //  72 KiB LDS, 4 waves (128x64 each), 2 WG / CU, prefetch 2
+using CfgS = Cfg<128, 256, 2, 2, 3, 32>;  //  72 KiB LDS, 4 waves (64x128 each), 2 WG / CU, prefetch 2
+constexpr int NUM_CFG = 11;  // 7 .. 10 = CfgP / CfgQ / CfgR / CfgS on the phase kernel
 constexpr int BK_MAX = 64;
 
 int g_gemm_config = -1;
 int g_gemm_ablate = 0;
 int g_gemm_persistent = 0;
-int g_gemm_heuristic = 0;
+int g_gemm_heuristic = 3;
 
 template <bool AT, bool BT, int EPI, class C, bool PIPE>
 int launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
   void (*kern)(GemmParams) = nullptr;
-  if constexpr (PIPE) kern = gemm_bf16_pipe_kernel<AT, BT, EPI, C>;
+  if (PIPE && p.bgrad != nullptr) {
+    cfhip_set_error("gemm: the fused bias gradient is not provided by the big-tile kernel (gemm_config 7 / 8)");
+    return CFHIP_ERR_INVALID;
+  }
+  if constexpr (PIPE) kern = gemm_bf16_phase_kernel<AT, BT, EPI, C>;
   else kern = gemm_bf16_kernel<AT, BT, EPI, C>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done && C::LDS_BYTES > 64 * 1024) {
@@ -714,12 +736,22 @@ int pick_config(int M, int N, int a_trans, int b_trans) {
     if (a_trans || b_trans) return 1;
     return N <= 1024 ? 1 : 0;
   }
+  if (g_gemm_heuristic >= 2) {  // + the 256x128 two-group kernel for the wide outputs
+    if (a_trans) return 1;
+    if (N >= 2560 && M >= 1024) return 8;
+    if (g_gemm_heuristic == 3) {  // 128x128x64 once it fills the 512 resident slots at least twice
+      const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+      if (tiles128 >= 1024) return 0;
+    }
+  }
   if (a_trans || b_trans) return 1;   // 128x128x32, 4 WG / CU
   if (N <= 1024) return 3;            // 128x64x64, 3 WG / CU
   return 0;                           // 128x128x64, 2 WG / CU
 }
 
 }  // namespace
+
+int cfhip_internal_set_attn_ablate(int v);  // attn.hip
 
 extern "C" int cfhip_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "gemm_config") == 0) {
@@ -738,6 +770,7 @@ extern "C" int cfhip_set_option(const char* name, int value) {
     g_gemm_ablate = value;
     return CFHIP_OK;
   }
+  if (name != nullptr && strcmp(name, "attn_ablate") == 0) return cfhip_internal_set_attn_ablate(value);
   cfhip_set_error("set_option: unknown option '%s'", name ? name : "(null)");
   return CFHIP_ERR_INVALID;
 }
@@ -818,7 +851,10 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
     case 4: rc = launch_layout<CfgE>(p, a_trans, b_trans, epilogue, split_k, s); break;
     case 5: rc = launch_layout<CfgF>(p, a_trans, b_trans, epilogue, split_k, s); break;
     case 6: rc = launch_layout<CfgG>(p, a_trans, b_trans, epilogue, split_k, s); break;
-    case 7: rc = launch_layout<CfgE, true>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 7: rc = launch_layout<CfgP, true>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 8: rc = launch_layout<CfgQ, true>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 9: rc = launch_layout<CfgR, true>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 10: rc = launch_layout<CfgS, true>(p, a_trans, b_trans, epilogue, split_k, s); break;
     default: rc = launch_layout<CfgA>(p, a_trans, b_trans, epilogue, split_k, s); break;
   }
   if (rc != CFHIP_OK) return rc;

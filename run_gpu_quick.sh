@@ -1,12 +1,8 @@
 #!/bin/bash
-# quick correctness + bandwidth + bench cycle
+# quick check: all GPU tests + default bench (no cpu baseline) + batch 64
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-for f in gemm norm_elem attn modules train; do
-  timeout 600 python -m pytest tests/test_gpu_$f.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/test_$f.log 2>&1
-  echo "== test_gpu_$f exit $?"; tail -n 2 gpurun_out/test_$f.log
-done
-timeout 300 python tools/bw_bench.py 2>&1 | grep -E "LN|colsum" 
-timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/bench_graph.log 2>&1
-echo "== bench graph exit $?"; grep -E "timed region" gpurun_out/bench_graph.log; tail -c 300 gpurun_out/bench_graph.log
+timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/pytest_gpu.log 2>&1; echo "== pytest -m gpu exit $?"; tail -n 3 gpurun_out/pytest_gpu.log
+timeout 600 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('b128', d['value'], d['ms_per_step'])"
+timeout 600 python bench.py --no-cpu-baseline --no-roofline --batch 64 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('b64', d['value'], d['ms_per_step'])"

@@ -177,12 +177,15 @@ def test_fused_bias_gradient_of_dw_gemm():
             assert_close(gw, 2 * want_w, 2e-5, "dW accumulate")
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_every_tile_config(cfg):
     """all tile configurations of the kernel on ragged shapes, all three layouts"""
     try:
         ops.set_option("gemm_config", cfg)
-        for (m, n, k) in ((333, 264, 200), (128, 64, 32), (520, 1000, 72)):
+        shapes = ((333, 264, 200), (128, 64, 32), (520, 1000, 72))
+        if cfg >= 7:  # big-tile phase kernel: several tiles, long K loops (ring wrap-around), K tails
+            shapes += ((1032, 776, 1000), (512, 512, 96), (256, 256, 32))
+        for (m, n, k) in shapes:
             for layout in ("nt", "nn", "tn"):
                 a_trans, b_trans = layout == "tn", layout in ("nn", "tn")
                 if a_trans and m % 8:

@@ -58,7 +58,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--configs", default="0,1,4,7")
+    ap.add_argument("--configs", default="0,1,3,7,8")
+    ap.add_argument("--lt", action="store_true", help="also time torch.matmul (hipBLASLt, no epilogue) for context")
     args = ap.parse_args()
     dev = torch.device("cuda")
     cfgs = [int(c) for c in args.configs.split(",")]
@@ -91,6 +92,18 @@ def main():
             totals[c] += count * us
             best = us if best is None else min(best, us)
             line.append(f"c{c}: {us:7.1f}us {tf:6.0f}TF {'ok' if ok else f'BAD({err:.1e})'}")
+        if args.lt:
+            fn = {"nt": lambda: a @ b.t(), "nn": lambda: a @ b, "tn": lambda: a.t() @ b}[layout]
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / args.reps
+            line.append(f"hipBLASLt(no epi): {us:7.1f}us {2.0 * m * n * k / us / 1e6:6.0f}TF")
         best_total += count * best
         flops_total += count * 2.0 * m * n * k
         print(f"{layout} {m:6d}x{n:5d}x{k:6d} {epi:9s} x{count:2d} | " + " | ".join(line), flush=True)

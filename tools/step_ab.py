@@ -13,13 +13,14 @@ torch.manual_seed(0)
 model = C.vit_b16_classifier(1000).to(dev)
 ts = TrainStep(model, lr=1e-4, use_graph=False)
 g = torch.Generator().manual_seed(1234)
-img = torch.randn(64, 3, 224, 224, generator=g).to(dev)
-labels = torch.randint(0, 1000, (64,), generator=g).to(dev)
+BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+img = torch.randn(BATCH, 3, 224, 224, generator=g).to(dev)
+labels = torch.randint(0, 1000, (BATCH,), generator=g).to(dev)
 
 VARIANTS = {
-    "2 side streams": dict(gemm_heuristic=0, gemm_persistent=0, side=True, lanes=2),
-    "1 side stream": dict(gemm_heuristic=0, gemm_persistent=0, side=True, lanes=1),
-    "no side stream": dict(gemm_heuristic=0, gemm_persistent=0, side=False, lanes=1),
+    "heuristic 0": dict(gemm_heuristic=0, gemm_persistent=0, side=True, lanes=2),
+    "heuristic 2 (+256x128)": dict(gemm_heuristic=2, gemm_persistent=0, side=True, lanes=2),
+    "heuristic 3 (+tile count)": dict(gemm_heuristic=3, gemm_persistent=0, side=True, lanes=2),
 }
 
 def apply(v):
