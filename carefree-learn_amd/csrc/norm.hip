@@ -9,7 +9,8 @@
 // wave-wide xor-shuffles, gamma / beta are hoisted into registers once per wave.  The backward
 // keeps per-lane partial dgamma / dbeta in registers across all rows a wave visits, folds the
 // waves of a workgroup through LDS float atomics, and a second tiny kernel reduces the per-
-// workgroup partials — no global atomics, deterministic for a fixed launch geometry.
+// workgroup partials — no global atomics.  The order in which a workgroup's waves reach the LDS
+// atomics is not fixed, so dgamma / dbeta are reproducible to fp32 rounding (~1e-7), not bitwise.
 #include "common.h"
 
 int cfhip_internal_colreduce_f32(const float* partials, int R, int D, float* out, int accumulate,

@@ -90,6 +90,71 @@ def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: T
     return dx
 
 
+def _block_fwd(x2: Tensor, prm: tuple, num_heads: int, eps1: float, eps2: float, bsz: int, t: int,
+               keep_mask: Optional[Tensor], causal: bool):
+    """One pre-norm block on the [B*T, D] residual stream (f32 or bf16).  Returns (y2, saved tensors)."""
+    ln1_w, ln1_b, in_w, qkv_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2 = prm
+    d = x2.shape[1]
+    fb = lambda p: None if p is None else p.detach().reshape(-1)  # noqa: E731
+    in_w16, out_w16 = shadow_bf16(in_w), shadow_bf16(out_w)
+    w1_16, w2_16 = shadow_bf16(w1), shadow_bf16(w2)
+
+    ln1, mean1, rstd1 = ops.layernorm_fwd(x2, ln1_w.detach(), ln1_b.detach(), eps1)
+    qkv = ops.gemm(ln1, in_w16, bias=fb(qkv_b))
+    qkv3 = qkv.view(bsz, t, 3 * d)
+    o, lse = ops.attn_fwd(qkv3[..., :d], qkv3[..., d:2 * d], qkv3[..., 2 * d:], num_heads,
+                          mask=keep_mask, causal=causal)
+    o2 = o.view(bsz * t, d)
+    x1 = ops.gemm(o2, out_w16, bias=fb(out_b), epilogue=ops.EPI_RESIDUAL, aux_in=x2, out_dtype=x2.dtype)
+    ln2, mean2, rstd2 = ops.layernorm_fwd(x1, ln2_w.detach(), ln2_b.detach(), eps2)
+    pre = torch.empty((bsz * t, w1.shape[0]), dtype=bf16, device=x2.device)
+    h = ops.gemm(ln2, w1_16, bias=fb(b1), epilogue=ops.EPI_GELU, aux_out=pre)
+    y = ops.gemm(h, w2_16, bias=fb(b2), epilogue=ops.EPI_RESIDUAL, aux_in=x1, out_dtype=x1.dtype)
+    saved = (x2, mean1, rstd1, ln1, qkv, o2, lse, x1, mean2, rstd2, ln2, pre, h, in_w16, out_w16, w1_16, w2_16)
+    return y, saved
+
+
+N_SAVED = 17  # tensors per block in `saved`
+
+
+def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_mask: Optional[Tensor],
+               causal: bool, d2: Tensor) -> Tensor:
+    """Backward of one block: d2 = dL/dy as bf16 [B*T, D]; returns dL/dx as bf16 [B*T, D]; parameter
+    gradients go straight into `.grad` (side streams)."""
+    x2, mean1, rstd1, ln1, qkv, o2, lse, x1, mean2, rstd2, ln2, pre, h, in_w16, out_w16, w1_16, w2_16 = saved
+    ln1_w, ln1_b, in_w, qkv_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2 = prm
+    d = d2.shape[1]
+    # Parameter-gradient GEMMs go to the side stream BEFORE their sibling dX GEMM is issued, so the
+    # two run concurrently; the dX chain on the main stream is the critical path.
+    # channel mixing
+    SideStream.run(lambda: _dw_db(w2, b2, d2, h), (d2, h))
+    dpre = ops.gemm(d2, w2_16, b_trans=True, epilogue=ops.EPI_DGELU, aux_in=pre)
+    SideStream.run(lambda: _dw_db(w1, b1, dpre, ln2), (dpre, ln2))
+    dln2 = ops.gemm(dpre, w1_16, b_trans=True)
+    dx1 = _ln_bwd(dln2, x1, ln2_w, ln2_b, mean2, rstd2, dx_add=d2)
+
+    # token mixing
+    SideStream.run(lambda: _dw_db(out_w, out_b, dx1, o2), (dx1, o2))
+    d_o = ops.gemm(dx1, out_w16, b_trans=True)
+    dqkv = torch.empty_like(qkv)
+    qkv3, dqkv3 = qkv.view(bsz, t, 3 * d), dqkv.view(bsz, t, 3 * d)
+    o3, do3 = o2.view(bsz, t, d), d_o.view(bsz, t, d)
+    akw = dict(dq=dqkv3[..., :d], dk=dqkv3[..., d:2 * d], dv=dqkv3[..., 2 * d:], mask=keep_mask,
+               causal=causal)
+    # (the two passes are independent kernels — `parts` — but running them on two streams measured
+    # slower end-to-end: the main stream has to wait for both anyway)
+    ops.attn_bwd(qkv3[..., :d], qkv3[..., d:2 * d], qkv3[..., 2 * d:], o3, do3, lse, num_heads, **akw)
+    SideStream.run(lambda: _dw_db(in_w, qkv_b, dqkv, ln1), (dqkv, ln1))
+    dln1 = ops.gemm(dqkv, in_w16, b_trans=True)
+    return _ln_bwd(dln1, x2, ln1_w, ln1_b, mean1, rstd1, dx_add=dx1)
+
+
+def _as_bf16_rows(dy: Tensor, rows: int, d: int) -> Tensor:
+    if dy.dtype != bf16:
+        dy = ops.to_bf16(dy.float().contiguous())
+    return dy.contiguous().view(rows, d)
+
+
 class MixingBlockFn(Function):
     @staticmethod
     def forward(ctx: Any, x: Tensor, ln1_w: Tensor, ln1_b: Tensor, in_w: Tensor, qkv_b: Optional[Tensor],
@@ -99,65 +164,62 @@ class MixingBlockFn(Function):
         bsz, t, d = x.shape
         if x.dtype not in (bf16, f32):
             x = x.float()
-        x = x.contiguous()
-        x2 = x.view(bsz * t, d)  # residual stream: f32 (reference autocast semantics) or bf16
-        fb = lambda p: None if p is None else p.detach().reshape(-1)  # noqa: E731
-        in_w16, out_w16 = shadow_bf16(in_w), shadow_bf16(out_w)
-        w1_16, w2_16 = shadow_bf16(w1), shadow_bf16(w2)
-
-        ln1, mean1, rstd1 = ops.layernorm_fwd(x2, ln1_w.detach(), ln1_b.detach(), eps1)
-        qkv = ops.gemm(ln1, in_w16, bias=fb(qkv_b))
-        qkv3 = qkv.view(bsz, t, 3 * d)
-        o, lse = ops.attn_fwd(qkv3[..., :d], qkv3[..., d:2 * d], qkv3[..., 2 * d:], num_heads,
-                              mask=keep_mask, causal=causal)
-        o2 = o.view(bsz * t, d)
-        x1 = ops.gemm(o2, out_w16, bias=fb(out_b), epilogue=ops.EPI_RESIDUAL, aux_in=x2, out_dtype=x2.dtype)
-        ln2, mean2, rstd2 = ops.layernorm_fwd(x1, ln2_w.detach(), ln2_b.detach(), eps2)
-        pre = torch.empty((bsz * t, w1.shape[0]), dtype=bf16, device=x.device)
-        h = ops.gemm(ln2, w1_16, bias=fb(b1), epilogue=ops.EPI_GELU, aux_out=pre)
-        y = ops.gemm(h, w2_16, bias=fb(b2), epilogue=ops.EPI_RESIDUAL, aux_in=x1, out_dtype=x1.dtype)
-
-        ctx.save_for_backward(x2, mean1, rstd1, ln1, qkv, o2, lse, x1, mean2, rstd2, ln2, pre, h,
-                              in_w16, out_w16, w1_16, w2_16, keep_mask)
-        ctx.params = (ln1_w, ln1_b, in_w, qkv_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2)
+        x2 = x.contiguous().view(bsz * t, d)  # residual stream: f32 (reference autocast semantics) or bf16
+        prm = (ln1_w, ln1_b, in_w, qkv_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2)
+        y, saved = _block_fwd(x2, prm, num_heads, eps1, eps2, bsz, t, keep_mask, causal)
+        ctx.save_for_backward(*saved, keep_mask)
+        ctx.params = prm
         ctx.meta = (bsz, t, d, num_heads, causal)
         return y.view(bsz, t, d)
 
     @staticmethod
     def backward(ctx: Any, dy: Tensor):  # type: ignore
-        (x2, mean1, rstd1, ln1, qkv, o2, lse, x1, mean2, rstd2, ln2, pre, h, in_w16, out_w16, w1_16,
-         w2_16, keep_mask) = ctx.saved_tensors
-        ln1_w, ln1_b, in_w, qkv_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2 = ctx.params
+        *saved, keep_mask = ctx.saved_tensors
         bsz, t, d, num_heads, causal = ctx.meta
-        if dy.dtype != bf16:
-            dy = ops.to_bf16(dy.float().contiguous())
-        d2 = dy.contiguous().view(bsz * t, d)
-
-        # Parameter-gradient GEMMs go to the side stream BEFORE their sibling dX GEMM is issued, so the
-        # two run concurrently; the dX chain on the main stream is the critical path.
-        # channel mixing
-        SideStream.run(lambda: _dw_db(w2, b2, d2, h), (d2, h))
-        dpre = ops.gemm(d2, w2_16, b_trans=True, epilogue=ops.EPI_DGELU, aux_in=pre)
-        SideStream.run(lambda: _dw_db(w1, b1, dpre, ln2), (dpre, ln2))
-        dln2 = ops.gemm(dpre, w1_16, b_trans=True)
-        dx1 = _ln_bwd(dln2, x1, ln2_w, ln2_b, mean2, rstd2, dx_add=d2)
-
-        # token mixing
-        SideStream.run(lambda: _dw_db(out_w, out_b, dx1, o2), (dx1, o2))
-        d_o = ops.gemm(dx1, out_w16, b_trans=True)
-        dqkv = torch.empty_like(qkv)
-        qkv3, dqkv3 = qkv.view(bsz, t, 3 * d), dqkv.view(bsz, t, 3 * d)
-        o3, do3 = o2.view(bsz, t, d), d_o.view(bsz, t, d)
-        akw = dict(dq=dqkv3[..., :d], dk=dqkv3[..., d:2 * d], dv=dqkv3[..., 2 * d:], mask=keep_mask,
-                   causal=causal)
-        # (the two passes are independent kernels — `parts` — but running them on two streams measured
-        # slower end-to-end: the main stream has to wait for both anyway)
-        ops.attn_bwd(qkv3[..., :d], qkv3[..., d:2 * d], qkv3[..., 2 * d:], o3, do3, lse, num_heads, **akw)
-        SideStream.run(lambda: _dw_db(in_w, qkv_b, dqkv, ln1), (dqkv, ln1))
-        dln1 = ops.gemm(dqkv, in_w16, b_trans=True)
-        dx = _ln_bwd(dln1, x2, ln1_w, ln1_b, mean1, rstd1, dx_add=dx1)
+        d2 = _as_bf16_rows(dy, bsz * t, d)
+        dx = _block_bwd(tuple(saved), ctx.params, num_heads, bsz, t, keep_mask, causal, d2)
         return (dx.view(bsz, t, d),) + (None,) * 17
+
+
+class MixingStackFn(Function):
+    """ALL blocks of a `MixedStackedEncoder` as one autograd node: the residual-gradient stream stays
+    bf16 from block to block (one node per block makes autograd cast every block's bf16 input gradient
+    to the f32 of the forward activation, and the next backward cast it back: 2 x 12 elementwise
+    kernels per step), and the engine walks 1 node instead of 12."""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, metas: tuple, keep_mask: Optional[Tensor], causal: bool,
+                *params: Optional[Tensor]) -> Tensor:
+        bsz, t, d = x.shape
+        if x.dtype not in (bf16, f32):
+            x = x.float()
+        cur = x.contiguous().view(bsz * t, d)
+        nblk = len(metas)
+        assert len(params) == 12 * nblk
+        all_saved = []
+        for i, (num_heads, eps1, eps2) in enumerate(metas):
+            cur, saved = _block_fwd(cur, params[12 * i:12 * i + 12], num_heads, eps1, eps2, bsz, t, keep_mask, causal)
+            all_saved.extend(saved)
+        ctx.save_for_backward(*all_saved, keep_mask)
+        ctx.params = params
+        ctx.meta = (bsz, t, d, metas, causal)
+        return cur.view(bsz, t, d)
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        *all_saved, keep_mask = ctx.saved_tensors
+        bsz, t, d, metas, causal = ctx.meta
+        d2 = _as_bf16_rows(dy, bsz * t, d)
+        for i in range(len(metas) - 1, -1, -1):
+            saved = tuple(all_saved[N_SAVED * i:N_SAVED * (i + 1)])
+            d2 = _block_bwd(saved, ctx.params[12 * i:12 * i + 12], metas[i][0], bsz, t, keep_mask, causal, d2)
+        return (d2.view(bsz, t, d), None, None, None) + (None,) * len(ctx.params)
 
 
 def mixing_block(x: Tensor, *args: Any) -> Tensor:
     return MixingBlockFn.apply(x, *args)
+
+
+def mixing_stack(x: Tensor, metas: tuple, keep_mask: Optional[Tensor], causal: bool, params: list) -> Tensor:
+    """`metas[i]` = (num_heads, eps1, eps2) of block i, `params` = its 12 parameters, concatenated."""
+    return MixingStackFn.apply(x, metas, keep_mask, causal, *params)

@@ -438,18 +438,21 @@ class MixingBlock(Module):
         params = [att.in_w, att.out_linear.linear.weight, cmix.net[0].linear.weight, cmix.net[3].linear.weight]
         return all(HF._is_direct(p) for p in params)
 
+    def fused_params(self) -> list:
+        """the 12 parameters in the order fused.MixingBlockFn / MixingStackFn take them"""
+        att, ff = self.token_mixing.net, self.channel_mixing
+        return [self.token_norm.weight, self.token_norm.bias, att.in_w, att.qkv_bias,
+                att.out_linear.linear.weight, att.out_linear.linear.bias, self.channel_norm.weight,
+                self.channel_norm.bias, ff.net[0].linear.weight, ff.net[0].linear.bias,
+                ff.net[3].linear.weight, ff.net[3].linear.bias]
+
     def forward(self, net: Tensor, hw: Optional[Tuple[int, int]] = None, *, deterministic: bool = False,
                 mask: Optional[Tensor] = None, **kwargs: Any) -> Tensor:
         if self.use_fused and not kwargs and net.dim() == 3 and self._fusable():
-            att, ff = self.token_mixing.net, self.channel_mixing
+            att = self.token_mixing.net
             keep = None if mask is None else expand_module_mask(mask, att.num_heads)
-            return fused.mixing_block(
-                net, self.token_norm.weight, self.token_norm.bias, att.in_w, att.qkv_bias,
-                att.out_linear.linear.weight, att.out_linear.linear.bias, self.channel_norm.weight,
-                self.channel_norm.bias, ff.net[0].linear.weight, ff.net[0].linear.bias,
-                ff.net[3].linear.weight, ff.net[3].linear.bias, att.num_heads, self.token_norm.eps,
-                self.channel_norm.eps, keep, False,
-            )
+            return fused.mixing_block(net, *self.fused_params(), att.num_heads, self.token_norm.eps,
+                                      self.channel_norm.eps, keep, False)
         # composed path: same kernels, one autograd node per op
         tkw = dict(hw=hw, deterministic=deterministic, residual=net)
         if mask is not None:
@@ -537,6 +540,8 @@ class MixedStackedEncoder(Module):
             nn.init.constant_(m.bias, 0.0)
             nn.init.constant_(m.weight, 1.0)
 
+    fuse_stack = True  # all blocks as ONE autograd node when every block can take the fused path
+
     def post_process(self, net: Tensor) -> Tensor:
         # LayerNorm is row-wise, so LN(x)[:, 0] == LN(x[:, 0]): normalise token 0 only (1/197 of
         # the reference's work, identical result) by handing the kernel a strided row view.
@@ -545,7 +550,15 @@ class MixedStackedEncoder(Module):
     def forward_tokens(self, tokens: Tensor, *, hw: Optional[Tuple[int, int]] = None,
                        deterministic: bool = False) -> Tensor:
         net = tokens
-        for block in self.mixing_blocks:
+        blocks = list(self.mixing_blocks)
+        if self.fuse_stack and len(blocks) > 1 and net.dim() == 3 and all(b.use_fused and b._fusable() for b in blocks):
+            # one autograd node for the whole stack (fused.MixingStackFn)
+            metas, params = [], []
+            for b in blocks:
+                metas.append((b.token_mixing.net.num_heads, b.token_norm.eps, b.channel_norm.eps))
+                params.extend(b.fused_params())
+            return self.post_process(fused.mixing_stack(net, tuple(metas), None, False, params))
+        for block in blocks:
             net = block(net, hw, deterministic=deterministic)
         return self.post_process(net)
 

@@ -128,6 +128,26 @@ def test_fused_equals_composed(golden):
         assert_close(outs[0][1][k], outs[1][1][k], 1e-2, f"fused vs composed {k}", abs_floor=1e-4)
 
 
+def test_stack_node_equals_block_nodes(golden):
+    """one autograd node for the whole stack (bf16 gradient stream) == one node per block: same kernels,
+    the only difference is a lossless bf16 -> f32 -> bf16 round trip of the inter-block gradient."""
+    g = golden("vit_small.pt")
+    outs = []
+    for stack in (True, False):
+        m = _small_vit(g)
+        m.encoder.encoder.fuse_stack = stack
+        assert len(m.encoder.encoder.mixing_blocks) > 1
+        logits = m(g["img"].to(DEV))["predictions"]
+        torch.nn.functional.cross_entropy(logits, g["labels"].view(-1).to(DEV)).backward()
+        outs.append((logits.detach(), _grads(m)))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        if "norm" in k:  # dgamma / dbeta fold a workgroup's waves through LDS float atomics: order not fixed
+            assert_close(outs[0][1][k], outs[1][1][k], 1e-5, k)
+        else:
+            assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
 def test_hook_contract_and_lowrank():
     """IBasicHook before/after_forward (LoRA contract, hijacks.py:33-49) and the low-rank Linear."""
 
