@@ -39,6 +39,7 @@ grad_ready_callbacks: List[Callable[[Tensor], None]] = []
 class SideStream:
     enabled = True
     lanes = 2  # side streams (0: dW GEMMs; 1: column sums / LayerNorm parameter grads)
+    heavy = True  # False: the dW GEMMs stay on the caller's stream, only the small reductions go aside
     streams: List[Optional["torch.cuda.Stream"]] = [None, None, None]
     keep: List[Tensor] = []  # operands produced on the main stream, alive until the join
 
@@ -51,7 +52,7 @@ class SideStream:
 
     @classmethod
     def run(cls, fn: Callable[[], None], keep: Tuple[Tensor, ...] = (), lane: int = 0) -> None:
-        if not cls.enabled or not torch.cuda.is_available():
+        if not cls.enabled or not torch.cuda.is_available() or (lane == 0 and not cls.heavy):
             fn()
             return
         if not cls._join_queued:

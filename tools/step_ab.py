@@ -18,9 +18,10 @@ img = torch.randn(BATCH, 3, 224, 224, generator=g).to(dev)
 labels = torch.randint(0, 1000, (BATCH,), generator=g).to(dev)
 
 VARIANTS = {
-    "heuristic 0": dict(gemm_heuristic=0, gemm_persistent=0, side=True, lanes=2),
-    "heuristic 2 (+256x128)": dict(gemm_heuristic=2, gemm_persistent=0, side=True, lanes=2),
-    "heuristic 3 (+tile count)": dict(gemm_heuristic=3, gemm_persistent=0, side=True, lanes=2),
+    "h3, dW on side stream": dict(gemm_heuristic=3, gemm_persistent=0, side=True, lanes=2, heavy=True),
+    "h4, dW on side stream": dict(gemm_heuristic=4, gemm_persistent=0, side=True, lanes=2, heavy=True),
+    "h3, dW on main stream": dict(gemm_heuristic=3, gemm_persistent=0, side=True, lanes=2, heavy=False),
+    "h4, dW on main stream": dict(gemm_heuristic=4, gemm_persistent=0, side=True, lanes=2, heavy=False),
 }
 
 def apply(v):
@@ -28,6 +29,7 @@ def apply(v):
     ops.set_option("gemm_persistent", v["gemm_persistent"])
     SideStream.enabled = v["side"]
     SideStream.lanes = v["lanes"]
+    SideStream.heavy = v.get("heavy", True)
 
 def run(n):
     torch.cuda.synchronize()
