@@ -1,7 +1,8 @@
 """carefree-learn_amd — MI355X-native (gfx950) implementation of carefree-learn's data-parallel
 training hot path: the `cflearn.modules` building blocks behind ViT (Linear / Attention /
-FeedForward / LayerNorm / patch embedding), the fused Adam step and the bucketed RCCL gradient
-exchange, behind the reference's module-registry surface.
+FeedForward / LayerNorm / patch embedding), the conv -> BatchNorm -> LeakyReLU stack of the MNIST
+classifier and the FCNN head (Conv2d as im2row + MFMA GEMM), the fused Adam step and the bucketed
+RCCL gradient exchange, behind the reference's module-registry surface.
 
 Importable as `cflearn_amd` (the directory name `carefree-learn_amd` is not a Python identifier;
 `cflearn_amd.py` at the repository root is the alias loader).
@@ -19,7 +20,10 @@ from .registry import (  # noqa: F401
 from .modules import (  # noqa: F401
     Attention,
     AttentionTokenMixer,
+    BatchNorm1d,
+    BatchNorm2d,
     Conv2d,
+    FCNN,
     FeedForward,
     HijackCustomLinear,
     HijackLinear,
@@ -27,8 +31,11 @@ from .modules import (  # noqa: F401
     Linear,
     MixedStackedEncoder,
     MixingBlock,
+    Mapping,
     NormFactory,
     VanillaClassifier,
+    VanillaEncoder,
+    VanillaEncoder1D,
     VanillaPatchEmbed,
     ViTEncoder,
     vit_b16_classifier,

@@ -62,6 +62,20 @@ SIGNATURES = {
     "cfhip_adam_step_dev": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, c_int, _P]),
     "cfhip_sumsq_f32": (c_int, [_P, _P, c_int64, _P]),
     "cfhip_softmax_xent": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "cfhip_softmax_focal": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, c_float, _P]),
+    "cfhip_conv_im2row": (c_int, [_P, c_int, _P] + [c_int] * 10 + [_P]),
+    "cfhip_conv_row2im": (c_int, [_P, _P] + [c_int] * 10 + [_P]),
+    "cfhip_transpose_batched": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
+    "cfhip_batchnorm_fwd": (
+        c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, _P]
+    ),
+    "cfhip_batchnorm_bwd": (
+        c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]
+    ),
+    "cfhip_leaky_relu_fwd": (c_int, [_P, _P, c_int64, c_float, _P]),
+    "cfhip_leaky_relu_bwd": (c_int, [_P, _P, _P, c_int64, c_float, _P]),
+    "cfhip_avgpool_fwd": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "cfhip_avgpool_bwd": (c_int, [_P, _P, c_int64, c_int, _P]),
 }
 
 

@@ -1,0 +1,429 @@
+// K8 (general form) / K9 / K10 and friends: the pieces around the MFMA GEMM that make the reference's
+// conv -> BatchNorm -> LeakyReLU stacks (convs/basic.py:41-184,529-571; cv/encoder/vanilla.py:18-158)
+// and its FCNN head (ml/fcnn.py:12-57) run on gfx950.
+//
+//   Conv2d (groups 1) = im2row + K1 GEMM:  rows[(b,oy,ox)][(c,ky,kx)] (zero padded, K rounded up to a
+//   multiple of 8 so the GEMM's 16-byte operand rule holds) x W[Cout][(c,ky,kx)]^T.  Backward: dW is the
+//   (tn) GEMM of the same rows, dX = row2im(dY W) where row2im GATHERS the <= kh*kw contributions of
+//   every input pixel (no atomics, deterministic).  NCHW <-> token-major conversions are batched LDS
+//   transposes.  All of it is HBM-bound glue: coalesced along the fastest output dimension.
+//
+//   BatchNorm (training statistics over (B, inner) per channel, biased variance for the normalisation,
+//   unbiased for running_var — torch semantics, norms.py:20-27,90-93), LeakyReLU / ReLU, global average
+//   pooling, focal loss (losses/basic.py:170-206).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+inline int grid_for(long work_items, int per_block, int cap = 4096) {
+  long b = (work_items + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__device__ __forceinline__ float ld_act(const void* p, long i, bool f32) {
+  return f32 ? reinterpret_cast<const float*>(p)[i] : bf16_to_f32(reinterpret_cast<const bf16_t*>(p)[i]);
+}
+
+struct ConvGeom {
+  int B, C, H, W, kh, kw, stride, pad, dil, Ho, Wo, K, Kp;
+};
+
+// rows[m][k], m = (b, oy, ox), k = (c, ky, kx); thread = one (m, k): writes coalesced along k
+template <bool IN_F32>
+__global__ void conv_im2row_kernel(const void* __restrict__ x, bf16_t* __restrict__ rows, ConvGeom g) {
+  const long total = (long)g.B * g.Ho * g.Wo * g.Kp;
+  const long step = (long)gridDim.x * blockDim.x;
+  const int kk = g.kh * g.kw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += step) {
+    const long m = i / g.Kp;
+    const int k = (int)(i - m * g.Kp);
+    float v = 0.f;
+    if (k < g.K) {
+      const int c = k / kk, r = k - c * kk;
+      const int ky = r / g.kw, kx = r - ky * g.kw;
+      const int ox = (int)(m % g.Wo);
+      const long t = m / g.Wo;
+      const int oy = (int)(t % g.Ho);
+      const int b = (int)(t / g.Ho);
+      const int iy = oy * g.stride - g.pad + ky * g.dil, ix = ox * g.stride - g.pad + kx * g.dil;
+      if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+        v = ld_act(x, (((long)b * g.C + c) * g.H + iy) * g.W + ix, IN_F32);
+    }
+    rows[i] = f32_to_bf16(v);
+  }
+}
+
+// dx[b][c][y][x] = sum over (ky, kx) of drows[(b, oy, ox)][(c, ky, kx)] with oy*stride - pad + ky*dil == y
+__global__ void conv_row2im_kernel(const bf16_t* __restrict__ drows, bf16_t* __restrict__ dx, ConvGeom g) {
+  const long total = (long)g.B * g.C * g.H * g.W;
+  const long step = (long)gridDim.x * blockDim.x;
+  const int kk = g.kh * g.kw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += step) {
+    const int xx = (int)(i % g.W);
+    long t = i / g.W;
+    const int yy = (int)(t % g.H);
+    t /= g.H;
+    const int c = (int)(t % g.C);
+    const int b = (int)(t / g.C);
+    float acc = 0.f;
+    for (int ky = 0; ky < g.kh; ++ky) {
+      const int ny = yy + g.pad - ky * g.dil;
+      if (ny < 0 || ny % g.stride != 0) continue;
+      const int oy = ny / g.stride;
+      if (oy >= g.Ho) continue;
+      for (int kx = 0; kx < g.kw; ++kx) {
+        const int nx = xx + g.pad - kx * g.dil;
+        if (nx < 0 || nx % g.stride != 0) continue;
+        const int ox = nx / g.stride;
+        if (ox >= g.Wo) continue;
+        acc += bf16_to_f32(drows[(((long)b * g.Ho + oy) * g.Wo + ox) * g.Kp + c * kk + ky * g.kw + kx]);
+      }
+    }
+    dx[i] = f32_to_bf16(acc);
+  }
+}
+
+// batched [R][C] -> [C][R] through a padded 64x64 LDS tile; source f32 or bf16, destination bf16
+template <bool IN_F32>
+__global__ void transpose_batched_kernel(const void* __restrict__ src, bf16_t* __restrict__ dst, int R, int C,
+                                         long bs_src, long bs_dst) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const long so = (long)blockIdx.z * bs_src, dofs = (long)blockIdx.z * bs_dst;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int rr = r0 + r, cc = c0 + tx;
+    tile[r][tx] = (rr < R && cc < C) ? f32_to_bf16(ld_act(src, so + (long)rr * C + cc, IN_F32)) : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    const int cc = c0 + c, rr = r0 + tx;
+    if (cc < C && rr < R) dst[dofs + (long)cc * R + rr] = tile[tx][c];
+  }
+}
+
+// ---- BatchNorm: one workgroup per channel; x [B][C][inner] --------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+  return s;
+}
+
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     float* running_mean, float* running_var, int B, int C,
+                                                     int inner, float eps, float momentum, int training) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  const long n = (long)B * inner;
+  float mean, rstd;
+  if (training) {
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) {
+      const long b = i / inner, j = i - b * inner;
+      s += ld_act(x, (b * C + c) * inner + j, IN_F32);
+    }
+    mean = block_sum(s, red) / (float)n;
+    float q = 0.f;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) {
+      const long b = i / inner, j = i - b * inner;
+      const float d = ld_act(x, (b * C + c) * inner + j, IN_F32) - mean;
+      q += d * d;
+    }
+    const float var = block_sum(q, red) / (float)n;
+    rstd = rsqrtf(var + eps);
+    if (threadIdx.x == 0) {
+      mean_out[c] = mean;
+      rstd_out[c] = rstd;
+      if (running_mean != nullptr) {
+        const float unbiased = n > 1 ? var * (float)n / (float)(n - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      }
+    }
+  } else {
+    mean = running_mean[c];
+    rstd = rsqrtf(running_var[c] + eps);
+    if (threadIdx.x == 0) {
+      mean_out[c] = mean;
+      rstd_out[c] = rstd;
+    }
+  }
+  const float ga = gamma != nullptr ? gamma[c] : 1.f, be = beta != nullptr ? beta[c] : 0.f;
+  const float a = rstd * ga, sh = be - mean * a;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const long b = i / inner, j = i - b * inner;
+    const long o = (b * C + c) * inner + j;
+    y[o] = f32_to_bf16(fmaf(ld_act(x, o, IN_F32), a, sh));
+  }
+}
+
+// training-mode backward; eval-mode (`training == 0`): dx = dy * gamma * rstd, the statistics are constants
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const bf16_t* __restrict__ dy, const void* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, bf16_t* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
+                                                     int C, int inner, int accumulate, int training) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  const long n = (long)B * inner;
+  const float mu = mean[c], rs = rstd[c], ga = gamma != nullptr ? gamma[c] : 1.f;
+  float sdy = 0.f, sdyx = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const long b = i / inner, j = i - b * inner;
+    const long o = (b * C + c) * inner + j;
+    const float g = bf16_to_f32(dy[o]);
+    sdy += g;
+    sdyx += g * (ld_act(x, o, IN_F32) - mu) * rs;
+  }
+  sdy = block_sum(sdy, red);
+  sdyx = block_sum(sdyx, red);
+  if (threadIdx.x == 0) {
+    if (dgamma != nullptr) dgamma[c] = accumulate ? dgamma[c] + sdyx : sdyx;
+    if (dbeta != nullptr) dbeta[c] = accumulate ? dbeta[c] + sdy : sdy;
+  }
+  if (dx == nullptr) return;
+  const float inv_n = 1.f / (float)n;
+  const float k = ga * rs;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const long b = i / inner, j = i - b * inner;
+    const long o = (b * C + c) * inner + j;
+    const float g = bf16_to_f32(dy[o]);
+    float r = g;
+    if (training) {
+      const float xh = (ld_act(x, o, IN_F32) - mu) * rs;
+      r = g - sdy * inv_n - xh * sdyx * inv_n;
+    }
+    dx[o] = f32_to_bf16(k * r);
+  }
+}
+
+// ---- LeakyReLU (slope 0 = ReLU), 4 bf16 per thread -------------------------------------------------------
+template <bool BWD>
+__global__ void leaky_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+                             long n, float slope) {
+  const long step = (long)gridDim.x * blockDim.x;
+  for (long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4; i < n; i += step * 4) {
+    if (i + 4 <= n) {
+      const u32x2 va = *reinterpret_cast<const u32x2*>(a + i);
+      u32x2 vx = va;
+      if (BWD) vx = *reinterpret_cast<const u32x2*>(x + i);
+      float r[4];
+      const float av[4] = {bf16lo(va[0]), bf16hi(va[0]), bf16lo(va[1]), bf16hi(va[1])};
+      const float xv[4] = {bf16lo(vx[0]), bf16hi(vx[0]), bf16lo(vx[1]), bf16hi(vx[1])};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = BWD ? (xv[e] > 0.f ? av[e] : av[e] * slope) : (av[e] > 0.f ? av[e] : av[e] * slope);
+      *reinterpret_cast<u32x2*>(out + i) = u32x2{pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+    } else {
+      for (long j = i; j < n; ++j) {
+        const float av = bf16_to_f32(a[j]);
+        const float xv = BWD ? bf16_to_f32(x[j]) : av;
+        out[j] = f32_to_bf16(xv > 0.f ? av : av * slope);
+      }
+    }
+  }
+}
+
+// ---- global average pool: x [BC][inner] -> y [BC]; one wave per (b, c) -------------------------------------
+__global__ void avgpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long BC, int inner) {
+  const long row = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= BC) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int j = lane; j < inner; j += 64) s += bf16_to_f32(x[row * inner + j]);
+  s = wave_sum(s);
+  if (lane == 0) y[row] = f32_to_bf16(s / (float)inner);
+}
+__global__ void avgpool_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, long total, int inner) {
+  const long step = (long)gridDim.x * blockDim.x;
+  const float inv = 1.f / (float)inner;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += step)
+    dx[i] = f32_to_bf16(bf16_to_f32(dy[i / inner]) * inv);
+}
+
+// ---- focal loss (losses/basic.py:170-206): p = softmax(z) + eps; L = -log(p_y) (1 - p_y)^gamma -------------
+// wave per sample; loss_sum += sum_b L_b; dlogits = grad_scale * dL/dz (the +eps is a constant shift)
+__global__ void softmax_focal_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                     float* __restrict__ loss_sum, float* __restrict__ dlogits, int B, int C,
+                                     float gamma, float eps, float grad_scale) {
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63;
+  const float* z = logits + (long)b * C;
+  float mx = -INFINITY;
+  for (int j = lane; j < C; j += 64) mx = fmaxf(mx, z[j]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int j = lane; j < C; j += 64) s += expf(z[j] - mx);
+  s = wave_sum(s);
+  const int yb = (int)labels[b];
+  const float sy = expf(z[yb] - mx) / s;
+  const float p = sy + eps;
+  const float om = 1.f - p;
+  const float lp = logf(p);
+  const float w = powf(om, gamma);
+  if (lane == 0) atomicAdd(loss_sum, -lp * w);
+  if (dlogits != nullptr) {
+    // dL/dp = -(1-p)^g / p + g (1-p)^(g-1) log p ;  dp/dz_j = s_y (delta_yj - s_j)
+    const float dldp = -w / p + gamma * powf(om, gamma - 1.f) * lp;
+    for (int j = lane; j < C; j += 64) {
+      const float sj = expf(z[j] - mx) / s;
+      dlogits[(long)b * C + j] = grad_scale * dldp * sy * ((j == yb ? 1.f : 0.f) - sj);
+    }
+  }
+}
+
+int check_geom(const char* who, const ConvGeom& g) {
+  CFHIP_REQUIRE(g.B > 0 && g.C > 0 && g.H > 0 && g.W > 0 && g.kh > 0 && g.kw > 0 && g.stride > 0 && g.dil > 0 &&
+                    g.pad >= 0,
+                "%s: bad geometry", who);
+  CFHIP_REQUIRE(g.Ho > 0 && g.Wo > 0, "%s: empty output (%d x %d)", who, g.Ho, g.Wo);
+  return CFHIP_OK;
+}
+
+ConvGeom make_geom(int B, int C, int H, int W, int kh, int kw, int stride, int pad, int dil, int Kp) {
+  ConvGeom g;
+  g.B = B; g.C = C; g.H = H; g.W = W; g.kh = kh; g.kw = kw; g.stride = stride; g.pad = pad; g.dil = dil;
+  g.Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1;
+  g.Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  g.K = C * kh * kw;
+  g.Kp = Kp;
+  return g;
+}
+
+}  // namespace
+
+extern "C" int cfhip_conv_im2row(const void* x, int x_is_f32, void* rows, int B, int C, int H, int W, int kh,
+                                 int kw, int stride, int pad, int dil, int Kp, void* stream) {
+  CFHIP_REQUIRE(x && rows, "conv_im2row: null pointer");
+  const ConvGeom g = make_geom(B, C, H, W, kh, kw, stride, pad, dil, Kp);
+  int rc = check_geom("conv_im2row", g);
+  if (rc != CFHIP_OK) return rc;
+  CFHIP_REQUIRE(Kp >= g.K, "conv_im2row: padded K %d < C*kh*kw = %d", Kp, g.K);
+  const long total = (long)B * g.Ho * g.Wo * Kp;
+  if (x_is_f32)
+    hipLaunchKernelGGL((conv_im2row_kernel<true>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (bf16_t*)rows, g);
+  else
+    hipLaunchKernelGGL((conv_im2row_kernel<false>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (bf16_t*)rows, g);
+  CFHIP_CHECK_LAUNCH("conv_im2row");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_conv_row2im(const void* drows, void* dx, int B, int C, int H, int W, int kh, int kw,
+                                 int stride, int pad, int dil, int Kp, void* stream) {
+  CFHIP_REQUIRE(drows && dx, "conv_row2im: null pointer");
+  const ConvGeom g = make_geom(B, C, H, W, kh, kw, stride, pad, dil, Kp);
+  int rc = check_geom("conv_row2im", g);
+  if (rc != CFHIP_OK) return rc;
+  CFHIP_REQUIRE(Kp >= g.K, "conv_row2im: padded K %d < C*kh*kw = %d", Kp, g.K);
+  const long total = (long)B * C * H * W;
+  hipLaunchKernelGGL(conv_row2im_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)drows, (bf16_t*)dx, g);
+  CFHIP_CHECK_LAUNCH("conv_row2im");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_transpose_batched(const void* src, int src_is_f32, void* dst, int batch, int R, int C,
+                                       void* stream) {
+  CFHIP_REQUIRE(src && dst && batch > 0 && R > 0 && C > 0, "transpose_batched: bad arguments");
+  CFHIP_REQUIRE(batch <= 65535, "transpose_batched: batch %d exceeds the grid limit", batch);
+  const dim3 grid((C + 63) / 64, (R + 63) / 64, batch);
+  const long bs = (long)R * C;
+  if (src_is_f32)
+    hipLaunchKernelGGL((transpose_batched_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, R,
+                       C, bs, bs);
+  else
+    hipLaunchKernelGGL((transpose_batched_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, R,
+                       C, bs, bs);
+  CFHIP_CHECK_LAUNCH("transpose_batched");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_batchnorm_fwd(const void* x, int x_is_f32, const float* gamma, const float* beta, void* y,
+                                   float* mean, float* rstd, float* running_mean, float* running_var, int B, int C,
+                                   int inner, float eps, float momentum, int training, void* stream) {
+  CFHIP_REQUIRE(x && y && mean && rstd && B > 0 && C > 0 && inner > 0, "batchnorm_fwd: bad arguments");
+  CFHIP_REQUIRE(training || (running_mean && running_var), "batchnorm_fwd: eval mode needs the running statistics");
+  if (x_is_f32)
+    hipLaunchKernelGGL((bn_fwd_kernel<true>), dim3(C), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16_t*)y,
+                       mean, rstd, running_mean, running_var, B, C, inner, eps, momentum, training);
+  else
+    hipLaunchKernelGGL((bn_fwd_kernel<false>), dim3(C), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16_t*)y,
+                       mean, rstd, running_mean, running_var, B, C, inner, eps, momentum, training);
+  CFHIP_CHECK_LAUNCH("batchnorm_fwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_batchnorm_bwd(const void* dy, const void* x, int x_is_f32, const float* gamma,
+                                   const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                                   int B, int C, int inner, int accumulate, int training, void* stream) {
+  CFHIP_REQUIRE(dy && x && mean && rstd && B > 0 && C > 0 && inner > 0, "batchnorm_bwd: bad arguments");
+  if (x_is_f32)
+    hipLaunchKernelGGL((bn_bwd_kernel<true>), dim3(C), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, gamma,
+                       mean, rstd, (bf16_t*)dx, dgamma, dbeta, B, C, inner, accumulate, training);
+  else
+    hipLaunchKernelGGL((bn_bwd_kernel<false>), dim3(C), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, gamma,
+                       mean, rstd, (bf16_t*)dx, dgamma, dbeta, B, C, inner, accumulate, training);
+  CFHIP_CHECK_LAUNCH("batchnorm_bwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_leaky_relu_fwd(const void* x, void* y, int64_t n, float slope, void* stream) {
+  CFHIP_REQUIRE(x && y && n >= 0, "leaky_relu_fwd: bad arguments");
+  if (n == 0) return CFHIP_OK;
+  CFHIP_REQUIRE(((uintptr_t)x & 7) == 0 && ((uintptr_t)y & 7) == 0, "leaky_relu_fwd: misaligned");
+  hipLaunchKernelGGL((leaky_kernel<false>), dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)x, (bf16_t*)y, (long)n, slope);
+  CFHIP_CHECK_LAUNCH("leaky_relu_fwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_leaky_relu_bwd(const void* dy, const void* x, void* dx, int64_t n, float slope, void* stream) {
+  CFHIP_REQUIRE(dy && x && dx && n >= 0, "leaky_relu_bwd: bad arguments");
+  if (n == 0) return CFHIP_OK;
+  CFHIP_REQUIRE(((uintptr_t)x & 7) == 0 && ((uintptr_t)dy & 7) == 0 && ((uintptr_t)dx & 7) == 0,
+                "leaky_relu_bwd: misaligned");
+  hipLaunchKernelGGL((leaky_kernel<true>), dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, (long)n, slope);
+  CFHIP_CHECK_LAUNCH("leaky_relu_bwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_avgpool_fwd(const void* x, void* y, int64_t BC, int inner, void* stream) {
+  CFHIP_REQUIRE(x && y && BC > 0 && inner > 0, "avgpool_fwd: bad arguments");
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((unsigned)((BC + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (bf16_t*)y, (long)BC, inner);
+  CFHIP_CHECK_LAUNCH("avgpool_fwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_avgpool_bwd(const void* dy, void* dx, int64_t BC, int inner, void* stream) {
+  CFHIP_REQUIRE(dy && dx && BC > 0 && inner > 0, "avgpool_bwd: bad arguments");
+  const long total = (long)BC * inner;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, (bf16_t*)dx, total, inner);
+  CFHIP_CHECK_LAUNCH("avgpool_bwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_softmax_focal(const float* logits, const int64_t* labels, float* loss_sum, float* dlogits,
+                                   int B, int C, float gamma, float eps, float grad_scale, void* stream) {
+  CFHIP_REQUIRE(logits && labels && loss_sum && B > 0 && C > 0, "softmax_focal: bad arguments");
+  hipLaunchKernelGGL(softmax_focal_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, labels,
+                     loss_sum, dlogits, B, C, gamma, eps, grad_scale);
+  CFHIP_CHECK_LAUNCH("softmax_focal");
+  return CFHIP_OK;
+}

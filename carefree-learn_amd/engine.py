@@ -30,14 +30,17 @@ class TrainStep:
     def __init__(self, model: torch.nn.Module, *, lr: float = 1.0e-4, betas: Any = (0.9, 0.999),
                  eps: float = 1.0e-8, weight_decay: float = 0.0, decoupled: bool = True,
                  use_graph: bool = False, distributed: bool = False, bucket_bytes: int = 64 << 20,
-                 output_key: str = "predictions"):
+                 output_key: str = "predictions", loss: str = "cross_entropy"):
+        if loss not in ("cross_entropy", "focal"):
+            raise ValueError(f"unknown loss '{loss}' (cross_entropy: losses/basic.py:126-141, focal: :170-206)")
         self.model = model
         self.output_key = output_key
+        self.loss = loss
         params = [p for p in model.parameters() if p.requires_grad]
         self.arena = ParamArena(params, with_shadow=True)
         self.optimizer = FusedAdam(None, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                    decoupled=decoupled, arena=self.arena)
-        self.optimizer.lazy_zero = True  # every ViT parameter gradient is written by a HIP backward kernel
+        self.optimizer.lazy_zero = True  # every parameter gradient is written by a HIP backward kernel
         self.reducer: Optional[BucketedAllReduce] = None
         if distributed:
             self.reducer = BucketedAllReduce(self.arena, bucket_bytes=bucket_bytes, optimizer=self.optimizer)
@@ -52,7 +55,10 @@ class TrainStep:
         self.optimizer.zero_grad()
         out = self.model(img)
         logits = out[self.output_key] if isinstance(out, dict) else out
-        loss_sum, dlogits = ops.softmax_xent(logits, labels, 1.0 / logits.shape[0])
+        if self.loss == "focal":
+            loss_sum, dlogits = ops.softmax_focal(logits, labels, 1.0 / logits.shape[0])
+        else:
+            loss_sum, dlogits = ops.softmax_xent(logits, labels, 1.0 / logits.shape[0])
         logits.backward(dlogits)
         SideStream.join()  # parameter-gradient kernels ran on the side stream
         if self.reducer is not None:

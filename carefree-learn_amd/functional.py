@@ -496,3 +496,201 @@ class PatchTokensFn(Function):
 def patch_tokens(img: Tensor, conv_w: Tensor, conv_b: Optional[Tensor], head_token: Tensor,
                  pos: Tensor) -> Tensor:
     return PatchTokensFn.apply(img, conv_w, conv_b, head_token, pos)
+
+
+# ---------------------------------------------------------------------------------------------
+# Conv2d general form (K8) = im2row + K1 GEMM; BatchNorm (K9/K10); LeakyReLU; global average pool
+# ---------------------------------------------------------------------------------------------
+
+
+def _conv_weight_rows(weight: Tensor, kp: int) -> Tensor:
+    """bf16 [Cout, Kp] view / zero-padded copy of the [Cout, Cin, kh, kw] weight (k = (c, ky, kx))."""
+    cout = weight.shape[0]
+    k = weight.numel() // cout
+    w16 = shadow_bf16(weight).view(cout, k)
+    if kp == k:
+        return w16
+    wp = torch.zeros((cout, kp), dtype=bf16, device=weight.device)
+    wp[:, :k] = w16  # first layer only (K = Cin*kh*kw not a multiple of 8): a few KB
+    return wp
+
+
+class Conv2dFn(Function):
+    """Replaces F.conv2d reached from Conv2d.forward (reference convs/basic.py:160-177), groups = 1:
+    NCHW in (f32 / bf16), NCHW bf16 out."""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int, pad: int,
+                dil: int) -> Tensor:
+        if x.dtype not in (bf16, f32):
+            x = x.float()
+        x = x.contiguous()
+        b, cin, h, w = x.shape
+        cout, _, kh, kw = weight.shape
+        ho, wo = ops.conv_out_hw(h, w, kh, kw, stride, pad, dil)
+        rows = ops.conv_im2row(x, kh, kw, stride, pad, dil)
+        wp = _conv_weight_rows(weight, rows.shape[1])
+        bias_f = None if bias is None else bias.detach().reshape(-1).contiguous()
+        y_rows = ops.gemm(rows, wp, bias=bias_f)  # [B*Ho*Wo, Cout] bf16
+        y = ops.transpose_batched(y_rows.view(b, ho * wo, cout)).view(b, cout, ho, wo)
+        ctx.save_for_backward(x, wp)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.geom = (kh, kw, stride, pad, dil, ho, wo)
+        return y
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        x, wp = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        kh, kw, stride, pad, dil, ho, wo = ctx.geom
+        b, cin, h, w = x.shape
+        cout = weight.shape[0]
+        k = cin * kh * kw
+        if dy.dtype != bf16:
+            dy = ops.to_bf16(dy.float().contiguous())
+        dy_rows = ops.transpose_batched(dy.contiguous().view(b, cout, ho * wo)).view(b * ho * wo, cout)
+        gw = gb = None
+        if weight.requires_grad:
+            rows = ops.conv_im2row(x, kh, kw, stride, pad, dil)  # recomputed: k^2 times the input, not kept
+            m = rows.shape[0]
+            kp = rows.shape[1]
+            split = ops.pick_split_k(cout, kp, m) if m % 8 == 0 else 1
+
+            def dw_into(out: Tensor, acc: bool) -> None:
+                if kp == k:
+                    ops.gemm(dy_rows, rows, a_trans=True, b_trans=True, out=out.view(cout, k), accumulate=acc,
+                             split_k=split)
+                else:
+                    tmp = ops.gemm(dy_rows, rows, a_trans=True, b_trans=True, out_dtype=f32, split_k=split)
+                    if acc:
+                        out.view(cout, k).add_(tmp[:, :k])
+                    else:
+                        out.view(cout, k).copy_(tmp[:, :k])
+
+            if _is_direct(weight):
+                write_param_grad(weight, dw_into)
+            else:
+                gw = torch.empty(weight.shape, dtype=f32, device=dy.device)
+                dw_into(gw, False)
+        if bias is not None and bias.requires_grad:
+            if _is_direct(bias):
+                write_param_grad(bias, lambda out, acc: ops.colsum(dy_rows, out=out.view(-1), accumulate=acc))
+            else:
+                gb = ops.colsum(dy_rows).view(bias.shape)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            drows = ops.gemm(dy_rows, wp, b_trans=True)  # [M, Kp] bf16
+            dx = ops.conv_row2im(drows, (b, cin, h, w), kh, kw, stride, pad, dil)
+        return dx, gw, gb, None, None, None
+
+
+def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int, pad: int, dil: int = 1) -> Tensor:
+    return Conv2dFn.apply(x, weight, bias, stride, pad, dil)
+
+
+class BatchNormFn(Function):
+    """Replaces nn.BatchNorm1d/2d.forward (reference norms.py:20-27,90-93) incl. the running-statistics update."""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor],
+                running_mean: Optional[Tensor], running_var: Optional[Tensor], eps: float, momentum: float,
+                training: bool) -> Tensor:
+        if x.dtype not in (bf16, f32):
+            x = x.float()
+        x = x.contiguous()
+        gamma = None if weight is None else weight.detach().contiguous()
+        beta = None if bias is None else bias.detach().contiguous()
+        y, mean, rstd = ops.batchnorm_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.weight, ctx.bias, ctx.training = weight, bias, training
+        return y
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        x, gamma, mean, rstd = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        if dy.dtype != bf16:
+            dy = ops.to_bf16(dy.float().contiguous())
+        dx, dg, db = ops.batchnorm_bwd(dy, x, gamma, mean, rstd, training=ctx.training,
+                                       want_dx=ctx.needs_input_grad[0])
+        gw = gb = None
+        for prm, g, which in ((weight, dg, 0), (bias, db, 1)):
+            if prm is None or not prm.requires_grad:
+                continue
+            if _is_direct(prm):
+                write_param_grad(prm, lambda out, acc, g=g: out.add_(g.view(out.shape)) if acc else out.copy_(g.view(out.shape)))
+            elif which == 0:
+                gw = g.view(prm.shape)
+            else:
+                gb = g.view(prm.shape)
+        return dx, gw, gb, None, None, None, None, None
+
+
+def batch_norm(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], running_mean: Optional[Tensor],
+               running_var: Optional[Tensor], eps: float, momentum: float, training: bool) -> Tensor:
+    return BatchNormFn.apply(x, weight, bias, running_mean, running_var, eps, momentum, training)
+
+
+class LeakyReLUFn(Function):
+    """nn.LeakyReLU(slope) / nn.ReLU (slope 0) (reference activations.py:35-43)."""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, slope: float) -> Tensor:
+        if x.dtype != bf16:
+            x = ops.to_bf16(x.float().contiguous())
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        return ops.leaky_relu_fwd(x, slope)
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        (x,) = ctx.saved_tensors
+        if dy.dtype != bf16:
+            dy = ops.to_bf16(dy.float().contiguous())
+        return ops.leaky_relu_bwd(dy.contiguous(), x, ctx.slope), None
+
+
+def leaky_relu(x: Tensor, slope: float) -> Tensor:
+    return LeakyReLUFn.apply(x, slope)
+
+
+class GlobalAvgPoolFn(Function):
+    """nn.AdaptiveAvgPool2d((1, 1)) + squeeze (reference cv/encoder/vanilla.py:144,155-158): [B,C,H,W] -> [B,C]."""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor) -> Tensor:
+        if x.dtype != bf16:
+            x = ops.to_bf16(x.float().contiguous())
+        ctx.shape = tuple(x.shape)
+        return ops.avgpool_fwd(x.contiguous())
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        if dy.dtype != bf16:
+            dy = ops.to_bf16(dy.float().contiguous())
+        return ops.avgpool_bwd(dy.contiguous(), ctx.shape)
+
+
+def global_avg_pool(x: Tensor) -> Tensor:
+    return GlobalAvgPoolFn.apply(x)
+
+
+class FocalLossFn(Function):
+    """mean focal loss (reference losses/basic.py:170-206) on f32 logits with int64 labels."""
+
+    @staticmethod
+    def forward(ctx: Any, logits: Tensor, labels: Tensor, gamma: float, eps: float) -> Tensor:
+        b = logits.shape[0]
+        loss, dlogits = ops.softmax_focal(logits.float().contiguous(), labels, 1.0 / b, gamma=gamma, eps=eps)
+        ctx.save_for_backward(dlogits)
+        return loss[0] / b
+
+    @staticmethod
+    def backward(ctx: Any, g: Tensor):  # type: ignore
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None, None, None
+
+
+def focal_loss(logits: Tensor, labels: Tensor, gamma: float = 2.0, eps: float = 1.0e-6) -> Tensor:
+    return FocalLossFn.apply(logits, labels, gamma, eps)

@@ -148,6 +148,88 @@ class LayerNorm(nn.LayerNorm):
         return HF.layer_norm(net, self.weight, self.bias, self.eps)
 
 
+class _BatchNormMixin:
+    """nn.BatchNorm{1,2}d semantics (reference norms.py:20-27,90-93) on `cfhip_batchnorm_fwd/bwd`: training
+    mode normalises with the batch statistics and updates running_mean / running_var (unbiased) /
+    num_batches_tracked; eval mode uses the running statistics.  State keys are nn.BatchNorm's."""
+
+    def _bn(self, net: Tensor) -> Tensor:
+        if self.momentum is None:
+            raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not built")
+        training = self.training or not self.track_running_stats
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        rm = self.running_mean if self.track_running_stats else None
+        rv = self.running_var if self.track_running_stats else None
+        return HF.batch_norm(net, self.weight, self.bias, rm, rv, self.eps, self.momentum, training)
+
+
+class BatchNorm2d(_BatchNormMixin, nn.BatchNorm2d):
+    """`NormFactory("batch").make(dim)`: [B, C, H, W]"""
+
+    def forward(self, net: Tensor) -> Tensor:  # type: ignore
+        if net.dim() != 4:
+            raise ValueError(f"expected 4D input (got {net.dim()}D input)")
+        return self._bn(net)
+
+
+class BatchNorm1d(_BatchNormMixin, nn.BatchNorm1d):
+    """`NormFactory("batch1d")`: [B, C] or [B, C, L]"""
+
+    def forward(self, net: Tensor) -> Tensor:  # type: ignore
+        if net.dim() not in (2, 3):
+            raise ValueError(f"expected 2D or 3D input (got {net.dim()}D input)")
+        return self._bn(net)
+
+
+class BN(BatchNorm1d):
+    """reference norms.py:20-27: BatchNorm1d that takes token-major [B, T, C] by transposing"""
+
+    def forward(self, net: Tensor) -> Tensor:  # type: ignore
+        if net.dim() == 3:
+            return super().forward(net.transpose(1, 2).contiguous()).transpose(1, 2)
+        return super().forward(net)
+
+
+class LeakyReLU(Module):
+    """`build_activation("leaky_relu_0.2")` (reference activations.py:35-40)"""
+
+    def __init__(self, negative_slope: float = 0.01, inplace: bool = True):
+        super().__init__()
+        self.negative_slope, self.inplace = negative_slope, inplace
+
+    def extra_repr(self) -> str:
+        return f"negative_slope={self.negative_slope}"
+
+    def forward(self, net: Tensor) -> Tensor:
+        return HF.leaky_relu(net, self.negative_slope)
+
+
+class ReLU(LeakyReLU):
+    """`build_activation("ReLU")` (reference activations.py:41-48)"""
+
+    def __init__(self, inplace: bool = True):
+        super().__init__(0.0, inplace)
+
+    def extra_repr(self) -> str:
+        return ""
+
+
+def build_activation(name: Optional[str], config: Optional[Dict[str, Any]] = None) -> Module:
+    """reference activations.py:27-53, restricted to the activations that have a HIP kernel"""
+    if name is None:
+        return nn.Identity()
+    config = dict(config or {})
+    if name.startswith("leaky_relu"):
+        splits = name.split("_")
+        if len(splits) == 3:
+            config["negative_slope"] = float(splits[-1])
+        return LeakyReLU(**config)
+    if name.lower() == "relu":
+        return ReLU(**config)
+    raise NotImplementedError(f"activation '{name}' as a stand-alone module is not on the accelerated hot path")
+
+
 class NormFactory:
     """reference norms.py:70-140 restricted to what the transformer path uses."""
 
@@ -164,7 +246,23 @@ class NormFactory:
         if self.norm_type == "layer":
             kw = update_dict(kwargs, {"eps": 1.0e-6})
             return LayerNorm(*args, **kw)
+        if self.norm_type == "batch":
+            kw = update_dict(kwargs, {"affine": True, "track_running_stats": True})
+            return BatchNorm2d(*args, **kw)
+        if self.norm_type == "batch1d":
+            return BatchNorm1d(*args, **kwargs)
+        if self.norm_type == "batch_norm":
+            return BN(*args, **kwargs)
         raise NotImplementedError(f"normalization '{self.norm_type}' is not on the accelerated hot path")
+
+    def inject_to(self, dim: int, norm_kwargs: Dict[str, Any], current_blocks: List[Module],
+                  *subsequent_blocks: Module) -> None:
+        """reference norms.py:126-140 (the "spectral" wrapper form is not built)"""
+        if self.norm_type is not None:
+            current_blocks.append(self.make(dim, **norm_kwargs))
+        else:
+            current_blocks.append(nn.Identity())
+        current_blocks.extend(subsequent_blocks)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -569,26 +667,187 @@ class MixedStackedEncoder(Module):
 
 
 class Conv2d(Module):
-    """reference convs/basic.py:41-184 — parameters `weight` [out, in, k, k], `bias`.  Only the
-    stride == kernel_size, padding 0 form (the ViT patch embedding, a GEMM) is on the hot path."""
+    """reference convs/basic.py:41-184 — parameters `weight` [out, in, k, k], `bias`.  groups = 1 only:
+    im2row + MFMA GEMM (`functional.Conv2dFn`); the stride == kernel, padding 0 form of the ViT patch
+    embedding has its own fused path (`functional.patch_tokens`).  Style modulation, kernel transform,
+    reflection padding and transposed convolution are outside the accelerated hot path."""
 
     def __init__(self, in_channels: int, out_channels: int, *, kernel_size: int, groups: int = 1,
-                 stride: int = 1, dilation: int = 1, padding: Any = "same", bias: bool = True,
+                 stride: int = 1, dilation: int = 1, padding: Any = "same", transform_kernel: bool = False,
+                 bias: bool = True, demodulate: bool = False, weight_scale: Optional[float] = None,
                  gain: float = math.sqrt(2.0)):
         super().__init__()
         if padding == "same":
             padding = kernel_size // 2
-        if groups != 1 or dilation != 1 or stride != kernel_size or padding != 0:
-            raise NotImplementedError("general convolutions are a later hot-path row; only the "
-                                      "patch-embedding form (stride == kernel, padding 0) is built")
+        if groups != 1 or transform_kernel or demodulate or weight_scale is not None or not isinstance(padding, int):
+            raise NotImplementedError("grouped / kernel-transformed / demodulated / reflection-padded "
+                                      "convolutions are outside the accelerated hot path")
         self.in_c, self.out_c, self.kernel_size = in_channels, out_channels, kernel_size
         self.groups, self.stride, self.dilation, self.padding = groups, stride, dilation, padding
+        self.reflection_pad = None
+        self.transform_kernel, self.demodulate, self.weight_scale = transform_kernel, demodulate, weight_scale
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         with torch.no_grad():
             nn.init.xavier_normal_(self.weight.data, gain / math.sqrt(2.0))
             if self.bias is not None:
                 self.bias.zero_()
+
+    def forward(self, net: Tensor, style: Optional[Tensor] = None, *, transpose: bool = False) -> Tensor:
+        if style is not None or transpose:
+            raise NotImplementedError("stylised / transposed convolution is outside the accelerated hot path")
+        return HF.conv2d(net, self.weight, self.bias, self.stride, self.padding, self.dilation)
+
+    def extra_repr(self) -> str:
+        return (f"{self.in_c}, {self.out_c}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"padding={self.padding}, dilation={self.dilation}, bias={self.bias is not None}")
+
+
+def get_conv_blocks(in_channels: int, out_channels: int, kernel_size: int, stride: int, *, bias: bool = True,
+                    norm_type: Optional[str] = None, norm_kwargs: Optional[Dict[str, Any]] = None,
+                    activation: Any = None, pre_activate: bool = False, **conv2d_kwargs: Any) -> List[Module]:
+    """reference convs/basic.py:529-571 (no ECA / CA blocks, no demodulation)"""
+    conv = Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, bias=bias, **conv2d_kwargs)
+    blocks: List[Module] = []
+    if not pre_activate:
+        blocks.append(conv)
+    NormFactory(norm_type).inject_to(out_channels, norm_kwargs or {}, blocks)
+    if activation is not None:
+        blocks.append(build_activation(activation) if isinstance(activation, str) else activation)
+    if pre_activate:
+        blocks.append(conv)
+    return blocks
+
+
+@encoders.register("vanilla")
+class VanillaEncoder(Module):
+    """reference cv/encoder/vanilla.py:18-104: conv(k = first_kernel_size) -> norm -> act, then
+    `num_downsample` stride-2 convs (the last one bare); state keys `encoder.<i>.*` of the nn.Sequential."""
+
+    def __init__(self, in_channels: int, num_downsample: int, latent_channels: int = 256, *, kernel_size: int = 3,
+                 first_kernel_size: int = 7, start_channels: Optional[int] = None, num_residual_blocks: int = 0,
+                 residual_dropout: float = 0.0, residual_kwargs: Optional[Dict[str, Any]] = None,
+                 norm_type: Optional[str] = "batch", norm_kwargs: Optional[Dict[str, Any]] = None,
+                 activation: str = "leaky_relu_0.2", padding: str = "same"):
+        super().__init__()
+        if num_residual_blocks != 0:
+            raise NotImplementedError("residual blocks in VanillaEncoder are outside the accelerated hot path")
+        self.in_channels, self.num_downsample = in_channels, num_downsample
+        self.latent_channels, self.first_kernel_size = latent_channels, first_kernel_size
+        if start_channels is None:
+            start_channels = int(round(latent_channels / (2 ** num_downsample)))
+        if start_channels <= 0:
+            raise ValueError(f"latent_channels ({latent_channels}) is too small for num_downsample ({num_downsample})")
+        blocks = get_conv_blocks(in_channels, start_channels, first_kernel_size, 1, norm_type=norm_type,
+                                 norm_kwargs=norm_kwargs, activation=activation, padding=padding)
+        in_nc = start_channels
+        for i in range(num_downsample):
+            is_last = i == num_downsample - 1
+            out_nc = latent_channels if is_last else min(in_nc * 2, latent_channels)
+            blocks.extend(get_conv_blocks(in_nc, out_nc, kernel_size, 2, norm_type=None if is_last else norm_type,
+                                          activation=None if is_last else activation, padding=padding))
+            in_nc = out_nc
+        self.encoder = nn.Sequential(*blocks)
+
+    def forward(self, net: Tensor) -> Tensor:
+        return self.encoder(net)
+
+    def encode(self, net: Tensor) -> Tensor:
+        return self(net)
+
+
+@encoders.register("vanilla_1d")
+class VanillaEncoder1D(Module):
+    """reference cv/encoder/vanilla.py:107-158: VanillaEncoder + AdaptiveAvgPool2d((1,1)) + squeeze -> [B, latent]"""
+
+    def __init__(self, in_channels: int, num_downsample: int, latent_dim: int = 128, *,
+                 img_size: Optional[int] = None, kernel_size: int = 3, first_kernel_size: int = 7,
+                 start_channels: Optional[int] = None, num_residual_blocks: int = 0, residual_dropout: float = 0.0,
+                 residual_kwargs: Optional[Dict[str, Any]] = None, norm_type: Optional[str] = "batch",
+                 activation: str = "leaky_relu_0.2", padding: str = "same", pool: str = "average"):
+        super().__init__()
+        if pool != "average":
+            raise NotImplementedError("only `pool='average'` is on the accelerated hot path")
+        self.in_channels, self.latent_dim = in_channels, latent_dim
+        self.encoder = VanillaEncoder(in_channels, num_downsample, latent_dim, kernel_size=kernel_size,
+                                      first_kernel_size=first_kernel_size, start_channels=start_channels,
+                                      num_residual_blocks=num_residual_blocks, residual_dropout=residual_dropout,
+                                      residual_kwargs=residual_kwargs, norm_type=norm_type, activation=activation,
+                                      padding=padding)
+        self.pool = nn.AdaptiveAvgPool2d((1, 1))  # parameter-free: kept for the module tree / repr
+
+    def forward(self, net: Tensor) -> Tensor:
+        return HF.global_avg_pool(self.encoder(net))
+
+    def encode(self, net: Tensor) -> Tensor:
+        return self(net)
+
+
+class Mapping(Module):
+    """reference modules/core/mappings.py:34-87: Linear -> (BN) -> activation -> (Dropout); state keys
+    `linear.linear.*`, `bn.*`."""
+
+    def __init__(self, in_dim: int, out_dim: int, *, bias: Optional[bool] = None,
+                 pruner_config: Optional[dict] = None, dropout: float = 0.5, batch_norm: bool = True,
+                 activation: Optional[str] = "ReLU", activation_config: Optional[Dict[str, Any]] = None,
+                 init_method: str = "xavier_normal", rank: Optional[int] = None,
+                 rank_ratio: Optional[float] = None):
+        super().__init__()
+        if bias is None:
+            bias = not batch_norm
+        if 0.0 < dropout < 1.0:
+            raise NotImplementedError("dropout > 0 is outside the accelerated hot path (no RNG kernels yet)")
+        self.linear = Linear(in_dim, out_dim, bias=bias, pruner_config=pruner_config, init_method=init_method,
+                             rank=rank, rank_ratio=rank_ratio)
+        self.bn = BN(out_dim) if batch_norm else None
+        self.activation = None if activation is None else build_activation(activation, activation_config)
+        self.dropout = None
+
+    @property
+    def weight(self) -> Tensor:
+        return self.linear.weight
+
+    @property
+    def bias(self) -> Optional[Tensor]:
+        return self.linear.bias
+
+    def forward(self, net: Tensor) -> Tensor:
+        net = self.linear(net)
+        if self.bn is not None:
+            net = self.bn(net)
+        if self.activation is not None:
+            net = self.activation(net)
+        return net
+
+
+@register_module("fcnn")
+class FCNN(Module):
+    """reference modules/ml/fcnn.py:12-57: `Mapping` per hidden unit + nn.Linear head; state keys
+    `net.<i>.linear.linear.*`, `net.<n>.{weight,bias}`.  Logits are fp32."""
+
+    def __init__(self, input_dim: int, output_dim: int, hidden_units: Optional[List[int]] = None, *,
+                 mapping_type: str = "basic", bias: bool = True, activation: str = "ReLU", batch_norm: bool = False,
+                 dropout: float = 0.0, rank: Optional[int] = None, rank_ratio: Optional[float] = None):
+        super().__init__()
+        if mapping_type != "basic":
+            raise NotImplementedError(f"mapping type '{mapping_type}' is outside the accelerated hot path")
+        if hidden_units is None:
+            dim = max(32, min(1024, 2 * input_dim))
+            hidden_units = 2 * [dim]
+        blocks: List[Module] = []
+        for hidden_unit in hidden_units:
+            blocks.append(Mapping(input_dim, hidden_unit, bias=bias, activation=activation, batch_norm=batch_norm,
+                                  dropout=dropout, rank=rank, rank_ratio=rank_ratio))
+            input_dim = hidden_unit
+        blocks.append(HijackLinear(input_dim, output_dim, bias))
+        self.hidden_units = hidden_units
+        self.net = nn.Sequential(*blocks)
+
+    def forward(self, net: Tensor) -> Tensor:
+        for blk in self.net[:-1]:
+            net = blk(net)
+        head = self.net[-1]
+        return HF.linear(net, head.weight, head.bias, out_f32=True)
 
 
 class VanillaPatchEmbed(Module):

@@ -445,3 +445,153 @@ def softmax_xent(logits: Tensor, labels: Tensor, grad_scale: float, want_grad: b
                                         b, c, float(grad_scale), _stream())
     _lib.check(rc, "softmax_xent")
     return loss, dlogits
+
+
+def softmax_focal(logits: Tensor, labels: Tensor, grad_scale: float, *, gamma: float = 2.0, eps: float = 1.0e-6,
+                  want_grad: bool = True):
+    """Focal loss of reference losses/basic.py:170-206: returns (loss_sum f32 [1], dlogits f32 [B, C])."""
+    _need(logits, f32, "logits")
+    if labels.dtype != torch.int64 or not labels.is_cuda:
+        raise TypeError("cfhip softmax_focal: labels must be int64 on the device")
+    if not logits.is_contiguous():
+        logits = logits.contiguous()
+    labels = labels.reshape(-1).contiguous()
+    b, c = logits.shape
+    loss = torch.zeros((1,), dtype=f32, device=logits.device)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    rc = _lib.load().cfhip_softmax_focal(logits.data_ptr(), labels.data_ptr(), loss.data_ptr(), _p(dlogits),
+                                         b, c, float(gamma), float(eps), float(grad_scale), _stream())
+    _lib.check(rc, "softmax_focal")
+    return loss, dlogits
+
+
+# ---------------------------------------------------------------------------------------------
+# conv / batch-norm family (K8 general form, K9, K10)
+# ---------------------------------------------------------------------------------------------
+
+
+def conv_out_hw(h: int, w: int, kh: int, kw: int, stride: int, pad: int, dil: int) -> Tuple[int, int]:
+    return ((h + 2 * pad - dil * (kh - 1) - 1) // stride + 1, (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1)
+
+
+def conv_im2row(x: Tensor, kh: int, kw: int, stride: int, pad: int, dil: int = 1) -> Tensor:
+    """x [B, C, H, W] (f32 / bf16, contiguous) -> rows bf16 [B*Ho*Wo, Kp], k = (c, ky, kx), Kp = K rounded up to 8."""
+    if x.dtype not in (f32, bf16) or not x.is_cuda or not x.is_contiguous() or x.dim() != 4:
+        raise ValueError("cfhip conv_im2row: x must be a contiguous f32/bf16 [B, C, H, W] device tensor")
+    b, c, h, w = x.shape
+    ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
+    kp = (c * kh * kw + 7) // 8 * 8
+    rows = torch.empty((b * ho * wo, kp), dtype=bf16, device=x.device)
+    rc = _lib.load().cfhip_conv_im2row(x.data_ptr(), int(x.dtype == f32), rows.data_ptr(), b, c, h, w, kh, kw,
+                                       stride, pad, dil, kp, _stream())
+    _lib.check(rc, "conv_im2row")
+    return rows
+
+
+def conv_row2im(drows: Tensor, shape: Tuple[int, int, int, int], kh: int, kw: int, stride: int, pad: int,
+                dil: int = 1) -> Tensor:
+    """drows bf16 [B*Ho*Wo, Kp] -> dx bf16 [B, C, H, W] (gather-sum of the overlapping windows)."""
+    _need(drows, bf16, "drows")
+    if not drows.is_contiguous():
+        drows = drows.contiguous()
+    b, c, h, w = shape
+    dx = torch.empty(shape, dtype=bf16, device=drows.device)
+    rc = _lib.load().cfhip_conv_row2im(drows.data_ptr(), dx.data_ptr(), b, c, h, w, kh, kw, stride, pad, dil,
+                                       drows.shape[1], _stream())
+    _lib.check(rc, "conv_row2im")
+    return dx
+
+
+def transpose_batched(x: Tensor) -> Tensor:
+    """x [batch, R, C] (f32 / bf16, contiguous) -> bf16 [batch, C, R]."""
+    if x.dtype not in (f32, bf16) or not x.is_cuda or not x.is_contiguous() or x.dim() != 3:
+        raise ValueError("cfhip transpose_batched: x must be a contiguous f32/bf16 [batch, R, C] device tensor")
+    n, r, c = x.shape
+    out = torch.empty((n, c, r), dtype=bf16, device=x.device)
+    rc = _lib.load().cfhip_transpose_batched(x.data_ptr(), int(x.dtype == f32), out.data_ptr(), n, r, c, _stream())
+    _lib.check(rc, "transpose_batched")
+    return out
+
+
+def batchnorm_fwd(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], running_mean: Optional[Tensor],
+                  running_var: Optional[Tensor], eps: float, momentum: float, training: bool):
+    """x [B, C, *] (f32 / bf16, contiguous) -> (y bf16, mean f32 [C], rstd f32 [C]); running stats updated in place."""
+    if x.dtype not in (f32, bf16) or not x.is_cuda or not x.is_contiguous() or x.dim() < 2:
+        raise ValueError("cfhip batchnorm_fwd: x must be a contiguous f32/bf16 [B, C, ...] device tensor")
+    b, c = x.shape[0], x.shape[1]
+    inner = x.numel() // (b * c)
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
+        if t is not None:
+            _need(t, f32, nm)
+    y = torch.empty(x.shape, dtype=bf16, device=x.device)
+    mean = torch.empty((c,), dtype=f32, device=x.device)
+    rstd = torch.empty((c,), dtype=f32, device=x.device)
+    rc = _lib.load().cfhip_batchnorm_fwd(x.data_ptr(), int(x.dtype == f32), _p(gamma), _p(beta), y.data_ptr(),
+                                         mean.data_ptr(), rstd.data_ptr(), _p(running_mean), _p(running_var), b, c,
+                                         inner, float(eps), float(momentum), int(training), _stream())
+    _lib.check(rc, "batchnorm_fwd")
+    return y, mean, rstd
+
+
+def batchnorm_bwd(dy: Tensor, x: Tensor, gamma: Optional[Tensor], mean: Tensor, rstd: Tensor, *, training: bool,
+                  want_dx: bool = True, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None,
+                  accumulate: bool = False):
+    """Returns (dx bf16 | None, dgamma f32 [C], dbeta f32 [C])."""
+    _need(dy, bf16, "dy")
+    if not dy.is_contiguous():
+        dy = dy.contiguous()
+    b, c = x.shape[0], x.shape[1]
+    inner = x.numel() // (b * c)
+    dx = torch.empty(x.shape, dtype=bf16, device=x.device) if want_dx else None
+    if dgamma is None:
+        dgamma, accumulate = torch.empty((c,), dtype=f32, device=x.device), False
+        dbeta = torch.empty((c,), dtype=f32, device=x.device)
+    rc = _lib.load().cfhip_batchnorm_bwd(dy.data_ptr(), x.data_ptr(), int(x.dtype == f32), _p(gamma), mean.data_ptr(),
+                                         rstd.data_ptr(), _p(dx), dgamma.data_ptr(), dbeta.data_ptr(), b, c, inner,
+                                         int(accumulate), int(training), _stream())
+    _lib.check(rc, "batchnorm_bwd")
+    return dx, dgamma, dbeta
+
+
+def leaky_relu_fwd(x: Tensor, slope: float) -> Tensor:
+    _need(x, bf16, "x")
+    if not x.is_contiguous():
+        x = x.contiguous()
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().cfhip_leaky_relu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), float(slope), _stream()),
+               "leaky_relu_fwd")
+    return y
+
+
+def leaky_relu_bwd(dy: Tensor, x: Tensor, slope: float) -> Tensor:
+    _need(dy, bf16, "dy")
+    _need(x, bf16, "x")
+    if not dy.is_contiguous():
+        dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    _lib.check(_lib.load().cfhip_leaky_relu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), float(slope),
+                                                _stream()), "leaky_relu_bwd")
+    return dx
+
+
+def avgpool_fwd(x: Tensor) -> Tensor:
+    """x bf16 [B, C, H, W] -> bf16 [B, C] (AdaptiveAvgPool2d((1, 1)) + squeeze)."""
+    _need(x, bf16, "x")
+    if not x.is_contiguous():
+        x = x.contiguous()
+    b, c = x.shape[0], x.shape[1]
+    inner = x.numel() // (b * c)
+    y = torch.empty((b, c), dtype=bf16, device=x.device)
+    _lib.check(_lib.load().cfhip_avgpool_fwd(x.data_ptr(), y.data_ptr(), b * c, inner, _stream()), "avgpool_fwd")
+    return y
+
+
+def avgpool_bwd(dy: Tensor, shape: Tuple[int, ...]) -> Tensor:
+    _need(dy, bf16, "dy")
+    if not dy.is_contiguous():
+        dy = dy.contiguous()
+    b, c = shape[0], shape[1]
+    dx = torch.empty(shape, dtype=bf16, device=dy.device)
+    inner = dx.numel() // (b * c)
+    _lib.check(_lib.load().cfhip_avgpool_bwd(dy.data_ptr(), dx.data_ptr(), b * c, inner, _stream()), "avgpool_bwd")
+    return dx

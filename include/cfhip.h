@@ -195,6 +195,43 @@ int cfhip_sumsq_f32(const float* g, float* out, int64_t n, void* stream);
  * (losses/basic.py:126-141; integer label gather is exact.) */
 int cfhip_softmax_xent(const float* logits, const int64_t* labels, float* loss_sum, float* dlogits,
                        int B, int C, float grad_scale, void* stream);
+/* focal loss (losses/basic.py:170-206, the examples' default): p = softmax(z) + eps,
+ * L_b = -log(p_y) (1 - p_y)^gamma; loss_sum += sum_b L_b; dlogits = grad_scale * dL/dz. */
+int cfhip_softmax_focal(const float* logits, const int64_t* labels, float* loss_sum, float* dlogits,
+                        int B, int C, float gamma, float eps, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K8 general form: Conv2d (groups 1) = im2row + K1 GEMM (convs/basic.py:104-177 -> F.conv2d)
+ *   conv_im2row: x f32/bf16 [B,C,H,W] -> rows bf16 [B*Ho*Wo][Kp], k = (c, ky, kx), zero padding,
+ *     columns K..Kp-1 zero (Kp = K rounded up to a multiple of 8: the GEMM operand rule), so
+ *     y_rows = rows x W[Cout][Kp]^T (+bias) is one cfhip_gemm_bf16 call and dW the (tn) GEMM of
+ *     the same rows;  Ho = (H + 2 pad - dil (kh - 1) - 1) / stride + 1.
+ *   conv_row2im: dx bf16 [B,C,H,W] = gather-sum of drows bf16 [B*Ho*Wo][Kp] (= dY_rows x W): every
+ *     input pixel sums its <= kh*kw contributions — no atomics, deterministic.
+ *   transpose_batched: src f32/bf16 [batch][R][C] -> dst bf16 [batch][C][R]: NCHW <-> token-major.
+ * K9/K10: BatchNorm over (B, inner) per channel of x [B][C][inner] (norms.py:20-27,90-93 ->
+ *   nn.BatchNorm1d/2d): training = batch statistics (biased variance), running statistics updated
+ *   with `momentum` and the UNBIASED variance; eval = running statistics.  y bf16, mean/rstd f32 [C]
+ *   saved for backward; bwd: dgamma/dbeta f32 [C] ((+)= with accumulate), dx bf16 (NULL to skip).
+ * LeakyReLU (slope 0 = ReLU; activations.py "leaky_relu_0.2", "ReLU"), AdaptiveAvgPool2d((1,1))
+ *   (cv/encoder/vanilla.py:144): x [BC][inner] -> y [BC].
+ * ------------------------------------------------------------------------------------------ */
+int cfhip_conv_im2row(const void* x, int x_is_f32, void* rows, int B, int C, int H, int W, int kh,
+                      int kw, int stride, int pad, int dil, int Kp, void* stream);
+int cfhip_conv_row2im(const void* drows, void* dx, int B, int C, int H, int W, int kh, int kw,
+                      int stride, int pad, int dil, int Kp, void* stream);
+int cfhip_transpose_batched(const void* src, int src_is_f32, void* dst, int batch, int R, int C,
+                            void* stream);
+int cfhip_batchnorm_fwd(const void* x, int x_is_f32, const float* gamma, const float* beta, void* y,
+                        float* mean, float* rstd, float* running_mean, float* running_var, int B, int C,
+                        int inner, float eps, float momentum, int training, void* stream);
+int cfhip_batchnorm_bwd(const void* dy, const void* x, int x_is_f32, const float* gamma,
+                        const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                        int B, int C, int inner, int accumulate, int training, void* stream);
+int cfhip_leaky_relu_fwd(const void* x, void* y, int64_t n, float slope, void* stream);
+int cfhip_leaky_relu_bwd(const void* dy, const void* x, void* dx, int64_t n, float slope, void* stream);
+int cfhip_avgpool_fwd(const void* x, void* y, int64_t BC, int inner, void* stream);
+int cfhip_avgpool_bwd(const void* dy, void* dx, int64_t BC, int inner, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 import vit_oracle as O  # noqa: E402
+import conv_oracle as CO  # noqa: E402
 from refharness import load_reference  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
@@ -170,11 +171,122 @@ def gen_vit(ref) -> None:
     )
 
 
+def gen_conv2d(ref) -> None:
+    """Conv2d (convs/basic.py:41-184) in the geometries the MNIST classifier uses + a dilated one."""
+    import importlib
+
+    cases = []
+    for seed, (cin, cout, k, stride, dil, hw) in enumerate(
+            [(1, 16, 7, 1, 1, 28), (16, 32, 3, 2, 1, 28), (64, 128, 3, 2, 1, 7), (8, 16, 3, 1, 2, 13)]):
+        torch.manual_seed(40 + seed)
+        m = ref.Conv2d(cin, cout, kernel_size=k, stride=stride, dilation=dil,
+                       padding="same" if dil == 1 else dil * (k // 2))
+        with torch.no_grad():
+            m.bias.normal_(0.0, 0.5)
+        x = torch.randn(3, cin, hw, hw, requires_grad=True)
+        y = m(x)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        _check(f"conv2d {cin}->{cout} k{k} s{stride} d{dil}",
+               CO.conv2d(x.detach(), m.weight.detach(), m.bias.detach(), stride, m.padding, dil), y.detach())
+        cases.append(dict(cfg=dict(in_channels=cin, out_channels=cout, kernel_size=k, stride=stride, dilation=dil,
+                                   padding=m.padding),
+                          w=m.weight.detach().clone(), b=m.bias.detach().clone(), x=x.detach(), y=y.detach(), gy=gy,
+                          gx=x.grad.clone(), gw=m.weight.grad.clone(), gb=m.bias.grad.clone()))
+    torch.save(cases, os.path.join(OUT, "conv2d.pt"))
+
+
+def gen_batchnorm(ref) -> None:
+    """NormFactory("batch") = nn.BatchNorm2d (norms.py:90-93,114-115): training step + running stats + eval."""
+    torch.manual_seed(50)
+    m = ref.NormFactory("batch").make(24)
+    with torch.no_grad():
+        m.weight.normal_(1.0, 0.3)
+        m.bias.normal_(0.0, 0.3)
+    x = (torch.randn(5, 24, 6, 7) * 1.7 + 0.4).requires_grad_(True)
+    m.train()
+    y = m(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    oy, mean, var = CO.batch_norm_train(x.detach(), m.weight.detach(), m.bias.detach(), m.eps)
+    _check("batchnorm train", oy, y.detach())
+    rm, rv = CO.running_update(torch.zeros(24), torch.ones(24), mean, var, 5 * 6 * 7, m.momentum)
+    _check("running_mean", rm, m.running_mean)
+    _check("running_var", rv, m.running_var)
+    m.eval()
+    x2 = torch.randn(3, 24, 6, 7)
+    y_eval = m(x2)
+    _check("batchnorm eval", CO.batch_norm_eval(x2, m.weight.detach(), m.bias.detach(), m.running_mean, m.running_var,
+                                                m.eps), y_eval.detach())
+    torch.save(dict(eps=m.eps, momentum=m.momentum, w=m.weight.detach().clone(), b=m.bias.detach().clone(),
+                    x=x.detach(), y=y.detach(), gy=gy, gx=x.grad.clone(), gw=m.weight.grad.clone(),
+                    gb=m.bias.grad.clone(), running_mean=m.running_mean.clone(), running_var=m.running_var.clone(),
+                    x_eval=x2, y_eval=y_eval.detach()),
+               os.path.join(OUT, "batchnorm.pt"))
+
+
+def gen_mnist_clf(ref) -> None:
+    """examples/cv/classification/mnist_clf.py: cv_clf(in_channels=1, num_classes=10, num_downsample=3), focal
+    loss, synthetic 28x28 batch (the data set cannot be downloaded)."""
+    import importlib
+
+    importlib.import_module("cflearn.modules.cv.encoder.vanilla")
+    importlib.import_module("cflearn.modules.cv.classifier.vanilla")
+    torch.manual_seed(60)
+    m = ref.build_module("cv_clf", config=dict(in_channels=1, num_classes=10, encoder_config=dict(num_downsample=3)))
+    with torch.no_grad():  # move away from the all-zero-bias / unit-gamma init so every gradient is exercised
+        for n_, p_ in m.named_parameters():
+            if p_.dim() == 1:
+                p_.add_(torch.randn_like(p_) * 0.1)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    img = torch.randn(8, 1, 28, 28)
+    labels = torch.randint(0, 10, (8, 1))
+    m.train()
+    logits = m(img)["predictions"]
+    loss = O.focal_loss(logits, labels)
+    loss.backward()
+    _check("mnist_clf logits", CO.mnist_classifier(img, sd0, 3), logits.detach())
+    grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+    sd1 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.eval()
+    logits_eval = m(img)["predictions"].detach()
+    _check("mnist_clf eval logits", CO.mnist_classifier(img, sd1, 3, training=False), logits_eval)
+    torch.save(dict(sd=sd0, img=img, labels=labels, logits=logits.detach(), loss=loss.detach(), grads=grads,
+                    sd_after=sd1, logits_eval=logits_eval),
+               os.path.join(OUT, "mnist_clf.pt"))
+
+
+def gen_fcnn(ref) -> None:
+    """examples/cv/classification/mnist_fcnn.py / config 1: fcnn(input_dim, output_dim=10) with the default two
+    hidden Mapping blocks, focal loss (input_dim 96 -> hidden 192 keeps the fixture small; 784 -> 1024 is the
+    same code)."""
+    torch.manual_seed(70)
+    m = ref.FCNN(96, 10)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.dim() == 1:
+                p_.normal_(0.0, 0.1)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(16, 96)
+    labels = torch.randint(0, 10, (16, 1))
+    logits = m(x)
+    loss = O.focal_loss(logits, labels)
+    loss.backward()
+    _check("fcnn logits", CO.fcnn(x, sd, 2), logits.detach(), atol=5e-5)
+    torch.save(dict(sd=sd, x=x, labels=labels, logits=logits.detach(), loss=loss.detach(),
+                    grads={k: p.grad.clone() for k, p in m.named_parameters()}),
+               os.path.join(OUT, "fcnn.pt"))
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
     torch.set_num_threads(4)
-    for fn in (gen_linear, gen_layernorm, gen_sdp, gen_attention, gen_feedforward, gen_vit):
+    only = sys.argv[1:]
+    for fn in (gen_linear, gen_layernorm, gen_sdp, gen_attention, gen_feedforward, gen_vit, gen_conv2d,
+               gen_batchnorm, gen_mnist_clf, gen_fcnn):
+        if only and fn.__name__ not in only:
+            continue
         print(fn.__name__)
         fn(ref)
     for f in sorted(os.listdir(OUT)):

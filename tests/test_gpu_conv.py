@@ -1,0 +1,225 @@
+"""Conv2d (im2row + MFMA GEMM) / BatchNorm / LeakyReLU / pooling / focal loss and the two models built from
+them (MNIST conv classifier, FCNN) on the GPU vs the reference-made golden fixtures and the CPU oracle.
+
+Tolerances: the HIP path rounds activations to bf16 between layers (what the reference does under
+mixed_precision="bf16"); fixtures are the reference's fp32 CPU run.  Index work (im2row / row2im / transposes) is
+checked bit-exactly on bf16-representable data."""
+import pytest
+import torch
+
+import cflearn_amd as C
+from cflearn_amd import functional as HF
+from cflearn_amd import ops
+from helpers import assert_close, bf16_round
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+
+def test_im2row_row2im_transposes_bit_exact():
+    import conv_oracle as CO
+
+    torch.manual_seed(0)
+    for (b, c, h, w, k, s, p, d) in ((2, 3, 9, 11, 3, 1, 1, 1), (3, 1, 28, 28, 7, 1, 3, 1), (2, 16, 14, 14, 3, 2, 1, 1),
+                                    (1, 5, 13, 10, 3, 2, 2, 2), (2, 8, 7, 7, 1, 1, 0, 1)):
+        x = bf16_round(torch.randn(b, c, h, w))
+        ho, wo = ops.conv_out_hw(h, w, k, k, s, p, d)
+        rows = ops.conv_im2row(x.to(DEV), k, k, s, p, d)
+        kk = c * k * k
+        # oracle rows through an identity "weight": conv with one-hot kernels picks the patch elements
+        eye = torch.eye(kk).view(kk, c, k, k)
+        want = CO.conv2d(x, eye, None, s, p, d).permute(0, 2, 3, 1).reshape(b * ho * wo, kk)
+        assert torch.equal(rows[:, :kk].float().cpu(), want)
+        assert rows.shape[1] % 8 == 0 and (rows[:, kk:] == 0).all()
+        # same from a bf16 input
+        assert torch.equal(ops.conv_im2row(x.to(DEV).bfloat16(), k, k, s, p, d), rows)
+        # row2im is the transpose of im2row: <im2row(x), r> == <x, row2im(r)> — check against autograd of the oracle
+        r = bf16_round(torch.randn(b * ho * wo, rows.shape[1]) * 0.25)
+        r[:, kk:] = 0
+        xg = x.clone().requires_grad_(True)
+        CO.conv2d(xg, eye, None, s, p, d).permute(0, 2, 3, 1).reshape(b * ho * wo, kk).backward(r[:, :kk])
+        got = ops.conv_row2im(r.to(DEV).bfloat16(), (b, c, h, w), k, k, s, p, d)
+        assert_close(got, xg.grad, 4e-3, "row2im")  # sums of <= k*k bf16 values, rounded once to bf16
+    t = bf16_round(torch.randn(5, 37, 70))
+    assert torch.equal(ops.transpose_batched(t.to(DEV)).float().cpu(), t.transpose(1, 2))
+    assert torch.equal(ops.transpose_batched(t.to(DEV).bfloat16()).float().cpu(), t.transpose(1, 2))
+
+
+def test_conv2d_golden(golden):
+    for case in golden("conv2d.pt"):
+        cfg = case["cfg"]
+        m = C.Conv2d(cfg["in_channels"], cfg["out_channels"], kernel_size=cfg["kernel_size"], stride=cfg["stride"],
+                     dilation=cfg["dilation"], padding=cfg["padding"]).to(DEV)
+        with torch.no_grad():
+            m.weight.copy_(case["w"])
+            m.bias.copy_(case["b"])
+        x = case["x"].to(DEV).requires_grad_(True)
+        y = m(x)
+        assert y.dtype == torch.bfloat16 and y.shape == case["y"].shape
+        assert_close(y, case["y"], 6e-3, f"conv y {cfg}")
+        y.backward(case["gy"].to(DEV).bfloat16())
+        assert_close(x.grad, case["gx"], 1e-2, f"conv gx {cfg}")
+        assert_close(m.weight.grad, case["gw"], 1e-2, f"conv gw {cfg}")
+        assert_close(m.bias.grad, case["gb"], 6e-3, f"conv gb {cfg}")
+        # accumulate into existing grads
+        y2 = m(x.detach())
+        y2.backward(case["gy"].to(DEV).bfloat16())
+        assert_close(m.weight.grad, 2 * case["gw"], 1e-2, "conv gw accumulate")
+
+
+def test_batchnorm_golden(golden):
+    g = golden("batchnorm.pt")
+    m = C.NormFactory("batch").make(g["w"].numel()).to(DEV)
+    assert isinstance(m, torch.nn.BatchNorm2d) and m.eps == g["eps"] and m.momentum == g["momentum"]
+    with torch.no_grad():
+        m.weight.copy_(g["w"])
+        m.bias.copy_(g["b"])
+    x = g["x"].to(DEV).requires_grad_(True)
+    m.train()
+    y = m(x)
+    assert_close(y, g["y"], 4e-3, "bn y")
+    y.backward(g["gy"].to(DEV).bfloat16())
+    assert_close(x.grad, g["gx"], 8e-3, "bn gx")
+    assert_close(m.weight.grad, g["gw"], 6e-3, "bn gw")
+    assert_close(m.bias.grad, g["gb"], 6e-3, "bn gb")
+    assert_close(m.running_mean, g["running_mean"], 1e-5, "running_mean")
+    assert_close(m.running_var, g["running_var"], 1e-5, "running_var")
+    assert int(m.num_batches_tracked) == 1
+    m.eval()
+    assert_close(m(g["x_eval"].to(DEV)), g["y_eval"], 4e-3, "bn eval")
+    # BatchNorm1d forms: [B, C] and the token-major BN wrapper
+    torch.manual_seed(3)
+    bn1 = C.NormFactory("batch1d").make(40).to(DEV)
+    ref1 = torch.nn.BatchNorm1d(40)
+    x1 = torch.randn(33, 40) * 2 + 1
+    assert_close(bn1(x1.to(DEV)), ref1(x1), 4e-3, "bn1d")
+    assert_close(bn1.running_var, ref1.running_var, 1e-5, "bn1d running_var")
+    bnt = C.NormFactory("batch_norm").make(24).to(DEV)
+    xt = torch.randn(4, 9, 24)
+    reft = torch.nn.BatchNorm1d(24)
+    assert_close(bnt(xt.to(DEV)), reft(xt.transpose(1, 2)).transpose(1, 2), 4e-3, "BN token-major")
+
+
+def test_activations_pool_focal():
+    import vit_oracle as O
+
+    torch.manual_seed(1)
+    x = bf16_round(torch.randn(3, 5, 7, 9))
+    for slope, act in ((0.2, C.modules.build_activation("leaky_relu_0.2")), (0.0, C.modules.build_activation("ReLU"))):
+        xg = x.to(DEV).bfloat16().requires_grad_(True)
+        y = act(xg)
+        want = torch.where(x > 0, x, x * slope)
+        assert torch.equal(y.float().cpu(), bf16_round(want))
+        gy = bf16_round(torch.randn_like(x))
+        y.backward(gy.to(DEV).bfloat16())
+        assert torch.equal(xg.grad.float().cpu(), bf16_round(torch.where(x > 0, gy, gy * slope)))
+    xg = x.to(DEV).bfloat16().requires_grad_(True)
+    p = HF.global_avg_pool(xg)
+    assert_close(p, x.mean(dim=(2, 3)), 4e-3, "avgpool")
+    gy = bf16_round(torch.randn(3, 5))
+    p.backward(gy.to(DEV).bfloat16())
+    assert_close(xg.grad, (gy / 63.0)[:, :, None, None].expand_as(x), 4e-3, "avgpool bwd")
+    # focal loss: value and gradient vs the fp32 oracle (labels: integer gather, exact)
+    logits = torch.randn(37, 10) * 2
+    labels = torch.randint(0, 10, (37, 1))
+    lg = logits.clone().requires_grad_(True)
+    want = O.focal_loss(lg, labels)
+    want.backward()
+    l2 = logits.to(DEV).requires_grad_(True)
+    got = HF.focal_loss(l2, labels.to(DEV))
+    got.backward()
+    assert abs(got.item() - want.item()) <= 1e-5 * max(1.0, abs(want.item()))
+    assert_close(l2.grad, lg.grad, 1e-5, "focal dlogits")
+
+
+def _grads(m):
+    return {k: p.grad.detach().float().cpu() for k, p in m.named_parameters() if p.grad is not None}
+
+
+def test_mnist_conv_classifier_golden(golden):
+    """examples/cv/classification/mnist_clf.py on a synthetic 28x28 batch: logits / focal loss / every parameter
+    gradient / running statistics after the step / eval-mode logits vs the reference's fp32 CPU run."""
+    g = golden("mnist_clf.pt")
+    m = C.build_module("cv_clf", config=dict(in_channels=1, num_classes=10, encoder_config=dict(num_downsample=3)))
+    m.load_state_dict(g["sd"])
+    m = m.to(DEV).train()
+    logits = m(g["img"].to(DEV))["predictions"]
+    assert logits.dtype == torch.float32
+    assert_close(logits, g["logits"], 2e-2, "logits")
+    loss = HF.focal_loss(logits, g["labels"].to(DEV))
+    assert abs(loss.item() - g["loss"].item()) <= 5e-3 * abs(g["loss"].item())
+    loss.backward()
+    grads = _grads(m)
+    assert set(grads) == set(g["grads"])
+    # (1) vs the oracle with bf16 storage emulated at the points where the HIP path stores bf16: kernel error only
+    import conv_oracle as CO
+    import vit_oracle as O
+
+    params = {k: v.clone().requires_grad_(True) for k, v in g["sd"].items() if k in g["grads"]}
+    buffers = {k: v for k, v in g["sd"].items() if k not in params}
+    O.focal_loss(CO.mnist_classifier(g["img"], {**buffers, **params}, 3, rnd=CO.bf16_round), g["labels"]).backward()
+    worst = 0.0
+    for k, v in grads.items():
+        worst = max(worst, assert_close(v, params[k].grad, 2.5e-2, f"grad {k} vs bf16-storage oracle", abs_floor=2e-4))
+    # (2) vs the reference's fp32 run: bf16 storage moves the deepest gradients by several percent on this model (the
+    # emulated oracle above differs from fp32 by the same amount), so this bound is loose by construction
+    for k, v in grads.items():
+        assert_close(v, g["grads"][k], 1.2e-1, f"grad {k} vs fp32 reference", abs_floor=2e-4)
+    print(f"mnist_clf worst grad rel-L2 vs bf16-storage oracle {worst:.3e}")
+    sd = m.state_dict()
+    for k, v in g["sd_after"].items():
+        if "running" in k:
+            assert_close(sd[k], v, 1e-2, k, abs_floor=1e-4)
+        if "num_batches_tracked" in k:
+            assert int(sd[k]) == int(v)
+    m.load_state_dict(g["sd_after"])
+    m.eval()
+    assert_close(m(g["img"].to(DEV))["predictions"], g["logits_eval"], 2e-2, "eval logits")
+
+
+def test_fcnn_golden(golden):
+    g = golden("fcnn.pt")
+    m = C.build_module("fcnn", config=dict(input_dim=96, output_dim=10))
+    m.load_state_dict(g["sd"])
+    m = m.to(DEV)
+    logits = m(g["x"].to(DEV))
+    assert logits.dtype == torch.float32
+    assert_close(logits, g["logits"], 1e-2, "fcnn logits")
+    loss = HF.focal_loss(logits, g["labels"].to(DEV))
+    assert abs(loss.item() - g["loss"].item()) <= 3e-3 * abs(g["loss"].item())
+    loss.backward()
+    import conv_oracle as CO
+    import vit_oracle as O
+
+    sd = {k: v.clone().requires_grad_(True) for k, v in g["sd"].items()}
+    O.focal_loss(CO.fcnn(g["x"], sd, 2, rnd=CO.bf16_round), g["labels"]).backward()
+    for k, v in _grads(m).items():
+        assert_close(v, sd[k].grad, 1.5e-2, f"fcnn grad {k} vs bf16-storage oracle", abs_floor=1e-4)
+        assert_close(v, g["grads"][k], 1.2e-1, f"fcnn grad {k} vs fp32 reference", abs_floor=1e-4)
+
+
+def test_conv_classifier_and_fcnn_train_steps(golden):
+    """engine.TrainStep (fused AdamW over the arena, focal loss kernel) drives both models: the loss of a fixed
+    batch goes down, BatchNorm running statistics move, nothing is NaN."""
+    from cflearn_amd.engine import TrainStep
+
+    g = golden("mnist_clf.pt")
+    m = C.build_module("cv_clf", config=dict(in_channels=1, num_classes=10, encoder_config=dict(num_downsample=3)))
+    m.load_state_dict(g["sd"])
+    m = m.to(DEV).train()
+    ts = TrainStep(m, lr=2e-3, loss="focal")
+    img, labels = g["img"].to(DEV), g["labels"].view(-1).to(DEV)
+    losses = [ts.step(img, labels).item() / img.shape[0] for _ in range(25)]
+    assert abs(losses[0] - g["loss"].item()) <= 5e-3 * g["loss"].item()
+    assert losses[-1] < 0.5 * losses[0] and all(l == l for l in losses)
+    assert int(m.encoder.encoder.encoder[1].num_batches_tracked) == 25
+
+    f = golden("fcnn.pt")
+    n = C.build_module("fcnn", config=dict(input_dim=96, output_dim=10))
+    n.load_state_dict(f["sd"])
+    n = n.to(DEV)
+    ts2 = TrainStep(n, lr=2e-3, loss="focal")
+    x, y = f["x"].to(DEV), f["labels"].view(-1).to(DEV)
+    losses = [ts2.step(x, y).item() / x.shape[0] for _ in range(25)]
+    assert abs(losses[0] - f["loss"].item()) <= 3e-3 * f["loss"].item()
+    assert losses[-1] < 0.5 * losses[0]

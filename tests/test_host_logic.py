@@ -83,7 +83,11 @@ def test_unsupported_features_raise():
     with pytest.raises(NotImplementedError):
         C.FeedForward(8, 16, 0.0, activation="geglu")
     with pytest.raises(NotImplementedError):
-        C.Conv2d(3, 8, kernel_size=3)
+        C.Conv2d(4, 8, kernel_size=3, groups=2)
+    with pytest.raises(NotImplementedError):
+        C.Conv2d(3, 8, kernel_size=3, padding="reflection")
+    with pytest.raises(NotImplementedError):
+        C.modules.Mapping(8, 8, dropout=0.5)
 
 
 def test_param_arena_views_and_lazy_zero():
@@ -125,3 +129,20 @@ def test_split_k_policy():
     s = pick_split_k(2304, 768, 12608)
     assert 2 <= s <= 8
     assert pick_split_k(1000, 768, 64) == 1
+
+
+def test_conv_classifier_and_fcnn_state_dict_keys_match_reference(golden):
+    """cv_clf(encoder="vanilla_1d") (examples/cv/classification/mnist_clf.py) and fcnn: key-for-key, shape-for-shape
+    equal to the state_dict the reference's own modules produced (fixtures made by oracle/gen_golden.py)."""
+    g = golden("mnist_clf.pt")
+    m = C.build_module("cv_clf", config=dict(in_channels=1, num_classes=10, encoder_config=dict(num_downsample=3)))
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["sd"].keys())
+    assert all(sd[k].shape == g["sd"][k].shape and sd[k].dtype == g["sd"][k].dtype for k in sd)
+    m.load_state_dict(g["sd"])
+    f = golden("fcnn.pt")
+    n = C.build_module("fcnn", config=dict(input_dim=96, output_dim=10))
+    assert list(n.state_dict().keys()) == list(f["sd"].keys())
+    assert all(n.state_dict()[k].shape == f["sd"][k].shape for k in f["sd"])
+    n.load_state_dict(f["sd"])
+    assert n.hidden_units == [192, 192]

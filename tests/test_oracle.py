@@ -110,3 +110,73 @@ def test_oracle_vs_reference_live():
     with torch.no_grad():
         want = att(x, x, x, mask=mask).output
     assert max_abs(O.self_attention(x, asd, "", 1, mask), want) < TOL
+
+
+# ---- conv / batch-norm / FCNN restatement (oracle/conv_oracle.py) vs the reference-made fixtures --------------
+
+
+def _autograd(fn, leaves):
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in leaves.items()}
+    return leaves, fn(leaves)
+
+
+def test_conv2d_oracle(golden):
+    import conv_oracle as CO
+
+    for case in golden("conv2d.pt"):
+        cfg = case["cfg"]
+        lv, y = _autograd(lambda t: CO.conv2d(t["x"], t["w"], t["b"], cfg["stride"], cfg["padding"], cfg["dilation"]),
+                          dict(x=case["x"], w=case["w"], b=case["b"]))
+        assert (y - case["y"]).abs().max() <= 2e-5 * max(1.0, case["y"].abs().max())
+        y.backward(case["gy"])
+        for k, g in (("x", "gx"), ("w", "gw"), ("b", "gb")):
+            assert (lv[k].grad - case[g]).abs().max() <= 1e-4 * max(1.0, case[g].abs().max()), (cfg, g)
+
+
+def test_batchnorm_oracle(golden):
+    import conv_oracle as CO
+
+    g = golden("batchnorm.pt")
+    lv, out = _autograd(lambda t: CO.batch_norm_train(t["x"], t["w"], t["b"], g["eps"]),
+                        dict(x=g["x"], w=g["w"], b=g["b"]))
+    y, mean, var = out
+    assert (y - g["y"]).abs().max() < 1e-5
+    y.backward(g["gy"])
+    for k, name in (("x", "gx"), ("w", "gw"), ("b", "gb")):
+        assert (lv[k].grad - g[name]).abs().max() <= 1e-4 * max(1.0, g[name].abs().max()), name
+    n = g["x"].numel() // g["x"].shape[1]
+    rm, rv = CO.running_update(torch.zeros_like(mean), torch.ones_like(var), mean.detach(), var.detach(), n,
+                               g["momentum"])
+    assert (rm - g["running_mean"]).abs().max() < 1e-6 and (rv - g["running_var"]).abs().max() < 1e-5
+    ye = CO.batch_norm_eval(g["x_eval"], g["w"], g["b"], g["running_mean"], g["running_var"], g["eps"])
+    assert (ye - g["y_eval"]).abs().max() < 1e-5
+
+
+def test_mnist_classifier_oracle(golden):
+    import conv_oracle as CO
+    import vit_oracle as O
+
+    g = golden("mnist_clf.pt")
+    params = {k: v for k, v in g["sd"].items() if v.dtype.is_floating_point and "running" not in k}
+    buffers = {k: v for k, v in g["sd"].items() if k not in params}
+    lv, logits = _autograd(lambda t: CO.mnist_classifier(g["img"], {**buffers, **t}, 3), params)
+    assert (logits - g["logits"]).abs().max() < 1e-5
+    loss = O.focal_loss(logits, g["labels"])
+    assert abs(loss.item() - g["loss"].item()) < 1e-6
+    loss.backward()
+    for k, ref in g["grads"].items():
+        assert (lv[k].grad - ref).abs().max() <= max(1e-6, 1e-4 * ref.abs().max()), k  # (conv bias under BN: true gradient is 0)
+    ev = CO.mnist_classifier(g["img"], g["sd_after"], 3, training=False)
+    assert (ev - g["logits_eval"]).abs().max() < 1e-5
+
+
+def test_fcnn_oracle(golden):
+    import conv_oracle as CO
+    import vit_oracle as O
+
+    g = golden("fcnn.pt")
+    lv, logits = _autograd(lambda t: CO.fcnn(g["x"], t, 2), g["sd"])
+    assert (logits - g["logits"]).abs().max() < 1e-5
+    O.focal_loss(logits, g["labels"]).backward()
+    for k, ref in g["grads"].items():
+        assert (lv[k].grad - ref).abs().max() <= max(1e-6, 1e-4 * ref.abs().max()), k  # (conv bias under BN: true gradient is 0)
