@@ -76,6 +76,12 @@ SIGNATURES = {
     "cfhip_leaky_relu_bwd": (c_int, [_P, _P, _P, c_int64, c_float, _P]),
     "cfhip_avgpool_fwd": (c_int, [_P, _P, c_int64, c_int, _P]),
     "cfhip_avgpool_bwd": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "cfhip_quick_gelu_fwd": (c_int, [_P, _P, c_int64, _P]),
+    "cfhip_quick_gelu_bwd": (c_int, [_P, _P, _P, c_int64, _P]),
+    "cfhip_embedding_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64, _P]),
+    "cfhip_embedding_bwd": (c_int, [_P, c_int, _P, _P, c_int64, c_int, c_int64, c_int64, _P]),
+    "cfhip_l2norm_fwd": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
+    "cfhip_l2norm_bwd": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
 }
 
 

@@ -82,6 +82,16 @@ __device__ __forceinline__ float gelu_erf_grad_f(float x) {
   return fmaf(x * 0.39894228040143267794f, e, cdf);  // Phi(x) + x phi(x)
 }
 
+// ---- quick GELU x * sigmoid(1.702 x) (reference activations.py "quick_gelu", the CLIP towers) ------------
+__device__ __forceinline__ float sigmoid_1702(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * (-1.702f * 1.4426950408889634f)));
+}
+__device__ __forceinline__ float quick_gelu_f(float x) { return x * sigmoid_1702(x); }
+__device__ __forceinline__ float quick_gelu_grad_f(float x) {
+  const float s = sigmoid_1702(x);
+  return s * fmaf(1.702f * x, 1.0f - s, 1.0f);
+}
+
 // ---- wave-level reductions over all 64 lanes ----------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -121,7 +121,7 @@ __global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __re
   for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride)
     dst[i] = bf16_to_f32(src[i]);
 }
-// MODE 0: y = gelu(x); 1: dx = dy * gelu'(x); 2: out = a + b
+// MODE 0: y = gelu(x); 1: dx = dy * gelu'(x); 2: out = a + b; 3 / 4: MODE 0 / 1 with quick GELU
 template <int MODE>
 __global__ void ew_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                bf16_t* __restrict__ out, long n) {
@@ -131,20 +131,22 @@ __global__ void ew_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __res
     const u32x2 wa = reinterpret_cast<const u32x2*>(a)[i];
     float va[4] = {bf16lo(wa[0]), bf16hi(wa[0]), bf16lo(wa[1]), bf16hi(wa[1])};
     float vb[4] = {0.f, 0.f, 0.f, 0.f};
-    if (MODE != 0) {
+    if (MODE != 0 && MODE != 3) {
       const u32x2 wb = reinterpret_cast<const u32x2*>(b)[i];
       vb[0] = bf16lo(wb[0]); vb[1] = bf16hi(wb[0]); vb[2] = bf16lo(wb[1]); vb[3] = bf16hi(wb[1]);
     }
     float o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      o[e] = MODE == 0 ? gelu_erf_f(va[e]) : MODE == 1 ? va[e] * gelu_erf_grad_f(vb[e]) : va[e] + vb[e];
+      o[e] = MODE == 0 ? gelu_erf_f(va[e]) : MODE == 1 ? va[e] * gelu_erf_grad_f(vb[e]) : MODE == 2 ? va[e] + vb[e]
+             : MODE == 3 ? quick_gelu_f(va[e]) : va[e] * quick_gelu_grad_f(vb[e]);
     reinterpret_cast<u32x2*>(out)[i] = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
   }
   for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
     const float x = bf16_to_f32(a[i]);
-    const float y = MODE != 0 ? bf16_to_f32(b[i]) : 0.f;
-    out[i] = f32_to_bf16(MODE == 0 ? gelu_erf_f(x) : MODE == 1 ? x * gelu_erf_grad_f(y) : x + y);
+    const float y = (MODE != 0 && MODE != 3) ? bf16_to_f32(b[i]) : 0.f;
+    out[i] = f32_to_bf16(MODE == 0 ? gelu_erf_f(x) : MODE == 1 ? x * gelu_erf_grad_f(y) : MODE == 2 ? x + y
+                         : MODE == 3 ? quick_gelu_f(x) : x * quick_gelu_grad_f(y));
   }
 }
 
@@ -455,6 +457,13 @@ extern "C" int cfhip_gelu_fwd(const void* x, void* y, int64_t n, void* stream) {
 extern "C" int cfhip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream) {
   CFHIP_REQUIRE(x, "gelu_bwd: null x");
   CFHIP_EW("gelu_bwd", 1, dy, x, dx)
+}
+extern "C" int cfhip_quick_gelu_fwd(const void* x, void* y, int64_t n, void* stream) {
+  CFHIP_EW("quick_gelu_fwd", 3, x, (const void*)nullptr, y)
+}
+extern "C" int cfhip_quick_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream) {
+  CFHIP_REQUIRE(x, "quick_gelu_bwd: null x");
+  CFHIP_EW("quick_gelu_bwd", 4, dy, x, dx)
 }
 extern "C" int cfhip_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {
   CFHIP_REQUIRE(b, "add_bf16: null b");

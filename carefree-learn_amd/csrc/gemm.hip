@@ -40,6 +40,7 @@ struct GemmParams {
   float* bgrad;        // (1,1) layout only: out[m] (+)= sum_k A(m,k)  — the bias gradient of a dW GEMM
   float* bgrad_slabs;  // split-K partials [z][M] of the above
   int bgrad_acc;
+  int quick;   // GELU / DGELU epilogues: 0 = exact-erf GELU, 1 = quick GELU x * sigmoid(1.702 x)
   int ablate;  // benchmarking only: bit0 skip in-loop DMA, bit1 skip MFMA/LDS reads, bit2 skip stores
 };
 
@@ -269,8 +270,13 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[C::FM
           if (c_hi) *reinterpret_cast<u32x4*>(p.aux_out + off) = w;
           else *reinterpret_cast<u32x2*>(p.aux_out + off) = u32x2{w[0], w[1]};
         }
-        lo = f32x4{gelu_erf_f(bf16lo(w[0])), gelu_erf_f(bf16hi(w[0])), gelu_erf_f(bf16lo(w[1])), gelu_erf_f(bf16hi(w[1]))};
-        hi = f32x4{gelu_erf_f(bf16lo(w[2])), gelu_erf_f(bf16hi(w[2])), gelu_erf_f(bf16lo(w[3])), gelu_erf_f(bf16hi(w[3]))};
+        if (p.quick) {  // wave-uniform
+          lo = f32x4{quick_gelu_f(bf16lo(w[0])), quick_gelu_f(bf16hi(w[0])), quick_gelu_f(bf16lo(w[1])), quick_gelu_f(bf16hi(w[1]))};
+          hi = f32x4{quick_gelu_f(bf16lo(w[2])), quick_gelu_f(bf16hi(w[2])), quick_gelu_f(bf16lo(w[3])), quick_gelu_f(bf16hi(w[3]))};
+        } else {
+          lo = f32x4{gelu_erf_f(bf16lo(w[0])), gelu_erf_f(bf16hi(w[0])), gelu_erf_f(bf16lo(w[1])), gelu_erf_f(bf16hi(w[1]))};
+          hi = f32x4{gelu_erf_f(bf16lo(w[2])), gelu_erf_f(bf16hi(w[2])), gelu_erf_f(bf16lo(w[3])), gelu_erf_f(bf16hi(w[3]))};
+        }
       } else if (EPI == CFHIP_EPI_RESIDUAL && p.out_f32) {
         // f32 residual stream: aux_in is f32 with the output's layout
         const float* r32 = reinterpret_cast<const float*>(p.aux_in) + off;
@@ -283,6 +289,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[C::FM
         if (EPI == CFHIP_EPI_RESIDUAL) {
           lo += f32x4{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
           hi += f32x4{bf16lo(w[2]), bf16hi(w[2]), bf16lo(w[3]), bf16hi(w[3])};
+        } else if (p.quick) {
+          lo *= f32x4{quick_gelu_grad_f(bf16lo(w[0])), quick_gelu_grad_f(bf16hi(w[0])), quick_gelu_grad_f(bf16lo(w[1])), quick_gelu_grad_f(bf16hi(w[1]))};
+          hi *= f32x4{quick_gelu_grad_f(bf16lo(w[2])), quick_gelu_grad_f(bf16hi(w[2])), quick_gelu_grad_f(bf16lo(w[3])), quick_gelu_grad_f(bf16hi(w[3]))};
         } else {
           lo *= f32x4{gelu_erf_grad_f(bf16lo(w[0])), gelu_erf_grad_f(bf16hi(w[0])), gelu_erf_grad_f(bf16lo(w[1])), gelu_erf_grad_f(bf16hi(w[1]))};
           hi *= f32x4{gelu_erf_grad_f(bf16lo(w[2])), gelu_erf_grad_f(bf16hi(w[2])), gelu_erf_grad_f(bf16lo(w[3])), gelu_erf_grad_f(bf16hi(w[3]))};
@@ -628,11 +637,11 @@ __global__ void gemm_bf16_generic_kernel(GemmParams p, int a_trans, int b_trans)
     if (p.epilogue == CFHIP_EPI_GELU) {
       const float pre = bf16_to_f32(f32_to_bf16(acc));
       if (p.aux_out != nullptr) p.aux_out[off] = f32_to_bf16(acc);
-      acc = gelu_erf_f(pre);
+      acc = p.quick ? quick_gelu_f(pre) : gelu_erf_f(pre);
     } else if (p.epilogue == CFHIP_EPI_RESIDUAL) {
       acc += p.out_f32 ? reinterpret_cast<const float*>(p.aux_in)[off] : bf16_to_f32(p.aux_in[off]);
     } else if (p.epilogue == CFHIP_EPI_DGELU) {
-      acc *= gelu_erf_grad_f(bf16_to_f32(p.aux_in[off]));
+      acc *= p.quick ? quick_gelu_grad_f(bf16_to_f32(p.aux_in[off])) : gelu_erf_grad_f(bf16_to_f32(p.aux_in[off]));
     }
     if (p.out_f32) {
       float* dst = reinterpret_cast<float*>(p.C) + off;
@@ -792,7 +801,10 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
   CFHIP_REQUIRE(bias_grad == nullptr || (a_trans && b_trans),
                 "gemm: the fused bias gradient exists for layout (1,1) only");
   CFHIP_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
-  CFHIP_REQUIRE(epilogue >= 0 && epilogue <= 3, "gemm: bad epilogue %d", epilogue);
+  CFHIP_REQUIRE(epilogue >= 0 && epilogue <= 5, "gemm: bad epilogue %d", epilogue);
+  const int quick = epilogue == CFHIP_EPI_QGELU || epilogue == CFHIP_EPI_DQGELU;
+  if (epilogue == CFHIP_EPI_QGELU) epilogue = CFHIP_EPI_GELU;      // same kernels, activation picked at run time
+  if (epilogue == CFHIP_EPI_DQGELU) epilogue = CFHIP_EPI_DGELU;
   CFHIP_REQUIRE(!(epilogue == CFHIP_EPI_RESIDUAL || epilogue == CFHIP_EPI_DGELU) || aux_in,
                 "gemm: epilogue %d needs aux_in", epilogue);
   CFHIP_REQUIRE(!accumulate || out_dtype == 1, "gemm: accumulate needs f32 output");
@@ -812,6 +824,7 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
   p.epilogue = epilogue; p.out_f32 = out_dtype; p.accumulate = accumulate;
   p.slabs = nullptr;
   p.tiles_m = p.tiles_n = 0;
+  p.quick = quick;
   p.ablate = g_gemm_ablate;
   p.bgrad = bias_grad;
   p.bgrad_acc = bias_grad_accumulate;

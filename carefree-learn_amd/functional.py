@@ -165,7 +165,7 @@ def _as_bf16_2d(x: Tensor) -> Tensor:
 # Linear (K1): y = x W^T + b, optional fused GELU / residual-add epilogue
 # ---------------------------------------------------------------------------------------------
 
-ACT_NONE, ACT_GELU = 0, 1
+ACT_NONE, ACT_GELU, ACT_QGELU = 0, 1, 2
 
 
 def _linear_param_grads(dy2: Tensor, x2: Tensor, weight: Tensor, bias: Optional[Tensor],
@@ -210,9 +210,10 @@ class LinearFn(Function):
         bias_f = None if bias is None else bias.detach().reshape(-1).contiguous()
         m, n = x2.shape[0], weight.shape[0]
         pre = None
-        if act == ACT_GELU:
+        if act in (ACT_GELU, ACT_QGELU):
             pre = torch.empty((m, n), dtype=bf16, device=x2.device)
-            y = ops.gemm(x2, w16, bias=bias_f, epilogue=ops.EPI_GELU, aux_out=pre)
+            y = ops.gemm(x2, w16, bias=bias_f, epilogue=ops.EPI_GELU if act == ACT_GELU else ops.EPI_QGELU,
+                         aux_out=pre)
         elif residual is not None:
             # the residual operand keeps its dtype: an f32 residual stream gives an f32 sum
             r2 = _as_rows(residual)
@@ -226,6 +227,7 @@ class LinearFn(Function):
         ctx.has_residual = residual is not None
         ctx.x_shape = x.shape
         ctx.in_dtype = x.dtype
+        ctx.act = act
         return y.view(*x.shape[:-1], n)
 
     @staticmethod
@@ -238,7 +240,7 @@ class LinearFn(Function):
         d_res = dy2.view(*ctx.x_shape[:-1], weight.shape[0]) if ctx.has_residual and ctx.needs_input_grad[4] else None
         # (autograd casts d_res to the residual's dtype; the gradient stream itself stays bf16)
         if pre is not None:
-            dy2 = ops.gelu_bwd(dy2, pre)
+            dy2 = ops.gelu_bwd(dy2, pre) if ctx.act == ACT_GELU else ops.quick_gelu_bwd(dy2, pre)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dy2, w16, b_trans=True).view(ctx.x_shape)  # bf16; autograd casts if needed
@@ -694,3 +696,94 @@ class FocalLossFn(Function):
 
 def focal_loss(logits: Tensor, labels: Tensor, gamma: float = 2.0, eps: float = 1.0e-6) -> Tensor:
     return FocalLossFn.apply(logits, labels, gamma, eps)
+
+
+# ---------------------------------------------------------------------------------------------
+# CLIP text tower: embedding lookup (+ positional add), row gather (EOT pooling), L2 normalisation
+# ---------------------------------------------------------------------------------------------
+
+
+class EmbeddingFn(Function):
+    """nn.Embedding lookup (reference multimodal/clip.py:160-164,238) optionally fused with the learned positional
+    add of `PositionalEncoding` (mixed_stacks/api.py:209-228): out f32 [..., D]."""
+
+    @staticmethod
+    def forward(ctx: Any, indices: Tensor, weight: Tensor, pos: Optional[Tensor], padding_idx: int) -> Tensor:
+        t = indices.shape[-1]
+        posd = None if pos is None else pos.detach().reshape(-1, pos.shape[-1])[:t].contiguous()
+        out = ops.embedding_fwd(weight.detach().contiguous(), indices, posd, period=t if pos is not None else 0)
+        ctx.save_for_backward(indices)
+        ctx.weight, ctx.pos, ctx.padding_idx, ctx.t = weight, pos, padding_idx, t
+        return out
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        (indices,) = ctx.saved_tensors
+        weight, pos = ctx.weight, ctx.pos
+        gw = gp = None
+        if weight.requires_grad:
+            def scatter(out: Tensor, acc: bool) -> None:
+                if not acc:
+                    out.zero_()
+                ops.embedding_bwd(dy, indices, out, ctx.padding_idx)
+
+            if _is_direct(weight):
+                write_param_grad(weight, scatter)
+            else:
+                gw = torch.zeros(weight.shape, dtype=f32, device=dy.device)
+                ops.embedding_bwd(dy, indices, gw, ctx.padding_idx)
+        if pos is not None and pos.requires_grad:
+            d = dy.shape[-1]
+            dy2 = dy if dy.dtype == bf16 else ops.to_bf16(dy.float().contiguous())
+            g = ops.colsum(dy2.reshape(-1, ctx.t * d))  # sum over the batch of [B, T*D]
+            gp = torch.zeros(pos.shape, dtype=f32, device=dy.device)
+            gp.view(-1, d)[:ctx.t] = g.view(ctx.t, d)
+        return None, gw, gp, None
+
+
+def embedding(indices: Tensor, weight: Tensor, pos: Optional[Tensor] = None, padding_idx: int = -1) -> Tensor:
+    return EmbeddingFn.apply(indices, weight, pos, padding_idx)
+
+
+class GatherRowsFn(Function):
+    """x[arange(B), index] on the [B, T, D] f32 stream (reference multimodal/clip.py:247-249, EOT pooling)."""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, index: Tensor) -> Tensor:
+        b, t, d = x.shape
+        x2 = x.float().contiguous().view(b * t, d) if x.dtype != f32 else x.contiguous().view(b * t, d)
+        flat = torch.arange(b, device=x.device, dtype=torch.int64) * t + index.reshape(-1)
+        ctx.save_for_backward(flat)
+        ctx.shape = (b, t, d)
+        return ops.embedding_fwd(x2, flat)
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        (flat,) = ctx.saved_tensors
+        b, t, d = ctx.shape
+        dx = torch.zeros((b * t, d), dtype=f32, device=dy.device)
+        ops.embedding_bwd(dy, flat, dx)
+        return dx.view(b, t, d), None
+
+
+def gather_rows(x: Tensor, index: Tensor) -> Tensor:
+    return GatherRowsFn.apply(x, index)
+
+
+class L2NormalizeFn(Function):
+    """cftool.array.l2_normalize (carefree-toolkit, not vendored): x / ||x||_2 over the last dim, no epsilon."""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor) -> Tensor:
+        y, inv = ops.l2norm_fwd(x.float().contiguous())
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        y, inv = ctx.saved_tensors
+        return ops.l2norm_bwd(dy.float().contiguous(), y, inv)
+
+
+def l2_normalize(x: Tensor) -> Tensor:
+    return L2NormalizeFn.apply(x)

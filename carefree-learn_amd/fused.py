@@ -91,7 +91,7 @@ def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: T
 
 
 def _block_fwd(x2: Tensor, prm: tuple, num_heads: int, eps1: float, eps2: float, bsz: int, t: int,
-               keep_mask: Optional[Tensor], causal: bool):
+               keep_mask: Optional[Tensor], causal: bool, quick: bool = False):
     """One pre-norm block on the [B*T, D] residual stream (f32 or bf16).  Returns (y2, saved tensors)."""
     ln1_w, ln1_b, in_w, qkv_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2 = prm
     d = x2.shape[1]
@@ -108,7 +108,7 @@ def _block_fwd(x2: Tensor, prm: tuple, num_heads: int, eps1: float, eps2: float,
     x1 = ops.gemm(o2, out_w16, bias=fb(out_b), epilogue=ops.EPI_RESIDUAL, aux_in=x2, out_dtype=x2.dtype)
     ln2, mean2, rstd2 = ops.layernorm_fwd(x1, ln2_w.detach(), ln2_b.detach(), eps2)
     pre = torch.empty((bsz * t, w1.shape[0]), dtype=bf16, device=x2.device)
-    h = ops.gemm(ln2, w1_16, bias=fb(b1), epilogue=ops.EPI_GELU, aux_out=pre)
+    h = ops.gemm(ln2, w1_16, bias=fb(b1), epilogue=ops.EPI_QGELU if quick else ops.EPI_GELU, aux_out=pre)
     y = ops.gemm(h, w2_16, bias=fb(b2), epilogue=ops.EPI_RESIDUAL, aux_in=x1, out_dtype=x1.dtype)
     saved = (x2, mean1, rstd1, ln1, qkv, o2, lse, x1, mean2, rstd2, ln2, pre, h, in_w16, out_w16, w1_16, w2_16)
     return y, saved
@@ -118,7 +118,7 @@ N_SAVED = 17  # tensors per block in `saved`
 
 
 def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_mask: Optional[Tensor],
-               causal: bool, d2: Tensor) -> Tensor:
+               causal: bool, d2: Tensor, quick: bool = False) -> Tensor:
     """Backward of one block: d2 = dL/dy as bf16 [B*T, D]; returns dL/dx as bf16 [B*T, D]; parameter
     gradients go straight into `.grad` (side streams)."""
     x2, mean1, rstd1, ln1, qkv, o2, lse, x1, mean2, rstd2, ln2, pre, h, in_w16, out_w16, w1_16, w2_16 = saved
@@ -128,7 +128,7 @@ def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_
     # two run concurrently; the dX chain on the main stream is the critical path.
     # channel mixing
     SideStream.run(lambda: _dw_db(w2, b2, d2, h), (d2, h))
-    dpre = ops.gemm(d2, w2_16, b_trans=True, epilogue=ops.EPI_DGELU, aux_in=pre)
+    dpre = ops.gemm(d2, w2_16, b_trans=True, epilogue=ops.EPI_DQGELU if quick else ops.EPI_DGELU, aux_in=pre)
     SideStream.run(lambda: _dw_db(w1, b1, dpre, ln2), (dpre, ln2))
     dln2 = ops.gemm(dpre, w1_16, b_trans=True)
     dx1 = _ln_bwd(dln2, x1, ln2_w, ln2_b, mean2, rstd2, dx_add=d2)
@@ -160,25 +160,25 @@ class MixingBlockFn(Function):
     def forward(ctx: Any, x: Tensor, ln1_w: Tensor, ln1_b: Tensor, in_w: Tensor, qkv_b: Optional[Tensor],
                 out_w: Tensor, out_b: Optional[Tensor], ln2_w: Tensor, ln2_b: Tensor, w1: Tensor,
                 b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], num_heads: int, eps1: float,
-                eps2: float, keep_mask: Optional[Tensor], causal: bool) -> Tensor:
+                eps2: float, keep_mask: Optional[Tensor], causal: bool, quick: bool = False) -> Tensor:
         bsz, t, d = x.shape
         if x.dtype not in (bf16, f32):
             x = x.float()
         x2 = x.contiguous().view(bsz * t, d)  # residual stream: f32 (reference autocast semantics) or bf16
         prm = (ln1_w, ln1_b, in_w, qkv_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2)
-        y, saved = _block_fwd(x2, prm, num_heads, eps1, eps2, bsz, t, keep_mask, causal)
+        y, saved = _block_fwd(x2, prm, num_heads, eps1, eps2, bsz, t, keep_mask, causal, quick)
         ctx.save_for_backward(*saved, keep_mask)
         ctx.params = prm
-        ctx.meta = (bsz, t, d, num_heads, causal)
+        ctx.meta = (bsz, t, d, num_heads, causal, quick)
         return y.view(bsz, t, d)
 
     @staticmethod
     def backward(ctx: Any, dy: Tensor):  # type: ignore
         *saved, keep_mask = ctx.saved_tensors
-        bsz, t, d, num_heads, causal = ctx.meta
+        bsz, t, d, num_heads, causal, quick = ctx.meta
         d2 = _as_bf16_rows(dy, bsz * t, d)
-        dx = _block_bwd(tuple(saved), ctx.params, num_heads, bsz, t, keep_mask, causal, d2)
-        return (dx.view(bsz, t, d),) + (None,) * 17
+        dx = _block_bwd(tuple(saved), ctx.params, num_heads, bsz, t, keep_mask, causal, d2, quick)
+        return (dx.view(bsz, t, d),) + (None,) * 18
 
 
 class MixingStackFn(Function):
@@ -197,8 +197,11 @@ class MixingStackFn(Function):
         nblk = len(metas)
         assert len(params) == 12 * nblk
         all_saved = []
-        for i, (num_heads, eps1, eps2) in enumerate(metas):
-            cur, saved = _block_fwd(cur, params[12 * i:12 * i + 12], num_heads, eps1, eps2, bsz, t, keep_mask, causal)
+        for i, meta in enumerate(metas):
+            num_heads, eps1, eps2 = meta[:3]
+            quick = bool(meta[3]) if len(meta) > 3 else False
+            cur, saved = _block_fwd(cur, params[12 * i:12 * i + 12], num_heads, eps1, eps2, bsz, t, keep_mask, causal,
+                                    quick)
             all_saved.extend(saved)
         ctx.save_for_backward(*all_saved, keep_mask)
         ctx.params = params
@@ -212,7 +215,8 @@ class MixingStackFn(Function):
         d2 = _as_bf16_rows(dy, bsz * t, d)
         for i in range(len(metas) - 1, -1, -1):
             saved = tuple(all_saved[N_SAVED * i:N_SAVED * (i + 1)])
-            d2 = _block_bwd(saved, ctx.params[12 * i:12 * i + 12], metas[i][0], bsz, t, keep_mask, causal, d2)
+            quick = bool(metas[i][3]) if len(metas[i]) > 3 else False
+            d2 = _block_bwd(saved, ctx.params[12 * i:12 * i + 12], metas[i][0], bsz, t, keep_mask, causal, d2, quick)
         return (d2.view(bsz, t, d), None, None, None) + (None,) * len(ctx.params)
 
 
@@ -221,5 +225,5 @@ def mixing_block(x: Tensor, *args: Any) -> Tensor:
 
 
 def mixing_stack(x: Tensor, metas: tuple, keep_mask: Optional[Tensor], causal: bool, params: list) -> Tensor:
-    """`metas[i]` = (num_heads, eps1, eps2) of block i, `params` = its 12 parameters, concatenated."""
+    """`metas[i]` = (num_heads, eps1, eps2[, quick_gelu]) of block i, `params` = its 12 parameters, concatenated."""
     return MixingStackFn.apply(x, metas, keep_mask, causal, *params)

@@ -441,6 +441,8 @@ class _Act(Module):
         self.name = name
 
     def forward(self, net: Tensor) -> Tensor:
+        if self.name == "quick_gelu":
+            raise NotImplementedError("quick GELU exists as a GEMM epilogue only (FeedForward.forward)")
         return HF.gelu(net)
 
 
@@ -452,8 +454,9 @@ class FeedForward(IChannelMixer):
     def __init__(self, in_dim: int, latent_dim: int, dropout: float, activation: str = "GELU",
                  add_last_dropout: bool = True):
         super().__init__(in_dim, latent_dim, dropout)
-        if activation != "GELU":
+        if activation not in ("GELU", "quick_gelu"):
             raise NotImplementedError(f"activation '{activation}' is not on the accelerated hot path yet")
+        self.activation = activation
         blocks: List[Module] = [HijackCustomLinear(in_dim, latent_dim), _Act(activation),
                                 nn.Dropout(dropout), HijackCustomLinear(latent_dim, in_dim)]
         if add_last_dropout:
@@ -467,7 +470,8 @@ class FeedForward(IChannelMixer):
     def forward(self, net: Tensor, *, residual: Optional[Tensor] = None) -> Tensor:
         if self.training and self.dropout > 0.0:
             raise NotImplementedError("dropout > 0 is outside the accelerated hot path")
-        h = self.net[0](net, act=HF.ACT_GELU)  # bias + exact-erf GELU fused in the GEMM epilogue
+        # bias + activation (exact-erf GELU / quick GELU) fused in the GEMM epilogue
+        h = self.net[0](net, act=HF.ACT_GELU if self.activation == "GELU" else HF.ACT_QGELU)
         return self.net[3](h, residual=residual)
 
 
@@ -544,15 +548,23 @@ class MixingBlock(Module):
                 self.channel_norm.bias, ff.net[0].linear.weight, ff.net[0].linear.bias,
                 ff.net[3].linear.weight, ff.net[3].linear.bias]
 
+    def fused_meta(self) -> tuple:
+        return (self.token_mixing.net.num_heads, self.token_norm.eps, self.channel_norm.eps,
+                self.channel_mixing.activation == "quick_gelu")
+
     def forward(self, net: Tensor, hw: Optional[Tuple[int, int]] = None, *, deterministic: bool = False,
-                mask: Optional[Tensor] = None, **kwargs: Any) -> Tensor:
+                mask: Optional[Tensor] = None, causal: bool = False, **kwargs: Any) -> Tensor:
+        """`causal=True` is the kernel-side form of the text tower's `triu(1)` mask (nlp/encoder/transformer.py:
+        44-50): no mask tensor is read."""
         if self.use_fused and not kwargs and net.dim() == 3 and self._fusable():
-            att = self.token_mixing.net
-            keep = None if mask is None else expand_module_mask(mask, att.num_heads)
-            return fused.mixing_block(net, *self.fused_params(), att.num_heads, self.token_norm.eps,
-                                      self.channel_norm.eps, keep, False)
+            keep = None if mask is None else expand_module_mask(mask, self.token_mixing.net.num_heads)
+            return fused.mixing_block(net, *self.fused_params(), *self.fused_meta()[:3], keep, causal,
+                                      self.fused_meta()[3])
         # composed path: same kernels, one autograd node per op
         tkw = dict(hw=hw, deterministic=deterministic, residual=net)
+        if causal and mask is None:
+            t = net.shape[1]
+            mask = torch.ones(t, t, dtype=torch.bool, device=net.device).triu_(1)
         if mask is not None:
             tkw["mask"] = mask
         tkw.update(kwargs)
@@ -577,8 +589,10 @@ class PositionalEncoding(Module):
 
 
 class MixedStackedEncoder(Module):
-    """reference mixed_stacks/api.py:270-458 (head token + learned positional encoding at native
-    resolution + pre-norm blocks + `PreNorm(LN) -> x[:, 0]` head, the ViT configuration)."""
+    """reference mixed_stacks/api.py:270-458: optional head token, learned positional encoding (native
+    resolution), optional embedding norm, pre-norm blocks, head = `x[:, 0]` (head token) or identity, normalised
+    before (`PreNorm`, state keys `head.norms.0.*`) or after (`head_norm.*`) the head.  Poolers other than the
+    head token / identity, aux heads and dropouts are outside the accelerated hot path."""
 
     def __init__(self, in_dim: int, num_tokens: int, *, token_mixing_type: str,
                  token_mixing_config: Optional[Dict[str, Any]] = None, channel_mixing_type: str = "ff",
@@ -594,19 +608,34 @@ class MixedStackedEncoder(Module):
                  positional_encoding_dropout: float = 0.0, no_head_norm: Optional[bool] = None,
                  norm_after_head: bool = False, aux_heads: Optional[List[str]] = None):
         super().__init__()
-        if aux_heads is not None or embedding_norm is not None or embedding_dropout is not None:
-            raise NotImplementedError("aux heads / embedding norm / dropout are outside the hot path")
-        if not use_head_token or not use_positional_encoding or norm_after_head or no_head_norm:
-            raise NotImplementedError("only the head-token + positional-encoding + PreNorm head "
-                                      "configuration (ViT) is on the accelerated hot path")
+        if aux_heads is not None or embedding_dropout is not None:
+            raise NotImplementedError("aux heads / embedding dropout are outside the accelerated hot path")
+        if not use_head_token and head_pooler is not None:
+            raise NotImplementedError(f"head pooler '{head_pooler}' is outside the accelerated hot path "
+                                      "(head token or `head_pooler=None` are built)")
+        if no_head_norm is None:
+            no_head_norm = norm_position == "post_norm"
+        if no_head_norm:
+            raise NotImplementedError("a head without normalisation is outside the accelerated hot path")
         self.aux_heads = None
-        self.head_token = nn.Parameter(torch.zeros(1, 1, in_dim))
-        self.num_heads = 1
-        num_tokens += 1
+        if use_head_token:
+            self.head_token = nn.Parameter(torch.zeros(1, 1, in_dim))
+            num_head_tokens = 1
+        else:
+            self.head_token = None
+            num_head_tokens = 0
+        self.num_heads = num_head_tokens
+        num_tokens += num_head_tokens
+        if is_vision_positional_encoding is None:
+            if use_positional_encoding:
+                raise ValueError("`is_vision_positional_encoding` should be specified when "
+                                 "`use_positional_encoding` is set to True")
+            is_vision_positional_encoding = False
         self.pos_encoding = PositionalEncoding(in_dim, num_tokens, positional_encoding_dropout,
-                                               num_head_tokens=1, is_vision=bool(is_vision_positional_encoding),
-                                               enable=True)
-        self.embedding_norm = None
+                                               num_head_tokens=num_head_tokens,
+                                               is_vision=bool(is_vision_positional_encoding),
+                                               enable=use_positional_encoding)
+        self.embedding_norm = embedding_norm
         self.embedding_dropout = None
         if dpr_list is None:
             dpr_list = [x.item() for x in torch.linspace(0, drop_path_rate, num_layers)]
@@ -622,10 +651,15 @@ class MixedStackedEncoder(Module):
                         residual_after_norm=residual_after_norm)
             for i, dp in enumerate(dpr_list)
         ])
-        self.head_norm = None
-        self.head = PreNorm(in_dim, module=Lambda(lambda x: x[:, 0], name="head_token"),
-                            norm_type=norm_type, norm_kwargs=norm_kwargs)
-        nn.init.trunc_normal_(self.head_token, std=0.02)
+        head: Module = Lambda(lambda x: x[:, 0], name="head_token") if use_head_token else nn.Identity()
+        if norm_after_head:
+            self.head_norm = NormFactory(norm_type).make(in_dim, **(norm_kwargs or {}))
+            self.head = head
+        else:
+            self.head_norm = None
+            self.head = PreNorm(in_dim, module=head, norm_type=norm_type, norm_kwargs=norm_kwargs)
+        if self.head_token is not None:
+            nn.init.trunc_normal_(self.head_token, std=0.02)
         self.apply(self._init_weights)
 
     @staticmethod
@@ -640,25 +674,58 @@ class MixedStackedEncoder(Module):
 
     fuse_stack = True  # all blocks as ONE autograd node when every block can take the fused path
 
+    def _head_ln(self) -> Module:
+        return self.head_norm if self.head_norm is not None else self.head.norms[0]
+
     def post_process(self, net: Tensor) -> Tensor:
-        # LayerNorm is row-wise, so LN(x)[:, 0] == LN(x[:, 0]): normalise token 0 only (1/197 of
-        # the reference's work, identical result) by handing the kernel a strided row view.
-        return self.head.norms[0](net[:, 0])
+        # LayerNorm is row-wise, so LN(x)[:, 0] == LN(x[:, 0]) (PreNorm head) — and with `norm_after_head` the
+        # reference computes LN(x[:, 0]) itself: normalise token 0 only (1/T of the PreNorm work, identical
+        # result) by handing the kernel a strided row view.  Identity head (text tower): every token.
+        if self.head_token is not None:
+            return self._head_ln()(net[:, 0])
+        return self._head_ln()(net)
+
+    def pre_process(self, net: Tensor, *, hwp: Any = None, deterministic: bool = False) -> Tensor:
+        """Generic token input [B, T, D] (reference :419-438).  The ViT / CLIP entry points do NOT come through
+        here: they fuse head token / positional add into their token-assembly kernels."""
+        if self.head_token is not None:
+            net = torch.cat([self.head_token.expand(net.shape[0], -1, -1).to(net.dtype), net], dim=1)
+        if self.pos_encoding.pos_encoding is not None:
+            pos = self.pos_encoding.pos_encoding
+            if pos.shape[1] != net.shape[1]:
+                if self.pos_encoding.is_vision:
+                    raise NotImplementedError("positional-encoding interpolation is outside the accelerated hot path")
+                pos = pos[:, :net.shape[1]]
+            net = net.float() + pos
+        if self.embedding_norm is not None:
+            net = self.embedding_norm(net)
+        return net
 
     def forward_tokens(self, tokens: Tensor, *, hw: Optional[Tuple[int, int]] = None,
-                       deterministic: bool = False) -> Tensor:
+                       deterministic: bool = False, causal: bool = False, mask: Optional[Tensor] = None,
+                       clip_skip: int = 0, apply_head: bool = True) -> Tensor:
+        """`tokens` = the output of pre_process (or of a fused token-assembly kernel + embedding norm)."""
         net = tokens
         blocks = list(self.mixing_blocks)
-        if self.fuse_stack and len(blocks) > 1 and net.dim() == 3 and all(b.use_fused and b._fusable() for b in blocks):
+        if clip_skip > 0:
+            blocks = blocks[:len(blocks) - clip_skip]
+        if (self.fuse_stack and len(blocks) > 1 and net.dim() == 3 and mask is None
+                and all(b.use_fused and b._fusable() for b in blocks)):
             # one autograd node for the whole stack (fused.MixingStackFn)
             metas, params = [], []
             for b in blocks:
-                metas.append((b.token_mixing.net.num_heads, b.token_norm.eps, b.channel_norm.eps))
+                metas.append(b.fused_meta())
                 params.extend(b.fused_params())
-            return self.post_process(fused.mixing_stack(net, tuple(metas), None, False, params))
-        for block in blocks:
-            net = block(net, hw, deterministic=deterministic)
-        return self.post_process(net)
+            net = fused.mixing_stack(net, tuple(metas), None, causal, params)
+        else:
+            for block in blocks:
+                net = block(net, hw, deterministic=deterministic, mask=mask, causal=causal)
+        return self.post_process(net) if apply_head else net
+
+    def forward(self, net: Tensor, *, hw: Optional[Tuple[int, int]] = None, hwp: Any = None,
+                deterministic: bool = False) -> Tensor:
+        return self.forward_tokens(self.pre_process(net, hwp=hwp, deterministic=deterministic), hw=hw,
+                                   deterministic=deterministic)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -916,10 +983,12 @@ class ViTEncoder(Module):
         conv = self.to_patches.projection
         enc = self.encoder
         tokens = HF.patch_tokens(net, conv.weight, conv.bias, enc.head_token, enc.pos_encoding.pos_encoding)
+        if enc.embedding_norm is not None:
+            tokens = enc.embedding_norm(tokens)  # CLIP vision tower: LayerNorm before the blocks (bf16 stream)
         g = self.img_size // self.to_patches.patch_size
         out = enc.forward_tokens(tokens, hw=(g, g), deterministic=deterministic)
         if self.output_projection is not None:
-            out = HF.linear(out, self.output_projection.t(), None)
+            out = HF.linear(out, self.output_projection.t(), None, out_f32=True)
         return out
 
     def encode(self, net: Tensor) -> Tensor:
@@ -960,3 +1029,166 @@ def vit_b16_classifier(num_classes: int = 1000, img_size: int = 224, **encoder_o
     cfg: Dict[str, Any] = dict(patch_size=16, latent_dim=768, num_layers=12)
     cfg.update(encoder_overrides)
     return VanillaClassifier(3, num_classes, img_size, cfg["latent_dim"], encoder="vit", encoder_config=cfg)
+
+
+# ---------------------------------------------------------------------------------------------
+# text transformer / CLIP towers
+# ---------------------------------------------------------------------------------------------
+
+
+@register_module("tet")
+class TeTEncoder(Module):
+    """reference nlp/encoder/transformer.py:17-99 — `encoder` (MixedStackedEncoder without head token, learned
+    positional encoding) and, with `use_triu_attn_mask`, the bool buffer `attention_mask` = triu(1) (True = masked).
+    On the HIP path the causal mask is a kernel flag (`causal=True`), the buffer exists for state_dict parity."""
+
+    def __init__(self, latent_dim: int = 384, context_length: int = 77, *, use_triu_attn_mask: bool = False,
+                 num_layers: int = 12, dropout: float = 0.0, drop_path_rate: float = 0.0,
+                 norm_position: str = "pre_norm", norm_type: Optional[str] = "layer",
+                 norm_kwargs: Optional[Dict[str, Any]] = None, embedding_norm: Optional[Module] = None,
+                 embedding_dropout: Optional[float] = None, residual_after_norm: bool = False,
+                 feedforward_dim_ratio: float = 4.0, attention_kwargs: Optional[Dict[str, Any]] = None,
+                 feedforward_kwargs: Optional[Dict[str, Any]] = None, use_positional_encoding: bool = True,
+                 head_pooler: Optional[str] = None, no_head_norm: Optional[bool] = None,
+                 norm_after_head: bool = False):
+        super().__init__()
+        if not use_triu_attn_mask:
+            self.attention_mask = None
+        else:
+            mask = torch.ones(context_length, context_length, dtype=torch.bool).triu_(1)
+            self.register_buffer("attention_mask", mask)
+        attention_kwargs = dict(attention_kwargs or {})
+        attention_kwargs.setdefault("bias", True)
+        attention_kwargs.setdefault("num_heads", 6)
+        self.encoder = MixedStackedEncoder(
+            latent_dim, context_length, token_mixing_type="attention", token_mixing_config=attention_kwargs,
+            channel_mixing_config=feedforward_kwargs, num_layers=num_layers, dropout=dropout,
+            drop_path_rate=drop_path_rate, norm_position=norm_position, norm_type=norm_type, norm_kwargs=norm_kwargs,
+            embedding_norm=embedding_norm, embedding_dropout=embedding_dropout,
+            residual_after_norm=residual_after_norm, latent_dim_ratio=feedforward_dim_ratio, use_head_token=False,
+            head_pooler=head_pooler, use_positional_encoding=use_positional_encoding,
+            is_vision_positional_encoding=False, no_head_norm=no_head_norm, norm_after_head=norm_after_head,
+        )
+
+    def forward_embedded(self, tokens: Tensor, *, apply_head: bool = True, clip_skip: int = 0) -> Tensor:
+        """`tokens` already carry the positional encoding (fused into the embedding lookup kernel)."""
+        if self.encoder.embedding_norm is not None:
+            tokens = self.encoder.embedding_norm(tokens)
+        return self.encoder.forward_tokens(tokens, causal=self.attention_mask is not None, clip_skip=clip_skip,
+                                           apply_head=apply_head)
+
+    def forward(self, net: Tensor, mask: Optional[Tensor] = None, *, apply_head: bool = True, clip_skip: int = 0,
+                **kwargs: Any) -> Tensor:
+        net = self.encoder.pre_process(net, **kwargs)
+        if mask is None:
+            return self.encoder.forward_tokens(net, causal=self.attention_mask is not None, clip_skip=clip_skip,
+                                               apply_head=apply_head)
+        t = net.shape[1]
+        if t != mask.shape[0]:
+            mask = mask[:t, :t]
+        return self.encoder.forward_tokens(net, mask=mask, clip_skip=clip_skip, apply_head=apply_head)
+
+
+@register_module("clip")
+class CLIP(Module):
+    """reference multimodal/clip.py:22-256 + multimodal/schema.py:10-32 (`IPerceptor`): ViT image tower
+    (patch conv without bias, embedding LayerNorm, quick GELU, LayerNorm after the head token, `output_projection`)
+    and causal text tower (nn.Embedding + learned positions, quick GELU, EOT pooling, `text_projection`), both
+    L2-normalised.  State keys: `logit_scale`, `vit.*`, `token_embedding.weight`, `text_transformer.*`,
+    `text_projection.*`."""
+
+    def __init__(self, img_size: int = 224, latent_dim: int = 512, *, use_vision: bool = True, in_channels: int = 3,
+                 vision_latent_dim: int = 768, vision_patch_size: int = 32, vision_num_heads: int = 12,
+                 vision_num_layers: int = 12, vision_norm_eps: float = 1.0e-5,
+                 vision_feedforward_activation: str = "quick_gelu", use_text: bool = True, vocab_size: int = 49408,
+                 context_length: int = 77, use_text_triu_attn_mask: bool = True,
+                 token_type_size: Optional[int] = None, text_latent_dim: int = 512, text_padding_idx: int = 0,
+                 use_text_embedding_norm: bool = False, text_embedding_dropout: Optional[bool] = None,
+                 text_dropout: float = 0.0, text_num_heads: int = 8, text_num_layers: int = 12,
+                 text_norm_position: str = "pre_norm", text_norm_eps: float = 1.0e-5,
+                 text_feedforward_activation: str = "quick_gelu", text_head_pooler: Optional[str] = None):
+        super().__init__()
+        if token_type_size is not None or text_dropout > 0.0 or text_head_pooler is not None:
+            raise NotImplementedError("token-type embeddings / text dropout / text poolers are outside the hot path")
+        self.img_size, self.context_length = img_size, context_length
+        self.logit_scale = nn.Parameter(torch.tensor(math.log(1 / 0.07)))
+        if not use_vision:
+            self.vit = None
+        else:
+            self.vision_latent_dim = vision_latent_dim
+            self.vit = ViTEncoder(
+                img_size=img_size, patch_size=vision_patch_size, in_channels=in_channels,
+                latent_dim=vision_latent_dim, to_patches_config={"bias": False}, num_layers=vision_num_layers,
+                norm_kwargs={"eps": vision_norm_eps}, embedding_norm=LayerNorm(vision_latent_dim, vision_norm_eps),
+                attention_kwargs={"num_heads": vision_num_heads},
+                feedforward_kwargs={"activation": vision_feedforward_activation}, norm_after_head=True,
+                output_dim=latent_dim,
+            )
+        if not use_text:
+            self.token_embedding = self.token_type_embedding = self.text_transformer = None
+            self.text_latent_dropout = self.text_projection = None
+        else:
+            self.text_num_layers, self.text_latent_dim = text_num_layers, text_latent_dim
+            self.token_embedding = nn.Embedding(vocab_size, text_latent_dim, padding_idx=text_padding_idx)
+            self.token_type_embedding = None
+            self.text_transformer = TeTEncoder(
+                text_latent_dim, context_length, use_triu_attn_mask=use_text_triu_attn_mask,
+                num_layers=text_num_layers, dropout=text_dropout, norm_position=text_norm_position,
+                norm_kwargs={"eps": text_norm_eps},
+                embedding_norm=LayerNorm(text_latent_dim, text_norm_eps) if use_text_embedding_norm else None,
+                embedding_dropout=text_embedding_dropout, attention_kwargs={"num_heads": text_num_heads},
+                feedforward_kwargs={"activation": text_feedforward_activation}, head_pooler=text_head_pooler,
+            )
+            self.text_head_pooler = text_head_pooler
+            self.text_latent_dropout = nn.Dropout(text_dropout)
+            self.text_projection = HijackLinear(text_latent_dim, latent_dim)
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        """reference clip.py:188-207"""
+        if self.token_embedding is None:
+            return
+        nn.init.normal_(self.token_embedding.weight, std=0.02)
+        tld = self.text_latent_dim
+        text_encoder = self.text_transformer.encoder
+        nn.init.normal_(text_encoder.pos_encoding.pos_encoding, std=0.01)
+        proj_std = (tld ** -0.5) * ((2 * self.text_num_layers) ** -0.5)
+        attn_std, fc_std = tld ** -0.5, (2 * tld) ** -0.5
+        for block in text_encoder.mixing_blocks:
+            attn, mlp = block.token_mixing.net, block.channel_mixing.net
+            nn.init.normal_(attn.in_w, std=attn_std)
+            nn.init.normal_(attn.out_linear.weight, std=proj_std)
+            nn.init.normal_(mlp[0].weight, std=fc_std)
+            nn.init.normal_(mlp[3].weight, std=proj_std)
+        nn.init.normal_(self.text_projection.weight, std=tld ** -0.5)
+        nn.init.zeros_(self.text_projection.bias)
+
+    def encode_image(self, image: Tensor) -> Tensor:
+        if self.vit is None:
+            raise ValueError("`vit` is not initialized, please set `use_vision=True` when initializing `CLIP`")
+        return HF.l2_normalize(self.vit(image, deterministic=True))
+
+    def encode_text(self, indices: Tensor, *, apply_pooling: bool = True, deterministic: bool = True,
+                    clip_skip: int = 0) -> Tensor:
+        if self.token_embedding is None:
+            raise ValueError("`token_embedding` is not initialized, please set `use_text=True` when "
+                             "initializing `CLIP`")
+        enc = self.text_transformer.encoder
+        pos = enc.pos_encoding.pos_encoding
+        pad = self.token_embedding.padding_idx
+        # embedding lookup + positional add in one gather kernel -> f32 stream [B, T, D]
+        tokens = HF.embedding(indices, self.token_embedding.weight, pos, -1 if pad is None else pad)
+        if not apply_pooling:
+            return self.text_transformer.forward_embedded(tokens, clip_skip=clip_skip)
+        net = self.text_transformer.forward_embedded(tokens, clip_skip=clip_skip, apply_head=False)
+        # EOT pooling BEFORE the head LayerNorm (row-wise, so LN(x)[b, i] == LN(x[b, i])): B rows instead of B*T
+        pooled = HF.gather_rows(net, indices.argmax(dim=-1))
+        pooled = enc.post_process(pooled)
+        feat = HF.linear(pooled, self.text_projection.weight, self.text_projection.bias, out_f32=True)
+        return HF.l2_normalize(feat)
+
+    def forward(self, image: Tensor, text: Tensor) -> Tensor:
+        """logits_per_image (reference multimodal/schema.py:25-30); the [B, D] x [D, B] product is left to torch"""
+        image_features = self.encode_image(image)
+        text_features = self.encode_text(text)
+        return self.logit_scale.exp() * image_features @ text_features.t()

@@ -11,7 +11,7 @@ from torch import Tensor
 
 from . import _lib
 
-EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU = 0, 1, 2, 3
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_QGELU, EPI_DQGELU = 0, 1, 2, 3, 4, 5
 
 bf16 = torch.bfloat16
 f32 = torch.float32
@@ -386,6 +386,14 @@ def gelu_bwd(dy: Tensor, x: Tensor) -> Tensor:
     return _ew("cfhip_gelu_bwd", dy, x)
 
 
+def quick_gelu_fwd(x: Tensor) -> Tensor:
+    return _ew("cfhip_quick_gelu_fwd", x)
+
+
+def quick_gelu_bwd(dy: Tensor, x: Tensor) -> Tensor:
+    return _ew("cfhip_quick_gelu_bwd", dy, x)
+
+
 def add(a: Tensor, b: Tensor) -> Tensor:
     return _ew("cfhip_add_bf16", a, b)
 
@@ -595,3 +603,62 @@ def avgpool_bwd(dy: Tensor, shape: Tuple[int, ...]) -> Tensor:
     inner = dx.numel() // (b * c)
     _lib.check(_lib.load().cfhip_avgpool_bwd(dy.data_ptr(), dx.data_ptr(), b * c, inner, _stream()), "avgpool_bwd")
     return dx
+
+
+# ---------------------------------------------------------------------------------------------
+# row gather / scatter-add, L2 normalisation (CLIP text tower)
+# ---------------------------------------------------------------------------------------------
+
+
+def embedding_fwd(table: Tensor, indices: Tensor, pos: Optional[Tensor] = None, *, period: int = 0,
+                  out_dtype: torch.dtype = f32) -> Tensor:
+    """out[n] = table[indices[n]] (+ pos[n % period]); table f32 [V, D], indices int64 [...], pos f32 [>= period, D]."""
+    _need(table, f32, "table")
+    if indices.dtype != torch.int64 or not indices.is_cuda:
+        raise TypeError("cfhip embedding_fwd: indices must be int64 on the device")
+    if table.dim() != 2 or not table.is_contiguous():
+        raise ValueError("cfhip embedding_fwd: table must be a contiguous [V, D] matrix")
+    idx = indices.reshape(-1).contiguous()
+    v, d = table.shape
+    if pos is not None:
+        _need(pos, f32, "pos")
+        if not pos.is_contiguous() or pos.shape[-1] != d or pos.numel() < period * d:
+            raise ValueError("cfhip embedding_fwd: pos must be contiguous [>= period, D]")
+    out = torch.empty((idx.numel(), d), dtype=out_dtype, device=table.device)
+    rc = _lib.load().cfhip_embedding_fwd(table.data_ptr(), idx.data_ptr(), _p(pos), out.data_ptr(),
+                                         int(out_dtype == f32), idx.numel(), d, int(period), v, _stream())
+    _lib.check(rc, "embedding_fwd")
+    return out.view(*indices.shape, d)
+
+
+def embedding_bwd(dy: Tensor, indices: Tensor, dtable: Tensor, padding_idx: int = -1) -> None:
+    """dtable[indices[n]] += dy[n] (dtable f32 [V, D], owned / zeroed by the caller)."""
+    _need(dtable, f32, "dtable")
+    if dy.dtype not in (f32, bf16) or not dy.is_cuda:
+        raise TypeError("cfhip embedding_bwd: dy must be f32 / bf16 on the device")
+    v, d = dtable.shape
+    dy2 = dy.reshape(-1, d).contiguous()
+    idx = indices.reshape(-1).contiguous()
+    rc = _lib.load().cfhip_embedding_bwd(dy2.data_ptr(), int(dy2.dtype == f32), idx.data_ptr(), dtable.data_ptr(),
+                                         idx.numel(), d, v, int(padding_idx), _stream())
+    _lib.check(rc, "embedding_bwd")
+
+
+def l2norm_fwd(x: Tensor) -> Tuple[Tensor, Tensor]:
+    _need(x, f32, "x")
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    y = torch.empty_like(x2)
+    inv = torch.empty((x2.shape[0],), dtype=f32, device=x.device)
+    _lib.check(_lib.load().cfhip_l2norm_fwd(x2.data_ptr(), y.data_ptr(), inv.data_ptr(), x2.shape[0], x2.shape[1],
+                                            _stream()), "l2norm_fwd")
+    return y.view(x.shape), inv
+
+
+def l2norm_bwd(dy: Tensor, y: Tensor, inv: Tensor) -> Tensor:
+    _need(dy, f32, "dy")
+    dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+    y2 = y.reshape(-1, y.shape[-1]).contiguous()
+    dx = torch.empty_like(dy2)
+    _lib.check(_lib.load().cfhip_l2norm_bwd(dy2.data_ptr(), y2.data_ptr(), inv.data_ptr(), dx.data_ptr(), dy2.shape[0],
+                                            dy2.shape[1], _stream()), "l2norm_bwd")
+    return dx.view(dy.shape)

@@ -64,6 +64,8 @@ int cfhip_set_option(const char* name, int value);
  *     CFHIP_EPI_GELU        aux_out (bf16 [M,ldc], may be NULL) = acc + bias ; C = gelu_erf(acc + bias)
  *     CFHIP_EPI_RESIDUAL    C = acc + bias + aux_in (bf16 [M,ldc]; f32 when out_dtype == 1)
  *     CFHIP_EPI_DGELU       C = acc * gelu_erf'(aux_in)   (aux_in = saved pre-activation, bf16)
+ *     CFHIP_EPI_QGELU / CFHIP_EPI_DQGELU   the same two with quick GELU x * sigmoid(1.702 x)
+ *                           (activations.py "quick_gelu": the CLIP towers, multimodal/clip.py)
  *   out_dtype: 0 = bf16, 1 = f32.   accumulate != 0 (f32 output only): C += result.
  *   split_k > 1: the K range is cut in `split_k` slices, partial tiles go to `workspace`
  *     (needs split_k*M*N*4 bytes) and a second kernel reduces them (epilogue NONE only).
@@ -75,6 +77,8 @@ int cfhip_set_option(const char* name, int value);
 #define CFHIP_EPI_GELU 1
 #define CFHIP_EPI_RESIDUAL 2
 #define CFHIP_EPI_DGELU 3
+#define CFHIP_EPI_QGELU 4
+#define CFHIP_EPI_DQGELU 5
 
 int cfhip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, const void* aux_in,
                     void* aux_out, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
@@ -167,6 +171,8 @@ int cfhip_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream)
 int cfhip_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 int cfhip_gelu_fwd(const void* x, void* y, int64_t n, void* stream);              /* bf16 */
 int cfhip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
+int cfhip_quick_gelu_fwd(const void* x, void* y, int64_t n, void* stream);        /* x * sigmoid(1.702 x) */
+int cfhip_quick_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
 int cfhip_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
 /* bf16 [R,C] -> bf16 [C,R] */
 int cfhip_transpose_bf16(const void* src, void* dst, int R, int C, int64_t ld_src, int64_t ld_dst,
@@ -232,6 +238,25 @@ int cfhip_leaky_relu_fwd(const void* x, void* y, int64_t n, float slope, void* s
 int cfhip_leaky_relu_bwd(const void* dy, const void* x, void* dx, int64_t n, float slope, void* stream);
 int cfhip_avgpool_fwd(const void* x, void* y, int64_t BC, int inner, void* stream);
 int cfhip_avgpool_bwd(const void* dy, void* dx, int64_t BC, int inner, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------
+ * CLIP text tower index work (multimodal/clip.py:209-256) — gathers are bit-exact
+ *   embedding_fwd: out[n][:] = table[indices[n]][:] (+ pos[n % T][:]) — nn.Embedding lookup fused with
+ *     the learned positional add (mixed_stacks/api.py:209-228); also the EOT pooling
+ *     `net[arange(B), indices.argmax(-1)]` with table = the [B*T, D] stream and indices = b*T + argmax.
+ *     table / pos f32, indices int64, out f32 or bf16, D % 4 == 0.
+ *   embedding_bwd: dtable[indices[n]][:] += dy[n][:] (f32 atomics; caller zeroes / owns dtable;
+ *     rows equal to padding_idx are skipped like nn.Embedding(padding_idx=...)).
+ *   l2norm: y = x / ||x||_2 per f32 row (cftool.array.l2_normalize, no epsilon); inv_norm saved.
+ * ------------------------------------------------------------------------------------------ */
+int cfhip_embedding_fwd(const float* table, const int64_t* indices, const float* pos, void* out,
+                        int out_is_f32, int64_t N, int D, int T, int64_t V, void* stream);
+int cfhip_embedding_bwd(const void* dy, int dy_is_f32, const int64_t* indices, float* dtable, int64_t N,
+                        int D, int64_t V, int64_t padding_idx, void* stream);
+int cfhip_l2norm_fwd(const float* x, float* y, float* inv_norm, int64_t N, int D, void* stream);
+int cfhip_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int64_t N, int D,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,74 @@
+"""CPU restatement (fp32) of the reference's CLIP towers — TEST INFRASTRUCTURE ONLY.
+
+Follows cflearn/modules/multimodal/clip.py:108-256 (tower construction, `encode_image`, `encode_text`),
+modules/nlp/encoder/transformer.py:17-99 (`TeTEncoder`: triu(1) mask, no head token, learned positions),
+modules/cv/encoder/transformer.py:17-100 (`ViTEncoder` with `embedding_norm`, `norm_after_head`,
+`output_projection`) and modules/multimodal/schema.py:25-30 (logits).  `l2_normalize` lives in the un-vendored
+dependency carefree-toolkit (`cftool.array.l2_normalize`, pinned only as >= 0.3.12 in setup.py:45): its published
+definition is x / ||x||_2 over the last axis without epsilon; the reference call sites are clip.py:217,256.
+
+Pinned by oracle/gen_golden.py::gen_clip against the reference CLIP module imported through oracle/refharness.
+"""
+import math
+from typing import Dict
+
+import torch
+from torch import Tensor
+
+import vit_oracle as O
+
+StateDict = Dict[str, Tensor]
+
+
+def _block(x: Tensor, sd: StateDict, prefix: str, num_heads: int, eps: float, causal: bool, activation: str) -> Tensor:
+    """pre-norm MixingBlock (mixed_stacks/api.py:130-158) with the FeedForward activation of the CLIP towers"""
+    n1 = O.layer_norm(x, sd[prefix + "token_norm.weight"], sd[prefix + "token_norm.bias"], eps)
+    mask = None
+    if causal:  # 2-D triu(1) mask, True = masked: broadcast over batch and heads (attentions.py:246-253)
+        t = x.shape[1]
+        mask = torch.ones(t, t, dtype=torch.bool).triu_(1)[None].expand(x.shape[0], -1, -1)
+    x = x + O.self_attention(n1, sd, prefix + "token_mixing.net.", num_heads, mask)
+    n2 = O.layer_norm(x, sd[prefix + "channel_norm.weight"], sd[prefix + "channel_norm.bias"], eps)
+    return x + O.feed_forward(n2, sd, prefix + "channel_mixing.", activation)
+
+
+def encode_image(img: Tensor, sd: StateDict, num_heads: int, num_layers: int, eps: float = 1.0e-5,
+                 activation: str = "quick_gelu") -> Tensor:
+    """CLIP.encode_image (clip.py:209-217): patch conv (no bias) -> [head token | patches] + pos -> embedding
+    LayerNorm -> blocks -> x[:, 0] -> head_norm -> @ output_projection -> L2 normalise"""
+    p = "vit."
+    x = O.patch_embed(img, sd[p + "to_patches.projection.weight"], sd.get(p + "to_patches.projection.bias"))
+    x = torch.cat([sd[p + "encoder.head_token"].expand(x.shape[0], -1, -1), x], dim=1)
+    x = x + sd[p + "encoder.pos_encoding.pos_encoding"]
+    x = O.layer_norm(x, sd[p + "encoder.embedding_norm.weight"], sd[p + "encoder.embedding_norm.bias"], eps)
+    for i in range(num_layers):
+        x = _block(x, sd, f"{p}encoder.mixing_blocks.{i}.", num_heads, eps, False, activation)
+    x = O.layer_norm(x[:, 0], sd[p + "encoder.head_norm.weight"], sd[p + "encoder.head_norm.bias"], eps)
+    x = x @ sd[p + "output_projection"]
+    return x / x.norm(dim=-1, keepdim=True)
+
+
+def encode_text(indices: Tensor, sd: StateDict, num_heads: int, num_layers: int, eps: float = 1.0e-5,
+                activation: str = "quick_gelu") -> Tensor:
+    """CLIP.encode_text (clip.py:219-256): token embedding -> + pos[:, :T] -> causal blocks -> LayerNorm (PreNorm
+    head over every token) -> row argmax(indices) (EOT) -> text_projection -> L2 normalise.  Integer index
+    gathers: exact."""
+    p = "text_transformer.encoder."
+    t = indices.shape[1]
+    x = sd["token_embedding.weight"][indices]
+    x = x + sd[p + "pos_encoding.pos_encoding"][:, :t]
+    for i in range(num_layers):
+        x = _block(x, sd, f"{p}mixing_blocks.{i}.", num_heads, eps, True, activation)
+    x = O.layer_norm(x, sd[p + "head.norms.0.weight"], sd[p + "head.norms.0.bias"], eps)
+    x = x[torch.arange(x.shape[0]), indices.argmax(dim=-1)]
+    x = x @ sd["text_projection.weight"].t() + sd["text_projection.bias"]
+    return x / x.norm(dim=-1, keepdim=True)
+
+
+def logits_per_image(img: Tensor, indices: Tensor, sd: StateDict, vision_heads: int, vision_layers: int,
+                     text_heads: int, text_layers: int) -> Tensor:
+    """IPerceptor.forward (multimodal/schema.py:25-30)"""
+    fi = encode_image(img, sd, vision_heads, vision_layers)
+    ft = encode_text(indices, sd, text_heads, text_layers)
+    return math.exp(sd["logit_scale"].item()) * fi @ ft.t() if not sd["logit_scale"].requires_grad else \
+        sd["logit_scale"].exp() * fi @ ft.t()

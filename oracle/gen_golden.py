@@ -20,6 +20,7 @@ sys.path.insert(0, HERE)
 
 import vit_oracle as O  # noqa: E402
 import conv_oracle as CO  # noqa: E402
+import clip_oracle as CL  # noqa: E402
 from refharness import load_reference  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
@@ -278,13 +279,49 @@ def gen_fcnn(ref) -> None:
                os.path.join(OUT, "fcnn.pt"))
 
 
+def gen_clip(ref) -> None:
+    """CLIP towers (multimodal/clip.py) at a small size with head_dim 64: image / text features, logits and every
+    parameter gradient of a symmetric contrastive objective on the logits (the loss itself is not part of the
+    reference — SURVEY F3 — it only gives the backward pass something to differentiate)."""
+    import importlib
+
+    clip = importlib.import_module("cflearn.modules.multimodal.clip")
+    torch.manual_seed(80)
+    cfg = dict(img_size=32, latent_dim=64, vision_latent_dim=128, vision_patch_size=8, vision_num_heads=2,
+               vision_num_layers=2, vocab_size=100, context_length=16, text_latent_dim=128, text_num_heads=2,
+               text_num_layers=2)
+    m = clip.CLIP(**cfg)
+    with torch.no_grad():  # biases / norm affine params away from their trivial init
+        for n_, p_ in m.named_parameters():
+            if p_.dim() == 1:
+                p_.add_(torch.randn_like(p_) * 0.05)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    img = torch.randn(4, 3, 32, 32)
+    txt = torch.randint(1, 100, (4, 16))
+    txt[0, 9:] = 0  # ragged captions: padding id 0 after the (largest-id) end token
+    txt[2, 5:] = 0
+    fi = m.encode_image(img)
+    ft = m.encode_text(txt)
+    logits = m(img, txt)
+    _check("clip image features", CL.encode_image(img, sd, 2, 2), fi.detach())
+    _check("clip text features", CL.encode_text(txt, sd, 2, 2), ft.detach())
+    _check("clip logits", CL.logits_per_image(img, txt, sd, 2, 2, 2, 2), logits.detach(), atol=5e-5)
+    target = torch.arange(4)
+    loss = 0.5 * (torch.nn.functional.cross_entropy(logits, target) + torch.nn.functional.cross_entropy(logits.t(), target))
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    torch.save(dict(cfg=cfg, sd=sd, img=img, txt=txt, image_features=fi.detach(), text_features=ft.detach(),
+                    logits=logits.detach(), loss=loss.detach(), grads=grads),
+               os.path.join(OUT, "clip_small.pt"))
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
     torch.set_num_threads(4)
     only = sys.argv[1:]
     for fn in (gen_linear, gen_layernorm, gen_sdp, gen_attention, gen_feedforward, gen_vit, gen_conv2d,
-               gen_batchnorm, gen_mnist_clf, gen_fcnn):
+               gen_batchnorm, gen_mnist_clf, gen_fcnn, gen_clip):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

@@ -24,6 +24,7 @@ _SHELLS = [
     "cflearn.modules.cv.classifier",
     "cflearn.modules.ml",
     "cflearn.modules.nlp",
+    "cflearn.modules.nlp.encoder",
     "cflearn.modules.multimodal",
     "cflearn.modules.multimodal.diffusion",
 ]
@@ -46,8 +47,19 @@ def load_reference() -> types.SimpleNamespace:
     if "cftool" not in sys.modules:
         sys.path.insert(0, here)
         importlib.import_module("cftool")
-        for sub in ("misc", "array", "types", "pipeline"):
+        for sub in ("misc", "array", "types", "pipeline", "cv"):
             importlib.import_module(f"cftool.{sub}")
+    if "torchvision" not in sys.modules:
+        # torchvision is not installed; the reference CLIP module imports transform class names at module
+        # level (used only by `get_transform`, which the oracle never calls)
+        tv = types.ModuleType("torchvision")
+        tvt = types.ModuleType("torchvision.transforms")
+        for name in ("Resize", "Compose", "ToTensor", "Normalize", "CenterCrop"):
+            setattr(tvt, name, type(name, (), {"__init__": lambda self, *a, **k: None}))
+        tvt.InterpolationMode = types.SimpleNamespace(BICUBIC="bicubic")
+        tv.transforms = tvt
+        sys.modules["torchvision"] = tv
+        sys.modules["torchvision.transforms"] = tvt
     for name in _SHELLS:
         if name in sys.modules:
             continue
@@ -74,6 +86,8 @@ def load_reference() -> types.SimpleNamespace:
             setattr(modules_shell, k, getattr(cv_common, k))
     vit = importlib.import_module("cflearn.modules.cv.encoder.transformer")
     fcnn = importlib.import_module("cflearn.modules.ml.fcnn")
+    # names the reference's package __init__ files would have re-exported (the shells skip them)
+    setattr(sys.modules["cflearn.modules.cv.encoder"], "ViTEncoder", vit.ViTEncoder)
 
     _loaded = types.SimpleNamespace(
         common=common,

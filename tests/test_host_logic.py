@@ -146,3 +146,13 @@ def test_conv_classifier_and_fcnn_state_dict_keys_match_reference(golden):
     assert all(n.state_dict()[k].shape == f["sd"][k].shape for k in f["sd"])
     n.load_state_dict(f["sd"])
     assert n.hidden_units == [192, 192]
+
+
+def test_clip_state_dict_keys_match_reference(golden):
+    g = golden("clip_small.pt")
+    m = C.build_module("clip", config=dict(g["cfg"]))
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["sd"].keys())
+    assert all(sd[k].shape == g["sd"][k].shape and sd[k].dtype == g["sd"][k].dtype for k in sd)
+    assert torch.equal(sd["text_transformer.attention_mask"], g["sd"]["text_transformer.attention_mask"])
+    m.load_state_dict(g["sd"])

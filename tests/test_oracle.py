@@ -180,3 +180,31 @@ def test_fcnn_oracle(golden):
     O.focal_loss(logits, g["labels"]).backward()
     for k, ref in g["grads"].items():
         assert (lv[k].grad - ref).abs().max() <= max(1e-6, 1e-4 * ref.abs().max()), k  # (conv bias under BN: true gradient is 0)
+
+
+def test_clip_towers_oracle(golden):
+    """oracle/clip_oracle.py (image tower, causal text tower, EOT pooling, L2 normalisation, logits) vs the
+    reference CLIP module's frozen outputs, forward and (through autograd of the restatement) every gradient."""
+    import clip_oracle as CL
+
+    g = golden("clip_small.pt")
+    params = {k: v for k, v in g["sd"].items() if k in g["grads"]}
+    buffers = {k: v for k, v in g["sd"].items() if k not in params}
+    lv = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    sd = {**buffers, **lv}
+    fi = CL.encode_image(g["img"], sd, 2, 2)
+    ft = CL.encode_text(g["txt"], sd, 2, 2)
+    assert (fi - g["image_features"]).abs().max() < 2e-6 and (ft - g["text_features"]).abs().max() < 2e-6
+    logits = sd["logit_scale"].exp() * fi @ ft.t()
+    assert (logits - g["logits"]).abs().max() < 5e-5
+    target = torch.arange(4)
+    loss = 0.5 * (torch.nn.functional.cross_entropy(logits, target) + torch.nn.functional.cross_entropy(logits.t(), target))
+    assert abs(loss.item() - g["loss"].item()) < 1e-5
+    loss.backward()
+    for k, ref in g["grads"].items():
+        got = lv[k].grad.clone()
+        if k == "token_embedding.weight":
+            # nn.Embedding(padding_idx=0) gives the padding row a zero gradient; the restatement indexes the table
+            # directly, so mask that row the same way before comparing
+            got[0] = 0
+        assert (got - ref).abs().max() <= max(2e-6, 2e-4 * ref.abs().max()), k
