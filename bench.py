@@ -58,7 +58,7 @@ def time_gemms(batch: int, reps: int):
 
     dev = torch.device("cuda", torch.cuda.current_device())
     rows = []
-    tot_flops = tot_time = 0.0
+    tot_flops = tot_time = tot_bytes = 0.0
     for count, layout, m, n, k, epi in gemm_shapes(batch):
         bf = torch.bfloat16
         g = torch.Generator(device=dev).manual_seed(m + n + k)
@@ -71,13 +71,19 @@ def time_gemms(batch: int, reps: int):
             a, b, kw = rnd(k, m), rnd(k, n), dict(a_trans=True, b_trans=True, out_dtype=torch.float32,
                                                   split_k=ops.pick_split_k(m, n, k))
         bias = torch.zeros(n, device=dev) if epi in ("bias", "residual", "gelu") else None
-        aux = rnd(m, n) if epi in ("residual", "dgelu") else None
+        # algorithmic HBM bytes of one launch: both operands once, the output once, epilogue operands once
+        nbytes = 2.0 * (m * k + n * k) + 2.0 * m * n
         if epi == "gelu":
             kw.update(epilogue=ops.EPI_GELU, aux_out=torch.empty(m, n, dtype=bf, device=dev))
-        elif epi == "residual":
-            kw.update(epilogue=ops.EPI_RESIDUAL, aux_in=aux)
+            nbytes += 2.0 * m * n  # the saved pre-activation
+        elif epi == "residual":  # f32 residual stream in and out, as in the model
+            kw.update(epilogue=ops.EPI_RESIDUAL, aux_in=torch.randn(m, n, generator=g, device=dev), out_dtype=torch.float32)
+            nbytes += 2.0 * m * n + 4.0 * m * n
         elif epi == "dgelu":
-            kw.update(epilogue=ops.EPI_DGELU, aux_in=aux)
+            kw.update(epilogue=ops.EPI_DGELU, aux_in=rnd(m, n))
+            nbytes += 2.0 * m * n
+        if layout == "tn":
+            nbytes += 2.0 * m * n  # f32 gradient output
         out = torch.empty(m, n, dtype=kw.pop("out_dtype", bf), device=dev)
         for _ in range(2):
             ops.gemm(a, b, bias=bias, out=out, **kw)
@@ -90,10 +96,23 @@ def time_gemms(batch: int, reps: int):
         dur = e0.elapsed_time(e1) * 1e-3 / reps
         flops = 2.0 * m * n * k
         rows.append(dict(layout=layout, M=m, N=n, K=k, epilogue=epi, count=count, us=round(dur * 1e6, 1),
-                         tflops=round(flops / dur / 1e12, 1)))
+                         tflops=round(flops / dur / 1e12, 1), algorithmic_mb=round(nbytes / 1e6, 1)))
         tot_flops += count * flops
         tot_time += count * dur
-    return tot_flops, tot_time, rows
+        tot_bytes += count * nbytes
+    return tot_flops, tot_time, rows, tot_bytes
+
+
+def pmc_traffic(batch: int):
+    """HBM bytes per step of the GEMM family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE over this script, tools/pmc_step_summary.py), or None when no pass exists for this batch."""
+    path = os.path.join(ROOT, "profiles", "r01", f"pmc_step_b{batch}.json")
+    if not os.path.isfile(path):
+        return None, None, None
+    with open(path) as f:
+        doc = json.load(f)
+    fam = doc["families"].get("gemm")
+    return (fam["total"] if fam else None, os.path.relpath(path, ROOT), doc.get("all_kernels", {}).get("total"))
 
 
 def cpu_baseline(batch: int, steps: int):
@@ -160,6 +179,10 @@ def main() -> None:
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for the "
                                                       "single-GPU dry run of the N > 1 code path)")
     ap.add_argument("--all-on-gpu0", action="store_true", help="dry run: every rank uses cuda:0")
+    ap.add_argument("--input", default="device", choices=["device", "host"],
+                    help="device (default, the headline number): the batch is resident in HBM.  host: every step "
+                         "pulls a fresh host batch through cflearn_amd.data.TensorBatcher (copy stream, one batch "
+                         "ahead) — the PCIe-inclusive rate, reported in DESIGN.md only")
     args = ap.parse_args()
     if args.watchdog > 0:
         import faulthandler
@@ -199,10 +222,34 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    note(f"model + arena ready on {dev}, launch={'graph' if ts.use_graph else 'eager'}")
+    feed = None
+    if args.input == "host":
+        import itertools
+
+        from cflearn_amd.data import TensorBatcher
+
+        host = [dict(input=torch.randn(args.batch, 3, 224, 224, generator=g).numpy(),
+                     labels=torch.randint(0, 1000, (args.batch,), generator=g).numpy()) for _ in range(4)]
+
+        class _Endless:
+            def __len__(self):
+                return 1 << 30
+
+            def __iter__(self):
+                return itertools.cycle(host)
+
+        feed = iter(TensorBatcher(_Endless(), dev, depth=1))
+
+    def next_batch():
+        if feed is None:
+            return img, labels
+        b = next(feed)
+        return b["input"], b["labels"]
+
+    note(f"model + arena ready on {dev}, launch={'graph' if ts.use_graph else 'eager'}, input={args.input}")
     first_loss = None
     for i in range(args.warmup):
-        loss = ts.step(img, labels)
+        loss = ts.step(*next_batch())
         if i == 0:
             first_loss = loss.item() / args.batch
             note(f"first step done, loss {first_loss:.4f}")
@@ -210,7 +257,7 @@ def main() -> None:
     note("warm-up done, timing")
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = ts.step(img, labels)
+        loss = ts.step(*next_batch())
     sync()
     dt = time.perf_counter() - t0
     if distributed:
@@ -242,6 +289,7 @@ def main() -> None:
             "seq_len": 197,
             "parallelism": f"dp{world}",
             "launch": "hipGraph replay" if ts.use_graph else "eager",
+            "input": "resident in HBM" if feed is None else "host numpy -> TensorBatcher (copy stream, 1 batch ahead, device buffer ring)",
             "grad_exchange": "none" if not distributed else f"bucketed RCCL all-reduce fp32, {args.bucket_mb} MB buckets, side stream",
             "loss_first_step": None if first_loss is None else round(first_loss, 4),
             "loss_last_step": round(last_loss, 4),
@@ -249,16 +297,24 @@ def main() -> None:
         "mfma_frac_whole_step": round(samples_per_s * FLOP_PER_SAMPLE / world / (PEAK_BF16_TFLOPS * 1e12), 4),
     }
     if rank == 0 and not args.no_roofline:
-        flops, tsec, rows = time_gemms(args.batch, args.gemm_reps)
+        flops, tsec, rows, algo_bytes = time_gemms(args.batch, args.gemm_reps)
+        traffic, traffic_src, step_bytes = pmc_traffic(args.batch)
         achieved = flops / tsec / 1e12
         note(f"GEMM roofline pass: {achieved:.1f} TFLOP/s over {tsec * 1e3:.2f} ms of GEMM per step")
         result["roofline"] = {
             "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "HBM-side bytes per step over all GEMM launches (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+            "traffic_source": traffic_src, "algorithmic_bytes": round(algo_bytes),
             "kernel": "gemm_bf16_kernel<AT,BT,EPI> (all GEMM launches of one step, weighted by count)",
             "gemm_ms_per_step": round(tsec * 1e3, 3),
             "shapes": rows,
         }
+        if step_bytes:
+            # whole-step HBM-side bytes (every kernel, PMC passes) over the measured step time
+            gbps = step_bytes / (dt / args.steps) / 1e9
+            result["hbm"] = {"bytes_per_step": step_bytes, "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
+                             "frac": round(gbps / 8000.0, 4), "source": traffic_src}
     if distributed:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,39 @@
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py` into HBM bytes per step and per kernel
+family.  FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide
+coalesced reads, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as is.
+
+    python tools/pmc_step_summary.py <fetch_counter_csv> <write_counter_csv> <steps> > profiles/rNN/pmc_step.json
+"""
+import csv, json, sys
+
+
+def family(name: str) -> str:
+    for key, fam in (("gemm_bf16", "gemm"), ("splitk_reduce", "gemm"), ("attn_", "attention"), ("layernorm", "layernorm"),
+                     ("colsum", "colsum"), ("colreduce", "colsum"), ("adam", "adam")):
+        if key in name:
+            return fam
+    return "other"
+
+
+def load(path: str, counter: str):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") != counter:
+            continue
+        fam = family(r.get("Kernel_Name", ""))
+        out[fam] = out.get(fam, 0.0) + float(r["Counter_Value"])
+    return out
+
+
+fetch, write, steps = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE"), float(sys.argv[3])
+res = {"steps_profiled": steps, "unit": "bytes per step", "fetch_correction": "x2 (gfx950 wide-read calibration)",
+       "families": {}}
+tot_r = tot_w = 0.0
+for fam in sorted(set(fetch) | set(write)):
+    r = fetch.get(fam, 0.0) * 1024.0 * 2.0 / steps
+    w = write.get(fam, 0.0) * 1024.0 / steps
+    res["families"][fam] = {"read": round(r), "written": round(w), "total": round(r + w)}
+    tot_r += r
+    tot_w += w
+res["all_kernels"] = {"read": round(tot_r), "written": round(tot_w), "total": round(tot_r + tot_w)}
+print(json.dumps(res, indent=1))
