@@ -76,6 +76,16 @@ SIGNATURES = {
     "cfhip_leaky_relu_bwd": (c_int, [_P, _P, _P, c_int64, c_float, _P]),
     "cfhip_avgpool_fwd": (c_int, [_P, _P, c_int64, c_int, _P]),
     "cfhip_avgpool_bwd": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "cfhip_groupnorm_fwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    "cfhip_groupnorm_bwd": (c_int, [_P, _P, c_int] + [_P] * 9 + [c_int] * 5 + [_P]),
+    "cfhip_silu_f32_fwd": (c_int, [_P, _P, c_int64, _P]),
+    "cfhip_silu_f32_bwd": (c_int, [_P, _P, _P, c_int64, _P]),
+    "cfhip_upsample2_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    "cfhip_upsample2_bwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    "cfhip_avgpool2_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    "cfhip_avgpool2_bwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    "cfhip_timestep_embedding": (c_int, [_P, _P, c_int, c_int, c_float, _P]),
+    "cfhip_colreduce_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "cfhip_quick_gelu_fwd": (c_int, [_P, _P, c_int64, _P]),
     "cfhip_quick_gelu_bwd": (c_int, [_P, _P, _P, c_int64, _P]),
     "cfhip_embedding_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64, _P]),

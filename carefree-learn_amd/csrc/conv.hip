@@ -284,6 +284,188 @@ __global__ void softmax_focal_kernel(const float* __restrict__ logits, const int
   }
 }
 
+// ---- GroupNorm (+ per-(b,c) additive term in front, + SiLU behind) -----------------------------------------
+// UNet residual blocks (convs/residual.py:154-253): net = conv1(..) + Linear(SiLU(t))[:, :, None, None];
+// net = SiLU(GroupNorm32(net)).  One workgroup per (b, group): the group's Cg * inner elements are reduced in two
+// passes (mean, then centred variance), statistics in fp32.  x' = x + add[b][c] is what gets normalised.
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
+__device__ __forceinline__ float silu_grad_f(float v) {
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+  return s * fmaf(v, 1.0f - s, 1.0f);
+}
+
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void gn_fwd_kernel(const void* __restrict__ x, const float* __restrict__ add,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     bf16_t* __restrict__ y, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, int C, int G, int inner, float eps,
+                                                     int silu) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int cg = C / G;
+  const long base = ((long)b * C + (long)g * cg) * inner;
+  const long n = (long)cg * inner;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const int c = (int)(i / inner);
+    s += ld_act(x, base + i, IN_F32) + (add != nullptr ? add[(long)b * C + g * cg + c] : 0.f);
+  }
+  const float mean = block_sum(s, red) / (float)n;
+  float q = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const int c = (int)(i / inner);
+    const float d = ld_act(x, base + i, IN_F32) + (add != nullptr ? add[(long)b * C + g * cg + c] : 0.f) - mean;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(block_sum(q, red) / (float)n + eps);
+  if (threadIdx.x == 0) {
+    mean_out[blockIdx.x] = mean;
+    rstd_out[blockIdx.x] = rstd;
+  }
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const int c = g * cg + (int)(i / inner);
+    const float v = ld_act(x, base + i, IN_F32) + (add != nullptr ? add[(long)b * C + c] : 0.f);
+    float o = (v - mean) * rstd * gamma[c] + beta[c];
+    if (silu) o = silu_f(o);
+    y[base + i] = f32_to_bf16(o);
+  }
+}
+
+// dx (bf16), partial dgamma / dbeta per (b, group) block [B][C] (reduced over b by the caller's column reduce),
+// dadd[b][c] = sum_inner dx (when the forward had an additive term)
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void gn_bwd_kernel(const bf16_t* __restrict__ dy, const void* __restrict__ x,
+                                                     const float* __restrict__ add, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, bf16_t* __restrict__ dx,
+                                                     float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
+                                                     float* __restrict__ dadd, int C, int G, int inner, int silu) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int cg = C / G;
+  const long base = ((long)b * C + (long)g * cg) * inner;
+  const long n = (long)cg * inner;
+  const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
+  // pass 1: per-channel dgamma / dbeta partials and the two group sums
+  float s1 = 0.f, s2 = 0.f;  // sum(dn * gamma), sum(dn * gamma * xhat)
+  for (int cl = 0; cl < cg; ++cl) {
+    const int c = g * cg + cl;
+    const float ad = add != nullptr ? add[(long)b * C + c] : 0.f;
+    const float ga = gamma[c], be = beta[c];
+    float sg = 0.f, sb = 0.f;
+    for (int j = threadIdx.x; j < inner; j += blockDim.x) {
+      const long o = base + (long)cl * inner + j;
+      const float xh = (ld_act(x, o, IN_F32) + ad - mu) * rs;
+      float dn = bf16_to_f32(dy[o]);
+      if (silu) dn *= silu_grad_f(xh * ga + be);
+      sg += dn * xh;
+      sb += dn;
+    }
+    sg = block_sum(sg, red);
+    sb = block_sum(sb, red);
+    if (threadIdx.x == 0) {
+      dgamma_part[(long)b * C + c] = sg;
+      dbeta_part[(long)b * C + c] = sb;
+    }
+    s1 += sb * ga;
+    s2 += sg * ga;
+  }
+  const float inv_n = 1.f / (float)n;
+  // pass 2: dx = rstd * (dn*gamma - s1/n - xhat * s2/n)
+  for (int cl = 0; cl < cg; ++cl) {
+    const int c = g * cg + cl;
+    const float ad = add != nullptr ? add[(long)b * C + c] : 0.f;
+    const float ga = gamma[c], be = beta[c];
+    float sd = 0.f;
+    for (int j = threadIdx.x; j < inner; j += blockDim.x) {
+      const long o = base + (long)cl * inner + j;
+      const float xh = (ld_act(x, o, IN_F32) + ad - mu) * rs;
+      float dn = bf16_to_f32(dy[o]);
+      if (silu) dn *= silu_grad_f(xh * ga + be);
+      const float d = rs * (dn * ga - s1 * inv_n - xh * s2 * inv_n);
+      dx[o] = f32_to_bf16(d);
+      sd += d;
+    }
+    if (dadd != nullptr) {
+      sd = block_sum(sd, red);
+      if (threadIdx.x == 0) dadd[(long)b * C + c] = sd;
+    }
+  }
+}
+
+// ---- SiLU on small f32 vectors (the time embedding), nearest x2 up-sampling, 2x2 average pooling ------------------
+template <bool BWD>
+__global__ void silu_f32_kernel(const float* __restrict__ a, const float* __restrict__ x, float* __restrict__ out, long n) {
+  const long step = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += step)
+    out[i] = BWD ? a[i] * silu_grad_f(x[i]) : silu_f(a[i]);
+}
+
+// fwd: y[b,c,2h+dy,2w+dx] = x[b,c,h,w]; bwd: dx[b,c,h,w] = sum of the 4 dy
+template <bool BWD>
+__global__ void upsample2_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, long BC, int H, int W) {
+  const long total = BWD ? BC * H * W : BC * 4L * H * W;
+  const long step = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += step) {
+    if (!BWD) {
+      const int ox = (int)(i % (2 * W));
+      const long t = i / (2 * W);
+      const int oy = (int)(t % (2 * H));
+      const long bc = t / (2 * H);
+      dst[i] = src[(bc * H + oy / 2) * W + ox / 2];
+    } else {
+      const int xw = (int)(i % W);
+      const long t = i / W;
+      const int yh = (int)(t % H);
+      const long bc = t / H;
+      const bf16_t* p = src + (bc * 2 * H + 2 * yh) * 2 * W + 2 * xw;
+      dst[i] = f32_to_bf16((bf16_to_f32(p[0]) + bf16_to_f32(p[1])) + (bf16_to_f32(p[2 * W]) + bf16_to_f32(p[2 * W + 1])));
+    }
+  }
+}
+// fwd: y[b,c,h,w] = mean of the 2x2 window (H, W = OUTPUT size); bwd: dx[.., 2h+dy, 2w+dx] = dy[.., h, w] / 4
+template <bool BWD>
+__global__ void avgpool2_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, long BC, int H, int W) {
+  const long total = BWD ? BC * 4L * H * W : BC * H * W;
+  const long step = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += step) {
+    if (!BWD) {
+      const int xw = (int)(i % W);
+      const long t = i / W;
+      const int yh = (int)(t % H);
+      const long bc = t / H;
+      const bf16_t* p = src + (bc * 2 * H + 2 * yh) * 2 * W + 2 * xw;
+      dst[i] = f32_to_bf16(0.25f * ((bf16_to_f32(p[0]) + bf16_to_f32(p[1])) + (bf16_to_f32(p[2 * W]) + bf16_to_f32(p[2 * W + 1]))));
+    } else {
+      const int ox = (int)(i % (2 * W));
+      const long t = i / (2 * W);
+      const int oy = (int)(t % (2 * H));
+      const long bc = t / (2 * H);
+      dst[i] = f32_to_bf16(0.25f * bf16_to_f32(src[(bc * H + oy / 2) * W + ox / 2]));
+    }
+  }
+}
+
+// timestep embedding (multimodal/diffusion/unet.py:52-74): freq_i = exp(-ln(max_period) * i / half);
+// out[b] = [cos(t_b * freq) | sin(t_b * freq) | 0 if dim is odd], computed in fp32
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int B, int dim,
+                                          float max_period) {
+  const int half = dim / 2;
+  const long total = (long)B * dim;
+  const long step = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += step) {
+    const int b = (int)(i / dim), j = (int)(i - (long)b * dim);
+    float v = 0.f;
+    if (j < 2 * half) {
+      const int k = j < half ? j : j - half;
+      const float freq = expf(-logf(max_period) * (float)k / (float)half);
+      const float arg = (float)t[b] * freq;
+      v = j < half ? cosf(arg) : sinf(arg);
+    }
+    out[i] = v;
+  }
+}
+
 int check_geom(const char* who, const ConvGeom& g) {
   CFHIP_REQUIRE(g.B > 0 && g.C > 0 && g.H > 0 && g.W > 0 && g.kh > 0 && g.kw > 0 && g.stride > 0 && g.dil > 0 &&
                     g.pad >= 0,
@@ -425,5 +607,87 @@ extern "C" int cfhip_softmax_focal(const float* logits, const int64_t* labels, f
   hipLaunchKernelGGL(softmax_focal_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, labels,
                      loss_sum, dlogits, B, C, gamma, eps, grad_scale);
   CFHIP_CHECK_LAUNCH("softmax_focal");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_groupnorm_fwd(const void* x, int x_is_f32, const float* add, const float* gamma, const float* beta,
+                                   void* y, float* mean, float* rstd, int B, int C, int G, int inner, float eps,
+                                   int silu, void* stream) {
+  CFHIP_REQUIRE(x && gamma && beta && y && mean && rstd && B > 0 && C > 0 && G > 0 && inner > 0, "groupnorm_fwd: bad arguments");
+  CFHIP_REQUIRE(C % G == 0, "groupnorm_fwd: %d channels do not split into %d groups", C, G);
+  if (x_is_f32)
+    hipLaunchKernelGGL((gn_fwd_kernel<true>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, add, gamma, beta,
+                       (bf16_t*)y, mean, rstd, C, G, inner, eps, silu);
+  else
+    hipLaunchKernelGGL((gn_fwd_kernel<false>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, add, gamma, beta,
+                       (bf16_t*)y, mean, rstd, C, G, inner, eps, silu);
+  CFHIP_CHECK_LAUNCH("groupnorm_fwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_groupnorm_bwd(const void* dy, const void* x, int x_is_f32, const float* add, const float* gamma,
+                                   const float* beta, const float* mean, const float* rstd, void* dx,
+                                   float* dgamma_part, float* dbeta_part, float* dadd, int B, int C, int G, int inner,
+                                   int silu, void* stream) {
+  CFHIP_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma_part && dbeta_part, "groupnorm_bwd: null pointer");
+  CFHIP_REQUIRE(B > 0 && C > 0 && G > 0 && inner > 0 && C % G == 0, "groupnorm_bwd: bad geometry");
+  CFHIP_REQUIRE((add == nullptr) == (dadd == nullptr) || dadd == nullptr, "groupnorm_bwd: dadd without add");
+  if (x_is_f32)
+    hipLaunchKernelGGL((gn_bwd_kernel<true>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, add,
+                       gamma, beta, mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu);
+  else
+    hipLaunchKernelGGL((gn_bwd_kernel<false>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x,
+                       add, gamma, beta, mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu);
+  CFHIP_CHECK_LAUNCH("groupnorm_bwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_silu_f32_fwd(const float* x, float* y, int64_t n, void* stream) {
+  CFHIP_REQUIRE(x && y && n > 0, "silu_f32_fwd: bad arguments");
+  hipLaunchKernelGGL((silu_f32_kernel<false>), dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, x, y, (long)n);
+  CFHIP_CHECK_LAUNCH("silu_f32_fwd");
+  return CFHIP_OK;
+}
+extern "C" int cfhip_silu_f32_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream) {
+  CFHIP_REQUIRE(dy && x && dx && n > 0, "silu_f32_bwd: bad arguments");
+  hipLaunchKernelGGL((silu_f32_kernel<true>), dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, (long)n);
+  CFHIP_CHECK_LAUNCH("silu_f32_bwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_upsample2_fwd(const void* x, void* y, int64_t BC, int H, int W, void* stream) {
+  CFHIP_REQUIRE(x && y && BC > 0 && H > 0 && W > 0, "upsample2_fwd: bad arguments");
+  hipLaunchKernelGGL((upsample2_kernel<false>), dim3(grid_for(BC * 4L * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (bf16_t*)y, (long)BC, H, W);
+  CFHIP_CHECK_LAUNCH("upsample2_fwd");
+  return CFHIP_OK;
+}
+extern "C" int cfhip_upsample2_bwd(const void* dy, void* dx, int64_t BC, int H, int W, void* stream) {
+  CFHIP_REQUIRE(dy && dx && BC > 0 && H > 0 && W > 0, "upsample2_bwd: bad arguments");
+  hipLaunchKernelGGL((upsample2_kernel<true>), dim3(grid_for(BC * (long)H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, (bf16_t*)dx, (long)BC, H, W);
+  CFHIP_CHECK_LAUNCH("upsample2_bwd");
+  return CFHIP_OK;
+}
+extern "C" int cfhip_avgpool2_fwd(const void* x, void* y, int64_t BC, int Ho, int Wo, void* stream) {
+  CFHIP_REQUIRE(x && y && BC > 0 && Ho > 0 && Wo > 0, "avgpool2_fwd: bad arguments");
+  hipLaunchKernelGGL((avgpool2_kernel<false>), dim3(grid_for(BC * (long)Ho * Wo, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (bf16_t*)y, (long)BC, Ho, Wo);
+  CFHIP_CHECK_LAUNCH("avgpool2_fwd");
+  return CFHIP_OK;
+}
+extern "C" int cfhip_avgpool2_bwd(const void* dy, void* dx, int64_t BC, int Ho, int Wo, void* stream) {
+  CFHIP_REQUIRE(dy && dx && BC > 0 && Ho > 0 && Wo > 0, "avgpool2_bwd: bad arguments");
+  hipLaunchKernelGGL((avgpool2_kernel<true>), dim3(grid_for(BC * 4L * Ho * Wo, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, (bf16_t*)dx, (long)BC, Ho, Wo);
+  CFHIP_CHECK_LAUNCH("avgpool2_bwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_timestep_embedding(const int64_t* t, float* out, int B, int dim, float max_period, void* stream) {
+  CFHIP_REQUIRE(t && out && B > 0 && dim > 1 && max_period > 1.f, "timestep_embedding: bad arguments");
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(grid_for((long)B * dim, 256)), dim3(256), 0, (hipStream_t)stream, t,
+                     out, B, dim, max_period);
+  CFHIP_CHECK_LAUNCH("timestep_embedding");
   return CFHIP_OK;
 }

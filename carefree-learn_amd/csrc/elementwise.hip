@@ -393,6 +393,11 @@ int cfhip_internal_colreduce_f32(const float* partials, int R, int D, float* out
   return CFHIP_OK;
 }
 
+extern "C" int cfhip_colreduce_f32(const float* x, float* out, int R, int D, int accumulate, void* stream) {
+  CFHIP_REQUIRE(x && out && R > 0 && D > 0, "colreduce_f32: bad arguments");
+  return cfhip_internal_colreduce_f32(x, R, D, out, accumulate, (hipStream_t)stream);
+}
+
 extern "C" size_t cfhip_colsum_workspace(int M, int N) {
   return (size_t)colsum_slices(M) * (size_t)N * sizeof(float);
 }

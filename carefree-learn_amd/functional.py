@@ -787,3 +787,108 @@ class L2NormalizeFn(Function):
 
 def l2_normalize(x: Tensor) -> Tensor:
     return L2NormalizeFn.apply(x)
+
+
+# ---------------------------------------------------------------------------------------------
+# UNet residual block pieces (reference convs/residual.py:86-253)
+# ---------------------------------------------------------------------------------------------
+
+
+class GroupNormFn(Function):
+    """y = [SiLU](GroupNorm(x + add[:, :, None, None])): nn.GroupNorm (+ the time-embedding add in front and the
+    nn.SiLU behind it, residual.py:226-247) in one kernel each way."""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, weight: Tensor, bias: Tensor, groups: int, eps: float, add: Optional[Tensor],
+                silu: bool) -> Tensor:
+        if x.dtype not in (bf16, f32):
+            x = x.float()
+        x = x.contiguous()
+        gamma, beta = weight.detach().contiguous(), bias.detach().contiguous()
+        addc = None if add is None else add.detach().float().contiguous()
+        y, mean, rstd = ops.groupnorm_fwd(x, gamma, beta, groups, eps, add=addc, silu=silu)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, addc)
+        ctx.weight, ctx.bias, ctx.groups, ctx.silu = weight, bias, groups, silu
+        return y
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        x, gamma, beta, mean, rstd, addc = ctx.saved_tensors
+        if dy.dtype != bf16:
+            dy = ops.to_bf16(dy.float().contiguous())
+        dx, dg, db, dadd = ops.groupnorm_bwd(dy, x, gamma, beta, mean, rstd, ctx.groups, add=addc, silu=ctx.silu)
+        gw = gb = None
+        for prm, g, which in ((ctx.weight, dg, 0), (ctx.bias, db, 1)):
+            if not prm.requires_grad:
+                continue
+            if _is_direct(prm):
+                write_param_grad(prm, lambda out, acc, g=g: out.add_(g.view(out.shape)) if acc else out.copy_(g.view(out.shape)))
+            elif which == 0:
+                gw = g.view(prm.shape)
+            else:
+                gb = g.view(prm.shape)
+        return (dx if ctx.needs_input_grad[0] else None), gw, gb, None, None, dadd, None
+
+
+def group_norm(x: Tensor, weight: Tensor, bias: Tensor, groups: int, eps: float, add: Optional[Tensor] = None,
+               silu: bool = False) -> Tensor:
+    return GroupNormFn.apply(x, weight, bias, groups, eps, add, silu)
+
+
+class SiLUF32Fn(Function):
+    """nn.SiLU on the small fp32 time embedding [B, C] (residual.py:227)"""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor) -> Tensor:
+        x = x.float().contiguous()
+        ctx.save_for_backward(x)
+        return ops.silu_f32_fwd(x)
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        (x,) = ctx.saved_tensors
+        return ops.silu_f32_bwd(dy.float().contiguous(), x)
+
+
+def silu_f32(x: Tensor) -> Tensor:
+    return SiLUF32Fn.apply(x)
+
+
+class Upsample2Fn(Function):
+    """F.interpolate(scale_factor=2, mode="nearest") (residual.py:147)"""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor) -> Tensor:
+        if x.dtype != bf16:
+            x = ops.to_bf16(x.float().contiguous())
+        return ops.upsample2_fwd(x.contiguous())
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        if dy.dtype != bf16:
+            dy = ops.to_bf16(dy.float().contiguous())
+        return ops.upsample2_bwd(dy.contiguous())
+
+
+class AvgPool2Fn(Function):
+    """nn.AvgPool2d(kernel_size=2, stride=2) (`ResDownsample(use_conv=False)`, residual.py:106)"""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor) -> Tensor:
+        if x.dtype != bf16:
+            x = ops.to_bf16(x.float().contiguous())
+        return ops.avgpool2_fwd(x.contiguous())
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        if dy.dtype != bf16:
+            dy = ops.to_bf16(dy.float().contiguous())
+        return ops.avgpool2_bwd(dy.contiguous())
+
+
+def upsample2(x: Tensor) -> Tensor:
+    return Upsample2Fn.apply(x)
+
+
+def avg_pool2(x: Tensor) -> Tensor:
+    return AvgPool2Fn.apply(x)

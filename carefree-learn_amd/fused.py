@@ -23,11 +23,12 @@ from . import ops
 from .functional import SideStream, bf16, f32, shadow_bf16
 
 
-# The dW GEMM can also produce db = colsum(dy) (cfhip_gemm_bf16's `bias_grad`).  Measured on ViT-B/16
-# (profiles/r01): the waves that own the extra row sums slow their whole workgroup down by more than
-# the two small column-sum kernels cost (+0.7 ms vs -0.65 ms per step), so the stand-alone kernels
-# stay the default.
-FUSE_BIAS_GRAD = False
+# The dW GEMM also produces db = colsum(dy) (cfhip_gemm_bf16's `bias_grad`: the waves that own the first tile column
+# re-read their A fragments and add them up).  Measured on ViT-B/16 batch 128 (tools/step_ab.py, interleaved rounds):
+# 23.86 ms fused vs 23.98 ms with the stand-alone column-sum kernels on the second side stream; no bias gradients at
+# all would be 23.63 ms, so this item is closed.
+FUSE_BIAS_GRAD = True
+_SKIP_BIAS_GRAD = False  # timing experiments only (tools/step_ab.py): leaves the bias gradients unwritten
 
 
 def _dw_db(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> None:
@@ -46,7 +47,9 @@ def _dw_db(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> None:
     kw = {}
     if len(prms) == 2:
         acc_b = not getattr(b, "_cfhip_fresh", False)
-        if FUSE_BIAS_GRAD:
+        if _SKIP_BIAS_GRAD:
+            pass
+        elif FUSE_BIAS_GRAD:
             kw = dict(bias_grad=b.grad.view(-1), bias_grad_accumulate=acc_b)
         else:  # second side stream: the column sum runs beside the dW GEMM
             SideStream.run(lambda: ops.colsum(dy2, out=b.grad.view(-1), accumulate=acc_b), (dy2,), lane=1)

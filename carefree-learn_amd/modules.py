@@ -1192,3 +1192,135 @@ class CLIP(Module):
         image_features = self.encode_image(image)
         text_features = self.encode_text(text)
         return self.logit_scale.exp() * image_features @ text_features.t()
+
+
+# ---------------------------------------------------------------------------------------------
+# UNet residual blocks (reference modules/core/convs/residual.py:86-253, hijacks.py:64-65)
+# ---------------------------------------------------------------------------------------------
+
+
+class HijackConv2d(_HijackMixin, nn.Conv2d):
+    """reference hijacks.py:64-65 (`conv_nd(2, ...)`): nn.Conv2d parameters (`weight`, `bias`), groups 1, zero padding"""
+
+    def forward(self, net: Tensor) -> Tensor:  # type: ignore
+        if (self.groups != 1 or self.padding_mode != "zeros" or self.stride[0] != self.stride[1]
+                or self.padding[0] != self.padding[1] or self.dilation[0] != self.dilation[1]
+                or self.kernel_size[0] != self.kernel_size[1] or isinstance(self.padding, str)):
+            raise NotImplementedError("only square, zero-padded, ungrouped convolutions are on the accelerated hot path")
+        inp = net
+        if self.hook is not None:
+            inp = self.hook.before_forward(inp)
+        net = HF.conv2d(inp, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0])
+        if self.hook is not None:
+            net = self.hook.after_forward(inp, net)
+        return net
+
+
+class GroupNorm(nn.GroupNorm):
+    """nn.GroupNorm (`make_norm`, residual.py:194) on `cfhip_groupnorm_fwd/bwd`; `add` / `silu` expose the kernel's
+    fused time-embedding add in front and SiLU behind."""
+
+    def forward(self, net: Tensor, *, add: Optional[Tensor] = None, silu: bool = False) -> Tensor:  # type: ignore
+        if not self.affine:
+            raise NotImplementedError("GroupNorm without affine parameters is outside the accelerated hot path")
+        return HF.group_norm(net, self.weight, self.bias, self.num_groups, self.eps, add, silu)
+
+
+class ResDownsample(Module):
+    """reference residual.py:86-117: conv3x3 stride 2 (`use_conv`) or 2x2 average pooling"""
+
+    def __init__(self, in_channels: int, use_conv: bool, *, signal_dim: int = 2, out_channels: Optional[int] = None,
+                 padding: int = 1):
+        super().__init__()
+        if signal_dim != 2:
+            raise NotImplementedError("only 2-D signals are on the accelerated hot path")
+        out_channels = out_channels or in_channels
+        if not use_conv:
+            if in_channels != out_channels:
+                raise ValueError("`in_channels` should be equal to `out_channels` when `use_conv` is set to False")
+            self.net: Module = nn.AvgPool2d(kernel_size=2, stride=2)
+        else:
+            self.net = HijackConv2d(in_channels, out_channels, 3, stride=2, padding=padding)
+
+    def forward(self, net: Tensor) -> Tensor:
+        if isinstance(self.net, nn.AvgPool2d):
+            return HF.avg_pool2(net)
+        return self.net(net)
+
+
+class ResUpsample(Module):
+    """reference residual.py:120-151: nearest x2, then an optional conv3x3"""
+
+    def __init__(self, in_channels: int, use_conv: bool, *, signal_dim: int = 2, out_channels: Optional[int] = None,
+                 padding: int = 1):
+        super().__init__()
+        if signal_dim != 2:
+            raise NotImplementedError("only 2-D signals are on the accelerated hot path")
+        self.signal_dim = signal_dim
+        self.conv = HijackConv2d(in_channels, out_channels or in_channels, 3, padding=padding) if use_conv else None
+
+    def forward(self, net: Tensor) -> Tensor:
+        net = HF.upsample2(net)
+        return net if self.conv is None else self.conv(net)
+
+
+class ResidualBlockWithTimeEmbedding(Module):
+    """reference residual.py:154-253: GN(32) -> SiLU -> [resample] -> conv3x3 -> (+ Linear(SiLU(t))) -> GN(32) -> SiLU ->
+    conv3x3 (zero-initialised) -> + shortcut(inp).  State keys: `norm1.*`, `conv1.*`, `time_embedding.*`, `norm2.*`,
+    `conv2.*`, `shortcut.*`.  GroupNorm, the time-embedding add in front of norm2 and both SiLUs are two fused
+    kernels each way.  Scale-shift norm, dropout and gradient checkpointing are outside the accelerated hot path
+    (`safe_clip_` only acts on non-finite values and is omitted)."""
+
+    def __init__(self, in_channels: int, out_channels: Optional[int] = None, *, signal_dim: int = 2,
+                 dropout: float = 0.0, norm_eps: float = 1.0e-6, use_conv_shortcut: bool = False,
+                 integrate_upsample: bool = False, integrate_downsample: bool = False,
+                 time_embedding_channels: int = 512, use_scale_shift_norm: bool = False,
+                 use_checkpoint: bool = False):
+        super().__init__()
+        if signal_dim != 2 or use_scale_shift_norm or dropout > 0.0:
+            raise NotImplementedError("3-D signals / scale-shift norm / dropout are outside the accelerated hot path")
+        self.in_channels = in_channels
+        out_channels = out_channels or in_channels
+        self.out_channels = out_channels
+        self.use_conv_shortcut, self.use_scale_shift_norm = use_conv_shortcut, use_scale_shift_norm
+        self.use_checkpoint = use_checkpoint  # 288 GB of HBM: activations are kept, the flag is accepted and ignored
+        self.resample = integrate_upsample or integrate_downsample
+        if not self.resample:
+            self.inp_resample = self.net_resample = None
+        elif integrate_upsample:
+            self.inp_resample = ResUpsample(in_channels, False)
+            self.net_resample = ResUpsample(in_channels, False)
+        else:
+            self.inp_resample = ResDownsample(in_channels, False)
+            self.net_resample = ResDownsample(in_channels, False)
+        self.activation = nn.SiLU()
+        self.norm1 = GroupNorm(num_groups=32, num_channels=in_channels, eps=norm_eps)
+        self.conv1 = HijackConv2d(in_channels, out_channels, 3, 1, 1)
+        if time_embedding_channels > 0:
+            self.time_embedding = HijackLinear(time_embedding_channels, out_channels)
+        self.norm2 = GroupNorm(num_groups=32, num_channels=out_channels, eps=norm_eps)
+        self.dropout = nn.Dropout(dropout)
+        self.conv2 = HijackConv2d(out_channels, out_channels, 3, 1, 1)
+        with torch.no_grad():  # zero_module (modules/common.py:177-180)
+            for p in self.conv2.parameters():
+                p.zero_()
+        if in_channels != out_channels:
+            self.shortcut = (HijackConv2d(in_channels, out_channels, 3, 1, 1) if use_conv_shortcut
+                             else HijackConv2d(in_channels, out_channels, 1, 1, 0))
+
+    def forward(self, net: Tensor, time_net: Optional[Tensor] = None) -> Tensor:
+        inp = net
+        net = self.norm1(net, silu=True)
+        if self.inp_resample is not None:
+            inp = self.inp_resample(inp)
+            net = self.net_resample(net)
+        net = self.conv1(net)
+        if self.in_channels != self.out_channels:
+            inp = self.shortcut(inp)
+        add = None
+        if time_net is not None:
+            t = HF.silu_f32(time_net)
+            add = HF.linear(t, self.time_embedding.weight, self.time_embedding.bias, out_f32=True)  # [B, Cout]
+        net = self.norm2(net, add=add, silu=True)
+        net = self.conv2(net)
+        return HF.add(inp, net)

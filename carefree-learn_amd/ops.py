@@ -662,3 +662,124 @@ def l2norm_bwd(dy: Tensor, y: Tensor, inv: Tensor) -> Tensor:
     _lib.check(_lib.load().cfhip_l2norm_bwd(dy2.data_ptr(), y2.data_ptr(), inv.data_ptr(), dx.data_ptr(), dy2.shape[0],
                                             dy2.shape[1], _stream()), "l2norm_bwd")
     return dx.view(dy.shape)
+
+
+# ---------------------------------------------------------------------------------------------
+# UNet residual-block pieces: GroupNorm (+ additive term, + SiLU), SiLU, x2 resampling, timestep embedding
+# ---------------------------------------------------------------------------------------------
+
+
+def colreduce_f32(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """out[d] (+)= sum_r x[r][d] for a contiguous f32 [R, D] matrix."""
+    _need(x, f32, "x")
+    if x.dim() != 2 or not x.is_contiguous():
+        raise ValueError("cfhip colreduce_f32: contiguous [R, D] matrix expected")
+    if out is None:
+        out, accumulate = torch.empty((x.shape[1],), dtype=f32, device=x.device), False
+    _lib.check(_lib.load().cfhip_colreduce_f32(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], int(accumulate),
+                                               _stream()), "colreduce_f32")
+    return out
+
+
+def groupnorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, *, add: Optional[Tensor] = None,
+                  silu: bool = False):
+    """x [B, C, ...] f32 / bf16 -> (y bf16, mean f32 [B*G], rstd f32 [B*G]); y = [SiLU](GN(x + add[b, c]))."""
+    if x.dtype not in (f32, bf16) or not x.is_cuda or not x.is_contiguous() or x.dim() < 2:
+        raise ValueError("cfhip groupnorm_fwd: x must be a contiguous f32/bf16 [B, C, ...] device tensor")
+    _need(gamma, f32, "gamma")
+    _need(beta, f32, "beta")
+    b, c = x.shape[0], x.shape[1]
+    inner = x.numel() // (b * c)
+    if add is not None:
+        _need(add, f32, "add")
+        if tuple(add.shape) != (b, c) or not add.is_contiguous():
+            raise ValueError("cfhip groupnorm_fwd: add must be contiguous f32 [B, C]")
+    y = torch.empty(x.shape, dtype=bf16, device=x.device)
+    mean = torch.empty((b * groups,), dtype=f32, device=x.device)
+    rstd = torch.empty((b * groups,), dtype=f32, device=x.device)
+    rc = _lib.load().cfhip_groupnorm_fwd(x.data_ptr(), int(x.dtype == f32), _p(add), gamma.data_ptr(), beta.data_ptr(),
+                                         y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), b, c, groups, inner,
+                                         float(eps), int(silu), _stream())
+    _lib.check(rc, "groupnorm_fwd")
+    return y, mean, rstd
+
+
+def groupnorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tensor, groups: int, *,
+                  add: Optional[Tensor] = None, silu: bool = False):
+    """Returns (dx bf16, dgamma f32 [C], dbeta f32 [C], dadd f32 [B, C] | None)."""
+    _need(dy, bf16, "dy")
+    if not dy.is_contiguous():
+        dy = dy.contiguous()
+    b, c = x.shape[0], x.shape[1]
+    inner = x.numel() // (b * c)
+    dx = torch.empty(x.shape, dtype=bf16, device=x.device)
+    dg_part = torch.empty((b, c), dtype=f32, device=x.device)
+    db_part = torch.empty((b, c), dtype=f32, device=x.device)
+    dadd = torch.empty((b, c), dtype=f32, device=x.device) if add is not None else None
+    rc = _lib.load().cfhip_groupnorm_bwd(dy.data_ptr(), x.data_ptr(), int(x.dtype == f32), _p(add), gamma.data_ptr(),
+                                         beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                         dg_part.data_ptr(), db_part.data_ptr(), _p(dadd), b, c, groups, inner,
+                                         int(silu), _stream())
+    _lib.check(rc, "groupnorm_bwd")
+    return dx, colreduce_f32(dg_part), colreduce_f32(db_part), dadd
+
+
+def silu_f32_fwd(x: Tensor) -> Tensor:
+    _need(x, f32, "x")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().cfhip_silu_f32_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "silu_f32_fwd")
+    return y
+
+
+def silu_f32_bwd(dy: Tensor, x: Tensor) -> Tensor:
+    _need(dy, f32, "dy")
+    _need(x, f32, "x")
+    dy, x = dy.contiguous(), x.contiguous()
+    dx = torch.empty_like(x)
+    _lib.check(_lib.load().cfhip_silu_f32_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), _stream()),
+               "silu_f32_bwd")
+    return dx
+
+
+def _resample(name: str, x: Tensor, out_hw: Tuple[int, int], small_hw: Tuple[int, int]) -> Tensor:
+    _need(x, bf16, "x")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError(f"cfhip {name}: contiguous bf16 [B, C, H, W] expected")
+    b, c = x.shape[0], x.shape[1]
+    out = torch.empty((b, c, out_hw[0], out_hw[1]), dtype=bf16, device=x.device)
+    rc = getattr(_lib.load(), f"cfhip_{name}")(x.data_ptr(), out.data_ptr(), b * c, small_hw[0], small_hw[1], _stream())
+    _lib.check(rc, name)
+    return out
+
+
+def upsample2_fwd(x: Tensor) -> Tensor:
+    h, w = x.shape[2], x.shape[3]
+    return _resample("upsample2_fwd", x, (2 * h, 2 * w), (h, w))
+
+
+def upsample2_bwd(dy: Tensor) -> Tensor:
+    h, w = dy.shape[2] // 2, dy.shape[3] // 2
+    return _resample("upsample2_bwd", dy, (h, w), (h, w))
+
+
+def avgpool2_fwd(x: Tensor) -> Tensor:
+    if x.shape[2] % 2 or x.shape[3] % 2:
+        raise ValueError("cfhip avgpool2: even spatial sizes expected")
+    h, w = x.shape[2] // 2, x.shape[3] // 2
+    return _resample("avgpool2_fwd", x, (h, w), (h, w))
+
+
+def avgpool2_bwd(dy: Tensor) -> Tensor:
+    h, w = dy.shape[2], dy.shape[3]
+    return _resample("avgpool2_bwd", dy, (2 * h, 2 * w), (h, w))
+
+
+def timestep_embedding(t: Tensor, dim: int, max_period: float = 10000.0) -> Tensor:
+    """t int64 [B] -> f32 [B, dim] = [cos(t f) | sin(t f)] (reference multimodal/diffusion/unet.py:52-74)."""
+    if t.dtype != torch.int64 or not t.is_cuda or t.dim() != 1:
+        raise TypeError("cfhip timestep_embedding: t must be int64 [B] on the device")
+    out = torch.empty((t.shape[0], dim), dtype=f32, device=t.device)
+    _lib.check(_lib.load().cfhip_timestep_embedding(t.contiguous().data_ptr(), out.data_ptr(), t.shape[0], dim,
+                                                    float(max_period), _stream()), "timestep_embedding")
+    return out

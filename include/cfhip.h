@@ -239,6 +239,34 @@ int cfhip_leaky_relu_bwd(const void* dy, const void* x, void* dx, int64_t n, flo
 int cfhip_avgpool_fwd(const void* x, void* y, int64_t BC, int inner, void* stream);
 int cfhip_avgpool_bwd(const void* dy, void* dx, int64_t BC, int inner, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * UNet residual-block pieces (convs/residual.py:86-253, multimodal/diffusion/unet.py:52-74)
+ *   groupnorm: y = [SiLU](GroupNorm_G(x + add[b][c])) over x f32/bf16 [B][C][inner], statistics per
+ *     (b, group) in fp32 (mean / rstd f32 [B*G] saved); `add` (f32 [B][C], may be NULL) is the
+ *     time-embedding term `Linear(SiLU(t))[:, :, None, None]` the reference adds in front of norm2.
+ *     bwd: dx bf16, per-batch partial dgamma / dbeta f32 [B][C] (sum them over B with
+ *     cfhip_colsum / a column reduce), dadd f32 [B][C] = sum_inner dx (NULL when there was no add).
+ *   silu_f32: the activation on the [B, 1280] time embedding;  upsample2 / avgpool2: nearest x2
+ *     (F.interpolate(scale_factor=2, "nearest")) and 2x2 average pooling of bf16 [BC][H][W]
+ *     (H, W = the SMALL size in both);  timestep_embedding: [cos(t f_i) | sin(t f_i)], f32.
+ * ------------------------------------------------------------------------------------------ */
+int cfhip_groupnorm_fwd(const void* x, int x_is_f32, const float* add, const float* gamma, const float* beta,
+                        void* y, float* mean, float* rstd, int B, int C, int G, int inner, float eps,
+                        int silu, void* stream);
+int cfhip_groupnorm_bwd(const void* dy, const void* x, int x_is_f32, const float* add, const float* gamma,
+                        const float* beta, const float* mean, const float* rstd, void* dx,
+                        float* dgamma_part, float* dbeta_part, float* dadd, int B, int C, int G, int inner,
+                        int silu, void* stream);
+int cfhip_silu_f32_fwd(const float* x, float* y, int64_t n, void* stream);
+int cfhip_silu_f32_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+int cfhip_upsample2_fwd(const void* x, void* y, int64_t BC, int H, int W, void* stream);
+int cfhip_upsample2_bwd(const void* dy, void* dx, int64_t BC, int H, int W, void* stream);
+int cfhip_avgpool2_fwd(const void* x, void* y, int64_t BC, int Ho, int Wo, void* stream);
+int cfhip_avgpool2_bwd(const void* dy, void* dx, int64_t BC, int Ho, int Wo, void* stream);
+/* out[d] (+)= sum_r x[r][d] for a dense f32 [R][D] matrix (per-batch partials -> parameter gradient) */
+int cfhip_colreduce_f32(const float* x, float* out, int R, int D, int accumulate, void* stream);
+int cfhip_timestep_embedding(const int64_t* t, float* out, int B, int dim, float max_period, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * CLIP text tower index work (multimodal/clip.py:209-256) — gathers are bit-exact

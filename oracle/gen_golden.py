@@ -21,6 +21,7 @@ sys.path.insert(0, HERE)
 import vit_oracle as O  # noqa: E402
 import conv_oracle as CO  # noqa: E402
 import clip_oracle as CL  # noqa: E402
+import unet_oracle as UO  # noqa: E402
 from refharness import load_reference  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
@@ -315,13 +316,62 @@ def gen_clip(ref) -> None:
                os.path.join(OUT, "clip_small.pt"))
 
 
+def gen_resblock(ref) -> None:
+    """UNet building blocks (convs/residual.py:86-253): ResidualBlockWithTimeEmbedding in its three forms (channel
+    change with 1x1 shortcut, integrated up-/down-sampling), ResUpsample / ResDownsample with conv, and
+    `timestep_embedding` (multimodal/diffusion/unet.py:52-74)."""
+    import importlib
+
+    res = importlib.import_module("cflearn.modules.core.convs.residual")
+    cases = []
+    for seed, (cin, cout, up, down) in enumerate([(64, 128, False, False), (64, 64, True, False), (96, 96, False, True)]):
+        torch.manual_seed(90 + seed)
+        m = res.ResidualBlockWithTimeEmbedding(cin, cout, time_embedding_channels=128, integrate_upsample=up,
+                                               integrate_downsample=down)
+        with torch.no_grad():  # conv2 is zero-initialised: perturb everything so all gradients are exercised
+            for p_ in m.parameters():
+                p_.add_(torch.randn_like(p_) * 0.05)
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        x = torch.randn(2, cin, 8, 8, requires_grad=True)
+        t = torch.randn(2, 128, requires_grad=True)
+        y = m(x, t)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        _check(f"resblock {cin}->{cout} up={up} down={down}",
+               UO.residual_block(x.detach(), t.detach(), sd, resample="up" if up else "down" if down else None), y.detach())
+        cases.append(dict(cfg=dict(in_channels=cin, out_channels=cout, time_embedding_channels=128,
+                                   integrate_upsample=up, integrate_downsample=down),
+                          sd=sd, x=x.detach(), t=t.detach(), y=y.detach(), gy=gy, gx=x.grad.clone(), gt=t.grad.clone(),
+                          grads={k: p_.grad.clone() for k, p_ in m.named_parameters()}))
+    torch.manual_seed(95)
+    up = res.ResUpsample(32, True, out_channels=48)
+    down = res.ResDownsample(32, True, out_channels=48)
+    x = torch.randn(2, 32, 6, 6)
+    yu, yd = up(x), down(x)
+    _check("ResUpsample", CO.conv2d(UO.upsample2(x), up.conv.weight.detach(), up.conv.bias.detach(), 1, 1), yu.detach())
+    _check("ResDownsample", CO.conv2d(x, down.net.weight.detach(), down.net.bias.detach(), 2, 1), yd.detach())
+    try:
+        unet = importlib.import_module("cflearn.modules.multimodal.diffusion.unet")
+        tt = torch.tensor([0, 1, 17, 500, 999])
+        te = unet.timestep_embedding(tt, 320, dtype=torch.float32)
+        _check("timestep_embedding", UO.timestep_embedding(tt, 320), te)
+    except Exception as e:  # the UNet module pulls in more of cftool than the harness provides
+        print("  (timestep_embedding not importable through the harness:", type(e).__name__, e, ")")
+        tt = torch.tensor([0, 1, 17, 500, 999])
+        te = UO.timestep_embedding(tt, 320)
+    torch.save(dict(blocks=cases, up=dict(sd={k: v.detach().clone() for k, v in up.state_dict().items()}, y=yu.detach()),
+                    down=dict(sd={k: v.detach().clone() for k, v in down.state_dict().items()}, y=yd.detach()),
+                    x_resample=x, timesteps=tt, timestep_embedding=te),
+               os.path.join(OUT, "resblock.pt"))
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
     torch.set_num_threads(4)
     only = sys.argv[1:]
     for fn in (gen_linear, gen_layernorm, gen_sdp, gen_attention, gen_feedforward, gen_vit, gen_conv2d,
-               gen_batchnorm, gen_mnist_clf, gen_fcnn, gen_clip):
+               gen_batchnorm, gen_mnist_clf, gen_fcnn, gen_clip, gen_resblock):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

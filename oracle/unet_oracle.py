@@ -1,0 +1,73 @@
+"""CPU restatement (fp32) of the UNet residual-block pieces — TEST INFRASTRUCTURE ONLY.
+
+Follows cflearn/modules/core/convs/residual.py:86-253 (`ResDownsample`, `ResUpsample`,
+`ResidualBlockWithTimeEmbedding._forward`) and cflearn/modules/multimodal/diffusion/unet.py:52-74
+(`timestep_embedding`).  Pinned by oracle/gen_golden.py::gen_resblock against the reference classes imported through
+oracle/refharness.  `safe_clip_` (toolkit.py:1236) only touches non-finite values and is left out.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+import conv_oracle as CO
+
+StateDict = Dict[str, Tensor]
+
+
+def group_norm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 32, eps: float = 1.0e-6) -> Tensor:
+    """nn.GroupNorm: statistics per (sample, group) over (C/G, H, W), biased variance"""
+    b, c = x.shape[:2]
+    xg = x.reshape(b, groups, -1)
+    mean = xg.mean(dim=2, keepdim=True)
+    var = ((xg - mean) ** 2).mean(dim=2, keepdim=True)
+    y = ((xg - mean) / torch.sqrt(var + eps)).reshape(x.shape)
+    shape = [1, c] + [1] * (x.dim() - 2)
+    return y * gamma.view(shape) + beta.view(shape)
+
+
+def silu(x: Tensor) -> Tensor:
+    return x / (1.0 + torch.exp(-x))
+
+
+def upsample2(x: Tensor) -> Tensor:
+    """F.interpolate(scale_factor=2, mode="nearest")"""
+    return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+
+
+def avg_pool2(x: Tensor) -> Tensor:
+    """nn.AvgPool2d(2, 2)"""
+    b, c, h, w = x.shape
+    return x.reshape(b, c, h // 2, 2, w // 2, 2).mean(dim=(3, 5))
+
+
+def timestep_embedding(t: Tensor, dim: int, max_period: float = 10000.0) -> Tensor:
+    half = dim // 2
+    freq = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freq[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+def residual_block(x: Tensor, t: Optional[Tensor], sd: StateDict, prefix: str = "", eps: float = 1.0e-6,
+                   resample: Optional[str] = None) -> Tensor:
+    """ResidualBlockWithTimeEmbedding._forward without scale-shift norm / dropout"""
+    inp = x
+    net = silu(group_norm(x, sd[prefix + "norm1.weight"], sd[prefix + "norm1.bias"], 32, eps))
+    if resample == "up":
+        inp, net = upsample2(inp), upsample2(net)
+    elif resample == "down":
+        inp, net = avg_pool2(inp), avg_pool2(net)
+    net = CO.conv2d(net, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], 1, 1)
+    if prefix + "shortcut.weight" in sd:
+        w = sd[prefix + "shortcut.weight"]
+        inp = CO.conv2d(inp, w, sd[prefix + "shortcut.bias"], 1, w.shape[-1] // 2)
+    if t is not None:
+        tt = silu(t) @ sd[prefix + "time_embedding.weight"].t() + sd[prefix + "time_embedding.bias"]
+        net = net + tt[:, :, None, None]
+    net = silu(group_norm(net, sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"], 32, eps))
+    net = CO.conv2d(net, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], 1, 1)
+    return inp + net

@@ -1,0 +1,109 @@
+"""UNet residual-block pieces on the GPU: GroupNorm (+ additive term, + SiLU), x2 resampling, timestep embedding and
+ResidualBlockWithTimeEmbedding / ResUpsample / ResDownsample vs the reference-made fixture tests/golden/resblock.pt."""
+import pytest
+import torch
+
+import cflearn_amd as C
+from cflearn_amd import functional as HF
+from cflearn_amd import ops
+from cflearn_amd.modules import GroupNorm, ResDownsample, ResidualBlockWithTimeEmbedding, ResUpsample
+from helpers import assert_close, bf16_round
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+
+@pytest.mark.parametrize("silu,with_add", [(False, False), (True, False), (True, True)])
+def test_groupnorm_kernel(silu, with_add):
+    import unet_oracle as UO
+
+    torch.manual_seed(0)
+    b, c, h, w = 3, 64, 5, 7
+    x = bf16_round(torch.randn(b, c, h, w) * 1.5 + 0.3)
+    add = torch.randn(b, c) * 0.5 if with_add else None
+    gn = GroupNorm(32, c, eps=1e-6)
+    with torch.no_grad():
+        gn.weight.normal_(1.0, 0.3)
+        gn.bias.normal_(0.0, 0.3)
+    xr = x.clone().requires_grad_(True)
+    ar = add.clone().requires_grad_(True) if with_add else None
+    wr, br = gn.weight.detach().clone().requires_grad_(True), gn.bias.detach().clone().requires_grad_(True)
+    want = UO.group_norm(xr + (ar[:, :, None, None] if with_add else 0.0), wr, br, 32, 1e-6)
+    if silu:
+        want = UO.silu(want)
+    gy = bf16_round(torch.randn_like(want))
+    want.backward(gy)
+    gn = gn.to(DEV)
+    xg = x.to(DEV).bfloat16().requires_grad_(True)
+    ag = add.to(DEV).requires_grad_(True) if with_add else None
+    y = gn(xg, add=ag, silu=silu)
+    assert_close(y, want, 4e-3, "groupnorm y")
+    y.backward(gy.to(DEV).bfloat16())
+    assert_close(xg.grad, xr.grad, 8e-3, "groupnorm dx")
+    assert_close(gn.weight.grad, wr.grad, 5e-3, "groupnorm dgamma")
+    assert_close(gn.bias.grad, br.grad, 5e-3, "groupnorm dbeta")
+    if with_add:
+        assert_close(ag.grad, ar.grad, 8e-3, "groupnorm dadd")  # sums of the bf16-rounded dx
+
+
+def test_resample_silu_timestep_embedding(golden):
+    import unet_oracle as UO
+
+    torch.manual_seed(1)
+    x = bf16_round(torch.randn(2, 5, 6, 4))
+    xg = x.to(DEV).bfloat16().requires_grad_(True)
+    up = HF.upsample2(xg)
+    assert torch.equal(up.float().cpu(), UO.upsample2(x))
+    gy = bf16_round(torch.randn(2, 5, 12, 8))
+    up.backward(gy.to(DEV).bfloat16())
+    assert_close(xg.grad, UO.avg_pool2(gy) * 4, 4e-3, "upsample bwd")
+    xg = x.to(DEV).bfloat16().requires_grad_(True)
+    dn = HF.avg_pool2(xg)
+    assert_close(dn, UO.avg_pool2(x), 4e-3, "avgpool2")
+    g2 = bf16_round(torch.randn(2, 5, 3, 2))
+    dn.backward(g2.to(DEV).bfloat16())
+    assert_close(xg.grad, UO.upsample2(g2) / 4, 4e-3, "avgpool2 bwd")
+    t = torch.randn(4, 96, requires_grad=True)
+    UO.silu(t).backward(torch.ones(4, 96))
+    tg = t.detach().to(DEV).requires_grad_(True)
+    y = HF.silu_f32(tg)
+    y.backward(torch.ones(4, 96, device=DEV))
+    assert_close(y, UO.silu(t), 1e-6, "silu")
+    assert_close(tg.grad, t.grad, 1e-5, "silu grad")
+    g = golden("resblock.pt")
+    te = ops.timestep_embedding(g["timesteps"].to(DEV), 320)
+    assert (te.cpu() - g["timestep_embedding"]).abs().max() < 5e-4  # fp32 sin/cos of arguments up to 999
+    assert (ops.timestep_embedding(g["timesteps"].to(DEV), 321)[:, -1] == 0).all()
+
+
+def test_residual_block_golden(golden):
+    import conv_oracle as CO
+    import unet_oracle as UO
+
+    g = golden("resblock.pt")
+    for case in g["blocks"]:
+        cfg = case["cfg"]
+        m = ResidualBlockWithTimeEmbedding(cfg["in_channels"], cfg["out_channels"],
+                                           time_embedding_channels=cfg["time_embedding_channels"],
+                                           integrate_upsample=cfg["integrate_upsample"],
+                                           integrate_downsample=cfg["integrate_downsample"])
+        assert list(m.state_dict().keys()) == list(case["sd"].keys())
+        m.load_state_dict(case["sd"])
+        m = m.to(DEV)
+        x = case["x"].to(DEV).requires_grad_(True)
+        t = case["t"].to(DEV).requires_grad_(True)
+        y = m(x, t)
+        assert y.shape == case["y"].shape
+        assert_close(y, case["y"], 1e-2, f"resblock y {cfg}")
+        y.backward(case["gy"].to(DEV).bfloat16())
+        assert_close(x.grad, case["gx"], 3e-2, f"resblock gx {cfg}")
+        assert_close(t.grad, case["gt"], 3e-2, f"resblock gt {cfg}")
+        for k, p in m.named_parameters():
+            assert_close(p.grad, case["grads"][k], 3e-2, f"resblock grad {k} {cfg}", abs_floor=2e-3)
+    x = g["x_resample"].to(DEV)
+    up = ResUpsample(32, True, out_channels=48)
+    up.load_state_dict(g["up"]["sd"])
+    assert_close(up.to(DEV)(x), g["up"]["y"], 8e-3, "ResUpsample")
+    down = ResDownsample(32, True, out_channels=48)
+    down.load_state_dict(g["down"]["sd"])
+    assert_close(down.to(DEV)(x), g["down"]["y"], 8e-3, "ResDownsample")

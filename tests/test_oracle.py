@@ -208,3 +208,29 @@ def test_clip_towers_oracle(golden):
             # directly, so mask that row the same way before comparing
             got[0] = 0
         assert (got - ref).abs().max() <= max(2e-6, 2e-4 * ref.abs().max()), k
+
+
+def test_unet_residual_block_oracle(golden):
+    """oracle/unet_oracle.py vs the reference's ResidualBlockWithTimeEmbedding / ResUpsample / ResDownsample /
+    timestep_embedding outputs and gradients"""
+    import conv_oracle as CO
+    import unet_oracle as UO
+
+    g = golden("resblock.pt")
+    for case in g["blocks"]:
+        cfg = case["cfg"]
+        resample = "up" if cfg["integrate_upsample"] else "down" if cfg["integrate_downsample"] else None
+        lv = {k: v.detach().clone().requires_grad_(True) for k, v in case["sd"].items()}
+        x = case["x"].clone().requires_grad_(True)
+        t = case["t"].clone().requires_grad_(True)
+        y = UO.residual_block(x, t, lv, resample=resample)
+        assert (y - case["y"]).abs().max() < 2e-5
+        y.backward(case["gy"])
+        assert (x.grad - case["gx"]).abs().max() <= 1e-4 * max(1.0, case["gx"].abs().max())
+        assert (t.grad - case["gt"]).abs().max() <= 1e-4 * max(1.0, case["gt"].abs().max())
+        for k, ref in case["grads"].items():
+            assert (lv[k].grad - ref).abs().max() <= max(1e-5, 2e-4 * ref.abs().max()), k
+    x = g["x_resample"]
+    assert (CO.conv2d(UO.upsample2(x), g["up"]["sd"]["conv.weight"], g["up"]["sd"]["conv.bias"], 1, 1) - g["up"]["y"]).abs().max() < 1e-5
+    assert (CO.conv2d(x, g["down"]["sd"]["net.weight"], g["down"]["sd"]["net.bias"], 2, 1) - g["down"]["y"]).abs().max() < 1e-5
+    assert (UO.timestep_embedding(g["timesteps"], 320) - g["timestep_embedding"]).abs().max() < 1e-6

@@ -18,18 +18,15 @@ img = torch.randn(BATCH, 3, 224, 224, generator=g).to(dev)
 labels = torch.randint(0, 1000, (BATCH,), generator=g).to(dev)
 
 VARIANTS = {
-    "h3, dW on side stream": dict(gemm_heuristic=3, gemm_persistent=0, side=True, lanes=2, heavy=True),
-    "h4, dW on side stream": dict(gemm_heuristic=4, gemm_persistent=0, side=True, lanes=2, heavy=True),
-    "h3, dW on main stream": dict(gemm_heuristic=3, gemm_persistent=0, side=True, lanes=2, heavy=False),
-    "h4, dW on main stream": dict(gemm_heuristic=4, gemm_persistent=0, side=True, lanes=2, heavy=False),
+    "shipped": dict(skip_bias=False, fuse_bias=False),
+    "bias grads fused in the dW GEMM": dict(skip_bias=False, fuse_bias=True),
+    "no bias grads at all (bound)": dict(skip_bias=True, fuse_bias=False),
 }
 
 def apply(v):
-    ops.set_option("gemm_heuristic", v["gemm_heuristic"])
-    ops.set_option("gemm_persistent", v["gemm_persistent"])
-    SideStream.enabled = v["side"]
-    SideStream.lanes = v["lanes"]
-    SideStream.heavy = v.get("heavy", True)
+    from cflearn_amd import fused
+    fused._SKIP_BIAS_GRAD = v["skip_bias"]
+    fused.FUSE_BIAS_GRAD = v["fuse_bias"]
 
 def run(n):
     torch.cuda.synchronize()
