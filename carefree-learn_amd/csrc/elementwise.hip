@@ -393,6 +393,40 @@ int cfhip_internal_colreduce_f32(const float* partials, int R, int D, float* out
   return CFHIP_OK;
 }
 
+// ---- EMA of the parameters (reference modules/common.py:126-137): ema = (1 - decay) * p + decay * ema ----------
+// two rounded products and one rounded sum, exactly the reference's expression (no FMA contraction): bit-exact
+__global__ void ema_update_kernel(float* __restrict__ ema, const float* __restrict__ p, long n, float one_minus_decay,
+                                  float decay) {
+#pragma clang fp contract(off)
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 pv = reinterpret_cast<const f32x4*>(p)[i];
+    f32x4 ev = reinterpret_cast<const f32x4*>(ema)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = one_minus_decay * pv[e];
+      const float b = decay * ev[e];
+      ev[e] = a + b;
+    }
+    reinterpret_cast<f32x4*>(ema)[i] = ev;
+  }
+  for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float a = one_minus_decay * p[i];
+    const float b = decay * ema[i];
+    ema[i] = a + b;
+  }
+}
+
+extern "C" int cfhip_ema_update(float* ema, const float* p, int64_t n, float one_minus_decay, float decay, void* stream) {
+  CFHIP_REQUIRE(ema && p && n > 0, "ema_update: bad arguments");
+  CFHIP_REQUIRE(((uintptr_t)ema & 15) == 0 && ((uintptr_t)p & 15) == 0, "ema_update: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(ema_update_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, ema, p,
+                     (long)n, one_minus_decay, decay);
+  CFHIP_CHECK_LAUNCH("ema_update");
+  return CFHIP_OK;
+}
+
 extern "C" int cfhip_colreduce_f32(const float* x, float* out, int R, int D, int accumulate, void* stream) {
   CFHIP_REQUIRE(x && out && R > 0 && D > 0, "colreduce_f32: bad arguments");
   return cfhip_internal_colreduce_f32(x, R, D, out, accumulate, (hipStream_t)stream);

@@ -783,3 +783,13 @@ def timestep_embedding(t: Tensor, dim: int, max_period: float = 10000.0) -> Tens
     _lib.check(_lib.load().cfhip_timestep_embedding(t.contiguous().data_ptr(), out.data_ptr(), t.shape[0], dim,
                                                     float(max_period), _stream()), "timestep_embedding")
     return out
+
+
+def ema_update(ema: Tensor, p: Tensor, decay: float) -> None:
+    """ema <- (1 - decay) * p + decay * ema over flat contiguous f32 buffers (bit-exact with the torch expression)."""
+    _need(ema, f32, "ema")
+    _need(p, f32, "p")
+    if not ema.is_contiguous() or not p.is_contiguous() or ema.numel() != p.numel():
+        raise ValueError("cfhip ema_update: contiguous f32 buffers of equal length expected")
+    _lib.check(_lib.load().cfhip_ema_update(ema.data_ptr(), p.data_ptr(), p.numel(), float(1.0 - decay), float(decay),
+                                            _stream()), "ema_update")

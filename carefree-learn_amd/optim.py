@@ -14,7 +14,7 @@ The reference selects `torch.optim.Adam` / `AdamW` by name (optimizers.py:29-33)
 `zero_grad()` / `state_dict()` surface.
 """
 import math
-from typing import Any, Dict, Iterable, List, Optional
+from typing import Any, Dict, Iterable, List, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -183,3 +183,84 @@ def clip_grad_norm_(arena: ParamArena, max_norm: float, optimizer: Optional[Fuse
         else:
             arena.flat_g.mul_(coef)
     return total
+
+
+class EMA(torch.nn.Module):
+    """reference modules/common.py:102-162 — same constructor, buffer names (`name.replace(".", "_")`, `num_updates`),
+    `forward()` update rule and train() / eval() parameter swapping; the update is ONE kernel over a flat buffer when
+    the parameters live in a `ParamArena` (the reference allocates and clones every parameter
+    every step — a second full-model HBM pass plus ~150 allocations).  ema = (1 - decay) * p + decay * ema, bit-exact."""
+
+    def __init__(self, decay: float, named_parameters: List[Tuple[str, torch.nn.Parameter]], *,
+                 use_num_updates: bool = False, arena: Optional[ParamArena] = None):
+        super().__init__()
+        self._cache: Dict[str, Tensor] = {}
+        self._decay = decay
+        self._named_parameters = list(named_parameters)
+        params = [p for _, p in self._named_parameters]
+        self._arena = arena if (arena is not None and len(arena.params) == len(params)
+                                and all(a is b for a, b in zip(arena.params, params))) else None
+        if self._arena is not None:
+            self._flat = self._arena.flat_p.detach().clone()
+            offsets = self._arena.offsets
+        else:
+            offsets, total = [], 0
+            for p in params:
+                offsets.append(total)
+                total += (p.numel() + 7) // 8 * 8
+            dev = params[0].device if params else None
+            self._flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        for (name, p), off in zip(self.tgt_params, offsets):
+            view = self._flat[off:off + p.numel()].view(p.shape)
+            if self._arena is None:
+                view.copy_(p.data)
+            self.register_buffer(name, view)
+        self.register_buffer("num_updates", torch.tensor(0 if use_num_updates else -1, dtype=torch.int))
+        self._offsets = offsets
+
+    @property
+    def tgt_params(self):
+        return [(n.replace(".", "_"), p) for n, p in self._named_parameters]
+
+    def _apply(self, fn, *args, **kwargs):  # type: ignore
+        """.to() / .cuda(): move the FLAT buffer and re-create the per-parameter views on it"""
+        self._flat = fn(self._flat)
+        for (name, p), off in zip(self.tgt_params, self._offsets):
+            self._buffers[name] = self._flat[off:off + p.numel()].view(p.shape)
+        self._buffers["num_updates"] = fn(self._buffers["num_updates"])
+        return self
+
+    def forward(self) -> None:
+        if not self.training:
+            raise ValueError("should not update `EMA` at inference stage")
+        if self.num_updates < 0:
+            decay = self._decay
+        else:
+            self.num_updates += 1
+            decay = min(self._decay, (1 + int(self.num_updates)) / (10 + int(self.num_updates)))
+        if self._arena is not None:
+            ops.ema_update(self._flat, self._arena.flat_p, decay)
+            return
+        for (name, p), off in zip(self.tgt_params, self._offsets):
+            n8 = (p.numel() + 7) // 8 * 8
+            if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.data_ptr() % 16 == 0:
+                ops.ema_update(self._flat[off:off + p.numel()], p.data.view(-1), decay)
+            else:
+                raise RuntimeError(f"EMA: parameter '{name}' must be a contiguous, 16-byte aligned f32 device tensor "
+                                   f"(slot {off}..{off + n8}); put the parameters in a ParamArena")
+
+    def train(self, mode: bool = True) -> "EMA":
+        super().train(mode)
+        if mode:
+            for name, param in self.tgt_params:
+                cached = self._cache.pop(name, None)
+                if cached is not None:
+                    param.data.copy_(cached)
+        else:
+            for name, param in self.tgt_params:
+                if name not in self._cache:
+                    self._cache[name] = param.data.clone()
+                param.data.copy_(getattr(self, name))
+        if self._arena is not None and self._arena.flat_p.is_cuda:
+            self._arena.refresh_shadow()  # the forward kernels read the bf16 copies of the weights
+        return self

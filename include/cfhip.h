@@ -193,6 +193,10 @@ int cfhip_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, 
  * grad_scale (f32, device). */
 int cfhip_adam_step_dev(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n,
                         const float* hyper, int decoupled, void* stream);
+/* EMA of the parameters (modules/common.py:126-137): ema = (1 - decay) * p + decay * ema over a flat f32 buffer
+ * (16-byte aligned); two rounded products + one rounded sum like the reference's expression: bit-exact.
+ * the reference clones every parameter every step. */
+int cfhip_ema_update(float* ema, const float* p, int64_t n, float one_minus_decay, float decay, void* stream);
 /* sum of squares of g (f32 [n]) into out[0] (+= ; caller zeroes) — gradient-norm clipping */
 int cfhip_sumsq_f32(const float* g, float* out, int64_t n, void* stream);
 

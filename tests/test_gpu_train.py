@@ -87,3 +87,36 @@ def test_grad_clip_and_lazy_zero(golden):
     logits.backward(dl)
     ts.arena.finalize_grads()
     assert_close(ts.arena.flat_g, snap, 1e-6, "lazy zero_grad")
+
+
+def test_ema_one_kernel_bit_exact():
+    """optim.EMA (reference modules/common.py:102-162): buffer names, num_updates decay rule, train/eval swap; the
+    update over the arena is one kernel and bit-equal to the reference expression in fp32."""
+    from cflearn_amd.optim import EMA, ParamArena
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.Linear(17, 5)).to(DEV)
+    named = list(net.named_parameters())
+    arena = ParamArena([p for _, p in named], with_shadow=False)
+    for use_num, with_arena in ((False, True), (True, True), (False, False)):
+        ema = EMA(0.999, named, use_num_updates=use_num, arena=arena if with_arena else None).to(DEV)
+        assert [n for n, _ in ema.named_buffers()] == ["0_weight", "0_bias", "1_weight", "1_bias", "num_updates"]
+        ref = {n.replace(".", "_"): p.detach().clone() for n, p in named}
+        for step in range(3):
+            with torch.no_grad():
+                for _, p in named:
+                    p.add_(torch.randn_like(p) * 0.1)
+            ema.train()
+            ema()
+            decay = 0.999 if not use_num else min(0.999, (1 + step + 1) / (10 + step + 1))
+            for n, p in named:
+                k = n.replace(".", "_")
+                ref[k] = (1.0 - decay) * p.data + decay * ref[k]
+                assert torch.equal(getattr(ema, k), ref[k]), (use_num, with_arena, step, k)
+        live = {n: p.detach().clone() for n, p in named}
+        ema.eval()
+        for n, p in named:
+            assert torch.equal(p.data, ref[n.replace(".", "_")])
+        ema.train()
+        for n, p in named:
+            assert torch.equal(p.data, live[n])
