@@ -432,6 +432,307 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_kernel(AttnParams p, int 
   }  // kv-tile loop
 }
 
+// ------------------------------------------------------------------------------------------------
+// Long sequences (T > 256): the same three kernels with an outer loop over 256-row CHUNKS of the operand that
+// the short form keeps resident in LDS.  Workgroup = (128-row chunk of the walking operand, head, batch), one
+// 16-row tile per wave, the chunk staged by LDS-DMA between two barriers.  Forward: online softmax across chunks
+// (running max m, sum l, rescaled O); backward: p = exp2(s * scale - lse) with the saved lse, so the chunks just
+// accumulate.  K / V (or Q / dO) are re-read once per 128-row workgroup: (T / 128) x the operand, from L2.
+// ------------------------------------------------------------------------------------------------
+constexpr int CH = 256;          // rows per staged chunk
+constexpr int CHB = CH / 32;     // 32-row blocks per chunk
+
+template <bool PLAIN>
+__global__ __launch_bounds__(512, 4) void attn_fwd_stream_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + CH * 128;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const bf16_t* kb = p.k + (long)b * p.kv_sb + h * DH;
+  const bf16_t* vb = p.v + (long)b * p.kv_sb + h * DH;
+  const bf16_t* qb = p.q + (long)b * p.q_sb + h * DH;
+  const int row0 = (blockIdx.x * nwaves + wave) * 16;
+  const bool active = row0 < p.Tq;  // inactive waves still stage and hit the barriers
+  const int qi = row0 + i;
+  bf16x8 qf0 = {0, 0, 0, 0, 0, 0, 0, 0}, qf1 = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (active) {
+    qf0 = frag_global(qb, p.q_st, row0, p.Tq, 0, lane);
+    qf1 = frag_global(qb, p.q_st, row0, p.Tq, 1, lane);
+  }
+  const float sl2 = p.scale * LOG2E;
+  float m = -INFINITY, l = 0.f;
+  f32x4 ot[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kv0 = 0; kv0 < p.Tk; kv0 += CH) {
+    const int rows = min(CH, p.Tk - kv0);
+    __syncthreads();  // every wave is done with the previous chunk
+    dma_tile(Ks, kb + (long)kv0 * p.kv_st, p.kv_st, rows, CH, wave, nwaves, lane);
+    dma_tile(Vs, vb + (long)kv0 * p.kv_st, p.kv_st, rows, CH, wave, nwaves, lane);
+    __syncthreads();  // vmcnt(0) + barrier
+    if (!active) continue;
+    if (p.causal && kv0 > row0 + 15) continue;  // chunk entirely in the future of this tile (wave-uniform)
+    f32x4 st[2 * CHB];
+#pragma unroll
+    for (int jt = 0; jt < 2 * CHB; ++jt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 0, lane), qf0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 1, lane), qf1, acc, 0, 0, 0);
+      st[jt] = acc;
+      if (jt & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    float mx = -INFINITY;
+    const bool tail = kv0 + CH > p.Tk;  // wave-uniform: only the last chunk needs the j < Tk test
+#pragma unroll
+    for (int jt = 0; jt < 2 * CHB; ++jt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = kv0 + jt * 16 + 4 * g + r;
+        float x = st[jt][r] * sl2;
+        if (PLAIN) {
+          if (tail) x = j < p.Tk ? x : -INFINITY;
+        } else {
+          x = keep_at(p, b, h, qi < p.Tq ? qi : p.Tq - 1, j) ? x : -INFINITY;
+        }
+        st[jt][r] = x;
+        mx = fmaxf(mx, x);
+      }
+    }
+    mx = group_max(mx);
+    const float m_new = fmaxf(m, mx);
+    // rows whose every position so far is masked (m_new = -inf) must not produce NaN from (-inf) - (-inf): use 0
+    // as the reference point for them (all their terms are exp2(-inf) = 0 anyway); no divergent branch around MFMAs
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m - m_use);  // m = -inf on the first chunk: 0
+    float ls = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2 * CHB; ++jt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(st[jt][r] - m_use);
+        st[jt][r] = e;
+        ls += e;
+      }
+    }
+    l = l * alpha + group_sum(ls);
+    m = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ot[dt] *= alpha;
+#pragma unroll
+    for (int a = 0; a < CHB; ++a) {
+      const bf16x8 pa = pack8(st[2 * a], st[2 * a + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Vs, a * 32, dt * 16, lane), pa, ot[dt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (active && qi < p.Tq) {
+    const float inv = 1.0f / l;
+    bf16_t* orow = p.o + (long)b * p.o_sb + (long)qi * p.o_st + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const f32x4 v = ot[dt] * inv;
+      *reinterpret_cast<u32x2*>(orow + dt * 16 + 4 * g) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+    if (g == 0 && p.lse != nullptr) p.lse[((long)b * p.H + h) * p.Tq + qi] = (m + log2f(l)) * (1.0f / LOG2E);
+  }
+}
+
+template <bool PLAIN>
+__global__ __launch_bounds__(512, 4) void attn_bwd_dq_stream_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + CH * 128;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int row0 = (blockIdx.x * nwaves + wave) * 16;
+  const bool active = row0 < p.Tq;
+  const int qi = row0 + i;
+  const bool qvalid = active && qi < p.Tq;
+  const bf16_t* qb = p.q + (long)b * p.q_sb + h * DH;
+  const bf16_t* dob = p.d_o + (long)b * p.o_sb + h * DH;
+  const bf16_t* ob = p.o_in + (long)b * p.o_sb + h * DH;
+  bf16x8 qf0 = {0, 0, 0, 0, 0, 0, 0, 0}, qf1 = qf0, dof0 = qf0, dof1 = qf0;
+  float delta = 0.f;
+  if (active) {
+    qf0 = frag_global(qb, p.q_st, row0, p.Tq, 0, lane);
+    qf1 = frag_global(qb, p.q_st, row0, p.Tq, 1, lane);
+    dof0 = frag_global(dob, p.o_st, row0, p.Tq, 0, lane);
+    dof1 = frag_global(dob, p.o_st, row0, p.Tq, 1, lane);
+    const bf16x8 of0 = frag_global(ob, p.o_st, row0, p.Tq, 0, lane);
+    const bf16x8 of1 = frag_global(ob, p.o_st, row0, p.Tq, 1, lane);
+    float sacc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sacc += bf16_to_f32((bf16_t)dof0[e]) * bf16_to_f32((bf16_t)of0[e]);
+      sacc += bf16_to_f32((bf16_t)dof1[e]) * bf16_to_f32((bf16_t)of1[e]);
+    }
+    delta = group_sum(sacc);
+  }
+  const long stat = ((long)b * p.H + h) * p.Tq + qi;
+  if (qvalid && g == 0) p.delta[stat] = delta;
+  const float lse2 = qvalid ? p.lse[stat] * LOG2E : INFINITY;
+  const float sl2 = p.scale * LOG2E;
+  f32x4 dqt[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dqt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kv0 = 0; kv0 < p.Tk; kv0 += CH) {
+    const int rows = min(CH, p.Tk - kv0);
+    __syncthreads();
+    dma_tile(Ks, p.k + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * DH, p.kv_st, rows, CH, wave, nwaves, lane);
+    dma_tile(Vs, p.v + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * DH, p.kv_st, rows, CH, wave, nwaves, lane);
+    __syncthreads();
+    if (!active) continue;
+    if (p.causal && kv0 > row0 + 15) continue;
+    const int nbl = (rows + 31) / 32;
+    for (int a = 0; a < nbl; ++a) {
+      f32x4 ds[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int jt = 2 * a + t;
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 0, lane), qf0, sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 1, lane), qf1, sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vs, jt * 16, 0, lane), dof0, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vs, jt * 16, 1, lane), dof1, dp, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pr = __builtin_amdgcn_exp2f(sc[r] * sl2 - lse2);
+          if (!PLAIN) pr = keep_at(p, b, h, qvalid ? qi : p.Tq - 1, kv0 + jt * 16 + 4 * g + r) ? pr : 0.f;
+          ds[t][r] = pr * (dp[r] - delta);
+        }
+      }
+      const bf16x8 dsp = pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Ks, a * 32, dt * 16, lane), dsp, dqt[dt], 0, 0, 0);
+    }
+  }
+  if (qvalid) {
+    bf16_t* dqrow = p.dq + (long)b * p.q_sb + (long)qi * p.q_st + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const f32x4 v = dqt[dt] * p.scale;
+      *reinterpret_cast<u32x2*>(dqrow + dt * 16 + 4 * g) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+  }
+}
+
+template <bool PLAIN>
+__global__ __launch_bounds__(512, 4) void attn_bwd_dkv_stream_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* dOs = smem + CH * 128;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * CH * 128);
+  float* delta_s = lse_s + CH;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int row0 = (blockIdx.x * nwaves + wave) * 16;
+  const bool active = row0 < p.Tk;
+  const int kj = row0 + n;
+  const bf16_t* kb = p.k + (long)b * p.kv_sb + h * DH;
+  const bf16_t* vb = p.v + (long)b * p.kv_sb + h * DH;
+  bf16x8 kf0 = {0, 0, 0, 0, 0, 0, 0, 0}, kf1 = kf0, vf0 = kf0, vf1 = kf0;
+  if (active) {
+    kf0 = frag_global(kb, p.kv_st, row0, p.Tk, 0, lane);
+    kf1 = frag_global(kb, p.kv_st, row0, p.Tk, 1, lane);
+    vf0 = frag_global(vb, p.kv_st, row0, p.Tk, 0, lane);
+    vf1 = frag_global(vb, p.kv_st, row0, p.Tk, 1, lane);
+  }
+  const float sl2 = p.scale * LOG2E;
+  f32x4 dkt[4], dvt[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { dkt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int q0 = 0; q0 < p.Tq; q0 += CH) {
+    const int rows = min(CH, p.Tq - q0);
+    __syncthreads();
+    dma_tile(Qs, p.q + (long)b * p.q_sb + (long)q0 * p.q_st + h * DH, p.q_st, rows, CH, wave, nwaves, lane);
+    dma_tile(dOs, p.d_o + (long)b * p.o_sb + (long)q0 * p.o_st + h * DH, p.o_st, rows, CH, wave, nwaves, lane);
+    for (int idx = threadIdx.x; idx < CH * 8; idx += blockDim.x) {
+      const int t = idx >> 3, slot = idx & 7;
+      const int tq = q0 + t;
+      float sacc = 0.f;
+      if (p.delta_ready) {
+        if (slot == 0 && tq < p.Tq) sacc = p.delta[((long)b * p.H + h) * p.Tq + tq];
+      } else if (tq < p.Tq) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(p.d_o + (long)b * p.o_sb + (long)tq * p.o_st + h * DH + slot * 8);
+        const u32x4 c = *reinterpret_cast<const u32x4*>(p.o_in + (long)b * p.o_sb + (long)tq * p.o_st + h * DH + slot * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sacc += bf16lo(a[e]) * bf16lo(c[e]) + bf16hi(a[e]) * bf16hi(c[e]);
+      }
+      if (!p.delta_ready) {
+        sacc += __shfl_xor(sacc, 1, 64);
+        sacc += __shfl_xor(sacc, 2, 64);
+        sacc += __shfl_xor(sacc, 4, 64);
+      }
+      if (slot == 0) {
+        delta_s[t] = sacc;
+        lse_s[t] = tq < p.Tq ? p.lse[((long)b * p.H + h) * p.Tq + tq] * LOG2E : INFINITY;
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+    if (p.causal && q0 + CH - 1 < row0) continue;  // every query of the chunk precedes this kv tile
+    const int nbl = (rows + 31) / 32;
+    for (int a = 0; a < nbl; ++a) {
+      f32x4 pp[2], ds[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int it = 2 * a + t;
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs, it * 16, 0, lane), kf0, sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs, it * 16, 1, lane), kf1, sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dOs, it * 16, 0, lane), vf0, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dOs, it * 16, 1, lane), vf1, dp, 0, 0, 0);
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + it * 16 + 4 * g);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + it * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pr = __builtin_amdgcn_exp2f(sc[r] * sl2 - l4[r]);
+          if (!PLAIN) {
+            const int qi = q0 + it * 16 + 4 * g + r;
+            pr = (qi < p.Tq && keep_at(p, b, h, qi, kj)) ? pr : 0.f;
+          }
+          pp[t][r] = pr;
+          ds[t][r] = pr * (dp[r] - d4[r]);
+        }
+      }
+      const bf16x8 ppk = pack8(pp[0], pp[1]);
+      const bf16x8 dsk = pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(dOs, a * 32, dt * 16, lane), ppk, dvt[dt], 0, 0, 0);
+        dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Qs, a * 32, dt * 16, lane), dsk, dkt[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (active && kj < p.Tk) {
+    bf16_t* dkrow = p.dk + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH;
+    bf16_t* dvrow = p.dv + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const f32x4 kk = dkt[dt] * p.scale;
+      const f32x4 vv = dvt[dt];
+      *reinterpret_cast<u32x2*>(dkrow + dt * 16 + 4 * g) = u32x2{pack_bf16x2(kk[0], kk[1]), pack_bf16x2(kk[2], kk[3])};
+      *reinterpret_cast<u32x2*>(dvrow + dt * 16 + 4 * g) = u32x2{pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3])};
+    }
+  }
+}
+
 // waves per workgroup: ONE workgroup per (batch, head) (the resident K / V — or Q / dO — tiles are
 // loaded once), its waves walk the 16-row tiles in rounds; pick the wave count that leaves the
 // fewest idle slots in the last round (at most 8 waves).
@@ -445,9 +746,7 @@ int check_common(const char* who, const void* q, const void* k, const void* v, i
                  int64_t q_sb, int64_t q_st, int64_t kv_sb, int64_t kv_st, int64_t o_sb, int64_t o_st) {
   CFHIP_REQUIRE(q && k && v, "%s: null q/k/v", who);
   CFHIP_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "%s: empty problem", who);
-  CFHIP_REQUIRE(Tq <= CFHIP_ATTN_MAX_T && Tk <= CFHIP_ATTN_MAX_T,
-                "%s: sequence length (Tq=%d, Tk=%d) exceeds the LDS-resident limit %d", who, Tq, Tk,
-                CFHIP_ATTN_MAX_T);
+  CFHIP_REQUIRE((long)B * 1 <= 65535 && H <= 65535, "%s: B = %d / H = %d exceed the grid limits", who, B, H);
   CFHIP_REQUIRE(q_sb % 8 == 0 && q_st % 8 == 0 && kv_sb % 8 == 0 && kv_st % 8 == 0 && o_sb % 8 == 0 &&
                     o_st % 8 == 0,
                 "%s: strides must be multiples of 8 elements", who);
@@ -502,6 +801,14 @@ extern "C" int cfhip_attn_fwd(const void* q, const void* k, const void* v, void*
   const size_t lds = (size_t)2 * nb * 32 * 128;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bool plain = mask == nullptr && !causal;
+  if (Tq > CFHIP_ATTN_MAX_T || Tk > CFHIP_ATTN_MAX_T) {  // long sequences: chunked K / V, online softmax
+    dim3 sgrid((Tq + 127) / 128, H, B), sblock(512);
+    const size_t slds = (size_t)2 * CH * 128;
+    if (plain) hipLaunchKernelGGL(attn_fwd_stream_kernel<true>, sgrid, sblock, slds, s, p);
+    else hipLaunchKernelGGL(attn_fwd_stream_kernel<false>, sgrid, sblock, slds, s, p);
+    CFHIP_CHECK_LAUNCH("attn_fwd_stream");
+    return CFHIP_OK;
+  }
 #define CFHIP_ATTN_FWD(NB_)                                                                         \
   case NB_:                                                                                         \
     if (plain) hipLaunchKernelGGL((attn_fwd_kernel<NB_, true>), grid, block, lds, s, p);            \
@@ -545,6 +852,26 @@ extern "C" int cfhip_attn_bwd(const void* q, const void* k, const void* v, const
   p.ablate = g_attn_ablate;
   const bool plain = mask == nullptr && !causal;
   CFHIP_REQUIRE((parts & 3) != 0, "attn_bwd: parts must select the dQ pass (1), the dK/dV pass (2) or both (3)");
+  if (Tq > CFHIP_ATTN_MAX_T || Tk > CFHIP_ATTN_MAX_T) {  // long sequences: chunked operands
+    if (parts & 1) {
+      dim3 sgrid((Tq + 127) / 128, H, B);
+      const size_t slds = (size_t)2 * CH * 128;
+      if (plain) hipLaunchKernelGGL(attn_bwd_dq_stream_kernel<true>, sgrid, dim3(512), slds, s, p);
+      else hipLaunchKernelGGL(attn_bwd_dq_stream_kernel<false>, sgrid, dim3(512), slds, s, p);
+      CFHIP_CHECK_LAUNCH("attn_bwd_dq_stream");
+    }
+    if (parts & 2) {
+      dim3 sgrid((Tk + 127) / 128, H, B);
+      const size_t slds = (size_t)2 * CH * 128 + (size_t)2 * CH * sizeof(float);
+      rc = plain ? set_lds(attn_bwd_dkv_stream_kernel<true>, slds, "attn_bwd_dkv_stream")
+                 : set_lds(attn_bwd_dkv_stream_kernel<false>, slds, "attn_bwd_dkv_stream");
+      if (rc != CFHIP_OK) return rc;
+      if (plain) hipLaunchKernelGGL(attn_bwd_dkv_stream_kernel<true>, sgrid, dim3(512), slds, s, p);
+      else hipLaunchKernelGGL(attn_bwd_dkv_stream_kernel<false>, sgrid, dim3(512), slds, s, p);
+      CFHIP_CHECK_LAUNCH("attn_bwd_dkv_stream");
+    }
+    return CFHIP_OK;
+  }
   if (parts & 1) {
     const int nb = (Tk + 31) / 32;
     const int nw = pick_waves(Tq);

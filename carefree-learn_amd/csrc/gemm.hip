@@ -831,7 +831,10 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
   p.bgrad_slabs = nullptr;
   p.k_chunk = ((K + BK_MAX - 1) / BK_MAX) * BK_MAX;
 
-  const bool fast = (K % 8 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (N % 4 == 0) &&
+  // K % 8 is an alignment rule of the k-major operands only (16-byte chunks along k); in the (1,1) layout k is
+  // the row index of both operands and any tail is zero-filled by the DMA's k-range check
+  const bool k_ok = (a_trans && b_trans) || (K % 8 == 0);
+  const bool fast = k_ok && (lda % 8 == 0) && (ldb % 8 == 0) && (N % 4 == 0) &&
                     (ldc % 4 == 0) && (!a_trans || M % 8 == 0) && (!b_trans || N % 8 == 0) &&
                     aligned16(A) && aligned16(B) && aligned16(C) &&
                     (bias == nullptr || aligned16(bias)) && (aux_in == nullptr || aligned16(aux_in)) &&

@@ -125,8 +125,10 @@ int cfhip_layernorm_bwd(const void* dy, const void* x, int x_is_f32, const float
  *
  *   q, k, v, o, dq, dk, dv, do: bf16, addressed as  ptr[b*stride_b + t*stride_t + h*DH + d]
  *   (so the packed [B,T,3,H,DH] projection output is consumed in place and o is written
- *   directly as [B,T,H*DH]).  head_dim DH must be 64.  Tq, Tk <= CFHIP_ATTN_MAX_T (whole K/V of
- *   one head is LDS-resident).  lse: f32 [B,H,Tq] (natural-log sum-exp of the scaled scores).
+ *   directly as [B,T,H*DH]).  head_dim DH must be 64.  Tq, Tk <= CFHIP_ATTN_MAX_T: the whole K/V of
+ *   one head is LDS-resident (one workgroup per (b, h)); longer sequences: the same kernels with an
+ *   outer loop over 256-row chunks (online softmax across chunks in the forward, one workgroup per
+ *   128 query / key rows).  lse: f32 [B,H,Tq] (natural-log sum-exp of the scaled scores).
  *   mask: optional uint8 "keep" mask (1 = attend), addressed mask[b*ms_b + h*ms_h + i*ms_q + j]
  *   (strides may be 0 for broadcasting), or NULL.  causal != 0 additionally masks j > i.
  *   bwd needs delta: f32 [B,H,Tq] scratch (rowsum(do * o), computed inside).

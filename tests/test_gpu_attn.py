@@ -119,3 +119,55 @@ def test_rows_sum_property_full_size():
     qkv[..., 2 * d:] = 1.0
     o, _ = ops.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], h)
     assert (o.float() - 1.0).abs().max().item() < 1.0 / 64
+
+
+LONG_CASES = [(2, 257, 2), (1, 577, 3), (1, 1024, 2), (2, 300, 1)]
+
+
+@pytest.mark.parametrize("b,t,h", LONG_CASES)
+def test_long_sequences_stream_kernels(b, t, h):
+    """T > 256 (the chunked / online-softmax kernels): ViT at 384^2 has T = 577, a 32x32 latent 1024 tokens"""
+    qkv = _qkv(b, t, h, 300 + t, scale=1.5)
+    d = h * 64
+    d_o = torch.randn(b, t, d, generator=torch.Generator().manual_seed(t)).to(torch.bfloat16)
+    want_o, want_g = _oracle(qkv, h, None, d_o)
+    dev = qkv.to(DEV)
+    o, lse = ops.attn_fwd(dev[..., :d], dev[..., d:2 * d], dev[..., 2 * d:], h)
+    assert_close(o, want_o, 1e-2, f"stream fwd {b}x{t}x{h}")
+    s = (_heads(qkv[..., :d], h) @ _heads(qkv[..., d:2 * d], h).transpose(-1, -2)) / 8.0
+    assert_close(lse, torch.logsumexp(s, -1), 1e-4, "stream lse")
+    for parts in ((3,), (1, 2)):  # both passes in one call, and separately (the dK/dV pass then recomputes delta)
+        dqkv = torch.zeros_like(dev)
+        for part in parts:
+            ops.attn_bwd(dev[..., :d], dev[..., d:2 * d], dev[..., 2 * d:], o, d_o.to(DEV), lse, h,
+                         dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], parts=part)
+        for nm, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+            assert_close(dqkv[..., sl], want_g[..., sl], 2e-2, f"stream {nm} {b}x{t}x{h} parts {parts}", abs_floor=1e-6)
+
+
+def test_long_sequences_masks_causal_and_cross_lengths():
+    b, t, h = 2, 333, 2
+    d = h * 64
+    qkv = _qkv(b, t, h, 17)
+    dev = qkv.to(DEV)
+    d_o = torch.randn(b, t, d, generator=torch.Generator().manual_seed(18)).to(torch.bfloat16)
+    causal_keep = ~torch.triu(torch.ones(t, t, dtype=torch.bool), diagonal=1)
+    rnd = torch.rand(b, h, t, t, generator=torch.Generator().manual_seed(19)) < 0.7
+    rnd[..., torch.arange(t), torch.arange(t)] = True
+    for tag, keep, kw in (("causal flag", causal_keep, dict(causal=True)),
+                          ("random mask", rnd, dict(mask=rnd.to(DEV)))):
+        want_o, want_g = _oracle(qkv, h, keep, d_o)
+        o, lse = ops.attn_fwd(dev[..., :d], dev[..., d:2 * d], dev[..., 2 * d:], h, **kw)
+        assert_close(o, want_o, 1e-2, f"stream fwd {tag}")
+        dqkv = torch.zeros_like(dev)
+        ops.attn_bwd(dev[..., :d], dev[..., d:2 * d], dev[..., 2 * d:], o, d_o.to(DEV), lse, h,
+                     dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], **kw)
+        assert_close(dqkv, want_g, 2e-2, f"stream bwd {tag}")
+    # Tq short, Tk long (cross attention over a long context) and the reverse
+    g = torch.Generator().manual_seed(21)
+    for tq, tk in ((37, 700), (513, 40)):
+        q = (torch.randn(b, tq, d, generator=g) * 2).to(torch.bfloat16)
+        kv = (torch.randn(b, tk, 2, d, generator=g) * 2).to(torch.bfloat16)
+        o, lse = ops.attn_fwd(q.to(DEV), kv.to(DEV)[:, :, 0], kv.to(DEV)[:, :, 1], h)
+        want = O.sdp_attention(_heads(q, h), _heads(kv[:, :, 0], h), _heads(kv[:, :, 1], h))
+        assert_close(o, want.permute(0, 2, 1, 3).reshape(b, tq, d), 1e-2, f"stream cross {tq}x{tk}")

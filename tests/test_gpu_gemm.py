@@ -196,3 +196,18 @@ def test_every_tile_config(cfg):
                 assert_close(got, _ref(a, b, a_trans, b_trans), 2e-5, f"cfg{cfg} {layout} {m}x{n}x{k}")
     finally:
         ops.set_option("gemm_config", -1)
+
+
+def test_dw_layout_with_unaligned_token_count():
+    """dW = dY^T X where the token count (the GEMM's K) is not a multiple of 8 — e.g. batch 3 x 197 tokens = 591 —
+    must stay on the MFMA path (split-K included): K is the row index of both operands in this layout."""
+    for kd in (591, 650, 1379):
+        n, k = 256, 384
+        dy, x = _mk(kd, n, 50).to(DEV), _mk(kd, k, 51).to(DEV)
+        want = dy.float().t().double() @ x.float().double()
+        for split in (1, 3, ops.pick_split_k(n, k, kd)):
+            gw = torch.empty(n, k, dtype=torch.float32, device=DEV)
+            gb = torch.empty(n, dtype=torch.float32, device=DEV)
+            ops.gemm(dy, x, a_trans=True, b_trans=True, out=gw, split_k=split, bias_grad=gb)
+            assert_close(gw, want, 2e-5, f"dW K={kd} split {split}")
+            assert_close(gb, dy.float().sum(0), 2e-5, f"db K={kd} split {split}")

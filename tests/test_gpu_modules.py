@@ -193,3 +193,31 @@ def test_vit_b16_loss_within_1e3_of_cpu_reference():
     got_loss = loss.item() / 2
     assert abs(got_loss - want_loss) <= 1e-3 * abs(want_loss), (got_loss, want_loss)
     assert_close(logits, want, 2e-2, "ViT-B/16 logits")
+
+
+def test_vit_long_sequence_matches_oracle():
+    """A ViT whose token count exceeds the LDS-resident attention limit (img 288, patch 16 -> 18 x 18 + 1 = 325
+    tokens): logits, loss and every gradient vs the fp32 CPU oracle (oracle/vit_oracle.py, pinned against the
+    reference).  Exercises the chunked attention kernels inside the fused block stack."""
+    import vit_oracle as O
+
+    torch.manual_seed(3)
+    cfg = dict(patch_size=16, latent_dim=128, num_layers=2)
+    m = C.VanillaClassifier(3, 10, 288, 128, encoder="vit", encoder_config=cfg)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(2, 3, 288, 288, generator=g)
+    labels = torch.randint(0, 10, (2, 1), generator=g)
+    want_loss, want_logits, want_grads = O.loss_and_grads(img, labels, sd, num_heads=2, num_layers=2)
+    m = m.to(DEV)
+    logits = m(img.to(DEV))["predictions"]
+    assert_close(logits, want_logits, 1.5e-2, "long-sequence logits")
+    loss = torch.nn.functional.cross_entropy(logits, labels.view(-1).to(DEV))
+    assert abs(loss.item() - want_loss.item()) <= 3e-3 * abs(want_loss.item())
+    loss.backward()
+    for k, v in _grads(m).items():
+        assert_close(v, want_grads[k], 4e-2, f"long-sequence grad {k}", abs_floor=2e-4)

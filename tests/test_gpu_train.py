@@ -120,3 +120,20 @@ def test_ema_one_kernel_bit_exact():
         ema.train()
         for n, p in named:
             assert torch.equal(p.data, live[n])
+
+
+def test_train_step_with_token_count_not_multiple_of_8():
+    """batch sizes whose B * T is not a multiple of 8 (37 x 17 = 629 token rows): every GEMM layout of the step —
+    in particular the split-K dW form, whose K is the token count — must run and train"""
+    import cflearn_amd as C
+    from cflearn_amd.engine import TrainStep
+
+    torch.manual_seed(0)
+    m = C.VanillaClassifier(3, 10, 32, 128, encoder="vit", encoder_config=dict(patch_size=8, latent_dim=128, num_layers=2))
+    m = m.to(DEV)
+    ts = TrainStep(m, lr=1e-3)
+    g = torch.Generator().manual_seed(1)
+    img = torch.randn(37, 3, 32, 32, generator=g).to(DEV)
+    labels = torch.randint(0, 10, (37,), generator=g).to(DEV)
+    losses = [ts.step(img, labels).item() / 37 for _ in range(12)]
+    assert all(l == l for l in losses) and losses[-1] < 0.7 * losses[0], losses
