@@ -45,6 +45,16 @@ SIGNATURES = {
         [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64,
          c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_int, _P],
     ),
+    "cfhip_attn_fwd_dh": (
+        c_int,
+        [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
+         c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, _P],
+    ),
+    "cfhip_attn_bwd_dh": (
+        c_int,
+        [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64,
+         c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_int, _P],
+    ),
     "cfhip_im2row": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cfhip_assemble_tokens_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "cfhip_assemble_tokens_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -36,6 +36,7 @@ struct AttnParams {
   long ms_b, ms_h, ms_q;
   float scale;
   int causal;
+  int dh;           // head_dim of the general kernels (the resident fast kernels are head_dim 64 only)
   int delta_ready;  // dK/dV pass: p.delta was already written by the dQ pass of the same call
   int ablate;       // benchmarking only (forward): bit0 skip the K/V DMA, bit1 skip the tile loop, bit2 skip stores
 };
@@ -433,63 +434,107 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_kernel(AttnParams p, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Long sequences (T > 256): the same three kernels with an outer loop over 256-row CHUNKS of the operand that
-// the short form keeps resident in LDS.  Workgroup = (128-row chunk of the walking operand, head, batch), one
-// 16-row tile per wave, the chunk staged by LDS-DMA between two barriers.  Forward: online softmax across chunks
-// (running max m, sum l, rescaled O); backward: p = exp2(s * scale - lse) with the saved lse, so the chunks just
-// accumulate.  K / V (or Q / dO) are re-read once per 128-row workgroup: (T / 128) x the operand, from L2.
+// General form: any sequence length, head_dim = any multiple of 8 up to 192 (UNet cross-attention heads of 40 / 80 /
+// 160 channels, convs / mixed_stacks/api.py:766-893).  The same three kernels with (1) an outer loop over CHUNKS of
+// the operand that the short form keeps resident in LDS and (2) the head dimension handled as NH = ceil(dh / 64)
+// zero-padded 64-column HALVES, each an ordinary swizzled [rows][64] tile (columns >= dh are range-checked to zero
+// by the DMA / never loaded into fragments / never stored).  Workgroup = (128-row chunk of the walking operand,
+// head, batch), one 16-row tile per wave.  Forward: online softmax across chunks (running max m, sum l, rescaled O);
+// backward: p = exp2(s * scale - lse) with the saved lse, so chunks just accumulate.  The chunked operand is re-read
+// once per 128-row workgroup, from L2.
 // ------------------------------------------------------------------------------------------------
-constexpr int CH = 256;          // rows per staged chunk
-constexpr int CHB = CH / 32;     // 32-row blocks per chunk
+template <int NH>
+struct Gen {
+  static constexpr int CH = NH == 1 ? 256 : 128;  // rows per staged chunk (LDS: 2 operands x NH halves x CH x 128 B)
+  static constexpr int CHB = CH / 32;
+  static constexpr int HALF_BYTES = CH * 128;
+  static constexpr int OPER_BYTES = NH * HALF_BYTES;
+};
 
-template <bool PLAIN>
-__global__ __launch_bounds__(512, 4) void attn_fwd_stream_kernel(AttnParams p) {
+// one 64-column half of `rows_pad` rows -> swizzled [rows][64] tile; columns >= dh and rows >= rows_valid are zero
+__device__ __forceinline__ void dma_half(char* tile, const bf16_t* base, long stride_t, int rows_valid, int rows_pad,
+                                         int half, int dh, int wave, int nwaves, int lane) {
+  long bytes = ((long)(rows_valid - 1) * stride_t + dh) * 2;
+  if (bytes > 0x7fffffffL) bytes = 0x7fffffffL;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, (int)bytes, 0x00020000);
+  const int r8 = lane >> 3, slot = lane & 7;
+  for (int inst = wave; inst < rows_pad / 8; inst += nwaves) {
+    const int row = inst * 8 + r8;
+    const int chunk = slot ^ ((row >> 1) & 7);
+    const bool ok = row < rows_valid && half * 64 + chunk * 8 < dh;
+    const unsigned off = ok ? (unsigned)(row * stride_t * 2 + half * 128 + chunk * 16) : 0x80000000u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(tile + inst * 1024), 16, off, 0, 0, 0);
+  }
+}
+template <int NH>
+__device__ __forceinline__ void dma_oper(char* tiles, const bf16_t* base, long stride_t, int rows_valid, int dh,
+                                         int wave, int nwaves, int lane) {
+#pragma unroll
+  for (int hf = 0; hf < NH; ++hf)
+    dma_half(tiles + hf * Gen<NH>::HALF_BYTES, base, stride_t, rows_valid, Gen<NH>::CH, hf, dh, wave, nwaves, lane);
+}
+
+// row-operand fragment ks (32 columns) of the wave's own 16 rows straight from global memory, zero beyond dh
+__device__ __forceinline__ bf16x8 frag_global_dh(const bf16_t* base, long stride_t, int row0, int rows_valid, int ks,
+                                                 int lane, int dh) {
+  const int row = row0 + (lane & 15);
+  const int col = ks * 32 + (lane >> 4) * 8;
+  bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (row < rows_valid && col < dh) r = *reinterpret_cast<const bf16x8*>(base + (long)row * stride_t + col);
+  return r;
+}
+
+template <int NH, bool PLAIN>
+__global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_fwd_kernel(AttnParams p) {
+  using G = Gen<NH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
-  char* Vs = smem + CH * 128;
+  char* Vs = smem + G::OPER_BYTES;
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const bf16_t* kb = p.k + (long)b * p.kv_sb + h * DH;
-  const bf16_t* vb = p.v + (long)b * p.kv_sb + h * DH;
-  const bf16_t* qb = p.q + (long)b * p.q_sb + h * DH;
+  const int dh = p.dh;
+  const bf16_t* kb = p.k + (long)b * p.kv_sb + h * dh;
+  const bf16_t* vb = p.v + (long)b * p.kv_sb + h * dh;
+  const bf16_t* qb = p.q + (long)b * p.q_sb + h * dh;
   const int row0 = (blockIdx.x * nwaves + wave) * 16;
   const bool active = row0 < p.Tq;  // inactive waves still stage and hit the barriers
   const int qi = row0 + i;
-  bf16x8 qf0 = {0, 0, 0, 0, 0, 0, 0, 0}, qf1 = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (active) {
-    qf0 = frag_global(qb, p.q_st, row0, p.Tq, 0, lane);
-    qf1 = frag_global(qb, p.q_st, row0, p.Tq, 1, lane);
-  }
+  bf16x8 qf[2 * NH];
+#pragma unroll
+  for (int ks = 0; ks < 2 * NH; ++ks) qf[ks] = frag_global_dh(qb, p.q_st, row0, active ? p.Tq : 0, ks, lane, dh);
   const float sl2 = p.scale * LOG2E;
   float m = -INFINITY, l = 0.f;
-  f32x4 ot[4];
+  f32x4 ot[4 * NH];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int dt = 0; dt < 4 * NH; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int kv0 = 0; kv0 < p.Tk; kv0 += CH) {
-    const int rows = min(CH, p.Tk - kv0);
+  for (int kv0 = 0; kv0 < p.Tk; kv0 += G::CH) {
+    const int rows = min(G::CH, p.Tk - kv0);
     __syncthreads();  // every wave is done with the previous chunk
-    dma_tile(Ks, kb + (long)kv0 * p.kv_st, p.kv_st, rows, CH, wave, nwaves, lane);
-    dma_tile(Vs, vb + (long)kv0 * p.kv_st, p.kv_st, rows, CH, wave, nwaves, lane);
+    dma_oper<NH>(Ks, kb + (long)kv0 * p.kv_st, p.kv_st, rows, dh, wave, nwaves, lane);
+    dma_oper<NH>(Vs, vb + (long)kv0 * p.kv_st, p.kv_st, rows, dh, wave, nwaves, lane);
     __syncthreads();  // vmcnt(0) + barrier
     if (!active) continue;
     if (p.causal && kv0 > row0 + 15) continue;  // chunk entirely in the future of this tile (wave-uniform)
-    f32x4 st[2 * CHB];
+    f32x4 st[2 * G::CHB];
 #pragma unroll
-    for (int jt = 0; jt < 2 * CHB; ++jt) {
+    for (int jt = 0; jt < 2 * G::CHB; ++jt) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 0, lane), qf0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 1, lane), qf1, acc, 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 2 * NH; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks + (ks >> 1) * G::HALF_BYTES, jt * 16, ks & 1, lane),
+                                                      qf[ks], acc, 0, 0, 0);
       st[jt] = acc;
       if (jt & 1) __builtin_amdgcn_sched_barrier(0);
     }
     float mx = -INFINITY;
-    const bool tail = kv0 + CH > p.Tk;  // wave-uniform: only the last chunk needs the j < Tk test
+    const bool tail = kv0 + G::CH > p.Tk;  // wave-uniform: only the last chunk needs the j < Tk test
 #pragma unroll
-    for (int jt = 0; jt < 2 * CHB; ++jt) {
+    for (int jt = 0; jt < 2 * G::CHB; ++jt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = kv0 + jt * 16 + 4 * g + r;
@@ -511,7 +556,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_stream_kernel(AttnParams p) {
     const float alpha = __builtin_amdgcn_exp2f(m - m_use);  // m = -inf on the first chunk: 0
     float ls = 0.f;
 #pragma unroll
-    for (int jt = 0; jt < 2 * CHB; ++jt) {
+    for (int jt = 0; jt < 2 * G::CHB; ++jt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float e = __builtin_amdgcn_exp2f(st[jt][r] - m_use);
@@ -522,75 +567,74 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_stream_kernel(AttnParams p) {
     l = l * alpha + group_sum(ls);
     m = m_new;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) ot[dt] *= alpha;
+    for (int dt = 0; dt < 4 * NH; ++dt) ot[dt] *= alpha;
 #pragma unroll
-    for (int a = 0; a < CHB; ++a) {
+    for (int a = 0; a < G::CHB; ++a) {
       const bf16x8 pa = pack8(st[2 * a], st[2 * a + 1]);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Vs, a * 32, dt * 16, lane), pa, ot[dt], 0, 0, 0);
+      for (int dt = 0; dt < 4 * NH; ++dt)
+        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            frag_cols(Vs + (dt >> 2) * G::HALF_BYTES, a * 32, (dt & 3) * 16, lane), pa, ot[dt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (active && qi < p.Tq) {
     const float inv = 1.0f / l;
-    bf16_t* orow = p.o + (long)b * p.o_sb + (long)qi * p.o_st + h * DH;
+    bf16_t* orow = p.o + (long)b * p.o_sb + (long)qi * p.o_st + h * dh;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
+    for (int dt = 0; dt < 4 * NH; ++dt) {
+      const int col = dt * 16 + 4 * g;
+      if (col >= dh) continue;  // dh % 8 == 0: a 4-column group is entirely inside or outside
       const f32x4 v = ot[dt] * inv;
-      *reinterpret_cast<u32x2*>(orow + dt * 16 + 4 * g) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(orow + col) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
     }
     if (g == 0 && p.lse != nullptr) p.lse[((long)b * p.H + h) * p.Tq + qi] = (m + log2f(l)) * (1.0f / LOG2E);
   }
 }
 
-template <bool PLAIN>
-__global__ __launch_bounds__(512, 4) void attn_bwd_dq_stream_kernel(AttnParams p) {
+template <int NH, bool PLAIN>
+__global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_bwd_dq_kernel(AttnParams p) {
+  using G = Gen<NH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
-  char* Vs = smem + CH * 128;
+  char* Vs = smem + G::OPER_BYTES;
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
   const int i = lane & 15, g = lane >> 4;
+  const int dh = p.dh;
   const int row0 = (blockIdx.x * nwaves + wave) * 16;
   const bool active = row0 < p.Tq;
   const int qi = row0 + i;
   const bool qvalid = active && qi < p.Tq;
-  const bf16_t* qb = p.q + (long)b * p.q_sb + h * DH;
-  const bf16_t* dob = p.d_o + (long)b * p.o_sb + h * DH;
-  const bf16_t* ob = p.o_in + (long)b * p.o_sb + h * DH;
-  bf16x8 qf0 = {0, 0, 0, 0, 0, 0, 0, 0}, qf1 = qf0, dof0 = qf0, dof1 = qf0;
-  float delta = 0.f;
-  if (active) {
-    qf0 = frag_global(qb, p.q_st, row0, p.Tq, 0, lane);
-    qf1 = frag_global(qb, p.q_st, row0, p.Tq, 1, lane);
-    dof0 = frag_global(dob, p.o_st, row0, p.Tq, 0, lane);
-    dof1 = frag_global(dob, p.o_st, row0, p.Tq, 1, lane);
-    const bf16x8 of0 = frag_global(ob, p.o_st, row0, p.Tq, 0, lane);
-    const bf16x8 of1 = frag_global(ob, p.o_st, row0, p.Tq, 1, lane);
-    float sacc = 0.f;
+  const bf16_t* qb = p.q + (long)b * p.q_sb + h * dh;
+  const bf16_t* dob = p.d_o + (long)b * p.o_sb + h * dh;
+  const bf16_t* ob = p.o_in + (long)b * p.o_sb + h * dh;
+  bf16x8 qf[2 * NH], dof[2 * NH];
+  float sacc = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      sacc += bf16_to_f32((bf16_t)dof0[e]) * bf16_to_f32((bf16_t)of0[e]);
-      sacc += bf16_to_f32((bf16_t)dof1[e]) * bf16_to_f32((bf16_t)of1[e]);
-    }
-    delta = group_sum(sacc);
+  for (int ks = 0; ks < 2 * NH; ++ks) {
+    qf[ks] = frag_global_dh(qb, p.q_st, row0, active ? p.Tq : 0, ks, lane, dh);
+    dof[ks] = frag_global_dh(dob, p.o_st, row0, active ? p.Tq : 0, ks, lane, dh);
+    const bf16x8 of = frag_global_dh(ob, p.o_st, row0, active ? p.Tq : 0, ks, lane, dh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sacc += bf16_to_f32((bf16_t)dof[ks][e]) * bf16_to_f32((bf16_t)of[e]);
   }
+  const float delta = group_sum(sacc);
   const long stat = ((long)b * p.H + h) * p.Tq + qi;
   if (qvalid && g == 0) p.delta[stat] = delta;
   const float lse2 = qvalid ? p.lse[stat] * LOG2E : INFINITY;
   const float sl2 = p.scale * LOG2E;
-  f32x4 dqt[4];
+  f32x4 dqt[4 * NH];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) dqt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int dt = 0; dt < 4 * NH; ++dt) dqt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int kv0 = 0; kv0 < p.Tk; kv0 += CH) {
-    const int rows = min(CH, p.Tk - kv0);
+  for (int kv0 = 0; kv0 < p.Tk; kv0 += G::CH) {
+    const int rows = min(G::CH, p.Tk - kv0);
     __syncthreads();
-    dma_tile(Ks, p.k + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * DH, p.kv_st, rows, CH, wave, nwaves, lane);
-    dma_tile(Vs, p.v + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * DH, p.kv_st, rows, CH, wave, nwaves, lane);
+    dma_oper<NH>(Ks, p.k + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * dh, p.kv_st, rows, dh, wave, nwaves, lane);
+    dma_oper<NH>(Vs, p.v + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * dh, p.kv_st, rows, dh, wave, nwaves, lane);
     __syncthreads();
     if (!active) continue;
     if (p.causal && kv0 > row0 + 15) continue;
@@ -601,10 +645,13 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_stream_kernel(AttnParams p
       for (int t = 0; t < 2; ++t) {
         const int jt = 2 * a + t;
         f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 0, lane), qf0, sc, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 1, lane), qf1, sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vs, jt * 16, 0, lane), dof0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vs, jt * 16, 1, lane), dof1, dp, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 2 * NH; ++ks) {
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks + (ks >> 1) * G::HALF_BYTES, jt * 16, ks & 1, lane),
+                                                       qf[ks], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vs + (ks >> 1) * G::HALF_BYTES, jt * 16, ks & 1, lane),
+                                                       dof[ks], dp, 0, 0, 0);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float pr = __builtin_amdgcn_exp2f(sc[r] * sl2 - lse2);
@@ -614,79 +661,83 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_stream_kernel(AttnParams p
       }
       const bf16x8 dsp = pack8(ds[0], ds[1]);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Ks, a * 32, dt * 16, lane), dsp, dqt[dt], 0, 0, 0);
+      for (int dt = 0; dt < 4 * NH; ++dt)
+        dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            frag_cols(Ks + (dt >> 2) * G::HALF_BYTES, a * 32, (dt & 3) * 16, lane), dsp, dqt[dt], 0, 0, 0);
     }
   }
   if (qvalid) {
-    bf16_t* dqrow = p.dq + (long)b * p.q_sb + (long)qi * p.q_st + h * DH;
+    bf16_t* dqrow = p.dq + (long)b * p.q_sb + (long)qi * p.q_st + h * dh;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
+    for (int dt = 0; dt < 4 * NH; ++dt) {
+      const int col = dt * 16 + 4 * g;
+      if (col >= dh) continue;
       const f32x4 v = dqt[dt] * p.scale;
-      *reinterpret_cast<u32x2*>(dqrow + dt * 16 + 4 * g) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(dqrow + col) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
     }
   }
 }
 
-template <bool PLAIN>
-__global__ __launch_bounds__(512, 4) void attn_bwd_dkv_stream_kernel(AttnParams p) {
+template <int NH, bool PLAIN>
+__global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_bwd_dkv_kernel(AttnParams p) {
+  using G = Gen<NH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
-  char* dOs = smem + CH * 128;
-  float* lse_s = reinterpret_cast<float*>(smem + 2 * CH * 128);
-  float* delta_s = lse_s + CH;
+  char* dOs = smem + G::OPER_BYTES;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * G::OPER_BYTES);
+  float* delta_s = lse_s + G::CH;
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
   const int n = lane & 15, g = lane >> 4;
+  const int dh = p.dh;
   const int row0 = (blockIdx.x * nwaves + wave) * 16;
   const bool active = row0 < p.Tk;
   const int kj = row0 + n;
-  const bf16_t* kb = p.k + (long)b * p.kv_sb + h * DH;
-  const bf16_t* vb = p.v + (long)b * p.kv_sb + h * DH;
-  bf16x8 kf0 = {0, 0, 0, 0, 0, 0, 0, 0}, kf1 = kf0, vf0 = kf0, vf1 = kf0;
-  if (active) {
-    kf0 = frag_global(kb, p.kv_st, row0, p.Tk, 0, lane);
-    kf1 = frag_global(kb, p.kv_st, row0, p.Tk, 1, lane);
-    vf0 = frag_global(vb, p.kv_st, row0, p.Tk, 0, lane);
-    vf1 = frag_global(vb, p.kv_st, row0, p.Tk, 1, lane);
+  const bf16_t* kb = p.k + (long)b * p.kv_sb + h * dh;
+  const bf16_t* vb = p.v + (long)b * p.kv_sb + h * dh;
+  bf16x8 kf[2 * NH], vf[2 * NH];
+#pragma unroll
+  for (int ks = 0; ks < 2 * NH; ++ks) {
+    kf[ks] = frag_global_dh(kb, p.kv_st, row0, active ? p.Tk : 0, ks, lane, dh);
+    vf[ks] = frag_global_dh(vb, p.kv_st, row0, active ? p.Tk : 0, ks, lane, dh);
   }
   const float sl2 = p.scale * LOG2E;
-  f32x4 dkt[4], dvt[4];
+  f32x4 dkt[4 * NH], dvt[4 * NH];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) { dkt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int dt = 0; dt < 4 * NH; ++dt) { dkt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int dslots = dh / 8;  // 16-byte slots of one row of dO / O
 
-  for (int q0 = 0; q0 < p.Tq; q0 += CH) {
-    const int rows = min(CH, p.Tq - q0);
+  for (int q0 = 0; q0 < p.Tq; q0 += G::CH) {
+    const int rows = min(G::CH, p.Tq - q0);
     __syncthreads();
-    dma_tile(Qs, p.q + (long)b * p.q_sb + (long)q0 * p.q_st + h * DH, p.q_st, rows, CH, wave, nwaves, lane);
-    dma_tile(dOs, p.d_o + (long)b * p.o_sb + (long)q0 * p.o_st + h * DH, p.o_st, rows, CH, wave, nwaves, lane);
-    for (int idx = threadIdx.x; idx < CH * 8; idx += blockDim.x) {
-      const int t = idx >> 3, slot = idx & 7;
+    dma_oper<NH>(Qs, p.q + (long)b * p.q_sb + (long)q0 * p.q_st + h * dh, p.q_st, rows, dh, wave, nwaves, lane);
+    dma_oper<NH>(dOs, p.d_o + (long)b * p.o_sb + (long)q0 * p.o_st + h * dh, p.o_st, rows, dh, wave, nwaves, lane);
+    // lse and delta_i = sum_d dO[i][d] * O[i][d] of the chunk's rows: thread t of the first CH threads owns row t
+    for (int t = threadIdx.x; t < G::CH; t += blockDim.x) {
       const int tq = q0 + t;
       float sacc = 0.f;
-      if (p.delta_ready) {
-        if (slot == 0 && tq < p.Tq) sacc = p.delta[((long)b * p.H + h) * p.Tq + tq];
-      } else if (tq < p.Tq) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(p.d_o + (long)b * p.o_sb + (long)tq * p.o_st + h * DH + slot * 8);
-        const u32x4 c = *reinterpret_cast<const u32x4*>(p.o_in + (long)b * p.o_sb + (long)tq * p.o_st + h * DH + slot * 8);
+      if (tq < p.Tq) {
+        if (p.delta_ready) {
+          sacc = p.delta[((long)b * p.H + h) * p.Tq + tq];
+        } else {
+          const bf16_t* dor = p.d_o + (long)b * p.o_sb + (long)tq * p.o_st + h * dh;
+          const bf16_t* orr = p.o_in + (long)b * p.o_sb + (long)tq * p.o_st + h * dh;
+          for (int sl = 0; sl < dslots; ++sl) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(dor + sl * 8);
+            const u32x4 c = *reinterpret_cast<const u32x4*>(orr + sl * 8);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sacc += bf16lo(a[e]) * bf16lo(c[e]) + bf16hi(a[e]) * bf16hi(c[e]);
+            for (int e = 0; e < 4; ++e) sacc += bf16lo(a[e]) * bf16lo(c[e]) + bf16hi(a[e]) * bf16hi(c[e]);
+          }
+        }
       }
-      if (!p.delta_ready) {
-        sacc += __shfl_xor(sacc, 1, 64);
-        sacc += __shfl_xor(sacc, 2, 64);
-        sacc += __shfl_xor(sacc, 4, 64);
-      }
-      if (slot == 0) {
-        delta_s[t] = sacc;
-        lse_s[t] = tq < p.Tq ? p.lse[((long)b * p.H + h) * p.Tq + tq] * LOG2E : INFINITY;
-      }
+      delta_s[t] = sacc;
+      lse_s[t] = tq < p.Tq ? p.lse[((long)b * p.H + h) * p.Tq + tq] * LOG2E : INFINITY;
     }
     __syncthreads();
     if (!active) continue;
-    if (p.causal && q0 + CH - 1 < row0) continue;  // every query of the chunk precedes this kv tile
+    if (p.causal && q0 + G::CH - 1 < row0) continue;  // every query of the chunk precedes this kv tile
     const int nbl = (rows + 31) / 32;
     for (int a = 0; a < nbl; ++a) {
       f32x4 pp[2], ds[2];
@@ -694,10 +745,13 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_stream_kernel(AttnParams 
       for (int t = 0; t < 2; ++t) {
         const int it = 2 * a + t;
         f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs, it * 16, 0, lane), kf0, sc, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs, it * 16, 1, lane), kf1, sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dOs, it * 16, 0, lane), vf0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dOs, it * 16, 1, lane), vf1, dp, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 2 * NH; ++ks) {
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs + (ks >> 1) * G::HALF_BYTES, it * 16, ks & 1, lane),
+                                                       kf[ks], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dOs + (ks >> 1) * G::HALF_BYTES, it * 16, ks & 1, lane),
+                                                       vf[ks], dp, 0, 0, 0);
+        }
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + it * 16 + 4 * g);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + it * 16 + 4 * g);
 #pragma unroll
@@ -714,21 +768,25 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_stream_kernel(AttnParams 
       const bf16x8 ppk = pack8(pp[0], pp[1]);
       const bf16x8 dsk = pack8(ds[0], ds[1]);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(dOs, a * 32, dt * 16, lane), ppk, dvt[dt], 0, 0, 0);
-        dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Qs, a * 32, dt * 16, lane), dsk, dkt[dt], 0, 0, 0);
+      for (int dt = 0; dt < 4 * NH; ++dt) {
+        dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            frag_cols(dOs + (dt >> 2) * G::HALF_BYTES, a * 32, (dt & 3) * 16, lane), ppk, dvt[dt], 0, 0, 0);
+        dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            frag_cols(Qs + (dt >> 2) * G::HALF_BYTES, a * 32, (dt & 3) * 16, lane), dsk, dkt[dt], 0, 0, 0);
       }
     }
   }
   if (active && kj < p.Tk) {
-    bf16_t* dkrow = p.dk + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH;
-    bf16_t* dvrow = p.dv + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH;
+    bf16_t* dkrow = p.dk + (long)b * p.kv_sb + (long)kj * p.kv_st + h * dh;
+    bf16_t* dvrow = p.dv + (long)b * p.kv_sb + (long)kj * p.kv_st + h * dh;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
+    for (int dt = 0; dt < 4 * NH; ++dt) {
+      const int col = dt * 16 + 4 * g;
+      if (col >= dh) continue;
       const f32x4 kk = dkt[dt] * p.scale;
       const f32x4 vv = dvt[dt];
-      *reinterpret_cast<u32x2*>(dkrow + dt * 16 + 4 * g) = u32x2{pack_bf16x2(kk[0], kk[1]), pack_bf16x2(kk[2], kk[3])};
-      *reinterpret_cast<u32x2*>(dvrow + dt * 16 + 4 * g) = u32x2{pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3])};
+      *reinterpret_cast<u32x2*>(dkrow + col) = u32x2{pack_bf16x2(kk[0], kk[1]), pack_bf16x2(kk[2], kk[3])};
+      *reinterpret_cast<u32x2*>(dvrow + col) = u32x2{pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3])};
     }
   }
 }
@@ -768,6 +826,49 @@ int set_lds(K kernel, size_t bytes, const char* who) {
   return CFHIP_OK;
 }
 
+template <int NH>
+int launch_gen_fwd(const AttnParams& p, bool plain, hipStream_t s) {
+  dim3 grid((p.Tq + 127) / 128, p.H, p.B);
+  const size_t lds = (size_t)2 * Gen<NH>::OPER_BYTES;
+  int rc = plain ? set_lds(attn_gen_fwd_kernel<NH, true>, lds, "attn_fwd") : set_lds(attn_gen_fwd_kernel<NH, false>, lds, "attn_fwd");
+  if (rc != CFHIP_OK) return rc;
+  if (plain) hipLaunchKernelGGL((attn_gen_fwd_kernel<NH, true>), grid, dim3(512), lds, s, p);
+  else hipLaunchKernelGGL((attn_gen_fwd_kernel<NH, false>), grid, dim3(512), lds, s, p);
+  CFHIP_CHECK_LAUNCH("attn_gen_fwd");
+  return CFHIP_OK;
+}
+
+template <int NH>
+int launch_gen_bwd(const AttnParams& p, bool plain, int parts, hipStream_t s) {
+  if (parts & 1) {
+    dim3 grid((p.Tq + 127) / 128, p.H, p.B);
+    const size_t lds = (size_t)2 * Gen<NH>::OPER_BYTES;
+    int rc = plain ? set_lds(attn_gen_bwd_dq_kernel<NH, true>, lds, "attn_bwd_dq")
+                   : set_lds(attn_gen_bwd_dq_kernel<NH, false>, lds, "attn_bwd_dq");
+    if (rc != CFHIP_OK) return rc;
+    if (plain) hipLaunchKernelGGL((attn_gen_bwd_dq_kernel<NH, true>), grid, dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((attn_gen_bwd_dq_kernel<NH, false>), grid, dim3(512), lds, s, p);
+    CFHIP_CHECK_LAUNCH("attn_gen_bwd_dq");
+  }
+  if (parts & 2) {
+    dim3 grid((p.Tk + 127) / 128, p.H, p.B);
+    const size_t lds = (size_t)2 * Gen<NH>::OPER_BYTES + (size_t)2 * Gen<NH>::CH * sizeof(float);
+    int rc = plain ? set_lds(attn_gen_bwd_dkv_kernel<NH, true>, lds, "attn_bwd_dkv")
+                   : set_lds(attn_gen_bwd_dkv_kernel<NH, false>, lds, "attn_bwd_dkv");
+    if (rc != CFHIP_OK) return rc;
+    if (plain) hipLaunchKernelGGL((attn_gen_bwd_dkv_kernel<NH, true>), grid, dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((attn_gen_bwd_dkv_kernel<NH, false>), grid, dim3(512), lds, s, p);
+    CFHIP_CHECK_LAUNCH("attn_gen_bwd_dkv");
+  }
+  return CFHIP_OK;
+}
+
+int check_head_dim(const char* who, int head_dim) {
+  CFHIP_REQUIRE(head_dim >= 8 && head_dim <= 192 && head_dim % 8 == 0,
+                "%s: head_dim %d is not a multiple of 8 in [8, 192]", who, head_dim);
+  return CFHIP_OK;
+}
+
 }  // namespace
 
 int cfhip_internal_set_attn_ablate(int v) {
@@ -775,12 +876,14 @@ int cfhip_internal_set_attn_ablate(int v) {
   return CFHIP_OK;
 }
 
-extern "C" int cfhip_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
-                              const uint8_t* mask, int B, int H, int Tq, int Tk, int64_t q_stride_b,
-                              int64_t q_stride_t, int64_t kv_stride_b, int64_t kv_stride_t,
-                              int64_t o_stride_b, int64_t o_stride_t, int64_t ms_b, int64_t ms_h,
-                              int64_t ms_q, float scale, int causal, void* stream) {
-  int rc = check_common("attn_fwd", q, k, v, B, H, Tq, Tk, q_stride_b, q_stride_t, kv_stride_b,
+static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse,
+                         const uint8_t* mask, int B, int H, int Tq, int Tk, int head_dim, int64_t q_stride_b,
+                         int64_t q_stride_t, int64_t kv_stride_b, int64_t kv_stride_t,
+                         int64_t o_stride_b, int64_t o_stride_t, int64_t ms_b, int64_t ms_h,
+                         int64_t ms_q, float scale, int causal, void* stream) {
+  int rc = check_head_dim("attn_fwd", head_dim);
+  if (rc != CFHIP_OK) return rc;
+  rc = check_common("attn_fwd", q, k, v, B, H, Tq, Tk, q_stride_b, q_stride_t, kv_stride_b,
                         kv_stride_t, o_stride_b, o_stride_t);
   if (rc != CFHIP_OK) return rc;
   CFHIP_REQUIRE(o && ((uintptr_t)o & 7) == 0, "attn_fwd: o must be non-null and 8-byte aligned");
@@ -793,6 +896,7 @@ extern "C" int cfhip_attn_fwd(const void* q, const void* k, const void* v, void*
   p.ms_b = ms_b; p.ms_h = ms_h; p.ms_q = ms_q;
   p.scale = scale; p.causal = causal;
   p.ablate = g_attn_ablate;
+  p.dh = head_dim;
   const int nb = (Tk + 31) / 32;
   const int nw = pick_waves(Tq);
   const int tiles = (Tq + 15) / 16;
@@ -801,13 +905,13 @@ extern "C" int cfhip_attn_fwd(const void* q, const void* k, const void* v, void*
   const size_t lds = (size_t)2 * nb * 32 * 128;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bool plain = mask == nullptr && !causal;
-  if (Tq > CFHIP_ATTN_MAX_T || Tk > CFHIP_ATTN_MAX_T) {  // long sequences: chunked K / V, online softmax
-    dim3 sgrid((Tq + 127) / 128, H, B), sblock(512);
-    const size_t slds = (size_t)2 * CH * 128;
-    if (plain) hipLaunchKernelGGL(attn_fwd_stream_kernel<true>, sgrid, sblock, slds, s, p);
-    else hipLaunchKernelGGL(attn_fwd_stream_kernel<false>, sgrid, sblock, slds, s, p);
-    CFHIP_CHECK_LAUNCH("attn_fwd_stream");
-    return CFHIP_OK;
+  if (head_dim != CFHIP_ATTN_HEAD_DIM || Tq > CFHIP_ATTN_MAX_T || Tk > CFHIP_ATTN_MAX_T) {
+    // general form: chunked K / V with online softmax, head_dim as zero-padded 64-column halves
+    switch ((head_dim + 63) / 64) {
+      case 1: return launch_gen_fwd<1>(p, plain, s);
+      case 2: return launch_gen_fwd<2>(p, plain, s);
+      default: return launch_gen_fwd<3>(p, plain, s);
+    }
   }
 #define CFHIP_ATTN_FWD(NB_)                                                                         \
   case NB_:                                                                                         \
@@ -824,13 +928,33 @@ extern "C" int cfhip_attn_fwd(const void* q, const void* k, const void* v, void*
   return CFHIP_OK;
 }
 
-extern "C" int cfhip_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
-                              const float* lse, float* delta, const uint8_t* mask, void* dq, void* dk,
-                              void* dv, int B, int H, int Tq, int Tk, int64_t q_stride_b,
+extern "C" int cfhip_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                              const uint8_t* mask, int B, int H, int Tq, int Tk, int64_t q_stride_b,
                               int64_t q_stride_t, int64_t kv_stride_b, int64_t kv_stride_t,
                               int64_t o_stride_b, int64_t o_stride_t, int64_t ms_b, int64_t ms_h,
-                              int64_t ms_q, float scale, int causal, int parts, void* stream) {
-  int rc = check_common("attn_bwd", q, k, v, B, H, Tq, Tk, q_stride_b, q_stride_t, kv_stride_b,
+                              int64_t ms_q, float scale, int causal, void* stream) {
+  return attn_fwd_impl(q, k, v, o, lse, mask, B, H, Tq, Tk, CFHIP_ATTN_HEAD_DIM, q_stride_b, q_stride_t, kv_stride_b,
+                       kv_stride_t, o_stride_b, o_stride_t, ms_b, ms_h, ms_q, scale, causal, stream);
+}
+
+extern "C" int cfhip_attn_fwd_dh(const void* q, const void* k, const void* v, void* o, float* lse,
+                                 const uint8_t* mask, int B, int H, int Tq, int Tk, int head_dim,
+                                 int64_t q_stride_b, int64_t q_stride_t, int64_t kv_stride_b,
+                                 int64_t kv_stride_t, int64_t o_stride_b, int64_t o_stride_t, int64_t ms_b,
+                                 int64_t ms_h, int64_t ms_q, float scale, int causal, void* stream) {
+  return attn_fwd_impl(q, k, v, o, lse, mask, B, H, Tq, Tk, head_dim, q_stride_b, q_stride_t, kv_stride_b,
+                       kv_stride_t, o_stride_b, o_stride_t, ms_b, ms_h, ms_q, scale, causal, stream);
+}
+
+static int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                         const float* lse, float* delta, const uint8_t* mask, void* dq, void* dk,
+                         void* dv, int B, int H, int Tq, int Tk, int head_dim, int64_t q_stride_b,
+                         int64_t q_stride_t, int64_t kv_stride_b, int64_t kv_stride_t,
+                         int64_t o_stride_b, int64_t o_stride_t, int64_t ms_b, int64_t ms_h,
+                         int64_t ms_q, float scale, int causal, int parts, void* stream) {
+  int rc = check_head_dim("attn_bwd", head_dim);
+  if (rc != CFHIP_OK) return rc;
+  rc = check_common("attn_bwd", q, k, v, B, H, Tq, Tk, q_stride_b, q_stride_t, kv_stride_b,
                         kv_stride_t, o_stride_b, o_stride_t);
   if (rc != CFHIP_OK) return rc;
   CFHIP_REQUIRE(o && d_o && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
@@ -850,27 +974,15 @@ extern "C" int cfhip_attn_bwd(const void* q, const void* k, const void* v, const
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   p.delta_ready = (parts & 3) == 3;
   p.ablate = g_attn_ablate;
+  p.dh = head_dim;
   const bool plain = mask == nullptr && !causal;
   CFHIP_REQUIRE((parts & 3) != 0, "attn_bwd: parts must select the dQ pass (1), the dK/dV pass (2) or both (3)");
-  if (Tq > CFHIP_ATTN_MAX_T || Tk > CFHIP_ATTN_MAX_T) {  // long sequences: chunked operands
-    if (parts & 1) {
-      dim3 sgrid((Tq + 127) / 128, H, B);
-      const size_t slds = (size_t)2 * CH * 128;
-      if (plain) hipLaunchKernelGGL(attn_bwd_dq_stream_kernel<true>, sgrid, dim3(512), slds, s, p);
-      else hipLaunchKernelGGL(attn_bwd_dq_stream_kernel<false>, sgrid, dim3(512), slds, s, p);
-      CFHIP_CHECK_LAUNCH("attn_bwd_dq_stream");
+  if (head_dim != CFHIP_ATTN_HEAD_DIM || Tq > CFHIP_ATTN_MAX_T || Tk > CFHIP_ATTN_MAX_T) {  // general form
+    switch ((head_dim + 63) / 64) {
+      case 1: return launch_gen_bwd<1>(p, plain, parts, s);
+      case 2: return launch_gen_bwd<2>(p, plain, parts, s);
+      default: return launch_gen_bwd<3>(p, plain, parts, s);
     }
-    if (parts & 2) {
-      dim3 sgrid((Tk + 127) / 128, H, B);
-      const size_t slds = (size_t)2 * CH * 128 + (size_t)2 * CH * sizeof(float);
-      rc = plain ? set_lds(attn_bwd_dkv_stream_kernel<true>, slds, "attn_bwd_dkv_stream")
-                 : set_lds(attn_bwd_dkv_stream_kernel<false>, slds, "attn_bwd_dkv_stream");
-      if (rc != CFHIP_OK) return rc;
-      if (plain) hipLaunchKernelGGL(attn_bwd_dkv_stream_kernel<true>, sgrid, dim3(512), slds, s, p);
-      else hipLaunchKernelGGL(attn_bwd_dkv_stream_kernel<false>, sgrid, dim3(512), slds, s, p);
-      CFHIP_CHECK_LAUNCH("attn_bwd_dkv_stream");
-    }
-    return CFHIP_OK;
   }
   if (parts & 1) {
     const int nb = (Tk + 31) / 32;
@@ -897,4 +1009,25 @@ extern "C" int cfhip_attn_bwd(const void* q, const void* k, const void* v, const
     CFHIP_CHECK_LAUNCH("attn_bwd_dkv");
   }
   return CFHIP_OK;
+}
+
+extern "C" int cfhip_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                              const float* lse, float* delta, const uint8_t* mask, void* dq, void* dk,
+                              void* dv, int B, int H, int Tq, int Tk, int64_t q_stride_b,
+                              int64_t q_stride_t, int64_t kv_stride_b, int64_t kv_stride_t,
+                              int64_t o_stride_b, int64_t o_stride_t, int64_t ms_b, int64_t ms_h,
+                              int64_t ms_q, float scale, int causal, int parts, void* stream) {
+  return attn_bwd_impl(q, k, v, o, d_o, lse, delta, mask, dq, dk, dv, B, H, Tq, Tk, CFHIP_ATTN_HEAD_DIM, q_stride_b,
+                       q_stride_t, kv_stride_b, kv_stride_t, o_stride_b, o_stride_t, ms_b, ms_h, ms_q, scale, causal,
+                       parts, stream);
+}
+
+extern "C" int cfhip_attn_bwd_dh(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                 const float* lse, float* delta, const uint8_t* mask, void* dq, void* dk,
+                                 void* dv, int B, int H, int Tq, int Tk, int head_dim, int64_t q_stride_b,
+                                 int64_t q_stride_t, int64_t kv_stride_b, int64_t kv_stride_t,
+                                 int64_t o_stride_b, int64_t o_stride_t, int64_t ms_b, int64_t ms_h,
+                                 int64_t ms_q, float scale, int causal, int parts, void* stream) {
+  return attn_bwd_impl(q, k, v, o, d_o, lse, delta, mask, dq, dk, dv, B, H, Tq, Tk, head_dim, q_stride_b, q_stride_t,
+                       kv_stride_b, kv_stride_t, o_stride_b, o_stride_t, ms_b, ms_h, ms_q, scale, causal, parts, stream);
 }

@@ -210,7 +210,7 @@ def layernorm_bwd(
 def _bth(t: Tensor, name: str) -> Tuple[int, int, int, int, int]:
     _need(t, bf16, name)
     if t.dim() != 3 or t.stride(2) != 1:
-        raise ValueError(f"cfhip attention: `{name}` must be [B, T, H*64] with a contiguous last dim")
+        raise ValueError(f"cfhip attention: `{name}` must be [B, T, H*head_dim] with a contiguous last dim")
     return t.shape[0], t.shape[1], t.shape[2], t.stride(0), t.stride(1)
 
 
@@ -232,24 +232,26 @@ def _mask_args(mask: Optional[Tensor], b: int, h: int, tq: int, tk: int):
 
 def attn_fwd(
     q: Tensor, k: Tensor, v: Tensor, num_heads: int, *, mask: Optional[Tensor] = None,
-    causal: bool = False, scale: Optional[float] = None,
+    causal: bool = False, scale: Optional[float] = None, head_dim: int = 64,
 ) -> Tuple[Tensor, Tensor]:
-    """Returns (o bf16 [B, Tq, H*64] contiguous, lse f32 [B, H, Tq])."""
+    """Returns (o bf16 [B, Tq, H*head_dim] contiguous, lse f32 [B, H, Tq]).  head_dim 64 with both lengths <= 256
+    takes the LDS-resident kernels; anything else (head_dim any multiple of 8 up to 192) the chunked general ones."""
     b, tq, d, q_sb, q_st = _bth(q, "q")
     _, tk, _, k_sb, k_st = _bth(k, "k")
     _, _, _, v_sb, v_st = _bth(v, "v")
-    if d != num_heads * 64:
-        raise ValueError(f"cfhip attention: head_dim must be 64 (embed {d}, heads {num_heads})")
+    if d != num_heads * head_dim or head_dim % 8 or not 8 <= head_dim <= 192:
+        raise ValueError(f"cfhip attention: embed {d} != heads {num_heads} x head_dim {head_dim} "
+                         "(head_dim: a multiple of 8 in [8, 192])")
     if (k_sb, k_st) != (v_sb, v_st):
         raise ValueError("cfhip attention: k and v must share batch / token strides")
     if scale is None:
-        scale = 1.0 / math.sqrt(64.0)
+        scale = 1.0 / math.sqrt(float(head_dim))
     o = torch.empty((b, tq, d), dtype=bf16, device=q.device)
     lse = torch.empty((b, num_heads, tq), dtype=f32, device=q.device)
     keep, mp, ms_b, ms_h, ms_q = _mask_args(mask, b, num_heads, tq, tk)
-    rc = _lib.load().cfhip_attn_fwd(
+    rc = _lib.load().cfhip_attn_fwd_dh(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), mp, b, num_heads, tq,
-        tk, q_sb, q_st, k_sb, k_st, o.stride(0), o.stride(1), ms_b, ms_h, ms_q, float(scale),
+        tk, int(head_dim), q_sb, q_st, k_sb, k_st, o.stride(0), o.stride(1), ms_b, ms_h, ms_q, float(scale),
         int(causal), _stream(),
     )
     _lib.check(rc, "attn_fwd")
@@ -259,7 +261,7 @@ def attn_fwd(
 def attn_bwd(
     q: Tensor, k: Tensor, v: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, num_heads: int, *,
     dq: Tensor, dk: Tensor, dv: Tensor, mask: Optional[Tensor] = None, causal: bool = False,
-    scale: Optional[float] = None, parts: int = 3, delta: Optional[Tensor] = None,
+    scale: Optional[float] = None, parts: int = 3, delta: Optional[Tensor] = None, head_dim: int = 64,
 ) -> None:
     """Writes dq / dk / dv (bf16, SAME strides as q / k / v — e.g. views of one packed buffer)."""
     b, tq, d, q_sb, q_st = _bth(q, "q")
@@ -274,14 +276,14 @@ def attn_bwd(
         if t.shape != ref.shape or t.stride() != ref.stride():
             raise ValueError(f"cfhip attention: `{nm}` must have the shape and strides of its primal")
     if scale is None:
-        scale = 1.0 / math.sqrt(64.0)
+        scale = 1.0 / math.sqrt(float(head_dim))
     if delta is None:
         delta = torch.empty((b, num_heads, tq), dtype=f32, device=q.device)
     keep, mp, ms_b, ms_h, ms_q = _mask_args(mask, b, num_heads, tq, tk)
-    rc = _lib.load().cfhip_attn_bwd(
+    rc = _lib.load().cfhip_attn_bwd_dh(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
-        delta.data_ptr(), mp, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), b, num_heads, tq, tk, q_sb,
-        q_st, k_sb, k_st, o_sb, o_st, ms_b, ms_h, ms_q, float(scale), int(causal), int(parts), _stream(),
+        delta.data_ptr(), mp, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), b, num_heads, tq, tk, int(head_dim),
+        q_sb, q_st, k_sb, k_st, o_sb, o_st, ms_b, ms_h, ms_q, float(scale), int(causal), int(parts), _stream(),
     )
     _lib.check(rc, "attn_bwd")
 

@@ -148,6 +148,20 @@ int cfhip_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
                    int64_t kv_stride_b, int64_t kv_stride_t, int64_t o_stride_b, int64_t o_stride_t,
                    int64_t ms_b, int64_t ms_h, int64_t ms_q, float scale, int causal, int parts,
                    void* stream);
+/* The same with an explicit head_dim (any multiple of 8 up to 192, e.g. the 40 / 80 / 160-channel heads of the UNet's
+ * SpatialTransformer, mixed_stacks/api.py:766-893; attentions.py:498-569): always the chunked general kernels unless
+ * head_dim == 64 and both lengths fit the resident form.  Addressing ptr[b*stride_b + t*stride_t + h*head_dim + d]. */
+int cfhip_attn_fwd_dh(const void* q, const void* k, const void* v, void* o, float* lse,
+                      const uint8_t* mask, int B, int H, int Tq, int Tk, int head_dim, int64_t q_stride_b,
+                      int64_t q_stride_t, int64_t kv_stride_b, int64_t kv_stride_t, int64_t o_stride_b,
+                      int64_t o_stride_t, int64_t ms_b, int64_t ms_h, int64_t ms_q, float scale, int causal,
+                      void* stream);
+int cfhip_attn_bwd_dh(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                      const float* lse, float* delta, const uint8_t* mask, void* dq, void* dk, void* dv,
+                      int B, int H, int Tq, int Tk, int head_dim, int64_t q_stride_b, int64_t q_stride_t,
+                      int64_t kv_stride_b, int64_t kv_stride_t, int64_t o_stride_b, int64_t o_stride_t,
+                      int64_t ms_b, int64_t ms_h, int64_t ms_q, float scale, int causal, int parts,
+                      void* stream);
 /* parts: 1 = dQ pass only, 2 = dK/dV pass only, 3 = both.  The two passes are independent kernels
  * (each recomputes S, dP and delta) and may be launched on two streams. */
 

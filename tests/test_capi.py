@@ -39,9 +39,11 @@ def test_version_and_error_string():
     assert b"null" in lib.cfhip_last_error()
     rc = lib.cfhip_layernorm_fwd(1, 0, 1, 1, 1, None, None, 4, 6, 8, 8, 1e-6, None)
     assert rc == -1 and b"multiple of 4" in lib.cfhip_last_error()
-    rc = lib.cfhip_attn_fwd(16, 16, 16, 16, None, None, 1, 1, 300, 300, 64, 64, 64, 64, 64, 64, 0, 0, 0, 0.125, 0, None)
-    assert rc == -1 and b"exceeds" in lib.cfhip_last_error()
-    with pytest.raises(RuntimeError, match="exceeds"):
+    # (long sequences are no longer an error: the chunked kernels take them) head_dim outside the supported set is
+    rc = lib.cfhip_attn_fwd_dh(16, 16, 16, 16, None, None, 1, 1, 300, 300, 200, 256, 256, 256, 256, 256, 256, 0, 0, 0,
+                               0.125, 0, None)
+    assert rc == -1 and b"head_dim" in lib.cfhip_last_error()
+    with pytest.raises(RuntimeError, match="head_dim"):
         _lib.check(rc, "attn_fwd")
 
 

@@ -171,3 +171,35 @@ def test_long_sequences_masks_causal_and_cross_lengths():
         o, lse = ops.attn_fwd(q.to(DEV), kv.to(DEV)[:, :, 0], kv.to(DEV)[:, :, 1], h)
         want = O.sdp_attention(_heads(q, h), _heads(kv[:, :, 0], h), _heads(kv[:, :, 1], h))
         assert_close(o, want.permute(0, 2, 1, 3).reshape(b, tq, d), 1e-2, f"stream cross {tq}x{tk}")
+
+
+def _oracle_dh(q, k, v, h, dh, d_o, keep=None):
+    ql, kl, vl = (t.float().requires_grad_(True) for t in (q, k, v))
+    b, tq, _ = q.shape
+    tk = k.shape[1]
+    hd = lambda z, t: z.reshape(b, t, h, dh).permute(0, 2, 1, 3)  # noqa: E731
+    o = O.sdp_attention(hd(ql, tq), hd(kl, tk), hd(vl, tk), keep)
+    o = o.permute(0, 2, 1, 3).reshape(b, tq, h * dh)
+    o.backward(d_o.float())
+    return o.detach(), ql.grad, kl.grad, vl.grad
+
+
+@pytest.mark.parametrize("dh,tq,tk,h", [(40, 64, 64, 8), (40, 300, 77, 2), (80, 256, 256, 3), (160, 64, 64, 2),
+                                         (160, 130, 300, 1), (64, 100, 77, 2), (8, 20, 33, 2), (96, 17, 17, 2)])
+def test_general_head_dims(dh, tq, tk, h):
+    """head_dim != 64 (the UNet's 40 / 80 / 160-channel heads) and Tq != Tk (cross attention over a context)"""
+    g = torch.Generator().manual_seed(dh * 1000 + tq)
+    d = h * dh
+    q = (torch.randn(2, tq, d, generator=g) * 1.2).to(torch.bfloat16)
+    k = (torch.randn(2, tk, d, generator=g) * 1.2).to(torch.bfloat16)
+    v = (torch.randn(2, tk, d, generator=g) * 1.2).to(torch.bfloat16)
+    d_o = torch.randn(2, tq, d, generator=g).to(torch.bfloat16)
+    want_o, gq, gk, gv = _oracle_dh(q, k, v, h, dh, d_o)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o, lse = ops.attn_fwd(qd, kd, vd, h, head_dim=dh)
+    assert_close(o, want_o, 1e-2, f"fwd dh={dh}")
+    dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
+    ops.attn_bwd(qd, kd, vd, o, d_o.to(DEV), lse, h, dq=dq, dk=dk, dv=dv, head_dim=dh)
+    assert_close(dq, gq, 2e-2, f"dq dh={dh}", abs_floor=1e-6)
+    assert_close(dk, gk, 2e-2, f"dk dh={dh}", abs_floor=1e-6)
+    assert_close(dv, gv, 2e-2, f"dv dh={dh}", abs_floor=1e-6)
