@@ -497,6 +497,55 @@ extern "C" int cfhip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n
   CFHIP_REQUIRE(x, "gelu_bwd: null x");
   CFHIP_EW("gelu_bwd", 1, dy, x, dx)
 }
+// ---- GEGLU (activations.py:150-158): out[m][c] = vg[m][c] * gelu(vg[m][L + c]); 4 bf16 per thread ------------------
+template <bool BWD>
+__global__ void geglu_kernel(const bf16_t* __restrict__ vg, const bf16_t* __restrict__ dy, bf16_t* __restrict__ out,
+                             long M, int L) {
+  const int l4 = L >> 2;
+  const long total = M * l4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long m = i / l4;
+    const int c = (int)(i - m * l4) * 4;
+    const u32x2 wv = *reinterpret_cast<const u32x2*>(vg + m * 2 * L + c);
+    const u32x2 wg = *reinterpret_cast<const u32x2*>(vg + m * 2 * L + L + c);
+    const float v[4] = {bf16lo(wv[0]), bf16hi(wv[0]), bf16lo(wv[1]), bf16hi(wv[1])};
+    const float g[4] = {bf16lo(wg[0]), bf16hi(wg[0]), bf16lo(wg[1]), bf16hi(wg[1])};
+    if (!BWD) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = v[e] * gelu_erf_f(g[e]);
+      *reinterpret_cast<u32x2*>(out + m * L + c) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+    } else {
+      const u32x2 wd = *reinterpret_cast<const u32x2*>(dy + m * L + c);
+      const float d[4] = {bf16lo(wd[0]), bf16hi(wd[0]), bf16lo(wd[1]), bf16hi(wd[1])};
+      float dv[4], dg[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dv[e] = d[e] * gelu_erf_f(g[e]);
+        dg[e] = d[e] * v[e] * gelu_erf_grad_f(g[e]);
+      }
+      *reinterpret_cast<u32x2*>(out + m * 2 * L + c) = u32x2{pack_bf16x2(dv[0], dv[1]), pack_bf16x2(dv[2], dv[3])};
+      *reinterpret_cast<u32x2*>(out + m * 2 * L + L + c) = u32x2{pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3])};
+    }
+  }
+}
+
+extern "C" int cfhip_geglu_fwd(const void* vg, void* out, int64_t M, int L, void* stream) {
+  CFHIP_REQUIRE(vg && out && M > 0 && L > 0 && L % 4 == 0, "geglu_fwd: bad arguments (L must be a multiple of 4)");
+  hipLaunchKernelGGL((geglu_kernel<false>), dim3(grid_for(M * (L / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)vg, (const bf16_t*)nullptr, (bf16_t*)out, (long)M, L);
+  CFHIP_CHECK_LAUNCH("geglu_fwd");
+  return CFHIP_OK;
+}
+extern "C" int cfhip_geglu_bwd(const void* dy, const void* vg, void* dvg, int64_t M, int L, void* stream) {
+  CFHIP_REQUIRE(dy && vg && dvg && M > 0 && L > 0 && L % 4 == 0, "geglu_bwd: bad arguments (L must be a multiple of 4)");
+  hipLaunchKernelGGL((geglu_kernel<true>), dim3(grid_for(M * (L / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)vg, (const bf16_t*)dy, (bf16_t*)dvg, (long)M, L);
+  CFHIP_CHECK_LAUNCH("geglu_bwd");
+  return CFHIP_OK;
+}
+
 extern "C" int cfhip_quick_gelu_fwd(const void* x, void* y, int64_t n, void* stream) {
   CFHIP_EW("quick_gelu_fwd", 3, x, (const void*)nullptr, y)
 }

@@ -341,31 +341,29 @@ class PackedSelfAttentionFn(Function):
 
 
 class AttentionCoreFn(Function):
-    """Same computation for separately projected q [B,Tq,D], k / v [B,Tk,D] (cross attention)."""
+    """Same computation for separately projected q [B,Tq,D], k / v [B,Tk,D] (cross attention), any head_dim that is
+    a multiple of 8 up to 192 (reference attentions.py:498-569 `CrossAttention` -> sdp_attn)."""
 
     @staticmethod
     def forward(ctx: Any, q: Tensor, k: Tensor, v: Tensor, num_heads: int, keep_mask: Optional[Tensor],
-                causal: bool) -> Tensor:
+                causal: bool, head_dim: int = 64) -> Tensor:
         q, k, v = (t if t.dtype == bf16 else ops.to_bf16(t.float().contiguous()) for t in (q, k, v))
-        q = q.contiguous()
-        kv = torch.stack([k, v], dim=2)  # [B, Tk, 2, D]: k and v share strides
-        k, v = kv[:, :, 0], kv[:, :, 1]
-        o, lse = ops.attn_fwd(q, k, v, num_heads, mask=keep_mask, causal=causal)
-        ctx.save_for_backward(q, kv, o, lse, keep_mask)
-        ctx.num_heads, ctx.causal = num_heads, causal
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()  # equal shapes -> k and v share strides
+        o, lse = ops.attn_fwd(q, k, v, num_heads, mask=keep_mask, causal=causal, head_dim=head_dim)
+        ctx.save_for_backward(q, k, v, o, lse, keep_mask)
+        ctx.num_heads, ctx.causal, ctx.head_dim = num_heads, causal, head_dim
         return o
 
     @staticmethod
     def backward(ctx: Any, d_o: Tensor):  # type: ignore
-        q, kv, o, lse, keep_mask = ctx.saved_tensors
+        q, k, v, o, lse, keep_mask = ctx.saved_tensors
         if d_o.dtype != bf16:
             d_o = ops.to_bf16(d_o.float())
         d_o = d_o.contiguous()
-        dq = torch.empty_like(q)
-        dkv = torch.empty_like(kv)
-        ops.attn_bwd(q, kv[:, :, 0], kv[:, :, 1], o, d_o, lse, ctx.num_heads, dq=dq, dk=dkv[:, :, 0],
-                     dv=dkv[:, :, 1], mask=keep_mask, causal=ctx.causal)
-        return dq, dkv[:, :, 0], dkv[:, :, 1], None, None, None
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ops.attn_bwd(q, k, v, o, d_o, lse, ctx.num_heads, dq=dq, dk=dk, dv=dv, mask=keep_mask, causal=ctx.causal,
+                     head_dim=ctx.head_dim)
+        return dq, dk, dv, None, None, None, None
 
 
 def packed_self_attention(qkv: Tensor, num_heads: int, keep_mask: Optional[Tensor] = None,
@@ -374,8 +372,8 @@ def packed_self_attention(qkv: Tensor, num_heads: int, keep_mask: Optional[Tenso
 
 
 def attention_core(q: Tensor, k: Tensor, v: Tensor, num_heads: int, keep_mask: Optional[Tensor] = None,
-                   causal: bool = False) -> Tensor:
-    return AttentionCoreFn.apply(q, k, v, num_heads, keep_mask, causal)
+                   causal: bool = False, head_dim: int = 64) -> Tensor:
+    return AttentionCoreFn.apply(q, k, v, num_heads, keep_mask, causal, head_dim)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -892,3 +890,69 @@ def upsample2(x: Tensor) -> Tensor:
 
 def avg_pool2(x: Tensor) -> Tensor:
     return AvgPool2Fn.apply(x)
+
+
+# ---------------------------------------------------------------------------------------------
+# SpatialTransformer glue (reference mixed_stacks/api.py:766-893): GEGLU, NCHW <-> token-major
+# ---------------------------------------------------------------------------------------------
+
+
+class GegluFn(Function):
+    """value * gelu(gate) with [value | gate] = the two halves of the last dim (reference activations.py:150-158)"""
+
+    @staticmethod
+    def forward(ctx: Any, vg: Tensor) -> Tensor:
+        vg = (vg if vg.dtype == bf16 else ops.to_bf16(vg.float().contiguous())).contiguous()
+        ctx.save_for_backward(vg)
+        return ops.geglu_fwd(vg)
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        (vg,) = ctx.saved_tensors
+        dy = (dy if dy.dtype == bf16 else ops.to_bf16(dy.float().contiguous())).contiguous()
+        return ops.geglu_bwd(dy, vg)
+
+
+def geglu(vg: Tensor) -> Tensor:
+    return GegluFn.apply(vg)
+
+
+class NchwToTokensFn(Function):
+    """[B, C, H, W] -> token-major [B, H*W, C] (`permute(0, 2, 3, 1).reshape`), bf16"""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor) -> Tensor:
+        if x.dtype not in (bf16, f32):
+            x = x.float()
+        b, c, h, w = x.shape
+        ctx.hw = (h, w)
+        return ops.transpose_batched(x.contiguous().view(b, c, h * w))
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        b, t, c = dy.shape
+        return ops.transpose_batched(dy.contiguous()).view(b, c, *ctx.hw)
+
+
+class TokensToNchwFn(Function):
+    """token-major [B, H*W, C] -> [B, C, H, W], bf16"""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, h: int, w: int) -> Tensor:
+        if x.dtype not in (bf16, f32):
+            x = x.float()
+        b, t, c = x.shape
+        return ops.transpose_batched(x.contiguous()).view(b, c, h, w)
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        b, c, h, w = dy.shape
+        return ops.transpose_batched(dy.contiguous().view(b, c, h * w)), None, None
+
+
+def nchw_to_tokens(x: Tensor) -> Tensor:
+    return NchwToTokensFn.apply(x)
+
+
+def tokens_to_nchw(x: Tensor, h: int, w: int) -> Tensor:
+    return TokensToNchwFn.apply(x, h, w)

@@ -446,6 +446,17 @@ class _Act(Module):
         return HF.gelu(net)
 
 
+class GEGLU(Module):
+    """reference activations.py:150-158: `net` = HijackLinear(in, 2 * out); value * gelu(gate)"""
+
+    def __init__(self, in_dim: int, out_dim: int):
+        super().__init__()
+        self.net = HijackLinear(in_dim, out_dim * 2)
+
+    def forward(self, net: Tensor) -> Tensor:
+        return HF.geglu(self.net(net))
+
+
 @channel_mixers.register("ff")
 class FeedForward(IChannelMixer):
     """reference mixed_stacks/channel_mixers.py:15-43 — `net.0` Linear, `net.1` act, `net.2`
@@ -454,11 +465,15 @@ class FeedForward(IChannelMixer):
     def __init__(self, in_dim: int, latent_dim: int, dropout: float, activation: str = "GELU",
                  add_last_dropout: bool = True):
         super().__init__(in_dim, latent_dim, dropout)
-        if activation not in ("GELU", "quick_gelu"):
+        if activation not in ("GELU", "quick_gelu", "geglu"):
             raise NotImplementedError(f"activation '{activation}' is not on the accelerated hot path yet")
         self.activation = activation
-        blocks: List[Module] = [HijackCustomLinear(in_dim, latent_dim), _Act(activation),
-                                nn.Dropout(dropout), HijackCustomLinear(latent_dim, in_dim)]
+        blocks: List[Module]
+        if activation == "geglu":  # state keys `net.0.net.*` (GEGLU's Linear(in, 2 * latent)), `net.2.linear.*`
+            blocks = [GEGLU(in_dim, latent_dim)]
+        else:
+            blocks = [HijackCustomLinear(in_dim, latent_dim), _Act(activation)]
+        blocks += [nn.Dropout(dropout), HijackCustomLinear(latent_dim, in_dim)]
         if add_last_dropout:
             blocks.append(nn.Dropout(dropout))
         self.net = nn.Sequential(*blocks)
@@ -470,6 +485,8 @@ class FeedForward(IChannelMixer):
     def forward(self, net: Tensor, *, residual: Optional[Tensor] = None) -> Tensor:
         if self.training and self.dropout > 0.0:
             raise NotImplementedError("dropout > 0 is outside the accelerated hot path")
+        if self.activation == "geglu":
+            return self.net[2](self.net[0](net), residual=residual)
         # bias + activation (exact-erf GELU / quick GELU) fused in the GEMM epilogue
         h = self.net[0](net, act=HF.ACT_GELU if self.activation == "GELU" else HF.ACT_QGELU)
         return self.net[3](h, residual=residual)
@@ -533,6 +550,8 @@ class MixingBlock(Module):
         if not (isinstance(att, Attention) and att.qkv_same and att.hook is None and att.head_dim == 64):
             return False
         if not (isinstance(self.token_norm, LayerNorm) and isinstance(self.channel_norm, LayerNorm)):
+            return False
+        if cmix.activation == "geglu":
             return False
         lins = (att.out_linear, cmix.net[0], cmix.net[3])
         if any(l.linear is None or l.hook is not None for l in lins):
@@ -1324,3 +1343,107 @@ class ResidualBlockWithTimeEmbedding(Module):
         net = self.norm2(net, add=add, silu=True)
         net = self.conv2(net)
         return HF.add(inp, net)
+
+
+# ---------------------------------------------------------------------------------------------
+# UNet spatial transformer (reference attentions.py:498-569, mixed_stacks/api.py:766-893)
+# ---------------------------------------------------------------------------------------------
+
+
+class CrossAttention(Module):
+    """reference attentions.py:498-569: `to_q` / `to_k` / `to_v` (HijackLinear, no bias), `out_linear.0` (HijackLinear)
+    + Dropout; heads of `head_dim` channels (any multiple of 8 up to 192), context = the input when None."""
+
+    def __init__(self, *, query_dim: int, context_dim: Optional[int] = None, num_heads: int = 8, head_dim: int = 64,
+                 dropout: float = 0.0):
+        super().__init__()
+        if dropout > 0.0:
+            raise NotImplementedError("dropout > 0 is outside the accelerated hot path")
+        self.has_context = context_dim is not None
+        latent_dim = head_dim * num_heads
+        context_dim = context_dim or query_dim
+        self.num_heads, self.head_dim = num_heads, head_dim
+        self.to_q = HijackLinear(query_dim, latent_dim, bias=False)
+        self.to_k = HijackLinear(context_dim, latent_dim, bias=False)
+        self.to_v = HijackLinear(context_dim, latent_dim, bias=False)
+        self.out_linear = nn.Sequential(HijackLinear(latent_dim, query_dim), nn.Dropout(dropout))
+
+    def forward(self, net: Tensor, *, context: Optional[Tensor] = None, mask: Optional[Tensor] = None,
+                residual: Optional[Tensor] = None) -> Tensor:
+        q = self.to_q(net)
+        if context is None:
+            context = net
+        k, v = self.to_k(context), self.to_v(context)
+        keep = None
+        if mask is not None:  # [B*H, Tq, Tk] bool, True = masked (the reference inverts it before sdp_attn)
+            b = net.shape[0]
+            keep = (~mask).view(b, self.num_heads, mask.shape[-2], mask.shape[-1]).to(torch.uint8)
+        o = HF.attention_core(q, k, v, self.num_heads, keep, False, self.head_dim)
+        lin = self.out_linear[0]
+        return HF.linear(o, lin.weight, lin.bias, residual=residual)
+
+
+class SpatialTransformerBlock(Module):
+    """reference mixed_stacks/api.py:766-827: LN -> self attention -> +x; LN -> cross attention(context) -> +x;
+    LN -> GEGLU feed-forward -> +x (the residual adds ride in the GEMM epilogues).  Hooks and gradient checkpointing
+    are outside the accelerated hot path."""
+
+    def __init__(self, query_dim: int, num_heads: int, head_dim: int, *, dropout: float = 0.0,
+                 context_dim: Optional[int] = None, feedforward_multiplier: float = 4.0,
+                 feedforward_activation: str = "geglu", use_checkpoint: bool = False,
+                 hooks_kwargs: Optional[Dict[str, Any]] = None):
+        super().__init__()
+        if hooks_kwargs:
+            raise NotImplementedError("SpatialTransformer hooks are outside the accelerated hot path")
+        self.attn1 = CrossAttention(query_dim=query_dim, num_heads=num_heads, head_dim=head_dim, dropout=dropout)
+        self.ff = FeedForward(query_dim, round(query_dim * feedforward_multiplier), dropout,
+                              activation=feedforward_activation, add_last_dropout=False)
+        self.attn2 = CrossAttention(query_dim=query_dim, context_dim=context_dim, num_heads=num_heads,
+                                    head_dim=head_dim, dropout=dropout)
+        self.norm1, self.norm2, self.norm3 = LayerNorm(query_dim), LayerNorm(query_dim), LayerNorm(query_dim)
+        self.use_checkpoint = use_checkpoint
+
+    def forward(self, net: Tensor, context: Optional[Tensor] = None) -> Tensor:
+        net = self.attn1(self.norm1(net), residual=net)
+        net = self.attn2(self.norm2(net), context=context, residual=net)
+        return self.ff(self.norm3(net), residual=net)
+
+
+class SpatialTransformer(Module):
+    """reference mixed_stacks/api.py:830-893: GroupNorm(32, eps 1e-6) -> to_latent (1x1 conv or Linear) -> tokens
+    [B, HW, C] -> blocks -> from_latent (zero-initialised) -> + input.  A 1x1 convolution over NCHW is a Linear over
+    the token-major rows, so the NCHW <-> token-major transposes happen once on the way in and once on the way out."""
+
+    def __init__(self, in_channels: int, num_heads: int, head_dim: int, *, num_layers: int = 1, dropout: float = 0.0,
+                 context_dim: Optional[int] = None, use_linear: bool = False, use_checkpoint: bool = False,
+                 hooks_kwargs: Optional[Dict[str, Any]] = None):
+        super().__init__()
+        self.norm = GroupNorm(32, in_channels, 1.0e-6, affine=True)
+        self.use_linear = use_linear
+        latent_channels = num_heads * head_dim
+        if not use_linear:
+            self.to_latent: Module = HijackConv2d(in_channels, latent_channels, 1, 1, 0)
+        else:
+            self.to_latent = HijackLinear(in_channels, latent_channels)
+        self.blocks = nn.ModuleList([
+            SpatialTransformerBlock(latent_channels, num_heads, head_dim, dropout=dropout, context_dim=context_dim,
+                                    use_checkpoint=use_checkpoint, hooks_kwargs=hooks_kwargs)
+            for _ in range(num_layers)
+        ])
+        self.from_latent: Module = (HijackConv2d(latent_channels, in_channels, 1, 1, 0) if not use_linear
+                                    else HijackLinear(in_channels, latent_channels))
+        with torch.no_grad():  # zero_module
+            for p in self.from_latent.parameters():
+                p.zero_()
+
+    def forward(self, net: Tensor, context: Optional[Tensor]) -> Tensor:
+        inp = net
+        b, c, h, w = net.shape
+        tokens = HF.nchw_to_tokens(self.norm(net))  # [B, HW, C]
+        wl = self.to_latent.weight
+        tokens = HF.linear(tokens, wl.view(wl.shape[0], -1), self.to_latent.bias)
+        for block in self.blocks:
+            tokens = block(tokens, context=context)
+        wo = self.from_latent.weight
+        tokens = HF.linear(tokens, wo.view(wo.shape[0], -1), self.from_latent.bias)
+        return HF.add(inp, HF.tokens_to_nchw(tokens, h, w))

@@ -795,3 +795,24 @@ def ema_update(ema: Tensor, p: Tensor, decay: float) -> None:
         raise ValueError("cfhip ema_update: contiguous f32 buffers of equal length expected")
     _lib.check(_lib.load().cfhip_ema_update(ema.data_ptr(), p.data_ptr(), p.numel(), float(1.0 - decay), float(decay),
                                             _stream()), "ema_update")
+
+
+def geglu_fwd(vg: Tensor) -> Tensor:
+    """vg bf16 [..., 2L] -> value * gelu(gate), bf16 [..., L]"""
+    _need(vg, bf16, "vg")
+    if not vg.is_contiguous() or vg.shape[-1] % 8:
+        raise ValueError("cfhip geglu_fwd: contiguous [..., 2L] with L a multiple of 4 expected")
+    l = vg.shape[-1] // 2
+    out = torch.empty((*vg.shape[:-1], l), dtype=bf16, device=vg.device)
+    _lib.check(_lib.load().cfhip_geglu_fwd(vg.data_ptr(), out.data_ptr(), vg.numel() // (2 * l), l, _stream()), "geglu_fwd")
+    return out
+
+
+def geglu_bwd(dy: Tensor, vg: Tensor) -> Tensor:
+    _need(dy, bf16, "dy")
+    _need(vg, bf16, "vg")
+    l = vg.shape[-1] // 2
+    dvg = torch.empty_like(vg)
+    _lib.check(_lib.load().cfhip_geglu_bwd(dy.contiguous().data_ptr(), vg.data_ptr(), dvg.data_ptr(),
+                                           vg.numel() // (2 * l), l, _stream()), "geglu_bwd")
+    return dvg

@@ -189,6 +189,9 @@ int cfhip_gelu_fwd(const void* x, void* y, int64_t n, void* stream);            
 int cfhip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
 int cfhip_quick_gelu_fwd(const void* x, void* y, int64_t n, void* stream);        /* x * sigmoid(1.702 x) */
 int cfhip_quick_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
+/* GEGLU (activations.py:150-158): out[m][c] = vg[m][c] * gelu_erf(vg[m][L + c]) for vg bf16 [M][2L]; bwd writes dvg */
+int cfhip_geglu_fwd(const void* vg, void* out, int64_t M, int L, void* stream);
+int cfhip_geglu_bwd(const void* dy, const void* vg, void* dvg, int64_t M, int L, void* stream);
 int cfhip_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
 /* bf16 [R,C] -> bf16 [C,R] */
 int cfhip_transpose_bf16(const void* src, void* dst, int R, int C, int64_t ld_src, int64_t ld_dst,

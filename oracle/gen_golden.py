@@ -365,13 +365,38 @@ def gen_resblock(ref) -> None:
                os.path.join(OUT, "resblock.pt"))
 
 
+def gen_spatial_transformer(ref) -> None:
+    """SpatialTransformer (mixed_stacks/api.py:830-893) with the UNet's head size 40 (320 channels / 8 heads in the zoo
+    model; 160 channels / 4 heads here — the reference's forward only works when in_channels == num_heads * head_dim)
+    and a text context of another width."""
+    import importlib
+
+    api = importlib.import_module("cflearn.modules.core.mixed_stacks.api")
+    torch.manual_seed(100)
+    cfg = dict(in_channels=160, num_heads=4, head_dim=40, num_layers=1, context_dim=96)
+    m = api.SpatialTransformer(160, 4, 40, num_layers=1, context_dim=96)
+    with torch.no_grad():  # from_latent is zero-initialised: perturb everything
+        for p_ in m.parameters():
+            p_.add_(torch.randn_like(p_) * 0.05)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 160, 6, 6, requires_grad=True)
+    ctx = torch.randn(2, 11, 96, requires_grad=True)
+    y = m(x, ctx)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    _check("spatial transformer", UO.spatial_transformer(x.detach(), ctx.detach(), sd, 4), y.detach(), atol=5e-5)
+    torch.save(dict(cfg=cfg, sd=sd, x=x.detach(), context=ctx.detach(), y=y.detach(), gy=gy, gx=x.grad.clone(),
+                    gcontext=ctx.grad.clone(), grads={k: p_.grad.clone() for k, p_ in m.named_parameters()}),
+               os.path.join(OUT, "spatial_transformer.pt"))
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
     torch.set_num_threads(4)
     only = sys.argv[1:]
     for fn in (gen_linear, gen_layernorm, gen_sdp, gen_attention, gen_feedforward, gen_vit, gen_conv2d,
-               gen_batchnorm, gen_mnist_clf, gen_fcnn, gen_clip, gen_resblock):
+               gen_batchnorm, gen_mnist_clf, gen_fcnn, gen_clip, gen_resblock, gen_spatial_transformer):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

@@ -71,3 +71,51 @@ def residual_block(x: Tensor, t: Optional[Tensor], sd: StateDict, prefix: str = 
     net = silu(group_norm(net, sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"], 32, eps))
     net = CO.conv2d(net, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], 1, 1)
     return inp + net
+
+
+# ---- SpatialTransformer (modules/core/attentions.py:498-569, mixed_stacks/api.py:766-893) ------------------------
+import vit_oracle as O  # noqa: E402
+
+
+def cross_attention(x: Tensor, context: Optional[Tensor], sd: StateDict, prefix: str, num_heads: int) -> Tensor:
+    """CrossAttention.forward: to_q / to_k / to_v without bias, heads split as view(B, T, H, dh), softmax(q k^T /
+    sqrt(dh)) v, merge, out_linear.0 with bias"""
+    ctx = x if context is None else context
+    q = x @ sd[prefix + "to_q.weight"].t()
+    k = ctx @ sd[prefix + "to_k.weight"].t()
+    v = ctx @ sd[prefix + "to_v.weight"].t()
+    b, tq, d = q.shape
+    dh = d // num_heads
+    hd = lambda z: z.reshape(b, z.shape[1], num_heads, dh).permute(0, 2, 1, 3)  # noqa: E731
+    o = O.sdp_attention(hd(q), hd(k), hd(v)).permute(0, 2, 1, 3).reshape(b, tq, d)
+    return o @ sd[prefix + "out_linear.0.weight"].t() + sd[prefix + "out_linear.0.bias"]
+
+
+def geglu_feed_forward(x: Tensor, sd: StateDict, prefix: str) -> Tensor:
+    """FeedForward(activation="geglu") (channel_mixers.py:25-36; activations.py:150-158)"""
+    vg = x @ sd[prefix + "net.0.net.weight"].t() + sd[prefix + "net.0.net.bias"]
+    value, gate = vg.chunk(2, dim=-1)
+    h = value * O.gelu_erf(gate)
+    return h @ sd[prefix + "net.2.linear.weight"].t() + sd[prefix + "net.2.linear.bias"]
+
+
+def spatial_transformer_block(x: Tensor, context: Optional[Tensor], sd: StateDict, prefix: str, num_heads: int) -> Tensor:
+    ln = lambda t, i: O.layer_norm(t, sd[f"{prefix}norm{i}.weight"], sd[f"{prefix}norm{i}.bias"], 1.0e-5)  # noqa: E731
+    x = cross_attention(ln(x, 1), None, sd, prefix + "attn1.", num_heads) + x
+    x = cross_attention(ln(x, 2), context, sd, prefix + "attn2.", num_heads) + x
+    return geglu_feed_forward(ln(x, 3), sd, prefix + "ff.") + x
+
+
+def spatial_transformer(x: Tensor, context: Optional[Tensor], sd: StateDict, num_heads: int, num_layers: int = 1,
+                        prefix: str = "") -> Tensor:
+    """SpatialTransformer.forward with use_linear=False: GroupNorm(32, 1e-6) -> 1x1 conv -> tokens -> blocks ->
+    1x1 conv -> + input"""
+    b, c, h, w = x.shape
+    net = group_norm(x, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], 32, 1.0e-6)
+    wl = sd[prefix + "to_latent.weight"]
+    net = net.permute(0, 2, 3, 1).reshape(b, h * w, c) @ wl.reshape(wl.shape[0], -1).t() + sd[prefix + "to_latent.bias"]
+    for i in range(num_layers):
+        net = spatial_transformer_block(net, context, sd, f"{prefix}blocks.{i}.", num_heads)
+    wo = sd[prefix + "from_latent.weight"]
+    net = net @ wo.reshape(wo.shape[0], -1).t() + sd[prefix + "from_latent.bias"]
+    return x + net.permute(0, 2, 1).reshape(b, c, h, w)

@@ -107,3 +107,48 @@ def test_residual_block_golden(golden):
     down = ResDownsample(32, True, out_channels=48)
     down.load_state_dict(g["down"]["sd"])
     assert_close(down.to(DEV)(x), g["down"]["y"], 8e-3, "ResDownsample")
+
+
+def test_geglu_and_layout_transposes():
+    import vit_oracle as O
+
+    torch.manual_seed(2)
+    vg = bf16_round(torch.randn(37, 2 * 24))
+    vr = vg.clone().requires_grad_(True)
+    v, gate = vr.chunk(2, dim=-1)
+    want = v * O.gelu_erf(gate)
+    gy = bf16_round(torch.randn(37, 24))
+    want.backward(gy)
+    vd = vg.to(DEV).bfloat16().requires_grad_(True)
+    y = HF.geglu(vd)
+    assert_close(y, want, 4e-3, "geglu")
+    y.backward(gy.to(DEV).bfloat16())
+    assert_close(vd.grad, vr.grad, 6e-3, "geglu grad")
+    x = bf16_round(torch.randn(2, 6, 3, 5))
+    xd = x.to(DEV).bfloat16().requires_grad_(True)
+    t = HF.nchw_to_tokens(xd)
+    assert torch.equal(t.float().cpu(), x.permute(0, 2, 3, 1).reshape(2, 15, 6))
+    back = HF.tokens_to_nchw(t, 3, 5)
+    assert torch.equal(back.float().cpu(), x)
+    back.backward(torch.ones_like(back))
+    assert torch.equal(xd.grad.float().cpu(), torch.ones_like(x))
+
+
+def test_spatial_transformer_golden(golden):
+    """SpatialTransformer with 40-channel heads and a cross-attention context vs the reference fixture"""
+    from cflearn_amd.modules import SpatialTransformer
+
+    g = golden("spatial_transformer.pt")
+    m = SpatialTransformer(**g["cfg"])
+    assert list(m.state_dict().keys()) == list(g["sd"].keys())
+    m.load_state_dict(g["sd"])
+    m = m.to(DEV)
+    x = g["x"].to(DEV).requires_grad_(True)
+    ctx = g["context"].to(DEV).requires_grad_(True)
+    y = m(x, ctx)
+    assert_close(y, g["y"], 1e-2, "spatial transformer y")
+    y.backward(g["gy"].to(DEV).bfloat16())
+    assert_close(x.grad, g["gx"], 3e-2, "spatial transformer gx")
+    assert_close(ctx.grad, g["gcontext"], 3e-2, "spatial transformer gcontext")
+    for k, p in m.named_parameters():
+        assert_close(p.grad, g["grads"][k], 4e-2, f"spatial transformer grad {k}", abs_floor=3e-3)

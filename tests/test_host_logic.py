@@ -81,7 +81,7 @@ def test_unsupported_features_raise():
     with pytest.raises(NotImplementedError):
         C.Attention(128, 2, reduction_ratio=2)
     with pytest.raises(NotImplementedError):
-        C.FeedForward(8, 16, 0.0, activation="geglu")
+        C.FeedForward(8, 16, 0.0, activation="glu")
     with pytest.raises(NotImplementedError):
         C.Conv2d(4, 8, kernel_size=3, groups=2)
     with pytest.raises(NotImplementedError):

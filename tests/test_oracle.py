@@ -234,3 +234,21 @@ def test_unet_residual_block_oracle(golden):
     assert (CO.conv2d(UO.upsample2(x), g["up"]["sd"]["conv.weight"], g["up"]["sd"]["conv.bias"], 1, 1) - g["up"]["y"]).abs().max() < 1e-5
     assert (CO.conv2d(x, g["down"]["sd"]["net.weight"], g["down"]["sd"]["net.bias"], 2, 1) - g["down"]["y"]).abs().max() < 1e-5
     assert (UO.timestep_embedding(g["timesteps"], 320) - g["timestep_embedding"]).abs().max() < 1e-6
+
+
+def test_spatial_transformer_oracle(golden):
+    """oracle/unet_oracle.py::spatial_transformer (GroupNorm, 1x1 convs, self / cross attention with 40-channel heads,
+    GEGLU feed-forward) vs the reference SpatialTransformer's frozen output and gradients"""
+    import unet_oracle as UO
+
+    g = golden("spatial_transformer.pt")
+    lv = {k: v.detach().clone().requires_grad_(True) for k, v in g["sd"].items()}
+    x = g["x"].clone().requires_grad_(True)
+    ctx = g["context"].clone().requires_grad_(True)
+    y = UO.spatial_transformer(x, ctx, lv, g["cfg"]["num_heads"])
+    assert (y - g["y"]).abs().max() < 5e-5
+    y.backward(g["gy"])
+    assert (x.grad - g["gx"]).abs().max() <= 2e-4 * max(1.0, g["gx"].abs().max())
+    assert (ctx.grad - g["gcontext"]).abs().max() <= 2e-4 * max(1.0, g["gcontext"].abs().max())
+    for k, ref in g["grads"].items():
+        assert (lv[k].grad - ref).abs().max() <= max(1e-5, 3e-4 * ref.abs().max()), k
