@@ -497,6 +497,33 @@ extern "C" int cfhip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n
   CFHIP_REQUIRE(x, "gelu_bwd: null x");
   CFHIP_EW("gelu_bwd", 1, dy, x, dx)
 }
+// ---- batched strided copy of bf16 rows: dst[b * dst_bs + i] = src[b * src_bs + i], i < n (n % 4 == 0) -------------
+// torch.cat([a, b], dim=1) of NCHW tensors (the UNet's skip connections, unet.py:311-316) = two of these; its
+// backward (the split) two more.
+__global__ void copy_strided_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, long batch, long n,
+                                         long src_bs, long dst_bs) {
+  const long n4 = n >> 2;
+  const long total = batch * n4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long b = i / n4, j = (i - b * n4) * 4;
+    *reinterpret_cast<u32x2*>(dst + b * dst_bs + j) = *reinterpret_cast<const u32x2*>(src + b * src_bs + j);
+  }
+}
+
+extern "C" int cfhip_copy_strided_bf16(const void* src, void* dst, int64_t batch, int64_t n, int64_t src_batch_stride,
+                                       int64_t dst_batch_stride, void* stream) {
+  CFHIP_REQUIRE(src && dst && batch > 0 && n > 0, "copy_strided_bf16: bad arguments");
+  CFHIP_REQUIRE(n % 4 == 0 && src_batch_stride % 4 == 0 && dst_batch_stride % 4 == 0 && ((uintptr_t)src & 7) == 0 &&
+                    ((uintptr_t)dst & 7) == 0,
+                "copy_strided_bf16: lengths / strides must be multiples of 4 elements, pointers 8-byte aligned");
+  hipLaunchKernelGGL(copy_strided_bf16_kernel, dim3(grid_for(batch * (n / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, (bf16_t*)dst, (long)batch, (long)n, (long)src_batch_stride,
+                     (long)dst_batch_stride);
+  CFHIP_CHECK_LAUNCH("copy_strided_bf16");
+  return CFHIP_OK;
+}
+
 // ---- GEGLU (activations.py:150-158): out[m][c] = vg[m][c] * gelu(vg[m][L + c]); 4 bf16 per thread ------------------
 template <bool BWD>
 __global__ void geglu_kernel(const bf16_t* __restrict__ vg, const bf16_t* __restrict__ dy, bf16_t* __restrict__ out,

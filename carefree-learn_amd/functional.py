@@ -554,7 +554,8 @@ class Conv2dFn(Function):
             rows = ops.conv_im2row(x, kh, kw, stride, pad, dil)  # recomputed: k^2 times the input, not kept
             m = rows.shape[0]
             kp = rows.shape[1]
-            split = ops.pick_split_k(cout, kp, m) if m % 8 == 0 else 1
+            # split-K lives on the MFMA path only: its (1,1) layout needs Cout % 8 == 0 (Kp already is)
+            split = ops.pick_split_k(cout, kp, m) if cout % 8 == 0 else 1
 
             def dw_into(out: Tensor, acc: bool) -> None:
                 if kp == k:
@@ -956,3 +957,36 @@ def nchw_to_tokens(x: Tensor) -> Tensor:
 
 def tokens_to_nchw(x: Tensor, h: int, w: int) -> Tensor:
     return TokensToNchwFn.apply(x, h, w)
+
+
+class ConcatChannelsFn(Function):
+    """torch.cat([a, b], dim=1) for NCHW bf16 tensors (the UNet's skip connections, unet.py:311-316)"""
+
+    @staticmethod
+    def forward(ctx: Any, a: Tensor, b: Tensor) -> Tensor:
+        a = (a if a.dtype == bf16 else ops.to_bf16(a.float().contiguous())).contiguous()
+        b = (b if b.dtype == bf16 else ops.to_bf16(b.float().contiguous())).contiguous()
+        n, ca, cb = a.shape[0], a.shape[1], b.shape[1]
+        inner = a.numel() // (n * ca)
+        out = torch.empty((n, ca + cb, *a.shape[2:]), dtype=bf16, device=a.device)
+        tot = (ca + cb) * inner
+        ops.copy_strided(a, out, n, ca * inner, ca * inner, tot)
+        ops.copy_strided(b, out, n, cb * inner, cb * inner, tot, dst_off=ca * inner)
+        ctx.split = (ca, cb, inner)
+        return out
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        ca, cb, inner = ctx.split
+        dy = (dy if dy.dtype == bf16 else ops.to_bf16(dy.float().contiguous())).contiguous()
+        n = dy.shape[0]
+        da = torch.empty((n, ca, *dy.shape[2:]), dtype=bf16, device=dy.device)
+        db = torch.empty((n, cb, *dy.shape[2:]), dtype=bf16, device=dy.device)
+        tot = (ca + cb) * inner
+        ops.copy_strided(dy, da, n, ca * inner, tot, ca * inner)
+        ops.copy_strided(dy, db, n, cb * inner, tot, cb * inner, src_off=ca * inner)
+        return da, db
+
+
+def concat_channels(a: Tensor, b: Tensor) -> Tensor:
+    return ConcatChannelsFn.apply(a, b)

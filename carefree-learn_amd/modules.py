@@ -1447,3 +1447,128 @@ class SpatialTransformer(Module):
         wo = self.from_latent.weight
         tokens = HF.linear(tokens, wo.view(wo.shape[0], -1), self.from_latent.bias)
         return HF.add(inp, HF.tokens_to_nchw(tokens, h, w))
+
+
+# ---------------------------------------------------------------------------------------------
+# UNet (reference modules/multimodal/diffusion/unet.py:25-322)
+# ---------------------------------------------------------------------------------------------
+
+
+class TimestepAttnSequential(nn.Sequential):
+    """reference unet.py:31-45: residual blocks get the time embedding, spatial transformers the context"""
+
+    def forward(self, net: Tensor, time_net: Tensor, context: Optional[Tensor] = None) -> Tensor:  # type: ignore
+        for layer in self:
+            if isinstance(layer, ResidualBlockWithTimeEmbedding):
+                net = layer(net, time_net)
+            elif isinstance(layer, SpatialTransformer):
+                net = layer(net, context)
+            else:
+                net = layer(net)
+        return net
+
+
+@register_module("unet_diffuser")
+class UNetDiffuser(Module):
+    """reference unet.py:76-322 with `use_spatial_transformer=True` (the zoo `diffusion/ddpm` configuration): time
+    embedding MLP, input blocks (ResBlock [+ SpatialTransformer] x num_res_blocks, conv down-sampling), middle block,
+    output blocks over channel-concatenated skip connections (+ nearest up-sampling), GroupNorm -> SiLU -> conv head.
+    State keys are the reference's (`time_embedding.{0,2}.*`, `input_blocks.<i>.<j>.*`, `residual.*`,
+    `output_blocks.*`, `head.{0,2}.*`).  Class labels, ControlNet residuals, `MultiHeadSpatialAttention`, scale-shift
+    norm, resampling through ResBlocks and dropout are outside the accelerated hot path."""
+
+    def __init__(self, in_channels: int, out_channels: int, *, num_heads: Optional[int] = None,
+                 num_head_channels: Optional[int] = None, use_spatial_transformer: bool = False,
+                 num_transformer_layers: int = 1, context_dim: Optional[int] = None, signal_dim: int = 2,
+                 start_channels: int = 320, num_res_blocks: int = 2,
+                 attention_downsample_rates: Tuple[int, ...] = (1, 2, 4), dropout: float = 0.0,
+                 channel_multipliers: Tuple[int, ...] = (1, 2, 4, 8), resample_with_conv: bool = True,
+                 resample_with_resblock: bool = False, use_scale_shift_norm: bool = False,
+                 num_classes: Optional[int] = None, use_linear_in_transformer: bool = False,
+                 use_checkpoint: bool = False, hooks_kwargs: Optional[Dict[str, Any]] = None):
+        super().__init__()
+        if (not use_spatial_transformer or signal_dim != 2 or resample_with_resblock or use_scale_shift_norm
+                or num_classes is not None or use_linear_in_transformer or dropout > 0.0 or hooks_kwargs):
+            raise NotImplementedError("only the spatial-transformer 2-D UNet without labels / scale-shift norm / "
+                                      "ResBlock resampling / dropout is on the accelerated hot path")
+        self.in_channels, self.out_channels, self.context_dim = in_channels, out_channels, context_dim
+        self.num_heads, self.num_head_channels = num_heads, num_head_channels
+        self.start_channels, self.num_res_blocks = start_channels, num_res_blocks
+        self.attention_downsample_rates = tuple(attention_downsample_rates)
+        self.channel_multipliers = tuple(channel_multipliers)
+        self.num_classes, self.label_embedding = None, None
+        ted = start_channels * 4
+        self.time_embedding = nn.Sequential(HijackLinear(start_channels, ted), nn.SiLU(), HijackLinear(ted, ted))
+
+        def res(in_c: int, out_c: int) -> Module:
+            return ResidualBlockWithTimeEmbedding(in_c, out_c, norm_eps=1.0e-5, time_embedding_channels=ted,
+                                                  use_checkpoint=use_checkpoint)
+
+        def attn(in_c: int) -> Module:
+            if num_head_channels is not None:
+                n_heads, head_c = in_c // num_head_channels, num_head_channels
+            else:
+                if num_heads is None:
+                    raise ValueError("either `num_heads` or `num_head_channels` should be provided")
+                n_heads, head_c = num_heads, in_c // num_heads
+            return SpatialTransformer(in_c, n_heads, head_c, num_layers=num_transformer_layers,
+                                      context_dim=context_dim, use_checkpoint=use_checkpoint)
+
+        input_blocks: List[Module] = [TimestepAttnSequential(HijackConv2d(in_channels, start_channels, 3, padding=1))]
+        skip_channels = [start_channels]
+        in_nc, rate = start_channels, 1
+        for i, mult in enumerate(self.channel_multipliers):
+            for _ in range(num_res_blocks):
+                out_nc = mult * start_channels
+                blocks = [res(in_nc, out_nc)]
+                in_nc = out_nc
+                if rate in self.attention_downsample_rates:
+                    blocks.append(attn(in_nc))
+                input_blocks.append(TimestepAttnSequential(*blocks))
+                skip_channels.append(in_nc)
+            if i != len(self.channel_multipliers) - 1:
+                input_blocks.append(TimestepAttnSequential(
+                    ResDownsample(in_nc, resample_with_conv, out_channels=in_nc)))
+                rate *= 2
+                skip_channels.append(in_nc)
+        self.input_blocks = nn.ModuleList(input_blocks)
+        self.residual = TimestepAttnSequential(res(in_nc, in_nc), attn(in_nc), res(in_nc, in_nc))
+        output_blocks: List[Module] = []
+        for i, mult in list(enumerate(self.channel_multipliers))[::-1]:
+            for idx in range(num_res_blocks + 1):
+                idx_nc = skip_channels.pop()
+                out_nc = start_channels * mult
+                blocks = [res(in_nc + idx_nc, out_nc)]
+                in_nc = out_nc
+                if rate in self.attention_downsample_rates:
+                    blocks.append(attn(in_nc))
+                if i != 0 and idx == num_res_blocks:
+                    blocks.append(ResUpsample(in_nc, resample_with_conv, out_channels=in_nc))
+                    rate //= 2
+                output_blocks.append(TimestepAttnSequential(*blocks))
+        self.output_blocks = nn.ModuleList(output_blocks)
+        head_conv = HijackConv2d(start_channels, out_channels, 3, padding=1)
+        with torch.no_grad():  # zero_module
+            for p in head_conv.parameters():
+                p.zero_()
+        self.head = nn.Sequential(GroupNorm(32, in_nc), nn.SiLU(), head_conv)
+
+    def forward(self, net: Tensor, *, timesteps: Tensor, context: Optional[Tensor] = None,
+                labels: Optional[Tensor] = None, control: Any = None, only_mid_control: bool = False) -> Tensor:
+        if labels is not None or control is not None:
+            raise NotImplementedError("class labels / ControlNet residuals are outside the accelerated hot path")
+        from . import ops
+
+        te = self.time_embedding
+        time_net = ops.timestep_embedding(timesteps.to(torch.int64), self.start_channels)  # f32 [B, start]
+        time_net = HF.linear(time_net, te[0].weight, te[0].bias, out_f32=True)
+        time_net = HF.linear(HF.silu_f32(time_net), te[2].weight, te[2].bias, out_f32=True)  # f32 [B, 4 * start]
+        nets: List[Tensor] = []
+        for block in self.input_blocks:
+            net = block(net, time_net, context)
+            nets.append(net)
+        net = self.residual(net, time_net, context)
+        for block in self.output_blocks:
+            net = block(HF.concat_channels(net, nets.pop()), time_net, context)
+        net = self.head[0](net, silu=True)  # GroupNorm + SiLU in one kernel
+        return self.head[2](net)

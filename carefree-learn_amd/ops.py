@@ -816,3 +816,13 @@ def geglu_bwd(dy: Tensor, vg: Tensor) -> Tensor:
     _lib.check(_lib.load().cfhip_geglu_bwd(dy.contiguous().data_ptr(), vg.data_ptr(), dvg.data_ptr(),
                                            vg.numel() // (2 * l), l, _stream()), "geglu_bwd")
     return dvg
+
+
+def copy_strided(src: Tensor, dst: Tensor, batch: int, n: int, src_bs: int, dst_bs: int, src_off: int = 0,
+                 dst_off: int = 0) -> None:
+    """dst.flat[dst_off + b*dst_bs + i] = src.flat[src_off + b*src_bs + i] for b < batch, i < n (bf16)"""
+    _need(src, bf16, "src")
+    _need(dst, bf16, "dst")
+    rc = _lib.load().cfhip_copy_strided_bf16(src.data_ptr() + 2 * src_off, dst.data_ptr() + 2 * dst_off, batch, n, src_bs,
+                                             dst_bs, _stream())
+    _lib.check(rc, "copy_strided_bf16")

@@ -189,6 +189,10 @@ int cfhip_gelu_fwd(const void* x, void* y, int64_t n, void* stream);            
 int cfhip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
 int cfhip_quick_gelu_fwd(const void* x, void* y, int64_t n, void* stream);        /* x * sigmoid(1.702 x) */
 int cfhip_quick_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
+/* dst[b * dst_bs + i] = src[b * src_bs + i] (bf16, i < n, everything a multiple of 4 elements): channel concat /
+ * split of NCHW tensors — torch.cat(dim=1) of the UNet skip connections (multimodal/diffusion/unet.py:311-316) */
+int cfhip_copy_strided_bf16(const void* src, void* dst, int64_t batch, int64_t n, int64_t src_batch_stride,
+                            int64_t dst_batch_stride, void* stream);
 /* GEGLU (activations.py:150-158): out[m][c] = vg[m][c] * gelu_erf(vg[m][L + c]) for vg bf16 [M][2L]; bwd writes dvg */
 int cfhip_geglu_fwd(const void* vg, void* out, int64_t M, int L, void* stream);
 int cfhip_geglu_bwd(const void* dy, const void* vg, void* dvg, int64_t M, int L, void* stream);

@@ -390,13 +390,43 @@ def gen_spatial_transformer(ref) -> None:
                os.path.join(OUT, "spatial_transformer.pt"))
 
 
+def gen_unet(ref) -> None:
+    """UNetDiffuser (multimodal/diffusion/unet.py:76-322) in the zoo `diffusion/ddpm` structure (spatial transformers at
+    every resolution, conv down-sampling, nearest up-sampling + conv, skip concatenation) at a small size, with the DDPM
+    epsilon-prediction objective (models/cv/diffusion.py:44-94: MSE between the prediction and the noise) as the scalar
+    the backward pass differentiates."""
+    import importlib
+
+    unet = importlib.import_module("cflearn.modules.multimodal.diffusion.unet")
+    torch.manual_seed(110)
+    cfg = dict(in_channels=3, out_channels=3, num_heads=4, use_spatial_transformer=True, num_transformer_layers=1,
+               context_dim=48, start_channels=32, num_res_blocks=1, attention_downsample_rates=(1, 2),
+               channel_multipliers=(1, 2))
+    m = unet.UNetDiffuser(**cfg)
+    with torch.no_grad():  # several layers are zero-initialised: perturb so every gradient is exercised
+        for p_ in m.parameters():
+            p_.add_(torch.randn_like(p_) * 0.03)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 3, 16, 16)
+    t = torch.tensor([7, 912])
+    ctx = torch.randn(2, 5, 48)
+    noise = torch.randn(2, 3, 16, 16)
+    y = m(x, timesteps=t, context=ctx)
+    _check("unet output", UO.unet_diffuser(x, t, ctx, sd, cfg), y.detach(), atol=1e-4)
+    loss = torch.nn.functional.mse_loss(y, noise)
+    loss.backward()
+    torch.save(dict(cfg=cfg, sd=sd, x=x, timesteps=t, context=ctx, noise=noise, y=y.detach(), loss=loss.detach(),
+                    grads={k: p_.grad.clone().half() for k, p_ in m.named_parameters()}),
+               os.path.join(OUT, "unet_small.pt"))
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
     torch.set_num_threads(4)
     only = sys.argv[1:]
     for fn in (gen_linear, gen_layernorm, gen_sdp, gen_attention, gen_feedforward, gen_vit, gen_conv2d,
-               gen_batchnorm, gen_mnist_clf, gen_fcnn, gen_clip, gen_resblock, gen_spatial_transformer):
+               gen_batchnorm, gen_mnist_clf, gen_fcnn, gen_clip, gen_resblock, gen_spatial_transformer, gen_unet):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

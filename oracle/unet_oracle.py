@@ -119,3 +119,67 @@ def spatial_transformer(x: Tensor, context: Optional[Tensor], sd: StateDict, num
     wo = sd[prefix + "from_latent.weight"]
     net = net @ wo.reshape(wo.shape[0], -1).t() + sd[prefix + "from_latent.bias"]
     return x + net.permute(0, 2, 1).reshape(b, c, h, w)
+
+
+# ---- UNetDiffuser (modules/multimodal/diffusion/unet.py:76-322), use_spatial_transformer=True ----------------------
+
+
+def unet_layout(cfg: dict):
+    """The block structure the constructor builds (unet.py:206-262): lists of layer kinds per TimestepAttnSequential"""
+    mults = tuple(cfg["channel_multipliers"])
+    nres = cfg["num_res_blocks"]
+    rates = tuple(cfg["attention_downsample_rates"])
+    inputs = [["conv"]]
+    rate = 1
+    for i, _ in enumerate(mults):
+        for _ in range(nres):
+            inputs.append(["res"] + (["attn"] if rate in rates else []))
+        if i != len(mults) - 1:
+            inputs.append(["down"])
+            rate *= 2
+    outputs = []
+    for i, _ in list(enumerate(mults))[::-1]:
+        for idx in range(nres + 1):
+            blk = ["res"] + (["attn"] if rate in rates else [])
+            if i != 0 and idx == nres:
+                blk.append("up")
+                rate //= 2
+            outputs.append(blk)
+    return inputs, ["res", "attn", "res"], outputs
+
+
+def unet_diffuser(x: Tensor, timesteps: Tensor, context: Optional[Tensor], sd: StateDict, cfg: dict) -> Tensor:
+    """UNetDiffuser.forward (unet.py:268-322) without labels / control"""
+    start = cfg["start_channels"]
+    heads = cfg["num_heads"]
+    nlayers = cfg.get("num_transformer_layers", 1)
+    t = timestep_embedding(timesteps, start)
+    t = t @ sd["time_embedding.0.weight"].t() + sd["time_embedding.0.bias"]
+    t = silu(t) @ sd["time_embedding.2.weight"].t() + sd["time_embedding.2.bias"]
+
+    def run(net: Tensor, kinds, prefix: str) -> Tensor:
+        for li, kind in enumerate(kinds):
+            p = f"{prefix}{li}."
+            if kind == "conv":
+                net = CO.conv2d(net, sd[p + "weight"], sd[p + "bias"], 1, 1)
+            elif kind == "res":
+                net = residual_block(net, t, sd, p, eps=1.0e-5)
+            elif kind == "attn":
+                net = spatial_transformer(net, context, sd, heads, nlayers, p)
+            elif kind == "down":
+                net = CO.conv2d(net, sd[p + "net.weight"], sd[p + "net.bias"], 2, 1)
+            elif kind == "up":
+                net = CO.conv2d(upsample2(net), sd[p + "conv.weight"], sd[p + "conv.bias"], 1, 1)
+        return net
+
+    inputs, mid, outputs = unet_layout(cfg)
+    nets = []
+    net = x
+    for bi, kinds in enumerate(inputs):
+        net = run(net, kinds, f"input_blocks.{bi}.")
+        nets.append(net)
+    net = run(net, mid, "residual.")
+    for bi, kinds in enumerate(outputs):
+        net = run(torch.cat([net, nets.pop()], dim=1), kinds, f"output_blocks.{bi}.")
+    net = silu(group_norm(net, sd["head.0.weight"], sd["head.0.bias"], 32, 1.0e-5))
+    return CO.conv2d(net, sd["head.2.weight"], sd["head.2.bias"], 1, 1)

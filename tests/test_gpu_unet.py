@@ -152,3 +152,28 @@ def test_spatial_transformer_golden(golden):
     assert_close(ctx.grad, g["gcontext"], 3e-2, "spatial transformer gcontext")
     for k, p in m.named_parameters():
         assert_close(p.grad, g["grads"][k], 4e-2, f"spatial transformer grad {k}", abs_floor=3e-3)
+
+
+def test_unet_diffuser_golden(golden):
+    """The whole UNet (time embedding MLP, res blocks, spatial transformers with 8 / 16-channel heads and a context,
+    strided-conv down-sampling, nearest up-sampling, skip concatenation, GroupNorm-SiLU-conv head) and the DDPM
+    epsilon-prediction MSE step vs the reference's fp32 CPU run."""
+    g = golden("unet_small.pt")
+    m = C.build_module("unet_diffuser", config=dict(g["cfg"]))
+    assert list(m.state_dict().keys()) == list(g["sd"].keys())
+    m.load_state_dict(g["sd"])
+    m = m.to(DEV)
+    y = m(g["x"].to(DEV), timesteps=g["timesteps"].to(DEV), context=g["context"].to(DEV))
+    assert y.shape == g["y"].shape
+    assert_close(y, g["y"], 2e-2, "unet output")
+    loss = torch.nn.functional.mse_loss(y.float(), g["noise"].to(DEV))
+    assert abs(loss.item() - g["loss"].item()) <= 1e-2 * abs(g["loss"].item())
+    loss.backward()
+    worst = 0.0
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        ref = g["grads"][k].float()
+        err = assert_close(p.grad, ref, 8e-2, f"unet grad {k}", abs_floor=1e-4)
+        if ref.abs().max() > 0:  # (32 channels in 32 groups: biases in front of such a GroupNorm have a zero gradient)
+            worst = max(worst, err)
+    print(f"unet worst grad rel-L2 vs fp32 reference {worst:.3e}")

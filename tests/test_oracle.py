@@ -252,3 +252,20 @@ def test_spatial_transformer_oracle(golden):
     assert (ctx.grad - g["gcontext"]).abs().max() <= 2e-4 * max(1.0, g["gcontext"].abs().max())
     for k, ref in g["grads"].items():
         assert (lv[k].grad - ref).abs().max() <= max(1e-5, 3e-4 * ref.abs().max()), k
+
+
+def test_unet_diffuser_oracle(golden):
+    """oracle/unet_oracle.py::unet_diffuser vs the reference UNetDiffuser (zoo diffusion/ddpm structure, small):
+    output, epsilon-prediction MSE loss and every parameter gradient (stored as fp16 in the fixture)"""
+    import unet_oracle as UO
+
+    g = golden("unet_small.pt")
+    lv = {k: v.detach().clone().requires_grad_(True) for k, v in g["sd"].items()}
+    y = UO.unet_diffuser(g["x"], g["timesteps"], g["context"], lv, g["cfg"])
+    assert (y - g["y"]).abs().max() < 1e-4
+    loss = torch.nn.functional.mse_loss(y, g["noise"])
+    assert abs(loss.item() - g["loss"].item()) < 1e-5
+    loss.backward()
+    for k, ref in g["grads"].items():
+        ref = ref.float()
+        assert (lv[k].grad - ref).abs().max() <= max(2e-5, 2e-3 * ref.abs().max()), k
