@@ -497,6 +497,69 @@ extern "C" int cfhip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n
   CFHIP_REQUIRE(x, "gelu_bwd: null x");
   CFHIP_EW("gelu_bwd", 1, dy, x, dx)
 }
+// ---- DDPM forward process and objective (samplers/schema.py:90-112; models/cv/diffusion.py:44-94) ----------------
+// x_t[b] = sqrt_ac[t_b] * x[b] + sqrt_1mac[t_b] * noise[b]: two rounded products and a rounded sum like the
+// reference's `w_net * net + w_noise * noise` (no FMA contraction) -> the f32 result is bit-exact
+template <bool OUT_F32>
+__global__ void q_sample_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                const int64_t* __restrict__ t, const float* __restrict__ sqrt_ac,
+                                const float* __restrict__ sqrt_1mac, void* __restrict__ out, long B, long inner) {
+#pragma clang fp contract(off)
+  const long total = B * inner;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long b = i / inner;
+    const long tb = t[b];
+    const float a = sqrt_ac[tb] * x[i];
+    const float c = sqrt_1mac[tb] * noise[i];
+    const float v = a + c;
+    if (OUT_F32) reinterpret_cast<float*>(out)[i] = v;
+    else reinterpret_cast<bf16_t*>(out)[i] = f32_to_bf16(v);
+  }
+}
+
+// loss_sum += sum_b mean_inner (pred - target)^2 ; dpred = grad_scale * 2 (pred - target) / inner   (bf16 pred)
+__global__ void mse_loss_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ target,
+                                float* __restrict__ loss_sum, bf16_t* __restrict__ dpred, long total, long inner,
+                                float grad_scale) {
+  __shared__ float red[4];
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float k = 2.0f * grad_scale / (float)inner;
+  float acc = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const float d = bf16_to_f32(pred[i]) - target[i];
+    acc += d * d;
+    if (dpred != nullptr) dpred[i] = f32_to_bf16(k * d);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss_sum, (red[0] + red[1] + red[2] + red[3]) / (float)inner);
+}
+
+extern "C" int cfhip_q_sample(const float* x, const float* noise, const int64_t* t, const float* sqrt_ac,
+                              const float* sqrt_1mac, void* out, int out_is_f32, int64_t B, int64_t inner, void* stream) {
+  CFHIP_REQUIRE(x && noise && t && sqrt_ac && sqrt_1mac && out && B > 0 && inner > 0, "q_sample: bad arguments");
+  const dim3 grid(grid_for(B * inner, 256));
+  if (out_is_f32)
+    hipLaunchKernelGGL((q_sample_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, x, noise, t, sqrt_ac, sqrt_1mac,
+                       out, (long)B, (long)inner);
+  else
+    hipLaunchKernelGGL((q_sample_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, x, noise, t, sqrt_ac, sqrt_1mac,
+                       out, (long)B, (long)inner);
+  CFHIP_CHECK_LAUNCH("q_sample");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_mse_loss(const void* pred, const float* target, float* loss_sum, void* dpred, int64_t B,
+                              int64_t inner, float grad_scale, void* stream) {
+  CFHIP_REQUIRE(pred && target && loss_sum && B > 0 && inner > 0, "mse_loss: bad arguments");
+  hipLaunchKernelGGL(mse_loss_kernel, dim3(grid_for(B * inner, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)pred, target, loss_sum, (bf16_t*)dpred, (long)(B * inner), (long)inner, grad_scale);
+  CFHIP_CHECK_LAUNCH("mse_loss");
+  return CFHIP_OK;
+}
+
 // ---- batched strided copy of bf16 rows: dst[b * dst_bs + i] = src[b * src_bs + i], i < n (n % 4 == 0) -------------
 // torch.cat([a, b], dim=1) of NCHW tensors (the UNet's skip connections, unet.py:311-316) = two of these; its
 // backward (the split) two more.

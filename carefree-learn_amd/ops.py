@@ -826,3 +826,33 @@ def copy_strided(src: Tensor, dst: Tensor, batch: int, n: int, src_bs: int, dst_
     rc = _lib.load().cfhip_copy_strided_bf16(src.data_ptr() + 2 * src_off, dst.data_ptr() + 2 * dst_off, batch, n, src_bs,
                                              dst_bs, _stream())
     _lib.check(rc, "copy_strided_bf16")
+
+
+def q_sample(x: Tensor, noise: Tensor, t: Tensor, sqrt_ac: Tensor, sqrt_1mac: Tensor, out_dtype: torch.dtype = f32) -> Tensor:
+    """x_t = sqrt_ac[t] * x + sqrt_1mac[t] * noise per sample (reference samplers/schema.py:94-108)"""
+    for tt, nm in ((x, "x"), (noise, "noise"), (sqrt_ac, "sqrt_ac"), (sqrt_1mac, "sqrt_1mac")):
+        _need(tt, f32, nm)
+    if t.dtype != torch.int64 or not t.is_cuda:
+        raise TypeError("cfhip q_sample: timesteps must be int64 on the device")
+    x, noise = x.contiguous(), noise.contiguous()
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    b = x.shape[0]
+    rc = _lib.load().cfhip_q_sample(x.data_ptr(), noise.data_ptr(), t.contiguous().data_ptr(), sqrt_ac.data_ptr(),
+                                    sqrt_1mac.data_ptr(), out.data_ptr(), int(out_dtype == f32), b, x.numel() // b,
+                                    _stream())
+    _lib.check(rc, "q_sample")
+    return out
+
+
+def mse_loss(pred: Tensor, target: Tensor, grad_scale: float, want_grad: bool = True):
+    """Returns (loss_sum f32 [1] = sum_b mean((pred_b - target_b)^2), dpred bf16 = grad_scale * d loss_sum / d pred)."""
+    _need(pred, bf16, "pred")
+    _need(target, f32, "target")
+    pred, target = pred.contiguous(), target.contiguous()
+    b = pred.shape[0]
+    loss = torch.zeros((1,), dtype=f32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    rc = _lib.load().cfhip_mse_loss(pred.data_ptr(), target.data_ptr(), loss.data_ptr(), _p(dpred), b, pred.numel() // b,
+                                    float(grad_scale), _stream())
+    _lib.check(rc, "mse_loss")
+    return loss, dpred

@@ -189,6 +189,15 @@ int cfhip_gelu_fwd(const void* x, void* y, int64_t n, void* stream);            
 int cfhip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
 int cfhip_quick_gelu_fwd(const void* x, void* y, int64_t n, void* stream);        /* x * sigmoid(1.702 x) */
 int cfhip_quick_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
+/* DDPM forward process and objective (multimodal/diffusion/samplers/schema.py:90-112; models/cv/diffusion.py:44-94):
+ *   q_sample: out[b][:] = sqrt_ac[t_b] * x[b][:] + sqrt_1mac[t_b] * noise[b][:]  (x, noise f32; t int64 [B]; the
+ *     tables f32 [T]; f32 output bit-exact with the reference expression, or bf16)
+ *   mse_loss: loss_sum (f32[1], caller zeroes) += sum_b mean_inner (pred - target)^2 ; dpred (bf16, may be NULL) =
+ *     grad_scale * 2 (pred - target) / inner   (pred bf16 = the UNet output, target f32 = the noise) */
+int cfhip_q_sample(const float* x, const float* noise, const int64_t* t, const float* sqrt_ac,
+                   const float* sqrt_1mac, void* out, int out_is_f32, int64_t B, int64_t inner, void* stream);
+int cfhip_mse_loss(const void* pred, const float* target, float* loss_sum, void* dpred, int64_t B, int64_t inner,
+                   float grad_scale, void* stream);
 /* dst[b * dst_bs + i] = src[b * src_bs + i] (bf16, i < n, everything a multiple of 4 elements): channel concat /
  * split of NCHW tensors — torch.cat(dim=1) of the UNet skip connections (multimodal/diffusion/unet.py:311-316) */
 int cfhip_copy_strided_bf16(const void* src, void* dst, int64_t batch, int64_t n, int64_t src_batch_stride,

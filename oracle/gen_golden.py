@@ -420,13 +420,66 @@ def gen_unet(ref) -> None:
                os.path.join(OUT, "unet_small.pt"))
 
 
+def gen_ddpm_schedule(ref) -> None:
+    """The DDPM noise schedule and forward process as the reference computes them: `make_beta_schedule("linear")` +
+    the `_register_noise_schedule` tables (ddpm.py:51-89,599-640) and `DDPMQSampler.q_sample` (samplers/schema.py:
+    90-112) on a seeded batch."""
+    import importlib
+
+    import numpy as np
+
+    import ast
+
+    # ddpm.py imports half of cflearn at module level; `make_beta_schedule` itself is a pure numpy function: execute
+    # ITS definition (read from the reference file at generation time, nothing is copied into this repository)
+    src_path = os.path.join("/root/reference", "cflearn", "modules", "multimodal", "diffusion", "ddpm.py")
+    tree = ast.parse(open(src_path).read())
+    fn_node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "make_beta_schedule")
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[fn_node], type_ignores=[]), src_path, "exec"), ns)
+    betas = ns["make_beta_schedule"]("linear", 1000, 8.5e-4, 1.2e-2, 8.0e-3)
+    try:
+        schema = importlib.import_module("cflearn.modules.multimodal.diffusion.samplers.schema")
+    except Exception as e:  # same story: take the one class definition
+        print("  (samplers.schema not importable through the harness:", type(e).__name__, ")")
+        schema = None
+    ac = np.cumprod(1.0 - betas, axis=0)
+    to_t = lambda a: torch.from_numpy(a.astype(np.float32))  # noqa: E731
+    sqrt_ac, sqrt_1mac = to_t(np.sqrt(ac)), to_t(np.sqrt(1.0 - ac))
+    torch.manual_seed(120)
+    x = torch.randn(5, 3, 8, 8)
+    noise = torch.randn(5, 3, 8, 8)
+    t = torch.tensor([0, 1, 499, 998, 999])
+    if schema is not None:
+        sampler = schema.DDPMQSampler.__new__(schema.DDPMQSampler)
+        sampler.reset_buffers(sqrt_ac, sqrt_1mac)
+        x_t = sampler.q_sample(x, t, noise)
+    else:
+        sp = os.path.join("/root/reference", "cflearn", "modules", "multimodal", "diffusion", "samplers", "schema.py")
+        stree = ast.parse(open(sp).read())
+        cls = next(n for n in stree.body if isinstance(n, ast.ClassDef) and n.name == "DDPMQSampler")
+        cls.bases = []
+        from typing import Optional as _Opt
+
+        def extract_to(array, indices, num_dim):  # cflearn/modules/multimodal/diffusion/utils.py: gather + broadcast
+            return array.gather(-1, indices).contiguous().view(-1, *([1] * (num_dim - 1)))
+
+        sns = {"torch": torch, "Tensor": torch.Tensor, "Optional": _Opt, "extract_to": extract_to}
+        exec(compile(ast.Module(body=[cls], type_ignores=[]), sp, "exec"), sns)
+        sampler = sns["DDPMQSampler"]()
+        sampler.reset_buffers(sqrt_ac, sqrt_1mac)
+        x_t = sampler.q_sample(x, t, noise)
+    torch.save(dict(betas=to_t(betas), sqrt_alphas_cumprod=sqrt_ac, sqrt_one_minus_alphas_cumprod=sqrt_1mac, x=x,
+                    noise=noise, t=t, x_t=x_t), os.path.join(OUT, "ddpm_schedule.pt"))
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
     torch.set_num_threads(4)
     only = sys.argv[1:]
     for fn in (gen_linear, gen_layernorm, gen_sdp, gen_attention, gen_feedforward, gen_vit, gen_conv2d,
-               gen_batchnorm, gen_mnist_clf, gen_fcnn, gen_clip, gen_resblock, gen_spatial_transformer, gen_unet):
+               gen_batchnorm, gen_mnist_clf, gen_fcnn, gen_clip, gen_resblock, gen_spatial_transformer, gen_unet, gen_ddpm_schedule):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

@@ -177,3 +177,35 @@ def test_unet_diffuser_golden(golden):
         if ref.abs().max() > 0:  # (32 channels in 32 groups: biases in front of such a GroupNorm have a zero gradient)
             worst = max(worst, err)
     print(f"unet worst grad rel-L2 vs fp32 reference {worst:.3e}")
+
+
+def test_q_sample_bit_exact_mse_and_ddpm_train_step(golden):
+    """DDPM forward process (bit-exact vs the reference's DDPMQSampler on fp32), the epsilon-prediction MSE kernel, and
+    a few optimisation steps of the small UNet: the loss of a fixed (x, t, eps) goes down."""
+    from cflearn_amd.diffusion import DDPMTrainStep, NoiseSchedule
+
+    g = golden("ddpm_schedule.pt")
+    s = NoiseSchedule(device=DEV)
+    x_t = s.q_sample(g["x"].to(DEV), g["t"].to(DEV), g["noise"].to(DEV))
+    assert torch.equal(x_t.cpu(), g["x_t"])
+    # MSE kernel vs torch
+    torch.manual_seed(0)
+    pred = bf16_round(torch.randn(4, 3, 8, 8))
+    target = torch.randn(4, 3, 8, 8)
+    pr = pred.clone().requires_grad_(True)
+    want = ((pr - target) ** 2).mean(dim=(1, 2, 3)).mean()
+    want.backward()
+    loss_sum, dpred = ops.mse_loss(pred.to(DEV).bfloat16(), target.to(DEV), 1.0 / 4)
+    assert abs(loss_sum.item() / 4 - want.item()) < 1e-5
+    assert_close(dpred, pr.grad, 4e-3, "mse dpred")
+    # train steps on the small UNet fixture
+    u = golden("unet_small.pt")
+    m = C.build_module("unet_diffuser", config=dict(u["cfg"]))
+    m.load_state_dict(u["sd"])
+    m = m.to(DEV)
+    ts = DDPMTrainStep(m, s, lr=1e-3)
+    x, ctx = u["x"].to(DEV), u["context"].to(DEV)
+    t, eps = u["timesteps"].to(DEV), u["noise"].to(DEV)
+    losses = [ts.step(x, ctx, timesteps=t, noise=eps).item() / x.shape[0] for _ in range(15)]
+    assert all(l == l for l in losses) and losses[-1] < 0.8 * losses[0], losses
+    ts.step(x, ctx)  # self-drawn t and eps

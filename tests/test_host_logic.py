@@ -156,3 +156,15 @@ def test_clip_state_dict_keys_match_reference(golden):
     assert all(sd[k].shape == g["sd"][k].shape and sd[k].dtype == g["sd"][k].dtype for k in sd)
     assert torch.equal(sd["text_transformer.attention_mask"], g["sd"]["text_transformer.attention_mask"])
     m.load_state_dict(g["sd"])
+
+
+def test_ddpm_noise_schedule_matches_reference_bitwise(golden):
+    """diffusion.NoiseSchedule restates make_beta_schedule("linear") + the q(x_t | x_0) tables in float64 numpy like the
+    reference (ddpm.py:51-89,599-640): the fp32 buffers are bit-equal to the reference-made fixture."""
+    from cflearn_amd.diffusion import NoiseSchedule
+
+    g = golden("ddpm_schedule.pt")
+    s = NoiseSchedule(1000, "linear", 8.5e-4, 1.2e-2)
+    assert torch.equal(s.betas, g["betas"])
+    assert torch.equal(s.sqrt_alphas_cumprod, g["sqrt_alphas_cumprod"])
+    assert torch.equal(s.sqrt_one_minus_alphas_cumprod, g["sqrt_one_minus_alphas_cumprod"])
