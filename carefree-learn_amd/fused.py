@@ -60,6 +60,9 @@ def _dw_db(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> None:
             cb(prm)
 
 
+SPLIT_LN_BWD = True
+
+
 def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: Tensor,
             dx_add: Optional[Tensor]) -> Tensor:
     """LayerNorm backward, split in two launches: the input gradient (with the residual-gradient add
@@ -69,7 +72,7 @@ def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: T
 
     gamma = w.detach()
 
-    def param_grads() -> None:
+    def param_grads(with_dx: bool = False) -> Optional[Tensor]:
         for prm in (w, b):
             if prm.grad is None:
                 prm.grad = torch.empty(prm.shape, dtype=f32, device=prm.device)
@@ -81,13 +84,16 @@ def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: T
                 if getattr(prm, "_cfhip_fresh", False):
                     prm.grad.zero_()
             acc_w = True
-        ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dgamma=w.grad.view(-1), dbeta=b.grad.view(-1),
-                          accumulate=acc_w, want_dx=False)
+        dx, _, _ = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dgamma=w.grad.view(-1), dbeta=b.grad.view(-1),
+                                     accumulate=acc_w, want_dx=with_dx, dx_add=dx_add if with_dx else None)
         for prm in (w, b):
             prm._cfhip_fresh = False
             for cb in grad_ready_callbacks:
                 cb(prm)
+        return dx
 
+    if not SPLIT_LN_BWD:
+        return param_grads(True)
     SideStream.run(param_grads, (dy2, x2, mean, rstd), lane=1)
     dx, _, _ = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dx_add=dx_add, want_param_grads=False)
     return dx

@@ -18,15 +18,14 @@ img = torch.randn(BATCH, 3, 224, 224, generator=g).to(dev)
 labels = torch.randint(0, 1000, (BATCH,), generator=g).to(dev)
 
 VARIANTS = {
-    "shipped": dict(skip_bias=False, fuse_bias=False),
-    "bias grads fused in the dW GEMM": dict(skip_bias=False, fuse_bias=True),
-    "no bias grads at all (bound)": dict(skip_bias=True, fuse_bias=False),
+    "shipped": dict(split_ln=True),
+    "LN backward in one launch on the main stream": dict(split_ln=False),
 }
 
 def apply(v):
     from cflearn_amd import fused
-    fused._SKIP_BIAS_GRAD = v["skip_bias"]
-    fused.FUSE_BIAS_GRAD = v["fuse_bias"]
+    fused.SPLIT_LN_BWD = v["split_ln"]
+
 
 def run(n):
     torch.cuda.synchronize()
