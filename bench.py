@@ -179,6 +179,9 @@ def main() -> None:
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for the "
                                                       "single-GPU dry run of the N > 1 code path)")
     ap.add_argument("--all-on-gpu0", action="store_true", help="dry run: every rank uses cuda:0")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="dry run: take the distributed code path (process group, bucketed all-reduce, barrier) even "
+                         "with WORLD_SIZE=1 -- exercises the RCCL calls on a 1-GPU box")
     ap.add_argument("--input", default="device", choices=["device", "host"],
                     help="device (default, the headline number): the batch is resident in HBM.  host: every step "
                          "pulls a fresh host batch through cflearn_amd.data.TensorBatcher (copy stream, one batch "
@@ -196,9 +199,12 @@ def main() -> None:
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
+    distributed = world > 1 or args.force_ddp
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # "nccl" == RCCL on ROCm
         else:

@@ -427,6 +427,22 @@ extern "C" int cfhip_ema_update(float* ema, const float* p, int64_t n, float one
   return CFHIP_OK;
 }
 
+// One wavefront that idles for `us` microseconds of the 100 MHz constant-rate counter.  Host use only: the stream
+// self-check of functional.distinct_stream launches it on two streams at once; if both finish in the time of one,
+// the streams sit on different hardware queues (ROCclr multiplexes streams onto GPU_MAX_HW_QUEUES queues, and two
+// streams that share a queue run their kernels back to back).
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+extern "C" int cfhip_spin(int microseconds, void* stream) {
+  CFHIP_REQUIRE(microseconds > 0 && microseconds <= 100000, "spin: 1..100000 us");
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100);
+  CFHIP_CHECK_LAUNCH("spin");
+  return CFHIP_OK;
+}
+
 extern "C" int cfhip_colreduce_f32(const float* x, float* out, int R, int D, int accumulate, void* stream) {
   CFHIP_REQUIRE(x && out && R > 0 && D > 0, "colreduce_f32: bad arguments");
   return cfhip_internal_colreduce_f32(x, R, D, out, accumulate, (hipStream_t)stream);

@@ -58,7 +58,12 @@ class BucketedAllReduce:
         self.sync_enabled = True
         self.optimizer = optimizer
         self.is_cuda = arena.flat_g.is_cuda
-        self.comm_stream = torch.cuda.Stream() if self.is_cuda else None
+        self.comm_stream = None
+        if self.is_cuda:
+            # helper streams are checked for their own hardware queue (functional.distinct_stream): created here,
+            # BEFORE the first collective makes the process group create its internal stream
+            HF.SideStream.ensure()
+            self.comm_stream = HF.distinct_stream(HF.SideStream.streams)
         # buckets: walk the parameters from LAST to FIRST (backward produces them in that order)
         self.buckets: List[_Bucket] = []
         ids: List[int] = []

@@ -41,6 +41,8 @@ class TrainStep:
         self.optimizer = FusedAdam(None, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                    decoupled=decoupled, arena=self.arena)
         self.optimizer.lazy_zero = True  # every parameter gradient is written by a HIP backward kernel
+        if params and params[0].is_cuda:
+            SideStream.ensure()  # the stream self-check runs here, not inside the first timed step
         self.reducer: Optional[BucketedAllReduce] = None
         if distributed:
             self.reducer = BucketedAllReduce(self.arena, bucket_bytes=bucket_bytes, optimizer=self.optimizer)

@@ -11,6 +11,7 @@ read-modify-write pass per parameter and lets the gradient arena / DDP bucket vi
 (`optim.ParamArena`, `ddp.BucketedAllReduce`) be the kernels' destination.  Because autograd's own
 post-accumulate hooks do not fire for such parameters, `grad_ready_callbacks` is invoked instead.
 """
+import os
 from typing import Any, Callable, List, Optional, Tuple
 
 import torch
@@ -36,6 +37,50 @@ grad_ready_callbacks: List[Callable[[Tensor], None]] = []
 # stream simply becomes a parallel branch of the graph.
 
 
+# ROCclr multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams that share a queue
+# run their kernels back to back.  Measured (profiles/r01/rccl_1rank_queues.log + the rocprofv3 queue column): once
+# torch.distributed had created its own streams, the dW side stream landed on the compute stream's queue and the step
+# lost its overlap (22.9 -> 26.8 ms).  So every helper stream is CHECKED: an idle wavefront on the new stream and on
+# each stream it must overlap with, launched together, has to take the time of one; a stream that fails is parked and
+# another one is created.  With the check the 1-rank RCCL step is 23.6 ms against 23.1 ms without DDP.  Raising
+# GPU_MAX_HW_QUEUES to 8 makes the DDP step SLOWER (27.5 ms, three alternating runs), so the default is left alone.
+_SPIN_US = 300
+_rejected_streams: List["torch.cuda.Stream"] = []  # kept alive so that their queue slot stays taken
+
+
+def _overlap(streams: List["torch.cuda.Stream"]) -> bool:
+    import time
+
+    for st in streams:  # the first launch on a stream creates its queue: not part of the measurement
+        with torch.cuda.stream(st):
+            ops.spin(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for st in streams:
+        with torch.cuda.stream(st):
+            ops.spin(_SPIN_US)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) < 1.6e-6 * _SPIN_US
+
+
+def distinct_stream(others: List["torch.cuda.Stream"], tries: int = 12) -> "torch.cuda.Stream":
+    """A new stream whose kernels run concurrently with those of every stream in `others` (and of the current one)."""
+    base = [torch.cuda.current_stream()] + [st for st in others if st is not None]
+    first = None
+    for _ in range(tries):
+        cand = torch.cuda.Stream()
+        first = first or cand
+        # pairwise against each stream: robust to `others` that already alias one another
+        if all(_overlap([st, cand]) for st in base):
+            return cand
+        _rejected_streams.append(cand)
+    import warnings
+
+    warnings.warn("cfhip: no helper stream on its own hardware queue after %d tries (GPU_MAX_HW_QUEUES=%s): "
+                  "side-stream work will serialise with the compute stream" % (tries, os.environ.get("GPU_MAX_HW_QUEUES")))
+    return first
+
+
 class SideStream:
     enabled = True
     lanes = 2  # side streams (0: dW GEMMs; 1: column sums / LayerNorm parameter grads)
@@ -44,6 +89,21 @@ class SideStream:
     keep: List[Tensor] = []  # operands produced on the main stream, alive until the join
 
     _join_queued = False
+
+    @classmethod
+    def get(cls, lane: int = 0) -> "torch.cuda.Stream":
+        """The side stream of a lane; created (and checked for its own hardware queue) on first use."""
+        lane = lane % max(1, cls.lanes)
+        if cls.streams[lane] is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("cfhip: side streams must exist before a hipGraph capture starts (run one eager step)")
+            cls.streams[lane] = distinct_stream(cls.streams)
+        return cls.streams[lane]
+
+    @classmethod
+    def ensure(cls) -> None:
+        for lane in range(max(1, cls.lanes)):
+            cls.get(lane)
 
     @classmethod
     def _end_of_backward(cls) -> None:
@@ -64,10 +124,7 @@ class SideStream:
             except RuntimeError:  # not inside a backward pass: stay on the current stream
                 fn()
                 return
-        lane = lane % max(1, cls.lanes)
-        if cls.streams[lane] is None:
-            cls.streams[lane] = torch.cuda.Stream()
-        side = cls.streams[lane]
+        side = cls.get(lane)
         side.wait_stream(torch.cuda.current_stream())  # everything issued so far is visible
         with torch.cuda.stream(side):
             fn()
@@ -78,11 +135,9 @@ class SideStream:
         """A side stream that has waited for the current stream (for work the caller joins itself)."""
         if not cls.enabled or not torch.cuda.is_available():
             return None
-        lane = lane % max(1, cls.lanes)
-        if cls.streams[lane] is None:
-            cls.streams[lane] = torch.cuda.Stream()
-        cls.streams[lane].wait_stream(torch.cuda.current_stream())
-        return cls.streams[lane]
+        side = cls.get(lane)
+        side.wait_stream(torch.cuda.current_stream())
+        return side
 
     @classmethod
     def join(cls) -> None:

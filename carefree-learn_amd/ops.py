@@ -787,6 +787,11 @@ def timestep_embedding(t: Tensor, dim: int, max_period: float = 10000.0) -> Tens
     return out
 
 
+def spin(microseconds: int) -> None:
+    """One idle wavefront on the current stream (stream self-check, see functional.distinct_stream)."""
+    _lib.check(_lib.load().cfhip_spin(int(microseconds), _stream()), "spin")
+
+
 def ema_update(ema: Tensor, p: Tensor, decay: float) -> None:
     """ema <- (1 - decay) * p + decay * ema over flat contiguous f32 buffers (bit-exact with the torch expression)."""
     _need(ema, f32, "ema")

@@ -229,6 +229,10 @@ int cfhip_adam_step_dev(float* p, const float* g, float* m, float* v, void* p_bf
  * (16-byte aligned); two rounded products + one rounded sum like the reference's expression: bit-exact.
  * the reference clones every parameter every step. */
 int cfhip_ema_update(float* ema, const float* p, int64_t n, float one_minus_decay, float decay, void* stream);
+/* One idle wavefront for `microseconds` (1..100000) on `stream`.  Host-side stream self-check only (two streams
+ * that share a ROCclr hardware queue run it back to back; the side streams of the backward pass and the RCCL
+ * stream must not share the compute stream's queue -- reference counterpart: none, torch DDP owns its streams). */
+int cfhip_spin(int microseconds, void* stream);
 /* sum of squares of g (f32 [n]) into out[0] (+= ; caller zeroes) — gradient-norm clipping */
 int cfhip_sumsq_f32(const float* g, float* out, int64_t n, void* stream);
 
