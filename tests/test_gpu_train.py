@@ -137,3 +137,19 @@ def test_train_step_with_token_count_not_multiple_of_8():
     labels = torch.randint(0, 10, (37,), generator=g).to(DEV)
     losses = [ts.step(img, labels).item() / 37 for _ in range(12)]
     assert all(l == l for l in losses) and losses[-1] < 0.7 * losses[0], losses
+
+
+@pytest.mark.gpu
+def test_helper_streams_have_their_own_hardware_queue():
+    """functional.distinct_stream: an idle wavefront on the compute stream and on the helper stream at once takes the
+    time of one (streams that share a ROCclr hardware queue would run them back to back)."""
+    from cflearn_amd import functional as HF
+
+    HF.SideStream.ensure()
+    cur = torch.cuda.current_stream()
+    lanes = [s for s in HF.SideStream.streams if s is not None]
+    assert len(lanes) == HF.SideStream.lanes
+    for s in lanes:
+        assert HF._overlap([cur, s])
+    assert HF._overlap([cur] + lanes)
+    assert not HF._overlap([cur, cur])  # the check itself: one stream serialises

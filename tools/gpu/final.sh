@@ -15,11 +15,12 @@ print({k:v for k,v in d.items() if k not in ('config','roofline','cpu_baseline')
 r=d.get('roofline',{}); print({k:v for k,v in r.items() if k!='shapes'}); print(d.get('cpu_baseline'))
 PY
 timeout 600 python bench.py --batch 64 --no-cpu-baseline > gpurun_out/bench_b64.json 2>/dev/null; echo "== b64 exit $?"
+timeout 600 python bench.py --batch 256 --no-cpu-baseline --no-roofline > gpurun_out/bench_b256.json 2>/dev/null; echo "== b256 exit $?"
 timeout 600 python bench.py --graph --no-cpu-baseline --no-roofline > gpurun_out/bench_graph.json 2>/dev/null; echo "== graph exit $?"
 timeout 600 python bench.py --input host --no-cpu-baseline --no-roofline > gpurun_out/bench_hostinput.json 2>/dev/null; echo "== host-input exit $?"
 python - <<'PY'
 import json
-for n in ('bench_b64', 'bench_graph', 'bench_hostinput'):
+for n in ('bench_b64', 'bench_b256', 'bench_graph', 'bench_hostinput'):
     try:
         d=json.loads(open(f'gpurun_out/{n}.json').read().strip().split('\n')[-1]); print(n, d['value'], d['ms_per_step'], d.get('roofline', {}).get('achieved'))
     except Exception as e: print(n, 'failed', e)
