@@ -41,6 +41,10 @@ struct GemmParams {
   float* bgrad_slabs;  // split-K partials [z][M] of the above
   int bgrad_acc;
   int quick;   // GELU / DGELU epilogues: 0 = exact-erf GELU, 1 = quick GELU x * sigmoid(1.702 x)
+  // implicit 3x3 / stride 1 / pad 1 convolution (CONV kernels only): A is the NHWC activation [M = B*H*W pixels][conv_c],
+  // the GEMM's k index is (tap = ky*3+kx, channel), a K-step (32 channels of one tap) is gathered straight from A
+  int conv_h, conv_w, conv_c, conv_kpt;  // image height / width, channels, K-steps per tap (= conv_c / 32)
+  float conv_inv_kpt;
   int ablate;  // benchmarking only: bit0 skip in-loop DMA, bit1 skip MFMA/LDS reads, bit2 skip stores
 };
 
@@ -325,9 +329,10 @@ struct ItemCtx {
   __amdgpu_buffer_rsrc_t a_rsrc, b_rsrc;
   StagePlan<C::A_INSTR> pa;
   StagePlan<C::B_INSTR> pb;
+  unsigned yx[C::A_INSTR];  // CONV: (y << 16 | x) of the pixel behind each A-staging instruction of this lane
 };
 
-template <bool AT, bool BT, class C>
+template <bool AT, bool BT, class C, bool CONV = false>
 __device__ __forceinline__ ItemCtx<AT, BT, C> setup_item(const GemmParams& p, int item, int wave, int lane) {
   ItemCtx<AT, BT, C> c;
   const int ntiles = p.tiles_m * p.tiles_n;
@@ -346,18 +351,58 @@ __device__ __forceinline__ ItemCtx<AT, BT, C> setup_item(const GemmParams& p, in
   const bf16_t* b_base = BT ? p.B + (long)kb * p.ldb + c.n0 : p.B + (long)c.n0 * p.ldb + kb;
   const long a_bytes = AT ? ((long)(c.klen - 1) * p.lda + rows_a) * 2 : ((long)(rows_a - 1) * p.lda + c.klen) * 2;
   const long b_bytes = BT ? ((long)(c.klen - 1) * p.ldb + rows_b) * 2 : ((long)(rows_b - 1) * p.ldb + c.klen) * 2;
-  c.a_rsrc = make_rsrc(a_base, a_bytes);
   c.b_rsrc = make_rsrc(b_base, b_bytes);
-  c.pa = make_plan<AT, C::BM, C::A_INSTR, C::BK>(wave, lane, p.lda, rows_a);
   c.pb = make_plan<BT, C::BN, C::B_INSTR, C::BK>(wave, lane, p.ldb, rows_b);
+  if constexpr (CONV) {
+    static_assert(!AT && C::BK == 32, "implicit convolution: k-major A, 32-channel K-steps");
+    // The descriptor starts W+1 pixels BEFORE the tile (clamped at pixel 0) so that the (-1,-1) tap is a
+    // non-negative offset; it ends W+1 pixels after it.  Taps outside the image are sent out of range per lane.
+    const int back = min(c.m0, p.conv_w + 1);
+    const long span = min((long)p.M - (c.m0 - back), (long)back + C::BM + p.conv_w + 1);
+    c.a_rsrc = make_rsrc(p.A + (long)(c.m0 - back) * p.conv_c, span * p.conv_c * 2);
+#pragma unroll
+    for (int j = 0; j < C::A_INSTR; ++j) {
+      const int inst = wave * C::A_INSTR + j;
+      const int row = inst * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ kswz<32>(row);
+      c.pa.kpos[j] = chunk * 8;
+      c.pa.voff[j] = (row < rows_a) ? (unsigned)(((back + row) * p.conv_c + chunk * 8) * 2) : OOB;
+      const int m = c.m0 + row;
+      const int q = m / p.conv_w;
+      c.yx[j] = ((unsigned)(q % p.conv_h) << 16) | (unsigned)(m - q * p.conv_w);
+    }
+  } else {
+    c.a_rsrc = make_rsrc(a_base, a_bytes);
+    c.pa = make_plan<AT, C::BM, C::A_INSTR, C::BK>(wave, lane, p.lda, rows_a);
+  }
   return c;
 }
 
-template <bool AT, bool BT, class C>
+// CONV: K-step `kstep` of the A operand = 32 channels (c0..) of tap (ky, kx) for the tile's BM pixels
+template <class C>
+__device__ __forceinline__ void stage_tile_conv(const __amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int wave,
+                                                const StagePlan<C::A_INSTR>& pl, const unsigned (&yx)[C::A_INSTR],
+                                                const GemmParams& p, int kstep) {
+  const int tap = (int)(((float)kstep + 0.5f) * p.conv_inv_kpt);  // kstep / conv_kpt (exact: kstep < 2^16)
+  const int c0 = (kstep - tap * p.conv_kpt) * 32;
+  const int ky = (tap * 11) >> 5;  // tap / 3 for tap in 0..8
+  const int dy = ky - 1, dx = tap - 3 * ky - 1;
+  const int shift = ((dy * p.conv_w + dx) * p.conv_c + c0) * 2;
+#pragma unroll
+  for (int j = 0; j < C::A_INSTR; ++j) {
+    const int y = (int)(yx[j] >> 16) + dy, x = (int)(yx[j] & 0xffffu) + dx;
+    const bool ok = pl.voff[j] != OOB && (unsigned)y < (unsigned)p.conv_h && (unsigned)x < (unsigned)p.conv_w;
+    const unsigned off = ok ? pl.voff[j] + (unsigned)shift : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + (wave * C::A_INSTR + j) * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+template <bool AT, bool BT, class C, bool CONV = false>
 __device__ __forceinline__ void stage_step(const ItemCtx<AT, BT, C>& c, const GemmParams& p, char* smem,
                                            int slot, int wave, int kstep) {
   char* st = smem + slot * C::STAGE_BYTES;
-  stage_tile<AT>(c.a_rsrc, st, wave, c.pa, p.lda, kstep * C::BK, c.klen);
+  if constexpr (CONV) stage_tile_conv<C>(c.a_rsrc, st, wave, c.pa, c.yx, p, kstep);
+  else stage_tile<AT>(c.a_rsrc, st, wave, c.pa, p.lda, kstep * C::BK, c.klen);
   stage_tile<BT>(c.b_rsrc, st + C::A_BYTES, wave, c.pb, p.ldb, kstep * C::BK, c.klen);
 }
 
@@ -375,7 +420,7 @@ __device__ __forceinline__ void stage_step(const ItemCtx<AT, BT, C>& c, const Ge
 //     only 12-24 K-steps: fill + drain per tile was a third of the kernel);
 //   * the epilogue transposes the accumulators through the one ring slot that is free (the slot
 //     of the last K-step) — see below.
-template <bool AT, bool BT, int EPI, class C>
+template <bool AT, bool BT, int EPI, class C, bool CONV = false>
 __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD)
 void gemm_bf16_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -397,11 +442,11 @@ void gemm_bf16_kernel(GemmParams p) {
   const int wm = wave / C::WN, wn = wave % C::WN;
   if (first >= total) return;
 
-  ItemCtx<AT, BT, C> cur = setup_item<AT, BT, C>(p, first, wave, lane);
+  ItemCtx<AT, BT, C> cur = setup_item<AT, BT, C, CONV>(p, first, wave, lane);
   int rd = 0;  // ring slot of the next K-step to compute
 #pragma unroll
   for (int st = 0; st < D; ++st)
-    if (st < cur.nk) stage_step<AT, BT, C>(cur, p, smem, st, wave, st);
+    if (st < cur.nk) stage_step<AT, BT, C, CONV>(cur, p, smem, st, wave, st);
 
   for (int item = first; item < total; item += G) {
     f32x4 acc[C::FM][C::FN];
@@ -424,7 +469,7 @@ void gemm_bf16_kernel(GemmParams p) {
       if (t + D < nk && !(p.ablate & 1)) {
         int wr = rd + D;
         if (wr >= C::NSTAGE) wr -= C::NSTAGE;
-        stage_step<AT, BT, C>(cur, p, smem, wr, wave, t + D);
+        stage_step<AT, BT, C, CONV>(cur, p, smem, wr, wave, t + D);
       }
       const char* tile = smem + rd * C::STAGE_BYTES;
       if (!(p.ablate & 2)) compute_tile<AT, BT, C>(tile, tile + C::A_BYTES, wm, wn, lane, acc);
@@ -436,13 +481,13 @@ void gemm_bf16_kernel(GemmParams p) {
     const int m0 = cur.m0, n0 = cur.n0, z = cur.z;
     const int nitem = item + G;
     if (nitem < total) {
-      cur = setup_item<AT, BT, C>(p, nitem, wave, lane);
+      cur = setup_item<AT, BT, C, CONV>(p, nitem, wave, lane);
 #pragma unroll
       for (int st = 0; st < D; ++st) {
         if (st < cur.nk) {
           int slot = rd + st;
           if (slot >= C::NSTAGE) slot -= C::NSTAGE;
-          stage_step<AT, BT, C>(cur, p, smem, slot, wave, st);  // slots of steps older than the last one
+          stage_step<AT, BT, C, CONV>(cur, p, smem, slot, wave, st);  // slots of steps older than the last one
         }
       }
     }
@@ -495,7 +540,7 @@ void gemm_bf16_kernel(GemmParams p) {
 //   WAR: slot (t+3)&3 held step t-1, last read in group 1's L(t-1, 1) (interval 4t-1) and retired by
 //        the lgkmcnt waits in front of its MFMAs in interval 4t; the DMA of step t+3 is issued AFTER the barrier
 //        that ends L(t, 1), i.e. in interval 4t+3 (group 0) / 4t+4 (group 1).
-template <bool AT, bool BT, int EPI, class C>
+template <bool AT, bool BT, int EPI, class C, bool CONV = false>
 __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD)
 void gemm_bf16_phase_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -517,7 +562,7 @@ void gemm_bf16_phase_kernel(GemmParams p) {
   const int wm = wave / C::WN, wn = wave % C::WN;
   const int i = lane & 15, g = lane >> 4;
 
-  const ItemCtx<AT, BT, C> cur = setup_item<AT, BT, C>(p, item, wave, lane);
+  const ItemCtx<AT, BT, C> cur = setup_item<AT, BT, C, CONV>(p, item, wave, lane);
   const int nk = cur.nk;
   f32x4 acc[C::FM][C::FN];
 #pragma unroll
@@ -527,7 +572,7 @@ void gemm_bf16_phase_kernel(GemmParams p) {
 
 #pragma unroll
   for (int st = 0; st < D; ++st)
-    if (st < nk) stage_step<AT, BT, C>(cur, p, smem, st, wave, st);
+    if (st < nk) stage_step<AT, BT, C, CONV>(cur, p, smem, st, wave, st);
   {  // K-step 0 has landed; the younger ones stay in flight
     const int younger = min(nk, D) - 1;
     if (D >= 3 && younger >= 2) CFHIP_WAIT_VMCNT(2 * C::LPS);
@@ -564,7 +609,7 @@ void gemm_bf16_phase_kernel(GemmParams p) {
       __builtin_amdgcn_sched_barrier(0);
       // ---- M segment
       // (the compiler's own lgkmcnt ladder in front of the MFMAs retires the fragment reads)
-      if (ph == PH - 1 && t + D < nk) stage_step<AT, BT, C>(cur, p, smem, wr, wave, t + D);
+      if (ph == PH - 1 && t + D < nk) stage_step<AT, BT, C, CONV>(cur, p, smem, wr, wave, t + D);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int m = 0; m < HM; ++m)
@@ -674,15 +719,15 @@ int g_gemm_ablate = 0;
 int g_gemm_persistent = 0;
 int g_gemm_heuristic = 5;
 
-template <bool AT, bool BT, int EPI, class C, bool PIPE>
+template <bool AT, bool BT, int EPI, class C, bool PIPE, bool CONV = false>
 int launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
   void (*kern)(GemmParams) = nullptr;
   if (PIPE && p.bgrad != nullptr) {
     cfhip_set_error("gemm: the fused bias gradient is not provided by the big-tile kernel (gemm_config 7 / 8)");
     return CFHIP_ERR_INVALID;
   }
-  if constexpr (PIPE) kern = gemm_bf16_phase_kernel<AT, BT, EPI, C>;
-  else kern = gemm_bf16_kernel<AT, BT, EPI, C>;
+  if constexpr (PIPE) kern = gemm_bf16_phase_kernel<AT, BT, EPI, C, CONV>;
+  else kern = gemm_bf16_kernel<AT, BT, EPI, C, CONV>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done && C::LDS_BYTES > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -830,6 +875,8 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
   p.bgrad = bias_grad;
   p.bgrad_acc = bias_grad_accumulate;
   p.bgrad_slabs = nullptr;
+  p.conv_h = p.conv_w = p.conv_c = p.conv_kpt = 0;
+  p.conv_inv_kpt = 0.f;
   p.k_chunk = ((K + BK_MAX - 1) / BK_MAX) * BK_MAX;
 
   // K % 8 is an alignment rule of the k-major operands only (16-byte chunks along k); in the (1,1) layout k is
@@ -892,5 +939,48 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
                        (long)ldc, split_k, out_dtype, accumulate, p.bgrad_slabs, p.bgrad, p.bgrad_acc);
     CFHIP_CHECK_LAUNCH("splitk_reduce");
   }
+  return CFHIP_OK;
+}
+
+// ---- implicit-GEMM 3x3 convolution ------------------------------------------------------------------
+template <class C, bool PIPE>
+static int launch_conv(GemmParams p, hipStream_t s) {
+  p.tiles_m = (p.M + C::BM - 1) / C::BM;
+  p.tiles_n = (p.N + C::BN - 1) / C::BN;
+  p.splits = 1;
+  return launch_cfg<false, false, CFHIP_EPI_NONE, C, PIPE, true>(p, dim3(p.tiles_m * p.tiles_n), s);
+}
+
+extern "C" int cfhip_conv3x3_nhwc_bf16(const void* X, const void* Wk, const float* bias, void* Y, int B, int H, int W,
+                                       int Cin, int Cout, void* stream) {
+  CFHIP_REQUIRE(X && Wk && Y, "conv3x3: null operand");
+  CFHIP_REQUIRE(B > 0 && H > 0 && W > 0 && H < 65536 && W < 65536, "conv3x3: bad image shape %d x %d x %d", B, H, W);
+  CFHIP_REQUIRE(Cin > 0 && Cin % 32 == 0, "conv3x3: Cin = %d must be a multiple of 32 (one K-step = 32 channels of a tap)", Cin);
+  CFHIP_REQUIRE(Cout > 0 && Cout % 8 == 0, "conv3x3: Cout = %d must be a multiple of 8", Cout);
+  const long pixels = (long)B * H * W;
+  CFHIP_REQUIRE(pixels < (1L << 30) && 9L * Cin < (1L << 20), "conv3x3: problem too large (%ld pixels, Cin %d)", pixels, Cin);
+  CFHIP_REQUIRE(aligned16(X) && aligned16(Wk) && aligned16(Y) && (bias == nullptr || aligned16(bias)),
+                "conv3x3: operands must be 16-byte aligned");
+  GemmParams p;
+  p.A = reinterpret_cast<const bf16_t*>(X);
+  p.B = reinterpret_cast<const bf16_t*>(Wk);
+  p.C = Y;
+  p.bias = bias;
+  p.aux_in = nullptr;
+  p.aux_out = nullptr;
+  p.M = (int)pixels; p.N = Cout; p.K = 9 * Cin;
+  p.lda = Cin; p.ldb = 9L * Cin; p.ldc = Cout;
+  p.epilogue = CFHIP_EPI_NONE; p.out_f32 = 0; p.accumulate = 0;
+  p.k_chunk = ((p.K + BK_MAX - 1) / BK_MAX) * BK_MAX;
+  p.slabs = nullptr;
+  p.tiles_m = p.tiles_n = 0; p.splits = 1;
+  p.bgrad = nullptr; p.bgrad_slabs = nullptr; p.bgrad_acc = 0;
+  p.quick = 0;
+  p.ablate = 0;
+  p.conv_h = H; p.conv_w = W; p.conv_c = Cin; p.conv_kpt = Cin / 32;
+  p.conv_inv_kpt = 1.0f / (float)p.conv_kpt;
+  const int rc = p.M >= 1024 ? launch_conv<CfgQ, true>(p, (hipStream_t)stream) : launch_conv<CfgB, false>(p, (hipStream_t)stream);
+  if (rc != CFHIP_OK) return rc;
+  CFHIP_CHECK_LAUNCH("conv3x3_nhwc");
   return CFHIP_OK;
 }

@@ -570,9 +570,22 @@ def _conv_weight_rows(weight: Tensor, kp: int) -> Tensor:
     return wp
 
 
+# 3x3 / stride 1 / pad 1 convolutions with Cin % 32 == 0 (every ResBlock / up-sampling conv of the UNet) skip the im2row
+# matrix: cfhip_conv3x3_nhwc_bf16 gathers the taps inside the GEMM's K loop.  UNet 64^2 x 8 step: im2row + row2im were
+# 38 ms of 140 (profiles/r01/prof_unet_summary.txt).  False: every convolution takes the im2row path (A/B, tests).
+IMPLICIT_CONV = True
+
+
+def _implicit_ok(cin: int, cout: int, kh: int, kw: int, stride: int, pad: int, dil: int, h: int, w: int) -> bool:
+    return (IMPLICIT_CONV and (kh, kw, stride, pad, dil) == (3, 3, 1, 1, 1) and cin % 32 == 0 and cout % 8 == 0
+            and h < 65536 and w < 65536)
+
+
 class Conv2dFn(Function):
     """Replaces F.conv2d reached from Conv2d.forward (reference convs/basic.py:160-177), groups = 1:
-    NCHW in (f32 / bf16), NCHW bf16 out."""
+    NCHW in (f32 / bf16), NCHW bf16 out.  Two routes: implicit GEMM on an NHWC copy (3x3 / stride 1 / pad 1,
+    Cin % 32 == 0: forward always, input gradient when Cout % 32 == 0 too) or im2row + GEMM (everything else, and
+    every weight gradient)."""
 
     @staticmethod
     def forward(ctx: Any, x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int, pad: int,
@@ -583,14 +596,35 @@ class Conv2dFn(Function):
         b, cin, h, w = x.shape
         cout, _, kh, kw = weight.shape
         ho, wo = ops.conv_out_hw(h, w, kh, kw, stride, pad, dil)
-        rows = ops.conv_im2row(x, kh, kw, stride, pad, dil)
-        wp = _conv_weight_rows(weight, rows.shape[1])
         bias_f = None if bias is None else bias.detach().reshape(-1).contiguous()
-        y_rows = ops.gemm(rows, wp, bias=bias_f)  # [B*Ho*Wo, Cout] bf16
-        y = ops.transpose_batched(y_rows.view(b, ho * wo, cout)).view(b, cout, ho, wo)
-        ctx.save_for_backward(x, wp)
         ctx.weight, ctx.bias = weight, bias
         ctx.geom = (kh, kw, stride, pad, dil, ho, wo)
+        ctx.implicit = _implicit_ok(cin, cout, kh, kw, stride, pad, dil, h, w)
+        if ctx.implicit:
+            x_rows = ops.transpose_batched(x.view(b, cin, h * w)).view(b * h * w, cin)  # NHWC bf16
+            w16 = shadow_bf16(weight)
+            wk = w16.permute(0, 2, 3, 1).reshape(cout, 9 * cin)  # k = (ky, kx, c): a K-step = 32 channels of a tap
+            y_rows = ops.conv3x3_nhwc(x_rows, wk, bias_f, b, h, w)
+            ctx.save_for_backward(x, w16)
+            return ops.transpose_batched(y_rows.view(b, h * w, cout)).view(b, cout, h, w)
+        rows = ops.conv_im2row(x, kh, kw, stride, pad, dil)
+        wp = _conv_weight_rows(weight, rows.shape[1])
+        # Cout that is not a multiple of 8 (the 3-channel head of the UNet) would fall off the MFMA path onto the
+        # one-thread-per-output kernel (3.6 ms per launch at 64^2 x 8): pad the output channels with zero filters
+        cp = (cout + 7) // 8 * 8
+        if cp != cout:
+            wpad = torch.zeros((cp, wp.shape[1]), dtype=bf16, device=x.device)
+            wpad[:cout] = wp
+            wp = wpad
+            if bias_f is not None:
+                bpad = torch.zeros((cp,), dtype=f32, device=x.device)
+                bpad[:cout] = bias_f
+                bias_f = bpad
+        y_rows = ops.gemm(rows, wp, bias=bias_f)  # [B*Ho*Wo, Cp] bf16
+        y = ops.transpose_batched(y_rows.view(b, ho * wo, cp)).view(b, cp, ho, wo)
+        if cp != cout:
+            y = y[:, :cout].contiguous()
+        ctx.save_for_backward(x, wp)
         return y
 
     @staticmethod
@@ -603,25 +637,30 @@ class Conv2dFn(Function):
         k = cin * kh * kw
         if dy.dtype != bf16:
             dy = ops.to_bf16(dy.float().contiguous())
-        dy_rows = ops.transpose_batched(dy.contiguous().view(b, cout, ho * wo)).view(b * ho * wo, cout)
+        # implicit forward: wp is the [Cout, Cin, 3, 3] bf16 shadow, the dW GEMM still reads an im2row matrix
+        cp = cout if ctx.implicit else wp.shape[0]  # output channels incl. the zero filters padding Cout to 8
+        if cp != cout:
+            dyp = torch.zeros((b, cp, ho * wo), dtype=bf16, device=dy.device)
+            dyp[:, :cout] = dy.reshape(b, cout, ho * wo)
+            dy = dyp
+        dy_rows = ops.transpose_batched(dy.contiguous().view(b, cp, ho * wo)).view(b * ho * wo, cp)
         gw = gb = None
         if weight.requires_grad:
             rows = ops.conv_im2row(x, kh, kw, stride, pad, dil)  # recomputed: k^2 times the input, not kept
             m = rows.shape[0]
             kp = rows.shape[1]
-            # split-K lives on the MFMA path only: its (1,1) layout needs Cout % 8 == 0 (Kp already is)
-            split = ops.pick_split_k(cout, kp, m) if cout % 8 == 0 else 1
+            split = ops.pick_split_k(cp, kp, m)
 
             def dw_into(out: Tensor, acc: bool) -> None:
-                if kp == k:
+                if kp == k and cp == cout:
                     ops.gemm(dy_rows, rows, a_trans=True, b_trans=True, out=out.view(cout, k), accumulate=acc,
                              split_k=split)
                 else:
                     tmp = ops.gemm(dy_rows, rows, a_trans=True, b_trans=True, out_dtype=f32, split_k=split)
                     if acc:
-                        out.view(cout, k).add_(tmp[:, :k])
+                        out.view(cout, k).add_(tmp[:cout, :k])
                     else:
-                        out.view(cout, k).copy_(tmp[:, :k])
+                        out.view(cout, k).copy_(tmp[:cout, :k])
 
             if _is_direct(weight):
                 write_param_grad(weight, dw_into)
@@ -629,14 +668,32 @@ class Conv2dFn(Function):
                 gw = torch.empty(weight.shape, dtype=f32, device=dy.device)
                 dw_into(gw, False)
         if bias is not None and bias.requires_grad:
+            def db_into(out: Tensor, acc: bool) -> None:
+                if cp == cout:
+                    ops.colsum(dy_rows, out=out.view(-1), accumulate=acc)
+                else:
+                    tmp = ops.colsum(dy_rows)[:cout]
+                    if acc:
+                        out.view(-1).add_(tmp)
+                    else:
+                        out.view(-1).copy_(tmp)
+
             if _is_direct(bias):
-                write_param_grad(bias, lambda out, acc: ops.colsum(dy_rows, out=out.view(-1), accumulate=acc))
+                write_param_grad(bias, db_into)
             else:
-                gb = ops.colsum(dy_rows).view(bias.shape)
+                gb = torch.empty(bias.shape, dtype=f32, device=dy.device)
+                db_into(gb, False)
         dx = None
         if ctx.needs_input_grad[0]:
-            drows = ops.gemm(dy_rows, wp, b_trans=True)  # [M, Kp] bf16
-            dx = ops.conv_row2im(drows, (b, cin, h, w), kh, kw, stride, pad, dil)
+            if ctx.implicit and cout % 32 == 0:
+                # dX = conv3x3(dY, filters rotated by 180 degrees, channels swapped): k = (ky, kx, co)
+                wr = wp.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout)
+                dx_rows = ops.conv3x3_nhwc(dy_rows, wr, None, b, h, w)
+                dx = ops.transpose_batched(dx_rows.view(b, h * w, cin)).view(b, cin, h, w)
+            else:
+                w2 = wp.reshape(cout, k) if ctx.implicit else wp
+                drows = ops.gemm(dy_rows, w2, b_trans=True)  # [M, Kp] bf16
+                dx = ops.conv_row2im(drows, (b, cin, h, w), kh, kw, stride, pad, dil)
         return dx, gw, gb, None, None, None
 
 

@@ -787,6 +787,24 @@ def timestep_embedding(t: Tensor, dim: int, max_period: float = 10000.0) -> Tens
     return out
 
 
+def conv3x3_nhwc(x_rows: Tensor, wk: Tensor, bias: Optional[Tensor], b: int, h: int, w: int) -> Tensor:
+    """Implicit-GEMM 3x3 / stride 1 / pad 1 convolution: x_rows bf16 [B*H*W, Cin] (NHWC), wk bf16 [Cout, 9*Cin] with
+    k = (ky*3 + kx)*Cin + c, bias f32 [Cout] | None -> bf16 [B*H*W, Cout]."""
+    _need(x_rows, bf16, "x_rows")
+    _need(wk, bf16, "wk")
+    m, cin = x_rows.shape
+    cout = wk.shape[0]
+    if m != b * h * w or wk.shape[1] != 9 * cin or not x_rows.is_contiguous() or not wk.is_contiguous():
+        raise ValueError(f"cfhip conv3x3_nhwc: x_rows {tuple(x_rows.shape)} / wk {tuple(wk.shape)} do not match "
+                         f"B={b} H={h} W={w} (dense NHWC rows and [Cout, 9*Cin] filters expected)")
+    if bias is not None:
+        _need(bias, f32, "bias")
+    y = torch.empty((m, cout), dtype=bf16, device=x_rows.device)
+    _lib.check(_lib.load().cfhip_conv3x3_nhwc_bf16(x_rows.data_ptr(), wk.data_ptr(), _p(bias), y.data_ptr(), b, h, w,
+                                                   cin, cout, _stream()), "conv3x3_nhwc")
+    return y
+
+
 def spin(microseconds: int) -> None:
     """One idle wavefront on the current stream (stream self-check, see functional.distinct_stream)."""
     _lib.check(_lib.load().cfhip_spin(int(microseconds), _stream()), "spin")

@@ -229,6 +229,15 @@ int cfhip_adam_step_dev(float* p, const float* g, float* m, float* v, void* p_bf
  * (16-byte aligned); two rounded products + one rounded sum like the reference's expression: bit-exact.
  * the reference clones every parameter every step. */
 int cfhip_ema_update(float* ema, const float* p, int64_t n, float one_minus_decay, float decay, void* stream);
+/* Implicit-GEMM 3x3 / stride 1 / padding 1 convolution on NHWC bf16 activations (F.conv2d reached from Conv2d.forward,
+ * reference convs/basic.py:160-177, as used 61 times by the DDPM UNet, unet.py:76-322): Y[p][co] = bias[co] +
+ * sum_{ky,kx,c} X[p + (ky-1)*W + (kx-1)][c] * Wk[co][(ky*3+kx)*Cin + c] over the pixels p of B images of H x W, taps
+ * outside the image contribute zero.  X [B*H*W][Cin], Wk [Cout][9*Cin] (tap-major, channel-minor), Y [B*H*W][Cout],
+ * all bf16; bias f32 [Cout] or NULL.  Cin % 32 == 0, Cout % 8 == 0.  No im2row matrix is materialised: each K-step of
+ * the MFMA GEMM gathers 32 channels of one tap straight from X.  The input gradient is the same call with dY in place
+ * of X and the filters rotated by 180 degrees and transposed: Wk'[c][(ky*3+kx)*Cout + co] = W[co][c][2-ky][2-kx]. */
+int cfhip_conv3x3_nhwc_bf16(const void* X, const void* Wk, const float* bias, void* Y, int B, int H, int W, int Cin,
+                            int Cout, void* stream);
 /* One idle wavefront for `microseconds` (1..100000) on `stream`.  Host-side stream self-check only (two streams
  * that share a ROCclr hardware queue run it back to back; the side streams of the backward pass and the RCCL
  * stream must not share the compute stream's queue -- reference counterpart: none, torch DDP owns its streams). */

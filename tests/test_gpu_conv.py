@@ -223,3 +223,57 @@ def test_conv_classifier_and_fcnn_train_steps(golden):
     losses = [ts2.step(x, y).item() / x.shape[0] for _ in range(25)]
     assert abs(losses[0] - f["loss"].item()) <= 3e-3 * f["loss"].item()
     assert losses[-1] < 0.5 * losses[0]
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 64, 96, 12, 10),    # M = 240 < 1024: 128x128x32 base kernel, ragged last tile, non-square image
+    (3, 32, 40, 20, 24),    # M = 1440: 256x128 phase kernel, Cout not a multiple of 32 (dX falls back to row2im)
+    (2, 320, 320, 32, 32),  # the UNet's first level (K = 2880 = 90 K-steps, 10 K-steps per tap)
+    (1, 96, 64, 5, 7),      # image smaller than a tile row: every tile crosses image rows
+])
+def test_implicit_conv3x3_matches_fp32_reference_and_im2row_route(shape):
+    """cfhip_conv3x3_nhwc_bf16 (taps gathered inside the GEMM K loop, zero padding by per-lane range checks) against
+    torch's fp32 conv2d on the bf16-rounded operands (CPU), forward / input gradient / weight + bias gradients, and
+    against the im2row route of the same Function."""
+    b, cin, cout, h, w = shape
+    g = torch.Generator().manual_seed(b * 1000 + cin + h)
+    x = bf16_round(torch.randn(b, cin, h, w, generator=g))
+    wt = bf16_round(torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5))
+    bias = torch.randn(cout, generator=g)
+    dy = bf16_round(torch.randn(b, cout, h, w, generator=g))
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, br, stride=1, padding=1)
+    yr.backward(dy)
+
+    def run(implicit):
+        HF.IMPLICIT_CONV = implicit
+        try:
+            xd = x.to(DEV).to(torch.bfloat16).requires_grad_(True)
+            wd = wt.to(DEV).requires_grad_(True)
+            bd = bias.to(DEV).requires_grad_(True)
+            y = HF.conv2d(xd, wd, bd, 1, 1, 1)
+            y.backward(dy.to(DEV).to(torch.bfloat16))
+            return y, xd.grad, wd.grad, bd.grad
+        finally:
+            HF.IMPLICIT_CONV = True
+
+    y, gx, gw, gb = run(True)
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == (b, cout, h, w)
+    assert_close(y, yr, 4e-3, "implicit conv forward")
+    assert_close(gx, xr.grad, 4e-3, "implicit conv dX")
+    assert_close(gw, wr.grad, 2e-3, "conv dW")
+    assert_close(gb, br.grad, 1e-5, "conv db")
+    y2, gx2, gw2, _ = run(False)
+    # same bf16 operands, fp32 accumulation in a different k order: equal up to the last bf16 rounding
+    assert_close(y, y2, 3e-3, "implicit vs im2row forward")
+    assert_close(gx, gx2, 3e-3, "implicit vs im2row dX")
+    assert_close(gw, gw2, 1e-5, "dW (same route both times)")
+    # the zero padding is exact: a single bright pixel in a corner only reaches its 2x2 neighbourhood
+    xi = torch.zeros(1, cin, h, w)
+    xi[0, :, 0, 0] = 1.0
+    yi = HF.conv2d(xi.to(DEV).to(torch.bfloat16), wt.to(DEV), None, 1, 1, 1).float().cpu()
+    assert torch.count_nonzero(yi[0, :, 2:, :]) == 0 and torch.count_nonzero(yi[0, :, :, 2:]) == 0
+    ref = torch.nn.functional.conv2d(xi, wt, None, stride=1, padding=1)
+    assert_close(yi, ref, 4e-3, "corner impulse")
