@@ -45,6 +45,9 @@ struct GemmParams {
   // the GEMM's k index is (tap = ky*3+kx, channel), a K-step (32 channels of one tap) is gathered straight from A
   int conv_h, conv_w, conv_c, conv_kpt;  // image height / width, channels, K-steps per tap (= conv_c / 32)
   float conv_inv_kpt;
+  // CONV == 2 (weight gradient): B is the NHWC activation, the GEMM's n index is (tap, channel), k = pixel;
+  // pixel -> (y, x) per K-step by multiply-high with floor(2^32 / d) + 1 (exact while pixel * d < 2^32)
+  unsigned conv_magic_w, conv_magic_h;
   int ablate;  // benchmarking only: bit0 skip in-loop DMA, bit1 skip MFMA/LDS reads, bit2 skip stores
 };
 
@@ -329,10 +332,13 @@ struct ItemCtx {
   __amdgpu_buffer_rsrc_t a_rsrc, b_rsrc;
   StagePlan<C::A_INSTR> pa;
   StagePlan<C::B_INSTR> pb;
-  unsigned yx[C::A_INSTR];  // CONV: (y << 16 | x) of the pixel behind each A-staging instruction of this lane
+  unsigned yx[C::A_INSTR];  // CONV 1: (y << 16 | x) of the pixel behind each A-staging instruction of this lane
+  int bshift[C::B_INSTR];   // CONV 2: byte offset of (tap shift, channel) + this lane's k-row, at K-step 0
+  int btap[C::B_INSTR];     // CONV 2: (dy + 1) | (dx + 1) << 2
+  int kb;
 };
 
-template <bool AT, bool BT, class C, bool CONV = false>
+template <bool AT, bool BT, class C, int CONV = 0>
 __device__ __forceinline__ ItemCtx<AT, BT, C> setup_item(const GemmParams& p, int item, int wave, int lane) {
   ItemCtx<AT, BT, C> c;
   const int ntiles = p.tiles_m * p.tiles_n;
@@ -343,6 +349,7 @@ __device__ __forceinline__ ItemCtx<AT, BT, C> setup_item(const GemmParams& p, in
   c.m0 = tile_m * C::BM;
   c.n0 = c.tile_n * C::BN;
   const int kb = c.z * p.k_chunk;
+  c.kb = kb;
   c.klen = min(p.K - kb, p.k_chunk);
   c.nk = (c.klen + C::BK - 1) / C::BK;
   // buffer descriptors relative to this tile's origin (small 32-bit offsets, range-checked)
@@ -351,9 +358,33 @@ __device__ __forceinline__ ItemCtx<AT, BT, C> setup_item(const GemmParams& p, in
   const bf16_t* b_base = BT ? p.B + (long)kb * p.ldb + c.n0 : p.B + (long)c.n0 * p.ldb + kb;
   const long a_bytes = AT ? ((long)(c.klen - 1) * p.lda + rows_a) * 2 : ((long)(rows_a - 1) * p.lda + c.klen) * 2;
   const long b_bytes = BT ? ((long)(c.klen - 1) * p.ldb + rows_b) * 2 : ((long)(rows_b - 1) * p.ldb + c.klen) * 2;
-  c.b_rsrc = make_rsrc(b_base, b_bytes);
-  c.pb = make_plan<BT, C::BN, C::B_INSTR, C::BK>(wave, lane, p.ldb, rows_b);
-  if constexpr (CONV) {
+  if constexpr (CONV == 2) {
+    static_assert(CONV != 2 || (AT && BT && C::BK == 32), "implicit weight gradient: layout (1,1), 32-pixel K-steps");
+    const int back = min(kb, p.conv_w + 1);
+    const long span = min((long)p.K - (kb - back), (long)back + c.klen + p.conv_w + 1);
+    c.b_rsrc = make_rsrc(p.B + (long)(kb - back) * p.conv_c, span * p.conv_c * 2);
+    constexpr int SLOTS = C::BN / 8;
+#pragma unroll
+    for (int j = 0; j < C::B_INSTR; ++j) {
+      const int inst = wave * C::B_INSTR + j;
+      const int krow = inst * (64 / SLOTS) + lane / SLOTS;
+      const int sl = lane % SLOTS;
+      const int col = (((sl >> 1) ^ mkey<C::BN>(krow)) << 4) + ((sl & 1) << 3);
+      const int n = c.n0 + col;  // 8 consecutive n = 8 channels of one tap (conv_c % 8 == 0)
+      const int tap = n / p.conv_c;
+      const int ch = n - tap * p.conv_c;
+      const int ky = (tap * 11) >> 5;
+      const int dy = ky - 1, dx = tap - 3 * ky - 1;
+      c.pb.kpos[j] = krow;
+      c.pb.voff[j] = (col < rows_b) ? 0u : OOB;
+      c.bshift[j] = ((back + krow + dy * p.conv_w + dx) * p.conv_c + ch) * 2;
+      c.btap[j] = (dy + 1) | ((dx + 1) << 2);
+    }
+  } else {
+    c.b_rsrc = make_rsrc(b_base, b_bytes);
+    c.pb = make_plan<BT, C::BN, C::B_INSTR, C::BK>(wave, lane, p.ldb, rows_b);
+  }
+  if constexpr (CONV == 1) {
     static_assert(!AT && C::BK == 32, "implicit convolution: k-major A, 32-channel K-steps");
     // The descriptor starts W+1 pixels BEFORE the tile (clamped at pixel 0) so that the (-1,-1) tap is a
     // non-negative offset; it ends W+1 pixels after it.  Taps outside the image are sent out of range per lane.
@@ -397,12 +428,33 @@ __device__ __forceinline__ void stage_tile_conv(const __amdgpu_buffer_rsrc_t rsr
   }
 }
 
-template <bool AT, bool BT, class C, bool CONV = false>
+// CONV 2: K-step `kstep` of the B operand = 32 pixels x the tile's BN (tap, channel) columns of the shifted activation
+template <class C, class Ctx>
+__device__ __forceinline__ void stage_tile_wgrad(const Ctx& c, char* lds_tile, int wave, const GemmParams& p, int kstep) {
+  const int k0 = kstep * 32;
+#pragma unroll
+  for (int j = 0; j < C::B_INSTR; ++j) {
+    const int kl = k0 + (int)c.pb.kpos[j];
+    const unsigned pix = (unsigned)(c.kb + kl);
+    const unsigned q = __umulhi(pix, p.conv_magic_w);                   // pix / W
+    const int x = (int)(pix - q * (unsigned)p.conv_w) + ((c.btap[j] >> 2) - 1);
+    const int y = (int)(q - __umulhi(q, p.conv_magic_h) * (unsigned)p.conv_h) + ((c.btap[j] & 3) - 1);
+    const bool ok = c.pb.voff[j] != OOB && kl < c.klen && (unsigned)y < (unsigned)p.conv_h && (unsigned)x < (unsigned)p.conv_w;
+    const unsigned off = ok ? (unsigned)(c.bshift[j] + k0 * p.conv_c * 2) : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.b_rsrc, LDS_PTR(lds_tile + (wave * C::B_INSTR + j) * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+template <bool AT, bool BT, class C, int CONV = 0>
 __device__ __forceinline__ void stage_step(const ItemCtx<AT, BT, C>& c, const GemmParams& p, char* smem,
                                            int slot, int wave, int kstep) {
   char* st = smem + slot * C::STAGE_BYTES;
-  if constexpr (CONV) stage_tile_conv<C>(c.a_rsrc, st, wave, c.pa, c.yx, p, kstep);
+  if constexpr (CONV == 1) stage_tile_conv<C>(c.a_rsrc, st, wave, c.pa, c.yx, p, kstep);
   else stage_tile<AT>(c.a_rsrc, st, wave, c.pa, p.lda, kstep * C::BK, c.klen);
+  if constexpr (CONV == 2) {
+    stage_tile_wgrad<C>(c, st + C::A_BYTES, wave, p, kstep);
+    return;
+  }
   stage_tile<BT>(c.b_rsrc, st + C::A_BYTES, wave, c.pb, p.ldb, kstep * C::BK, c.klen);
 }
 
@@ -420,7 +472,7 @@ __device__ __forceinline__ void stage_step(const ItemCtx<AT, BT, C>& c, const Ge
 //     only 12-24 K-steps: fill + drain per tile was a third of the kernel);
 //   * the epilogue transposes the accumulators through the one ring slot that is free (the slot
 //     of the last K-step) — see below.
-template <bool AT, bool BT, int EPI, class C, bool CONV = false>
+template <bool AT, bool BT, int EPI, class C, int CONV = 0>
 __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD)
 void gemm_bf16_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -540,7 +592,7 @@ void gemm_bf16_kernel(GemmParams p) {
 //   WAR: slot (t+3)&3 held step t-1, last read in group 1's L(t-1, 1) (interval 4t-1) and retired by
 //        the lgkmcnt waits in front of its MFMAs in interval 4t; the DMA of step t+3 is issued AFTER the barrier
 //        that ends L(t, 1), i.e. in interval 4t+3 (group 0) / 4t+4 (group 1).
-template <bool AT, bool BT, int EPI, class C, bool CONV = false>
+template <bool AT, bool BT, int EPI, class C, int CONV = 0>
 __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD)
 void gemm_bf16_phase_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -719,7 +771,7 @@ int g_gemm_ablate = 0;
 int g_gemm_persistent = 0;
 int g_gemm_heuristic = 5;
 
-template <bool AT, bool BT, int EPI, class C, bool PIPE, bool CONV = false>
+template <bool AT, bool BT, int EPI, class C, bool PIPE, int CONV = 0>
 int launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
   void (*kern)(GemmParams) = nullptr;
   if (PIPE && p.bgrad != nullptr) {
@@ -877,6 +929,7 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
   p.bgrad_slabs = nullptr;
   p.conv_h = p.conv_w = p.conv_c = p.conv_kpt = 0;
   p.conv_inv_kpt = 0.f;
+  p.conv_magic_w = p.conv_magic_h = 0u;
   p.k_chunk = ((K + BK_MAX - 1) / BK_MAX) * BK_MAX;
 
   // K % 8 is an alignment rule of the k-major operands only (16-byte chunks along k); in the (1,1) layout k is
@@ -948,7 +1001,7 @@ static int launch_conv(GemmParams p, hipStream_t s) {
   p.tiles_m = (p.M + C::BM - 1) / C::BM;
   p.tiles_n = (p.N + C::BN - 1) / C::BN;
   p.splits = 1;
-  return launch_cfg<false, false, CFHIP_EPI_NONE, C, PIPE, true>(p, dim3(p.tiles_m * p.tiles_n), s);
+  return launch_cfg<false, false, CFHIP_EPI_NONE, C, PIPE, 1>(p, dim3(p.tiles_m * p.tiles_n), s);
 }
 
 extern "C" int cfhip_conv3x3_nhwc_bf16(const void* X, const void* Wk, const float* bias, void* Y, int B, int H, int W,
@@ -979,8 +1032,75 @@ extern "C" int cfhip_conv3x3_nhwc_bf16(const void* X, const void* Wk, const floa
   p.ablate = 0;
   p.conv_h = H; p.conv_w = W; p.conv_c = Cin; p.conv_kpt = Cin / 32;
   p.conv_inv_kpt = 1.0f / (float)p.conv_kpt;
+  p.conv_magic_w = p.conv_magic_h = 0u;
   const int rc = p.M >= 1024 ? launch_conv<CfgQ, true>(p, (hipStream_t)stream) : launch_conv<CfgB, false>(p, (hipStream_t)stream);
   if (rc != CFHIP_OK) return rc;
   CFHIP_CHECK_LAUNCH("conv3x3_nhwc");
+  return CFHIP_OK;
+}
+
+extern "C" size_t cfhip_conv3x3_wgrad_workspace(int Cin, int Cout, int split_k) {
+  return split_k > 1 ? (size_t)split_k * Cout * (9 * (size_t)Cin + 1) * sizeof(float) : 0;
+}
+
+extern "C" int cfhip_conv3x3_wgrad_nhwc_bf16(const void* dY, const void* X, float* dWk, float* bias_grad,
+                                             int bias_grad_accumulate, int B, int H, int W, int Cin, int Cout,
+                                             int split_k, void* workspace, size_t workspace_bytes, void* stream) {
+  CFHIP_REQUIRE(dY && X && dWk, "conv3x3_wgrad: null operand");
+  CFHIP_REQUIRE(B > 0 && H >= 2 && W >= 2 && H < 65536 && W < 65536, "conv3x3_wgrad: bad image shape %d x %d x %d", B, H, W);
+  CFHIP_REQUIRE(Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 8 == 0, "conv3x3_wgrad: Cin = %d and Cout = %d must be multiples of 8", Cin, Cout);
+  const long pixels = (long)B * H * W;
+  CFHIP_REQUIRE(pixels * (W > H ? W : H) < (1L << 32) && 9L * Cin < (1L << 20),
+                "conv3x3_wgrad: problem too large (%ld pixels of %d x %d, Cin %d)", pixels, H, W, Cin);
+  CFHIP_REQUIRE(aligned16(dY) && aligned16(X) && aligned16(dWk), "conv3x3_wgrad: operands must be 16-byte aligned");
+  if (split_k < 1) split_k = 1;
+  GemmParams p;
+  p.A = reinterpret_cast<const bf16_t*>(dY);
+  p.B = reinterpret_cast<const bf16_t*>(X);
+  p.C = dWk;
+  p.bias = nullptr; p.aux_in = nullptr; p.aux_out = nullptr;
+  p.M = Cout; p.N = 9 * Cin; p.K = (int)pixels;
+  p.lda = Cout; p.ldb = Cin; p.ldc = 9L * Cin;
+  p.epilogue = CFHIP_EPI_NONE; p.out_f32 = 1; p.accumulate = 0;
+  p.slabs = nullptr;
+  p.bgrad = bias_grad; p.bgrad_acc = bias_grad_accumulate; p.bgrad_slabs = nullptr;
+  p.quick = 0; p.ablate = 0;
+  p.conv_h = H; p.conv_w = W; p.conv_c = Cin; p.conv_kpt = 0; p.conv_inv_kpt = 0.f;
+  p.conv_magic_w = (unsigned)((1ULL << 32) / (unsigned)W + 1ULL);
+  p.conv_magic_h = (unsigned)((1ULL << 32) / (unsigned)H + 1ULL);
+  p.k_chunk = ((p.K + BK_MAX - 1) / BK_MAX) * BK_MAX;
+  if (split_k > 1) {
+    const int steps = (p.K + BK_MAX - 1) / BK_MAX;
+    if (split_k > steps) split_k = steps;
+    const int per = (steps + split_k - 1) / split_k;
+    split_k = (steps + per - 1) / per;
+    p.k_chunk = per * BK_MAX;
+  }
+  CFHIP_REQUIRE(((long)p.k_chunk + 2L * W + 2) * Cin * 2 < 0x7fffffffL && (long)p.k_chunk * Cout * 2 < 0x7fffffffL,
+                "conv3x3_wgrad: a K slice of %d pixels exceeds the 2 GiB descriptor range (raise split_k)", p.k_chunk);
+  if (split_k > 1) {
+    const size_t need = (size_t)split_k * p.M * p.N * sizeof(float) + (bias_grad ? (size_t)split_k * p.M * sizeof(float) : 0);
+    if (workspace == nullptr || workspace_bytes < need) {
+      cfhip_set_error("conv3x3_wgrad: split_k=%d needs %zu workspace bytes, got %zu", split_k, need, workspace_bytes);
+      return CFHIP_ERR_WORKSPACE;
+    }
+    p.slabs = reinterpret_cast<float*>(workspace);
+    if (bias_grad) p.bgrad_slabs = p.slabs + (size_t)split_k * p.M * p.N;
+  }
+  p.tiles_m = (p.M + CfgC::BM - 1) / CfgC::BM;
+  p.tiles_n = (p.N + CfgC::BN - 1) / CfgC::BN;
+  p.splits = split_k;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = launch_cfg<true, true, CFHIP_EPI_NONE, CfgC, false, 2>(p, dim3(p.tiles_m * p.tiles_n * split_k), s);
+  if (rc != CFHIP_OK) return rc;
+  CFHIP_CHECK_LAUNCH("conv3x3_wgrad");
+  if (split_k > 1) {
+    const long total = (long)p.M * (p.N / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slabs, (void*)dWk, (const float*)nullptr,
+                       p.M, p.N, (long)p.ldc, split_k, 1, 0, p.bgrad_slabs, p.bgrad, p.bgrad_acc);
+    CFHIP_CHECK_LAUNCH("splitk_reduce");
+  }
   return CFHIP_OK;
 }

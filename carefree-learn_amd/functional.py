@@ -605,7 +605,8 @@ class Conv2dFn(Function):
             w16 = shadow_bf16(weight)
             wk = w16.permute(0, 2, 3, 1).reshape(cout, 9 * cin)  # k = (ky, kx, c): a K-step = 32 channels of a tap
             y_rows = ops.conv3x3_nhwc(x_rows, wk, bias_f, b, h, w)
-            ctx.save_for_backward(x, w16)
+            ctx.save_for_backward(x_rows, w16)  # the NHWC bf16 copy serves the weight gradient; x itself is not kept
+            ctx.xshape = (b, cin, h, w)
             return ops.transpose_batched(y_rows.view(b, h * w, cout)).view(b, cout, h, w)
         rows = ops.conv_im2row(x, kh, kw, stride, pad, dil)
         wp = _conv_weight_rows(weight, rows.shape[1])
@@ -625,14 +626,15 @@ class Conv2dFn(Function):
         if cp != cout:
             y = y[:, :cout].contiguous()
         ctx.save_for_backward(x, wp)
+        ctx.xshape = (b, cin, h, w)
         return y
 
     @staticmethod
     def backward(ctx: Any, dy: Tensor):  # type: ignore
-        x, wp = ctx.saved_tensors
+        x, wp = ctx.saved_tensors  # implicit route: x is the NHWC row matrix [B*H*W, Cin]
         weight, bias = ctx.weight, ctx.bias
         kh, kw, stride, pad, dil, ho, wo = ctx.geom
-        b, cin, h, w = x.shape
+        b, cin, h, w = ctx.xshape
         cout = weight.shape[0]
         k = cin * kh * kw
         if dy.dtype != bf16:
@@ -645,7 +647,26 @@ class Conv2dFn(Function):
             dy = dyp
         dy_rows = ops.transpose_batched(dy.contiguous().view(b, cp, ho * wo)).view(b * ho * wo, cp)
         gw = gb = None
-        if weight.requires_grad:
+        wgrad_implicit = ctx.implicit and ops.conv3x3_wgrad_ok(b, h, w)
+        if ctx.implicit and not wgrad_implicit and weight.requires_grad:
+            x = ops.transpose_batched(x.view(b, h * w, cin)).view(b, cin, h, w)  # back to NCHW for the im2row route
+        if weight.requires_grad and wgrad_implicit:
+            split = ops.pick_split_k(cout, 9 * cin, b * h * w)
+
+            def dw_implicit(out: Tensor, acc: bool) -> None:
+                tmp = ops.conv3x3_wgrad_nhwc(dy_rows, x, b, h, w, split)  # [Cout, (ky, kx, c)] f32
+                tmp = tmp.view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+                if acc:
+                    out.view(cout, cin, 3, 3).add_(tmp)
+                else:
+                    out.view(cout, cin, 3, 3).copy_(tmp)
+
+            if _is_direct(weight):
+                write_param_grad(weight, dw_implicit)
+            else:
+                gw = torch.empty(weight.shape, dtype=f32, device=dy.device)
+                dw_implicit(gw, False)
+        elif weight.requires_grad:
             rows = ops.conv_im2row(x, kh, kw, stride, pad, dil)  # recomputed: k^2 times the input, not kept
             m = rows.shape[0]
             kp = rows.shape[1]

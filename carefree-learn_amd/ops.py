@@ -805,6 +805,32 @@ def conv3x3_nhwc(x_rows: Tensor, wk: Tensor, bias: Optional[Tensor], b: int, h: 
     return y
 
 
+def conv3x3_wgrad_ok(b: int, h: int, w: int) -> bool:
+    return h >= 2 and w >= 2 and h < 65536 and w < 65536 and b * h * w * max(h, w) < (1 << 32)
+
+
+def conv3x3_wgrad_nhwc(dy_rows: Tensor, x_rows: Tensor, b: int, h: int, w: int, split_k: int = 1,
+                       bias_grad: Optional[Tensor] = None, bias_grad_accumulate: bool = False) -> Tensor:
+    """dy_rows bf16 [B*H*W, Cout], x_rows bf16 [B*H*W, Cin] (NHWC) -> f32 [Cout, 9*Cin] with k = (ky*3 + kx)*Cin + c
+    (tap-major: `.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)` is the reference's [Cout, Cin, 3, 3])."""
+    _need(dy_rows, bf16, "dy_rows")
+    _need(x_rows, bf16, "x_rows")
+    m, cout = dy_rows.shape
+    cin = x_rows.shape[1]
+    if m != b * h * w or x_rows.shape[0] != m or not dy_rows.is_contiguous() or not x_rows.is_contiguous():
+        raise ValueError("cfhip conv3x3_wgrad_nhwc: dense NHWC rows [B*H*W, C] expected for both operands")
+    if bias_grad is not None:
+        _need(bias_grad, f32, "bias_grad")
+    out = torch.empty((cout, 9 * cin), dtype=f32, device=dy_rows.device)
+    lib = _lib.load()
+    nbytes = lib.cfhip_conv3x3_wgrad_workspace(cin, cout, split_k)
+    ws = torch.empty((max(nbytes, 4) // 4,), dtype=f32, device=dy_rows.device)
+    _lib.check(lib.cfhip_conv3x3_wgrad_nhwc_bf16(dy_rows.data_ptr(), x_rows.data_ptr(), out.data_ptr(), _p(bias_grad),
+                                                 int(bias_grad_accumulate), b, h, w, cin, cout, split_k, ws.data_ptr(),
+                                                 nbytes, _stream()), "conv3x3_wgrad_nhwc")
+    return out
+
+
 def spin(microseconds: int) -> None:
     """One idle wavefront on the current stream (stream self-check, see functional.distinct_stream)."""
     _lib.check(_lib.load().cfhip_spin(int(microseconds), _stream()), "spin")

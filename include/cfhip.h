@@ -238,6 +238,15 @@ int cfhip_ema_update(float* ema, const float* p, int64_t n, float one_minus_deca
  * of X and the filters rotated by 180 degrees and transposed: Wk'[c][(ky*3+kx)*Cout + co] = W[co][c][2-ky][2-kx]. */
 int cfhip_conv3x3_nhwc_bf16(const void* X, const void* Wk, const float* bias, void* Y, int B, int H, int W, int Cin,
                             int Cout, void* stream);
+/* Weight gradient of the same convolution without an im2row matrix: dWk[co][(ky*3+kx)*Cin + c] = sum_p dY[p][co] *
+ * X[p + (ky-1)*W + (kx-1)][c] (taps outside the image contribute zero), f32 [Cout][9*Cin], overwritten (the caller
+ * permutes it into the reference's [Cout][Cin][3][3] layout while accumulating).  dY [B*H*W][Cout], X [B*H*W][Cin] bf16
+ * NHWC; Cin % 8 == 0, Cout % 8 == 0, H, W >= 2, B*H*W*max(H, W) < 2^32.  bias_grad (f32 [Cout] or NULL) (+)= colsum(dY).
+ * split_k > 1 needs cfhip_conv3x3_wgrad_workspace() bytes; partial sums are reduced in a fixed order (deterministic). */
+size_t cfhip_conv3x3_wgrad_workspace(int Cin, int Cout, int split_k);
+int cfhip_conv3x3_wgrad_nhwc_bf16(const void* dY, const void* X, float* dWk, float* bias_grad, int bias_grad_accumulate,
+                                  int B, int H, int W, int Cin, int Cout, int split_k, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 /* One idle wavefront for `microseconds` (1..100000) on `stream`.  Host-side stream self-check only (two streams
  * that share a ROCclr hardware queue run it back to back; the side streams of the backward pass and the RCCL
  * stream must not share the compute stream's queue -- reference counterpart: none, torch DDP owns its streams). */

@@ -232,7 +232,7 @@ def test_conv_classifier_and_fcnn_train_steps(golden):
     (1, 96, 64, 5, 7),      # image smaller than a tile row: every tile crosses image rows
 ])
 def test_implicit_conv3x3_matches_fp32_reference_and_im2row_route(shape):
-    """cfhip_conv3x3_nhwc_bf16 (taps gathered inside the GEMM K loop, zero padding by per-lane range checks) against
+    """cfhip_conv3x3_nhwc_bf16 / cfhip_conv3x3_wgrad_nhwc_bf16 (taps gathered inside the GEMM K loop, zero padding by per-lane range checks) against
     torch's fp32 conv2d on the bf16-rounded operands (CPU), forward / input gradient / weight + bias gradients, and
     against the im2row route of the same Function."""
     b, cin, cout, h, w = shape
@@ -269,7 +269,7 @@ def test_implicit_conv3x3_matches_fp32_reference_and_im2row_route(shape):
     # same bf16 operands, fp32 accumulation in a different k order: equal up to the last bf16 rounding
     assert_close(y, y2, 3e-3, "implicit vs im2row forward")
     assert_close(gx, gx2, 3e-3, "implicit vs im2row dX")
-    assert_close(gw, gw2, 1e-5, "dW (same route both times)")
+    assert_close(gw, gw2, 2e-5, "implicit vs im2row dW (fp32 sums in a different order)")
     # the zero padding is exact: a single bright pixel in a corner only reaches its 2x2 neighbourhood
     xi = torch.zeros(1, cin, h, w)
     xi[0, :, 0, 0] = 1.0
