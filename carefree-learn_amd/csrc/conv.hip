@@ -393,6 +393,162 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// ---- GroupNorm, vector form: inner % 8 == 0, 16-byte aligned rows.  Same arithmetic as the scalar kernels above (two-pass
+// statistics in fp32), 8 elements per lane per load (one 16-byte load of bf16, two of f32) and no integer division in
+// the loops; the second and third pass over a group (80 KB - 1.3 MB) come out of L2.  UNet 64^2 x 8: the scalar forms
+// took 74 / 116 us per call, 11.5 ms of a 101 ms step (profiles/r01/prof_unet64_b8_implicit_summary.txt).
+template <bool IN_F32>
+__device__ __forceinline__ void gn_load8(const void* p, long off, float (&v)[8]) {
+  if (IN_F32) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + off);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + off + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  } else {
+    const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p) + off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] = bf16lo(w[e]);
+      v[2 * e + 1] = bf16hi(w[e]);
+    }
+  }
+}
+__device__ __forceinline__ void gn_store8(bf16_t* p, long off, const float (&v)[8]) {
+  *reinterpret_cast<u32x4*>(p + off) = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                             pack_bf16x2(v[6], v[7])};
+}
+
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void gn_fwd_vec_kernel(const void* __restrict__ x, const float* __restrict__ add,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         bf16_t* __restrict__ y, float* __restrict__ mean_out,
+                                                         float* __restrict__ rstd_out, int C, int G, int inner, float eps,
+                                                         int silu) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int cg = C / G;
+  const int inner8 = inner >> 3;
+  const long base = ((long)b * C + (long)g * cg) * inner;
+  const float inv_n = 1.f / ((float)cg * (float)inner);
+  float s = 0.f;
+  for (int cl = 0; cl < cg; ++cl) {
+    const float ad = add != nullptr ? add[(long)b * C + g * cg + cl] : 0.f;
+    for (int j = threadIdx.x; j < inner8; j += 256) {
+      float v[8];
+      gn_load8<IN_F32>(x, base + (long)cl * inner + j * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[e] + ad;
+    }
+  }
+  const float mean = block_sum(s, red) * inv_n;
+  float q = 0.f;
+  for (int cl = 0; cl < cg; ++cl) {
+    const float ad = (add != nullptr ? add[(long)b * C + g * cg + cl] : 0.f) - mean;
+    for (int j = threadIdx.x; j < inner8; j += 256) {
+      float v[8];
+      gn_load8<IN_F32>(x, base + (long)cl * inner + j * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[e] + ad;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(block_sum(q, red) * inv_n + eps);
+  if (threadIdx.x == 0) {
+    mean_out[blockIdx.x] = mean;
+    rstd_out[blockIdx.x] = rstd;
+  }
+  for (int cl = 0; cl < cg; ++cl) {
+    const int c = g * cg + cl;
+    const float ad = add != nullptr ? add[(long)b * C + c] : 0.f;
+    const float ga = gamma[c], be = beta[c];
+    for (int j = threadIdx.x; j < inner8; j += 256) {
+      float v[8];
+      const long o = base + (long)cl * inner + j * 8;
+      gn_load8<IN_F32>(x, o, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float r = ((v[e] + ad) - mean) * rstd * ga + be;
+        if (silu) r = silu_f(r);
+        v[e] = r;
+      }
+      gn_store8(y, o, v);
+    }
+  }
+}
+
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void gn_bwd_vec_kernel(const bf16_t* __restrict__ dy, const void* __restrict__ x,
+                                                         const float* __restrict__ add, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, bf16_t* __restrict__ dx,
+                                                         float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
+                                                         float* __restrict__ dadd, int C, int G, int inner, int silu) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int cg = C / G;
+  const int inner8 = inner >> 3;
+  const long base = ((long)b * C + (long)g * cg) * inner;
+  const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
+  float s1 = 0.f, s2 = 0.f;  // sum(dn * gamma), sum(dn * gamma * xhat)
+  for (int cl = 0; cl < cg; ++cl) {
+    const int c = g * cg + cl;
+    const float ad = add != nullptr ? add[(long)b * C + c] : 0.f;
+    const float ga = gamma[c], be = beta[c];
+    float sg = 0.f, sb = 0.f;
+    for (int j = threadIdx.x; j < inner8; j += 256) {
+      const long o = base + (long)cl * inner + j * 8;
+      float v[8], d[8];
+      gn_load8<IN_F32>(x, o, v);
+      gn_load8<false>(dy, o, d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (v[e] + ad - mu) * rs;
+        float dn = d[e];
+        if (silu) dn *= silu_grad_f(xh * ga + be);
+        sg += dn * xh;
+        sb += dn;
+      }
+    }
+    sg = block_sum(sg, red);
+    sb = block_sum(sb, red);
+    if (threadIdx.x == 0) {
+      dgamma_part[(long)b * C + c] = sg;
+      dbeta_part[(long)b * C + c] = sb;
+    }
+    s1 += sb * ga;
+    s2 += sg * ga;
+  }
+  const float inv_n = 1.f / ((float)cg * (float)inner);
+  for (int cl = 0; cl < cg; ++cl) {
+    const int c = g * cg + cl;
+    const float ad = add != nullptr ? add[(long)b * C + c] : 0.f;
+    const float ga = gamma[c], be = beta[c];
+    float sd = 0.f;
+    for (int j = threadIdx.x; j < inner8; j += 256) {
+      const long o = base + (long)cl * inner + j * 8;
+      float v[8], d[8];
+      gn_load8<IN_F32>(x, o, v);
+      gn_load8<false>(dy, o, d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (v[e] + ad - mu) * rs;
+        float dn = d[e];
+        if (silu) dn *= silu_grad_f(xh * ga + be);
+        const float r = rs * (dn * ga - s1 * inv_n - xh * s2 * inv_n);
+        d[e] = r;
+        // the scalar kernel sums the fp32 value too (the bf16 rounding happens at the store only)
+        sd += r;
+      }
+      gn_store8(dx, o, d);
+    }
+    if (dadd != nullptr) {
+      sd = block_sum(sd, red);
+      if (threadIdx.x == 0) dadd[(long)b * C + c] = sd;
+    }
+  }
+}
+
 // ---- SiLU on small f32 vectors (the time embedding), nearest x2 up-sampling, 2x2 average pooling ------------------
 template <bool BWD>
 __global__ void silu_f32_kernel(const float* __restrict__ a, const float* __restrict__ x, float* __restrict__ out, long n) {
@@ -615,7 +771,14 @@ extern "C" int cfhip_groupnorm_fwd(const void* x, int x_is_f32, const float* add
                                    int silu, void* stream) {
   CFHIP_REQUIRE(x && gamma && beta && y && mean && rstd && B > 0 && C > 0 && G > 0 && inner > 0, "groupnorm_fwd: bad arguments");
   CFHIP_REQUIRE(C % G == 0, "groupnorm_fwd: %d channels do not split into %d groups", C, G);
-  if (x_is_f32)
+  const bool vec = inner % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0;
+  if (vec && x_is_f32)
+    hipLaunchKernelGGL((gn_fwd_vec_kernel<true>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, add, gamma, beta,
+                       (bf16_t*)y, mean, rstd, C, G, inner, eps, silu);
+  else if (vec)
+    hipLaunchKernelGGL((gn_fwd_vec_kernel<false>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, add, gamma, beta,
+                       (bf16_t*)y, mean, rstd, C, G, inner, eps, silu);
+  else if (x_is_f32)
     hipLaunchKernelGGL((gn_fwd_kernel<true>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, add, gamma, beta,
                        (bf16_t*)y, mean, rstd, C, G, inner, eps, silu);
   else
@@ -632,7 +795,14 @@ extern "C" int cfhip_groupnorm_bwd(const void* dy, const void* x, int x_is_f32, 
   CFHIP_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma_part && dbeta_part, "groupnorm_bwd: null pointer");
   CFHIP_REQUIRE(B > 0 && C > 0 && G > 0 && inner > 0 && C % G == 0, "groupnorm_bwd: bad geometry");
   CFHIP_REQUIRE((add == nullptr) == (dadd == nullptr) || dadd == nullptr, "groupnorm_bwd: dadd without add");
-  if (x_is_f32)
+  const bool vec = inner % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0;
+  if (vec && x_is_f32)
+    hipLaunchKernelGGL((gn_bwd_vec_kernel<true>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, add,
+                       gamma, beta, mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu);
+  else if (vec)
+    hipLaunchKernelGGL((gn_bwd_vec_kernel<false>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, add,
+                       gamma, beta, mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu);
+  else if (x_is_f32)
     hipLaunchKernelGGL((gn_bwd_kernel<true>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, add,
                        gamma, beta, mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu);
   else

@@ -449,7 +449,7 @@ template <bool AT, bool BT, class C, int CONV = 0>
 __device__ __forceinline__ void stage_step(const ItemCtx<AT, BT, C>& c, const GemmParams& p, char* smem,
                                            int slot, int wave, int kstep) {
   char* st = smem + slot * C::STAGE_BYTES;
-  if constexpr (CONV == 1) stage_tile_conv<C>(c.a_rsrc, st, wave, c.pa, c.yx, p, kstep);
+  if constexpr (CONV == 1) stage_tile_conv<C>(c.a_rsrc, st, wave, c.pa, c.yx, p, kstep + (c.kb >> 5));
   else stage_tile<AT>(c.a_rsrc, st, wave, c.pa, p.lda, kstep * C::BK, c.klen);
   if constexpr (CONV == 2) {
     stage_tile_wgrad<C>(c, st + C::A_BYTES, wave, p, kstep);
@@ -997,15 +997,37 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
 
 // ---- implicit-GEMM 3x3 convolution ------------------------------------------------------------------
 template <class C, bool PIPE>
-static int launch_conv(GemmParams p, hipStream_t s) {
+static int launch_conv(GemmParams p, int split_k, hipStream_t s) {
   p.tiles_m = (p.M + C::BM - 1) / C::BM;
   p.tiles_n = (p.N + C::BN - 1) / C::BN;
-  p.splits = 1;
-  return launch_cfg<false, false, CFHIP_EPI_NONE, C, PIPE, 1>(p, dim3(p.tiles_m * p.tiles_n), s);
+  p.splits = split_k;
+  return launch_cfg<false, false, CFHIP_EPI_NONE, C, PIPE, 1>(p, dim3(p.tiles_m * p.tiles_n * split_k), s);
+}
+
+// The UNet's deeper levels have few output tiles (32^2 x 8 x 640: 160 tiles of 256x128, 8^2 x 8 x 1280: 40 of 128x128)
+// under a deep reduction (K = 9 * Cin = 5 760 .. 23 040): split K until the grid covers the resident slots.
+static int conv_pick_split(long pixels, int Cin, int Cout) {
+  const bool phase = pixels >= 1024;
+  const int bm = phase ? 256 : 128;
+  const long tiles = ((pixels + bm - 1) / bm) * ((Cout + 127) / 128);
+  const long slots = phase ? 512 : 1024;
+  const int steps = (9 * Cin + BK_MAX - 1) / BK_MAX;
+  if (tiles * 2 > slots || steps < 16) return 1;
+  long split = (slots + tiles - 1) / tiles;
+  if (split > steps / 8) split = steps / 8;
+  if (split < 1) split = 1;
+  const int per = (int)((steps + split - 1) / split);
+  return (steps + per - 1) / per;
+}
+
+extern "C" size_t cfhip_conv3x3_workspace(int B, int H, int W, int Cin, int Cout) {
+  const long pixels = (long)B * H * W;
+  const int split = conv_pick_split(pixels, Cin, Cout);
+  return split > 1 ? (size_t)split * pixels * Cout * sizeof(float) : 0;
 }
 
 extern "C" int cfhip_conv3x3_nhwc_bf16(const void* X, const void* Wk, const float* bias, void* Y, int B, int H, int W,
-                                       int Cin, int Cout, void* stream) {
+                                       int Cin, int Cout, void* workspace, size_t workspace_bytes, void* stream) {
   CFHIP_REQUIRE(X && Wk && Y, "conv3x3: null operand");
   CFHIP_REQUIRE(B > 0 && H > 0 && W > 0 && H < 65536 && W < 65536, "conv3x3: bad image shape %d x %d x %d", B, H, W);
   CFHIP_REQUIRE(Cin > 0 && Cin % 32 == 0, "conv3x3: Cin = %d must be a multiple of 32 (one K-step = 32 channels of a tap)", Cin);
@@ -1033,9 +1055,29 @@ extern "C" int cfhip_conv3x3_nhwc_bf16(const void* X, const void* Wk, const floa
   p.conv_h = H; p.conv_w = W; p.conv_c = Cin; p.conv_kpt = Cin / 32;
   p.conv_inv_kpt = 1.0f / (float)p.conv_kpt;
   p.conv_magic_w = p.conv_magic_h = 0u;
-  const int rc = p.M >= 1024 ? launch_conv<CfgQ, true>(p, (hipStream_t)stream) : launch_conv<CfgB, false>(p, (hipStream_t)stream);
+  const int split = conv_pick_split(pixels, Cin, Cout);
+  if (split > 1) {
+    const size_t need = (size_t)split * pixels * Cout * sizeof(float);
+    if (workspace == nullptr || workspace_bytes < need) {
+      cfhip_set_error("conv3x3: split_k=%d needs %zu workspace bytes (cfhip_conv3x3_workspace), got %zu", split, need, workspace_bytes);
+      return CFHIP_ERR_WORKSPACE;
+    }
+    const int steps = (p.K + BK_MAX - 1) / BK_MAX;
+    p.k_chunk = ((steps + split - 1) / split) * BK_MAX;
+    p.slabs = reinterpret_cast<float*>(workspace);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = p.M >= 1024 ? launch_conv<CfgQ, true>(p, split, s) : launch_conv<CfgB, false>(p, split, s);
   if (rc != CFHIP_OK) return rc;
   CFHIP_CHECK_LAUNCH("conv3x3_nhwc");
+  if (split > 1) {
+    const long total = (long)p.M * (p.N / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slabs, Y, bias, p.M, p.N, (long)p.ldc, split,
+                       0, 0, (const float*)nullptr, (float*)nullptr, 0);
+    CFHIP_CHECK_LAUNCH("splitk_reduce");
+  }
   return CFHIP_OK;
 }
 

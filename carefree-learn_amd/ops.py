@@ -800,8 +800,11 @@ def conv3x3_nhwc(x_rows: Tensor, wk: Tensor, bias: Optional[Tensor], b: int, h: 
     if bias is not None:
         _need(bias, f32, "bias")
     y = torch.empty((m, cout), dtype=bf16, device=x_rows.device)
-    _lib.check(_lib.load().cfhip_conv3x3_nhwc_bf16(x_rows.data_ptr(), wk.data_ptr(), _p(bias), y.data_ptr(), b, h, w,
-                                                   cin, cout, _stream()), "conv3x3_nhwc")
+    lib = _lib.load()
+    nbytes = lib.cfhip_conv3x3_workspace(b, h, w, cin, cout)  # > 0 when the shape splits its reduction
+    ws = torch.empty((max(nbytes, 4) // 4,), dtype=f32, device=x_rows.device)
+    _lib.check(lib.cfhip_conv3x3_nhwc_bf16(x_rows.data_ptr(), wk.data_ptr(), _p(bias), y.data_ptr(), b, h, w, cin, cout,
+                                           ws.data_ptr(), nbytes, _stream()), "conv3x3_nhwc")
     return y
 
 

@@ -235,9 +235,12 @@ int cfhip_ema_update(float* ema, const float* p, int64_t n, float one_minus_deca
  * outside the image contribute zero.  X [B*H*W][Cin], Wk [Cout][9*Cin] (tap-major, channel-minor), Y [B*H*W][Cout],
  * all bf16; bias f32 [Cout] or NULL.  Cin % 32 == 0, Cout % 8 == 0.  No im2row matrix is materialised: each K-step of
  * the MFMA GEMM gathers 32 channels of one tap straight from X.  The input gradient is the same call with dY in place
- * of X and the filters rotated by 180 degrees and transposed: Wk'[c][(ky*3+kx)*Cout + co] = W[co][c][2-ky][2-kx]. */
+ * of X and the filters rotated by 180 degrees and transposed: Wk'[c][(ky*3+kx)*Cout + co] = W[co][c][2-ky][2-kx].
+ * Shapes with few output tiles split the reduction (deterministic ordered reduce of fp32 partials): pass
+ * cfhip_conv3x3_workspace() bytes of scratch (0 when the shape does not split). */
+size_t cfhip_conv3x3_workspace(int B, int H, int W, int Cin, int Cout);
 int cfhip_conv3x3_nhwc_bf16(const void* X, const void* Wk, const float* bias, void* Y, int B, int H, int W, int Cin,
-                            int Cout, void* stream);
+                            int Cout, void* workspace, size_t workspace_bytes, void* stream);
 /* Weight gradient of the same convolution without an im2row matrix: dWk[co][(ky*3+kx)*Cin + c] = sum_p dY[p][co] *
  * X[p + (ky-1)*W + (kx-1)][c] (taps outside the image contribute zero), f32 [Cout][9*Cin], overwritten (the caller
  * permutes it into the reference's [Cout][Cin][3][3] layout while accumulating).  dY [B*H*W][Cout], X [B*H*W][Cin] bf16

@@ -228,8 +228,9 @@ def test_conv_classifier_and_fcnn_train_steps(golden):
 @pytest.mark.parametrize("shape", [
     (2, 64, 96, 12, 10),    # M = 240 < 1024: 128x128x32 base kernel, ragged last tile, non-square image
     (3, 32, 40, 20, 24),    # M = 1440: 256x128 phase kernel, Cout not a multiple of 32 (dX falls back to row2im)
-    (2, 320, 320, 32, 32),  # the UNet's first level (K = 2880 = 90 K-steps, 10 K-steps per tap)
+    (2, 320, 320, 32, 32),  # UNet level (K = 2880 = 90 K-steps, 10 per tap); 24 tiles: the reduction is split 5 ways
     (1, 96, 64, 5, 7),      # image smaller than a tile row: every tile crosses image rows
+    (2, 256, 128, 8, 8),    # the UNet's deepest level: one output tile, the reduction is split 4 ways (base kernel)
 ])
 def test_implicit_conv3x3_matches_fp32_reference_and_im2row_route(shape):
     """cfhip_conv3x3_nhwc_bf16 / cfhip_conv3x3_wgrad_nhwc_bf16 (taps gathered inside the GEMM K loop, zero padding by per-lane range checks) against
