@@ -477,6 +477,10 @@ __global__ __launch_bounds__(256) void gn_fwd_vec_kernel(const void* __restrict_
   }
 }
 
+// Backward: the per-channel sums (dgamma / dbeta partials, dadd) are reduced per WAVE inside the channel loop (shuffles
+// only) and parked in LDS; the workgroup synchronises once per pass instead of 4-6 times per channel, so the loads of
+// the next channel overlap the arithmetic of this one.  Channels per group <= GN_MAX_CG (the UNet's widest: 2560 / 32).
+constexpr int GN_MAX_CG = 128;
 template <bool IN_F32>
 __global__ __launch_bounds__(256) void gn_bwd_vec_kernel(const bf16_t* __restrict__ dy, const void* __restrict__ x,
                                                          const float* __restrict__ add, const float* __restrict__ gamma,
@@ -485,12 +489,13 @@ __global__ __launch_bounds__(256) void gn_bwd_vec_kernel(const bf16_t* __restric
                                                          float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
                                                          float* __restrict__ dadd, int C, int G, int inner, int silu) {
   __shared__ float red[4];
+  __shared__ float part[2][GN_MAX_CG][4];
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
   const int cg = C / G;
   const int inner8 = inner >> 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long base = ((long)b * C + (long)g * cg) * inner;
   const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
-  float s1 = 0.f, s2 = 0.f;  // sum(dn * gamma), sum(dn * gamma * xhat)
   for (int cl = 0; cl < cg; ++cl) {
     const int c = g * cg + cl;
     const float ad = add != nullptr ? add[(long)b * C + c] : 0.f;
@@ -510,15 +515,26 @@ __global__ __launch_bounds__(256) void gn_bwd_vec_kernel(const bf16_t* __restric
         sb += dn;
       }
     }
-    sg = block_sum(sg, red);
-    sb = block_sum(sb, red);
-    if (threadIdx.x == 0) {
-      dgamma_part[(long)b * C + c] = sg;
-      dbeta_part[(long)b * C + c] = sb;
+    sg = wave_sum(sg);
+    sb = wave_sum(sb);
+    if (lane == 0) {
+      part[0][cl][wave] = sg;
+      part[1][cl][wave] = sb;
     }
-    s1 += sb * ga;
-    s2 += sg * ga;
   }
+  __syncthreads();
+  float t1 = 0.f, t2 = 0.f;  // this thread's channel: gamma * sum(dn), gamma * sum(dn * xhat)
+  if ((int)threadIdx.x < cg) {
+    const int c = g * cg + threadIdx.x;
+    const float sg = (part[0][threadIdx.x][0] + part[0][threadIdx.x][1]) + (part[0][threadIdx.x][2] + part[0][threadIdx.x][3]);
+    const float sb = (part[1][threadIdx.x][0] + part[1][threadIdx.x][1]) + (part[1][threadIdx.x][2] + part[1][threadIdx.x][3]);
+    dgamma_part[(long)b * C + c] = sg;
+    dbeta_part[(long)b * C + c] = sb;
+    t1 = sb * gamma[c];
+    t2 = sg * gamma[c];
+  }
+  const float s1 = block_sum(t1, red);
+  const float s2 = block_sum(t2, red);
   const float inv_n = 1.f / ((float)cg * (float)inner);
   for (int cl = 0; cl < cg; ++cl) {
     const int c = g * cg + cl;
@@ -537,14 +553,56 @@ __global__ __launch_bounds__(256) void gn_bwd_vec_kernel(const bf16_t* __restric
         if (silu) dn *= silu_grad_f(xh * ga + be);
         const float r = rs * (dn * ga - s1 * inv_n - xh * s2 * inv_n);
         d[e] = r;
-        // the scalar kernel sums the fp32 value too (the bf16 rounding happens at the store only)
-        sd += r;
+        sd += r;  // the fp32 value, as in the scalar kernel (the bf16 rounding happens at the store only)
       }
       gn_store8(dx, o, d);
     }
     if (dadd != nullptr) {
-      sd = block_sum(sd, red);
-      if (threadIdx.x == 0) dadd[(long)b * C + c] = sd;
+      sd = wave_sum(sd);
+      if (lane == 0) part[0][cl][wave] = sd;  // pass-1 contents were consumed before the block_sum barriers above
+    }
+  }
+  if (dadd != nullptr) {
+    __syncthreads();
+    if ((int)threadIdx.x < cg)
+      dadd[(long)b * C + g * cg + threadIdx.x] =
+          (part[0][threadIdx.x][0] + part[0][threadIdx.x][1]) + (part[0][threadIdx.x][2] + part[0][threadIdx.x][3]);
+  }
+}
+
+// ---- 3x3 filter repacking for the implicit-GEMM convolution -----------------------------------------------------------
+// w bf16 [Cout][Cin][3][3] (the reference's layout, arena-backed shadow of the fp32 master) ->
+//   FWD: wk[co][tap][c]        = w[co][c][tap]         (tap = ky*3 + kx; a K-step of the GEMM = 32 channels of one tap)
+//   BWD: wr[c][tap][co]        = w[co][c][8 - tap]     (rotated by 180 degrees, channels swapped: the dX convolution)
+// One lane owns 8 channels of one filter: 72 consecutive bf16 (144 B, nine 16-byte loads), transposed in registers.
+template <bool BWD>
+__global__ __launch_bounds__(256) void conv3x3_pack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out,
+                                                           int Cout, int Cin) {
+  const int c8n = Cin >> 3;
+  const long total = (long)Cout * c8n;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    // FWD: adjacent lanes take adjacent channel blocks (16-byte stores, contiguous over c);
+    // BWD: adjacent lanes take adjacent filters (2-byte stores, contiguous over co)
+    const int co = BWD ? (int)(idx % Cout) : (int)(idx / c8n);
+    const int c0 = (BWD ? (int)(idx / Cout) : (int)(idx % c8n)) << 3;
+    union { u32x4 v[9]; bf16_t e[72]; } u;
+    const u32x4* src = reinterpret_cast<const u32x4*>(w + ((long)co * Cin + c0) * 9);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) u.v[i] = src[i];
+    if (!BWD) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        union { u32x4 v; bf16_t e[8]; } o;
+#pragma unroll
+        for (int cl = 0; cl < 8; ++cl) o.e[cl] = u.e[cl * 9 + tap];
+        *reinterpret_cast<u32x4*>(out + ((long)co * 9 + tap) * Cin + c0) = o.v;
+      }
+    } else {
+#pragma unroll
+      for (int cl = 0; cl < 8; ++cl)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+          out[((long)(c0 + cl) * 9 + tap) * Cout + co] = u.e[cl * 9 + (8 - tap)];
     }
   }
 }
@@ -795,7 +853,8 @@ extern "C" int cfhip_groupnorm_bwd(const void* dy, const void* x, int x_is_f32, 
   CFHIP_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma_part && dbeta_part, "groupnorm_bwd: null pointer");
   CFHIP_REQUIRE(B > 0 && C > 0 && G > 0 && inner > 0 && C % G == 0, "groupnorm_bwd: bad geometry");
   CFHIP_REQUIRE((add == nullptr) == (dadd == nullptr) || dadd == nullptr, "groupnorm_bwd: dadd without add");
-  const bool vec = inner % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0;
+  const bool vec = inner % 8 == 0 && C / G <= GN_MAX_CG && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 &&
+                   ((uintptr_t)dx & 15) == 0;
   if (vec && x_is_f32)
     hipLaunchKernelGGL((gn_bwd_vec_kernel<true>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, add,
                        gamma, beta, mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu);
@@ -859,5 +918,19 @@ extern "C" int cfhip_timestep_embedding(const int64_t* t, float* out, int B, int
   hipLaunchKernelGGL(timestep_embedding_kernel, dim3(grid_for((long)B * dim, 256)), dim3(256), 0, (hipStream_t)stream, t,
                      out, B, dim, max_period);
   CFHIP_CHECK_LAUNCH("timestep_embedding");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_conv3x3_pack_filters(const void* w, void* out, int Cout, int Cin, int rotate, void* stream) {
+  CFHIP_REQUIRE(w && out && Cout > 0 && Cin > 0 && Cin % 8 == 0, "conv3x3_pack_filters: bad arguments (Cin %% 8 == 0)");
+  CFHIP_REQUIRE(((uintptr_t)w & 15) == 0 && ((uintptr_t)out & 15) == 0, "conv3x3_pack_filters: 16-byte alignment");
+  const long total = (long)Cout * (Cin / 8);
+  if (rotate)
+    hipLaunchKernelGGL((conv3x3_pack_kernel<true>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)w, (bf16_t*)out, Cout, Cin);
+  else
+    hipLaunchKernelGGL((conv3x3_pack_kernel<false>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)w, (bf16_t*)out, Cout, Cin);
+  CFHIP_CHECK_LAUNCH("conv3x3_pack_filters");
   return CFHIP_OK;
 }

@@ -713,6 +713,42 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, void* C, c
   }
 }
 
+// Second pass of the implicit 3x3 weight gradient: slabs [z][Cout][tap*Cin + c] (the GEMM's n order) -> the reference's
+// filter layout dW[co][c][tap], (+)=.  A lane owns 4 channels of one filter: nine 16-byte loads per slab (coalesced over
+// c), 36 consecutive floats out (nine 16-byte stores).  Fixed summation order: deterministic.
+__global__ void splitk_reduce_filter_kernel(const float* __restrict__ slabs, float* __restrict__ dW, int Cout, int Cin,
+                                            int splits, int accumulate, const float* __restrict__ bgrad_slabs,
+                                            float* bgrad, int bgrad_acc) {
+  const long c4n = Cin >> 2;
+  const long total = (long)Cout * c4n;
+  const long N = 9L * Cin;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    if (bgrad != nullptr && idx < Cout) {
+      float b = 0.f;
+      for (int z = 0; z < splits; ++z) b += bgrad_slabs[(long)z * Cout + idx];
+      bgrad[idx] = bgrad_acc ? bgrad[idx] + b : b;
+    }
+    const int co = (int)(idx / c4n);
+    const int c = (int)(idx - (long)co * c4n) * 4;
+    float o[36];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int z = 0; z < splits; ++z)
+        v += *reinterpret_cast<const f32x4*>(slabs + ((long)z * Cout + co) * N + (long)tap * Cin + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e * 9 + tap] = v[e];
+    }
+    float* dst = dW + ((long)co * Cin + c) * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      f32x4 v = {o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
+      if (accumulate) v += *reinterpret_cast<const f32x4*>(dst + 4 * i);
+      *reinterpret_cast<f32x4*>(dst + 4 * i) = v;
+    }
+  }
+}
+
 // Shape-agnostic kernel for operands the MFMA path cannot take (K or leading dims not multiples
 // of 8, N not a multiple of 4, unaligned bases): one output element per thread, fp32 FMA chain.
 // Used by tiny tabular layers (FCNN 10 -> 3 etc.); never on the ViT path.
@@ -1082,53 +1118,48 @@ extern "C" int cfhip_conv3x3_nhwc_bf16(const void* X, const void* Wk, const floa
 }
 
 extern "C" size_t cfhip_conv3x3_wgrad_workspace(int Cin, int Cout, int split_k) {
-  return split_k > 1 ? (size_t)split_k * Cout * (9 * (size_t)Cin + 1) * sizeof(float) : 0;
+  if (split_k < 1) split_k = 1;
+  return (size_t)split_k * Cout * (9 * (size_t)Cin + 1) * sizeof(float);
 }
 
-extern "C" int cfhip_conv3x3_wgrad_nhwc_bf16(const void* dY, const void* X, float* dWk, float* bias_grad,
+extern "C" int cfhip_conv3x3_wgrad_nhwc_bf16(const void* dY, const void* X, float* dW, int accumulate, float* bias_grad,
                                              int bias_grad_accumulate, int B, int H, int W, int Cin, int Cout,
                                              int split_k, void* workspace, size_t workspace_bytes, void* stream) {
-  CFHIP_REQUIRE(dY && X && dWk, "conv3x3_wgrad: null operand");
+  CFHIP_REQUIRE(dY && X && dW, "conv3x3_wgrad: null operand");
   CFHIP_REQUIRE(B > 0 && H >= 2 && W >= 2 && H < 65536 && W < 65536, "conv3x3_wgrad: bad image shape %d x %d x %d", B, H, W);
   CFHIP_REQUIRE(Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 8 == 0, "conv3x3_wgrad: Cin = %d and Cout = %d must be multiples of 8", Cin, Cout);
   const long pixels = (long)B * H * W;
   CFHIP_REQUIRE(pixels * (W > H ? W : H) < (1L << 32) && 9L * Cin < (1L << 20),
                 "conv3x3_wgrad: problem too large (%ld pixels of %d x %d, Cin %d)", pixels, H, W, Cin);
-  CFHIP_REQUIRE(aligned16(dY) && aligned16(X) && aligned16(dWk), "conv3x3_wgrad: operands must be 16-byte aligned");
+  CFHIP_REQUIRE(aligned16(dY) && aligned16(X) && aligned16(dW), "conv3x3_wgrad: operands must be 16-byte aligned");
   if (split_k < 1) split_k = 1;
   GemmParams p;
   p.A = reinterpret_cast<const bf16_t*>(dY);
   p.B = reinterpret_cast<const bf16_t*>(X);
-  p.C = dWk;
+  p.C = nullptr;  // partial sums always go through the slabs; the second pass writes the filter layout
   p.bias = nullptr; p.aux_in = nullptr; p.aux_out = nullptr;
   p.M = Cout; p.N = 9 * Cin; p.K = (int)pixels;
   p.lda = Cout; p.ldb = Cin; p.ldc = 9L * Cin;
   p.epilogue = CFHIP_EPI_NONE; p.out_f32 = 1; p.accumulate = 0;
-  p.slabs = nullptr;
   p.bgrad = bias_grad; p.bgrad_acc = bias_grad_accumulate; p.bgrad_slabs = nullptr;
   p.quick = 0; p.ablate = 0;
   p.conv_h = H; p.conv_w = W; p.conv_c = Cin; p.conv_kpt = 0; p.conv_inv_kpt = 0.f;
   p.conv_magic_w = (unsigned)((1ULL << 32) / (unsigned)W + 1ULL);
   p.conv_magic_h = (unsigned)((1ULL << 32) / (unsigned)H + 1ULL);
-  p.k_chunk = ((p.K + BK_MAX - 1) / BK_MAX) * BK_MAX;
-  if (split_k > 1) {
-    const int steps = (p.K + BK_MAX - 1) / BK_MAX;
-    if (split_k > steps) split_k = steps;
-    const int per = (steps + split_k - 1) / split_k;
-    split_k = (steps + per - 1) / per;
-    p.k_chunk = per * BK_MAX;
-  }
+  const int steps = (p.K + BK_MAX - 1) / BK_MAX;
+  if (split_k > steps) split_k = steps;
+  const int per = (steps + split_k - 1) / split_k;
+  split_k = (steps + per - 1) / per;
+  p.k_chunk = per * BK_MAX;
   CFHIP_REQUIRE(((long)p.k_chunk + 2L * W + 2) * Cin * 2 < 0x7fffffffL && (long)p.k_chunk * Cout * 2 < 0x7fffffffL,
                 "conv3x3_wgrad: a K slice of %d pixels exceeds the 2 GiB descriptor range (raise split_k)", p.k_chunk);
-  if (split_k > 1) {
-    const size_t need = (size_t)split_k * p.M * p.N * sizeof(float) + (bias_grad ? (size_t)split_k * p.M * sizeof(float) : 0);
-    if (workspace == nullptr || workspace_bytes < need) {
-      cfhip_set_error("conv3x3_wgrad: split_k=%d needs %zu workspace bytes, got %zu", split_k, need, workspace_bytes);
-      return CFHIP_ERR_WORKSPACE;
-    }
-    p.slabs = reinterpret_cast<float*>(workspace);
-    if (bias_grad) p.bgrad_slabs = p.slabs + (size_t)split_k * p.M * p.N;
+  const size_t need = (size_t)split_k * p.M * p.N * sizeof(float) + (bias_grad ? (size_t)split_k * p.M * sizeof(float) : 0);
+  if (workspace == nullptr || workspace_bytes < need) {
+    cfhip_set_error("conv3x3_wgrad: split_k=%d needs %zu workspace bytes, got %zu", split_k, need, workspace_bytes);
+    return CFHIP_ERR_WORKSPACE;
   }
+  p.slabs = reinterpret_cast<float*>(workspace);
+  if (bias_grad) p.bgrad_slabs = p.slabs + (size_t)split_k * p.M * p.N;
   p.tiles_m = (p.M + CfgC::BM - 1) / CfgC::BM;
   p.tiles_n = (p.N + CfgC::BN - 1) / CfgC::BN;
   p.splits = split_k;
@@ -1136,13 +1167,11 @@ extern "C" int cfhip_conv3x3_wgrad_nhwc_bf16(const void* dY, const void* X, floa
   const int rc = launch_cfg<true, true, CFHIP_EPI_NONE, CfgC, false, 2>(p, dim3(p.tiles_m * p.tiles_n * split_k), s);
   if (rc != CFHIP_OK) return rc;
   CFHIP_CHECK_LAUNCH("conv3x3_wgrad");
-  if (split_k > 1) {
-    const long total = (long)p.M * (p.N / 4);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slabs, (void*)dWk, (const float*)nullptr,
-                       p.M, p.N, (long)p.ldc, split_k, 1, 0, p.bgrad_slabs, p.bgrad, p.bgrad_acc);
-    CFHIP_CHECK_LAUNCH("splitk_reduce");
-  }
+  const long total = (long)Cout * (Cin / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_filter_kernel, dim3(blocks), dim3(256), 0, s, p.slabs, dW, Cout, Cin, split_k, accumulate,
+                     p.bgrad_slabs, p.bgrad, p.bgrad_acc);
+  CFHIP_CHECK_LAUNCH("splitk_reduce_filter");
   return CFHIP_OK;
 }

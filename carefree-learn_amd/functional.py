@@ -602,8 +602,8 @@ class Conv2dFn(Function):
         ctx.implicit = _implicit_ok(cin, cout, kh, kw, stride, pad, dil, h, w)
         if ctx.implicit:
             x_rows = ops.transpose_batched(x.view(b, cin, h * w)).view(b * h * w, cin)  # NHWC bf16
-            w16 = shadow_bf16(weight)
-            wk = w16.permute(0, 2, 3, 1).reshape(cout, 9 * cin)  # k = (ky, kx, c): a K-step = 32 channels of a tap
+            w16 = shadow_bf16(weight).view(cout, cin, 3, 3)
+            wk = ops.conv3x3_pack_filters(w16, False)  # k = (ky, kx, c): a K-step = 32 channels of a tap
             y_rows = ops.conv3x3_nhwc(x_rows, wk, bias_f, b, h, w)
             ctx.save_for_backward(x_rows, w16)  # the NHWC bf16 copy serves the weight gradient; x itself is not kept
             ctx.xshape = (b, cin, h, w)
@@ -654,12 +654,7 @@ class Conv2dFn(Function):
             split = ops.pick_split_k(cout, 9 * cin, b * h * w)
 
             def dw_implicit(out: Tensor, acc: bool) -> None:
-                tmp = ops.conv3x3_wgrad_nhwc(dy_rows, x, b, h, w, split)  # [Cout, (ky, kx, c)] f32
-                tmp = tmp.view(cout, 3, 3, cin).permute(0, 3, 1, 2)
-                if acc:
-                    out.view(cout, cin, 3, 3).add_(tmp)
-                else:
-                    out.view(cout, cin, 3, 3).copy_(tmp)
+                ops.conv3x3_wgrad_nhwc(dy_rows, x, b, h, w, split, out=out.view(cout, cin, 3, 3), accumulate=acc)
 
             if _is_direct(weight):
                 write_param_grad(weight, dw_implicit)
@@ -708,7 +703,7 @@ class Conv2dFn(Function):
         if ctx.needs_input_grad[0]:
             if ctx.implicit and cout % 32 == 0:
                 # dX = conv3x3(dY, filters rotated by 180 degrees, channels swapped): k = (ky, kx, co)
-                wr = wp.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout)
+                wr = ops.conv3x3_pack_filters(wp, True)
                 dx_rows = ops.conv3x3_nhwc(dy_rows, wr, None, b, h, w)
                 dx = ops.transpose_batched(dx_rows.view(b, h * w, cin)).view(b, cin, h, w)
             else:

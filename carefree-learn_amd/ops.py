@@ -813,9 +813,10 @@ def conv3x3_wgrad_ok(b: int, h: int, w: int) -> bool:
 
 
 def conv3x3_wgrad_nhwc(dy_rows: Tensor, x_rows: Tensor, b: int, h: int, w: int, split_k: int = 1,
-                       bias_grad: Optional[Tensor] = None, bias_grad_accumulate: bool = False) -> Tensor:
-    """dy_rows bf16 [B*H*W, Cout], x_rows bf16 [B*H*W, Cin] (NHWC) -> f32 [Cout, 9*Cin] with k = (ky*3 + kx)*Cin + c
-    (tap-major: `.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)` is the reference's [Cout, Cin, 3, 3])."""
+                       out: Optional[Tensor] = None, accumulate: bool = False, bias_grad: Optional[Tensor] = None,
+                       bias_grad_accumulate: bool = False) -> Tensor:
+    """dy_rows bf16 [B*H*W, Cout], x_rows bf16 [B*H*W, Cin] (NHWC) -> f32 [Cout, Cin, 3, 3] (the reference's filter
+    layout), written or added to `out`."""
     _need(dy_rows, bf16, "dy_rows")
     _need(x_rows, bf16, "x_rows")
     m, cout = dy_rows.shape
@@ -824,13 +825,31 @@ def conv3x3_wgrad_nhwc(dy_rows: Tensor, x_rows: Tensor, b: int, h: int, w: int, 
         raise ValueError("cfhip conv3x3_wgrad_nhwc: dense NHWC rows [B*H*W, C] expected for both operands")
     if bias_grad is not None:
         _need(bias_grad, f32, "bias_grad")
-    out = torch.empty((cout, 9 * cin), dtype=f32, device=dy_rows.device)
+    if out is None:
+        out, accumulate = torch.empty((cout, cin, 3, 3), dtype=f32, device=dy_rows.device), False
+    else:
+        _need(out, f32, "out")
+        if out.numel() != cout * cin * 9 or not out.is_contiguous():
+            raise ValueError("cfhip conv3x3_wgrad_nhwc: `out` must be a contiguous f32 [Cout, Cin, 3, 3]")
     lib = _lib.load()
     nbytes = lib.cfhip_conv3x3_wgrad_workspace(cin, cout, split_k)
-    ws = torch.empty((max(nbytes, 4) // 4,), dtype=f32, device=dy_rows.device)
-    _lib.check(lib.cfhip_conv3x3_wgrad_nhwc_bf16(dy_rows.data_ptr(), x_rows.data_ptr(), out.data_ptr(), _p(bias_grad),
-                                                 int(bias_grad_accumulate), b, h, w, cin, cout, split_k, ws.data_ptr(),
-                                                 nbytes, _stream()), "conv3x3_wgrad_nhwc")
+    ws = torch.empty((nbytes // 4,), dtype=f32, device=dy_rows.device)
+    _lib.check(lib.cfhip_conv3x3_wgrad_nhwc_bf16(dy_rows.data_ptr(), x_rows.data_ptr(), out.data_ptr(), int(accumulate),
+                                                 _p(bias_grad), int(bias_grad_accumulate), b, h, w, cin, cout, split_k,
+                                                 ws.data_ptr(), nbytes, _stream()), "conv3x3_wgrad_nhwc")
+    return out
+
+
+def conv3x3_pack_filters(w16: Tensor, rotate: bool) -> Tensor:
+    """w16 bf16 [Cout, Cin, 3, 3] -> [Cout, 9*Cin] (k = (ky, kx, c)) or, rotate=True, [Cin, 9*Cout] with the taps rotated
+    by 180 degrees (k = (ky, kx, co)): the filter matrices of conv3x3_nhwc for the forward / the input gradient."""
+    _need(w16, bf16, "w16")
+    if w16.dim() != 4 or tuple(w16.shape[2:]) != (3, 3) or not w16.is_contiguous():
+        raise ValueError("cfhip conv3x3_pack_filters: contiguous bf16 [Cout, Cin, 3, 3] expected")
+    cout, cin = w16.shape[0], w16.shape[1]
+    out = torch.empty((cin, 9 * cout) if rotate else (cout, 9 * cin), dtype=bf16, device=w16.device)
+    _lib.check(_lib.load().cfhip_conv3x3_pack_filters(w16.data_ptr(), out.data_ptr(), cout, cin, int(rotate), _stream()),
+               "conv3x3_pack_filters")
     return out
 
 

@@ -241,15 +241,20 @@ int cfhip_ema_update(float* ema, const float* p, int64_t n, float one_minus_deca
 size_t cfhip_conv3x3_workspace(int B, int H, int W, int Cin, int Cout);
 int cfhip_conv3x3_nhwc_bf16(const void* X, const void* Wk, const float* bias, void* Y, int B, int H, int W, int Cin,
                             int Cout, void* workspace, size_t workspace_bytes, void* stream);
-/* Weight gradient of the same convolution without an im2row matrix: dWk[co][(ky*3+kx)*Cin + c] = sum_p dY[p][co] *
- * X[p + (ky-1)*W + (kx-1)][c] (taps outside the image contribute zero), f32 [Cout][9*Cin], overwritten (the caller
- * permutes it into the reference's [Cout][Cin][3][3] layout while accumulating).  dY [B*H*W][Cout], X [B*H*W][Cin] bf16
- * NHWC; Cin % 8 == 0, Cout % 8 == 0, H, W >= 2, B*H*W*max(H, W) < 2^32.  bias_grad (f32 [Cout] or NULL) (+)= colsum(dY).
- * split_k > 1 needs cfhip_conv3x3_wgrad_workspace() bytes; partial sums are reduced in a fixed order (deterministic). */
+/* Weight gradient of the same convolution without an im2row matrix: dW[co][c][ky][kx] (+)= sum_p dY[p][co] *
+ * X[p + (ky-1)*W + (kx-1)][c] (taps outside the image contribute zero), f32 in the reference's [Cout][Cin][3][3] layout
+ * (`accumulate` != 0: added to dW).  dY [B*H*W][Cout], X [B*H*W][Cin] bf16 NHWC; Cin % 8 == 0, Cout % 8 == 0, H, W >= 2,
+ * B*H*W*max(H, W) < 2^32.  bias_grad (f32 [Cout] or NULL) (+)= colsum(dY).  The GEMM writes fp32 partial sums per K slice
+ * ([split_k][Cout][9*Cin], tap-major) into the workspace (cfhip_conv3x3_wgrad_workspace() bytes, needed for every
+ * split_k >= 1); a second pass adds them in a fixed order and writes the filter layout: deterministic. */
 size_t cfhip_conv3x3_wgrad_workspace(int Cin, int Cout, int split_k);
-int cfhip_conv3x3_wgrad_nhwc_bf16(const void* dY, const void* X, float* dWk, float* bias_grad, int bias_grad_accumulate,
-                                  int B, int H, int W, int Cin, int Cout, int split_k, void* workspace,
-                                  size_t workspace_bytes, void* stream);
+int cfhip_conv3x3_wgrad_nhwc_bf16(const void* dY, const void* X, float* dW, int accumulate, float* bias_grad,
+                                  int bias_grad_accumulate, int B, int H, int W, int Cin, int Cout, int split_k,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+/* Filter repacking for the two calls above, w bf16 [Cout][Cin][3][3] (Cin % 8 == 0):
+ *   rotate == 0: out[co][(ky*3+kx)*Cin + c]        = w[co][c][ky][kx]       ([Cout][9*Cin], the forward's Wk)
+ *   rotate != 0: out[c][(ky*3+kx)*Cout + co]       = w[co][c][2-ky][2-kx]   ([Cin][9*Cout], the input gradient's Wk') */
+int cfhip_conv3x3_pack_filters(const void* w, void* out, int Cout, int Cin, int rotate, void* stream);
 /* One idle wavefront for `microseconds` (1..100000) on `stream`.  Host-side stream self-check only (two streams
  * that share a ROCclr hardware queue run it back to back; the side streams of the backward pass and the RCCL
  * stream must not share the compute stream's queue -- reference counterpart: none, torch DDP owns its streams). */

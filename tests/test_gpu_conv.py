@@ -278,3 +278,14 @@ def test_implicit_conv3x3_matches_fp32_reference_and_im2row_route(shape):
     assert torch.count_nonzero(yi[0, :, 2:, :]) == 0 and torch.count_nonzero(yi[0, :, :, 2:]) == 0
     ref = torch.nn.functional.conv2d(xi, wt, None, stride=1, padding=1)
     assert_close(yi, ref, 4e-3, "corner impulse")
+
+
+def test_conv3x3_filter_packing_bit_exact():
+    """cfhip_conv3x3_pack_filters: pure data movement, compared bit for bit with the permutes it replaces."""
+    g = torch.Generator().manual_seed(5)
+    for cout, cin in ((40, 32), (320, 640), (8, 96)):
+        w16 = torch.randn(cout, cin, 3, 3, generator=g).to(DEV).to(torch.bfloat16)
+        wk = ops.conv3x3_pack_filters(w16, False)
+        wr = ops.conv3x3_pack_filters(w16, True)
+        assert torch.equal(wk, w16.permute(0, 2, 3, 1).reshape(cout, 9 * cin))
+        assert torch.equal(wr, w16.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout))
