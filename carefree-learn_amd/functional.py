@@ -223,6 +223,13 @@ def _as_bf16_2d(x: Tensor) -> Tensor:
 ACT_NONE, ACT_GELU, ACT_QGELU = 0, 1, 2
 
 
+def _all_direct(weight: Tensor, bias: Optional[Tensor]) -> bool:
+    """Every gradient this op owes is written straight into an arena-owned `.grad` (nothing is returned to autograd)."""
+    if weight.requires_grad and not _is_direct(weight):
+        return False
+    return bias is None or not bias.requires_grad or _is_direct(bias)
+
+
 def _linear_param_grads(dy2: Tensor, x2: Tensor, weight: Tensor, bias: Optional[Tensor],
                         weight_direct: bool, bias_direct: bool) -> Tuple[Optional[Tensor], Optional[Tensor]]:
     """dW = dy^T x, db = colsum(dy): direct-to-.grad when possible, returned otherwise."""
@@ -296,10 +303,17 @@ class LinearFn(Function):
         # (autograd casts d_res to the residual's dtype; the gradient stream itself stays bf16)
         if pre is not None:
             dy2 = ops.gelu_bwd(dy2, pre) if ctx.act == ACT_GELU else ops.quick_gelu_bwd(dy2, pre)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = ops.gemm(dy2, w16, b_trans=True).view(ctx.x_shape)  # bf16; autograd casts if needed
-        gw, gb = _linear_param_grads(dy2, x2, weight, bias, _is_direct(weight), _is_direct(bias))
+        gw = gb = None
+        if _all_direct(weight, bias):
+            # gradients that land straight in `.grad` do not go back through autograd: they run on the side stream,
+            # beside the dX GEMM below (issued first so that the side stream does not wait for dX)
+            SideStream.run(lambda: _linear_param_grads(dy2, x2, weight, bias, True, True), (dy2, x2))
+            dx = ops.gemm(dy2, w16, b_trans=True).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        else:
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = ops.gemm(dy2, w16, b_trans=True).view(ctx.x_shape)  # bf16; autograd casts if needed
+            gw, gb = _linear_param_grads(dy2, x2, weight, bias, _is_direct(weight), _is_direct(bias))
         return dx, gw, gb, None, d_res, None
 
 
@@ -646,59 +660,69 @@ class Conv2dFn(Function):
             dyp[:, :cout] = dy.reshape(b, cout, ho * wo)
             dy = dyp
         dy_rows = ops.transpose_batched(dy.contiguous().view(b, cp, ho * wo)).view(b * ho * wo, cp)
-        gw = gb = None
         wgrad_implicit = ctx.implicit and ops.conv3x3_wgrad_ok(b, h, w)
-        if ctx.implicit and not wgrad_implicit and weight.requires_grad:
-            x = ops.transpose_batched(x.view(b, h * w, cin)).view(b, cin, h, w)  # back to NCHW for the im2row route
-        if weight.requires_grad and wgrad_implicit:
-            split = ops.pick_split_k(cout, 9 * cin, b * h * w)
 
-            def dw_implicit(out: Tensor, acc: bool) -> None:
-                ops.conv3x3_wgrad_nhwc(dy_rows, x, b, h, w, split, out=out.view(cout, cin, 3, 3), accumulate=acc)
+        def param_grads(x: Tensor = x) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+            gw = gb = None
+            if ctx.implicit and not wgrad_implicit and weight.requires_grad:
+                x = ops.transpose_batched(x.view(b, h * w, cin)).view(b, cin, h, w)  # back to NCHW for the im2row route
+            if weight.requires_grad and wgrad_implicit:
+                split = ops.pick_split_k(cout, 9 * cin, b * h * w)
 
-            if _is_direct(weight):
-                write_param_grad(weight, dw_implicit)
-            else:
-                gw = torch.empty(weight.shape, dtype=f32, device=dy.device)
-                dw_implicit(gw, False)
-        elif weight.requires_grad:
-            rows = ops.conv_im2row(x, kh, kw, stride, pad, dil)  # recomputed: k^2 times the input, not kept
-            m = rows.shape[0]
-            kp = rows.shape[1]
-            split = ops.pick_split_k(cp, kp, m)
+                def dw_implicit(out: Tensor, acc: bool) -> None:
+                    ops.conv3x3_wgrad_nhwc(dy_rows, x, b, h, w, split, out=out.view(cout, cin, 3, 3), accumulate=acc)
 
-            def dw_into(out: Tensor, acc: bool) -> None:
-                if kp == k and cp == cout:
-                    ops.gemm(dy_rows, rows, a_trans=True, b_trans=True, out=out.view(cout, k), accumulate=acc,
-                             split_k=split)
+                if _is_direct(weight):
+                    write_param_grad(weight, dw_implicit)
                 else:
-                    tmp = ops.gemm(dy_rows, rows, a_trans=True, b_trans=True, out_dtype=f32, split_k=split)
-                    if acc:
-                        out.view(cout, k).add_(tmp[:cout, :k])
-                    else:
-                        out.view(cout, k).copy_(tmp[:cout, :k])
+                    gw = torch.empty(weight.shape, dtype=f32, device=dy.device)
+                    dw_implicit(gw, False)
+            elif weight.requires_grad:
+                rows = ops.conv_im2row(x, kh, kw, stride, pad, dil)  # recomputed: k^2 times the input, not kept
+                m = rows.shape[0]
+                kp = rows.shape[1]
+                split = ops.pick_split_k(cp, kp, m)
 
-            if _is_direct(weight):
-                write_param_grad(weight, dw_into)
-            else:
-                gw = torch.empty(weight.shape, dtype=f32, device=dy.device)
-                dw_into(gw, False)
-        if bias is not None and bias.requires_grad:
-            def db_into(out: Tensor, acc: bool) -> None:
-                if cp == cout:
-                    ops.colsum(dy_rows, out=out.view(-1), accumulate=acc)
+                def dw_into(out: Tensor, acc: bool) -> None:
+                    if kp == k and cp == cout:
+                        ops.gemm(dy_rows, rows, a_trans=True, b_trans=True, out=out.view(cout, k), accumulate=acc,
+                                 split_k=split)
+                    else:
+                        tmp = ops.gemm(dy_rows, rows, a_trans=True, b_trans=True, out_dtype=f32, split_k=split)
+                        if acc:
+                            out.view(cout, k).add_(tmp[:cout, :k])
+                        else:
+                            out.view(cout, k).copy_(tmp[:cout, :k])
+
+                if _is_direct(weight):
+                    write_param_grad(weight, dw_into)
                 else:
-                    tmp = ops.colsum(dy_rows)[:cout]
-                    if acc:
-                        out.view(-1).add_(tmp)
+                    gw = torch.empty(weight.shape, dtype=f32, device=dy.device)
+                    dw_into(gw, False)
+            if bias is not None and bias.requires_grad:
+                def db_into(out: Tensor, acc: bool) -> None:
+                    if cp == cout:
+                        ops.colsum(dy_rows, out=out.view(-1), accumulate=acc)
                     else:
-                        out.view(-1).copy_(tmp)
+                        tmp = ops.colsum(dy_rows)[:cout]
+                        if acc:
+                            out.view(-1).add_(tmp)
+                        else:
+                            out.view(-1).copy_(tmp)
 
-            if _is_direct(bias):
-                write_param_grad(bias, db_into)
-            else:
-                gb = torch.empty(bias.shape, dtype=f32, device=dy.device)
-                db_into(gb, False)
+                if _is_direct(bias):
+                    write_param_grad(bias, db_into)
+                else:
+                    gb = torch.empty(bias.shape, dtype=f32, device=dy.device)
+                    db_into(gb, False)
+            return gw, gb
+
+        if _all_direct(weight, bias):
+            # nothing goes back through autograd: the weight / bias gradients run on the side stream beside dX
+            SideStream.run(param_grads, (dy_rows, x))
+            gw = gb = None
+        else:
+            gw, gb = param_grads()
         dx = None
         if ctx.needs_input_grad[0]:
             if ctx.implicit and cout % 32 == 0:

@@ -23,6 +23,7 @@ from . import ops
 
 f32 = torch.float32
 bf16 = torch.bfloat16
+_HYPER_RING = 8  # the host may run this many optimizer steps ahead of the GPU
 _ALIGN = 8  # elements: keeps every bf16 shadow view 16-byte aligned (MFMA GEMM operand rule)
 
 
@@ -117,7 +118,14 @@ class FusedAdam:
         a = self.arena
         self.exp_avg = torch.zeros_like(a.flat_p)
         self.exp_avg_sq = torch.zeros_like(a.flat_p)
-        self._hyper_host = torch.zeros(8, dtype=f32, pin_memory=a.flat_p.is_cuda)
+        # The step-dependent scalars travel as a 32-byte record: pinned host slot -> async copy -> device record the
+        # kernel reads.  The host runs ahead of the GPU (nothing in a training loop synchronises), so ONE host buffer
+        # would be overwritten with step t+1's values before the queued copy of step t has executed (observed: the
+        # loss trajectory of the UNet bench depended on launch timing from the 6th step on).  Hence a ring of slots,
+        # each guarded by the event of the copy that last read it.
+        self._hyper_ring = [torch.zeros(8, dtype=f32, pin_memory=a.flat_p.is_cuda) for _ in range(_HYPER_RING)]
+        self._hyper_events: List[Any] = [None] * _HYPER_RING
+        self._hyper_host = self._hyper_ring[0]
         self._hyper_dev = torch.zeros(8, dtype=f32, device=a.flat_p.device)
 
     def zero_grad(self, set_to_none: bool = False) -> None:
@@ -127,7 +135,11 @@ class FusedAdam:
         g = self.param_groups[0]
         b1, b2 = g["betas"]
         t = self.step_count
-        h = self._hyper_host
+        slot = t % _HYPER_RING
+        ev = self._hyper_events[slot]
+        if ev is not None:
+            ev.synchronize()  # the copy that read this slot _HYPER_RING steps ago has executed
+        h = self._hyper_host = self._hyper_ring[slot]
         h[0], h[1], h[2], h[3], h[4] = g["lr"], b1, b2, g["eps"], g["weight_decay"]
         h[5] = 1.0 - b1 ** t
         h[6] = 1.0 / math.sqrt(1.0 - b2 ** t)
@@ -139,6 +151,10 @@ class FusedAdam:
         self.step_count += 1
         self._fill_hyper()
         self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+        if self._hyper_dev.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._hyper_events[self.step_count % _HYPER_RING] = ev
 
     def launch_step(self) -> None:
         a = self.arena

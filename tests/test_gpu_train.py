@@ -153,3 +153,29 @@ def test_helper_streams_have_their_own_hardware_queue():
         assert HF._overlap([cur, s])
     assert HF._overlap([cur] + lanes)
     assert not HF._overlap([cur, cur])  # the check itself: one stream serialises
+
+
+@pytest.mark.gpu
+def test_optimizer_scalars_survive_a_host_that_runs_ahead(golden):
+    """The Adam step reads its step-dependent scalars from a device record filled by an async copy out of pinned host
+    memory.  With the GPU kept busy (an idle wavefront for 100 ms) the host enqueues many steps before the first copy
+    executes: every step must still see ITS OWN bias corrections (a single host buffer would be overwritten)."""
+    from cflearn_amd import ops
+
+    def run(stall):
+        g, m = _small(golden)
+        ts = TrainStep(m, lr=1e-3, weight_decay=0.01)
+        x, y = g["img"].to(DEV), g["labels"].view(-1).to(DEV)
+        torch.cuda.synchronize()
+        if stall:
+            ops.spin(100000)
+        for _ in range(6):
+            ts.step(x, y)
+            if not stall:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return ts.arena.flat_p.clone()
+
+    a, b = run(False), run(True)
+    # (LayerNorm parameter gradients use LDS float atomics: equal up to the last bits, not bitwise)
+    assert_close(b, a, 2e-6, "parameters after 6 steps, stalled GPU vs step-by-step")

@@ -26,7 +26,25 @@ def main() -> None:
     ap.add_argument("--start-channels", type=int, default=320)
     ap.add_argument("--in-channels", type=int, default=3)
     ap.add_argument("--context-dim", type=int, default=0, help="> 0: cross-attention on a [B, 77, dim] context")
+    ap.add_argument("--no-side-stream", action="store_true", help="parameter gradients on the compute stream (A/B, race check)")
+    ap.add_argument("--poison", action="store_true",
+                    help="debug: every torch.empty() buffer (outputs, workspaces) is filled with NaN first, so a kernel "
+                         "that reads memory it never wrote shows up as a NaN loss")
     args = ap.parse_args()
+    if args.poison:
+        _empty = torch.empty
+
+        def _poisoned(*a, **k):
+            t = _empty(*a, **k)
+            if t.is_cuda and t.numel():
+                t.fill_(float("nan")) if t.is_floating_point() else t.fill_(0x7F)
+            return t
+
+        torch.empty = _poisoned
+    if args.no_side_stream:
+        from cflearn_amd.functional import SideStream
+
+        SideStream.enabled = False
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     cfg = dict(in_channels=args.in_channels, out_channels=args.in_channels, start_channels=args.start_channels,
@@ -49,14 +67,18 @@ def main() -> None:
             print(f"[unet_bench] first step done, loss {first:.4f}", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    losses = []
     for _ in range(args.steps):
         loss = ts.step(x, ctx, timesteps=t, noise=eps)
+        losses.append(loss)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     last = loss.item() / args.batch
     print(json.dumps(dict(workload=f"DDPM UNet (zoo diffusion/ddpm) {args.img}^2, batch {args.batch}", params=n_params,
                           ms_per_step=round(dt * 1e3, 2), samples_per_s=round(args.batch / dt, 3),
                           first_loss=round(first, 5) if first is not None else None, last_loss=round(last, 5),
+                          losses=[round(l.item() / args.batch, 7) for l in losses],
+                          grad_checksum=float(ts.arena.flat_g.double().abs().sum().item()),
                           peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 2), steps=args.steps,
                           warmup=args.warmup, dtype="bf16", data="synthetic")))
 
