@@ -97,6 +97,8 @@ SIGNATURES = {
     "cfhip_timestep_embedding": (c_int, [_P, _P, c_int, c_int, c_float, _P]),
     "cfhip_ema_update": (c_int, [_P, _P, c_int64, c_float, c_float, _P]),
     "cfhip_spin": (c_int, [c_int, _P]),
+    "cfhip_sgemm_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, c_int64, c_int, c_int, _P, c_float, _P]),
+    "cfhip_dot_f32": (c_int, [_P, _P, _P, c_int64, _P]),
     "cfhip_conv3x3_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "cfhip_conv3x3_nhwc_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "cfhip_conv3x3_wgrad_workspace": (c_size_t, [c_int, c_int, c_int]),

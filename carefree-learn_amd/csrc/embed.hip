@@ -75,6 +75,49 @@ __global__ void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __r
   for (int d = lane; d < D; d += 64) dx[n * D + d] = (dy[n * D + d] - y[n * D + d] * s) * inv;
 }
 
+// ---- similarity logits of the two CLIP towers in fp32 (multimodal/schema.py:25-30: logit_scale * I @ T^T) --------------
+// C[m][n] = alpha * sum_k A(m,k) * B(n,k); A(m,k) = ta ? A[k*lda + m] : A[m*lda + k], likewise B.  fp32 FMA chain in k
+// order: the features are L2-normalised fp32 rows and the logits feed a softmax at scale ~14-100, so the operands are
+// NOT rounded to bf16.  [B x W*B] x 512: < 1 GFLOP per launch, a workgroup computes a 16x16 output block from LDS tiles.
+__global__ __launch_bounds__(256) void sgemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                        float* __restrict__ C, int M, int N, int K, long lda, long ldb,
+                                                        int ta, int tb, const float* __restrict__ alpha_ptr, float alpha) {
+  __shared__ float sa[16][17], sb[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    // sa[r][c] = A(m0 + r, k0 + c), sb[r][c] = B(n0 + r, k0 + c); the lane -> element map follows the contiguous axis
+    {
+      const int r = ta ? tx : ty, c = ta ? ty : tx;
+      const int mm = blockIdx.y * 16 + r, kk = k0 + c;
+      sa[r][c] = (mm < M && kk < K) ? (ta ? A[(long)kk * lda + mm] : A[(long)mm * lda + kk]) : 0.f;
+    }
+    {
+      const int r = tb ? tx : ty, c = tb ? ty : tx;
+      const int nn = blockIdx.x * 16 + r, kk = k0 + c;
+      sb[r][c] = (nn < N && kk < K) ? (tb ? B[(long)kk * ldb + nn] : B[(long)nn * ldb + kk]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc = fmaf(sa[ty][c], sb[tx][c], acc);
+    __syncthreads();
+  }
+  if (m < M && n < N) C[(long)m * N + n] = acc * (alpha_ptr != nullptr ? alpha_ptr[0] * alpha : alpha);
+}
+
+// out[0] += sum_i a[i] * b[i]  (caller zeroes; d logit_scale = sum(dlogits * logits))
+__global__ __launch_bounds__(256) void dot_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ out, long n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s = fmaf(a[i], b[i], s);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
 }  // namespace
 
 extern "C" int cfhip_embedding_fwd(const float* table, const int64_t* indices, const float* pos, void* out,
@@ -123,5 +166,23 @@ extern "C" int cfhip_l2norm_bwd(const float* dy, const float* y, const float* in
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy, y,
                      inv_norm, dx, (long)N, D);
   CFHIP_CHECK_LAUNCH("l2norm_bwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_sgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                               int a_trans, int b_trans, const float* alpha_dev, float alpha, void* stream) {
+  CFHIP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "sgemm_f32: bad arguments");
+  hipLaunchKernelGGL(sgemm_f32_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, A, B, C, M, N,
+                     K, (long)lda, (long)ldb, a_trans, b_trans, alpha_dev, alpha);
+  CFHIP_CHECK_LAUNCH("sgemm_f32");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_dot_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
+  CFHIP_REQUIRE(a && b && out && n > 0, "dot_f32: bad arguments");
+  long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(dot_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)n);
+  CFHIP_CHECK_LAUNCH("dot_f32");
   return CFHIP_OK;
 }

@@ -1207,10 +1207,17 @@ class CLIP(Module):
         return HF.l2_normalize(feat)
 
     def forward(self, image: Tensor, text: Tensor) -> Tensor:
-        """logits_per_image (reference multimodal/schema.py:25-30); the [B, D] x [D, B] product is left to torch"""
-        image_features = self.encode_image(image)
-        text_features = self.encode_text(text)
-        return self.logit_scale.exp() * image_features @ text_features.t()
+        """logits_per_image (reference multimodal/schema.py:25-30), fp32 similarity kernel"""
+        from .contrastive import similarity_logits
+
+        return similarity_logits(self.encode_image(image), self.encode_text(text), self.logit_scale)
+
+    def contrastive_loss(self, image: Tensor, text: Tensor, group: Any = None) -> Tensor:
+        """Symmetric InfoNCE over the local batch against the embeddings of every rank (contrastive.py; the
+        reference has no training loss for CLIP: new design, parity unpinned)."""
+        from .contrastive import clip_contrastive_loss
+
+        return clip_contrastive_loss(self.encode_image(image), self.encode_text(text), self.logit_scale, group)
 
 
 # ---------------------------------------------------------------------------------------------

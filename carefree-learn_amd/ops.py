@@ -853,6 +853,37 @@ def conv3x3_pack_filters(w16: Tensor, rotate: bool) -> Tensor:
     return out
 
 
+def sgemm_f32(a: Tensor, b: Tensor, *, a_trans: bool = False, b_trans: bool = False,
+              alpha_dev: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
+    """fp32 C[m,n] = alpha * alpha_dev[0] * sum_k A(m,k) B(n,k) on dense f32 matrices (a: [M,K] or, a_trans, [K,M];
+    b: [N,K] or, b_trans, [K,N]) -- the CLIP similarity logits and the products of their backward."""
+    _need(a, f32, "a")
+    _need(b, f32, "b")
+    if a.dim() != 2 or b.dim() != 2 or not a.is_contiguous() or not b.is_contiguous():
+        raise ValueError("cfhip sgemm_f32: dense 2-D f32 operands expected")
+    m, k = (a.shape[1], a.shape[0]) if a_trans else (a.shape[0], a.shape[1])
+    n, kb = (b.shape[1], b.shape[0]) if b_trans else (b.shape[0], b.shape[1])
+    if k != kb:
+        raise ValueError(f"cfhip sgemm_f32: reduction dims differ ({k} vs {kb})")
+    if alpha_dev is not None:
+        _need(alpha_dev, f32, "alpha_dev")
+    out = torch.empty((m, n), dtype=f32, device=a.device)
+    _lib.check(_lib.load().cfhip_sgemm_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), m, n, k, a.stride(0), b.stride(0),
+                                           int(a_trans), int(b_trans), _p(alpha_dev), float(alpha), _stream()), "sgemm_f32")
+    return out
+
+
+def dot_f32(a: Tensor, b: Tensor) -> Tensor:
+    """f32 [1] = sum(a * b) over two dense f32 tensors of equal size."""
+    _need(a, f32, "a")
+    _need(b, f32, "b")
+    if a.numel() != b.numel() or not a.is_contiguous() or not b.is_contiguous():
+        raise ValueError("cfhip dot_f32: dense f32 tensors of equal size expected")
+    out = torch.zeros((1,), dtype=f32, device=a.device)
+    _lib.check(_lib.load().cfhip_dot_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "dot_f32")
+    return out
+
+
 def spin(microseconds: int) -> None:
     """One idle wavefront on the current stream (stream self-check, see functional.distinct_stream)."""
     _lib.check(_lib.load().cfhip_spin(int(microseconds), _stream()), "spin")

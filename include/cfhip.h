@@ -351,6 +351,15 @@ int cfhip_embedding_bwd(const void* dy, int dy_is_f32, const int64_t* indices, f
 int cfhip_l2norm_fwd(const float* x, float* y, float* inv_norm, int64_t N, int D, void* stream);
 int cfhip_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int64_t N, int D,
                      void* stream);
+/* Similarity logits of the CLIP towers in fp32 (IPerceptor.forward, multimodal/schema.py:25-30:
+ * `logit_scale.exp() * image_features @ text_features.t()`) and the products of its backward:
+ * C[m][n] = alpha * alpha_dev[0] * sum_k A(m,k) * B(n,k), A(m,k) = a_trans ? A[k*lda + m] : A[m*lda + k] (B likewise),
+ * C dense [M][N]; alpha_dev (device scalar, e.g. exp(logit_scale)) may be NULL.  fp32 FMA in k order: the operands are
+ * not rounded to bf16.  dot: out[0] += sum a[i]*b[i] (d logit_scale = sum(dlogits * logits); caller zeroes).
+ * The contrastive loss built on them (contrastive.py) has no counterpart in the reference: parity unpinned. */
+int cfhip_sgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                    int a_trans, int b_trans, const float* alpha_dev, float alpha, void* stream);
+int cfhip_dot_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

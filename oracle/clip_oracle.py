@@ -72,3 +72,20 @@ def logits_per_image(img: Tensor, indices: Tensor, sd: StateDict, vision_heads: 
     ft = encode_text(indices, sd, text_heads, text_layers)
     return math.exp(sd["logit_scale"].item()) * fi @ ft.t() if not sd["logit_scale"].requires_grad else \
         sd["logit_scale"].exp() * fi @ ft.t()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Contrastive loss: NOT in the reference (multimodal/clip.py is inference only) -> "parity unpinned": a plain fp32
+# statement of the CLIP paper's symmetric InfoNCE, the checker for carefree-learn_amd/contrastive.py.
+# ---------------------------------------------------------------------------------------------------------------------
+def contrastive_loss_local(img, txt, all_img, all_txt, logit_scale, offset=0):
+    """Mean over the local rows of ( CE(s I all_T^T, y) + CE(s T all_I^T, y) ) / 2, y_i = offset + i, s = exp(logit_scale)."""
+    import torch
+
+    s = logit_scale.exp()
+    b = img.shape[0]
+    y = torch.arange(offset, offset + b)
+    li = s * img @ all_txt.t()
+    lt = s * txt @ all_img.t()
+    ce = torch.nn.functional.cross_entropy
+    return 0.5 * (ce(li, y) + ce(lt, y))

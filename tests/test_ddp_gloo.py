@@ -180,3 +180,58 @@ def test_direct_write_notifications_two_ranks(tmp_path):
     for p, off in zip(model.parameters(), r0["offsets"]):
         flat[off:off + p.numel()] = p.grad.reshape(-1)
     assert (r0["g0"] - flat).abs().max() < 1e-6
+
+
+def _gather_worker(rank: int, world: int, port: int, out: str) -> None:
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cflearn_amd.contrastive import gather_rows_with_grad
+    from clip_oracle import contrastive_loss_local
+
+    torch.manual_seed(11)
+    b, d = 3, 8
+    img = torch.nn.functional.normalize(torch.randn(world * b, d), dim=-1)
+    txt = torch.nn.functional.normalize(torch.randn(world * b, d), dim=-1)
+    ls = torch.tensor(1.3, requires_grad=True)
+    il = img[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+    tl = txt[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+    all_i, all_t = gather_rows_with_grad(il), gather_rows_with_grad(tl)
+    assert torch.equal(all_i.detach(), img) and torch.equal(all_t.detach(), txt)  # rank-major order
+    loss = contrastive_loss_local(il, tl, all_i, all_t, ls, offset=rank * b)
+    loss.backward()
+    torch.save(dict(loss=loss.detach(), gi=il.grad, gt=tl.grad, gls=ls.grad), f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_embedding_gather_with_grad_two_ranks(tmp_path):
+    """The "local loss + autograd-aware all-gather" scheme of contrastive.py: per-rank gradients, averaged over the
+    ranks like DDP does, equal the gradients of the global-batch loss computed in one process."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from clip_oracle import contrastive_loss_local
+
+    world, port = 2, _free_port()
+    out = str(tmp_path / "gather")
+    mp.spawn(_gather_worker, args=(world, port, out), nprocs=world, join=True)
+    res = [torch.load(f"{out}.{r}") for r in range(world)]
+    torch.manual_seed(11)
+    b, d = 3, 8
+    img = torch.nn.functional.normalize(torch.randn(world * b, d), dim=-1).requires_grad_(True)
+    txt = torch.nn.functional.normalize(torch.randn(world * b, d), dim=-1).requires_grad_(True)
+    ls = torch.tensor(1.3, requires_grad=True)
+    glob = contrastive_loss_local(img, txt, img, txt, ls)
+    glob.backward()
+    assert abs(sum(r["loss"] for r in res).item() / world - glob.item()) < 1e-6
+    for r in range(world):
+        # d(global mean loss)/d(features of rank r) = (1/W) * what rank r holds after the gather's backward
+        assert (res[r]["gi"] / world - img.grad[r * b:(r + 1) * b]).abs().max() < 1e-6
+        assert (res[r]["gt"] / world - txt.grad[r * b:(r + 1) * b]).abs().max() < 1e-6
+    assert abs(sum(r["gls"] for r in res).item() / world - ls.grad.item()) < 1e-6

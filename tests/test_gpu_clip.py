@@ -128,3 +128,55 @@ def test_clip_fused_equals_composed(golden):
     assert_close(outs[0][0], outs[1][0], 5e-3, "fused vs composed logits")
     for k in outs[0][1]:
         assert_close(outs[0][1][k], outs[1][1][k], 3e-2, f"fused vs composed {k}", abs_floor=2e-4)
+
+
+def test_contrastive_loss_kernels_vs_fp32_formula():
+    """contrastive.ClipLossFn / SimilarityFn (fp32 similarity GEMMs + softmax-CE + dot) against the plain fp32
+    statement of the symmetric InfoNCE (oracle/clip_oracle.contrastive_loss_local), ragged sizes."""
+    import clip_oracle as CL
+    from cflearn_amd.contrastive import clip_contrastive_loss, similarity_logits
+
+    for b, d in ((19, 40), (32, 64), (5, 7)):
+        gen = torch.Generator().manual_seed(b * 7 + d)
+        img = torch.nn.functional.normalize(torch.randn(b, d, generator=gen), dim=-1)
+        txt = torch.nn.functional.normalize(torch.randn(b, d, generator=gen), dim=-1)
+        ir, tr = img.clone().requires_grad_(True), txt.clone().requires_grad_(True)
+        lsr = torch.tensor(2.0, requires_grad=True)
+        want = CL.contrastive_loss_local(ir, tr, ir, tr, lsr)
+        want.backward()
+        idv, tdv = img.to(DEV).requires_grad_(True), txt.to(DEV).requires_grad_(True)
+        lsd = torch.tensor(2.0, device=DEV, requires_grad=True)
+        got = clip_contrastive_loss(idv, tdv, lsd)
+        assert got.shape == (1,) and got.dtype == torch.float32
+        assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item())
+        (got * 3.0).sum().backward()  # a non-trivial upstream gradient
+        assert_close(idv.grad, 3.0 * ir.grad, 1e-5, "d image features")
+        assert_close(tdv.grad, 3.0 * tr.grad, 1e-5, "d text features")
+        assert abs(lsd.grad.item() - 3.0 * lsr.grad.item()) <= 1e-4 * abs(3.0 * lsr.grad.item()) + 1e-6
+        # the logits alone, with their own backward
+        i2, t2 = img.to(DEV).requires_grad_(True), txt.to(DEV).requires_grad_(True)
+        ls2 = torch.tensor(2.0, device=DEV, requires_grad=True)
+        lg = similarity_logits(i2, t2, ls2)
+        ref = (lsr.detach().exp() * img @ txt.t())
+        assert_close(lg, ref, 1e-6, "similarity logits")
+        w = torch.randn(b, b, generator=gen)
+        (lg * w.to(DEV)).sum().backward()
+        ir2, tr2, ls3 = img.clone().requires_grad_(True), txt.clone().requires_grad_(True), torch.tensor(2.0, requires_grad=True)
+        ((ls3.exp() * ir2 @ tr2.t()) * w).sum().backward()
+        assert_close(i2.grad, ir2.grad, 1e-5, "similarity d image")
+        assert_close(t2.grad, tr2.grad, 1e-5, "similarity d text")
+        assert abs(ls2.grad.item() - ls3.grad.item()) <= 1e-4 * abs(ls3.grad.item()) + 1e-6
+
+
+def test_clip_contrastive_step_golden(golden):
+    """CLIP.contrastive_loss (single process) against the fixture's loss and parameter gradients — the fixture was
+    produced with torch's cross_entropy on the reference's logits_per_image and its transpose."""
+    g = golden("clip_small.pt")
+    m = _clip(g)
+    loss = m.contrastive_loss(g["img"].to(DEV), g["txt"].to(DEV))
+    assert abs(loss.item() - g["loss"].item()) <= 2e-2 * abs(g["loss"].item())
+    loss.sum().backward()
+    grads = {k: p.grad.detach().float().cpu() for k, p in m.named_parameters() if p.grad is not None}
+    assert set(grads) == set(g["grads"])
+    for k, v in grads.items():
+        assert_close(v, g["grads"][k], 1.2e-1, f"grad {k}", abs_floor=3e-4)
