@@ -10,7 +10,8 @@ Importable as `cflearn_amd` (the directory name `carefree-learn_amd` is not a Py
 Importing the package never touches the GPU; the first kernel call loads `libcfhip.so`
 (built by `__graft_entry__.build()`), and raises if it is missing — there is no CPU fallback.
 """
-from . import _lib, ops, functional, fused, registry, modules, optim, ddp, contrastive  # noqa: F401
+from . import _lib, ops, functional, fused, registry, modules, optim, ddp, contrastive, checkpoint  # noqa: F401
+from .checkpoint import AsyncCheckpointer  # noqa: F401
 from .registry import (  # noqa: F401
     PrefixModules,
     build_module,
