@@ -75,3 +75,27 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "vit_oracle" not in src and "refharness" not in src and "import oracle" not in src, f
+
+
+def test_conv3x3_host_side_checks_and_split_heuristic():
+    """No launch happens: argument validation and the split-K decision of the implicit-GEMM convolution."""
+    lib = _lib.load()
+    # one K-step = 32 channels of a tap
+    rc = lib.cfhip_conv3x3_nhwc_bf16(16, 16, None, 16, 1, 8, 8, 48, 64, None, 0, None)
+    assert rc == -1 and b"multiple of 32" in lib.cfhip_last_error()
+    rc = lib.cfhip_conv3x3_nhwc_bf16(16, 16, None, 16, 1, 8, 8, 64, 60, None, 0, None)
+    assert rc == -1 and b"multiple of 8" in lib.cfhip_last_error()
+    rc = lib.cfhip_conv3x3_wgrad_nhwc_bf16(16, 16, 16, 0, None, 0, 1, 1, 8, 64, 64, 1, None, 0, None)
+    assert rc == -1 and b"bad image shape" in lib.cfhip_last_error()
+    rc = lib.cfhip_conv3x3_pack_filters(16, 16, 8, 12, 0, None)
+    assert rc == -1
+    # zoo UNet at 64^2 x 8: level 0 (32768 pixels x 320) fills the chip -> no split, no workspace; the deeper levels
+    # (8192 x 640: 160 tiles, 2048 x 1280: 80, 512 x 1280: 40) split and ask for split * pixels * Cout fp32
+    assert lib.cfhip_conv3x3_workspace(8, 64, 64, 320, 320) == 0
+    for (hw, cin, cout) in ((32, 640, 640), (16, 1280, 1280), (8, 1280, 1280)):
+        nbytes = lib.cfhip_conv3x3_workspace(8, hw, hw, cin, cout)
+        pixels = 8 * hw * hw
+        assert nbytes > 0 and nbytes % (pixels * cout * 4) == 0
+        split = nbytes // (pixels * cout * 4)
+        assert 2 <= split <= (9 * cin // 64) // 8
+    assert lib.cfhip_conv3x3_wgrad_workspace(320, 640, 4) == 4 * 640 * (9 * 320 + 1) * 4
