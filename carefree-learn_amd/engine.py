@@ -96,3 +96,38 @@ class TrainStep:
         self.optimizer.prepare_step()
         self.loss_sum = self._body(img, labels)
         return self.loss_sum
+
+
+class LossTrainStep:
+    """The same step engine for any module whose loss is computed by HIP autograd functions: `loss_fn(model, batch)`
+    returns a device scalar (e.g. `CLIP.contrastive_loss`); backward; side-stream join; bucketed gradient all-reduce
+    when `distributed`; fused Adam(W) over the arena.  No host synchronisation inside `step()`."""
+
+    def __init__(self, model: torch.nn.Module, loss_fn: Any, *, lr: float = 1.0e-4, betas: Any = (0.9, 0.999),
+                 eps: float = 1.0e-8, weight_decay: float = 0.0, decoupled: bool = True, distributed: bool = False,
+                 bucket_bytes: int = 64 << 20):
+        self.model, self.loss_fn = model, loss_fn
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.arena = ParamArena(params, with_shadow=True)
+        self.optimizer = FusedAdam(None, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=decoupled,
+                                   arena=self.arena)
+        # NOT lazy: parameters such as CLIP's logit_scale receive their gradient through autograd's accumulation
+        self.optimizer.lazy_zero = False
+        if params and params[0].is_cuda:
+            SideStream.ensure()
+        self.reducer: Optional[BucketedAllReduce] = None
+        if distributed:
+            self.reducer = BucketedAllReduce(self.arena, bucket_bytes=bucket_bytes, optimizer=self.optimizer)
+            self.reducer.broadcast_parameters(0)
+        self.loss: Optional[Tensor] = None
+
+    def step(self, batch: Any) -> Tensor:
+        self.optimizer.prepare_step()
+        self.optimizer.zero_grad()
+        self.loss = self.loss_fn(self.model, batch)
+        self.loss.sum().backward()
+        SideStream.join()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.launch_step()
+        return self.loss

@@ -180,3 +180,19 @@ def test_clip_contrastive_step_golden(golden):
     assert set(grads) == set(g["grads"])
     for k, v in grads.items():
         assert_close(v, g["grads"][k], 1.2e-1, f"grad {k}", abs_floor=3e-4)
+
+
+def test_clip_contrastive_train_steps(golden):
+    """engine.LossTrainStep on CLIP.contrastive_loss: arena + fused AdamW, first loss = the fixture's, then it falls."""
+    from cflearn_amd.engine import LossTrainStep
+
+    g = golden("clip_small.pt")
+    m = _clip(g)
+    ts = LossTrainStep(m, lambda mod, b: mod.contrastive_loss(b["image"], b["text"]), lr=1e-3)
+    batch = dict(image=g["img"].to(DEV), text=g["txt"].to(DEV))
+    losses = [ts.step(batch).item() for _ in range(6)]
+    assert abs(losses[0] - g["loss"].item()) <= 2e-2 * abs(g["loss"].item())
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    # logit_scale (a 0-d parameter whose gradient comes back through autograd) lives in the arena and moved
+    assert m.logit_scale.grad is not None and m.logit_scale.grad.data_ptr() >= ts.arena.flat_g.data_ptr()
+    assert abs(m.logit_scale.item() - g["sd"]["logit_scale"].item()) > 1e-4
