@@ -10,7 +10,7 @@ patch embedding -> 12 pre-norm transformer blocks -> head LN + Linear -> softmax
 Rank 0 prints ONE JSON line (metric = BASELINE.json's: train samples/sec + step ms).
 
 Extra objects:
-  roofline      dominant kernel family = the MFMA GEMM (`gemm_bf16_kernel<*>`, 96 % of the step's
+  roofline      dominant kernel family = the MFMA GEMM (`gemm_bf16_phase_kernel<*>` / `gemm_bf16_kernel<*>`, 96 % of the step's
                 FLOPs).  achieved = algorithmic FLOPs of every GEMM launch of one step (2*M*N*K each,
                 the per-sample figure of SURVEY §8d x the batch) / sum of their durations, each shape
                 timed live with HIP events on the launch stream; peak = 2500 TFLOP/s dense bf16.
@@ -312,7 +312,7 @@ def main() -> None:
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "traffic_unit": "HBM-side bytes per step over all GEMM launches (PMC FETCH_SIZE x2 + WRITE_SIZE)",
             "traffic_source": traffic_src, "algorithmic_bytes": round(algo_bytes),
-            "kernel": "gemm_bf16_kernel<AT,BT,EPI> (all GEMM launches of one step, weighted by count)",
+            "kernel": "gemm_bf16_phase_kernel / gemm_bf16_kernel <AT,BT,EPI,Cfg> (all GEMM launches of one step, weighted by count)",
             "gemm_ms_per_step": round(tsec * 1e3, 3),
             "shapes": rows,
         }
