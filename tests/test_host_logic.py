@@ -168,3 +168,26 @@ def test_ddpm_noise_schedule_matches_reference_bitwise(golden):
     assert torch.equal(s.betas, g["betas"])
     assert torch.equal(s.sqrt_alphas_cumprod, g["sqrt_alphas_cumprod"])
     assert torch.equal(s.sqrt_one_minus_alphas_cumprod, g["sqrt_one_minus_alphas_cumprod"])
+
+
+def test_adam_hyper_record_ring_host_side():
+    """FusedAdam.prepare_step: every step fills ITS OWN slot of the pinned ring (a single host buffer was overwritten
+    by a host running ahead of the GPU), and the record holds the bias corrections of that step."""
+    import math
+
+    import torch
+
+    from cflearn_amd.optim import _HYPER_RING, FusedAdam, ParamArena
+
+    p = torch.nn.Parameter(torch.zeros(16))
+    opt = FusedAdam(None, lr=2e-3, betas=(0.9, 0.99), eps=1e-7, weight_decay=0.05, arena=ParamArena([p], with_shadow=False))
+    opt.grad_scale = 0.5
+    seen = []
+    for t in range(1, 2 * _HYPER_RING + 2):
+        opt.prepare_step()
+        h = opt._hyper_dev.clone()
+        want = [2e-3, 0.9, 0.99, 1e-7, 0.05, 1.0 - 0.9 ** t, 1.0 / math.sqrt(1.0 - 0.99 ** t), 0.5]
+        assert torch.allclose(h, torch.tensor(want, dtype=torch.float32), rtol=1e-6, atol=0), (t, h)
+        seen.append(opt._hyper_host.data_ptr())
+    assert len(set(seen[:_HYPER_RING])) == _HYPER_RING           # distinct slots within one lap
+    assert seen[:_HYPER_RING] == seen[_HYPER_RING:2 * _HYPER_RING]  # and the ring wraps
