@@ -123,6 +123,10 @@ class BucketedAllReduce:
         if i is None:
             return
         b = self.buckets[self.bucket_of[i]]
+        if not direct and not self._direct[i]:
+            # autograd accumulated this gradient: after the trainer's `optimizer.zero_grad()` (set_to_none) it sits
+            # in a fresh tensor, not in the arena slot the bucket reduces
+            self.arena.adopt_grad(p)
         if direct:
             self._direct[i] = True
         elif self._direct[i]:

@@ -181,13 +181,29 @@ def _is_direct(param: Optional[Tensor]) -> bool:
     return param is not None and param.is_leaf and param.requires_grad and param.dtype == f32
 
 
+def grad_buffer(param: Tensor, zero: bool = False) -> Tensor:
+    """The tensor a backward kernel writes `param`'s gradient into when `param.grad is None`: the parameter's slot of
+    its `optim.ParamArena` when it lives in one (the reference trainer's `optimizer.zero_grad()` sets `.grad` to None
+    every step; the bucketed all-reduce and the fused Adam read the arena), a new tensor otherwise.  Contents are
+    undefined unless `zero`."""
+    arena = getattr(param, "_cfhip_arena", None)
+    if arena is not None:
+        buf = arena.grad_view(param)
+        if zero:
+            buf.zero_()
+        return buf
+    make = torch.zeros if zero else torch.empty
+    return make(param.shape, dtype=f32, device=param.device)
+
+
 def write_param_grad(param: Tensor, compute: Callable[[Tensor, bool], None]) -> None:
     """`compute(out, accumulate)` must write (accumulate=False) or add (True) the f32 gradient."""
     g = param.grad
     if g is None:
-        buf = torch.empty(param.shape, dtype=f32, device=param.device)
+        buf = grad_buffer(param)
         compute(buf, False)
         param.grad = buf
+        param._cfhip_fresh = False
     else:
         fresh = getattr(param, "_cfhip_fresh", False)
         compute(g, not fresh)
@@ -522,7 +538,7 @@ class PatchTokensFn(Function):
             # both written by one kernel: hand it the two destinations
             for prm in (head_token, pos):
                 if prm.grad is None:
-                    prm.grad = torch.zeros(prm.shape, dtype=f32, device=prm.device)
+                    prm.grad = grad_buffer(prm, zero=True)
                     prm._cfhip_fresh = False
             acc_h = not getattr(head_token, "_cfhip_fresh", False)
             acc_p = not getattr(pos, "_cfhip_fresh", False)

@@ -20,7 +20,7 @@ from torch import Tensor
 from torch.autograd import Function
 
 from . import ops
-from .functional import SideStream, bf16, f32, shadow_bf16
+from .functional import SideStream, bf16, f32, grad_buffer, shadow_bf16
 
 
 # The dW GEMM also produces db = colsum(dy) (cfhip_gemm_bf16's `bias_grad`: the waves that own the first tile column
@@ -41,7 +41,7 @@ def _dw_db(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> None:
     prms = [w] + ([b] if (b is not None and b.requires_grad) else [])
     for prm in prms:
         if prm.grad is None:
-            prm.grad = torch.empty(prm.shape, dtype=f32, device=prm.device)
+            prm.grad = grad_buffer(prm)
             prm._cfhip_fresh = True
     acc_w = not getattr(w, "_cfhip_fresh", False)
     kw = {}
@@ -75,7 +75,7 @@ def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: T
     def param_grads(with_dx: bool = False) -> Optional[Tensor]:
         for prm in (w, b):
             if prm.grad is None:
-                prm.grad = torch.empty(prm.shape, dtype=f32, device=prm.device)
+                prm.grad = grad_buffer(prm)
                 prm._cfhip_fresh = True
         acc_w = not getattr(w, "_cfhip_fresh", False)
         acc_b = not getattr(b, "_cfhip_fresh", False)

@@ -53,6 +53,7 @@ class ParamArena:
                 self.flat_p[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[o:o + n].view(p.shape)
                 p.grad = self.flat_g[o:o + n].view(p.shape)
+                p._cfhip_arena = self   # functional.grad_buffer: a `.grad` that was set to None comes back as this view
                 p._cfhip_fresh = False  # the arena starts zeroed: accumulate into it
                 if self.flat_p16 is not None:
                     p._cfhip_shadow = self.flat_p16[o:o + n].view(p.shape)
@@ -91,9 +92,23 @@ class ParamArena:
             idx = p._cfhip_arena_index
         return idx
 
-    def _rebind_grad(self, p: Tensor) -> None:
+    def grad_view(self, p: Tensor) -> Tensor:
         o = self.offsets[self._index(p)]
-        p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        return self.flat_g[o:o + p.numel()].view(p.shape)
+
+    def _rebind_grad(self, p: Tensor) -> None:
+        p.grad = self.grad_view(p)
+
+    def adopt_grad(self, p: Tensor) -> None:
+        """`p.grad` was produced outside the arena (the trainer called `optimizer.zero_grad()` with torch's default
+        `set_to_none=True` and autograd allocated a fresh tensor): move it into the slot and point `.grad` back."""
+        g = p.grad
+        if g is None:
+            return
+        view = self.grad_view(p)
+        if g.data_ptr() != view.data_ptr():
+            view.copy_(g)
+            p.grad = view
 
     def finalize_grads(self) -> None:
         """Zero the gradient slots no backward kernel touched this step (unused parameters)."""

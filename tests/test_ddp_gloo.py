@@ -235,3 +235,63 @@ def test_embedding_gather_with_grad_two_ranks(tmp_path):
         assert (res[r]["gi"] / world - img.grad[r * b:(r + 1) * b]).abs().max() < 1e-6
         assert (res[r]["gt"] / world - txt.grad[r * b:(r + 1) * b]).abs().max() < 1e-6
     assert abs(sum(r["gls"] for r in res).item() / world - ls.grad.item()) < 1e-6
+
+
+def _callback_worker(rank: int, world: int, port: int, out: str) -> None:
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cflearn_amd.ddp import RcclDDPCallback
+
+    model = _model()
+    if rank == 1:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(3.0)  # the broadcast of before_loop must undo this
+
+    class _Obj:
+        pass
+
+    trainer = _Obj()
+    trainer.model = _Obj()
+    trainer.model.m = model
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    trainer.optimizers = {"all": opt}
+    cb = RcclDDPCallback(bucket_bytes=256)
+    cb.before_loop(trainer)  # reference trainer.py:312-313
+    torch.manual_seed(100)
+    x, y = torch.randn(8, 6), torch.randn(8, 3)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    for _ in range(3):  # the reference's step: zero_grad (set_to_none), backward, optimizer.step
+        opt.zero_grad()
+        ((model(xs) - ys) ** 2).mean().backward()
+        opt.step()
+    torch.save([p.detach().clone() for p in model.parameters()], f"{out}.{rank}")
+    cb.reducer.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_trainer_callback_with_set_to_none_zero_grad(tmp_path):
+    """`RcclDDPCallback` under the reference trainer's own step (torch optimizer, `zero_grad()` with set_to_none): three
+    SGD steps on two ranks == three steps in one process on the concatenated batch."""
+    world, port = 2, _free_port()
+    out = str(tmp_path / "cb")
+    mp.spawn(_callback_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    for a, b in zip(r0, r1):
+        assert torch.equal(a, b)
+    model = _model()
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    torch.manual_seed(100)
+    x, y = torch.randn(8, 6), torch.randn(8, 3)
+    for _ in range(3):
+        opt.zero_grad()
+        ((model(x) - y) ** 2).mean().backward()
+        opt.step()
+    for a, p in zip(r0, model.parameters()):
+        assert (a - p.detach()).abs().max() < 1e-6

@@ -191,3 +191,32 @@ def test_adam_hyper_record_ring_host_side():
         seen.append(opt._hyper_host.data_ptr())
     assert len(set(seen[:_HYPER_RING])) == _HYPER_RING           # distinct slots within one lap
     assert seen[:_HYPER_RING] == seen[_HYPER_RING:2 * _HYPER_RING]  # and the ring wraps
+
+
+def test_gradients_return_to_the_arena_after_set_to_none():
+    """The reference trainer calls `optimizer.zero_grad()` (torch default: set_to_none=True) every step.  A direct-writing
+    backward (functional.write_param_grad) and the reducer's adoption of autograd-made gradients must both end up in
+    the arena slot, which is what the bucketed all-reduce and the fused Adam read."""
+    import torch
+
+    from cflearn_amd import functional as HF
+
+    lin = torch.nn.Linear(3, 2)
+    arena = C.ParamArena(lin.parameters(), with_shadow=False)
+    w, b = lin.weight, lin.bias
+    torch.optim.SGD(lin.parameters(), lr=0.1).zero_grad()  # set_to_none
+    assert w.grad is None and b.grad is None
+    arena.flat_g.fill_(7.0)  # stale values of the previous step
+    HF.write_param_grad(w, lambda out, acc: out.copy_(torch.full_like(out, 2.0)) if not acc else out.add_(2.0))
+    assert w.grad.data_ptr() == arena.grad_view(w).data_ptr() and torch.all(w.grad == 2.0)
+    HF.write_param_grad(w, lambda out, acc: out.copy_(torch.full_like(out, 2.0)) if not acc else out.add_(2.0))
+    assert torch.all(arena.grad_view(w) == 4.0)  # the second contribution of the same backward accumulates
+    # autograd-made gradient of the bias: adopted into its slot
+    (lin(torch.ones(1, 3)).sum()).backward(inputs=[b])
+    assert b.grad.data_ptr() != arena.grad_view(b).data_ptr()
+    arena.adopt_grad(b)
+    assert b.grad.data_ptr() == arena.grad_view(b).data_ptr() and torch.all(b.grad == 1.0)
+    # a parameter outside any arena still gets a private tensor
+    q = torch.nn.Parameter(torch.zeros(4))
+    HF.write_param_grad(q, lambda out, acc: out.copy_(torch.ones_like(out)))
+    assert q.grad is not None and torch.all(q.grad == 1.0)
