@@ -41,7 +41,7 @@ from .modules import (  # noqa: F401
     ViTEncoder,
     vit_b16_classifier,
 )
-from .optim import FusedAdam, ParamArena, clip_grad_norm_  # noqa: F401
+from .optim import FusedAdam, FusedAdamOptimizer, FusedAdamWOptimizer, ParamArena, clip_grad_norm_  # noqa: F401
 from .ddp import BucketedAllReduce, RcclDDPCallback, get_ddp_info  # noqa: F401
 
 __version__ = "0.1.0"

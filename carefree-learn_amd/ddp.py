@@ -196,9 +196,18 @@ class RcclDDPCallback:
         if get_ddp_info() is None or not dist.is_initialized():
             return
         params = [p for p in trainer.model.m.parameters() if p.requires_grad]
-        arena = ParamArena(params, with_shadow=True)
-        self.reducer = BucketedAllReduce(arena, bucket_bytes=self.bucket_bytes)
+        inners = [getattr(opt, "optimizer", opt) for opt in trainer.optimizers.values()]  # accelerate wraps the torch one
+        # an optimizer that already owns the arena (optim.FusedAdamOptimizer): reduce ITS gradient buffer and let its
+        # kernel apply the 1 / W; otherwise re-home the parameters here and average in finish()
+        arena, fused = None, None
+        for inner in inners:
+            a = getattr(inner, "arena", None)
+            if a is not None and {id(p) for p in a.params} == {id(p) for p in params}:
+                arena, fused = a, getattr(inner, "fused", None)
+                break
+        if arena is None:
+            arena = ParamArena(params, with_shadow=True)
+        self.reducer = BucketedAllReduce(arena, bucket_bytes=self.bucket_bytes, optimizer=fused)
         self.reducer.broadcast_parameters(0)
-        for opt in trainer.optimizers.values():
-            inner = getattr(opt, "optimizer", opt)  # accelerate's AcceleratedOptimizer wraps the torch one
+        for inner in inners:
             inner.register_step_pre_hook(lambda *_a, **_k: self.reducer.finish())

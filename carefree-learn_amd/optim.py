@@ -201,6 +201,57 @@ class FusedAdam:
             g.update(s)
 
 
+class FusedAdamOptimizer(torch.optim.Optimizer):
+    """`FusedAdam` behind the `torch.optim.Optimizer` interface, for the reference's registries: its schedulers derive
+    from `torch.optim.lr_scheduler._LRScheduler` (schedulers.py:13,60,126), which insists on an `Optimizer` instance,
+    `accelerate` wraps one, and the DDP callback uses `register_step_pre_hook`.  Same constructor keywords as
+    `torch.optim.Adam` / `AdamW` (optimizers.py:29-31: `register_optimizer("adam")(FusedAdamOptimizer)`,
+    `register_optimizer("adamw")(FusedAdamWOptimizer)`).  `param_groups` is ONE list shared with the fused optimizer, so
+    a scheduler's `group["lr"] = ...` is what the next step's 32-byte hyper-parameter record carries.  One group only:
+    the update is one kernel over one flat arena."""
+
+    decoupled_default = False
+
+    def __init__(self, params: Any, lr: float = 1.0e-3, betas: Any = (0.9, 0.999), eps: float = 1.0e-8,
+                 weight_decay: float = 0.0, *, decoupled: Optional[bool] = None, arena: Optional[ParamArena] = None):
+        if arena is None:
+            params = list(params)
+            if params and isinstance(params[0], dict):
+                if len(params) != 1:
+                    raise ValueError("FusedAdamOptimizer: one parameter group only (one kernel over one flat arena)")
+                params = list(params[0]["params"])
+            arena = ParamArena(params)
+        self.fused = FusedAdam(None, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                               decoupled=self.decoupled_default if decoupled is None else decoupled, arena=arena)
+        super().__init__(arena.params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self.fused.param_groups = self.param_groups  # shared: schedulers write the learning rate here
+        self.arena = arena
+
+    def zero_grad(self, set_to_none: bool = False) -> None:  # the arena views stay bound either way
+        self.fused.zero_grad()
+
+    def step(self, closure: Any = None) -> Any:  # type: ignore
+        loss = None if closure is None else closure()
+        self.fused.step()
+        return loss
+
+    def state_dict(self) -> Dict[str, Any]:  # type: ignore
+        return self.fused.state_dict()
+
+    def load_state_dict(self, state_dict: Dict[str, Any]) -> None:  # type: ignore
+        self.fused.load_state_dict(state_dict)
+
+
+class FusedAdamWOptimizer(FusedAdamOptimizer):
+    """Decoupled weight decay (`torch.optim.AdamW`, optimizers.py:31); default weight_decay 1e-2 like torch."""
+
+    decoupled_default = True
+
+    def __init__(self, params: Any, lr: float = 1.0e-3, betas: Any = (0.9, 0.999), eps: float = 1.0e-8,
+                 weight_decay: float = 1.0e-2, **kwargs: Any):
+        super().__init__(params, lr, betas, eps, weight_decay, **kwargs)
+
+
 def clip_grad_norm_(arena: ParamArena, max_norm: float, optimizer: Optional[FusedAdam] = None) -> Tensor:
     """Global L2 clipping on the gradient arena (reference trainer.py:170-176 semantics).  With an
     optimizer the clip coefficient is folded into the Adam kernel's grad_scale (needs one host

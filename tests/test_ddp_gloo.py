@@ -295,3 +295,61 @@ def test_trainer_callback_with_set_to_none_zero_grad(tmp_path):
         opt.step()
     for a, p in zip(r0, model.parameters()):
         assert (a - p.detach()).abs().max() < 1e-6
+
+
+def _callback_fused_worker(rank: int, world: int, port: int, out: str) -> None:
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cflearn_amd.ddp import RcclDDPCallback
+    from cflearn_amd.optim import FusedAdamWOptimizer
+
+    model = _model()
+    if rank == 1:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+
+    class _Obj:
+        pass
+
+    trainer = _Obj()
+    trainer.model = _Obj()
+    trainer.model.m = model
+    opt = FusedAdamWOptimizer(model.parameters(), lr=1e-3)
+    trainer.optimizers = {"all": opt}
+    cb = RcclDDPCallback(bucket_bytes=256)
+    cb.before_loop(trainer)
+    assert cb.reducer.arena is opt.arena            # the optimizer's own arena is the one that is reduced
+    assert opt.fused.grad_scale == 1.0 / world      # and its kernel applies the 1 / W
+    opt.zero_grad()
+    torch.manual_seed(100)
+    x, y = torch.randn(8, 6), torch.randn(8, 3)
+    ((model(x[rank * 4:(rank + 1) * 4]) - y[rank * 4:(rank + 1) * 4]) ** 2).mean().backward()
+    try:
+        opt.step()  # pre-step hook = the gradient exchange; the update itself needs the GPU
+    except RuntimeError as e:
+        assert "no CPU fallback" in str(e)
+    torch.save(dict(p=opt.arena.flat_p.clone(), g=opt.arena.flat_g.clone()), f"{out}.{rank}")
+    cb.reducer.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_trainer_callback_reuses_the_fused_optimizers_arena(tmp_path):
+    world, port = 2, _free_port()
+    out = str(tmp_path / "cbf")
+    mp.spawn(_callback_fused_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["p"], r1["p"])  # broadcast from rank 0
+    assert torch.equal(r0["g"], r1["g"])  # SUM over the ranks (the Adam kernel scales by 1 / W)
+    model = _model()
+    torch.manual_seed(100)
+    x, y = torch.randn(8, 6), torch.randn(8, 3)
+    ((model(x) - y) ** 2).mean().backward()
+    flat = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1), (0, (-p.numel()) % 8)) for p in model.parameters()])
+    assert (r0["g"] / world - flat).abs().max() < 1e-6

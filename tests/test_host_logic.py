@@ -220,3 +220,43 @@ def test_gradients_return_to_the_arena_after_set_to_none():
     q = torch.nn.Parameter(torch.zeros(4))
     HF.write_param_grad(q, lambda out, acc: out.copy_(torch.ones_like(out)))
     assert q.grad is not None and torch.all(q.grad == 1.0)
+
+
+def test_fused_adam_behind_the_torch_optimizer_interface():
+    """FusedAdamOptimizer: what the reference's scheduler / accelerate / DDP-callback code needs from an optimizer."""
+    import torch
+
+    from cflearn_amd.optim import FusedAdamOptimizer, FusedAdamWOptimizer
+
+    lin = torch.nn.Linear(4, 3)
+    opt = FusedAdamWOptimizer(lin.parameters(), lr=2e-3)
+    assert isinstance(opt, torch.optim.Optimizer) and opt.fused.decoupled and opt.defaults["weight_decay"] == 1e-2
+    assert not FusedAdamOptimizer(torch.nn.Linear(2, 2).parameters()).fused.decoupled
+    # parameters and gradients live in the arena, zero_grad keeps them bound
+    for p in lin.parameters():
+        assert p.grad is not None and p.grad.data_ptr() == opt.arena.grad_view(p).data_ptr()
+    lin(torch.randn(5, 4)).sum().backward()
+    assert opt.arena.flat_g.abs().sum() > 0
+    opt.zero_grad()
+    assert opt.arena.flat_g.abs().sum() == 0 and lin.weight.grad is not None
+    # a torch scheduler (the reference's schedulers subclass _LRScheduler) drives the lr the kernel will read
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda epoch: 0.5 ** epoch)
+    assert opt.fused.param_groups is opt.param_groups
+    opt.fused.prepare_step()
+    assert abs(opt.fused._hyper_dev[0].item() - 2e-3) < 1e-9
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # "scheduler.step() before optimizer.step()": no GPU here to step with
+        sched.step()
+    opt.fused.prepare_step()
+    assert abs(opt.fused._hyper_dev[0].item() - 1e-3) < 1e-9
+    # step hooks (ddp.RcclDDPCallback registers one) fire; the update itself is GPU-only
+    seen = []
+    opt.register_step_pre_hook(lambda *a, **k: seen.append(1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        opt.step()
+    assert seen == [1]
+    sd = opt.state_dict()
+    assert sd["step"] == opt.fused.step_count and sd["exp_avg"].shape == opt.arena.flat_p.shape
+    with pytest.raises(ValueError, match="one parameter group"):
+        FusedAdamOptimizer([dict(params=[torch.nn.Parameter(torch.zeros(2))]), dict(params=[torch.nn.Parameter(torch.zeros(2))])])
