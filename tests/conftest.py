@@ -13,6 +13,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    # a fresh checkout has no libcfhip.so (it is git-ignored): build it once, like __graft_entry__.build()
+    lib = os.path.join(ROOT, "carefree-learn_amd", "libcfhip.so")
+    if not os.path.isfile(lib):
+        import shutil
+        import subprocess
+
+        if shutil.which("hipcc") or os.path.isfile("/opt/rocm/bin/hipcc"):
+            subprocess.run(["bash", os.path.join(ROOT, "build_lib.sh")], cwd=ROOT, check=False,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 def pytest_collection_modifyitems(config, items):
