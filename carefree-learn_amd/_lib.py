@@ -9,7 +9,8 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcfhip.so")
+# CFHIP_LIB selects another build of the same C-ABI (the benchmark tools use it for the -DCFHIP_ABLATE library)
+LIB_PATH = os.environ.get("CFHIP_LIB") or os.path.join(_HERE, "libcfhip.so")
 
 _lib: Optional[ctypes.CDLL] = None
 

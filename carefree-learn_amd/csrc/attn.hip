@@ -38,10 +38,18 @@ struct AttnParams {
   int causal;
   int dh;           // head_dim of the general kernels (the resident fast kernels are head_dim 64 only)
   int delta_ready;  // dK/dV pass: p.delta was already written by the dQ pass of the same call
+#ifdef CFHIP_ABLATE
   int ablate;       // benchmarking only (forward): bit0 skip the K/V DMA, bit1 skip the tile loop, bit2 skip stores
+#endif
 };
 
+// Timing ablations exist only in -DCFHIP_ABLATE builds (tools/build_variant.sh); the product library has none.
+#ifdef CFHIP_ABLATE
 int g_attn_ablate = 0;
+#define ATTN_ABL(bit) (p.ablate & (bit))
+#else
+#define ATTN_ABL(bit) false
+#endif
 
 // byte offset of element (row, col) in a swizzled [rows][64] bf16 tile (128 B per row)
 __device__ __forceinline__ int tile_off(int row, int col) {
@@ -141,12 +149,12 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnParams p) {
   const int nwaves = blockDim.x >> 6;
   const bf16_t* kb = p.k + (long)b * p.kv_sb + h * DH;
   const bf16_t* vb = p.v + (long)b * p.kv_sb + h * DH;
-  if (!(p.ablate & 1)) {
+  if (!ATTN_ABL(1)) {
     dma_tile(Ks, kb, p.kv_st, p.Tk, NB * 32, wave, nwaves, lane);
     dma_tile(Vs, vb, p.kv_st, p.Tk, NB * 32, wave, nwaves, lane);
   }
   __syncthreads();  // (drains the DMA: vmcnt(0) + barrier)
-  if (p.ablate & 2) return;
+  if (ATTN_ABL(2)) return;
 
   const int i = lane & 15, g = lane >> 4;
   const bf16_t* qb = p.q + (long)b * p.q_sb + h * DH;
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnParams p) {
       ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Vs, a * 32, dt * 16, lane), pa, ot[dt], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (qi < p.Tq && !(p.ablate & 4)) {
+  if (qi < p.Tq && !ATTN_ABL(4)) {
     const float inv = 1.0f / l;
     bf16_t* orow = p.o + (long)b * p.o_sb + (long)qi * p.o_st + h * DH;
 #pragma unroll
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_kernel(AttnParams p, int 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
-  if (!(p.ablate & 1)) {
+  if (!ATTN_ABL(1)) {
   dma_tile(Qs, p.q + (long)b * p.q_sb + h * DH, p.q_st, p.Tq, nbq * 32, wave, nwaves, lane);
   dma_tile(dOs, p.d_o + (long)b * p.o_sb + h * DH, p.o_st, p.Tq, nbq * 32, wave, nwaves, lane);
   // lse and delta_i = sum_d dO[i][d] * O[i][d] of every query row (delta is recomputed here from the
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_kernel(AttnParams p, int 
   }
   }
   __syncthreads();
-  if (p.ablate & 2) return;
+  if (ATTN_ABL(2)) return;
 
   const int n = lane & 15, g = lane >> 4;
   for (int row0 = (blockIdx.x * nwaves + wave) * 16; row0 < p.Tk; row0 += gridDim.x * nwaves * 16) {
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_kernel(AttnParams p, int 
       dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Qs, a * 32, dt * 16, lane), dsk, dkt[dt], 0, 0, 0);
     }
   }
-  if (kj < p.Tk && !(p.ablate & 4)) {
+  if (kj < p.Tk && !ATTN_ABL(4)) {
     bf16_t* dkrow = p.dk + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH;
     bf16_t* dvrow = p.dv + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH;
 #pragma unroll
@@ -871,10 +879,12 @@ int check_head_dim(const char* who, int head_dim) {
 
 }  // namespace
 
+#ifdef CFHIP_ABLATE
 int cfhip_internal_set_attn_ablate(int v) {
   g_attn_ablate = v;
   return CFHIP_OK;
 }
+#endif
 
 static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse,
                          const uint8_t* mask, int B, int H, int Tq, int Tk, int head_dim, int64_t q_stride_b,
@@ -895,7 +905,9 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
   p.o_sb = o_stride_b; p.o_st = o_stride_t;
   p.ms_b = ms_b; p.ms_h = ms_h; p.ms_q = ms_q;
   p.scale = scale; p.causal = causal;
+#ifdef CFHIP_ABLATE
   p.ablate = g_attn_ablate;
+#endif
   p.dh = head_dim;
   const int nb = (Tk + 31) / 32;
   const int nw = pick_waves(Tq);
@@ -973,7 +985,9 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
   p.scale = scale; p.causal = causal;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   p.delta_ready = (parts & 3) == 3;
+#ifdef CFHIP_ABLATE
   p.ablate = g_attn_ablate;
+#endif
   p.dh = head_dim;
   const bool plain = mask == nullptr && !causal;
   CFHIP_REQUIRE((parts & 3) != 0, "attn_bwd: parts must select the dQ pass (1), the dK/dV pass (2) or both (3)");

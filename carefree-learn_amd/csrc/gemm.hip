@@ -48,7 +48,9 @@ struct GemmParams {
   // CONV == 2 (weight gradient): B is the NHWC activation, the GEMM's n index is (tap, channel), k = pixel;
   // pixel -> (y, x) per K-step by multiply-high with floor(2^32 / d) + 1 (exact while pixel * d < 2^32)
   unsigned conv_magic_w, conv_magic_h;
+#ifdef CFHIP_ABLATE
   int ablate;  // benchmarking only: bit0 skip in-loop DMA, bit1 skip MFMA/LDS reads, bit2 skip stores
+#endif
 };
 
 // Tile configuration.  BM x BN x 64 workgroup tile, WM x WN waves (each a (BM/WM) x (BN/WN) sub-tile of
@@ -223,6 +225,14 @@ __device__ __forceinline__ void bias_rows(const char* a_tile, int wm, int lane, 
 
 #define CFHIP_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
+// Timing ablations (skip the in-loop DMA / the MFMAs / the stores: results are then WRONG) exist only in builds
+// with -DCFHIP_ABLATE (tools/build_variant.sh ablate -DCFHIP_ABLATE -> tools/libcfhip_ablate.so); the product library has no such code.
+#ifdef CFHIP_ABLATE
+#define CFHIP_ABLATE_AND(cond) && (cond)
+#else
+#define CFHIP_ABLATE_AND(cond)
+#endif
+
 
 // ---- epilogue ----------------------------------------------------------------------------------------
 // The MFMA result layout (lane = row l&15, 4 consecutive columns per 16x16 tile) would give 8-byte
@@ -231,23 +241,183 @@ __device__ __forceinline__ void bias_rows(const char* a_tile, int wm, int lane, 
 // a lane ends up with 8 CONSECUTIVE columns of one row: residual / pre-activation traffic becomes
 // 16-byte coalesced loads and every store instruction writes whole 128-byte row segments.  16-byte
 // chunks are XOR-swizzled by the row (no padding: the strips of all waves exactly fill 16 KiB).
-template <int EPI, class C>
-__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[C::FM][C::FN], char* stage,
-                                         int m0, int n0, int z, int wm, int wn, int wave, int lane) {
+// All global traffic of the epilogue goes through buffer descriptors anchored at the tile's origin: a row beyond M
+// or a column beyond N becomes an out-of-range OFFSET (loads return 0, stores are dropped by the range check), so
+// the whole epilogue is straight-line code — no divergent branches, no exec-mask juggling between the passes.
+// Operands the epilogue READS (residual stream, saved pre-activation) are fetched a few row passes AHEAD of their
+// use into a small register ring: the stores of pass i and the loads of pass i+1 may alias as far as the compiler
+// can tell, so the straightforward loop issued each pass's loads only after the previous pass's stores — one
+// exposed HBM round trip (~2 us under load) per pass, 8 per tile.  With the ring the round trips overlap.
+struct AuxRegs { u32x4 a, b; };  // f32 operand: 8 values (a, b); bf16 operand: 8 values in a (b is dead code)
+#ifndef CFHIP_PF_F32
+#define CFHIP_PF_F32 2
+#endif
+#ifndef CFHIP_PF_BF16
+#define CFHIP_PF_BF16 4
+#endif
+
+__device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ u32x2 bload8(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ void bstore16(__amdgpu_buffer_rsrc_t r, unsigned off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v), r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void bstore8(__amdgpu_buffer_rsrc_t r, unsigned off, u32x2 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, v), r, (int)off, 0, 0);
+}
+// descriptor of an [M][ld] matrix of ES-byte elements, anchored at (m0, n0); valid bytes end with element (M-1, N-1)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, long ld, int es, int m0, int n0, int M, int N) {
+  const char* origin = reinterpret_cast<const char*>(base) + ((long)m0 * ld + n0) * es;
+  return make_rsrc(origin, ((long)(M - 1 - m0) * ld + (N - n0)) * es);
+}
+
+// N8: N % 8 == 0, every lane's 8 columns are all inside or all outside the matrix (one 16-byte access for bf16)
+// QUICK: quick GELU x * sigmoid(1.702 x) instead of the exact-erf GELU (GELU / DGELU epilogues)
+template <int EPI, class C, bool F32, bool N8, bool QUICK>
+__device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[C::FM][C::FN], char* stage,
+                                              int m0, int n0, int wm, int wn, int wave, int lane) {
   constexpr int WCOLS = C::FN * 16;           // columns of the wave's sub-tile
   constexpr int LPR = WCOLS / 8;              // lanes per row when every lane takes 8 columns
   constexpr int RPP = 64 / LPR;               // rows covered by one pass of the wave
+  constexpr int PPM = 16 / RPP;               // passes per 16-row fragment
+  constexpr int NIT = C::FM * PPM;            // passes per tile
+  constexpr bool HAS_AUX = EPI == CFHIP_EPI_RESIDUAL || EPI == CFHIP_EPI_DGELU;
+  constexpr bool AUX_F32 = EPI == CFHIP_EPI_RESIDUAL && F32;  // f32 residual stream: aux_in is f32 with the output's layout
+  constexpr int PFW = AUX_F32 ? CFHIP_PF_F32 : CFHIP_PF_BF16;  // ring depth: 8 / 4 registers per entry
+  constexpr int PF = HAS_AUX ? (PFW < NIT ? PFW : NIT) : 1;
+  constexpr int ES = F32 ? 4 : 2, AES = AUX_F32 ? 4 : 2;
   float* stg = reinterpret_cast<float*>(stage) + wave * (16 * WCOLS);
   const int i = lane & 15, g = lane >> 4;
   const int rr = lane / LPR, c8 = lane % LPR;
-  const bool to_slab = p.slabs != nullptr;
-  const int col = n0 + wn * WCOLS + c8 * 8;
-  const bool c_lo = col < p.N, c_hi = col + 4 < p.N;  // N % 4 == 0 on this path
+  const int lcol = wn * WCOLS + c8 * 8;                       // column inside the tile
+  const bool c_lo = n0 + lcol < p.N, c_hi = n0 + lcol + 4 < p.N;  // N % 4 == 0 on this path
+  const int lrow0 = wm * (C::FM * 16) + rr;                   // row inside the tile of pass 0
   f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias != nullptr && !to_slab) {
-    if (c_lo) b_lo = *reinterpret_cast<const f32x4*>(p.bias + col);
-    if (c_hi) b_hi = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+  if (p.bias != nullptr) {
+    if (c_lo) b_lo = *reinterpret_cast<const f32x4*>(p.bias + n0 + lcol);
+    if (c_hi) b_hi = *reinterpret_cast<const f32x4*>(p.bias + n0 + lcol + 4);
   }
+  const __amdgpu_buffer_rsrc_t c_rsrc = tile_rsrc(p.C, p.ldc, ES, m0, n0, p.M, p.N);
+  __amdgpu_buffer_rsrc_t x_rsrc = c_rsrc, o_rsrc = c_rsrc;
+  if constexpr (HAS_AUX) x_rsrc = tile_rsrc(p.aux_in, p.ldc, AES, m0, n0, p.M, p.N);
+  if constexpr (EPI == CFHIP_EPI_GELU) o_rsrc = tile_rsrc(p.aux_out, p.ldc, 2, m0, n0, p.M, p.N);
+  const bool has_pre = EPI == CFHIP_EPI_GELU && p.aux_out != nullptr;
+  // element offset of pass `it` (rows beyond M fall outside the descriptor by themselves)
+  auto eoff = [&](int it) -> unsigned { return (unsigned)((lrow0 + (it / PPM) * 16 + (it % PPM) * RPP) * (int)p.ldc + lcol); };
+  auto load_aux = [&](int it) -> AuxRegs {
+    AuxRegs r;
+    r.b = u32x4{0u, 0u, 0u, 0u};
+    const unsigned e = eoff(it);
+    if constexpr (AUX_F32) {
+      r.a = bload16(x_rsrc, c_lo ? e * 4u : OOB);
+      r.b = bload16(x_rsrc, c_hi ? e * 4u + 16u : OOB);
+    } else if constexpr (N8) {
+      r.a = bload16(x_rsrc, c_lo ? e * 2u : OOB);
+    } else {
+      const u32x2 h0 = bload8(x_rsrc, c_lo ? e * 2u : OOB), h1 = bload8(x_rsrc, c_hi ? e * 2u + 8u : OOB);
+      r.a = u32x4{h0[0], h0[1], h1[0], h1[1]};
+    }
+    return r;
+  };
+  AuxRegs ring[PF];
+  if constexpr (HAS_AUX) {
+#pragma unroll
+    for (int it = 0; it < PF; ++it) ring[it] = load_aux(it);
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int mi = it / PPM, ps = it % PPM;
+    if (ps == 0) {
+#pragma unroll
+      for (int ni = 0; ni < C::FN; ++ni)
+        *reinterpret_cast<f32x4*>(stg + i * WCOLS + (((ni * 4 + g) ^ (i & 7)) << 2)) = acc[mi][ni];
+    }
+    const int r = ps * RPP + rr;
+    f32x4 lo = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + (((2 * c8) ^ (r & 7)) << 2));
+    f32x4 hi = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + (((2 * c8 + 1) ^ (r & 7)) << 2));
+    AuxRegs aux;
+    if constexpr (HAS_AUX) {
+      aux = ring[it % PF];
+      if (it + PF < NIT) ring[it % PF] = load_aux(it + PF);
+    }
+    const unsigned e = eoff(it);
+    lo += b_lo;
+    hi += b_hi;
+    if constexpr (EPI == CFHIP_EPI_GELU) {
+      // GELU of the bf16-rounded pre-activation (what the saved tensor holds for backward)
+      const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                       pack_bf16x2(hi[2], hi[3])};
+      if constexpr (N8) {
+        bstore16(o_rsrc, (has_pre && c_lo) ? e * 2u : OOB, w);
+      } else {
+        bstore8(o_rsrc, (has_pre && c_lo) ? e * 2u : OOB, u32x2{w[0], w[1]});
+        bstore8(o_rsrc, (has_pre && c_hi) ? e * 2u + 8u : OOB, u32x2{w[2], w[3]});
+      }
+      if constexpr (QUICK) {
+        lo = f32x4{quick_gelu_f(bf16lo(w[0])), quick_gelu_f(bf16hi(w[0])), quick_gelu_f(bf16lo(w[1])), quick_gelu_f(bf16hi(w[1]))};
+        hi = f32x4{quick_gelu_f(bf16lo(w[2])), quick_gelu_f(bf16hi(w[2])), quick_gelu_f(bf16lo(w[3])), quick_gelu_f(bf16hi(w[3]))};
+      } else {
+        lo = f32x4{gelu_erf_f(bf16lo(w[0])), gelu_erf_f(bf16hi(w[0])), gelu_erf_f(bf16lo(w[1])), gelu_erf_f(bf16hi(w[1]))};
+        hi = f32x4{gelu_erf_f(bf16lo(w[2])), gelu_erf_f(bf16hi(w[2])), gelu_erf_f(bf16lo(w[3])), gelu_erf_f(bf16hi(w[3]))};
+      }
+    } else if constexpr (AUX_F32) {
+      lo += __builtin_bit_cast(f32x4, aux.a);
+      hi += __builtin_bit_cast(f32x4, aux.b);
+    } else if constexpr (HAS_AUX) {
+      const u32x4 w = aux.a;
+      if constexpr (EPI == CFHIP_EPI_RESIDUAL) {
+        lo += f32x4{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
+        hi += f32x4{bf16lo(w[2]), bf16hi(w[2]), bf16lo(w[3]), bf16hi(w[3])};
+      } else if constexpr (QUICK) {
+        lo *= f32x4{quick_gelu_grad_f(bf16lo(w[0])), quick_gelu_grad_f(bf16hi(w[0])), quick_gelu_grad_f(bf16lo(w[1])), quick_gelu_grad_f(bf16hi(w[1]))};
+        hi *= f32x4{quick_gelu_grad_f(bf16lo(w[2])), quick_gelu_grad_f(bf16hi(w[2])), quick_gelu_grad_f(bf16lo(w[3])), quick_gelu_grad_f(bf16hi(w[3]))};
+      } else {
+        lo *= f32x4{gelu_erf_grad_f(bf16lo(w[0])), gelu_erf_grad_f(bf16hi(w[0])), gelu_erf_grad_f(bf16lo(w[1])), gelu_erf_grad_f(bf16hi(w[1]))};
+        hi *= f32x4{gelu_erf_grad_f(bf16lo(w[2])), gelu_erf_grad_f(bf16hi(w[2])), gelu_erf_grad_f(bf16lo(w[3])), gelu_erf_grad_f(bf16hi(w[3]))};
+      }
+    }
+    if constexpr (F32) {
+      if constexpr (EPI == CFHIP_EPI_NONE) {
+        if (p.accumulate) {  // wave-uniform; the dW forms only (checked on the host)
+          lo += __builtin_bit_cast(f32x4, bload16(c_rsrc, c_lo ? e * 4u : OOB));
+          hi += __builtin_bit_cast(f32x4, bload16(c_rsrc, c_hi ? e * 4u + 16u : OOB));
+        }
+      }
+#ifdef CFHIP_ABLATE
+      if ((p.ablate & 8) && lo[0] != 12345.678f) continue;  // timing only: epilogue math without the store
+#endif
+      bstore16(c_rsrc, c_lo ? e * 4u : OOB, __builtin_bit_cast(u32x4, lo));
+      bstore16(c_rsrc, c_hi ? e * 4u + 16u : OOB, __builtin_bit_cast(u32x4, hi));
+    } else {
+      const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                       pack_bf16x2(hi[2], hi[3])};
+#ifdef CFHIP_ABLATE
+      if ((p.ablate & 8) && w[0] != 0x12345678u) continue;  // timing only: epilogue math without the store
+#endif
+      if constexpr (N8) {
+        bstore16(c_rsrc, c_lo ? e * 2u : OOB, w);
+      } else {
+        bstore8(c_rsrc, c_lo ? e * 2u : OOB, u32x2{w[0], w[1]});
+        bstore8(c_rsrc, c_hi ? e * 2u + 8u : OOB, u32x2{w[2], w[3]});
+      }
+    }
+  }
+}
+
+// split-K partials: the raw accumulators of K slice z go to slab z (f32), same LDS transposition
+template <class C>
+__device__ __forceinline__ void epilogue_slab(const GemmParams& p, f32x4 (&acc)[C::FM][C::FN], char* stage,
+                                              int m0, int n0, int z, int wm, int wn, int wave, int lane) {
+  constexpr int WCOLS = C::FN * 16, LPR = WCOLS / 8, RPP = 64 / LPR;
+  float* stg = reinterpret_cast<float*>(stage) + wave * (16 * WCOLS);
+  const int i = lane & 15, g = lane >> 4;
+  const int rr = lane / LPR, c8 = lane % LPR;
+  const int lcol = wn * WCOLS + c8 * 8;
+  const bool c_lo = n0 + lcol < p.N, c_hi = n0 + lcol + 4 < p.N;
+  const __amdgpu_buffer_rsrc_t s_rsrc = tile_rsrc(p.slabs + (long)z * p.M * p.N, p.N, 4, m0, n0, p.M, p.N);
 #pragma unroll
   for (int mi = 0; mi < C::FM; ++mi) {
 #pragma unroll
@@ -256,72 +426,36 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[C::FM
 #pragma unroll
     for (int ps = 0; ps < 16 / RPP; ++ps) {
       const int r = ps * RPP + rr;
-      f32x4 lo = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + (((2 * c8) ^ (r & 7)) << 2));
-      f32x4 hi = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + (((2 * c8 + 1) ^ (r & 7)) << 2));
-      const int row = m0 + wm * (C::FM * 16) + mi * 16 + r;
-      if (row >= p.M || !c_lo) continue;
-      if (to_slab) {
-        float* dst = p.slabs + ((long)z * p.M + row) * p.N + col;
-        *reinterpret_cast<f32x4*>(dst) = lo;
-        if (c_hi) *reinterpret_cast<f32x4*>(dst + 4) = hi;
-        continue;
-      }
-      lo += b_lo;
-      hi += b_hi;
-      const long off = (long)row * p.ldc + col;
-      if (EPI == CFHIP_EPI_GELU) {
-        // GELU of the bf16-rounded pre-activation (what the saved tensor holds for backward)
-        const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                         pack_bf16x2(hi[2], hi[3])};
-        if (p.aux_out != nullptr) {
-          if (c_hi) *reinterpret_cast<u32x4*>(p.aux_out + off) = w;
-          else *reinterpret_cast<u32x2*>(p.aux_out + off) = u32x2{w[0], w[1]};
-        }
-        if (p.quick) {  // wave-uniform
-          lo = f32x4{quick_gelu_f(bf16lo(w[0])), quick_gelu_f(bf16hi(w[0])), quick_gelu_f(bf16lo(w[1])), quick_gelu_f(bf16hi(w[1]))};
-          hi = f32x4{quick_gelu_f(bf16lo(w[2])), quick_gelu_f(bf16hi(w[2])), quick_gelu_f(bf16lo(w[3])), quick_gelu_f(bf16hi(w[3]))};
-        } else {
-          lo = f32x4{gelu_erf_f(bf16lo(w[0])), gelu_erf_f(bf16hi(w[0])), gelu_erf_f(bf16lo(w[1])), gelu_erf_f(bf16hi(w[1]))};
-          hi = f32x4{gelu_erf_f(bf16lo(w[2])), gelu_erf_f(bf16hi(w[2])), gelu_erf_f(bf16lo(w[3])), gelu_erf_f(bf16hi(w[3]))};
-        }
-      } else if (EPI == CFHIP_EPI_RESIDUAL && p.out_f32) {
-        // f32 residual stream: aux_in is f32 with the output's layout
-        const float* r32 = reinterpret_cast<const float*>(p.aux_in) + off;
-        lo += *reinterpret_cast<const f32x4*>(r32);
-        if (c_hi) hi += *reinterpret_cast<const f32x4*>(r32 + 4);
-      } else if (EPI == CFHIP_EPI_RESIDUAL || EPI == CFHIP_EPI_DGELU) {
-        u32x4 w = {0u, 0u, 0u, 0u};
-        if (c_hi) w = *reinterpret_cast<const u32x4*>(p.aux_in + off);
-        else { const u32x2 h2 = *reinterpret_cast<const u32x2*>(p.aux_in + off); w[0] = h2[0]; w[1] = h2[1]; }
-        if (EPI == CFHIP_EPI_RESIDUAL) {
-          lo += f32x4{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
-          hi += f32x4{bf16lo(w[2]), bf16hi(w[2]), bf16lo(w[3]), bf16hi(w[3])};
-        } else if (p.quick) {
-          lo *= f32x4{quick_gelu_grad_f(bf16lo(w[0])), quick_gelu_grad_f(bf16hi(w[0])), quick_gelu_grad_f(bf16lo(w[1])), quick_gelu_grad_f(bf16hi(w[1]))};
-          hi *= f32x4{quick_gelu_grad_f(bf16lo(w[2])), quick_gelu_grad_f(bf16hi(w[2])), quick_gelu_grad_f(bf16lo(w[3])), quick_gelu_grad_f(bf16hi(w[3]))};
-        } else {
-          lo *= f32x4{gelu_erf_grad_f(bf16lo(w[0])), gelu_erf_grad_f(bf16hi(w[0])), gelu_erf_grad_f(bf16lo(w[1])), gelu_erf_grad_f(bf16hi(w[1]))};
-          hi *= f32x4{gelu_erf_grad_f(bf16lo(w[2])), gelu_erf_grad_f(bf16hi(w[2])), gelu_erf_grad_f(bf16lo(w[3])), gelu_erf_grad_f(bf16hi(w[3]))};
-        }
-      }
-      if (p.out_f32) {
-        float* dst = reinterpret_cast<float*>(p.C) + off;
-        if (p.accumulate) {
-          lo += *reinterpret_cast<const f32x4*>(dst);
-          if (c_hi) hi += *reinterpret_cast<const f32x4*>(dst + 4);
-        }
-        if ((p.ablate & 8) && lo[0] != 12345.678f) continue;  // timing only: epilogue math without the store
-        *reinterpret_cast<f32x4*>(dst) = lo;
-        if (c_hi) *reinterpret_cast<f32x4*>(dst + 4) = hi;
-      } else {
-        bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + off;
-        const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                         pack_bf16x2(hi[2], hi[3])};
-        if ((p.ablate & 8) && w[0] != 0x12345678u) continue;  // timing only: epilogue math without the store
-        if (c_hi) *reinterpret_cast<u32x4*>(dst) = w;
-        else *reinterpret_cast<u32x2*>(dst) = u32x2{w[0], w[1]};
-      }
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + (((2 * c8) ^ (r & 7)) << 2));
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + (((2 * c8 + 1) ^ (r & 7)) << 2));
+      const unsigned e = (unsigned)((wm * (C::FM * 16) + mi * 16 + r) * p.N + lcol);
+      bstore16(s_rsrc, c_lo ? e * 4u : OOB, __builtin_bit_cast(u32x4, lo));
+      bstore16(s_rsrc, c_hi ? e * 4u + 16u : OOB, __builtin_bit_cast(u32x4, hi));
     }
+  }
+}
+
+template <int EPI, class C>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[C::FM][C::FN], char* stage,
+                                         int m0, int n0, int z, int wm, int wn, int wave, int lane) {
+  if constexpr (EPI == CFHIP_EPI_NONE) {  // split-K (host-checked: epilogue NONE only)
+    if (p.slabs != nullptr) {
+      epilogue_slab<C>(p, acc, stage, m0, n0, z, wm, wn, wave, lane);
+      return;
+    }
+  }
+  if constexpr (EPI == CFHIP_EPI_GELU || EPI == CFHIP_EPI_DGELU) {  // bf16 outputs (checked on the host)
+    if (p.quick) {
+      if ((p.N & 7) == 0) epilogue_impl<EPI, C, false, true, true>(p, acc, stage, m0, n0, wm, wn, wave, lane);
+      else epilogue_impl<EPI, C, false, false, true>(p, acc, stage, m0, n0, wm, wn, wave, lane);
+    } else {
+      if ((p.N & 7) == 0) epilogue_impl<EPI, C, false, true, false>(p, acc, stage, m0, n0, wm, wn, wave, lane);
+      else epilogue_impl<EPI, C, false, false, false>(p, acc, stage, m0, n0, wm, wn, wave, lane);
+    }
+  } else {
+    if (p.out_f32) epilogue_impl<EPI, C, true, true, false>(p, acc, stage, m0, n0, wm, wn, wave, lane);  // f32: 16-byte halves either way
+    else if ((p.N & 7) == 0) epilogue_impl<EPI, C, false, true, false>(p, acc, stage, m0, n0, wm, wn, wave, lane);
+    else epilogue_impl<EPI, C, false, false, false>(p, acc, stage, m0, n0, wm, wn, wave, lane);
   }
 }
 
@@ -458,93 +592,81 @@ __device__ __forceinline__ void stage_step(const ItemCtx<AT, BT, C>& c, const Ge
   stage_tile<BT>(c.b_rsrc, st + C::A_BYTES, wave, c.pb, p.ldb, kstep * C::BK, c.klen);
 }
 
-// PERSISTENT kernel: the grid is (#CUs x resident workgroups per CU); every workgroup walks work
-// items item, item + G, ... and treats them as ONE long K loop over an NSTAGE-deep LDS ring fed by
-// LDS-DMA:
-//   * inside an item the DMA of K-step t + D (D = NSTAGE-1) is issued right after the barrier of
-//     step t and stays in flight ACROSS barriers: waits are counted (`s_waitcnt vmcnt(N)`), the
-//     barrier is the raw s_barrier (a `__syncthreads()` would drain vmcnt to 0).  One barrier per
-//     K-step — RAW: a wave passes barrier(t) only after its own DMA of step t landed; WAR: the DMA
-//     issued after barrier(t) overwrites the slot read in step t-1, which every wave has left;
-//   * at an item boundary the first D K-steps of the NEXT item are issued BEFORE the epilogue of the
-//     current one, into the ring slots the finished item no longer needs, so the pipeline-fill
-//     latency of the next tile and the drain of this tile's stores overlap (with K = 768 a tile has
-//     only 12-24 K-steps: fill + drain per tile was a third of the kernel);
-//   * the epilogue transposes the accumulators through the one ring slot that is free (the slot
-//     of the last K-step) — see below.
-template <bool AT, bool BT, int EPI, class C, int CONV = 0>
+// One workgroup per work item (output tile x K slice), an NSTAGE-deep LDS ring fed by LDS-DMA:
+//   * the DMA of K-step t + D (D = NSTAGE-1) is issued right after the barrier of step t and stays in flight
+//     ACROSS barriers: waits are counted (`s_waitcnt vmcnt(N)`), the barrier is the raw s_barrier (a
+//     `__syncthreads()` would drain vmcnt to 0).  One barrier per K-step — RAW: a wave passes barrier(t) only
+//     after its own DMA of step t landed; WAR: the DMA issued after barrier(t) overwrites the slot read in
+//     step t-1, which every wave has left;
+//   * the epilogue transposes the accumulators through the ring slot of the last K-step — see epilogue<>.
+// (A persistent-grid form of this kernel with cross-tile prefetch existed in round 1; it was slower inside the
+// training step — it keeps every CU slot and blocks the co-scheduling with the side streams — and kept the next
+// item's context live across the K loop, which put the 128-VGPR forms into scratch.  Removed.)
+// BG: the launch also owes the bias gradient (bias_rows): a separate instantiation, so that the plain dW kernel
+// does not carry the row accumulators and the extra fragment reads.
+template <bool AT, bool BT, int EPI, class C, int CONV = 0, bool BG = false>
 __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD)
 void gemm_bf16_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = C::NSTAGE - 1;  // prefetch distance
   static_assert(C::NW * 16 * (C::FN * 16) * 4 <= C::STAGE_BYTES, "epilogue staging must fit in one ring slot");
 
-  // XCD-aware, bijective remap of the persistent grid: XCD x (= bid % 8) owns a contiguous range of
-  // slots, hence in every round a contiguous range of tiles (neighbours share A / B panels in its L2).
+  // XCD-aware, bijective remap of the grid: XCD x (= bid % 8) owns a contiguous range of work items
+  // (neighbours share A / B panels in its L2).
   const int G = gridDim.x;
   const int bid = blockIdx.x;
   const int q8 = G >> 3, r8 = G & 7;
   const int xcd = bid & 7, loc = bid >> 3;
-  const int first = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-  const int total = p.tiles_m * p.tiles_n * p.splits;
+  const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / C::WN, wn = wave % C::WN;
-  if (first >= total) return;
 
-  ItemCtx<AT, BT, C> cur = setup_item<AT, BT, C, CONV>(p, first, wave, lane);
+  const ItemCtx<AT, BT, C> cur = setup_item<AT, BT, C, CONV>(p, item, wave, lane);
+  const int nk = cur.nk;
   int rd = 0;  // ring slot of the next K-step to compute
 #pragma unroll
   for (int st = 0; st < D; ++st)
-    if (st < cur.nk) stage_step<AT, BT, C, CONV>(cur, p, smem, st, wave, st);
+    if (st < nk) stage_step<AT, BT, C, CONV>(cur, p, smem, st, wave, st);
 
-  for (int item = first; item < total; item += G) {
-    f32x4 acc[C::FM][C::FN];
+  f32x4 acc[C::FM][C::FN];
 #pragma unroll
-    for (int mi = 0; mi < C::FM; ++mi)
+  for (int mi = 0; mi < C::FM; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < C::FN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float accb[C::FM];
+    for (int ni = 0; ni < C::FN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float accb[BG ? C::FM : 1];
+  if constexpr (BG) {
 #pragma unroll
     for (int mi = 0; mi < C::FM; ++mi) accb[mi] = 0.f;
-    const bool do_bg = AT && p.bgrad != nullptr && cur.tile_n == 0 && wn == 0;
-    const int nk = cur.nk;
+  }
+  const bool do_bg = BG && cur.tile_n == 0 && wn == 0;
 
-    for (int t = 0; t < nk; ++t) {
-      const int younger = min(D - 1, nk - 1 - t);  // stages of THIS item allowed to stay in flight
-      if (D >= 3 && younger >= 2) CFHIP_WAIT_VMCNT(2 * C::LPS);
-      else if (D >= 2 && younger == 1) CFHIP_WAIT_VMCNT(1 * C::LPS);
-      else CFHIP_WAIT_VMCNT(0);
-      __builtin_amdgcn_s_barrier();
-      if (t + D < nk && !(p.ablate & 1)) {
-        int wr = rd + D;
-        if (wr >= C::NSTAGE) wr -= C::NSTAGE;
-        stage_step<AT, BT, C, CONV>(cur, p, smem, wr, wave, t + D);
-      }
-      const char* tile = smem + rd * C::STAGE_BYTES;
-      if (!(p.ablate & 2)) compute_tile<AT, BT, C>(tile, tile + C::A_BYTES, wm, wn, lane, acc);
-      if (AT && do_bg) bias_rows<C>(tile, wm, lane, accb);
-      rd = rd + 1 == C::NSTAGE ? 0 : rd + 1;
+  for (int t = 0; t < nk; ++t) {
+    const int younger = min(D - 1, nk - 1 - t);  // younger stages allowed to stay in flight
+    if (D >= 3 && younger >= 2) CFHIP_WAIT_VMCNT(2 * C::LPS);
+    else if (D >= 2 && younger == 1) CFHIP_WAIT_VMCNT(1 * C::LPS);
+    else CFHIP_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    if (t + D < nk CFHIP_ABLATE_AND(!(p.ablate & 1))) {
+      int wr = rd + D;
+      if (wr >= C::NSTAGE) wr -= C::NSTAGE;
+      stage_step<AT, BT, C, CONV>(cur, p, smem, wr, wave, t + D);
     }
-
-    // ---- item boundary: start the next item's pipeline fill, then this item's epilogue -----------
-    const int m0 = cur.m0, n0 = cur.n0, z = cur.z;
-    const int nitem = item + G;
-    if (nitem < total) {
-      cur = setup_item<AT, BT, C, CONV>(p, nitem, wave, lane);
-#pragma unroll
-      for (int st = 0; st < D; ++st) {
-        if (st < cur.nk) {
-          int slot = rd + st;
-          if (slot >= C::NSTAGE) slot -= C::NSTAGE;
-          stage_step<AT, BT, C, CONV>(cur, p, smem, slot, wave, st);  // slots of steps older than the last one
-        }
-      }
+    const char* tile = smem + rd * C::STAGE_BYTES;
+    if (true CFHIP_ABLATE_AND(!(p.ablate & 2))) compute_tile<AT, BT, C>(tile, tile + C::A_BYTES, wm, wn, lane, acc);
+    if constexpr (BG) {
+      if (do_bg) bias_rows<C>(tile, wm, lane, accb);
     }
-    if (p.ablate & 4) continue;
-    if (AT && do_bg) {
+    rd = rd + 1 == C::NSTAGE ? 0 : rd + 1;
+  }
+#ifdef CFHIP_ABLATE
+  if (p.ablate & 4) return;
+#endif
+  const int m0 = cur.m0, n0 = cur.n0, z = cur.z;
+  if constexpr (BG) {
+    if (do_bg) {
 #pragma unroll
       for (int mi = 0; mi < C::FM; ++mi) {
         float v = accb[mi];  // lane (i, g) holds the k-slots of group g: fold the 4 groups
@@ -557,15 +679,13 @@ void gemm_bf16_kernel(GemmParams p) {
         }
       }
     }
-
-    // ---- epilogue (see epilogue<>): the strip lives in the ring slot of the last K-step, free once
-    // every wave is past the raw barrier below; it is re-used by the DMA of the next item's step D
-    // only after that item's first barrier, i.e. after every wave's epilogue.
-    __builtin_amdgcn_s_barrier();
-    int eslot = rd - 1;
-    if (eslot < 0) eslot += C::NSTAGE;
-    epilogue<EPI, C>(p, acc, smem + eslot * C::STAGE_BYTES, m0, n0, z, wm, wn, wave, lane);
   }
+  // ---- epilogue (see epilogue<>): the strip lives in the ring slot of the last K-step, free once every wave is
+  // past the raw barrier below (all DMA retired: the last wait was vmcnt(0)).
+  __builtin_amdgcn_s_barrier();
+  int eslot = rd - 1;
+  if (eslot < 0) eslot += C::NSTAGE;
+  epilogue<EPI, C>(p, acc, smem + eslot * C::STAGE_BYTES, m0, n0, z, wm, wn, wave, lane);
 }
 
 // ---- big-tile, two-group "ping-pong" variant -----------------------------------------------------------
@@ -677,7 +797,9 @@ void gemm_bf16_phase_kernel(GemmParams p) {
     wr = wr + 1 == C::NSTAGE ? 0 : wr + 1;
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();  // every wave has executed the same number of barriers
+#ifdef CFHIP_ABLATE
   if (p.ablate & 4) return;
+#endif
   // all DMA retired (the last wait was vmcnt(0)), all fragment reads retired: the ring is free
   epilogue<EPI, C>(p, acc, smem, cur.m0, cur.n0, cur.z, wm, wn, wave, lane);
 }
@@ -803,8 +925,9 @@ constexpr int NUM_CFG = 11;  // 7 .. 10 = CfgP / CfgQ / CfgR / CfgS on the phase
 constexpr int BK_MAX = 64;
 
 int g_gemm_config = -1;
+#ifdef CFHIP_ABLATE
 int g_gemm_ablate = 0;
-int g_gemm_persistent = 0;
+#endif
 int g_gemm_heuristic = 5;
 
 template <bool AT, bool BT, int EPI, class C, bool PIPE, int CONV = 0>
@@ -815,8 +938,12 @@ int launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
     return CFHIP_ERR_INVALID;
   }
   if constexpr (PIPE) kern = gemm_bf16_phase_kernel<AT, BT, EPI, C, CONV>;
-  else kern = gemm_bf16_kernel<AT, BT, EPI, C, CONV>;
-  static bool attr_done = false;  // per instantiation
+  else if constexpr (AT && BT && EPI == CFHIP_EPI_NONE) {
+    if (p.bgrad != nullptr) kern = gemm_bf16_kernel<AT, BT, EPI, C, CONV, true>;
+    else kern = gemm_bf16_kernel<AT, BT, EPI, C, CONV, false>;
+  } else kern = gemm_bf16_kernel<AT, BT, EPI, C, CONV>;
+  static bool attr_done_bg[2] = {false, false};  // per instantiation and per kernel picked above
+  bool& attr_done = attr_done_bg[p.bgrad != nullptr ? 1 : 0];
   if (!attr_done && C::LDS_BYTES > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -839,20 +966,7 @@ int launch_layout(GemmParams p, int a_trans, int b_trans, int epilogue, int spli
   CFHIP_REQUIRE(a_span < 0x7fffffffL && b_span < 0x7fffffffL,
                 "gemm: operand tile span exceeds 2 GiB (lda=%ld ldb=%ld K=%d)", p.lda, p.ldb, p.K);
   p.splits = split_k;
-  // persistent grid: one workgroup per resident slot (or per work item when there are fewer)
-  int dev = 0, cus = 256;
-  static int cached_cus = 0;
-  if (cached_cus == 0) {
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached_cus = prop.multiProcessorCount;
-    else cached_cus = 256;
-  }
-  cus = cached_cus;
-  const int items = p.tiles_m * p.tiles_n * split_k;
-  const int slots = cus * C::WGS_PER_CU;
-  // Persistence is optional: a persistent grid keeps every CU slot for the kernel's lifetime, which
-  // blocks the co-scheduling with the side-stream kernels (measured slower end-to-end on ViT-B/16).
-  dim3 grid((!PIPE && g_gemm_persistent && items > slots) ? slots : items);
+  dim3 grid(p.tiles_m * p.tiles_n * split_k);  // one workgroup per (output tile, K slice)
   if (!a_trans && !b_trans) {
     switch (epilogue) {
       case CFHIP_EPI_NONE: return launch_cfg<false, false, CFHIP_EPI_NONE, C, PIPE>(p, grid, s);
@@ -901,7 +1015,9 @@ int pick_config(int M, int N, int a_trans, int b_trans) {
 
 }  // namespace
 
+#ifdef CFHIP_ABLATE
 int cfhip_internal_set_attn_ablate(int v);  // attn.hip
+#endif
 
 extern "C" int cfhip_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "gemm_config") == 0) {
@@ -912,15 +1028,13 @@ extern "C" int cfhip_set_option(const char* name, int value) {
     g_gemm_heuristic = value;
     return CFHIP_OK;
   }
-  if (name != nullptr && strcmp(name, "gemm_persistent") == 0) {
-    g_gemm_persistent = value;
-    return CFHIP_OK;
-  }
+#ifdef CFHIP_ABLATE
   if (name != nullptr && strcmp(name, "gemm_ablate") == 0) {
     g_gemm_ablate = value;
     return CFHIP_OK;
   }
   if (name != nullptr && strcmp(name, "attn_ablate") == 0) return cfhip_internal_set_attn_ablate(value);
+#endif
   cfhip_set_error("set_option: unknown option '%s'", name ? name : "(null)");
   return CFHIP_ERR_INVALID;
 }
@@ -941,7 +1055,9 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
   if (epilogue == CFHIP_EPI_DQGELU) epilogue = CFHIP_EPI_DGELU;
   CFHIP_REQUIRE(!(epilogue == CFHIP_EPI_RESIDUAL || epilogue == CFHIP_EPI_DGELU) || aux_in,
                 "gemm: epilogue %d needs aux_in", epilogue);
-  CFHIP_REQUIRE(!accumulate || out_dtype == 1, "gemm: accumulate needs f32 output");
+  CFHIP_REQUIRE(!accumulate || (out_dtype == 1 && epilogue == CFHIP_EPI_NONE), "gemm: accumulate needs f32 output and epilogue NONE");
+  CFHIP_REQUIRE(!(epilogue == CFHIP_EPI_GELU || epilogue == CFHIP_EPI_DGELU) || out_dtype == 0,
+                "gemm: the GELU / GELU' epilogues write bf16");
   CFHIP_REQUIRE(!(a_trans && !b_trans), "gemm: layout (a_trans=1, b_trans=0) is not provided");
   if (split_k < 1) split_k = 1;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -959,7 +1075,9 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
   p.slabs = nullptr;
   p.tiles_m = p.tiles_n = 0;
   p.quick = quick;
+#ifdef CFHIP_ABLATE
   p.ablate = g_gemm_ablate;
+#endif
   p.bgrad = bias_grad;
   p.bgrad_acc = bias_grad_accumulate;
   p.bgrad_slabs = nullptr;
@@ -1087,7 +1205,9 @@ extern "C" int cfhip_conv3x3_nhwc_bf16(const void* X, const void* Wk, const floa
   p.tiles_m = p.tiles_n = 0; p.splits = 1;
   p.bgrad = nullptr; p.bgrad_slabs = nullptr; p.bgrad_acc = 0;
   p.quick = 0;
+#ifdef CFHIP_ABLATE
   p.ablate = 0;
+#endif
   p.conv_h = H; p.conv_w = W; p.conv_c = Cin; p.conv_kpt = Cin / 32;
   p.conv_inv_kpt = 1.0f / (float)p.conv_kpt;
   p.conv_magic_w = p.conv_magic_h = 0u;
@@ -1142,7 +1262,10 @@ extern "C" int cfhip_conv3x3_wgrad_nhwc_bf16(const void* dY, const void* X, floa
   p.lda = Cout; p.ldb = Cin; p.ldc = 9L * Cin;
   p.epilogue = CFHIP_EPI_NONE; p.out_f32 = 1; p.accumulate = 0;
   p.bgrad = bias_grad; p.bgrad_acc = bias_grad_accumulate; p.bgrad_slabs = nullptr;
-  p.quick = 0; p.ablate = 0;
+  p.quick = 0;
+#ifdef CFHIP_ABLATE
+  p.ablate = 0;
+#endif
   p.conv_h = H; p.conv_w = W; p.conv_c = Cin; p.conv_kpt = 0; p.conv_inv_kpt = 0.f;
   p.conv_magic_w = (unsigned)((1ULL << 32) / (unsigned)W + 1ULL);
   p.conv_magic_h = (unsigned)((1ULL << 32) / (unsigned)H + 1ULL);

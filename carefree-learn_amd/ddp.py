@@ -47,8 +47,19 @@ def get_ddp_info() -> Optional[dict]:
 
 
 class BucketedAllReduce:
+    """`average`: True = `finish()` leaves the rank-AVERAGED gradients in the arena (one extra pass over it; what a
+    trainer that clips / inspects gradients between backward and `optimizer.step()` needs); False = the arena holds the
+    SUM and the fused Adam kernel applies 1 / W as its `grad_scale` (engine.TrainStep).  Default: False when a fused
+    optimizer is given, True otherwise.
+    `finish_after_backward`: queue `finish()` as an autograd end-of-backward callback (first gradient notification of
+    a backward pass), so that whatever runs between `backward()` and `optimizer.step()` sees reduced gradients; the
+    explicit `finish()` (optimizer pre-step hook, `TrainStep`) then finds nothing left to do.
+    `sync_fn`: evaluated once per backward pass; False = this pass only accumulates locally (gradient accumulation,
+    reference schema.py:1277-1282) — nothing is launched and `finish()` is a no-op."""
+
     def __init__(self, arena: ParamArena, *, process_group: Any = None, bucket_bytes: int = 64 << 20,
-                 overlap: bool = True, optimizer: Optional[FusedAdam] = None):
+                 overlap: bool = True, optimizer: Optional[FusedAdam] = None, average: Optional[bool] = None,
+                 finish_after_backward: bool = False, sync_fn: Any = None, wire_bf16: bool = False):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("BucketedAllReduce needs an initialised torch.distributed process group")
         self.arena = arena
@@ -56,7 +67,11 @@ class BucketedAllReduce:
         self.world_size = dist.get_world_size(process_group)
         self.overlap = overlap
         self.sync_enabled = True
+        self.sync_fn = sync_fn
         self.optimizer = optimizer
+        self.average = (optimizer is None) if average is None else bool(average)
+        self.finish_after_backward = finish_after_backward
+        self.wire_bf16 = wire_bf16
         self.is_cuda = arena.flat_g.is_cuda
         self.comm_stream = None
         if self.is_cuda:
@@ -84,10 +99,15 @@ class BucketedAllReduce:
         self._ready = [False] * n
         self._direct = [False] * n  # notified by a HIP backward (functional.grad_ready_callbacks)
         self._index = {id(p): i for i, p in enumerate(arena.params)}
+        self._pass_open = False      # a backward pass has notified since the last finish()
+        self._pass_sync = True       # ... and it is a synchronising pass (sync_fn at its first notification)
+        self._wire: Optional[Tensor] = None  # bf16 staging of the gradient arena (wire_bf16)
+        self.exposed_events: List[Any] = []  # (start, end) event pairs around finish()'s waits, when timing is on
+        self.time_exposed = False
         HF.grad_ready_callbacks.append(self._on_direct)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_ready) for p in arena.params]
         if optimizer is not None:
-            optimizer.grad_scale = 1.0 / self.world_size
+            optimizer.grad_scale = 1.0 if self.average else 1.0 / self.world_size
 
     # -- life cycle ---------------------------------------------------------------------------
     def close(self) -> None:
@@ -116,17 +136,34 @@ class BucketedAllReduce:
     def _on_direct(self, p: Tensor) -> None:
         self._on_ready(p, True)
 
+    def _open_pass(self) -> None:
+        """First gradient notification of a backward pass: decide whether this pass synchronises."""
+        self._pass_open = True
+        self._pass_sync = self.sync_fn is None or bool(self.sync_fn())  # `sync_enabled` (no_sync()) is read live
+        if self.finish_after_backward:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+            except RuntimeError:  # not inside a backward pass: the explicit finish() does the work
+                pass
+
+    def _end_of_backward(self) -> None:
+        if self._pass_open and self._pass_sync and self.sync_enabled:
+            self.finish()
+        self._pass_open = False
+
     def _on_ready(self, p: Tensor, direct: bool = False) -> None:
-        if not self.sync_enabled or not self.overlap:
-            return
         i = self._index.get(id(p))
         if i is None:
             return
-        b = self.buckets[self.bucket_of[i]]
+        if not self._pass_open:
+            self._open_pass()
         if not direct and not self._direct[i]:
             # autograd accumulated this gradient: after the trainer's `optimizer.zero_grad()` (set_to_none) it sits
             # in a fresh tensor, not in the arena slot the bucket reduces
             self.arena.adopt_grad(p)
+        if not (self._pass_sync and self.sync_enabled) or not self.overlap:
+            return
+        b = self.buckets[self.bucket_of[i]]
         if direct:
             self._direct[i] = True
         elif self._direct[i]:
@@ -148,6 +185,13 @@ class BucketedAllReduce:
 
     def _launch(self, b: _Bucket) -> None:
         view = self.arena.flat_g[b.start:b.end]
+        if self.wire_bf16:
+            # bf16 on the wire (half the xGMI bytes): round the bucket into a staging arena, reduce that, widen back in
+            # finish().  The sum of W bf16 values is exact in the f32 accumulate RCCL performs per element pair only up
+            # to bf16 rounding of the partial sums — a numerics trade the caller opts into (default off).
+            if self._wire is None:
+                self._wire = torch.empty(self.arena.total, dtype=torch.bfloat16, device=view.device)
+            wire = self._wire[b.start:b.end]
         if self.is_cuda:
             # The bucket's gradients were written by kernels on the current stream AND on the side
             # streams of functional.SideStream (dW GEMMs on one lane, column sums / LayerNorm parameter
@@ -157,48 +201,104 @@ class BucketedAllReduce:
                 if side is not None:
                     self.comm_stream.wait_stream(side)
             with torch.cuda.stream(self.comm_stream):
-                b.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.wire_bf16:
+                    wire.copy_(view)
+                    b.work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                else:
+                    b.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
-            b.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.wire_bf16:
+                wire.copy_(view)
+                b.work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                b.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         b.launched = True
 
     # -- before the optimizer step ----------------------------------------------------------------
     def finish(self) -> None:
-        """Issue whatever has not been issued (unused parameters, overlap=False), then make the
-        compute stream wait for every bucket.  Gradients hold the SUM over ranks afterwards; the
-        1/W factor is applied by the optimizer's grad_scale (or here when there is none)."""
-        if not self.sync_enabled:
+        """Issue whatever has not been issued (unused parameters, overlap=False), then make the compute stream wait
+        for every bucket.  Afterwards the arena holds the rank AVERAGE (`average=True`) or the rank SUM with 1 / W left
+        to the optimizer's grad_scale.  Idempotent within one backward pass: the second call (e.g. the optimizer
+        pre-step hook after the end-of-backward callback) returns at once; a pass that does not synchronise
+        (`no_sync()`, `sync_fn` False) is left untouched."""
+        if not self.sync_enabled or (self._pass_open and not self._pass_sync):
+            self._pass_open = False
             return
+        any_launched = any(b.launched for b in self.buckets)
+        if not self._pass_open and not any_launched and self.overlap:
+            return  # nothing was produced since the last finish()
+        self._pass_open = False
         self.arena.finalize_grads()
         for b in self.buckets:  # fixed order on every rank
             if not b.launched:
                 self._launch(b)
+        ev0 = ev1 = None
+        if self.time_exposed and self.is_cuda:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         for b in self.buckets:
             b.work.wait()
+            if self.wire_bf16:
+                self.arena.flat_g[b.start:b.end].copy_(self._wire[b.start:b.end])
             b.work, b.launched, b.pending = None, False, len(b.param_ids)
+        if ev0 is not None:
+            ev1.record()
+            self.exposed_events.append((ev0, ev1))
         self._ready = [False] * len(self._ready)
         self._direct = [False] * len(self._direct)
-        if self.optimizer is None and self.world_size > 1:
+        if self.average and self.world_size > 1:
             self.arena.flat_g.mul_(1.0 / self.world_size)
+
+    def exposed_ms(self) -> List[float]:
+        """Milliseconds the compute stream spent waiting for the exchange in each `finish()` since the last call (the
+        'all-reduce ms (exposed)' column of BASELINE.md §4); needs `time_exposed = True`.  Synchronises."""
+        out = []
+        for e0, e1 in self.exposed_events:
+            e1.synchronize()
+            out.append(e0.elapsed_time(e1))
+        self.exposed_events = []
+        return out
 
 
 class RcclDDPCallback:
     """Trainer-side seam (no trainer edits): duck-typed `TrainerCallback` whose `before_loop(trainer)`
     (reference trainer.py:312-313, schema.py:1755) re-homes the model's parameters into an arena,
-    installs the bucketed all-reduce and broadcasts rank 0's weights; the optimizer pre-step hook
-    waits for the exchange.  Registration under the reference: see INTEGRATION.md."""
+    installs the bucketed all-reduce and broadcasts rank 0's weights.
+
+    Ordering inside the reference's update (schema.py:977-986): `accelerator.backward(loss)` ->
+    `trainer.clip_norm_step()` -> `optimizer.step()`.  Gradient clipping reads AND rescales the gradients, so the
+    exchange must be complete — and averaged — when backward returns: `finish()` is queued as an end-of-backward
+    callback and leaves the rank average in the arena; the optimizer pre-step hook stays as an idempotent fallback.
+    Gradient accumulation (schema.py:1277-1282: update iff `state.step % grad_accumulate == 0`): passes that do not
+    update only accumulate locally; the update pass reduces the accumulated sum once."""
 
     def __init__(self, bucket_bytes: int = 64 << 20):
         self.bucket_bytes = bucket_bytes
         self.reducer: Optional[BucketedAllReduce] = None
+
+    @staticmethod
+    def _sync_fn(trainer: Any) -> Any:
+        def is_update_pass() -> bool:
+            state = getattr(trainer, "state", None)
+            config = getattr(trainer, "config", None)
+            if state is None:
+                return True
+            steps = getattr(getattr(trainer, "model", None), "train_steps", None) or [None]
+            for ts in steps:
+                ga = getattr(ts, "grad_accumulate", None) or getattr(config, "grad_accumulate", 1) or 1
+                if state.step % ga == 0:
+                    return True
+            return False
+
+        return is_update_pass
 
     def before_loop(self, trainer: Any) -> None:
         if get_ddp_info() is None or not dist.is_initialized():
             return
         params = [p for p in trainer.model.m.parameters() if p.requires_grad]
         inners = [getattr(opt, "optimizer", opt) for opt in trainer.optimizers.values()]  # accelerate wraps the torch one
-        # an optimizer that already owns the arena (optim.FusedAdamOptimizer): reduce ITS gradient buffer and let its
-        # kernel apply the 1 / W; otherwise re-home the parameters here and average in finish()
+        # an optimizer that already owns the arena (optim.FusedAdamOptimizer): reduce ITS gradient buffer;
+        # otherwise re-home the parameters here
         arena, fused = None, None
         for inner in inners:
             a = getattr(inner, "arena", None)
@@ -206,8 +306,16 @@ class RcclDDPCallback:
                 arena, fused = a, getattr(inner, "fused", None)
                 break
         if arena is None:
+            owned = [p for p in params if getattr(p, "_cfhip_arena", None) is not None]
+            if owned:
+                raise RuntimeError(
+                    f"RcclDDPCallback: {len(owned)} of the model's {len(params)} trainable parameters already live in "
+                    "another ParamArena (several fused optimizers / scopes, or a frozen subset): re-homing them would "
+                    "detach the fused Adam kernel from the buffers it updates.  Use one FusedAdam(W)Optimizer over "
+                    "all trainable parameters, or a torch optimizer")
             arena = ParamArena(params, with_shadow=True)
-        self.reducer = BucketedAllReduce(arena, bucket_bytes=self.bucket_bytes, optimizer=fused)
+        self.reducer = BucketedAllReduce(arena, bucket_bytes=self.bucket_bytes, optimizer=fused, average=True,
+                                         finish_after_backward=True, sync_fn=self._sync_fn(trainer))
         self.reducer.broadcast_parameters(0)
         for inner in inners:
             inner.register_step_pre_hook(lambda *_a, **_k: self.reducer.finish())

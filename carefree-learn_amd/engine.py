@@ -23,19 +23,21 @@ from torch import Tensor
 from . import ops
 from .functional import SideStream
 from .ddp import BucketedAllReduce
-from .optim import FusedAdam, ParamArena
+from .optim import FusedAdam, ParamArena, clip_grad_norm_
 
 
 class TrainStep:
     def __init__(self, model: torch.nn.Module, *, lr: float = 1.0e-4, betas: Any = (0.9, 0.999),
                  eps: float = 1.0e-8, weight_decay: float = 0.0, decoupled: bool = True,
                  use_graph: bool = False, distributed: bool = False, bucket_bytes: int = 64 << 20,
-                 output_key: str = "predictions", loss: str = "cross_entropy"):
+                 output_key: str = "predictions", loss: str = "cross_entropy", clip_norm: float = 0.0):
         if loss not in ("cross_entropy", "focal"):
             raise ValueError(f"unknown loss '{loss}' (cross_entropy: losses/basic.py:126-141, focal: :170-206)")
         self.model = model
         self.output_key = output_key
         self.loss = loss
+        self.clip_norm = float(clip_norm)  # reference TrainerConfig.clip_norm (trainer.py:170-176); 0 = off
+        self.grad_norm: Optional[Tensor] = None  # device scalar of the last clipped step
         params = [p for p in model.parameters() if p.requires_grad]
         self.arena = ParamArena(params, with_shadow=True)
         self.optimizer = FusedAdam(None, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
@@ -65,6 +67,8 @@ class TrainStep:
         SideStream.join()  # parameter-gradient kernels ran on the side stream
         if self.reducer is not None:
             self.reducer.finish()
+        if self.clip_norm > 0.0:
+            self.grad_norm = clip_grad_norm_(self.arena, self.clip_norm, self.optimizer)  # device-side, no host read
         self.optimizer.launch_step()
         return loss_sum
 

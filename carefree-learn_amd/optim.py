@@ -128,7 +128,8 @@ class FusedAdam:
         self.param_groups = [dict(params=self.arena.params, **self.defaults)]
         self.decoupled = decoupled
         self.step_count = 0
-        self.grad_scale = 1.0
+        self.grad_scale = 1.0   # persistent factor on the gradients (1 / W when the arena holds the rank SUM)
+        self._step_clip: Optional[Tensor] = None  # device scalar, ONE step only: the clipping coefficient
         self.lazy_zero = False  # see ParamArena.zero_grad
         a = self.arena
         self.exp_avg = torch.zeros_like(a.flat_p)
@@ -171,12 +172,23 @@ class FusedAdam:
             ev.record()
             self._hyper_events[self.step_count % _HYPER_RING] = ev
 
+    def set_step_clip(self, coef: Tensor) -> None:
+        """Gradient clipping for the NEXT `launch_step()` only: `coef` is a device scalar (<= 1) that multiplies the
+        persistent `grad_scale` inside this step's hyper-parameter record ON THE DEVICE — no host read of the norm,
+        nothing carried over to later steps (round 1 folded it into `grad_scale` itself: it compounded)."""
+        self._step_clip = coef.reshape(1).to(f32)
+
     def launch_step(self) -> None:
         a = self.arena
         a.finalize_grads()
         if not a.flat_p.is_cuda:
             raise RuntimeError("FusedAdam: the arena must live on the HIP device (no CPU fallback)")
         from . import _lib
+
+        if self._step_clip is not None:
+            # after the upload of prepare_step() in stream order, before the kernel reads the record
+            self._hyper_dev[7:8].copy_(self._step_clip * float(self.grad_scale))
+            self._step_clip = None
 
         rc = _lib.load().cfhip_adam_step_dev(
             a.flat_p.data_ptr(), a.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
@@ -253,17 +265,20 @@ class FusedAdamWOptimizer(FusedAdamOptimizer):
 
 
 def clip_grad_norm_(arena: ParamArena, max_norm: float, optimizer: Optional[FusedAdam] = None) -> Tensor:
-    """Global L2 clipping on the gradient arena (reference trainer.py:170-176 semantics).  With an
-    optimizer the clip coefficient is folded into the Adam kernel's grad_scale (needs one host
-    read of the norm, like accelerate's clip_grad_norm_)."""
+    """Global L2 clipping on the gradient arena (reference trainer.py:170-176: `accelerator.clip_grad_norm_` when
+    `clip_norm > 0`).  Returns the norm as a DEVICE scalar and never reads it on the host (accelerate's version
+    synchronises every step).  The norm is that of the gradients the update will see: when the arena holds the rank
+    SUM and the optimizer applies 1 / W (`grad_scale`), the sum's norm is scaled by it.  With an optimizer the
+    coefficient min(1, max_norm / (norm + 1e-6)) — torch's formula — rides in this ONE step's hyper-parameter record
+    (`FusedAdam.set_step_clip`); without one the arena is scaled in place."""
     arena.finalize_grads()
-    total = ops.sumsq(arena.flat_g).sqrt()
-    coef = float(max_norm) / (float(total) + 1.0e-6)
-    if coef < 1.0:
-        if optimizer is not None:
-            optimizer.grad_scale *= coef
-        else:
-            arena.flat_g.mul_(coef)
+    base = float(optimizer.grad_scale) if optimizer is not None else 1.0
+    total = ops.sumsq(arena.flat_g).sqrt() * base
+    coef = (float(max_norm) / (total + 1.0e-6)).clamp(max=1.0)
+    if optimizer is not None:
+        optimizer.set_step_clip(coef)
+    else:
+        arena.flat_g.mul_(coef)
     return total
 
 
@@ -343,6 +358,12 @@ class EMA(torch.nn.Module):
                 if name not in self._cache:
                     self._cache[name] = param.data.clone()
                 param.data.copy_(getattr(self, name))
+        # the forward kernels read bf16 copies of the weights, cached on `param._version` — which `.data.copy_()` does
+        # not bump: refresh the arena's shadows in one pass, invalidate every other cached shadow
         if self._arena is not None and self._arena.flat_p.is_cuda:
-            self._arena.refresh_shadow()  # the forward kernels read the bf16 copies of the weights
+            self._arena.refresh_shadow()
+        else:
+            for _, param in self.tgt_params:
+                if hasattr(param, "_cfhip_shadow_version"):
+                    param._cfhip_shadow_version = None
         return self

@@ -42,9 +42,9 @@ const char* cfhip_last_error(void);
  *                     (0: 128x128x64, 1: 128x128x32, 3: 128x64x64, 7: 256x256x32 two-group kernel,
  *                      8: 256x128x32 two-group kernel, ...; see csrc/gemm.hip)
  *   "gemm_heuristic"  0..5, which shape -> configuration table pick_config() uses (default 5)
- *   "gemm_persistent" 0/1, persistent grid for the 128-class kernels (default 0)
- *   "gemm_ablate" / "attn_ablate"  bit masks that skip DMA / MFMA / stores — results are then WRONG,
- *                     for timing the phases of a kernel only (tools/gemm_ablate.py, tools/attn_bench.py) */
+ * Unknown names are an error.  (The phase-timing ablation masks "gemm_ablate" / "attn_ablate" of round 1 are
+ * not part of this library any more: they exist only in the -DCFHIP_ABLATE build that tools/build_variant.sh
+ * writes to tools/libcfhip_ablate.so, selected by the tools through CFHIP_LIB.) */
 int cfhip_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------

@@ -325,7 +325,7 @@ def _callback_fused_worker(rank: int, world: int, port: int, out: str) -> None:
     cb = RcclDDPCallback(bucket_bytes=256)
     cb.before_loop(trainer)
     assert cb.reducer.arena is opt.arena            # the optimizer's own arena is the one that is reduced
-    assert opt.fused.grad_scale == 1.0 / world      # and its kernel applies the 1 / W
+    assert opt.fused.grad_scale == 1.0              # the callback leaves the rank AVERAGE in the arena (clipping reads it)
     opt.zero_grad()
     torch.manual_seed(100)
     x, y = torch.randn(8, 6), torch.randn(8, 3)
@@ -346,10 +346,90 @@ def test_trainer_callback_reuses_the_fused_optimizers_arena(tmp_path):
     mp.spawn(_callback_fused_worker, args=(world, port, out), nprocs=world, join=True)
     r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
     assert torch.equal(r0["p"], r1["p"])  # broadcast from rank 0
-    assert torch.equal(r0["g"], r1["g"])  # SUM over the ranks (the Adam kernel scales by 1 / W)
+    assert torch.equal(r0["g"], r1["g"])  # the rank average, already in the arena when backward() returned
     model = _model()
     torch.manual_seed(100)
     x, y = torch.randn(8, 6), torch.randn(8, 3)
     ((model(x) - y) ** 2).mean().backward()
     flat = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1), (0, (-p.numel()) % 8)) for p in model.parameters()])
-    assert (r0["g"] / world - flat).abs().max() < 1e-6
+    assert (r0["g"] - flat).abs().max() < 1e-6
+
+
+def _callback_clip_accum_worker(rank: int, world: int, port: int, out: str, clip: float, accumulate: int) -> None:
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cflearn_amd.ddp import RcclDDPCallback
+
+    model = _model()
+
+    class _Obj:
+        pass
+
+    trainer = _Obj()
+    trainer.model = _Obj()
+    trainer.model.m = model
+    step_obj = _Obj()
+    step_obj.grad_accumulate = None
+    trainer.model.train_steps = [step_obj]
+    trainer.state = _Obj()
+    trainer.state.step = 0
+    trainer.config = _Obj()
+    trainer.config.grad_accumulate = accumulate
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    trainer.optimizers = {"all": opt}
+    cb = RcclDDPCallback(bucket_bytes=256)
+    cb.before_loop(trainer)
+    torch.manual_seed(100)
+    launches = []
+    orig = cb.reducer._launch
+    cb.reducer._launch = lambda b: (launches.append(trainer.state.step), orig(b))[1]
+    for it in range(4):  # the reference's update (schema.py:977-986, 1277-1282): backward; if update: clip, step, zero
+        trainer.state.step += 1
+        x, y = torch.randn(8, 6), torch.randn(8, 3)
+        ((model(x[rank * 4:(rank + 1) * 4]) - y[rank * 4:(rank + 1) * 4]) ** 2).mean().backward()
+        if trainer.state.step % accumulate == 0:
+            if clip > 0:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), clip)  # what accelerator.clip_grad_norm_ runs
+            opt.step()
+            opt.zero_grad()
+    torch.save(dict(p=[p.detach().clone() for p in model.parameters()], launches=launches), f"{out}.{rank}")
+    cb.reducer.close()
+    dist.destroy_process_group()
+
+
+def _single_process_clip_accum(clip: float, accumulate: int):
+    model = _model()
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    torch.manual_seed(100)
+    for it in range(1, 5):
+        x, y = torch.randn(8, 6), torch.randn(8, 3)
+        ((model(x) - y) ** 2).mean().backward()
+        if it % accumulate == 0:
+            if clip > 0:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+            opt.step()
+            opt.zero_grad()
+    return [p.detach() for p in model.parameters()]
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("clip,accumulate", [(0.05, 1), (0.0, 2), (0.05, 2)])
+def test_trainer_callback_clipping_and_accumulation(tmp_path, clip, accumulate):
+    """with clip_norm > 0 the reference clips between backward and optimizer.step — the exchange must be
+    complete and AVERAGED by then (end-of-backward finish); with grad_accumulate > 1 only the update pass reduces."""
+    world, port = 2, _free_port()
+    out = str(tmp_path / "cca")
+    mp.spawn(_callback_clip_accum_worker, args=(world, port, out, clip, accumulate), nprocs=world, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    for a, b in zip(r0["p"], r1["p"]):
+        assert torch.equal(a, b)
+    want = _single_process_clip_accum(clip, accumulate)
+    for a, w in zip(r0["p"], want):
+        assert (a - w).abs().max() < 1e-6
+    # all-reduces were launched on update passes only
+    assert r0["launches"] and all(s % accumulate == 0 for s in r0["launches"])

@@ -89,6 +89,51 @@ def test_grad_clip_and_lazy_zero(golden):
     assert_close(ts.arena.flat_g, snap, 1e-6, "lazy zero_grad")
 
 
+def test_grad_clip_is_applied_to_this_step_only(golden):
+    """the clip coefficient must act on the CURRENT step (the hyper record is uploaded before backward) and
+    must not compound into later steps.  Adam's first moment is linear in the gradient: after step t,
+    m_t - beta1 * m_{t-1} = (1 - beta1) * clip(g_t), whose norm is (1 - beta1) * max_norm whenever |g_t| > max_norm."""
+    g, m = _small(golden)
+    max_norm, b1 = 0.05, 0.9
+    ts = TrainStep(m, lr=1e-5, betas=(b1, 0.999), clip_norm=max_norm)
+    img, labels = g["img"].to(DEV), g["labels"].view(-1).to(DEV)
+    prev = torch.zeros_like(ts.optimizer.exp_avg)
+    for step in range(3):
+        ts.step(img, labels)
+        total = ts.grad_norm.item()
+        assert total > 4 * max_norm, total  # the clip is active in every step
+        delta = (ts.optimizer.exp_avg - b1 * prev).norm().item() / (1 - b1)
+        assert abs(delta - max_norm) <= 2e-3 * max_norm, (step, delta, max_norm)
+        prev = ts.optimizer.exp_avg.clone()
+    assert ts.optimizer.grad_scale == 1.0
+
+
+def test_ema_eval_swaps_the_weights_the_kernels_read():
+    """EMA.eval() / .train() swap `param.data` (no `_version` bump): without an arena the cached bf16
+    shadows went stale and eval silently ran on the non-EMA weights."""
+    from cflearn_amd.optim import EMA
+
+    torch.manual_seed(0)
+    lin = C.Linear(64, 32).to(DEV)
+    x = torch.randn(16, 64, device=DEV)
+    named = list(lin.named_parameters())
+    ema = EMA(0.5, named).to(DEV)
+    y0 = lin(x).float().clone()  # caches the bf16 shadow of the initial weights
+    with torch.no_grad():
+        for _, p in named:
+            p.add_(0.5)  # in-place: bumps _version, the training-time path
+    ema.train()
+    ema()  # ema = 0.5 * old + 0.5 * new
+    y_new = lin(x).float().clone()
+    ema.eval()  # weights <- EMA (param.data.copy_)
+    y_ema = lin(x).float().clone()
+    ema.train()  # weights <- cached training weights
+    y_back = lin(x).float().clone()
+    assert (y_new - y0).abs().max() > 1.0
+    assert_close(y_ema, 0.5 * (y0 + y_new), 2e-2, "EMA weights are the ones eval runs on")
+    assert torch.equal(y_back, y_new)
+
+
 def test_ema_one_kernel_bit_exact():
     """optim.EMA (reference modules/common.py:102-162): buffer names, num_updates decay rule, train/eval swap; the
     update over the arena is one kernel and bit-equal to the reference expression in fp32."""
