@@ -1018,6 +1018,7 @@ int pick_config(int M, int N, int a_trans, int b_trans) {
 #ifdef CFHIP_ABLATE
 int cfhip_internal_set_attn_ablate(int v);  // attn.hip
 #endif
+int cfhip_internal_set_ln_fused(int v);  // norm.hip
 
 extern "C" int cfhip_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "gemm_config") == 0) {
@@ -1028,6 +1029,7 @@ extern "C" int cfhip_set_option(const char* name, int value) {
     g_gemm_heuristic = value;
     return CFHIP_OK;
   }
+  if (name != nullptr && strcmp(name, "ln_bwd_fused") == 0) return cfhip_internal_set_ln_fused(value);
 #ifdef CFHIP_ABLATE
   if (name != nullptr && strcmp(name, "gemm_ablate") == 0) {
     g_gemm_ablate = value;

@@ -261,6 +261,173 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
   for (int i = threadIdx.x; i < 2 * D; i += LN_THREADS) out[i] = red[i];
 }
 
+// ---- fused backward, one launch: dx (+ residual-gradient add) AND the dgamma / dbeta partials -------------------
+// Reads dy and x exactly once.  A HALF-wave (32 lanes) owns a row, so a wave works on two rows at a time and every
+// lane owns G groups of 8 consecutive columns (col = g * 256 + 8 * (lane & 31)): every bf16 access is a 16-byte
+// load / store (one instruction = 512 contiguous bytes per row), every f32 access two of them — the 8-byte accesses
+// of the one-wave-per-row kernel above run at 0.55-0.7x the 16-byte rate (MI355X_MICROARCH.md).  dgamma / dbeta
+// stay in registers across all rows a lane visits (lanes l and l + 32 own the same columns and are folded with one
+// shuffle at the end), the workgroup's waves are folded through LDS in a FIXED order and the per-workgroup partial
+// rows go to the same column reduce as before: no atomics anywhere, bitwise reproducible.
+constexpr int LN2_WAVES = 4;
+constexpr int LN2_THREADS = LN2_WAVES * 64;
+constexpr int LN2_MAX_BLOCKS = 768;  // 3 workgroups of 4 waves per CU (160 VGPRs at D = 768)
+
+// sum over the 32 lanes of each half-wave; every lane gets its own half's total
+__device__ __forceinline__ float half_sum_dpp(float v, int half) {
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  v = dpp_add<0x140>(v);  // every lane holds its 16-lane row total
+  const int iv = __float_as_int(v);
+  const float t0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+  const float t1 = __int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+  return half ? t1 : t0;
+}
+
+template <typename XT> struct Row8;
+template <> struct Row8<bf16_t> {
+  u32x4 w;
+  __device__ __forceinline__ void load(const bf16_t* p) { w = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ void zero() { w = u32x4{0u, 0u, 0u, 0u}; }
+  __device__ __forceinline__ void get(float (&v)[8]) const {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = bf16lo(w[e]); v[2 * e + 1] = bf16hi(w[e]); }
+  }
+};
+template <> struct Row8<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const f32x4*>(p);
+    b = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  __device__ __forceinline__ void zero() { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }
+  __device__ __forceinline__ void get(float (&v)[8]) const {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+  }
+};
+
+template <int G, typename XT>
+__global__ __launch_bounds__(LN2_THREADS) void layernorm_bwd_fused_kernel(
+    const bf16_t* __restrict__ dy, const XT* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+    const bf16_t* __restrict__ dx_add, bf16_t* __restrict__ dx, float* __restrict__ partials, int M,
+    long dys, long xs, long dxs) {
+  constexpr int D = G * 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // gamma [D] | red [LN2_WAVES][2][D]
+  float* gs = lds;
+  float* red = lds + D;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int hl = lane & 31, half = lane >> 5;
+  for (int i = threadIdx.x; i < D; i += LN2_THREADS) gs[i] = gamma[i];
+  __syncthreads();
+
+  float dg[G][8], db[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dg[g][e] = 0.f; db[g][e] = 0.f; }
+
+  const float inv_d = 1.0f / (float)D;
+  const int npairs = (M + 1) >> 1;
+  const int nw = gridDim.x * LN2_WAVES;
+  for (int pair = blockIdx.x * LN2_WAVES + wave; pair < npairs; pair += nw) {
+    const int row = 2 * pair + half;
+    const bool ok = row < M;
+    Row8<XT> rx[G];
+    u32x4 ry[G], ra[G];
+    float mean = 0.f, rstd = 0.f;
+    if (ok) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int col = g * 256 + hl * 8;
+        rx[g].load(x + (long)row * xs + col);
+        ry[g] = *reinterpret_cast<const u32x4*>(dy + (long)row * dys + col);
+        ra[g] = dx_add != nullptr ? *reinterpret_cast<const u32x4*>(dx_add + (long)row * dxs + col) : u32x4{0u, 0u, 0u, 0u};
+      }
+      mean = mean_in[row];
+      rstd = rstd_in[row];
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; ++g) { rx[g].zero(); ry[g] = u32x4{0u, 0u, 0u, 0u}; ra[g] = ry[g]; }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float xv[8];
+      rx[g].get(xv);
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gs + g * 256 + hl * 8);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(gs + g * 256 + hl * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dv = (e & 1) ? bf16hi(ry[g][e >> 1]) : bf16lo(ry[g][e >> 1]);
+        const float xh = (xv[e] - mean) * rstd;  // 0 for an absent row (mean = rstd = x = 0)
+        const float gg = dv * (e < 4 ? g0[e] : g1[e - 4]);
+        s1 += gg;
+        s2 += gg * xh;
+        dg[g][e] += dv * xh;
+        db[g][e] += dv;
+      }
+    }
+    s1 = half_sum_dpp(s1, half) * inv_d;
+    s2 = half_sum_dpp(s2, half) * inv_d;
+    if (ok) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float xv[8], o[8];
+        rx[g].get(xv);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gs + g * 256 + hl * 8);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gs + g * 256 + hl * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dv = (e & 1) ? bf16hi(ry[g][e >> 1]) : bf16lo(ry[g][e >> 1]);
+          const float av = (e & 1) ? bf16hi(ra[g][e >> 1]) : bf16lo(ra[g][e >> 1]);
+          const float xh = (xv[e] - mean) * rstd;
+          o[e] = rstd * (dv * (e < 4 ? g0[e] : g1[e - 4]) - s1 - xh * s2) + av;
+        }
+        *reinterpret_cast<u32x4*>(dx + (long)row * dxs + g * 256 + hl * 8) =
+            u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+      }
+    }
+  }
+  // lanes l and l + 32 own the same columns: fold them, then the waves of the workgroup in a fixed order
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dg[g][e] += __shfl_xor(dg[g][e], 32, 64);
+      db[g][e] += __shfl_xor(db[g][e], 32, 64);
+    }
+  if (half == 0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float* r0 = red + (wave * 2 + 0) * D + g * 256 + hl * 8;
+      float* r1 = red + (wave * 2 + 1) * D + g * 256 + hl * 8;
+      *reinterpret_cast<f32x4*>(r0) = f32x4{dg[g][0], dg[g][1], dg[g][2], dg[g][3]};
+      *reinterpret_cast<f32x4*>(r0 + 4) = f32x4{dg[g][4], dg[g][5], dg[g][6], dg[g][7]};
+      *reinterpret_cast<f32x4*>(r1) = f32x4{db[g][0], db[g][1], db[g][2], db[g][3]};
+      *reinterpret_cast<f32x4*>(r1 + 4) = f32x4{db[g][4], db[g][5], db[g][6], db[g][7]};
+    }
+  }
+  __syncthreads();
+  float* out = partials + (long)blockIdx.x * 2 * D;
+  for (int i = threadIdx.x; i < 2 * D; i += LN2_THREADS) {
+    float v = red[i];  // wave 0: [dgamma | dbeta]
+#pragma unroll
+    for (int w = 1; w < LN2_WAVES; ++w) v += red[w * 2 * D + i];
+    out[i] = v;
+  }
+}
+
+inline int ln2_grid(int M) {
+  const int pairs = (M + 1) / 2;
+  const int iters = (pairs + LN2_MAX_BLOCKS * LN2_WAVES - 1) / (LN2_MAX_BLOCKS * LN2_WAVES);
+  int blocks = (pairs + LN2_WAVES * iters - 1) / (LN2_WAVES * iters);
+  return blocks < 1 ? 1 : blocks;
+}
+
 inline int ln_grid(int M, int cap = 512) {
   int blocks = (M + LN_WAVES - 1) / LN_WAVES;
   if (blocks > cap) blocks = cap;  // 512 = 2 workgroups of 8 waves per CU
@@ -311,7 +478,14 @@ extern "C" int cfhip_layernorm_fwd(const void* x, int x_is_f32, const float* gam
 }
 
 extern "C" size_t cfhip_layernorm_bwd_workspace(int M, int D) {
-  return (size_t)ln_grid(M) * 2 * (size_t)D * sizeof(float);
+  const int rows = ln_grid(M) > ln2_grid(M) ? ln_grid(M) : ln2_grid(M);  // either kernel may be picked
+  return (size_t)rows * 2 * (size_t)D * sizeof(float);
+}
+
+static int g_ln_fused = 1;  // "ln_bwd_fused" option: 1 = the one-launch kernel when both outputs are asked for (default)
+int cfhip_internal_set_ln_fused(int v) {
+  g_ln_fused = v;
+  return CFHIP_OK;
 }
 
 extern "C" int cfhip_layernorm_bwd(const void* dy, const void* x, int x_is_f32, const float* gamma,
@@ -338,8 +512,46 @@ extern "C" int cfhip_layernorm_bwd(const void* dy, const void* x, int x_is_f32, 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int nch = (D + 255) / 256;
   const bool exact = (D % 256) == 0;
-  const int blocks = ln_grid(M, do_pg ? 512 : 1024);  // dx-only: fewer registers, twice the waves
   float* partials = reinterpret_cast<float*>(workspace);
+  // one launch for both outputs: D a multiple of 256 up to 1280, 16-byte aligned rows
+  const bool fused_ok = g_ln_fused && do_dx && do_pg && exact && nch <= 5 && dy_row_stride % 8 == 0 && dx_row_stride % 8 == 0 &&
+                        x_row_stride % (x_is_f32 ? 4 : 8) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0 &&
+                        ((uintptr_t)dx & 15) == 0 && ((uintptr_t)dx_add & 15) == 0;
+  if (fused_ok) {
+    const int blocks2 = ln2_grid(M);
+    const size_t lds2 = (size_t)(1 + 2 * LN2_WAVES) * D * sizeof(float);
+#define LN_BWD2(G_)                                                                                                  \
+  do {                                                                                                               \
+    if (x_is_f32)                                                                                                    \
+      hipLaunchKernelGGL((layernorm_bwd_fused_kernel<G_, float>), dim3(blocks2), dim3(LN2_THREADS), lds2, s,         \
+                         (const bf16_t*)dy, (const float*)x, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx,  \
+                         partials, M, (long)dy_row_stride, (long)x_row_stride, (long)dx_row_stride);                 \
+    else                                                                                                             \
+      hipLaunchKernelGGL((layernorm_bwd_fused_kernel<G_, bf16_t>), dim3(blocks2), dim3(LN2_THREADS), lds2, s,        \
+                         (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, \
+                         partials, M, (long)dy_row_stride, (long)x_row_stride, (long)dx_row_stride);                 \
+  } while (0)
+    switch (nch) {
+      case 1: LN_BWD2(1); break;
+      case 2: LN_BWD2(2); break;
+      case 3: LN_BWD2(3); break;
+      case 4: LN_BWD2(4); break;
+      default: LN_BWD2(5); break;
+    }
+#undef LN_BWD2
+    CFHIP_CHECK_LAUNCH("layernorm_bwd_fused");
+    if (dgamma != nullptr && dbeta == dgamma + D)
+      return cfhip_internal_colreduce_f32(partials, blocks2, 2 * D, dgamma, accumulate_param_grads, s);
+    int rc = cfhip_internal_colreduce_f32(partials, blocks2, 2 * D, partials, 0, s);
+    if (rc != CFHIP_OK) return rc;
+    if (dgamma != nullptr) {
+      rc = cfhip_internal_colreduce_f32(partials, 1, D, dgamma, accumulate_param_grads, s);
+      if (rc != CFHIP_OK) return rc;
+    }
+    if (dbeta != nullptr) rc = cfhip_internal_colreduce_f32(partials + D, 1, D, dbeta, accumulate_param_grads, s);
+    return rc;
+  }
+  const int blocks = ln_grid(M, do_pg ? 512 : 1024);  // dx-only: fewer registers, twice the waves
   const size_t lds = do_pg ? (size_t)2 * D * sizeof(float) : 0;
 #define LN_BWD_ONE(N_, EX_, XT_, DX_, PG_)                                                               \
   hipLaunchKernelGGL((layernorm_bwd_kernel<N_, EX_, XT_, DX_, PG_>), dim3(blocks), dim3(LN_THREADS), lds, \

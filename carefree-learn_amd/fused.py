@@ -60,7 +60,7 @@ def _dw_db(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> None:
             cb(prm)
 
 
-SPLIT_LN_BWD = True
+SPLIT_LN_BWD = False  # round 2: ONE launch (half-wave-per-row kernel, dy and x read once) beats dx on the main stream + dgamma/dbeta on the side stream by 0.5 ms / step (profiles/r02/step_ab_ln_b128.log)
 
 
 def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: Tensor,

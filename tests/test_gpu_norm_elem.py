@@ -143,9 +143,49 @@ def test_layernorm_bwd_split_modes():
     _, mean, rstd = ops.layernorm_fwd(x, w, b, 1e-6)
     dx_all, dg_all, db_all = ops.layernorm_bwd(dy, x, w, mean, rstd, dx_add=dy)
     dx_only, none1, none2 = ops.layernorm_bwd(dy, x, w, mean, rstd, dx_add=dy, want_param_grads=False)
-    assert none1 is None and none2 is None and torch.equal(dx_only, dx_all)
+    assert none1 is None and none2 is None
+    # (the combined launch is the half-wave-per-row kernel: other summation order than the dx-only kernel)
+    assert_close(dx_only, dx_all, 2e-3, "dx split")
     pg = torch.zeros(2 * d, device=DEV)
     nodx, _, _ = ops.layernorm_bwd(dy, x, w, mean, rstd, dgamma=pg[:d], dbeta=pg[d:], want_dx=False)
     assert nodx is None
     assert_close(pg[:d], dg_all, 1e-5, "dgamma split")
     assert_close(pg[d:], db_all, 1e-5, "dbeta split")
+
+
+@pytest.mark.parametrize("m,d,xf32", [(25216, 768, True), (1001, 768, False), (7, 256, True), (130, 512, False),
+                                      (999, 1024, True), (513, 1280, True), (1, 768, True)])
+def test_layernorm_bwd_one_launch(m, d, xf32):
+    """The one-launch backward (dx + dgamma / dbeta, dy and x read once; reference norms.py:88-119 = nn.LayerNorm):
+    vs torch autograd in fp32, vs the round-1 kernels (option ln_bwd_fused = 0), and bitwise run-to-run."""
+    g = torch.Generator().manual_seed(m * 7 + d)
+    x = torch.randn(m, d, generator=g) * 2 + 0.5
+    if not xf32:
+        x = x.to(torch.bfloat16)
+    w = torch.randn(d, generator=g) * 0.2 + 1
+    b = torch.randn(d, generator=g) * 0.2
+    dy = torch.randn(m, d, generator=g).to(torch.bfloat16)
+    add = torch.randn(m, d, generator=g).to(torch.bfloat16)
+    xr = x.float().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (d,), wr, br, 1e-6).backward(dy.float())
+    xd, wd, bd, dyd, addd = x.to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV), add.to(DEV)
+    _, mean, rstd = ops.layernorm_fwd(xd, wd, bd, 1e-6)
+    pg = torch.full((2 * d,), 0.5, device=DEV)
+    dx, _, _ = ops.layernorm_bwd(dyd, xd, wd, mean, rstd, dx_add=addd, dgamma=pg[:d], dbeta=pg[d:], accumulate=True)
+    assert_close(dx, xr.grad + add.float(), 5e-3, "dx + add")
+    assert_close(pg[:d], wr.grad + 0.5, 2e-4, "dgamma (+=)", abs_floor=1e-4)
+    assert_close(pg[d:], br.grad + 0.5, 2e-4, "dbeta (+=)", abs_floor=1e-4)
+    # bitwise reproducible: no atomics anywhere
+    pg2 = torch.full((2 * d,), 0.5, device=DEV)
+    dx2, _, _ = ops.layernorm_bwd(dyd, xd, wd, mean, rstd, dx_add=addd, dgamma=pg2[:d], dbeta=pg2[d:], accumulate=True)
+    assert torch.equal(dx, dx2) and torch.equal(pg, pg2)
+    # the round-1 path on the same inputs
+    ops.set_option("ln_bwd_fused", 0)
+    try:
+        dx0, dg0, db0 = ops.layernorm_bwd(dyd, xd, wd, mean, rstd, dx_add=addd)
+    finally:
+        ops.set_option("ln_bwd_fused", 1)
+    assert_close(dx, dx0, 2e-3, "dx vs round-1 kernel")
+    assert_close(pg[:d] - 0.5, dg0, 1e-4, "dgamma vs round-1 kernel", abs_floor=1e-4)
+    assert_close(pg[d:] - 0.5, db0, 1e-4, "dbeta vs round-1 kernel", abs_floor=1e-4)

@@ -18,13 +18,15 @@ img = torch.randn(BATCH, 3, 224, 224, generator=g).to(dev)
 labels = torch.randint(0, 1000, (BATCH,), generator=g).to(dev)
 
 VARIANTS = {
-    "shipped": dict(split_ln=True),
-    "LN backward in one launch on the main stream": dict(split_ln=False),
+    "LN bwd split: dx main stream, dgamma/dbeta side stream (round 1)": dict(split_ln=True, fused=1),
+    "LN bwd ONE launch, half-wave-per-row kernel": dict(split_ln=False, fused=1),
+    "LN bwd one launch, round-1 one-wave-per-row kernel": dict(split_ln=False, fused=0),
 }
 
 def apply(v):
     from cflearn_amd import fused
     fused.SPLIT_LN_BWD = v["split_ln"]
+    ops.set_option("ln_bwd_fused", v["fused"])
 
 
 def run(n):
@@ -43,4 +45,4 @@ for rnd in range(5):
         apply(v)
         res[k].append(run(10))
 for k, v in res.items():
-    print(f"{k:28s} median {statistics.median(v):7.3f} ms  min {min(v):7.3f}  all {[round(x, 2) for x in v]}")
+    print(f"{k:68s} median {statistics.median(v):7.3f} ms  min {min(v):7.3f}  all {[round(x, 2) for x in v]}")
