@@ -16,6 +16,7 @@ from .registry import (  # noqa: F401
     PrefixModules,
     build_module,
     module_dict,
+    override_reference_registry,
     register_module,
 )
 from .modules import (  # noqa: F401

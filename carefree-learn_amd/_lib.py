@@ -5,7 +5,7 @@ this file.  There is NO fallback: if it is missing or a call fails, a RuntimeErr
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_uint64, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -118,6 +118,12 @@ SIGNATURES = {
     "cfhip_embedding_bwd": (c_int, [_P, c_int, _P, _P, c_int64, c_int, c_int64, c_int64, _P]),
     "cfhip_l2norm_fwd": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "cfhip_l2norm_bwd": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
+    "cfhip_dropout": (c_int, [_P, _P, c_int, c_int64, c_float, c_uint64, c_uint64, _P, _P, _P]),
+    "cfhip_drop_path_mask": (c_int, [_P, c_int64, c_float, c_uint64, c_uint64, _P]),
+    "cfhip_drop_path": (c_int, [_P, _P, c_int, _P, c_float, c_int64, c_int64, _P]),
+    "cfhip_ml_encode_fwd": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int, _P, _P, _P]),
+    "cfhip_ml_encode_indices": (c_int, [_P, c_int64, c_int64, _P, _P, c_int, _P, _P]),
+    "cfhip_ml_encode_bwd": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, c_int, _P, _P, _P]),
 }
 
 

@@ -225,6 +225,19 @@ __device__ __forceinline__ void bias_rows(const char* a_tile, int wm, int lane, 
 
 #define CFHIP_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
+// wait until at most `n` STAGES (n * LPS LDS-DMA instructions of this wave) are still in flight
+template <int LPS>
+__device__ __forceinline__ void wait_stages(int n) {
+  switch (n) {
+    case 0: CFHIP_WAIT_VMCNT(0); break;
+    case 1: CFHIP_WAIT_VMCNT(1 * LPS); break;
+    case 2: CFHIP_WAIT_VMCNT(2 * LPS); break;
+    case 3: CFHIP_WAIT_VMCNT(3 * LPS); break;
+    case 4: CFHIP_WAIT_VMCNT(4 * LPS); break;
+    default: CFHIP_WAIT_VMCNT(5 * LPS); break;
+  }
+}
+
 // Timing ablations (skip the in-loop DMA / the MFMAs / the stores: results are then WRONG) exist only in builds
 // with -DCFHIP_ABLATE (tools/build_variant.sh ablate -DCFHIP_ABLATE -> tools/libcfhip_ablate.so); the product library has no such code.
 #ifdef CFHIP_ABLATE
@@ -407,16 +420,76 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
   }
 }
 
-// split-K partials: the raw accumulators of K slice z go to slab z (f32), same LDS transposition
+// f32 output (the f32 residual stream, f32 logits, the un-split dW forms): a lane takes FOUR consecutive columns per
+// pass (one 16-byte access), so that the lanes of a row cover one contiguous 128-byte segment per instruction.  (With
+// 8 columns per lane the f32 row needed two instructions that each touched every other 16 bytes of it: the f32
+// residual epilogue cost 50 us on the 25216 x 768 x 3072 GEMM where the bf16 one costs 8.)
+template <int EPI, class C>
+__device__ __forceinline__ void epilogue_f32(const GemmParams& p, f32x4 (&acc)[C::FM][C::FN], char* stage,
+                                             int m0, int n0, int wm, int wn, int wave, int lane) {
+  static_assert(EPI == CFHIP_EPI_NONE || EPI == CFHIP_EPI_RESIDUAL, "f32 output: bias / residual / accumulate only");
+  constexpr int WCOLS = C::FN * 16;
+  constexpr int LPR = WCOLS / 4;              // lanes per row, 4 columns each
+  constexpr int RPP = 64 / LPR;               // rows per pass
+  constexpr int PPM = 16 / RPP;               // passes per 16-row fragment
+  constexpr int NIT = C::FM * PPM;
+  constexpr bool HAS_AUX = EPI == CFHIP_EPI_RESIDUAL;
+  constexpr int PF = HAS_AUX ? (CFHIP_PF_BF16 < NIT ? CFHIP_PF_BF16 : NIT) : 1;  // 4 registers per ring entry
+  float* stg = reinterpret_cast<float*>(stage) + wave * (16 * WCOLS);
+  const int i = lane & 15, g = lane >> 4;
+  const int rr = lane / LPR, c4 = lane % LPR;
+  const int lcol = wn * WCOLS + c4 * 4;
+  const bool c_ok = n0 + lcol < p.N;  // N % 4 == 0 on this path
+  const int lrow0 = wm * (C::FM * 16) + rr;
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias != nullptr && c_ok) bias = *reinterpret_cast<const f32x4*>(p.bias + n0 + lcol);
+  const __amdgpu_buffer_rsrc_t c_rsrc = tile_rsrc(p.C, p.ldc, 4, m0, n0, p.M, p.N);
+  __amdgpu_buffer_rsrc_t x_rsrc = c_rsrc;
+  if constexpr (HAS_AUX) x_rsrc = tile_rsrc(p.aux_in, p.ldc, 4, m0, n0, p.M, p.N);
+  auto boff = [&](int it) -> unsigned {
+    return c_ok ? (unsigned)((lrow0 + (it / PPM) * 16 + (it % PPM) * RPP) * (int)p.ldc + lcol) * 4u : OOB;
+  };
+  u32x4 ring[PF];
+  if constexpr (HAS_AUX) {
+#pragma unroll
+    for (int it = 0; it < PF; ++it) ring[it] = bload16(x_rsrc, boff(it));
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int mi = it / PPM, ps = it % PPM;
+    if (ps == 0) {
+#pragma unroll
+      for (int ni = 0; ni < C::FN; ++ni)
+        *reinterpret_cast<f32x4*>(stg + i * WCOLS + (((ni * 4 + g) ^ (i & 7)) << 2)) = acc[mi][ni];
+    }
+    const int r = ps * RPP + rr;
+    f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + ((c4 ^ (r & 7)) << 2));
+    v += bias;
+    if constexpr (HAS_AUX) {
+      v += __builtin_bit_cast(f32x4, ring[it % PF]);
+      if (it + PF < NIT) ring[it % PF] = bload16(x_rsrc, boff(it + PF));
+    }
+    const unsigned off = boff(it);
+    if constexpr (EPI == CFHIP_EPI_NONE) {
+      if (p.accumulate) v += __builtin_bit_cast(f32x4, bload16(c_rsrc, off));  // wave-uniform; the dW forms only
+    }
+#ifdef CFHIP_ABLATE
+    if ((p.ablate & 8) && v[0] != 12345.678f) continue;  // timing only: epilogue math without the store
+#endif
+    bstore16(c_rsrc, off, __builtin_bit_cast(u32x4, v));
+  }
+}
+
+// split-K partials: the raw accumulators of K slice z go to slab z (f32), same LDS transposition, 4 columns per lane
 template <class C>
 __device__ __forceinline__ void epilogue_slab(const GemmParams& p, f32x4 (&acc)[C::FM][C::FN], char* stage,
                                               int m0, int n0, int z, int wm, int wn, int wave, int lane) {
-  constexpr int WCOLS = C::FN * 16, LPR = WCOLS / 8, RPP = 64 / LPR;
+  constexpr int WCOLS = C::FN * 16, LPR = WCOLS / 4, RPP = 64 / LPR;
   float* stg = reinterpret_cast<float*>(stage) + wave * (16 * WCOLS);
   const int i = lane & 15, g = lane >> 4;
-  const int rr = lane / LPR, c8 = lane % LPR;
-  const int lcol = wn * WCOLS + c8 * 8;
-  const bool c_lo = n0 + lcol < p.N, c_hi = n0 + lcol + 4 < p.N;
+  const int rr = lane / LPR, c4 = lane % LPR;
+  const int lcol = wn * WCOLS + c4 * 4;
+  const bool c_ok = n0 + lcol < p.N;
   const __amdgpu_buffer_rsrc_t s_rsrc = tile_rsrc(p.slabs + (long)z * p.M * p.N, p.N, 4, m0, n0, p.M, p.N);
 #pragma unroll
   for (int mi = 0; mi < C::FM; ++mi) {
@@ -426,11 +499,9 @@ __device__ __forceinline__ void epilogue_slab(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
     for (int ps = 0; ps < 16 / RPP; ++ps) {
       const int r = ps * RPP + rr;
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + (((2 * c8) ^ (r & 7)) << 2));
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + (((2 * c8 + 1) ^ (r & 7)) << 2));
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * WCOLS + ((c4 ^ (r & 7)) << 2));
       const unsigned e = (unsigned)((wm * (C::FM * 16) + mi * 16 + r) * p.N + lcol);
-      bstore16(s_rsrc, c_lo ? e * 4u : OOB, __builtin_bit_cast(u32x4, lo));
-      bstore16(s_rsrc, c_hi ? e * 4u + 16u : OOB, __builtin_bit_cast(u32x4, hi));
+      bstore16(s_rsrc, c_ok ? e * 4u : OOB, __builtin_bit_cast(u32x4, v));
     }
   }
 }
@@ -453,7 +524,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[C::FM
       else epilogue_impl<EPI, C, false, false, false>(p, acc, stage, m0, n0, wm, wn, wave, lane);
     }
   } else {
-    if (p.out_f32) epilogue_impl<EPI, C, true, true, false>(p, acc, stage, m0, n0, wm, wn, wave, lane);  // f32: 16-byte halves either way
+    if (p.out_f32) epilogue_f32<EPI, C>(p, acc, stage, m0, n0, wm, wn, wave, lane);
     else if ((p.N & 7) == 0) epilogue_impl<EPI, C, false, true, false>(p, acc, stage, m0, n0, wm, wn, wave, lane);
     else epilogue_impl<EPI, C, false, false, false>(p, acc, stage, m0, n0, wm, wn, wave, lane);
   }
@@ -716,7 +787,8 @@ template <bool AT, bool BT, int EPI, class C, int CONV = 0>
 __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD)
 void gemm_bf16_phase_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(C::BK == 32 && (C::NSTAGE == 3 || C::NSTAGE == 4) && C::WM == 2, "phase kernel: BK = 32, 3-4 ring slots, 2 wave rows");
+  static_assert(C::BK == 32 && C::NSTAGE >= 3 && C::NSTAGE <= 7 && C::WM == 2, "phase kernel: BK = 32, 3-7 ring slots, 2 wave rows");
+  static_assert(5 * C::LPS < 64, "vmcnt is a 6-bit counter");
   constexpr int D = C::NSTAGE - 1;  // prefetch distance (K-steps)
   static_assert(C::NW * 16 * (C::FN * 16) * 4 <= C::LDS_BYTES, "epilogue staging must fit in the (free) ring");
   // phases per K-step: two (upper / lower half of the wave's rows) when a half still carries 16 MFMAs,
@@ -745,12 +817,7 @@ void gemm_bf16_phase_kernel(GemmParams p) {
 #pragma unroll
   for (int st = 0; st < D; ++st)
     if (st < nk) stage_step<AT, BT, C, CONV>(cur, p, smem, st, wave, st);
-  {  // K-step 0 has landed; the younger ones stay in flight
-    const int younger = min(nk, D) - 1;
-    if (D >= 3 && younger >= 2) CFHIP_WAIT_VMCNT(2 * C::LPS);
-    else if (younger == 1) CFHIP_WAIT_VMCNT(1 * C::LPS);
-    else CFHIP_WAIT_VMCNT(0);
-  }
+  wait_stages<C::LPS>(min(min(nk, D) - 1, 5));  // K-step 0 has landed; the younger ones stay in flight
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();  // the stagger
 
@@ -772,10 +839,8 @@ void gemm_bf16_phase_kernel(GemmParams p) {
       for (int m = 0; m < HM; ++m)
         af[m] = AT ? frag_mmajor<C::BM>(a_tile, wm * (C::FM * 16) + (ph * HM + m) * 16, 0, lane)
                    : frag_kmajor<C::BK>(a_tile, wm * (C::FM * 16) + (ph * HM + m) * 16, 0, i, g);
-      if (ph == PH - 1) {  // own DMA of K-step t+1 retired (step t+2 may still be in flight when D == 3)
-        if (D >= 3 && t + 2 < nk) CFHIP_WAIT_VMCNT(1 * C::LPS);
-        else CFHIP_WAIT_VMCNT(0);
-      }
+      if (ph == PH - 1)  // own DMA of K-step t+1 retired; steps t+2 .. t+D-1 (already issued) may stay in flight
+        wait_stages<C::LPS>(max(0, min(min(D - 2, nk - 2 - t), 5)));
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -921,7 +986,9 @@ using CfgP = Cfg<256, 256, 2, 4, 4, 32>;  // 128 KiB LDS, 8 waves, 1 WG / CU, pr
 using CfgQ = Cfg<256, 128, 2, 4, 3, 32>;  //  72 KiB LDS, 8 waves (128x32 each), 2 WG / CU
 using CfgR = Cfg<256, 128, 2, 2, 3, 32>;  //  72 KiB LDS, 4 waves (128x64 each), 2 WG / CU, prefetch 2
 using CfgS = Cfg<128, 256, 2, 2, 3, 32>;  //  72 KiB LDS, 4 waves (64x128 each), 2 WG / CU, prefetch 2
-constexpr int NUM_CFG = 11;  // 7 .. 10 = CfgP / CfgQ / CfgR / CfgS on the phase kernel
+using CfgT = Cfg<256, 128, 2, 4, 6, 32>;  // 144 KiB LDS, 8 waves, ONE WG / CU, prefetch 5 (probe: can one workgroup feed a CU?)
+using CfgU = Cfg<256, 256, 2, 4, 5, 32>;  // 160 KiB LDS, 8 waves, ONE WG / CU, prefetch 4
+constexpr int NUM_CFG = 13;  // 7 .. 12 = CfgP / CfgQ / CfgR / CfgS / CfgT / CfgU on the phase kernel
 constexpr int BK_MAX = 64;
 
 int g_gemm_config = -1;
@@ -1135,6 +1202,8 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
     case 8: rc = launch_layout<CfgQ, true>(p, a_trans, b_trans, epilogue, split_k, s); break;
     case 9: rc = launch_layout<CfgR, true>(p, a_trans, b_trans, epilogue, split_k, s); break;
     case 10: rc = launch_layout<CfgS, true>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 11: rc = launch_layout<CfgT, true>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 12: rc = launch_layout<CfgU, true>(p, a_trans, b_trans, epilogue, split_k, s); break;
     default: rc = launch_layout<CfgA>(p, a_trans, b_trans, epilogue, split_k, s); break;
   }
   if (rc != CFHIP_OK) return rc;

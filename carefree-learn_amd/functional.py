@@ -251,12 +251,13 @@ def _linear_param_grads(dy2: Tensor, x2: Tensor, weight: Tensor, bias: Optional[
     """dW = dy^T x, db = colsum(dy): direct-to-.grad when possible, returned otherwise."""
     gw = gb = None
     n, k, m = weight.shape[0], weight.shape[1], x2.shape[0]
-    split = ops.pick_split_k(n, k, m)
+    fast_ok = dy2.shape[1] % 8 == 0 and x2.shape[1] % 8 == 0 and dy2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0
+    # split-K lives on the MFMA path only; narrow tabular heads (3 classes, 10 features) take the shape-agnostic kernel
+    split = ops.pick_split_k(n, k, m) if fast_ok else 1
 
     def dw_into(out: Tensor, acc: bool) -> None:
         ops.gemm(dy2, x2, a_trans=True, b_trans=True, out=out, accumulate=acc, split_k=split)
 
-    fast_ok = dy2.shape[1] % 8 == 0 and x2.shape[1] % 8 == 0 and dy2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0
     if (weight.requires_grad and weight_direct and bias is not None and bias.requires_grad and bias_direct
             and fast_ok):
         from .fused import _dw_db  # one launch for dW and db
@@ -1158,3 +1159,126 @@ class ConcatChannelsFn(Function):
 
 def concat_channels(a: Tensor, b: Tensor) -> Tensor:
     return ConcatChannelsFn.apply(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# gradient checkpointing (reference toolkit.py:2535-2647 `gradient_checkpoint`: `use_checkpoint=True` in the zoo
+# `diffusion/ddpm` config wraps every ResidualBlockWithTimeEmbedding / SpatialTransformerBlock)
+# ---------------------------------------------------------------------------------------------
+
+
+class _CheckpointFn(Function):
+    """Runs `fn` without recording in forward (nothing inside is saved for backward) and again, recording, inside
+    backward; the gradients of that second run are what flows out.  The HIP Functions inside are re-entered under
+    `torch.autograd.grad`: their parameter gradients are written straight into `.grad` (arena) during the inner
+    backward and returned as None, so this node returns None for every parameter as well — nothing is counted twice.
+    With 288 GB of HBM per GPU the default stays OFF; the switch is for the configurations that set it."""
+
+    @staticmethod
+    def forward(ctx: Any, fn: Callable, n_inputs: int, *args: Any) -> Any:  # type: ignore
+        ctx.fn = fn
+        ctx.inputs = list(args[:n_inputs])
+        ctx.params = list(args[n_inputs:])
+        ctx.requires = [isinstance(x, Tensor) and x.requires_grad for x in ctx.inputs]
+        with torch.no_grad():
+            return fn(*ctx.inputs)
+
+    @staticmethod
+    def backward(ctx: Any, *grad_outputs: Any) -> Any:  # type: ignore
+        inputs = [x.detach().requires_grad_(r) if isinstance(x, Tensor) else x for x, r in zip(ctx.inputs, ctx.requires)]
+        with torch.enable_grad():
+            outputs = ctx.fn(*[x.view_as(x) if isinstance(x, Tensor) else x for x in inputs])
+        if isinstance(outputs, Tensor):
+            outputs = (outputs,)
+        wrt = [x for x, r in zip(inputs, ctx.requires) if r]
+        wrt_params = [p for p in ctx.params if p.requires_grad]
+        grads = torch.autograd.grad(outputs, wrt + wrt_params, grad_outputs, allow_unused=True)
+        it = iter(grads[:len(wrt)])
+        in_grads = [next(it) if r else None for r in ctx.requires]
+        it = iter(grads[len(wrt):])
+        p_grads = [next(it) if p.requires_grad else None for p in ctx.params]
+        ctx.inputs = ctx.params = None
+        return (None, None) + tuple(in_grads) + tuple(p_grads)
+
+
+def gradient_checkpoint(fn: Callable, inputs: Any, params: Any, enabled: bool) -> Any:
+    """Same call signature and semantics as the reference's `gradient_checkpoint(func, inputs, params, enabled)`."""
+    if not enabled or not torch.is_grad_enabled():
+        return fn(*inputs)
+    inputs = tuple(inputs)
+    return _CheckpointFn.apply(fn, len(inputs), *(inputs + tuple(params)))
+
+
+# ---------------------------------------------------------------------------------------------
+# A12: dropout / DropPath as autograd Functions.  Forward draws (seed, offset) from ops.PhiloxState and remembers the
+# pair; backward runs the SAME kernel on dy with the same pair (the mask is regenerated, never stored).
+# ---------------------------------------------------------------------------------------------
+
+
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, p: float, mask: Optional[Tensor]) -> Tensor:  # type: ignore
+        ctx.p, ctx.mask = float(p), mask
+        ctx.seed, ctx.offset = (0, 0) if mask is not None else ops.PhiloxState.take((x.numel() + 3) // 4)
+        y, _ = ops.dropout(x, ctx.p, seed=ctx.seed, offset=ctx.offset, mask=mask)
+        return y
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor) -> Any:  # type: ignore
+        dx, _ = ops.dropout(dy.contiguous(), ctx.p, seed=ctx.seed, offset=ctx.offset, mask=ctx.mask)
+        return dx, None, None
+
+
+def dropout(x: Tensor, p: float, training: bool, mask: Optional[Tensor] = None) -> Tensor:
+    """nn.Dropout semantics (identity unless training and 0 < p < 1); `mask` (uint8, 1 = keep) injects the mask."""
+    if not training or not 0.0 < p < 1.0:
+        return x
+    return DropoutFn.apply(x, p, mask)
+
+
+class DropPathFn(Function):
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, keep_prob: float, mask: Tensor) -> Tensor:  # type: ignore
+        ctx.keep_prob = float(keep_prob)
+        ctx.save_for_backward(mask)
+        return ops.drop_path(x, mask, ctx.keep_prob)
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor) -> Any:  # type: ignore
+        (mask,) = ctx.saved_tensors
+        return ops.drop_path(dy.contiguous(), mask, ctx.keep_prob), None, None
+
+
+def drop_path(x: Tensor, rate: float, training: bool, mask: Optional[Tensor] = None) -> Tensor:
+    """reference customs.py:434-443: per-sample stochastic depth; `mask` (f32 [B] of 0 / 1) injects the sample mask."""
+    if not training or not 0.0 < rate < 1.0:
+        return x
+    keep_prob = 1.0 - rate
+    if mask is None:
+        b = x.shape[0]
+        seed, offset = ops.PhiloxState.take((b + 3) // 4)
+        mask = ops.drop_path_mask(b, keep_prob, x.device, seed=seed, offset=offset)
+    return DropPathFn.apply(x, keep_prob, mask)
+
+
+# ---------------------------------------------------------------------------------------------
+# A16: tabular encoder
+# ---------------------------------------------------------------------------------------------
+
+
+class MLEncodeFn(Function):
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, plan: Tensor, tables_ptr: Optional[Tensor], out_dim: int, *tables: Tensor) -> Tensor:  # type: ignore
+        ctx.save_for_backward(x, plan)
+        ctx.tables = tables
+        return ops.ml_encode_fwd(x, plan, tables_ptr, out_dim)
+
+    @staticmethod
+    def backward(ctx: Any, dout: Tensor) -> Any:  # type: ignore
+        x, plan = ctx.saved_tensors
+        grads = [torch.zeros_like(t) if t.requires_grad else None for t in ctx.tables]
+        ptrs = None
+        if grads:
+            ptrs = torch.tensor([0 if g is None else g.data_ptr() for g in grads], dtype=torch.int64).to(x.device)
+        dx = ops.ml_encode_bwd(dout.float(), x, plan, ptrs, ctx.needs_input_grad[0])
+        return (dx, None, None, None) + tuple(grads)

@@ -16,8 +16,10 @@ from torch.nn import Module
 
 from . import functional as HF
 from . import fused
+from . import ops
 from .registry import (
     attentions,
+    build_module,
     channel_mixers,
     encoders,
     register_module,
@@ -404,6 +406,42 @@ class Attention(Module):
 # ---------------------------------------------------------------------------------------------
 
 
+class Dropout(Module):
+    """nn.Dropout on the HIP path (no parameters, same position in every `nn.Sequential` as the reference's, so
+    state_dict keys are unchanged): Philox mask regenerated in backward (`functional.DropoutFn`), identity in eval
+    mode or for p outside (0, 1).  `inject_mask` (uint8, 1 = keep; consumed by the next forward) pins the mask for
+    parity tests — given the mask the result is bit-equal to torch's."""
+
+    def __init__(self, p: float = 0.5, inplace: bool = False):
+        super().__init__()
+        self.p, self.inplace = float(p), inplace
+        self.inject_mask: Optional[Tensor] = None
+
+    def forward(self, net: Tensor) -> Tensor:
+        mask, self.inject_mask = self.inject_mask, None
+        return HF.dropout(net, self.p, self.training, mask)
+
+    def extra_repr(self) -> str:
+        return f"p={self.p}"
+
+
+class DropPath(Module):
+    """reference modules/core/customs.py:429-446: `net.div(keep) * floor(keep + U[0, 1))` per sample, training only.
+    `inject_mask` (f32 [B] of 0 / 1; consumed by the next forward) pins the sample mask for parity tests."""
+
+    def __init__(self, dropout: float = 0.0):
+        super().__init__()
+        self.dropout = dropout
+        self.inject_mask: Optional[Tensor] = None
+
+    def forward(self, net: Tensor) -> Tensor:
+        mask, self.inject_mask = self.inject_mask, None
+        return HF.drop_path(net, self.dropout, self.training, mask)
+
+    def extra_repr(self) -> str:
+        return str(self.dropout)
+
+
 class ITokenMixer(Module):
     def __init__(self, in_dim: int, num_tokens: int):
         super().__init__()
@@ -473,23 +511,36 @@ class FeedForward(IChannelMixer):
             blocks = [GEGLU(in_dim, latent_dim)]
         else:
             blocks = [HijackCustomLinear(in_dim, latent_dim), _Act(activation)]
-        blocks += [nn.Dropout(dropout), HijackCustomLinear(latent_dim, in_dim)]
+        blocks += [Dropout(dropout), HijackCustomLinear(latent_dim, in_dim)]
         if add_last_dropout:
-            blocks.append(nn.Dropout(dropout))
+            blocks.append(Dropout(dropout))
+        self.add_last_dropout = add_last_dropout
         self.net = nn.Sequential(*blocks)
 
     @property
     def need_2d(self) -> bool:
         return False
 
+    @property
+    def drops(self) -> bool:
+        return self.training and 0.0 < self.dropout < 1.0
+
     def forward(self, net: Tensor, *, residual: Optional[Tensor] = None) -> Tensor:
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError("dropout > 0 is outside the accelerated hot path")
+        drops = self.drops
+        last = len(self.net) - (2 if self.add_last_dropout else 1)  # index of the second Linear
         if self.activation == "geglu":
-            return self.net[2](self.net[0](net), residual=residual)
-        # bias + activation (exact-erf GELU / quick GELU) fused in the GEMM epilogue
-        h = self.net[0](net, act=HF.ACT_GELU if self.activation == "GELU" else HF.ACT_QGELU)
-        return self.net[3](h, residual=residual)
+            h = self.net[0](net)
+        else:  # bias + activation (exact-erf GELU / quick GELU) fused in the GEMM epilogue
+            h = self.net[0](net, act=HF.ACT_GELU if self.activation == "GELU" else HF.ACT_QGELU)
+        if not drops:
+            return self.net[last](h, residual=residual)
+        # dropout > 0 (training): the reference's op sequence, the last dropout sits between the second Linear and
+        # the residual add, so the add cannot ride in the GEMM epilogue
+        h = self.net[last - 1](h)
+        out = self.net[last](h)
+        if self.add_last_dropout:
+            out = self.net[last + 1](out)
+        return out if residual is None else HF.add(residual, out) if residual.dtype == out.dtype else residual + out
 
 
 class PreNorm(Module):
@@ -524,16 +575,16 @@ class MixingBlock(Module):
         super().__init__()
         if norm_position != "pre_norm":
             raise NotImplementedError("only `pre_norm` blocks are on the accelerated hot path")
-        if drop_path > 0.0 or dropout > 0.0 or residual_after_norm:
-            raise NotImplementedError("dropout / drop_path / residual_after_norm are outside the hot path")
+        if residual_after_norm:
+            raise NotImplementedError("residual_after_norm is outside the hot path")
         self.norm_position = norm_position
-        self.drop_path = nn.Identity()
+        self.drop_path = DropPath(drop_path)  # api.py:84: one DropPath module, used on both branches
         tm = dict(token_mixing_config or {})
         tm.update(layer_idx=layer_idx, num_layers=num_layers, num_tokens=num_tokens, in_dim=in_dim,
                   latent_dim=latent_dim, dropout=dropout)
         self.token_norm = NormFactory(norm_type).make(in_dim, **(norm_kwargs or {}))
         self.token_mixing = token_mixers.build(token_mixing_type, config=tm)
-        self.token_mixing_dropout = nn.Dropout(dropout if token_mixing_dropout is None else token_mixing_dropout)
+        self.token_mixing_dropout = Dropout(dropout if token_mixing_dropout is None else token_mixing_dropout)
         cm = dict(channel_mixing_config or {})
         cm.update(layer_idx=layer_idx, num_layers=num_layers, in_dim=in_dim, latent_dim=latent_dim,
                   dropout=dropout)
@@ -542,8 +593,17 @@ class MixingBlock(Module):
         self.channel_mixing = channel_mixers.build(channel_mixing_type, config=cm)
         self.use_fused = True
 
+    def _stochastic(self) -> bool:
+        """any dropout / stochastic depth active in this forward (training mode with a rate in (0, 1))"""
+        if not self.training:
+            return False
+        rates = (self.drop_path.dropout, self.token_mixing_dropout.p, getattr(self.channel_mixing, "dropout", 0.0))
+        return any(0.0 < r < 1.0 for r in rates)
+
     def _fusable(self) -> bool:
         tmix, cmix = self.token_mixing, self.channel_mixing
+        if self._stochastic():  # the fused block / stack kernels have no random masks: composed path
+            return False
         if not (isinstance(tmix, AttentionTokenMixer) and isinstance(cmix, FeedForward)):
             return False
         att = tmix.net
@@ -587,8 +647,15 @@ class MixingBlock(Module):
         if mask is not None:
             tkw["mask"] = mask
         tkw.update(kwargs)
-        net = self.token_mixing(self.token_norm(net), **tkw)
-        return self.channel_mixing(self.channel_norm(net), residual=net)
+        if not self._stochastic():
+            net = self.token_mixing(self.token_norm(net), **tkw)
+            return self.channel_mixing(self.channel_norm(net), residual=net)
+        # dropout / DropPath active (api.py:130-158): branch -> dropout -> drop_path -> + residual, op by op
+        tkw.pop("residual")
+        branch = self.drop_path(self.token_mixing_dropout(self.token_mixing(self.token_norm(net), **tkw)))
+        net = net + branch.to(net.dtype) if net.dtype != branch.dtype else HF.add(net, branch)
+        branch = self.drop_path(self.channel_mixing(self.channel_norm(net)))
+        return net + branch.to(net.dtype) if net.dtype != branch.dtype else HF.add(net, branch)
 
 
 class PositionalEncoding(Module):
@@ -600,7 +667,7 @@ class PositionalEncoding(Module):
         self.pos_drop = None
         self.pos_encoding = None
         if enable:
-            self.pos_drop = nn.Dropout(p=dropout)
+            self.pos_drop = Dropout(p=dropout)
             self.pos_encoding = nn.Parameter(torch.zeros(1, num_tokens, dim))
             nn.init.trunc_normal_(self.pos_encoding, std=0.02)
         self.num_head_tokens = num_head_tokens
@@ -627,8 +694,8 @@ class MixedStackedEncoder(Module):
                  positional_encoding_dropout: float = 0.0, no_head_norm: Optional[bool] = None,
                  norm_after_head: bool = False, aux_heads: Optional[List[str]] = None):
         super().__init__()
-        if aux_heads is not None or embedding_dropout is not None:
-            raise NotImplementedError("aux heads / embedding dropout are outside the accelerated hot path")
+        if aux_heads is not None:
+            raise NotImplementedError("aux heads are outside the accelerated hot path")
         if not use_head_token and head_pooler is not None:
             raise NotImplementedError(f"head pooler '{head_pooler}' is outside the accelerated hot path "
                                       "(head token or `head_pooler=None` are built)")
@@ -655,7 +722,7 @@ class MixedStackedEncoder(Module):
                                                is_vision=bool(is_vision_positional_encoding),
                                                enable=use_positional_encoding)
         self.embedding_norm = embedding_norm
-        self.embedding_dropout = None
+        self.embedding_dropout = None if embedding_dropout is None else Dropout(embedding_dropout)  # api.py:330-333
         if dpr_list is None:
             dpr_list = [x.item() for x in torch.linspace(0, drop_path_rate, num_layers)]
         if latent_dim is None:
@@ -704,6 +771,14 @@ class MixedStackedEncoder(Module):
             return self._head_ln()(net[:, 0])
         return self._head_ln()(net)
 
+    def check_fused_token_assembly(self) -> None:
+        """The ViT / CLIP entry points add the positional encoding inside their token-assembly kernels: a dropout ON
+        the encoding (api.py:220, `positional_encoding_dropout` > 0 in training) has no place there."""
+        drop = self.pos_encoding.pos_drop
+        if drop is not None and self.training and 0.0 < drop.p < 1.0:
+            raise NotImplementedError("positional_encoding_dropout > 0 is not provided by the fused token-assembly "
+                                      "kernels (patch embedding / token embedding); use the generic pre_process path")
+
     def pre_process(self, net: Tensor, *, hwp: Any = None, deterministic: bool = False) -> Tensor:
         """Generic token input [B, T, D] (reference :419-438).  The ViT / CLIP entry points do NOT come through
         here: they fuse head token / positional add into their token-assembly kernels."""
@@ -715,9 +790,13 @@ class MixedStackedEncoder(Module):
                 if self.pos_encoding.is_vision:
                     raise NotImplementedError("positional-encoding interpolation is outside the accelerated hot path")
                 pos = pos[:, :net.shape[1]]
+            if self.pos_encoding.pos_drop is not None:
+                pos = self.pos_encoding.pos_drop(pos)  # api.py:220: the dropout acts on the encoding itself
             net = net.float() + pos
         if self.embedding_norm is not None:
             net = self.embedding_norm(net)
+        if self.embedding_dropout is not None:
+            net = self.embedding_dropout(net)
         return net
 
     def forward_tokens(self, tokens: Tensor, *, hw: Optional[Tuple[int, int]] = None,
@@ -881,13 +960,11 @@ class Mapping(Module):
         super().__init__()
         if bias is None:
             bias = not batch_norm
-        if 0.0 < dropout < 1.0:
-            raise NotImplementedError("dropout > 0 is outside the accelerated hot path (no RNG kernels yet)")
         self.linear = Linear(in_dim, out_dim, bias=bias, pruner_config=pruner_config, init_method=init_method,
                              rank=rank, rank_ratio=rank_ratio)
         self.bn = BN(out_dim) if batch_norm else None
         self.activation = None if activation is None else build_activation(activation, activation_config)
-        self.dropout = None
+        self.dropout = Dropout(dropout) if 0.0 < dropout < 1.0 else None  # mappings.py:66-67
 
     @property
     def weight(self) -> Tensor:
@@ -903,6 +980,8 @@ class Mapping(Module):
             net = self.bn(net)
         if self.activation is not None:
             net = self.activation(net)
+        if self.dropout is not None:
+            net = self.dropout(net)
         return net
 
 
@@ -1001,9 +1080,12 @@ class ViTEncoder(Module):
                                       "outside the accelerated hot path")
         conv = self.to_patches.projection
         enc = self.encoder
+        enc.check_fused_token_assembly()
         tokens = HF.patch_tokens(net, conv.weight, conv.bias, enc.head_token, enc.pos_encoding.pos_encoding)
         if enc.embedding_norm is not None:
             tokens = enc.embedding_norm(tokens)  # CLIP vision tower: LayerNorm before the blocks (bf16 stream)
+        if enc.embedding_dropout is not None:
+            tokens = enc.embedding_dropout(tokens)
         g = self.img_size // self.to_patches.patch_size
         out = enc.forward_tokens(tokens, hw=(g, g), deterministic=deterministic)
         if self.output_projection is not None:
@@ -1093,6 +1175,8 @@ class TeTEncoder(Module):
         """`tokens` already carry the positional encoding (fused into the embedding lookup kernel)."""
         if self.encoder.embedding_norm is not None:
             tokens = self.encoder.embedding_norm(tokens)
+        if self.encoder.embedding_dropout is not None:
+            tokens = self.encoder.embedding_dropout(tokens)
         return self.encoder.forward_tokens(tokens, causal=self.attention_mask is not None, clip_skip=clip_skip,
                                            apply_head=apply_head)
 
@@ -1196,6 +1280,7 @@ class CLIP(Module):
         pos = enc.pos_encoding.pos_encoding
         pad = self.token_embedding.padding_idx
         # embedding lookup + positional add in one gather kernel -> f32 stream [B, T, D]
+        enc.check_fused_token_assembly()
         tokens = HF.embedding(indices, self.token_embedding.weight, pos, -1 if pad is None else pad)
         if not apply_pooling:
             return self.text_transformer.forward_embedded(tokens, clip_skip=clip_skip)
@@ -1294,8 +1379,9 @@ class ResidualBlockWithTimeEmbedding(Module):
     """reference residual.py:154-253: GN(32) -> SiLU -> [resample] -> conv3x3 -> (+ Linear(SiLU(t))) -> GN(32) -> SiLU ->
     conv3x3 (zero-initialised) -> + shortcut(inp).  State keys: `norm1.*`, `conv1.*`, `time_embedding.*`, `norm2.*`,
     `conv2.*`, `shortcut.*`.  GroupNorm, the time-embedding add in front of norm2 and both SiLUs are two fused
-    kernels each way.  Scale-shift norm, dropout and gradient checkpointing are outside the accelerated hot path
-    (`safe_clip_` only acts on non-finite values and is omitted)."""
+    kernels each way.  `use_checkpoint=True` recomputes the block in backward like the reference (residual.py:217-222).
+    Scale-shift norm and dropout are outside the accelerated hot path (`safe_clip_` only acts on non-finite values and
+    is omitted)."""
 
     def __init__(self, in_channels: int, out_channels: Optional[int] = None, *, signal_dim: int = 2,
                  dropout: float = 0.0, norm_eps: float = 1.0e-6, use_conv_shortcut: bool = False,
@@ -1309,7 +1395,7 @@ class ResidualBlockWithTimeEmbedding(Module):
         out_channels = out_channels or in_channels
         self.out_channels = out_channels
         self.use_conv_shortcut, self.use_scale_shift_norm = use_conv_shortcut, use_scale_shift_norm
-        self.use_checkpoint = use_checkpoint  # 288 GB of HBM: activations are kept, the flag is accepted and ignored
+        self.use_checkpoint = use_checkpoint  # residual.py:217-222: recompute the block in backward (HF.gradient_checkpoint)
         self.resample = integrate_upsample or integrate_downsample
         if not self.resample:
             self.inp_resample = self.net_resample = None
@@ -1335,6 +1421,13 @@ class ResidualBlockWithTimeEmbedding(Module):
                              else HijackConv2d(in_channels, out_channels, 1, 1, 0))
 
     def forward(self, net: Tensor, time_net: Optional[Tensor] = None) -> Tensor:
+        if self.use_checkpoint:  # residual.py:210-216 (a no-op without grad mode)
+            if time_net is None:
+                return HF.gradient_checkpoint(lambda n: self._forward(n, None), (net,), self.parameters(), True)
+            return HF.gradient_checkpoint(self._forward, (net, time_net), self.parameters(), True)
+        return self._forward(net, time_net)
+
+    def _forward(self, net: Tensor, time_net: Optional[Tensor] = None) -> Tensor:
         inp = net
         net = self.norm1(net, silu=True)
         if self.inp_resample is not None:
@@ -1392,8 +1485,8 @@ class CrossAttention(Module):
 
 class SpatialTransformerBlock(Module):
     """reference mixed_stacks/api.py:766-827: LN -> self attention -> +x; LN -> cross attention(context) -> +x;
-    LN -> GEGLU feed-forward -> +x (the residual adds ride in the GEMM epilogues).  Hooks and gradient checkpointing
-    are outside the accelerated hot path."""
+    LN -> GEGLU feed-forward -> +x (the residual adds ride in the GEMM epilogues); `use_checkpoint=True` recomputes
+    the block in backward.  Hooks are outside the accelerated hot path."""
 
     def __init__(self, query_dim: int, num_heads: int, head_dim: int, *, dropout: float = 0.0,
                  context_dim: Optional[int] = None, feedforward_multiplier: float = 4.0,
@@ -1411,6 +1504,13 @@ class SpatialTransformerBlock(Module):
         self.use_checkpoint = use_checkpoint
 
     def forward(self, net: Tensor, context: Optional[Tensor] = None) -> Tensor:
+        if self.use_checkpoint:  # mixed_stacks/api.py:806-813 (a no-op without grad mode)
+            if context is None:
+                return HF.gradient_checkpoint(lambda n: self._forward(n, None), (net,), self.parameters(), True)
+            return HF.gradient_checkpoint(self._forward, (net, context), self.parameters(), True)
+        return self._forward(net, context)
+
+    def _forward(self, net: Tensor, context: Optional[Tensor] = None) -> Tensor:
         net = self.attn1(self.norm1(net), residual=net)
         net = self.attn2(self.norm2(net), context=context, residual=net)
         return self.ff(self.norm3(net), residual=net)
@@ -1579,3 +1679,174 @@ class UNetDiffuser(Module):
             net = block(HF.concat_channels(net, nets.pop()), time_net, context)
         net = self.head[0](net, silu=True)  # GroupNorm + SiLU in one kernel
         return self.head[2](net)
+
+
+# ---------------------------------------------------------------------------------------------
+# A16: tabular encoder (reference modules/core/ml_encoder.py:131-258, models/ml/common.py:27-93)
+# ---------------------------------------------------------------------------------------------
+
+
+class _EmbeddingTable(Module):
+    """reference ml_encoder.Embedding (:45-70): parameter `weights` [in_dim, out_dim]; the lookup itself happens in
+    the encoder's gather kernel, the dropout (default 0.1, :113-117) on the embedding block of its output."""
+
+    def __init__(self, in_dim: int, out_dim: int, init_std: float = 0.02, dropout: float = 0.1):
+        super().__init__()
+        weights = torch.empty(in_dim, out_dim)
+        nn.init.trunc_normal_(weights, mean=0.0, std=init_std, a=-2.0 * init_std, b=2.0 * init_std)
+        self.weights = nn.Parameter(weights)
+        self.dropout = Dropout(dropout) if 0.0 < dropout < 1.0 else None
+        self.in_dim, self.out_dim = in_dim, out_dim
+
+    def extra_repr(self) -> str:
+        return f"{self.in_dim} -> {self.out_dim}"
+
+
+def _embedding_out_dim(in_dim: int, out_dim: Any) -> int:
+    """ml_encoder.get_embedding_config (:90-111)"""
+    import math
+
+    if isinstance(out_dim, int):
+        return out_dim
+    if out_dim == "log":
+        return math.ceil(math.log2(in_dim))
+    if out_dim == "sqrt":
+        return math.ceil(math.sqrt(in_dim))
+    if out_dim == "auto":
+        return max(4, min(8, math.ceil(math.log2(in_dim))))
+    raise ValueError(f"embedding dim '{out_dim}' is not defined")
+
+
+@register_module("ml.encoder")
+class MLEncoder(Module):
+    """`Encoder` of the reference (ml_encoder.py:131-258) with `CommonMLModel.encode`'s concatenation (models/ml/
+    common.py:67-87) folded in: `forward(x)` returns `merged_all` = [numerical | one-hot | embedding] from ONE gather
+    kernel (`cfhip_ml_encode_fwd`); `encode_result(x)` returns the reference's (indices, one_hot, embedding) triple.
+    `settings`: {"<column>": dict(dim=..., methods="embedding" | "one_hot" | [both], method_configs={...})} — the
+    fields of the reference's `MLEncoderSettings` (schema.py:1956-1990), as dicts or objects with those attributes.
+    State-dict keys as in the reference: `embeddings.<column>.weights`, buffer `dims`."""
+
+    def __init__(self, settings: Dict[str, Any], global_encoder_settings: Any = None):
+        super().__init__()
+        get = lambda obj, key, default=None: (obj.get(key, default) if isinstance(obj, dict) else getattr(obj, key, default))  # noqa: E731
+        ges_dim = get(global_encoder_settings, "embedding_dim") if global_encoder_settings is not None else None
+        ges_drop = get(global_encoder_settings, "embedding_dropout") if global_encoder_settings is not None else None
+        self.embeddings = nn.ModuleDict()
+        self.tgt_columns: List[int] = []
+        self.one_hot_columns: List[int] = []
+        self.embedding_columns: List[int] = []
+        dims: List[int] = []
+        self.one_hot_dim = self.embedding_dim = self.dim_increment = 0
+        for str_idx in sorted(settings):
+            st = settings[str_idx]
+            idx, dim = int(str_idx), int(get(st, "dim"))
+            methods = get(st, "methods", "embedding")
+            methods = [methods] if isinstance(methods, str) else list(methods)
+            dims.append(dim)
+            self.tgt_columns.append(idx)
+            if "one_hot" in methods:
+                self.one_hot_columns.append(idx)
+                self.one_hot_dim += dim
+                self.dim_increment += dim - 1
+            if "embedding" in methods:
+                kw = dict(get(st, "method_configs") or {})
+                out_dim = _embedding_out_dim(dim, kw.get("out_dim", "auto" if ges_dim is None else ges_dim))
+                init = kw.get("init_config", {"mean": 0.0, "std": 0.02})
+                if kw.get("init_method", "truncated_normal") != "truncated_normal":
+                    raise NotImplementedError("embedding init methods other than truncated_normal are not provided")
+                drop = kw.get("dropout", 0.1 if ges_drop is None else ges_drop)
+                self.embedding_columns.append(idx)
+                self.embeddings[str_idx] = _EmbeddingTable(dim, out_dim, float(init.get("std", 0.02)), float(drop))
+                self.embedding_dim += out_dim
+                self.dim_increment += out_dim - 1
+        self.categorical_dim = self.one_hot_dim + self.embedding_dim
+        self.use_one_hot, self.use_embedding = bool(self.one_hot_columns), bool(self.embedding_columns)
+        self.is_empty = not self.use_one_hot and not self.use_embedding
+        self.register_buffer("dims", torch.tensor(dims, dtype=torch.float32))
+        self._dims_int = dims
+        self._plans: Dict[int, Any] = {}
+
+    def _plan(self, num_features: int, device: torch.device) -> Any:
+        """Output-column plan for inputs with `num_features` columns (built once per width and device)."""
+        key = (num_features, str(device))
+        if key in self._plans:
+            return self._plans[key]
+        dim_of = dict(zip(self.tgt_columns, self._dims_int))
+        rows: List[List[int]] = []
+        numerical = [c for c in range(num_features) if c not in self.tgt_columns]
+        for c in numerical:
+            rows.append([c, 0, 0, 0, 0, 0])
+        for c in self.one_hot_columns:
+            rows.extend([c, 1, v, 0, dim_of[c], 0] for v in range(dim_of[c]))
+        emb_slices = []
+        for t_id, c in enumerate(self.embedding_columns):
+            tab = self.embeddings[str(c)]
+            emb_slices.append((len(rows), tab.out_dim))
+            rows.extend([c, 2, k, t_id, dim_of[c], tab.out_dim] for k in range(tab.out_dim))
+        plan = torch.tensor(rows, dtype=torch.int32).to(device)
+        cols = torch.tensor(self.tgt_columns, dtype=torch.int32).to(device)
+        dims = torch.tensor(self._dims_int, dtype=torch.int32).to(device)
+        self._plans[key] = (plan, len(rows), len(numerical), emb_slices, cols, dims)
+        return self._plans[key]
+
+    def _table_pointers(self, device: torch.device) -> Tuple[Optional[Tensor], List[Tensor]]:
+        tables = [self.embeddings[str(c)].weights for c in self.embedding_columns]
+        if not tables:
+            return None, []
+        ptrs = tuple(t.data_ptr() for t in tables)
+        if getattr(self, "_ptr_key", None) != ptrs:
+            self._ptr_key = ptrs
+            self._ptr_dev = torch.tensor(list(ptrs), dtype=torch.int64).to(device)
+        return self._ptr_dev, tables
+
+    def forward(self, x_batch: Tensor) -> Tensor:
+        """merged_all [B, F - K + one_hot_dim + embedding_dim] (f32)"""
+        lead = x_batch.shape[:-1]
+        x2 = x_batch.reshape(-1, x_batch.shape[-1]).float().contiguous()
+        plan, out_dim, n_num, emb_slices, _, _ = self._plan(x2.shape[1], x2.device)
+        ptrs, tables = self._table_pointers(x2.device)
+        out = HF.MLEncodeFn.apply(x2, plan, ptrs, out_dim, *tables)
+        if self.training and any(self.embeddings[str(c)].dropout is not None for c in self.embedding_columns):
+            pieces = [out[:, :emb_slices[0][0]]] if emb_slices else [out]
+            for (start, width), c in zip(emb_slices, self.embedding_columns):
+                piece = out[:, start:start + width]
+                drop = self.embeddings[str(c)].dropout
+                pieces.append(piece if drop is None else drop(piece.contiguous()))
+            out = torch.cat(pieces, dim=-1)
+        return out.view(*lead, out.shape[-1])
+
+    def encode_result(self, x_batch: Tensor) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
+        """(indices int64 [B, K], one_hot [B, one_hot_dim] or None, embedding [B, embedding_dim] or None) — the
+        reference's `EncodingResult` (ml_encoder.py:73-88, eval-mode embedding: no dropout)."""
+        x2 = x_batch.reshape(-1, x_batch.shape[-1]).float().contiguous()
+        plan, out_dim, n_num, emb_slices, cols, dims = self._plan(x2.shape[1], x2.device)
+        ptrs, tables = self._table_pointers(x2.device)
+        indices = ops.ml_encode_indices(x2, cols, dims)
+        merged = HF.MLEncodeFn.apply(x2, plan, ptrs, out_dim, *tables)
+        one_hot = merged[:, n_num:n_num + self.one_hot_dim] if self.use_one_hot else None
+        embedding = merged[:, n_num + self.one_hot_dim:] if self.use_embedding else None
+        return indices, one_hot, embedding
+
+
+class CommonMLModule(Module):
+    """`CommonMLModel.forward` (models/ml/common.py:27-93) as a module: `m["encoder"]` (or None) + `m["module"]`;
+    `module_config["input_dim"]` grows by the encoder's `dim_increment` (:45-52)."""
+
+    def __init__(self, module_name: str, module_config: Dict[str, Any], encoder_settings: Optional[Dict[str, Any]] = None,
+                 global_encoder_settings: Any = None):
+        super().__init__()
+        self.m = nn.ModuleDict()
+        encoder = None if encoder_settings is None else MLEncoder(encoder_settings, global_encoder_settings)
+        cfg = shallow_copy_dict(module_config)
+        if encoder is not None:
+            cfg["input_dim"] = cfg["input_dim"] + encoder.dim_increment
+            self.m["encoder"] = encoder
+        cfg["input_dim"] *= cfg.get("num_history", 1)
+        self.m["module"] = build_module(module_name, config=cfg)
+
+    def forward(self, net: Tensor, **kwargs: Any) -> Any:
+        if "encoder" in self.m and not self.m["encoder"].is_empty:
+            net = self.m["encoder"](net)
+        if net.dim() > 2:
+            net = net.contiguous().view(len(net), -1)
+        return self.m["module"](net, **kwargs)

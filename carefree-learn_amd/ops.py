@@ -958,3 +958,119 @@ def mse_loss(pred: Tensor, target: Tensor, grad_scale: float, want_grad: bool = 
                                     float(grad_scale), _stream())
     _lib.check(rc, "mse_loss")
     return loss, dpred
+
+
+# ---------------------------------------------------------------------------------------------
+# A12: dropout / DropPath (csrc/random.hip).  The generator state is (seed, offset): every call that draws random bits
+# advances `offset` by the number of Philox counters it consumed, so that no two calls share bits and a backward pass
+# can regenerate its mask from the (seed, offset) pair the forward recorded.
+# ---------------------------------------------------------------------------------------------
+
+
+class PhiloxState:
+    """Process-wide counter-based generator state.  `manual_seed` (re)starts the stream; under data parallelism seed
+    each rank differently (e.g. seed + rank) exactly as `torch.manual_seed` users do."""
+
+    seed: int = 0x5EED5EED
+    offset: int = 0
+
+    @classmethod
+    def manual_seed(cls, seed: int) -> None:
+        cls.seed, cls.offset = int(seed) & 0xFFFFFFFFFFFFFFFF, 0
+
+    @classmethod
+    def take(cls, counters: int) -> Tuple[int, int]:
+        """Reserve `counters` Philox counters; returns the (seed, offset) to hand to the kernel."""
+        off = cls.offset
+        cls.offset += int(counters)
+        return cls.seed, off
+
+
+def dropout(x: Tensor, p: float, *, seed: int = 0, offset: int = 0, mask: Optional[Tensor] = None,
+            want_mask: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    """y = keep ? x / (1 - p) : 0 (bf16 or f32, any shape).  `mask` (uint8, same number of elements) injects the keep
+    mask instead of the Philox stream keyed by (seed, offset).  Returns (y, mask_out or None)."""
+    if x.dtype not in (bf16, f32):
+        raise TypeError(f"cfhip dropout: x must be bf16 or f32, got {x.dtype}")
+    _need(x, x.dtype, "x")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    if mask is not None:
+        _need(mask, torch.uint8, "mask")
+        if mask.numel() != x.numel():
+            raise ValueError("cfhip dropout: mask must have one byte per element of x")
+        mask = mask.contiguous()
+    mask_out = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_mask else None
+    rc = _lib.load().cfhip_dropout(x.data_ptr(), y.data_ptr(), int(x.dtype == f32), x.numel(), float(p), int(seed),
+                                   int(offset), _p(mask), _p(mask_out), _stream())
+    _lib.check(rc, "dropout")
+    return y, mask_out
+
+
+def drop_path_mask(batch: int, keep_prob: float, device: torch.device, *, seed: int = 0, offset: int = 0) -> Tensor:
+    """mask[b] = floor(keep_prob + u_b) in {0, 1} (f32 [B]) — reference customs.py:439-441"""
+    out = torch.empty((batch,), dtype=f32, device=device)
+    rc = _lib.load().cfhip_drop_path_mask(out.data_ptr(), batch, float(keep_prob), int(seed), int(offset), _stream())
+    _lib.check(rc, "drop_path_mask")
+    return out
+
+
+def drop_path(x: Tensor, mask: Tensor, keep_prob: float) -> Tensor:
+    """y[b] = (x[b] / keep_prob) * mask[b] for a [B, ...] tensor (bf16 or f32); also its own backward on dy."""
+    if x.dtype not in (bf16, f32):
+        raise TypeError(f"cfhip drop_path: x must be bf16 or f32, got {x.dtype}")
+    _need(x, x.dtype, "x")
+    _need(mask, f32, "mask")
+    x = x.contiguous()
+    b = x.shape[0]
+    if mask.numel() != b:
+        raise ValueError("cfhip drop_path: one mask value per sample")
+    y = torch.empty_like(x)
+    rc = _lib.load().cfhip_drop_path(x.data_ptr(), y.data_ptr(), int(x.dtype == f32), mask.contiguous().data_ptr(),
+                                     float(keep_prob), b, x.numel() // b, _stream())
+    _lib.check(rc, "drop_path")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# A16: tabular encoder gather (csrc/tabular.hip)
+# ---------------------------------------------------------------------------------------------
+
+
+def ml_encode_fwd(x: Tensor, plan: Tensor, tables: Optional[Tensor], out_dim: int) -> Tensor:
+    """x f32 [B, F] -> merged_all f32 [B, out_dim]; `plan` int32 [out_dim, 6] on the device (see include/cfhip.h),
+    `tables` int64 device array of embedding-table base pointers (or None when there is no embedding column)."""
+    _need(x, f32, "x")
+    _need(plan, torch.int32, "plan")
+    b, f, xs = _mat(x, "x")
+    out = torch.empty((b, out_dim), dtype=f32, device=x.device)
+    rc = _lib.load().cfhip_ml_encode_fwd(x.data_ptr(), b, f, xs, plan.data_ptr(), out_dim, _p(tables), out.data_ptr(),
+                                         _stream())
+    _lib.check(rc, "ml_encode_fwd")
+    return out
+
+
+def ml_encode_indices(x: Tensor, cols: Tensor, dims: Tensor) -> Tensor:
+    """int64 [B, K]: the reference's `EncodingResult.indices` (oob -> 0, truncation)"""
+    _need(x, f32, "x")
+    _need(cols, torch.int32, "cols")
+    _need(dims, torch.int32, "dims")
+    b, _, xs = _mat(x, "x")
+    k = cols.numel()
+    out = torch.empty((b, k), dtype=torch.int64, device=x.device)
+    rc = _lib.load().cfhip_ml_encode_indices(x.data_ptr(), b, xs, cols.data_ptr(), dims.data_ptr(), k, out.data_ptr(),
+                                             _stream())
+    _lib.check(rc, "ml_encode_indices")
+    return out
+
+
+def ml_encode_bwd(dout: Tensor, x: Tensor, plan: Tensor, dtables: Optional[Tensor], want_dx: bool) -> Optional[Tensor]:
+    _need(dout, f32, "dout")
+    _need(x, f32, "x")
+    b, f, xs = _mat(x, "x")
+    dout = dout.contiguous()
+    dx = torch.zeros((b, f), dtype=f32, device=x.device) if want_dx else None
+    rc = _lib.load().cfhip_ml_encode_bwd(dout.data_ptr(), x.data_ptr(), b, f, xs, plan.data_ptr(), dout.shape[1],
+                                         _p(dtables), _p(dx), _stream())
+    _lib.check(rc, "ml_encode_bwd")
+    return dx

@@ -94,3 +94,19 @@ attentions = PrefixModules("attention")
 token_mixers = PrefixModules("token_mixer")
 channel_mixers = PrefixModules("channel_mixer")
 encoders = PrefixModules("encoders")
+
+
+def override_reference_registry(reference_module_dict: Dict[str, Any], names: Optional[List[str]] = None) -> int:
+    """INTEGRATION.md §2 as one call: put this package's classes into the REFERENCE's registry
+    (`cflearn.modules.common.module_dict`) under the reference's own names, so that the reference's unchanged
+    `build_module` (modules/common.py:37-53 — how `CommonDLModel.build`, `build_encoder`, `build_attention` ... create
+    every module) returns the HIP-backed classes.  Direct dict assignment, because the reference's
+    `register_module` warns and SKIPS an existing name (cftool `register_core`, allow_duplicate=False).
+    `names`: restrict the override (default: every name this package registers).  Returns the number of entries set."""
+    count = 0
+    for name, cls in module_dict.items():
+        if names is not None and name not in names:
+            continue
+        reference_module_dict[name] = cls
+        count += 1
+    return count

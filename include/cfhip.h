@@ -363,6 +363,47 @@ int cfhip_sgemm_f32(const float* A, const float* B, float* C, int M, int N, int 
                     int a_trans, int b_trans, const float* alpha_dev, float alpha, void* stream);
 int cfhip_dot_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * A12  dropout / stochastic depth (nn.Dropout at channel_mixers.py:30-41, mixed_stacks/api.py:130-158,
+ *      ml_encoder.py:60-70, mappings.py:60-80; DropPath at modules/core/customs.py:429-446)
+ *   dropout: y[i] = keep_i ? x[i] * s : 0 with s = 1 / (1 - p) in x's dtype (bf16 tensors: s rounded to bf16 first,
+ *     as torch forms its noise `mask / (1 - p)` in the input's dtype) — bit-equal to torch given the mask.  keep_i = mask_in[i] != 0 when mask_in is given (one byte per element: parity tests inject the
+ *     reference's mask), else u_i >= p with u from Philox4x32-10 keyed by `seed`, counter = offset + i / 4, lane i % 4
+ *     — a pure function of (seed, offset, i), so the BACKWARD is the same call on dy with the same (seed, offset):
+ *     no mask tensor is stored.  A call consumes ceil(n / 4) counters.  mask_out (optional) receives the mask.
+ *     x / y bf16 or f32, 16-byte aligned; 0 <= p < 1.
+ *   drop_path_mask: mask[b] = floor(keep_prob + u_b), 0 or 1 (customs.py:439-441), u_b from the same generator
+ *     (counter = offset + b / 4).  drop_path: y[b][:] = (x[b][:] / keep_prob) * mask[b] — the reference's two
+ *     roundings (customs.py:442) with a true IEEE division, `inner` elements per sample (inner % 4 == 0), bf16 or
+ *     f32; bit-equal to the reference given the mask.  Its backward is the same call on dy.
+ * ------------------------------------------------------------------------------------------ */
+int cfhip_dropout(const void* x, void* y, int is_f32, int64_t n, float p, uint64_t seed, uint64_t offset,
+                  const uint8_t* mask_in, uint8_t* mask_out, void* stream);
+int cfhip_drop_path_mask(float* mask, int64_t B, float keep_prob, uint64_t seed, uint64_t offset, void* stream);
+int cfhip_drop_path(const void* x, void* y, int is_f32, const float* mask, float keep_prob, int64_t B, int64_t inner,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A16  tabular encoder (ml_encoder.Encoder.forward, modules/core/ml_encoder.py:171-209, + CommonMLModel.encode,
+ *      models/ml/common.py:67-87) as one gather: out[b] = [numerical columns | one-hot blocks | embedding rows].
+ *   plan: Fo entries of 6 int32 {src column, kind (0 copy / 1 one-hot / 2 embedding), payload (class id / table
+ *     column), table id, dim (number of categories), table row pitch}, built by the host once per encoder.
+ *   Categorical value v -> index: v >= dim -> 0 (the reference's out-of-bound imputation), else (int64)v
+ *     (truncation, `.to(torch.long)`).  Integer index work: one-hot block and gathered rows are bit-exact.
+ *   tables / dtables: device arrays of f32 base pointers, one per embedding column (`embeddings.<col>.weights`,
+ *     [dim][pitch]); a NULL dtables entry skips that table's gradient.
+ *   indices: int64 [B][K] of the K categorical columns (EncodingResult.indices).
+ *   bwd: numerical outputs -> dx[b][src] (dx may be NULL), embedding outputs -> f32 atomic scatter-add into dtables
+ *     (caller zeroes / owns them); one-hot outputs carry no gradient.
+ * ------------------------------------------------------------------------------------------ */
+int cfhip_ml_encode_fwd(const float* x, int64_t B, int F, int64_t x_row_stride, const int32_t* plan, int Fo,
+                        const void* const* tables, float* out, void* stream);
+int cfhip_ml_encode_indices(const float* x, int64_t B, int64_t x_row_stride, const int32_t* cols, const int32_t* dims,
+                            int K, int64_t* indices, void* stream);
+int cfhip_ml_encode_bwd(const float* dout, const float* x, int64_t B, int F, int64_t x_row_stride, const int32_t* plan,
+                        int Fo, void* const* dtables, float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

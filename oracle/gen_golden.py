@@ -473,13 +473,84 @@ def gen_ddpm_schedule(ref) -> None:
                     noise=noise, t=t, x_t=x_t), os.path.join(OUT, "ddpm_schedule.pt"))
 
 
+def gen_ml_encoder(ref) -> None:
+    """The reference's own `ml.encoder` + `CommonMLModel.encode`.  Two cases: mixed one-hot / embedding columns with
+    in-range categories, and all-embedding columns with out-of-bound categories (the reference imputes out-of-bound
+    values only through the shared `indices`, i.e. when every categorical column uses the same method:
+    ml_encoder.py:186-199 re-reads the raw batch otherwise and F.one_hot / F.embedding raise)."""
+    import ml_oracle as MO
+
+    Settings = sys.modules["cflearn.schema"].MLEncoderSettings
+    CommonMLModel = sys.modules["cflearn.models.ml.common"].CommonMLModel
+    cases = {}
+    for name, settings, oob in (
+        ("mixed", {"1": Settings(5, "one_hot"), "3": Settings(7, "embedding", dict(out_dim=6)),
+                   "4": Settings(3, ["one_hot", "embedding"]), "6": Settings(11, "embedding")}, 0),
+        ("all_embedding_oob", {"0": Settings(4, "embedding"), "2": Settings(9, "embedding", dict(out_dim="sqrt"))}, 2),
+    ):
+        torch.manual_seed(21)
+        enc = ref.build_module("ml.encoder", config=dict(settings=settings))
+        enc.eval()  # embedding dropout off: the deterministic part
+        b, f = 37, 8
+        x = torch.randn(b, f)
+        for c, st in settings.items():
+            x[:, int(c)] = torch.randint(0, st.dim + oob, (b,)).float()  # dim, dim + 1 are out of bound -> 0
+        first = int(sorted(settings)[0])
+        x[0, first] = settings[str(first)].dim - 1 + 0.9  # truncation toward zero, not rounding
+        model = CommonMLModel()
+        model.m = torch.nn.ModuleDict(dict(encoder=enc))
+        pack = model.encode(x)
+        res = enc(x)
+        sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+        tables = {int(k.split(".")[1]): v for k, v in sd.items() if k.startswith("embeddings.")}
+        idx, oh, emb, merged = MO.encode(x, enc.tgt_columns, [settings[str(c)].dim for c in enc.tgt_columns],
+                                         enc.one_hot_columns, enc.embedding_columns, tables)
+        assert torch.equal(idx, res.indices) and torch.equal(emb, res.embedding)
+        assert (oh is None and res.one_hot is None) or torch.equal(oh, res.one_hot)
+        assert torch.equal(merged, pack.merged_all)
+        enc.zero_grad()
+        g = torch.randn_like(pack.merged_all)
+        model.encode(x).merged_all.backward(g)
+        grads = {k: p.grad.detach().clone() for k, p in enc.named_parameters()}
+        cfg = {k: dict(dim=v.dim, methods=v.methods, method_configs=v.method_configs) for k, v in settings.items()}
+        cases[name] = dict(settings=cfg, sd=sd, x=x, indices=res.indices,
+                           one_hot=None if res.one_hot is None else res.one_hot.detach(),
+                           embedding=res.embedding.detach(), merged_all=pack.merged_all.detach(), gy=g, grads=grads,
+                           dim_increment=enc.dim_increment)
+    torch.save(cases, os.path.join(OUT, "ml_encoder.pt"))
+
+
+def gen_stochastic(ref) -> None:
+    """nn.Dropout and the reference's DropPath: outputs AND the masks they drew (recovered from the outputs), so that
+    the kernels can be checked bit-for-bit with the mask injected."""
+    import ml_oracle as MO
+
+    torch.manual_seed(31)
+    out = {}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        x = (torch.randn(33, 40) + 3.0).to(dt)  # no zeros: the keep mask is recoverable from y != 0
+        p = 0.3
+        y = torch.nn.functional.dropout(x, p, training=True)
+        mask = (y != 0).to(torch.uint8)
+        assert torch.equal(MO.dropout(x, mask, p), y)
+        dp = ref.core.DropPath(0.25)
+        dp.train()
+        xb = (torch.randn(9, 5, 8) + 3.0).to(dt)
+        yb = dp(xb)
+        mb = (yb.reshape(9, -1).abs().sum(1) != 0).float()
+        assert torch.equal(MO.drop_path(xb, mb, 0.75), yb)
+        out[name] = dict(x=x, p=p, y=y, mask=mask, xb=xb, rate=0.25, yb=yb, mb=mb)
+    torch.save(out, os.path.join(OUT, "stochastic.pt"))
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
     torch.set_num_threads(4)
     only = sys.argv[1:]
     for fn in (gen_linear, gen_layernorm, gen_sdp, gen_attention, gen_feedforward, gen_vit, gen_conv2d,
-               gen_batchnorm, gen_mnist_clf, gen_fcnn, gen_clip, gen_resblock, gen_spatial_transformer, gen_unet, gen_ddpm_schedule):
+               gen_batchnorm, gen_mnist_clf, gen_fcnn, gen_clip, gen_resblock, gen_spatial_transformer, gen_unet, gen_ddpm_schedule,
+               gen_ml_encoder, gen_stochastic):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

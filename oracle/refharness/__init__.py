@@ -1,12 +1,20 @@
-"""Import the reference's OWN hot-path modules from /root/reference (read-only).
+"""Import the reference's OWN package from /root/reference (read-only) and run it.
 
 TEST INFRASTRUCTURE ONLY (build container only: /root/reference does not exist on the GPU box).
-Used by `oracle/gen_golden.py` and by the `not gpu` tests that pin `oracle/vit_oracle.py`
-against the reference; never by the product path.
+Used by `oracle/gen_golden.py`, by the `not gpu` tests that pin `oracle/*_oracle.py` against the reference, by the
+tests that drive the reference's own trainer / step engine over this repo's modules, and by `bench.py`'s
+`cpu_baseline` leg (kind "reference"); never by the product path.
 
-Recipe: package *shells* whose `__path__` points at the reference directories are
-put in `sys.modules`, which skips the reference's `__init__.py` files (they pull in data / api /
-torchvision), and a small `cftool` stand-in (./cftool) satisfies the un-vendored dependency.
+Recipe (full-shim row): `import cflearn` — the real package, through its own `__init__.py` files —
+works once three gaps are filled from here:
+  * `cftool` (carefree-toolkit, un-vendored, pinned only as >= 0.3.12 by setup.py:45): ./cftool restates the names the
+    reference imports, with behaviour where its call sites need it (registry, safe_execute, Serializer, IPipeline /
+    IBlock, DataClassBase ...);
+  * `torchvision` (not installed): ./stubs.py installs placeholder modules (datasets / PIL transforms are never used
+    on the training path);
+  * two version drifts: `importlib.metadata.version("carefree-learn")` (the tree is not pip-installed) and
+    `ReduceLROnPlateau(verbose=...)` (keyword removed from torch 2.10) — patched in ./stubs.py, the reference itself
+    is untouched.
 """
 import importlib
 import os
@@ -16,19 +24,6 @@ from typing import Optional
 
 REFERENCE_ROOT = os.environ.get("CFLEARN_REFERENCE_ROOT", "/root/reference")
 
-_SHELLS = [
-    "cflearn",
-    "cflearn.modules",
-    "cflearn.modules.cv",
-    "cflearn.modules.cv.encoder",
-    "cflearn.modules.cv.classifier",
-    "cflearn.modules.ml",
-    "cflearn.modules.nlp",
-    "cflearn.modules.nlp.encoder",
-    "cflearn.modules.multimodal",
-    "cflearn.modules.multimodal.diffusion",
-]
-
 _loaded: Optional[types.SimpleNamespace] = None
 
 
@@ -36,60 +31,38 @@ def reference_available() -> bool:
     return os.path.isdir(os.path.join(REFERENCE_ROOT, "cflearn", "modules", "core"))
 
 
+def import_cflearn() -> types.ModuleType:
+    """`import cflearn` from the reference tree (the whole package: schema, trainer, pipeline, api ...)."""
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found under {REFERENCE_ROOT}")
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    from . import stubs
+
+    stubs.install_torchvision()
+    stubs.patch_torch_compat()
+    stubs.patch_package_version()
+    if "cftool" not in sys.modules:
+        importlib.import_module("cftool")
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    return importlib.import_module("cflearn")
+
+
 def load_reference() -> types.SimpleNamespace:
     """Returns a namespace with the reference classes used by the oracle checks."""
     global _loaded
     if _loaded is not None:
         return _loaded
-    if not reference_available():
-        raise RuntimeError(f"reference tree not found under {REFERENCE_ROOT}")
-    here = os.path.dirname(os.path.abspath(__file__))
-    if "cftool" not in sys.modules:
-        sys.path.insert(0, here)
-        importlib.import_module("cftool")
-        for sub in ("misc", "array", "types", "pipeline", "cv"):
-            importlib.import_module(f"cftool.{sub}")
-    if "torchvision" not in sys.modules:
-        # torchvision is not installed; the reference CLIP module imports transform class names at module
-        # level (used only by `get_transform`, which the oracle never calls)
-        tv = types.ModuleType("torchvision")
-        tvt = types.ModuleType("torchvision.transforms")
-        for name in ("Resize", "Compose", "ToTensor", "Normalize", "CenterCrop"):
-            setattr(tvt, name, type(name, (), {"__init__": lambda self, *a, **k: None}))
-        tvt.InterpolationMode = types.SimpleNamespace(BICUBIC="bicubic")
-        tv.transforms = tvt
-        sys.modules["torchvision"] = tv
-        sys.modules["torchvision.transforms"] = tvt
-    for name in _SHELLS:
-        if name in sys.modules:
-            continue
-        shell = types.ModuleType(name)
-        shell.__path__ = [os.path.join(REFERENCE_ROOT, *name.split("."))]  # type: ignore
-        shell.__package__ = name
-        sys.modules[name] = shell
-        if "." in name:
-            parent, child = name.rsplit(".", 1)
-            setattr(sys.modules[parent], child, shell)
-
+    cflearn = import_cflearn()
     common = importlib.import_module("cflearn.modules.common")
     core = importlib.import_module("cflearn.modules.core")
     toolkit = importlib.import_module("cflearn.toolkit")
-    # emulate `from .common import *` / `from .core import *` of cflearn/modules/__init__.py
-    modules_shell = sys.modules["cflearn.modules"]
-    for mod in (common, core):
-        for k in dir(mod):
-            if not k.startswith("_") and not hasattr(modules_shell, k):
-                setattr(modules_shell, k, getattr(mod, k))
-    cv_common = importlib.import_module("cflearn.modules.cv.common")
-    for k in dir(cv_common):
-        if not k.startswith("_") and not hasattr(modules_shell, k):
-            setattr(modules_shell, k, getattr(cv_common, k))
     vit = importlib.import_module("cflearn.modules.cv.encoder.transformer")
     fcnn = importlib.import_module("cflearn.modules.ml.fcnn")
-    # names the reference's package __init__ files would have re-exported (the shells skip them)
-    setattr(sys.modules["cflearn.modules.cv.encoder"], "ViTEncoder", vit.ViTEncoder)
-
     _loaded = types.SimpleNamespace(
+        cflearn=cflearn,
         common=common,
         core=core,
         toolkit=toolkit,

@@ -15,3 +15,5 @@ except Exception:  # pragma: no cover
 np_dict_type = Dict[str, Any]
 general_config_type = Any
 configs_type = Any
+
+TNumberPair = Any

@@ -86,8 +86,16 @@ def test_unsupported_features_raise():
         C.Conv2d(4, 8, kernel_size=3, groups=2)
     with pytest.raises(NotImplementedError):
         C.Conv2d(3, 8, kernel_size=3, padding="reflection")
-    with pytest.raises(NotImplementedError):
-        C.modules.Mapping(8, 8, dropout=0.5)
+    # round 2: dropout / DropPath are built (csrc/random.hip): the constructors keep the reference's modules in place
+    mp = C.modules.Mapping(8, 8, dropout=0.5)
+    assert isinstance(mp.dropout, C.modules.Dropout) and mp.dropout.p == 0.5
+    assert C.modules.Mapping(8, 8, dropout=0.0).dropout is None  # mappings.py:66-67
+    blk = C.MixingBlock(0, 2, 5, 64, 128, token_mixing_type="attention", token_mixing_config=dict(num_heads=1),
+                        dropout=0.1, drop_path=0.2, norm_type="layer")
+    assert isinstance(blk.drop_path, C.modules.DropPath) and blk.drop_path.dropout == 0.2
+    assert blk._stochastic() and not blk._fusable()      # training mode: the composed path with the random masks
+    blk.eval()
+    assert not blk._stochastic()                          # eval mode: dropout is the identity, fused path allowed
 
 
 def test_param_arena_views_and_lazy_zero():

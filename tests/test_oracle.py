@@ -269,3 +269,23 @@ def test_unet_diffuser_oracle(golden):
     for k, ref in g["grads"].items():
         ref = ref.float()
         assert (lv[k].grad - ref).abs().max() <= max(2e-5, 2e-3 * ref.abs().max()), k
+
+
+def test_ml_and_stochastic_oracles_match_reference_fixtures(golden):
+    """oracle/ml_oracle.py against tests/golden/ml_encoder.pt / stochastic.pt (made from the reference's `ml.encoder`,
+    `CommonMLModel.encode`, `DropPath` and torch's dropout by oracle/gen_golden.py): bit-exact."""
+    import ml_oracle as MO
+
+    for case in golden("ml_encoder.pt").values():
+        st = case["settings"]
+        cols = sorted(int(k) for k in st)
+        uses = lambda k, m: st[str(k)]["methods"] == m or (isinstance(st[str(k)]["methods"], list) and m in st[str(k)]["methods"])  # noqa: E731
+        tables = {int(k.split(".")[1]): v for k, v in case["sd"].items() if k.startswith("embeddings.")}
+        idx, oh, emb, merged = MO.encode(case["x"], cols, [st[str(c)]["dim"] for c in cols],
+                                         [c for c in cols if uses(c, "one_hot")], [c for c in cols if uses(c, "embedding")],
+                                         tables)
+        assert torch.equal(idx, case["indices"]) and torch.equal(emb, case["embedding"])
+        assert torch.equal(merged, case["merged_all"])
+    for g in golden("stochastic.pt").values():
+        assert torch.equal(MO.dropout(g["x"], g["mask"], g["p"]), g["y"])
+        assert torch.equal(MO.drop_path(g["xb"], g["mb"], 1.0 - g["rate"]), g["yb"])

@@ -1,0 +1,172 @@
+"""The reference's OWN package (imported from /root/reference through oracle/refharness) on CPU:
+
+  * BASELINE config 1: `cflearn.api.fit_ml` FCNN on synthetic tabular data (api/api.py:496-526), CPU, world size 1;
+  * the drop-in boundary: INTEGRATION.md §2's registry override executed on the reference's real `module_dict`, built
+    through the reference's `build_module` (modules/common.py:37-53);
+  * the pin of `oracle/trainer_oracle.py` (the step-engine restatement the GPU tests drive the HIP modules with)
+    against the reference's `IDLModel.train` / `get_update_fn` / `Trainer.clip_norm_step` (schema.py:977-986,
+    1174-1294; trainer.py:170-176): bit-equal losses and weights on the same model and batches;
+  * the reference's gradient checkpointing (`toolkit.py:2535-2647`) around modules of this package (row U6).
+
+Build container only (`/root/reference` is absent on the GPU box): every test here is `not gpu`.
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import refharness  # noqa: E402
+import trainer_oracle as TO  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not refharness.reference_available(), reason="/root/reference is not present")
+
+
+@pytest.fixture(scope="module")
+def cflearn():
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return refharness.import_cflearn()
+
+
+def test_reference_fit_ml_fcnn_cpu(cflearn, tmp_path, monkeypatch):
+    """BASELINE.json configs[0]: FCNN tabular classifier on synthetic data via cflearn.api (SURVEY §8d inputs)."""
+    monkeypatch.chdir(tmp_path)
+    x = np.random.RandomState(0).randn(2000, 32).astype(np.float32)
+    w = np.random.RandomState(1).randn(32, 3)
+    y = (x @ w).argmax(1).reshape(-1, 1)  # learnable labels: the loss must go down
+    config = cflearn.MLConfig(module_name="fcnn", module_config=dict(input_dim=32, output_dim=3), loss_name="focal",
+                              fixed_steps=200, tqdm_settings=None)
+    m = cflearn.api.fit_ml(x, y, config=config, device="cpu")
+    loader = m.data.build_loader(x, y)
+    preds = m.predict(loader)[TO.PREDICTIONS_KEY]
+    assert preds.shape == (2000, 3)
+    acc = (preds.argmax(1) == y.ravel()).mean()
+    assert acc > 0.8, acc  # 200 steps of the reference's own trainer on the CPU learn the linear rule
+
+
+def test_registry_override_on_the_reference_module_dict(cflearn):
+    """INTEGRATION.md §2 on the reference's REAL registry: after the override, the reference's own `build_module`
+    (the only way its models create modules) hands out this package's classes, which keep the reference's
+    constructor keywords and state_dict keys."""
+    import cflearn_amd as C
+
+    common = sys.modules["cflearn.modules.common"]
+    cfg = dict(input_dim=10, output_dim=3, hidden_units=[16, 16])
+    ref_fcnn = common.build_module("fcnn", config=dict(cfg))
+    ref_keys = list(ref_fcnn.state_dict().keys())
+    saved = dict(common.module_dict)
+    try:
+        n = C.override_reference_registry(common.module_dict)
+        assert n >= 5
+        ours = common.build_module("fcnn", config=dict(cfg, some_unknown_keyword=1))  # safe_execute drops extras
+        assert type(ours).__module__.startswith("cflearn_amd")
+        assert list(ours.state_dict().keys()) == ref_keys
+        ours.load_state_dict(ref_fcnn.state_dict())  # checkpoints move both ways
+        clf = common.build_module("cv_clf", config=dict(in_channels=1, num_classes=10, img_size=28, latent_dim=64,
+                                                        encoder="vanilla_1d",
+                                                        encoder_config=dict(num_downsample=3)))
+        assert type(clf).__module__.startswith("cflearn_amd")
+    finally:
+        common.module_dict.clear()
+        common.module_dict.update(saved)
+    assert type(common.build_module("fcnn", config=dict(cfg))).__module__.startswith("cflearn.")
+
+
+def _mlp() -> torch.nn.Module:
+    torch.manual_seed(3)
+    return torch.nn.Sequential(torch.nn.Linear(12, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+
+
+def _batches(n: int):
+    g = torch.Generator().manual_seed(7)
+    return [{TO.INPUT_KEY: torch.randn(8, 12, generator=g), TO.LABEL_KEY: torch.randint(0, 4, (8, 1), generator=g)}
+            for _ in range(n)]
+
+
+@pytest.mark.parametrize("loss_name,grad_accumulate,clip_norm", [("focal", 1, 0.0), ("cross_entropy", 2, 0.05),
+                                                                  ("focal", 3, 0.1)])
+def test_step_engine_oracle_matches_the_reference(cflearn, loss_name, grad_accumulate, clip_norm):
+    """`oracle/trainer_oracle.StepEngine` against the reference's `CommonDLModel.train` driven by a trainer object
+    that carries the reference's own `Trainer.clip_norm_step`: same losses (the `.item()` values) and bit-equal weights
+    after 6 batches, with gradient accumulation and clipping."""
+    CommonDLModel = sys.modules["cflearn.models.common"].CommonDLModel
+    build_loss = sys.modules["cflearn.losses"].build_loss
+    Trainer = sys.modules["cflearn.trainer"].Trainer
+
+    # reference side
+    ref = CommonDLModel()
+    ref.m = _mlp()
+    ref.loss = build_loss(loss_name)
+    opt_ref = torch.optim.SGD(ref.m.parameters(), lr=0.1)
+
+    class _Accel:
+        sync_gradients = True
+
+        @staticmethod
+        def backward(loss):
+            loss.backward()
+
+        @staticmethod
+        def clip_grad_norm_(params, max_norm):
+            return torch.nn.utils.clip_grad_norm_(params, max_norm)
+
+    trainer = types.SimpleNamespace(state=TO.State(), accelerator=_Accel(), optimizers={"all": opt_ref},
+                                    config=TO.Config(grad_accumulate, clip_norm), should_autocast=False,
+                                    model_for_training=ref.m, scheduler_step=lambda: None, _gradient_norm=None)
+    trainer.clip_norm_step = types.MethodType(Trainer.clip_norm_step, trainer)  # the reference's own method
+    ref_losses = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # torch.cuda.amp.autocast deprecation inside the reference
+        for i, batch in enumerate(_batches(6)):
+            trainer.state.step += 1
+            out = ref.train(i, batch, trainer, {}, {})
+            ref_losses.append(out.loss_dict[TO.LOSS_KEY])
+
+    # restatement
+    mine = _mlp()
+    eng = TO.StepEngine(mine, loss_name, torch.optim.SGD(mine.parameters(), lr=0.1), grad_accumulate=grad_accumulate,
+                        clip_norm=clip_norm)
+    eng.fit(_batches(6))
+    assert [d[TO.LOSS_KEY] for d in eng.loss_log] == ref_losses
+    for a, b in zip(mine.parameters(), ref.m.parameters()):
+        assert torch.equal(a, b)
+    for a, b in zip(mine.parameters(), _mlp().parameters()):
+        assert not torch.equal(a, b)  # and training did move them
+
+
+def test_reference_gradient_checkpoint_reenters_custom_functions(cflearn):
+    """Row U6: the reference's `gradient_checkpoint` (toolkit.py:2535-2647) re-runs the wrapped forward inside
+    backward under `torch.autograd.grad` — a second, re-entrant trip through every custom autograd Function in it.
+    The parameter-gradient protocol of this package's Functions (write straight into `.grad`, return None, run the
+    gradient-ready callbacks) must survive that: exercised here with the CPU stand-in that follows the same protocol
+    (tests/test_ddp_gloo._DirectLinear); the HIP Functions themselves are covered on the GPU by
+    tests/test_gpu_unet.py::test_gradient_checkpoint_matches_plain_backward."""
+    from test_ddp_gloo import _DirectLinear
+
+    gradient_checkpoint = sys.modules["cflearn.toolkit"].gradient_checkpoint
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(6, 6)
+    for p in lin.parameters():
+        p.grad = torch.zeros_like(p)
+    x = torch.randn(5, 6, requires_grad=True)
+
+    def block(inp):
+        return torch.tanh(_DirectLinear.apply(inp, lin.weight, lin.bias))
+
+    y = gradient_checkpoint(block, (x,), tuple(lin.parameters()), True)
+    y.sum().backward()
+    gw, gb, gx = lin.weight.grad.clone(), lin.bias.grad.clone(), x.grad.clone()
+    # plain autograd on the same math
+    lin2 = torch.nn.Linear(6, 6)
+    lin2.load_state_dict(lin.state_dict())
+    x2 = x.detach().clone().requires_grad_(True)
+    torch.tanh(lin2(x2)).sum().backward()
+    assert torch.allclose(gx, x2.grad, atol=1e-6)
+    assert torch.allclose(gw, lin2.weight.grad, atol=1e-6) and torch.allclose(gb, lin2.bias.grad, atol=1e-6)

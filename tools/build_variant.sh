@@ -9,7 +9,7 @@ ROOT="$(dirname "$(readlink -f "$0")")/.."
 cd "$ROOT/carefree-learn_amd/csrc"
 mkdir -p ../_build/$NAME
 pids=()
-for f in errors gemm attn norm elementwise conv embed; do
+for f in errors gemm attn norm elementwise conv embed random tabular; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics "$@" -c $f.hip -o ../_build/$NAME/$f.o &
   pids+=($!)
 done
