@@ -30,7 +30,8 @@ class TrainStep:
     def __init__(self, model: torch.nn.Module, *, lr: float = 1.0e-4, betas: Any = (0.9, 0.999),
                  eps: float = 1.0e-8, weight_decay: float = 0.0, decoupled: bool = True,
                  use_graph: bool = False, distributed: bool = False, bucket_bytes: int = 64 << 20,
-                 output_key: str = "predictions", loss: str = "cross_entropy", clip_norm: float = 0.0):
+                 output_key: str = "predictions", loss: str = "cross_entropy", clip_norm: float = 0.0,
+                 wire_bf16: bool = False):
         if loss not in ("cross_entropy", "focal"):
             raise ValueError(f"unknown loss '{loss}' (cross_entropy: losses/basic.py:126-141, focal: :170-206)")
         self.model = model
@@ -47,7 +48,8 @@ class TrainStep:
             SideStream.ensure()  # the stream self-check runs here, not inside the first timed step
         self.reducer: Optional[BucketedAllReduce] = None
         if distributed:
-            self.reducer = BucketedAllReduce(self.arena, bucket_bytes=bucket_bytes, optimizer=self.optimizer)
+            self.reducer = BucketedAllReduce(self.arena, bucket_bytes=bucket_bytes, optimizer=self.optimizer,
+                                             wire_bf16=wire_bf16)
             self.reducer.broadcast_parameters(0)
         self.use_graph = use_graph and not distributed
         self._graph: Optional[torch.cuda.CUDAGraph] = None

@@ -57,6 +57,28 @@ def pick_split_k(m: int, n: int, k: int) -> int:
     return max(1, min(steps // 4, (512 + tiles - 1) // tiles))
 
 
+class GemmTimer:
+    """Opt-in (bench.py's roofline pass): HIP-event pairs around every GEMM launch of the REAL training step, recorded
+    on the stream the kernel is launched on (torch's current stream at the call: the main stream or a side stream),
+    keyed by (layout, M, N, K, epilogue).  Off by default: `ops.GEMM_TIMER is None` costs one attribute read."""
+
+    def __init__(self) -> None:
+        self.records: list = []
+
+    def durations(self) -> dict:
+        """key -> [count, total seconds]; synchronises on the recorded events"""
+        out: dict = {}
+        for key, e0, e1 in self.records:
+            e1.synchronize()
+            ent = out.setdefault(key, [0, 0.0])
+            ent[0] += 1
+            ent[1] += e0.elapsed_time(e1) * 1.0e-3
+        return out
+
+
+GEMM_TIMER: Optional[GemmTimer] = None
+
+
 def gemm(
     a: Tensor,
     b: Tensor,
@@ -109,12 +131,20 @@ def gemm(
     if split_k > 1:
         ws = torch.empty((split_k * m * (n + (1 if bias_grad is not None else 0)),), dtype=f32, device=a.device)
         ws_bytes = ws.numel() * 4
+    timer = GEMM_TIMER
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = _lib.load().cfhip_gemm_bf16(
         a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(bias), _p(aux_in), _p(aux_out), m, n, k, lda,
         ldb, ldc, int(a_trans), int(b_trans), epilogue, 1 if out.dtype == f32 else 0,
         int(accumulate), split_k, _p(ws), ws_bytes, _p(bias_grad), int(bias_grad_accumulate), _stream(),
     )
     _lib.check(rc, "gemm")
+    if timer is not None:
+        e1.record()
+        layout = "tn" if a_trans else ("nn" if b_trans else "nt")
+        timer.records.append(((layout, m, n, k, int(epilogue)), e0, e1))
     return out
 
 

@@ -1,7 +1,2 @@
-#!/bin/bash
-cd "${GRAFT_REPO_ROOT:-/root/repo}"
-export TMPDIR=/tmp
-mkdir -p gpurun_out
-for b in "$@"; do
-timeout 300 python tools/step_ab.py $b > gpurun_out/step_ab$b.log 2>&1; echo "== ab$b exit $?"; tail -6 gpurun_out/step_ab$b.log
-done
+mkdir -p gpurun_out/ab
+timeout 300 python tools/step_ab.py 128 > gpurun_out/ab/step_ab.log 2>&1; tail -4 gpurun_out/ab/step_ab.log

@@ -9,5 +9,5 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   echo "== $ctr exit $?"; tail -n 2 gpurun_out/pmc_step/$ctr.log | cut -c1-300
 done
 f=$(ls gpurun_out/pmc_step/FETCH_SIZE/*counter_collection.csv | head -1); w=$(ls gpurun_out/pmc_step/WRITE_SIZE/*counter_collection.csv | head -1)
-python tools/pmc_step_summary.py "$f" "$w" 3 > gpurun_out/pmc_step/pmc_step.json; cat gpurun_out/pmc_step/pmc_step.json
+python tools/pmc_step_summary.py "$f" "$w" 3 > gpurun_out/pmc_step/pmc_step_b128.json; cat gpurun_out/pmc_step/pmc_step_b128.json
 rm -rf gpurun_out/pmc_step/FETCH_SIZE gpurun_out/pmc_step/WRITE_SIZE

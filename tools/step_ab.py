@@ -17,23 +17,28 @@ BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 img = torch.randn(BATCH, 3, 224, 224, generator=g).to(dev)
 labels = torch.randint(0, 1000, (BATCH,), generator=g).to(dev)
 
+HIGH = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[1] if False else -1)
 VARIANTS = {
-    "LN bwd split: dx main stream, dgamma/dbeta side stream (round 1)": dict(split_ln=True, fused=1),
-    "LN bwd ONE launch, half-wave-per-row kernel": dict(split_ln=False, fused=1),
-    "LN bwd one launch, round-1 one-wave-per-row kernel": dict(split_ln=False, fused=0),
+    "shipped (main = default stream)": dict(high=False),
+    "whole step issued on a HIGH-priority stream (side streams stay normal)": dict(high=True),
 }
+STATE = dict(high=False)
 
 def apply(v):
-    from cflearn_amd import fused
-    fused.SPLIT_LN_BWD = v["split_ln"]
-    ops.set_option("ln_bwd_fused", v["fused"])
+    STATE["high"] = v["high"]
 
 
 def run(n):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(n):
-        ts.step(img, labels)
+    if STATE["high"]:
+        HIGH.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(HIGH):
+            for _ in range(n):
+                ts.step(img, labels)
+    else:
+        for _ in range(n):
+            ts.step(img, labels)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 
