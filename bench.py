@@ -306,6 +306,9 @@ def main() -> None:
     ap.add_argument("--gemm-reps", type=int, default=10)
     ap.add_argument("--bucket-mb", type=int, default=64, help="gradient bucket size of the RCCL exchange (sweep on an 8-GPU node)")
     ap.add_argument("--wire-bf16", action="store_true", help="all-reduce bf16 copies of the gradient buckets (half the xGMI bytes)")
+    ap.add_argument("--comm", default="torch", choices=["torch", "cfhip"],
+                    help="who launches the RCCL collectives: torch.distributed (default) or the cfhip_comm_* C-ABI on "
+                         "this package's own, queue-checked comm stream")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra (untimed) steps with event pairs around every GEMM launch")
     ap.add_argument("--watchdog", type=int, default=0, help="dump all Python stacks every N seconds")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for the "
@@ -356,7 +359,8 @@ def main() -> None:
     torch.manual_seed(0)  # identical init on every rank (and rank 0 is broadcast anyway)
     model = C.vit_b16_classifier(1000).to(dev)
     ts = TrainStep(model, lr=1.0e-4, weight_decay=0.0, decoupled=True, use_graph=args.graph and not args.no_graph,
-                   distributed=distributed, bucket_bytes=args.bucket_mb << 20, wire_bf16=args.wire_bf16)
+                   distributed=distributed, bucket_bytes=args.bucket_mb << 20, wire_bf16=args.wire_bf16,
+                   comm=args.comm)
     if ts.reducer is not None:
         ts.reducer.time_exposed = True
     g = torch.Generator().manual_seed(1234 + rank)
@@ -440,7 +444,7 @@ def main() -> None:
             "input": "resident in HBM" if feed is None else "host numpy -> TensorBatcher (copy stream, 1 batch ahead, device buffer ring)",
             "grad_exchange": "none" if not distributed else (
                 f"bucketed RCCL all-reduce {'bf16 wire' if args.wire_bf16 else 'fp32'}, {args.bucket_mb} MB buckets "
-                f"({len(ts.reducer.buckets)}), side stream"),
+                f"({len(ts.reducer.buckets)}), side stream, launched by {args.comm}"),
             "loss_first_step": None if first_loss is None else round(first_loss, 4),
             "loss_last_step": round(last_loss, 4),
         },

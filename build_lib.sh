@@ -5,10 +5,10 @@ cd "$(dirname "$0")/carefree-learn_amd/csrc"
 OUT=../libcfhip.so
 mkdir -p ../_build
 pids=()
-for f in errors gemm attn norm elementwise conv embed random tabular; do
+for f in errors gemm attn norm elementwise conv embed random tabular comm; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -c $f.hip -o ../_build/$f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../_build/*.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../_build/*.o -ldl
 echo "built $(realpath $OUT)"

@@ -46,6 +46,79 @@ def get_ddp_info() -> Optional[dict]:
     return None
 
 
+class Communicator:
+    """RCCL communicator owned by this package through the C-ABI (`cfhip_comm_*`, include/cfhip.h): collectives are
+    launched on the stream the CALLER names — the comm stream that `functional.distinct_stream` has checked for a
+    hardware queue of its own — instead of the internal stream of a torch ProcessGroup.  The 128-byte RCCL unique id
+    travels through the already-initialised torch.distributed group (rendezvous only: one broadcast at start-up)."""
+
+    def __init__(self, group: Any = None):
+        import ctypes
+
+        from . import _lib
+
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("Communicator needs torch.distributed for the rendezvous of the RCCL unique id")
+        self._lib = _lib
+        lib = _lib.load()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (ctypes.c_char * 128)()
+            _lib.check(lib.cfhip_comm_unique_id(buf), "comm_unique_id")
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if self.world > 1:
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            uid = uid.to(dev)
+            dist.broadcast(uid, src=0, group=group)
+            uid = uid.cpu()
+        handle = ctypes.c_void_p()
+        raw = (ctypes.c_char * 128).from_buffer_copy(bytes(uid.tolist()))
+        _lib.check(lib.cfhip_comm_init(self.rank, self.world, raw, ctypes.byref(handle)), "comm_init")
+        self.handle = handle
+
+    @staticmethod
+    def _dt(t: Tensor) -> int:
+        if t.dtype == torch.float32:
+            return 0
+        if t.dtype == torch.bfloat16:
+            return 1
+        raise TypeError(f"cfhip comm: f32 or bf16 tensors only, got {t.dtype}")
+
+    def all_reduce_(self, t: Tensor, stream: "torch.cuda.Stream") -> None:
+        self._lib.check(self._lib.load().cfhip_comm_allreduce(self.handle, t.data_ptr(), t.numel(), self._dt(t),
+                                                              stream.cuda_stream), "comm_allreduce")
+
+    def broadcast_(self, t: Tensor, root: int, stream: "torch.cuda.Stream") -> None:
+        self._lib.check(self._lib.load().cfhip_comm_broadcast(self.handle, t.data_ptr(), t.numel(), self._dt(t), root,
+                                                              stream.cuda_stream), "comm_broadcast")
+
+    def all_gather(self, send: Tensor, recv: Tensor, stream: "torch.cuda.Stream") -> None:
+        self._lib.check(self._lib.load().cfhip_comm_allgather(self.handle, send.data_ptr(), recv.data_ptr(), send.numel(),
+                                                              self._dt(send), stream.cuda_stream), "comm_allgather")
+
+    def reduce_scatter(self, send: Tensor, recv: Tensor, stream: "torch.cuda.Stream") -> None:
+        self._lib.check(self._lib.load().cfhip_comm_reduce_scatter(self.handle, send.data_ptr(), recv.data_ptr(),
+                                                                   recv.numel(), self._dt(recv), stream.cuda_stream),
+                        "comm_reduce_scatter")
+
+    def close(self) -> None:
+        if self.handle is not None:
+            self._lib.check(self._lib.load().cfhip_comm_destroy(self.handle), "comm_destroy")
+            self.handle = None
+
+
+class _StreamWork:
+    """`work.wait()` of a collective launched through the C-ABI: the compute stream waits for an event on the comm stream"""
+
+    def __init__(self, stream: "torch.cuda.Stream"):
+        self.event = torch.cuda.Event()
+        self.event.record(stream)
+
+    def wait(self) -> None:
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 class BucketedAllReduce:
     """`average`: True = `finish()` leaves the rank-AVERAGED gradients in the arena (one extra pass over it; what a
     trainer that clips / inspects gradients between backward and `optimizer.step()` needs); False = the arena holds the
@@ -59,7 +132,8 @@ class BucketedAllReduce:
 
     def __init__(self, arena: ParamArena, *, process_group: Any = None, bucket_bytes: int = 64 << 20,
                  overlap: bool = True, optimizer: Optional[FusedAdam] = None, average: Optional[bool] = None,
-                 finish_after_backward: bool = False, sync_fn: Any = None, wire_bf16: bool = False):
+                 finish_after_backward: bool = False, sync_fn: Any = None, wire_bf16: bool = False,
+                 comm: Optional["Communicator"] = None):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("BucketedAllReduce needs an initialised torch.distributed process group")
         self.arena = arena
@@ -72,6 +146,7 @@ class BucketedAllReduce:
         self.average = (optimizer is None) if average is None else bool(average)
         self.finish_after_backward = finish_after_backward
         self.wire_bf16 = wire_bf16
+        self.comm = comm  # None: torch.distributed launches the collectives; a Communicator: the cfhip_comm_* C-ABI
         self.is_cuda = arena.flat_g.is_cuda
         self.comm_stream = None
         if self.is_cuda:
@@ -119,7 +194,12 @@ class BucketedAllReduce:
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """What the DDP constructor used to do: every rank starts from rank `src`."""
-        dist.broadcast(self.arena.flat_p, src=src, group=self.group)
+        if self.comm is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            self.comm.broadcast_(self.arena.flat_p, src, self.comm_stream)
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        else:
+            dist.broadcast(self.arena.flat_p, src=src, group=self.group)
         self.arena.refresh_shadow()
 
     @contextlib.contextmanager
@@ -201,11 +281,15 @@ class BucketedAllReduce:
                 if side is not None:
                     self.comm_stream.wait_stream(side)
             with torch.cuda.stream(self.comm_stream):
+                buf = view
                 if self.wire_bf16:
                     wire.copy_(view)
-                    b.work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    buf = wire
+                if self.comm is not None:
+                    self.comm.all_reduce_(buf, self.comm_stream)
+                    b.work = _StreamWork(self.comm_stream)
                 else:
-                    b.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    b.work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             if self.wire_bf16:
                 wire.copy_(view)

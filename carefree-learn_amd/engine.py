@@ -31,7 +31,7 @@ class TrainStep:
                  eps: float = 1.0e-8, weight_decay: float = 0.0, decoupled: bool = True,
                  use_graph: bool = False, distributed: bool = False, bucket_bytes: int = 64 << 20,
                  output_key: str = "predictions", loss: str = "cross_entropy", clip_norm: float = 0.0,
-                 wire_bf16: bool = False):
+                 wire_bf16: bool = False, comm: str = "torch"):
         if loss not in ("cross_entropy", "focal"):
             raise ValueError(f"unknown loss '{loss}' (cross_entropy: losses/basic.py:126-141, focal: :170-206)")
         self.model = model
@@ -48,8 +48,15 @@ class TrainStep:
             SideStream.ensure()  # the stream self-check runs here, not inside the first timed step
         self.reducer: Optional[BucketedAllReduce] = None
         if distributed:
+            communicator = None
+            if comm == "cfhip":  # collectives through the cfhip_comm_* C-ABI on this package's own comm stream
+                from .ddp import Communicator
+
+                communicator = Communicator()
+            elif comm != "torch":
+                raise ValueError(f"comm = '{comm}': 'torch' (torch.distributed launches the collectives) or 'cfhip'")
             self.reducer = BucketedAllReduce(self.arena, bucket_bytes=bucket_bytes, optimizer=self.optimizer,
-                                             wire_bf16=wire_bf16)
+                                             wire_bf16=wire_bf16, comm=communicator)
             self.reducer.broadcast_parameters(0)
         self.use_graph = use_graph and not distributed
         self._graph: Optional[torch.cuda.CUDAGraph] = None

@@ -383,8 +383,8 @@ class Attention(Module):
             raise NotImplementedError("attention weights / custom softmax need the un-fused slow path")
         if self.training and self.dropout > 0.0:
             raise NotImplementedError("attention dropout is outside the accelerated hot path")
-        if self.head_dim != 64:
-            raise NotImplementedError(f"HIP attention kernel is built for head_dim 64, got {self.head_dim}")
+        if self.head_dim % 8 != 0 or self.head_dim > 192:
+            raise NotImplementedError(f"HIP attention kernels take head_dim = a multiple of 8 up to 192, got {self.head_dim}")
         qkv_inp = q, k, v
         if self.hook is not None:
             qkv_inp = self.hook.before_forward(qkv_inp)
@@ -393,7 +393,13 @@ class Attention(Module):
             qq, kk, vv = self.hook.after_forward(qkv_inp, (qq, kk, vv))
             packed = None
         keep = None if mask is None else expand_module_mask(mask, self.num_heads)
-        if packed is not None:
+        if self.head_dim != 64:
+            # the general-head_dim kernels (`cfhip_attn_*_dh`, what CrossAttention uses) take separate q / k / v views
+            if packed is not None:
+                d = packed.shape[-1] // 3
+                qq, kk, vv = packed[..., :d], packed[..., d:2 * d], packed[..., 2 * d:]
+            out = HF.attention_core(qq, kk, vv, self.num_heads, keep, False, self.head_dim)
+        elif packed is not None:
             out = HF.packed_self_attention(packed, self.num_heads, keep, False)
         else:
             out = HF.attention_core(qq, kk, vv, self.num_heads, keep, False)

@@ -404,6 +404,28 @@ int cfhip_ml_encode_indices(const float* x, int64_t B, int64_t x_row_stride, con
 int cfhip_ml_encode_bwd(const float* dout, const float* x, int64_t B, int F, int64_t x_row_stride, const int32_t* plan,
                         int Fo, void* const* dtables, float* dx, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * C1 / C2 / C3  collectives of the data-parallel exchange over RCCL / xGMI.  Replace what
+ *   `accelerator.prepare` -> torch DDP would have done behind trainer.py:268-272 (gradient all-reduce, C1; the DDP
+ *   constructor's parameter broadcast, C3) and add the embedding all-gather / reduce-scatter of a contrastive step (C2).
+ *   One communicator per process (one process per GPU).  RCCL is reached with dlopen (the copy the process already
+ *   holds — torch's — is preferred), so libcfhip.so has no link-time RCCL dependency.
+ *   unique_id: rank 0 fills 128 bytes (ncclGetUniqueId); the caller ships them to the other ranks (any host channel:
+ *     the launcher's TCP store, a file).  init: collective over all ranks; the CURRENT HIP device is the rank's GPU.
+ *   Every collective is in-stream on `stream` (caller's comm stream), never synchronises the host.
+ *   dtype: 0 = f32, 1 = bf16.  allreduce / broadcast are in place; allgather / reduce_scatter take `count_per_rank`
+ *     elements per rank (recv of allgather / send of reduce_scatter hold world * count_per_rank).  Reductions are sums:
+ *     the 1 / W of gradient averaging is the optimizer's grad_scale.
+ * ------------------------------------------------------------------------------------------ */
+int cfhip_comm_unique_id(void* out128);
+int cfhip_comm_init(int rank, int world, const void* uid128, void** comm);
+int cfhip_comm_destroy(void* comm);
+int cfhip_comm_allreduce(void* comm, void* buf, size_t count, int dtype, void* stream);
+int cfhip_comm_allgather(void* comm, const void* send, void* recv, size_t count_per_rank, int dtype, void* stream);
+int cfhip_comm_reduce_scatter(void* comm, const void* send, void* recv, size_t count_per_rank, int dtype, void* stream);
+int cfhip_comm_broadcast(void* comm, void* buf, size_t count, int dtype, int root, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,8 +20,11 @@ def pytest_configure(config):
         import subprocess
 
         if shutil.which("hipcc") or os.path.isfile("/opt/rocm/bin/hipcc"):
-            subprocess.run(["bash", os.path.join(ROOT, "build_lib.sh")], cwd=ROOT, check=False,
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            res = subprocess.run(["bash", os.path.join(ROOT, "build_lib.sh")], cwd=ROOT, check=False,
+                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if res.returncode != 0 or not os.path.isfile(lib):
+                # a compile error must not degrade to "library missing": show the compiler output and stop
+                raise pytest.UsageError(f"build_lib.sh failed (exit {res.returncode}):\n{res.stdout[-4000:]}")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import vit_oracle as O
-from helpers import assert_close
+from helpers import assert_close, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -69,6 +69,32 @@ def test_attention_golden(golden, tag):
     assert_close(x.grad, g[tag]["gx"], 3e-2, "attention gx")
     for k, v in _grads(m).items():
         assert_close(v, g[tag]["grads"][k], 3e-2, f"attention grad {k}")
+
+
+@pytest.mark.parametrize("dim,heads", [(192, 2), (160, 4), (256, 8)])
+def test_attention_module_other_head_dims(dim, heads):
+    """`Attention` with head_dim != 64 (96 / 40 / 32) dispatches to the general-head_dim kernels instead of raising
+    (VERDICT r1 #13); checked against the oracle restatement of attentions.py:198-279 incl. a 3-D mask."""
+    torch.manual_seed(dim + heads)
+    m = C.Attention(dim, heads, is_self_attention=True)
+    with torch.no_grad():
+        m.qkv_bias.normal_(0.0, 0.1)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(3, 21, dim)
+    mask = torch.rand(3, 21, 21) < 0.3
+    mask[:, :, 0] = False  # no fully masked row
+    for msk in (None, mask):
+        xr = x.clone().requires_grad_(True)
+        want = O.self_attention(xr, sd, "", heads, msk)
+        gy = torch.randn_like(want)
+        want.backward(gy)
+        md = m.to(DEV)
+        md.zero_grad()
+        xd = x.to(DEV).requires_grad_(True)
+        out = md(xd, xd, xd, mask=None if msk is None else msk.to(DEV)).output
+        assert_close(out, want, 1.5e-2, f"attention dh={dim // heads} y")
+        out.backward(gy.to(DEV).to(torch.bfloat16))
+        assert_close(xd.grad, xr.grad, 3e-2, f"attention dh={dim // heads} gx")
 
 
 def test_feedforward_golden(golden):
@@ -173,26 +199,47 @@ def test_hook_contract_and_lowrank():
 
 
 def test_vit_b16_loss_within_1e3_of_cpu_reference():
-    """North-star bound: ViT-B/16 224^2 logits / loss vs the fp32 CPU reference on the same inputs
-    and the same (reference-initialised) weights.  Loss within 1e-3 relative; logits are compared
-    in rel-L2 with the documented bf16 bound (the reference's own bf16-autocast run differs from its
-    fp32 run by 8e-3 on this metric)."""
+    """North-star bound: ViT-B/16 224^2 vs the fp32 CPU reference on the same inputs and the same
+    (reference-initialised) weights.
+      * loss within 1e-3 relative (the north-star number);
+      * logits: at least as close to fp32 as the reference's OWN bf16-autocast CPU run is, and <= 8e-3 rel-L2
+        (measured on the MI355X: ours 7.25e-3, the reference's bf16-autocast run 8.00e-3 — at initialisation the
+        logits are tiny sums of 0.02-scale weights, so bf16 operand rounding is a large fraction of them: 1e-3 on raw
+        logits is not attainable by any bf16 implementation, the reference's included; the small perturbed model of
+        smoke() sits at 2.8e-3); vs the bf16-autocast run itself <= 1.2e-2;
+      * every parameter gradient of the full-size model vs the oracle's fp32 backward."""
     torch.manual_seed(0)
     m = C.vit_b16_classifier(num_classes=1000)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(1234)
     img = torch.randn(2, 3, 224, 224, generator=g)
     labels = torch.randint(0, 1000, (2, 1), generator=g)
-    torch.set_num_threads(max(1, torch.get_num_threads()))
-    with torch.no_grad():
-        want = O.vit_classifier(img, sd, 12, 12)
-    want_loss = O.cross_entropy(want, labels).item()
+    torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
+    want_loss_t, want, want_grads = O.loss_and_grads(img, labels, sd, 12, 12)
+    want_loss = want_loss_t.item()
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        want_bf16 = O.vit_classifier(img, sd, 12, 12).float()
     m = m.to(DEV)
     logits = m(img.to(DEV))["predictions"]
-    loss, _ = C.ops.softmax_xent(logits, labels.to(DEV), 1.0, want_grad=False)
+    loss, dlogits = C.ops.softmax_xent(logits, labels.to(DEV), 0.5)
     got_loss = loss.item() / 2
-    assert abs(got_loss - want_loss) <= 1e-3 * abs(want_loss), (got_loss, want_loss)
-    assert_close(logits, want, 2e-2, "ViT-B/16 logits")
+    rel_loss = abs(got_loss - want_loss) / abs(want_loss)
+    ours_vs_f32 = rel_l2(logits, want)
+    cpu16_vs_f32 = rel_l2(want_bf16, want)
+    ours_vs_cpu16 = rel_l2(logits, want_bf16)
+    print(f"ViT-B/16: loss rel err {rel_loss:.2e}; logits rel-L2 ours vs fp32 {ours_vs_f32:.2e}, reference bf16-autocast "
+          f"vs fp32 {cpu16_vs_f32:.2e}, ours vs bf16-autocast {ours_vs_cpu16:.2e}")
+    assert rel_loss <= 1e-3, (got_loss, want_loss)
+    assert ours_vs_f32 <= min(8e-3, cpu16_vs_f32), (ours_vs_f32, cpu16_vs_f32)
+    assert ours_vs_cpu16 <= 1.2e-2, ours_vs_cpu16
+    # full-size gradient parity: every one of the 152 parameter tensors
+    logits.backward(dlogits)
+    worst = ("", 0.0)
+    for k, v in _grads(m).items():
+        err = assert_close(v, want_grads[k], 6e-2, f"ViT-B/16 grad {k}", abs_floor=1e-5)
+        if want_grads[k].abs().max() > 1e-5 and err > worst[1]:
+            worst = (k, err)
+    print(f"ViT-B/16: worst parameter-gradient rel-L2 {worst[1]:.2e} ({worst[0]})")
 
 
 def test_vit_long_sequence_matches_oracle():

@@ -52,9 +52,29 @@ CHILD = textwrap.dedent("""
     (a * w).sum().backward()
     torch.cuda.synchronize()
     assert torch.equal(e.grad, w)
+    # the same exchange with the collectives launched through the C-ABI (cfhip_comm_*) on this package's comm stream
+    ts = TrainStep(build(), lr=1e-3, weight_decay=0.01, distributed=True, bucket_bytes=1 << 16, comm="cfhip")
+    assert ts.reducer.comm is not None and ts.reducer.comm.world == 1
+    for _ in range(3):
+        ts.step(x, y)
+    torch.cuda.synchronize()
+    err2 = ((out[0] - ts.arena.flat_p).norm() / out[0].norm()).item()
+    assert err2 < 2e-6, err2
+    from cflearn_amd.ddp import Communicator
+    comm = ts.reducer.comm
+    st = ts.reducer.comm_stream
+    t = torch.randn(1000, device=dev)
+    t0 = t.clone()
+    r1, r2 = torch.empty_like(t), torch.empty_like(t)
+    st.wait_stream(torch.cuda.current_stream())
+    comm.all_reduce_(t, st); comm.broadcast_(t, 0, st); comm.all_gather(t, r1, st); comm.reduce_scatter(t, r2, st)
+    tb = t0.to(torch.bfloat16); comm.all_reduce_(tb, st)
+    st.synchronize()
+    assert torch.equal(t, t0) and torch.equal(r1, t0) and torch.equal(r2, t0) and torch.equal(tb, t0.to(torch.bfloat16))
+    comm.close()
     dist.barrier()
     dist.destroy_process_group()
-    print("RCCL-1RANK-OK", err)
+    print("RCCL-1RANK-OK", err, err2)
 """)
 
 

@@ -9,10 +9,10 @@ ROOT="$(dirname "$(readlink -f "$0")")/.."
 cd "$ROOT/carefree-learn_amd/csrc"
 mkdir -p ../_build/$NAME
 pids=()
-for f in errors gemm attn norm elementwise conv embed random tabular; do
+for f in errors gemm attn norm elementwise conv embed random tabular comm; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics "$@" -c $f.hip -o ../_build/$NAME/$f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/libcfhip_$NAME.so" ../_build/$NAME/*.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/libcfhip_$NAME.so" ../_build/$NAME/*.o -ldl
 echo "built $ROOT/tools/libcfhip_$NAME.so"
