@@ -170,3 +170,38 @@ def test_reference_gradient_checkpoint_reenters_custom_functions(cflearn):
     torch.tanh(lin2(x2)).sum().backward()
     assert torch.allclose(gx, x2.grad, atol=1e-6)
     assert torch.allclose(gw, lin2.weight.grad, atol=1e-6) and torch.allclose(gb, lin2.bias.grad, atol=1e-6)
+
+
+def test_lazy_loss_patch_under_the_reference_trainer(cflearn, tmp_path, monkeypatch):
+    """(f)3 for cflearn users: `compat.patch_lazy_losses()` removes the per-step `.item()` of models/common.py:40-43;
+    the reference's own trainer still trains, logs and snapshots (the values are read only when consumed)."""
+    from cflearn_amd import compat
+
+    monkeypatch.chdir(tmp_path)
+    x = np.random.RandomState(0).randn(1000, 16).astype(np.float32)
+    w = np.random.RandomState(1).randn(16, 3)
+    y = (x @ w).argmax(1).reshape(-1, 1)
+    seen = []
+    orig = compat.patch_lazy_losses()
+    try:
+        common = sys.modules["cflearn.models.common"]
+        wrapped = common.CommonTrainStep.loss_fn
+
+        def spy(self, m_, state, *a, **k):
+            out = wrapped(self, m_, state, *a, **k)
+            if state is not None:  # a TRAINING step (evaluation passes state=None and consumes its losses at once)
+                seen.append(out.losses[TO.LOSS_KEY])
+            return out
+
+        common.CommonTrainStep.loss_fn = spy
+        config = cflearn.MLConfig(module_name="fcnn", module_config=dict(input_dim=16, output_dim=3), loss_name="focal",
+                                  fixed_steps=60, tqdm_settings=None)
+        m = cflearn.api.fit_ml(x, y, config=config, device="cpu")
+    finally:
+        compat.restore_losses(orig)
+    assert len(seen) == 60 and all(isinstance(v, compat.LazyFloat) for v in seen)
+    # per-step values are read back only where the trainer consumes them (monitor / logging steps), not every step
+    assert sum(v.is_materialized for v in seen) < len(seen), [v.is_materialized for v in seen]
+    preds = m.predict(m.data.build_loader(x, y))[TO.PREDICTIONS_KEY]
+    assert (preds.argmax(1) == y.ravel()).mean() > 0.6
+    assert float(seen[-1]) < float(seen[0])
