@@ -306,9 +306,11 @@ def main() -> None:
     ap.add_argument("--gemm-reps", type=int, default=10)
     ap.add_argument("--bucket-mb", type=int, default=64, help="gradient bucket size of the RCCL exchange (sweep on an 8-GPU node)")
     ap.add_argument("--wire-bf16", action="store_true", help="all-reduce bf16 copies of the gradient buckets (half the xGMI bytes)")
-    ap.add_argument("--comm", default="torch", choices=["torch", "cfhip"],
-                    help="who launches the RCCL collectives: torch.distributed (default) or the cfhip_comm_* C-ABI on "
-                         "this package's own, queue-checked comm stream")
+    ap.add_argument("--comm", default="auto", choices=["auto", "torch", "cfhip"],
+                    help="who launches the RCCL collectives: the cfhip_comm_* C-ABI on this package's own, queue-checked "
+                         "comm stream (auto with the nccl backend: measured 22.4 ms vs 23.0 ms for the torch.distributed "
+                         "launch at 1 rank, 22.3 ms without any exchange — profiles/r02/rccl_1rank_comm_*.json), or "
+                         "torch.distributed (auto with gloo; fallback when the communicator cannot be created)")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra (untimed) steps with event pairs around every GEMM launch")
     ap.add_argument("--watchdog", type=int, default=0, help="dump all Python stacks every N seconds")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for the "
@@ -356,11 +358,22 @@ def main() -> None:
     import cflearn_amd as C
     from cflearn_amd.engine import TrainStep
 
+    if args.comm == "auto":
+        args.comm = "cfhip" if (distributed and args.backend == "nccl" and not args.all_on_gpu0) else "torch"
     torch.manual_seed(0)  # identical init on every rank (and rank 0 is broadcast anyway)
     model = C.vit_b16_classifier(1000).to(dev)
-    ts = TrainStep(model, lr=1.0e-4, weight_decay=0.0, decoupled=True, use_graph=args.graph and not args.no_graph,
-                   distributed=distributed, bucket_bytes=args.bucket_mb << 20, wire_bf16=args.wire_bf16,
-                   comm=args.comm)
+    def make_step(comm: str):
+        return TrainStep(model, lr=1.0e-4, weight_decay=0.0, decoupled=True, use_graph=args.graph and not args.no_graph,
+                         distributed=distributed, bucket_bytes=args.bucket_mb << 20, wire_bf16=args.wire_bf16, comm=comm)
+
+    try:
+        ts = make_step(args.comm)
+    except RuntimeError as e:  # the RCCL communicator could not be created: torch.distributed launches the collectives
+        if args.comm != "cfhip":
+            raise
+        print(f"[bench] rank {rank}: cfhip communicator unavailable ({e}); falling back to --comm torch", file=sys.stderr)
+        args.comm = "torch"
+        ts = make_step("torch")
     if ts.reducer is not None:
         ts.reducer.time_exposed = True
     g = torch.Generator().manual_seed(1234 + rank)

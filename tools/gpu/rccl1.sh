@@ -1,14 +1,7 @@
-#!/bin/bash
-# the distributed code path over RCCL with one rank (the only RCCL configuration a 1-GPU box allows),
-# alternating the number of ROCclr hardware queues
-cd "${GRAFT_REPO_ROOT:-/root/repo}"
-export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-mkdir -p gpurun_out
-run() {
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
-  bench.py --gpus 1 --steps 20 --warmup 5 --force-ddp --no-cpu-baseline --no-roofline "$@" 2>&1 | grep -o "timed region.*\|UserWarning.*"
-}
-for rep in 1 2 3; do
-for q in 8 4 2; do echo "ddp, GPU_MAX_HW_QUEUES=$q: $(GPU_MAX_HW_QUEUES=$q run)"; done
-done 2>&1 | tee gpurun_out/rccl_1rank_queues.log
-echo "no ddp (8): $(timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | grep -o 'timed region.*')" | tee -a gpurun_out/rccl_1rank_queues.log
+mkdir -p gpurun_out/rccl1
+export MASTER_ADDR=127.0.0.1
+for comm in torch cfhip torch cfhip; do
+  timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --force-ddp --comm $comm --no-cpu-baseline --no-roofline > gpurun_out/rccl1/bench_$comm.json 2> gpurun_out/rccl1/bench_$comm.err
+  python -c "import json; d=json.loads(open('gpurun_out/rccl1/bench_$comm.json').read().strip().split('\n')[-1]); print('$comm', d['ms_per_step'], d.get('allreduce_exposed_ms',{}).get('mean'), d['config']['grad_exchange'])"
+done
+timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('no ddp', d['ms_per_step'])"
