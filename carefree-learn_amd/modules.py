@@ -579,8 +579,8 @@ class MixingBlock(Module):
                  drop_path: float = 0.0, norm_type: Optional[str] = "batch_norm",
                  norm_kwargs: Optional[Dict[str, Any]] = None, residual_after_norm: bool = False):
         super().__init__()
-        if norm_position != "pre_norm":
-            raise NotImplementedError("only `pre_norm` blocks are on the accelerated hot path")
+        if norm_position not in ("pre_norm", "post_norm"):
+            raise ValueError("`norm_position` should be either 'pre_norm' or 'post_norm'")  # api.py:79-81
         if residual_after_norm:
             raise NotImplementedError("residual_after_norm is outside the hot path")
         self.norm_position = norm_position
@@ -608,7 +608,9 @@ class MixingBlock(Module):
 
     def _fusable(self) -> bool:
         tmix, cmix = self.token_mixing, self.channel_mixing
-        if self._stochastic():  # the fused block / stack kernels have no random masks: composed path
+        if self.norm_position != "pre_norm":  # the fused block / stack kernels are the pre-norm form
+            return False
+        if self._stochastic():  # ... and have no random masks: composed path
             return False
         if not (isinstance(tmix, AttentionTokenMixer) and isinstance(cmix, FeedForward)):
             return False
@@ -653,6 +655,24 @@ class MixingBlock(Module):
         if mask is not None:
             tkw["mask"] = mask
         tkw.update(kwargs)
+        stoch = self._stochastic()
+
+        def plus(x: Tensor, branch: Tensor) -> Tensor:
+            return x + branch.to(x.dtype) if x.dtype != branch.dtype else HF.add(x, branch)
+
+        if self.norm_position == "post_norm":
+            # api.py:160-185: x = LN(x + dp(drop(token_mix(x)))); x = LN(x + dp(channel_mix(x)))
+            if not stoch:
+                s1 = self.token_mixing(net, **tkw)  # the residual add rides in the output GEMM's epilogue
+            else:
+                tkw.pop("residual")
+                s1 = plus(net, self.drop_path(self.token_mixing_dropout(self.token_mixing(net, **tkw))))
+            net = self.token_norm(s1)
+            if not stoch:
+                s2 = self.channel_mixing(net, residual=net)
+            else:
+                s2 = plus(net, self.drop_path(self.channel_mixing(net)))
+            return self.channel_norm(s2)
         if not self._stochastic():
             net = self.token_mixing(self.token_norm(net), **tkw)
             return self.channel_mixing(self.channel_norm(net), residual=net)
@@ -678,6 +698,38 @@ class PositionalEncoding(Module):
             nn.init.trunc_normal_(self.pos_encoding, std=0.02)
         self.num_head_tokens = num_head_tokens
         self.is_vision = is_vision
+
+    def interpolate_pos_encoding(self, num_tokens_now: int, hwp: Optional[Tuple[int, int, int]]) -> Tensor:
+        """reference api.py:231-267 (vision encodings at a non-native resolution): the [sqrt(T) x sqrt(T)] grid of
+        learned encodings is resampled bicubically (align_corners=False, recompute_scale_factor=True — toolkit.py:
+        2841-2861) to the current patch grid; head-token encodings pass through.  A once-per-forward resample of a
+        [1, T, D] table: done with torch's interpolate (glue, like the argmax of the CLIP pooling), its gradient flows
+        back to the parameter through autograd."""
+        import math
+
+        pos = self.pos_encoding
+        num_current = num_tokens_now - self.num_head_tokens
+        num_history = pos.shape[1] - self.num_head_tokens
+        h = w = patch_size = None
+        if hwp is not None:
+            h, w, patch_size = hwp
+        if num_current == num_history and w == h:
+            return pos
+        if w is None or h is None or patch_size is None:
+            raise ValueError("`hwp` should be provided for `interpolate_pos_encoding`")
+        head = pos[:, :self.num_head_tokens] if self.num_head_tokens > 0 else None
+        grid = pos[:, self.num_head_tokens:]
+        dim = pos.shape[-1]
+        sqrt = math.sqrt(num_history)
+        wh_ratio = w / h
+        pw = math.sqrt(num_current * wh_ratio) + 0.1
+        ph = math.sqrt(num_current / wh_ratio) + 0.1
+        grid = torch.nn.functional.interpolate(grid.reshape(1, int(sqrt), int(sqrt), dim).permute(0, 3, 1, 2),
+                                               mode="bicubic", scale_factor=(pw / sqrt, ph / sqrt),
+                                               recompute_scale_factor=True, align_corners=False)
+        assert int(pw) == grid.shape[-2] and int(ph) == grid.shape[-1]
+        grid = grid.permute(0, 2, 3, 1).reshape(1, -1, dim)
+        return grid if head is None else torch.cat([head, grid], dim=1)
 
 
 class MixedStackedEncoder(Module):
@@ -707,8 +759,7 @@ class MixedStackedEncoder(Module):
                                       "(head token or `head_pooler=None` are built)")
         if no_head_norm is None:
             no_head_norm = norm_position == "post_norm"
-        if no_head_norm:
-            raise NotImplementedError("a head without normalisation is outside the accelerated hot path")
+        self.no_head_norm = bool(no_head_norm)  # api.py:372-377: post-norm stacks end in a LayerNorm already
         self.aux_heads = None
         if use_head_token:
             self.head_token = nn.Parameter(torch.zeros(1, 1, in_dim))
@@ -744,7 +795,10 @@ class MixedStackedEncoder(Module):
             for i, dp in enumerate(dpr_list)
         ])
         head: Module = Lambda(lambda x: x[:, 0], name="head_token") if use_head_token else nn.Identity()
-        if norm_after_head:
+        if self.no_head_norm:
+            self.head_norm = None
+            self.head = head
+        elif norm_after_head:
             self.head_norm = NormFactory(norm_type).make(in_dim, **(norm_kwargs or {}))
             self.head = head
         else:
@@ -773,6 +827,8 @@ class MixedStackedEncoder(Module):
         # LayerNorm is row-wise, so LN(x)[:, 0] == LN(x[:, 0]) (PreNorm head) — and with `norm_after_head` the
         # reference computes LN(x[:, 0]) itself: normalise token 0 only (1/T of the PreNorm work, identical
         # result) by handing the kernel a strided row view.  Identity head (text tower): every token.
+        if self.no_head_norm:  # post-norm stacks: the last block already ended in its LayerNorm
+            return net[:, 0] if self.head_token is not None else net
         if self.head_token is not None:
             return self._head_ln()(net[:, 0])
         return self._head_ln()(net)
@@ -792,13 +848,23 @@ class MixedStackedEncoder(Module):
             net = torch.cat([self.head_token.expand(net.shape[0], -1, -1).to(net.dtype), net], dim=1)
         if self.pos_encoding.pos_encoding is not None:
             pos = self.pos_encoding.pos_encoding
-            if pos.shape[1] != net.shape[1]:
-                if self.pos_encoding.is_vision:
-                    raise NotImplementedError("positional-encoding interpolation is outside the accelerated hot path")
-                pos = pos[:, :net.shape[1]]
+            heads = self.pos_encoding.num_head_tokens
+            if self.pos_encoding.is_vision:
+                span = net.shape[1]
+                if pos.shape[1] != net.shape[1] or hwp is not None:
+                    pos = self.pos_encoding.interpolate_pos_encoding(net.shape[1], hwp)
+            else:
+                # api.py:216-227: sequence encodings cover the first T - num_head_tokens positions of the stream
+                # (the head token sits in FRONT, so the last feature token goes without one — mirrored as is)
+                span = net.shape[1] - heads
+                pos = pos[:, :span]
             if self.pos_encoding.pos_drop is not None:
                 pos = self.pos_encoding.pos_drop(pos)  # api.py:220: the dropout acts on the encoding itself
-            net = net.float() + pos
+            net = net.float()
+            if span == net.shape[1]:
+                net = net + pos
+            else:
+                net = torch.cat([net[:, :span] + pos, net[:, span:]], dim=1)
         if self.embedding_norm is not None:
             net = self.embedding_norm(net)
         if self.embedding_dropout is not None:
@@ -1081,19 +1147,21 @@ class ViTEncoder(Module):
 
     def forward(self, net: Tensor, *, hw: Optional[Tuple[int, int]] = None, hwp: Any = None,
                 deterministic: bool = False) -> Tensor:
-        if net.shape[-1] != self.img_size or net.shape[-2] != self.img_size:
-            raise NotImplementedError("positional-encoding interpolation (non-native resolution) is "
-                                      "outside the accelerated hot path")
         conv = self.to_patches.projection
         enc = self.encoder
         enc.check_fused_token_assembly()
-        tokens = HF.patch_tokens(net, conv.weight, conv.bias, enc.head_token, enc.pos_encoding.pos_encoding)
+        pos = enc.pos_encoding.pos_encoding
+        psz = self.to_patches.patch_size
+        gh, gw = net.shape[-2] // psz, net.shape[-1] // psz
+        if net.shape[-1] != self.img_size or net.shape[-2] != self.img_size:
+            # non-native resolution: resampled positional grid (api.py:231-267; the caller passes hwp like upstream)
+            pos = enc.pos_encoding.interpolate_pos_encoding(gh * gw + enc.pos_encoding.num_head_tokens, hwp)
+        tokens = HF.patch_tokens(net, conv.weight, conv.bias, enc.head_token, pos)
         if enc.embedding_norm is not None:
             tokens = enc.embedding_norm(tokens)  # CLIP vision tower: LayerNorm before the blocks (bf16 stream)
         if enc.embedding_dropout is not None:
             tokens = enc.embedding_dropout(tokens)
-        g = self.img_size // self.to_patches.patch_size
-        out = enc.forward_tokens(tokens, hw=(g, g), deterministic=deterministic)
+        out = enc.forward_tokens(tokens, hw=(gh, gw), deterministic=deterministic)
         if self.output_projection is not None:
             out = HF.linear(out, self.output_projection.t(), None, out_f32=True)
         return out

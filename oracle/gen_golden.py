@@ -520,6 +520,44 @@ def gen_ml_encoder(ref) -> None:
     torch.save(cases, os.path.join(OUT, "ml_encoder.pt"))
 
 
+def gen_postnorm_interp(ref) -> None:
+    """(1) a post-norm `MixedStackedEncoder` (api.py:160-185; no head norm), (2) the ViT encoder at a NON-native
+    resolution (bicubic positional-encoding interpolation, api.py:231-267): outputs and gradients of the reference."""
+    torch.manual_seed(41)
+    cfg = dict(in_dim=64, num_tokens=9, token_mixing_type="attention", token_mixing_config=dict(num_heads=1, bias=True),
+               channel_mixing_config=dict(), num_layers=2, drop_path_rate=0.0, norm_position="post_norm", norm_type="layer",
+               use_head_token=True, use_positional_encoding=True, is_vision_positional_encoding=False)
+    enc = ref.MixedStackedEncoder(**cfg)
+    with torch.no_grad():
+        for p in enc.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.05)
+    x = torch.randn(3, 9, 64, requires_grad=True)
+    y = enc(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    post = dict(cfg=cfg, sd=sd, x=x.detach(), y=y.detach(), gy=gy, gx=x.grad.clone(),
+                grads={k: p.grad.clone() for k, p in enc.named_parameters()})
+    # (2) non-native resolution
+    vcfg = dict(img_size=32, patch_size=8, in_channels=3, latent_dim=64, num_layers=1, feedforward_dim_ratio=2.0)
+    vit = ref.ViTEncoder(**vcfg)
+    img = torch.randn(2, 3, 48, 32)
+    out = vit(img, hwp=(48, 32, 8))
+    gv = torch.randn_like(out)
+    out.backward(gv)
+    vsd = {k: v.detach().clone() for k, v in vit.state_dict().items()}
+    pos = O.interpolate_pos_encoding(vsd["encoder.pos_encoding.pos_encoding"], 1, 24, 48, 32)
+    _check("interpolated pos encoding", pos, vit.encoder.pos_encoding.interpolate_pos_encoding(
+        torch.zeros(1, 25, 64), (48, 32, 8)).detach(), atol=1e-6)
+    vsd2 = dict(vsd)
+    vsd2["encoder.pos_encoding.pos_encoding"] = pos
+    _check("vit @ 48x32", O.vit_encoder(img, vsd2, 1, 1), out.detach())
+    interp = dict(cfg=vcfg, sd=vsd, img=img, hwp=(48, 32, 8), y=out.detach(), gy=gv,
+                  gpos=vit.encoder.pos_encoding.pos_encoding.grad.clone())
+    torch.save(dict(post_norm=post, interp=interp), os.path.join(OUT, "postnorm_interp.pt"))
+
+
 def gen_stochastic(ref) -> None:
     """nn.Dropout and the reference's DropPath: outputs AND the masks they drew (recovered from the outputs), so that
     the kernels can be checked bit-for-bit with the mask injected."""
@@ -550,7 +588,7 @@ def main() -> None:
     only = sys.argv[1:]
     for fn in (gen_linear, gen_layernorm, gen_sdp, gen_attention, gen_feedforward, gen_vit, gen_conv2d,
                gen_batchnorm, gen_mnist_clf, gen_fcnn, gen_clip, gen_resblock, gen_spatial_transformer, gen_unet, gen_ddpm_schedule,
-               gen_ml_encoder, gen_stochastic):
+               gen_ml_encoder, gen_stochastic, gen_postnorm_interp):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

@@ -159,6 +159,33 @@ def mixing_block(
     return x + feed_forward(n2, sd, prefix + "channel_mixing.")
 
 
+def mixing_block_post_norm(x: Tensor, sd: StateDict, prefix: str, num_heads: int, eps: float = 1.0e-6) -> Tensor:
+    """Post-norm `MixingBlock` (mixed_stacks/api.py:160-185): x1 = LN(x + attn(x)); x2 = LN(x1 + ff(x1))."""
+    x = x + self_attention(x, sd, prefix + "token_mixing.net.", num_heads)
+    x = layer_norm(x, sd[prefix + "token_norm.weight"], sd[prefix + "token_norm.bias"], eps)
+    x = x + feed_forward(x, sd, prefix + "channel_mixing.")
+    return layer_norm(x, sd[prefix + "channel_norm.weight"], sd[prefix + "channel_norm.bias"], eps)
+
+
+def interpolate_pos_encoding(pos: Tensor, num_head_tokens: int, num_current: int, h: int, w: int) -> Tensor:
+    """`PositionalEncoding.interpolate_pos_encoding` (mixed_stacks/api.py:231-267): bicubic resample of the learned
+    [sqrt(T) x sqrt(T)] grid (align_corners=False, recompute_scale_factor=True, toolkit.py:2841-2861) to the patch
+    grid of an `h x w` image; head-token rows pass through."""
+    import math
+
+    head, grid = pos[:, :num_head_tokens], pos[:, num_head_tokens:]
+    num_history, dim = grid.shape[1], pos.shape[-1]
+    sqrt = math.sqrt(num_history)
+    wh_ratio = w / h
+    pw = math.sqrt(num_current * wh_ratio) + 0.1
+    ph = math.sqrt(num_current / wh_ratio) + 0.1
+    grid = torch.nn.functional.interpolate(grid.reshape(1, int(sqrt), int(sqrt), dim).permute(0, 3, 1, 2), mode="bicubic",
+                                           scale_factor=(pw / sqrt, ph / sqrt), recompute_scale_factor=True,
+                                           align_corners=False)
+    grid = grid.permute(0, 2, 3, 1).reshape(1, -1, dim)
+    return torch.cat([head, grid], dim=1)
+
+
 # ---------------------------------------------------------------------------------------------
 # ViT encoder + classifier
 # ---------------------------------------------------------------------------------------------

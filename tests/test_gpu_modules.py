@@ -268,3 +268,34 @@ def test_vit_long_sequence_matches_oracle():
     loss.backward()
     for k, v in _grads(m).items():
         assert_close(v, want_grads[k], 4e-2, f"long-sequence grad {k}", abs_floor=2e-4)
+
+
+def test_post_norm_stack_and_positional_interpolation_golden(golden):
+    """VERDICT r1 'smaller unbuilt pieces': the post-norm `MixingBlock` / `MixedStackedEncoder` (api.py:160-185, no
+    head norm, sequence positional encoding incl. its head-token offset quirk) and the ViT encoder at a NON-native
+    resolution (bicubic positional-encoding interpolation, api.py:231-267) against reference-made fixtures."""
+    g = golden("postnorm_interp.pt")
+    pn = g["post_norm"]
+    m = C.MixedStackedEncoder(**pn["cfg"])
+    assert list(m.state_dict().keys()) == list(pn["sd"].keys())
+    m.load_state_dict(pn["sd"])
+    m = m.to(DEV)
+    x = pn["x"].to(DEV).requires_grad_(True)
+    y = m(x)
+    assert_close(y, pn["y"], 1.5e-2, "post-norm encoder y")
+    y.backward(pn["gy"].to(DEV).to(y.dtype))
+    assert_close(x.grad, pn["gx"], 4e-2, "post-norm encoder gx")
+    for k, v in _grads(m).items():
+        assert_close(v, pn["grads"][k], 5e-2, f"post-norm grad {k}", abs_floor=2e-3)
+    it = g["interp"]
+    v = C.build_module("encoders.vit", config=dict(it["cfg"]))
+    assert list(v.state_dict().keys()) == list(it["sd"].keys())
+    v.load_state_dict(it["sd"])
+    v = v.to(DEV)
+    out = v(it["img"].to(DEV), hwp=tuple(it["hwp"]))
+    assert_close(out, it["y"], 1.5e-2, "ViT at 48x32 (native 32x32)")
+    out.backward(it["gy"].to(DEV).to(out.dtype))
+    assert_close(v.encoder.pos_encoding.pos_encoding.grad, it["gpos"], 4e-2, "d pos_encoding through the bicubic resample",
+                 abs_floor=1e-3)
+    with pytest.raises(ValueError):
+        v(it["img"].to(DEV))  # like upstream: a non-native resolution needs hwp
