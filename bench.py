@@ -278,6 +278,86 @@ def cpu_baseline(batch: int, steps: int, limit_s: float = 45.0):
     return out
 
 
+def bench_other_workload(args) -> None:
+    """`--workload unet | clip`: BASELINE configs 3 / 4 on ONE GPU (the multi-GPU path of these models is the same
+    `BucketedAllReduce`; their default batch follows SURVEY §8d).  One JSON line with the same keys; `roofline` is the
+    MFMA roofline of the whole step: counted MFMA-class FLOPs (ops.FlopCounter: GEMMs, implicit convolutions,
+    attention) / wall time."""
+    import cflearn_amd as C
+    from cflearn_amd import ops
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1234)
+    if args.workload == "unet":
+        from cflearn_amd.diffusion import DDPMTrainStep, NoiseSchedule
+
+        batch = args.batch if args.batch != 128 else (8 if args.img <= 64 else 1)
+        cfg = dict(in_channels=3, out_channels=3, start_channels=320, num_heads=8, use_spatial_transformer=True,
+                   num_transformer_layers=1, num_res_blocks=2, attention_downsample_rates=(1, 2, 4),
+                   channel_multipliers=(1, 2, 4, 4), context_dim=None)
+        m = C.build_module("unet_diffuser", config=cfg).to(dev)
+        ts = DDPMTrainStep(m, NoiseSchedule(device=dev), lr=1.0e-4)
+        x = torch.randn(batch, 3, args.img, args.img, generator=g).clamp_(-1, 1).to(dev)
+        t = torch.randint(0, 1000, (batch,), generator=g).to(dev)
+        eps = torch.randn(x.shape, generator=g).to(dev)
+        step = lambda: ts.step(x, None, timesteps=t, noise=eps)  # noqa: E731
+        name = (f"DDPM UNet (zoo diffusion/ddpm: start 320, multipliers 1/2/4/4, SpatialTransformer at rates 1/2/4) "
+                f"{args.img}^2, q_sample + fwd + MSE + bwd + fused AdamW")
+        loss_div = batch
+    else:
+        from cflearn_amd.engine import LossTrainStep
+
+        batch = args.batch if args.batch != 128 else 256
+        m = C.build_module("clip", config={}).to(dev)
+        ts = LossTrainStep(m, lambda mod, b_: mod.contrastive_loss(b_["image"], b_["text"]), lr=1.0e-4)
+        img = torch.randn(batch, 3, 224, 224, generator=g)
+        txt = torch.randint(1, 49407, (batch, 77), generator=g)
+        eot = torch.randint(8, 77, (batch,), generator=g)
+        for i in range(batch):
+            txt[i, eot[i]] = 49407
+            txt[i, eot[i] + 1:] = 0
+        data = dict(image=img.to(dev), text=txt.to(dev))
+        step = lambda: ts.step(data)  # noqa: E731
+        name = "CLIP (ViT-B/32 + 12 x 512 causal text tower) symmetric InfoNCE step, fwd + bwd + fused AdamW"
+        loss_div = 1
+    n_params = sum(p.numel() for p in m.parameters())
+    first = None
+    for i in range(args.warmup):
+        loss = step()
+        if i == 0:
+            first = loss.item() / loss_div
+            note(f"first step done, loss {first:.4f}")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    counter = ops.FlopCounter()
+    ops.FLOP_COUNTER = counter
+    try:
+        step()
+        torch.cuda.synchronize()
+    finally:
+        ops.FLOP_COUNTER = None
+    tf = counter.total() / dt / 1e12
+    print(json.dumps({
+        "metric": f"train samples/sec + step ms, {args.workload}", "value": round(batch / dt, 3), "unit": "samples/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": name, "per_gpu_batch": batch, "parameters": n_params,
+                   "loss_first_step": None if first is None else round(first, 5),
+                   "loss_last_step": round(loss.item() / loss_div, 5)},
+        "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                     "definition": "algorithmic MFMA-class FLOPs of one step (ops.FlopCounter) / measured wall time of the step",
+                     "flops_per_step": {k: v for k, v in counter.flops.items()}},
+        "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
+    }))
+
+
 _T0 = time.perf_counter()
 
 
@@ -300,6 +380,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--workload", default="vit", choices=["vit", "unet", "clip"],
+                    help="vit (default: the headline metric, BASELINE configs[1/2]); unet / clip: configs 3 / 4 on one GPU")
+    ap.add_argument("--img", type=int, default=64, help="--workload unet: image side (64 or 256)")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--cpu-child", default=None, help="(internal) run the CPU baseline in this process: fp32 | bf16")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -326,6 +409,11 @@ def main() -> None:
     args = ap.parse_args()
     if args.cpu_child is not None:
         _cpu_child(args.cpu_child, args.cpu_batch, args.cpu_steps, args.cpu_threads or (os.cpu_count() or 1))
+        return
+    if args.workload != "vit":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        bench_other_workload(args)
         return
     if args.watchdog > 0:
         import faulthandler

@@ -79,6 +79,22 @@ class GemmTimer:
 GEMM_TIMER: Optional[GemmTimer] = None
 
 
+class FlopCounter:
+    """Opt-in (bench.py --workload unet | clip): algorithmic MFMA-class FLOPs of the launches of a step, by family.
+    GEMM 2*M*N*K; implicit 3x3 convolution 2 * pixels * Cout * 9 * Cin (forward, input gradient = the same kernel,
+    weight gradient); attention 4 * B * H * Tq * Tk * dh forward and 2.5x that backward (5 products: the algorithmic
+    count, not the 7 the two-pass backward executes)."""
+
+    def __init__(self) -> None:
+        self.flops = {"gemm": 0.0, "conv3x3": 0.0, "attention": 0.0}
+
+    def total(self) -> float:
+        return sum(self.flops.values())
+
+
+FLOP_COUNTER: Optional[FlopCounter] = None
+
+
 def gemm(
     a: Tensor,
     b: Tensor,
@@ -131,6 +147,8 @@ def gemm(
     if split_k > 1:
         ws = torch.empty((split_k * m * (n + (1 if bias_grad is not None else 0)),), dtype=f32, device=a.device)
         ws_bytes = ws.numel() * 4
+    if FLOP_COUNTER is not None:
+        FLOP_COUNTER.flops["gemm"] += 2.0 * m * n * k
     timer = GEMM_TIMER
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -279,6 +297,8 @@ def attn_fwd(
     o = torch.empty((b, tq, d), dtype=bf16, device=q.device)
     lse = torch.empty((b, num_heads, tq), dtype=f32, device=q.device)
     keep, mp, ms_b, ms_h, ms_q = _mask_args(mask, b, num_heads, tq, tk)
+    if FLOP_COUNTER is not None:
+        FLOP_COUNTER.flops["attention"] += 4.0 * b * num_heads * tq * tk * head_dim
     rc = _lib.load().cfhip_attn_fwd_dh(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), mp, b, num_heads, tq,
         tk, int(head_dim), q_sb, q_st, k_sb, k_st, o.stride(0), o.stride(1), ms_b, ms_h, ms_q, float(scale),
@@ -310,6 +330,8 @@ def attn_bwd(
     if delta is None:
         delta = torch.empty((b, num_heads, tq), dtype=f32, device=q.device)
     keep, mp, ms_b, ms_h, ms_q = _mask_args(mask, b, num_heads, tq, tk)
+    if FLOP_COUNTER is not None:
+        FLOP_COUNTER.flops["attention"] += 10.0 * b * num_heads * tq * tk * head_dim
     rc = _lib.load().cfhip_attn_bwd_dh(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
         delta.data_ptr(), mp, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), b, num_heads, tq, tk, int(head_dim),
@@ -830,6 +852,8 @@ def conv3x3_nhwc(x_rows: Tensor, wk: Tensor, bias: Optional[Tensor], b: int, h: 
     if bias is not None:
         _need(bias, f32, "bias")
     y = torch.empty((m, cout), dtype=bf16, device=x_rows.device)
+    if FLOP_COUNTER is not None:
+        FLOP_COUNTER.flops["conv3x3"] += 2.0 * m * cout * 9 * cin
     lib = _lib.load()
     nbytes = lib.cfhip_conv3x3_workspace(b, h, w, cin, cout)  # > 0 when the shape splits its reduction
     ws = torch.empty((max(nbytes, 4) // 4,), dtype=f32, device=x_rows.device)
@@ -861,6 +885,8 @@ def conv3x3_wgrad_nhwc(dy_rows: Tensor, x_rows: Tensor, b: int, h: int, w: int, 
         _need(out, f32, "out")
         if out.numel() != cout * cin * 9 or not out.is_contiguous():
             raise ValueError("cfhip conv3x3_wgrad_nhwc: `out` must be a contiguous f32 [Cout, Cin, 3, 3]")
+    if FLOP_COUNTER is not None:
+        FLOP_COUNTER.flops["conv3x3"] += 2.0 * m * cout * 9 * cin
     lib = _lib.load()
     nbytes = lib.cfhip_conv3x3_wgrad_workspace(cin, cout, split_k)
     ws = torch.empty((nbytes // 4,), dtype=f32, device=dy_rows.device)
