@@ -48,6 +48,7 @@ struct GemmParams {
   // CONV == 2 (weight gradient): B is the NHWC activation, the GEMM's n index is (tap, channel), k = pixel;
   // pixel -> (y, x) per K-step by multiply-high with floor(2^32 / d) + 1 (exact while pixel * d < 2^32)
   unsigned conv_magic_w, conv_magic_h;
+  int group_n;  // > 0: tiles are walked in column groups of this many tile columns (all rows of a group first); set in launch_cfg
 #ifdef CFHIP_ABLATE
   int ablate;  // benchmarking only: bit0 skip in-loop DMA, bit1 skip MFMA/LDS reads, bit2 skip stores
 #endif
@@ -269,17 +270,24 @@ struct AuxRegs { u32x4 a, b; };  // f32 operand: 8 values (a, b); bf16 operand: 
 #define CFHIP_PF_BF16 4
 #endif
 
+// cache policy of the epilogue's global accesses (buffer aux bits: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef CFHIP_ST_AUX
+#define CFHIP_ST_AUX 0
+#endif
+#ifndef CFHIP_LD_AUX
+#define CFHIP_LD_AUX 0
+#endif
 __device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, CFHIP_LD_AUX));
 }
 __device__ __forceinline__ u32x2 bload8(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, CFHIP_LD_AUX));
 }
 __device__ __forceinline__ void bstore16(__amdgpu_buffer_rsrc_t r, unsigned off, u32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v), r, (int)off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v), r, (int)off, 0, CFHIP_ST_AUX);
 }
 __device__ __forceinline__ void bstore8(__amdgpu_buffer_rsrc_t r, unsigned off, u32x2 v) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, v), r, (int)off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, v), r, (int)off, 0, CFHIP_ST_AUX);
 }
 // descriptor of an [M][ld] matrix of ES-byte elements, anchored at (m0, n0); valid bytes end with element (M-1, N-1)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, long ld, int es, int m0, int n0, int M, int N) {
@@ -549,8 +557,31 @@ __device__ __forceinline__ ItemCtx<AT, BT, C> setup_item(const GemmParams& p, in
   const int ntiles = p.tiles_m * p.tiles_n;
   c.z = item / ntiles;
   const int tile = item - c.z * ntiles;
-  const int tile_m = tile / p.tiles_n;
-  c.tile_n = tile - tile_m * p.tiles_n;
+  int tile_m;
+  if (p.group_n > 0) {
+    // column groups: the workgroups resident on an XCD at one time share `group_n` B panels (kept hot in its L2) while
+    // the A panels stream through once per group
+    const int per_group = p.group_n * p.tiles_m;
+    const int grp = tile / per_group;
+    const int first_n = grp * p.group_n;
+    const int gw = min(p.group_n, p.tiles_n - first_n);
+    const int r = tile - grp * per_group;
+    tile_m = r / gw;
+    c.tile_n = first_n + (r - tile_m * gw);
+  } else if (p.group_n < 0) {
+    // row groups of -group_n panels, walked column by column (rows fastest): the A panels of a group stay hot
+    const int gm = -p.group_n;
+    const int per_group = gm * p.tiles_n;
+    const int grp = tile / per_group;
+    const int first_m = grp * gm;
+    const int gh = min(gm, p.tiles_m - first_m);
+    const int r = tile - grp * per_group;
+    c.tile_n = r / gh;
+    tile_m = first_m + (r - c.tile_n * gh);
+  } else {
+    tile_m = tile / p.tiles_n;
+    c.tile_n = tile - tile_m * p.tiles_n;
+  }
   c.m0 = tile_m * C::BM;
   c.n0 = c.tile_n * C::BN;
   const int kb = c.z * p.k_chunk;
@@ -996,6 +1027,7 @@ int g_gemm_config = -1;
 int g_gemm_ablate = 0;
 #endif
 int g_gemm_heuristic = 5;
+int g_gemm_group_n = 8;
 
 template <bool AT, bool BT, int EPI, class C, bool PIPE, int CONV = 0>
 int launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
@@ -1020,7 +1052,12 @@ int launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::LDS_BYTES, s, p);
+  GemmParams q = p;
+  // tile walk order (profiles/r02/gemm_group_sweep_b128.log, gemm_group_step_ab.log): outputs wider than 8 tile columns are
+  // walked in groups of 8 columns (whole step -1.4 %; per-shape group widths were better in isolation, not in the step)
+  const int gn = g_gemm_group_n;
+  q.group_n = (gn > 0 && gn < p.tiles_n) || (gn < 0 && p.tiles_m > 1) ? gn : 0;
+  hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::LDS_BYTES, s, q);
   return CFHIP_OK;
 }
 
@@ -1094,6 +1131,10 @@ extern "C" int cfhip_set_option(const char* name, int value) {
   }
   if (name != nullptr && strcmp(name, "gemm_heuristic") == 0) {
     g_gemm_heuristic = value;
+    return CFHIP_OK;
+  }
+  if (name != nullptr && strcmp(name, "gemm_group_n") == 0) {
+    g_gemm_group_n = value;
     return CFHIP_OK;
   }
   if (name != nullptr && strcmp(name, "ln_bwd_fused") == 0) return cfhip_internal_set_ln_fused(value);

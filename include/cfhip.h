@@ -42,6 +42,9 @@ const char* cfhip_last_error(void);
  *                     (0: 128x128x64, 1: 128x128x32, 3: 128x64x64, 7: 256x256x32 two-group kernel,
  *                      8: 256x128x32 two-group kernel, ...; see csrc/gemm.hip)
  *   "gemm_heuristic"  0..5, which shape -> configuration table pick_config() uses (default 5)
+ *   "gemm_group_n"    tile walk order of a GEMM launch: n > 0 (default 8): outputs wider than n tile columns are walked in
+ *                     groups of n columns, all rows of a group first (an XCD's resident workgroups then share n B panels
+ *                     that stay in its L2); n < 0: row groups of -n panels, columns outer; 0: rows outer, every column inner
  *   "ln_bwd_fused"    1 (default): cfhip_layernorm_bwd asked for dx AND dgamma / dbeta runs the one-launch kernel
  *                     (D a multiple of 256 up to 1280); 0: the round-1 one-wave-per-row kernel
  * Unknown names are an error.  (The phase-timing ablation masks "gemm_ablate" / "attn_ablate" of round 1 are
