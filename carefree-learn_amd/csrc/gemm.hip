@@ -90,12 +90,14 @@ template <int BK>
 __device__ __forceinline__ int kswz(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 
 // 32-byte chunk swizzle key of k-row `krow` of an m-major tile with R columns: the 8 k-rows a
-// half-wave touches in one ds_read_b64_tr_b16 must land on distinct chunks modulo the 256-B bank
-// row.  R >= 128 (row pitch >= 256 B): 8 distinct keys; R == 64 (pitch 128 B): even / odd rows are
-// already on different bank halves, 4 keys suffice.  mkey(krow) == mkey(krow + 4) for krow % 8 < 4.
+// half-wave touches in one ds_read_b64_tr_b16 (krow = 8 g + j: j = 0..3, two values of g) must land on distinct chunks
+// modulo the 256-B bank row.  Row pitch a multiple of 256 B (R = 128, 256): 8 distinct keys; pitch = 128 mod 256
+// (R = 64, 192): even / odd rows are already on different bank halves, 4 keys (which keep a chunk inside its aligned
+// group of four, so the key never leaves a 12-chunk row).  mkey(krow) == mkey(krow + 4) for krow % 8 < 4.
 template <int R>
 __device__ __forceinline__ int mkey(int krow) {
-  return R >= 128 ? ((krow & 3) | (((krow >> 3) & 1) << 2)) : (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1));
+  static_assert(R % 64 == 0, "m-major tiles: whole 128-byte lines per k-row");
+  return R % 128 == 0 ? ((krow & 3) | (((krow >> 3) & 1) << 2)) : (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1));
 }
 
 template <bool TRANS, int R, int NI, int BK>
@@ -116,8 +118,9 @@ __device__ __forceinline__ StagePlan<NI> make_plan(int wave, int lane, long ld, 
       // m-major tile [BK k][R cols]: one k-row = R/8 slots of 16 B; 32-B chunk c of k-row kr holds
       // source chunk c ^ mkey(kr)
       constexpr int SLOTS = R / 8;
-      const int krow = inst * (64 / SLOTS) + lane / SLOTS;
-      const int s = lane % SLOTS;
+      const int slot = inst * 64 + lane;  // 16-byte slot of the tile image (SLOTS need not divide 64: R = 192)
+      const int krow = slot / SLOTS;
+      const int s = slot - krow * SLOTS;
       const int col = (((s >> 1) ^ mkey<R>(krow)) << 4) + ((s & 1) << 3);
       p.kpos[j] = krow;
       p.voff[j] = (col < extent_valid) ? (unsigned)(krow * ld * 2 + col * 2) : OOB;
@@ -1019,14 +1022,16 @@ using CfgR = Cfg<256, 128, 2, 2, 3, 32>;  //  72 KiB LDS, 4 waves (128x64 each),
 using CfgS = Cfg<128, 256, 2, 2, 3, 32>;  //  72 KiB LDS, 4 waves (64x128 each), 2 WG / CU, prefetch 2
 using CfgT = Cfg<256, 128, 2, 4, 6, 32>;  // 144 KiB LDS, 8 waves, ONE WG / CU, prefetch 5 (probe: can one workgroup feed a CU?)
 using CfgU = Cfg<256, 256, 2, 4, 5, 32>;  // 160 KiB LDS, 8 waves, ONE WG / CU, prefetch 4
-constexpr int NUM_CFG = 13;  // 7 .. 12 = CfgP / CfgQ / CfgR / CfgS / CfgT / CfgU on the phase kernel
+using CfgW = Cfg<256, 256, 2, 4, 2, 64>;  // 128 KiB LDS, 8 waves (128x64 each), ONE WG / CU, BK = 64 (plain kernel)
+using CfgY = Cfg<192, 128, 2, 4, 2, 64>;  //  80 KiB LDS, 8 waves (96x32 each), 2 WG / CU, BK = 64 (plain kernel)
+constexpr int NUM_CFG = 15;  // 7 .. 12 = CfgP / CfgQ / CfgR / CfgS / CfgT / CfgU on the phase kernel; 13 / 14 = CfgW / CfgY
 constexpr int BK_MAX = 64;
 
 int g_gemm_config = -1;
 #ifdef CFHIP_ABLATE
 int g_gemm_ablate = 0;
 #endif
-int g_gemm_heuristic = 5;
+int g_gemm_heuristic = 6;
 int g_gemm_group_n = 8;
 
 template <bool AT, bool BT, int EPI, class C, bool PIPE, int CONV = 0>
@@ -1091,12 +1096,25 @@ int launch_layout(GemmParams p, int a_trans, int b_trans, int epilogue, int spli
   return CFHIP_ERR_INVALID;
 }
 
-// Shape-aware tile choice, from the measured A/B table of tools/gemm_bench.py on the ViT-B/16 shapes
-// (profiles/): the kernels are bound by how well DMA, MFMA and the store tail of co-resident
-// workgroups overlap, so the small-LDS configurations (3-4 workgroups / CU) win whenever the
-// operand is read through the transposing LDS path or the output is narrow.
+// Shape-aware tile choice.  What the K loops are bound by is the L2 -> LDS line traffic (round 2, profiles/README.md): a
+// k-major operand staged 32 k per step uses HALF of every 128-byte line it pulls through the CU's L1 (the other half is
+// gone again one K-step later), so the forward (nt) forms take BK = 64 configurations; the choice between configurations
+// that are close in isolation was made by A/B runs of the whole training step (gemm_heuristic_step_ab.log), where the
+// dX GEMMs share the chip with the dW GEMMs of the side stream:
+//   6 (default): dW (tn) -> 128x128x32, 4 WG / CU; dX (nn) -> 256x128x32 phase kernel; forward (nt): N >= 2560 ->
+//                192x128x64, otherwise 128x128x64
+//   5: round-2-start table (every M >= 1024 GEMM on the 256x128x32 phase kernel); 1 .. 4: the round-1 tables
 int pick_config(int M, int N, int a_trans, int b_trans) {
   if (g_gemm_config >= 0 && g_gemm_config < NUM_CFG) return g_gemm_config;
+  if (g_gemm_heuristic >= 6) {
+    if (a_trans) return 1;  // (192x128x64 is 10 % faster alone on the dW forms and 1.2 % slower in the step)
+    if (M >= 1024) {
+      if (b_trans) return 8;
+      return N >= 2560 ? 14 : 0;
+    }
+    if (b_trans) return 1;
+    return N <= 1024 ? 3 : 0;
+  }
   if (g_gemm_heuristic == 1) {
     if (a_trans && (long)M * N <= 768L * 768L) return 0;  // small dW outputs: few tiles, deep split-K
     if (a_trans || b_trans) return 1;
@@ -1106,7 +1124,7 @@ int pick_config(int M, int N, int a_trans, int b_trans) {
     if (a_trans) return 1;
     if (N >= 2560 && M >= 1024) return 8;
     if (g_gemm_heuristic >= 4 && b_trans && M >= 1024) return 8;  // every dX GEMM
-    if (g_gemm_heuristic >= 5 && M >= 1024) return 8;             // and every forward GEMM (step A/B: -0.8 %)
+    if (g_gemm_heuristic >= 5 && M >= 1024) return 8;             // and every forward GEMM
     if (g_gemm_heuristic >= 3) {  // 128x128x64 once it fills the 512 resident slots at least twice
       const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
       if (tiles128 >= 1024) return 0;
@@ -1245,6 +1263,8 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
     case 10: rc = launch_layout<CfgS, true>(p, a_trans, b_trans, epilogue, split_k, s); break;
     case 11: rc = launch_layout<CfgT, true>(p, a_trans, b_trans, epilogue, split_k, s); break;
     case 12: rc = launch_layout<CfgU, true>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 13: rc = launch_layout<CfgW>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 14: rc = launch_layout<CfgY>(p, a_trans, b_trans, epilogue, split_k, s); break;
     default: rc = launch_layout<CfgA>(p, a_trans, b_trans, epilogue, split_k, s); break;
   }
   if (rc != CFHIP_OK) return rc;

@@ -38,10 +38,11 @@ extern "C" {
 int cfhip_version(void);
 const char* cfhip_last_error(void);
 /* tuning knobs (process-wide, used by the benchmarks' A/B runs; defaults are the shipped behaviour):
- *   "gemm_config"     -1 (shape heuristic, default) or 0..10 to force one tile configuration
+ *   "gemm_config"     -1 (shape heuristic, default) or 0..14 to force one tile configuration
  *                     (0: 128x128x64, 1: 128x128x32, 3: 128x64x64, 7: 256x256x32 two-group kernel,
- *                      8: 256x128x32 two-group kernel, ...; see csrc/gemm.hip)
- *   "gemm_heuristic"  0..5, which shape -> configuration table pick_config() uses (default 5)
+ *                      8: 256x128x32 two-group kernel, 13: 256x256x64, 14: 192x128x64, ...; see csrc/gemm.hip)
+ *   "gemm_heuristic"  1..6, which shape -> configuration table pick_config() uses (default 6: forward GEMMs on the
+ *                     BK = 64 configurations, dX on the 256x128x32 two-group kernel, dW on 128x128x32)
  *   "gemm_group_n"    tile walk order of a GEMM launch: n > 0 (default 8): outputs wider than n tile columns are walked in
  *                     groups of n columns, all rows of a group first (an XCD's resident workgroups then share n B panels
  *                     that stay in its L2); n < 0: row groups of -n panels, columns outer; 0: rows outer, every column inner

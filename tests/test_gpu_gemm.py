@@ -177,7 +177,7 @@ def test_fused_bias_gradient_of_dw_gemm():
             assert_close(gw, 2 * want_w, 2e-5, "dW accumulate")
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
 def test_every_tile_config(cfg):
     """all tile configurations of the kernel on ragged shapes, all three layouts"""
     try:
@@ -211,3 +211,21 @@ def test_dw_layout_with_unaligned_token_count():
             ops.gemm(dy, x, a_trans=True, b_trans=True, out=gw, split_k=split, bias_grad=gb)
             assert_close(gw, want, 2e-5, f"dW K={kd} split {split}")
             assert_close(gb, dy.float().sum(0), 2e-5, f"db K={kd} split {split}")
+
+
+def test_tile_walk_orders_give_identical_results():
+    """`gemm_group_n` only permutes which workgroup computes which tile"""
+    m, n, k = 3000, 3072, 136
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(m, k, generator=g).to(torch.bfloat16).to(DEV)
+    w = torch.randn(n, k, generator=g).to(torch.bfloat16).to(DEV)
+    try:
+        outs = []
+        for gn in (0, 8, 5, 1, -4, -7):
+            ops.set_option("gemm_group_n", gn)
+            outs.append(ops.gemm(a, w, out_dtype=torch.float32))
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+    finally:
+        ops.set_option("gemm_group_n", 8)
+    assert_close(outs[0], a.float().double() @ w.float().t().double(), 2e-5, "walk order")
