@@ -89,6 +89,10 @@ SIGNATURES = {
     "cfhip_avgpool_bwd": (c_int, [_P, _P, c_int64, c_int, _P]),
     "cfhip_groupnorm_fwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "cfhip_groupnorm_bwd": (c_int, [_P, _P, c_int] + [_P] * 9 + [c_int] * 5 + [_P]),
+    "cfhip_groupnorm_affine_fwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int,
+                                           c_int, _P]),
+    "cfhip_groupnorm_affine_bwd": (c_int, [_P, _P, c_int] + [_P] * 9 + [c_int] * 6 + [_P]),
+    "cfhip_diffusion_loss": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int, _P]),
     "cfhip_silu_f32_fwd": (c_int, [_P, _P, c_int64, _P]),
     "cfhip_silu_f32_bwd": (c_int, [_P, _P, _P, c_int64, _P]),
     "cfhip_upsample2_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),

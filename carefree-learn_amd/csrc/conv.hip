@@ -299,9 +299,11 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const void* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      bf16_t* __restrict__ y, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int C, int G, int inner, float eps,
-                                                     int silu) {
+                                                     int silu, int affine_bs) {
   __shared__ float red[4];
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  gamma += (long)b * affine_bs;  // per-sample affine (scale-shift norm): gamma / beta are [B][C] when affine_bs == C
+  beta += (long)b * affine_bs;
   const int cg = C / G;
   const long base = ((long)b * C + (long)g * cg) * inner;
   const long n = (long)cg * inner;
@@ -339,9 +341,11 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ beta, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, bf16_t* __restrict__ dx,
                                                      float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
-                                                     float* __restrict__ dadd, int C, int G, int inner, int silu) {
+                                                     float* __restrict__ dadd, int C, int G, int inner, int silu, int affine_bs) {
   __shared__ float red[4];
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  gamma += (long)b * affine_bs;
+  beta += (long)b * affine_bs;
   const int cg = C / G;
   const long base = ((long)b * C + (long)g * cg) * inner;
   const long n = (long)cg * inner;
@@ -422,9 +426,11 @@ __global__ __launch_bounds__(256) void gn_fwd_vec_kernel(const void* __restrict_
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          bf16_t* __restrict__ y, float* __restrict__ mean_out,
                                                          float* __restrict__ rstd_out, int C, int G, int inner, float eps,
-                                                         int silu) {
+                                                         int silu, int affine_bs) {
   __shared__ float red[4];
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  gamma += (long)b * affine_bs;
+  beta += (long)b * affine_bs;
   const int cg = C / G;
   const int inner8 = inner >> 3;
   const long base = ((long)b * C + (long)g * cg) * inner;
@@ -487,10 +493,12 @@ __global__ __launch_bounds__(256) void gn_bwd_vec_kernel(const bf16_t* __restric
                                                          const float* __restrict__ beta, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, bf16_t* __restrict__ dx,
                                                          float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
-                                                         float* __restrict__ dadd, int C, int G, int inner, int silu) {
+                                                         float* __restrict__ dadd, int C, int G, int inner, int silu, int affine_bs) {
   __shared__ float red[4];
   __shared__ float part[2][GN_MAX_CG][4];
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  gamma += (long)b * affine_bs;
+  beta += (long)b * affine_bs;
   const int cg = C / G;
   const int inner8 = inner >> 3;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -824,32 +832,36 @@ extern "C" int cfhip_softmax_focal(const float* logits, const int64_t* labels, f
   return CFHIP_OK;
 }
 
-extern "C" int cfhip_groupnorm_fwd(const void* x, int x_is_f32, const float* add, const float* gamma, const float* beta,
-                                   void* y, float* mean, float* rstd, int B, int C, int G, int inner, float eps,
-                                   int silu, void* stream) {
+extern "C" int cfhip_groupnorm_affine_fwd(const void* x, int x_is_f32, const float* add, const float* gamma, const float* beta,
+                                          void* y, float* mean, float* rstd, int B, int C, int G, int inner, float eps,
+                                          int silu, int affine_batch_stride, void* stream) {
+  CFHIP_REQUIRE(affine_batch_stride == 0 || affine_batch_stride == C, "groupnorm_fwd: affine batch stride must be 0 or C");
+  const int affine_bs = affine_batch_stride;
   CFHIP_REQUIRE(x && gamma && beta && y && mean && rstd && B > 0 && C > 0 && G > 0 && inner > 0, "groupnorm_fwd: bad arguments");
   CFHIP_REQUIRE(C % G == 0, "groupnorm_fwd: %d channels do not split into %d groups", C, G);
   const bool vec = inner % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0;
   if (vec && x_is_f32)
     hipLaunchKernelGGL((gn_fwd_vec_kernel<true>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, add, gamma, beta,
-                       (bf16_t*)y, mean, rstd, C, G, inner, eps, silu);
+                       (bf16_t*)y, mean, rstd, C, G, inner, eps, silu, affine_bs);
   else if (vec)
     hipLaunchKernelGGL((gn_fwd_vec_kernel<false>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, add, gamma, beta,
-                       (bf16_t*)y, mean, rstd, C, G, inner, eps, silu);
+                       (bf16_t*)y, mean, rstd, C, G, inner, eps, silu, affine_bs);
   else if (x_is_f32)
     hipLaunchKernelGGL((gn_fwd_kernel<true>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, add, gamma, beta,
-                       (bf16_t*)y, mean, rstd, C, G, inner, eps, silu);
+                       (bf16_t*)y, mean, rstd, C, G, inner, eps, silu, affine_bs);
   else
     hipLaunchKernelGGL((gn_fwd_kernel<false>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, add, gamma, beta,
-                       (bf16_t*)y, mean, rstd, C, G, inner, eps, silu);
+                       (bf16_t*)y, mean, rstd, C, G, inner, eps, silu, affine_bs);
   CFHIP_CHECK_LAUNCH("groupnorm_fwd");
   return CFHIP_OK;
 }
 
-extern "C" int cfhip_groupnorm_bwd(const void* dy, const void* x, int x_is_f32, const float* add, const float* gamma,
-                                   const float* beta, const float* mean, const float* rstd, void* dx,
-                                   float* dgamma_part, float* dbeta_part, float* dadd, int B, int C, int G, int inner,
-                                   int silu, void* stream) {
+extern "C" int cfhip_groupnorm_affine_bwd(const void* dy, const void* x, int x_is_f32, const float* add, const float* gamma,
+                                          const float* beta, const float* mean, const float* rstd, void* dx,
+                                          float* dgamma_part, float* dbeta_part, float* dadd, int B, int C, int G, int inner,
+                                          int silu, int affine_batch_stride, void* stream) {
+  CFHIP_REQUIRE(affine_batch_stride == 0 || affine_batch_stride == C, "groupnorm_bwd: affine batch stride must be 0 or C");
+  const int affine_bs = affine_batch_stride;
   CFHIP_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma_part && dbeta_part, "groupnorm_bwd: null pointer");
   CFHIP_REQUIRE(B > 0 && C > 0 && G > 0 && inner > 0 && C % G == 0, "groupnorm_bwd: bad geometry");
   CFHIP_REQUIRE((add == nullptr) == (dadd == nullptr) || dadd == nullptr, "groupnorm_bwd: dadd without add");
@@ -857,18 +869,32 @@ extern "C" int cfhip_groupnorm_bwd(const void* dy, const void* x, int x_is_f32, 
                    ((uintptr_t)dx & 15) == 0;
   if (vec && x_is_f32)
     hipLaunchKernelGGL((gn_bwd_vec_kernel<true>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, add,
-                       gamma, beta, mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu);
+                       gamma, beta, mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu, affine_bs);
   else if (vec)
     hipLaunchKernelGGL((gn_bwd_vec_kernel<false>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, add,
-                       gamma, beta, mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu);
+                       gamma, beta, mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu, affine_bs);
   else if (x_is_f32)
     hipLaunchKernelGGL((gn_bwd_kernel<true>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, add,
-                       gamma, beta, mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu);
+                       gamma, beta, mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu, affine_bs);
   else
     hipLaunchKernelGGL((gn_bwd_kernel<false>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x,
-                       add, gamma, beta, mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu);
+                       add, gamma, beta, mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu, affine_bs);
   CFHIP_CHECK_LAUNCH("groupnorm_bwd");
   return CFHIP_OK;
+}
+
+extern "C" int cfhip_groupnorm_fwd(const void* x, int x_is_f32, const float* add, const float* gamma, const float* beta,
+                                   void* y, float* mean, float* rstd, int B, int C, int G, int inner, float eps,
+                                   int silu, void* stream) {
+  return cfhip_groupnorm_affine_fwd(x, x_is_f32, add, gamma, beta, y, mean, rstd, B, C, G, inner, eps, silu, 0, stream);
+}
+
+extern "C" int cfhip_groupnorm_bwd(const void* dy, const void* x, int x_is_f32, const float* add, const float* gamma,
+                                   const float* beta, const float* mean, const float* rstd, void* dx,
+                                   float* dgamma_part, float* dbeta_part, float* dadd, int B, int C, int G, int inner,
+                                   int silu, void* stream) {
+  return cfhip_groupnorm_affine_bwd(dy, x, x_is_f32, add, gamma, beta, mean, rstd, dx, dgamma_part, dbeta_part, dadd, B, C,
+                                    G, inner, silu, 0, stream);
 }
 
 extern "C" int cfhip_silu_f32_fwd(const float* x, float* y, int64_t n, void* stream) {

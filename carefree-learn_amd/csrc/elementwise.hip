@@ -553,6 +553,42 @@ __global__ void mse_loss_kernel(const bf16_t* __restrict__ pred, const float* __
   if (threadIdx.x == 0) atomicAdd(loss_sum, (red[0] + red[1] + red[2] + red[3]) / (float)inner);
 }
 
+// per-sample objective of DDPMStep.loss_fn: grid.y = sample, grid.x walks its `inner` elements
+template <bool L1>
+__global__ void diffusion_loss_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ target,
+                                      const float* __restrict__ weight, float* __restrict__ per_sample,
+                                      bf16_t* __restrict__ dpred, long inner) {
+  __shared__ float red[4];
+  const long b = blockIdx.y;
+  const long base = b * inner;
+  const float k = weight[b] / (float)inner;
+  float acc = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < inner; i += (long)gridDim.x * blockDim.x) {
+    const float d = bf16_to_f32(pred[base + i]) - target[base + i];
+    acc += L1 ? fabsf(d) : d * d;
+    if (dpred != nullptr) dpred[base + i] = f32_to_bf16(L1 ? (d > 0.f ? k : (d < 0.f ? -k : 0.f)) : 2.0f * k * d);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(per_sample + b, (red[0] + red[1] + red[2] + red[3]) / (float)inner);
+}
+
+extern "C" int cfhip_diffusion_loss(const void* pred, const float* target, const float* weight, float* per_sample,
+                                    void* dpred, int64_t B, int64_t inner, int loss_type, void* stream) {
+  CFHIP_REQUIRE(pred && target && weight && per_sample && B > 0 && B <= 65535 && inner > 0, "diffusion_loss: bad arguments");
+  CFHIP_REQUIRE(loss_type == 0 || loss_type == 1, "diffusion_loss: loss_type %d (0 = l2, 1 = l1)", loss_type);
+  const dim3 grid(grid_for(inner, 256, 256), (unsigned)B);
+  if (loss_type == 1)
+    hipLaunchKernelGGL((diffusion_loss_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred, target,
+                       weight, per_sample, (bf16_t*)dpred, (long)inner);
+  else
+    hipLaunchKernelGGL((diffusion_loss_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred, target,
+                       weight, per_sample, (bf16_t*)dpred, (long)inner);
+  CFHIP_CHECK_LAUNCH("diffusion_loss");
+  return CFHIP_OK;
+}
+
 extern "C" int cfhip_q_sample(const float* x, const float* noise, const int64_t* t, const float* sqrt_ac,
                               const float* sqrt_1mac, void* out, int out_is_f32, int64_t B, int64_t inner, void* stream) {
   CFHIP_REQUIRE(x && noise && t && sqrt_ac && sqrt_1mac && out && B > 0 && inner > 0, "q_sample: bad arguments");

@@ -181,6 +181,19 @@ def _is_direct(param: Optional[Tensor]) -> bool:
     return param is not None and param.is_leaf and param.requires_grad and param.dtype == f32
 
 
+def whole_param(t: Optional[Tensor]) -> Optional[Tensor]:
+    """`t` itself, or — when `t` is a contiguous view of a WHOLE leaf parameter (a [Cout, Cin, 1, 1] filter seen as the
+    [Cout, Cin] matrix of the GEMM it is) — that parameter: its gradient can then be written straight into `.grad` (and
+    run on the side stream) instead of travelling back through autograd's view chain."""
+    if t is None or t.is_leaf or not t._is_view():
+        return t
+    base = t._base
+    if (base is not None and base.is_leaf and base.requires_grad and base.dtype == f32 and base.numel() == t.numel()
+            and t.is_contiguous() and base.is_contiguous() and t.data_ptr() == base.data_ptr()):
+        return base
+    return t
+
+
 def grad_buffer(param: Tensor, zero: bool = False) -> Tensor:
     """The tensor a backward kernel writes `param`'s gradient into when `param.grad is None`: the parameter's slot of
     its `optim.ParamArena` when it lives in one (the reference trainer's `optimizer.zero_grad()` sets `.grad` to None
@@ -250,13 +263,13 @@ def _linear_param_grads(dy2: Tensor, x2: Tensor, weight: Tensor, bias: Optional[
                         weight_direct: bool, bias_direct: bool) -> Tuple[Optional[Tensor], Optional[Tensor]]:
     """dW = dy^T x, db = colsum(dy): direct-to-.grad when possible, returned otherwise."""
     gw = gb = None
-    n, k, m = weight.shape[0], weight.shape[1], x2.shape[0]
+    n, k, m = dy2.shape[1], x2.shape[1], x2.shape[0]  # (the parameter may be a [n, k, 1, 1] filter: whole_param)
     fast_ok = dy2.shape[1] % 8 == 0 and x2.shape[1] % 8 == 0 and dy2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0
     # split-K lives on the MFMA path only; narrow tabular heads (3 classes, 10 features) take the shape-agnostic kernel
     split = ops.pick_split_k(n, k, m) if fast_ok else 1
 
     def dw_into(out: Tensor, acc: bool) -> None:
-        ops.gemm(dy2, x2, a_trans=True, b_trans=True, out=out, accumulate=acc, split_k=split)
+        ops.gemm(dy2, x2, a_trans=True, b_trans=True, out=out.view(n, k), accumulate=acc, split_k=split)
 
     if (weight.requires_grad and weight_direct and bias is not None and bias.requires_grad and bias_direct
             and fast_ok):
@@ -285,9 +298,11 @@ class LinearFn(Function):
     def forward(ctx: Any, x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int,
                 residual: Optional[Tensor], out_f32: bool) -> Tensor:
         x2 = _as_bf16_2d(x)
-        w16 = shadow_bf16(weight)
+        wshape = weight.shape
+        weight, bias = whole_param(weight), whole_param(bias)
+        w16 = shadow_bf16(weight).view(wshape)
         bias_f = None if bias is None else bias.detach().reshape(-1).contiguous()
-        m, n = x2.shape[0], weight.shape[0]
+        m, n = x2.shape[0], wshape[0]
         pre = None
         if act in (ACT_GELU, ACT_QGELU):
             pre = torch.empty((m, n), dtype=bf16, device=x2.device)
@@ -303,6 +318,7 @@ class LinearFn(Function):
             y = ops.gemm(x2, w16, bias=bias_f, out_dtype=f32 if out_f32 else bf16)
         ctx.save_for_backward(x2, w16, pre)
         ctx.weight, ctx.bias = weight, bias
+        ctx.n = n
         ctx.has_residual = residual is not None
         ctx.x_shape = x.shape
         ctx.in_dtype = x.dtype
@@ -316,7 +332,7 @@ class LinearFn(Function):
         dy2 = _as_bf16_2d(dy)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        d_res = dy2.view(*ctx.x_shape[:-1], weight.shape[0]) if ctx.has_residual and ctx.needs_input_grad[4] else None
+        d_res = dy2.view(*ctx.x_shape[:-1], ctx.n) if ctx.has_residual and ctx.needs_input_grad[4] else None
         # (autograd casts d_res to the residual's dtype; the gradient stream itself stays bf16)
         if pre is not None:
             dy2 = ops.gelu_bwd(dy2, pre) if ctx.act == ACT_GELU else ops.quick_gelu_bwd(dy2, pre)
@@ -1000,7 +1016,46 @@ class GroupNormFn(Function):
 
 def group_norm(x: Tensor, weight: Tensor, bias: Tensor, groups: int, eps: float, add: Optional[Tensor] = None,
                silu: bool = False) -> Tensor:
+    """`weight` / `bias`: [C], or [B, C] for one affine per sample (see `scale_shift_affine`)."""
     return GroupNormFn.apply(x, weight, bias, groups, eps, add, silu)
+
+
+class ScaleShiftAffineFn(Function):
+    """The scale-shift norm `norm(net) * (1 + scale) + shift` (reference residual.py:236-239) as GroupNorm with one affine
+    per sample: gamma_eff[b, c] = gamma[c] (1 + scale[b, c]), beta_eff[b, c] = beta[c] (1 + scale[b, c]) + shift[b, c]
+    (f32 [B, C]: a few hundred values; the normalisation itself stays one kernel).  The parameter gradients follow the
+    package's direct-write protocol."""
+
+    @staticmethod
+    def forward(ctx: Any, weight: Tensor, bias: Tensor, scale: Tensor, shift: Tensor):  # type: ignore
+        g, b_ = weight.detach().float(), bias.detach().float()
+        sc = scale.detach().float()
+        one_plus = sc + 1.0
+        ctx.save_for_backward(g, b_, one_plus)
+        ctx.weight, ctx.bias = weight, bias
+        return (g[None, :] * one_plus).contiguous(), (b_[None, :] * one_plus + shift.detach().float()).contiguous()
+
+    @staticmethod
+    def backward(ctx: Any, dge: Tensor, dbe: Tensor):  # type: ignore
+        g, b_, one_plus = ctx.saved_tensors
+        dge, dbe = dge.float(), dbe.float()
+        dgamma, dbeta = (dge * one_plus).sum(0), (dbe * one_plus).sum(0)
+        gw = gb = None
+        for prm, gr, which in ((ctx.weight, dgamma, 0), (ctx.bias, dbeta, 1)):
+            if not prm.requires_grad:
+                continue
+            if _is_direct(prm):
+                write_param_grad(prm, lambda out, acc, gr=gr: out.add_(gr.view(out.shape)) if acc else out.copy_(gr.view(out.shape)))
+            elif which == 0:
+                gw = gr.view(prm.shape)
+            else:
+                gb = gr.view(prm.shape)
+        dscale = dge * g[None, :] + dbe * b_[None, :]
+        return gw, gb, dscale, dbe
+
+
+def scale_shift_affine(weight: Tensor, bias: Tensor, scale: Tensor, shift: Tensor):
+    return ScaleShiftAffineFn.apply(weight, bias, scale, shift)
 
 
 class SiLUF32Fn(Function):

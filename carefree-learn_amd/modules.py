@@ -1403,12 +1403,17 @@ class HijackConv2d(_HijackMixin, nn.Conv2d):
 
 class GroupNorm(nn.GroupNorm):
     """nn.GroupNorm (`make_norm`, residual.py:194) on `cfhip_groupnorm_fwd/bwd`; `add` / `silu` expose the kernel's
-    fused time-embedding add in front and SiLU behind."""
+    fused time-embedding add in front and SiLU behind; `scale_shift=(scale, shift)` (f32 [B, C] each) is the scale-shift
+    form `norm(net) * (1 + scale) + shift` of residual.py:236-239, still one kernel each way."""
 
-    def forward(self, net: Tensor, *, add: Optional[Tensor] = None, silu: bool = False) -> Tensor:  # type: ignore
+    def forward(self, net: Tensor, *, add: Optional[Tensor] = None, silu: bool = False,  # type: ignore
+                scale_shift: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
         if not self.affine:
             raise NotImplementedError("GroupNorm without affine parameters is outside the accelerated hot path")
-        return HF.group_norm(net, self.weight, self.bias, self.num_groups, self.eps, add, silu)
+        weight, bias = self.weight, self.bias
+        if scale_shift is not None:
+            weight, bias = HF.scale_shift_affine(self.weight, self.bias, scale_shift[0], scale_shift[1])
+        return HF.group_norm(net, weight, bias, self.num_groups, self.eps, add, silu)
 
 
 class ResDownsample(Module):
@@ -1452,10 +1457,10 @@ class ResUpsample(Module):
 class ResidualBlockWithTimeEmbedding(Module):
     """reference residual.py:154-253: GN(32) -> SiLU -> [resample] -> conv3x3 -> (+ Linear(SiLU(t))) -> GN(32) -> SiLU ->
     conv3x3 (zero-initialised) -> + shortcut(inp).  State keys: `norm1.*`, `conv1.*`, `time_embedding.*`, `norm2.*`,
-    `conv2.*`, `shortcut.*`.  GroupNorm, the time-embedding add in front of norm2 and both SiLUs are two fused
-    kernels each way.  `use_checkpoint=True` recomputes the block in backward like the reference (residual.py:217-222).
-    Scale-shift norm and dropout are outside the accelerated hot path (`safe_clip_` only acts on non-finite values and
-    is omitted)."""
+    `conv2.*`, `shortcut.*`.  GroupNorm, the time-embedding add in front of norm2 (or, with `use_scale_shift_norm`, the
+    `norm2(net) * (1 + scale) + shift` modulation behind it) and both SiLUs are two fused kernels each way; `dropout`
+    is the Philox kernel of `Dropout`.  `use_checkpoint=True` recomputes the block in backward like the reference
+    (residual.py:217-222).  (`safe_clip_` only acts on non-finite values and is omitted.)"""
 
     def __init__(self, in_channels: int, out_channels: Optional[int] = None, *, signal_dim: int = 2,
                  dropout: float = 0.0, norm_eps: float = 1.0e-6, use_conv_shortcut: bool = False,
@@ -1463,8 +1468,8 @@ class ResidualBlockWithTimeEmbedding(Module):
                  time_embedding_channels: int = 512, use_scale_shift_norm: bool = False,
                  use_checkpoint: bool = False):
         super().__init__()
-        if signal_dim != 2 or use_scale_shift_norm or dropout > 0.0:
-            raise NotImplementedError("3-D signals / scale-shift norm / dropout are outside the accelerated hot path")
+        if signal_dim != 2:
+            raise NotImplementedError("only 2-D signals are on the accelerated hot path")
         self.in_channels = in_channels
         out_channels = out_channels or in_channels
         self.out_channels = out_channels
@@ -1483,9 +1488,10 @@ class ResidualBlockWithTimeEmbedding(Module):
         self.norm1 = GroupNorm(num_groups=32, num_channels=in_channels, eps=norm_eps)
         self.conv1 = HijackConv2d(in_channels, out_channels, 3, 1, 1)
         if time_embedding_channels > 0:
-            self.time_embedding = HijackLinear(time_embedding_channels, out_channels)
+            self.time_embedding = HijackLinear(time_embedding_channels,
+                                               2 * out_channels if use_scale_shift_norm else out_channels)
         self.norm2 = GroupNorm(num_groups=32, num_channels=out_channels, eps=norm_eps)
-        self.dropout = nn.Dropout(dropout)
+        self.dropout = Dropout(dropout)
         self.conv2 = HijackConv2d(out_channels, out_channels, 3, 1, 1)
         with torch.no_grad():  # zero_module (modules/common.py:177-180)
             for p in self.conv2.parameters():
@@ -1510,13 +1516,78 @@ class ResidualBlockWithTimeEmbedding(Module):
         net = self.conv1(net)
         if self.in_channels != self.out_channels:
             inp = self.shortcut(inp)
-        add = None
+        add = scale_shift = None
         if time_net is not None:
             t = HF.silu_f32(time_net)
-            add = HF.linear(t, self.time_embedding.weight, self.time_embedding.bias, out_f32=True)  # [B, Cout]
-        net = self.norm2(net, add=add, silu=True)
+            t = HF.linear(t, self.time_embedding.weight, self.time_embedding.bias, out_f32=True)  # [B, Cout] / [B, 2 Cout]
+            if self.use_scale_shift_norm:
+                scale_shift = tuple(torch.chunk(t, 2, dim=1))  # residual.py:236-239
+            else:
+                add = t
+        net = self.norm2(net, add=add, silu=True, scale_shift=scale_shift)
+        net = self.dropout(net)
         net = self.conv2(net)
         return HF.add(inp, net)
+
+
+# ---------------------------------------------------------------------------------------------
+# UNet self attention over pixels (reference attentions.py:373-460), the `use_spatial_transformer=False` UNets
+# ---------------------------------------------------------------------------------------------
+
+
+class MultiHeadSpatialAttention(Module):
+    """reference attentions.py:373-460: GroupNorm(32) -> 1x1 conv1d to 3C -> per-head softmax(q^T k / sqrt(hd)) v over
+    the H*W pixels -> 1x1 conv1d (zero-initialised) -> + input.  State keys `norm.*`, `to_qkv.{weight [3C, C, 1], bias}`,
+    `to_out.*` as in the reference.  Here the pixels become token-major rows once ([B, HW, C]), the two 1x1 convolutions
+    are GEMMs over them (three for q / k / v: each reads the ROWS of `to_qkv.weight` that belong to it, so no activation
+    is permuted — `split_qkv_before_heads=False`, the reference default, interleaves q / k / v per head along the 3C
+    output channels) and the attention is the flash kernel for general head widths; the reference scales q and k by
+    hd^-1/4 each, the kernel applies hd^-1/2 to their product."""
+
+    def __init__(self, in_channels: int, *, num_heads: Optional[int] = 1, num_head_channels: Optional[int] = None,
+                 split_qkv_before_heads: bool = False, use_checkpoint: bool = False):
+        super().__init__()
+        self.in_channels = in_channels
+        if num_head_channels is None:
+            if num_heads is None:
+                raise ValueError("either `num_heads` or `num_head_channels` should be provided")
+            self.num_heads = num_heads
+        else:
+            self.num_heads = in_channels // num_head_channels
+        head_dim = in_channels // self.num_heads
+        if head_dim * self.num_heads != in_channels or head_dim % 8 != 0 or head_dim > 192:
+            raise NotImplementedError(f"head width {head_dim} is outside the attention kernels (multiples of 8 up to 192)")
+        self.split_qkv_before_heads = split_qkv_before_heads
+        self.use_checkpoint = use_checkpoint
+        self.norm = GroupNorm(32, in_channels)
+        self.to_qkv = nn.Conv1d(in_channels, in_channels * 3, 1)
+        self.to_out = nn.Conv1d(in_channels, in_channels, 1)
+        with torch.no_grad():  # zero_module
+            for p in self.to_out.parameters():
+                p.zero_()
+
+    def forward(self, net: Tensor) -> Tensor:
+        if self.use_checkpoint:
+            return HF.gradient_checkpoint(self._forward, (net,), self.parameters(), True)
+        return self._forward(net)
+
+    def _qkv_rows(self) -> Tuple[List[Tensor], List[Tensor]]:
+        c, h = self.in_channels, self.num_heads
+        hd = c // h
+        w, b = self.to_qkv.weight.view(3 * c, c), self.to_qkv.bias
+        if self.split_qkv_before_heads:  # channels [q (all heads) | k | v]
+            return [w[i * c:(i + 1) * c] for i in range(3)], [b[i * c:(i + 1) * c] for i in range(3)]
+        w4, b3 = w.view(h, 3, hd, c), b.view(h, 3, hd)  # channels [head][q | k | v][hd]
+        return [w4[:, i].reshape(c, c) for i in range(3)], [b3[:, i].reshape(c) for i in range(3)]
+
+    def _forward(self, net: Tensor) -> Tensor:
+        b, c, h, w = net.shape
+        tokens = HF.nchw_to_tokens(self.norm(net))  # [B, HW, C]
+        ws, bs = self._qkv_rows()
+        q, k, v = (HF.linear(tokens, wi, bi) for wi, bi in zip(ws, bs))
+        o = HF.attention_core(q, k, v, self.num_heads, None, False, c // self.num_heads)
+        out = HF.linear(o, self.to_out.weight.view(c, c), self.to_out.bias)
+        return HF.add(net, HF.tokens_to_nchw(out, h, w))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1644,19 +1715,21 @@ class TimestepAttnSequential(nn.Sequential):
                 net = layer(net, time_net)
             elif isinstance(layer, SpatialTransformer):
                 net = layer(net, context)
-            else:
+            else:  # MultiHeadSpatialAttention, resampling, the stem convolution
                 net = layer(net)
         return net
 
 
 @register_module("unet_diffuser")
 class UNetDiffuser(Module):
-    """reference unet.py:76-322 with `use_spatial_transformer=True` (the zoo `diffusion/ddpm` configuration): time
-    embedding MLP, input blocks (ResBlock [+ SpatialTransformer] x num_res_blocks, conv down-sampling), middle block,
-    output blocks over channel-concatenated skip connections (+ nearest up-sampling), GroupNorm -> SiLU -> conv head.
-    State keys are the reference's (`time_embedding.{0,2}.*`, `input_blocks.<i>.<j>.*`, `residual.*`,
-    `output_blocks.*`, `head.{0,2}.*`).  Class labels, ControlNet residuals, `MultiHeadSpatialAttention`, scale-shift
-    norm, resampling through ResBlocks and dropout are outside the accelerated hot path."""
+    """reference unet.py:76-322: time embedding MLP (+ class-label embedding), input blocks (ResBlock [+ attention] x
+    num_res_blocks, down-sampling), middle block, output blocks over channel-concatenated skip connections (+
+    up-sampling), GroupNorm -> SiLU -> conv head.  Attention = `SpatialTransformer` (`use_spatial_transformer=True`, the
+    zoo `diffusion/ddpm` configuration; conv or `use_linear_in_transformer` projections) or `MultiHeadSpatialAttention`;
+    resampling = conv / pooling / nearest, or ResBlocks with `resample_with_resblock`; `use_scale_shift_norm`, `dropout`
+    and ControlNet residuals (`control`, `only_mid_control`) as in the reference.  State keys are the reference's
+    (`time_embedding.{0,2}.*`, `label_embedding.weight`, `input_blocks.<i>.<j>.*`, `residual.*`, `output_blocks.*`,
+    `head.{0,2}.*`).  3-D signals and SpatialTransformer hooks are outside the accelerated hot path."""
 
     def __init__(self, in_channels: int, out_channels: int, *, num_heads: Optional[int] = None,
                  num_head_channels: Optional[int] = None, use_spatial_transformer: bool = False,
@@ -1668,22 +1741,22 @@ class UNetDiffuser(Module):
                  num_classes: Optional[int] = None, use_linear_in_transformer: bool = False,
                  use_checkpoint: bool = False, hooks_kwargs: Optional[Dict[str, Any]] = None):
         super().__init__()
-        if (not use_spatial_transformer or signal_dim != 2 or resample_with_resblock or use_scale_shift_norm
-                or num_classes is not None or use_linear_in_transformer or dropout > 0.0 or hooks_kwargs):
-            raise NotImplementedError("only the spatial-transformer 2-D UNet without labels / scale-shift norm / "
-                                      "ResBlock resampling / dropout is on the accelerated hot path")
+        if signal_dim != 2 or hooks_kwargs:
+            raise NotImplementedError("only the 2-D UNet without SpatialTransformer hooks is on the accelerated hot path")
         self.in_channels, self.out_channels, self.context_dim = in_channels, out_channels, context_dim
         self.num_heads, self.num_head_channels = num_heads, num_head_channels
         self.start_channels, self.num_res_blocks = start_channels, num_res_blocks
         self.attention_downsample_rates = tuple(attention_downsample_rates)
         self.channel_multipliers = tuple(channel_multipliers)
-        self.num_classes, self.label_embedding = None, None
+        self.use_scale_shift_norm, self.num_classes = use_scale_shift_norm, num_classes
         ted = start_channels * 4
         self.time_embedding = nn.Sequential(HijackLinear(start_channels, ted), nn.SiLU(), HijackLinear(ted, ted))
+        self.label_embedding = None if num_classes is None else nn.Embedding(num_classes, ted)  # unet.py:148-151
 
-        def res(in_c: int, out_c: int) -> Module:
+        def res(in_c: int, out_c: int, **kwargs: Any) -> Module:
             return ResidualBlockWithTimeEmbedding(in_c, out_c, norm_eps=1.0e-5, time_embedding_channels=ted,
-                                                  use_checkpoint=use_checkpoint)
+                                                  dropout=dropout, use_checkpoint=use_checkpoint,
+                                                  use_scale_shift_norm=use_scale_shift_norm, **kwargs)
 
         def attn(in_c: int) -> Module:
             if num_head_channels is not None:
@@ -1692,8 +1765,22 @@ class UNetDiffuser(Module):
                 if num_heads is None:
                     raise ValueError("either `num_heads` or `num_head_channels` should be provided")
                 n_heads, head_c = num_heads, in_c // num_heads
+            if not use_spatial_transformer:  # unet.py:174-180
+                return MultiHeadSpatialAttention(in_c, num_heads=n_heads, num_head_channels=head_c,
+                                                 use_checkpoint=use_checkpoint)
             return SpatialTransformer(in_c, n_heads, head_c, num_layers=num_transformer_layers,
-                                      context_dim=context_dim, use_checkpoint=use_checkpoint)
+                                      context_dim=context_dim, use_linear=use_linear_in_transformer,
+                                      use_checkpoint=use_checkpoint)
+
+        def down(in_c: int) -> Module:  # unet.py:192-203
+            if not resample_with_resblock:
+                return TimestepAttnSequential(ResDownsample(in_c, resample_with_conv, out_channels=in_c))
+            return TimestepAttnSequential(res(in_c, in_c, integrate_downsample=True))
+
+        def up(in_c: int) -> Module:  # unet.py:205-213
+            if not resample_with_resblock:
+                return ResUpsample(in_c, resample_with_conv, out_channels=in_c)
+            return res(in_c, in_c, integrate_upsample=True)
 
         input_blocks: List[Module] = [TimestepAttnSequential(HijackConv2d(in_channels, start_channels, 3, padding=1))]
         skip_channels = [start_channels]
@@ -1708,8 +1795,7 @@ class UNetDiffuser(Module):
                 input_blocks.append(TimestepAttnSequential(*blocks))
                 skip_channels.append(in_nc)
             if i != len(self.channel_multipliers) - 1:
-                input_blocks.append(TimestepAttnSequential(
-                    ResDownsample(in_nc, resample_with_conv, out_channels=in_nc)))
+                input_blocks.append(down(in_nc))
                 rate *= 2
                 skip_channels.append(in_nc)
         self.input_blocks = nn.ModuleList(input_blocks)
@@ -1724,7 +1810,7 @@ class UNetDiffuser(Module):
                 if rate in self.attention_downsample_rates:
                     blocks.append(attn(in_nc))
                 if i != 0 and idx == num_res_blocks:
-                    blocks.append(ResUpsample(in_nc, resample_with_conv, out_channels=in_nc))
+                    blocks.append(up(in_nc))
                     rate //= 2
                 output_blocks.append(TimestepAttnSequential(*blocks))
         self.output_blocks = nn.ModuleList(output_blocks)
@@ -1736,21 +1822,27 @@ class UNetDiffuser(Module):
 
     def forward(self, net: Tensor, *, timesteps: Tensor, context: Optional[Tensor] = None,
                 labels: Optional[Tensor] = None, control: Any = None, only_mid_control: bool = False) -> Tensor:
-        if labels is not None or control is not None:
-            raise NotImplementedError("class labels / ControlNet residuals are outside the accelerated hot path")
-        from . import ops
-
+        if (labels is None) ^ (self.num_classes is None):
+            raise ValueError("`labels` should be given iff `num_classes` is specified")
         te = self.time_embedding
         time_net = ops.timestep_embedding(timesteps.to(torch.int64), self.start_channels)  # f32 [B, start]
         time_net = HF.linear(time_net, te[0].weight, te[0].bias, out_f32=True)
         time_net = HF.linear(HF.silu_f32(time_net), te[2].weight, te[2].bias, out_f32=True)  # f32 [B, 4 * start]
+        if self.label_embedding is not None:  # unet.py:303-304
+            time_net = time_net + HF.embedding(labels.reshape(-1).to(torch.int64), self.label_embedding.weight)
+        control = None if control is None else list(control)
         nets: List[Tensor] = []
         for block in self.input_blocks:
             net = block(net, time_net, context)
             nets.append(net)
         net = self.residual(net, time_net, context)
+        if control is not None:  # unet.py:311-318
+            net = HF.add(net, control.pop())
         for block in self.output_blocks:
-            net = block(HF.concat_channels(net, nets.pop()), time_net, context)
+            skip = nets.pop()
+            if control is not None and not only_mid_control:
+                skip = HF.add(skip, control.pop())
+            net = block(HF.concat_channels(net, skip), time_net, context)
         net = self.head[0](net, silu=True)  # GroupNorm + SiLU in one kernel
         return self.head[2](net)
 

@@ -735,15 +735,27 @@ def colreduce_f32(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = Fa
     return out
 
 
+def _gn_affine_stride(gamma: Tensor, beta: Tensor, b: int, c: int) -> int:
+    if gamma.shape != beta.shape or not gamma.is_contiguous() or not beta.is_contiguous():
+        raise ValueError("cfhip groupnorm: gamma / beta must be contiguous and of one shape")
+    if tuple(gamma.shape) == (c,):
+        return 0
+    if tuple(gamma.shape) == (b, c):
+        return c
+    raise ValueError(f"cfhip groupnorm: gamma must be [C] or [B, C], got {tuple(gamma.shape)}")
+
+
 def groupnorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, *, add: Optional[Tensor] = None,
                   silu: bool = False):
-    """x [B, C, ...] f32 / bf16 -> (y bf16, mean f32 [B*G], rstd f32 [B*G]); y = [SiLU](GN(x + add[b, c]))."""
+    """x [B, C, ...] f32 / bf16 -> (y bf16, mean f32 [B*G], rstd f32 [B*G]); y = [SiLU](GN(x + add[b, c])).
+    gamma / beta: f32 [C], or [B, C] = one affine per sample (the scale-shift norm of residual.py:236-239)."""
     if x.dtype not in (f32, bf16) or not x.is_cuda or not x.is_contiguous() or x.dim() < 2:
         raise ValueError("cfhip groupnorm_fwd: x must be a contiguous f32/bf16 [B, C, ...] device tensor")
     _need(gamma, f32, "gamma")
     _need(beta, f32, "beta")
     b, c = x.shape[0], x.shape[1]
     inner = x.numel() // (b * c)
+    affine_bs = _gn_affine_stride(gamma, beta, b, c)
     if add is not None:
         _need(add, f32, "add")
         if tuple(add.shape) != (b, c) or not add.is_contiguous():
@@ -751,30 +763,34 @@ def groupnorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: floa
     y = torch.empty(x.shape, dtype=bf16, device=x.device)
     mean = torch.empty((b * groups,), dtype=f32, device=x.device)
     rstd = torch.empty((b * groups,), dtype=f32, device=x.device)
-    rc = _lib.load().cfhip_groupnorm_fwd(x.data_ptr(), int(x.dtype == f32), _p(add), gamma.data_ptr(), beta.data_ptr(),
-                                         y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), b, c, groups, inner,
-                                         float(eps), int(silu), _stream())
+    rc = _lib.load().cfhip_groupnorm_affine_fwd(x.data_ptr(), int(x.dtype == f32), _p(add), gamma.data_ptr(),
+                                                beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), b, c,
+                                                groups, inner, float(eps), int(silu), affine_bs, _stream())
     _lib.check(rc, "groupnorm_fwd")
     return y, mean, rstd
 
 
 def groupnorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tensor, groups: int, *,
                   add: Optional[Tensor] = None, silu: bool = False):
-    """Returns (dx bf16, dgamma f32 [C], dbeta f32 [C], dadd f32 [B, C] | None)."""
+    """Returns (dx bf16, dgamma, dbeta, dadd f32 [B, C] | None); dgamma / dbeta have the shape of gamma ([C], or [B, C]
+    for a per-sample affine)."""
     _need(dy, bf16, "dy")
     if not dy.is_contiguous():
         dy = dy.contiguous()
     b, c = x.shape[0], x.shape[1]
     inner = x.numel() // (b * c)
+    affine_bs = _gn_affine_stride(gamma, beta, b, c)
     dx = torch.empty(x.shape, dtype=bf16, device=x.device)
     dg_part = torch.empty((b, c), dtype=f32, device=x.device)
     db_part = torch.empty((b, c), dtype=f32, device=x.device)
     dadd = torch.empty((b, c), dtype=f32, device=x.device) if add is not None else None
-    rc = _lib.load().cfhip_groupnorm_bwd(dy.data_ptr(), x.data_ptr(), int(x.dtype == f32), _p(add), gamma.data_ptr(),
-                                         beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
-                                         dg_part.data_ptr(), db_part.data_ptr(), _p(dadd), b, c, groups, inner,
-                                         int(silu), _stream())
+    rc = _lib.load().cfhip_groupnorm_affine_bwd(dy.data_ptr(), x.data_ptr(), int(x.dtype == f32), _p(add),
+                                                gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                dx.data_ptr(), dg_part.data_ptr(), db_part.data_ptr(), _p(dadd), b, c,
+                                                groups, inner, int(silu), affine_bs, _stream())
     _lib.check(rc, "groupnorm_bwd")
+    if affine_bs:
+        return dx, dg_part, db_part, dadd
     return dx, colreduce_f32(dg_part), colreduce_f32(db_part), dadd
 
 
@@ -1014,6 +1030,26 @@ def mse_loss(pred: Tensor, target: Tensor, grad_scale: float, want_grad: bool = 
                                     float(grad_scale), _stream())
     _lib.check(rc, "mse_loss")
     return loss, dpred
+
+
+def diffusion_loss(pred: Tensor, target: Tensor, weight: Tensor, loss_type: str = "l2", want_grad: bool = True):
+    """DDPMStep.loss_fn's per-sample objective: returns (per_sample f32 [B] = mean_inner f(pred - target), dpred bf16 =
+    weight[b] * f' / inner); f = square ("l2") or abs ("l1")."""
+    _need(pred, bf16, "pred")
+    _need(target, f32, "target")
+    _need(weight, f32, "weight")
+    if loss_type not in ("l1", "l2"):
+        raise ValueError(f"unrecognized loss '{loss_type}' occurred")
+    pred, target, weight = pred.contiguous(), target.contiguous(), weight.contiguous()
+    b = pred.shape[0]
+    if weight.numel() != b or target.numel() != pred.numel():
+        raise ValueError("cfhip diffusion_loss: shapes differ")
+    per_sample = torch.zeros((b,), dtype=f32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    rc = _lib.load().cfhip_diffusion_loss(pred.data_ptr(), target.data_ptr(), weight.data_ptr(), per_sample.data_ptr(),
+                                          _p(dpred), b, pred.numel() // b, 1 if loss_type == "l1" else 0, _stream())
+    _lib.check(rc, "diffusion_loss")
+    return per_sample, dpred
 
 
 # ---------------------------------------------------------------------------------------------

@@ -55,10 +55,27 @@ class ParamArena:
                 p.grad = self.flat_g[o:o + n].view(p.shape)
                 p._cfhip_arena = self   # functional.grad_buffer: a `.grad` that was set to None comes back as this view
                 p._cfhip_fresh = False  # the arena starts zeroed: accumulate into it
+                p.register_hook(self._fresh_guard(p))
                 if self.flat_p16 is not None:
                     p._cfhip_shadow = self.flat_p16[o:o + n].view(p.shape)
                     p._cfhip_shadow_version = None  # filled by refresh_shadow()
         self.refresh_shadow()
+
+    @staticmethod
+    def _fresh_guard(p: Tensor):
+        """Lazy zero-grad and gradients that arrive THROUGH AUTOGRAD (an op that was handed a slice / permutation of the
+        parameter returns its gradient instead of writing `.grad`): autograd ADDS to `.grad`, so the slot's stale values
+        must go first.  The tensor hook runs in front of the accumulation, only for such gradients (the direct-write
+        kernels return None to autograd), and clears the 'fresh' mark so that `finalize_grads()` keeps the result."""
+
+        def guard(grad: Tensor) -> None:
+            if getattr(p, "_cfhip_fresh", False):
+                if p.grad is not None:
+                    p.grad.zero_()
+                p._cfhip_fresh = False
+            return None
+
+        return guard
 
     def refresh_shadow(self) -> None:
         """bf16 shadow <- fp32 masters (after construction / load_state_dict)."""
@@ -75,8 +92,8 @@ class ParamArena:
         """Default: one memset over the gradient arena (autograd accumulates INTO `.grad`, so stale
         values must be gone).  `lazy=True` skips the memset and marks every gradient 'fresh' instead:
         the first HIP backward kernel that writes a parameter's gradient then OVERWRITES it and
-        whatever nobody wrote is zeroed by `finalize_grads()`.  Only valid when every parameter's
-        gradient is produced by the direct-write HIP backward kernels (true for the ViT modules)."""
+        whatever nobody wrote is zeroed by `finalize_grads()`.  Gradients that autograd accumulates itself are covered by
+        `_fresh_guard`."""
         if not lazy:
             self.flat_g.zero_()
         for p in self.params:

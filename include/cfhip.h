@@ -204,6 +204,12 @@ int cfhip_q_sample(const float* x, const float* noise, const int64_t* t, const f
                    const float* sqrt_1mac, void* out, int out_is_f32, int64_t B, int64_t inner, void* stream);
 int cfhip_mse_loss(const void* pred, const float* target, float* loss_sum, void* dpred, int64_t B, int64_t inner,
                    float grad_scale, void* stream);
+/* DDPMStep.loss_fn (models/cv/diffusion.py:44-94) for every objective it has: per_sample[b] (f32, must be zero on entry)
+ * += mean_inner f(pred - target), f = square (loss_type 0, "l2") or abs (1, "l1"); dpred (bf16, may be NULL) =
+ * weight[b] * f'(pred - target) / inner.  weight f32 [B] carries everything the reference multiplies a sample's loss by
+ * (l_simple_weight / exp(log_var[t]) + original_elbo_weight * lvlb_weights[t], over the batch size). */
+int cfhip_diffusion_loss(const void* pred, const float* target, const float* weight, float* per_sample, void* dpred,
+                         int64_t B, int64_t inner, int loss_type, void* stream);
 /* dst[b * dst_bs + i] = src[b * src_bs + i] (bf16, i < n, everything a multiple of 4 elements): channel concat /
  * split of NCHW tensors — torch.cat(dim=1) of the UNet skip connections (multimodal/diffusion/unet.py:311-316) */
 int cfhip_copy_strided_bf16(const void* src, void* dst, int64_t batch, int64_t n, int64_t src_batch_stride,
@@ -329,6 +335,17 @@ int cfhip_groupnorm_bwd(const void* dy, const void* x, int x_is_f32, const float
                         const float* beta, const float* mean, const float* rstd, void* dx,
                         float* dgamma_part, float* dbeta_part, float* dadd, int B, int C, int G, int inner,
                         int silu, void* stream);
+/* the same two kernels with ONE AFFINE PER SAMPLE: gamma / beta are f32 [B][C] when affine_batch_stride == C (0: the
+ * plain [C] form above).  `norm2(net) * (1 + scale) + shift` of the scale-shift residual block (convs/residual.py:
+ * 236-239) is GroupNorm with gamma_eff[b][c] = gamma[c] (1 + scale[b][c]), beta_eff[b][c] = beta[c] (1 + scale[b][c]) +
+ * shift[b][c]; bwd then leaves d gamma_eff / d beta_eff in dgamma_part / dbeta_part [B][C] (no reduction over B). */
+int cfhip_groupnorm_affine_fwd(const void* x, int x_is_f32, const float* add, const float* gamma, const float* beta,
+                               void* y, float* mean, float* rstd, int B, int C, int G, int inner, float eps,
+                               int silu, int affine_batch_stride, void* stream);
+int cfhip_groupnorm_affine_bwd(const void* dy, const void* x, int x_is_f32, const float* add, const float* gamma,
+                               const float* beta, const float* mean, const float* rstd, void* dx,
+                               float* dgamma_part, float* dbeta_part, float* dadd, int B, int C, int G, int inner,
+                               int silu, int affine_batch_stride, void* stream);
 int cfhip_silu_f32_fwd(const float* x, float* y, int64_t n, void* stream);
 int cfhip_silu_f32_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
 int cfhip_upsample2_fwd(const void* x, void* y, int64_t BC, int H, int W, void* stream);

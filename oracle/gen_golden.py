@@ -473,6 +473,153 @@ def gen_ddpm_schedule(ref) -> None:
                     noise=noise, t=t, x_t=x_t), os.path.join(OUT, "ddpm_schedule.pt"))
 
 
+def gen_unet_variants(ref) -> None:
+    """The UNet options beyond the zoo `diffusion/ddpm` configuration, from the reference's own classes:
+    `MultiHeadSpatialAttention` (attentions.py:373-460, both head layouts), the scale-shift residual block
+    (residual.py:236-239), and two small `UNetDiffuser`s — (a) pixel self attention + ResBlock resampling + scale-shift
+    norm + class labels, (b) spatial transformers with Linear projections + ControlNet residuals."""
+    import importlib
+
+    attn = importlib.import_module("cflearn.modules.core.attentions")
+    res = importlib.import_module("cflearn.modules.core.convs.residual")
+    unet = importlib.import_module("cflearn.modules.multimodal.diffusion.unet")
+
+    def perturb(m, std):
+        with torch.no_grad():
+            for p_ in m.parameters():
+                p_.add_(torch.randn_like(p_) * std)
+
+    out = {"mhsa": [], "unets": []}
+    for seed, kw in ((130, dict(num_heads=2)), (131, dict(num_heads=None, num_head_channels=16, split_qkv_before_heads=True))):
+        torch.manual_seed(seed)
+        m = attn.MultiHeadSpatialAttention(64, **kw)
+        perturb(m, 0.05)
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        x = torch.randn(2, 64, 6, 6, requires_grad=True)
+        y = m(x)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        _check(f"mhsa {kw}", UO.multi_head_spatial_attention(x.detach(), sd, m.num_heads, m.split_qkv_before_heads), y.detach(), atol=5e-5)
+        out["mhsa"].append(dict(cfg=dict(in_channels=64, **kw), sd=sd, x=x.detach(), y=y.detach(), gy=gy, gx=x.grad.clone(),
+                                grads={k: p_.grad.clone() for k, p_ in m.named_parameters()}))
+    torch.manual_seed(132)
+    m = res.ResidualBlockWithTimeEmbedding(32, 64, time_embedding_channels=128, use_scale_shift_norm=True)
+    perturb(m, 0.05)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 32, 8, 8, requires_grad=True)
+    t = torch.randn(2, 128, requires_grad=True)
+    y = m(x, t)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    _check("scale-shift resblock", UO.residual_block(x.detach(), t.detach(), sd, scale_shift=True), y.detach(), atol=5e-5)
+    out["scale_shift"] = dict(cfg=dict(in_channels=32, out_channels=64, time_embedding_channels=128, use_scale_shift_norm=True),
+                              sd=sd, x=x.detach(), t=t.detach(), y=y.detach(), gy=gy, gx=x.grad.clone(), gt=t.grad.clone(),
+                              grads={k: p_.grad.clone() for k, p_ in m.named_parameters()})
+    cfgs = [
+        dict(in_channels=3, out_channels=3, num_heads=2, use_spatial_transformer=False, start_channels=32, num_res_blocks=1,
+             attention_downsample_rates=(1, 2), channel_multipliers=(1, 2), resample_with_resblock=True,
+             use_scale_shift_norm=True, num_classes=5),
+        dict(in_channels=3, out_channels=3, num_heads=4, use_spatial_transformer=True, num_transformer_layers=1,
+             context_dim=48, start_channels=32, num_res_blocks=1, attention_downsample_rates=(1, 2),
+             channel_multipliers=(1, 2), use_linear_in_transformer=True),
+    ]
+    for i, cfg in enumerate(cfgs):
+        torch.manual_seed(133 + i)
+        m = unet.UNetDiffuser(**cfg)
+        perturb(m, 0.03)
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        x = torch.randn(2, 3, 16, 16)
+        t = torch.tensor([3, 700])
+        noise = torch.randn(2, 3, 16, 16)
+        kw = {}
+        if cfg.get("num_classes"):
+            kw["labels"] = torch.tensor([4, 1])
+        if cfg["use_spatial_transformer"]:
+            kw["context"] = torch.randn(2, 5, 48)
+            # ControlNet residuals: one per skip connection + one for the middle block, popped from the end (unet.py:311-318)
+            shapes = []
+            net = x
+            probe = []
+            hooks = [blk.register_forward_hook(lambda _m, _i, o: probe.append(o.shape)) for blk in m.input_blocks]
+            m(x, timesteps=t, **{k: v for k, v in kw.items()})
+            for h_ in hooks:
+                h_.remove()
+            shapes = list(probe) + [probe[-1]]
+            kw["control"] = [torch.randn(*s_) * 0.1 for s_ in shapes]
+        y = m(x, timesteps=t, **{k: (list(v) if k == "control" else v) for k, v in kw.items()})
+        loss = torch.nn.functional.mse_loss(y, noise)
+        loss.backward()
+        out["unets"].append(dict(cfg=cfg, sd=sd, x=x, timesteps=t, noise=noise, kw=kw, y=y.detach(), loss=loss.detach(),
+                                 grads={k: p_.grad.clone().half() for k, p_ in m.named_parameters()}))
+    torch.save(out, os.path.join(OUT, "unet_variants.pt"))
+
+
+def gen_ddpm_objectives(ref) -> None:
+    """`DDPMStep.loss_fn` (models/cv/diffusion.py:44-94) and `DDPM._register_noise_schedule` (ddpm.py:599-679) run as the
+    reference's own code on stand-in objects that carry exactly the attributes they read: every parameterization / loss
+    type / log-variance / ELBO-weight combination on one seeded batch, with d loss / d prediction and d loss / d log_var
+    from autograd."""
+    import types
+
+    from refharness import import_cflearn
+
+    import_cflearn()
+    ddpm_mod = sys.modules["cflearn.modules.multimodal.diffusion.ddpm"]
+    step_mod = sys.modules["cflearn.models.cv.diffusion"]
+    DDPM = ddpm_mod.DDPM
+
+    class _Tables(torch.nn.Module):
+        def __init__(self, parameterization, v_posterior):
+            super().__init__()
+            self.parameterization, self.v_posterior = parameterization, v_posterior
+
+    def tables(parameterization, schedule, v_posterior=0.0):
+        m = _Tables(parameterization, v_posterior)
+        DDPM._register_noise_schedule(m, 1000, None, schedule, 8.5e-4, 1.2e-2, 8.0e-3)
+        return m
+
+    torch.manual_seed(140)
+    x = torch.randn(4, 3, 8, 8)
+    noise = torch.randn(4, 3, 8, 8)
+    t = torch.tensor([0, 17, 500, 999])
+    cases = []
+    for (par, sched, lt, lv_init, learn, lsw, elbo, vp) in [
+        ("eps", "linear", "l2", 0.0, False, 1.0, 0.0, 0.0),
+        ("x0", "linear", "l2", 0.3, False, 1.0, 0.0, 0.0),
+        ("v", "cosine", "l2", 0.0, False, 0.7, 0.0, 0.0),
+        ("eps", "cosine", "l1", -0.4, True, 1.0, 0.0, 0.0),
+        ("eps", "linear", "l2", 0.2, True, 0.9, 1.0e-3, 0.5),
+        ("x0", "sqrt_linear", "l1", 0.0, False, 1.0, 0.5, 0.0),
+    ]:
+        tb = tables(par, sched, vp)
+        log_var = torch.full((1000,), lv_init)
+        if learn:
+            log_var = torch.nn.Parameter(log_var + torch.randn(1000) * 0.1)
+        ddpm = types.SimpleNamespace(parameterization=par, noise_key=DDPM.noise_key, timesteps_key=DDPM.timesteps_key,
+                                     log_var=log_var, learn_log_var=learn, lvlb_weights=tb.lvlb_weights,
+                                     sqrt_alphas_cumprod=tb.sqrt_alphas_cumprod,
+                                     sqrt_one_minus_alphas_cumprod=tb.sqrt_one_minus_alphas_cumprod)
+        step = step_mod.DDPMStep("learnable")
+        step.setup(loss_type=lt, l_simple_weight=lsw, original_elbo_weight=elbo)
+        pred = (torch.randn(4, 3, 8, 8) * 0.7).requires_grad_(True)
+        res_ = step.loss_fn(types.SimpleNamespace(m=ddpm), None, {"input": x},
+                            {"predictions": pred, DDPM.noise_key: noise, DDPM.timesteps_key: t})
+        res_.loss.backward()
+        tbl = dict(sqrt_alphas_cumprod=tb.sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod=tb.sqrt_one_minus_alphas_cumprod,
+                   lvlb_weights=tb.lvlb_weights)
+        mine = UO.ddpm_objective(pred.detach(), x, noise, t, tbl, parameterization=par, loss_type=lt,
+                                 log_var=log_var.detach(), l_simple_weight=lsw, original_elbo_weight=elbo)
+        _check(f"ddpm objective {par}/{sched}/{lt}", mine, res_.loss.detach(), atol=1e-6)
+        cases.append(dict(parameterization=par, schedule=sched, loss_type=lt, log_var_init=lv_init, learn_log_var=learn,
+                          l_simple_weight=lsw, original_elbo_weight=elbo, v_posterior=vp, log_var=log_var.detach().clone(),
+                          pred=pred.detach(), loss=res_.loss.detach(), losses=dict(res_.losses), dpred=pred.grad.clone(),
+                          dlog_var=None if not learn else log_var.grad.clone(), betas=tb.betas.clone(),
+                          lvlb_weights=tb.lvlb_weights.clone(), posterior_variance=tb.posterior_variance.clone(),
+                          sqrt_alphas_cumprod=tb.sqrt_alphas_cumprod.clone(),
+                          sqrt_one_minus_alphas_cumprod=tb.sqrt_one_minus_alphas_cumprod.clone()))
+    torch.save(dict(x=x, noise=noise, t=t, cases=cases), os.path.join(OUT, "ddpm_objectives.pt"))
+
+
 def gen_ml_encoder(ref) -> None:
     """The reference's own `ml.encoder` + `CommonMLModel.encode`.  Two cases: mixed one-hot / embedding columns with
     in-range categories, and all-embedding columns with out-of-bound categories (the reference imputes out-of-bound
@@ -588,7 +735,7 @@ def main() -> None:
     only = sys.argv[1:]
     for fn in (gen_linear, gen_layernorm, gen_sdp, gen_attention, gen_feedforward, gen_vit, gen_conv2d,
                gen_batchnorm, gen_mnist_clf, gen_fcnn, gen_clip, gen_resblock, gen_spatial_transformer, gen_unet, gen_ddpm_schedule,
-               gen_ml_encoder, gen_stochastic, gen_postnorm_interp):
+               gen_ml_encoder, gen_stochastic, gen_postnorm_interp, gen_unet_variants, gen_ddpm_objectives):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

@@ -53,8 +53,8 @@ def timestep_embedding(t: Tensor, dim: int, max_period: float = 10000.0) -> Tens
 
 
 def residual_block(x: Tensor, t: Optional[Tensor], sd: StateDict, prefix: str = "", eps: float = 1.0e-6,
-                   resample: Optional[str] = None) -> Tensor:
-    """ResidualBlockWithTimeEmbedding._forward without scale-shift norm / dropout"""
+                   resample: Optional[str] = None, scale_shift: bool = False) -> Tensor:
+    """ResidualBlockWithTimeEmbedding._forward (dropout 0); `scale_shift`: residual.py:236-239"""
     inp = x
     net = silu(group_norm(x, sd[prefix + "norm1.weight"], sd[prefix + "norm1.bias"], 32, eps))
     if resample == "up":
@@ -67,6 +67,11 @@ def residual_block(x: Tensor, t: Optional[Tensor], sd: StateDict, prefix: str = 
         inp = CO.conv2d(inp, w, sd[prefix + "shortcut.bias"], 1, w.shape[-1] // 2)
     if t is not None:
         tt = silu(t) @ sd[prefix + "time_embedding.weight"].t() + sd[prefix + "time_embedding.bias"]
+        if scale_shift:
+            scale, shift = torch.chunk(tt[:, :, None, None], 2, dim=1)
+            net = group_norm(net, sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"], 32, eps) * (1.0 + scale) + shift
+            net = CO.conv2d(silu(net), sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], 1, 1)
+            return inp + net
         net = net + tt[:, :, None, None]
     net = silu(group_norm(net, sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"], 32, eps))
     net = CO.conv2d(net, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], 1, 1)
@@ -119,6 +124,47 @@ def spatial_transformer(x: Tensor, context: Optional[Tensor], sd: StateDict, num
     wo = sd[prefix + "from_latent.weight"]
     net = net @ wo.reshape(wo.shape[0], -1).t() + sd[prefix + "from_latent.bias"]
     return x + net.permute(0, 2, 1).reshape(b, c, h, w)
+
+
+def multi_head_spatial_attention(x: Tensor, sd: StateDict, num_heads: int, split_qkv_before_heads: bool = False,
+                                 prefix: str = "") -> Tensor:
+    """MultiHeadSpatialAttention._forward (attentions.py:413-460): GroupNorm(32, eps 1e-5) -> conv1d 1x1 to 3C -> heads
+    (q | k | v chunks of the 3C channels first, or per head [q | k | v]) -> softmax((q s)^T (k s)) v with s = hd^-1/4 ->
+    conv1d 1x1 -> + input"""
+    b, c, h, w = x.shape
+    area, hd = h * w, c // num_heads
+    net = group_norm(x, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], 32, 1.0e-5).reshape(b, c, area)
+    qkv = torch.einsum("oc,bct->bot", sd[prefix + "to_qkv.weight"][:, :, 0], net) + sd[prefix + "to_qkv.bias"][None, :, None]
+    if split_qkv_before_heads:
+        q, k, v = (z.reshape(b * num_heads, hd, area) for z in qkv.chunk(3, dim=1))
+    else:
+        q, k, v = qkv.reshape(b * num_heads, hd * 3, area).split(hd, dim=1)
+    scale = 1.0 / math.sqrt(math.sqrt(hd))
+    prob = torch.softmax(torch.einsum("bct,bcs->bts", q * scale, k * scale), dim=-1)
+    out = torch.einsum("bts,bcs->bct", prob, v).reshape(b, c, area)
+    out = torch.einsum("oc,bct->bot", sd[prefix + "to_out.weight"][:, :, 0], out) + sd[prefix + "to_out.bias"][None, :, None]
+    return (x.reshape(b, c, area) + out).reshape(b, c, h, w)
+
+
+def ddpm_objective(pred: Tensor, x: Tensor, noise: Tensor, t: Tensor, tables: Dict[str, Tensor], *,
+                   parameterization: str = "eps", loss_type: str = "l2", log_var: Optional[Tensor] = None,
+                   l_simple_weight: float = 1.0, original_elbo_weight: float = 0.0) -> Tensor:
+    """DDPMStep.loss_fn (models/cv/diffusion.py:44-94): the scalar the trainer differentiates"""
+    shape = [-1] + [1] * (x.dim() - 1)
+    if parameterization == "eps":
+        target = noise
+    elif parameterization == "x0":
+        target = x
+    else:
+        target = (tables["sqrt_alphas_cumprod"][t].view(shape) * noise
+                  - tables["sqrt_one_minus_alphas_cumprod"][t].view(shape) * x)
+    d = pred - target
+    loss = (d.abs() if loss_type == "l1" else d * d).mean(dim=(1, 2, 3))
+    lv = torch.zeros_like(loss) if log_var is None else log_var[t]
+    total = l_simple_weight * (loss / torch.exp(lv) + lv).mean()
+    if original_elbo_weight > 0:
+        total = total + original_elbo_weight * (tables["lvlb_weights"][t] * loss).mean()
+    return total
 
 
 # ---- UNetDiffuser (modules/multimodal/diffusion/unet.py:76-322), use_spatial_transformer=True ----------------------

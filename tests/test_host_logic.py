@@ -268,3 +268,31 @@ def test_fused_adam_behind_the_torch_optimizer_interface():
     assert sd["step"] == opt.fused.step_count and sd["exp_avg"].shape == opt.arena.flat_p.shape
     with pytest.raises(ValueError, match="one parameter group"):
         FusedAdamOptimizer([dict(params=[torch.nn.Parameter(torch.zeros(2))]), dict(params=[torch.nn.Parameter(torch.zeros(2))])])
+
+
+def test_lazy_zero_grad_with_gradients_that_arrive_through_autograd():
+    """`ParamArena.zero_grad(lazy=True)` marks every slot 'fresh' instead of clearing it.  A gradient that autograd
+    accumulates itself (the op saw a slice of the parameter) must neither be added onto the previous step's values nor be
+    wiped by `finalize_grads()`: the arena's tensor hook clears the slot in front of the accumulation."""
+    from cflearn_amd.functional import write_param_grad
+    from cflearn_amd.optim import ParamArena
+
+    torch.manual_seed(0)
+    a = torch.nn.Parameter(torch.randn(6, 4))   # gets its gradient through autograd (sliced use)
+    b = torch.nn.Parameter(torch.randn(5))      # direct-written
+    c = torch.nn.Parameter(torch.randn(3))      # unused: must end up zero
+    arena = ParamArena([a, b, c], with_shadow=False)
+    for step in range(3):
+        arena.zero_grad(lazy=True)
+        x = torch.randn(4)
+        loss = (a[1:4] @ x).sum() * (step + 1) + (a[4:] ** 2).sum()
+        loss.backward()
+        write_param_grad(b, lambda out, acc: out.add_(torch.ones(5)) if acc else out.copy_(torch.full((5,), 2.0 + step)))
+        arena.finalize_grads()
+        want = torch.zeros(6, 4)
+        want[1:4] = x * (step + 1)
+        want[4:] = 2 * a.detach()[4:]
+        assert torch.allclose(a.grad, want), step
+        assert torch.equal(b.grad, torch.full((5,), 2.0 + step))
+        assert torch.equal(c.grad, torch.zeros(3))
+        assert a.grad.data_ptr() == arena.grad_view(a).data_ptr()

@@ -289,3 +289,36 @@ def test_ml_and_stochastic_oracles_match_reference_fixtures(golden):
     for g in golden("stochastic.pt").values():
         assert torch.equal(MO.dropout(g["x"], g["mask"], g["p"]), g["y"])
         assert torch.equal(MO.drop_path(g["xb"], g["mb"], 1.0 - g["rate"]), g["yb"])
+
+
+def test_unet_variant_oracles_match_the_reference_fixtures(golden):
+    """pins of the restatements added for the non-default UNet options (fixtures made by the reference's own classes)"""
+    import unet_oracle as UO
+
+    g = golden("unet_variants.pt")
+    for c in g["mhsa"]:
+        heads = c["cfg"].get("num_heads") or 64 // c["cfg"]["num_head_channels"]
+        y = UO.multi_head_spatial_attention(c["x"], c["sd"], heads, c["cfg"].get("split_qkv_before_heads", False))
+        assert (y - c["y"]).abs().max() <= 5e-5 * c["y"].abs().max()
+    c = g["scale_shift"]
+    y = UO.residual_block(c["x"], c["t"], c["sd"], scale_shift=True)
+    assert (y - c["y"]).abs().max() <= 5e-5 * c["y"].abs().max()
+
+
+def test_ddpm_objective_oracle_and_noise_schedule_tables(golden):
+    """`oracle.unet_oracle.ddpm_objective` == the reference's DDPMStep.loss_fn on the fixture; the host-side schedule of
+    the package (`diffusion.NoiseSchedule`: numpy float64 -> fp32 tables, no GPU involved) reproduces the reference's
+    betas / cumulative products / posterior variance / lvlb weights bit for bit for every schedule in the fixture"""
+    import unet_oracle as UO
+    from cflearn_amd.diffusion import NoiseSchedule
+
+    g = golden("ddpm_objectives.pt")
+    for c in g["cases"]:
+        tbl = {k: c[k] for k in ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "lvlb_weights")}
+        got = UO.ddpm_objective(c["pred"], g["x"], g["noise"], g["t"], tbl, parameterization=c["parameterization"],
+                                loss_type=c["loss_type"], log_var=c["log_var"], l_simple_weight=c["l_simple_weight"],
+                                original_elbo_weight=c["original_elbo_weight"])
+        assert abs(got.item() - c["loss"].item()) <= 1e-6 * max(1.0, abs(c["loss"].item()))
+        s = NoiseSchedule(1000, c["schedule"], parameterization=c["parameterization"], v_posterior=c["v_posterior"])
+        for name in ("betas", "lvlb_weights", "posterior_variance", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod"):
+            assert torch.equal(getattr(s, name), c[name]), (c["schedule"], c["parameterization"], name)
