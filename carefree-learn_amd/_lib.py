@@ -56,6 +56,18 @@ SIGNATURES = {
         [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64,
          c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_int, _P],
     ),
+    "cfhip_attn_fwd_dropout": (
+        c_int,
+        [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
+         c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_float, c_uint64, c_uint64, _P],
+    ),
+    "cfhip_attn_bwd_dropout": (
+        c_int,
+        [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64,
+         c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_int, c_float, c_uint64,
+         c_uint64, _P],
+    ),
+    "cfhip_attn_dropout_mask": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_uint64, c_uint64, _P]),
     "cfhip_im2row": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cfhip_assemble_tokens_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "cfhip_assemble_tokens_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

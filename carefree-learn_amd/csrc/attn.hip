@@ -38,6 +38,14 @@ struct AttnParams {
   int causal;
   int dh;           // head_dim of the general kernels (the resident fast kernels are head_dim 64 only)
   int delta_ready;  // dK/dV pass: p.delta was already written by the dQ pass of the same call
+  // dropout on the attention probabilities (general kernels, DROP instantiations): keep(b, h, i, j) = byte (j & 3) of word
+  // (i & 3) of philox(drop_offset + ((b H + h) drop_bq + (i >> 2)) drop_bk + (j >> 2), drop_seed) >= drop_thresh, i.e. one
+  // Philox call per 4 x 4 block of the score matrix, the same bits whichever way a kernel walks it; kept values are
+  // scaled by drop_scale = 1 / (1 - drop_thresh / 256)
+  unsigned long long drop_seed, drop_offset;
+  int drop_bq, drop_bk;
+  unsigned drop_thresh;
+  float drop_scale;
 #ifdef CFHIP_ABLATE
   int ablate;       // benchmarking only (forward): bit0 skip the K/V DMA, bit1 skip the tile loop, bit2 skip stores
 #endif
@@ -122,6 +130,16 @@ __device__ __forceinline__ bool keep_at(const AttnParams& p, int b, int h, int i
   if (p.causal && j > i) return false;
   if (p.mask != nullptr) return p.mask[(long)b * p.ms_b + (long)h * p.ms_h + (long)i * p.ms_q + j] != 0;
   return true;
+}
+
+__device__ __forceinline__ Philox drop_block(const AttnParams& p, int b, int h, int block_row, int block_col) {
+  const unsigned long long ctr =
+      p.drop_offset + ((unsigned long long)(b * p.H + h) * p.drop_bq + block_row) * p.drop_bk + block_col;
+  return philox4x32_10(ctr, p.drop_seed);
+}
+__device__ __forceinline__ unsigned pick_word(const Philox& r, int w) {  // r.c[w & 3] without a private-memory array
+  const unsigned lo = (w & 1) ? r.c[1] : r.c[0], hi = (w & 1) ? r.c[3] : r.c[2];
+  return (w & 2) ? hi : lo;
 }
 
 __device__ __forceinline__ float group_max(float v) {  // across the 4 lanes sharing l & 15
@@ -493,7 +511,7 @@ __device__ __forceinline__ bf16x8 frag_global_dh(const bf16_t* base, long stride
   return r;
 }
 
-template <int NH, bool PLAIN>
+template <int NH, bool PLAIN, bool DROP = false>
 __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_fwd_kernel(AttnParams p) {
   using G = Gen<NH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -574,6 +592,14 @@ __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_fwd_kernel(Attn
     }
     l = l * alpha + group_sum(ls);
     m = m_new;
+    if (DROP) {  // the row sum above is the softmax denominator: dropout acts on the normalised probabilities
+#pragma unroll
+      for (int jt = 0; jt < 2 * G::CHB; ++jt) {
+        const unsigned w = pick_word(drop_block(p, b, h, qi >> 2, (kv0 >> 2) + jt * 4 + g), qi);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[jt][r] = ((w >> (8 * r)) & 255u) >= p.drop_thresh ? st[jt][r] : 0.f;
+      }
+    }
 #pragma unroll
     for (int dt = 0; dt < 4 * NH; ++dt) ot[dt] *= alpha;
 #pragma unroll
@@ -587,7 +613,7 @@ __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_fwd_kernel(Attn
     }
   }
   if (active && qi < p.Tq) {
-    const float inv = 1.0f / l;
+    const float inv = (DROP ? p.drop_scale : 1.0f) / l;
     bf16_t* orow = p.o + (long)b * p.o_sb + (long)qi * p.o_st + h * dh;
 #pragma unroll
     for (int dt = 0; dt < 4 * NH; ++dt) {
@@ -600,7 +626,7 @@ __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_fwd_kernel(Attn
   }
 }
 
-template <int NH, bool PLAIN>
+template <int NH, bool PLAIN, bool DROP = false>
 __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_bwd_dq_kernel(AttnParams p) {
   using G = Gen<NH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -660,11 +686,15 @@ __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_bwd_dq_kernel(A
           dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vs + (ks >> 1) * G::HALF_BYTES, jt * 16, ks & 1, lane),
                                                        dof[ks], dp, 0, 0, 0);
         }
+        unsigned w = 0u;
+        if (DROP) w = pick_word(drop_block(p, b, h, qi >> 2, (kv0 >> 2) + jt * 4 + g), qi);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float pr = __builtin_amdgcn_exp2f(sc[r] * sl2 - lse2);
           if (!PLAIN) pr = keep_at(p, b, h, qvalid ? qi : p.Tq - 1, kv0 + jt * 16 + 4 * g + r) ? pr : 0.f;
-          ds[t][r] = pr * (dp[r] - delta);
+          float dpr = dp[r];  // d loss / d (dropped probability)
+          if (DROP) dpr = ((w >> (8 * r)) & 255u) >= p.drop_thresh ? dpr * p.drop_scale : 0.f;
+          ds[t][r] = pr * (dpr - delta);
         }
       }
       const bf16x8 dsp = pack8(ds[0], ds[1]);
@@ -686,7 +716,7 @@ __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_bwd_dq_kernel(A
   }
 }
 
-template <int NH, bool PLAIN>
+template <int NH, bool PLAIN, bool DROP = false>
 __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_bwd_dkv_kernel(AttnParams p) {
   using G = Gen<NH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -762,6 +792,8 @@ __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_bwd_dkv_kernel(
         }
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + it * 16 + 4 * g);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + it * 16 + 4 * g);
+        Philox rb = {{0u, 0u, 0u, 0u}};
+        if (DROP) rb = drop_block(p, b, h, (q0 >> 2) + it * 4 + g, kj >> 2);  // rows 4g .. 4g + 3 = words 0 .. 3
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float pr = __builtin_amdgcn_exp2f(sc[r] * sl2 - l4[r]);
@@ -769,8 +801,10 @@ __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_bwd_dkv_kernel(
             const int qi = q0 + it * 16 + 4 * g + r;
             pr = (qi < p.Tq && keep_at(p, b, h, qi, kj)) ? pr : 0.f;
           }
-          pp[t][r] = pr;
-          ds[t][r] = pr * (dp[r] - d4[r]);
+          float keep_scale = 1.0f;
+          if (DROP) keep_scale = ((rb.c[r] >> (8 * (kj & 3))) & 255u) >= p.drop_thresh ? p.drop_scale : 0.f;
+          pp[t][r] = pr * keep_scale;
+          ds[t][r] = pr * (dp[r] * keep_scale - d4[r]);
         }
       }
       const bf16x8 ppk = pack8(pp[0], pp[1]);
@@ -834,6 +868,47 @@ int set_lds(K kernel, size_t bytes, const char* who) {
   return CFHIP_OK;
 }
 
+template <typename K>
+int set_lds(K kernel, size_t bytes, const char* who);
+
+// dropout variants: same geometry, DROP instantiations
+template <int NH>
+int launch_gen_fwd_drop(const AttnParams& p, bool plain, hipStream_t s) {
+  dim3 grid((p.Tq + 127) / 128, p.H, p.B);
+  const size_t lds = (size_t)2 * Gen<NH>::OPER_BYTES;
+  int rc = plain ? set_lds(attn_gen_fwd_kernel<NH, true, true>, lds, "attn_fwd") : set_lds(attn_gen_fwd_kernel<NH, false, true>, lds, "attn_fwd");
+  if (rc != CFHIP_OK) return rc;
+  if (plain) hipLaunchKernelGGL((attn_gen_fwd_kernel<NH, true, true>), grid, dim3(512), lds, s, p);
+  else hipLaunchKernelGGL((attn_gen_fwd_kernel<NH, false, true>), grid, dim3(512), lds, s, p);
+  CFHIP_CHECK_LAUNCH("attn_gen_fwd(dropout)");
+  return CFHIP_OK;
+}
+
+template <int NH>
+int launch_gen_bwd_drop(const AttnParams& p, bool plain, int parts, hipStream_t s) {
+  if (parts & 1) {
+    dim3 grid((p.Tq + 127) / 128, p.H, p.B);
+    const size_t lds = (size_t)2 * Gen<NH>::OPER_BYTES;
+    int rc = plain ? set_lds(attn_gen_bwd_dq_kernel<NH, true, true>, lds, "attn_bwd_dq")
+                   : set_lds(attn_gen_bwd_dq_kernel<NH, false, true>, lds, "attn_bwd_dq");
+    if (rc != CFHIP_OK) return rc;
+    if (plain) hipLaunchKernelGGL((attn_gen_bwd_dq_kernel<NH, true, true>), grid, dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((attn_gen_bwd_dq_kernel<NH, false, true>), grid, dim3(512), lds, s, p);
+    CFHIP_CHECK_LAUNCH("attn_gen_bwd_dq(dropout)");
+  }
+  if (parts & 2) {
+    dim3 grid((p.Tk + 127) / 128, p.H, p.B);
+    const size_t lds = (size_t)2 * Gen<NH>::OPER_BYTES + (size_t)2 * Gen<NH>::CH * sizeof(float);
+    int rc = plain ? set_lds(attn_gen_bwd_dkv_kernel<NH, true, true>, lds, "attn_bwd_dkv")
+                   : set_lds(attn_gen_bwd_dkv_kernel<NH, false, true>, lds, "attn_bwd_dkv");
+    if (rc != CFHIP_OK) return rc;
+    if (plain) hipLaunchKernelGGL((attn_gen_bwd_dkv_kernel<NH, true, true>), grid, dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((attn_gen_bwd_dkv_kernel<NH, false, true>), grid, dim3(512), lds, s, p);
+    CFHIP_CHECK_LAUNCH("attn_gen_bwd_dkv(dropout)");
+  }
+  return CFHIP_OK;
+}
+
 template <int NH>
 int launch_gen_fwd(const AttnParams& p, bool plain, hipStream_t s) {
   dim3 grid((p.Tq + 127) / 128, p.H, p.B);
@@ -871,6 +946,21 @@ int launch_gen_bwd(const AttnParams& p, bool plain, int parts, hipStream_t s) {
   return CFHIP_OK;
 }
 
+// fills the dropout fields; false = no dropout (p <= 0).  The probability is quantised to 1/256 (as flash attention
+// implementations do): thresh = round(256 p), kept values are scaled by 1 / (1 - thresh / 256).
+bool set_dropout(AttnParams& p, float dropout_p, uint64_t seed, uint64_t offset) {
+  if (!(dropout_p > 0.f)) return false;
+  int t = (int)lrintf(dropout_p * 256.0f);
+  t = t < 1 ? 1 : (t > 255 ? 255 : t);
+  p.drop_thresh = (unsigned)t;
+  p.drop_scale = 256.0f / (float)(256 - t);
+  p.drop_seed = seed;
+  p.drop_offset = offset;
+  p.drop_bq = (p.Tq + 3) / 4;
+  p.drop_bk = (p.Tk + 3) / 4;
+  return true;
+}
+
 int check_head_dim(const char* who, int head_dim) {
   CFHIP_REQUIRE(head_dim >= 8 && head_dim <= 192 && head_dim % 8 == 0,
                 "%s: head_dim %d is not a multiple of 8 in [8, 192]", who, head_dim);
@@ -890,7 +980,8 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
                          const uint8_t* mask, int B, int H, int Tq, int Tk, int head_dim, int64_t q_stride_b,
                          int64_t q_stride_t, int64_t kv_stride_b, int64_t kv_stride_t,
                          int64_t o_stride_b, int64_t o_stride_t, int64_t ms_b, int64_t ms_h,
-                         int64_t ms_q, float scale, int causal, void* stream) {
+                         int64_t ms_q, float scale, int causal, void* stream, float dropout_p = 0.f,
+                         uint64_t seed = 0, uint64_t offset = 0) {
   int rc = check_head_dim("attn_fwd", head_dim);
   if (rc != CFHIP_OK) return rc;
   rc = check_common("attn_fwd", q, k, v, B, H, Tq, Tk, q_stride_b, q_stride_t, kv_stride_b,
@@ -917,6 +1008,13 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
   const size_t lds = (size_t)2 * nb * 32 * 128;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bool plain = mask == nullptr && !causal;
+  if (set_dropout(p, dropout_p, seed, offset)) {  // dropout on the probabilities: the general kernels' DROP forms
+    switch ((head_dim + 63) / 64) {
+      case 1: return launch_gen_fwd_drop<1>(p, plain, s);
+      case 2: return launch_gen_fwd_drop<2>(p, plain, s);
+      default: return launch_gen_fwd_drop<3>(p, plain, s);
+    }
+  }
   if (head_dim != CFHIP_ATTN_HEAD_DIM || Tq > CFHIP_ATTN_MAX_T || Tk > CFHIP_ATTN_MAX_T) {
     // general form: chunked K / V with online softmax, head_dim as zero-padded 64-column halves
     switch ((head_dim + 63) / 64) {
@@ -963,7 +1061,8 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
                          void* dv, int B, int H, int Tq, int Tk, int head_dim, int64_t q_stride_b,
                          int64_t q_stride_t, int64_t kv_stride_b, int64_t kv_stride_t,
                          int64_t o_stride_b, int64_t o_stride_t, int64_t ms_b, int64_t ms_h,
-                         int64_t ms_q, float scale, int causal, int parts, void* stream) {
+                         int64_t ms_q, float scale, int causal, int parts, void* stream, float dropout_p = 0.f,
+                         uint64_t seed = 0, uint64_t offset = 0) {
   int rc = check_head_dim("attn_bwd", head_dim);
   if (rc != CFHIP_OK) return rc;
   rc = check_common("attn_bwd", q, k, v, B, H, Tq, Tk, q_stride_b, q_stride_t, kv_stride_b,
@@ -991,6 +1090,13 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
   p.dh = head_dim;
   const bool plain = mask == nullptr && !causal;
   CFHIP_REQUIRE((parts & 3) != 0, "attn_bwd: parts must select the dQ pass (1), the dK/dV pass (2) or both (3)");
+  if (set_dropout(p, dropout_p, seed, offset)) {
+    switch ((head_dim + 63) / 64) {
+      case 1: return launch_gen_bwd_drop<1>(p, plain, parts, s);
+      case 2: return launch_gen_bwd_drop<2>(p, plain, parts, s);
+      default: return launch_gen_bwd_drop<3>(p, plain, parts, s);
+    }
+  }
   if (head_dim != CFHIP_ATTN_HEAD_DIM || Tq > CFHIP_ATTN_MAX_T || Tk > CFHIP_ATTN_MAX_T) {  // general form
     switch ((head_dim + 63) / 64) {
       case 1: return launch_gen_bwd<1>(p, plain, parts, s);
@@ -1044,4 +1150,58 @@ extern "C" int cfhip_attn_bwd_dh(const void* q, const void* k, const void* v, co
                                  int64_t ms_q, float scale, int causal, int parts, void* stream) {
   return attn_bwd_impl(q, k, v, o, d_o, lse, delta, mask, dq, dk, dv, B, H, Tq, Tk, head_dim, q_stride_b, q_stride_t,
                        kv_stride_b, kv_stride_t, o_stride_b, o_stride_t, ms_b, ms_h, ms_q, scale, causal, parts, stream);
+}
+
+extern "C" int cfhip_attn_fwd_dropout(const void* q, const void* k, const void* v, void* o, float* lse,
+                                      const uint8_t* mask, int B, int H, int Tq, int Tk, int head_dim,
+                                      int64_t q_stride_b, int64_t q_stride_t, int64_t kv_stride_b,
+                                      int64_t kv_stride_t, int64_t o_stride_b, int64_t o_stride_t, int64_t ms_b,
+                                      int64_t ms_h, int64_t ms_q, float scale, int causal, float dropout_p,
+                                      uint64_t seed, uint64_t offset, void* stream) {
+  CFHIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "attn_fwd_dropout: p = %f is not in [0, 1)", (double)dropout_p);
+  return attn_fwd_impl(q, k, v, o, lse, mask, B, H, Tq, Tk, head_dim, q_stride_b, q_stride_t, kv_stride_b,
+                       kv_stride_t, o_stride_b, o_stride_t, ms_b, ms_h, ms_q, scale, causal, stream, dropout_p, seed, offset);
+}
+
+extern "C" int cfhip_attn_bwd_dropout(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                      const float* lse, float* delta, const uint8_t* mask, void* dq, void* dk,
+                                      void* dv, int B, int H, int Tq, int Tk, int head_dim, int64_t q_stride_b,
+                                      int64_t q_stride_t, int64_t kv_stride_b, int64_t kv_stride_t,
+                                      int64_t o_stride_b, int64_t o_stride_t, int64_t ms_b, int64_t ms_h,
+                                      int64_t ms_q, float scale, int causal, int parts, float dropout_p,
+                                      uint64_t seed, uint64_t offset, void* stream) {
+  CFHIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "attn_bwd_dropout: p = %f is not in [0, 1)", (double)dropout_p);
+  return attn_bwd_impl(q, k, v, o, d_o, lse, delta, mask, dq, dk, dv, B, H, Tq, Tk, head_dim, q_stride_b, q_stride_t,
+                       kv_stride_b, kv_stride_t, o_stride_b, o_stride_t, ms_b, ms_h, ms_q, scale, causal, parts, stream,
+                       dropout_p, seed, offset);
+}
+
+/* the keep mask the DROP kernels use, one byte per (b, h, i, j): for tests and for callers that need the mask itself */
+namespace {
+__global__ void attn_dropout_mask_kernel(AttnParams p, unsigned char* out) {
+  const long total = (long)p.B * p.H * p.Tq * p.Tk;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % p.Tk);
+    long t = idx / p.Tk;
+    const int i = (int)(t % p.Tq);
+    t /= p.Tq;
+    const int h = (int)(t % p.H), b = (int)(t / p.H);
+    const unsigned w = pick_word(drop_block(p, b, h, i >> 2, j >> 2), i);
+    out[idx] = ((w >> (8 * (j & 3))) & 255u) >= p.drop_thresh ? 1 : 0;
+  }
+}
+}  // namespace
+
+extern "C" int cfhip_attn_dropout_mask(void* mask_out, int B, int H, int Tq, int Tk, float dropout_p, uint64_t seed,
+                                       uint64_t offset, void* stream) {
+  CFHIP_REQUIRE(mask_out && B > 0 && H > 0 && Tq > 0 && Tk > 0, "attn_dropout_mask: bad arguments");
+  CFHIP_REQUIRE(dropout_p > 0.f && dropout_p < 1.f, "attn_dropout_mask: p = %f is not in (0, 1)", (double)dropout_p);
+  AttnParams p = {};
+  p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
+  set_dropout(p, dropout_p, seed, offset);
+  const long total = (long)B * H * Tq * Tk;
+  hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p,
+                     (unsigned char*)mask_out);
+  CFHIP_CHECK_LAUNCH("attn_dropout_mask");
+  return CFHIP_OK;
 }

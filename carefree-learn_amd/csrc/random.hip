@@ -12,28 +12,6 @@
 
 namespace {
 
-struct Philox {
-  unsigned c[4];
-};
-
-__device__ __forceinline__ Philox philox4x32_10(unsigned long long ctr, unsigned long long seed) {
-  constexpr unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0u, c3 = 0u;
-  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    const unsigned hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-    c0 = hi1 ^ c1 ^ k0;
-    c1 = lo1;
-    c2 = hi0 ^ c3 ^ k1;
-    c3 = lo0;
-    k0 += W0;
-    k1 += W1;
-  }
-  return Philox{{c0, c1, c2, c3}};
-}
-
 // uniform in [0, 1) with 24 random bits (every value exactly representable)
 __device__ __forceinline__ float u01(unsigned r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
 

@@ -414,14 +414,16 @@ class PackedSelfAttentionFn(Function):
     reference attentions.py:214-216,180-185).  Output [B, T, D], heads already merged."""
 
     @staticmethod
-    def forward(ctx: Any, qkv: Tensor, num_heads: int, keep_mask: Optional[Tensor], causal: bool) -> Tensor:
+    def forward(ctx: Any, qkv: Tensor, num_heads: int, keep_mask: Optional[Tensor], causal: bool,
+                dropout_p: float = 0.0) -> Tensor:
         if qkv.dtype != bf16:
             qkv = ops.to_bf16(qkv.float().contiguous())
         if not qkv.is_contiguous():
             qkv = qkv.contiguous()
         d = qkv.shape[-1] // 3
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
-        o, lse = ops.attn_fwd(q, k, v, num_heads, mask=keep_mask, causal=causal)
+        ctx.drop = _take_attn_dropout(dropout_p, qkv.shape[0], num_heads, qkv.shape[1], qkv.shape[1])
+        o, lse = ops.attn_fwd(q, k, v, num_heads, mask=keep_mask, causal=causal, **ctx.drop)
         ctx.save_for_backward(qkv, o, lse, keep_mask)
         ctx.num_heads, ctx.causal = num_heads, causal
         return o
@@ -437,9 +439,9 @@ class PackedSelfAttentionFn(Function):
         ops.attn_bwd(
             qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, d_o, lse, ctx.num_heads,
             dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], mask=keep_mask,
-            causal=ctx.causal,
+            causal=ctx.causal, **ctx.drop,
         )
-        return dqkv, None, None, None
+        return dqkv, None, None, None, None
 
 
 class AttentionCoreFn(Function):
@@ -448,10 +450,11 @@ class AttentionCoreFn(Function):
 
     @staticmethod
     def forward(ctx: Any, q: Tensor, k: Tensor, v: Tensor, num_heads: int, keep_mask: Optional[Tensor],
-                causal: bool, head_dim: int = 64) -> Tensor:
+                causal: bool, head_dim: int = 64, dropout_p: float = 0.0) -> Tensor:
         q, k, v = (t if t.dtype == bf16 else ops.to_bf16(t.float().contiguous()) for t in (q, k, v))
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()  # equal shapes -> k and v share strides
-        o, lse = ops.attn_fwd(q, k, v, num_heads, mask=keep_mask, causal=causal, head_dim=head_dim)
+        ctx.drop = _take_attn_dropout(dropout_p, q.shape[0], num_heads, q.shape[1], k.shape[1])
+        o, lse = ops.attn_fwd(q, k, v, num_heads, mask=keep_mask, causal=causal, head_dim=head_dim, **ctx.drop)
         ctx.save_for_backward(q, k, v, o, lse, keep_mask)
         ctx.num_heads, ctx.causal, ctx.head_dim = num_heads, causal, head_dim
         return o
@@ -464,18 +467,27 @@ class AttentionCoreFn(Function):
         d_o = d_o.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         ops.attn_bwd(q, k, v, o, d_o, lse, ctx.num_heads, dq=dq, dk=dk, dv=dv, mask=keep_mask, causal=ctx.causal,
-                     head_dim=ctx.head_dim)
-        return dq, dk, dv, None, None, None, None
+                     head_dim=ctx.head_dim, **ctx.drop)
+        return dq, dk, dv, None, None, None, None, None
+
+
+def _take_attn_dropout(dropout_p: float, b: int, num_heads: int, tq: int, tk: int) -> dict:
+    """kernel arguments of one attention call with dropout on the probabilities: draws its (seed, offset) from the
+    process-wide Philox stream; the backward passes get the same pair and regenerate the mask"""
+    if not 0.0 < dropout_p < 1.0:
+        return {}
+    seed, offset = ops.PhiloxState.take(ops.attn_dropout_blocks(b, num_heads, tq, tk))
+    return dict(dropout_p=float(dropout_p), seed=seed, offset=offset)
 
 
 def packed_self_attention(qkv: Tensor, num_heads: int, keep_mask: Optional[Tensor] = None,
-                          causal: bool = False) -> Tensor:
-    return PackedSelfAttentionFn.apply(qkv, num_heads, keep_mask, causal)
+                          causal: bool = False, dropout_p: float = 0.0) -> Tensor:
+    return PackedSelfAttentionFn.apply(qkv, num_heads, keep_mask, causal, dropout_p)
 
 
 def attention_core(q: Tensor, k: Tensor, v: Tensor, num_heads: int, keep_mask: Optional[Tensor] = None,
-                   causal: bool = False, head_dim: int = 64) -> Tensor:
-    return AttentionCoreFn.apply(q, k, v, num_heads, keep_mask, causal, head_dim)
+                   causal: bool = False, head_dim: int = 64, dropout_p: float = 0.0) -> Tensor:
+    return AttentionCoreFn.apply(q, k, v, num_heads, keep_mask, causal, head_dim, dropout_p)
 
 
 # ---------------------------------------------------------------------------------------------

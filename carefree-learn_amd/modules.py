@@ -381,8 +381,7 @@ class Attention(Module):
                 deterministic: bool = False, residual: Optional[Tensor] = None) -> AttentionOutput:
         if require_weights or self.customize_sdp:
             raise NotImplementedError("attention weights / custom softmax need the un-fused slow path")
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError("attention dropout is outside the accelerated hot path")
+        drop = self.dropout if (self.training and 0.0 < self.dropout < 1.0) else 0.0  # attentions.py:254: on the probabilities
         if self.head_dim % 8 != 0 or self.head_dim > 192:
             raise NotImplementedError(f"HIP attention kernels take head_dim = a multiple of 8 up to 192, got {self.head_dim}")
         qkv_inp = q, k, v
@@ -398,11 +397,11 @@ class Attention(Module):
             if packed is not None:
                 d = packed.shape[-1] // 3
                 qq, kk, vv = packed[..., :d], packed[..., d:2 * d], packed[..., 2 * d:]
-            out = HF.attention_core(qq, kk, vv, self.num_heads, keep, False, self.head_dim)
+            out = HF.attention_core(qq, kk, vv, self.num_heads, keep, False, self.head_dim, drop)
         elif packed is not None:
-            out = HF.packed_self_attention(packed, self.num_heads, keep, False)
+            out = HF.packed_self_attention(packed, self.num_heads, keep, False, drop)
         else:
-            out = HF.attention_core(qq, kk, vv, self.num_heads, keep, False)
+            out = HF.attention_core(qq, kk, vv, self.num_heads, keep, False, 64, drop)
         net = self.out_linear(out, residual=residual)
         return AttentionOutput(net, None)
 
@@ -1602,8 +1601,6 @@ class CrossAttention(Module):
     def __init__(self, *, query_dim: int, context_dim: Optional[int] = None, num_heads: int = 8, head_dim: int = 64,
                  dropout: float = 0.0):
         super().__init__()
-        if dropout > 0.0:
-            raise NotImplementedError("dropout > 0 is outside the accelerated hot path")
         self.has_context = context_dim is not None
         latent_dim = head_dim * num_heads
         context_dim = context_dim or query_dim
@@ -1611,7 +1608,7 @@ class CrossAttention(Module):
         self.to_q = HijackLinear(query_dim, latent_dim, bias=False)
         self.to_k = HijackLinear(context_dim, latent_dim, bias=False)
         self.to_v = HijackLinear(context_dim, latent_dim, bias=False)
-        self.out_linear = nn.Sequential(HijackLinear(latent_dim, query_dim), nn.Dropout(dropout))
+        self.out_linear = nn.Sequential(HijackLinear(latent_dim, query_dim), Dropout(dropout))
 
     def forward(self, net: Tensor, *, context: Optional[Tensor] = None, mask: Optional[Tensor] = None,
                 residual: Optional[Tensor] = None) -> Tensor:
@@ -1624,7 +1621,10 @@ class CrossAttention(Module):
             b = net.shape[0]
             keep = (~mask).view(b, self.num_heads, mask.shape[-2], mask.shape[-1]).to(torch.uint8)
         o = HF.attention_core(q, k, v, self.num_heads, keep, False, self.head_dim)
-        lin = self.out_linear[0]
+        lin, drop = self.out_linear[0], self.out_linear[1]
+        if self.training and 0.0 < drop.p < 1.0:  # attentions.py:517-521: Linear -> Dropout, then the caller's residual
+            out = drop(HF.linear(o, lin.weight, lin.bias))
+            return out if residual is None else HF.add(residual, out)
         return HF.linear(o, lin.weight, lin.bias, residual=residual)
 
 

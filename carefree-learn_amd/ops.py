@@ -280,10 +280,12 @@ def _mask_args(mask: Optional[Tensor], b: int, h: int, tq: int, tk: int):
 
 def attn_fwd(
     q: Tensor, k: Tensor, v: Tensor, num_heads: int, *, mask: Optional[Tensor] = None,
-    causal: bool = False, scale: Optional[float] = None, head_dim: int = 64,
+    causal: bool = False, scale: Optional[float] = None, head_dim: int = 64, dropout_p: float = 0.0,
+    seed: int = 0, offset: int = 0,
 ) -> Tuple[Tensor, Tensor]:
     """Returns (o bf16 [B, Tq, H*head_dim] contiguous, lse f32 [B, H, Tq]).  head_dim 64 with both lengths <= 256
-    takes the LDS-resident kernels; anything else (head_dim any multiple of 8 up to 192) the chunked general ones."""
+    takes the LDS-resident kernels; anything else (head_dim any multiple of 8 up to 192) the chunked general ones.
+    `dropout_p` > 0: dropout on the attention probabilities, mask = f(seed, offset) (see `attn_dropout_blocks`)."""
     b, tq, d, q_sb, q_st = _bth(q, "q")
     _, tk, _, k_sb, k_st = _bth(k, "k")
     _, _, _, v_sb, v_st = _bth(v, "v")
@@ -299,19 +301,42 @@ def attn_fwd(
     keep, mp, ms_b, ms_h, ms_q = _mask_args(mask, b, num_heads, tq, tk)
     if FLOP_COUNTER is not None:
         FLOP_COUNTER.flops["attention"] += 4.0 * b * num_heads * tq * tk * head_dim
-    rc = _lib.load().cfhip_attn_fwd_dh(
-        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), mp, b, num_heads, tq,
-        tk, int(head_dim), q_sb, q_st, k_sb, k_st, o.stride(0), o.stride(1), ms_b, ms_h, ms_q, float(scale),
-        int(causal), _stream(),
-    )
+    if dropout_p > 0.0:
+        rc = _lib.load().cfhip_attn_fwd_dropout(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), mp, b, num_heads, tq,
+            tk, int(head_dim), q_sb, q_st, k_sb, k_st, o.stride(0), o.stride(1), ms_b, ms_h, ms_q, float(scale),
+            int(causal), float(dropout_p), int(seed), int(offset), _stream(),
+        )
+    else:
+        rc = _lib.load().cfhip_attn_fwd_dh(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), mp, b, num_heads, tq,
+            tk, int(head_dim), q_sb, q_st, k_sb, k_st, o.stride(0), o.stride(1), ms_b, ms_h, ms_q, float(scale),
+            int(causal), _stream(),
+        )
     _lib.check(rc, "attn_fwd")
     return o, lse
+
+
+def attn_dropout_blocks(b: int, num_heads: int, tq: int, tk: int) -> int:
+    """Philox counters one attention call with dropout consumes (`PhiloxState.take` this many)"""
+    return b * num_heads * ((tq + 3) // 4) * ((tk + 3) // 4)
+
+
+def attn_dropout_mask(b: int, num_heads: int, tq: int, tk: int, dropout_p: float, seed: int, offset: int,
+                      device: object = "cuda") -> Tensor:
+    """uint8 [B, H, Tq, Tk] (1 = keep): the mask `attn_fwd(..., dropout_p, seed, offset)` applies"""
+    out = torch.empty((b, num_heads, tq, tk), dtype=torch.uint8, device=device)
+    rc = _lib.load().cfhip_attn_dropout_mask(out.data_ptr(), b, num_heads, tq, tk, float(dropout_p), int(seed),
+                                             int(offset), _stream())
+    _lib.check(rc, "attn_dropout_mask")
+    return out
 
 
 def attn_bwd(
     q: Tensor, k: Tensor, v: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, num_heads: int, *,
     dq: Tensor, dk: Tensor, dv: Tensor, mask: Optional[Tensor] = None, causal: bool = False,
     scale: Optional[float] = None, parts: int = 3, delta: Optional[Tensor] = None, head_dim: int = 64,
+    dropout_p: float = 0.0, seed: int = 0, offset: int = 0,
 ) -> None:
     """Writes dq / dk / dv (bf16, SAME strides as q / k / v — e.g. views of one packed buffer)."""
     b, tq, d, q_sb, q_st = _bth(q, "q")
@@ -332,11 +357,19 @@ def attn_bwd(
     keep, mp, ms_b, ms_h, ms_q = _mask_args(mask, b, num_heads, tq, tk)
     if FLOP_COUNTER is not None:
         FLOP_COUNTER.flops["attention"] += 10.0 * b * num_heads * tq * tk * head_dim
-    rc = _lib.load().cfhip_attn_bwd_dh(
-        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
-        delta.data_ptr(), mp, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), b, num_heads, tq, tk, int(head_dim),
-        q_sb, q_st, k_sb, k_st, o_sb, o_st, ms_b, ms_h, ms_q, float(scale), int(causal), int(parts), _stream(),
-    )
+    if dropout_p > 0.0:
+        rc = _lib.load().cfhip_attn_bwd_dropout(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
+            delta.data_ptr(), mp, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), b, num_heads, tq, tk, int(head_dim),
+            q_sb, q_st, k_sb, k_st, o_sb, o_st, ms_b, ms_h, ms_q, float(scale), int(causal), int(parts),
+            float(dropout_p), int(seed), int(offset), _stream(),
+        )
+    else:
+        rc = _lib.load().cfhip_attn_bwd_dh(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
+            delta.data_ptr(), mp, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), b, num_heads, tq, tk, int(head_dim),
+            q_sb, q_st, k_sb, k_st, o_sb, o_st, ms_b, ms_h, ms_q, float(scale), int(causal), int(parts), _stream(),
+        )
     _lib.check(rc, "attn_bwd")
 
 

@@ -168,6 +168,27 @@ int cfhip_attn_bwd_dh(const void* q, const void* k, const void* v, const void* o
                       int64_t kv_stride_b, int64_t kv_stride_t, int64_t o_stride_b, int64_t o_stride_t,
                       int64_t ms_b, int64_t ms_h, int64_t ms_q, float scale, int causal, int parts,
                       void* stream);
+/* The same with DROPOUT ON THE ATTENTION PROBABILITIES (reference attentions.py:254 -> sdp_attn(..., dropout) ->
+ * F.scaled_dot_product_attention(dropout_p); attentions.py:264-265 in the weights path): O = dropout(softmax(S)) V.
+ * The keep mask is a pure function of (seed, offset, b, h, i, j) — one Philox4x32-10 call per 4 x 4 block of the score
+ * matrix, counter = offset + ((b H + h) ceil(Tq / 4) + i / 4) ceil(Tk / 4) + j / 4, byte (j % 4) of word (i % 4) >=
+ * round(256 p) keeps — so the two backward passes regenerate it from the pair the forward used (advance `offset` by
+ * B H ceil(Tq / 4) ceil(Tk / 4) per call) and no mask is ever stored.  The probability is quantised to 1/256 (kept
+ * values scale by 256 / (256 - round(256 p))).  Any head_dim / length: these run the chunked kernels.
+ * cfhip_attn_dropout_mask writes that mask (uint8 [B][H][Tq][Tk], 1 = keep) for tests and debugging. */
+int cfhip_attn_fwd_dropout(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* mask,
+                           int B, int H, int Tq, int Tk, int head_dim, int64_t q_stride_b, int64_t q_stride_t,
+                           int64_t kv_stride_b, int64_t kv_stride_t, int64_t o_stride_b, int64_t o_stride_t,
+                           int64_t ms_b, int64_t ms_h, int64_t ms_q, float scale, int causal, float dropout_p,
+                           uint64_t seed, uint64_t offset, void* stream);
+int cfhip_attn_bwd_dropout(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                           const float* lse, float* delta, const uint8_t* mask, void* dq, void* dk, void* dv, int B,
+                           int H, int Tq, int Tk, int head_dim, int64_t q_stride_b, int64_t q_stride_t,
+                           int64_t kv_stride_b, int64_t kv_stride_t, int64_t o_stride_b, int64_t o_stride_t,
+                           int64_t ms_b, int64_t ms_h, int64_t ms_q, float scale, int causal, int parts,
+                           float dropout_p, uint64_t seed, uint64_t offset, void* stream);
+int cfhip_attn_dropout_mask(void* mask_out, int B, int H, int Tq, int Tk, float dropout_p, uint64_t seed,
+                            uint64_t offset, void* stream);
 /* parts: 1 = dQ pass only, 2 = dK/dV pass only, 3 = both.  The two passes are independent kernels
  * (each recomputes S, dP and delta) and may be launched on two streams. */
 

@@ -203,3 +203,102 @@ def test_general_head_dims(dh, tq, tk, h):
     assert_close(dq, gq, 2e-2, f"dq dh={dh}", abs_floor=1e-6)
     assert_close(dk, gk, 2e-2, f"dk dh={dh}", abs_floor=1e-6)
     assert_close(dv, gv, 2e-2, f"dv dh={dh}", abs_floor=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# dropout on the attention probabilities (reference attentions.py:254 -> sdp_attn(..., dropout))
+# ---------------------------------------------------------------------------------------------
+
+
+def _dropout_reference(q, k, v, h, dh, keep_prob_mask, p_eff, user_keep=None, causal=False, d_o=None):
+    """fp32 autograd of O = (softmax(S) * M / (1 - p)) V for a GIVEN mask M [B, H, Tq, Tk]"""
+    leaves = [t.float().requires_grad_(True) for t in (q, k, v)]
+    b, tq, _ = q.shape
+    tk = k.shape[1]
+    hd = lambda z, t: z.reshape(b, t, h, dh).permute(0, 2, 1, 3)  # noqa: E731
+    s = hd(leaves[0], tq) @ hd(leaves[1], tk).transpose(-1, -2) / math.sqrt(dh)
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(tq, tk, dtype=torch.bool), 1), float("-inf"))
+    if user_keep is not None:
+        s = s.masked_fill(user_keep == 0, float("-inf"))
+    prob = torch.softmax(s, -1) * (keep_prob_mask.float() / (1.0 - p_eff))
+    o = (prob @ hd(leaves[2], tk)).permute(0, 2, 1, 3).reshape(b, tq, h * dh)
+    if d_o is not None:
+        o.backward(d_o.float())
+        return o.detach(), [t.grad for t in leaves]
+    return o.detach(), None
+
+
+@pytest.mark.parametrize("dh,tq,tk,h,causal", [(64, 197, 197, 3, False), (64, 70, 90, 2, False), (40, 130, 77, 2, False),
+                                               (64, 300, 300, 1, True), (128, 50, 260, 2, False)])
+def test_attention_probability_dropout_matches_the_formula_for_its_own_mask(dh, tq, tk, h, causal):
+    """O = dropout(softmax(S)) V and all three gradients, against fp32 autograd with the mask the kernels derive from
+    (seed, offset) — exported by cfhip_attn_dropout_mask — for resident-size and chunked shapes, head widths 40 / 64 /
+    128, cross lengths, causal and a user keep-mask.  p is quantised to 1/256: 0.3 -> 77/256."""
+    b, p = 2, 0.3
+    p_eff = round(p * 256) / 256
+    g = torch.Generator().manual_seed(dh + tq)
+    q = torch.randn(b, tq, h * dh, generator=g).to(torch.bfloat16)
+    k = torch.randn(b, tk, h * dh, generator=g).to(torch.bfloat16)
+    v = torch.randn(b, tk, h * dh, generator=g).to(torch.bfloat16)
+    d_o = torch.randn(b, tq, h * dh, generator=g).to(torch.bfloat16)
+    user_keep = None
+    if dh == 40:  # with a user mask too (every row keeps its first key)
+        user_keep = (torch.rand(b, h, tq, tk, generator=g) > 0.4).to(torch.uint8)
+        user_keep[..., 0] = 1
+    seed, offset = 1234567, 4096
+    mask = ops.attn_dropout_mask(b, h, tq, tk, p, seed, offset)
+    frac = mask.float().mean().item()
+    n = mask.numel()
+    assert abs(frac - (1 - p_eff)) < 5 * math.sqrt(p_eff * (1 - p_eff) / n), (frac, 1 - p_eff)
+    want_o, want_g = _dropout_reference(q, k, v, h, dh, mask.cpu(), p_eff, user_keep, causal, d_o)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    ukd = None if user_keep is None else user_keep.to(DEV)
+    kw = dict(mask=ukd, causal=causal, head_dim=dh, dropout_p=p, seed=seed, offset=offset)
+    o, lse = ops.attn_fwd(qd, kd, vd, h, **kw)
+    assert_close(o, want_o, 1e-2, "dropout attention fwd")
+    o2, _ = ops.attn_fwd(qd, kd, vd, h, **kw)
+    assert torch.equal(o, o2)  # a pure function of (seed, offset)
+    o3, _ = ops.attn_fwd(qd, kd, vd, h, **dict(kw, offset=offset + ops.attn_dropout_blocks(b, h, tq, tk)))
+    assert not torch.equal(o, o3)
+    dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
+    ops.attn_bwd(qd, kd, vd, o, d_o.to(DEV), lse, h, dq=dq, dk=dk, dv=dv, **kw)
+    assert_close(dq, want_g[0], 2e-2, "dropout attention dq")
+    assert_close(dk, want_g[1], 2e-2, "dropout attention dk")
+    assert_close(dv, want_g[2], 2e-2, "dropout attention dv")
+    # the two passes launched separately (two streams in the step) see the same mask
+    dq2, dk2, dv2 = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
+    ops.attn_bwd(qd, kd, vd, o, d_o.to(DEV), lse, h, dq=dq2, dk=dk2, dv=dv2, parts=1, **kw)
+    ops.attn_bwd(qd, kd, vd, o, d_o.to(DEV), lse, h, dq=dq2, dk=dk2, dv=dv2, parts=2, **kw)
+    assert torch.equal(dq, dq2) and torch.equal(dv, dv2)
+    assert_close(dk2, dk, 2e-3, "dk of the stand-alone pass")  # (it recomputes delta = rowsum(dO * O) in another order)
+
+
+def test_attention_module_dropout_trains_and_is_off_in_eval():
+    import cflearn_amd as C
+
+    torch.manual_seed(0)
+    m = C.Attention(128, 2, dropout=0.2).to(DEV)  # head_dim 64: packed path
+    x = torch.randn(3, 50, 128, device=DEV)
+    m.eval()
+    y_eval = m(x, x, x).output
+    m.dropout = 0.0
+    assert torch.equal(m(x, x, x).output, y_eval)
+    m.dropout = 0.2
+    m.train()
+    ops.PhiloxState.manual_seed(5)
+    off0 = ops.PhiloxState.offset
+    xr = x.clone().requires_grad_(True)
+    y1 = m(xr, xr, xr).output
+    assert ops.PhiloxState.offset - off0 == ops.attn_dropout_blocks(3, 2, 50, 50)
+    y2 = m(x, x, x).output
+    assert not torch.equal(y1, y2) and not torch.equal(y1, y_eval)  # fresh mask every call
+    y1.float().sum().backward()
+    assert torch.isfinite(xr.grad).all() and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    ops.PhiloxState.manual_seed(5)
+    assert torch.equal(m(x, x, x).output, y1)  # reseeding reproduces the run
+    # E[dropout(P)] = P: the train-mode output averages to the eval-mode one
+    acc = torch.zeros_like(y_eval, dtype=torch.float32)
+    for _ in range(200):
+        acc += m(x, x, x).output.float()
+    assert_close(acc / 200, y_eval.float(), 5e-2, "mean over dropout masks")

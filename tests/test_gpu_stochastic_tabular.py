@@ -82,7 +82,8 @@ def test_mixing_block_with_dropout_and_drop_path_matches_the_reference_formula(g
     m = m.to(DEV)
     for b_ in m.encoder.encoder.mixing_blocks:
         # the same `dropout` also reaches Attention as the dropout ON THE ATTENTION PROBABILITIES (inside sdp_attn,
-        # toolkit.py:953-963): that one is not built into the attention kernels and raises — switched off here
+        # toolkit.py:953-963; tests/test_gpu_attn.py::test_attention_probability_dropout*): its mask comes from the
+        # Philox stream and cannot be injected, so it is switched off for this formula check
         assert b_.token_mixing.net.dropout == 0.25
         b_.token_mixing.net.dropout = 0.0
     blk = m.encoder.encoder.mixing_blocks[1]
