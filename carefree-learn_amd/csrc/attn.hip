@@ -699,9 +699,10 @@ __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_bwd_dq_kernel(A
       }
       const bf16x8 dsp = pack8(ds[0], ds[1]);
 #pragma unroll
-      for (int dt = 0; dt < 4 * NH; ++dt)
+      for (int dt = 0; dt < 4 * NH; ++dt) {
         dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
             frag_cols(Ks + (dt >> 2) * G::HALF_BYTES, a * 32, (dt & 3) * 16, lane), dsp, dqt[dt], 0, 0, 0);
+      }
     }
   }
   if (qvalid) {
