@@ -59,9 +59,17 @@ int g_attn_ablate = 0;
 #define ATTN_ABL(bit) false
 #endif
 
+// XOR key of the 16-byte slots of a tile row (128 B per row: two rows per 256-byte LDS bank row).  The key moves whole
+// 32-byte chunks (bit 0 clear) and takes four values over the row pairs of an 8-row block: the 16 lanes of a
+// ds_read_b128 group (8 rows on each half of the bank row, two adjacent slots) land on 8 distinct slots per half, and the
+// 8 rows x 32 bytes a half-wave of ds_read_b64_tr_b16 touches land on 4 distinct chunks per half — both conflict-free.
+// (The first version, key (row >> 1) & 7, differed only in bit 0 between rows r and r + 2: the two slots of a 32-byte
+// chunk swapped places and every transposing read was a 2-way conflict — SQ_LDS_BANK_CONFLICT 26 % of the LDS cycles.)
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 3) << 1; }
+
 // byte offset of element (row, col) in a swizzled [rows][64] bf16 tile (128 B per row)
 __device__ __forceinline__ int tile_off(int row, int col) {
-  return row * 128 + ((((col >> 3) ^ ((row >> 1) & 7))) << 4) + ((col & 7) << 1);
+  return row * 128 + ((((col >> 3) ^ swz(row))) << 4) + ((col & 7) << 1);
 }
 
 // Cooperative asynchronous load of `rows_pad` rows (zero beyond rows_valid) of one head into a swizzled
@@ -78,7 +86,7 @@ __device__ __forceinline__ void dma_tile(char* tile, const bf16_t* base, long st
   const int r8 = lane >> 3, slot = lane & 7;
   for (int inst = wave; inst < rows_pad / 8; inst += nwaves) {
     const int row = inst * 8 + r8;
-    const int chunk = slot ^ ((row >> 1) & 7);
+    const int chunk = slot ^ swz(row);
     const unsigned off = row < rows_valid ? (unsigned)(row * stride_t * 2 + chunk * 16) : 0x80000000u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(tile + inst * 1024), 16, off, 0, 0, 0);
   }
@@ -88,7 +96,7 @@ __device__ __forceinline__ void dma_tile(char* tile, const bf16_t* base, long st
 __device__ __forceinline__ bf16x8 frag_rows(const char* tile, int row0, int ks, int lane) {
   const int row = row0 + (lane & 15);
   const int slot = ks * 4 + (lane >> 4);
-  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((slot ^ swz(row)) << 4));
 }
 
 // column-operand fragment over the 32-row block starting at `r32`, columns c0..c0+15:
@@ -123,6 +131,28 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   u.w[0] = pack_bf16x2(a[0], a[1]); u.w[1] = pack_bf16x2(a[2], a[3]);
   u.w[2] = pack_bf16x2(b[0], b[1]); u.w[3] = pack_bf16x2(b[2], b[3]);
   return u.v;
+}
+
+// One 64-column output row per lane group: lane (n = l & 15, g = l >> 4) holds columns 16 dt + 4 g .. + 3 of row n for the
+// four 16-column tiles dt.  Written as they are, that is four 8-byte stores per lane, 32-byte runs per row and
+// instruction — the store tail of these kernels is issue-bound (dK/dV: 34 of 105 us).  Lanes g and g ^ 1 swap half of
+// their values instead (two ds_bpermute per tile pair), so that every lane owns 8 consecutive columns of ONE tile and
+// the row goes out as two 16-byte stores per lane, 64-byte runs per row and instruction.  Call with all lanes active.
+__device__ __forceinline__ void store_row64(bf16_t* row, const f32x4 (&t)[4], float mul, int g, bool valid) {
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    const f32x4 a = t[2 * pr] * mul, b = t[2 * pr + 1] * mul;
+    const unsigned a0 = pack_bf16x2(a[0], a[1]), a1 = pack_bf16x2(a[2], a[3]);
+    const unsigned b0 = pack_bf16x2(b[0], b[1]), b1 = pack_bf16x2(b[2], b[3]);
+    const bool odd = (g & 1) != 0;
+    const unsigned r0 = (unsigned)__shfl_xor((int)(odd ? a0 : b0), 16, 64);  // even g sends tile 2pr+1, odd g tile 2pr
+    const unsigned r1 = (unsigned)__shfl_xor((int)(odd ? a1 : b1), 16, 64);
+    // even g: own tile-2pr columns 4g..4g+3, then the partner's (g + 1); odd g: the partner's (g - 1) tile-(2pr+1)
+    // columns, then its own
+    const u32x4 w = odd ? u32x4{r0, r1, b0, b1} : u32x4{a0, a1, r0, r1};
+    const int col = (2 * pr + (odd ? 1 : 0)) * 16 + 4 * (g & 2);
+    if (valid) *reinterpret_cast<u32x4*>(row + col) = w;
+  }
 }
 
 __device__ __forceinline__ bool keep_at(const AttnParams& p, int b, int h, int i, int j) {
@@ -250,16 +280,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnParams p) {
       ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Vs, a * 32, dt * 16, lane), pa, ot[dt], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (qi < p.Tq && !ATTN_ABL(4)) {
+  {
+    const bool valid = qi < p.Tq && !ATTN_ABL(4);
     const float inv = 1.0f / l;
-    bf16_t* orow = p.o + (long)b * p.o_sb + (long)qi * p.o_st + h * DH;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const f32x4 v = ot[dt] * inv;
-      *reinterpret_cast<u32x2*>(orow + dt * 16 + 4 * g) =
-          u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-    }
-    if (g == 0 && p.lse != nullptr)
+    store_row64(p.o + (long)b * p.o_sb + (long)qi * p.o_st + h * DH, ot, inv, g, valid);
+    if (valid && g == 0 && p.lse != nullptr)
       p.lse[((long)b * p.H + h) * p.Tq + qi] = (mx + log2f(l)) * (1.0f / LOG2E);
   }
   }  // query-tile loop
@@ -337,15 +362,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(AttnParams p, int n
     for (int dt = 0; dt < 4; ++dt)
       dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Ks, a * 32, dt * 16, lane), dsp, dqt[dt], 0, 0, 0);
   }
-  if (qvalid) {
-    bf16_t* dqrow = p.dq + (long)b * p.q_sb + (long)qi * p.q_st + h * DH;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const f32x4 v = dqt[dt] * p.scale;
-      *reinterpret_cast<u32x2*>(dqrow + dt * 16 + 4 * g) =
-          u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-    }
-  }
+  store_row64(p.dq + (long)b * p.q_sb + (long)qi * p.q_st + h * DH, dqt, p.scale, g, qvalid);
   }  // query-tile loop
 }
 
@@ -443,20 +460,155 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_kernel(AttnParams p, int 
       dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Qs, a * 32, dt * 16, lane), dsk, dkt[dt], 0, 0, 0);
     }
   }
-  if (kj < p.Tk && !ATTN_ABL(4)) {
-    bf16_t* dkrow = p.dk + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH;
-    bf16_t* dvrow = p.dv + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const f32x4 kk = dkt[dt] * p.scale;
-      const f32x4 vv = dvt[dt];
-      *reinterpret_cast<u32x2*>(dkrow + dt * 16 + 4 * g) =
-          u32x2{pack_bf16x2(kk[0], kk[1]), pack_bf16x2(kk[2], kk[3])};
-      *reinterpret_cast<u32x2*>(dvrow + dt * 16 + 4 * g) =
-          u32x2{pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3])};
-    }
+  {
+    const bool valid = kj < p.Tk && !ATTN_ABL(4);
+    store_row64(p.dk + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH, dkt, p.scale, g, valid);
+    store_row64(p.dv + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH, dvt, 1.0f, g, valid);
   }
   }  // kv-tile loop
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent forms of the three resident kernels (PLAIN only, sequence lengths 129 .. 256 = the ViT step).
+// One 16-wave workgroup per CU walks (batch, head) pairs; the operands of the NEXT head stream into a second LDS buffer
+// while the waves work on the current one.  In the one-shot kernels above the prologue DMA (57 KB per head) is not
+// covered by anything: every workgroup of a launch sits in it at the same time (dK/dV pass: 105 us, 56 us without the DMA,
+// profiles/r02/attn_vit_ablation.log).  The DMA / statistics loads of the next head are issued UNCONDITIONALLY (out of
+// range offsets when there is no next head), right after this head's own fragment loads, so that the compiler's vmcnt
+// bookkeeping can wait for the fragments while the younger DMA stays in flight.
+// ------------------------------------------------------------------------------------------------
+constexpr int PERS_WAVES = 16;
+
+// 2 instructions per wave cover up to 256 rows (32 instructions of 8 rows)
+__device__ __forceinline__ void dma_tile_pers(char* tile, const bf16_t* base, long stride_t, int rows_valid, bool live,
+                                              int wave, int lane) {
+  long bytes = ((long)(rows_valid - 1) * stride_t + DH) * 2;
+  if (bytes > 0x7fffffffL) bytes = 0x7fffffffL;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, live ? (int)bytes : 0, 0x00020000);
+  const int r8 = lane >> 3, slot = lane & 7;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int inst = wave + j * PERS_WAVES;
+    const int row = inst * 8 + r8;
+    const int chunk = slot ^ swz(row);
+    const unsigned off = (live && row < rows_valid) ? (unsigned)(row * stride_t * 2 + chunk * 16) : 0x80000000u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(tile + inst * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+template <int NBQ>
+__global__ __launch_bounds__(PERS_WAVES * 64, 4) void attn_bwd_dkv_pers_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // every wave issues 2 DMA instructions per operand whatever NBQ is (a fixed count the compiler can wait on): the tile
+  // slot is 256 rows, the instructions beyond ROWS write zeros into its padding
+  constexpr int ROWS = NBQ * 32, TILE = 256 * 128, BUF = 2 * TILE + 2 * ROWS * 4;
+  static_assert(ROWS <= 256 && ROWS * 8 <= 2 * PERS_WAVES * 64, "two DMA instructions / two statistics slots per thread");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int heads = p.B * p.H;
+  const float sl2 = p.scale * LOG2E;
+
+  auto issue = [&](int hh, char* buf, bool live) {
+    const int b = hh / p.H, h = hh - b * p.H;
+    dma_tile_pers(buf, p.q + (long)b * p.q_sb + h * DH, p.q_st, p.Tq, live, wave, lane);
+    dma_tile_pers(buf + TILE, p.d_o + (long)b * p.o_sb + h * DH, p.o_st, p.Tq, live, wave, lane);
+  };
+  // lse (log2 domain) and delta of row t = idx (thread-per-row, 2 slots per thread); needs p.delta from the dQ pass
+  auto stats_load = [&](int hh, bool live, float (&lv)[2], float (&dv)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = (int)threadIdx.x + j * PERS_WAVES * 64;
+      const bool ok = live && t < p.Tq;
+      const long at = (long)hh * p.Tq + (ok ? t : 0);
+      const float l = p.lse[ok ? at : 0], d = p.delta[ok ? at : 0];
+      lv[j] = ok ? l * LOG2E : INFINITY;
+      dv[j] = ok ? d : 0.f;
+    }
+  };
+  auto stats_store = [&](char* buf, const float (&lv)[2], const float (&dv)[2]) {
+    float* lse_s = reinterpret_cast<float*>(buf + 2 * TILE);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = (int)threadIdx.x + j * PERS_WAVES * 64;
+      if (t < ROWS) {
+        lse_s[t] = lv[j];
+        lse_s[ROWS + t] = dv[j];
+      }
+    }
+  };
+
+  int hh = blockIdx.x;
+  int cur = 0;
+  {
+    float lv[2], dv[2];
+    issue(hh, smem, hh < heads);
+    stats_load(hh, hh < heads, lv, dv);
+    stats_store(smem, lv, dv);
+  }
+  __syncthreads();
+  for (; hh < heads; hh += gridDim.x) {
+    const int b = hh / p.H, h = hh - b * p.H;
+    char* Qs = smem + cur * BUF;
+    char* dOs = Qs + TILE;
+    const float* lse_s = reinterpret_cast<const float*>(Qs + 2 * TILE);
+    const float* delta_s = lse_s + ROWS;
+    const int row0 = wave * 16;
+    const int kj = row0 + n;
+    const bf16_t* kb = p.k + (long)b * p.kv_sb + h * DH;
+    const bf16_t* vb = p.v + (long)b * p.kv_sb + h * DH;
+    // this head's own fragments first: older than the DMA below in the vmcnt order
+    const bf16x8 kf0 = frag_global(kb, p.kv_st, row0, p.Tk, 0, lane);
+    const bf16x8 kf1 = frag_global(kb, p.kv_st, row0, p.Tk, 1, lane);
+    const bf16x8 vf0 = frag_global(vb, p.kv_st, row0, p.Tk, 0, lane);
+    const bf16x8 vf1 = frag_global(vb, p.kv_st, row0, p.Tk, 1, lane);
+    const int nxt = hh + gridDim.x;
+    float lv[2], dv[2];
+    issue(nxt < heads ? nxt : hh, smem + (cur ^ 1) * BUF, nxt < heads);
+    stats_load(nxt < heads ? nxt : hh, nxt < heads, lv, dv);
+
+    f32x4 dkt[4], dvt[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dkt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (row0 < p.Tk) {
+      for (int a = 0; a < NBQ; ++a) {
+        f32x4 pp[2], ds[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int it = 2 * a + t;
+          f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs, it * 16, 0, lane), kf0, sc, 0, 0, 0);
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs, it * 16, 1, lane), kf1, sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dOs, it * 16, 0, lane), vf0, dp, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dOs, it * 16, 1, lane), vf1, dp, 0, 0, 0);
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + it * 16 + 4 * g);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + it * 16 + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(sc[r] * sl2 - l4[r]);
+            pp[t][r] = pr;
+            ds[t][r] = pr * (dp[r] - d4[r]);
+          }
+        }
+        const bf16x8 ppk = pack8(pp[0], pp[1]);
+        const bf16x8 dsk = pack8(ds[0], ds[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(dOs, a * 32, dt * 16, lane), ppk, dvt[dt], 0, 0, 0);
+          dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Qs, a * 32, dt * 16, lane), dsk, dkt[dt], 0, 0, 0);
+        }
+      }
+    }
+    {
+      const bool valid = kj < p.Tk;
+      store_row64(p.dk + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH, dkt, p.scale, g, valid);
+      store_row64(p.dv + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH, dvt, 1.0f, g, valid);
+    }
+    stats_store(smem + (cur ^ 1) * BUF, lv, dv);
+    __syncthreads();  // the next head's operands have landed (vmcnt 0) and nobody reads this head's buffer any more
+    cur ^= 1;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -487,7 +639,7 @@ __device__ __forceinline__ void dma_half(char* tile, const bf16_t* base, long st
   const int r8 = lane >> 3, slot = lane & 7;
   for (int inst = wave; inst < rows_pad / 8; inst += nwaves) {
     const int row = inst * 8 + r8;
-    const int chunk = slot ^ ((row >> 1) & 7);
+    const int chunk = slot ^ swz(row);
     const bool ok = row < rows_valid && half * 64 + chunk * 8 < dh;
     const unsigned off = ok ? (unsigned)(row * stride_t * 2 + half * 128 + chunk * 16) : 0x80000000u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(tile + inst * 1024), 16, off, 0, 0, 0);
@@ -962,6 +1114,8 @@ bool set_dropout(AttnParams& p, float dropout_p, uint64_t seed, uint64_t offset)
   return true;
 }
 
+int g_attn_persistent = 1;
+
 int check_head_dim(const char* who, int head_dim) {
   CFHIP_REQUIRE(head_dim >= 8 && head_dim <= 192 && head_dim % 8 == 0,
                 "%s: head_dim %d is not a multiple of 8 in [8, 192]", who, head_dim);
@@ -969,6 +1123,11 @@ int check_head_dim(const char* who, int head_dim) {
 }
 
 }  // namespace
+
+int cfhip_internal_set_attn_persistent(int v) {
+  g_attn_persistent = v;
+  return CFHIP_OK;
+}
 
 #ifdef CFHIP_ABLATE
 int cfhip_internal_set_attn_ablate(int v) {
@@ -1116,7 +1275,25 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
     else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, block, lds, s, p, nb);
     CFHIP_CHECK_LAUNCH("attn_bwd_dq");
   }
-  if (parts & 2) {
+  if ((parts & 2) && plain && p.delta_ready && g_attn_persistent && Tq > 128 && Tk <= PERS_WAVES * 16) {
+    // the ViT shape: persistent workgroups, next head's Q / dO streaming in behind the current one
+    const int nbq = (Tq + 31) / 32;
+    const size_t lds = 2 * ((size_t)2 * 256 * 128 + (size_t)2 * nbq * 32 * sizeof(float));
+    const int heads = B * H;
+    dim3 grid(heads < 256 ? heads : 256), block(PERS_WAVES * 64);
+#define CFHIP_DKV_PERS(NBQ_)                                                                                         \
+  case NBQ_:                                                                                                         \
+    rc = set_lds(attn_bwd_dkv_pers_kernel<NBQ_>, lds, "attn_bwd_dkv");                                              \
+    if (rc != CFHIP_OK) return rc;                                                                                  \
+    hipLaunchKernelGGL(attn_bwd_dkv_pers_kernel<NBQ_>, grid, block, lds, s, p);                                     \
+    break;
+    switch (nbq) {
+      CFHIP_DKV_PERS(5) CFHIP_DKV_PERS(6) CFHIP_DKV_PERS(7) CFHIP_DKV_PERS(8)
+      default: cfhip_set_error("attn_bwd: bad nbq %d", nbq); return CFHIP_ERR_INVALID;
+    }
+#undef CFHIP_DKV_PERS
+    CFHIP_CHECK_LAUNCH("attn_bwd_dkv(persistent)");
+  } else if (parts & 2) {
     const int nbq = (Tq + 31) / 32;
     const int nw = pick_waves(Tk);
     const int tiles = (Tk + 15) / 16;

@@ -1141,6 +1141,7 @@ int pick_config(int M, int N, int a_trans, int b_trans) {
 int cfhip_internal_set_attn_ablate(int v);  // attn.hip
 #endif
 int cfhip_internal_set_ln_fused(int v);  // norm.hip
+int cfhip_internal_set_attn_persistent(int v);  // attn.hip
 
 extern "C" int cfhip_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "gemm_config") == 0) {
@@ -1156,6 +1157,7 @@ extern "C" int cfhip_set_option(const char* name, int value) {
     return CFHIP_OK;
   }
   if (name != nullptr && strcmp(name, "ln_bwd_fused") == 0) return cfhip_internal_set_ln_fused(value);
+  if (name != nullptr && strcmp(name, "attn_persistent") == 0) return cfhip_internal_set_attn_persistent(value);
 #ifdef CFHIP_ABLATE
   if (name != nullptr && strcmp(name, "gemm_ablate") == 0) {
     g_gemm_ablate = value;

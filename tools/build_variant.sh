@@ -7,12 +7,12 @@ set -e
 NAME=$1; shift
 ROOT="$(dirname "$(readlink -f "$0")")/.."
 cd "$ROOT/carefree-learn_amd/csrc"
-mkdir -p ../_build/$NAME
+mkdir -p /tmp/cfhip_build_$NAME
 pids=()
 for f in errors gemm attn norm elementwise conv embed random tabular comm; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics "$@" -c $f.hip -o ../_build/$NAME/$f.o &
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics "$@" -c $f.hip -o /tmp/cfhip_build_$NAME/$f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/libcfhip_$NAME.so" ../_build/$NAME/*.o -ldl
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/libcfhip_$NAME.so" /tmp/cfhip_build_$NAME/*.o -ldl
 echo "built $ROOT/tools/libcfhip_$NAME.so"
