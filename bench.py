@@ -454,14 +454,51 @@ def main() -> None:
         return TrainStep(model, lr=1.0e-4, weight_decay=0.0, decoupled=True, use_graph=args.graph and not args.no_graph,
                          distributed=distributed, bucket_bytes=args.bucket_mb << 20, wire_bf16=args.wire_bf16, comm=comm)
 
-    try:
+    if args.comm == "cfhip":
+        # The C-ABI communicator has only ever run with one rank on the builder's 1-GPU boxes: check it before trusting it.
+        # (1) a watchdog ends the process loudly if its creation / first collective does not come back (a hang here must
+        # not look like a slow benchmark); (2) one all-reduce of known values; (3) the ranks agree — through the torch
+        # process group — whether everybody passed, otherwise ALL of them let torch.distributed launch the collectives.
+        import threading
+
+        def _stuck() -> None:
+            print(f"[bench] rank {rank}: the cfhip communicator did not answer within 180 s (creation or first all-reduce); "
+                  "rerun with --comm torch", file=sys.stderr, flush=True)
+            os._exit(17)
+
+        dog = threading.Timer(180.0, _stuck)
+        dog.daemon = True
+        dog.start()
+        ok, why = 1, ""
+        try:
+            ts = make_step("cfhip")
+            if ts.reducer is not None and ts.reducer.comm is not None:
+                probe = torch.full((1024,), float(rank + 1), device=dev)
+                ts.reducer.comm_stream.wait_stream(torch.cuda.current_stream())
+                ts.reducer.comm.all_reduce_(probe, ts.reducer.comm_stream)
+                torch.cuda.current_stream().wait_stream(ts.reducer.comm_stream)
+                torch.cuda.synchronize()
+                want = world * (world + 1) / 2.0
+                if not bool((probe == want).all()):
+                    ok, why = 0, f"all-reduce self-test gave {probe[0].item()} instead of {want}"
+        except RuntimeError as e:  # the RCCL communicator could not be created
+            ok, why = 0, str(e)
+        dog.cancel()
+        if distributed:
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            everybody = int(flag.item())
+        else:
+            everybody = ok
+        if not everybody:
+            print(f"[bench] rank {rank}: cfhip communicator not usable ({why or 'another rank failed'}); "
+                  "all ranks fall back to --comm torch", file=sys.stderr)
+            args.comm = "torch"
+            torch.manual_seed(0)
+            model = C.vit_b16_classifier(1000).to(dev)  # a fresh model: the first arena / reducer hooks stay with the old one
+            ts = make_step("torch")
+    else:
         ts = make_step(args.comm)
-    except RuntimeError as e:  # the RCCL communicator could not be created: torch.distributed launches the collectives
-        if args.comm != "cfhip":
-            raise
-        print(f"[bench] rank {rank}: cfhip communicator unavailable ({e}); falling back to --comm torch", file=sys.stderr)
-        args.comm = "torch"
-        ts = make_step("torch")
     if ts.reducer is not None:
         ts.reducer.time_exposed = True
     g = torch.Generator().manual_seed(1234 + rank)
