@@ -221,31 +221,40 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnParams p) {
     st[jt] = acc;
     if (jt & 1) __builtin_amdgcn_sched_barrier(0);  // at most 4 K fragments in flight: 128 VGPRs, 4 waves / SIMD
   }
-  // scaled scores in the log2 domain, masked; row max / sum
+  // row max / sum of the scaled scores in the log2 domain, masked
   const float sl2 = p.scale * LOG2E;
   float mx = -INFINITY;
+  float l = 0.f;
+  if (PLAIN) {
+    // (sl2 > 0: the maximum commutes with the scaling, so the pass over the 8 NB scores per lane is max only and the
+    // scaling rides in the FMA of the exponent: e = exp2(s * sl2 - max * sl2), two scores per v_pk_fma_f32 / v_pk_add_f32)
 #pragma unroll
-  for (int jt = 0; jt < 2 * NB; ++jt) {
-    if (PLAIN) {
-      // nb = ceil(Tk / 32): only the last two tiles can touch the tail
-      if (jt >= 2 * NB - 2 && jt * 16 >= p.Tk) {  // tile entirely past the end (wave-uniform)
+    for (int jt = 2 * NB - 2; jt < 2 * NB; ++jt) {  // nb = ceil(Tk / 32): only the last two tiles can touch the kv tail
+      if (jt * 16 >= p.Tk) {                         // tile entirely past the end (wave-uniform)
         st[jt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      } else if (jt >= 2 * NB - 2 && jt * 16 + 15 >= p.Tk) {  // the tile straddling Tk
+      } else if (jt * 16 + 15 >= p.Tk) {             // the tile straddling Tk
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = (jt * 16 + 4 * g + r < p.Tk) ? st[jt][r] * sl2 : -INFINITY;
-          st[jt][r] = x;
-          mx = fmaxf(mx, x);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = st[jt][r] * sl2;
-          st[jt][r] = x;
-          mx = fmaxf(mx, x);
-        }
+        for (int r = 0; r < 4; ++r) st[jt][r] = (jt * 16 + 4 * g + r < p.Tk) ? st[jt][r] : -INFINITY;
       }
-    } else {
+    }
+#pragma unroll
+    for (int jt = 0; jt < 2 * NB; ++jt) mx = fmaxf(mx, fmaxf(fmaxf(st[jt][0], st[jt][1]), fmaxf(st[jt][2], st[jt][3])));
+    mx = group_max(mx) * sl2;
+    const f32x4 sc4 = {sl2, sl2, sl2, sl2}, nm4 = {-mx, -mx, -mx, -mx};
+    f32x4 l4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < 2 * NB; ++jt) {
+      const f32x4 x = __builtin_elementwise_fma(st[jt], sc4, nm4);
+      f32x4 e;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(x[r]);  // raw v_exp_f32: arguments are <= 0
+      st[jt] = e;
+      l4 += e;
+    }
+    l = group_sum((l4[0] + l4[1]) + (l4[2] + l4[3]));
+  } else {
+#pragma unroll
+    for (int jt = 0; jt < 2 * NB; ++jt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = jt * 16 + 4 * g + r;
@@ -254,19 +263,18 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnParams p) {
         mx = fmaxf(mx, x);
       }
     }
-  }
-  mx = group_max(mx);
-  float l = 0.f;
+    mx = group_max(mx);
 #pragma unroll
-  for (int jt = 0; jt < 2 * NB; ++jt) {
+    for (int jt = 0; jt < 2 * NB; ++jt) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float e = __builtin_amdgcn_exp2f(st[jt][r] - mx);  // raw v_exp_f32: arguments are <= 0
-      st[jt][r] = e;
-      l += e;
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(st[jt][r] - mx);  // raw v_exp_f32: arguments are <= 0
+        st[jt][r] = e;
+        l += e;
+      }
     }
+    l = group_sum(l);
   }
-  l = group_sum(l);
 
   // O^T[d][i] = sum_j V^T[d][j] P^T[j][i]   (operands swapped: lane ends with 4 consecutive d of row i)
   f32x4 ot[4];
@@ -469,11 +477,12 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_kernel(AttnParams p, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Persistent forms of the three resident kernels (PLAIN only, sequence lengths 129 .. 256 = the ViT step).
+// Persistent form of the dK/dV pass (PLAIN only, sequence lengths 129 .. 256 = the ViT step).
 // One 16-wave workgroup per CU walks (batch, head) pairs; the operands of the NEXT head stream into a second LDS buffer
 // while the waves work on the current one.  In the one-shot kernels above the prologue DMA (57 KB per head) is not
-// covered by anything: every workgroup of a launch sits in it at the same time (dK/dV pass: 105 us, 56 us without the DMA,
-// profiles/r02/attn_vit_ablation.log).  The DMA / statistics loads of the next head are issued UNCONDITIONALLY (out of
+// covered by anything: every workgroup of a launch sits in it at the same time.  Worth 8 % on this pass alone and 40 us of
+// its in-step duration, nothing on the wall clock of the step (profiles/r02/attn_vit_ablation.log); the same form of the
+// forward and dQ passes was built, measured (no gain alone or in the step) and removed.  The DMA / statistics loads of the next head are issued UNCONDITIONALLY (out of
 // range offsets when there is no next head), right after this head's own fragment loads, so that the compiler's vmcnt
 // bookkeeping can wait for the fragments while the younger DMA stays in flight.
 // ------------------------------------------------------------------------------------------------
