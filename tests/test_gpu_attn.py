@@ -301,4 +301,4 @@ def test_attention_module_dropout_trains_and_is_off_in_eval():
     acc = torch.zeros_like(y_eval, dtype=torch.float32)
     for _ in range(600):
         acc += m(x, x, x).output.float()
-    assert_close(acc / 600, y_eval.float(), 6e-2, "mean over dropout masks")  # (measured 1.5e-2 .. 2.5e-2 at 200 draws)
+    assert_close(acc / 600, y_eval.float(), 6e-2, "mean over dropout masks")
