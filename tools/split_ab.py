@@ -9,7 +9,9 @@ from cflearn_amd import ops
 from cflearn_amd.engine import TrainStep
 
 BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-TARGETS = [512, 256, 384, 768, 1024]
+TARGETS = [int(v) for v in os.environ.get("SPLIT_TARGETS", "512,256,384,768,1024").split(",")]
+if os.environ.get("GEMM_HEURISTIC"):
+    ops.set_option("gemm_heuristic", int(os.environ["GEMM_HEURISTIC"]))
 STATE = {"target": 512}
 
 
