@@ -1107,7 +1107,7 @@ int launch_layout(GemmParams p, int a_trans, int b_trans, int epilogue, int spli
 int pick_config(int M, int N, int a_trans, int b_trans) {
   if (g_gemm_config >= 0 && g_gemm_config < NUM_CFG) return g_gemm_config;
   if (g_gemm_heuristic >= 6) {
-    if (a_trans) return 1;  // (192x128x64 is 10 % faster alone on the dW forms and 1.2 % slower in the step at any split factor)
+    if (a_trans) return 1;  // (192x128x64 is 10 % faster alone on the dW forms and 1.2 % slower in the step)
     if (M >= 1024) {
       if (b_trans) return 8;
       return N >= 2560 ? 14 : 0;
