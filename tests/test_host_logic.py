@@ -296,3 +296,28 @@ def test_lazy_zero_grad_with_gradients_that_arrive_through_autograd():
         assert torch.equal(b.grad, torch.full((5,), 2.0 + step))
         assert torch.equal(c.grad, torch.zeros(3))
         assert a.grad.data_ptr() == arena.grad_view(a).data_ptr()
+
+
+def test_unet_variant_state_dict_keys_and_shapes_match_reference(golden):
+    """Every UNet option of round 2 builds the reference's parameter layout (names, order, shapes): reference-made
+    checkpoints load — `MultiHeadSpatialAttention` (both head layouts), the scale-shift residual block (time embedding of
+    2 x out_channels), the class-conditional pixel-attention UNet with ResBlock resampling, the Linear-projection
+    spatial-transformer UNet."""
+    from cflearn_amd.modules import MultiHeadSpatialAttention, ResidualBlockWithTimeEmbedding
+
+    g = golden("unet_variants.pt")
+
+    def same(m, sd):
+        mine = m.state_dict()
+        assert list(mine.keys()) == list(sd.keys())
+        for k in sd:
+            assert tuple(mine[k].shape) == tuple(sd[k].shape), k
+        m.load_state_dict(sd)
+
+    for c in g["mhsa"]:
+        same(MultiHeadSpatialAttention(**c["cfg"]), c["sd"])
+    same(ResidualBlockWithTimeEmbedding(**g["scale_shift"]["cfg"]), g["scale_shift"]["sd"])
+    for c in g["unets"]:
+        m = C.build_module("unet_diffuser", config=dict(c["cfg"]))
+        same(m, c["sd"])
+        assert sum(p.numel() for p in m.parameters()) == sum(v.numel() for v in c["sd"].values())
