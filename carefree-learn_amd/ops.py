@@ -189,16 +189,18 @@ def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) ->
 
 
 def layernorm_fwd(
-    x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out: Optional[Tensor] = None
+    x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out: Optional[Tensor] = None,
+    mean: Optional[Tensor] = None, rstd: Optional[Tensor] = None,
 ) -> Tuple[Tensor, Tensor, Tensor]:
-    """x: bf16 or f32 [M, D] (row stride free) -> y bf16 [M, D], mean f32 [M], rstd f32 [M]."""
+    """x: bf16 or f32 [M, D] (row stride free) -> y bf16 [M, D], mean f32 [M], rstd f32 [M] (`out` / `mean` / `rstd`:
+    caller-owned destinations, e.g. row slices of larger tensors)."""
     _need(x, x.dtype if x.dtype in (bf16, f32) else bf16, "x")
     _need(gamma, f32, "gamma")
     _need(beta, f32, "beta")
     m, d, xs = _mat(x, "x")
     y = torch.empty((m, d), dtype=bf16, device=x.device) if out is None else out
-    mean = torch.empty((m,), dtype=f32, device=x.device)
-    rstd = torch.empty((m,), dtype=f32, device=x.device)
+    mean = torch.empty((m,), dtype=f32, device=x.device) if mean is None else mean
+    rstd = torch.empty((m,), dtype=f32, device=x.device) if rstd is None else rstd
     rc = _lib.load().cfhip_layernorm_fwd(
         x.data_ptr(), int(x.dtype == f32), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
         rstd.data_ptr(), m, d, xs, y.stride(0), float(eps), _stream(),
@@ -281,7 +283,7 @@ def _mask_args(mask: Optional[Tensor], b: int, h: int, tq: int, tk: int):
 def attn_fwd(
     q: Tensor, k: Tensor, v: Tensor, num_heads: int, *, mask: Optional[Tensor] = None,
     causal: bool = False, scale: Optional[float] = None, head_dim: int = 64, dropout_p: float = 0.0,
-    seed: int = 0, offset: int = 0,
+    seed: int = 0, offset: int = 0, out: Optional[Tensor] = None, lse: Optional[Tensor] = None,
 ) -> Tuple[Tensor, Tensor]:
     """Returns (o bf16 [B, Tq, H*head_dim] contiguous, lse f32 [B, H, Tq]).  head_dim 64 with both lengths <= 256
     takes the LDS-resident kernels; anything else (head_dim any multiple of 8 up to 192) the chunked general ones.
@@ -296,8 +298,8 @@ def attn_fwd(
         raise ValueError("cfhip attention: k and v must share batch / token strides")
     if scale is None:
         scale = 1.0 / math.sqrt(float(head_dim))
-    o = torch.empty((b, tq, d), dtype=bf16, device=q.device)
-    lse = torch.empty((b, num_heads, tq), dtype=f32, device=q.device)
+    o = torch.empty((b, tq, d), dtype=bf16, device=q.device) if out is None else out
+    lse = torch.empty((b, num_heads, tq), dtype=f32, device=q.device) if lse is None else lse
     keep, mp, ms_b, ms_h, ms_q = _mask_args(mask, b, num_heads, tq, tk)
     if FLOP_COUNTER is not None:
         FLOP_COUNTER.flops["attention"] += 4.0 * b * num_heads * tq * tk * head_dim

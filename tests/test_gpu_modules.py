@@ -299,3 +299,34 @@ def test_post_norm_stack_and_positional_interpolation_golden(golden):
                  abs_floor=1e-3)
     with pytest.raises(ValueError):
         v(it["img"].to(DEV))  # like upstream: a non-native resolution needs hwp
+
+
+def test_forward_slices_on_streams_are_bit_equal_to_one_pass(golden):
+    """`fused.FWD_HALVES`: the block stack's forward as 2 / 3 batch-slice pipelines on separate streams gives the same
+    bits as one pass — logits and every parameter gradient (the backward is the same full-batch pass either way)"""
+    from cflearn_amd import fused
+
+    g = golden("vit_small.pt")
+    cfg = dict(g["cfg"])
+    m = C.build_module("cv_clf", config=dict(in_channels=3, num_classes=g["num_classes"], img_size=cfg.pop("img_size"),
+                                             latent_dim=cfg["latent_dim"], encoder="vit", encoder_config=cfg))
+    m.load_state_dict(g["sd"])
+    m = m.to(DEV)
+    torch.manual_seed(3)
+    x = torch.randn(9, *g["x"].shape[1:], device=DEV)
+    keep = fused.FWD_HALVES
+    try:
+        res = {}
+        for v in (1, 2, 3):
+            fused.FWD_HALVES = v
+            m.zero_grad(set_to_none=True)
+            y = m(x)
+            y = y["predictions"] if isinstance(y, dict) else y
+            y.float().square().mean().backward()
+            torch.cuda.synchronize()
+            res[v] = (y.detach().clone(), [p.grad.detach().clone() for p in m.parameters()])
+        for v in (2, 3):
+            assert torch.equal(res[1][0], res[v][0]), v
+            assert all(torch.equal(a, b) for a, b in zip(res[1][1], res[v][1])), v
+    finally:
+        fused.FWD_HALVES = keep
