@@ -303,17 +303,13 @@ def test_post_norm_stack_and_positional_interpolation_golden(golden):
 
 def test_forward_slices_on_streams_are_bit_equal_to_one_pass(golden):
     """`fused.FWD_HALVES`: the block stack's forward as 2 / 3 batch-slice pipelines on separate streams gives the same
-    bits as one pass — logits and every parameter gradient (the backward is the same full-batch pass either way)"""
+    bits as one pass for the logits, and the same gradients (the backward is the same full-batch pass either way)"""
     from cflearn_amd import fused
 
     g = golden("vit_small.pt")
-    cfg = dict(g["cfg"])
-    m = C.build_module("cv_clf", config=dict(in_channels=3, num_classes=g["num_classes"], img_size=cfg.pop("img_size"),
-                                             latent_dim=cfg["latent_dim"], encoder="vit", encoder_config=cfg))
-    m.load_state_dict(g["sd"])
-    m = m.to(DEV)
+    m = _small_vit(g)
     torch.manual_seed(3)
-    x = torch.randn(9, *g["x"].shape[1:], device=DEV)
+    x = torch.randn(9, *g["img"].shape[1:], device=DEV)
     keep = fused.FWD_HALVES
     try:
         res = {}
@@ -327,6 +323,10 @@ def test_forward_slices_on_streams_are_bit_equal_to_one_pass(golden):
             res[v] = (y.detach().clone(), [p.grad.detach().clone() for p in m.parameters()])
         for v in (2, 3):
             assert torch.equal(res[1][0], res[v][0]), v
-            assert all(torch.equal(a, b) for a, b in zip(res[1][1], res[v][1])), v
+            # (this fixture's width 128 takes the round-1 LayerNorm backward, whose dgamma / dbeta fold uses LDS float
+            # atomics: run-to-run differences of an ulp; at ViT-B/16 size every gradient is bit-equal too —
+            # tools/fwd_halves_ab.py, profiles/r02/fwd_halves_ab.log)
+            for a, b in zip(res[1][1], res[v][1]):
+                assert_close(b, a, 1e-5, f"gradient with {v} forward slices", abs_floor=1e-7)
     finally:
         fused.FWD_HALVES = keep
