@@ -44,14 +44,24 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
 def gemm_shapes(batch: int, t: int = 197, d: int = 768, dff: int = 3072, layers: int = 12, classes: int = 1000):
-    """(count, layout, M, N, K, epilogue) of every GEMM launch in one training step."""
+    """(count, layout, M, N, K, epilogue) of every GEMM launch in one training step.  The forward of the block stack runs
+    as `fused.FWD_HALVES` batch slices (one launch per slice and operator); the backward is one pass over the batch."""
+    from cflearn_amd import fused
+
     m = batch * t
     mp = batch * (t - 1)
     L = layers
-    return [
-        # forward (k-major x k-major)
-        (L, "nt", m, 3 * d, d, "bias"), (L, "nt", m, d, d, "residual"), (L, "nt", m, dff, d, "gelu"),
-        (L, "nt", m, d, dff, "residual"), (1, "nt", mp, d, d, "bias"), (1, "nt", batch, classes, d, "bias"),
+    nsl = fused.FWD_HALVES if batch >= 2 * fused.FWD_HALVES else 1
+    fwd = []
+    for i in range(nsl):
+        ms = (batch * (i + 1) // nsl - batch * i // nsl) * t
+        fwd += [(L, "nt", ms, 3 * d, d, "bias"), (L, "nt", ms, d, d, "residual"), (L, "nt", ms, dff, d, "gelu"),
+                (L, "nt", ms, d, dff, "residual")]
+    merged = {}
+    for c, lay, mm, n, k, e in fwd:  # equal slices are one shape with twice the count
+        merged[(lay, mm, n, k, e)] = merged.get((lay, mm, n, k, e), 0) + c
+    return [(c,) + key for key, c in merged.items()] + [
+        (1, "nt", mp, d, d, "bias"), (1, "nt", batch, classes, d, "bias"),
         # backward dX = dY W (W read n-major through the transposing LDS read)
         (L, "nn", m, dff, d, "dgelu"), (L, "nn", m, d, dff, "none"), (L, "nn", m, d, d, "none"),
         (L, "nn", m, d, 3 * d, "none"), (1, "nn", batch, d, classes, "none"),

@@ -1,8 +1,13 @@
 #!/bin/bash
-# reduced round-end evidence (when little GPU budget is left): full GPU suite, smoke, the default bench line
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "== pytest -m gpu exit $?"; tail -n 3 gpurun_out/pytest_gpu.log
-timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "== smoke exit $?"; tail -n 1 gpurun_out/smoke.log
-timeout 400 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "== bench exit $?"; grep "timed region\|GEMM roofline" gpurun_out/bench.err; tail -c 600 gpurun_out/bench.json
+O=gpurun_out/final
+mkdir -p $O
+timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "== pytest -m gpu exit $?"; grep -E "passed|failed" $O/pytest_gpu.log | tail -1
+timeout 420 python bench.py > $O/bench.json 2> $O/bench.err; echo "== bench exit $?"; grep "bench +" $O/bench.err | tail -3
+timeout 200 python bench.py --batch 64 --no-cpu-baseline > $O/bench_b64.json 2>/dev/null; echo "== b64 exit $?"
+python - <<'PY'
+import json
+for n in ('bench', 'bench_b64'):
+    d=json.loads(open(f'gpurun_out/final/{n}.json').read().strip().split('\n')[-1]); r=d.get('roofline', {})
+    print(n, d['value'], d['ms_per_step'], r.get('achieved'), r.get('frac'), r.get('wall', {}).get('achieved'), r.get('isolated', {}).get('achieved'), r.get('traffic'), d.get('cpu_baseline', {}).get('value'))
+PY
