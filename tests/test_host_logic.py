@@ -321,3 +321,21 @@ def test_unet_variant_state_dict_keys_and_shapes_match_reference(golden):
         m = C.build_module("unet_diffuser", config=dict(c["cfg"]))
         same(m, c["sd"])
         assert sum(p.numel() for p in m.parameters()) == sum(v.numel() for v in c["sd"].values())
+
+
+def test_bench_gemm_shapes_conserve_flops_under_forward_slices():
+    """bench.gemm_shapes lists the launches of one step; slicing the forward changes the launch shapes, not the work"""
+    import bench
+    from cflearn_amd import fused
+
+    keep = fused.FWD_HALVES
+    try:
+        totals = []
+        for v in (1, 2, 3):
+            fused.FWD_HALVES = v
+            shapes = bench.gemm_shapes(128)
+            totals.append(sum(c * 2.0 * m * n * k for c, _, m, n, k, _ in shapes))
+            assert sum(c * m for c, lay, m, n, k, e in shapes if lay == "nt" and e == "gelu") == 12 * 128 * 197
+        assert totals[0] == totals[1] == totals[2] == 12910053556224.0
+    finally:
+        fused.FWD_HALVES = keep
