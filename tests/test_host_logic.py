@@ -339,3 +339,42 @@ def test_bench_gemm_shapes_conserve_flops_under_forward_slices():
         assert totals[0] == totals[1] == totals[2] == 12910053556224.0
     finally:
         fused.FWD_HALVES = keep
+
+
+def test_scale_shift_affine_function_matches_autograd():
+    """`functional.ScaleShiftAffineFn` (the per-sample affine the scale-shift GroupNorm kernel is fed, residual.py:236-239):
+    outputs and all four gradients against plain autograd; the parameter gradients follow the direct-write protocol."""
+    from cflearn_amd import functional as HF
+
+    torch.manual_seed(0)
+    b, c = 3, 8
+    gamma, beta = torch.randn(c, requires_grad=True), torch.randn(c, requires_grad=True)
+    scale, shift = torch.randn(b, c, requires_grad=True), torch.randn(b, c, requires_grad=True)
+    ge, be = HF.scale_shift_affine(gamma, beta, scale, shift)
+    wg, wb = torch.randn(b, c), torch.randn(b, c)
+    ((ge * wg).sum() + (be * wb).sum()).backward()
+    g2, b2, s2, t2 = (t.detach().clone().requires_grad_(True) for t in (gamma, beta, scale, shift))
+    ge2 = g2[None] * (1 + s2)
+    be2 = b2[None] * (1 + s2) + t2
+    ((ge2 * wg).sum() + (be2 * wb).sum()).backward()
+    assert torch.allclose(ge, ge2.detach()) and torch.allclose(be, be2.detach())
+    for mine, ref in ((gamma, g2), (beta, b2), (scale, s2), (shift, t2)):
+        assert torch.allclose(mine.grad, ref.grad, atol=1e-6), (mine.grad, ref.grad)
+    # second use accumulates into the same .grad (not 'fresh'): twice the gradient
+    ge, be = HF.scale_shift_affine(gamma, beta, scale.detach(), shift.detach())
+    ((ge * wg).sum() + (be * wb).sum()).backward()
+    assert torch.allclose(gamma.grad, 2 * g2.grad, atol=1e-6) and torch.allclose(beta.grad, 2 * b2.grad, atol=1e-6)
+
+
+def test_attention_dropout_counter_accounting():
+    """every attention call with dropout reserves exactly its B * H * ceil(Tq/4) * ceil(Tk/4) Philox counters, so no two
+    calls (and no call and its neighbours in the stream) share random bits"""
+    from cflearn_amd import functional as HF, ops
+
+    ops.PhiloxState.manual_seed(11)
+    kw1 = HF._take_attn_dropout(0.1, 2, 3, 197, 197)
+    kw2 = HF._take_attn_dropout(0.25, 1, 1, 5, 9)
+    assert kw1["offset"] == 0 and kw1["seed"] == 11 and kw1["dropout_p"] == 0.1
+    assert kw2["offset"] == ops.attn_dropout_blocks(2, 3, 197, 197) == 2 * 3 * 50 * 50
+    assert ops.PhiloxState.offset == kw2["offset"] + 1 * 1 * 2 * 3
+    assert HF._take_attn_dropout(0.0, 2, 3, 4, 4) == {} and HF._take_attn_dropout(1.0, 2, 3, 4, 4) == {}
