@@ -378,3 +378,24 @@ def test_attention_dropout_counter_accounting():
     assert kw2["offset"] == ops.attn_dropout_blocks(2, 3, 197, 197) == 2 * 3 * 50 * 50
     assert ops.PhiloxState.offset == kw2["offset"] + 1 * 1 * 2 * 3
     assert HF._take_attn_dropout(0.0, 2, 3, 4, 4) == {} and HF._take_attn_dropout(1.0, 2, 3, 4, 4) == {}
+
+
+def test_whole_param_resolves_reshaped_views_only():
+    """`functional.whole_param`: a contiguous view of a WHOLE leaf parameter (a 1x1 filter seen as its GEMM matrix) is
+    written through its base parameter; slices, permutations and non-leaf tensors keep the autograd route."""
+    from cflearn_amd.functional import whole_param
+
+    w = torch.nn.Parameter(torch.randn(6, 4, 1, 1))
+    assert whole_param(w) is w
+    assert whole_param(w.view(6, 4)) is w
+    assert whole_param(w.view(6, -1)) is w
+    sl = w.view(6, 4)[2:5]
+    assert whole_param(sl) is sl
+    pm = w.view(2, 3, 4).transpose(0, 1).reshape(6, 4)  # a copy: not a view of the storage in order
+    assert whole_param(pm) is pm
+    frozen = torch.nn.Parameter(torch.randn(3, 3), requires_grad=False)
+    v = frozen.view(9)
+    assert whole_param(v) is v
+    assert whole_param(None) is None
+    h = torch.randn(4, 4)  # a non-parameter leaf that does not require grad
+    assert whole_param(h.view(16)) is not h
