@@ -43,9 +43,12 @@ FLOP_PER_SAMPLE = 105.38e9  # fwd + bwd, SURVEY §8d (17 563 828 224 MAC fwd x 2
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def gemm_shapes(batch: int, t: int = 197, d: int = 768, dff: int = 3072, layers: int = 12, classes: int = 1000):
+def gemm_shapes(batch: int, t: int = 197, d: int = 768, dff: int = 3072, layers: int = 12, classes: int = 1000,
+                grouped=None):
     """(count, layout, M, N, K, epilogue) of every GEMM launch in one training step.  The forward of the block stack runs
-    as `fused.FWD_HALVES` batch slices (one launch per slice and operator); the backward is one pass over the batch."""
+    as `fused.FWD_HALVES` batch slices (one launch per slice and operator); the backward is one pass over the batch.
+    The weight gradients of the blocks are grouped launches (`fused.DW_GROUP_BLOCKS` blocks each; `grouped=False`: the
+    per-GEMM rows): (count, "tn-grouped", ((M, N, K), ...), 0, 0, "none")."""
     from cflearn_amd import fused
 
     m = batch * t
@@ -60,15 +63,30 @@ def gemm_shapes(batch: int, t: int = 197, d: int = 768, dff: int = 3072, layers:
     merged = {}
     for c, lay, mm, n, k, e in fwd:  # equal slices are one shape with twice the count
         merged[(lay, mm, n, k, e)] = merged.get((lay, mm, n, k, e), 0) + c
-    return [(c,) + key for key, c in merged.items()] + [
-        (1, "nt", mp, d, d, "bias"), (1, "nt", batch, classes, d, "bias"),
-        # backward dX = dY W (W read n-major through the transposing LDS read)
-        (L, "nn", m, dff, d, "dgelu"), (L, "nn", m, d, dff, "none"), (L, "nn", m, d, d, "none"),
-        (L, "nn", m, d, 3 * d, "none"), (1, "nn", batch, d, classes, "none"),
-        # backward dW = dY^T X (both operands token-major), split-K
-        (L, "tn", d, dff, m, "none"), (L, "tn", dff, d, m, "none"), (L, "tn", d, d, m, "none"),
-        (L, "tn", 3 * d, d, m, "none"), (1, "tn", d, d, mp, "none"), (1, "tn", classes, d, batch, "none"),
-    ]
+    # backward dX = dY W (W read n-major through the transposing LDS read): `fused.BWD_HALVES` batch slices as well
+    nbs = fused.BWD_HALVES if batch >= 2 * fused.BWD_HALVES else 1
+    bwd = {}
+    for i in range(nbs):
+        ms = (batch * (i + 1) // nbs - batch * i // nbs) * t
+        for key in (("nn", ms, dff, d, "dgelu"), ("nn", ms, d, dff, "none"), ("nn", ms, d, d, "none"), ("nn", ms, d, 3 * d, "none")):
+            bwd[key] = bwd.get(key, 0) + L
+    return [(c,) + key for key, c in merged.items()] + [(c,) + key for key, c in bwd.items()] + [
+        (1, "nt", mp, d, d, "bias"), (1, "nt", batch, classes, d, "bias"), (1, "nn", batch, d, classes, "none"),
+        # backward dW = dY^T X (both operands token-major)
+        (1, "tn", d, d, mp, "none"), (1, "tn", classes, d, batch, "none"),
+    ] + _dw_rows(L, d, dff, m, fused.DW_GROUP_BLOCKS if grouped is None else (fused.DW_GROUP_BLOCKS if grouped else 0))
+
+
+def _dw_rows(L: int, d: int, dff: int, m: int, nb: int):
+    per_block = ((d, dff, m), (dff, d, m), (d, d, m), (3 * d, d, m))
+    if nb <= 0:  # round-1/2 path: one split-K GEMM (+ reduce) per weight gradient
+        return [(L, "tn") + sh + ("none",) for sh in per_block]
+    rows = []
+    if L // nb:
+        rows.append((L // nb, "tn-grouped", per_block * nb, 0, 0, "none"))
+    if L % nb:
+        rows.append((1, "tn-grouped", per_block * (L % nb), 0, 0, "none"))
+    return rows
 
 
 def time_gemms(batch: int, reps: int):
@@ -80,6 +98,29 @@ def time_gemms(batch: int, reps: int):
     tot_flops = tot_time = tot_bytes = 0.0
     for count, layout, m, n, k, epi in gemm_shapes(batch):
         bf = torch.bfloat16
+        if layout == "tn-grouped":
+            g = torch.Generator(device=dev).manual_seed(len(m))
+            rnd = lambda *s: (torch.randn(*s, generator=g, device=dev) * 0.5).to(bf)  # noqa: E731
+            probs = [(rnd(kk, mm), rnd(kk, nn), torch.empty(mm, nn, dtype=torch.float32, device=dev), False,
+                      torch.empty(mm, dtype=torch.float32, device=dev), False) for mm, nn, kk in m]
+            for _ in range(2):
+                ops.gemm_grouped_tn(probs)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ops.gemm_grouped_tn(probs)
+            e1.record()
+            e1.synchronize()
+            dur = e0.elapsed_time(e1) * 1e-3 / reps
+            flops = sum(2.0 * mm * nn * kk for mm, nn, kk in m)
+            nbytes = sum(2.0 * (mm * kk + nn * kk) + 4.0 * mm * nn for mm, nn, kk in m)
+            rows.append(dict(layout=layout, problems=[list(x) for x in m], count=count, us=round(dur * 1e6, 1),
+                             tflops=round(flops / dur / 1e12, 1), algorithmic_mb=round(nbytes / 1e6, 1)))
+            tot_flops += count * flops
+            tot_time += count * dur
+            tot_bytes += count * nbytes
+            del probs
+            continue
         g = torch.Generator(device=dev).manual_seed(m + n + k)
         rnd = lambda *s: (torch.randn(*s, generator=g, device=dev) * 0.5).to(bf)  # noqa: E731
         if layout == "nt":
@@ -165,11 +206,18 @@ def time_gemms_in_step(ts, batch_fn, steps: int):
         ops.GEMM_TIMER = None
     rows, tot_t, tot_f = [], 0.0, 0.0
     for (layout, m, n, k, epi), (count, secs) in sorted(timer.durations().items(), key=lambda kv: -kv[1][1]):
-        flops = 2.0 * m * n * k * count
+        if layout == "tn-grouped":  # m = ((M, N, K), ...) of one grouped weight-gradient launch
+            flops = sum(2.0 * mm * nn * kk for mm, nn, kk in m) * count
+            row = dict(layout=layout, problems=len(m), tiles=sum(((mm + 255) // 256) * ((nn + 255) // 256) for mm, nn, _ in m),
+                       K=m[0][2])
+        else:
+            flops = 2.0 * m * n * k * count
+            row = dict(layout=layout, M=m, N=n, K=k, epilogue=epi)
         tot_t += secs
         tot_f += flops
-        rows.append(dict(layout=layout, M=m, N=n, K=k, epilogue=epi, launches_per_step=round(count / steps, 2),
-                         us=round(secs / count * 1e6, 1), tflops=round(flops / secs / 1e12, 1)))
+        row.update(launches_per_step=round(count / steps, 2), us=round(secs / count * 1e6, 1), tflops=round(flops / secs / 1e12, 1),
+                   ms_per_step=round(secs / steps * 1e3, 3))
+        rows.append(row)
     return tot_f / steps, tot_t / steps, rows
 
 
@@ -289,15 +337,18 @@ def cpu_baseline(batch: int, steps: int, limit_s: float = 45.0):
 
 
 def bench_other_workload(args) -> None:
-    """`--workload unet | clip`: BASELINE configs 3 / 4 on ONE GPU (the multi-GPU path of these models is the same
-    `BucketedAllReduce`; their default batch follows SURVEY §8d).  One JSON line with the same keys; `roofline` is the
-    MFMA roofline of the whole step: counted MFMA-class FLOPs (ops.FlopCounter: GEMMs, implicit convolutions,
-    attention) / wall time."""
+    """`--workload unet | clip`: one JSON line for BASELINE config 3 / 4 on ONE GPU."""
+    print(json.dumps(run_other_workload(args)))
+
+
+def run_other_workload(args) -> dict:
+    """BASELINE configs 3 / 4 on ONE GPU (the multi-GPU path of these models is the same `BucketedAllReduce`; their
+    default batch follows SURVEY §8d).  A dict with the keys of the headline line; `roofline` is the MFMA roofline of the
+    whole step: counted MFMA-class FLOPs (ops.FlopCounter: GEMMs, implicit convolutions, attention) / wall time."""
     import cflearn_amd as C
     from cflearn_amd import ops
 
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
+    dev = torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(0)
     g = torch.Generator().manual_seed(1234)
     if args.workload == "unet":
@@ -353,7 +404,7 @@ def bench_other_workload(args) -> None:
     finally:
         ops.FLOP_COUNTER = None
     tf = counter.total() / dt / 1e12
-    print(json.dumps({
+    return {
         "metric": f"train samples/sec + step ms, {args.workload}", "value": round(batch / dt, 3), "unit": "samples/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -365,7 +416,49 @@ def bench_other_workload(args) -> None:
                      "definition": "algorithmic MFMA-class FLOPs of one step (ops.FlopCounter) / measured wall time of the step",
                      "flops_per_step": {k: v for k, v in counter.flops.items()}},
         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
-    }))
+    }
+
+
+def _pct(sorted_vals: list, q: float) -> float:
+    """q-quantile of an ascending list (linear interpolation)"""
+    if not sorted_vals:
+        return float("nan")
+    pos = q * (len(sorted_vals) - 1)
+    lo = int(math.floor(pos))
+    hi = min(lo + 1, len(sorted_vals) - 1)
+    return sorted_vals[lo] + (sorted_vals[hi] - sorted_vals[lo]) * (pos - lo)
+
+
+def launch_command(n: int, argv: list, port: int) -> list:
+    """The command line of `python -m torch.distributed.run` that starts `n` ranks of this script on this node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n: int, argv: list) -> int:
+    """Re-execute this script as `n` ranks under torch.distributed.run (one per GPU; with `--backend gloo --all-on-gpu0`
+    the ranks share cuda:0 — the dry run of the N > 1 path on a 1-GPU box).  Returns the launcher's exit code."""
+    import subprocess
+
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if "--all-on-gpu0" not in argv and visible < n:
+        print(f"[bench] --gpus {n} needs {n} visible GPUs, this node shows {visible} (dry run of the distributed path on one "
+              "GPU: add --backend gloo --all-on-gpu0)", file=sys.stderr)
+        return 2
+    env = dict(os.environ, CFHIP_BENCH_LAUNCHER="self", MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL peer buffers)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = launch_command(n, argv, free_port())
+    print(f"[bench] starting {n} ranks: {' '.join(cmd[1:10])} ...", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
 
 
 _T0 = time.perf_counter()
@@ -389,6 +482,8 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true", help="(default now) kept for compatibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the bounded UNet 64^2 x 8 / CLIP b256 runs (BASELINE configs 3 / 4) appended to the default N = 1 line")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--workload", default="vit", choices=["vit", "unet", "clip"],
                     help="vit (default: the headline metric, BASELINE configs[1/2]); unet / clip: configs 3 / 4 on one GPU")
@@ -430,6 +525,10 @@ def main() -> None:
 
         faulthandler.dump_traceback_later(args.watchdog, repeat=True, file=sys.stderr)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` from a plain shell: start the N ranks ourselves (the reference launches its own ranks
+        # too: api/api.py:269-293 run_accelerate -> `accelerate launch`); rank 0's JSON line passes through
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if "--all-on-gpu0" in sys.argv else int(os.environ.get("LOCAL_RANK", "0"))
@@ -447,9 +546,9 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=dev)  # "nccl" == RCCL on ROCm
         else:
             dist.init_process_group(args.backend)
-    if args.gpus != world and not (args.force_ddp or args.all_on_gpu0):
-        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: start one rank per GPU "
-                         "(python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N)")
+    if args.gpus != world and not args.force_ddp:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started by an external launcher with WORLD_SIZE={world}: the "
+                         "two must agree (plain `python bench.py --gpus N` starts its own N ranks)")
     if distributed:
         assert dist.get_world_size() == world
 
@@ -464,6 +563,7 @@ def main() -> None:
         return TrainStep(model, lr=1.0e-4, weight_decay=0.0, decoupled=True, use_graph=args.graph and not args.no_graph,
                          distributed=distributed, bucket_bytes=args.bucket_mb << 20, wire_bf16=args.wire_bf16, comm=comm)
 
+    comm_selftest = None
     if args.comm == "cfhip":
         # The C-ABI communicator has only ever run with one rank on the builder's 1-GPU boxes: check it before trusting it.
         # (1) a watchdog ends the process loudly if its creation / first collective does not come back (a hang here must
@@ -494,6 +594,7 @@ def main() -> None:
         except RuntimeError as e:  # the RCCL communicator could not be created
             ok, why = 0, str(e)
         dog.cancel()
+        comm_selftest = "all-reduce of (rank + 1) over the cfhip communicator == W (W + 1) / 2: ok" if ok else f"failed: {why}"
         if distributed:
             flag = torch.tensor([ok], device=dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -555,11 +656,17 @@ def main() -> None:
         ts.reducer.exposed_ms()  # drop the warm-up records
     sync()
     note("warm-up done, timing")
+    # per-step durations: one HIP event between steps on the stream the step is issued on (the side streams join it
+    # before the optimizer kernel, so consecutive events bracket whole steps) — SURVEY §8d: median, p10, p90
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = ts.step(*next_batch())
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if distributed:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -597,7 +704,19 @@ def main() -> None:
             "loss_last_step": round(last_loss, 4),
         },
         "mfma_frac_whole_step": round(samples_per_s * FLOP_PER_SAMPLE / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+        "step_ms": {"median": round(_pct(per_step, 0.5), 3), "p10": round(_pct(per_step, 0.1), 3),
+                    "p90": round(_pct(per_step, 0.9), 3), "min": round(per_step[0], 3), "max": round(per_step[-1], 3),
+                    "n": len(per_step), "definition": "HIP events between consecutive steps on the issuing stream (this rank)"},
+        "launcher": {"self": "bench.py started its own ranks (torch.distributed.run)", None: "external"}[
+            os.environ.get("CFHIP_BENCH_LAUNCHER")] if distributed else "single process",
     }
+    if distributed:
+        result["rccl"] = {
+            "ranks": dist.get_world_size(), "backend": args.backend, "collectives_launched_by": args.comm,
+            "communicator_ranks": (ts.reducer.comm.world if (ts.reducer is not None and ts.reducer.comm is not None) else None),
+            "self_test": comm_selftest, "buckets": len(ts.reducer.buckets) if ts.reducer is not None else 0,
+            "bucket_mb": args.bucket_mb, "wire": "bf16" if args.wire_bf16 else "fp32",
+        }
     if ts.reducer is not None:
         ex = ts.reducer.exposed_ms()
         if ex:
@@ -639,6 +758,31 @@ def main() -> None:
                              "frac": round(gbps / 8000.0, 4), "source": traffic_src}
     if distributed:
         dist.barrier()
+    if rank == 0 and world == 1 and not args.no_other_workloads and not args.force_ddp:
+        # BASELINE configs 3 and 4 ride on the default run (a few steps each) so that the driver's own clock sees them
+        import copy
+        import gc
+
+        del ts, model
+        gc.collect()
+        torch.cuda.empty_cache()
+        others = {}
+        for wl, kw in (("unet", dict(img=64, steps=3, warmup=2)), ("clip", dict(steps=4, warmup=2))):
+            a2 = copy.copy(args)
+            a2.workload, a2.batch = wl, 128  # 128 = "the workload's default batch" (8 for the 64^2 UNet, 256 for CLIP)
+            for k_, v_ in kw.items():
+                setattr(a2, k_, v_)
+            note(f"other workload: {wl} ...")
+            try:
+                r = run_other_workload(a2)
+                others[wl] = {k_: r[k_] for k_ in ("value", "unit", "ms_per_step", "steps", "warmup", "roofline", "peak_mem_gb")}
+                others[wl]["workload"] = r["config"]["workload"]
+                others[wl]["per_gpu_batch"] = r["config"]["per_gpu_batch"]
+            except Exception as e:  # the headline line must survive a failure here
+                others[wl] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            gc.collect()
+            torch.cuda.empty_cache()
+        result["other_workloads"] = others
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         note("cpu baseline (the reference's PyTorch-CPU step on the host cores) ...")
         result["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)

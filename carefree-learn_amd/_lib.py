@@ -14,6 +14,17 @@ LIB_PATH = os.environ.get("CFHIP_LIB") or os.path.join(_HERE, "libcfhip.so")
 
 _lib: Optional[ctypes.CDLL] = None
 
+
+class GemmProblem(ctypes.Structure):
+    """`cfhip_gemm_problem` of include/cfhip.h (one weight-gradient GEMM of a grouped launch)."""
+
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias_grad", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("lda", c_int64), ("ldb", c_int64), ("ldc", c_int64),
+        ("accumulate", c_int), ("bias_grad_accumulate", c_int),
+    ]
+
 # name -> (restype, argtypes); mirrors include/cfhip.h line by line
 _P = c_void_p
 SIGNATURES = {
@@ -25,6 +36,7 @@ SIGNATURES = {
         [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int,
          c_int, c_int, c_int, _P, c_size_t, _P, c_int, _P],
     ),
+    "cfhip_gemm_bf16_grouped_tn": (c_int, [_P, c_int, _P]),
     "cfhip_colsum_workspace": (c_size_t, [c_int, c_int]),
     "cfhip_colsum_bf16": (c_int, [_P, _P, c_int, c_int, c_int64, c_int, _P, c_size_t, _P]),
     "cfhip_layernorm_fwd": (

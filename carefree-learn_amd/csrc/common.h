@@ -16,6 +16,22 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// One LDS-DMA instruction (buffer_load_dwordx4 ... lds: 64 lanes x 16 bytes -> LDS[lds_dst + 16 * lane], lds_dst wave-uniform)
+// as INLINE ASM.  Round 3: hipcc's s_waitcnt pass treats the builtin form (__builtin_amdgcn_raw_ptr_buffer_load_lds) as a
+// pending LDS store that may alias every later ds_read and puts `s_waitcnt vmcnt(0)` in front of the next LDS read — in the
+// K loops of the GEMM kernels that drained the DMA queue once per K-step, i.e. the rings never prefetched anything (the ISA
+// of every round-1/2 GEMM loop shows it: tools/isa_waits.py).  The asm form is invisible to that pass: completion is counted
+// by hand (CFHIP_WAIT_VMCNT, then a barrier, then the ds_read — the protocol the kernels were written for anyway).  M0 is
+// written in the same statement that reads it (the compiler neither preserves nor uses it around LDS instructions on gfx950).
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, const void* lds_dst, unsigned voff) {
+#ifdef CFHIP_DMA_BUILTIN  // A/B builds only (tools/build_variant.sh dmabuiltin -DCFHIP_DMA_BUILTIN): the round-1/2 form
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(const_cast<void*>(lds_dst)), 16, voff, 0, 0, 0);
+  return;
+#endif
+  const unsigned la = (unsigned)(uintptr_t)LDS_PTR(const_cast<void*>(lds_dst));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(rsrc) : "memory");
+}
+
 void cfhip_set_error(const char* fmt, ...);
 
 #define CFHIP_REQUIRE(cond, ...)          \

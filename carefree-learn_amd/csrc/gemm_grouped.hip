@@ -1,0 +1,275 @@
+// Grouped weight-gradient GEMM: up to 8 problems  dW_i[M_i][N_i] (+)= dY_i^T X_i  (and db_i (+)= colsum(dY_i)) in ONE launch.
+//
+// Replaces the parameter half of F.linear's autograd backward (reference modules/core/customs.py:89,
+// attentions.py:214: grad_weight = grad_output^T @ input, grad_bias = grad_output.sum(0)) for ALL Linear layers of one or
+// more transformer blocks at once.
+//
+// Why a group: one weight gradient of ViT-B/16 is 9 .. 36 tiles of 256 x 256 under a K = batch * tokens = 25 216 deep
+// reduction — far fewer tiles than the 256 CUs.  The one-GEMM-per-launch path filled the chip by cutting K into slices
+// (fp32 slabs + an ordered reduce launch per GEMM: 3 GB of slab traffic and 49 reduce launches per step).  Here the tiles of
+// several GEMMs share the chip instead: the four weight gradients of TWO blocks are 216 tiles = one round on 256 CUs, every
+// tile runs its whole reduction (788 K-steps of 32: prologue and store tail are noise), writes its output once, nothing is
+// split, no slabs, no second pass, deterministic.
+//
+// Kernel = the two-group phase structure of gemm_bf16_phase_kernel (gemm.hip) on 256 x 256 x 32 tiles, 8 waves of 128 x 64,
+// both operands m-major ([k][rows], rows contiguous: whole 512-byte lines per k-row whatever the K-step) read with
+// ds_read_b64_tr_b16, with two changes:
+//   * the LDS-DMA of K-step t + D is issued in the L (fragment-read) segments of K-step t — the A half in phase 0, the B half
+//     in phase 1 — instead of in front of the MFMAs of an M segment: a wave in its L segment does not own the SIMD's matrix
+//     pipe (its partner does), so the ~60-180 issue cycles of a DMA instruction no longer delay MFMAs;
+//   * every K-step issues its DMA unconditionally (K-steps beyond the reduction are out-of-range offsets: zero fill, no
+//     traffic), so every `s_waitcnt vmcnt` in the loop is the same compile-time count.
+// The bias gradient rides on the matrix pipe: colsum(dY) = dY^T 1, i.e. one extra MFMA with a ones operand per A fragment,
+// spread over the four column waves (one fragment per wave and phase) of the workgroups that own a first tile column.
+#include "gemm_device.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int GROUP_MAX = 8;
+
+struct GroupedProblem {
+  const bf16_t* A;  // dY  [K][M]  (m-major: element (m, k) at A[k * lda + m])
+  const bf16_t* B;  // X   [K][N]
+  float* C;         // dW  [M][N] f32
+  float* bgrad;     // db  [M] f32 or nullptr
+  int M, N, K;
+  int lda, ldb, ldc;
+  int tiles_n;
+  int tile_end;  // tiles of problems 0 .. this one (exclusive prefix sum)
+  int flags;     // bit 0: C += ; bit 1: bgrad +=
+};
+
+struct GroupedParams {
+  GroupedProblem pr[GROUP_MAX];
+  int count;
+};
+
+// Ring safety (by barrier count; intervals numbered as in gemm_bf16_phase_kernel: group 0 runs L(t, ph) in interval
+// 4t + 2ph and M(t, ph) in 4t + 2ph + 1, group 1 one interval later):
+//   WAR: the DMA of K-step t + D is issued in L(t, 0) / L(t, 1) (intervals >= 4t) into slot (t + D) % NSTAGE, which held
+//        K-step t + D - NSTAGE <= t - 2 (D <= NSTAGE - 2): last read in group 1's L(t - 2, 1), interval 4t - 5, retired by
+//        the lgkmcnt wait in front of its MFMAs in interval 4t - 4.
+//   RAW: every wave waits for its own DMA of K-step t + 1 (vmcnt((D - 1) * LPS): K-steps t + 2 .. t + D stay in flight)
+//        BEFORE the barrier that ends its L(t, 1) (intervals 4t + 2 / 4t + 3); the first read of K-step t + 1 is group 0's
+//        L(t + 1, 0) in interval 4t + 4.
+template <class C, int D, bool BG>
+__global__ __launch_bounds__(C::NT, 2)
+void gemm_grouped_tn_kernel(GroupedParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(C::BM == 256 && C::BN == 256 && C::BK == 32 && C::WM == 2 && C::WN == 4, "grouped dW kernel: 256 x 256 x 32, 2 x 4 waves");
+  static_assert(D >= 1 && D <= C::NSTAGE - 2, "DMA issued in L segments: prefetch distance <= NSTAGE - 2");
+  static_assert(C::A_INSTR == 2 && C::B_INSTR == 2, "two DMA instructions per operand, wave and K-step");
+  static_assert((D - 1) * C::LPS < 64, "vmcnt is a 6-bit counter");
+  constexpr int HM = C::FM / 2;  // row fragments per phase (4)
+
+  const int G = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = G >> 3, r8 = G & 7;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // problem of this tile: constant indices only (a run-time index into the by-value table would go through scratch)
+  GroupedProblem q = p.pr[0];
+  int first = 0;
+#pragma unroll
+  for (int i = 1; i < GROUP_MAX; ++i) {
+    if (i < p.count && item >= p.pr[i - 1].tile_end) {
+      q = p.pr[i];
+      first = p.pr[i - 1].tile_end;
+    }
+  }
+  const int tile = item - first;
+  const int tile_m = tile / q.tiles_n;
+  const int tile_n = tile - tile_m * q.tiles_n;
+  const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+  const int rows_a = q.M - m0, rows_b = q.N - n0;
+  const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(q.A + m0, ((long)(q.K - 1) * q.lda + rows_a) * 2);
+  const __amdgpu_buffer_rsrc_t b_rsrc = make_rsrc(q.B + n0, ((long)(q.K - 1) * q.ldb + rows_b) * 2);
+  const StagePlan<2> pa = make_plan<true, C::BM, 2, 32>(wave, lane, q.lda, rows_a);
+  const StagePlan<2> pb = make_plan<true, C::BN, 2, 32>(wave, lane, q.ldb, rows_b);
+  const int K = q.K;
+  const int nk = (K + 31) >> 5;
+
+  f32x4 acc[C::FM][C::FN];
+#pragma unroll
+  for (int mi = 0; mi < C::FM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::FN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accb0 = {0.f, 0.f, 0.f, 0.f}, accb1 = {0.f, 0.f, 0.f, 0.f};
+  const bool do_bg = BG && q.bgrad != nullptr && tile_n == 0;
+  const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+#pragma unroll
+  for (int st = 0; st < D; ++st) {
+    stage_tile<true>(a_rsrc, smem + st * C::STAGE_BYTES, wave, pa, q.lda, st * 32, K);
+    stage_tile<true>(b_rsrc, smem + st * C::STAGE_BYTES + C::A_BYTES, wave, pb, q.ldb, st * 32, K);
+  }
+  CFHIP_WAIT_VMCNT((D - 1) * C::LPS);  // K-step 0 has landed; the younger ones stay in flight
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // the stagger
+
+  // The K loop exists twice — with and without the bias-gradient MFMA — and the (workgroup-uniform) choice is made ONCE,
+  // outside: a branch inside the M segment broke the MFMA stream (register copies of the two accumulators + their hazard
+  // nops on every phase: the launch was 17 % slower with bias gradients than without, profiles/r03/gemm_grouped_bench.log).
+  // In a first-tile-column workgroup every wave issues ONE extra MFMA per phase: fragment `wn` of the phase's four, picked
+  // with wave-uniform selects (no run-time register index).
+  auto k_loop = [&](auto bg_tag) {
+    constexpr bool DO_BG = decltype(bg_tag)::value;
+    int rd = 0, wr = D;
+    for (int t = 0; t < nk; ++t) {
+      const char* a_tile = smem + rd * C::STAGE_BYTES;
+      const char* b_tile = a_tile + C::A_BYTES;
+      char* w_tile = smem + wr * C::STAGE_BYTES;
+      const int kw = (t + D) * 32;
+      bf16x8 bfr[C::FN], af[HM];
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        // ---- L segment: this phase's fragments, then half of the DMA of K-step t + D
+        if (ph == 0) {
+#pragma unroll
+          for (int n = 0; n < C::FN; ++n) bfr[n] = frag_mmajor<C::BN>(b_tile, wn * 64 + n * 16, 0, lane);
+        }
+#pragma unroll
+        for (int m = 0; m < HM; ++m) af[m] = frag_mmajor<C::BM>(a_tile, wm * 128 + (ph * HM + m) * 16, 0, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph == 0) {
+          stage_tile<true>(a_rsrc, w_tile, wave, pa, q.lda, kw, K);
+        } else {
+          stage_tile<true>(b_rsrc, w_tile + C::A_BYTES, wave, pb, q.ldb, kw, K);
+          CFHIP_WAIT_VMCNT((D - 1) * C::LPS);  // own DMA of K-step t + 1 retired
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- M segment (the compiler's lgkmcnt ladder in front of the MFMAs retires the fragment reads)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < HM; ++m)
+#pragma unroll
+          for (int n = 0; n < C::FN; ++n)
+            acc[ph * HM + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[n], af[m], acc[ph * HM + m][n], 0, 0, 0);
+        if constexpr (DO_BG) {
+          const bf16x8 mine = wn == 0 ? af[0] : wn == 1 ? af[1] : wn == 2 ? af[2] : af[3];
+          if (ph == 0) accb0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, mine, accb0, 0, 0, 0);
+          else accb1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, mine, accb1, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      rd = rd + 1 == C::NSTAGE ? 0 : rd + 1;
+      wr = wr + 1 == C::NSTAGE ? 0 : wr + 1;
+    }
+  };
+  if (do_bg) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // every wave has executed the same number of barriers
+  // the trailing (zero-fill) DMAs still target ring slots: retire them everywhere before the ring becomes the epilogue's strip
+  CFHIP_WAIT_VMCNT(0);
+  __builtin_amdgcn_s_barrier();
+
+  if constexpr (BG) {
+    // accb0 / accb1: colsum over k of fragment `wn` of phase 0 / 1 (rows (ph * 4 + wn) * 16 .. + 15 of the wave's 128)
+    if (do_bg && (lane >> 4) == 0) {
+      const int m = m0 + wm * 128 + wn * 16 + (lane & 15);
+      if (m < q.M) q.bgrad[m] = (q.flags & 2) ? q.bgrad[m] + accb0[0] : accb0[0];
+      if (m + 64 < q.M) q.bgrad[m + 64] = (q.flags & 2) ? q.bgrad[m + 64] + accb1[0] : accb1[0];
+    }
+  }
+  GemmParams gp;
+  gp.C = q.C;
+  gp.bias = nullptr;
+  gp.aux_in = nullptr;
+  gp.aux_out = nullptr;
+  gp.M = q.M;
+  gp.N = q.N;
+  gp.ldc = q.ldc;
+  gp.accumulate = q.flags & 1;
+  epilogue_f32<CFHIP_EPI_NONE, C>(gp, acc, smem, m0, n0, wm, wn, wave, lane);
+}
+
+using CfgG4 = Cfg<256, 256, 2, 4, 4, 32>;  // 128 KiB ring
+using CfgG5 = Cfg<256, 256, 2, 4, 5, 32>;  // 160 KiB ring (the whole LDS)
+
+int g_grouped_variant = 0;  // 0: 5-slot ring, DMA 3 K-steps ahead; 1: 4 slots, 2 ahead; 2: 5 slots, 2 ahead
+
+template <class C, int D, bool BG>
+int launch_grouped(const GroupedParams& p, int tiles, hipStream_t s) {
+  void (*kern)(GroupedParams) = gemm_grouped_tn_kernel<C, D, BG>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) {
+      cfhip_set_error("gemm_grouped: cannot reserve %d bytes of LDS: %s", C::LDS_BYTES, hipGetErrorString(e));
+      return CFHIP_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(C::NT), C::LDS_BYTES, s, p);
+  return CFHIP_OK;
+}
+
+template <bool BG>
+int launch_variant(const GroupedParams& p, int tiles, hipStream_t s) {
+  switch (g_grouped_variant) {
+    case 1: return launch_grouped<CfgG4, 2, BG>(p, tiles, s);
+    case 2: return launch_grouped<CfgG5, 2, BG>(p, tiles, s);
+    default: return launch_grouped<CfgG5, 3, BG>(p, tiles, s);
+  }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+int cfhip_internal_set_grouped_variant(int v) {
+  g_grouped_variant = v;
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_gemm_bf16_grouped_tn(const cfhip_gemm_problem* problems, int count, void* stream) {
+  CFHIP_REQUIRE(problems != nullptr && count > 0, "gemm_grouped: no problems");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  for (int base = 0; base < count; base += GROUP_MAX) {
+    const int n = count - base < GROUP_MAX ? count - base : GROUP_MAX;
+    GroupedParams p;
+    memset(&p, 0, sizeof(p));
+    p.count = n;
+    int tiles = 0;
+    bool any_bg = false;
+    for (int i = 0; i < n; ++i) {
+      const cfhip_gemm_problem& src = problems[base + i];
+      CFHIP_REQUIRE(src.A && src.B && src.C, "gemm_grouped: null operand in problem %d", base + i);
+      CFHIP_REQUIRE(src.M > 0 && src.N > 0 && src.K > 0, "gemm_grouped: empty problem %d (M=%d N=%d K=%d)", base + i, src.M, src.N, src.K);
+      CFHIP_REQUIRE(src.M % 8 == 0 && src.N % 8 == 0 && src.lda % 8 == 0 && src.ldb % 8 == 0 && src.ldc % 4 == 0,
+                    "gemm_grouped: problem %d: M, N, lda, ldb must be multiples of 8 and ldc of 4 (M=%d N=%d lda=%ld ldb=%ld ldc=%ld)",
+                    base + i, src.M, src.N, (long)src.lda, (long)src.ldb, (long)src.ldc);
+      CFHIP_REQUIRE(al16(src.A) && al16(src.B) && al16(src.C), "gemm_grouped: problem %d: operands must be 16-byte aligned", base + i);
+      CFHIP_REQUIRE((long)src.K * src.lda * 2 < 0x7fffffffL && (long)src.K * src.ldb * 2 < 0x7fffffffL && (long)src.M * src.ldc * 4 < 0x7fffffffL,
+                    "gemm_grouped: problem %d exceeds the 2 GiB descriptor range (K=%d lda=%ld ldb=%ld)", base + i, src.K, (long)src.lda, (long)src.ldb);
+      GroupedProblem& d = p.pr[i];
+      d.A = reinterpret_cast<const bf16_t*>(src.A);
+      d.B = reinterpret_cast<const bf16_t*>(src.B);
+      d.C = reinterpret_cast<float*>(src.C);
+      d.bgrad = src.bias_grad;
+      d.M = src.M; d.N = src.N; d.K = src.K;
+      d.lda = (int)src.lda; d.ldb = (int)src.ldb; d.ldc = (int)src.ldc;
+      d.tiles_n = (src.N + 255) / 256;
+      tiles += ((src.M + 255) / 256) * d.tiles_n;
+      d.tile_end = tiles;
+      d.flags = (src.accumulate ? 1 : 0) | (src.bias_grad_accumulate ? 2 : 0);
+      any_bg = any_bg || src.bias_grad != nullptr;
+    }
+    const int rc = any_bg ? launch_variant<true>(p, tiles, s) : launch_variant<false>(p, tiles, s);
+    if (rc != CFHIP_OK) return rc;
+    CFHIP_CHECK_LAUNCH("gemm_grouped_tn");
+  }
+  return CFHIP_OK;
+}

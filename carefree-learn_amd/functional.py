@@ -83,7 +83,7 @@ def distinct_stream(others: List["torch.cuda.Stream"], tries: int = 12) -> "torc
 
 class SideStream:
     enabled = True
-    lanes = 2  # side streams (0: dW GEMMs; 1: column sums / LayerNorm parameter grads)
+    lanes = 3  # side streams (0: weight-gradient launches, second forward slice; 1, 2: further batch slices of the forward / backward)
     heavy = True  # False: the dW GEMMs stay on the caller's stream, only the small reductions go aside
     streams: List[Optional["torch.cuda.Stream"]] = [None, None, None]
     keep: List[Tensor] = []  # operands produced on the main stream, alive until the join
@@ -111,8 +111,13 @@ class SideStream:
         cls.join()
 
     @classmethod
-    def run(cls, fn: Callable[[], None], keep: Tuple[Tensor, ...] = (), lane: int = 0) -> None:
+    def run(cls, fn: Callable[[], None], keep: Tuple[Tensor, ...] = (), lane: int = 0,
+            wait: Tuple["torch.cuda.Stream", ...] = ()) -> None:
+        """`fn` on the side stream of `lane`, ordered after the current stream and after every stream in `wait`
+        (operands written by other streams, e.g. the second batch slice of the backward pass)."""
         if not cls.enabled or not torch.cuda.is_available() or (lane == 0 and not cls.heavy):
+            for st in wait:
+                torch.cuda.current_stream().wait_stream(st)
             fn()
             return
         if not cls._join_queued:
@@ -122,10 +127,15 @@ class SideStream:
                 torch.autograd.Variable._execution_engine.queue_callback(cls._end_of_backward)
                 cls._join_queued = True
             except RuntimeError:  # not inside a backward pass: stay on the current stream
+                for st in wait:
+                    torch.cuda.current_stream().wait_stream(st)
                 fn()
                 return
         side = cls.get(lane)
         side.wait_stream(torch.cuda.current_stream())  # everything issued so far is visible
+        for st in wait:
+            if st is not side:
+                side.wait_stream(st)
         with torch.cuda.stream(side):
             fn()
         cls.keep.extend(keep)

@@ -60,11 +60,73 @@ def _dw_db(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> None:
             cb(prm)
 
 
+# Round 3: the weight gradients of DW_GROUP_BLOCKS consecutive blocks (4 GEMMs each) go out as ONE grouped launch
+# (ops.gemm_grouped_tn: 256 x 256 tiles of all problems share the chip, every tile runs its whole K = batch * tokens
+# reduction — no split-K slabs, no reduce launches).  ViT-B/16: 108 tiles per block, two blocks = 216 tiles = one round on
+# 256 CUs.  0 = the round-1/2 path (one split-K GEMM + reduce per weight gradient, issued beside its sibling dX GEMM).
+DW_GROUP_BLOCKS = 2
+DW_GROUP_ON_MAIN = False  # True: the grouped launch runs on the caller's stream (after the blocks' dX chain) instead of the side stream
+_pending_dw: list = []
+_slice_streams: list = []  # streams of the backward's batch slices beyond the caller's (what a dW launch has to wait for)
+
+
+def _groupable(w: Tensor, dy2: Tensor, x2: Tensor) -> bool:
+    n, k = w.shape[0], x2.shape[1]
+    return (dy2.is_cuda and w.dim() == 2 and w.is_contiguous() and n % 8 == 0 and k % 8 == 0 and dy2.stride(0) % 8 == 0
+            and x2.stride(0) % 8 == 0 and x2.shape[0] * max(dy2.stride(0), x2.stride(0)) * 2 < 2 ** 31
+            and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0)
+
+
+def _queue_dw(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> None:
+    """dW = dy^T x (+ db): queued for the next grouped launch, or issued now on the side stream (round-1/2 path)."""
+    if DW_GROUP_BLOCKS <= 0 or not _groupable(w, dy2, x2):
+        SideStream.run(lambda: _dw_db(w, b, dy2, x2), (dy2, x2), wait=tuple(_slice_streams))
+        return
+    _pending_dw.append((w, b, dy2, x2))
+
+
+def _flush_dw(wait: tuple = ()) -> None:
+    """One grouped launch for every queued weight gradient; gradients land straight in `.grad`.  `wait`: streams other
+    than the current one that wrote operands (the backward's second batch slice)."""
+    from .functional import grad_ready_callbacks
+
+    if not _pending_dw:
+        return
+    items = list(_pending_dw)
+    _pending_dw.clear()
+
+    def launch() -> None:
+        probs, done = [], []
+        for w, b, dy2, x2 in items:
+            prms = [w] + ([b] if (b is not None and b.requires_grad) else [])
+            for prm in prms:
+                if prm.grad is None:
+                    prm.grad = grad_buffer(prm)
+                    prm._cfhip_fresh = True
+            bg, acc_b = None, False
+            if len(prms) == 2 and not _SKIP_BIAS_GRAD:
+                bg, acc_b = b.grad.view(-1), not getattr(b, "_cfhip_fresh", False)
+            probs.append((dy2, x2, w.grad.view(w.shape[0], x2.shape[1]), not getattr(w, "_cfhip_fresh", False), bg, acc_b))
+            done.extend(prms)
+        ops.gemm_grouped_tn(probs)
+        for prm in done:
+            prm._cfhip_fresh = False
+            for cb in grad_ready_callbacks:
+                cb(prm)
+
+    if DW_GROUP_ON_MAIN:
+        for st in wait:
+            torch.cuda.current_stream().wait_stream(st)
+        launch()
+    else:
+        SideStream.run(launch, tuple(t for it in items for t in (it[2], it[3])), wait=wait)
+
+
 SPLIT_LN_BWD = False  # round 2: ONE launch (half-wave-per-row kernel, dy and x read once) beats dx on the main stream + dgamma/dbeta on the side stream by 0.5 ms / step (profiles/r02/step_ab_ln_b128.log)
 
 
 def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: Tensor,
-            dx_add: Optional[Tensor]) -> Tensor:
+            dx_add: Optional[Tensor], dx_out: Optional[Tensor] = None, notify: bool = True) -> Tensor:
     """LayerNorm backward, split in two launches: the input gradient (with the residual-gradient add
     fused) on the main stream — it is the critical path — and dgamma / dbeta (a streaming column
     reduction straight into `.grad`) on the side stream."""
@@ -85,11 +147,13 @@ def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: T
                     prm.grad.zero_()
             acc_w = True
         dx, _, _ = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dgamma=w.grad.view(-1), dbeta=b.grad.view(-1),
-                                     accumulate=acc_w, want_dx=with_dx, dx_add=dx_add if with_dx else None)
+                                     accumulate=acc_w, want_dx=with_dx, dx_add=dx_add if with_dx else None,
+                                     dx_out=dx_out if with_dx else None)
         for prm in (w, b):
             prm._cfhip_fresh = False
-            for cb in grad_ready_callbacks:
-                cb(prm)
+            if notify:  # (a batch-sliced backward notifies once, after the LAST slice has added its rows)
+                for cb in grad_ready_callbacks:
+                    cb(prm)
         return dx
 
     if not SPLIT_LN_BWD:
@@ -159,36 +223,80 @@ def _block_fwd(x2: Tensor, prm: tuple, num_heads: int, eps1: float, eps2: float,
 N_SAVED = 17  # tensors per block in `saved`
 
 
+# The backward of a block stack runs as BWD_HALVES batch-slice pipelines too (round 3): with the weight gradients gone
+# from the per-operator path (grouped launches on their own stream) the dX chain was ONE saturated queue (19.35 of 19.95 ms
+# busy on the main stream, profiles/r03) of kernels that each leave part of the chip idle (tile quantisation, LayerNorm /
+# attention beside GEMMs).  Every operator of the chain is row- or sample-wise except the LayerNorm parameter gradients
+# (column sums over ALL rows): slice i + 1's LayerNorm-backward launch waits for slice i's (one event) and accumulates.
+BWD_HALVES = 2
+
+
 def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_mask: Optional[Tensor],
-               causal: bool, d2: Tensor, quick: bool = False) -> Tensor:
+               causal: bool, d2: Tensor, quick: bool = False, streams: Optional[list] = None) -> Tensor:
     """Backward of one block: d2 = dL/dy as bf16 [B*T, D]; returns dL/dx as bf16 [B*T, D]; parameter
-    gradients go straight into `.grad` (side streams)."""
+    gradients go straight into `.grad`.  `streams`: None = one pass over all rows on the current stream; a list = the
+    batch is cut into len(streams) contiguous slices, slice i runs on streams[i] (row slices of the same full-size
+    tensors)."""
     x2, mean1, rstd1, ln1, qkv, o2, lse, x1, mean2, rstd2, ln2, pre, h, in_w16, out_w16, w1_16, w2_16 = saved
     ln1_w, ln1_b, in_w, qkv_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2 = prm
     d = d2.shape[1]
-    # Parameter-gradient GEMMs go to the side stream BEFORE their sibling dX GEMM is issued, so the
-    # two run concurrently; the dX chain on the main stream is the critical path.
-    # channel mixing
-    SideStream.run(lambda: _dw_db(w2, b2, d2, h), (d2, h))
-    dpre = ops.gemm(d2, w2_16, b_trans=True, epilogue=ops.EPI_DQGELU if quick else ops.EPI_DGELU, aux_in=pre)
-    SideStream.run(lambda: _dw_db(w1, b1, dpre, ln2), (dpre, ln2))
-    dln2 = ops.gemm(dpre, w1_16, b_trans=True)
-    dx1 = _ln_bwd(dln2, x1, ln2_w, ln2_b, mean2, rstd2, dx_add=d2)
+    m = bsz * t
+    E = lambda cols: torch.empty((m, cols), dtype=bf16, device=d2.device)  # noqa: E731
+    # tensors that cross streams (operands of the grouped weight-gradient launch, the next block's input) are allocated
+    # here, on the caller's stream, and stay alive until the end-of-backward join (_pending_dw / SideStream.keep)
+    dpre, dx1, dqkv, dx = E(pre.shape[1]), E(d), E(3 * d), E(d)
+    qkv3, dqkv3, o3 = qkv.view(bsz, t, 3 * d), dqkv.view(bsz, t, 3 * d), o2.view(bsz, t, d)
+    dact = ops.EPI_DQGELU if quick else ops.EPI_DGELU
+    nsl = len(streams) if streams else 1
+    if bsz < 2 * nsl:
+        nsl, streams = 1, None
+    cuts = [bsz * i // nsl for i in range(nsl + 1)]
+    ln_done: list = [None, None]  # event after the previous slice's LayerNorm-backward launch (LN2, LN1)
 
-    # token mixing
-    SideStream.run(lambda: _dw_db(out_w, out_b, dx1, o2), (dx1, o2))
-    d_o = ops.gemm(dx1, out_w16, b_trans=True)
-    dqkv = torch.empty_like(qkv)
-    qkv3, dqkv3 = qkv.view(bsz, t, 3 * d), dqkv.view(bsz, t, 3 * d)
-    o3, do3 = o2.view(bsz, t, d), d_o.view(bsz, t, d)
-    akw = dict(dq=dqkv3[..., :d], dk=dqkv3[..., d:2 * d], dv=dqkv3[..., 2 * d:], mask=keep_mask,
-               causal=causal)
-    # (the two passes are independent kernels — `parts` — but running them on two streams measured
-    # slower end-to-end: the main stream has to wait for both anyway)
-    ops.attn_bwd(qkv3[..., :d], qkv3[..., d:2 * d], qkv3[..., 2 * d:], o3, do3, lse, num_heads, **akw)
-    SideStream.run(lambda: _dw_db(in_w, qkv_b, dqkv, ln1), (dqkv, ln1))
-    dln1 = ops.gemm(dqkv, in_w16, b_trans=True)
-    return _ln_bwd(dln1, x2, ln1_w, ln1_b, mean1, rstd1, dx_add=dx1)
+    def run(i: int) -> None:
+        b0, b1_ = cuts[i], cuts[i + 1]
+        r = slice(b0 * t, b1_ * t)
+        nb = b1_ - b0
+        last = i == nsl - 1
+        km = None if keep_mask is None else keep_mask[b0:b1_] if keep_mask.shape[0] == bsz else keep_mask
+        cur = torch.cuda.current_stream() if d2.is_cuda else None
+
+        def ln(which: int, dy_, x_, w_, b_, mean_, rstd_, add_, out_) -> None:
+            if ln_done[which] is not None:
+                cur.wait_event(ln_done[which])
+            _ln_bwd(dy_, x_, w_, b_, mean_, rstd_, dx_add=add_, dx_out=out_, notify=last)
+            if nsl > 1 and not last:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                ln_done[which] = ev
+
+        # channel mixing
+        ops.gemm(d2[r], w2_16, b_trans=True, epilogue=dact, aux_in=pre[r], out=dpre[r])
+        dln2 = ops.gemm(dpre[r], w1_16, b_trans=True)
+        ln(0, dln2, x1[r], ln2_w, ln2_b, mean2[r], rstd2[r], d2[r], dx1[r])
+        # token mixing
+        d_o = ops.gemm(dx1[r], out_w16, b_trans=True)
+        q3, dq3 = qkv3[b0:b1_], dqkv3[b0:b1_]
+        # (the two attention passes are independent kernels — `parts` — but running them on two streams measured
+        # slower end-to-end: the chain has to wait for both anyway)
+        ops.attn_bwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], o3[b0:b1_], d_o.view(nb, t, d), lse[b0:b1_], num_heads,
+                     dq=dq3[..., :d], dk=dq3[..., d:2 * d], dv=dq3[..., 2 * d:], mask=km, causal=causal)
+        dln1 = ops.gemm(dqkv[r], in_w16, b_trans=True)
+        ln(1, dln1, x2[r], ln1_w, ln1_b, mean1[r], rstd1[r], dx1[r], dx[r])
+
+    if nsl == 1:
+        run(0)
+    else:
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                run(i)
+    # parameter gradients: queued for the grouped launch (or issued on the side stream — round-1/2 path); whoever
+    # launches them waits for every slice stream
+    _queue_dw(w2, b2, d2, h)
+    _queue_dw(w1, b1, dpre, ln2)
+    _queue_dw(out_w, out_b, dx1, o2)
+    _queue_dw(in_w, qkv_b, dqkv, ln1)
+    return dx
 
 
 def _as_bf16_rows(dy: Tensor, rows: int, d: int) -> Tensor:
@@ -220,6 +328,7 @@ class MixingBlockFn(Function):
         bsz, t, d, num_heads, causal, quick = ctx.meta
         d2 = _as_bf16_rows(dy, bsz * t, d)
         dx = _block_bwd(tuple(saved), ctx.params, num_heads, bsz, t, keep_mask, causal, d2, quick)
+        _flush_dw()
         return (dx.view(bsz, t, d),) + (None,) * 18
 
 
@@ -241,6 +350,13 @@ class MixingStackFn(Function):
         all_saved = []
         streams = None
         if FWD_HALVES > 1 and cur.is_cuda and bsz >= 2 * FWD_HALVES:
+            # every bf16 weight shadow a slice will read is (re)cast HERE, on the caller's stream, BEFORE the side streams
+            # fork: a stale shadow (weights stepped by a torch optimizer, first forward without a ParamArena) would
+            # otherwise be re-cast on the main stream after the fork while the side-stream slice already reads it
+            # (ADVICE r2, high).  With fresh shadows the calls below are attribute reads.
+            for i in range(nblk):
+                for j in (2, 4, 8, 10):  # in_w, out_w, w1, w2
+                    shadow_bf16(params[12 * i + j])
             # slice 0 stays on the caller's stream, the others take side streams that have waited for it; every slice
             # is an independent pipeline through all blocks, joined once at the end of the stack
             main = torch.cuda.current_stream()
@@ -266,10 +382,28 @@ class MixingStackFn(Function):
         *all_saved, keep_mask = ctx.saved_tensors
         bsz, t, d, metas, causal = ctx.meta
         d2 = _as_bf16_rows(dy, bsz * t, d)
-        for i in range(len(metas) - 1, -1, -1):
-            saved = tuple(all_saved[N_SAVED * i:N_SAVED * (i + 1)])
-            quick = bool(metas[i][3]) if len(metas[i]) > 3 else False
-            d2 = _block_bwd(saved, ctx.params[12 * i:12 * i + 12], metas[i][0], bsz, t, keep_mask, causal, d2, quick)
+        streams = None
+        if BWD_HALVES > 1 and d2.is_cuda and bsz >= 2 * BWD_HALVES:
+            main = torch.cuda.current_stream()
+            # lane 1, 2, ...: lane 0 is the stream of the weight-gradient launches
+            streams = [main] + [SideStream.fork(lane + 1) for lane in range(BWD_HALVES - 1)]
+            if any(st is None for st in streams) or len({id(st) for st in streams}) != len(streams) or SideStream.get(0) in streams[1:]:
+                streams = None
+        _slice_streams[:] = streams[1:] if streams else []
+        try:
+            for i in range(len(metas) - 1, -1, -1):
+                saved = tuple(all_saved[N_SAVED * i:N_SAVED * (i + 1)])
+                quick = bool(metas[i][3]) if len(metas[i]) > 3 else False
+                d2 = _block_bwd(saved, ctx.params[12 * i:12 * i + 12], metas[i][0], bsz, t, keep_mask, causal, d2, quick, streams)
+                if DW_GROUP_BLOCKS > 0 and (len(metas) - i) % DW_GROUP_BLOCKS == 0:
+                    _flush_dw(tuple(_slice_streams))
+            _flush_dw(tuple(_slice_streams))
+            if streams is not None:
+                for st in streams[1:]:
+                    torch.cuda.current_stream().wait_stream(st)
+                SideStream.keep.append(d2)  # written by both slice streams, allocated on the caller's
+        finally:
+            _slice_streams[:] = []
         return (d2.view(bsz, t, d), None, None, None) + (None,) * len(ctx.params)
 
 

@@ -6,6 +6,8 @@ current stream and never synchronises.  PyTorch is used only as the owner of dev
 import math
 from typing import Optional, Tuple
 
+import ctypes
+
 import torch
 from torch import Tensor
 
@@ -166,6 +168,47 @@ def gemm(
     return out
 
 
+def gemm_grouped_tn(problems: list) -> None:
+    """Weight gradients of several Linear layers in ONE launch (cfhip_gemm_bf16_grouped_tn).
+
+    `problems`: list of (dy [K, M] bf16, x [K, N] bf16, out [M, N] f32, accumulate, bias_grad f32 [M] or None,
+    bias_grad_accumulate): out (+)= dy^T x, bias_grad (+)= colsum(dy).  256 x 256 tiles of all problems share the chip and
+    every tile runs its whole reduction: no split-K workspace, no reduce pass."""
+    if not problems:
+        return
+    arr = (_lib.GemmProblem * len(problems))()
+    flops = 0.0
+    for i, (dy, x, out, acc, bg, bg_acc) in enumerate(problems):
+        _need(dy, bf16, "dy")
+        _need(x, bf16, "x")
+        _need(out, f32, "out")
+        k, m, lda = _mat(dy, "dy")
+        kb, n, ldb = _mat(x, "x")
+        if k != kb or tuple(out.shape) != (m, n) or out.stride(1) != 1:
+            raise ValueError(f"cfhip gemm_grouped_tn: problem {i}: dy {tuple(dy.shape)} x {tuple(x.shape)} out {tuple(out.shape)}")
+        if bg is not None:
+            _need(bg, f32, "bias_grad")
+            if bg.numel() != m or not bg.is_contiguous():
+                raise ValueError("cfhip gemm_grouped_tn: bias_grad must be a contiguous f32 [M]")
+        pr = arr[i]
+        pr.A, pr.B, pr.C, pr.bias_grad = dy.data_ptr(), x.data_ptr(), out.data_ptr(), _p(bg)
+        pr.M, pr.N, pr.K = m, n, k
+        pr.lda, pr.ldb, pr.ldc = lda, ldb, out.stride(0)
+        pr.accumulate, pr.bias_grad_accumulate = int(bool(acc)), int(bool(bg_acc))
+        flops += 2.0 * m * n * k
+    if FLOP_COUNTER is not None:
+        FLOP_COUNTER.flops["gemm"] += flops
+    timer = GEMM_TIMER
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.load().cfhip_gemm_bf16_grouped_tn(ctypes.cast(arr, ctypes.c_void_p), len(problems), _stream())
+    _lib.check(rc, "gemm_grouped_tn")
+    if timer is not None:
+        e1.record()
+        timer.records.append((("tn-grouped", tuple((int(pr.M), int(pr.N), int(pr.K)) for pr in arr), 0, 0, 0), e0, e1))
+
+
 def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
     """out[n] (f32) (+)= sum_m x[m, n]   (bias gradient)."""
     _need(x, bf16, "x")
@@ -222,13 +265,21 @@ def layernorm_bwd(
     accumulate: bool = False,
     want_dx: bool = True,
     want_param_grads: bool = True,
+    dx_out: Optional[Tensor] = None,
 ) -> Tuple[Optional[Tensor], Optional[Tensor], Optional[Tensor]]:
-    """x bf16 or f32.  Returns (dx bf16 [M, D] (+ dx_add), dgamma f32 [D], dbeta f32 [D])."""
+    """x bf16 or f32.  Returns (dx bf16 [M, D] (+ dx_add), dgamma f32 [D], dbeta f32 [D]).  `dx_out`: dense bf16 [M, D]
+    destination for dx (e.g. a row slice of a full-batch tensor)."""
     _need(dy, bf16, "dy")
     _need(x, x.dtype if x.dtype in (bf16, f32) else bf16, "x")
     m, d, xs = _mat(x, "x")
     _, _, dys = _mat(dy, "dy")
-    dx = torch.empty((m, d), dtype=bf16, device=x.device) if want_dx else None
+    if dx_out is not None and want_dx:
+        _need(dx_out, bf16, "dx_out")
+        if tuple(dx_out.shape) != (m, d) or dx_out.stride(0) != d or dx_out.stride(1) != 1:
+            raise ValueError("cfhip layernorm_bwd: dx_out must be a dense [M, D] bf16 tensor")
+        dx = dx_out
+    else:
+        dx = torch.empty((m, d), dtype=bf16, device=x.device) if want_dx else None
     if dx_add is not None:
         _need(dx_add, bf16, "dx_add")
         if tuple(dx_add.shape) != (m, d) or dx_add.stride(0) != d or dx_add.stride(1) != 1:

@@ -41,13 +41,18 @@ const char* cfhip_last_error(void);
  *   "gemm_config"     -1 (shape heuristic, default) or 0..14 to force one tile configuration
  *                     (0: 128x128x64, 1: 128x128x32, 3: 128x64x64, 7: 256x256x32 two-group kernel,
  *                      8: 256x128x32 two-group kernel, 13: 256x256x64, 14: 192x128x64, ...; see csrc/gemm.hip)
- *   "gemm_heuristic"  1..6, which shape -> configuration table pick_config() uses (default 6: forward GEMMs on the
- *                     BK = 64 configurations, dX on the 256x128x32 two-group kernel, dW on 128x128x32)
+ *   "gemm_heuristic"  1..7, which shape -> configuration table pick_config() uses (default 7: every M >= 1024 forward and
+ *                     dX GEMM on 192x128x64, single dW GEMMs on 128x128x32; 6: the round-2 table — forward on the BK = 64
+ *                     configurations, dX on the 256x128x32 two-group kernel)
  *   "gemm_group_n"    tile walk order of a GEMM launch: n > 0 (default 8): outputs wider than n tile columns are walked in
  *                     groups of n columns, all rows of a group first (an XCD's resident workgroups then share n B panels
  *                     that stay in its L2); n < 0: row groups of -n panels, columns outer; 0: rows outer, every column inner
  *   "ln_bwd_fused"    1 (default): cfhip_layernorm_bwd asked for dx AND dgamma / dbeta runs the one-launch kernel
  *                     (D a multiple of 256 up to 1280); 0: the round-1 one-wave-per-row kernel
+ *   "gemm_cfg_nt_wide" / "gemm_cfg_nt" / "gemm_cfg_nn" / "gemm_cfg_tn"   tile configuration of one class of M >= 1024 GEMMs
+ *                     (forward with N >= 2560, other forward, dX, dW); -1 (default): the heuristic table
+ *   "grouped_variant" ring of cfhip_gemm_bf16_grouped_tn: 0 (default) 5 slots, DMA 3 K-steps ahead; 1: 4 slots, 2 ahead;
+ *                     2: 5 slots, 2 ahead
  * Unknown names are an error.  (The phase-timing ablation masks "gemm_ablate" / "attn_ablate" of round 1 are
  * not part of this library any more: they exist only in the -DCFHIP_ABLATE build that tools/build_variant.sh
  * writes to tools/libcfhip_ablate.so, selected by the tools through CFHIP_LIB.) */
@@ -91,6 +96,25 @@ int cfhip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, co
                     int a_trans, int b_trans, int epilogue, int out_dtype, int accumulate,
                     int split_k, void* workspace, size_t workspace_bytes, float* bias_grad,
                     int bias_grad_accumulate, void* stream);
+
+/* Grouped weight gradients: dW_i[M_i][N_i] (+)= dY_i^T X_i and db_i[M_i] (+)= colsum(dY_i) for `count` Linear layers in ONE
+ * launch (the parameter half of F.linear's autograd backward, customs.py:89 / attentions.py:214: grad_weight =
+ * grad_output^T @ input, grad_bias = grad_output.sum(0), for every Linear of one or more blocks).  Layout (1,1) of
+ * cfhip_gemm_bf16: A = dY [K][M] (lda), B = X [K][N] (ldb), both bf16 token-major; C f32 [M][N] (ldc).  256 x 256 output
+ * tiles of all problems share the chip, every tile runs its whole reduction: no split-K, no workspace, no second pass,
+ * deterministic.  M, N, lda, ldb multiples of 8, ldc of 4, 16-byte aligned bases, K*ld*2 < 2 GiB.  `problems` is a HOST
+ * array (copied into the kernel arguments, 8 per launch).  bias_grad may be NULL per problem. */
+typedef struct cfhip_gemm_problem {
+  const void* A;
+  const void* B;
+  void* C;
+  float* bias_grad;
+  int M, N, K;
+  int64_t lda, ldb, ldc;
+  int accumulate;            /* C += */
+  int bias_grad_accumulate;  /* bias_grad += */
+} cfhip_gemm_problem;
+int cfhip_gemm_bf16_grouped_tn(const cfhip_gemm_problem* problems, int count, void* stream);
 
 /* column sums of a bf16 matrix: out[n] (f32) (+)= sum_m X[m*ldx + n]   (bias gradients)
  * workspace: >= cfhip_colsum_workspace(M, N) bytes. */

@@ -229,3 +229,59 @@ def test_tile_walk_orders_give_identical_results():
     finally:
         ops.set_option("gemm_group_n", 8)
     assert_close(outs[0], a.float().double() @ w.float().t().double(), 2e-5, "walk order")
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_grouped_weight_gradients(variant):
+    """cfhip_gemm_bf16_grouped_tn: several dW = dY^T X (+ db = colsum dY) problems in one launch vs fp64 on the same bf16
+    operands — ragged shapes (M, N not multiples of the 256-wide tile, K not a multiple of the 32-deep K-step, K shorter
+    than the ring), accumulate flags, problems with and without a bias gradient, more problems than one launch takes (8)."""
+    try:
+        ops.set_option("grouped_variant", variant)
+        specs = [  # (K, M, N, accumulate, bias, bias_accumulate)
+            (1000, 256, 256, False, True, False), (591, 768, 264, True, True, True), (40, 8, 8, False, False, False),
+            (1379, 520, 1000, False, True, False), (96, 264, 512, True, False, False), (3000, 768, 768, False, True, True),
+            (32, 256, 512, False, True, False), (333, 136, 72, False, True, False), (2050, 512, 256, True, True, False),
+            (64, 1000, 776, False, True, False),
+        ]
+        probs, wants = [], []
+        for i, (k, m, n, acc, has_b, acc_b) in enumerate(specs):
+            dy, x = _mk(k, m, 100 + i).to(DEV), _mk(k, n, 200 + i).to(DEV)
+            out = torch.full((m, n), 3.0, dtype=torch.float32, device=DEV)
+            bg = torch.full((m,), 5.0, dtype=torch.float32, device=DEV) if has_b else None
+            probs.append((dy, x, out, acc, bg, acc_b))
+            w = dy.float().t().double() @ x.float().double() + (3.0 if acc else 0.0)
+            b = dy.float().double().sum(0) + (5.0 if acc_b else 0.0)
+            wants.append((w, b))
+        ops.gemm_grouped_tn(probs)
+        for i, ((dy, x, out, acc, bg, acc_b), (w, b)) in enumerate(zip(probs, wants)):
+            assert_close(out, w, 2e-5, f"variant {variant} problem {i} dW {specs[i]}")
+            if bg is not None:
+                assert_close(bg, b, 2e-5, f"variant {variant} problem {i} db {specs[i]}")
+        # strided operands (column slices of wider matrices, as the packed qkv gradient is) and a transpose-detecting case
+        big_dy, big_x = _mk(700, 1024, 7).to(DEV), _mk(700, 640, 8).to(DEV)
+        dy, x = big_dy[:, 256:768], big_x[:, 128:384]
+        out = torch.empty(512, 256, dtype=torch.float32, device=DEV)
+        ops.gemm_grouped_tn([(dy, x, out, False, None, False)])
+        assert_close(out, dy.float().t().double() @ x.float().double(), 2e-5, "strided operands")
+    finally:
+        ops.set_option("grouped_variant", 0)
+
+
+def test_grouped_weight_gradients_at_the_benchmark_shapes():
+    """the four weight gradients of a ViT-B/16 block at batch 128 (K = 25 216), two blocks per launch = 216 tiles; fp64
+    reference on row / column samples of every output"""
+    k = 128 * 197
+    g = torch.Generator(device=DEV).manual_seed(5)
+    rnd = lambda r, c: (torch.randn(r, c, generator=g, device=DEV) * 0.5).to(torch.bfloat16)  # noqa: E731
+    probs = []
+    for _ in range(2):
+        for m, n in ((768, 3072), (3072, 768), (768, 768), (2304, 768)):
+            probs.append((rnd(k, m), rnd(k, n), torch.empty(m, n, dtype=torch.float32, device=DEV), False,
+                          torch.empty(m, dtype=torch.float32, device=DEV), False))
+    ops.gemm_grouped_tn(probs)
+    for i, (dy, x, out, _, bg, _) in enumerate(probs):
+        rows = torch.randint(0, dy.shape[1], (48,), generator=g, device=DEV)
+        want = dy[:, rows].double().t() @ x.double()
+        assert_close(out[rows], want, 2e-5, f"problem {i} dW rows")
+        assert_close(bg, dy.double().sum(0), 2e-5, f"problem {i} db")

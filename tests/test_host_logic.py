@@ -328,17 +328,26 @@ def test_bench_gemm_shapes_conserve_flops_under_forward_slices():
     import bench
     from cflearn_amd import fused
 
-    keep = fused.FWD_HALVES
+    keep = fused.FWD_HALVES, fused.BWD_HALVES, fused.DW_GROUP_BLOCKS
+
+    def flops(row):
+        c, lay, m, n, k, _ = row
+        if lay == "tn-grouped":  # m = ((M, N, K), ...) of one grouped weight-gradient launch
+            return c * sum(2.0 * mm * nn * kk for mm, nn, kk in m)
+        return c * 2.0 * m * n * k
+
     try:
         totals = []
-        for v in (1, 2, 3):
-            fused.FWD_HALVES = v
+        for v, bv, grp in ((1, 1, 0), (2, 1, 0), (3, 2, 2), (2, 2, 1), (2, 3, 5), (1, 2, 12)):
+            fused.FWD_HALVES, fused.BWD_HALVES, fused.DW_GROUP_BLOCKS = v, bv, grp
             shapes = bench.gemm_shapes(128)
-            totals.append(sum(c * 2.0 * m * n * k for c, _, m, n, k, _ in shapes))
+            totals.append(sum(flops(r) for r in shapes))
             assert sum(c * m for c, lay, m, n, k, e in shapes if lay == "nt" and e == "gelu") == 12 * 128 * 197
-        assert totals[0] == totals[1] == totals[2] == 12910053556224.0
+            assert sum(c * m for c, lay, m, n, k, e in shapes if lay == "nn" and e == "dgelu") == 12 * 128 * 197
+            assert sum(c * len(m) for c, lay, m, *_ in shapes if lay == "tn-grouped") == (48 if grp else 0)
+        assert all(tot == 12910053556224.0 for tot in totals), totals
     finally:
-        fused.FWD_HALVES = keep
+        fused.FWD_HALVES, fused.BWD_HALVES, fused.DW_GROUP_BLOCKS = keep
 
 
 def test_scale_shift_affine_function_matches_autograd():

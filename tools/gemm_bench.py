@@ -63,7 +63,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda")
     cfgs = [int(c) for c in args.configs.split(",")]
-    shapes = [s for s in bench.gemm_shapes(args.batch) if s[2] > 64 and s[4] > 64]  # skip the tiny head GEMMs
+    shapes = [s for s in bench.gemm_shapes(args.batch, grouped=False) if s[2] > 64 and s[4] > 64]  # skip the tiny head GEMMs
     totals = {c: 0.0 for c in cfgs}
     best_total = 0.0
     flops_total = 0.0

@@ -1,0 +1,79 @@
+"""Within-process A/B of whole-step variants of the ViT-B/16 training step (interleaved rounds, medians).
+
+    python tools/step_variants.py [batch] [name=python-expression ...]
+Built-in variants exercise the round-3 switches: fused.DW_GROUP_BLOCKS / DW_GROUP_ON_MAIN, ring variants."""
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import cflearn_amd as C  # noqa: E402
+from cflearn_amd import fused, ops  # noqa: E402
+from cflearn_amd.engine import TrainStep  # noqa: E402
+
+dev = torch.device("cuda")
+torch.manual_seed(0)
+BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+model = C.vit_b16_classifier(1000).to(dev)
+ts = TrainStep(model, lr=1e-4, use_graph=False)
+g = torch.Generator().manual_seed(1234)
+img = torch.randn(BATCH, 3, 224, 224, generator=g).to(dev)
+labels = torch.randint(0, 1000, (BATCH,), generator=g).to(dev)
+
+
+def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt=-1, nn=-1):
+    def f():
+        fused.DW_GROUP_BLOCKS = blocks
+        fused.DW_GROUP_ON_MAIN = on_main
+        fused.FWD_HALVES = halves
+        fused.BWD_HALVES = bhalves
+        ops.set_option("grouped_variant", variant)
+        ops.set_option("gemm_cfg_nt_wide", nt_wide)
+        ops.set_option("gemm_cfg_nt", nt)
+        ops.set_option("gemm_cfg_nn", nn)
+    return f
+
+
+VARIANTS = {
+    "default (g2, s2, table 7)": setv(2),
+    "nn=c13": setv(2, nn=13),
+    "ntw=c13": setv(2, nt_wide=13),
+    "ntw=c0": setv(2, nt_wide=0),
+    "nt=c0": setv(2, nt=0),
+    "nn=c8": setv(2, nn=8),
+    "3-slice bwd": setv(2, bhalves=3),
+    "3-slice fwd": setv(2, halves=3),
+    "3-slice both": setv(2, halves=3, bhalves=3),
+    "grouped 1 blk": setv(1),
+    "grouped 3 blk": setv(3),
+    "grouped 4 blk": setv(4),
+    "ring variant 2": setv(2, variant=2),
+}
+if len(sys.argv) > 2:
+    sel = sys.argv[2:]
+    VARIANTS = {k: v for k, v in VARIANTS.items() if any(s in k for s in sel)}
+
+
+def run(n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ts.step(img, labels)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+for v in VARIANTS.values():
+    v()
+    run(3)
+res = {k: [] for k in VARIANTS}
+for rnd in range(5):
+    for k, v in VARIANTS.items():
+        v()
+        res[k].append(run(10))
+for k, v in res.items():
+    print(f"{k:52s} median {statistics.median(v):7.3f} ms  min {min(v):7.3f}  all {[round(x, 2) for x in v]}")
