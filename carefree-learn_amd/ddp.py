@@ -133,7 +133,7 @@ class BucketedAllReduce:
     def __init__(self, arena: ParamArena, *, process_group: Any = None, bucket_bytes: int = 64 << 20,
                  overlap: bool = True, optimizer: Optional[FusedAdam] = None, average: Optional[bool] = None,
                  finish_after_backward: bool = False, sync_fn: Any = None, wire_bf16: bool = False,
-                 comm: Optional["Communicator"] = None):
+                 comm: Optional["Communicator"] = None, tail_bytes: int = 4 << 20):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("BucketedAllReduce needs an initialised torch.distributed process group")
         self.arena = arena
@@ -154,16 +154,24 @@ class BucketedAllReduce:
             # BEFORE the first collective makes the process group create its internal stream
             HF.SideStream.ensure()
             self.comm_stream = HF.distinct_stream(HF.SideStream.streams)
-        # buckets: walk the parameters from LAST to FIRST (backward produces them in that order)
+        # buckets: walk the parameters from LAST to FIRST (backward produces them in that order).  The bucket that
+        # closes LAST (the first-registered parameters: stem / positional encoding, whose gradients appear when backward
+        # ends) is the one exchange nothing can hide: it is kept small (`tail_bytes`) — the parameters before the first
+        # cut-off go into a bucket of their own instead of riding on up to `bucket_bytes` of earlier-finished gradients.
         self.buckets: List[_Bucket] = []
+        n = len(arena.params)
+        n_tail, acc = 0, 0
+        if tail_bytes > 0 and arena.total * 4 > bucket_bytes:
+            while n_tail < n - 1 and acc < tail_bytes:
+                acc += arena.params[n_tail].numel() * 4
+                n_tail += 1
         ids: List[int] = []
         end = arena.total
         acc = 0
-        n = len(arena.params)
         for i in range(n - 1, -1, -1):
             ids.append(i)
             acc += arena.params[i].numel() * 4
-            if acc >= bucket_bytes or i == 0:
+            if acc >= bucket_bytes or i == 0 or i == n_tail:
                 start = arena.offsets[i]
                 self.buckets.append(_Bucket(start, end, ids))
                 end, ids, acc = start, [], 0
@@ -180,6 +188,7 @@ class BucketedAllReduce:
         self.exposed_events: List[Any] = []  # (start, end) event pairs around finish()'s waits, when timing is on
         self.time_exposed = False
         HF.grad_ready_callbacks.append(self._on_direct)
+        HF.backward_entered_callbacks.append(self._on_backward_entered)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_ready) for p in arena.params]
         if optimizer is not None:
             optimizer.grad_scale = 1.0 if self.average else 1.0 / self.world_size
@@ -188,19 +197,52 @@ class BucketedAllReduce:
     def close(self) -> None:
         if self._on_direct in HF.grad_ready_callbacks:
             HF.grad_ready_callbacks.remove(self._on_direct)
+        if self._on_backward_entered in HF.backward_entered_callbacks:
+            HF.backward_entered_callbacks.remove(self._on_backward_entered)
         for h in self._hooks:
             h.remove()
         self._hooks = []
 
-    def broadcast_parameters(self, src: int = 0) -> None:
-        """What the DDP constructor used to do (SURVEY §2a C3): every rank starts from rank `src`."""
-        if self.comm is not None:
+    def _broadcast(self, t: Tensor, src: int) -> None:
+        if self.comm is not None and t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous():
             self.comm_stream.wait_stream(torch.cuda.current_stream())
-            self.comm.broadcast_(self.arena.flat_p, src, self.comm_stream)
+            self.comm.broadcast_(t, src, self.comm_stream)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
-            dist.broadcast(self.arena.flat_p, src=src, group=self.group)
+            dist.broadcast(t, src=src, group=self.group)
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """What the DDP constructor used to do (SURVEY §2a C3): every rank starts from rank `src`."""
+        self._broadcast(self.arena.flat_p, src)
         self.arena.refresh_shadow()
+
+    def broadcast_buffers(self, modules: Any, src: int = 0) -> int:
+        """The other half of the DDP constructor's `_sync_module_states` (torch DDP broadcasts parameters AND buffers at
+        wrap time; behind trainer.py:268-272): BatchNorm running statistics, `num_batches_tracked`, attention masks ...
+        of every module in `modules` follow rank `src`.  f32 buffers travel as ONE flat tensor.  Returns the number of
+        buffers sent."""
+        seen, f32s, others = set(), [], []
+        for m in modules:
+            for b in m.buffers():
+                if id(b) in seen or b.numel() == 0:
+                    continue
+                seen.add(id(b))
+                (f32s if b.dtype == torch.float32 else others).append(b)
+        if f32s:
+            flat = torch.cat([b.detach().reshape(-1) for b in f32s])
+            self._broadcast(flat, src)
+            off = 0
+            with torch.no_grad():
+                for b in f32s:
+                    b.copy_(flat[off:off + b.numel()].view_as(b))
+                    off += b.numel()
+        for b in others:
+            t = b.detach().contiguous()
+            t = t.to(torch.uint8) if t.dtype == torch.bool else t
+            dist.broadcast(t, src=src, group=self.group)
+            with torch.no_grad():
+                b.copy_(t.to(b.dtype).view_as(b))
+        return len(f32s) + len(others)
 
     @contextlib.contextmanager
     def no_sync(self) -> Iterator[None]:
@@ -215,6 +257,12 @@ class BucketedAllReduce:
     # -- backward-time notifications ----------------------------------------------------------
     def _on_direct(self, p: Tensor) -> None:
         self._on_ready(p, True)
+
+    def _on_backward_entered(self) -> None:
+        """A checkpointed block is about to re-enter autograd (functional.backward_entered_callbacks): open the pass
+        from HERE, the outer graph task, so that the end-of-backward callback belongs to the whole backward pass."""
+        if not self._pass_open:
+            self._open_pass()
 
     def _open_pass(self) -> None:
         """First gradient notification of a backward pass: decide whether this pass synchronises."""
@@ -356,9 +404,41 @@ class RcclDDPCallback:
     Gradient accumulation (schema.py:1277-1282: update iff `state.step % grad_accumulate == 0`): passes that do not
     update only accumulate locally; the update pass reduces the accumulated sum once."""
 
-    def __init__(self, bucket_bytes: int = 64 << 20):
+    def __init__(self, bucket_bytes: int = 64 << 20, comm: str = "auto"):
         self.bucket_bytes = bucket_bytes
+        self.comm_mode = comm  # "auto": the cfhip_comm_* C-ABI communicator under the nccl backend, else torch.distributed
         self.reducer: Optional[BucketedAllReduce] = None
+
+    @staticmethod
+    def _modules(trainer: Any) -> List[Any]:
+        """Everything `accelerator.prepare(*model.all_modules, ...)` wrapped (trainer.py:268-272): the model's modules
+        and, when it carries parameters or buffers of its own, the loss module (schema.py:1088-1091)."""
+        model = trainer.model
+        mods = [m for m in (getattr(model, "all_modules", None) or []) if isinstance(m, torch.nn.Module)]
+        if not mods:
+            mods = [model.m]
+        loss = getattr(model, "loss", None)
+        if isinstance(loss, torch.nn.Module) and all(loss is not m for m in mods):
+            mods.append(loss)
+        return mods
+
+    def _communicator(self) -> Optional["Communicator"]:
+        """The C-ABI communicator (collectives on this package's own queue-checked stream) when the process group is
+        RCCL; every rank must agree, so a rank that cannot create it makes all of them fall back to torch.distributed."""
+        if self.comm_mode == "torch" or not torch.cuda.is_available() or dist.get_backend() != "nccl":
+            return None
+        comm, ok = None, 1
+        try:
+            comm = Communicator()
+        except Exception:  # missing RCCL symbol, communicator refused: the ProcessGroup launches the collectives
+            ok = 0
+        flag = torch.tensor([ok], device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if comm is not None:
+                comm.close()
+            return None
+        return comm
 
     @staticmethod
     def _sync_fn(trainer: Any) -> Any:
@@ -379,7 +459,13 @@ class RcclDDPCallback:
     def before_loop(self, trainer: Any) -> None:
         if get_ddp_info() is None or not dist.is_initialized():
             return
-        params = [p for p in trainer.model.m.parameters() if p.requires_grad]
+        modules = self._modules(trainer)
+        params, seen = [], set()
+        for m in modules:
+            for p in m.parameters():
+                if p.requires_grad and id(p) not in seen:
+                    seen.add(id(p))
+                    params.append(p)
         inners = [getattr(opt, "optimizer", opt) for opt in trainer.optimizers.values()]  # accelerate wraps the torch one
         # an optimizer that already owns the arena (optim.FusedAdamOptimizer): reduce ITS gradient buffer;
         # otherwise re-home the parameters here
@@ -399,7 +485,9 @@ class RcclDDPCallback:
                     "all trainable parameters, or a torch optimizer")
             arena = ParamArena(params, with_shadow=True)
         self.reducer = BucketedAllReduce(arena, bucket_bytes=self.bucket_bytes, optimizer=fused, average=True,
-                                         finish_after_backward=True, sync_fn=self._sync_fn(trainer))
+                                         finish_after_backward=True, sync_fn=self._sync_fn(trainer),
+                                         comm=self._communicator())
         self.reducer.broadcast_parameters(0)
+        self.reducer.broadcast_buffers(modules, 0)
         for inner in inners:
             inner.register_step_pre_hook(lambda *_a, **_k: self.reducer.finish())

@@ -25,6 +25,11 @@ f32 = torch.float32
 
 # called as cb(param) right after a parameter's gradient has been written by a HIP backward
 grad_ready_callbacks: List[Callable[[Tensor], None]] = []
+# Called at the top of a backward that re-enters autograd (gradient checkpointing: `torch.autograd.grad` inside
+# `_CheckpointFn.backward`), i.e. still in the OUTER graph task: whoever wants an end-of-backward callback of the whole
+# pass (ddp.BucketedAllReduce) must queue it from here — queued from a gradient notification inside the nested task it
+# would fire when that block's inner backward ends.
+backward_entered_callbacks: List[Callable[[], None]] = []
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1262,6 +1267,8 @@ class _CheckpointFn(Function):
 
     @staticmethod
     def backward(ctx: Any, *grad_outputs: Any) -> Any:  # type: ignore
+        for cb in backward_entered_callbacks:  # outer graph task: see the note at the list's definition
+            cb()
         inputs = [x.detach().requires_grad_(r) if isinstance(x, Tensor) else x for x, r in zip(ctx.inputs, ctx.requires)]
         with torch.enable_grad():
             outputs = ctx.fn(*[x.view_as(x) if isinstance(x, Tensor) else x for x in inputs])

@@ -303,56 +303,56 @@ class Attention(Module):
                  out_linear_config: Optional[Dict[str, Any]] = None, reduction_ratio: Optional[int] = None,
                  hook: Any = None):
         super().__init__()
-        if reduction_ratio is not None and reduction_ratio > 1:
-            raise NotImplementedError("spatial `reduction_ratio` is outside the accelerated hot path")
-        if activation is not None:
-            raise NotImplementedError("`activation` on q/k/v is outside the accelerated hot path")
-        self.input_dim = input_dim
-        if kv_same is None:
-            kv_same = not (k_dim is not None and v_dim is not None and k_dim != v_dim)
-        self.kv_same = kv_same
-        self.qkv_same = is_self_attention
-        if not is_self_attention:
+        for what, hit in (("spatial `reduction_ratio`", reduction_ratio is not None and reduction_ratio > 1),
+                          ("`activation` on q/k/v", activation is not None)):
+            if hit:
+                raise NotImplementedError(f"{what} is outside the accelerated hot path")
+        # -- geometry.  The attribute names, the parameter names / shapes / initialisers and their REGISTRATION ORDER are the
+        # reference's state_dict contract (attentions.py:57-147; tests/test_host_logic.py compares key for key); how they are
+        # derived is this file's: one table of projection weights and one of biases per operand layout.
+        self.input_dim, self.num_heads = input_dim, num_heads
+        self.qkv_same = bool(is_self_attention)
+        if self.qkv_same:
+            for name, given in (("k_dim", k_dim), ("v_dim", v_dim)):
+                if given not in (None, input_dim):
+                    raise ValueError(f"self attention is used but `{name}` != `input_dim`")
+            self.k_dim = self.v_dim = input_dim
+        else:
             self.k_dim = k_dim or input_dim
             self.v_dim = v_dim or self.k_dim
-        else:
-            if k_dim is not None and k_dim != input_dim:
-                raise ValueError("self attention is used but `k_dim` != `input_dim`")
-            if v_dim is not None and v_dim != input_dim:
-                raise ValueError("self attention is used but `v_dim` != `input_dim`")
-            self.k_dim = self.v_dim = input_dim
-        self.embed_dim = embed_dim or input_dim
-        self.num_heads = num_heads
-        self.head_dim = self.embed_dim // num_heads
-        self.scaling = qk_scale or float(self.head_dim) ** 0.5
-        if self.head_dim * num_heads != self.embed_dim:
+        self.kv_same = (k_dim is None or v_dim is None or k_dim == v_dim) if kv_same is None else kv_same
+        self.embed_dim = e = embed_dim or input_dim
+        self.head_dim, rest = divmod(e, num_heads)
+        if rest:
             raise ValueError("`embed_dim` must be divisible by `num_heads`")
-        e = self.embed_dim
-        P = nn.Parameter
-        self.in_w = self.q_w = self.k_w = self.v_w = self.kv_w = None
-        if self.qkv_same:
-            self.in_w = P(torch.empty(3 * e, input_dim))
-            nn.init.trunc_normal_(self.in_w, std=0.02)
-        elif kv_same:
-            self.q_w = P(torch.empty(e, input_dim))
-            self.kv_w = P(torch.empty(2 * e, input_dim))
-            nn.init.trunc_normal_(self.q_w, std=0.02)
-            nn.init.trunc_normal_(self.kv_w, std=0.02)
+        self.scaling = qk_scale or float(self.head_dim) ** 0.5
+
+        def trunc(w: Tensor) -> None:
+            nn.init.trunc_normal_(w, std=0.02)
+
+        layout = "packed" if self.qkv_same else ("q+kv" if self.kv_same else "q,k,v")
+        weights = {
+            "packed": (("in_w", 3 * e, input_dim, trunc),),
+            "q+kv": (("q_w", e, input_dim, trunc), ("kv_w", 2 * e, input_dim, trunc)),
+            "q,k,v": (("q_w", e, input_dim, nn.init.xavier_uniform_), ("k_w", e, self.k_dim, nn.init.xavier_uniform_),
+                      ("v_w", e, self.v_dim, nn.init.xavier_uniform_)),
+        }[layout]
+        if not bias:
+            biases: tuple = ()
+        elif not qkv_bias_same:
+            biases = (("q_bias", e), ("k_bias", e), ("v_bias", e))
+        elif layout == "q+kv":
+            biases = (("q_bias", e), ("kv_bias", 2 * e))
         else:
-            self.q_w = P(torch.empty(e, input_dim))
-            self.k_w = P(torch.empty(e, self.k_dim))
-            self.v_w = P(torch.empty(e, self.v_dim))
-            for w in (self.q_w, self.k_w, self.v_w):
-                nn.init.xavier_uniform_(w)
-        self.q_bias = self.k_bias = self.v_bias = self.kv_bias = self.qkv_bias = None
-        if bias:
-            if not qkv_bias_same:
-                self.q_bias, self.k_bias, self.v_bias = (P(torch.zeros(e)) for _ in range(3))
-            elif self.qkv_same or not kv_same:
-                self.qkv_bias = P(torch.zeros(3 * e))
-            else:
-                self.q_bias = P(torch.zeros(e))
-                self.kv_bias = P(torch.zeros(2 * e))
+            biases = (("qkv_bias", 3 * e),)
+        for name in ("in_w", "q_w", "k_w", "v_w", "kv_w", "q_bias", "k_bias", "v_bias", "kv_bias", "qkv_bias"):
+            setattr(self, name, None)
+        for name, rows, cols, init in weights:
+            w = nn.Parameter(torch.empty(rows, cols))
+            init(w)
+            setattr(self, name, w)
+        for name, rows in biases:
+            setattr(self, name, nn.Parameter(torch.zeros(rows)))
         self.out_linear = HijackCustomLinear(e, input_dim, **(out_linear_config or {}))
         self.dropout = dropout
         self.activation = nn.Identity()

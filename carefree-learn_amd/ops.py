@@ -1146,10 +1146,13 @@ def diffusion_loss(pred: Tensor, target: Tensor, weight: Tensor, loss_type: str 
 
 
 class PhiloxState:
-    """Process-wide counter-based generator state.  `manual_seed` (re)starts the stream; under data parallelism seed
-    each rank differently (e.g. seed + rank) exactly as `torch.manual_seed` users do."""
+    """Process-wide counter-based generator state.  The stream starts from `torch.initial_seed()` + the rank of the process
+    (so `torch.manual_seed` / the reference's `seed_everything` before the first draw seed it, and data-parallel ranks
+    draw different masks); `manual_seed` (re)starts it explicitly.  (seed, offset) travel to the kernels as launch
+    ARGUMENTS: a captured hipGraph would replay one frozen pair — the same masks every step — so drawing while a
+    stream is capturing is an error (run stochastic modules eagerly: `TrainStep(use_graph=False)`)."""
 
-    seed: int = 0x5EED5EED
+    seed: Optional[int] = None  # None: derived from torch.initial_seed() + RANK at the first draw
     offset: int = 0
 
     @classmethod
@@ -1159,6 +1162,14 @@ class PhiloxState:
     @classmethod
     def take(cls, counters: int) -> Tuple[int, int]:
         """Reserve `counters` Philox counters; returns the (seed, offset) to hand to the kernel."""
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("cfhip: a dropout / DropPath mask was drawn during hipGraph capture: the (seed, offset) pair "
+                               "would be frozen into the graph and every replay would apply the same mask; run models with "
+                               "dropout or drop_path eagerly (TrainStep(use_graph=False))")
+        if cls.seed is None:
+            import os
+
+            cls.seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (int(os.environ.get("RANK", "0")) + 1)) & 0xFFFFFFFFFFFFFFFF
         off = cls.offset
         cls.offset += int(counters)
         return cls.seed, off

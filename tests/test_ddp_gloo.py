@@ -433,3 +433,176 @@ def test_trainer_callback_clipping_and_accumulation(tmp_path, clip, accumulate):
         assert (a - w).abs().max() < 1e-6
     # all-reduces were launched on update passes only
     assert r0["launches"] and all(s % accumulate == 0 for s in r0["launches"])
+
+
+class _LossWithParam(torch.nn.Module):
+    """a loss module that owns a parameter (the reference prepares `model.all_modules`, loss included: trainer.py:268-272)"""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.log_scale = torch.nn.Parameter(torch.zeros(()))
+        self.register_buffer("seen", torch.zeros((), dtype=torch.long))
+
+    def forward(self, pred, y):
+        return ((pred - y) ** 2).mean() * torch.exp(self.log_scale)
+
+
+def _bn_model():
+    torch.manual_seed(11)
+    return torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.BatchNorm1d(16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+
+
+def _callback_buffers_worker(rank: int, world: int, port: int, out: str) -> None:
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cflearn_amd.ddp import RcclDDPCallback
+
+    model, loss = _bn_model(), _LossWithParam()
+    if rank == 1:  # rank 1 starts from other weights AND other buffers: the callback must bring both in line with rank 0
+        with torch.no_grad():
+            for p in list(model.parameters()) + list(loss.parameters()):
+                p.add_(1.0)
+            model[1].running_mean.add_(3.0)
+            model[1].running_var.mul_(5.0)
+            model[1].num_batches_tracked.add_(7)
+            loss.seen.add_(9)
+
+    class _Obj:
+        pass
+
+    trainer = _Obj()
+    trainer.model = _Obj()
+    trainer.model.m, trainer.model.loss = model, loss
+    trainer.model.all_modules = [model]  # the loss is found through `model.loss`
+    opt = torch.optim.SGD(list(model.parameters()) + list(loss.parameters()), lr=0.05)
+    trainer.optimizers = {"all": opt}
+    cb = RcclDDPCallback(bucket_bytes=256)
+    cb.before_loop(trainer)
+    assert cb.reducer.comm is None  # gloo: the ProcessGroup launches the collectives
+    assert any(p is loss.log_scale for p in cb.reducer.arena.params)
+    buffers_after = [b.detach().clone() for b in list(model.buffers()) + list(loss.buffers())]
+    torch.manual_seed(100)
+    x, y = torch.randn(8, 6), torch.randn(8, 3)
+    for _ in range(2):
+        opt.zero_grad()
+        loss(model(x[rank * 4:(rank + 1) * 4]), y[rank * 4:(rank + 1) * 4]).backward()
+        opt.step()
+    torch.save(dict(buffers=buffers_after, params=[p.detach().clone() for p in list(model.parameters()) + list(loss.parameters())],
+                    n_buckets=len(cb.reducer.buckets), tail=len(cb.reducer.buckets[-1].param_ids)), f"{out}.{rank}")
+    cb.reducer.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_trainer_callback_broadcasts_buffers_and_hooks_the_loss_parameters(tmp_path):
+    """the DDP constructor the callback replaces also synchronised module BUFFERS (BatchNorm running
+    statistics of the MNIST / FCNN configurations) and wrapped every prepared module, the loss included."""
+    world, port = 2, _free_port()
+    out = str(tmp_path / "cbb")
+    mp.spawn(_callback_buffers_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    ref_model, ref_loss = _bn_model(), _LossWithParam()
+    want = [b.detach().clone() for b in list(ref_model.buffers()) + list(ref_loss.buffers())]
+    for a, b, w in zip(r0["buffers"], r1["buffers"], want):  # right after before_loop: rank 0's (= the seed's) values everywhere
+        assert torch.equal(a, b) and torch.equal(a, w)
+    for a, b in zip(r0["params"], r1["params"]):  # weights AND the loss parameter stay in lock-step
+        assert torch.equal(a, b)
+    assert (r0["params"][-1] - 0.0).abs() > 0  # the loss parameter was trained (its gradient was exchanged and applied)
+
+
+def _tail_bucket_worker(rank: int, world: int, port: int, out: str) -> None:
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cflearn_amd as C
+    from cflearn_amd import functional as HF
+
+    torch.manual_seed(3)
+    layers = [torch.nn.Linear(8, 8) for _ in range(6)]
+    model = torch.nn.Sequential(*layers)
+    arena = C.ParamArena(list(model.parameters()), with_shadow=False)
+    red = C.BucketedAllReduce(arena, bucket_bytes=2 * 72 * 4, tail_bytes=72 * 4, finish_after_backward=True, average=True)
+    # the LAST bucket (first-registered parameters) holds just the stem: one Linear (weight 64 + bias 8 floats)
+    sizes = [sum(arena.params[i].numel() for i in b.param_ids) for b in red.buckets]
+    launched_at_end = []
+    # a checkpointed LAST block: its inner backward is a nested graph task; the end-of-backward callback must still
+    # belong to the whole pass (ADVICE r2): all buckets reduced exactly once, gradients == the rank average
+    torch.manual_seed(50 + rank)
+    x = torch.randn(4, 8)
+
+    class DirectLinear(torch.autograd.Function):
+        """what the HIP Functions do: the parameter gradients are written straight into `.grad` (the arena) inside
+        backward, announced through `grad_ready_callbacks`, and None is returned for them"""
+
+        @staticmethod
+        def forward(ctx, h, w, b):
+            ctx.save_for_backward(h, w)
+            ctx.prm = (w, b)
+            return h @ w.t() + b
+
+        @staticmethod
+        def backward(ctx, dy):
+            h, w = ctx.saved_tensors
+            wp, bp = ctx.prm
+            with torch.no_grad():
+                wp.grad.add_(dy.t() @ h)
+                bp.grad.add_(dy.sum(0))
+            for prm in (wp, bp):
+                for cb in HF.grad_ready_callbacks:
+                    cb(prm)
+            return dy @ w, None, None
+
+    def tail_block(h):
+        return DirectLinear.apply(torch.tanh(layers[4](h)), layers[5].weight, layers[5].bias)
+
+    arena.zero_grad()
+    h = x
+    for lyr in layers[:4]:
+        h = torch.tanh(lyr(h))
+    out_t = HF.gradient_checkpoint(tail_block, (h,), list(layers[4].parameters()) + list(layers[5].parameters()), True)
+    calls = {"n": 0}
+    orig = red._launch
+
+    def counting(b):
+        calls["n"] += 1
+        return orig(b)
+
+    red._launch = counting
+    out_t.pow(2).mean().backward()
+    launched_at_end.append(calls["n"])
+    g = arena.flat_g.clone()
+    # reference: plain backward of the same graph, local gradient
+    arena.zero_grad()
+    red.sync_enabled = False
+    h = x
+    for lyr in layers[:4]:
+        h = torch.tanh(lyr(h))
+    tail_block(h).pow(2).mean().backward()
+    local = arena.flat_g.clone()
+    red.sync_enabled = True
+    both = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(both, local)
+    torch.save(dict(sizes=sizes, g=g, avg=sum(both) / world, launches=launched_at_end, n_buckets=len(red.buckets)), f"{out}.{rank}")
+    red.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_small_tail_bucket_and_checkpointed_last_block(tmp_path):
+    world, port = 2, _free_port()
+    out = str(tmp_path / "tail")
+    mp.spawn(_tail_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["sizes"][-1] == 72 and sum(r0["sizes"]) == 6 * 72 and r0["sizes"][0] == 144  # tail = the stem only
+    assert r0["launches"] == [r0["n_buckets"]]  # every bucket launched exactly once in the checkpointed pass
+    assert torch.equal(r0["g"], r1["g"])
+    assert (r0["g"] - r0["avg"]).abs().max() < 1e-6

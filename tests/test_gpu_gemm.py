@@ -285,3 +285,58 @@ def test_grouped_weight_gradients_at_the_benchmark_shapes():
         want = dy[:, rows].double().t() @ x.double()
         assert_close(out[rows], want, 2e-5, f"problem {i} dW rows")
         assert_close(bg, dy.double().sum(0), 2e-5, f"problem {i} db")
+
+
+def _fp64_rows(a, b, layout, rows):
+    A = a.double().t()[rows] if layout == "tn" else a.double()[rows]
+    B = b.double() if layout in ("nn", "tn") else b.double().t()
+    return A @ B
+
+
+@pytest.mark.parametrize("layout,m,n,k,epi", [
+    ("nt", 12608, 3072, 768, "gelu"),       # FF1 of one forward slice (bias + exact-erf GELU, saves the pre-activation)
+    ("nt", 12608, 768, 3072, "residual"),   # FF2: bias + f32 residual stream in / out
+    ("nt", 12608, 2304, 768, "bias"),       # packed qkv projection
+    ("nn", 12608, 3072, 768, "dgelu"),      # dX of FF2 with the GELU' epilogue, one backward slice
+    ("nn", 25216, 3072, 768, "dgelu"),      # ... and the full batch (one-pass backward)
+    ("nn", 12608, 768, 3072, "none"),       # dX of FF1
+    ("tn", 768, 3072, 25216, "none"),       # dW of FF2 as ONE GEMM: split-K by ops.pick_split_k + ordered reduce
+    ("tn", 2304, 768, 25216, "none"),
+])
+def test_gemm_at_the_benchmark_shapes(layout, m, n, k, epi):
+    """The exact launch shapes of the ViT-B/16 batch-128 step (bench.gemm_shapes) with their epilogues, against fp64 math on
+    the same bf16 operands for 96 sampled rows (the full-size numerics were only covered up to K = 12 608)."""
+    g = torch.Generator(device=DEV).manual_seed(m + n + k)
+    bf = torch.bfloat16
+    rnd = lambda *s: (torch.randn(*s, generator=g, device=DEV) * 0.5).to(bf)  # noqa: E731
+    kw = {}
+    if layout == "nt":
+        a, b = rnd(m, k), rnd(n, k)
+    elif layout == "nn":
+        a, b, kw = rnd(m, k), rnd(k, n), dict(b_trans=True)
+    else:
+        a, b = rnd(k, m), rnd(k, n)
+        kw = dict(a_trans=True, b_trans=True, out_dtype=torch.float32, split_k=ops.pick_split_k(m, n, k))
+    rows = torch.randint(0, m, (96,), generator=g, device=DEV)
+    want = _fp64_rows(a, b, layout, rows)
+    bias = torch.randn(n, generator=g, device=DEV) if epi in ("bias", "gelu", "residual") else None
+    if bias is not None:
+        want = want + bias.double()
+    if epi == "gelu":
+        pre = torch.empty(m, n, dtype=bf, device=DEV)
+        out = ops.gemm(a, b, bias=bias, epilogue=ops.EPI_GELU, aux_out=pre, **kw)
+        assert_close(pre[rows], want, 4e-3, f"{layout} {m}x{n}x{k} pre-activation")
+        assert_close(out[rows], torch.nn.functional.gelu(pre[rows].double()), 4e-3, f"{layout} {m}x{n}x{k} gelu")
+    elif epi == "residual":
+        res = torch.randn(m, n, generator=g, device=DEV)
+        out = ops.gemm(a, b, bias=bias, epilogue=ops.EPI_RESIDUAL, aux_in=res, out_dtype=torch.float32, **kw)
+        assert_close(out[rows], want + res[rows].double(), 2e-5, f"{layout} {m}x{n}x{k} f32 residual")
+    elif epi == "dgelu":
+        pre = rnd(m, n)
+        out = ops.gemm(a, b, epilogue=ops.EPI_DGELU, aux_in=pre, **kw)
+        x = pre[rows].double().requires_grad_(True)
+        torch.nn.functional.gelu(x).backward(torch.ones_like(x))
+        assert_close(out[rows], want * x.grad, 4e-3, f"{layout} {m}x{n}x{k} gelu'")
+    else:
+        out = ops.gemm(a, b, bias=bias, **kw)
+        assert_close(out[rows], want, 2e-5 if out.dtype == torch.float32 else 4e-3, f"{layout} {m}x{n}x{k}")

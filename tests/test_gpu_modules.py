@@ -236,7 +236,7 @@ def test_vit_b16_loss_within_1e3_of_cpu_reference():
     logits.backward(dlogits)
     worst = ("", 0.0)
     for k, v in _grads(m).items():
-        err = assert_close(v, want_grads[k], 6e-2, f"ViT-B/16 grad {k}", abs_floor=1e-5)
+        err = assert_close(v, want_grads[k], 2.5e-2, f"ViT-B/16 grad {k}", abs_floor=1e-5)  # measured worst 1.3e-2
         if want_grads[k].abs().max() > 1e-5 and err > worst[1]:
             worst = (k, err)
     print(f"ViT-B/16: worst parameter-gradient rel-L2 {worst[1]:.2e} ({worst[0]})")
@@ -303,7 +303,8 @@ def test_post_norm_stack_and_positional_interpolation_golden(golden):
 
 def test_forward_slices_on_streams_are_bit_equal_to_one_pass(golden):
     """`fused.FWD_HALVES`: the block stack's forward as 2 / 3 batch-slice pipelines on separate streams gives the same
-    bits as one pass for the logits, and the same gradients (the backward is the same full-batch pass either way)"""
+    bits as one pass for the logits, and the same gradients (round 3: the backward is sliced too, `fused.BWD_HALVES`;
+    its LayerNorm parameter gradients then add the slices in order)"""
     from cflearn_amd import fused
 
     g = golden("vit_small.pt")
@@ -330,3 +331,40 @@ def test_forward_slices_on_streams_are_bit_equal_to_one_pass(golden):
                 assert_close(b, a, 1e-5, f"gradient with {v} forward slices", abs_floor=1e-7)
     finally:
         fused.FWD_HALVES = keep
+
+
+def test_sliced_passes_with_stale_weight_shadows(golden):
+    """with forward slices on side streams, a STALE bf16 weight shadow (weights changed in place by a
+    torch optimizer, no ParamArena; or the very first forward of a fresh module) used to be re-cast on the main stream
+    AFTER the side stream had forked — the side slice could read old / half-written weights.  Fresh module, sliced from
+    the first call, weights stepped in place between forwards; every step must match an identical model run as one pass
+    on one stream."""
+    import copy
+
+    from cflearn_amd import fused
+
+    g = golden("vit_small.pt")
+    torch.manual_seed(5)
+    xs = [torch.randn(8, *g["img"].shape[1:], device=DEV) for _ in range(4)]
+    keep = fused.FWD_HALVES, fused.BWD_HALVES
+    try:
+        outs = {}
+        for name, (fh, bh) in (("sliced", (2, 2)), ("one pass", (1, 1))):
+            fused.FWD_HALVES, fused.BWD_HALVES = fh, bh
+            m = _small_vit(g)  # fresh module: no shadow exists yet
+            opt = torch.optim.SGD(m.parameters(), lr=0.05)
+            rec = []
+            for x in xs:
+                opt.zero_grad(set_to_none=True)
+                y = m(x)
+                y = y["predictions"] if isinstance(y, dict) else y
+                y.float().square().mean().backward()
+                opt.step()  # in-place update: every shadow is stale at the next forward
+                rec.append(y.detach().clone())
+            torch.cuda.synchronize()
+            outs[name] = rec
+        for i, (a, b) in enumerate(zip(outs["sliced"], outs["one pass"])):
+            assert_close(a, b, 2e-3 if i else 0.0, f"logits of step {i}", abs_floor=1e-6)
+        assert torch.equal(outs["sliced"][0], outs["one pass"][0])
+    finally:
+        fused.FWD_HALVES, fused.BWD_HALVES = keep

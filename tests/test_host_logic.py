@@ -408,3 +408,19 @@ def test_whole_param_resolves_reshaped_views_only():
     assert whole_param(None) is None
     h = torch.randn(4, 4)  # a non-parameter leaf that does not require grad
     assert whole_param(h.view(16)) is not h
+
+
+def test_bench_self_launch_command_and_percentiles():
+    """`python bench.py --gpus N` from a plain shell starts its own ranks: the launcher command line, the
+    refusal when the node has fewer GPUs than ranks, and the percentile helper of the per-step timings."""
+    import bench
+
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "3"], 29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert 1024 < bench.free_port() < 65536
+    assert bench.self_launch(2, ["--gpus", "2"]) == 2  # no GPU in this container: refused, not launched
+    vals = sorted([20.0, 21.0, 19.0, 25.0, 20.5])
+    assert bench._pct(vals, 0.5) == 20.5 and bench._pct(vals, 0.0) == 19.0 and bench._pct(vals, 1.0) == 25.0
+    assert abs(bench._pct(vals, 0.1) - 19.4) < 1e-9
