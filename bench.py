@@ -707,8 +707,8 @@ def main() -> None:
         "step_ms": {"median": round(_pct(per_step, 0.5), 3), "p10": round(_pct(per_step, 0.1), 3),
                     "p90": round(_pct(per_step, 0.9), 3), "min": round(per_step[0], 3), "max": round(per_step[-1], 3),
                     "n": len(per_step), "definition": "HIP events between consecutive steps on the issuing stream (this rank)"},
-        "launcher": {"self": "bench.py started its own ranks (torch.distributed.run)", None: "external"}[
-            os.environ.get("CFHIP_BENCH_LAUNCHER")] if distributed else "single process",
+        "launcher": ("bench.py started its own ranks (torch.distributed.run)" if os.environ.get("CFHIP_BENCH_LAUNCHER") == "self"
+                     else "external torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process"),
     }
     if distributed:
         result["rccl"] = {

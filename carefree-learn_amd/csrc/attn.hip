@@ -18,6 +18,7 @@
 //     accumulates dQ; pass B (wave = kv tile) recomputes them transposed and accumulates dK, dV.
 //     Deterministic; costs 7 instead of 5 GEMM units, attention is 3.4 % of the ViT FLOPs.
 #include "common.h"
+#include <type_traits>
 #include <math.h>
 
 namespace {
@@ -88,7 +89,7 @@ __device__ __forceinline__ void dma_tile(char* tile, const bf16_t* base, long st
     const int row = inst * 8 + r8;
     const int chunk = slot ^ swz(row);
     const unsigned off = row < rows_valid ? (unsigned)(row * stride_t * 2 + chunk * 16) : 0x80000000u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(tile + inst * 1024), 16, off, 0, 0, 0);
+    lds_dma16(rsrc, tile + inst * 1024, off);
   }
 }
 
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnParams p) {
     dma_tile(Ks, kb, p.kv_st, p.Tk, NB * 32, wave, nwaves, lane);
     dma_tile(Vs, vb, p.kv_st, p.Tk, NB * 32, wave, nwaves, lane);
   }
+  lds_dma_wait_all();
   __syncthreads();  // (drains the DMA: vmcnt(0) + barrier)
   if (ATTN_ABL(2)) return;
 
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(AttnParams p, int n
   const int nwaves = blockDim.x >> 6;
   dma_tile(Ks, p.k + (long)b * p.kv_sb + h * DH, p.kv_st, p.Tk, nb * 32, wave, nwaves, lane);
   dma_tile(Vs, p.v + (long)b * p.kv_sb + h * DH, p.kv_st, p.Tk, nb * 32, wave, nwaves, lane);
+  lds_dma_wait_all();
   __syncthreads();
 
   const int i = lane & 15, g = lane >> 4;
@@ -419,6 +422,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_kernel(AttnParams p, int 
     }
   }
   }
+  lds_dma_wait_all();
   __syncthreads();
   if (ATTN_ABL(2)) return;
 
@@ -502,7 +506,7 @@ __device__ __forceinline__ void dma_tile_pers(char* tile, const bf16_t* base, lo
     const int row = inst * 8 + r8;
     const int chunk = slot ^ swz(row);
     const unsigned off = (live && row < rows_valid) ? (unsigned)(row * stride_t * 2 + chunk * 16) : 0x80000000u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(tile + inst * 1024), 16, off, 0, 0, 0);
+    lds_dma16(rsrc, tile + inst * 1024, off);
   }
 }
 
@@ -556,6 +560,7 @@ __global__ __launch_bounds__(PERS_WAVES * 64, 4) void attn_bwd_dkv_pers_kernel(A
     stats_load(hh, hh < heads, lv, dv);
     stats_store(smem, lv, dv);
   }
+  lds_dma_wait_all();
   __syncthreads();
   for (; hh < heads; hh += gridDim.x) {
     const int b = hh / p.H, h = hh - b * p.H;
@@ -615,6 +620,7 @@ __global__ __launch_bounds__(PERS_WAVES * 64, 4) void attn_bwd_dkv_pers_kernel(A
       store_row64(p.dv + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH, dvt, 1.0f, g, valid);
     }
     stats_store(smem + (cur ^ 1) * BUF, lv, dv);
+    lds_dma_wait_all();
     __syncthreads();  // the next head's operands have landed (vmcnt 0) and nobody reads this head's buffer any more
     cur ^= 1;
   }
@@ -630,12 +636,20 @@ __global__ __launch_bounds__(PERS_WAVES * 64, 4) void attn_bwd_dkv_pers_kernel(A
 // backward: p = exp2(s * scale - lse) with the saved lse, so chunks just accumulate.  The chunked operand is re-read
 // once per 128-row workgroup, from L2.
 // ------------------------------------------------------------------------------------------------
+// Round 3 measured a TWO-slot chunk ring for head_dim <= 64 (chunk c + 1 streaming into the other slot while chunk c is
+// computed, 128-row chunks, one barrier per chunk; the code path is still here: NSLOT = 2): UNet shape B1 H8 T65536 dh40 forward
+// 12.47 -> 13.86 ms, dQ 12.84 -> 13.21, dK/dV after a dQ pass 17.5 -> 20.2; 256^2 step 611 -> 645 ms
+// (profiles/r03/attn_long_bench_{r02kernels,two_slot_ring}.log).  The load was already covered by the second workgroup of
+// the CU; what the ring costs is twice the online-softmax steps per key (128- instead of 256-key chunks) and every wave of
+// the workgroup in lock-step on one barrier.  Kept: NSLOT = 1, 256-row chunks for head_dim <= 64.
 template <int NH>
 struct Gen {
-  static constexpr int CH = NH == 1 ? 256 : 128;  // rows per staged chunk (LDS: 2 operands x NH halves x CH x 128 B)
+  static constexpr int CH = NH == 1 ? 256 : 128;  // rows per staged chunk (LDS: 2 operands x NH halves x CH x 128 B per slot)
   static constexpr int CHB = CH / 32;
   static constexpr int HALF_BYTES = CH * 128;
   static constexpr int OPER_BYTES = NH * HALF_BYTES;
+  static constexpr int SLOT_BYTES = 2 * OPER_BYTES;
+  static constexpr int NSLOT = 1;
 };
 
 // one 64-column half of `rows_pad` rows -> swizzled [rows][64] tile; columns >= dh and rows >= rows_valid are zero
@@ -651,7 +665,7 @@ __device__ __forceinline__ void dma_half(char* tile, const bf16_t* base, long st
     const int chunk = slot ^ swz(row);
     const bool ok = row < rows_valid && half * 64 + chunk * 8 < dh;
     const unsigned off = ok ? (unsigned)(row * stride_t * 2 + half * 128 + chunk * 16) : 0x80000000u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(tile + inst * 1024), 16, off, 0, 0, 0);
+    lds_dma16(rsrc, tile + inst * 1024, off);
   }
 }
 template <int NH>
@@ -699,12 +713,27 @@ __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_fwd_kernel(Attn
 #pragma unroll
   for (int dt = 0; dt < 4 * NH; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int kv0 = 0; kv0 < p.Tk; kv0 += G::CH) {
-    const int rows = min(G::CH, p.Tk - kv0);
-    __syncthreads();  // every wave is done with the previous chunk
-    dma_oper<NH>(Ks, kb + (long)kv0 * p.kv_st, p.kv_st, rows, dh, wave, nwaves, lane);
-    dma_oper<NH>(Vs, vb + (long)kv0 * p.kv_st, p.kv_st, rows, dh, wave, nwaves, lane);
-    __syncthreads();  // vmcnt(0) + barrier
+  auto issue = [&](int k0, char* slot) {
+    const int rows_ = min(G::CH, p.Tk - k0);
+    int ln = lane;  // opaque copy: the per-lane DMA offsets are recomputed per chunk (a few VALU) instead of being hoisted out
+    asm volatile("" : "+v"(ln));  // of the chunk loop and spilled around it
+    dma_oper<NH>(slot, kb + (long)k0 * p.kv_st, p.kv_st, rows_, dh, wave, nwaves, ln);
+    dma_oper<NH>(slot + G::OPER_BYTES, vb + (long)k0 * p.kv_st, p.kv_st, rows_, dh, wave, nwaves, ln);
+  };
+  if (G::NSLOT == 2) issue(0, smem);
+  for (int kv0 = 0, c = 0; kv0 < p.Tk; kv0 += G::CH, ++c) {
+    if (G::NSLOT == 2) {
+      lds_dma_wait_all();
+      __syncthreads();  // chunk c has landed everywhere; every wave is done with chunk c - 1 (the other slot)
+      if (kv0 + G::CH < p.Tk) issue(kv0 + G::CH, smem + ((c + 1) & 1) * G::SLOT_BYTES);
+      Ks = smem + (c & 1) * G::SLOT_BYTES;
+      Vs = Ks + G::OPER_BYTES;
+    } else {
+      __syncthreads();  // every wave is done with the previous chunk
+      issue(kv0, smem);
+      lds_dma_wait_all();
+      __syncthreads();
+    }
     if (!active) continue;
     if (p.causal && kv0 > row0 + 15) continue;  // chunk entirely in the future of this tile (wave-uniform)
     f32x4 st[2 * G::CHB];
@@ -825,12 +854,28 @@ __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_bwd_dq_kernel(A
 #pragma unroll
   for (int dt = 0; dt < 4 * NH; ++dt) dqt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int kv0 = 0; kv0 < p.Tk; kv0 += G::CH) {
+  auto issue = [&](int k0, char* slot) {
+    const int rows_ = min(G::CH, p.Tk - k0);
+    int ln = lane;  // opaque copy: the per-lane DMA offsets are recomputed per chunk (a few VALU) instead of being hoisted out
+    asm volatile("" : "+v"(ln));  // of the chunk loop and spilled around it
+    dma_oper<NH>(slot, p.k + (long)b * p.kv_sb + (long)k0 * p.kv_st + h * dh, p.kv_st, rows_, dh, wave, nwaves, ln);
+    dma_oper<NH>(slot + G::OPER_BYTES, p.v + (long)b * p.kv_sb + (long)k0 * p.kv_st + h * dh, p.kv_st, rows_, dh, wave, nwaves, ln);
+  };
+  if (G::NSLOT == 2) issue(0, smem);
+  for (int kv0 = 0, c = 0; kv0 < p.Tk; kv0 += G::CH, ++c) {
     const int rows = min(G::CH, p.Tk - kv0);
-    __syncthreads();
-    dma_oper<NH>(Ks, p.k + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * dh, p.kv_st, rows, dh, wave, nwaves, lane);
-    dma_oper<NH>(Vs, p.v + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * dh, p.kv_st, rows, dh, wave, nwaves, lane);
-    __syncthreads();
+    if (G::NSLOT == 2) {
+      lds_dma_wait_all();
+      __syncthreads();  // chunk c has landed everywhere; every wave is done with chunk c - 1 (the other slot)
+      if (kv0 + G::CH < p.Tk) issue(kv0 + G::CH, smem + ((c + 1) & 1) * G::SLOT_BYTES);
+      Ks = smem + (c & 1) * G::SLOT_BYTES;
+      Vs = Ks + G::OPER_BYTES;
+    } else {
+      __syncthreads();
+      issue(kv0, smem);
+      lds_dma_wait_all();
+      __syncthreads();
+    }
     if (!active) continue;
     if (p.causal && kv0 > row0 + 15) continue;
     const int nbl = (rows + 31) / 32;
@@ -909,76 +954,126 @@ __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_bwd_dkv_kernel(
   for (int dt = 0; dt < 4 * NH; ++dt) { dkt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const int dslots = dh / 8;  // 16-byte slots of one row of dO / O
 
-  for (int q0 = 0; q0 < p.Tq; q0 += G::CH) {
+  // lse (log2 domain) and delta_i = sum_d dO[i][d] * O[i][d] of a chunk's rows: thread t of the first CH threads owns row t
+  auto stats_load = [&](int q0_, float& lv, float& dv) {
+    const int t = threadIdx.x;
+    lv = INFINITY;
+    dv = 0.f;
+    if (t >= G::CH) return;
+    const int tq = q0_ + t;
+    if (tq >= p.Tq) return;
+    if (G::NSLOT == 2 || p.delta_ready) {  // (the two-slot launches always find delta filled: attn_delta_kernel)
+      dv = p.delta[((long)b * p.H + h) * p.Tq + tq];
+    } else {
+      const bf16_t* dor = p.d_o + (long)b * p.o_sb + (long)tq * p.o_st + h * dh;
+      const bf16_t* orr = p.o_in + (long)b * p.o_sb + (long)tq * p.o_st + h * dh;
+      for (int sl = 0; sl < dslots; ++sl) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(dor + sl * 8);
+        const u32x4 c = *reinterpret_cast<const u32x4*>(orr + sl * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dv += bf16lo(a[e]) * bf16lo(c[e]) + bf16hi(a[e]) * bf16hi(c[e]);
+      }
+    }
+    lv = p.lse[((long)b * p.H + h) * p.Tq + tq] * LOG2E;
+  };
+  auto stats_store = [&](char* slot, float lv, float dv) {
+    if ((int)threadIdx.x < G::CH) {
+      float* ls = reinterpret_cast<float*>(slot + G::SLOT_BYTES);
+      ls[threadIdx.x] = lv;
+      ls[G::CH + threadIdx.x] = dv;
+    }
+  };
+  auto issue = [&](int q0_, char* slot) {
+    const int rows_ = min(G::CH, p.Tq - q0_);
+    int ln = lane;  // opaque copy: see attn_gen_fwd_kernel
+    asm volatile("" : "+v"(ln));
+    dma_oper<NH>(slot, p.q + (long)b * p.q_sb + (long)q0_ * p.q_st + h * dh, p.q_st, rows_, dh, wave, nwaves, ln);
+    dma_oper<NH>(slot + G::OPER_BYTES, p.d_o + (long)b * p.o_sb + (long)q0_ * p.o_st + h * dh, p.o_st, rows_, dh, wave, nwaves, ln);
+  };
+  constexpr int RING = G::SLOT_BYTES + 2 * G::CH * (int)sizeof(float);  // operands + statistics of one chunk
+  float nlv = INFINITY, ndv = 0.f;  // statistics of the NEXT chunk: loaded before this chunk's MFMAs, stored after them
+  if (G::NSLOT == 2) {
+    stats_load(0, nlv, ndv);
+    issue(0, smem);
+    stats_store(smem, nlv, ndv);
+  }
+  for (int q0 = 0, c = 0; q0 < p.Tq; q0 += G::CH, ++c) {
     const int rows = min(G::CH, p.Tq - q0);
-    __syncthreads();
-    dma_oper<NH>(Qs, p.q + (long)b * p.q_sb + (long)q0 * p.q_st + h * dh, p.q_st, rows, dh, wave, nwaves, lane);
-    dma_oper<NH>(dOs, p.d_o + (long)b * p.o_sb + (long)q0 * p.o_st + h * dh, p.o_st, rows, dh, wave, nwaves, lane);
-    // lse and delta_i = sum_d dO[i][d] * O[i][d] of the chunk's rows: thread t of the first CH threads owns row t
-    for (int t = threadIdx.x; t < G::CH; t += blockDim.x) {
-      const int tq = q0 + t;
-      float sacc = 0.f;
-      if (tq < p.Tq) {
-        if (p.delta_ready) {
-          sacc = p.delta[((long)b * p.H + h) * p.Tq + tq];
-        } else {
-          const bf16_t* dor = p.d_o + (long)b * p.o_sb + (long)tq * p.o_st + h * dh;
-          const bf16_t* orr = p.o_in + (long)b * p.o_sb + (long)tq * p.o_st + h * dh;
-          for (int sl = 0; sl < dslots; ++sl) {
-            const u32x4 a = *reinterpret_cast<const u32x4*>(dor + sl * 8);
-            const u32x4 c = *reinterpret_cast<const u32x4*>(orr + sl * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sacc += bf16lo(a[e]) * bf16lo(c[e]) + bf16hi(a[e]) * bf16hi(c[e]);
+    const bool more = q0 + G::CH < p.Tq;
+    if (G::NSLOT == 2) {
+      lds_dma_wait_all();
+      __syncthreads();  // chunk c (operands and statistics) is visible; every wave is done with chunk c - 1 (the other slot)
+      if (more) {
+        stats_load(q0 + G::CH, nlv, ndv);  // (issued BEFORE the DMA: the compiler's wait for these loads at the store below
+        issue(q0 + G::CH, smem + ((c + 1) & 1) * RING);  //  comes after this chunk's MFMAs, when the DMA has landed anyway)
+      }
+    } else {
+      __syncthreads();
+      issue(q0, smem);
+      stats_load(q0, nlv, ndv);
+      stats_store(smem, nlv, ndv);
+      lds_dma_wait_all();
+      __syncthreads();
+    }
+    const bool skip = !active || (p.causal && q0 + G::CH - 1 < row0);  // inactive tile / every query of the chunk precedes it
+    if (skip) {
+      if (G::NSLOT == 2 && more) stats_store(smem + ((c + 1) & 1) * RING, nlv, ndv);
+      continue;
+    }
+    // the chunk's MFMA work, once per ring slot with COMPILE-TIME LDS addresses (a run-time slot base costs an address
+    // register per fragment read: the 128-register budget of two workgroups per CU does not have them)
+    auto body = [&](auto slot_tag) {
+      constexpr int S = decltype(slot_tag)::value;
+      const char* Qs_ = smem + S * RING;
+      const char* dOs_ = Qs_ + G::OPER_BYTES;
+      const float* lse_ = reinterpret_cast<const float*>(Qs_ + G::SLOT_BYTES);
+      const float* delta_ = lse_ + G::CH;
+      const int nbl = (rows + 31) / 32;
+#pragma unroll 1
+      for (int a = 0; a < nbl; ++a) {
+        f32x4 pp[2], ds[2];
+  #pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int it = 2 * a + t;
+          f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+          for (int ks = 0; ks < 2 * NH; ++ks) {
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs_ + (ks >> 1) * G::HALF_BYTES, it * 16, ks & 1, lane),
+                                                         kf[ks], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dOs_ + (ks >> 1) * G::HALF_BYTES, it * 16, ks & 1, lane),
+                                                         vf[ks], dp, 0, 0, 0);
+          }
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_ + it * 16 + 4 * g);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_ + it * 16 + 4 * g);
+          Philox rb = {{0u, 0u, 0u, 0u}};
+          if (DROP) rb = drop_block(p, b, h, (q0 >> 2) + it * 4 + g, kj >> 2);  // rows 4g .. 4g + 3 = words 0 .. 3
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pr = __builtin_amdgcn_exp2f(sc[r] * sl2 - l4[r]);
+            if (!PLAIN) {
+              const int qi = q0 + it * 16 + 4 * g + r;
+              pr = (qi < p.Tq && keep_at(p, b, h, qi, kj)) ? pr : 0.f;
+            }
+            float keep_scale = 1.0f;
+            if (DROP) keep_scale = ((rb.c[r] >> (8 * (kj & 3))) & 255u) >= p.drop_thresh ? p.drop_scale : 0.f;
+            pp[t][r] = pr * keep_scale;
+            ds[t][r] = pr * (dp[r] * keep_scale - d4[r]);
           }
         }
-      }
-      delta_s[t] = sacc;
-      lse_s[t] = tq < p.Tq ? p.lse[((long)b * p.H + h) * p.Tq + tq] * LOG2E : INFINITY;
-    }
-    __syncthreads();
-    if (!active) continue;
-    if (p.causal && q0 + G::CH - 1 < row0) continue;  // every query of the chunk precedes this kv tile
-    const int nbl = (rows + 31) / 32;
-    for (int a = 0; a < nbl; ++a) {
-      f32x4 pp[2], ds[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int it = 2 * a + t;
-        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2 * NH; ++ks) {
-          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs + (ks >> 1) * G::HALF_BYTES, it * 16, ks & 1, lane),
-                                                       kf[ks], sc, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dOs + (ks >> 1) * G::HALF_BYTES, it * 16, ks & 1, lane),
-                                                       vf[ks], dp, 0, 0, 0);
-        }
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + it * 16 + 4 * g);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + it * 16 + 4 * g);
-        Philox rb = {{0u, 0u, 0u, 0u}};
-        if (DROP) rb = drop_block(p, b, h, (q0 >> 2) + it * 4 + g, kj >> 2);  // rows 4g .. 4g + 3 = words 0 .. 3
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float pr = __builtin_amdgcn_exp2f(sc[r] * sl2 - l4[r]);
-          if (!PLAIN) {
-            const int qi = q0 + it * 16 + 4 * g + r;
-            pr = (qi < p.Tq && keep_at(p, b, h, qi, kj)) ? pr : 0.f;
-          }
-          float keep_scale = 1.0f;
-          if (DROP) keep_scale = ((rb.c[r] >> (8 * (kj & 3))) & 255u) >= p.drop_thresh ? p.drop_scale : 0.f;
-          pp[t][r] = pr * keep_scale;
-          ds[t][r] = pr * (dp[r] * keep_scale - d4[r]);
+        const bf16x8 ppk = pack8(pp[0], pp[1]);
+        const bf16x8 dsk = pack8(ds[0], ds[1]);
+  #pragma unroll
+        for (int dt = 0; dt < 4 * NH; ++dt) {
+          dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              frag_cols(dOs_ + (dt >> 2) * G::HALF_BYTES, a * 32, (dt & 3) * 16, lane), ppk, dvt[dt], 0, 0, 0);
+          dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              frag_cols(Qs_ + (dt >> 2) * G::HALF_BYTES, a * 32, (dt & 3) * 16, lane), dsk, dkt[dt], 0, 0, 0);
         }
       }
-      const bf16x8 ppk = pack8(pp[0], pp[1]);
-      const bf16x8 dsk = pack8(ds[0], ds[1]);
-#pragma unroll
-      for (int dt = 0; dt < 4 * NH; ++dt) {
-        dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            frag_cols(dOs + (dt >> 2) * G::HALF_BYTES, a * 32, (dt & 3) * 16, lane), ppk, dvt[dt], 0, 0, 0);
-        dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            frag_cols(Qs + (dt >> 2) * G::HALF_BYTES, a * 32, (dt & 3) * 16, lane), dsk, dkt[dt], 0, 0, 0);
-      }
-    }
+    };
+    if (G::NSLOT == 2 && (c & 1)) body(std::integral_constant<int, 1>{});
+    else body(std::integral_constant<int, 0>{});
+    if (G::NSLOT == 2 && more) stats_store(smem + ((c + 1) & 1) * RING, nlv, ndv);
   }
   if (active && kj < p.Tk) {
     bf16_t* dkrow = p.dk + (long)b * p.kv_sb + (long)kj * p.kv_st + h * dh;
@@ -1017,6 +1112,27 @@ int check_common(const char* who, const void* q, const void* k, const void* v, i
   return CFHIP_OK;
 }
 
+// delta[b][h][t] = sum_d dO[b][t][h][d] * O[b][t][h][d]: what the dQ pass leaves behind for the dK / dV pass; launched on its
+// own when the dK / dV pass of the two-slot kernels runs without a dQ pass in front of it (one thread per row).
+__global__ void attn_delta_kernel(AttnParams p) {
+  const long total = (long)p.B * p.H * p.Tq;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(idx % p.Tq);
+    const long bh = idx / p.Tq;
+    const int h = (int)(bh % p.H), b = (int)(bh / p.H);
+    const bf16_t* dor = p.d_o + (long)b * p.o_sb + (long)t * p.o_st + h * p.dh;
+    const bf16_t* orr = p.o_in + (long)b * p.o_sb + (long)t * p.o_st + h * p.dh;
+    float s = 0.f;
+    for (int sl = 0; sl < p.dh / 8; ++sl) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(dor + sl * 8);
+      const u32x4 c = *reinterpret_cast<const u32x4*>(orr + sl * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += bf16lo(a[e]) * bf16lo(c[e]) + bf16hi(a[e]) * bf16hi(c[e]);
+    }
+    p.delta[idx] = s;
+  }
+}
+
 template <typename K>
 int set_lds(K kernel, size_t bytes, const char* who) {
   if (bytes > 65536) {
@@ -1037,7 +1153,7 @@ int set_lds(K kernel, size_t bytes, const char* who);
 template <int NH>
 int launch_gen_fwd_drop(const AttnParams& p, bool plain, hipStream_t s) {
   dim3 grid((p.Tq + 127) / 128, p.H, p.B);
-  const size_t lds = (size_t)2 * Gen<NH>::OPER_BYTES;
+  const size_t lds = (size_t)Gen<NH>::NSLOT * Gen<NH>::SLOT_BYTES;
   int rc = plain ? set_lds(attn_gen_fwd_kernel<NH, true, true>, lds, "attn_fwd") : set_lds(attn_gen_fwd_kernel<NH, false, true>, lds, "attn_fwd");
   if (rc != CFHIP_OK) return rc;
   if (plain) hipLaunchKernelGGL((attn_gen_fwd_kernel<NH, true, true>), grid, dim3(512), lds, s, p);
@@ -1050,7 +1166,7 @@ template <int NH>
 int launch_gen_bwd_drop(const AttnParams& p, bool plain, int parts, hipStream_t s) {
   if (parts & 1) {
     dim3 grid((p.Tq + 127) / 128, p.H, p.B);
-    const size_t lds = (size_t)2 * Gen<NH>::OPER_BYTES;
+    const size_t lds = (size_t)Gen<NH>::NSLOT * Gen<NH>::SLOT_BYTES;
     int rc = plain ? set_lds(attn_gen_bwd_dq_kernel<NH, true, true>, lds, "attn_bwd_dq")
                    : set_lds(attn_gen_bwd_dq_kernel<NH, false, true>, lds, "attn_bwd_dq");
     if (rc != CFHIP_OK) return rc;
@@ -1059,8 +1175,13 @@ int launch_gen_bwd_drop(const AttnParams& p, bool plain, int parts, hipStream_t 
     CFHIP_CHECK_LAUNCH("attn_gen_bwd_dq(dropout)");
   }
   if (parts & 2) {
+    if (Gen<NH>::NSLOT == 2 && !p.delta_ready && !(parts & 1)) {
+      const long rows = (long)p.B * p.H * p.Tq;
+      hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 255) / 256 > 4096 ? 4096 : (rows + 255) / 256)), dim3(256), 0, s, p);
+      CFHIP_CHECK_LAUNCH("attn_delta");
+    }
     dim3 grid((p.Tk + 127) / 128, p.H, p.B);
-    const size_t lds = (size_t)2 * Gen<NH>::OPER_BYTES + (size_t)2 * Gen<NH>::CH * sizeof(float);
+    const size_t lds = (size_t)Gen<NH>::NSLOT * (Gen<NH>::SLOT_BYTES + (size_t)2 * Gen<NH>::CH * sizeof(float));
     int rc = plain ? set_lds(attn_gen_bwd_dkv_kernel<NH, true, true>, lds, "attn_bwd_dkv")
                    : set_lds(attn_gen_bwd_dkv_kernel<NH, false, true>, lds, "attn_bwd_dkv");
     if (rc != CFHIP_OK) return rc;
@@ -1074,7 +1195,7 @@ int launch_gen_bwd_drop(const AttnParams& p, bool plain, int parts, hipStream_t 
 template <int NH>
 int launch_gen_fwd(const AttnParams& p, bool plain, hipStream_t s) {
   dim3 grid((p.Tq + 127) / 128, p.H, p.B);
-  const size_t lds = (size_t)2 * Gen<NH>::OPER_BYTES;
+  const size_t lds = (size_t)Gen<NH>::NSLOT * Gen<NH>::SLOT_BYTES;
   int rc = plain ? set_lds(attn_gen_fwd_kernel<NH, true>, lds, "attn_fwd") : set_lds(attn_gen_fwd_kernel<NH, false>, lds, "attn_fwd");
   if (rc != CFHIP_OK) return rc;
   if (plain) hipLaunchKernelGGL((attn_gen_fwd_kernel<NH, true>), grid, dim3(512), lds, s, p);
@@ -1087,7 +1208,7 @@ template <int NH>
 int launch_gen_bwd(const AttnParams& p, bool plain, int parts, hipStream_t s) {
   if (parts & 1) {
     dim3 grid((p.Tq + 127) / 128, p.H, p.B);
-    const size_t lds = (size_t)2 * Gen<NH>::OPER_BYTES;
+    const size_t lds = (size_t)Gen<NH>::NSLOT * Gen<NH>::SLOT_BYTES;
     int rc = plain ? set_lds(attn_gen_bwd_dq_kernel<NH, true>, lds, "attn_bwd_dq")
                    : set_lds(attn_gen_bwd_dq_kernel<NH, false>, lds, "attn_bwd_dq");
     if (rc != CFHIP_OK) return rc;
@@ -1096,8 +1217,13 @@ int launch_gen_bwd(const AttnParams& p, bool plain, int parts, hipStream_t s) {
     CFHIP_CHECK_LAUNCH("attn_gen_bwd_dq");
   }
   if (parts & 2) {
+    if (Gen<NH>::NSLOT == 2 && !p.delta_ready && !(parts & 1)) {
+      const long rows = (long)p.B * p.H * p.Tq;
+      hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 255) / 256 > 4096 ? 4096 : (rows + 255) / 256)), dim3(256), 0, s, p);
+      CFHIP_CHECK_LAUNCH("attn_delta");
+    }
     dim3 grid((p.Tk + 127) / 128, p.H, p.B);
-    const size_t lds = (size_t)2 * Gen<NH>::OPER_BYTES + (size_t)2 * Gen<NH>::CH * sizeof(float);
+    const size_t lds = (size_t)Gen<NH>::NSLOT * (Gen<NH>::SLOT_BYTES + (size_t)2 * Gen<NH>::CH * sizeof(float));
     int rc = plain ? set_lds(attn_gen_bwd_dkv_kernel<NH, true>, lds, "attn_bwd_dkv")
                    : set_lds(attn_gen_bwd_dkv_kernel<NH, false>, lds, "attn_bwd_dkv");
     if (rc != CFHIP_OK) return rc;

@@ -32,6 +32,11 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, const voi
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(rsrc) : "memory");
 }
 
+// Every LDS-DMA this wave has issued has landed (follow with a barrier before other waves read the tile).  Needed because
+// the asm form above is invisible to the compiler: `__syncthreads()` no longer implies the vmcnt(0) it used to emit for the
+// builtin form.
+__device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 void cfhip_set_error(const char* fmt, ...);
 
 #define CFHIP_REQUIRE(cond, ...)          \

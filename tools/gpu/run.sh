@@ -6,6 +6,7 @@
 #   tests [pytest args]            pytest -m gpu (default: the whole suite)            -> gpurun_out/tests/pytest.log
 #   bench <tag> [bench.py args]    one bench.py run                                    -> gpurun_out/<tag>/bench.json
 #   prof <tag> [bench.py args]     rocprofv3 --kernel-trace --stats of bench.py        -> gpurun_out/<tag>/prof_summary.txt
+#   profw <tag> <n> [bench.py args]  the same for --workload unet | clip (n = steps + warm-up + 1 FLOP-count step in the trace)
 #   pmc <tag> [bench.py args]      HBM bytes: FETCH_SIZE and WRITE_SIZE in separate passes -> gpurun_out/<tag>/pmc_step.json
 #   trace <tag> [bench.py args]    kernel timeline (start / end / stream per launch)   -> gpurun_out/<tag>/timeline.csv.gz
 #   py <tag> <script> [args]       python <script> args                                -> gpurun_out/<tag>/<script>.log
@@ -30,6 +31,12 @@ case "$recipe" in
     f=$(ls $OUT/prof/*kernel_stats.csv 2>/dev/null | head -1)
     [ -n "$f" ] && python tools/prof_summary.py "$f" 7 > $OUT/prof_summary.txt && cp "$f" $OUT/kernel_stats.csv
     head -40 $OUT/prof_summary.txt | cut -c1-150; rm -rf $OUT/prof ;;
+  profw)  # rocprofv3 kernel stats of another workload: profw <tag> <steps-in-trace> [bench.py args, e.g. --workload unet --img 64 --steps 3 --warmup 2]
+    tag=$1; nsteps=$2; shift 2; OUT=gpurun_out/$tag; mkdir -p $OUT
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/prof" -o step -- python "$R/bench.py" "$@" ) > $OUT/prof.log 2>&1
+    f=$(ls $OUT/prof/*kernel_stats.csv 2>/dev/null | head -1)
+    [ -n "$f" ] && python tools/prof_summary.py "$f" $nsteps > $OUT/prof_summary.txt && cp "$f" $OUT/kernel_stats.csv
+    head -32 $OUT/prof_summary.txt | cut -c1-150; tail -2 $OUT/prof.log | cut -c1-300; rm -rf $OUT/prof ;;
   pmc)
     tag=$1; shift; OUT=gpurun_out/$tag; mkdir -p $OUT
     for ctr in FETCH_SIZE WRITE_SIZE; do
