@@ -1090,6 +1090,166 @@ __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_bwd_dkv_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 3, head_dim <= 64 without dropout: TWO 16-row tiles per wave.
+// In the kernels above every wave reads the WHOLE staged chunk from LDS for its 16 rows: per 256-key chunk 32 ds_read_b128
+// + 64 ds_read_b64_tr_b16 per wave = 256 LDS cycles, sixteen waves per CU = 4096 — exactly the matrix time of the chunk
+// (64 MFMAs x 16 cycles x 4 waves per SIMD): LDS bandwidth and the matrix pipe are co-bottlenecks and neither gets above
+// half.  Here a wave owns 32 query rows (forward, dQ) / 32 key rows (dK, dV): every K / V (Q / dO) fragment read from LDS
+// feeds two MFMAs, a workgroup covers 256 rows per staged chunk instead of 128 (half the L2 -> LDS bytes per FLOP), and
+// the two tiles are independent dependency chains inside the wave.  Scores live in registers for 64 keys at a time (32
+// registers for both tiles; the 256-key form would need 128), online softmax per 64-key block; the row sum is kept per
+// lane and folded across the four lanes of a row once, at the end.  Output columns beyond head_dim are not computed:
+// NDT = 3 column tiles for head_dim <= 48 (the UNet's 40-channel heads), 4 otherwise.
+// ------------------------------------------------------------------------------------------------
+constexpr int A2_ROWS = 256;   // rows of the walking operand per workgroup (8 waves x 32)
+constexpr int A2_CH = 256;     // rows of the staged operand per chunk (64 KB: K + V, or Q + dO)
+constexpr int A2_TILE = A2_CH * 128;
+
+template <bool PLAIN, int NDT>
+__global__ __launch_bounds__(512, 4) void attn_fwd2_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + A2_TILE;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int dh = p.dh;
+  const bf16_t* kb = p.k + (long)b * p.kv_sb + h * dh;
+  const bf16_t* vb = p.v + (long)b * p.kv_sb + h * dh;
+  const bf16_t* qb = p.q + (long)b * p.q_sb + h * dh;
+  const int row0 = (blockIdx.x * 8 + wave) * 32;
+  const bool active = row0 < p.Tq;  // inactive waves still stage and hit the barriers
+  bf16x8 qf[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[t][ks] = frag_global_dh(qb, p.q_st, row0 + 16 * t, active ? p.Tq : 0, ks, lane, dh);
+  const float sl2 = p.scale * LOG2E;
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};  // l: this LANE's share of the row sum
+  f32x4 ot[2][NDT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) ot[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kv0 = 0; kv0 < p.Tk; kv0 += A2_CH) {
+    const int rows = min(A2_CH, p.Tk - kv0);
+    __syncthreads();  // every wave is done with the previous chunk
+    {
+      int ln = lane;  // opaque copy: the per-lane DMA offsets are recomputed per chunk instead of hoisted and spilled
+      asm volatile("" : "+v"(ln));
+      dma_oper<1>(Ks, kb + (long)kv0 * p.kv_st, p.kv_st, rows, dh, wave, 8, ln);
+      dma_oper<1>(Vs, vb + (long)kv0 * p.kv_st, p.kv_st, rows, dh, wave, 8, ln);
+    }
+    lds_dma_wait_all();
+    __syncthreads();
+    if (!active) continue;
+    if (p.causal && kv0 > row0 + 31) continue;  // chunk entirely in the future of both tiles (wave-uniform)
+    const int nsb = (rows + 63) >> 6;
+#pragma unroll 1
+    for (int sb = 0; sb < nsb; ++sb) {
+      const int k0 = sb * 64;
+      if (p.causal && kv0 + k0 > row0 + 31) break;
+      f32x4 st[2][4];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const bf16x8 kf0 = frag_rows(Ks, k0 + jt * 16, 0, lane);
+        const bf16x8 kf1 = frag_rows(Ks, k0 + jt * 16, 1, lane);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[t][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[t][1], acc, 0, 0, 0);
+          st[t][jt] = acc;
+        }
+      }
+      // Key positions >= Tk (zero rows of the staged chunk) exist only in the last 64-key block of a sequence whose length
+      // is not a multiple of 64: a REAL wave-uniform branch around a masking pass.  Written as `if (tail) x = j < Tk ? x :
+      // -inf` inside the softmax loop, hipcc if-converted the test into two v_cndmask + index arithmetic for every score of
+      // every block: 104 of the loop's ~250 VALU instructions, in a kernel that is VALU-bound (10.9 VALU per MFMA:
+      // profiles/r03/pmc_attn_fwd2_first.txt); an empty asm inside the branch was not enough either (the selects were
+      // hoisted above it), the compared bound has to be opaque.
+      if (PLAIN && kv0 + k0 + 64 > p.Tk) {
+        int lim = p.Tk - (kv0 + k0);    // valid keys of this block
+        asm volatile("" : "+s"(lim));  // opaque and produced INSIDE the branch: the selects cannot be hoisted above it
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              st[t][jt][r] = jt * 16 + 4 * g + r < lim ? st[t][jt][r] : -INFINITY;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int qi = row0 + 16 * t + i;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = st[t][jt][r];  // raw score: the scale is folded into the exponent below (scale > 0)
+            if (!PLAIN) {
+              x = keep_at(p, b, h, qi < p.Tq ? qi : p.Tq - 1, kv0 + k0 + jt * 16 + 4 * g + r) ? x : -INFINITY;
+              st[t][jt][r] = x;
+            }
+            mx = fmaxf(mx, x);
+          }
+        }
+        mx = group_max(mx) * sl2;
+        const float m_new = fmaxf(m[t], mx);
+        // rows whose every position so far is masked (m_new = -inf) must not produce NaN from (-inf) - (-inf): use 0
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m[t] - m_use);  // m = -inf on the first block: 0
+        float ls = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(st[t][jt][r], sl2, -m_use));
+            st[t][jt][r] = e;
+            ls += e;
+          }
+        }
+        l[t] = l[t] * alpha + ls;
+        m[t] = m_new;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) ot[t][dt] *= alpha;
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const bf16x8 pa0 = pack8(st[0][2 * a], st[0][2 * a + 1]);
+        const bf16x8 pa1 = pack8(st[1][2 * a], st[1][2 * a + 1]);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          const bf16x8 vf = frag_cols(Vs, k0 + a * 32, dt * 16, lane);
+          ot[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pa0, ot[0][dt], 0, 0, 0);
+          ot[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pa1, ot[1][dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int qi = row0 + 16 * t + i;
+    const float lsum = group_sum(l[t]);
+    if (active && qi < p.Tq) {
+      const float inv = 1.0f / lsum;
+      bf16_t* orow = p.o + (long)b * p.o_sb + (long)qi * p.o_st + h * dh;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int col = dt * 16 + 4 * g;
+        if (col >= dh) continue;  // dh % 8 == 0: a 4-column group is entirely inside or outside
+        const f32x4 v = ot[t][dt] * inv;
+        *reinterpret_cast<u32x2*>(orow + col) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      }
+      if (g == 0 && p.lse != nullptr) p.lse[((long)b * p.H + h) * p.Tq + qi] = (m[t] + log2f(lsum)) * (1.0f / LOG2E);
+    }
+  }
+}
+
 // waves per workgroup: ONE workgroup per (batch, head) (the resident K / V — or Q / dO — tiles are
 // loaded once), its waves walk the 16-row tiles in rounds; pick the wave count that leaves the
 // fewest idle slots in the last round (at most 8 waves).
@@ -1192,8 +1352,23 @@ int launch_gen_bwd_drop(const AttnParams& p, bool plain, int parts, hipStream_t 
   return CFHIP_OK;
 }
 
+int g_attn_two_tiles = 1;  // "attn_two_tiles" option: 1 (default) head_dim <= 64 takes the two-tiles-per-wave kernels
+
+template <int NDT>
+int launch_fwd2(const AttnParams& p, bool plain, hipStream_t s) {
+  dim3 grid((p.Tq + A2_ROWS - 1) / A2_ROWS, p.H, p.B);
+  const size_t lds = (size_t)2 * A2_TILE;
+  int rc = plain ? set_lds(attn_fwd2_kernel<true, NDT>, lds, "attn_fwd") : set_lds(attn_fwd2_kernel<false, NDT>, lds, "attn_fwd");
+  if (rc != CFHIP_OK) return rc;
+  if (plain) hipLaunchKernelGGL((attn_fwd2_kernel<true, NDT>), grid, dim3(512), lds, s, p);
+  else hipLaunchKernelGGL((attn_fwd2_kernel<false, NDT>), grid, dim3(512), lds, s, p);
+  CFHIP_CHECK_LAUNCH("attn_fwd2");
+  return CFHIP_OK;
+}
+
 template <int NH>
 int launch_gen_fwd(const AttnParams& p, bool plain, hipStream_t s) {
+  if (NH == 1 && g_attn_two_tiles) return p.dh <= 48 ? launch_fwd2<3>(p, plain, s) : launch_fwd2<4>(p, plain, s);
   dim3 grid((p.Tq + 127) / 128, p.H, p.B);
   const size_t lds = (size_t)Gen<NH>::NSLOT * Gen<NH>::SLOT_BYTES;
   int rc = plain ? set_lds(attn_gen_fwd_kernel<NH, true>, lds, "attn_fwd") : set_lds(attn_gen_fwd_kernel<NH, false>, lds, "attn_fwd");
@@ -1258,6 +1433,11 @@ int check_head_dim(const char* who, int head_dim) {
 }
 
 }  // namespace
+
+int cfhip_internal_set_attn_two_tiles(int v) {
+  g_attn_two_tiles = v;
+  return CFHIP_OK;
+}
 
 int cfhip_internal_set_attn_persistent(int v) {
   g_attn_persistent = v;

@@ -304,7 +304,7 @@ def test_attention_module_dropout_trains_and_is_off_in_eval():
     assert_close(acc / 600, y_eval.float(), 6e-2, "mean over dropout masks")
 
 
-@pytest.mark.parametrize("t,dh", [(4096, 40), (4096, 80), (16384, 40), (16384, 80), (4096, 160)])
+@pytest.mark.parametrize("t,dh", [(4096, 40), (4096, 80), (16384, 40), (16384, 80), (4096, 160), (4096, 64), (5000, 48)])
 def test_attention_at_the_unet_token_counts(t, dh):
     """The general-length kernels at the sizes the DDPM UNet runs them (BASELINE config 4: `SpatialTransformer` self
     attention over 64^2 / 128^2 pixels with 40- / 80- / 160-channel heads — mixed_stacks/api.py:766-893,
