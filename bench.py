@@ -18,7 +18,7 @@ Extra objects:
                 streams overlap, that sum exceeds the wall time of the step; two more views are carried next to it:
                 `isolated` (each shape timed alone, random operands) and `wall` (GEMM FLOPs / measured step time — the
                 lower bound nobody can argue with).  peak = 2500 TFLOP/s dense bf16.
-                `traffic` = HBM-side bytes of the family from PMC passes (tools/gpu/pmc_step.sh): only reported when
+                `traffic` = HBM-side bytes of the family from PMC passes (tools/gpu/run.sh pmc): only reported when
                 the committed pass was taken on THIS kernel source (sha256 of csrc/gemm.hip recorded in the JSON),
                 otherwise null with `traffic_stale`.
   cpu_baseline  the same step (fwd + CE + bwd + AdamW) on the host cores, bounded sample.  kind "reference": the
@@ -163,17 +163,23 @@ def time_gemms(batch: int, reps: int):
     return tot_flops, tot_time, rows, tot_bytes
 
 
+GEMM_SOURCES = ("gemm.hip", "gemm_device.h", "gemm_grouped.hip", "common.h")  # what a PMC pass of the GEMM family is valid for
+
+
 def _gemm_source_hash() -> str:
     import hashlib
 
-    with open(os.path.join(ROOT, "carefree-learn_amd", "csrc", "gemm.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    hsh = hashlib.sha256()
+    for name in GEMM_SOURCES:
+        with open(os.path.join(ROOT, "carefree-learn_amd", "csrc", name), "rb") as f:
+            hsh.update(f.read())
+    return hsh.hexdigest()[:16]
 
 
 def pmc_traffic(batch: int):
     """HBM bytes per step of the GEMM family from the newest committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE over this script, tools/gpu/pmc_step.sh -> tools/pmc_step_summary.py).  A pass is only valid for the
-    kernel source it was taken on: returns (bytes or None, source path, whole-step bytes or None, stale note or None)."""
+    WRITE_SIZE over this script, tools/gpu/run.sh pmc -> tools/pmc_step_summary.py).  A pass is only valid for the
+    kernel sources it was taken on (GEMM_SOURCES): returns (bytes or None, source path, whole-step bytes or None, stale note or None)."""
     best = None
     for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
         path = os.path.join(ROOT, "profiles", rnd, f"pmc_step_b{batch}.json")
@@ -186,7 +192,7 @@ def pmc_traffic(batch: int):
         doc = json.load(f)
     rel = os.path.relpath(best, ROOT)
     if doc.get("gemm_source_sha256_16") != _gemm_source_hash():
-        return None, rel, None, (f"{rel} was taken on another csrc/gemm.hip "
+        return None, rel, None, (f"{rel} was taken on other GEMM sources "
                                  f"({doc.get('gemm_source_sha256_16', 'unrecorded')} != {_gemm_source_hash()})")
     fam = doc["families"].get("gemm")
     return (fam["total"] if fam else None), rel, doc.get("all_kernels", {}).get("total"), None
@@ -219,6 +225,18 @@ def time_gemms_in_step(ts, batch_fn, steps: int):
                    ms_per_step=round(secs / steps * 1e3, 3))
         rows.append(row)
     return tot_f / steps, tot_t / steps, rows
+
+
+def _dominant(rows: list) -> dict:
+    """The launch shape with the most in-step kernel time per step, with its own roofline fraction (what a rocprofv3
+    --kernel-trace --stats summary of the same command lists first)."""
+    if not rows:
+        return {}
+    top = max(rows, key=lambda r: r.get("ms_per_step", 0.0))
+    name = ("gemm_grouped_tn_kernel<Cfg<256,256,2,4,5,32>,3,true> (8 weight gradients of two blocks per launch)"
+            if top["layout"] == "tn-grouped" else f"gemm_bf16_kernel {top['layout']} {top.get('M')}x{top.get('N')}x{top.get('K')} epilogue {top.get('epilogue')}")
+    return {"kernel": name, "launches_per_step": top["launches_per_step"], "avg_us": top["us"], "ms_per_step": top["ms_per_step"],
+            "achieved": top["tflops"], "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_BF16_TFLOPS, 4)}
 
 
 def _cpu_step_port(batch: int):
@@ -747,7 +765,9 @@ def main() -> None:
             "traffic": traffic,
             "traffic_unit": "HBM-side bytes per step over all GEMM launches (PMC FETCH_SIZE x2 + WRITE_SIZE)",
             "traffic_source": traffic_src, "traffic_stale": stale, "algorithmic_bytes": round(algo_bytes),
-            "kernel": "gemm_bf16_phase_kernel / gemm_bf16_kernel <AT,BT,EPI,Cfg> (all GEMM launches of one step)",
+            "kernel": "gemm_bf16_kernel<AT,BT,EPI,Cfg<192,128,2,4,2,64>> (forward, dX) + gemm_grouped_tn_kernel<Cfg<256,256,2,4,5,32>,3,BG> "
+                      "(weight gradients): all GEMM launches of one step",
+            "dominant_launch": _dominant(in_step_rows),
             "gemm_ms_per_step": round(gemm_sec * 1e3, 3), "gemm_flops_per_step": flops_step,
             "shapes": in_step_rows, "shapes_isolated": iso_rows,
         }

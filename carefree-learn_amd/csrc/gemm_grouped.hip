@@ -45,6 +45,15 @@ struct GroupedParams {
   int count;
 };
 
+// instruction J (0 / 1) of an m-major operand's two-instruction K-step
+template <int J>
+__device__ __forceinline__ void stage_one(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int wave, const StagePlan<2>& p, long ld,
+                                          int k0, int klen) {
+  unsigned off = p.voff[J] + (unsigned)((long)k0 * ld * 2);
+  off = ((int)(k0 + p.kpos[J]) < klen && p.voff[J] != OOB) ? off : OOB;
+  lds_dma16(rsrc, lds_tile + (wave * 2 + J) * 1024, off);
+}
+
 // Ring safety (by barrier count; intervals numbered as in gemm_bf16_phase_kernel: group 0 runs L(t, ph) in interval
 // 4t + 2ph and M(t, ph) in 4t + 2ph + 1, group 1 one interval later):
 //   WAR: the DMA of K-step t + D is issued in L(t, 0) / L(t, 1) (intervals >= 4t) into slot (t + D) % NSTAGE, which held
@@ -53,7 +62,10 @@ struct GroupedParams {
 //   RAW: every wave waits for its own DMA of K-step t + 1 (vmcnt((D - 1) * LPS): K-steps t + 2 .. t + D stay in flight)
 //        BEFORE the barrier that ends its L(t, 1) (intervals 4t + 2 / 4t + 3); the first read of K-step t + 1 is group 0's
 //        L(t + 1, 0) in interval 4t + 4.
-template <class C, int D, bool BG>
+// PLACE: where the four DMA instructions of a K-step are issued.  0: A in L(t, 0), B in L(t, 1) (behind the fragment reads);
+// 1: A inside M(t, 0), B inside M(t, 1), between the 8th and 9th MFMA; 2: one instruction per segment (L0, M0, L1, M1).
+// The wait in L(t, 1) leaves (D - 2) * 4 + {4, 2, 3} instructions in flight: everything younger than K-step t + 1.
+template <class C, int D, bool BG, int PLACE = 0>
 __global__ __launch_bounds__(C::NT, 2)
 void gemm_grouped_tn_kernel(GroupedParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -138,22 +150,36 @@ void gemm_grouped_tn_kernel(GroupedParams p) {
 #pragma unroll
         for (int m = 0; m < HM; ++m) af[m] = frag_mmajor<C::BM>(a_tile, wm * 128 + (ph * HM + m) * 16, 0, lane);
         __builtin_amdgcn_sched_barrier(0);
-        if (ph == 0) {
-          stage_tile<true>(a_rsrc, w_tile, wave, pa, q.lda, kw, K);
-        } else {
-          stage_tile<true>(b_rsrc, w_tile + C::A_BYTES, wave, pb, q.ldb, kw, K);
-          CFHIP_WAIT_VMCNT((D - 1) * C::LPS);  // own DMA of K-step t + 1 retired
+        if (PLACE == 0) {
+          if (ph == 0) stage_tile<true>(a_rsrc, w_tile, wave, pa, q.lda, kw, K);
+          else stage_tile<true>(b_rsrc, w_tile + C::A_BYTES, wave, pb, q.ldb, kw, K);
+        } else if (PLACE == 2) {
+          if (ph == 0) stage_one<0>(a_rsrc, w_tile, wave, pa, q.lda, kw, K);
+          else stage_one<0>(b_rsrc, w_tile + C::A_BYTES, wave, pb, q.ldb, kw, K);
         }
+        if (ph == 1) CFHIP_WAIT_VMCNT(PLACE == 0 ? (D - 1) * 4 : PLACE == 1 ? (D - 2) * 4 + 2 : (D - 2) * 4 + 3);  // own DMA of K-step t + 1 retired
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- M segment (the compiler's lgkmcnt ladder in front of the MFMAs retires the fragment reads)
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int m = 0; m < HM; ++m)
+        for (int m = 0; m < HM; ++m) {
 #pragma unroll
           for (int n = 0; n < C::FN; ++n)
             acc[ph * HM + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[n], af[m], acc[ph * HM + m][n], 0, 0, 0);
+          if (PLACE != 0 && m == HM / 2 - 1) {  // after the 8th MFMA
+            __builtin_amdgcn_sched_barrier(0);
+            if (PLACE == 1) {
+              if (ph == 0) stage_tile<true>(a_rsrc, w_tile, wave, pa, q.lda, kw, K);
+              else stage_tile<true>(b_rsrc, w_tile + C::A_BYTES, wave, pb, q.ldb, kw, K);
+            } else {
+              if (ph == 0) stage_one<1>(a_rsrc, w_tile, wave, pa, q.lda, kw, K);
+              else stage_one<1>(b_rsrc, w_tile + C::A_BYTES, wave, pb, q.ldb, kw, K);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
         if constexpr (DO_BG) {
           const bf16x8 mine = wn == 0 ? af[0] : wn == 1 ? af[1] : wn == 2 ? af[2] : af[3];
           if (ph == 0) accb0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, mine, accb0, 0, 0, 0);
@@ -198,11 +224,11 @@ void gemm_grouped_tn_kernel(GroupedParams p) {
 using CfgG4 = Cfg<256, 256, 2, 4, 4, 32>;  // 128 KiB ring
 using CfgG5 = Cfg<256, 256, 2, 4, 5, 32>;  // 160 KiB ring (the whole LDS)
 
-int g_grouped_variant = 0;  // 0: 5-slot ring, DMA 3 K-steps ahead; 1: 4 slots, 2 ahead; 2: 5 slots, 2 ahead
+int g_grouped_variant = 0;  // 0: 5-slot ring, DMA 3 K-steps ahead; 1: 4 slots, 2 ahead; 2: 5 slots, 2 ahead; 3 / 4: as 0 with DMA placement 1 / 2
 
-template <class C, int D, bool BG>
+template <class C, int D, bool BG, int PLACE = 0>
 int launch_grouped(const GroupedParams& p, int tiles, hipStream_t s) {
-  void (*kern)(GroupedParams) = gemm_grouped_tn_kernel<C, D, BG>;
+  void (*kern)(GroupedParams) = gemm_grouped_tn_kernel<C, D, BG, PLACE>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -221,6 +247,8 @@ int launch_variant(const GroupedParams& p, int tiles, hipStream_t s) {
   switch (g_grouped_variant) {
     case 1: return launch_grouped<CfgG4, 2, BG>(p, tiles, s);
     case 2: return launch_grouped<CfgG5, 2, BG>(p, tiles, s);
+    case 3: return launch_grouped<CfgG5, 3, BG, 1>(p, tiles, s);
+    case 4: return launch_grouped<CfgG5, 3, BG, 2>(p, tiles, s);
     default: return launch_grouped<CfgG5, 3, BG>(p, tiles, s);
   }
 }

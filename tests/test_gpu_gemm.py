@@ -231,7 +231,7 @@ def test_tile_walk_orders_give_identical_results():
     assert_close(outs[0], a.float().double() @ w.float().t().double(), 2e-5, "walk order")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_grouped_weight_gradients(variant):
     """cfhip_gemm_bf16_grouped_tn: several dW = dY^T X (+ db = colsum dY) problems in one launch vs fp64 on the same bf16
     operands — ragged shapes (M, N not multiples of the 256-wide tile, K not a multiple of the 32-deep K-step, K shorter

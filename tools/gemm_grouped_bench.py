@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--configs", default="1,7,14")
+    ap.add_argument("--variants", default="0,1,2,3,4")
     args = ap.parse_args()
     dev = torch.device("cuda")
     k = args.batch * 197
@@ -65,7 +66,7 @@ def main():
     ops.set_option("gemm_config", -1)
     us = timed(old_path, args.reps)
     print(f"per-GEMM split-K + reduce, heuristic     : {us:8.1f} us / block  {flops_block / us / 1e6:6.0f} TF", flush=True)
-    for variant in (0, 1, 2):
+    for variant in [int(v) for v in args.variants.split(",")]:
         ops.set_option("grouped_variant", variant)
         for nb in (1, 2, 3):
             probs = [p for b in blocks[:nb] for p in b]

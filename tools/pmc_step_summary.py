@@ -8,7 +8,7 @@ import csv, json, sys
 
 
 def family(name: str) -> str:
-    for key, fam in (("gemm_bf16", "gemm"), ("splitk_reduce", "gemm"), ("attn_", "attention"), ("layernorm", "layernorm"),
+    for key, fam in (("gemm_bf16", "gemm"), ("gemm_grouped", "gemm"), ("splitk_reduce", "gemm"), ("attn_", "attention"), ("layernorm", "layernorm"),
                      ("colsum", "colsum"), ("colreduce", "colsum"), ("adam", "adam")):
         if key in name:
             return fam
@@ -26,11 +26,12 @@ def load(path: str, counter: str):
 
 
 fetch, write, steps = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE"), float(sys.argv[3])
-import hashlib, os
-_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "carefree-learn_amd", "csrc", "gemm.hip")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 res = {"steps_profiled": steps, "unit": "bytes per step", "fetch_correction": "x2 (gfx950 wide-read calibration)",
-       # bench.py reports these bytes only while csrc/gemm.hip is the source they were measured on
-       "gemm_source_sha256_16": hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16],
+       # bench.py reports these bytes only while the GEMM sources (bench.GEMM_SOURCES) are what they were measured on
+       "gemm_source_sha256_16": bench._gemm_source_hash(),
        "families": {}}
 tot_r = tot_w = 0.0
 for fam in sorted(set(fetch) | set(write)):
