@@ -20,6 +20,11 @@ struct PlanEntry {
   int src, kind, payload, table_id, dim, pitch;
 };
 
+// Known divergences from the reference, on inputs it does not define: (1) the out-of-bound imputation
+// (value >= dim -> 0, ml_encoder.py:176-183) is applied to EVERY categorical column, also on the mixed one-hot / embedding
+// path where the reference indexes with the raw value and raises; (2) negative or NaN categorical values give an all-zero
+// one-hot row / a zero embedding instead of an index error.  In-range inputs are bit-exact (tests/test_gpu_stochastic_tabular.py).
+// The host (modules.MLEncoder._plan) checks that every categorical column index is inside the input.
 __device__ __forceinline__ long categorical_index(float v, int dim) {
   if (v >= (float)dim) return 0;  // ml_encoder.py:176-183: oob -> 0
   return (long)v;                 // .to(torch.long): truncation

@@ -1937,6 +1937,9 @@ class MLEncoder(Module):
         key = (num_features, str(device))
         if key in self._plans:
             return self._plans[key]
+        bad = [c for c in self.tgt_columns if not 0 <= c < num_features]
+        if bad:  # the kernel reads x[b, column] without a range check of its own
+            raise ValueError(f"tabular encoder: categorical column(s) {bad} outside the input's {num_features} features")
         dim_of = dict(zip(self.tgt_columns, self._dims_int))
         rows: List[List[int]] = []
         numerical = [c for c in range(num_features) if c not in self.tgt_columns]

@@ -80,6 +80,9 @@ def test_reference_step_engine_drives_the_hip_path(golden, one_rank_rccl, lazy, 
     batch = {TO.INPUT_KEY: img, TO.LABEL_KEY: labels}
     eng.fit([batch] * steps)
     assert cb.reducer is not None and cb.reducer.arena is opt.arena  # the seam was installed on the fused optimizer's arena
+    # round 3: under RCCL the callback owns a C-ABI communicator (cfhip_comm_*): its collectives run on this package's own,
+    # queue-checked comm stream, not on the ProcessGroup's internal one
+    assert cb.reducer.comm is not None and cb.reducer.comm.world == 1
     got = [float(d[TO.LOSS_KEY]) for d in eng.loss_log]
     assert all(torch.isfinite(torch.tensor(got)))
     if lazy:
