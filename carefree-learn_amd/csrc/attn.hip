@@ -1250,6 +1250,237 @@ __global__ __launch_bounds__(512, 4) void attn_fwd2_kernel(AttnParams p) {
   }
 }
 
+// dQ pass, two query tiles per wave (see attn_fwd2_kernel): per 32-key block the four K / V row fragments and the NDT K column
+// fragments are read once for both tiles: 22 MFMAs per 8 ds_read_b128 + 6 ds_read_b64_tr_b16 (NDT = 3) against 12 per 8 + 8.
+// Key rows beyond Tk are zero rows of the staged chunk: their p is finite, their dP and their K are zero, they add nothing.
+template <bool PLAIN, int NDT>
+__global__ __launch_bounds__(512, 4) void attn_bwd_dq2_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + A2_TILE;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int dh = p.dh;
+  const int row0 = (blockIdx.x * 8 + wave) * 32;
+  const bool active = row0 < p.Tq;
+  const bf16_t* qb = p.q + (long)b * p.q_sb + h * dh;
+  const bf16_t* dob = p.d_o + (long)b * p.o_sb + h * dh;
+  const bf16_t* ob = p.o_in + (long)b * p.o_sb + h * dh;
+  bf16x8 qf[2][2], dof[2][2];
+  float delta[2], lse2[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[t][ks] = frag_global_dh(qb, p.q_st, row0 + 16 * t, active ? p.Tq : 0, ks, lane, dh);
+      dof[t][ks] = frag_global_dh(dob, p.o_st, row0 + 16 * t, active ? p.Tq : 0, ks, lane, dh);
+      const bf16x8 of = frag_global_dh(ob, p.o_st, row0 + 16 * t, active ? p.Tq : 0, ks, lane, dh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sacc += bf16_to_f32((bf16_t)dof[t][ks][e]) * bf16_to_f32((bf16_t)of[e]);
+    }
+    delta[t] = group_sum(sacc);
+    const int qi = row0 + 16 * t + i;
+    const bool qvalid = active && qi < p.Tq;
+    const long stat = ((long)b * p.H + h) * p.Tq + qi;
+    if (qvalid && g == 0) p.delta[stat] = delta[t];
+    lse2[t] = qvalid ? p.lse[stat] * LOG2E : INFINITY;
+  }
+  const float sl2 = p.scale * LOG2E;
+  f32x4 dqt[2][NDT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) dqt[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kv0 = 0; kv0 < p.Tk; kv0 += A2_CH) {
+    const int rows = min(A2_CH, p.Tk - kv0);
+    __syncthreads();
+    {
+      int ln = lane;  // opaque copy: see attn_fwd2_kernel
+      asm volatile("" : "+v"(ln));
+      dma_oper<1>(Ks, p.k + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * dh, p.kv_st, rows, dh, wave, 8, ln);
+      dma_oper<1>(Vs, p.v + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * dh, p.kv_st, rows, dh, wave, 8, ln);
+    }
+    lds_dma_wait_all();
+    __syncthreads();
+    if (!active) continue;
+    if (p.causal && kv0 > row0 + 31) continue;
+    const int nbl = (rows + 31) / 32;
+#pragma unroll 1
+    for (int a = 0; a < nbl; ++a) {
+      f32x4 ds[2][2];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        const int r16 = a * 32 + jt * 16;
+        const bf16x8 kf0 = frag_rows(Ks, r16, 0, lane), kf1 = frag_rows(Ks, r16, 1, lane);
+        const bf16x8 vf0 = frag_rows(Vs, r16, 0, lane), vf1 = frag_rows(Vs, r16, 1, lane);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[t][0], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, dof[t][0], dp, 0, 0, 0);
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[t][1], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, dof[t][1], dp, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pr = __builtin_amdgcn_exp2f(fmaf(sc[r], sl2, -lse2[t]));
+            if (!PLAIN) {
+              const int qi = row0 + 16 * t + i;
+              pr = keep_at(p, b, h, qi < p.Tq ? qi : p.Tq - 1, kv0 + r16 + 4 * g + r) ? pr : 0.f;
+            }
+            ds[t][jt][r] = pr * (dp[r] - delta[t]);
+          }
+        }
+      }
+      const bf16x8 dsp0 = pack8(ds[0][0], ds[0][1]);
+      const bf16x8 dsp1 = pack8(ds[1][0], ds[1][1]);
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const bf16x8 kc = frag_cols(Ks, a * 32, dt * 16, lane);
+        dqt[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc, dsp0, dqt[0][dt], 0, 0, 0);
+        dqt[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc, dsp1, dqt[1][dt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int qi = row0 + 16 * t + i;
+    if (active && qi < p.Tq) {
+      bf16_t* dqrow = p.dq + (long)b * p.q_sb + (long)qi * p.q_st + h * dh;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int col = dt * 16 + 4 * g;
+        if (col >= dh) continue;
+        const f32x4 v = dqt[t][dt] * p.scale;
+        *reinterpret_cast<u32x2*>(dqrow + col) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      }
+    }
+  }
+}
+
+// dK / dV pass, two key tiles per wave: 4-wave workgroups of 128 key rows over 128-row chunks of Q / dO (33 KB of LDS: three to
+// four workgroups per CU).  Per 32-query block the eight Q / dO row fragments, the statistics and the 2 NDT column fragments are
+// read once for both key tiles: 28 MFMAs per 12 ds_read_b128 + 12 ds_read_b64_tr_b16 (NDT = 3) against 16 per 12 + 16 — the
+// one-tile kernel is LDS-bandwidth-bound (80 LDS cycles per wave and block x 16 waves = 1 280 per CU against 1 024 matrix cycles
+// per SIMD).  ~165 registers: three waves per SIMD.  delta must be ready (the dQ pass, or attn_delta_kernel).
+constexpr int A2D_CH = 128;
+constexpr int A2D_TILE = A2D_CH * 128;
+
+template <bool PLAIN, int NDT>
+__global__ __launch_bounds__(256, NDT == 3 ? 3 : 2) void attn_bwd_dkv2_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* dOs = smem + A2D_TILE;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * A2D_TILE);
+  float* delta_s = lse_s + A2D_CH;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int dh = p.dh;
+  const int row0 = (blockIdx.x * 4 + wave) * 32;
+  const bool active = row0 < p.Tk;
+  const bf16_t* kb = p.k + (long)b * p.kv_sb + h * dh;
+  const bf16_t* vb = p.v + (long)b * p.kv_sb + h * dh;
+  bf16x8 kf[2][2], vf[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[u][ks] = frag_global_dh(kb, p.kv_st, row0 + 16 * u, active ? p.Tk : 0, ks, lane, dh);
+      vf[u][ks] = frag_global_dh(vb, p.kv_st, row0 + 16 * u, active ? p.Tk : 0, ks, lane, dh);
+    }
+  const float sl2 = p.scale * LOG2E;
+  f32x4 dkt[2][NDT], dvt[2][NDT];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) { dkt[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int q0 = 0; q0 < p.Tq; q0 += A2D_CH) {
+    const int rows = min(A2D_CH, p.Tq - q0);
+    __syncthreads();
+    {
+      int ln = lane;  // opaque copy: see attn_fwd2_kernel
+      asm volatile("" : "+v"(ln));
+      dma_half(Qs, p.q + (long)b * p.q_sb + (long)q0 * p.q_st + h * dh, p.q_st, rows, A2D_CH, 0, dh, wave, 4, ln);
+      dma_half(dOs, p.d_o + (long)b * p.o_sb + (long)q0 * p.o_st + h * dh, p.o_st, rows, A2D_CH, 0, dh, wave, 4, ln);
+    }
+    if ((int)threadIdx.x < A2D_CH) {  // thread t owns the statistics of row t of the chunk
+      const int tq = q0 + (int)threadIdx.x;
+      const long at = ((long)b * p.H + h) * p.Tq + tq;
+      lse_s[threadIdx.x] = tq < p.Tq ? p.lse[at] * LOG2E : INFINITY;
+      delta_s[threadIdx.x] = tq < p.Tq ? p.delta[at] : 0.f;
+    }
+    lds_dma_wait_all();
+    __syncthreads();
+    if (!active) continue;
+    if (p.causal && q0 + A2D_CH - 1 < row0) continue;  // every query of the chunk precedes both kv tiles
+    const int nbl = (rows + 31) / 32;
+#pragma unroll 1
+    for (int a = 0; a < nbl; ++a) {
+      f32x4 pp[2][2], ds[2][2];  // [kv tile][query 16-row tile]
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int r16 = a * 32 + it * 16;
+        const bf16x8 qf0 = frag_rows(Qs, r16, 0, lane), qf1 = frag_rows(Qs, r16, 1, lane);
+        const bf16x8 of0 = frag_rows(dOs, r16, 0, lane), of1 = frag_rows(dOs, r16, 1, lane);
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + r16 + 4 * g);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + r16 + 4 * g);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf0, kf[u][0], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of0, vf[u][0], dp, 0, 0, 0);
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf1, kf[u][1], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of1, vf[u][1], dp, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pr = __builtin_amdgcn_exp2f(fmaf(sc[r], sl2, -l4[r]));
+            if (!PLAIN) {
+              const int qi = q0 + r16 + 4 * g + r;
+              pr = (qi < p.Tq && keep_at(p, b, h, qi, row0 + 16 * u + n)) ? pr : 0.f;
+            }
+            pp[u][it][r] = pr;
+            ds[u][it][r] = pr * (dp[r] - d4[r]);
+          }
+        }
+      }
+      const bf16x8 ppk0 = pack8(pp[0][0], pp[0][1]), ppk1 = pack8(pp[1][0], pp[1][1]);
+      const bf16x8 dsk0 = pack8(ds[0][0], ds[0][1]), dsk1 = pack8(ds[1][0], ds[1][1]);
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const bf16x8 oc = frag_cols(dOs, a * 32, dt * 16, lane);
+        dvt[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oc, ppk0, dvt[0][dt], 0, 0, 0);
+        dvt[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oc, ppk1, dvt[1][dt], 0, 0, 0);
+        const bf16x8 qc = frag_cols(Qs, a * 32, dt * 16, lane);
+        dkt[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qc, dsk0, dkt[0][dt], 0, 0, 0);
+        dkt[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qc, dsk1, dkt[1][dt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int kj = row0 + 16 * u + n;
+    if (active && kj < p.Tk) {
+      bf16_t* dkrow = p.dk + (long)b * p.kv_sb + (long)kj * p.kv_st + h * dh;
+      bf16_t* dvrow = p.dv + (long)b * p.kv_sb + (long)kj * p.kv_st + h * dh;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int col = dt * 16 + 4 * g;
+        if (col >= dh) continue;
+        const f32x4 kk = dkt[u][dt] * p.scale;
+        const f32x4 vv = dvt[u][dt];
+        *reinterpret_cast<u32x2*>(dkrow + col) = u32x2{pack_bf16x2(kk[0], kk[1]), pack_bf16x2(kk[2], kk[3])};
+        *reinterpret_cast<u32x2*>(dvrow + col) = u32x2{pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3])};
+      }
+    }
+  }
+}
+
 // waves per workgroup: ONE workgroup per (batch, head) (the resident K / V — or Q / dO — tiles are
 // loaded once), its waves walk the 16-row tiles in rounds; pick the wave count that leaves the
 // fewest idle slots in the last round (at most 8 waves).
@@ -1352,7 +1583,7 @@ int launch_gen_bwd_drop(const AttnParams& p, bool plain, int parts, hipStream_t 
   return CFHIP_OK;
 }
 
-int g_attn_two_tiles = 1;  // "attn_two_tiles" option: 1 (default) head_dim <= 64 takes the two-tiles-per-wave kernels
+int g_attn_two_tiles = 15;  // "attn_two_tiles" option (bits): 1 forward, 2 dQ pass (4: also head_dim > 48), 8 dK / dV pass of head_dim <= 64 on the two-tiles-per-wave kernels
 
 template <int NDT>
 int launch_fwd2(const AttnParams& p, bool plain, hipStream_t s) {
@@ -1368,7 +1599,7 @@ int launch_fwd2(const AttnParams& p, bool plain, hipStream_t s) {
 
 template <int NH>
 int launch_gen_fwd(const AttnParams& p, bool plain, hipStream_t s) {
-  if (NH == 1 && g_attn_two_tiles) return p.dh <= 48 ? launch_fwd2<3>(p, plain, s) : launch_fwd2<4>(p, plain, s);
+  if (NH == 1 && (g_attn_two_tiles & 1)) return p.dh <= 48 ? launch_fwd2<3>(p, plain, s) : launch_fwd2<4>(p, plain, s);
   dim3 grid((p.Tq + 127) / 128, p.H, p.B);
   const size_t lds = (size_t)Gen<NH>::NSLOT * Gen<NH>::SLOT_BYTES;
   int rc = plain ? set_lds(attn_gen_fwd_kernel<NH, true>, lds, "attn_fwd") : set_lds(attn_gen_fwd_kernel<NH, false>, lds, "attn_fwd");
@@ -1379,9 +1610,34 @@ int launch_gen_fwd(const AttnParams& p, bool plain, hipStream_t s) {
   return CFHIP_OK;
 }
 
+template <int NDT>
+int launch_dq2(const AttnParams& p, bool plain, hipStream_t s) {
+  dim3 grid((p.Tq + A2_ROWS - 1) / A2_ROWS, p.H, p.B);
+  const size_t lds = (size_t)2 * A2_TILE;
+  int rc = plain ? set_lds(attn_bwd_dq2_kernel<true, NDT>, lds, "attn_bwd_dq") : set_lds(attn_bwd_dq2_kernel<false, NDT>, lds, "attn_bwd_dq");
+  if (rc != CFHIP_OK) return rc;
+  if (plain) hipLaunchKernelGGL((attn_bwd_dq2_kernel<true, NDT>), grid, dim3(512), lds, s, p);
+  else hipLaunchKernelGGL((attn_bwd_dq2_kernel<false, NDT>), grid, dim3(512), lds, s, p);
+  CFHIP_CHECK_LAUNCH("attn_bwd_dq2");
+  return CFHIP_OK;
+}
+
+template <int NDT>
+int launch_dkv2(const AttnParams& p, bool plain, hipStream_t s) {
+  dim3 grid((p.Tk + 127) / 128, p.H, p.B);
+  const size_t lds = (size_t)2 * A2D_TILE + (size_t)2 * A2D_CH * sizeof(float);
+  if (plain) hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true, NDT>), grid, dim3(256), lds, s, p);
+  else hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false, NDT>), grid, dim3(256), lds, s, p);
+  CFHIP_CHECK_LAUNCH("attn_bwd_dkv2");
+  return CFHIP_OK;
+}
+
 template <int NH>
 int launch_gen_bwd(const AttnParams& p, bool plain, int parts, hipStream_t s) {
-  if (parts & 1) {
+  if ((parts & 1) && NH == 1 && (g_attn_two_tiles & 2) && (p.dh <= 48 || (g_attn_two_tiles & 4))) {  // (the 4-column-tile form spills: bit 4 to try it)
+    const int rc = p.dh <= 48 ? launch_dq2<3>(p, plain, s) : launch_dq2<4>(p, plain, s);
+    if (rc != CFHIP_OK) return rc;
+  } else if (parts & 1) {
     dim3 grid((p.Tq + 127) / 128, p.H, p.B);
     const size_t lds = (size_t)Gen<NH>::NSLOT * Gen<NH>::SLOT_BYTES;
     int rc = plain ? set_lds(attn_gen_bwd_dq_kernel<NH, true>, lds, "attn_bwd_dq")
@@ -1391,7 +1647,15 @@ int launch_gen_bwd(const AttnParams& p, bool plain, int parts, hipStream_t s) {
     else hipLaunchKernelGGL((attn_gen_bwd_dq_kernel<NH, false>), grid, dim3(512), lds, s, p);
     CFHIP_CHECK_LAUNCH("attn_gen_bwd_dq");
   }
-  if (parts & 2) {
+  if ((parts & 2) && NH == 1 && (g_attn_two_tiles & 8)) {
+    if (!(parts & 1)) {  // no dQ pass in front of this one: fill delta
+      const long rows = (long)p.B * p.H * p.Tq;
+      hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 255) / 256 > 4096 ? 4096 : (rows + 255) / 256)), dim3(256), 0, s, p);
+      CFHIP_CHECK_LAUNCH("attn_delta");
+    }
+    const int rc = p.dh <= 48 ? launch_dkv2<3>(p, plain, s) : launch_dkv2<4>(p, plain, s);
+    if (rc != CFHIP_OK) return rc;
+  } else if (parts & 2) {
     if (Gen<NH>::NSLOT == 2 && !p.delta_ready && !(parts & 1)) {
       const long rows = (long)p.B * p.H * p.Tq;
       hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 255) / 256 > 4096 ? 4096 : (rows + 255) / 256)), dim3(256), 0, s, p);

@@ -31,6 +31,9 @@ cases = [  # (B, H, T, dh, reps)
     (1, 8, 65536, 40, 2), (1, 8, 16384, 80, 4), (1, 8, 4096, 160, 10),     # UNet 256^2 x 1
     (4, 12, 4096, 64, 5),
 ]
+for a in sys.argv[1:]:
+    if a.startswith("--two-tiles="):
+        ops.set_option("attn_two_tiles", int(a.split("=")[1]))
 if "--quick" in sys.argv:
     cases = [c for c in cases if c[2] <= 16384]
 g = torch.Generator(device=dev).manual_seed(0)
