@@ -1102,6 +1102,11 @@ __global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_bwd_dkv_kernel(
 // lane and folded across the four lanes of a row once, at the end.  Output columns beyond head_dim are not computed:
 // NDT = 3 column tiles for head_dim <= 48 (the UNet's 40-channel heads), 4 otherwise.
 // ------------------------------------------------------------------------------------------------
+// Tried and NOT kept: columns 32 .. 47 of a head_dim <= 48 product through ONE v_mfma_f32_16x16x16_bf16 instead of the second,
+// three-quarters-empty 16x16x32.  hipcc schedules the 16-deep MFMA directly behind the 32-deep one whose result it accumulates
+// onto, with a DIFFERENT destination register and no wait states; the results are wrong (tools/micro/mfma_chain.hip shows the
+// in-place chain is fine, tools/micro/mfma16_layout.hip that the operand layout is what one expects).  The gain would have been
+// 2-5 % on the backward passes and nothing on the VALU-bound forward; a hand-padded chain is not worth a silent-corruption risk.
 constexpr int A2_ROWS = 256;   // rows of the walking operand per workgroup (8 waves x 32)
 constexpr int A2_CH = 256;     // rows of the staged operand per chunk (64 KB: K + V, or Q + dO)
 constexpr int A2_TILE = A2_CH * 128;
