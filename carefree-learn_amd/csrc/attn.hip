@@ -1588,6 +1588,7 @@ int launch_gen_bwd_drop(const AttnParams& p, bool plain, int parts, hipStream_t 
   return CFHIP_OK;
 }
 
+int g_attn_short_max = CFHIP_ATTN_MAX_T;  // "attn_short_max" option: head_dim-64 sequences up to this length take the LDS-resident kernels
 int g_attn_two_tiles = 15;  // "attn_two_tiles" option (bits): 1 forward, 2 dQ pass (4: also head_dim > 48), 8 dK / dV pass of head_dim <= 64 on the two-tiles-per-wave kernels
 
 template <int NDT>
@@ -1703,6 +1704,11 @@ int check_head_dim(const char* who, int head_dim) {
 
 }  // namespace
 
+int cfhip_internal_set_attn_short_max(int v) {
+  g_attn_short_max = v < 0 ? 0 : (v > CFHIP_ATTN_MAX_T ? CFHIP_ATTN_MAX_T : v);
+  return CFHIP_OK;
+}
+
 int cfhip_internal_set_attn_two_tiles(int v) {
   g_attn_two_tiles = v;
   return CFHIP_OK;
@@ -1759,7 +1765,7 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
       default: return launch_gen_fwd_drop<3>(p, plain, s);
     }
   }
-  if (head_dim != CFHIP_ATTN_HEAD_DIM || Tq > CFHIP_ATTN_MAX_T || Tk > CFHIP_ATTN_MAX_T) {
+  if (head_dim != CFHIP_ATTN_HEAD_DIM || Tq > g_attn_short_max || Tk > g_attn_short_max) {
     // general form: chunked K / V with online softmax, head_dim as zero-padded 64-column halves
     switch ((head_dim + 63) / 64) {
       case 1: return launch_gen_fwd<1>(p, plain, s);
@@ -1841,7 +1847,7 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
       default: return launch_gen_bwd_drop<3>(p, plain, parts, s);
     }
   }
-  if (head_dim != CFHIP_ATTN_HEAD_DIM || Tq > CFHIP_ATTN_MAX_T || Tk > CFHIP_ATTN_MAX_T) {  // general form
+  if (head_dim != CFHIP_ATTN_HEAD_DIM || Tq > g_attn_short_max || Tk > g_attn_short_max) {  // general form
     switch ((head_dim + 63) / 64) {
       case 1: return launch_gen_bwd<1>(p, plain, parts, s);
       case 2: return launch_gen_bwd<2>(p, plain, parts, s);

@@ -639,6 +639,7 @@ int cfhip_internal_set_ln_fused(int v);  // norm.hip
 int cfhip_internal_set_attn_persistent(int v);  // attn.hip
 int cfhip_internal_set_grouped_variant(int v);  // gemm_grouped.hip
 int cfhip_internal_set_attn_two_tiles(int v);  // attn.hip
+int cfhip_internal_set_attn_short_max(int v);  // attn.hip
 
 extern "C" int cfhip_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "gemm_config") == 0) {
@@ -663,6 +664,7 @@ extern "C" int cfhip_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "attn_persistent") == 0) return cfhip_internal_set_attn_persistent(value);
   if (name != nullptr && strcmp(name, "grouped_variant") == 0) return cfhip_internal_set_grouped_variant(value);
   if (name != nullptr && strcmp(name, "attn_two_tiles") == 0) return cfhip_internal_set_attn_two_tiles(value);
+  if (name != nullptr && strcmp(name, "attn_short_max") == 0) return cfhip_internal_set_attn_short_max(value);
 #ifdef CFHIP_ABLATE
   if (name != nullptr && strcmp(name, "gemm_ablate") == 0) {
     g_gemm_ablate = value;

@@ -32,10 +32,12 @@ def t(fn, n=20):
 
 abl = [0] + ([1, 2, 4] if "ablate" in os.environ.get("CFHIP_LIB", "") else [])
 if len(abl) == 1:
-    abl = [("persistent", 1), ("persistent", 0), ("persistent", 1), ("persistent", 0)]
+    abl = [("persistent", 1), ("short_max", 0), ("persistent", 1), ("short_max", 0)]
 for a in abl:
     if isinstance(a, tuple):
-        ops.set_option("attn_persistent", a[1])
+        ops.set_option("attn_short_max", 256 if a[0] == "persistent" else a[1])  # short_max 0: the general two-tile kernels
+        if a[0] == "persistent":
+            ops.set_option("attn_persistent", a[1])
     elif a or len(abl) > 1:
         ops.set_option("attn_ablate", a)
     fw = t(lambda: ops.attn_fwd(q, k, v, H))
