@@ -1,4 +1,4 @@
-// Grouped weight-gradient GEMM: up to 8 problems  dW_i[M_i][N_i] (+)= dY_i^T X_i  (and db_i (+)= colsum(dY_i)) in ONE launch.
+// Grouped weight-gradient GEMM: up to 24 problems  dW_i[M_i][N_i] (+)= dY_i^T X_i  (and db_i (+)= colsum(dY_i)) in ONE launch.
 //
 // Replaces the parameter half of F.linear's autograd backward (reference modules/core/customs.py:89,
 // attentions.py:214: grad_weight = grad_output^T @ input, grad_bias = grad_output.sum(0)) for ALL Linear layers of one or
@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int GROUP_MAX = 8;
+constexpr int GROUP_MAX = 24;  // problems per launch (72 bytes of kernel arguments each)
 
 struct GroupedProblem {
   const bf16_t* A;  // dY  [K][M]  (m-major: element (m, k) at A[k * lda + m])

@@ -65,6 +65,10 @@ def _dw_db(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> None:
 # reduction — no split-K slabs, no reduce launches).  ViT-B/16: 108 tiles per block, two blocks = 216 tiles = one round on
 # 256 CUs.  0 = the round-1/2 path (one split-K GEMM + reduce per weight gradient, issued beside its sibling dX GEMM).
 DW_GROUP_BLOCKS = 2
+# When a block has far fewer than 108 tiles (the CLIP text tower: 512 wide = 48 tiles per block) two blocks leave most of the
+# chip idle: with DW_GROUP_TILES > 0 the queue is flushed by TILE count instead — as soon as another block like the last one
+# would not fit into one round of 256-tile slots — and DW_GROUP_BLOCKS only says "grouping on" (ViT-B/16: still two blocks).
+DW_GROUP_TILES = 256
 DW_GROUP_ON_MAIN = False  # True: the grouped launch runs on the caller's stream (after the blocks' dX chain) instead of the side stream
 _pending_dw: list = []
 _slice_streams: list = []  # streams of the backward's batch slices beyond the caller's (what a dW launch has to wait for)
@@ -83,6 +87,11 @@ def _queue_dw(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> None:
         SideStream.run(lambda: _dw_db(w, b, dy2, x2), (dy2, x2), wait=tuple(_slice_streams))
         return
     _pending_dw.append((w, b, dy2, x2))
+
+
+def _pending_tiles() -> int:
+    """256 x 256 output tiles of the queued weight gradients"""
+    return sum(((w.shape[0] + 255) // 256) * ((x2.shape[1] + 255) // 256) for w, _, _, x2 in _pending_dw)
 
 
 def _flush_dw(wait: tuple = ()) -> None:
@@ -394,8 +403,13 @@ class MixingStackFn(Function):
             for i in range(len(metas) - 1, -1, -1):
                 saved = tuple(all_saved[N_SAVED * i:N_SAVED * (i + 1)])
                 quick = bool(metas[i][3]) if len(metas[i]) > 3 else False
+                before = _pending_tiles()
                 d2 = _block_bwd(saved, ctx.params[12 * i:12 * i + 12], metas[i][0], bsz, t, keep_mask, causal, d2, quick, streams)
-                if DW_GROUP_BLOCKS > 0 and (len(metas) - i) % DW_GROUP_BLOCKS == 0:
+                if DW_GROUP_BLOCKS > 0 and DW_GROUP_TILES > 0:
+                    now = _pending_tiles()
+                    if now + (now - before) > DW_GROUP_TILES:  # one more block like this one would start a second round
+                        _flush_dw(tuple(_slice_streams))
+                elif DW_GROUP_BLOCKS > 0 and (len(metas) - i) % DW_GROUP_BLOCKS == 0:
                     _flush_dw(tuple(_slice_streams))
             _flush_dw(tuple(_slice_streams))
             if streams is not None:

@@ -103,7 +103,7 @@ int cfhip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, co
  * cfhip_gemm_bf16: A = dY [K][M] (lda), B = X [K][N] (ldb), both bf16 token-major; C f32 [M][N] (ldc).  256 x 256 output
  * tiles of all problems share the chip, every tile runs its whole reduction: no split-K, no workspace, no second pass,
  * deterministic.  M, N, lda, ldb multiples of 8, ldc of 4, 16-byte aligned bases, K*ld*2 < 2 GiB.  `problems` is a HOST
- * array (copied into the kernel arguments, 8 per launch).  bias_grad may be NULL per problem. */
+ * array (copied into the kernel arguments, 24 per launch).  bias_grad may be NULL per problem. */
 typedef struct cfhip_gemm_problem {
   const void* A;
   const void* B;

@@ -235,7 +235,7 @@ def test_tile_walk_orders_give_identical_results():
 def test_grouped_weight_gradients(variant):
     """cfhip_gemm_bf16_grouped_tn: several dW = dY^T X (+ db = colsum dY) problems in one launch vs fp64 on the same bf16
     operands — ragged shapes (M, N not multiples of the 256-wide tile, K not a multiple of the 32-deep K-step, K shorter
-    than the ring), accumulate flags, problems with and without a bias gradient, more problems than one launch takes (8)."""
+    than the ring), accumulate flags, problems with and without a bias gradient, more problems than one launch takes (24)."""
     try:
         ops.set_option("grouped_variant", variant)
         specs = [  # (K, M, N, accumulate, bias, bias_accumulate)
@@ -244,6 +244,7 @@ def test_grouped_weight_gradients(variant):
             (32, 256, 512, False, True, False), (333, 136, 72, False, True, False), (2050, 512, 256, True, True, False),
             (64, 1000, 776, False, True, False),
         ]
+        specs += [(100 + 8 * j, 8 * (1 + j % 5), 8 * (2 + j % 3), bool(j & 1), bool(j & 2), False) for j in range(18)]  # > 24: two launches
         probs, wants = [], []
         for i, (k, m, n, acc, has_b, acc_b) in enumerate(specs):
             dy, x = _mk(k, m, 100 + i).to(DEV), _mk(k, n, 200 + i).to(DEV)

@@ -28,6 +28,7 @@ labels = torch.randint(0, 1000, (BATCH,), generator=g).to(dev)
 def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt=-1, nn=-1):
     def f():
         fused.DW_GROUP_BLOCKS = blocks
+        fused.DW_GROUP_TILES = 0  # the variants of this tool group by block count
         fused.DW_GROUP_ON_MAIN = on_main
         fused.FWD_HALVES = halves
         fused.BWD_HALVES = bhalves
