@@ -42,17 +42,12 @@ def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt
 VARIANTS = {
     "default (g2, s2, table 7)": setv(2),
     "nn=c13": setv(2, nn=13),
-    "ntw=c13": setv(2, nt_wide=13),
-    "ntw=c0": setv(2, nt_wide=0),
-    "nt=c0": setv(2, nt=0),
-    "nn=c8": setv(2, nn=8),
-    "3-slice bwd": setv(2, bhalves=3),
-    "3-slice fwd": setv(2, halves=3),
-    "3-slice both": setv(2, halves=3, bhalves=3),
-    "grouped 1 blk": setv(1),
-    "grouped 3 blk": setv(3),
-    "grouped 4 blk": setv(4),
-    "ring variant 2": setv(2, variant=2),
+    "nn=c13 ntw=c13": setv(2, nn=13, nt_wide=13),
+    "nn=c13 ntw=c13 nt=c13": setv(2, nn=13, nt_wide=13, nt=13),
+    "nn=c13 nt=c13": setv(2, nn=13, nt=13),
+    "nn=c0 ntw=c0 nt=c0": setv(2, nn=0, nt_wide=0, nt=0),
+    "one-pass fwd, nn=c13 ntw=c13 nt=c13": setv(2, halves=1, nn=13, nt_wide=13, nt=13),
+    "one-pass both, all c13": setv(2, halves=1, bhalves=1, nn=13, nt_wide=13, nt=13),
 }
 if len(sys.argv) > 2:
     sel = sys.argv[2:]
