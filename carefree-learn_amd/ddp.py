@@ -275,6 +275,8 @@ class BucketedAllReduce:
                 pass
 
     def _end_of_backward(self) -> None:
+        for flush in HF.deferred_grad_flushes:  # weight gradients still queued for a grouped launch (fused.py)
+            flush()
         if self._pass_open and self._pass_sync and self.sync_enabled:
             self.finish()
         self._pass_open = False

@@ -30,6 +30,10 @@ grad_ready_callbacks: List[Callable[[Tensor], None]] = []
 # pass (ddp.BucketedAllReduce) must queue it from here — queued from a gradient notification inside the nested task it
 # would fire when that block's inner backward ends.
 backward_entered_callbacks: List[Callable[[], None]] = []
+# Weight gradients may be queued for a later grouped launch (fused.queue_linear_dw): whoever is about to consume ALL
+# gradients of the pass from an end-of-backward callback of its own (ddp.BucketedAllReduce.finish) calls these first —
+# the order in which autograd runs end-of-backward callbacks is the order they were queued in, which is not ours to pick.
+deferred_grad_flushes: List[Callable[[], None]] = []
 
 
 # ---------------------------------------------------------------------------------------------
@@ -355,7 +359,10 @@ class LinearFn(Function):
         if _all_direct(weight, bias):
             # gradients that land straight in `.grad` do not go back through autograd: they run on the side stream,
             # beside the dX GEMM below (issued first so that the side stream does not wait for dX)
-            SideStream.run(lambda: _linear_param_grads(dy2, x2, weight, bias, True, True), (dy2, x2))
+            from . import fused  # (round 3) weight gradients of stand-alone Linear layers join the grouped launches
+
+            if not fused.queue_linear_dw(weight, bias, dy2, x2):
+                SideStream.run(lambda: _linear_param_grads(dy2, x2, weight, bias, True, True), (dy2, x2))
             dx = ops.gemm(dy2, w16, b_trans=True).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         else:
             dx = None

@@ -13,12 +13,14 @@ GEMM(+bias +residual).  Backward: every dX GEMM reads W row-major through the tr
 GELU' is the epilogue of the FF2 dX GEMM, both residual-gradient adds are folded into the LayerNorm
 backward kernels, and all parameter gradients are written directly into `param.grad`.
 """
+import os
 from typing import Any, Optional
 
 import torch
 from torch import Tensor
 from torch.autograd import Function
 
+from . import functional as _functional
 from . import ops
 from .functional import SideStream, bf16, f32, grad_buffer, shadow_bf16
 
@@ -74,9 +76,19 @@ _pending_dw: list = []
 _slice_streams: list = []  # streams of the backward's batch slices beyond the caller's (what a dW launch has to wait for)
 
 
+# Stand-alone Linear layers (functional.LinearFn: the UNet's ~600 small projections, CLIP projections, classifier heads, the
+# patch embedding) queue their weight gradients here too: flushed when LINEAR_DW_TILES tiles are waiting, together with the next
+# block-stack flush, or when the backward pass ends.  A flush of fewer than DW_MIN_TILES tiles falls back to one split-K GEMM
+# per gradient (whole-reduction 256 x 256 tiles on a handful of CUs would take longer than 128 x 128 split-K tiles on all).
+LINEAR_DW_TILES = int(os.environ.get("CFHIP_LINEAR_DW_TILES", "0"))  # (env: A/B runs)  0: LinearFn computes its weight gradient on the spot (round-1/2 behaviour)
+DW_MIN_TILES = int(os.environ.get("CFHIP_DW_MIN_TILES", "48"))
+GROUP_MAX = 24  # problems per launch (gemm_grouped.hip: the by-value problem table)
+_end_flush_queued = False
+
+
 def _groupable(w: Tensor, dy2: Tensor, x2: Tensor) -> bool:
-    n, k = w.shape[0], x2.shape[1]
-    return (dy2.is_cuda and w.dim() == 2 and w.is_contiguous() and n % 8 == 0 and k % 8 == 0 and dy2.stride(0) % 8 == 0
+    n, k = dy2.shape[1], x2.shape[1]
+    return (dy2.is_cuda and w.numel() == n * k and w.is_contiguous() and n % 8 == 0 and k % 8 == 0 and dy2.stride(0) % 8 == 0
             and x2.stride(0) % 8 == 0 and x2.shape[0] * max(dy2.stride(0), x2.stride(0)) * 2 < 2 ** 31
             and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0)
 
@@ -89,9 +101,47 @@ def _queue_dw(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> None:
     _pending_dw.append((w, b, dy2, x2))
 
 
+def queue_linear_dw(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> bool:
+    """`functional.LinearFn.backward`: take over dW (+ db) of a stand-alone Linear whose gradients go straight into `.grad`.
+    False = not taken (grouping off, shapes the grouped kernel does not accept, not inside a backward pass)."""
+    global _end_flush_queued
+    if LINEAR_DW_TILES <= 0 or DW_GROUP_BLOCKS <= 0 or not w.requires_grad or not _groupable(w, dy2, x2):
+        return False
+    if not _end_flush_queued:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_flush)
+        except RuntimeError:  # not inside a backward pass
+            return False
+        _end_flush_queued = True
+    _pending_dw.append((w, b, dy2, x2))
+    if _pending_tiles() >= LINEAR_DW_TILES:
+        _flush_dw(tuple(_slice_streams))
+    return True
+
+
+def _end_of_backward_flush() -> None:
+    global _end_flush_queued
+    _end_flush_queued = False
+    if _pending_dw:
+        _flush_dw(tuple(_slice_streams))
+        SideStream.join()  # (the side streams' own end-of-backward join may already have run)
+
+
+def _flush_deferred() -> None:
+    if _pending_dw:
+        _flush_dw(tuple(_slice_streams))
+
+
+_functional.deferred_grad_flushes.append(_flush_deferred)
+
+
+def _tiles_of(items: list) -> int:
+    return sum(((dy2.shape[1] + 255) // 256) * ((x2.shape[1] + 255) // 256) for _, _, dy2, x2 in items)
+
+
 def _pending_tiles() -> int:
     """256 x 256 output tiles of the queued weight gradients"""
-    return sum(((w.shape[0] + 255) // 256) * ((x2.shape[1] + 255) // 256) for w, _, _, x2 in _pending_dw)
+    return _tiles_of(_pending_dw)
 
 
 def _flush_dw(wait: tuple = ()) -> None:
@@ -103,25 +153,40 @@ def _flush_dw(wait: tuple = ()) -> None:
         return
     items = list(_pending_dw)
     _pending_dw.clear()
+    if _tiles_of(items) < DW_MIN_TILES:  # too few tiles for one-tile-per-CU whole reductions: split-K GEMMs
+        for w, b, dy2, x2 in items:
+            SideStream.run(lambda w=w, b=b, dy2=dy2, x2=x2: _dw_db(w, b, dy2, x2), (dy2, x2), wait=wait)
+        return
+    # a parameter that is queued twice (shared weights) must not be written by two problems of ONE launch
+    launches: list = [[]]
+    seen: set = set()
+    for it in items:
+        if id(it[0]) in seen or len(launches[-1]) == GROUP_MAX:
+            launches.append([])
+            seen = set()
+        seen.add(id(it[0]))
+        launches[-1].append(it)
 
     def launch() -> None:
-        probs, done = [], []
-        for w, b, dy2, x2 in items:
-            prms = [w] + ([b] if (b is not None and b.requires_grad) else [])
-            for prm in prms:
-                if prm.grad is None:
-                    prm.grad = grad_buffer(prm)
-                    prm._cfhip_fresh = True
-            bg, acc_b = None, False
-            if len(prms) == 2 and not _SKIP_BIAS_GRAD:
-                bg, acc_b = b.grad.view(-1), not getattr(b, "_cfhip_fresh", False)
-            probs.append((dy2, x2, w.grad.view(w.shape[0], x2.shape[1]), not getattr(w, "_cfhip_fresh", False), bg, acc_b))
-            done.extend(prms)
-        ops.gemm_grouped_tn(probs)
-        for prm in done:
-            prm._cfhip_fresh = False
-            for cb in grad_ready_callbacks:
-                cb(prm)
+        for group in launches:
+            probs, done = [], []
+            for w, b, dy2, x2 in group:
+                prms = [w] + ([b] if (b is not None and b.requires_grad) else [])
+                for prm in prms:
+                    if prm.grad is None:
+                        prm.grad = grad_buffer(prm)
+                        prm._cfhip_fresh = True
+                bg, acc_b = None, False
+                if len(prms) == 2 and not _SKIP_BIAS_GRAD:
+                    bg, acc_b = b.grad.view(-1), not getattr(b, "_cfhip_fresh", False)
+                probs.append((dy2, x2, w.grad.view(dy2.shape[1], x2.shape[1]), not getattr(w, "_cfhip_fresh", False), bg, acc_b))
+                for prm in prms:
+                    prm._cfhip_fresh = False
+                done.extend(prms)
+            ops.gemm_grouped_tn(probs)
+            for prm in done:
+                for cb in grad_ready_callbacks:
+                    cb(prm)
 
     if DW_GROUP_ON_MAIN:
         for st in wait:

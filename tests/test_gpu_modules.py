@@ -368,3 +368,57 @@ def test_sliced_passes_with_stale_weight_shadows(golden):
         assert torch.equal(outs["sliced"][0], outs["one pass"][0])
     finally:
         fused.FWD_HALVES, fused.BWD_HALVES = keep
+
+
+def test_stand_alone_linear_weight_gradients_join_the_grouped_launches():
+    """Round 3: the weight gradients of stand-alone Linear layers are queued (fused.queue_linear_dw) and written by grouped
+    launches — flushed by tile count, at the end of the backward pass, or as split-K GEMMs when too few tiles are waiting.
+    A chain of Linear layers incl. one SHARED weight (queued twice in one pass: the second problem must accumulate onto the
+    first, never race it inside one launch), two backward passes without zeroing in between (accumulation onto existing
+    `.grad`); compared with the on-the-spot path (LINEAR_DW_TILES = 0) and with fp32 torch."""
+    from cflearn_amd import fused
+
+    torch.manual_seed(11)
+    dims = [512, 768, 768, 512, 1024, 512]
+    x = torch.randn(384, dims[0], device=DEV)
+    keep = fused.LINEAR_DW_TILES, fused.DW_MIN_TILES
+    try:
+        res = {}
+        for name, (tiles, floor) in (("grouped", (12, 1)), ("end of pass", (10 ** 6, 1)), ("few tiles", (10 ** 6, 10 ** 6)), ("on the spot", (0, 1))):
+            fused.LINEAR_DW_TILES, fused.DW_MIN_TILES = tiles, floor
+            torch.manual_seed(12)
+            layers = [C.Linear(a, b).to(DEV) for a, b in zip(dims[:-1], dims[1:])]
+            shared = layers[1]  # 768 -> 768, applied twice
+
+            def run():
+                h = x
+                for i, l in enumerate(layers):
+                    h = l(h)
+                    if i == 1:
+                        h = shared(h)
+                return h.float().square().mean()
+
+            run().backward()
+            loss = run()
+            loss.backward()  # second pass accumulates
+            torch.cuda.synchronize()
+            res[name] = [p.grad.detach().clone() for l in layers for p in l.parameters()]
+            if name == "grouped":
+                ws = [l.linear.weight.detach().double() for l in layers]
+                bs = [l.linear.bias.detach().double() for l in layers]
+        # fp32/64 torch reference of the same chain
+        ps = [t.clone().requires_grad_(True) for pair in zip(ws, bs) for t in pair]
+        h = x.double()
+        for i in range(len(layers)):
+            h = h @ ps[2 * i].t() + ps[2 * i + 1]
+            if i == 1:
+                h = h @ ps[2].t() + ps[3]
+        (2.0 * h.square().mean()).backward()
+        for name in ("grouped", "end of pass", "few tiles"):
+            for i, (a, b) in enumerate(zip(res[name], res["on the spot"])):
+                assert_close(a, b, 2e-3, f"{name}: gradient {i} vs the on-the-spot path", abs_floor=1e-7)
+        for i, (a, r) in enumerate(zip(res["grouped"], ps)):
+            assert_close(a, r.grad.float(), 3e-2, f"gradient {i} vs torch", abs_floor=1e-7)
+        assert not fused._pending_dw
+    finally:
+        fused.LINEAR_DW_TILES, fused.DW_MIN_TILES = keep
