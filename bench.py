@@ -422,6 +422,12 @@ def run_other_workload(args) -> dict:
     finally:
         ops.FLOP_COUNTER = None
     tf = counter.total() / dt / 1e12
+    gemm_rows = None
+    if getattr(args, "gemm_table", False):  # in-step event pairs around every GEMM launch, by shape
+        class _Step:
+            step = staticmethod(lambda: step())
+        f_step, t_step, rows = time_gemms_in_step(_Step, lambda: (), 2)
+        gemm_rows = {"flops_per_step": f_step, "kernel_ms_per_step": round(t_step * 1e3, 3), "rows": rows[:40]}
     return {
         "metric": f"train samples/sec + step ms, {args.workload}", "value": round(batch / dt, 3), "unit": "samples/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
@@ -432,7 +438,7 @@ def run_other_workload(args) -> dict:
         "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
                      "definition": "algorithmic MFMA-class FLOPs of one step (ops.FlopCounter) / measured wall time of the step",
-                     "flops_per_step": {k: v for k, v in counter.flops.items()}},
+                     "flops_per_step": {k: v for k, v in counter.flops.items()}, "gemm_table": gemm_rows},
         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
     }
 
@@ -497,6 +503,7 @@ def main() -> None:
                     help="replay the step from a captured hipGraph (single GPU).  Default is eager multi-stream "
                          "launches: with the parameter-gradient kernels on side streams the eager step measured "
                          "faster than the graph replay (profiles/r01)")
+    ap.add_argument("--gemm-table", action="store_true", help="--workload unet | clip: add the in-step per-shape GEMM table")
     ap.add_argument("--no-graph", action="store_true", help="(default now) kept for compatibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

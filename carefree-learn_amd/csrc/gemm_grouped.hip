@@ -20,13 +20,23 @@
 //   * every K-step issues its DMA unconditionally (K-steps beyond the reduction are out-of-range offsets: zero fill, no
 //     traffic), so every `s_waitcnt vmcnt` in the loop is the same compile-time count.
 // The bias gradient rides on the matrix pipe: colsum(dY) = dY^T 1, i.e. one extra MFMA with a ones operand per A fragment,
-// spread over the four column waves (one fragment per wave and phase) of the workgroups that own a first tile column.
+// spread over the four column waves (one fragment per wave and phase).  Round 3b: the reduction of a bias gradient is SHARED by
+// the tiles_n workgroups of a tile row — workgroup (tile_m, tile_n) sums the K-steps t = tile_n (mod tiles_n) — so that every
+// workgroup of the launch runs the same instruction stream at the same pace.  When only the first tile column did it (every
+// K-step), those workgroups ran ~8 % behind the others that share their operand panels, fell out of the L2 window (4 MiB =
+// ~20 K-steps of an XCD's panels) and re-fetched both panels on their own: 2242 MB of L2 fills per launch against 1661 MB
+// without bias gradients (1239 MB algorithmic; profiles/r03/grouped_dw_traffic.txt).  The tiles_n partial sums meet in a
+// per-stream workspace; the LAST workgroup of a tile row to arrive (one atomic counter per tile row) adds them in tile_n
+// order — deterministic, no float atomics — and writes db.
+// Tile order inside a problem: the shorter tile dimension runs fastest, so that the contiguous tile range an XCD owns covers
+// whole panels of the longer operand (fc2's dW is 3 x 12 tiles: row-major order made every XCD read all of X).
 #include "gemm_device.h"
+#include <mutex>
 #include <type_traits>
 
 namespace {
 
-constexpr int GROUP_MAX = 24;  // problems per launch (72 bytes of kernel arguments each)
+constexpr int GROUP_MAX = 24;  // problems per launch (88 bytes of kernel arguments each)
 
 struct GroupedProblem {
   const bf16_t* A;  // dY  [K][M]  (m-major: element (m, k) at A[k * lda + m])
@@ -35,14 +45,19 @@ struct GroupedProblem {
   float* bgrad;     // db  [M] f32 or nullptr
   int M, N, K;
   int lda, ldb, ldc;
-  int tiles_n;
+  int tiles_m, tiles_n;
   int tile_end;  // tiles of problems 0 .. this one (exclusive prefix sum)
-  int flags;     // bit 0: C += ; bit 1: bgrad +=
+  int flags;     // bit 0: C += ; bit 1: bgrad += ; bit 2: tiles numbered with tile_m fastest
+  int bg_parts;  // workgroups of a tile row that share the bias-gradient reduction (tiles_n, or 1: the first tile column alone)
+  int bg_ws;     // float offset of this problem's [bg_parts][M] partial sums in GroupedParams::ws
+  int bg_cnt;    // offset of its tiles_m arrival counters in GroupedParams::cnt
 };
 
 struct GroupedParams {
   GroupedProblem pr[GROUP_MAX];
   int count;
+  float* ws;  // bias-gradient partial sums (per-stream workspace of the library)
+  int* cnt;   // arrival counters, zero between launches
 };
 
 // instruction J (0 / 1) of an m-major operand's two-instruction K-step
@@ -97,8 +112,14 @@ void gemm_grouped_tn_kernel(GroupedParams p) {
     }
   }
   const int tile = item - first;
-  const int tile_m = tile / q.tiles_n;
-  const int tile_n = tile - tile_m * q.tiles_n;
+  int tile_m, tile_n;
+  if (q.flags & 4) {
+    tile_n = tile / q.tiles_m;
+    tile_m = tile - tile_n * q.tiles_m;
+  } else {
+    tile_m = tile / q.tiles_n;
+    tile_n = tile - tile_m * q.tiles_n;
+  }
   const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
   const int rows_a = q.M - m0, rows_b = q.N - n0;
   const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(q.A + m0, ((long)(q.K - 1) * q.lda + rows_a) * 2);
@@ -114,7 +135,7 @@ void gemm_grouped_tn_kernel(GroupedParams p) {
 #pragma unroll
     for (int ni = 0; ni < C::FN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 accb0 = {0.f, 0.f, 0.f, 0.f}, accb1 = {0.f, 0.f, 0.f, 0.f};
-  const bool do_bg = BG && q.bgrad != nullptr && tile_n == 0;
+  const bool do_bg = BG && q.bgrad != nullptr && tile_n < q.bg_parts;
   const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
 #pragma unroll
@@ -126,15 +147,13 @@ void gemm_grouped_tn_kernel(GroupedParams p) {
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();  // the stagger
 
-  // The K loop exists twice — with and without the bias-gradient MFMA — and the (workgroup-uniform) choice is made ONCE,
-  // outside: a branch inside the M segment broke the MFMA stream (register copies of the two accumulators + their hazard
-  // nops on every phase: the launch was 17 % slower with bias gradients than without, profiles/r03/gemm_grouped_bench.log).
-  // In a first-tile-column workgroup every wave issues ONE extra MFMA per phase: fragment `wn` of the phase's four, picked
-  // with wave-uniform selects (no run-time register index).
-  auto k_loop = [&](auto bg_tag) {
-    constexpr bool DO_BG = decltype(bg_tag)::value;
-    int rd = 0, wr = D;
-    for (int t = 0; t < nk; ++t) {
+  // In a bias-gradient K-step (workgroup-uniform, one in bg_parts) every wave issues ONE extra MFMA per phase: fragment `wn`
+  // of the phase's four, picked with wave-uniform selects (no run-time register index), behind a scalar branch at the end of
+  // the M segment.  (History: with the builtin MFMA behind that branch the compiler copied both accumulators around the join
+  // on every phase, +17 %, profiles/r03/gemm_grouped_bench.log; round 3a therefore duplicated the whole K loop.)
+  int rd = 0, wr = D;
+  auto k_step = [&](const int t, const bool bg_step) {
+    {
       const char* a_tile = smem + rd * C::STAGE_BYTES;
       const char* b_tile = a_tile + C::A_BYTES;
       char* w_tile = smem + wr * C::STAGE_BYTES;
@@ -180,10 +199,16 @@ void gemm_grouped_tn_kernel(GroupedParams p) {
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        if constexpr (DO_BG) {
-          const bf16x8 mine = wn == 0 ? af[0] : wn == 1 ? af[1] : wn == 2 ? af[2] : af[3];
-          if (ph == 0) accb0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, mine, accb0, 0, 0, 0);
-          else accb1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, mine, accb1, 0, 0, 0);
+        if constexpr (BG) {
+          if (bg_step) {  // wave-uniform: a scalar branch over 12 selects + one MFMA
+            const bf16x8 mine = wn == 0 ? af[0] : wn == 1 ? af[1] : wn == 2 ? af[2] : af[3];
+            // inline asm: the accumulator stays in ITS registers on both sides of the branch (the builtin made the compiler
+            // copy accb0 / accb1 around the join on every phase).  Nothing reads them before the loop ends.
+            // `s_nop 1`: the two wait states between a VALU write (the selects, the re-materialised ones) and an MFMA reading
+            // it as A / B — the compiler pads nothing inside an asm string, and without them the MFMA read stale operands.
+            if (ph == 0) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accb0) : "v"(ones), "v"(mine));
+            else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accb1) : "v"(ones), "v"(mine));
+          }
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -194,8 +219,17 @@ void gemm_grouped_tn_kernel(GroupedParams p) {
       wr = wr + 1 == C::NSTAGE ? 0 : wr + 1;
     }
   };
-  if (do_bg) k_loop(std::true_type{});
-  else k_loop(std::false_type{});
+  if constexpr (BG) {
+    int next_bg = do_bg ? tile_n : 0x7fffffff;  // this workgroup's share of the bias-gradient reduction: t = tile_n (mod bg_parts)
+    const int bg_stride = q.bg_parts;
+    for (int t = 0; t < nk; ++t) {
+      const bool mine = t == next_bg;
+      k_step(t, mine);
+      next_bg += mine ? bg_stride : 0;
+    }
+  } else {
+    for (int t = 0; t < nk; ++t) k_step(t, false);
+  }
   if (wm == 0) __builtin_amdgcn_s_barrier();  // every wave has executed the same number of barriers
   // the trailing (zero-fill) DMAs still target ring slots: retire them everywhere before the ring becomes the epilogue's strip
   CFHIP_WAIT_VMCNT(0);
@@ -203,10 +237,39 @@ void gemm_grouped_tn_kernel(GroupedParams p) {
 
   if constexpr (BG) {
     // accb0 / accb1: colsum over k of fragment `wn` of phase 0 / 1 (rows (ph * 4 + wn) * 16 .. + 15 of the wave's 128)
-    if (do_bg && (lane >> 4) == 0) {
-      const int m = m0 + wm * 128 + wn * 16 + (lane & 15);
-      if (m < q.M) q.bgrad[m] = (q.flags & 2) ? q.bgrad[m] + accb0[0] : accb0[0];
-      if (m + 64 < q.M) q.bgrad[m + 64] = (q.flags & 2) ? q.bgrad[m + 64] + accb1[0] : accb1[0];
+    // -> partial sums of this workgroup's K-steps in the workspace; the last workgroup of the tile row to arrive adds the
+    // bg_parts partials in order and writes db.  The partials cross XCDs, whose L2s are not coherent for plain accesses:
+    // relaxed agent-scope atomic stores / loads (sc1: write-through / read from memory), every wave drains its stores
+    // before the barrier, then ONE relaxed ticket.  No release / acquire fences: those write back and invalidate the whole
+    // L2 of the XCD, which the kernels of the main queue are working in at the same time (the fenced version cost the
+    // step +0.28 ms, profiles/r03/step_variants_d.log).  The ring is free here (DMAs retired, fragment reads done).
+    if (do_bg) {  // workgroup-uniform
+      float* part = p.ws + q.bg_ws + (long)tile_n * q.M;
+      if ((lane >> 4) == 0) {
+        const int m = m0 + wm * 128 + wn * 16 + (lane & 15);
+        if (m < q.M) __hip_atomic_store(part + m, accb0[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (m + 64 < q.M) __hip_atomic_store(part + m + 64, accb1[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sc1 (write-through) stores have reached memory
+      __syncthreads();
+      int* last = reinterpret_cast<int*>(smem);
+      if (tid == 0) {
+        int* c = p.cnt + q.bg_cnt + tile_m;
+        const int arrived = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *last = arrived == q.bg_parts - 1;
+        if (arrived == q.bg_parts - 1) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero for the next launch
+      }
+      __syncthreads();
+      if (*last) {
+        const int m = m0 + tid;
+        if (tid < 256 && m < q.M) {
+          float sum = 0.f;
+          for (int j = 0; j < q.bg_parts; ++j)
+            sum += __hip_atomic_load(p.ws + q.bg_ws + (long)j * q.M + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          q.bgrad[m] = (q.flags & 2) ? q.bgrad[m] + sum : sum;
+        }
+      }
+      __syncthreads();  // `last` is read before the epilogue reuses the ring
     }
   }
   GemmParams gp;
@@ -255,10 +318,59 @@ int launch_variant(const GroupedParams& p, int tiles, hipStream_t s) {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+int g_grouped_bias_shared = 1;  // 1: a tile row shares the bias-gradient reduction; 0: its first tile alone (round-3a behaviour)
+int g_grouped_short_fastest = 1;  // 1: tiles of a problem numbered with the shorter tile dimension fastest; 0: row-major
+
+// Bias-gradient workspace: one per stream (launches on one stream run one after the other; a different stream gets its own
+// partial sums and counters), grown on demand.  Allocation is illegal inside a hipGraph capture: run one eager step first.
+struct BiasWorkspace {
+  hipStream_t stream;
+  float* ws;
+  int* cnt;
+  size_t floats, counters;
+};
+constexpr int MAX_WS = 16;
+BiasWorkspace g_bias_ws[MAX_WS];
+int g_bias_ws_count = 0;
+std::mutex g_bias_ws_mutex;
+
+int bias_workspace(hipStream_t s, size_t floats, size_t counters, float** ws, int** cnt) {
+  std::lock_guard<std::mutex> lock(g_bias_ws_mutex);
+  BiasWorkspace* w = nullptr;
+  for (int i = 0; i < g_bias_ws_count; ++i)
+    if (g_bias_ws[i].stream == s) w = &g_bias_ws[i];
+  if (w == nullptr) {
+    CFHIP_REQUIRE(g_bias_ws_count < MAX_WS, "gemm_grouped: bias gradients requested on more than %d different streams", MAX_WS);
+    w = &g_bias_ws[g_bias_ws_count++];
+    *w = BiasWorkspace{s, nullptr, nullptr, 0, 0};
+  }
+  if (w->floats < floats || w->counters < counters) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    CFHIP_REQUIRE(cap == hipStreamCaptureStatusNone, "gemm_grouped: the bias-gradient workspace must exist before a hipGraph capture (run one eager step)");
+    const size_t nf = floats > (size_t)1 << 18 ? floats * 2 : (size_t)1 << 18, nc = counters > 4096 ? counters * 2 : 4096;
+    if (w->ws) (void)hipFree(w->ws);  // (synchronises the device: nothing is still reading the old buffers)
+    if (w->cnt) (void)hipFree(w->cnt);
+    w->ws = nullptr; w->cnt = nullptr; w->floats = w->counters = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&w->ws), nf * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&w->cnt), nc * sizeof(int)) != hipSuccess || hipMemset(w->cnt, 0, nc * sizeof(int)) != hipSuccess) {
+      cfhip_set_error("gemm_grouped: cannot allocate the bias-gradient workspace (%zu floats, %zu counters)", nf, nc);
+      return CFHIP_ERR_LAUNCH;
+    }
+    w->floats = nf; w->counters = nc;
+  }
+  *ws = w->ws;
+  *cnt = w->cnt;
+  return CFHIP_OK;
+}
+
 }  // namespace
 
 int cfhip_internal_set_grouped_variant(int v) {
-  g_grouped_variant = v;
+  // 0 .. 4: ring / DMA placement; +16: bias gradients by the first tile column alone; +32: row-major tile order (A/B runs)
+  g_grouped_variant = v & 15;
+  g_grouped_bias_shared = (v & 16) ? 0 : 1;
+  g_grouped_short_fastest = (v & 32) ? 0 : 1;
   return CFHIP_OK;
 }
 
@@ -272,6 +384,7 @@ extern "C" int cfhip_gemm_bf16_grouped_tn(const cfhip_gemm_problem* problems, in
     p.count = n;
     int tiles = 0;
     bool any_bg = false;
+    size_t ws_floats = 0, ws_counters = 0;
     for (int i = 0; i < n; ++i) {
       const cfhip_gemm_problem& src = problems[base + i];
       CFHIP_REQUIRE(src.A && src.B && src.C, "gemm_grouped: null operand in problem %d", base + i);
@@ -289,11 +402,24 @@ extern "C" int cfhip_gemm_bf16_grouped_tn(const cfhip_gemm_problem* problems, in
       d.bgrad = src.bias_grad;
       d.M = src.M; d.N = src.N; d.K = src.K;
       d.lda = (int)src.lda; d.ldb = (int)src.ldb; d.ldc = (int)src.ldc;
+      d.tiles_m = (src.M + 255) / 256;
       d.tiles_n = (src.N + 255) / 256;
-      tiles += ((src.M + 255) / 256) * d.tiles_n;
+      tiles += d.tiles_m * d.tiles_n;
       d.tile_end = tiles;
-      d.flags = (src.accumulate ? 1 : 0) | (src.bias_grad_accumulate ? 2 : 0);
-      any_bg = any_bg || src.bias_grad != nullptr;
+      d.flags = (src.accumulate ? 1 : 0) | (src.bias_grad_accumulate ? 2 : 0) | (g_grouped_short_fastest && d.tiles_m < d.tiles_n ? 4 : 0);
+      if (src.bias_grad != nullptr) {
+        any_bg = true;
+        d.bg_parts = g_grouped_bias_shared ? d.tiles_n : 1;
+        d.bg_ws = (int)ws_floats;
+        d.bg_cnt = (int)ws_counters;
+        ws_floats += (size_t)d.bg_parts * src.M;
+        ws_counters += d.tiles_m;
+        CFHIP_REQUIRE(ws_floats < 0x7fffffffUL, "gemm_grouped: bias-gradient workspace of problem %d out of range", base + i);
+      }
+    }
+    if (any_bg) {
+      const int rc = bias_workspace(s, ws_floats, ws_counters, &p.ws, &p.cnt);
+      if (rc != CFHIP_OK) return rc;
     }
     const int rc = any_bg ? launch_variant<true>(p, tiles, s) : launch_variant<false>(p, tiles, s);
     if (rc != CFHIP_OK) return rc;

@@ -52,7 +52,8 @@ const char* cfhip_last_error(void);
  *   "gemm_cfg_nt_wide" / "gemm_cfg_nt" / "gemm_cfg_nn" / "gemm_cfg_tn"   tile configuration of one class of M >= 1024 GEMMs
  *                     (forward with N >= 2560, other forward, dX, dW); -1 (default): the heuristic table
  *   "grouped_variant" ring of cfhip_gemm_bf16_grouped_tn: 0 (default) 5 slots, DMA 3 K-steps ahead; 1: 4 slots, 2 ahead;
- *                     2: 5 slots, 2 ahead
+ *                     2: 5 slots, 2 ahead; 3 / 4: DMA placement variants of 0.  +16: bias gradients reduced by the first tile
+ *                     column alone instead of shared by the tile row; +32: row-major tile order (both: A/B runs)
  * Unknown names are an error.  (The phase-timing ablation masks "gemm_ablate" / "attn_ablate" of round 1 are
  * not part of this library any more: they exist only in the -DCFHIP_ABLATE build that tools/build_variant.sh
  * writes to tools/libcfhip_ablate.so, selected by the tools through CFHIP_LIB.) */
@@ -103,7 +104,10 @@ int cfhip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, co
  * cfhip_gemm_bf16: A = dY [K][M] (lda), B = X [K][N] (ldb), both bf16 token-major; C f32 [M][N] (ldc).  256 x 256 output
  * tiles of all problems share the chip, every tile runs its whole reduction: no split-K, no workspace, no second pass,
  * deterministic.  M, N, lda, ldb multiples of 8, ldc of 4, 16-byte aligned bases, K*ld*2 < 2 GiB.  `problems` is a HOST
- * array (copied into the kernel arguments, 24 per launch).  bias_grad may be NULL per problem. */
+ * array (copied into the kernel arguments, 24 per launch).  bias_grad may be NULL per problem.  With bias gradients the
+ * workgroups of a tile row share the column-sum reduction and meet in a small workspace the LIBRARY owns, one per stream
+ * (<= 16 streams; allocated on the first such launch of a stream — before any hipGraph capture); partial sums are added in a
+ * fixed order, results do not depend on arrival order. */
 typedef struct cfhip_gemm_problem {
   const void* A;
   const void* B;

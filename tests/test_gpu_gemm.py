@@ -231,7 +231,7 @@ def test_tile_walk_orders_give_identical_results():
     assert_close(outs[0], a.float().double() @ w.float().t().double(), 2e-5, "walk order")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 16, 32, 48])  # +16: bias gradients by the first tile column alone; +32: row-major tiles
 def test_grouped_weight_gradients(variant):
     """cfhip_gemm_bf16_grouped_tn: several dW = dY^T X (+ db = colsum dY) problems in one launch vs fp64 on the same bf16
     operands — ragged shapes (M, N not multiples of the 256-wide tile, K not a multiple of the 32-deep K-step, K shorter
@@ -286,6 +286,49 @@ def test_grouped_weight_gradients_at_the_benchmark_shapes():
         want = dy[:, rows].double().t() @ x.double()
         assert_close(out[rows], want, 2e-5, f"problem {i} dW rows")
         assert_close(bg, dy.double().sum(0), 2e-5, f"problem {i} db")
+
+
+def test_grouped_bias_gradients_are_shared_deterministically():
+    """The workgroups of a tile row share the bias-gradient reduction through a per-stream workspace and arrival counters:
+    repeated launches (counters back at zero), launches racing on two streams (a workspace each) and a workspace that has to
+    grow all give bit-identical results, equal to fp64 within rounding."""
+    g = torch.Generator(device=DEV).manual_seed(9)
+    rnd = lambda r, c: (torch.randn(r, c, generator=g, device=DEV) * 0.5).to(torch.bfloat16)  # noqa: E731
+    shapes = ((4104, 1000, 776), (2050, 512, 2304), (333, 136, 3072), (5000, 2304, 768))  # (K, M, N): 4, 9, 12, 3 tile columns
+
+    def problems():
+        return [(dy, x, torch.empty(dy.shape[1], x.shape[1], dtype=torch.float32, device=DEV), False,
+                 torch.empty(dy.shape[1], dtype=torch.float32, device=DEV), False) for dy, x in operands]
+
+    operands = [(rnd(k, m), rnd(k, n)) for k, m, n in shapes]
+    first = problems()
+    ops.gemm_grouped_tn(first)
+    torch.cuda.synchronize()
+    for (dy, x, out, _, bg, _) in first:
+        assert_close(bg, dy.double().sum(0), 2e-5, "shared bias gradient")
+        assert_close(out, dy.double().t() @ x.double(), 2e-5, "dW")
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    runs = []
+    for rep in range(3):
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                pr = problems()
+                ops.gemm_grouped_tn(pr)
+                runs.append(pr)
+    torch.cuda.synchronize()
+    for pr in runs:
+        for (_, _, out, _, bg, _), (_, _, out0, _, bg0, _) in zip(pr, first):
+            assert torch.equal(bg, bg0) and torch.equal(out, out0)
+    # a launch that needs a larger workspace than the first allocation (2^18 floats): 40 tile columns x 8192 rows
+    dy, x = rnd(64, 8192), rnd(64, 10240)
+    out, bg = torch.empty(8192, 10240, dtype=torch.float32, device=DEV), torch.empty(8192, dtype=torch.float32, device=DEV)
+    ops.gemm_grouped_tn([(dy, x, out, False, bg, False)])
+    assert_close(bg, dy.double().sum(0), 2e-5, "bias gradient after the workspace grew")
+    again = problems()
+    ops.gemm_grouped_tn(again)
+    for (_, _, out, _, bg, _), (_, _, out0, _, bg0, _) in zip(again, first):
+        assert torch.equal(bg, bg0) and torch.equal(out, out0)
 
 
 def _fp64_rows(a, b, layout, rows):

@@ -15,6 +15,14 @@ def family(name: str) -> str:
     return "other"
 
 
+def short(name: str) -> str:
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0][:110]
+
+
+by_kernel: dict = {}  # (kernel, grid) -> {counter: KiB, "n": dispatches}
+
+
 def load(path: str, counter: str):
     out = {}
     for r in csv.DictReader(open(path)):
@@ -22,6 +30,11 @@ def load(path: str, counter: str):
             continue
         fam = family(r.get("Kernel_Name", ""))
         out[fam] = out.get(fam, 0.0) + float(r["Counter_Value"])
+        if fam == "gemm":
+            ent = by_kernel.setdefault((short(r["Kernel_Name"]), int(r.get("Grid_Size", 0) or 0)), {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": 0})
+            ent[counter] += float(r["Counter_Value"])
+            if counter == "FETCH_SIZE":
+                ent["n"] += 1
     return out
 
 
@@ -40,5 +53,11 @@ for fam in sorted(set(fetch) | set(write)):
     res["families"][fam] = {"read": round(r), "written": round(w), "total": round(r + w)}
     tot_r += r
     tot_w += w
+# the GEMM family by kernel instantiation and grid (one row per launch shape class), bytes per step
+rows = []
+for (name, grid), ent in by_kernel.items():
+    rows.append({"kernel": name, "grid_threads": grid, "launches_per_step": round(ent["n"] / steps, 2),
+                 "read": round(ent["FETCH_SIZE"] * 2048.0 / steps), "written": round(ent["WRITE_SIZE"] * 1024.0 / steps)})
+res["gemm_by_launch_shape"] = sorted(rows, key=lambda r: -(r["read"] + r["written"]))[:24]
 res["all_kernels"] = {"read": round(tot_r), "written": round(tot_w), "total": round(tot_r + tot_w)}
 print(json.dumps(res, indent=1))

@@ -41,6 +41,9 @@ def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt
 
 VARIANTS = {
     "default (g2, s2, table 7)": setv(2),
+    "bias gradients by the first tile column (r3a)": setv(2, variant=16),
+    "row-major tiles (r3a)": setv(2, variant=32),
+    "r3a grouped kernel behaviour": setv(2, variant=48),
     "nn=c13": setv(2, nn=13),
     "nn=c13 ntw=c13": setv(2, nn=13, nt_wide=13),
     "nn=c13 ntw=c13 nt=c13": setv(2, nn=13, nt_wide=13, nt=13),
