@@ -116,6 +116,9 @@ SIGNATURES = {
     "cfhip_groupnorm_affine_fwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int,
                                            c_int, _P]),
     "cfhip_groupnorm_affine_bwd": (c_int, [_P, _P, c_int] + [_P] * 9 + [c_int] * 6 + [_P]),
+    "cfhip_groupnorm_split_fwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int,
+                                          c_int, c_int, _P, _P]),
+    "cfhip_groupnorm_split_bwd": (c_int, [_P, _P, c_int] + [_P] * 9 + [c_int] * 7 + [_P, _P]),
     "cfhip_diffusion_loss": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int, _P]),
     "cfhip_silu_f32_fwd": (c_int, [_P, _P, c_int64, _P]),
     "cfhip_silu_f32_bwd": (c_int, [_P, _P, _P, c_int64, _P]),

@@ -578,6 +578,250 @@ __global__ __launch_bounds__(256) void gn_bwd_vec_kernel(const bf16_t* __restric
   }
 }
 
+// ---- GroupNorm, split form: a (sample, group) pair is cut into S slices along `inner`, one workgroup each ------------
+// The vector kernels above run ONE workgroup per (sample, group): B * G = 32 workgroups for the batch-1 256^2 UNet step (a
+// tenth of the chip: 61 + 61 launches took 11.7 + 17.8 ms of a 533 ms step, profiles/r03/prof_unet256_b1_summary.txt) and
+// one 4-wave workgroup per CU at 64^2 x 8.  Split form: the statistics kernel writes one (mean, M2) pair per slice — a local
+// two-pass over the slice (second pass out of L2) — and every workgroup of the apply kernel merges the S pairs of its group
+// in slice order (Chan's parallel-variance update: deterministic, no cancellation) before it normalises its own slice.
+// Backward: per-slice per-channel sums (dn * xhat, dn) -> merged per channel by the apply kernel, which also leaves per-slice
+// sums of dx for the time-embedding gradient (reduced by gn_split_dadd_kernel).
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void gn_split_stats_kernel(const void* __restrict__ x, const float* __restrict__ add,
+                                                             float* __restrict__ part, int C, int G, int inner, int S) {
+  __shared__ float red[4];
+  const int bg = blockIdx.x, sl = blockIdx.y;
+  const int b = bg / G, g = bg - b * G;
+  const int cg = C / G;
+  const int inner8 = inner >> 3;
+  const int j0 = (int)((long)sl * inner8 / S), j1 = (int)((long)(sl + 1) * inner8 / S);
+  const long base = ((long)b * C + (long)g * cg) * inner;
+  const float inv_n = 1.f / ((float)cg * (float)(j1 - j0) * 8.f);
+  float s = 0.f;
+  for (int cl = 0; cl < cg; ++cl) {
+    const float ad = add != nullptr ? add[(long)b * C + g * cg + cl] : 0.f;
+    for (int j = j0 + threadIdx.x; j < j1; j += 256) {
+      float v[8];
+      gn_load8<IN_F32>(x, base + (long)cl * inner + (long)j * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[e] + ad;
+    }
+  }
+  const float mean = block_sum(s, red) * inv_n;
+  float q = 0.f;
+  for (int cl = 0; cl < cg; ++cl) {
+    const float ad = (add != nullptr ? add[(long)b * C + g * cg + cl] : 0.f) - mean;
+    for (int j = j0 + threadIdx.x; j < j1; j += 256) {
+      float v[8];
+      gn_load8<IN_F32>(x, base + (long)cl * inner + (long)j * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[e] + ad;
+        q += d * d;
+      }
+    }
+  }
+  q = block_sum(q, red);
+  if (threadIdx.x == 0) {
+    part[((long)bg * S + sl) * 2] = mean;
+    part[((long)bg * S + sl) * 2 + 1] = q;
+  }
+}
+
+// (mean, rstd) of group `bg` from its S slice pairs; every thread computes the same values (S <= 64 pairs: 512 bytes)
+__device__ __forceinline__ void gn_merge_slices(const float* __restrict__ part, int bg, int S, int cg, int inner8, float eps,
+                                                float& mean, float& rstd) {
+  float n = 0.f, mu = 0.f, m2 = 0.f;
+  for (int sl = 0; sl < S; ++sl) {
+    const int j0 = (int)((long)sl * inner8 / S), j1 = (int)((long)(sl + 1) * inner8 / S);
+    const float nb = (float)cg * (float)(j1 - j0) * 8.f;
+    const float mb = part[((long)bg * S + sl) * 2], qb = part[((long)bg * S + sl) * 2 + 1];
+    const float nt = n + nb, d = mb - mu;
+    mu += d * (nb / nt);
+    m2 += qb + d * d * (n * nb / nt);
+    n = nt;
+  }
+  mean = mu;
+  rstd = rsqrtf(m2 / n + eps);
+}
+
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void gn_split_apply_kernel(const void* __restrict__ x, const float* __restrict__ add,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ part, bf16_t* __restrict__ y,
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out, int C,
+                                                             int G, int inner, float eps, int silu, int affine_bs, int S) {
+  const int bg = blockIdx.x, sl = blockIdx.y;
+  const int b = bg / G, g = bg - b * G;
+  gamma += (long)b * affine_bs;
+  beta += (long)b * affine_bs;
+  const int cg = C / G;
+  const int inner8 = inner >> 3;
+  float mean, rstd;
+  gn_merge_slices(part, bg, S, cg, inner8, eps, mean, rstd);
+  if (sl == 0 && threadIdx.x == 0) {
+    mean_out[bg] = mean;
+    rstd_out[bg] = rstd;
+  }
+  const int j0 = (int)((long)sl * inner8 / S), j1 = (int)((long)(sl + 1) * inner8 / S);
+  const long base = ((long)b * C + (long)g * cg) * inner;
+  for (int cl = 0; cl < cg; ++cl) {
+    const int c = g * cg + cl;
+    const float ad = add != nullptr ? add[(long)b * C + c] : 0.f;
+    const float ga = gamma[c], be = beta[c];
+    for (int j = j0 + threadIdx.x; j < j1; j += 256) {
+      float v[8];
+      const long o = base + (long)cl * inner + (long)j * 8;
+      gn_load8<IN_F32>(x, o, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float r = ((v[e] + ad) - mean) * rstd * ga + be;
+        if (silu) r = silu_f(r);
+        v[e] = r;
+      }
+      gn_store8(y, o, v);
+    }
+  }
+}
+
+// part layout (backward): [bg][slice][3][cg]: sum(dn * xhat), sum(dn), sum(dx) per channel of the slice
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void gn_split_bwd_stats_kernel(const bf16_t* __restrict__ dy, const void* __restrict__ x,
+                                                                 const float* __restrict__ add, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, float* __restrict__ part, int C,
+                                                                 int G, int inner, int silu, int affine_bs, int S) {
+  __shared__ float wpart[2][GN_MAX_CG][4];
+  const int bg = blockIdx.x, sl = blockIdx.y;
+  const int b = bg / G, g = bg - b * G;
+  gamma += (long)b * affine_bs;
+  beta += (long)b * affine_bs;
+  const int cg = C / G;
+  const int inner8 = inner >> 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j0 = (int)((long)sl * inner8 / S), j1 = (int)((long)(sl + 1) * inner8 / S);
+  const long base = ((long)b * C + (long)g * cg) * inner;
+  const float mu = mean[bg], rs = rstd[bg];
+  for (int cl = 0; cl < cg; ++cl) {
+    const int c = g * cg + cl;
+    const float ad = add != nullptr ? add[(long)b * C + c] : 0.f;
+    const float ga = gamma[c], be = beta[c];
+    float sg = 0.f, sb = 0.f;
+    for (int j = j0 + threadIdx.x; j < j1; j += 256) {
+      const long o = base + (long)cl * inner + (long)j * 8;
+      float v[8], d[8];
+      gn_load8<IN_F32>(x, o, v);
+      gn_load8<false>(dy, o, d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (v[e] + ad - mu) * rs;
+        float dn = d[e];
+        if (silu) dn *= silu_grad_f(xh * ga + be);
+        sg += dn * xh;
+        sb += dn;
+      }
+    }
+    sg = wave_sum(sg);
+    sb = wave_sum(sb);
+    if (lane == 0) {
+      wpart[0][cl][wave] = sg;
+      wpart[1][cl][wave] = sb;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < cg) {
+    float* dst = part + ((long)bg * S + sl) * 3 * cg;
+    const int t = threadIdx.x;
+    dst[t] = (wpart[0][t][0] + wpart[0][t][1]) + (wpart[0][t][2] + wpart[0][t][3]);
+    dst[cg + t] = (wpart[1][t][0] + wpart[1][t][1]) + (wpart[1][t][2] + wpart[1][t][3]);
+  }
+}
+
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void gn_split_bwd_apply_kernel(const bf16_t* __restrict__ dy, const void* __restrict__ x,
+                                                                 const float* __restrict__ add, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, float* __restrict__ part,
+                                                                 bf16_t* __restrict__ dx, float* __restrict__ dgamma_part,
+                                                                 float* __restrict__ dbeta_part, int want_dadd, int C, int G,
+                                                                 int inner, int silu, int affine_bs, int S) {
+  __shared__ float red[4];
+  __shared__ float wpart[GN_MAX_CG][4];
+  const int bg = blockIdx.x, sl = blockIdx.y;
+  const int b = bg / G, g = bg - b * G;
+  gamma += (long)b * affine_bs;
+  beta += (long)b * affine_bs;
+  const int cg = C / G;
+  const int inner8 = inner >> 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float mu = mean[bg], rs = rstd[bg];
+  float t1 = 0.f, t2 = 0.f;
+  if ((int)threadIdx.x < cg) {  // this thread's channel: the S slice sums in slice order
+    const int c = g * cg + threadIdx.x;
+    float sg = 0.f, sb = 0.f;
+    for (int k = 0; k < S; ++k) {
+      const float* src = part + ((long)bg * S + k) * 3 * cg;
+      sg += src[threadIdx.x];
+      sb += src[cg + threadIdx.x];
+    }
+    if (sl == 0) {
+      dgamma_part[(long)b * C + c] = sg;
+      dbeta_part[(long)b * C + c] = sb;
+    }
+    t1 = sb * gamma[c];
+    t2 = sg * gamma[c];
+  }
+  const float s1 = block_sum(t1, red);
+  const float s2 = block_sum(t2, red);
+  const float inv_n = 1.f / ((float)cg * (float)inner);
+  const int j0 = (int)((long)sl * inner8 / S), j1 = (int)((long)(sl + 1) * inner8 / S);
+  const long base = ((long)b * C + (long)g * cg) * inner;
+  for (int cl = 0; cl < cg; ++cl) {
+    const int c = g * cg + cl;
+    const float ad = add != nullptr ? add[(long)b * C + c] : 0.f;
+    const float ga = gamma[c], be = beta[c];
+    float sd = 0.f;
+    for (int j = j0 + threadIdx.x; j < j1; j += 256) {
+      const long o = base + (long)cl * inner + (long)j * 8;
+      float v[8], d[8];
+      gn_load8<IN_F32>(x, o, v);
+      gn_load8<false>(dy, o, d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (v[e] + ad - mu) * rs;
+        float dn = d[e];
+        if (silu) dn *= silu_grad_f(xh * ga + be);
+        const float r = rs * (dn * ga - s1 * inv_n - xh * s2 * inv_n);
+        d[e] = r;
+        sd += r;
+      }
+      gn_store8(dx, o, d);
+    }
+    if (want_dadd) {
+      sd = wave_sum(sd);
+      if (lane == 0) wpart[cl][wave] = sd;
+    }
+  }
+  if (want_dadd) {
+    __syncthreads();
+    if ((int)threadIdx.x < cg)
+      part[((long)bg * S + sl) * 3 * cg + 2 * cg + threadIdx.x] =
+          (wpart[threadIdx.x][0] + wpart[threadIdx.x][1]) + (wpart[threadIdx.x][2] + wpart[threadIdx.x][3]);
+  }
+}
+
+__global__ __launch_bounds__(128) void gn_split_dadd_kernel(const float* __restrict__ part, float* __restrict__ dadd, int C, int G,
+                                                            int S) {
+  const int bg = blockIdx.x;
+  const int b = bg / G, g = bg - b * G;
+  const int cg = C / G;
+  if ((int)threadIdx.x < cg) {
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[((long)bg * S + k) * 3 * cg + 2 * cg + threadIdx.x];
+    dadd[(long)b * C + g * cg + threadIdx.x] = s;
+  }
+}
+
 // ---- 3x3 filter repacking for the implicit-GEMM convolution -----------------------------------------------------------
 // w bf16 [Cout][Cin][3][3] (the reference's layout, arena-backed shadow of the fp32 master) ->
 //   FWD: wk[co][tap][c]        = w[co][c][tap]         (tap = ky*3 + kx; a K-step of the GEMM = 32 channels of one tap)
@@ -880,6 +1124,61 @@ extern "C" int cfhip_groupnorm_affine_bwd(const void* dy, const void* x, int x_i
     hipLaunchKernelGGL((gn_bwd_kernel<false>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x,
                        add, gamma, beta, mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu, affine_bs);
   CFHIP_CHECK_LAUNCH("groupnorm_bwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_groupnorm_split_fwd(const void* x, int x_is_f32, const float* add, const float* gamma, const float* beta,
+                                         void* y, float* mean, float* rstd, int B, int C, int G, int inner, float eps, int silu,
+                                         int affine_batch_stride, int splits, float* workspace, void* stream) {
+  CFHIP_REQUIRE(affine_batch_stride == 0 || affine_batch_stride == C, "groupnorm_split_fwd: affine batch stride must be 0 or C");
+  CFHIP_REQUIRE(x && gamma && beta && y && mean && rstd && workspace && B > 0 && C > 0 && G > 0 && inner > 0,
+                "groupnorm_split_fwd: bad arguments");
+  CFHIP_REQUIRE(C % G == 0, "groupnorm_split_fwd: %d channels do not split into %d groups", C, G);
+  CFHIP_REQUIRE(inner % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0,
+                "groupnorm_split_fwd: inner must be a multiple of 8 and x / y 16-byte aligned (use cfhip_groupnorm_affine_fwd)");
+  CFHIP_REQUIRE(splits >= 1 && splits <= 64 && splits <= inner / 8, "groupnorm_split_fwd: %d slices for inner = %d", splits, inner);
+  const dim3 grid(B * G, splits);
+  hipStream_t s = (hipStream_t)stream;
+  if (x_is_f32) {
+    hipLaunchKernelGGL((gn_split_stats_kernel<true>), grid, dim3(256), 0, s, x, add, workspace, C, G, inner, splits);
+    hipLaunchKernelGGL((gn_split_apply_kernel<true>), grid, dim3(256), 0, s, x, add, gamma, beta, workspace, (bf16_t*)y, mean, rstd,
+                       C, G, inner, eps, silu, affine_batch_stride, splits);
+  } else {
+    hipLaunchKernelGGL((gn_split_stats_kernel<false>), grid, dim3(256), 0, s, x, add, workspace, C, G, inner, splits);
+    hipLaunchKernelGGL((gn_split_apply_kernel<false>), grid, dim3(256), 0, s, x, add, gamma, beta, workspace, (bf16_t*)y, mean, rstd,
+                       C, G, inner, eps, silu, affine_batch_stride, splits);
+  }
+  CFHIP_CHECK_LAUNCH("groupnorm_split_fwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_groupnorm_split_bwd(const void* dy, const void* x, int x_is_f32, const float* add, const float* gamma,
+                                         const float* beta, const float* mean, const float* rstd, void* dx, float* dgamma_part,
+                                         float* dbeta_part, float* dadd, int B, int C, int G, int inner, int silu,
+                                         int affine_batch_stride, int splits, float* workspace, void* stream) {
+  CFHIP_REQUIRE(affine_batch_stride == 0 || affine_batch_stride == C, "groupnorm_split_bwd: affine batch stride must be 0 or C");
+  CFHIP_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma_part && dbeta_part && workspace, "groupnorm_split_bwd: null pointer");
+  CFHIP_REQUIRE(B > 0 && C > 0 && G > 0 && inner > 0 && C % G == 0, "groupnorm_split_bwd: bad geometry");
+  CFHIP_REQUIRE(dadd == nullptr || add != nullptr, "groupnorm_split_bwd: dadd without add");
+  CFHIP_REQUIRE(inner % 8 == 0 && C / G <= GN_MAX_CG && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0,
+                "groupnorm_split_bwd: inner %% 8, <= %d channels per group and 16-byte alignment required (use cfhip_groupnorm_affine_bwd)", GN_MAX_CG);
+  CFHIP_REQUIRE(splits >= 1 && splits <= 64 && splits <= inner / 8, "groupnorm_split_bwd: %d slices for inner = %d", splits, inner);
+  const dim3 grid(B * G, splits);
+  hipStream_t s = (hipStream_t)stream;
+  const int want = dadd != nullptr;
+  if (x_is_f32) {
+    hipLaunchKernelGGL((gn_split_bwd_stats_kernel<true>), grid, dim3(256), 0, s, (const bf16_t*)dy, x, add, gamma, beta, mean, rstd,
+                       workspace, C, G, inner, silu, affine_batch_stride, splits);
+    hipLaunchKernelGGL((gn_split_bwd_apply_kernel<true>), grid, dim3(256), 0, s, (const bf16_t*)dy, x, add, gamma, beta, mean, rstd,
+                       workspace, (bf16_t*)dx, dgamma_part, dbeta_part, want, C, G, inner, silu, affine_batch_stride, splits);
+  } else {
+    hipLaunchKernelGGL((gn_split_bwd_stats_kernel<false>), grid, dim3(256), 0, s, (const bf16_t*)dy, x, add, gamma, beta, mean, rstd,
+                       workspace, C, G, inner, silu, affine_batch_stride, splits);
+    hipLaunchKernelGGL((gn_split_bwd_apply_kernel<false>), grid, dim3(256), 0, s, (const bf16_t*)dy, x, add, gamma, beta, mean, rstd,
+                       workspace, (bf16_t*)dx, dgamma_part, dbeta_part, want, C, G, inner, silu, affine_batch_stride, splits);
+  }
+  if (want) hipLaunchKernelGGL(gn_split_dadd_kernel, dim3(B * G), dim3(128), 0, s, workspace, dadd, C, G, splits);
+  CFHIP_CHECK_LAUNCH("groupnorm_split_bwd");
   return CFHIP_OK;
 }
 

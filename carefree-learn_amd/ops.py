@@ -831,6 +831,19 @@ def _gn_affine_stride(gamma: Tensor, beta: Tensor, b: int, c: int) -> int:
     raise ValueError(f"cfhip groupnorm: gamma must be [C] or [B, C], got {tuple(gamma.shape)}")
 
 
+GN_TARGET_WORKGROUPS = 1024  # four 4-wave workgroups per CU; 0: never split (round-1/2 kernels only)
+GN_MIN_SLICE = 2048  # elements of `inner` per slice and channel below which splitting further stops paying
+
+
+def gn_splits(b: int, c: int, groups: int, inner: int) -> int:
+    """Slices per (sample, group) of the split GroupNorm kernels: enough workgroups to fill the chip when B * G alone does
+    not (batch 1 at 256^2: 32 workgroups on 256 CUs), never slices shorter than GN_MIN_SLICE elements per channel."""
+    if GN_TARGET_WORKGROUPS <= 0 or inner % 8 != 0:
+        return 1
+    want = -(-GN_TARGET_WORKGROUPS // (b * groups))
+    return max(1, min(64, want, inner // GN_MIN_SLICE))
+
+
 def groupnorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, *, add: Optional[Tensor] = None,
                   silu: bool = False):
     """x [B, C, ...] f32 / bf16 -> (y bf16, mean f32 [B*G], rstd f32 [B*G]); y = [SiLU](GN(x + add[b, c])).
@@ -849,6 +862,14 @@ def groupnorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: floa
     y = torch.empty(x.shape, dtype=bf16, device=x.device)
     mean = torch.empty((b * groups,), dtype=f32, device=x.device)
     rstd = torch.empty((b * groups,), dtype=f32, device=x.device)
+    splits = gn_splits(b, c, groups, inner)
+    if splits > 1 and x.data_ptr() % 16 == 0:
+        ws = torch.empty((b * groups * splits * 2,), dtype=f32, device=x.device)
+        rc = _lib.load().cfhip_groupnorm_split_fwd(x.data_ptr(), int(x.dtype == f32), _p(add), gamma.data_ptr(), beta.data_ptr(),
+                                                   y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), b, c, groups, inner, float(eps),
+                                                   int(silu), affine_bs, splits, ws.data_ptr(), _stream())
+        _lib.check(rc, "groupnorm_split_fwd")
+        return y, mean, rstd
     rc = _lib.load().cfhip_groupnorm_affine_fwd(x.data_ptr(), int(x.dtype == f32), _p(add), gamma.data_ptr(),
                                                 beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), b, c,
                                                 groups, inner, float(eps), int(silu), affine_bs, _stream())
@@ -870,6 +891,17 @@ def groupnorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, beta: Tensor, mean: Tens
     dg_part = torch.empty((b, c), dtype=f32, device=x.device)
     db_part = torch.empty((b, c), dtype=f32, device=x.device)
     dadd = torch.empty((b, c), dtype=f32, device=x.device) if add is not None else None
+    splits = gn_splits(b, c, groups, inner)
+    if splits > 1 and c // groups <= 128 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0:
+        ws = torch.empty((b * groups * splits * 3 * (c // groups),), dtype=f32, device=x.device)
+        rc = _lib.load().cfhip_groupnorm_split_bwd(dy.data_ptr(), x.data_ptr(), int(x.dtype == f32), _p(add), gamma.data_ptr(),
+                                                   beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                                   dg_part.data_ptr(), db_part.data_ptr(), _p(dadd), b, c, groups, inner,
+                                                   int(silu), affine_bs, splits, ws.data_ptr(), _stream())
+        _lib.check(rc, "groupnorm_split_bwd")
+        if affine_bs:
+            return dx, dg_part, db_part, dadd
+        return dx, colreduce_f32(dg_part), colreduce_f32(db_part), dadd
     rc = _lib.load().cfhip_groupnorm_affine_bwd(dy.data_ptr(), x.data_ptr(), int(x.dtype == f32), _p(add),
                                                 gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                 dx.data_ptr(), dg_part.data_ptr(), db_part.data_ptr(), _p(dadd), b, c,

@@ -395,6 +395,18 @@ int cfhip_groupnorm_affine_bwd(const void* dy, const void* x, int x_is_f32, cons
                                const float* beta, const float* mean, const float* rstd, void* dx,
                                float* dgamma_part, float* dbeta_part, float* dadd, int B, int C, int G, int inner,
                                int silu, int affine_batch_stride, void* stream);
+/* the same arithmetic with every (sample, group) cut into `splits` (1 .. 64, <= inner / 8) slices along `inner`, one
+ * workgroup each — for few samples (B * G workgroups do not fill 256 CUs: the batch-1 256^2 UNet step).  inner % 8 == 0,
+ * 16-byte aligned tensors, <= 128 channels per group.  Statistics: per-slice (mean, M2) merged in slice order (Chan's
+ * update), so results do not depend on scheduling.  workspace: f32, B * G * splits * 2 (fwd) / B * G * splits * 3 * (C / G)
+ * (bwd) elements, owned by the caller. */
+int cfhip_groupnorm_split_fwd(const void* x, int x_is_f32, const float* add, const float* gamma, const float* beta,
+                              void* y, float* mean, float* rstd, int B, int C, int G, int inner, float eps, int silu,
+                              int affine_batch_stride, int splits, float* workspace, void* stream);
+int cfhip_groupnorm_split_bwd(const void* dy, const void* x, int x_is_f32, const float* add, const float* gamma,
+                              const float* beta, const float* mean, const float* rstd, void* dx, float* dgamma_part,
+                              float* dbeta_part, float* dadd, int B, int C, int G, int inner, int silu,
+                              int affine_batch_stride, int splits, float* workspace, void* stream);
 int cfhip_silu_f32_fwd(const float* x, float* y, int64_t n, void* stream);
 int cfhip_silu_f32_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
 int cfhip_upsample2_fwd(const void* x, void* y, int64_t BC, int H, int W, void* stream);

@@ -46,6 +46,52 @@ def test_groupnorm_kernel(silu, with_add):
         assert_close(ag.grad, ar.grad, 8e-3, "groupnorm dadd")  # sums of the bf16-rounded dx
 
 
+@pytest.mark.parametrize("b,c,h,w,dtype,per_sample", [(1, 320, 64, 64, torch.bfloat16, False), (2, 64, 40, 72, torch.float32, False),
+                                                      (1, 640, 32, 48, torch.bfloat16, True), (3, 2560, 16, 16, torch.bfloat16, False)])
+def test_groupnorm_split_form(b, c, h, w, dtype, per_sample):
+    """Round 3: few samples -> every (sample, group) is cut into slices, one workgroup each (ops.gn_splits); ragged slice
+    bounds (inner / 8 not a multiple of the slice count), f32 and bf16 inputs, SiLU + additive term, the per-sample affine
+    of the scale-shift block.  Against the oracle (fp32 CPU) and against the one-workgroup kernels on the same inputs."""
+    import unet_oracle as UO
+
+    torch.manual_seed(b * c + h)
+    x = bf16_round(torch.randn(b, c, h, w) * 1.5 + 2.0)  # mean >> 0: a sum-of-squares formula would cancel
+    add = torch.randn(b, c) * 0.5
+    gamma = torch.randn(b, c) * 0.3 + 1.0 if per_sample else torch.randn(c) * 0.3 + 1.0
+    beta = torch.randn(b, c) * 0.3 if per_sample else torch.randn(c) * 0.3
+    gy = bf16_round(torch.randn(b, c, h, w))
+    xd, ad, gd, bd, gyd = x.to(DEV).to(dtype), add.to(DEV), gamma.to(DEV), beta.to(DEV), gy.to(DEV).bfloat16()
+    keep = ops.GN_TARGET_WORKGROUPS, ops.GN_MIN_SLICE
+    try:
+        res = {}
+        for name, (target, floor) in (("split", (1000, 64)), ("one workgroup", (0, 64))):
+            ops.GN_TARGET_WORKGROUPS, ops.GN_MIN_SLICE = target, floor
+            assert (ops.gn_splits(b, c, 32, h * w) > 1) == (name == "split")
+            y, mean, rstd = ops.groupnorm_fwd(xd, gd, bd, 32, 1e-6, add=ad, silu=True)
+            dx, dg, db, dadd = ops.groupnorm_bwd(gyd, xd, gd, bd, mean, rstd, 32, add=ad, silu=True)
+            torch.cuda.synchronize()
+            res[name] = (y, mean, rstd, dx, dg, db, dadd)
+        for what, a, r, tol in zip(("y", "mean", "rstd", "dx", "dgamma", "dbeta", "dadd"), res["split"], res["one workgroup"],
+                                   (4e-3, 1e-5, 1e-5, 8e-3, 2e-4, 2e-4, 2e-3)):
+            assert_close(a, r, tol, f"split vs one-workgroup {what}", abs_floor=1e-6)
+    finally:
+        ops.GN_TARGET_WORKGROUPS, ops.GN_MIN_SLICE = keep
+    xr, ar = x.clone().requires_grad_(True), add.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    if per_sample:
+        n = torch.nn.functional.group_norm(xr + ar[:, :, None, None], 32, None, None, 1e-6)
+        want = UO.silu(n * gr[:, :, None, None] + br[:, :, None, None])
+    else:
+        want = UO.silu(UO.group_norm(xr + ar[:, :, None, None], gr, br, 32, 1e-6))
+    want.backward(gy)
+    y, _, _, dx, dg, db, dadd = res["split"]
+    assert_close(y, want, 4e-3, "split groupnorm y")
+    assert_close(dx, xr.grad, 8e-3, "split groupnorm dx")
+    assert_close(dg, gr.grad, 5e-3, "split groupnorm dgamma")
+    assert_close(db, br.grad, 5e-3, "split groupnorm dbeta")
+    assert_close(dadd, ar.grad, 8e-3, "split groupnorm dadd")
+
+
 def test_resample_silu_timestep_embedding(golden):
     import unet_oracle as UO
 
