@@ -652,7 +652,10 @@ struct Gen {
   static constexpr int NSLOT = 1;
 };
 
-// one 64-column half of `rows_pad` rows -> swizzled [rows][64] tile; columns >= dh and rows >= rows_valid are zero
+// one 64-column half of `rows_pad` rows -> swizzled [rows][64] tile; columns >= dh and rows >= rows_valid are zero.
+// SKIP_PAD: the lanes whose 16-byte chunk lies beyond dh are switched off (EXEC) instead of fetching zeros, so the DMA never
+// writes the pad columns of the tile: whatever the kernel put there once (zeros; attn_fwd2_kernel's column of ones) stays.
+template <bool SKIP_PAD = false>
 __device__ __forceinline__ void dma_half(char* tile, const bf16_t* base, long stride_t, int rows_valid, int rows_pad,
                                          int half, int dh, int wave, int nwaves, int lane) {
   long bytes = ((long)(rows_valid - 1) * stride_t + dh) * 2;
@@ -665,15 +668,19 @@ __device__ __forceinline__ void dma_half(char* tile, const bf16_t* base, long st
     const int chunk = slot ^ swz(row);
     const bool ok = row < rows_valid && half * 64 + chunk * 8 < dh;
     const unsigned off = ok ? (unsigned)(row * stride_t * 2 + half * 128 + chunk * 16) : 0x80000000u;
-    lds_dma16(rsrc, tile + inst * 1024, off);
+    if (SKIP_PAD) {
+      if (half * 64 + chunk * 8 < dh) lds_dma16(rsrc, tile + inst * 1024, off);  // (rows beyond rows_valid still fetch zeros)
+    } else {
+      lds_dma16(rsrc, tile + inst * 1024, off);
+    }
   }
 }
-template <int NH>
+template <int NH, bool SKIP_PAD = false>
 __device__ __forceinline__ void dma_oper(char* tiles, const bf16_t* base, long stride_t, int rows_valid, int dh,
                                          int wave, int nwaves, int lane) {
 #pragma unroll
   for (int hf = 0; hf < NH; ++hf)
-    dma_half(tiles + hf * Gen<NH>::HALF_BYTES, base, stride_t, rows_valid, Gen<NH>::CH, hf, dh, wave, nwaves, lane);
+    dma_half<SKIP_PAD>(tiles + hf * Gen<NH>::HALF_BYTES, base, stride_t, rows_valid, Gen<NH>::CH, hf, dh, wave, nwaves, lane);
 }
 
 // row-operand fragment ks (32 columns) of the wave's own 16 rows straight from global memory, zero beyond dh
@@ -1111,7 +1118,14 @@ constexpr int A2_ROWS = 256;   // rows of the walking operand per workgroup (8 w
 constexpr int A2_CH = 256;     // rows of the staged operand per chunk (64 KB: K + V, or Q + dO)
 constexpr int A2_TILE = A2_CH * 128;
 
-template <bool PLAIN, int NDT>
+// SUMCOL (head_dim = 8 mod 16, e.g. the UNet's 40: the last column tile has free columns): the softmax row sum comes out of
+// the matrix pipe.  Column dh of the staged V tile is a column of ONES (written once: the chunk DMAs skip the pad columns,
+// dma_half<SKIP_PAD>), so O[:, dh] = sum_j p_ij accumulates — and is rescaled by alpha — with the output it normalises,
+// and the 32 adds per 64-key block (16 v_pk_add_f32 per wave in a VALU-bound loop: 163 VALU per 28 MFMAs) disappear.  The sum
+// is then that of the bf16-rounded probabilities, i.e. of exactly what multiplied V.
+// Both forms skip the rescale of O when no row of the wave raised its running maximum in this block (alpha == 1 for all 32
+// rows — the common case after the first few blocks of a long sequence): a wave-uniform branch around 12-16 v_pk_mul_f32.
+template <bool PLAIN, int NDT, bool SUMCOL = false>
 __global__ __launch_bounds__(512, 4) void attn_fwd2_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
@@ -1121,6 +1135,17 @@ __global__ __launch_bounds__(512, 4) void attn_fwd2_kernel(AttnParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int dh = p.dh;
+  if (SUMCOL) {
+    // pad chunks of both tiles, once: zeros, and 1.0 in column dh of V (dh % 16 == 8: element 0 of its 16-byte chunk)
+    for (int idx = threadIdx.x; idx < A2_CH * 8; idx += 512) {
+      const int row = idx >> 3, chunk = idx & 7;
+      if (chunk * 8 >= dh) {
+        const int off = row * 128 + ((chunk ^ swz(row)) << 4);
+        *reinterpret_cast<u32x4*>(Ks + off) = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(Vs + off) = u32x4{chunk * 8 == dh ? 0x3F80u : 0u, 0u, 0u, 0u};
+      }
+    }
+  }
   const bf16_t* kb = p.k + (long)b * p.kv_sb + h * dh;
   const bf16_t* vb = p.v + (long)b * p.kv_sb + h * dh;
   const bf16_t* qb = p.q + (long)b * p.q_sb + h * dh;
@@ -1145,8 +1170,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd2_kernel(AttnParams p) {
     {
       int ln = lane;  // opaque copy: the per-lane DMA offsets are recomputed per chunk instead of hoisted and spilled
       asm volatile("" : "+v"(ln));
-      dma_oper<1>(Ks, kb + (long)kv0 * p.kv_st, p.kv_st, rows, dh, wave, 8, ln);
-      dma_oper<1>(Vs, vb + (long)kv0 * p.kv_st, p.kv_st, rows, dh, wave, 8, ln);
+      dma_oper<1, SUMCOL>(Ks, kb + (long)kv0 * p.kv_st, p.kv_st, rows, dh, wave, 8, ln);
+      dma_oper<1, SUMCOL>(Vs, vb + (long)kv0 * p.kv_st, p.kv_st, rows, dh, wave, 8, ln);
     }
     lds_dma_wait_all();
     __syncthreads();
@@ -1187,6 +1212,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd2_kernel(AttnParams p) {
             for (int r = 0; r < 4; ++r)
               st[t][jt][r] = jt * 16 + 4 * g + r < lim ? st[t][jt][r] : -INFINITY;
       }
+      float alpha[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int qi = row0 + 16 * t + i;
@@ -1207,7 +1233,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd2_kernel(AttnParams p) {
         const float m_new = fmaxf(m[t], mx);
         // rows whose every position so far is masked (m_new = -inf) must not produce NaN from (-inf) - (-inf): use 0
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m[t] - m_use);  // m = -inf on the first block: 0
+        alpha[t] = __builtin_amdgcn_exp2f(m[t] - m_use);  // m = -inf on the first block: 0; unchanged maximum: exactly 1
         float ls = 0.f;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
@@ -1215,13 +1241,17 @@ __global__ __launch_bounds__(512, 4) void attn_fwd2_kernel(AttnParams p) {
           for (int r = 0; r < 4; ++r) {
             const float e = __builtin_amdgcn_exp2f(fmaf(st[t][jt][r], sl2, -m_use));
             st[t][jt][r] = e;
-            ls += e;
+            if (!SUMCOL) ls += e;
           }
         }
-        l[t] = l[t] * alpha + ls;
+        if (!SUMCOL) l[t] = l[t] * alpha[t] + ls;
         m[t] = m_new;
+      }
+      if (__builtin_amdgcn_ballot_w64(alpha[0] != 1.f || alpha[1] != 1.f) != 0) {  // wave-uniform
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) ot[t][dt] *= alpha;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) ot[t][dt] *= alpha[t];
       }
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
@@ -1239,7 +1269,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd2_kernel(AttnParams p) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int qi = row0 + 16 * t + i;
-    const float lsum = group_sum(l[t]);
+    // SUMCOL: the row sum is column dh = (NDT - 1) * 16 + 8 of O: register 0 of the lanes with g = 2
+    const float lsum = SUMCOL ? __shfl(ot[t][NDT - 1][0], 32 + i) : group_sum(l[t]);
     if (active && qi < p.Tq) {
       const float inv = 1.0f / lsum;
       bf16_t* orow = p.o + (long)b * p.o_sb + (long)qi * p.o_st + h * dh;
@@ -1589,12 +1620,20 @@ int launch_gen_bwd_drop(const AttnParams& p, bool plain, int parts, hipStream_t 
 }
 
 int g_attn_short_max = CFHIP_ATTN_MAX_T;  // "attn_short_max" option: head_dim-64 sequences up to this length take the LDS-resident kernels
-int g_attn_two_tiles = 15;  // "attn_two_tiles" option (bits): 1 forward, 2 dQ pass (4: also head_dim > 48), 8 dK / dV pass of head_dim <= 64 on the two-tiles-per-wave kernels
+int g_attn_two_tiles = 31;  // "attn_two_tiles" option (bits): 1 forward, 2 dQ pass (4: also head_dim > 48), 8 dK / dV pass of head_dim <= 64 on the two-tiles-per-wave kernels; 16: forward row sums through the ones column when head_dim = 8 mod 16
 
+extern int g_attn_two_tiles;
 template <int NDT>
 int launch_fwd2(const AttnParams& p, bool plain, hipStream_t s) {
   dim3 grid((p.Tq + A2_ROWS - 1) / A2_ROWS, p.H, p.B);
   const size_t lds = (size_t)2 * A2_TILE;
+  if (plain && p.dh == (NDT - 1) * 16 + 8 && (g_attn_two_tiles & 16)) {  // a free column in the last tile: row sums by MFMA
+    const int rc = set_lds(attn_fwd2_kernel<true, NDT, true>, lds, "attn_fwd");
+    if (rc != CFHIP_OK) return rc;
+    hipLaunchKernelGGL((attn_fwd2_kernel<true, NDT, true>), grid, dim3(512), lds, s, p);
+    CFHIP_CHECK_LAUNCH("attn_fwd2");
+    return CFHIP_OK;
+  }
   int rc = plain ? set_lds(attn_fwd2_kernel<true, NDT>, lds, "attn_fwd") : set_lds(attn_fwd2_kernel<false, NDT>, lds, "attn_fwd");
   if (rc != CFHIP_OK) return rc;
   if (plain) hipLaunchKernelGGL((attn_fwd2_kernel<true, NDT>), grid, dim3(512), lds, s, p);
