@@ -1405,12 +1405,17 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq2_kernel(AttnParams p) {
 constexpr int A2D_CH = 128;
 constexpr int A2D_TILE = A2D_CH * 128;
 
+// NDT = 5 / 6 (head_dim 72 .. 96, the UNet's 80-channel heads; round 3b): the same loop over KS = 3 reduction steps and two
+// 64-column halves of the staged operands (66 KB of LDS, ~215 registers: two workgroups per CU) — the general one-tile kernel
+// ran this head_dim at 342 TFLOP/s against 800 for head_dim 40 here.
 template <bool PLAIN, int NDT>
 __global__ __launch_bounds__(256, NDT == 3 ? 3 : 2) void attn_bwd_dkv2_kernel(AttnParams p) {
+  constexpr int KS = (NDT + 1) / 2;     // 32-deep steps of the reductions over head_dim
+  constexpr int NHALF = (NDT + 3) / 4;  // 64-column halves of a staged operand
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
-  char* dOs = smem + A2D_TILE;
-  float* lse_s = reinterpret_cast<float*>(smem + 2 * A2D_TILE);
+  char* dOs = smem + NHALF * A2D_TILE;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * NHALF * A2D_TILE);
   float* delta_s = lse_s + A2D_CH;
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63;
@@ -1421,11 +1426,11 @@ __global__ __launch_bounds__(256, NDT == 3 ? 3 : 2) void attn_bwd_dkv2_kernel(At
   const bool active = row0 < p.Tk;
   const bf16_t* kb = p.k + (long)b * p.kv_sb + h * dh;
   const bf16_t* vb = p.v + (long)b * p.kv_sb + h * dh;
-  bf16x8 kf[2][2], vf[2][2];
+  bf16x8 kf[2][KS], vf[2][KS];
 #pragma unroll
   for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       kf[u][ks] = frag_global_dh(kb, p.kv_st, row0 + 16 * u, active ? p.Tk : 0, ks, lane, dh);
       vf[u][ks] = frag_global_dh(vb, p.kv_st, row0 + 16 * u, active ? p.Tk : 0, ks, lane, dh);
     }
@@ -1442,8 +1447,11 @@ __global__ __launch_bounds__(256, NDT == 3 ? 3 : 2) void attn_bwd_dkv2_kernel(At
     {
       int ln = lane;  // opaque copy: see attn_fwd2_kernel
       asm volatile("" : "+v"(ln));
-      dma_half(Qs, p.q + (long)b * p.q_sb + (long)q0 * p.q_st + h * dh, p.q_st, rows, A2D_CH, 0, dh, wave, 4, ln);
-      dma_half(dOs, p.d_o + (long)b * p.o_sb + (long)q0 * p.o_st + h * dh, p.o_st, rows, A2D_CH, 0, dh, wave, 4, ln);
+#pragma unroll
+      for (int hf = 0; hf < NHALF; ++hf) {
+        dma_half(Qs + hf * A2D_TILE, p.q + (long)b * p.q_sb + (long)q0 * p.q_st + h * dh, p.q_st, rows, A2D_CH, hf, dh, wave, 4, ln);
+        dma_half(dOs + hf * A2D_TILE, p.d_o + (long)b * p.o_sb + (long)q0 * p.o_st + h * dh, p.o_st, rows, A2D_CH, hf, dh, wave, 4, ln);
+      }
     }
     if ((int)threadIdx.x < A2D_CH) {  // thread t owns the statistics of row t of the chunk
       const int tq = q0 + (int)threadIdx.x;
@@ -1462,17 +1470,22 @@ __global__ __launch_bounds__(256, NDT == 3 ? 3 : 2) void attn_bwd_dkv2_kernel(At
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int r16 = a * 32 + it * 16;
-        const bf16x8 qf0 = frag_rows(Qs, r16, 0, lane), qf1 = frag_rows(Qs, r16, 1, lane);
-        const bf16x8 of0 = frag_rows(dOs, r16, 0, lane), of1 = frag_rows(dOs, r16, 1, lane);
+        bf16x8 qf[KS], of[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          qf[ks] = frag_rows(Qs + (ks >> 1) * A2D_TILE, r16, ks & 1, lane);
+          of[ks] = frag_rows(dOs + (ks >> 1) * A2D_TILE, r16, ks & 1, lane);
+        }
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + r16 + 4 * g);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + r16 + 4 * g);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf0, kf[u][0], sc, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of0, vf[u][0], dp, 0, 0, 0);
-          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf1, kf[u][1], sc, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of1, vf[u][1], dp, 0, 0, 0);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf[u][ks], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of[ks], vf[u][ks], dp, 0, 0, 0);
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float pr = __builtin_amdgcn_exp2f(fmaf(sc[r], sl2, -l4[r]));
@@ -1489,10 +1502,10 @@ __global__ __launch_bounds__(256, NDT == 3 ? 3 : 2) void attn_bwd_dkv2_kernel(At
       const bf16x8 dsk0 = pack8(ds[0][0], ds[0][1]), dsk1 = pack8(ds[1][0], ds[1][1]);
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        const bf16x8 oc = frag_cols(dOs, a * 32, dt * 16, lane);
+        const bf16x8 oc = frag_cols(dOs + (dt >> 2) * A2D_TILE, a * 32, (dt & 3) * 16, lane);
         dvt[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oc, ppk0, dvt[0][dt], 0, 0, 0);
         dvt[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oc, ppk1, dvt[1][dt], 0, 0, 0);
-        const bf16x8 qc = frag_cols(Qs, a * 32, dt * 16, lane);
+        const bf16x8 qc = frag_cols(Qs + (dt >> 2) * A2D_TILE, a * 32, (dt & 3) * 16, lane);
         dkt[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qc, dsk0, dkt[0][dt], 0, 0, 0);
         dkt[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qc, dsk1, dkt[1][dt], 0, 0, 0);
       }
@@ -1620,7 +1633,7 @@ int launch_gen_bwd_drop(const AttnParams& p, bool plain, int parts, hipStream_t 
 }
 
 int g_attn_short_max = CFHIP_ATTN_MAX_T;  // "attn_short_max" option: head_dim-64 sequences up to this length take the LDS-resident kernels
-int g_attn_two_tiles = 31;  // "attn_two_tiles" option (bits): 1 forward, 2 dQ pass (4: also head_dim > 48), 8 dK / dV pass of head_dim <= 64 on the two-tiles-per-wave kernels; 16: forward row sums through the ones column when head_dim = 8 mod 16
+int g_attn_two_tiles = 63;  // "attn_two_tiles" option (bits): 1 forward, 2 dQ pass (4: also head_dim > 48), 8 dK / dV pass of head_dim <= 64 on the two-tiles-per-wave kernels; 16: forward row sums through the ones column when head_dim = 8 mod 16; 32: dK / dV pass of head_dim 72 .. 96 on the two-tile kernel
 
 extern int g_attn_two_tiles;
 template <int NDT>
@@ -1670,7 +1683,11 @@ int launch_dq2(const AttnParams& p, bool plain, hipStream_t s) {
 template <int NDT>
 int launch_dkv2(const AttnParams& p, bool plain, hipStream_t s) {
   dim3 grid((p.Tk + 127) / 128, p.H, p.B);
-  const size_t lds = (size_t)2 * A2D_TILE + (size_t)2 * A2D_CH * sizeof(float);
+  const size_t lds = (size_t)2 * ((NDT + 3) / 4) * A2D_TILE + (size_t)2 * A2D_CH * sizeof(float);
+  if (lds > 64 * 1024) {
+    const int rc = plain ? set_lds(attn_bwd_dkv2_kernel<true, NDT>, lds, "attn_bwd_dkv") : set_lds(attn_bwd_dkv2_kernel<false, NDT>, lds, "attn_bwd_dkv");
+    if (rc != CFHIP_OK) return rc;
+  }
   if (plain) hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true, NDT>), grid, dim3(256), lds, s, p);
   else hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false, NDT>), grid, dim3(256), lds, s, p);
   CFHIP_CHECK_LAUNCH("attn_bwd_dkv2");
@@ -1692,13 +1709,14 @@ int launch_gen_bwd(const AttnParams& p, bool plain, int parts, hipStream_t s) {
     else hipLaunchKernelGGL((attn_gen_bwd_dq_kernel<NH, false>), grid, dim3(512), lds, s, p);
     CFHIP_CHECK_LAUNCH("attn_gen_bwd_dq");
   }
-  if ((parts & 2) && NH == 1 && (g_attn_two_tiles & 8)) {
-    if (!(parts & 1)) {  // no dQ pass in front of this one: fill delta
+  if ((parts & 2) && (g_attn_two_tiles & 8) && (NH == 1 || (NH == 2 && p.dh <= 96 && (g_attn_two_tiles & 32)))) {
+    if (!(parts & 1) || (NH == 2 && !p.delta_ready)) {  // no (delta-writing) dQ pass in front of this one: fill delta
       const long rows = (long)p.B * p.H * p.Tq;
       hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 255) / 256 > 4096 ? 4096 : (rows + 255) / 256)), dim3(256), 0, s, p);
       CFHIP_CHECK_LAUNCH("attn_delta");
     }
-    const int rc = p.dh <= 48 ? launch_dkv2<3>(p, plain, s) : launch_dkv2<4>(p, plain, s);
+    const int rc = p.dh <= 48 ? launch_dkv2<3>(p, plain, s) : p.dh <= 64 ? launch_dkv2<4>(p, plain, s)
+                 : p.dh <= 80 ? launch_dkv2<5>(p, plain, s) : launch_dkv2<6>(p, plain, s);
     if (rc != CFHIP_OK) return rc;
   } else if (parts & 2) {
     if (Gen<NH>::NSLOT == 2 && !p.delta_ready && !(parts & 1)) {

@@ -185,7 +185,8 @@ def _oracle_dh(q, k, v, h, dh, d_o, keep=None):
 
 
 @pytest.mark.parametrize("dh,tq,tk,h", [(40, 64, 64, 8), (40, 300, 77, 2), (80, 256, 256, 3), (160, 64, 64, 2),
-                                         (160, 130, 300, 1), (64, 100, 77, 2), (8, 20, 33, 2), (96, 17, 17, 2)])
+                                         (160, 130, 300, 1), (64, 100, 77, 2), (8, 20, 33, 2), (96, 17, 17, 2),
+                                         (72, 200, 333, 2), (88, 150, 260, 1), (56, 90, 200, 2)])
 def test_general_head_dims(dh, tq, tk, h):
     """head_dim != 64 (the UNet's 40 / 80 / 160-channel heads) and Tq != Tk (cross attention over a context)"""
     g = torch.Generator().manual_seed(dh * 1000 + tq)
