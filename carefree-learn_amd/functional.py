@@ -90,6 +90,56 @@ def distinct_stream(others: List["torch.cuda.Stream"], tries: int = 12) -> "torc
     return first
 
 
+# torch.cuda.current_stream() / torch.cuda.stream(...) walk four Python layers per call (9 / ~20 us); the side-stream
+# plumbing below runs ~600 times per UNet step, on the thread that issues every launch.  Same torch entry points, called
+# directly (tools/host_profile.py: 14 ms of 65 ms host time per step).
+_get_cur = getattr(torch._C, "_cuda_getCurrentStream", None)
+_set_cur = getattr(torch._C, "_cuda_setStream", None)
+_get_dev = getattr(torch._C, "_cuda_getDevice", None)
+_FAST_STREAMS = _get_cur is not None and _set_cur is not None and _get_dev is not None
+_cuda_ok: Optional[bool] = None
+
+
+def cuda_ok() -> bool:
+    global _cuda_ok
+    if _cuda_ok is None:
+        _cuda_ok = torch.cuda.is_available()
+    return _cuda_ok
+
+
+def cur_stream() -> "torch.cuda.Stream":
+    """torch.cuda.current_stream() of the current device"""
+    if _FAST_STREAMS:
+        sid, idx, typ = _get_cur(_get_dev())
+        return torch.cuda.Stream(stream_id=sid, device_index=idx, device_type=typ)
+    return torch.cuda.current_stream()
+
+
+class on_stream:
+    """`with torch.cuda.stream(side)` without the Python layers (same allocator semantics: tensors created inside belong
+    to `side`)."""
+
+    __slots__ = ("side", "prev")
+
+    def __init__(self, side: "torch.cuda.Stream") -> None:
+        self.side = side
+        self.prev = None
+
+    def __enter__(self) -> None:
+        if _FAST_STREAMS:
+            self.prev = _get_cur(_get_dev())
+            _set_cur(stream_id=self.side.stream_id, device_index=self.side.device_index, device_type=self.side.device_type)
+        else:
+            self.prev = torch.cuda.current_stream()
+            torch.cuda.set_stream(self.side)
+
+    def __exit__(self, *exc: Any) -> None:
+        if _FAST_STREAMS:
+            _set_cur(stream_id=self.prev[0], device_index=self.prev[1], device_type=self.prev[2])
+        else:
+            torch.cuda.set_stream(self.prev)
+
+
 class SideStream:
     enabled = True
     lanes = 3  # side streams (0: weight-gradient launches, second forward slice; 1, 2: further batch slices of the forward / backward)
@@ -124,9 +174,9 @@ class SideStream:
             wait: Tuple["torch.cuda.Stream", ...] = ()) -> None:
         """`fn` on the side stream of `lane`, ordered after the current stream and after every stream in `wait`
         (operands written by other streams, e.g. the second batch slice of the backward pass)."""
-        if not cls.enabled or not torch.cuda.is_available() or (lane == 0 and not cls.heavy):
+        if not cls.enabled or not cuda_ok() or (lane == 0 and not cls.heavy):
             for st in wait:
-                torch.cuda.current_stream().wait_stream(st)
+                cur_stream().wait_stream(st)
             fn()
             return
         if not cls._join_queued:
@@ -137,25 +187,25 @@ class SideStream:
                 cls._join_queued = True
             except RuntimeError:  # not inside a backward pass: stay on the current stream
                 for st in wait:
-                    torch.cuda.current_stream().wait_stream(st)
+                    cur_stream().wait_stream(st)
                 fn()
                 return
         side = cls.get(lane)
-        side.wait_stream(torch.cuda.current_stream())  # everything issued so far is visible
+        side.wait_stream(cur_stream())  # everything issued so far is visible
         for st in wait:
             if st is not side:
                 side.wait_stream(st)
-        with torch.cuda.stream(side):
+        with on_stream(side):
             fn()
         cls.keep.extend(keep)
 
     @classmethod
     def fork(cls, lane: int = 0) -> Optional["torch.cuda.Stream"]:
         """A side stream that has waited for the current stream (for work the caller joins itself)."""
-        if not cls.enabled or not torch.cuda.is_available():
+        if not cls.enabled or not cuda_ok():
             return None
         side = cls.get(lane)
-        side.wait_stream(torch.cuda.current_stream())
+        side.wait_stream(cur_stream())
         return side
 
     @classmethod
@@ -163,7 +213,7 @@ class SideStream:
         """Make the current stream wait for the side stream (call before consuming parameter grads)."""
         for side in cls.streams:
             if side is not None:
-                torch.cuda.current_stream().wait_stream(side)
+                cur_stream().wait_stream(side)
         cls.keep.clear()
 
 

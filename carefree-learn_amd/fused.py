@@ -190,7 +190,7 @@ def _flush_dw(wait: tuple = ()) -> None:
 
     if DW_GROUP_ON_MAIN:
         for st in wait:
-            torch.cuda.current_stream().wait_stream(st)
+            _functional.cur_stream().wait_stream(st)
         launch()
     else:
         SideStream.run(launch, tuple(t for it in items for t in (it[2], it[3])), wait=wait)
@@ -288,7 +288,7 @@ def _block_fwd(x2: Tensor, prm: tuple, num_heads: int, eps1: float, eps2: float,
         n = len(streams)
         cuts = [bsz * i // n for i in range(n + 1)]
         for i, st in enumerate(streams):
-            with torch.cuda.stream(st):
+            with _functional.on_stream(st):
                 run(cuts[i], cuts[i + 1])
     saved = (x2, mean1, rstd1, ln1, qkv, o2, lse, x1, mean2, rstd2, ln2, pre, h, in_w16, out_w16, w1_16, w2_16)
     return y, saved
@@ -333,7 +333,7 @@ def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_
         nb = b1_ - b0
         last = i == nsl - 1
         km = None if keep_mask is None else keep_mask[b0:b1_] if keep_mask.shape[0] == bsz else keep_mask
-        cur = torch.cuda.current_stream() if d2.is_cuda else None
+        cur = _functional.cur_stream() if d2.is_cuda else None
 
         def ln(which: int, dy_, x_, w_, b_, mean_, rstd_, add_, out_) -> None:
             if ln_done[which] is not None:
@@ -362,7 +362,7 @@ def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_
         run(0)
     else:
         for i, st in enumerate(streams):
-            with torch.cuda.stream(st):
+            with _functional.on_stream(st):
                 run(i)
     # parameter gradients: queued for the grouped launch (or issued on the side stream — round-1/2 path); whoever
     # launches them waits for every slice stream
@@ -433,7 +433,7 @@ class MixingStackFn(Function):
                     shadow_bf16(params[12 * i + j])
             # slice 0 stays on the caller's stream, the others take side streams that have waited for it; every slice
             # is an independent pipeline through all blocks, joined once at the end of the stack
-            main = torch.cuda.current_stream()
+            main = _functional.cur_stream()
             streams = [main] + [SideStream.fork(lane) for lane in range(FWD_HALVES - 1)]
             if any(st is None for st in streams):
                 streams = None
@@ -445,7 +445,7 @@ class MixingStackFn(Function):
             all_saved.extend(saved)
         if streams is not None:
             for st in streams[1:]:
-                torch.cuda.current_stream().wait_stream(st)
+                _functional.cur_stream().wait_stream(st)
         ctx.save_for_backward(*all_saved, keep_mask)
         ctx.params = params
         ctx.meta = (bsz, t, d, metas, causal)
@@ -458,7 +458,7 @@ class MixingStackFn(Function):
         d2 = _as_bf16_rows(dy, bsz * t, d)
         streams = None
         if BWD_HALVES > 1 and d2.is_cuda and bsz >= 2 * BWD_HALVES:
-            main = torch.cuda.current_stream()
+            main = _functional.cur_stream()
             # lane 1, 2, ...: lane 0 is the stream of the weight-gradient launches
             streams = [main] + [SideStream.fork(lane + 1) for lane in range(BWD_HALVES - 1)]
             if any(st is None for st in streams) or len({id(st) for st in streams}) != len(streams) or SideStream.get(0) in streams[1:]:
@@ -479,7 +479,7 @@ class MixingStackFn(Function):
             _flush_dw(tuple(_slice_streams))
             if streams is not None:
                 for st in streams[1:]:
-                    torch.cuda.current_stream().wait_stream(st)
+                    _functional.cur_stream().wait_stream(st)
                 SideStream.keep.append(d2)  # written by both slice streams, allocated on the caller's
         finally:
             _slice_streams[:] = []

@@ -257,6 +257,36 @@ def test_q_sample_bit_exact_mse_and_ddpm_train_step(golden):
     ts.step(x, ctx)  # self-drawn t and eps
 
 
+def test_ddpm_train_step_as_a_hipgraph_matches_the_eager_step(golden):
+    """DDPMTrainStep(use_graph=True): the recorded step (side-stream branches, direct-to-.grad gradient kernels, fused Adam)
+    replayed with new inputs gives the losses of the eager step engine on the same sequence of batches."""
+    from cflearn_amd.diffusion import DDPMTrainStep, NoiseSchedule
+
+    u = golden("unet_small.pt")
+    x, ctx = u["x"].to(DEV), u["context"].to(DEV)
+    gen = torch.Generator().manual_seed(3)
+    batches = [(torch.randint(0, 1000, u["timesteps"].shape, generator=gen).to(DEV), torch.randn(u["noise"].shape, generator=gen).to(DEV))
+               for _ in range(6)]
+    losses = {}
+    for graph in (False, True):
+        m = C.build_module("unet_diffuser", config=dict(u["cfg"]))
+        m.load_state_dict(u["sd"])
+        ts = DDPMTrainStep(m.to(DEV), NoiseSchedule(device=DEV), lr=1e-3, use_graph=graph)
+        out = []
+        for t, eps in batches:
+            out.append(ts.step(x, ctx, timesteps=t, noise=eps).item())
+        losses[graph] = out
+    # the graph engine runs two extra warm-up steps on the FIRST batch before it records: compare the trend, and the
+    # eager engine given the same three first-batch steps exactly
+    m = C.build_module("unet_diffuser", config=dict(u["cfg"]))
+    m.load_state_dict(u["sd"])
+    ts = DDPMTrainStep(m.to(DEV), NoiseSchedule(device=DEV), lr=1e-3)
+    ref = [ts.step(x, ctx, timesteps=batches[0][0], noise=batches[0][1]).item() for _ in range(3)][-1:]
+    ref += [ts.step(x, ctx, timesteps=t, noise=eps).item() for t, eps in batches[1:]]
+    for a, b in zip(losses[True], ref):
+        assert abs(a - b) <= 2e-3 * abs(b) + 1e-5, (losses[True], ref)
+
+
 def test_gradient_checkpoint_matches_plain_backward(golden):
     """Row U6 (reference toolkit.py:2535-2647, switched on by `use_checkpoint=True` in the zoo diffusion/ddpm config):
     the block is recomputed inside backward, i.e. every HIP Function in it is entered a second time under a
