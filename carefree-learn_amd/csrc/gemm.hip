@@ -597,6 +597,13 @@ int pick_config(int M, int N, int a_trans, int b_trans) {
     // on their own stream; backward in two batch slices): 192x128x64 for every big forward AND dX GEMM — whole-step A/B
     // 19.06 -> 18.35 ms against table 6 (profiles/r03/step_variants_a.log)
     if (a_trans) return 1;
+    // round 3b, the UNet's shapes (tools/gemm_unet_sweep.py, profiles/r03/gemm_unet_sweep.log): 128x64x64 when 192x128 tiles
+    // would leave most CUs without a workgroup (2048 x 1280: 110 tiles, 18.8 -> 14.9 us) and for narrow outputs that 128
+    // columns do not divide (N = 320: 17.7 / 18.8 -> 15.4 / 13.7 us)
+    if (M >= 512) {
+      const long t14 = (long)((M + 191) / 192) * ((N + 127) / 128);
+      if (t14 < 160 || (N < 512 && N % 128 != 0 && N % 64 == 0)) return 3;
+    }
     if (M >= 1024) return 14;
     if (b_trans) return 1;
     return N <= 1024 ? 3 : 0;
