@@ -295,6 +295,26 @@ def write_param_grad(param: Tensor, compute: Callable[[Tensor, bool], None]) -> 
         cb(param)
 
 
+def write_param_grad_pair(a: Tensor, b: Tensor, compute: Callable[[Tensor, Tensor, bool], None]) -> bool:
+    """Two gradients that ONE kernel writes with one accumulate flag (LayerNorm's dgamma / dbeta): `compute(out_a, out_b,
+    accumulate)`.  False (nothing done) when one of the two has to be accumulated and the other written."""
+    def accumulates(prm: Tensor) -> bool:
+        return prm.grad is not None and not getattr(prm, "_cfhip_fresh", False)
+
+    acc = accumulates(a)
+    if acc != accumulates(b):
+        return False
+    for prm in (a, b):
+        if prm.grad is None:
+            prm.grad = grad_buffer(prm)
+    compute(a.grad, b.grad, acc)
+    for prm in (a, b):
+        prm._cfhip_fresh = False
+        for cb in grad_ready_callbacks:
+            cb(prm)
+    return True
+
+
 def _as_rows(x: Tensor) -> Tensor:
     """[..., D] -> 2-D view with a contiguous last dim, keeping f32 or bf16 as is."""
     x2 = x.reshape(-1, x.shape[-1])
@@ -453,10 +473,11 @@ class LayerNormFn(Function):
         dy2 = _as_bf16_2d(dy)
         wd, bd = _is_direct(weight), _is_direct(bias)
         gw = gb = None
-        if wd and bd and weight.grad is None and bias.grad is None:
-            dx, dg, db = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd)
-            write_param_grad(weight, lambda out, acc: out.copy_(dg.view(out.shape)))
-            write_param_grad(bias, lambda out, acc: out.copy_(db.view(out.shape)))
+        res: list = []
+        if wd and bd and write_param_grad_pair(
+                weight, bias, lambda ga, gb_, acc: res.append(ops.layernorm_bwd(
+                    dy2, x2, gamma, mean, rstd, dgamma=ga.view(-1), dbeta=gb_.view(-1), accumulate=acc)[0])):
+            dx = res[0]  # the kernel reduced dgamma / dbeta straight into `.grad` (round 1-2: two device copies per call)
         else:
             dx, dg, db = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd)
             if wd:
@@ -1084,11 +1105,20 @@ class GroupNormFn(Function):
         x, gamma, beta, mean, rstd, addc = ctx.saved_tensors
         if dy.dtype != bf16:
             dy = ops.to_bf16(dy.float().contiguous())
-        dx, dg, db, dadd = ops.groupnorm_bwd(dy, x, gamma, beta, mean, rstd, ctx.groups, add=addc, silu=ctx.silu)
+        per_sample = gamma.dim() == 2  # one affine per sample: dgamma / dbeta stay [B, C] (ScaleShiftAffineFn reduces them)
+        dx, dg, db, dadd = ops.groupnorm_bwd(dy, x, gamma, beta, mean, rstd, ctx.groups, add=addc, silu=ctx.silu,
+                                             reduce=per_sample)
         gw = gb = None
         for prm, g, which in ((ctx.weight, dg, 0), (ctx.bias, db, 1)):
             if not prm.requires_grad:
                 continue
+            if per_sample:
+                pass
+            elif _is_direct(prm):  # the [B, C] partial sums are reduced over B straight into `.grad`
+                write_param_grad(prm, lambda out, acc, g=g: ops.colreduce_f32(g, out=out.view(-1), accumulate=acc))
+                continue
+            else:
+                g = ops.colreduce_f32(g)
             if _is_direct(prm):
                 write_param_grad(prm, lambda out, acc, g=g: out.add_(g.view(out.shape)) if acc else out.copy_(g.view(out.shape)))
             elif which == 0:

@@ -63,9 +63,9 @@ def pick_split_k(m: int, n: int, k: int) -> int:
     """Split the reduction when the output has too few 128x128 tiles to fill 256 CUs."""
     tiles = ((m + 127) // 128) * ((n + 127) // 128)
     steps = (k + 63) // 64
-    if tiles >= 256 or steps < 8:
+    if tiles >= 256 or steps < 16:
         return 1
-    return max(1, min(steps // 4, (512 + tiles - 1) // tiles))
+    return max(1, min(steps // 4, (512 + tiles - 1) // tiles, 32))  # (deeper than 32: the reduce pass costs more than it fills)
 
 
 class GemmTimer:
@@ -887,9 +887,10 @@ def groupnorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: floa
 
 
 def groupnorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tensor, groups: int, *,
-                  add: Optional[Tensor] = None, silu: bool = False):
+                  add: Optional[Tensor] = None, silu: bool = False, reduce: bool = True):
     """Returns (dx bf16, dgamma, dbeta, dadd f32 [B, C] | None); dgamma / dbeta have the shape of gamma ([C], or [B, C]
-    for a per-sample affine)."""
+    for a per-sample affine).  reduce=False: the per-sample partial sums [B, C] are returned as they are (the caller
+    reduces them over B where they belong, e.g. `colreduce_f32(part, out=param.grad)`)."""
     _need(dy, bf16, "dy")
     if not dy.is_contiguous():
         dy = dy.contiguous()
@@ -908,7 +909,7 @@ def groupnorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, beta: Tensor, mean: Tens
                                                    dg_part.data_ptr(), db_part.data_ptr(), _p(dadd), b, c, groups, inner,
                                                    int(silu), affine_bs, splits, ws.data_ptr(), _stream())
         _lib.check(rc, "groupnorm_split_bwd")
-        if affine_bs:
+        if affine_bs or not reduce:
             return dx, dg_part, db_part, dadd
         return dx, colreduce_f32(dg_part), colreduce_f32(db_part), dadd
     rc = _lib.load().cfhip_groupnorm_affine_bwd(dy.data_ptr(), x.data_ptr(), int(x.dtype == f32), _p(add),
@@ -916,7 +917,7 @@ def groupnorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, beta: Tensor, mean: Tens
                                                 dx.data_ptr(), dg_part.data_ptr(), db_part.data_ptr(), _p(dadd), b, c,
                                                 groups, inner, int(silu), affine_bs, _stream())
     _lib.check(rc, "groupnorm_bwd")
-    if affine_bs:
+    if affine_bs or not reduce:
         return dx, dg_part, db_part, dadd
     return dx, colreduce_f32(dg_part), colreduce_f32(db_part), dadd
 
