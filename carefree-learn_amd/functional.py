@@ -760,7 +760,14 @@ class Conv2dFn(Function):
             ctx.save_for_backward(x_rows, w16)  # the NHWC bf16 copy serves the weight gradient; x itself is not kept
             ctx.xshape = (b, cin, h, w)
             return ops.transpose_batched(y_rows.view(b, h * w, cout)).view(b, cout, h, w)
-        rows = ops.conv_im2row(x, kh, kw, stride, pad, dil)
+        # 1x1 / stride 1 (the skip connections of the UNet's residual blocks): the im2row matrix IS the NHWC copy of x — one
+        # batched transpose instead of the gather kernel, kept for the weight gradient (the im2row route recomputes it), and
+        # dX comes back through a transpose instead of row2im (UNet 64^2 x 8: 38 im2row + 18 row2im launches, 3.7 ms)
+        ctx.pointwise = (kh, kw, stride, pad, dil) == (1, 1, 1, 0, 1) and cin % 8 == 0
+        if ctx.pointwise:
+            rows = ops.transpose_batched(x.view(b, cin, h * w)).view(b * h * w, cin)
+        else:
+            rows = ops.conv_im2row(x, kh, kw, stride, pad, dil)
         wp = _conv_weight_rows(weight, rows.shape[1])
         # Cout that is not a multiple of 8 (the 3-channel head of the UNet) would fall off the MFMA path onto the
         # one-thread-per-output kernel (3.6 ms per launch at 64^2 x 8): pad the output channels with zero filters
@@ -777,7 +784,7 @@ class Conv2dFn(Function):
         y = ops.transpose_batched(y_rows.view(b, ho * wo, cp)).view(b, cp, ho, wo)
         if cp != cout:
             y = y[:, :cout].contiguous()
-        ctx.save_for_backward(x, wp)
+        ctx.save_for_backward(rows if ctx.pointwise else x, wp)
         ctx.xshape = (b, cin, h, w)
         return y
 
@@ -816,7 +823,8 @@ class Conv2dFn(Function):
                     gw = torch.empty(weight.shape, dtype=f32, device=dy.device)
                     dw_implicit(gw, False)
             elif weight.requires_grad:
-                rows = ops.conv_im2row(x, kh, kw, stride, pad, dil)  # recomputed: k^2 times the input, not kept
+                # (im2row is recomputed: k^2 times the input, not kept; a 1x1 convolution saved its NHWC rows instead)
+                rows = x if getattr(ctx, "pointwise", False) else ops.conv_im2row(x, kh, kw, stride, pad, dil)
                 m = rows.shape[0]
                 kp = rows.shape[1]
                 split = ops.pick_split_k(cp, kp, m)
@@ -871,7 +879,10 @@ class Conv2dFn(Function):
             else:
                 w2 = wp.reshape(cout, k) if ctx.implicit else wp
                 drows = ops.gemm(dy_rows, w2, b_trans=True)  # [M, Kp] bf16
-                dx = ops.conv_row2im(drows, (b, cin, h, w), kh, kw, stride, pad, dil)
+                if getattr(ctx, "pointwise", False):
+                    dx = ops.transpose_batched(drows.view(b, h * w, cin)).view(b, cin, h, w)
+                else:
+                    dx = ops.conv_row2im(drows, (b, cin, h, w), kh, kw, stride, pad, dil)
         return dx, gw, gb, None, None, None
 
 

@@ -289,3 +289,28 @@ def test_conv3x3_filter_packing_bit_exact():
         wr = ops.conv3x3_pack_filters(w16, True)
         assert torch.equal(wk, w16.permute(0, 2, 3, 1).reshape(cout, 9 * cin))
         assert torch.equal(wr, w16.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout))
+
+
+@pytest.mark.parametrize("cin,cout,dtype", [(40, 24, torch.bfloat16), (64, 3, torch.float32), (320, 640, torch.bfloat16)])
+def test_pointwise_convolution_route(cin, cout, dtype):
+    """1x1 / stride 1 convolutions (the UNet's skip connections) take the transpose route of Conv2dFn: NHWC rows saved for the
+    weight gradient, dX back through a batched transpose; Cout not a multiple of 8 is padded.  Against torch fp32 on the same
+    bf16-rounded operands, two backward passes (accumulation onto existing gradients)."""
+    torch.manual_seed(cin + cout)
+    b, h, w = 3, 9, 12
+    x = bf16_round(torch.randn(b, cin, h, w))
+    wt = bf16_round(torch.randn(cout, cin, 1, 1) * 0.2)
+    bias = torch.randn(cout) * 0.1
+    gy = bf16_round(torch.randn(b, cout, h, w))
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    want = torch.nn.functional.conv2d(xr, wr, br)
+    want.backward(gy)
+    xd = x.to(DEV).to(dtype).requires_grad_(True)
+    wd, bd = wt.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    for rep in (1, 2):
+        y = HF.conv2d(xd, wd, bd, 1, 0, 1)
+        y.backward(gy.to(DEV).bfloat16())
+        assert_close(y, want, 6e-3, "1x1 conv y")
+        assert_close(wd.grad, rep * wr.grad, 1e-2, "1x1 conv gw")
+        assert_close(bd.grad, rep * br.grad, 6e-3, "1x1 conv gb")
+    assert_close(xd.grad, 2 * xr.grad, 1e-2, "1x1 conv gx")
