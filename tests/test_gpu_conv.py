@@ -43,6 +43,11 @@ def test_im2row_row2im_transposes_bit_exact():
     t = bf16_round(torch.randn(5, 37, 70))
     assert torch.equal(ops.transpose_batched(t.to(DEV)).float().cpu(), t.transpose(1, 2))
     assert torch.equal(ops.transpose_batched(t.to(DEV).bfloat16()).float().cpu(), t.transpose(1, 2))
+    # the 16-bytes-per-lane form (R % 8 == 0 and C % 8 == 0): partial edge tiles, f32 and bf16 sources, a batch
+    for n, r, c in ((3, 72, 200), (2, 4096, 320), (1, 8, 8), (5, 64, 1280), (2, 136, 64)):
+        t = bf16_round(torch.randn(n, r, c))
+        assert torch.equal(ops.transpose_batched(t.to(DEV)).float().cpu(), t.transpose(1, 2)), (n, r, c)
+        assert torch.equal(ops.transpose_batched(t.to(DEV).bfloat16()).float().cpu(), t.transpose(1, 2)), (n, r, c)
 
 
 def test_conv2d_golden(golden):
