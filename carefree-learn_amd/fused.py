@@ -286,7 +286,7 @@ def _block_fwd(x2: Tensor, prm: tuple, num_heads: int, eps1: float, eps2: float,
         run(0, bsz)
     else:
         n = len(streams)
-        cuts = [bsz * i // n for i in range(n + 1)]
+        cuts = _slice_cuts(bsz, n)
         for i, st in enumerate(streams):
             with _functional.on_stream(st):
                 run(cuts[i], cuts[i + 1])
@@ -295,6 +295,17 @@ def _block_fwd(x2: Tensor, prm: tuple, num_heads: int, eps1: float, eps2: float,
 
 
 N_SAVED = 17  # tensors per block in `saved`
+
+# Share of the batch the FIRST slice (the caller's stream, which also carries the patch embedding, the head, the loss and the
+# optimizer) takes when a pass runs as two slices; 0.5 = equal halves.
+FIRST_SLICE_SHARE = 0.5
+
+
+def _slice_cuts(bsz: int, n: int) -> list:
+    if n == 2 and FIRST_SLICE_SHARE != 0.5:
+        first = min(bsz - 1, max(1, int(round(bsz * FIRST_SLICE_SHARE))))
+        return [0, first, bsz]
+    return [bsz * i // n for i in range(n + 1)]
 
 
 # The backward of a block stack runs as BWD_HALVES batch-slice pipelines too (round 3): with the weight gradients gone
@@ -324,7 +335,7 @@ def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_
     nsl = len(streams) if streams else 1
     if bsz < 2 * nsl:
         nsl, streams = 1, None
-    cuts = [bsz * i // nsl for i in range(nsl + 1)]
+    cuts = _slice_cuts(bsz, nsl)
     ln_done: list = [None, None]  # event after the previous slice's LayerNorm-backward launch (LN2, LN1)
 
     def run(i: int) -> None:

@@ -13,7 +13,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "unet"
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+steps = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 5
 dev = torch.device("cuda")
 torch.manual_seed(0)
 import cflearn_amd as C  # noqa: E402
@@ -45,6 +45,8 @@ else:
     img = torch.randn(128, 3, 224, 224, generator=g).to(dev)
     lab = torch.randint(0, 1000, (128,), generator=g).to(dev)
     step = lambda: ts.step(img, lab)  # noqa: E731
+if "--inline-backward" in sys.argv:  # run autograd's backward on this thread so that cProfile sees the Python backward functions
+    torch.autograd.set_multithreading_enabled(False)
 for _ in range(3):
     step()
 torch.cuda.synchronize()
@@ -61,5 +63,5 @@ for (fn, line, name), (cc, nc, tt, ct, _) in st.stats.items():
 rows.sort(reverse=True)
 print(f"{which}: host time per step by function (own ms, cumulative ms, calls) — profiler overhead included")
 print(f"total own time {sum(r[0] for r in rows):.1f} ms/step")
-for tt, ct, nc, name in rows[:45]:
+for tt, ct, nc, name in rows[:60]:
     print(f"{tt:8.2f} {ct:8.2f} {nc:8.0f}  {name[:110]}")

@@ -25,8 +25,9 @@ img = torch.randn(BATCH, 3, 224, 224, generator=g).to(dev)
 labels = torch.randint(0, 1000, (BATCH,), generator=g).to(dev)
 
 
-def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt=-1, nn=-1):
+def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt=-1, nn=-1, share=0.5):
     def f():
+        fused.FIRST_SLICE_SHARE = share
         fused.DW_GROUP_BLOCKS = blocks
         fused.DW_GROUP_TILES = 0  # the variants of this tool group by block count
         fused.DW_GROUP_ON_MAIN = on_main
@@ -41,6 +42,10 @@ def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt
 
 VARIANTS = {
     "default (g2, s2, table 7)": setv(2),
+    "first slice 60 of 128": setv(2, share=60 / 128),
+    "first slice 56 of 128": setv(2, share=56 / 128),
+    "first slice 52 of 128": setv(2, share=52 / 128),
+    "first slice 68 of 128": setv(2, share=68 / 128),
     "bias gradients by the first tile column (r3a)": setv(2, variant=16),
     "row-major tiles (r3a)": setv(2, variant=32),
     "r3a grouped kernel behaviour": setv(2, variant=48),
