@@ -107,6 +107,12 @@ def queue_linear_dw(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> 
     global _end_flush_queued
     if LINEAR_DW_TILES <= 0 or DW_GROUP_BLOCKS <= 0 or not w.requires_grad or not _groupable(w, dy2, x2):
         return False
+    if _functional.grad_ready_callbacks:
+        # A gradient reducer is listening.  LinearFn takes its parameters as tensor inputs, so autograd runs their
+        # post-accumulate hooks (the reducer's per-parameter notification) when LinearFn.backward returns — before a
+        # queued gradient is written: the bucket would be reduced with stale contents
+        # (tests/test_ddp_gloo.py::test_gradients_queued_for_a_later_launch...).  Deferral is for single-process runs.
+        return False
     if not _end_flush_queued:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_flush)

@@ -606,3 +606,91 @@ def test_small_tail_bucket_and_checkpointed_last_block(tmp_path):
     assert r0["launches"] == [r0["n_buckets"]]  # every bucket launched exactly once in the checkpointed pass
     assert torch.equal(r0["g"], r1["g"])
     assert (r0["g"] - r0["avg"]).abs().max() < 1e-6
+
+
+def _deferred_flush_worker(rank: int, world: int, port: int, out: str) -> None:
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cflearn_amd as C
+    from cflearn_amd import functional as HF
+
+    torch.manual_seed(3)
+    layers = [torch.nn.Linear(8, 8) for _ in range(4)]
+    arena = C.ParamArena([p for lyr in layers for p in lyr.parameters()], with_shadow=False)
+    red = C.BucketedAllReduce(arena, bucket_bytes=72 * 4, tail_bytes=72 * 4, finish_after_backward=True, average=True)
+    queue: list = []
+
+    def flush() -> None:  # what fused._flush_deferred does with its queued weight gradients
+        while queue:
+            (wp, bp), dy, h = queue.pop(0)
+            with torch.no_grad():
+                wp.grad.add_(dy.t() @ h)
+                bp.grad.add_(dy.sum(0))
+            for prm in (wp, bp):
+                for cb in HF.grad_ready_callbacks:
+                    cb(prm)
+
+    class DeferredLinear(torch.autograd.Function):
+        """parameter gradients QUEUED in backward (one grouped launch later).  The parameters are NOT tensor inputs of the
+        Function (as in the fused block stack): autograd then has no AccumulateGrad edge whose post-accumulate hook would
+        announce the parameter — with nothing written yet — the moment this backward returns."""
+
+        @staticmethod
+        def forward(ctx, h, lyr):
+            w = lyr.weight.detach()
+            ctx.save_for_backward(h, w)
+            ctx.prm = (lyr.weight, lyr.bias)
+            return h @ w.t() + lyr.bias.detach()
+
+        @staticmethod
+        def backward(ctx, dy):
+            h, w = ctx.saved_tensors
+            queue.append((ctx.prm, dy, h))
+            return dy @ w, None
+
+    def net(x, deferred):
+        h = x
+        for i, lyr in enumerate(layers):
+            # the FIRST layer's gradients are the last of the pass: still queued when autograd's end-of-backward callbacks run
+            h = DeferredLinear.apply(h, lyr) if (deferred and i in (0, 2)) else lyr(h)
+            h = torch.tanh(h)
+        return h.pow(2).mean()
+
+    torch.manual_seed(60 + rank)
+    x = torch.randn(5, 8, requires_grad=True)  # (layer 0 is deferred: its Function needs an input that wants a gradient)
+    HF.deferred_grad_flushes.append(flush)
+    try:
+        arena.zero_grad()
+        net(x, True).backward()
+        g = arena.flat_g.clone()
+        leftover = len(queue)
+    finally:
+        HF.deferred_grad_flushes.remove(flush)
+    arena.zero_grad()
+    red.sync_enabled = False
+    net(x, False).backward()
+    local = arena.flat_g.clone()
+    both = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(both, local)
+    torch.save(dict(g=g, avg=sum(both) / world, leftover=leftover), f"{out}.{rank}")
+    red.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gradients_queued_for_a_later_launch_are_flushed_before_the_pass_is_finished(tmp_path):
+    """Round 3: weight gradients may sit in a queue (fused.queue_linear_dw) when the backward pass ends; the reducer's
+    end-of-backward callback runs the registered flushes (functional.deferred_grad_flushes) BEFORE it finishes the pass, whatever
+    the order autograd runs its callbacks in: every bucket reduced, gradients = the rank average."""
+    world, port = 2, _free_port()
+    out = str(tmp_path / "defer")
+    mp.spawn(_deferred_flush_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["leftover"] == 0 and r1["leftover"] == 0
+    assert torch.equal(r0["g"], r1["g"])
+    assert (r0["g"] - r0["avg"]).abs().max() < 1e-6
