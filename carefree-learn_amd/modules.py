@@ -7,6 +7,7 @@ classes that are outside the hot path (pruners, style-modulated convs, spatial r
 softmax callbacks...) raise NotImplementedError instead of silently doing something else.
 """
 import math
+import os
 from typing import Any, Callable, Dict, List, NamedTuple, Optional, Tuple
 
 import torch
@@ -1594,6 +1595,9 @@ class MultiHeadSpatialAttention(Module):
 # ---------------------------------------------------------------------------------------------
 
 
+FUSE_SELF_ATTENTION_QKV = os.environ.get("CFHIP_FUSE_QKV", "1") != "0"  # CrossAttention without a context: to_q | to_k | to_v as one GEMM when their weights are adjacent
+
+
 class CrossAttention(Module):
     """reference attentions.py:498-569: `to_q` / `to_k` / `to_v` (HijackLinear, no bias), `out_linear.0` (HijackLinear)
     + Dropout; heads of `head_dim` channels (any multiple of 8 up to 192), context = the input when None."""
@@ -1610,17 +1614,28 @@ class CrossAttention(Module):
         self.to_v = HijackLinear(context_dim, latent_dim, bias=False)
         self.out_linear = nn.Sequential(HijackLinear(latent_dim, query_dim), Dropout(dropout))
 
+    def _plain_projections(self) -> bool:
+        """to_q / to_k / to_v are full-rank, hook-free, bias-free Linear layers (what the packed projection replaces)"""
+        return all(type(m) is HijackLinear and getattr(m, "hook", None) is None and m.bias is None
+                   for m in (self.to_q, self.to_k, self.to_v))
+
     def forward(self, net: Tensor, *, context: Optional[Tensor] = None, mask: Optional[Tensor] = None,
                 residual: Optional[Tensor] = None) -> Tensor:
-        q = self.to_q(net)
-        if context is None:
-            context = net
-        k, v = self.to_k(context), self.to_v(context)
         keep = None
         if mask is not None:  # [B*H, Tq, Tk] bool, True = masked (the reference inverts it before sdp_attn)
             b = net.shape[0]
             keep = (~mask).view(b, self.num_heads, mask.shape[-2], mask.shape[-1]).to(torch.uint8)
-        o = HF.attention_core(q, k, v, self.num_heads, keep, False, self.head_dim)
+        if context is None and FUSE_SELF_ATTENTION_QKV and self._plain_projections() and HF.qkv_weights_adjacent(
+                self.to_q.weight, self.to_k.weight, self.to_v.weight):
+            # self attention, the three projection weights back to back in the arena: one packed projection GEMM
+            qkv = HF.qkv_linear(net, self.to_q.weight, self.to_k.weight, self.to_v.weight)
+            o = HF.packed_self_attention(qkv, self.num_heads, keep, False, 0.0, self.head_dim)
+        else:
+            q = self.to_q(net)
+            if context is None:
+                context = net
+            k, v = self.to_k(context), self.to_v(context)
+            o = HF.attention_core(q, k, v, self.num_heads, keep, False, self.head_dim)
         lin, drop = self.out_linear[0], self.out_linear[1]
         if self.training and 0.0 < drop.p < 1.0:  # attentions.py:517-521: Linear -> Dropout, then the caller's residual
             out = drop(HF.linear(o, lin.weight, lin.bias))

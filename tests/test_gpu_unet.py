@@ -456,3 +456,58 @@ def test_ddpm_train_step_learned_log_var_and_labels(golden):
     moved = (ts.log_var.detach() - 0.1).abs() > 0
     assert moved[t].all() and int(moved.sum()) == 2
     assert all(torch.isfinite(p).all() for p in m.parameters())
+
+
+def test_self_attention_packed_projection_matches_the_three_linears(golden):
+    """Round 3: CrossAttention without a context runs to_q | to_k | to_v as ONE GEMM when the three weights are adjacent in a
+    ParamArena (one dX GEMM, one dW GEMM into the three adjacent gradient slots).  Same module, same weights, with the switch
+    on / off: outputs and every gradient agree to bf16 rounding; the switch-on run must really have taken the packed path."""
+    import cflearn_amd.modules as M
+    from cflearn_amd import functional as HF
+    from cflearn_amd.modules import SpatialTransformer
+
+    g = golden("spatial_transformer.pt")
+    x = g["x"].to(DEV)
+    gy = g["gy"].to(DEV).bfloat16()
+    cfg = dict(g["cfg"], context_dim=None)  # no context: attn1 AND attn2 are self attention over the tokens
+    torch.manual_seed(21)
+    sd = SpatialTransformer(**cfg).state_dict()
+    res = {}
+    keep = M.FUSE_SELF_ATTENTION_QKV
+    try:
+        for fuse in (True, False):
+            M.FUSE_SELF_ATTENTION_QKV = fuse
+            m = SpatialTransformer(**cfg)
+            m.load_state_dict(sd)
+            m = m.to(DEV)
+            arena = C.ParamArena(list(m.parameters()), with_shadow=True)
+            blk = m.blocks[0] if hasattr(m, "blocks") else next(mod for mod in m.modules() if isinstance(mod, M.SpatialTransformerBlock))
+            assert HF.qkv_weights_adjacent(blk.attn1.to_q.weight, blk.attn1.to_k.weight, blk.attn1.to_v.weight)
+            for rep in range(2):  # the second pass accumulates onto the first one's gradients
+                xr = x.clone().requires_grad_(True)
+                y = m(xr, None)
+                y.backward(gy)
+            torch.cuda.synchronize()
+            res[fuse] = (y.detach().clone(), xr.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()})
+    finally:
+        M.FUSE_SELF_ATTENTION_QKV = keep
+    assert_close(res[True][0], res[False][0], 4e-3, "packed projection: output")
+    assert_close(res[True][1], res[False][1], 1e-2, "packed projection: dx")
+    for k in res[False][2]:
+        assert_close(res[True][2][k], res[False][2][k], 1e-2, f"packed projection: grad {k}", abs_floor=1e-6)
+    # and the packed path was really taken: the autograd graph of a fused run contains QKVLinearFn
+    M.FUSE_SELF_ATTENTION_QKV = True
+    try:
+        m = SpatialTransformer(**cfg).to(DEV)
+        C.ParamArena(list(m.parameters()), with_shadow=True)
+        y = m(x.clone().requires_grad_(True), None)
+        seen, stack = set(), [y.grad_fn]
+        while stack:
+            fn = stack.pop()
+            if fn is None or fn in seen:
+                continue
+            seen.add(fn)
+            stack.extend(nf for nf, _ in fn.next_functions)
+        assert any("QKVLinearFn" in type(fn).__name__ for fn in seen)
+    finally:
+        M.FUSE_SELF_ATTENTION_QKV = keep
