@@ -249,7 +249,7 @@ def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: T
 # one slice — which leave the matrix cores idle — run beside the GEMMs of the other.  Whole step, one process, interleaved:
 # batch 64 11.91 -> 11.36 ms, batch 128 20.92 -> 20.60, batch 256 40.14 -> 39.87; three slices 20.72 (tools/fwd_halves_ab.py,
 # profiles/r02/fwd_halves_ab.log).  The backward is already two saturated queues (dX chain + dW GEMMs).
-FWD_HALVES = 2
+FWD_HALVES = int(os.environ.get("CFHIP_FWD_HALVES", "2"))
 
 
 def _block_fwd(x2: Tensor, prm: tuple, num_heads: int, eps1: float, eps2: float, bsz: int, t: int,
@@ -319,7 +319,7 @@ def _slice_cuts(bsz: int, n: int) -> list:
 # busy on the main stream, profiles/r03) of kernels that each leave part of the chip idle (tile quantisation, LayerNorm /
 # attention beside GEMMs).  Every operator of the chain is row- or sample-wise except the LayerNorm parameter gradients
 # (column sums over ALL rows): slice i + 1's LayerNorm-backward launch waits for slice i's (one event) and accumulates.
-BWD_HALVES = 2
+BWD_HALVES = int(os.environ.get("CFHIP_BWD_HALVES", "2"))
 
 
 def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_mask: Optional[Tensor],

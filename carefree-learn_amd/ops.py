@@ -4,6 +4,7 @@ Every function takes / returns torch tensors that live on the HIP device, launch
 current stream and never synchronises.  PyTorch is used only as the owner of device memory.
 """
 import math
+import os
 from typing import Optional, Tuple
 
 import ctypes
@@ -840,8 +841,8 @@ def _gn_affine_stride(gamma: Tensor, beta: Tensor, b: int, c: int) -> int:
     raise ValueError(f"cfhip groupnorm: gamma must be [C] or [B, C], got {tuple(gamma.shape)}")
 
 
-GN_TARGET_WORKGROUPS = 1024  # four 4-wave workgroups per CU; 0: never split (round-1/2 kernels only)
-GN_MIN_SLICE = 2048  # elements of `inner` per slice and channel below which splitting further stops paying
+GN_TARGET_WORKGROUPS = int(os.environ.get("CFHIP_GN_TARGET", "1024"))  # four 4-wave workgroups per CU; 0: never split
+GN_MIN_SLICE = int(os.environ.get("CFHIP_GN_MIN_SLICE", "2048"))  # elements of `inner` per slice and channel below which splitting stops paying
 
 
 def gn_splits(b: int, c: int, groups: int, inner: int) -> int:
