@@ -126,31 +126,40 @@ def gemm(
 ) -> Tensor:
     """C[m,n] = epilogue(sum_k A(m,k) B(n,k)); see cfhip_gemm_bf16 in include/cfhip.h.
     `bias_grad` (f32 [M], layout a_trans & b_trans only): (+)= sum_k A(m,k), i.e. colsum(dY) of a dW GEMM."""
-    _need(a, bf16, "a")
-    _need(b, bf16, "b")
-    ra, ca, lda = _mat(a, "a")
-    rb, cb, ldb = _mat(b, "b")
-    m, k = (ca, ra) if a_trans else (ra, ca)
-    n, kb = (cb, rb) if b_trans else (rb, cb)
+    # (this wrapper runs 400-500 times per UNet / CLIP step on the thread that issues every launch: shapes and strides are
+    # read once as tuples, the checks are inline — tools/host_profile.py had it at 10 us per call, a tenth of the host's step)
+    if a.dtype is not bf16 or b.dtype is not bf16 or not a.is_cuda or not b.is_cuda:
+        _need(a, bf16, "a")
+        _need(b, bf16, "b")
+    sha, shb, sta, stb = a.shape, b.shape, a.stride(), b.stride()
+    if len(sha) != 2 or sta[1] != 1:
+        _mat(a, "a")
+    if len(shb) != 2 or stb[1] != 1:
+        _mat(b, "b")
+    lda, ldb = sta[0], stb[0]
+    m, k = (sha[1], sha[0]) if a_trans else (sha[0], sha[1])
+    n, kb = (shb[1], shb[0]) if b_trans else (shb[0], shb[1])
     if k != kb:
         raise ValueError(f"cfhip gemm: reduction dims differ ({k} vs {kb})")
     if out is None:
         out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+        ldc, odt = n, out_dtype
     else:
-        _need(out, out.dtype, "out")
-        if out.dtype not in (bf16, f32) or tuple(out.shape) != (m, n) or out.stride(1) != 1:
+        odt, sho, sto = out.dtype, out.shape, out.stride()
+        if not out.is_cuda or (odt is not bf16 and odt is not f32) or len(sho) != 2 or sho[0] != m or sho[1] != n or sto[1] != 1:
             raise ValueError("cfhip gemm: bad `out`")
-    ldc = out.stride(0)
-    if bias is not None:
+        ldc = sto[0]
+    if bias is not None and (bias.dtype is not f32 or not bias.is_cuda or bias.numel() != n or not bias.is_contiguous()):
         _need(bias, f32, "bias")
-        if bias.numel() != n or not bias.is_contiguous():
-            raise ValueError("cfhip gemm: bias must be a contiguous f32 [N]")
-    for t, nm in ((aux_in, "aux_in"), (aux_out, "aux_out")):
-        if t is not None:
-            # the residual operand follows the output dtype (f32 residual stream); everything else is bf16
-            _need(t, f32 if (nm == "aux_in" and epilogue == EPI_RESIDUAL and out.dtype == f32) else bf16, nm)
-            if tuple(t.shape) != (m, n) or t.stride(1) != 1 or t.stride(0) != ldc:
-                raise ValueError(f"cfhip gemm: `{nm}` must match the output layout")
+        raise ValueError("cfhip gemm: bias must be a contiguous f32 [N]")
+    if aux_in is not None or aux_out is not None:
+        for t, nm in ((aux_in, "aux_in"), (aux_out, "aux_out")):
+            if t is not None:
+                # the residual operand follows the output dtype (f32 residual stream); everything else is bf16
+                _need(t, f32 if (nm == "aux_in" and epilogue == EPI_RESIDUAL and odt is f32) else bf16, nm)
+                stt = t.stride()
+                if tuple(t.shape) != (m, n) or stt[1] != 1 or stt[0] != ldc:
+                    raise ValueError(f"cfhip gemm: `{nm}` must match the output layout")
     if bias_grad is not None:
         _need(bias_grad, f32, "bias_grad")
         if bias_grad.numel() != m or not bias_grad.is_contiguous():
@@ -167,7 +176,7 @@ def gemm(
         e0.record()
     rc = _lib.load().cfhip_gemm_bf16(
         a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(bias), _p(aux_in), _p(aux_out), m, n, k, lda,
-        ldb, ldc, int(a_trans), int(b_trans), epilogue, 1 if out.dtype == f32 else 0,
+        ldb, ldc, int(a_trans), int(b_trans), epilogue, 1 if odt is f32 else 0,
         int(accumulate), split_k, _p(ws), ws_bytes, _p(bias_grad), int(bias_grad_accumulate), _stream(),
     )
     _lib.check(rc, "gemm")
