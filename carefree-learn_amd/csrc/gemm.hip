@@ -504,14 +504,16 @@ using CfgT = Cfg<256, 128, 2, 4, 6, 32>;  // 144 KiB LDS, 8 waves, ONE WG / CU, 
 using CfgU = Cfg<256, 256, 2, 4, 5, 32>;  // 160 KiB LDS, 8 waves, ONE WG / CU, prefetch 4
 using CfgW = Cfg<256, 256, 2, 4, 2, 64>;  // 128 KiB LDS, 8 waves (128x64 each), ONE WG / CU, BK = 64 (plain kernel)
 using CfgY = Cfg<192, 128, 2, 4, 2, 64>;  //  80 KiB LDS, 8 waves (96x32 each), 2 WG / CU, BK = 64 (plain kernel)
-constexpr int NUM_CFG = 15;  // 7 .. 12 = CfgP / CfgQ / CfgR / CfgS / CfgT / CfgU on the phase kernel; 13 / 14 = CfgW / CfgY
+using CfgZ = Cfg<192, 128, 2, 2, 2, 64>;  //  80 KiB LDS, 4 waves (96x64 each: 2.4 MFMAs per fragment read against 1.5), 2 WG / CU
+using CfgV = Cfg<128, 256, 2, 4, 2, 64>;  //  96 KiB LDS, 8 waves (64x64 each), 1 WG / CU
+constexpr int NUM_CFG = 17;  // 7 .. 12 = CfgP / CfgQ / CfgR / CfgS / CfgT / CfgU on the phase kernel; 13 / 14 = CfgW / CfgY; 15 / 16 = CfgZ / CfgV
 constexpr int BK_MAX = 64;
 
 int g_gemm_config = -1;
 #ifdef CFHIP_ABLATE
 int g_gemm_ablate = 0;
 #endif
-int g_gemm_heuristic = 7;
+int g_gemm_heuristic = 8;
 int g_gemm_group_n = 8;
 
 template <bool AT, bool BT, int EPI, class C, bool PIPE, int CONV = 0>
@@ -604,7 +606,10 @@ int pick_config(int M, int N, int a_trans, int b_trans) {
       const long t14 = (long)((M + 191) / 192) * ((N + 127) / 128);
       if (t14 < 160 || (N < 512 && N % 128 != 0 && N % 64 == 0)) return 3;
     }
-    if (M >= 1024) return 14;
+    // round 3c: the same 192x128x64 tile on FOUR waves of 96x64 for outputs up to 1 024 columns wide (2.4 MFMAs per
+    // fragment read against 1.5 with eight 96x32 waves): N = 768 shapes 5-10 % faster alone (K = 2 304 dX 898 -> 992 TFLOP/s),
+    // wider outputs lose (their waves' epilogues are twice as long); profiles/r03/gemm_bench_b128_c15.log
+    if (M >= 1024) return (g_gemm_heuristic >= 8 && N <= 1024) ? 15 : 14;
     if (b_trans) return 1;
     return N <= 1024 ? 3 : 0;
   }
@@ -781,6 +786,8 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
     case 12: rc = launch_layout<CfgU, true>(p, a_trans, b_trans, epilogue, split_k, s); break;
     case 13: rc = launch_layout<CfgW>(p, a_trans, b_trans, epilogue, split_k, s); break;
     case 14: rc = launch_layout<CfgY>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 15: rc = launch_layout<CfgZ>(p, a_trans, b_trans, epilogue, split_k, s); break;
+    case 16: rc = launch_layout<CfgV>(p, a_trans, b_trans, epilogue, split_k, s); break;
     default: rc = launch_layout<CfgA>(p, a_trans, b_trans, epilogue, split_k, s); break;
   }
   if (rc != CFHIP_OK) return rc;

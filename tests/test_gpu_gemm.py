@@ -177,7 +177,7 @@ def test_fused_bias_gradient_of_dw_gemm():
             assert_close(gw, 2 * want_w, 2e-5, "dW accumulate")
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 def test_every_tile_config(cfg):
     """all tile configurations of the kernel on ragged shapes, all three layouts"""
     try:

@@ -25,9 +25,10 @@ img = torch.randn(BATCH, 3, 224, 224, generator=g).to(dev)
 labels = torch.randint(0, 1000, (BATCH,), generator=g).to(dev)
 
 
-def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt=-1, nn=-1, share=0.5):
+def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt=-1, nn=-1, share=0.5, heuristic=8):
     def f():
         fused.FIRST_SLICE_SHARE = share
+        ops.set_option("gemm_heuristic", heuristic)
         fused.DW_GROUP_BLOCKS = blocks
         fused.DW_GROUP_TILES = 0  # the variants of this tool group by block count
         fused.DW_GROUP_ON_MAIN = on_main
@@ -42,6 +43,9 @@ def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt
 
 VARIANTS = {
     "default (g2, s2, table 7)": setv(2),
+    "heuristic 7 (192x128 on eight waves everywhere)": setv(2, heuristic=7),
+    "nn=c15 (all dX on four waves)": setv(2, nn=15),
+    "nn=c15 nt=c15": setv(2, nn=15, nt=15),
     "first slice 60 of 128": setv(2, share=60 / 128),
     "first slice 56 of 128": setv(2, share=56 / 128),
     "first slice 52 of 128": setv(2, share=52 / 128),
