@@ -32,7 +32,7 @@ for m, n, k, cnt in SHAPES:
     bg = torch.empty(m, dtype=torch.float32, device=dev)
     auto = ops.pick_split_k(m, n, k)
     row = []
-    for cfg in (-1, 1, 0, 3, 14):
+    for cfg in (-1, 1, 0, 3, 14, 15):
         ops.set_option("gemm_config", cfg)
         for sk in sorted({auto, 1, 4, 8, 16, 32, 64}):
             if sk > max(1, k // 256):
