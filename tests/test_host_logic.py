@@ -424,3 +424,51 @@ def test_bench_self_launch_command_and_percentiles():
     vals = sorted([20.0, 21.0, 19.0, 25.0, 20.5])
     assert bench._pct(vals, 0.5) == 20.5 and bench._pct(vals, 0.0) == 19.0 and bench._pct(vals, 1.0) == 25.0
     assert abs(bench._pct(vals, 0.1) - 19.4) < 1e-9
+
+
+def test_round3_host_rules():
+    """Host-side rules added in round 3, no device needed: GroupNorm slice counts, batch-slice cuts, split-K cap, and the
+    adjacency test that lets a self-attention run to_q | to_k | to_v as one GEMM."""
+    import torch
+
+    import cflearn_amd as C
+    from cflearn_amd import functional as HF
+    from cflearn_amd import fused, ops
+    from cflearn_amd.modules import CrossAttention
+
+    # GroupNorm: few samples -> slices; never slices shorter than GN_MIN_SLICE, never more than 64, 1 when B * G fills the chip
+    assert ops.gn_splits(1, 320, 32, 256 * 256) == 32
+    assert ops.gn_splits(8, 320, 32, 64 * 64) == 2
+    assert ops.gn_splits(8, 1280, 32, 8 * 8) == 1
+    assert ops.gn_splits(64, 320, 32, 64 * 64) == 1
+    assert ops.gn_splits(1, 320, 32, 1001) == 1  # inner not a multiple of 8: the vector kernels do not apply
+    assert ops.gn_splits(1, 32, 32, 1 << 24) == 32  # (want = 1024 / 32 workgroups)
+    # batch slices: equal halves by default, the share knob moves the cut, one sample per slice at least
+    assert fused._slice_cuts(128, 2) == [0, 64, 128] and fused._slice_cuts(7, 3) == [0, 2, 4, 7]
+    keep = fused.FIRST_SLICE_SHARE
+    try:
+        fused.FIRST_SLICE_SHARE = 60 / 128
+        assert fused._slice_cuts(128, 2) == [0, 60, 128]
+        fused.FIRST_SLICE_SHARE = 0.0
+        assert fused._slice_cuts(128, 2) == [0, 1, 128]
+    finally:
+        fused.FIRST_SLICE_SHARE = keep
+    # split-K: capped at 32 slices, none for short reductions or outputs that fill the chip
+    assert ops.pick_split_k(320, 320, 32768) == 32 and ops.pick_split_k(1280, 1280, 512) == 1
+    assert ops.pick_split_k(4096, 4096, 100000) == 1 and 1 < ops.pick_split_k(768, 768, 25088) <= 32
+    # adjacency of the three projection weights: true inside one arena in registration order, false without an arena, across
+    # arenas, or when the shapes differ (a cross attention with its own context width)
+    torch.manual_seed(0)
+    m = CrossAttention(query_dim=64, num_heads=2, head_dim=16)
+    assert not HF.qkv_weights_adjacent(m.to_q.weight, m.to_k.weight, m.to_v.weight)
+    C.ParamArena(list(m.parameters()), with_shadow=True)
+    assert HF.qkv_weights_adjacent(m.to_q.weight, m.to_k.weight, m.to_v.weight)
+    assert not HF.qkv_weights_adjacent(m.to_k.weight, m.to_q.weight, m.to_v.weight)
+    x = CrossAttention(query_dim=64, context_dim=48, num_heads=2, head_dim=16)
+    C.ParamArena(list(x.parameters()), with_shadow=True)
+    assert not HF.qkv_weights_adjacent(x.to_q.weight, x.to_k.weight, x.to_v.weight)
+    a, b = CrossAttention(query_dim=64, num_heads=2, head_dim=16), CrossAttention(query_dim=64, num_heads=2, head_dim=16)
+    C.ParamArena(list(a.parameters()), with_shadow=True)
+    C.ParamArena(list(b.parameters()), with_shadow=True)
+    assert not HF.qkv_weights_adjacent(a.to_q.weight, b.to_k.weight, a.to_v.weight)
+    assert m._plain_projections()
