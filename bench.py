@@ -9,8 +9,11 @@ patch embedding -> 12 pre-norm transformer blocks -> head LN + Linear -> softmax
 -> (N > 1: bucketed gradient all-reduce) -> fused AdamW update of all 86.6 M parameters.
 Rank 0 prints ONE JSON line (metric = BASELINE.json's: train samples/sec + step ms).
 
-Extra objects:
-  roofline      dominant kernel family = the MFMA GEMM (`gemm_bf16_phase_kernel<*>` / `gemm_bf16_kernel<*>`, 96 % of the step's
+Extra fields / objects:
+  host_issue_ms_per_step   wall time the host needed to ISSUE the timed steps (it never waits for the device inside): the device is
+                the bound when this is well below ms_per_step (ViT: 10.3 of 18.0 ms), the Python path when it is not.
+  step_ms       median / p10 / p90 / min / max of per-step HIP-event timings;  other_workloads: UNet 64^2 x 8 and CLIP b256 steps.
+  roofline      dominant kernel family = the MFMA GEMM (`gemm_grouped_tn_kernel<*>` / `gemm_bf16_kernel<*>`, 96 % of the step's
                 FLOPs).  `achieved` = algorithmic FLOPs of every GEMM launch of one step (2*M*N*K each, the per-sample
                 figure of SURVEY §8d x the batch) / the SUM OF THEIR IN-STEP DURATIONS: HIP-event pairs around every
                 GEMM launch of real training steps, on the stream each one is launched on (`ops.GemmTimer`) — the same
@@ -19,7 +22,7 @@ Extra objects:
                 `isolated` (each shape timed alone, random operands) and `wall` (GEMM FLOPs / measured step time — the
                 lower bound nobody can argue with).  peak = 2500 TFLOP/s dense bf16.
                 `traffic` = HBM-side bytes of the family from PMC passes (tools/gpu/run.sh pmc): only reported when
-                the committed pass was taken on THIS kernel source (sha256 of csrc/gemm.hip recorded in the JSON),
+                the committed pass was taken on THIS kernel source (sha256 of the GEMM sources recorded in the JSON),
                 otherwise null with `traffic_stale`.
   cpu_baseline  the same step (fwd + CE + bwd + AdamW) on the host cores, bounded sample.  kind "reference": the
                 reference's own modules imported from /root/reference (build container); kind "port": the oracle
