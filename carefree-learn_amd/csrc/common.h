@@ -35,6 +35,13 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, const voi
 // Every LDS-DMA this wave has issued has landed (follow with a barrier before other waves read the tile).  Needed because
 // the asm form above is invisible to the compiler: `__syncthreads()` no longer implies the vmcnt(0) it used to emit for the
 // builtin form.
+// The same with a SCALAR byte offset on top of the lane's (soffset operand of the buffer instruction): the K advance of a GEMM
+// operand is wave-uniform, so the per-lane offsets stay what they were computed to be once per tile — no VALU per K-step.
+// (gfx9 raw buffers: the range check covers voffset only, an out-of-range lane stays out of range whatever the soffset.)
+__device__ __forceinline__ void lds_dma16_s(__amdgpu_buffer_rsrc_t rsrc, const void* lds_dst, unsigned voff, unsigned soff) {
+  const unsigned la = (unsigned)(uintptr_t)LDS_PTR(const_cast<void*>(lds_dst));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(la), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
 __device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 void cfhip_set_error(const char* fmt, ...);

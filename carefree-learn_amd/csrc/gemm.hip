@@ -169,12 +169,12 @@ __device__ __forceinline__ void stage_step(const ItemCtx<AT, BT, C>& c, const Ge
                                            int slot, int wave, int kstep) {
   char* st = smem + slot * C::STAGE_BYTES;
   if constexpr (CONV == 1) stage_tile_conv<C>(c.a_rsrc, st, wave, c.pa, c.yx, p, kstep + (c.kb >> 5));
-  else stage_tile<AT>(c.a_rsrc, st, wave, c.pa, p.lda, kstep * C::BK, c.klen);
+  else stage_tile<AT, C::A_INSTR, C::BK>(c.a_rsrc, st, wave, c.pa, p.lda, kstep * C::BK, c.klen);
   if constexpr (CONV == 2) {
     stage_tile_wgrad<C>(c, st + C::A_BYTES, wave, p, kstep);
     return;
   }
-  stage_tile<BT>(c.b_rsrc, st + C::A_BYTES, wave, c.pb, p.ldb, kstep * C::BK, c.klen);
+  stage_tile<BT, C::B_INSTR, C::BK>(c.b_rsrc, st + C::A_BYTES, wave, c.pb, p.ldb, kstep * C::BK, c.klen);
 }
 
 // One workgroup per work item (output tile x K slice), an NSTAGE-deep LDS ring fed by LDS-DMA:

@@ -114,9 +114,20 @@ __device__ __forceinline__ StagePlan<NI> make_plan(int wave, int lane, long ld, 
   return p;
 }
 
-template <bool TRANS, int NI>
+template <bool TRANS, int NI, int BKS = 0>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int wave,
                                            const StagePlan<NI>& p, long ld, int k0, int klen) {
+  // Full K-steps (every K-step but a ragged last one, and the zero-fill steps the grouped kernel issues beyond K): the K advance
+  // rides on the instruction's scalar offset, the per-lane offsets (out-of-range sentinel included) are the plan's — no VALU.
+  // SQ counters had 2.5 VALU instructions per MFMA in the K loop of the plain kernel, most of them this arithmetic
+  // (profiles/r03/pmc_gemm_c14_vs_c15.txt).
+  // BKS = the K-step depth of the caller's tile (every kpos < BKS); 0: the caller keeps the per-lane form.
+  if (BKS > 0 && k0 + BKS <= klen) {  // wave-uniform
+    const unsigned soff = TRANS ? (unsigned)((long)k0 * ld * 2) : (unsigned)(k0 * 2);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) lds_dma16_s(rsrc, lds_tile + (wave * NI + j) * 1024, p.voff[j], soff);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     unsigned off = TRANS ? p.voff[j] + (unsigned)((long)k0 * ld * 2) : p.voff[j] + (unsigned)(k0 * 2);
