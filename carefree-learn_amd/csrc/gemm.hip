@@ -506,7 +506,8 @@ using CfgW = Cfg<256, 256, 2, 4, 2, 64>;  // 128 KiB LDS, 8 waves (128x64 each),
 using CfgY = Cfg<192, 128, 2, 4, 2, 64>;  //  80 KiB LDS, 8 waves (96x32 each), 2 WG / CU, BK = 64 (plain kernel)
 using CfgZ = Cfg<192, 128, 2, 2, 2, 64>;  //  80 KiB LDS, 4 waves (96x64 each: 2.4 MFMAs per fragment read against 1.5), 2 WG / CU
 using CfgV = Cfg<128, 256, 2, 4, 2, 64>;  //  96 KiB LDS, 8 waves (64x64 each), 1 WG / CU
-constexpr int NUM_CFG = 17;  // 7 .. 12 = CfgP / CfgQ / CfgR / CfgS / CfgT / CfgU on the phase kernel; 13 / 14 = CfgW / CfgY; 15 / 16 = CfgZ / CfgV
+constexpr int PP_BASE = 17, PP_COUNT = 4;  // 17 .. 20: the software-pipelined 32x32x16 kernels of gemm_pp.hip
+constexpr int NUM_CFG = PP_BASE + PP_COUNT;  // 7 .. 12 = CfgP / CfgQ / CfgR / CfgS / CfgT / CfgU on the phase kernel; 13 / 14 = CfgW / CfgY; 15 / 16 = CfgZ / CfgV
 constexpr int BK_MAX = 64;
 
 int g_gemm_config = -1;
@@ -515,6 +516,7 @@ int g_gemm_ablate = 0;
 #endif
 int g_gemm_heuristic = 8;
 int g_gemm_group_n = 8;
+int g_pp_group_n = 0;  // tile walk of the gemm_pp kernels: 0 row-major, n > 0 column groups of n tiles
 
 template <bool AT, bool BT, int EPI, class C, bool PIPE, int CONV = 0>
 int launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
@@ -648,6 +650,9 @@ int pick_config(int M, int N, int a_trans, int b_trans) {
 int cfhip_internal_set_attn_ablate(int v);  // attn.hip
 #endif
 int cfhip_internal_set_ln_fused(int v);  // norm.hip
+int cfhip_internal_gemm_pp_supported(int M, int N, int K, long ldc, int a_trans, int epilogue, int out_dtype, int accumulate, int split_k,
+                                     int variant);  // gemm_pp.hip
+int cfhip_internal_gemm_pp(const void* params, int variant, int b_trans, int epilogue, void* stream);
 int cfhip_internal_set_attn_persistent(int v);  // attn.hip
 int cfhip_internal_set_grouped_variant(int v);  // gemm_grouped.hip
 int cfhip_internal_set_attn_two_tiles(int v);  // attn.hip
@@ -670,6 +675,10 @@ extern "C" int cfhip_set_option(const char* name, int value) {
     }
   if (name != nullptr && strcmp(name, "gemm_group_n") == 0) {
     g_gemm_group_n = value;
+    return CFHIP_OK;
+  }
+  if (name != nullptr && strcmp(name, "gemm_pp_group_n") == 0) {
+    g_pp_group_n = value;
     return CFHIP_OK;
   }
   if (name != nullptr && strcmp(name, "ln_bwd_fused") == 0) return cfhip_internal_set_ln_fused(value);
@@ -771,7 +780,19 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
   }
 
   int rc;
-  switch (pick_config(M, N, a_trans, b_trans)) {
+  int cfg = pick_config(M, N, a_trans, b_trans);
+  if (cfg >= PP_BASE) {
+    if (cfhip_internal_gemm_pp_supported(M, N, K, ldc, a_trans, epilogue, out_dtype, accumulate, split_k, cfg - PP_BASE)) {
+      // tile walk of the persistent kernels: an XCD's 32 resident tiles should form a compact block of the tile grid
+      p.group_n = g_pp_group_n;
+      rc = cfhip_internal_gemm_pp(&p, cfg - PP_BASE, b_trans, epilogue, stream);
+      if (rc != CFHIP_OK) return rc;
+      CFHIP_CHECK_LAUNCH("gemm_pp");
+      return CFHIP_OK;
+    }
+    cfg = a_trans ? 1 : 15;  // shapes the pipelined kernels do not take
+  }
+  switch (cfg) {
     case 1: rc = launch_layout<CfgB>(p, a_trans, b_trans, epilogue, split_k, s); break;
     case 2: rc = launch_layout<CfgC>(p, a_trans, b_trans, epilogue, split_k, s); break;
     case 3: rc = launch_layout<CfgD>(p, a_trans, b_trans, epilogue, split_k, s); break;

@@ -85,7 +85,17 @@ __device__ __forceinline__ int mkey(int krow) {
   return R % 128 == 0 ? ((krow & 3) | (((krow >> 3) & 1) << 2)) : (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1));
 }
 
-template <bool TRANS, int R, int NI, int BK>
+// Swizzle key of an m-major tile read as 32-column fragments (v_mfma_f32_32x32x16_bf16 operands: a half-wave = two 16-lane
+// groups on the SAME four k-rows, columns c0 .. c0+15 and c0+16 .. c0+31): the eight 32-byte pieces (k-row j, column block e)
+// of one ds_read_b64_tr_b16 must land on distinct bank octets.  Pitch a multiple of 256 B: chunk (cb + e) ^ 2 j;
+// pitch = 128 mod 256 (R = 64, 192): odd k-rows already sit on the other bank half, key = krow & 2.
+template <int R>
+__device__ __forceinline__ int mkey32(int krow) {
+  static_assert(R % 64 == 0, "m-major tiles: whole 128-byte lines per k-row");
+  return R % 128 == 0 ? ((krow & 3) << 1) : (krow & 2);
+}
+
+template <bool TRANS, int R, int NI, int BK, bool KEY32 = false>
 __device__ __forceinline__ StagePlan<NI> make_plan(int wave, int lane, long ld, int extent_valid) {
   StagePlan<NI> p;
 #pragma unroll
@@ -106,7 +116,7 @@ __device__ __forceinline__ StagePlan<NI> make_plan(int wave, int lane, long ld, 
       const int slot = inst * 64 + lane;  // 16-byte slot of the tile image (SLOTS need not divide 64: R = 192)
       const int krow = slot / SLOTS;
       const int s = slot - krow * SLOTS;
-      const int col = (((s >> 1) ^ mkey<R>(krow)) << 4) + ((s & 1) << 3);
+      const int col = (((s >> 1) ^ (KEY32 ? mkey32<R>(krow) : mkey<R>(krow))) << 4) + ((s & 1) << 3);
       p.kpos[j] = krow;
       p.voff[j] = (col < extent_valid) ? (unsigned)(krow * ld * 2 + col * 2) : OOB;
     }

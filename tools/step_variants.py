@@ -60,7 +60,14 @@ VARIANTS = {
     "nn=c0 ntw=c0 nt=c0": setv(2, nn=0, nt_wide=0, nt=0),
     "one-pass fwd, nn=c13 ntw=c13 nt=c13": setv(2, halves=1, nn=13, nt_wide=13, nt=13),
     "one-pass both, all c13": setv(2, halves=1, bhalves=1, nn=13, nt_wide=13, nt=13),
+    # round 4: the software-pipelined 32x32x16 kernels of csrc/gemm_pp.hip (pass the configuration numbers: pp=<ntw>,<nt>,<nn>)
 }
+for a in list(sys.argv[2:]):
+    if a.startswith("pp="):
+        w, t, n = (int(x) for x in a[3:].split(","))
+        VARIANTS[f"pp ntw={w} nt={t} nn={n}"] = setv(2, nt_wide=w, nt=t, nn=n)
+        sys.argv.remove(a)
+        sys.argv.append(f"pp ntw={w} nt={t} nn={n}")
 if len(sys.argv) > 2:
     sel = sys.argv[2:]
     VARIANTS = {k: v for k, v in VARIANTS.items() if any(s in k for s in sel)}
