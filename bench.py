@@ -525,6 +525,9 @@ def main() -> None:
     ap.add_argument("--gemm-reps", type=int, default=10)
     ap.add_argument("--bucket-mb", type=int, default=64, help="gradient bucket size of the RCCL exchange (sweep on an 8-GPU node)")
     ap.add_argument("--wire-bf16", action="store_true", help="all-reduce bf16 copies of the gradient buckets (half the xGMI bytes)")
+    ap.add_argument("--no-step-in-backward", action="store_true",
+                    help="A/B: one fused Adam(W) launch at the end of the step instead of range updates inside backward")
+    ap.add_argument("--range-mb", type=int, default=32, help="arena range of one in-backward optimizer update")
     ap.add_argument("--comm", default="auto", choices=["auto", "torch", "cfhip"],
                     help="who launches the RCCL collectives: the cfhip_comm_* C-ABI on this package's own, queue-checked "
                          "comm stream (auto with the nccl backend: measured 22.4 ms vs 23.0 ms for the torch.distributed "
@@ -592,7 +595,8 @@ def main() -> None:
     model = C.vit_b16_classifier(1000).to(dev)
     def make_step(comm: str):
         return TrainStep(model, lr=1.0e-4, weight_decay=0.0, decoupled=True, use_graph=args.graph and not args.no_graph,
-                         distributed=distributed, bucket_bytes=args.bucket_mb << 20, wire_bf16=args.wire_bf16, comm=comm)
+                         distributed=distributed, bucket_bytes=args.bucket_mb << 20, wire_bf16=args.wire_bf16, comm=comm,
+                         step_in_backward=not args.no_step_in_backward, range_bytes=args.range_mb << 20)
 
     comm_selftest = None
     if args.comm == "cfhip":

@@ -133,7 +133,7 @@ class BucketedAllReduce:
     def __init__(self, arena: ParamArena, *, process_group: Any = None, bucket_bytes: int = 64 << 20,
                  overlap: bool = True, optimizer: Optional[FusedAdam] = None, average: Optional[bool] = None,
                  finish_after_backward: bool = False, sync_fn: Any = None, wire_bf16: bool = False,
-                 comm: Optional["Communicator"] = None, tail_bytes: int = 4 << 20):
+                 comm: Optional["Communicator"] = None, tail_bytes: int = 4 << 20, step_in_backward: bool = False):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("BucketedAllReduce needs an initialised torch.distributed process group")
         self.arena = arena
@@ -146,6 +146,12 @@ class BucketedAllReduce:
         self.average = (optimizer is None) if average is None else bool(average)
         self.finish_after_backward = finish_after_backward
         self.wire_bf16 = wire_bf16
+        # the fused Adam(W) update of a bucket's arena range right behind its all-reduce, on the comm stream (the arena holds
+        # the rank SUM and the kernel applies 1 / W): see optim.StepInBackward for why no running kernel sees a half-updated
+        # weight.  Not with bf16 on the wire (widened in finish()), not with an averaged arena (a trainer that clips).
+        self.step_in_backward = bool(step_in_backward) and optimizer is not None and not wire_bf16 and arena.flat_g.is_cuda
+        if self.step_in_backward:
+            arena.double_buffer_shadows()
         self.comm = comm  # None: torch.distributed launches the collectives; a Communicator: the cfhip_comm_* C-ABI
         self.is_cuda = arena.flat_g.is_cuda
         self.comm_stream = None
@@ -340,6 +346,10 @@ class BucketedAllReduce:
                     b.work = _StreamWork(self.comm_stream)
                 else:
                     b.work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.step_in_backward and not self.average and self._pass_open:
+                    if self.comm is None:
+                        b.work.wait()  # the process group reduces on a stream of its own: the comm stream follows it
+                    self.optimizer.launch_range(b.start, b.end, self.comm_stream)
         else:
             if self.wire_bf16:
                 wire.copy_(view)

@@ -31,7 +31,7 @@ class TrainStep:
                  eps: float = 1.0e-8, weight_decay: float = 0.0, decoupled: bool = True,
                  use_graph: bool = False, distributed: bool = False, bucket_bytes: int = 64 << 20,
                  output_key: str = "predictions", loss: str = "cross_entropy", clip_norm: float = 0.0,
-                 wire_bf16: bool = False, comm: str = "torch"):
+                 wire_bf16: bool = False, comm: str = "torch", step_in_backward: bool = True, range_bytes: int = 32 << 20):
         if loss not in ("cross_entropy", "focal"):
             raise ValueError(f"unknown loss '{loss}' (cross_entropy: losses/basic.py:126-141, focal: :170-206)")
         self.model = model
@@ -44,6 +44,9 @@ class TrainStep:
         self.optimizer = FusedAdam(None, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                    decoupled=decoupled, arena=self.arena)
         self.optimizer.lazy_zero = True  # every parameter gradient is written by a HIP backward kernel
+        # the optimizer update rides inside backward, range by range (optim.StepInBackward); clipping needs the global norm
+        # first and a hipGraph records the one end-of-step launch
+        in_bwd = bool(step_in_backward) and self.clip_norm == 0.0 and not use_graph and bool(params) and params[0].is_cuda
         if params and params[0].is_cuda:
             SideStream.ensure()  # the stream self-check runs here, not inside the first timed step
         self.reducer: Optional[BucketedAllReduce] = None
@@ -56,8 +59,10 @@ class TrainStep:
             elif comm != "torch":
                 raise ValueError(f"comm = '{comm}': 'torch' (torch.distributed launches the collectives) or 'cfhip'")
             self.reducer = BucketedAllReduce(self.arena, bucket_bytes=bucket_bytes, optimizer=self.optimizer,
-                                             wire_bf16=wire_bf16, comm=communicator)
+                                             wire_bf16=wire_bf16, comm=communicator, step_in_backward=in_bwd)
             self.reducer.broadcast_parameters(0)
+        elif in_bwd:
+            self.optimizer.enable_step_in_backward(range_bytes)
         self.use_graph = use_graph and not distributed
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._static: Dict[str, Tensor] = {}

@@ -47,6 +47,7 @@ class ParamArena:
         self.flat_p = torch.zeros(off, dtype=f32, device=dev)
         self.flat_g = torch.zeros(off, dtype=f32, device=dev)
         self.flat_p16 = torch.zeros(off, dtype=bf16, device=dev) if with_shadow else None
+        self.flat_p16_alt: Optional[Tensor] = None  # second shadow arena (update-in-backward: see double_buffer_shadows)
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 n = p.numel()
@@ -76,6 +77,26 @@ class ParamArena:
             return None
 
         return guard
+
+    def double_buffer_shadows(self) -> None:
+        """A second bf16 shadow arena.  An optimizer that updates parameter ranges while backward is still running
+        (`FusedAdam.enable_step_in_backward`) writes the NEW bf16 weights there: the dX GEMMs of this backward pass keep
+        reading the arena the forward used, and `swap_shadows()` makes the new one current once the step is complete."""
+        if self.flat_p16 is not None and self.flat_p16_alt is None:
+            self.flat_p16_alt = self.flat_p16.clone()
+            # both sets of per-parameter views exist up front: a swap is one attribute store per parameter
+            self._shadow_views = [[p._cfhip_shadow for p in self.params],
+                                  [self.flat_p16_alt[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]]
+            self._shadow_cur = 0
+
+    def swap_shadows(self) -> None:
+        """The shadow arena the optimizer has just filled becomes the one `functional.shadow_bf16` hands out."""
+        if self.flat_p16_alt is None:
+            return
+        self.flat_p16, self.flat_p16_alt = self.flat_p16_alt, self.flat_p16
+        self._shadow_cur ^= 1
+        for p, v in zip(self.params, self._shadow_views[self._shadow_cur]):
+            p._cfhip_shadow = v
 
     def refresh_shadow(self) -> None:
         """bf16 shadow <- fp32 masters (after construction / load_state_dict)."""
@@ -160,9 +181,40 @@ class FusedAdam:
         self._hyper_events: List[Any] = [None] * _HYPER_RING
         self._hyper_host = self._hyper_ring[0]
         self._hyper_dev = torch.zeros(8, dtype=f32, device=a.flat_p.device)
+        self._done: List[Tuple[int, int]] = []  # arena ranges already updated in this step (update-in-backward)
+        self._range_streams: List[Any] = []     # ... and the streams those updates were issued on
+        self.in_backward: Optional["StepInBackward"] = None
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.arena.zero_grad(lazy=self.lazy_zero)
+
+    def enable_step_in_backward(self, range_bytes: int = 32 << 20) -> "StepInBackward":
+        """Update each arena range as soon as every gradient in it is final, on a side stream, while backward is still
+        running (the update is HBM-bound — 30 bytes per parameter — and backward's kernels are matrix-bound); what is left
+        at `launch_step()` is the ranges that closed last.  See `StepInBackward` for what makes that safe."""
+        if self.in_backward is None:
+            self.in_backward = StepInBackward(self, range_bytes)
+        return self.in_backward
+
+    def launch_range(self, lo: int, hi: int, stream: Any = None) -> None:
+        """The update of arena elements [lo, hi) (multiples of 8) on `stream` (default: current).  Element-wise: ranges in
+        any order and number give bit-identical parameters to one launch over the arena."""
+        a = self.arena
+        if hi <= lo:
+            return
+        from . import _lib
+
+        out16 = a.flat_p16_alt if a.flat_p16_alt is not None else a.flat_p16
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream.cuda_stream
+        rc = _lib.load().cfhip_adam_step_dev(
+            a.flat_p.data_ptr() + 4 * lo, a.flat_g.data_ptr() + 4 * lo, self.exp_avg.data_ptr() + 4 * lo,
+            self.exp_avg_sq.data_ptr() + 4 * lo, None if out16 is None else out16.data_ptr() + 2 * lo, hi - lo,
+            self._hyper_dev.data_ptr(), int(self.decoupled), st,
+        )
+        _lib.check(rc, "adam_step_dev")
+        self._done.append((lo, hi))
+        if stream is not None and all(stream != t for t in self._range_streams):
+            self._range_streams.append(stream)
 
     def _fill_hyper(self) -> None:
         g = self.param_groups[0]
@@ -188,11 +240,16 @@ class FusedAdam:
             ev = torch.cuda.Event()
             ev.record()
             self._hyper_events[self.step_count % _HYPER_RING] = ev
+        if self.in_backward is not None:
+            self.in_backward.begin_step()
 
     def set_step_clip(self, coef: Tensor) -> None:
         """Gradient clipping for the NEXT `launch_step()` only: `coef` is a device scalar (<= 1) that multiplies the
         persistent `grad_scale` inside this step's hyper-parameter record ON THE DEVICE — no host read of the norm,
         nothing carried over to later steps (round 1 folded it into `grad_scale` itself: it compounded)."""
+        if self._done:
+            raise RuntimeError("FusedAdam: global-norm clipping needs every gradient before any update — do not enable "
+                               "update-in-backward (enable_step_in_backward) together with clip_norm")
         self._step_clip = coef.reshape(1).to(f32)
 
     def launch_step(self) -> None:
@@ -207,12 +264,29 @@ class FusedAdam:
             self._hyper_dev[7:8].copy_(self._step_clip * float(self.grad_scale))
             self._step_clip = None
 
-        rc = _lib.load().cfhip_adam_step_dev(
-            a.flat_p.data_ptr(), a.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-            None if a.flat_p16 is None else a.flat_p16.data_ptr(), a.total, self._hyper_dev.data_ptr(),
-            int(self.decoupled), torch.cuda.current_stream().cuda_stream,
-        )
-        _lib.check(rc, "adam_step_dev")
+        for st in self._range_streams:  # the caller's stream now follows every range update issued so far
+            torch.cuda.current_stream().wait_stream(st)
+        self._range_streams = []
+        if not self._done:
+            rc = _lib.load().cfhip_adam_step_dev(
+                a.flat_p.data_ptr(), a.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                None if (a.flat_p16_alt if a.flat_p16_alt is not None else a.flat_p16) is None
+                else (a.flat_p16_alt if a.flat_p16_alt is not None else a.flat_p16).data_ptr(),
+                a.total, self._hyper_dev.data_ptr(), int(self.decoupled), torch.cuda.current_stream().cuda_stream,
+            )
+            _lib.check(rc, "adam_step_dev")
+        else:  # what the in-backward updates left: the complement of the ranges already done
+            done = sorted(self._done)
+            self._done = []
+            pos = 0
+            for lo, hi in done:
+                if lo > pos:
+                    self.launch_range(pos, lo)
+                pos = max(pos, hi)
+            if pos < a.total:
+                self.launch_range(pos, a.total)
+            self._done = []
+        a.swap_shadows()
 
     def step(self, closure: Any = None) -> None:
         self.prepare_step()
@@ -228,6 +302,101 @@ class FusedAdam:
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)
+
+
+class StepInBackward:
+    """The optimizer step inside the backward pass: the gradient arena is cut into ranges
+    (whole parameters, last-registered first — the order backward produces them); the HIP backward kernels announce every
+    parameter gradient they have written (`functional.grad_ready_callbacks`); when the last gradient of a range is in, the
+    fused Adam(W) kernel runs over that range on its own stream, ordered after every stream that wrote into it.  The
+    reference steps the optimizer after backward (schema.py:977-986 -> optimizers.py:29-33); element for element the
+    update is the same kernel on the same inputs, so the parameters are bit-identical to the end-of-step launch
+    (tests/test_gpu_train.py).
+
+    Why nothing still running can see a half-updated weight:
+      * GEMMs and convolutions read bf16 SHADOWS of the weights; the range updates write the new shadows into a second
+        arena (`ParamArena.double_buffer_shadows`) that becomes current when the step is complete;
+      * fp32 masters are read during backward only by the normalisation kernels (gamma), and the kernel that reads a
+        gamma is the one that writes — and announces — its gradient;
+      * a parameter whose gradient arrives through autograd's own accumulation never announces, so its range stays
+        open until `launch_step()`; a parameter that announces twice in one pass (shared weights) after its range was
+        updated is an error (construct the step engine with `step_in_backward=False` for such models).
+    Not combined with global-norm clipping (the norm needs every gradient first) — `FusedAdam.set_step_clip` refuses."""
+
+    def __init__(self, optimizer: FusedAdam, range_bytes: int = 32 << 20):
+        from . import functional as HF
+
+        self.opt = optimizer
+        a = optimizer.arena
+        a.double_buffer_shadows()
+        self.ranges: List[List[int]] = []  # [start, end, pending, n_params]
+        self.range_of = [0] * len(a.params)
+        ids: List[int] = []
+        end, acc = a.total, 0
+        for i in range(len(a.params) - 1, -1, -1):
+            ids.append(i)
+            acc += a.params[i].numel() * 4
+            if acc >= range_bytes or i == 0:
+                for j in ids:
+                    self.range_of[j] = len(self.ranges)
+                self.ranges.append([a.offsets[i], end, len(ids), len(ids)])
+                end, ids, acc = a.offsets[i], [], 0
+        self._index = {id(p): i for i, p in enumerate(a.params)}
+        self._ready = [False] * len(a.params)
+        self._launched = [False] * len(self.ranges)
+        self.enabled = True
+        self.stream = None
+        if a.flat_p.is_cuda:
+            HF.SideStream.ensure()
+            self.stream = HF.SideStream.get(0)  # the weight-gradient lane: most ranges close behind a grouped dW launch on it
+        self.launched_in_backward = 0  # ranges of the last step that did not wait for launch_step()
+        HF.grad_ready_callbacks.append(self._on_grad)
+
+    def close(self) -> None:
+        from . import functional as HF
+
+        if self._on_grad in HF.grad_ready_callbacks:
+            HF.grad_ready_callbacks.remove(self._on_grad)
+
+    def begin_step(self) -> None:
+        for r in self.ranges:
+            r[2] = r[3]
+        self._ready = [False] * len(self._ready)
+        self._launched = [False] * len(self.ranges)
+        self.launched_in_backward = 0
+
+    def _on_grad(self, p: Tensor) -> None:
+        i = self._index.get(id(p))
+        if i is None or not self.enabled or self.stream is None:
+            return
+        ri = self.range_of[i]
+        if self._ready[i]:
+            if self._launched[ri]:
+                raise RuntimeError(f"parameter #{i} {tuple(p.shape)}: gradient written again after its range was updated "
+                                   "(shared weights): build the step engine with step_in_backward=False")
+            return
+        self._ready[i] = True
+        r = self.ranges[ri]
+        r[2] -= 1
+        if r[2] == 0:
+            self._launch(ri)
+
+    def _launch(self, ri: int) -> None:
+        from . import functional as HF
+
+        if torch.cuda.is_current_stream_capturing():
+            return  # a hipGraph capture records the end-of-step launch instead
+        r = self.ranges[ri]
+        st = self.stream
+        cur = torch.cuda.current_stream()
+        if cur != st:
+            st.wait_stream(cur)
+        for side in HF.SideStream.streams:  # batch slices of the backward, LayerNorm parameter gradients
+            if side is not None and side != st:
+                st.wait_stream(side)
+        self.opt.launch_range(r[0], r[1], st)
+        self._launched[ri] = True
+        self.launched_in_backward += 1
 
 
 class FusedAdamOptimizer(torch.optim.Optimizer):

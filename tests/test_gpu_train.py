@@ -33,7 +33,7 @@ def test_one_adamw_step_matches_oracle(golden):
 
     g, m = _small(golden)
     lr, wd = 1e-3, 0.01
-    ts = TrainStep(m, lr=lr, weight_decay=wd, decoupled=True)
+    ts = TrainStep(m, lr=lr, weight_decay=wd, decoupled=True, step_in_backward=False)  # (the gradients are read back below)
     img, labels = g["img"].to(DEV), g["labels"].view(-1).to(DEV)
     for step in (1, 2):  # the second step exercises non-trivial moments and bias corrections
         ts.optimizer.prepare_step()
@@ -56,6 +56,47 @@ def test_one_adamw_step_matches_oracle(golden):
         assert (ts.optimizer.exp_avg.cpu() - m0).abs().max().item() <= 1e-6 * max(1.0, m0.abs().max().item())
     for p in ts.arena.params:
         assert torch.equal(p._cfhip_shadow.cpu(), p.detach().cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("range_bytes", [64 << 10, 1 << 20, 32 << 20])
+def test_optimizer_step_inside_backward_is_bit_identical(golden, range_bytes):
+    """`optim.StepInBackward`: the arena ranges are updated on a side stream as soon as their gradients are final, while
+    backward is still running.  After every step: parameters, moments and the (swapped-in) bf16 shadows are bit-equal to ONE
+    launch of the same kernel over the whole arena on the state before the step and the gradients this backward left in the
+    arena (a range updated before its last gradient kernel had finished, or twice, cannot pass), ranges really were launched
+    from inside backward, and the trajectory follows the end-of-step engine."""
+    from cflearn_amd import _lib
+
+    g, m1 = _small(golden)
+    _, m2 = _small(golden)
+    img, labels = g["img"].to(DEV), g["labels"].view(-1).to(DEV)
+    ref = TrainStep(m1, lr=2e-3, weight_decay=0.01, step_in_backward=False)
+    ovl = TrainStep(m2, lr=2e-3, weight_decay=0.01, step_in_backward=True, range_bytes=range_bytes)
+    assert ref.optimizer.in_backward is None and ovl.optimizer.in_backward is not None
+    opt, ar = ovl.optimizer, ovl.arena
+    for step in range(4):
+        p0, m0, v0 = ar.flat_p.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()
+        l_ref = ref.step(img, labels).item()
+        l_ovl = ovl.step(img, labels).item()
+        torch.cuda.synchronize()
+        # (LayerNorm parameter gradients of this 128-wide model come from the atomic round-1 kernel: not bitwise reproducible
+        # between two runs, so the reference update is applied to the gradients of THIS run)
+        p16 = torch.empty(ar.total, dtype=torch.bfloat16, device=DEV)
+        rc = _lib.load().cfhip_adam_step_dev(p0.data_ptr(), ar.flat_g.data_ptr(), m0.data_ptr(), v0.data_ptr(), p16.data_ptr(), ar.total,
+                                             opt._hyper_dev.data_ptr(), int(opt.decoupled), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "adam_step_dev")
+        torch.cuda.synchronize()
+        assert torch.equal(p0, ar.flat_p), step
+        assert torch.equal(m0, opt.exp_avg) and torch.equal(v0, opt.exp_avg_sq), step
+        assert torch.equal(p16, ar.flat_p16), step  # the shadow arena that is current after the swap
+        for p in ar.params:
+            assert ar.flat_p16.data_ptr() <= p._cfhip_shadow.data_ptr() < ar.flat_p16.data_ptr() + 2 * ar.total
+            assert torch.equal(p._cfhip_shadow, p.detach().to(torch.bfloat16))
+        if range_bytes < (32 << 20):
+            assert opt.in_backward.launched_in_backward >= 2, opt.in_backward.launched_in_backward
+        assert not opt._done
+        assert abs(l_ref - l_ovl) <= 1e-4 * abs(l_ref), (step, l_ref, l_ovl)
+        assert (ref.arena.flat_p - ar.flat_p).abs().max().item() <= 1e-5  # same trajectory (up to those LayerNorm atomics)
 
 
 def test_training_reduces_loss_and_graph_matches_eager(golden):

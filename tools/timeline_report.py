@@ -13,10 +13,17 @@ def main() -> None:
     back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rows = list(csv.DictReader(gzip.open(path, "rt") if path.endswith(".gz") else open(path)))
     rows = [dict(q=r["queue"], name=r["name"], s=float(r["start_us"]), d=float(r["dur_us"])) for r in rows]
-    adam = [r for r in rows if "adam_dev" in r["name"]]
-    if len(adam) < back + 1:
-        raise SystemExit("not enough steps in the trace")
-    t0, t1 = adam[-back - 1]["s"] + adam[-back - 1]["d"], adam[-back]["s"] + adam[-back]["d"]
+    # a step = from the first kernel of one forward (the patch embedding's im2row) to the next (round 4: the optimizer runs as
+    # several range launches inside backward, so "the Adam kernel" no longer marks the end of a step); traces without an
+    # im2row kernel fall back to the round-1..3 rule (end of one adam_dev_kernel to the end of the next)
+    marks = [r for r in rows if "im2row" in r["name"]]
+    if len(marks) >= back + 1:
+        t0, t1 = marks[-back - 1]["s"], marks[-back]["s"]
+    else:
+        adam = [r for r in rows if "adam_dev" in r["name"]]
+        if len(adam) < back + 1:
+            raise SystemExit("not enough steps in the trace")
+        t0, t1 = adam[-back - 1]["s"] + adam[-back - 1]["d"], adam[-back]["s"] + adam[-back]["d"]
     step = [r for r in rows if t0 <= r["s"] < t1]
     print(f"step window {t1 - t0:.1f} us, {len(step)} kernels")
     xent = [r for r in step if "xent" in r["name"]]
