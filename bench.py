@@ -485,6 +485,11 @@ def self_launch(n: int, argv: list) -> int:
         return 2
     env = dict(os.environ, CFHIP_BENCH_LAUNCHER="self", MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL peer buffers)
+    for i, a in enumerate(argv):  # --nchannels N: RCCL reads the variable when the communicator is created
+        if a == "--nchannels" and i + 1 < len(argv) and int(argv[i + 1]) > 0:
+            env["NCCL_MAX_NCHANNELS"] = argv[i + 1]
+        elif a.startswith("--nchannels=") and int(a.split("=", 1)[1]) > 0:
+            env["NCCL_MAX_NCHANNELS"] = a.split("=", 1)[1]
     env.setdefault("OMP_NUM_THREADS", "8")
     cmd = launch_command(n, argv, free_port())
     print(f"[bench] starting {n} ranks: {' '.join(cmd[1:10])} ...", file=sys.stderr, flush=True)
@@ -525,6 +530,11 @@ def main() -> None:
     ap.add_argument("--gemm-reps", type=int, default=10)
     ap.add_argument("--bucket-mb", type=int, default=64, help="gradient bucket size of the RCCL exchange (sweep on an 8-GPU node)")
     ap.add_argument("--wire-bf16", action="store_true", help="all-reduce bf16 copies of the gradient buckets (half the xGMI bytes)")
+    ap.add_argument("--nchannels", type=int, default=0,
+                    help="NCCL_MAX_NCHANNELS for the ranks (RCCL's kernels take one workgroup per channel: fewer channels leave more "
+                         "CUs to a step whose kernels already share the chip; 0 = RCCL's default).  Sweep on an 8-GPU node.")
+    ap.add_argument("--allow-aliased-streams", action="store_true",
+                    help="do not fail a multi-GPU run whose helper streams had to share a hardware queue (see `streams` in the JSON line)")
     ap.add_argument("--no-step-in-backward", action="store_true",
                     help="A/B: one fused Adam(W) launch at the end of the step instead of range updates inside backward")
     ap.add_argument("--range-mb", type=int, default=32, help="arena range of one in-backward optimizer update")
@@ -571,6 +581,8 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or args.force_ddp
+    if args.nchannels > 0:  # (also when an external launcher started the ranks; RCCL reads it at communicator creation)
+        os.environ["NCCL_MAX_NCHANNELS"] = str(args.nchannels)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -735,8 +747,11 @@ def main() -> None:
             "launch": "hipGraph replay" if ts.use_graph else "eager",
             "input": "resident in HBM" if feed is None else "host numpy -> TensorBatcher (copy stream, 1 batch ahead, device buffer ring)",
             "grad_exchange": "none" if not distributed else (
-                f"bucketed RCCL all-reduce {'bf16 wire' if args.wire_bf16 else 'fp32'}, {args.bucket_mb} MB buckets "
-                f"({len(ts.reducer.buckets)}), side stream, launched by {args.comm}"),
+                f"bucketed {'RCCL' if args.backend == 'nccl' else args.backend} all-reduce {'bf16 wire' if args.wire_bf16 else 'fp32'}, "
+                f"{args.bucket_mb} MB buckets ({len(ts.reducer.buckets)}), comm stream, launched by {args.comm}"),
+            "optimizer": ("fused AdamW, arena ranges updated inside backward" + (" behind each bucket's all-reduce" if distributed else "")
+                          if (ts.optimizer.in_backward is not None or (ts.reducer is not None and ts.reducer.step_in_backward))
+                          else "fused AdamW, one launch at the end of the step"),
             "loss_first_step": None if first_loss is None else round(first_loss, 4),
             "loss_last_step": round(last_loss, 4),
         },
@@ -747,10 +762,16 @@ def main() -> None:
         "launcher": ("bench.py started its own ranks (torch.distributed.run)" if os.environ.get("CFHIP_BENCH_LAUNCHER") == "self"
                      else "external torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process"),
     }
+    from cflearn_amd.functional import stream_report
+
+    result["streams"] = stream_report()  # helper streams on hardware queues of their own? (False = a serialised step)
     if distributed:
         result["rccl"] = {
             "ranks": dist.get_world_size(), "backend": args.backend, "collectives_launched_by": args.comm,
-            "communicator_ranks": (ts.reducer.comm.world if (ts.reducer is not None and ts.reducer.comm is not None) else None),
+            # what RCCL itself reports for the C-ABI communicator (ncclCommCount / ncclCommUserRank), not this script's bookkeeping
+            "communicator_ranks": (ts.reducer.comm.count()[0] if (ts.reducer is not None and ts.reducer.comm is not None) else None),
+            "communicator_rank": (ts.reducer.comm.count()[1] if (ts.reducer is not None and ts.reducer.comm is not None) else None),
+            "max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS", "default"),
             "self_test": comm_selftest, "buckets": len(ts.reducer.buckets) if ts.reducer is not None else 0,
             "bucket_mb": args.bucket_mb, "wire": "bf16" if args.wire_bf16 else "fp32",
         }
@@ -826,11 +847,24 @@ def main() -> None:
         note("cpu baseline (the reference's PyTorch-CPU step on the host cores) ...")
         result["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
         note("cpu baseline done")
+    # a helper stream that shares a hardware queue turns the overlapped step into a serialised one: every rank looks at its own
+    # check, rank 0 prints the line either way, and a multi-GPU run FAILS on it (the first scaling curve must not silently be
+    # the serialised one; --allow-aliased-streams to measure that case on purpose)
+    aliased = not result["streams"]["distinct"]
+    if distributed:
+        flag = torch.tensor([1 if aliased else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        aliased = bool(flag.item())
+        result["streams"]["distinct_on_every_rank"] = not aliased
     if rank == 0:
         print(json.dumps(result))
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if aliased and world > 1 and not args.allow_aliased_streams:
+        print("[bench] a helper stream had to share a hardware queue (see `streams`): the step ran serialised; failing the run "
+              "(--allow-aliased-streams to accept it)", file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -158,6 +158,7 @@ SIGNATURES = {
     "cfhip_comm_unique_id": (c_int, [_P]),
     "cfhip_comm_init": (c_int, [c_int, c_int, _P, _P]),
     "cfhip_comm_destroy": (c_int, [_P]),
+    "cfhip_comm_count": (c_int, [_P, _P, _P]),
     "cfhip_comm_allreduce": (c_int, [_P, _P, c_size_t, c_int, _P]),
     "cfhip_comm_allgather": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
     "cfhip_comm_reduce_scatter": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),

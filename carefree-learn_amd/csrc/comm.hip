@@ -21,6 +21,8 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -51,6 +53,8 @@ bool load_rccl() {
   CFHIP_SYM(GetUniqueId, "ncclGetUniqueId")
   CFHIP_SYM(CommInitRank, "ncclCommInitRank")
   CFHIP_SYM(CommDestroy, "ncclCommDestroy")
+  CFHIP_SYM(CommCount, "ncclCommCount")
+  CFHIP_SYM(CommUserRank, "ncclCommUserRank")
   CFHIP_SYM(AllReduce, "ncclAllReduce")
   CFHIP_SYM(AllGather, "ncclAllGather")
   CFHIP_SYM(ReduceScatter, "ncclReduceScatter")
@@ -105,6 +109,15 @@ extern "C" int cfhip_comm_destroy(void* comm) {
   if (comm == nullptr) return CFHIP_OK;
   if (!load_rccl()) return CFHIP_ERR_LAUNCH;
   CFHIP_RCCL(g_rccl.CommDestroy(reinterpret_cast<ncclComm_t>(comm)), "ncclCommDestroy");
+  return CFHIP_OK;
+}
+
+// What RCCL itself says about the communicator (not the caller's bookkeeping): ranks in it and this process's rank.
+extern "C" int cfhip_comm_count(void* comm, int* world, int* rank) {
+  CFHIP_REQUIRE(comm != nullptr && world != nullptr, "comm_count: null pointer");
+  if (!load_rccl()) return CFHIP_ERR_LAUNCH;
+  CFHIP_RCCL(g_rccl.CommCount(reinterpret_cast<ncclComm_t>(comm), world), "ncclCommCount");
+  if (rank != nullptr) CFHIP_RCCL(g_rccl.CommUserRank(reinterpret_cast<ncclComm_t>(comm), rank), "ncclCommUserRank");
   return CFHIP_OK;
 }
 

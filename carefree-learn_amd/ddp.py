@@ -77,6 +77,14 @@ class Communicator:
         _lib.check(lib.cfhip_comm_init(self.rank, self.world, raw, ctypes.byref(handle)), "comm_init")
         self.handle = handle
 
+    def count(self) -> tuple:
+        """(ranks, this rank) as RCCL reports them for the communicator (ncclCommCount / ncclCommUserRank)"""
+        import ctypes
+
+        world, rank = ctypes.c_int(-1), ctypes.c_int(-1)
+        self._lib.check(self._lib.load().cfhip_comm_count(self.handle, ctypes.byref(world), ctypes.byref(rank)), "comm_count")
+        return world.value, rank.value
+
     @staticmethod
     def _dt(t: Tensor) -> int:
         if t.dtype == torch.float32:

@@ -55,6 +55,7 @@ deferred_grad_flushes: List[Callable[[], None]] = []
 # GPU_MAX_HW_QUEUES to 8 makes the DDP step SLOWER (27.5 ms, three alternating runs), so the default is left alone.
 _SPIN_US = 300
 _rejected_streams: List["torch.cuda.Stream"] = []  # kept alive so that their queue slot stays taken
+_stream_checks: List[dict] = []  # one record per distinct_stream() call: what stream_report() sums up
 
 
 def _overlap(streams: List["torch.cuda.Stream"]) -> bool:
@@ -76,18 +77,31 @@ def distinct_stream(others: List["torch.cuda.Stream"], tries: int = 12) -> "torc
     """A new stream whose kernels run concurrently with those of every stream in `others` (and of the current one)."""
     base = [torch.cuda.current_stream()] + [st for st in others if st is not None]
     first = None
-    for _ in range(tries):
+    for n in range(tries):
         cand = torch.cuda.Stream()
         first = first or cand
         # pairwise against each stream: robust to `others` that already alias one another
         if all(_overlap([st, cand]) for st in base):
+            _stream_checks.append(dict(distinct=True, tries=n + 1, against=len(base)))
             return cand
         _rejected_streams.append(cand)
     import warnings
 
+    _stream_checks.append(dict(distinct=False, tries=tries, against=len(base)))
     warnings.warn("cfhip: no helper stream on its own hardware queue after %d tries (GPU_MAX_HW_QUEUES=%s): "
                   "side-stream work will serialise with the compute stream" % (tries, os.environ.get("GPU_MAX_HW_QUEUES")))
     return first
+
+
+def stream_report() -> dict:
+    """What the helper-stream checks of this process found: `distinct` is False as soon as ONE helper stream (batch slice,
+    weight-gradient lane, comm stream) had to share a hardware queue with a stream it must overlap with — the step then
+    still computes the same numbers, serialised (22.9 -> 26.8 ms when it happened in round 1).  The budget: ROCclr
+    multiplexes HIP streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; the step uses the caller's stream, two
+    side lanes (SideStream.lanes) and — data parallel — one comm stream: four."""
+    return dict(distinct=all(c["distinct"] for c in _stream_checks), helper_streams=len(_stream_checks),
+                tries=max([c["tries"] for c in _stream_checks] or [0]), rejected=len(_rejected_streams),
+                max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"))
 
 
 # torch.cuda.current_stream() / torch.cuda.stream(...) walk four Python layers per call (9 / ~20 us); the side-stream
@@ -142,9 +156,14 @@ class on_stream:
 
 class SideStream:
     enabled = True
-    lanes = 3  # side streams (0: weight-gradient launches, second forward slice; 1, 2: further batch slices of the forward / backward)
+    # side streams: lane 0 carries the weight-gradient launches (and the forward's second batch slice), lane 1 the backward's
+    # second batch slice.  TWO, not more: with the caller's stream and the comm stream of a data-parallel run that is the four
+    # hardware queues ROCclr has by default — a third lane (three batch slices measured slower anyway) left the comm stream
+    # without a queue of its own in every ProcessGroup run of round 3.  fused.py raises it when
+    # CFHIP_FWD_HALVES / CFHIP_BWD_HALVES ask for more slices.
+    lanes = 2
     heavy = True  # False: the dW GEMMs stay on the caller's stream, only the small reductions go aside
-    streams: List[Optional["torch.cuda.Stream"]] = [None, None, None]
+    streams: List[Optional["torch.cuda.Stream"]] = [None, None, None, None]
     keep: List[Tensor] = []  # operands produced on the main stream, alive until the join
 
     _join_queued = False

@@ -320,6 +320,7 @@ def _slice_cuts(bsz: int, n: int) -> list:
 # attention beside GEMMs).  Every operator of the chain is row- or sample-wise except the LayerNorm parameter gradients
 # (column sums over ALL rows): slice i + 1's LayerNorm-backward launch waits for slice i's (one event) and accumulates.
 BWD_HALVES = int(os.environ.get("CFHIP_BWD_HALVES", "2"))
+SideStream.lanes = min(4, max(SideStream.lanes, BWD_HALVES, FWD_HALVES - 1))  # lane 0: dW / forward slice 1; lanes 1 ..: backward slices
 
 
 def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_mask: Optional[Tensor],

@@ -264,6 +264,8 @@ class FusedAdam:
             self._hyper_dev[7:8].copy_(self._step_clip * float(self.grad_scale))
             self._step_clip = None
 
+        if self.in_backward is not None:
+            self.in_backward.end_step()
         for st in self._range_streams:  # the caller's stream now follows every range update issued so far
             torch.cuda.current_stream().wait_stream(st)
         self._range_streams = []
@@ -345,6 +347,7 @@ class StepInBackward:
         self._ready = [False] * len(a.params)
         self._launched = [False] * len(self.ranges)
         self.enabled = True
+        self.armed = False  # between prepare_step() and launch_step()
         self.stream = None
         if a.flat_p.is_cuda:
             HF.SideStream.ensure()
@@ -359,15 +362,21 @@ class StepInBackward:
             HF.grad_ready_callbacks.remove(self._on_grad)
 
     def begin_step(self) -> None:
+        """`FusedAdam.prepare_step()`: the hyper-parameter record of this step is on its way — updates may start.  A backward
+        pass outside a prepare_step() / launch_step() pair (somebody only wants gradients) updates nothing."""
         for r in self.ranges:
             r[2] = r[3]
         self._ready = [False] * len(self._ready)
         self._launched = [False] * len(self.ranges)
         self.launched_in_backward = 0
+        self.armed = True
+
+    def end_step(self) -> None:
+        self.armed = False
 
     def _on_grad(self, p: Tensor) -> None:
         i = self._index.get(id(p))
-        if i is None or not self.enabled or self.stream is None:
+        if i is None or not self.enabled or not self.armed or self.stream is None:
             return
         ri = self.range_of[i]
         if self._ready[i]:

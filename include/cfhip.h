@@ -503,6 +503,8 @@ int cfhip_ml_encode_bwd(const float* dout, const float* x, int64_t B, int F, int
 int cfhip_comm_unique_id(void* out128);
 int cfhip_comm_init(int rank, int world, const void* uid128, void** comm);
 int cfhip_comm_destroy(void* comm);
+/* ncclCommCount / ncclCommUserRank of the communicator: what RCCL reports, for the benchmark's evidence line (`rank` may be NULL) */
+int cfhip_comm_count(void* comm, int* world, int* rank);
 int cfhip_comm_allreduce(void* comm, void* buf, size_t count, int dtype, void* stream);
 int cfhip_comm_allgather(void* comm, const void* send, void* recv, size_t count_per_rank, int dtype, void* stream);
 int cfhip_comm_reduce_scatter(void* comm, const void* send, void* recv, size_t count_per_rank, int dtype, void* stream);

@@ -83,6 +83,15 @@ def test_reference_step_engine_drives_the_hip_path(golden, one_rank_rccl, lazy, 
     # round 3: under RCCL the callback owns a C-ABI communicator (cfhip_comm_*): its collectives run on this package's own,
     # queue-checked comm stream, not on the ProcessGroup's internal one
     assert cb.reducer.comm is not None and cb.reducer.comm.world == 1
+    assert cb.reducer.comm.count() == (1, 0)  # ncclCommCount / ncclCommUserRank: what RCCL says, not the Python bookkeeping
+    # round 4: the stream plan fits the four hardware queues WITH a ProcessGroup alive — caller's stream,
+    # two side lanes, comm stream: every helper stream passed its own-queue check (round 3 warned here in all four cases)
+    from cflearn_amd import functional as HF
+
+    rep = HF.stream_report()
+    assert rep["distinct"], rep
+    assert HF.SideStream.lanes == 2 and cb.reducer.comm_stream is not None
+    assert HF._overlap([torch.cuda.current_stream(), cb.reducer.comm_stream] + [st for st in HF.SideStream.streams if st is not None])
     got = [float(d[TO.LOSS_KEY]) for d in eng.loss_log]
     assert all(torch.isfinite(torch.tensor(got)))
     if lazy:
