@@ -331,3 +331,54 @@ def test_attention_at_the_unet_token_counts(t, dh):
     ops.attn_bwd(q, k, v, o, d_o, lse, h, dq=dq, dk=dk, dv=dv, head_dim=dh)
     for nm, got, leaf in (("dq", dq, leaves[0]), ("dk", dk, leaves[1]), ("dv", dv, leaves[2])):
         assert_close(got, leaf.grad, 2e-2, f"{nm} T={t} dh={dh}", abs_floor=1e-6)
+
+
+def test_attention_at_the_256px_unet_level_sampled():
+    """T = 65 536 tokens, 8 heads of 40 channels, batch 1: the full-resolution self-attention of the DDPM UNet at 256^2
+    (BASELINE config 4; mixed_stacks/api.py:766-893 -> attentions.py:498-569 -> toolkit.py:911-974) — the three kernels that
+    are 72 % of that step (`attn_fwd2_kernel<true,3,true>`, `attn_bwd_dq2_kernel<true,3>`, `attn_bwd_dkv2_kernel<true,3>`) and
+    were compared with fp32 math only up to T = 16 384.  The T x T scores do not fit as one tensor: the fp32
+    reference walks the query rows in chunks of 1 024 (output and log-sum-exp of EVERY row), dQ is checked on 256 sampled
+    query rows against all 65 536 keys, dK / dV on 256 sampled keys against all 65 536 queries."""
+    b, h, t, dh = 1, 8, 65536, 40
+    d = h * dh
+    scale = 1.0 / math.sqrt(dh)
+    g = torch.Generator(device=DEV).manual_seed(65536)
+    rnd = lambda *s: torch.randn(*s, generator=g, device=DEV).to(torch.bfloat16)  # noqa: E731
+    q, k, v, d_o = rnd(b, t, d), rnd(b, t, d), rnd(b, t, d), rnd(b, t, d)
+    o, lse = ops.attn_fwd(q, k, v, h, head_dim=dh)
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    ops.attn_bwd(q, k, v, o, d_o, lse, h, dq=dq, dk=dk, dv=dv, head_dim=dh)
+
+    hd = lambda z: z.float().reshape(t, h, dh).permute(1, 0, 2).contiguous()  # noqa: E731  [h, T, dh]
+    qf, kf, vf, dof = hd(q[0]), hd(k[0]), hd(v[0]), hd(d_o[0])
+    want_o = torch.empty(h, t, dh, device=DEV)
+    want_lse = torch.empty(h, t, device=DEV)
+    for r0 in range(0, t, 1024):
+        s = (qf[:, r0:r0 + 1024] @ kf.transpose(1, 2)) * scale          # [h, 1024, T] fp32: 2 GB
+        want_lse[:, r0:r0 + 1024] = torch.logsumexp(s, -1)
+        want_o[:, r0:r0 + 1024] = torch.softmax(s, -1) @ vf
+        del s
+    assert_close(o[0].float().reshape(t, h, dh).permute(1, 0, 2), want_o, 1e-2, "fwd T=65536 dh=40")
+    assert_close(lse[0], want_lse, 1e-4, "lse T=65536 dh=40")
+    delta = (dof * want_o).sum(-1)                                        # [h, T]
+
+    rows = torch.randperm(t, generator=g, device=DEV)[:256].sort().values
+    s = (qf[:, rows] @ kf.transpose(1, 2)) * scale                        # [h, 256, T]
+    p = torch.exp(s - want_lse[:, rows, None])
+    ds = p * (dof[:, rows] @ vf.transpose(1, 2) - delta[:, rows, None])
+    want_dq = (ds @ kf) * scale                                           # [h, 256, dh]
+    got_dq = dq[0].float().reshape(t, h, dh)[rows].permute(1, 0, 2)
+    assert_close(got_dq, want_dq, 2e-2, "dq (256 sampled query rows, all keys)", abs_floor=1e-6)
+    del s, p, ds
+
+    keys = torch.randperm(t, generator=g, device=DEV)[:256].sort().values
+    s = (qf @ kf[:, keys].transpose(1, 2)) * scale                        # [h, T, 256]
+    p = torch.exp(s - want_lse[:, :, None])
+    want_dv = p.transpose(1, 2) @ dof                                     # [h, 256, dh]
+    ds = p * (dof @ vf[:, keys].transpose(1, 2) - delta[:, :, None])
+    want_dk = (ds.transpose(1, 2) @ qf) * scale
+    got_dk = dk[0].float().reshape(t, h, dh)[keys].permute(1, 0, 2)
+    got_dv = dv[0].float().reshape(t, h, dh)[keys].permute(1, 0, 2)
+    assert_close(got_dv, want_dv, 2e-2, "dv (256 sampled keys, all queries)", abs_floor=1e-6)
+    assert_close(got_dk, want_dk, 2e-2, "dk (256 sampled keys, all queries)", abs_floor=1e-6)

@@ -511,3 +511,113 @@ def test_self_attention_packed_projection_matches_the_three_linears(golden):
         assert any("QKVLinearFn" in type(fn).__name__ for fn in seen)
     finally:
         M.FUSE_SELF_ATTENTION_QKV = keep
+
+
+ZOO_SAMPLED = [
+    "time_embedding.0.weight",                              # sinusoidal embedding -> Linear
+    "input_blocks.0.0.weight",                              # stem: 3 input channels (im2row route)
+    "input_blocks.1.0.conv1.weight",                        # 64^2 x 320: implicit-GEMM 3x3
+    "input_blocks.1.0.norm1.weight",                        # GroupNorm(32) + SiLU
+    "input_blocks.1.0.time_embedding.weight",               # per-block time projection (the add in front of norm2)
+    "input_blocks.1.1.to_latent.weight",                    # 1x1 convolution
+    "input_blocks.1.1.blocks.0.attn1.to_q.weight",          # packed q | k | v projection, T = 4 096, 40-channel heads
+    "input_blocks.1.1.blocks.0.ff.net.0.net.weight",        # GEGLU
+    "input_blocks.3.0.net.weight",                          # strided-convolution down-sampling
+    "input_blocks.4.0.shortcut.weight",                     # 320 -> 640 shortcut
+    "input_blocks.4.0.conv2.weight",                        # 32^2 x 640 (few tiles: split K)
+    "input_blocks.7.1.blocks.0.attn1.out_linear.0.weight",  # 16^2 x 1280, 160-channel heads
+    "input_blocks.10.0.conv1.weight",                       # 8^2 x 1280
+    "residual.0.conv1.weight",                              # middle block
+    "residual.1.blocks.0.ff.net.2.linear.weight",
+    "output_blocks.0.0.conv1.weight",                       # 2560 -> 1280: skip concatenation
+    "output_blocks.2.1.conv.weight",                        # nearest up-sampling + convolution
+    "output_blocks.5.1.blocks.0.attn1.to_k.weight",
+    "output_blocks.11.0.conv1.weight",                      # 640 -> 320 at 64^2
+    "head.0.weight",
+    "head.2.weight",                                        # 3 output channels (padded to 8)
+]
+
+
+def test_unet_zoo_full_size_step_vs_oracle():
+    """The 865 M-parameter zoo UNet (zoo/configs/diffusion/ddpm/default.json: start 320, multipliers 1/2/4/4, SpatialTransformer at
+    rates 1/2/4; multimodal/diffusion/unet.py:97-322, mixed_stacks/api.py:766-893, models/cv/diffusion.py:44-94) — the model
+    bench.py times — at 64^2 x 1 from a seeded initialisation: output, epsilon-prediction MSE loss and 21 sampled parameter
+    gradients (one per resolution level and layer type: shapes the small fixtures never produce — C = 1280 at 8^2, the
+    2560 -> 1280 skip-concatenation convolutions, split-K filter gradients) against `oracle/unet_oracle.py` in fp32 on the host
+    cores of the GPU box (VERDICT r3 #4)."""
+    import os
+    import time
+
+    import unet_oracle as UO
+
+    cfg = dict(in_channels=3, out_channels=3, start_channels=320, num_heads=8, use_spatial_transformer=True,
+               num_transformer_layers=1, num_res_blocks=2, attention_downsample_rates=(1, 2, 4),
+               channel_multipliers=(1, 2, 4, 4), context_dim=None)
+    torch.manual_seed(0)
+    m = C.build_module("unet_diffuser", config=cfg)
+    assert sum(p.numel() for p in m.parameters()) == 865126723  # BASELINE.md §2
+    # the reference zero-initialises the last convolution of every residual block / transformer / the head (`zero_module`):
+    # at that point the output is 0 and every gradient but the head's vanishes — give those tensors seeded small values, as a
+    # few optimizer steps would, so that all 686 tensors take part
+    zeroed = 0
+    with torch.no_grad():
+        for prm in m.parameters():
+            if float(prm.abs().max()) == 0.0:
+                prm.normal_(0.0, 0.02 if prm.dim() > 1 else 0.01)
+                zeroed += 1
+    assert zeroed > 0
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for k in ZOO_SAMPLED:
+        assert k in sd, k
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(1, 3, 64, 64, generator=g).clamp_(-1, 1)
+    t = torch.randint(0, 1000, (1,), generator=g)
+    noise = torch.randn(1, 3, 64, 64, generator=g)
+
+    m = m.to(DEV)
+    y = m(x.to(DEV), timesteps=t.to(DEV), context=None)
+    loss = torch.nn.functional.mse_loss(y.float(), noise.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    got = {k: p.grad.detach().float().cpu() for k, p in m.named_parameters() if k in ZOO_SAMPLED}
+    got_y, got_loss = y.detach().float().cpu(), loss.item()
+    del m, y, loss
+    torch.cuda.empty_cache()
+
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    try:
+        t0 = time.time()
+        leaves = {k: sd[k].requires_grad_(True) for k in ZOO_SAMPLED}
+        want_y = UO.unet_diffuser(x, t, None, sd, cfg)
+        want_loss = torch.nn.functional.mse_loss(want_y, noise)
+        grads = torch.autograd.grad(want_loss, [leaves[k] for k in ZOO_SAMPLED])
+        print(f"oracle forward + backward on the host: {time.time() - t0:.1f} s")
+        # the same arithmetic under bf16 autocast (what the reference runs with mixed_precision="bf16"): how far ANY bf16
+        # execution of this 60-layer network sits from fp32 — the yardstick for the bounds below
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ac_y = UO.unet_diffuser(x, t, None, sd, cfg)
+            ac_loss = torch.nn.functional.mse_loss(ac_y.float(), noise)
+        ac_grads = torch.autograd.grad(ac_loss, [leaves[k] for k in ZOO_SAMPLED])
+    finally:
+        torch.set_num_threads(prev)
+    from helpers import rel_l2
+
+    errs = {k: rel_l2(got[k], ref) for k, ref in zip(ZOO_SAMPLED, grads)}
+    ac_errs = {k: rel_l2(a.float(), ref) for k, a, ref in zip(ZOO_SAMPLED, ac_grads, grads)}
+    y_err, loss_err = rel_l2(got_y, want_y.detach()), abs(got_loss - want_loss.item()) / abs(want_loss.item())
+    ac_y_err = rel_l2(ac_y.detach().float(), want_y.detach())
+    worst = max(errs, key=errs.get)
+    print(f"zoo UNet 64^2 x 1: output rel-L2 {y_err:.3e} (bf16-autocast oracle {ac_y_err:.3e}), loss {got_loss:.6f} vs "
+          f"{want_loss.item():.6f} (rel {loss_err:.2e}); worst sampled gradient rel-L2 {errs[worst]:.3e} ({worst})")
+    for k in ZOO_SAMPLED:
+        print(f"    {k:55s} {errs[k]:.3e}   bf16-autocast oracle {ac_errs[k]:.3e}")
+    # Bounds.  Loss: 2e-3 relative (VERDICT r3; measured 1.7e-4).  Output and gradients: VERDICT r3 proposed 3e-2 for the
+    # gradients; the deepest tensors (8^2 x 1280, the middle block) sit at 4.5-5.2e-2 — and so does the ORACLE's own arithmetic
+    # under bf16 autocast (4.5-4.6e-2 on the same tensors: bf16 rounding through ~30 layers each way), so the bound is
+    # relative to that run: no tensor more than 1.3 x as far from fp32 as the reference's own bf16 execution (measured
+    # 0.9-1.2 x on all 21), and never beyond the small fixture's 8e-2.
+    assert loss_err <= 2e-3, (got_loss, want_loss.item())
+    assert y_err <= max(1e-2, 1.3 * ac_y_err) and y_err <= 2e-2, (y_err, ac_y_err)
+    for k in ZOO_SAMPLED:
+        assert errs[k] <= max(1e-2, 1.3 * ac_errs[k]) and errs[k] <= 8e-2, (k, errs[k], ac_errs[k])
