@@ -155,6 +155,7 @@ SIGNATURES = {
     "cfhip_ml_encode_fwd": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int, _P, _P, _P]),
     "cfhip_ml_encode_indices": (c_int, [_P, c_int64, c_int64, _P, _P, c_int, _P, _P]),
     "cfhip_ml_encode_bwd": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, c_int, _P, _P, _P]),
+    "cfhip_gemm_kernel_name": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t]),
     "cfhip_comm_unique_id": (c_int, [_P]),
     "cfhip_comm_init": (c_int, [c_int, c_int, _P, _P]),
     "cfhip_comm_destroy": (c_int, [_P]),

@@ -234,7 +234,12 @@ class BucketedAllReduce:
         """The other half of the DDP constructor's `_sync_module_states` (torch DDP broadcasts parameters AND buffers at
         wrap time; behind trainer.py:268-272): BatchNorm running statistics, `num_batches_tracked`, attention masks ...
         of every module in `modules` follow rank `src`.  f32 buffers travel as ONE flat tensor.  Returns the number of
-        buffers sent."""
+        buffers sent.
+        Divergence from torch DDP: DDP's default `broadcast_buffers=True` repeats this at EVERY forward, so
+        BatchNorm running statistics are rank 0's everywhere; here they are synchronised when the callback is installed and
+        whenever the caller asks again (`RcclDDPCallback.sync_buffers()`, e.g. before evaluation or a checkpoint) — in between
+        each rank keeps the statistics of its own shard, which does not enter the training arithmetic (train-mode BatchNorm
+        normalises with batch statistics).  Buffers are expected on one device (the rank's GPU)."""
         seen, f32s, others = set(), [], []
         for m in modules:
             for b in m.buffers():
@@ -242,6 +247,9 @@ class BucketedAllReduce:
                     continue
                 seen.add(id(b))
                 (f32s if b.dtype == torch.float32 else others).append(b)
+        devs = {b.device for b in f32s}
+        if len(devs) > 1:
+            raise ValueError(f"broadcast_buffers: buffers on several devices ({sorted(str(d) for d in devs)})")
         if f32s:
             flat = torch.cat([b.detach().reshape(-1) for b in f32s])
             self._broadcast(flat, src)
@@ -429,6 +437,13 @@ class RcclDDPCallback:
         self.comm_mode = comm  # "auto": the cfhip_comm_* C-ABI communicator under the nccl backend, else torch.distributed
         self.reducer: Optional[BucketedAllReduce] = None
 
+    def sync_buffers(self, src: int = 0) -> int:
+        """Every rank's module buffers (BatchNorm running statistics ...) <- rank `src`, again: call before evaluation or a
+        checkpoint when the ranks must agree on them (torch DDP does this at every forward; see `broadcast_buffers`)."""
+        if self.reducer is None:
+            return 0
+        return self.reducer.broadcast_buffers(getattr(self, "_buffer_modules", []), src)
+
     @staticmethod
     def _modules(trainer: Any) -> List[Any]:
         """Everything `accelerator.prepare(*model.all_modules, ...)` wrapped (trainer.py:268-272): the model's modules
@@ -508,6 +523,7 @@ class RcclDDPCallback:
                                          finish_after_backward=True, sync_fn=self._sync_fn(trainer),
                                          comm=self._communicator())
         self.reducer.broadcast_parameters(0)
+        self._buffer_modules = modules
         self.reducer.broadcast_buffers(modules, 0)
         for inner in inners:
             inner.register_step_pre_hook(lambda *_a, **_k: self.reducer.finish())

@@ -193,13 +193,14 @@ class DDPMTrainStep:
 
     def _graph_step(self, x: Tensor, context: Optional[Tensor], timesteps: Tensor, noise: Tensor,
                     labels: Optional[Tensor]) -> Tensor:
-        """`use_graph`: the step is recorded ONCE into a hipGraph (after two eager steps: allocator, side streams, lazy
-        initialisations) and replayed; the ~2 900 launches of a UNet step then cost the host one call (the eager step at
+        """`use_graph`: the step is recorded ONCE into a hipGraph (after two eager passes for the allocator, the side streams
+        and the lazy initialisations, whose updates are rolled back) and replayed; the ~2 900 launches of a UNet step then cost the host one call (the eager step at
         64^2 x 8 is bound by the host's issue rate: 65 ms of Python per 69 ms step).  Inputs are copied into the recorded
         buffers; shapes (and the presence of context / labels) must not change between steps."""
         ins = dict(x=x, context=context, timesteps=timesteps, noise=noise, labels=labels)
         if self._graph is None:
             self._static = {k: (None if v is None else v.clone()) for k, v in ins.items()}
+            snap = self.optimizer.snapshot()  # the two warm-up passes below are not training steps (ADVICE r3)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -208,6 +209,7 @@ class DDPMTrainStep:
                     self._body(**self._static)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            self.optimizer.restore(snap)
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):  # records, does not execute: this call goes on to replay it once
                 self._graph_loss = self._body(**self._static)
@@ -219,4 +221,4 @@ class DDPMTrainStep:
                 st.copy_(v, non_blocking=True)
         self.optimizer.prepare_step()
         self._graph.replay()
-        return self._graph_loss
+        return self._graph_loss.clone()  # (the recorded tensor is overwritten by every replay)

@@ -88,6 +88,7 @@ class TrainStep:
 
     def _capture(self, img: Tensor, labels: Tensor) -> None:
         self._static = dict(img=img.clone(), labels=labels.clone())
+        snap = self.optimizer.snapshot()  # the warm-up passes are not training steps: their updates are rolled back
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up off the capture stream (allocator, lazy inits)
@@ -96,6 +97,7 @@ class TrainStep:
                 self._body(self._static["img"], self._static["labels"])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self.optimizer.restore(snap)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):  # records, does not execute
             self.loss_sum = self._body(self._static["img"], self._static["labels"])
@@ -104,13 +106,13 @@ class TrainStep:
         """Runs one step; returns the device tensor holding the summed CE loss of the batch."""
         if self.use_graph:
             if self._graph is None:
-                self._capture(img, labels)  # 2 eager warm-up steps (real updates), then the recording
+                self._capture(img, labels)  # 2 eager warm-up passes (rolled back), then the recording
             if img.data_ptr() != self._static["img"].data_ptr():
                 self._static["img"].copy_(img, non_blocking=True)
                 self._static["labels"].copy_(labels, non_blocking=True)
             self.optimizer.prepare_step()
             self._graph.replay()
-            return self.loss_sum
+            return self.loss_sum.clone()  # (the recorded tensor is overwritten by every replay)
         self.optimizer.prepare_step()
         self.loss_sum = self._body(img, labels)
         return self.loss_sum

@@ -88,6 +88,9 @@ _end_flush_queued = False
 
 def _groupable(w: Tensor, dy2: Tensor, x2: Tensor) -> bool:
     n, k = dy2.shape[1], x2.shape[1]
+    g = w.grad  # a user-replaced `.grad` that the grouped kernel could not write (strided / unaligned): the split-K path takes it
+    if g is not None and (not g.is_contiguous() or g.data_ptr() % 16 != 0 or g.dtype != f32):
+        return False
     return (dy2.is_cuda and w.numel() == n * k and w.is_contiguous() and n % 8 == 0 and k % 8 == 0 and dy2.stride(0) % 8 == 0
             and x2.stride(0) % 8 == 0 and x2.shape[0] * max(dy2.stride(0), x2.stride(0)) * 2 < 2 ** 31
             and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0)
@@ -499,6 +502,9 @@ class MixingStackFn(Function):
                 for st in streams[1:]:
                     _functional.cur_stream().wait_stream(st)
                 SideStream.keep.append(d2)  # written by both slice streams, allocated on the caller's
+        except BaseException:
+            _pending_dw.clear()  #  nothing queued by a failed pass may be flushed into `.grad` by the next one
+            raise
         finally:
             _slice_streams[:] = []
         return (d2.view(bsz, t, d), None, None, None) + (None,) * len(ctx.params)

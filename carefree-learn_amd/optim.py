@@ -294,6 +294,25 @@ class FusedAdam:
         self.prepare_step()
         self.launch_step()
 
+    def snapshot(self) -> Dict[str, Any]:
+        """Everything a step changes (masters, current bf16 shadows, moments, step counter): a hipGraph capture runs eager
+        warm-up steps for the allocator and the lazy initialisations — `restore()` afterwards, so that the first replay is
+        the FIRST update of its batch (three updates of the first batch, bias corrections advanced by 3)."""
+        a = self.arena
+        return dict(p=a.flat_p.clone(), p16=None if a.flat_p16 is None else a.flat_p16.clone(), m=self.exp_avg.clone(),
+                    v=self.exp_avg_sq.clone(), step=self.step_count)
+
+    def restore(self, snap: Dict[str, Any]) -> None:
+        a = self.arena
+        a.flat_p.copy_(snap["p"])
+        if a.flat_p16 is not None:
+            a.flat_p16.copy_(snap["p16"])  # (whichever shadow arena is current now: both hold pre-step values afterwards)
+            if a.flat_p16_alt is not None:
+                a.flat_p16_alt.copy_(snap["p16"])
+        self.exp_avg.copy_(snap["m"])
+        self.exp_avg_sq.copy_(snap["v"])
+        self.step_count = snap["step"]
+
     def state_dict(self) -> Dict[str, Any]:
         return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq,
                     param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])

@@ -38,12 +38,16 @@ extern "C" {
 int cfhip_version(void);
 const char* cfhip_last_error(void);
 /* tuning knobs (process-wide, used by the benchmarks' A/B runs; defaults are the shipped behaviour):
- *   "gemm_config"     -1 (shape heuristic, default) or 0..14 to force one tile configuration
+ *   "gemm_config"     -1 (shape heuristic, default) or 0..20 to force one tile configuration
  *                     (0: 128x128x64, 1: 128x128x32, 3: 128x64x64, 7: 256x256x32 two-group kernel,
- *                      8: 256x128x32 two-group kernel, 13: 256x256x64, 14: 192x128x64, ...; see csrc/gemm.hip)
- *   "gemm_heuristic"  1..7, which shape -> configuration table pick_config() uses (default 7: every M >= 1024 forward and
- *                     dX GEMM on 192x128x64, single dW GEMMs on 128x128x32; 6: the round-2 table — forward on the BK = 64
- *                     configurations, dX on the 256x128x32 two-group kernel)
+ *                      8: 256x128x32 two-group kernel, 13: 256x256x64, 14 / 15: 192x128x64 on eight / four waves, 16: 128x256x64;
+ *                      17..20: the software-pipelined 32x32x16 kernels of csrc/gemm_pp.hip — persistent 256x256 on four waves,
+ *                      256x256 on eight waves, 256x128 with loader waves, 192x128; see csrc/gemm.hip, csrc/gemm_pp.hip)
+ *   "gemm_pp_group_n" tile walk of the gemm_pp kernels: 0 (default) row-major, n > 0 column groups of n tiles
+ *   "gemm_heuristic"  1..8, which shape -> configuration table pick_config() uses (default 8: every M >= 1024 forward and
+ *                     dX GEMM on 192x128x64 — four waves for outputs up to 1 024 columns wide, eight otherwise —, single dW GEMMs
+ *                     on 128x128x32; 7: eight waves everywhere; 6: the round-2 table — forward on the BK = 64 configurations, dX on
+ *                     the 256x128x32 two-group kernel)
  *   "gemm_group_n"    tile walk order of a GEMM launch: n > 0 (default 8): outputs wider than n tile columns are walked in
  *                     groups of n columns, all rows of a group first (an XCD's resident workgroups then share n B panels
  *                     that stay in its L2); n < 0: row groups of -n panels, columns outer; 0: rows outer, every column inner
@@ -97,6 +101,11 @@ int cfhip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, co
                     int a_trans, int b_trans, int epilogue, int out_dtype, int accumulate,
                     int split_k, void* workspace, size_t workspace_bytes, float* bias_grad,
                     int bias_grad_accumulate, void* stream);
+
+/* The kernel instantiation (as a profiler prints it, e.g. "gemm_bf16_kernel<false, true, 0, Cfg<192, 128, 2, 2, 2, 64>>") that
+ * cfhip_gemm_bf16 launches for an aligned problem of this shape under the current options; `out` holds at least 96 bytes.
+ * For evidence lines (bench.py groups its in-step timings by it); not needed to run anything. */
+int cfhip_gemm_kernel_name(int M, int N, int K, int a_trans, int b_trans, int epilogue, char* out, size_t out_bytes);
 
 /* Grouped weight gradients: dW_i[M_i][N_i] (+)= dY_i^T X_i and db_i[M_i] (+)= colsum(dY_i) for `count` Linear layers in ONE
  * launch (the parameter half of F.linear's autograd backward, customs.py:89 / attentions.py:214: grad_weight =
