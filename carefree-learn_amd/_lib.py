@@ -171,11 +171,37 @@ def lib_exists() -> bool:
     return os.path.isfile(LIB_PATH)
 
 
+# Launch recording (fused.StackPlan, round 4): while RECORDER is a list, every C-ABI call made through `load().<name>(...)`
+# is executed AND appended as (function, argument tuple) — raw pointers, sizes, stream handles: exactly what a replay needs.
+RECORDER: Optional[list] = None
+
+
+class _Recording:
+    __slots__ = ("lib",)
+
+    def __init__(self, lib: ctypes.CDLL) -> None:
+        self.lib = lib
+
+    def __getattr__(self, name: str):
+        fn = getattr(self.lib, name)
+        rec = RECORDER
+        if name.endswith("_workspace") or name in ("cfhip_version", "cfhip_last_error", "cfhip_set_option", "cfhip_gemm_kernel_name"):
+            return fn  # host-side queries: nothing to replay
+
+        def call(*args):
+            rc = fn(*args)
+            if rec is not None:
+                rec.append((0, fn, args))
+            return rc
+
+        return call
+
+
 def load() -> ctypes.CDLL:
     """Load libcfhip.so once; raises if it has not been built (no CPU / eager fallback exists)."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _lib if RECORDER is None else _Recording(_lib)  # type: ignore[return-value]
     if not lib_exists():
         raise RuntimeError(
             f"libcfhip.so not found at {LIB_PATH}: run `python -c 'import __graft_entry__ as g; "

@@ -18,6 +18,7 @@ import torch
 from torch import Tensor
 from torch.autograd import Function
 
+from . import _lib as _lib_mod
 from . import ops
 
 bf16 = torch.bfloat16
@@ -34,6 +35,44 @@ backward_entered_callbacks: List[Callable[[], None]] = []
 # gradients of the pass from an end-of-backward callback of its own (ddp.BucketedAllReduce.finish) calls these first —
 # the order in which autograd runs end-of-backward callbacks is the order they were queued in, which is not ours to pick.
 deferred_grad_flushes: List[Callable[[], None]] = []
+
+
+def notify_grad_ready(prm: Tensor) -> None:
+    """A HIP backward kernel has been LAUNCHED that leaves `prm.grad` final for this pass: tell the listeners (DDP buckets,
+    the optimizer's in-backward ranges).  Recorded by a launch plan (fused.StackPlan) together with the stream it fired on."""
+    prm._cfhip_fresh = False
+    rec = _lib_mod.RECORDER
+    if rec is None:
+        for cb in grad_ready_callbacks:
+            cb(prm)
+        return
+    # recording: what the listeners launch themselves (an optimizer range update, a bucket's all-reduce) is THEIR business at
+    # replay time too — the plan records the notification, not those launches
+    _lib_mod.RECORDER = None
+    try:
+        for cb in grad_ready_callbacks:
+            cb(prm)
+    finally:
+        _lib_mod.RECORDER = rec
+    rec.append((2, prm, cur_stream()))
+
+
+def rec_wait_stream(waiter: "torch.cuda.Stream", waited: "torch.cuda.Stream") -> None:
+    waiter.wait_stream(waited)
+    if _lib_mod.RECORDER is not None:
+        _lib_mod.RECORDER.append((1, waiter.wait_stream, (waited,)))
+
+
+def rec_wait_event(stream: "torch.cuda.Stream", ev: Any) -> None:
+    stream.wait_event(ev)
+    if _lib_mod.RECORDER is not None:
+        _lib_mod.RECORDER.append((1, stream.wait_event, (ev,)))
+
+
+def rec_record_event(ev: Any, stream: "torch.cuda.Stream") -> None:
+    ev.record(stream)
+    if _lib_mod.RECORDER is not None:
+        _lib_mod.RECORDER.append((1, ev.record, (stream,)))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -210,10 +249,10 @@ class SideStream:
                 fn()
                 return
         side = cls.get(lane)
-        side.wait_stream(cur_stream())  # everything issued so far is visible
+        rec_wait_stream(side, cur_stream())  # everything issued so far is visible
         for st in wait:
             if st is not side:
-                side.wait_stream(st)
+                rec_wait_stream(side, st)
         with on_stream(side):
             fn()
         cls.keep.extend(keep)
@@ -224,8 +263,19 @@ class SideStream:
         if not cls.enabled or not cuda_ok():
             return None
         side = cls.get(lane)
-        side.wait_stream(cur_stream())
+        rec_wait_stream(side, cur_stream())
         return side
+
+    @classmethod
+    def queue_join(cls) -> None:
+        """A replayed backward (fused.StackPlan) put work on the side lanes without going through `run`: make sure the
+        running backward pass ends with the join."""
+        if not cls._join_queued:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(cls._end_of_backward)
+                cls._join_queued = True
+            except RuntimeError:
+                pass
 
     @classmethod
     def join(cls) -> None:

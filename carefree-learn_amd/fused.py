@@ -57,9 +57,7 @@ def _dw_db(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> None:
             SideStream.run(lambda: ops.colsum(dy2, out=b.grad.view(-1), accumulate=acc_b), (dy2,), lane=1)
     ops.gemm(dy2, x2, a_trans=True, b_trans=True, out=w.grad.view(n, k), accumulate=acc_w, split_k=split, **kw)
     for prm in prms:
-        prm._cfhip_fresh = False
-        for cb in grad_ready_callbacks:
-            cb(prm)
+        _functional.notify_grad_ready(prm)
 
 
 # Round 3: the weight gradients of DW_GROUP_BLOCKS consecutive blocks (4 GEMMs each) go out as ONE grouped launch
@@ -194,8 +192,7 @@ def _flush_dw(wait: tuple = ()) -> None:
                 done.extend(prms)
             ops.gemm_grouped_tn(probs)
             for prm in done:
-                for cb in grad_ready_callbacks:
-                    cb(prm)
+                _functional.notify_grad_ready(prm)
 
     if DW_GROUP_ON_MAIN:
         for st in wait:
@@ -233,10 +230,10 @@ def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: T
                                      accumulate=acc_w, want_dx=with_dx, dx_add=dx_add if with_dx else None,
                                      dx_out=dx_out if with_dx else None)
         for prm in (w, b):
-            prm._cfhip_fresh = False
             if notify:  # (a batch-sliced backward notifies once, after the LAST slice has added its rows)
-                for cb in grad_ready_callbacks:
-                    cb(prm)
+                _functional.notify_grad_ready(prm)
+            else:
+                prm._cfhip_fresh = False
         return dx
 
     if not SPLIT_LN_BWD:
@@ -358,11 +355,11 @@ def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_
 
         def ln(which: int, dy_, x_, w_, b_, mean_, rstd_, add_, out_) -> None:
             if ln_done[which] is not None:
-                cur.wait_event(ln_done[which])
+                _functional.rec_wait_event(cur, ln_done[which])
             _ln_bwd(dy_, x_, w_, b_, mean_, rstd_, dx_add=add_, dx_out=out_, notify=last)
             if nsl > 1 and not last:
                 ev = torch.cuda.Event()
-                ev.record(cur)
+                _functional.rec_record_event(ev, cur)
                 ln_done[which] = ev
 
         # channel mixing
@@ -427,6 +424,152 @@ class MixingBlockFn(Function):
         return (dx.view(bsz, t, d),) + (None,) * 18
 
 
+# ---- launch plans (round 4) -------------------------------------------------------------------------------
+# The host pays ~20 us of Python per kernel launch of a block stack (argument checks, torch.empty, stream contexts, ctypes
+# marshalling: 10 ms of a ViT-B/16 step's 18, 17.5 of the CLIP step's 18.8 — which is therefore bound by the host).  A stack
+# called again with the same shapes issues the SAME launches on the SAME streams; only addresses could differ.  So: the
+# second call of a stack is RECORDED at the C-ABI boundary (`_lib.RECORDER`: function + raw argument tuple of every
+# cfhip_* call, plus the stream waits / event records between the batch slices and the gradient notifications), every
+# tensor allocated while recording is kept, and later calls REPLAY the list: the same cfhip_* calls with the same
+# arguments, ~2 us each, no wrappers, no allocations.  Still eager launches on the same streams — not a hipGraph (whose replay
+# costs ~25 us per node on this ROCm) — and bit-identical by construction (same kernels, same arguments).
+#   * inputs (x in forward, dy in backward) that arrive at another address are copied into the recorded buffer (one D2D copy);
+#   * the bf16 weight shadows alternate between two arenas when the optimizer updates inside backward: the plan carries the
+#     address map and a twin argument list;
+#   * anything the recording did not see — another shape, a mask at another address, gradient accumulation state, timers or
+#     FLOP counters attached, a hipGraph capture, a second forward before the backward of the first — takes the normal path.
+STACK_PLANS = os.environ.get("CFHIP_STACK_PLANS", "1") != "0"
+_plans: dict = {}  # id(first parameter) -> StackPlan
+_PLAN_CACHE = 8
+
+
+class StackPlan:
+    def __init__(self, key: tuple, params: tuple) -> None:
+        self.key = key
+        self.calls = 0            # forward calls seen with this key (the first one runs unrecorded: lazy initialisations)
+        self.fwd: list = []       # recorded (kind, fn, args)
+        self.bwd: list = []
+        self.fwd_alt: Optional[list] = None  # the same with the weight shadows of the other arena
+        self.bwd_alt: Optional[list] = None
+        self.keep: list = []      # every tensor allocated while recording
+        self.x_in: Optional[Tensor] = None
+        self.y_out: Optional[Tensor] = None
+        self.dy_in: Optional[Tensor] = None
+        self.dx_out: Optional[Tensor] = None
+        self.all_saved: Optional[list] = None
+        self.w_ptr = 0            # address of the first weight shadow at recording time
+        self.w_alt = 0
+        self.in_flight = False    # forward replayed / recorded, backward not yet run
+        self.ready_fwd = False
+        self.ready_bwd = False
+        self.disabled = False     # a usage the plan cannot follow was seen (two forwards before a backward): normal path from then on
+        self.mask_tensor: Optional[Tensor] = None
+        self.state = key[-1]      # 1: every gradient slot of the stack is written first (lazy zero), 0: every one is accumulated into
+        self.params_ref = [__import__("weakref").ref(p) for p in params if p is not None][:1]
+
+    @staticmethod
+    def _subst(ops_: list, mp: dict) -> list:
+        out = []
+        for kind, f, a in ops_:
+            if kind == 0:
+                a = tuple(mp.get(v, v) if type(v) is int else v for v in a)
+            out.append((kind, f, a))
+        return out
+
+    def finish_recording(self, params: tuple) -> None:
+        """after the recorded backward: the twin lists for the other shadow arena"""
+        mp = {}
+        for p in params:
+            ar = getattr(p, "_cfhip_arena", None) if p is not None else None
+            views = getattr(ar, "_shadow_views", None) if ar is not None else None
+            if views is None:
+                continue
+            i = ar._index(p)
+            a0, a1 = views[0][i].data_ptr(), views[1][i].data_ptr()
+            mp[a0], mp[a1] = a1, a0
+        if mp:
+            self.fwd_alt, self.bwd_alt = self._subst(self.fwd, mp), self._subst(self.bwd, mp)
+            self.w_alt = mp.get(self.w_ptr, 0)
+
+
+def _replay(ops_: list) -> None:
+    from . import _lib
+
+    for kind, f, a in ops_:
+        if kind == 0:
+            rc = f(*a)
+            if rc:
+                _lib.check(rc, "launch plan")
+        elif kind == 1:
+            f(*a)
+        else:  # gradient notification, on the stream it fired on
+            with _functional.on_stream(a):
+                _functional.notify_grad_ready(f)
+
+
+class _KeepAllocations:
+    """while recording: every tensor torch.empty / empty_like hands out stays alive with the plan (its address is in the
+    recorded arguments).  The wrappers allocate with these two calls only (no fills: nothing an ATen kernel would have to redo)."""
+
+    def __init__(self, keep: list) -> None:
+        self.keep = keep
+
+    def __enter__(self) -> None:
+        self.empty, self.empty_like = torch.empty, torch.empty_like
+        keep, e0, e1 = self.keep, self.empty, self.empty_like
+
+        def empty(*a, **k):
+            t = e0(*a, **k)
+            keep.append(t)
+            return t
+
+        def empty_like(*a, **k):
+            t = e1(*a, **k)
+            keep.append(t)
+            return t
+
+        torch.empty, torch.empty_like = empty, empty_like
+
+    def __exit__(self, *exc) -> None:
+        torch.empty, torch.empty_like = self.empty, self.empty_like
+
+
+def _grad_state(params: tuple) -> Optional[int]:
+    """1: every parameter gradient of the stack is 'fresh' (the first kernel writes it: lazy zero-grad); 0: none is (zeroed
+    arena, kernels accumulate); None: mixed, or a gradient that does not live where the recording saw it"""
+    n_fresh = n = 0
+    for p in params:
+        if p is None:
+            continue
+        if p.grad is None or not p.requires_grad:
+            return None
+        n += 1
+        n_fresh += 1 if getattr(p, "_cfhip_fresh", False) else 0
+    return 1 if n_fresh == n else 0 if n_fresh == 0 else None
+
+
+def _plan_for(x: Tensor, metas: tuple, keep_mask: Optional[Tensor], causal: bool, params: tuple, training: bool) -> Optional[StackPlan]:
+    """the plan of this stack call, or None when plans do not apply to it (`training`: a backward pass will follow)"""
+    from . import _lib
+
+    if (not STACK_PLANS or not x.is_cuda or not training or ops.GEMM_TIMER is not None or ops.FLOP_COUNTER is not None
+            or _lib.RECORDER is not None or torch.cuda.is_current_stream_capturing() or params[2] is None):
+        return None
+    state = _grad_state(params)
+    if state is None:
+        return None  # gradients outside an arena / frozen weights / some slots written and others accumulated: the normal path
+    key = (tuple(x.shape), x.dtype, metas, causal, None if keep_mask is None else keep_mask.data_ptr(), FWD_HALVES, BWD_HALVES,
+           DW_GROUP_BLOCKS, DW_GROUP_TILES, DW_GROUP_ON_MAIN, FIRST_SLICE_SHARE, FUSE_BIAS_GRAD,
+           tuple(id(cb) for cb in _functional.grad_ready_callbacks), x.requires_grad, state)
+    pid = id(params[0])
+    plan = _plans.get(pid)
+    if plan is None or plan.key != key or (plan.params_ref and plan.params_ref[0]() is not params[0]):
+        if len(_plans) >= _PLAN_CACHE:
+            _plans.pop(next(iter(_plans)))
+        plan = _plans[pid] = StackPlan(key, params)
+    return plan
+
+
 class MixingStackFn(Function):
     """ALL blocks of a `MixedStackedEncoder` as one autograd node: the residual-gradient stream stays
     bf16 from block to block (one node per block makes autograd cast every block's bf16 input gradient
@@ -434,14 +577,8 @@ class MixingStackFn(Function):
     kernels per step), and the engine walks 1 node instead of 12."""
 
     @staticmethod
-    def forward(ctx: Any, x: Tensor, metas: tuple, keep_mask: Optional[Tensor], causal: bool,
-                *params: Optional[Tensor]) -> Tensor:
-        bsz, t, d = x.shape
-        if x.dtype not in (bf16, f32):
-            x = x.float()
-        cur = x.contiguous().view(bsz * t, d)
+    def _forward_body(cur: Tensor, bsz: int, t: int, metas: tuple, keep_mask: Optional[Tensor], causal: bool, params: tuple):
         nblk = len(metas)
-        assert len(params) == 12 * nblk
         all_saved = []
         streams = None
         if FWD_HALVES > 1 and cur.is_cuda and bsz >= 2 * FWD_HALVES:
@@ -466,17 +603,62 @@ class MixingStackFn(Function):
             all_saved.extend(saved)
         if streams is not None:
             for st in streams[1:]:
-                _functional.cur_stream().wait_stream(st)
-        ctx.save_for_backward(*all_saved, keep_mask)
-        ctx.params = params
-        ctx.meta = (bsz, t, d, metas, causal)
-        return cur.view(bsz, t, d)
+                _functional.rec_wait_stream(_functional.cur_stream(), st)
+        return cur, all_saved
 
     @staticmethod
-    def backward(ctx: Any, dy: Tensor):  # type: ignore
-        *all_saved, keep_mask = ctx.saved_tensors
-        bsz, t, d, metas, causal = ctx.meta
-        d2 = _as_bf16_rows(dy, bsz * t, d)
+    def forward(ctx: Any, x: Tensor, metas: tuple, keep_mask: Optional[Tensor], causal: bool,
+                *params: Optional[Tensor]) -> Tensor:
+        from . import _lib
+
+        bsz, t, d = x.shape
+        if x.dtype not in (bf16, f32):
+            x = x.float()
+        cur = x.contiguous().view(bsz * t, d)
+        assert len(params) == 12 * len(metas)
+        ctx.params = params
+        ctx.meta = (bsz, t, d, metas, causal)
+        ctx.plan = None
+        plan = _plan_for(x, metas, keep_mask, causal, params, any(ctx.needs_input_grad))
+        if plan is not None and plan.in_flight and not plan.disabled:
+            # a second forward of this stack before the backward of the first (shared towers, evaluation between steps): the
+            # recorded buffers would be overwritten under the pending backward — this stack keeps the normal path
+            plan.disabled = True
+        if plan is not None and not plan.in_flight and not plan.disabled:
+            plan.calls += 1
+            plan.mask_tensor = keep_mask
+            w_now = shadow_bf16(params[2]).data_ptr()
+            if plan.ready_fwd and plan.ready_bwd and w_now in (plan.w_ptr, plan.w_alt):
+                # ---- replay
+                if cur.data_ptr() != plan.x_in.data_ptr():
+                    plan.x_in.copy_(cur)
+                _replay(plan.fwd if w_now == plan.w_ptr else plan.fwd_alt)
+                plan.in_flight = True
+                ctx.plan = plan
+                ctx.plan_alt = w_now != plan.w_ptr
+                return plan.y_out.detach().view(bsz, t, d)
+            if plan.calls >= 2 and not plan.ready_fwd:
+                # ---- record (the first call ran the normal path: side streams, shadows and lazy state exist by now)
+                plan.keep, plan.fwd, plan.bwd = [], [], []
+                plan.w_ptr = w_now
+                _lib.RECORDER = plan.fwd
+                try:
+                    with _KeepAllocations(plan.keep):
+                        plan.x_in = cur
+                        y, all_saved = MixingStackFn._forward_body(cur, bsz, t, metas, keep_mask, causal, params)
+                finally:
+                    _lib.RECORDER = None
+                plan.y_out, plan.all_saved = y, all_saved
+                plan.ready_fwd, plan.in_flight = True, True
+                ctx.plan, ctx.plan_alt = plan, False
+                return y.detach().view(bsz, t, d)
+        y, all_saved = MixingStackFn._forward_body(cur, bsz, t, metas, keep_mask, causal, params)
+        ctx.save_for_backward(*all_saved, keep_mask)
+        return y.view(bsz, t, d)
+
+    @staticmethod
+    def _backward_body(all_saved: list, keep_mask: Optional[Tensor], bsz: int, t: int, metas: tuple, causal: bool, d2: Tensor,
+                       params: tuple) -> Tensor:
         streams = None
         if BWD_HALVES > 1 and d2.is_cuda and bsz >= 2 * BWD_HALVES:
             main = _functional.cur_stream()
@@ -490,7 +672,7 @@ class MixingStackFn(Function):
                 saved = tuple(all_saved[N_SAVED * i:N_SAVED * (i + 1)])
                 quick = bool(metas[i][3]) if len(metas[i]) > 3 else False
                 before = _pending_tiles()
-                d2 = _block_bwd(saved, ctx.params[12 * i:12 * i + 12], metas[i][0], bsz, t, keep_mask, causal, d2, quick, streams)
+                d2 = _block_bwd(saved, params[12 * i:12 * i + 12], metas[i][0], bsz, t, keep_mask, causal, d2, quick, streams)
                 if DW_GROUP_BLOCKS > 0 and DW_GROUP_TILES > 0:
                     now = _pending_tiles()
                     if now + (now - before) > DW_GROUP_TILES:  # one more block like this one would start a second round
@@ -500,14 +682,59 @@ class MixingStackFn(Function):
             _flush_dw(tuple(_slice_streams))
             if streams is not None:
                 for st in streams[1:]:
-                    _functional.cur_stream().wait_stream(st)
+                    _functional.rec_wait_stream(_functional.cur_stream(), st)
                 SideStream.keep.append(d2)  # written by both slice streams, allocated on the caller's
         except BaseException:
             _pending_dw.clear()  #  nothing queued by a failed pass may be flushed into `.grad` by the next one
             raise
         finally:
             _slice_streams[:] = []
-        return (d2.view(bsz, t, d), None, None, None) + (None,) * len(ctx.params)
+        return d2
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        from . import _lib
+
+        bsz, t, d, metas, causal = ctx.meta
+        params = ctx.params
+        plan: Optional[StackPlan] = ctx.plan
+        nret = (None, None, None) + (None,) * len(params)
+        if plan is None:
+            *all_saved, keep_mask = ctx.saved_tensors
+            d2 = _as_bf16_rows(dy, bsz * t, d)
+            d2 = MixingStackFn._backward_body(list(all_saved), keep_mask, bsz, t, metas, causal, d2, params)
+            return (d2.view(bsz, t, d),) + nret
+        plan.in_flight = False
+        km = plan.mask_tensor
+        fresh = _grad_state(params) == plan.state  # the write / accumulate flags in the recorded arguments still apply
+        if plan.ready_bwd and fresh and _lib.RECORDER is None and ops.GEMM_TIMER is None and ops.FLOP_COUNTER is None:
+            # ---- replay
+            d2 = _as_bf16_rows(dy, bsz * t, d)
+            if d2.data_ptr() != plan.dy_in.data_ptr():
+                plan.dy_in.copy_(d2)
+            SideStream.queue_join()
+            _replay(plan.bwd_alt if ctx.plan_alt else plan.bwd)
+            return (plan.dx_out.detach().view(bsz, t, d),) + nret
+        if not plan.ready_bwd and fresh and _lib.RECORDER is None:
+            # ---- record the backward of the recorded forward (the incoming gradient is converted BEFORE the recording
+            # starts: that launch reads this pass's autograd buffer, which no later pass will see at that address)
+            d2 = _as_bf16_rows(dy, bsz * t, d)
+            plan.dy_in = d2
+            _lib.RECORDER = plan.bwd
+            try:
+                with _KeepAllocations(plan.keep):
+                    dx = MixingStackFn._backward_body(plan.all_saved, km, bsz, t, metas, causal, d2, params)
+            finally:
+                _lib.RECORDER = None
+            plan.dx_out = dx
+            plan.keep.append(dx)
+            plan.finish_recording(params)
+            plan.ready_bwd = True
+            return (dx.detach().view(bsz, t, d),) + nret
+        # the plan cannot serve this backward (gradient accumulation state, timers attached): the normal path on its buffers
+        d2 = _as_bf16_rows(dy, bsz * t, d)
+        d2 = MixingStackFn._backward_body(plan.all_saved, km, bsz, t, metas, causal, d2, params)
+        return (d2.view(bsz, t, d),) + nret
 
 
 def mixing_block(x: Tensor, *args: Any) -> Tensor:

@@ -278,3 +278,79 @@ def test_optimizer_scalars_survive_a_host_that_runs_ahead(golden):
     a, b = run(False), run(True)
     # (LayerNorm parameter gradients use LDS float atomics: equal up to the last bits, not bitwise)
     assert_close(b, a, 2e-6, "parameters after 6 steps, stalled GPU vs step-by-step")
+
+
+def test_stack_launch_plans_replay_bit_identically():
+    """fused.StackPlan (round 4): the second step of a block stack is recorded at the C-ABI boundary, later steps replay the
+    recorded launches.  Same kernels, same arguments: the trajectory of a 256-wide ViT (LayerNorm gradients on the
+    deterministic kernel, batch large enough for the two batch slices, optimizer inside backward with both shadow arenas)
+    must be BIT-identical with plans on and off — parameters and moments after every step, losses — and the plan must really
+    have replayed."""
+    from cflearn_amd import fused
+
+    def run(plans: bool, steps: int = 7):
+        prev = fused.STACK_PLANS
+        fused.STACK_PLANS = plans
+        fused._plans.clear()
+        try:
+            torch.manual_seed(3)
+            m = C.vit_b16_classifier(10, img_size=32, patch_size=8, latent_dim=256, num_layers=3).to(DEV)
+            ts = TrainStep(m, lr=1e-3, weight_decay=0.01)
+            gen = torch.Generator().manual_seed(5)
+            batches = [(torch.randn(8, 3, 32, 32, generator=gen).to(DEV), torch.randint(0, 10, (8,), generator=gen).to(DEV)) for _ in range(3)]
+            out = []
+            for i in range(steps):
+                img, lab = batches[i % 3]
+                loss = ts.step(img, lab)
+                torch.cuda.synchronize()
+                out.append((loss.item(), ts.arena.flat_p.clone(), ts.optimizer.exp_avg_sq.clone()))
+            plan = next(iter(fused._plans.values())) if fused._plans else None
+            return out, plan
+        finally:
+            fused.STACK_PLANS = prev
+            fused._plans.clear()
+
+    ref, no_plan = run(False)
+    got, plan = run(True)
+    assert no_plan is None
+    assert plan is not None and plan.ready_fwd and plan.ready_bwd and not plan.disabled and plan.calls == 7
+    assert plan.fwd_alt is not None and len(plan.fwd) > 30 and len(plan.bwd) > 60  # both shadow arenas, real launch lists
+    for i, ((l0, p0, v0), (l1, p1, v1)) in enumerate(zip(ref, got)):
+        assert abs(l0 - l1) <= 1e-5 * abs(l0), (i, l0, l1)  # (the scalar loss is a sum of per-sample f32 atomics: not bitwise)
+        assert torch.equal(p0, p1) and torch.equal(v0, v1), i
+
+
+def test_stack_launch_plans_fall_back():
+    """what a plan cannot follow takes the normal path: another batch size re-records, a forward-only call between steps
+    (two forwards before a backward) switches the plan of that stack off, evaluation runs without one."""
+    from cflearn_amd import fused
+
+    fused._plans.clear()
+    torch.manual_seed(3)
+    m = C.vit_b16_classifier(10, img_size=32, patch_size=8, latent_dim=256, num_layers=2).to(DEV)
+    ts = TrainStep(m, lr=1e-3)
+    gen = torch.Generator().manual_seed(5)
+    img, lab = torch.randn(8, 3, 32, 32, generator=gen).to(DEV), torch.randint(0, 10, (8,), generator=gen).to(DEV)
+    for _ in range(4):
+        ts.step(img, lab)
+    plan = next(iter(fused._plans.values()))
+    assert plan.ready_bwd
+    l8 = ts.step(img, lab).item()
+    ts.step(img[:6], lab[:6])  # another shape: a new plan object for this stack
+    plan2 = next(iter(fused._plans.values()))
+    assert plan2 is not plan and not plan2.ready_fwd
+    for _ in range(3):
+        ts.step(img, lab)
+    plan3 = next(iter(fused._plans.values()))
+    assert plan3.ready_bwd
+    ts.optimizer.zero_grad()
+    m(img)  # forward in training mode without a backward ...
+    ts.step(img, lab)  # ... then a step: the stack is asked again while the plan is in flight
+    assert plan3.disabled
+    l_after = ts.step(img, lab).item()
+    assert l_after == l_after and l_after < l8 * 1.5
+    m.eval()
+    with torch.no_grad():
+        y = m(img)["predictions"]
+    assert torch.isfinite(y.float()).all()
+    fused._plans.clear()
