@@ -415,7 +415,8 @@ def run_other_workload(args) -> dict:
                    num_transformer_layers=1, num_res_blocks=2, attention_downsample_rates=(1, 2, 4),
                    channel_multipliers=(1, 2, 4, 4), context_dim=None)
         m = C.build_module("unet_diffuser", config=cfg).to(dev)
-        ts = DDPMTrainStep(m, NoiseSchedule(device=dev), lr=1.0e-4, use_graph=bool(getattr(args, "graph", False)))
+        ts = DDPMTrainStep(m, NoiseSchedule(device=dev), lr=1.0e-4, use_graph=bool(getattr(args, "graph", False)),
+                           step_in_backward=not getattr(args, "no_step_in_backward", False))
         x = torch.randn(batch, 3, args.img, args.img, generator=g).clamp_(-1, 1).to(dev)
         t = torch.randint(0, 1000, (batch,), generator=g).to(dev)
         eps = torch.randn(x.shape, generator=g).to(dev)
@@ -862,12 +863,15 @@ def main() -> None:
         gc.collect()
         torch.cuda.empty_cache()
         others = {}
-        for wl, kw in (("unet", dict(img=64, steps=3, warmup=2)), ("clip", dict(steps=4, warmup=2))):
+        # (unet256: BASELINE config 4 AS STATED — the zoo DDPM UNet at 256^2, batch 1 — next to the 64^2 x 8 line)
+        for name, wl, kw in (("unet", "unet", dict(img=64, steps=3, warmup=2)), ("unet256", "unet", dict(img=256, steps=3, warmup=2)),
+                             ("clip", "clip", dict(steps=4, warmup=2))):
             a2 = copy.copy(args)
-            a2.workload, a2.batch = wl, 128  # 128 = "the workload's default batch" (8 for the 64^2 UNet, 256 for CLIP)
+            a2.workload, a2.batch = wl, 128  # 128 = "the workload's default batch" (8 for the 64^2 UNet, 1 at 256^2, 256 for CLIP)
             for k_, v_ in kw.items():
                 setattr(a2, k_, v_)
-            note(f"other workload: {wl} ...")
+            note(f"other workload: {name} ...")
+            wl = name
             try:
                 r = run_other_workload(a2)
                 others[wl] = {k_: r[k_] for k_ in ("value", "unit", "ms_per_step", "steps", "warmup", "roofline", "peak_mem_gb")}

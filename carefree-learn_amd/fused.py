@@ -69,6 +69,10 @@ DW_GROUP_BLOCKS = 2
 # chip idle: with DW_GROUP_TILES > 0 the queue is flushed by TILE count instead — as soon as another block like the last one
 # would not fit into one round of 256-tile slots — and DW_GROUP_BLOCKS only says "grouping on" (ViT-B/16: still two blocks).
 DW_GROUP_TILES = 256
+# The LAST blocks of a backward pass (block indices below this) are flushed one by one: when the dX chain ends, what is left on
+# the weight-gradient lane is then one block's launch (108 tiles) instead of two blocks' (216) — nothing else is left to
+# share the chip with at that point, so the tail of the step is that launch's duration.
+DW_TAIL_BLOCKS = int(os.environ.get("CFHIP_DW_TAIL_BLOCKS", "0"))  # measured (profiles/r04/dw_tail_ab.txt): 1 .. 3 cost 0.3 ms per step — whole-reduction tiles on 108 of 256 CUs; kept as a knob
 DW_GROUP_ON_MAIN = False  # True: the grouped launch runs on the caller's stream (after the blocks' dX chain) instead of the side stream
 _pending_dw: list = []
 _slice_streams: list = []  # streams of the backward's batch slices beyond the caller's (what a dW launch has to wait for)
@@ -462,6 +466,10 @@ class StackPlan:
         self.in_flight = False    # forward replayed / recorded, backward not yet run
         self.ready_fwd = False
         self.ready_bwd = False
+        self.x_live: Optional[Tensor] = None  # the caller's input of the forward in flight (replayed launches read it in place)
+        self.x_sites: list = []
+        self.dy_sites: list = []
+        self.x_now = self.dy_now = 0
         self.disabled = False     # a usage the plan cannot follow was seen (two forwards before a backward): normal path from then on
         self.mask_tensor: Optional[Tensor] = None
         self.state = key[-1]      # 1: every gradient slot of the stack is written first (lazy zero), 0: every one is accumulated into
@@ -476,8 +484,33 @@ class StackPlan:
             out.append((kind, f, a))
         return out
 
+    def _patch_sites(self, base: int, nbytes: int) -> list:
+        """(list id, entry index, argument index, byte offset) of every recorded pointer argument inside [base, base + nbytes)"""
+        sites = []
+        for li, ops_ in enumerate((self.fwd, self.bwd)):
+            for ei, (kind, _f, a) in enumerate(ops_):
+                if kind != 0:
+                    continue
+                for ai, v in enumerate(a):
+                    if type(v) is int and base <= v < base + nbytes:
+                        sites.append((li, ei, ai, v - base))
+        return sites
+
+    def repoint(self, sites: list, new_base: int) -> None:
+        """the stack's input (or incoming gradient) lives at another address this step: rewrite the few launches that read it —
+        in both twin lists — instead of copying the tensor into the recorded buffer"""
+        for li, ei, ai, off in sites:
+            for ops_ in ((self.fwd, self.fwd_alt) if li == 0 else (self.bwd, self.bwd_alt)):
+                if ops_ is None:
+                    continue
+                kind, f, a = ops_[ei]
+                ops_[ei] = (kind, f, a[:ai] + (new_base + off,) + a[ai + 1:])
+
     def finish_recording(self, params: tuple) -> None:
-        """after the recorded backward: the twin lists for the other shadow arena"""
+        """after the recorded backward: the twin lists for the other shadow arena, the launches that read the inputs"""
+        self.x_sites = self._patch_sites(self.x_in.data_ptr(), self.x_in.numel() * self.x_in.element_size())
+        self.dy_sites = self._patch_sites(self.dy_in.data_ptr(), self.dy_in.numel() * self.dy_in.element_size())
+        self.x_now, self.dy_now = self.x_in.data_ptr(), self.dy_in.data_ptr()
         mp = {}
         for p in params:
             ar = getattr(p, "_cfhip_arena", None) if p is not None else None
@@ -559,7 +592,7 @@ def _plan_for(x: Tensor, metas: tuple, keep_mask: Optional[Tensor], causal: bool
     if state is None:
         return None  # gradients outside an arena / frozen weights / some slots written and others accumulated: the normal path
     key = (tuple(x.shape), x.dtype, metas, causal, None if keep_mask is None else keep_mask.data_ptr(), FWD_HALVES, BWD_HALVES,
-           DW_GROUP_BLOCKS, DW_GROUP_TILES, DW_GROUP_ON_MAIN, FIRST_SLICE_SHARE, FUSE_BIAS_GRAD,
+           DW_GROUP_BLOCKS, DW_GROUP_TILES, DW_TAIL_BLOCKS, DW_GROUP_ON_MAIN, FIRST_SLICE_SHARE, FUSE_BIAS_GRAD,
            tuple(id(cb) for cb in _functional.grad_ready_callbacks), x.requires_grad, state)
     pid = id(params[0])
     plan = _plans.get(pid)
@@ -630,8 +663,10 @@ class MixingStackFn(Function):
             w_now = shadow_bf16(params[2]).data_ptr()
             if plan.ready_fwd and plan.ready_bwd and w_now in (plan.w_ptr, plan.w_alt):
                 # ---- replay
-                if cur.data_ptr() != plan.x_in.data_ptr():
-                    plan.x_in.copy_(cur)
+                if cur.data_ptr() != plan.x_now:
+                    plan.repoint(plan.x_sites, cur.data_ptr())
+                    plan.x_now = cur.data_ptr()
+                plan.x_live = cur  # (block 0's backward reads it again: alive until then)
                 _replay(plan.fwd if w_now == plan.w_ptr else plan.fwd_alt)
                 plan.in_flight = True
                 ctx.plan = plan
@@ -675,7 +710,8 @@ class MixingStackFn(Function):
                 d2 = _block_bwd(saved, params[12 * i:12 * i + 12], metas[i][0], bsz, t, keep_mask, causal, d2, quick, streams)
                 if DW_GROUP_BLOCKS > 0 and DW_GROUP_TILES > 0:
                     now = _pending_tiles()
-                    if now + (now - before) > DW_GROUP_TILES:  # one more block like this one would start a second round
+                    # one more block like this one would start a second round — or: the pass is about to end (DW_TAIL_BLOCKS)
+                    if now + (now - before) > DW_GROUP_TILES or i <= DW_TAIL_BLOCKS:
                         _flush_dw(tuple(_slice_streams))
                 elif DW_GROUP_BLOCKS > 0 and (len(metas) - i) % DW_GROUP_BLOCKS == 0:
                     _flush_dw(tuple(_slice_streams))
@@ -710,10 +746,13 @@ class MixingStackFn(Function):
         if plan.ready_bwd and fresh and _lib.RECORDER is None and ops.GEMM_TIMER is None and ops.FLOP_COUNTER is None:
             # ---- replay
             d2 = _as_bf16_rows(dy, bsz * t, d)
-            if d2.data_ptr() != plan.dy_in.data_ptr():
-                plan.dy_in.copy_(d2)
+            if d2.data_ptr() != plan.dy_now:
+                plan.repoint(plan.dy_sites, d2.data_ptr())
+                plan.dy_now = d2.data_ptr()
             SideStream.queue_join()
             _replay(plan.bwd_alt if ctx.plan_alt else plan.bwd)
+            SideStream.keep.append(d2)  # read by launches on the side lanes: alive until the end-of-backward join
+            plan.x_live = None
             return (plan.dx_out.detach().view(bsz, t, d),) + nret
         if not plan.ready_bwd and fresh and _lib.RECORDER is None:
             # ---- record the backward of the recorded forward (the incoming gradient is converted BEFORE the recording
@@ -733,7 +772,11 @@ class MixingStackFn(Function):
             return (dx.detach().view(bsz, t, d),) + nret
         # the plan cannot serve this backward (gradient accumulation state, timers attached): the normal path on its buffers
         d2 = _as_bf16_rows(dy, bsz * t, d)
-        d2 = MixingStackFn._backward_body(plan.all_saved, km, bsz, t, metas, causal, d2, params)
+        saved = list(plan.all_saved)
+        if plan.x_live is not None:
+            saved[0] = plan.x_live  # (a replayed forward read the caller's input in place, not the recorded buffer)
+            plan.x_live = None
+        d2 = MixingStackFn._backward_body(saved, km, bsz, t, metas, causal, d2, params)
         return (d2.view(bsz, t, d),) + nret
 
 

@@ -616,3 +616,34 @@ def test_unet_zoo_full_size_step_vs_oracle():
     assert y_err <= max(1e-2, 1.3 * ac_y_err) and y_err <= 2e-2, (y_err, ac_y_err)
     for k in ZOO_SAMPLED:
         assert errs[k] <= max(1e-2, 1.3 * ac_errs[k]) and errs[k] <= 8e-2, (k, errs[k], ac_errs[k])
+
+
+def test_ddpm_step_updates_inside_backward_bit_identically(golden):
+    """DDPMTrainStep with the optimizer inside backward (optim.StepInBackward over the UNet's Conv2dFn / LinearFn / GroupNorm
+    gradient notifications): after every step the parameters, moments and bf16 shadows equal ONE launch of the Adam kernel on
+    the pre-step state and the gradients this backward left in the arena; ranges were launched from inside backward."""
+    from cflearn_amd import _lib
+    from cflearn_amd.diffusion import DDPMTrainStep, NoiseSchedule
+
+    u = golden("unet_small.pt")
+    m = C.build_module("unet_diffuser", config=dict(u["cfg"]))
+    m.load_state_dict(u["sd"])
+    ts = DDPMTrainStep(m.to(DEV), NoiseSchedule(device=DEV), lr=1e-3, weight_decay=0.01, range_bytes=32 << 10)
+    opt, ar = ts.optimizer, ts.arena
+    assert opt.in_backward is not None
+    x, ctx = u["x"].to(DEV), u["context"].to(DEV)
+    t, eps = u["timesteps"].to(DEV), u["noise"].to(DEV)
+    losses = []
+    for step in range(4):
+        p0, m0, v0 = ar.flat_p.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()
+        losses.append(ts.step(x, ctx, timesteps=t, noise=eps).item())
+        torch.cuda.synchronize()
+        p16 = torch.empty(ar.total, dtype=torch.bfloat16, device=DEV)
+        rc = _lib.load().cfhip_adam_step_dev(p0.data_ptr(), ar.flat_g.data_ptr(), m0.data_ptr(), v0.data_ptr(), p16.data_ptr(), ar.total,
+                                             opt._hyper_dev.data_ptr(), int(opt.decoupled), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "adam_step_dev")
+        torch.cuda.synchronize()
+        assert torch.equal(p0, ar.flat_p) and torch.equal(m0, opt.exp_avg) and torch.equal(v0, opt.exp_avg_sq), step
+        assert torch.equal(p16, ar.flat_p16), step
+        assert opt.in_backward.launched_in_backward >= 4, opt.in_backward.launched_in_backward
+    assert losses[-1] < losses[0], losses
