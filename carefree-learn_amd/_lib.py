@@ -48,6 +48,10 @@ SIGNATURES = {
         [_P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int64, c_int64, c_int64, c_int, _P,
          c_size_t, _P],
     ),
+    "cfhip_layernorm_bwd_partials": (
+        c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int64, c_int64, c_int64, _P, c_size_t, _P, _P]
+    ),
+    "cfhip_layernorm_bwd_reduce": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P]),
     "cfhip_attn_fwd": (
         c_int,
         [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,

@@ -488,12 +488,29 @@ int cfhip_internal_set_ln_fused(int v) {
   return CFHIP_OK;
 }
 
-extern "C" int cfhip_layernorm_bwd(const void* dy, const void* x, int x_is_f32, const float* gamma,
-                                   const float* mean, const float* rstd, const void* dx_add, void* dx,
-                                   float* dgamma, float* dbeta, int M, int D, int64_t dy_row_stride,
-                                   int64_t x_row_stride, int64_t dx_row_stride,
-                                   int accumulate_param_grads, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
+// the column sums of the per-workgroup partial rows [rows][2 D] (dgamma | dbeta) -> dgamma, dbeta
+static int ln_bwd_reduce(float* partials, int rows, int D, float* dgamma, float* dbeta, int accumulate_param_grads, hipStream_t s) {
+  if (dgamma != nullptr && dbeta == dgamma + D)
+    return cfhip_internal_colreduce_f32(partials, rows, 2 * D, dgamma, accumulate_param_grads, s);
+  // separate destinations: both halves into row 0 of the partials first (colreduce takes a dense [R][D] matrix)
+  int rc = cfhip_internal_colreduce_f32(partials, rows, 2 * D, partials, 0, s);
+  if (rc != CFHIP_OK) return rc;
+  if (dgamma != nullptr) {
+    rc = cfhip_internal_colreduce_f32(partials, 1, D, dgamma, accumulate_param_grads, s);
+    if (rc != CFHIP_OK) return rc;
+  }
+  if (dbeta != nullptr) rc = cfhip_internal_colreduce_f32(partials + D, 1, D, dbeta, accumulate_param_grads, s);
+  return rc;
+}
+
+// `rows_out` != nullptr: only the row kernel runs; the partial rows stay in the workspace and *rows_out says how many there are
+// (cfhip_layernorm_bwd_partials / _reduce: the reduction can then run on another stream, off the input-gradient chain)
+static int ln_bwd_impl(const void* dy, const void* x, int x_is_f32, const float* gamma,
+                       const float* mean, const float* rstd, const void* dx_add, void* dx,
+                       float* dgamma, float* dbeta, int M, int D, int64_t dy_row_stride,
+                       int64_t x_row_stride, int64_t dx_row_stride,
+                       int accumulate_param_grads, void* workspace,
+                       size_t workspace_bytes, void* stream, int* rows_out) {
   CFHIP_REQUIRE(dy && x && gamma && mean && rstd, "layernorm_bwd: null pointer");
   const bool do_dx = dx != nullptr, do_pg = dgamma != nullptr || dbeta != nullptr;
   CFHIP_REQUIRE(do_dx || do_pg, "layernorm_bwd: nothing to compute (dx, dgamma and dbeta are all NULL)");
@@ -540,16 +557,11 @@ extern "C" int cfhip_layernorm_bwd(const void* dy, const void* x, int x_is_f32, 
     }
 #undef LN_BWD2
     CFHIP_CHECK_LAUNCH("layernorm_bwd_fused");
-    if (dgamma != nullptr && dbeta == dgamma + D)
-      return cfhip_internal_colreduce_f32(partials, blocks2, 2 * D, dgamma, accumulate_param_grads, s);
-    int rc = cfhip_internal_colreduce_f32(partials, blocks2, 2 * D, partials, 0, s);
-    if (rc != CFHIP_OK) return rc;
-    if (dgamma != nullptr) {
-      rc = cfhip_internal_colreduce_f32(partials, 1, D, dgamma, accumulate_param_grads, s);
-      if (rc != CFHIP_OK) return rc;
+    if (rows_out != nullptr) {
+      *rows_out = blocks2;
+      return CFHIP_OK;
     }
-    if (dbeta != nullptr) rc = cfhip_internal_colreduce_f32(partials + D, 1, D, dbeta, accumulate_param_grads, s);
-    return rc;
+    return ln_bwd_reduce(partials, blocks2, D, dgamma, dbeta, accumulate_param_grads, s);
   }
   const int blocks = ln_grid(M, do_pg ? 512 : 1024);  // dx-only: fewer registers, twice the waves
   const size_t lds = do_pg ? (size_t)2 * D * sizeof(float) : 0;
@@ -574,25 +586,39 @@ extern "C" int cfhip_layernorm_bwd(const void* dy, const void* x, int x_is_f32, 
 #undef LN_BWD_MODE
 #undef LN_BWD_ONE
   CFHIP_CHECK_LAUNCH("layernorm_bwd");
-  if (dgamma != nullptr || dbeta != nullptr) {
-    // partial rows are [2*D] wide: dgamma in the first half, dbeta in the second
-    if (dgamma != nullptr && dbeta == dgamma + D) {
-      return cfhip_internal_colreduce_f32(partials, blocks, 2 * D, dgamma, accumulate_param_grads, s);
-    }
-    // separate destinations: reduce each half with a row pitch of 2*D
-    // (colreduce takes a dense [R][D] matrix, so reduce into the workspace tail first)
-    float* tmp = partials;  // reuse row 0 region after the reduce of both halves
-    int rc = cfhip_internal_colreduce_f32(partials, blocks, 2 * D, tmp, 0, s);
-    if (rc != CFHIP_OK) return rc;
-    // tmp[0:D] = dgamma, tmp[D:2D] = dbeta (row 0 of the partials was consumed in place)
-    if (dgamma != nullptr) {
-      rc = cfhip_internal_colreduce_f32(tmp, 1, D, dgamma, accumulate_param_grads, s);
-      if (rc != CFHIP_OK) return rc;
-    }
-    if (dbeta != nullptr) {
-      rc = cfhip_internal_colreduce_f32(tmp + D, 1, D, dbeta, accumulate_param_grads, s);
-      if (rc != CFHIP_OK) return rc;
-    }
+  if (rows_out != nullptr) {
+    *rows_out = do_pg ? blocks : 0;
+    return CFHIP_OK;
   }
+  if (do_pg) return ln_bwd_reduce(partials, blocks, D, dgamma, dbeta, accumulate_param_grads, s);  // partial rows: dgamma | dbeta
   return CFHIP_OK;
+}
+
+extern "C" int cfhip_layernorm_bwd(const void* dy, const void* x, int x_is_f32, const float* gamma,
+                                   const float* mean, const float* rstd, const void* dx_add, void* dx,
+                                   float* dgamma, float* dbeta, int M, int D, int64_t dy_row_stride,
+                                   int64_t x_row_stride, int64_t dx_row_stride,
+                                   int accumulate_param_grads, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  return ln_bwd_impl(dy, x, x_is_f32, gamma, mean, rstd, dx_add, dx, dgamma, dbeta, M, D, dy_row_stride, x_row_stride, dx_row_stride,
+                     accumulate_param_grads, workspace, workspace_bytes, stream, nullptr);
+}
+
+// The same in two calls: `_partials` runs the row kernel (dx, and the per-workgroup partial sums of dgamma / dbeta into
+// `workspace`: cfhip_layernorm_bwd_workspace bytes) and reports the number of partial rows; `_reduce` adds them into dgamma /
+// dbeta — on whatever stream the caller likes (ordered after `_partials` by the caller): the parameter gradients are needed by
+// the optimizer only, the input gradient by the next kernel of the backward chain.
+extern "C" int cfhip_layernorm_bwd_partials(const void* dy, const void* x, int x_is_f32, const float* gamma,
+                                            const float* mean, const float* rstd, const void* dx_add, void* dx, int M, int D,
+                                            int64_t dy_row_stride, int64_t x_row_stride, int64_t dx_row_stride, void* workspace,
+                                            size_t workspace_bytes, int* rows_out, void* stream) {
+  CFHIP_REQUIRE(rows_out != nullptr && workspace != nullptr, "layernorm_bwd_partials: null pointer");
+  float* marker = reinterpret_cast<float*>(workspace);  // (any non-null destination: selects the parameter-gradient kernels)
+  return ln_bwd_impl(dy, x, x_is_f32, gamma, mean, rstd, dx_add, dx, marker, marker + D, M, D, dy_row_stride, x_row_stride,
+                     dx_row_stride, 0, workspace, workspace_bytes, stream, rows_out);
+}
+
+extern "C" int cfhip_layernorm_bwd_reduce(void* workspace, int rows, int D, float* dgamma, float* dbeta, int accumulate, void* stream) {
+  CFHIP_REQUIRE(workspace != nullptr && rows > 0 && D > 0 && (dgamma != nullptr || dbeta != nullptr), "layernorm_bwd_reduce: bad arguments");
+  return ln_bwd_reduce(reinterpret_cast<float*>(workspace), rows, D, dgamma, dbeta, accumulate, reinterpret_cast<hipStream_t>(stream));
 }

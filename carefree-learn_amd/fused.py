@@ -206,7 +206,19 @@ def _flush_dw(wait: tuple = ()) -> None:
         SideStream.run(launch, tuple(t for it in items for t in (it[2], it[3])), wait=wait)
 
 
+# Round 4: the column reduce of the LayerNorm parameter gradients (13 us in the step, twice per block and batch slice: 0.35 ms
+# of each slice's dX chain) runs on the weight-gradient lane instead: only the optimizer needs its result.  The row kernels of
+# the two batch slices then write separate partial buffers and no longer wait for each other.
+LN_REDUCE_ASIDE = os.environ.get("CFHIP_LN_REDUCE_ASIDE", "1") != "0"
 SPLIT_LN_BWD = False  # round 2: ONE launch (half-wave-per-row kernel, dy and x read once) beats dx on the main stream + dgamma/dbeta on the side stream by 0.5 ms / step (profiles/r02/step_ab_ln_b128.log)
+
+
+def _ln_defers(w: Tensor, b: Tensor, dy2: Tensor) -> bool:
+    """LN_REDUCE_ASIDE applies: the one-launch row kernel serves this width, dgamma | dbeta are adjacent in the gradient arena
+    (one reduce launch), and there is a side lane to put the reduce on"""
+    return (LN_REDUCE_ASIDE and not SPLIT_LN_BWD and dy2.is_cuda and SideStream.enabled and _functional.cuda_ok()
+            and w.shape[0] % 256 == 0 and w.shape[0] <= 1280 and w.grad is not None and b.grad is not None
+            and b.grad.dtype == f32 and b.grad.data_ptr() == w.grad.data_ptr() + 4 * w.numel() and dy2.stride(0) % 8 == 0)
 
 
 def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: Tensor,
@@ -217,6 +229,25 @@ def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: T
     from .functional import grad_ready_callbacks
 
     gamma = w.detach()
+    if _ln_defers(w, b, dy2):
+        dx, ws, rows = ops.layernorm_bwd_partials(dy2, x2, gamma, mean, rstd, dx_add=dx_add, dx_out=dx_out)
+        acc = not getattr(w, "_cfhip_fresh", False)
+        if acc != (not getattr(b, "_cfhip_fresh", False)):
+            for prm in (w, b):
+                if getattr(prm, "_cfhip_fresh", False):
+                    prm.grad.zero_()
+            acc = True
+        w._cfhip_fresh = b._cfhip_fresh = False
+        d = w.shape[0]
+
+        def reduce() -> None:
+            ops.layernorm_bwd_reduce(ws, rows, d, w.grad.view(-1), b.grad.view(-1), acc)
+            if notify:
+                _functional.notify_grad_ready(w)
+                _functional.notify_grad_ready(b)
+
+        SideStream.run(reduce, (ws,))
+        return dx
 
     def param_grads(with_dx: bool = False) -> Optional[Tensor]:
         for prm in (w, b):
@@ -358,6 +389,9 @@ def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_
         cur = _functional.cur_stream() if d2.is_cuda else None
 
         def ln(which: int, dy_, x_, w_, b_, mean_, rstd_, add_, out_) -> None:
+            if _ln_defers(w_, b_, dy_):  # (the reduces of both slices queue up on ONE lane, in order: no event between the slices)
+                _ln_bwd(dy_, x_, w_, b_, mean_, rstd_, dx_add=add_, dx_out=out_, notify=last)
+                return
             if ln_done[which] is not None:
                 _functional.rec_wait_event(cur, ln_done[which])
             _ln_bwd(dy_, x_, w_, b_, mean_, rstd_, dx_add=add_, dx_out=out_, notify=last)
@@ -592,7 +626,7 @@ def _plan_for(x: Tensor, metas: tuple, keep_mask: Optional[Tensor], causal: bool
     if state is None:
         return None  # gradients outside an arena / frozen weights / some slots written and others accumulated: the normal path
     key = (tuple(x.shape), x.dtype, metas, causal, None if keep_mask is None else keep_mask.data_ptr(), FWD_HALVES, BWD_HALVES,
-           DW_GROUP_BLOCKS, DW_GROUP_TILES, DW_TAIL_BLOCKS, DW_GROUP_ON_MAIN, FIRST_SLICE_SHARE, FUSE_BIAS_GRAD,
+           DW_GROUP_BLOCKS, DW_GROUP_TILES, DW_TAIL_BLOCKS, LN_REDUCE_ASIDE, DW_GROUP_ON_MAIN, FIRST_SLICE_SHARE, FUSE_BIAS_GRAD,
            tuple(id(cb) for cb in _functional.grad_ready_callbacks), x.requires_grad, state)
     pid = id(params[0])
     plan = _plans.get(pid)

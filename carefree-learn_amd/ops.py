@@ -326,6 +326,30 @@ def layernorm_bwd(
     return dx, dgamma, dbeta
 
 
+def layernorm_bwd_partials(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, *, dx_add: Optional[Tensor] = None,
+                           dx_out: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, int]:
+    """The row kernel of `layernorm_bwd` alone: dx (+ dx_add) and the per-workgroup partial sums of dgamma | dbeta.  Returns
+    (dx, workspace, rows) for `layernorm_bwd_reduce` — which may run on another stream (cfhip_layernorm_bwd_partials / _reduce)."""
+    _need(dy, bf16, "dy")
+    m, d, xs = _mat(x, "x")
+    _, _, dys = _mat(dy, "dy")
+    dx = dx_out if dx_out is not None else torch.empty((m, d), dtype=bf16, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.cfhip_layernorm_bwd_workspace(m, d)
+    ws = torch.empty((max(nbytes, 4) // 4,), dtype=f32, device=x.device)
+    rows = ctypes.c_int(0)
+    rc = lib.cfhip_layernorm_bwd_partials(dy.data_ptr(), x.data_ptr(), int(x.dtype == f32), gamma.data_ptr(), mean.data_ptr(),
+                                          rstd.data_ptr(), _p(dx_add), dx.data_ptr(), m, d, dys, xs, dx.stride(0), ws.data_ptr(),
+                                          nbytes, ctypes.byref(rows), _stream())
+    _lib.check(rc, "layernorm_bwd_partials")
+    return dx, ws, rows.value
+
+
+def layernorm_bwd_reduce(ws: Tensor, rows: int, d: int, dgamma: Tensor, dbeta: Tensor, accumulate: bool) -> None:
+    rc = _lib.load().cfhip_layernorm_bwd_reduce(ws.data_ptr(), rows, d, dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate), _stream())
+    _lib.check(rc, "layernorm_bwd_reduce")
+
+
 # ---------------------------------------------------------------------------------------------
 # attention (head_dim 64).  q / k / v / o are [B, T, H*64] views (any batch / token strides).
 # ---------------------------------------------------------------------------------------------

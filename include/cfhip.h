@@ -158,6 +158,14 @@ int cfhip_layernorm_bwd(const void* dy, const void* x, int x_is_f32, const float
                         int M, int D, int64_t dy_row_stride, int64_t x_row_stride,
                         int64_t dx_row_stride, int accumulate_param_grads, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* cfhip_layernorm_bwd in two calls: `_partials` = the row kernel (dx (+ dx_add), per-workgroup partial sums of dgamma | dbeta into
+ * `workspace`, *rows_out = number of partial rows), `_reduce` = their column sums (+)= into dgamma / dbeta on any stream the caller
+ * orders behind it.  The input gradient is on the backward's critical chain, the parameter gradients are not. */
+int cfhip_layernorm_bwd_partials(const void* dy, const void* x, int x_is_f32, const float* gamma, const float* mean,
+                                 const float* rstd, const void* dx_add, void* dx, int M, int D, int64_t dy_row_stride,
+                                 int64_t x_row_stride, int64_t dx_row_stride, void* workspace, size_t workspace_bytes,
+                                 int* rows_out, void* stream);
+int cfhip_layernorm_bwd_reduce(void* workspace, int rows, int D, float* dgamma, float* dbeta, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K3/K4  fused scaled-dot-product attention (replaces F.scaled_dot_product_attention reached
