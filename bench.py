@@ -397,12 +397,9 @@ def bench_other_workload(args) -> None:
     print(json.dumps(run_other_workload(args)))
 
 
-def run_other_workload(args) -> dict:
-    """BASELINE configs 3 / 4 on ONE GPU (the multi-GPU path of these models is the same `BucketedAllReduce`; their
-    default batch follows SURVEY §8d).  A dict with the keys of the headline line; `roofline` is the MFMA roofline of the
-    whole step: counted MFMA-class FLOPs (ops.FlopCounter: GEMMs, implicit convolutions, attention) / wall time."""
+def build_other_workload(args):
+    """model + step engine + synthetic batch of `--workload unet | clip`: (step closure, model, name, batch, loss divisor)"""
     import cflearn_amd as C
-    from cflearn_amd import ops
 
     dev = torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(0)
@@ -440,6 +437,16 @@ def run_other_workload(args) -> dict:
         step = lambda: ts.step(data)  # noqa: E731
         name = "CLIP (ViT-B/32 + 12 x 512 causal text tower) symmetric InfoNCE step, fwd + bwd + fused AdamW"
         loss_div = 1
+    return step, m, name, batch, loss_div
+
+
+def run_other_workload(args) -> dict:
+    """BASELINE configs 3 / 4 on ONE GPU (the multi-GPU path of these models is the same `BucketedAllReduce`; their
+    default batch follows SURVEY §8d).  A dict with the keys of the headline line; `roofline` is the MFMA roofline of the
+    whole step: counted MFMA-class FLOPs (ops.FlopCounter: GEMMs, implicit convolutions, attention) / wall time."""
+    from cflearn_amd import ops
+
+    step, m, name, batch, loss_div = build_other_workload(args)
     n_params = sum(p.numel() for p in m.parameters())
     first = None
     for i in range(args.warmup):

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(AttnParams p, int n
 // PLAIN: no predicate — a kv row past Tk only pollutes its own (never stored) dK / dV row, padded query
 // rows carry lse = +inf (p = 0).
 template <bool PLAIN>
-__global__ __launch_bounds__(512, 4) void attn_bwd_dkv_kernel(AttnParams p, int nbq) {
+__global__ __launch_bounds__(512, PLAIN ? 4 : 2) void attn_bwd_dkv_kernel(AttnParams p, int nbq) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
   char* dOs = smem + nbq * 32 * 128;
@@ -693,8 +693,9 @@ __device__ __forceinline__ bf16x8 frag_global_dh(const bf16_t* base, long stride
   return r;
 }
 
+// (DROP: the Philox state and the keep bytes need registers beyond the 128 of four waves per SIMD — two per SIMD, no scratch)
 template <int NH, bool PLAIN, bool DROP = false>
-__global__ __launch_bounds__(512, NH == 1 ? 4 : 2) void attn_gen_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(512, (NH == 1 && !DROP) ? 4 : 2) void attn_gen_fwd_kernel(AttnParams p) {
   using G = Gen<NH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
@@ -1289,8 +1290,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd2_kernel(AttnParams p) {
 // dQ pass, two query tiles per wave (see attn_fwd2_kernel): per 32-key block the four K / V row fragments and the NDT K column
 // fragments are read once for both tiles: 22 MFMAs per 8 ds_read_b128 + 6 ds_read_b64_tr_b16 (NDT = 3) against 12 per 8 + 8.
 // Key rows beyond Tk are zero rows of the staged chunk: their p is finite, their dP and their K are zero, they add nothing.
+// (masked / causal instantiations: the predicate registers do not fit beside two 16-row tiles at 128 registers — two waves per
+// SIMD for them, no scratch; PLAIN, the UNet's and the ViT's path, keeps four)
 template <bool PLAIN, int NDT>
-__global__ __launch_bounds__(512, 4) void attn_bwd_dq2_kernel(AttnParams p) {
+__global__ __launch_bounds__(512, PLAIN ? 4 : 2) void attn_bwd_dq2_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + A2_TILE;
@@ -1409,7 +1412,7 @@ constexpr int A2D_TILE = A2D_CH * 128;
 // 64-column halves of the staged operands (66 KB of LDS, ~215 registers: two workgroups per CU) — the general one-tile kernel
 // ran this head_dim at 342 TFLOP/s against 800 for head_dim 40 here.
 template <bool PLAIN, int NDT>
-__global__ __launch_bounds__(256, NDT == 3 ? 3 : 2) void attn_bwd_dkv2_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (NDT == 3 && PLAIN) ? 3 : 2) void attn_bwd_dkv2_kernel(AttnParams p) {
   constexpr int KS = (NDT + 1) / 2;     // 32-deep steps of the reductions over head_dim
   constexpr int NHALF = (NDT + 3) / 4;  // 64-column halves of a staged operand
   extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -527,8 +527,15 @@ int launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
   }
   if constexpr (PIPE) kern = gemm_bf16_phase_kernel<AT, BT, EPI, C, CONV>;
   else if constexpr (AT && BT && EPI == CFHIP_EPI_NONE) {
-    if (p.bgrad != nullptr) kern = gemm_bf16_kernel<AT, BT, EPI, C, CONV, true>;
-    else kern = gemm_bf16_kernel<AT, BT, EPI, C, CONV, false>;
+    if (p.bgrad != nullptr) {
+      // (the bias-gradient rows of a 256-row tile do not fit beside its accumulators: 52 bytes of scratch per lane — such
+      // requests are routed to configuration 1 in cfhip_gemm_bf16, the instantiation does not exist)
+      if constexpr (C::BM * C::BN <= 192 * 128) kern = gemm_bf16_kernel<AT, BT, EPI, C, CONV, true>;
+      else {
+        cfhip_set_error("gemm: the fused bias gradient is not provided by this tile configuration");
+        return CFHIP_ERR_INVALID;
+      }
+    } else kern = gemm_bf16_kernel<AT, BT, EPI, C, CONV, false>;
   } else kern = gemm_bf16_kernel<AT, BT, EPI, C, CONV>;
   static bool attr_done_bg[2] = {false, false};  // per instantiation and per kernel picked above
   bool& attr_done = attr_done_bg[p.bgrad != nullptr ? 1 : 0];
@@ -550,6 +557,13 @@ int launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
   return CFHIP_OK;
 }
 
+// instantiations that spilled and are not needed: the residual / GELU' epilogues on 128x128x32 (configuration 1: 12 / 40 bytes per
+// lane — cfhip_gemm_bf16 sends those requests to 128x64x64), the weight-gradient layout on the 256x128x32 phase kernel (12 bytes)
+template <class C, bool PIPE>
+constexpr bool kHasEpilogues = !(C::BM == 128 && C::BN == 128 && C::BK == 32 && C::NSTAGE == 2);
+template <class C, bool PIPE>
+constexpr bool kHasTn = !(PIPE && C::BM == 256 && C::BN == 128 && C::WN == 4 && C::NSTAGE == 3);
+
 template <class C, bool PIPE = false>
 int launch_layout(GemmParams p, int a_trans, int b_trans, int epilogue, int split_k, hipStream_t s) {
   p.tiles_m = (p.M + C::BM - 1) / C::BM;
@@ -564,17 +578,21 @@ int launch_layout(GemmParams p, int a_trans, int b_trans, int epilogue, int spli
     switch (epilogue) {
       case CFHIP_EPI_NONE: return launch_cfg<false, false, CFHIP_EPI_NONE, C, PIPE>(p, grid, s);
       case CFHIP_EPI_GELU: return launch_cfg<false, false, CFHIP_EPI_GELU, C, PIPE>(p, grid, s);
-      case CFHIP_EPI_RESIDUAL: return launch_cfg<false, false, CFHIP_EPI_RESIDUAL, C, PIPE>(p, grid, s);
+      case CFHIP_EPI_RESIDUAL:
+        if constexpr (kHasEpilogues<C, PIPE>) return launch_cfg<false, false, CFHIP_EPI_RESIDUAL, C, PIPE>(p, grid, s);
+        break;
       default: break;
     }
   } else if (!a_trans && b_trans) {
     switch (epilogue) {
       case CFHIP_EPI_NONE: return launch_cfg<false, true, CFHIP_EPI_NONE, C, PIPE>(p, grid, s);
-      case CFHIP_EPI_DGELU: return launch_cfg<false, true, CFHIP_EPI_DGELU, C, PIPE>(p, grid, s);
+      case CFHIP_EPI_DGELU:
+        if constexpr (kHasEpilogues<C, PIPE>) return launch_cfg<false, true, CFHIP_EPI_DGELU, C, PIPE>(p, grid, s);
+        break;
       default: break;
     }
   } else if (epilogue == CFHIP_EPI_NONE) {
-    return launch_cfg<true, true, CFHIP_EPI_NONE, C, PIPE>(p, grid, s);
+    if constexpr (kHasTn<C, PIPE>) return launch_cfg<true, true, CFHIP_EPI_NONE, C, PIPE>(p, grid, s);
   }
   cfhip_set_error("gemm: epilogue %d is not provided for layout (%d,%d)", epilogue, a_trans, b_trans);
   return CFHIP_ERR_INVALID;
@@ -812,6 +830,10 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
     }
     cfg = a_trans ? 1 : 15;  // shapes the pipelined kernels do not take
   }
+  // requests whose instantiation does not exist (see kHasEpilogues / kHasTn / the bias-gradient note in launch_cfg)
+  if (cfg == 1 && (epilogue == CFHIP_EPI_RESIDUAL || epilogue == CFHIP_EPI_DGELU)) cfg = 3;
+  if (cfg == 8 && a_trans) cfg = 1;
+  if (bias_grad != nullptr && (cfg == 13 || cfg == 16 || cfg == 7 || cfg == 12)) cfg = 1;
   switch (cfg) {
     case 1: rc = launch_layout<CfgB>(p, a_trans, b_trans, epilogue, split_k, s); break;
     case 2: rc = launch_layout<CfgC>(p, a_trans, b_trans, epilogue, split_k, s); break;

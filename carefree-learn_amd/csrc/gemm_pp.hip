@@ -180,7 +180,10 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x16 (&acc)[C
     const int row = wm * C::TM + (ch / (C::TN / 64)) * 32 + ps * RPP + rr;
     return (unsigned)(row * (int)p.ldc + col_of(ch));
   };
-  u32x4 aux[2][NP];
+  // operands the epilogue reads are fetched one chunk ahead (two register sets) — except for the f32 residual stream on the
+  // 128x128 wave tile, where the second set (32 registers) pushed the kernel into scratch: one set, fetched per chunk
+  constexpr int AD = (F32 && C::FM * C::FN >= 16) ? 1 : 2;
+  u32x4 aux[AD][NP];
   auto load_aux = [&](int ch, u32x4 (&dst)[NP]) {
     const bool ok = n0 + col_of(ch) < p.N;
 #pragma unroll
@@ -191,7 +194,8 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x16 (&acc)[C
   for (int ch = 0; ch < NCH; ++ch) {
     const int mb = ch / (C::TN / 64), cc = ch % (C::TN / 64);
     if constexpr (HAS_AUX) {
-      if (ch + 1 < NCH) load_aux(ch + 1, aux[(ch + 1) & 1]);
+      if (AD == 2 && ch + 1 < NCH) load_aux(ch + 1, aux[(ch + 1) % AD]);
+      if (AD == 1 && ch > 0) load_aux(ch, aux[0]);
     }
     // accumulators -> strip
 #pragma unroll
@@ -213,7 +217,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x16 (&acc)[C
       if constexpr (F32) {
         f32x4 v = *reinterpret_cast<const f32x4*>(strip + r * 256 + ((((cl >> 2)) ^ (r & 15)) << 4));
         v += b_lo;
-        if constexpr (HAS_AUX) v += __builtin_bit_cast(f32x4, aux[ch & 1][ps]);
+        if constexpr (HAS_AUX) v += __builtin_bit_cast(f32x4, aux[ch % AD][ps]);
         bstore16(c_rsrc, c_ok ? e * 4u : OOB, __builtin_bit_cast(u32x4, v));
       } else {
         f32x4 lo = *reinterpret_cast<const f32x4*>(strip + r * 256 + ((((cl >> 2)) ^ (r & 15)) << 4));
@@ -232,11 +236,11 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x16 (&acc)[C
             hi = f32x4{gelu_erf_f(bf16lo(w[2])), gelu_erf_f(bf16hi(w[2])), gelu_erf_f(bf16lo(w[3])), gelu_erf_f(bf16hi(w[3]))};
           }
         } else if constexpr (EPI == CFHIP_EPI_RESIDUAL) {
-          const u32x4 w = aux[ch & 1][ps];
+          const u32x4 w = aux[ch % AD][ps];
           lo += f32x4{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
           hi += f32x4{bf16lo(w[2]), bf16hi(w[2]), bf16lo(w[3]), bf16hi(w[3])};
         } else if constexpr (EPI == CFHIP_EPI_DGELU) {
-          const u32x4 w = aux[ch & 1][ps];
+          const u32x4 w = aux[ch % AD][ps];
           if constexpr (QUICK) {
             lo *= f32x4{quick_gelu_grad_f(bf16lo(w[0])), quick_gelu_grad_f(bf16hi(w[0])), quick_gelu_grad_f(bf16lo(w[1])), quick_gelu_grad_f(bf16hi(w[1]))};
             hi *= f32x4{quick_gelu_grad_f(bf16lo(w[2])), quick_gelu_grad_f(bf16hi(w[2])), quick_gelu_grad_f(bf16lo(w[3])), quick_gelu_grad_f(bf16hi(w[3]))};

@@ -563,6 +563,15 @@ static int ln_bwd_impl(const void* dy, const void* x, int x_is_f32, const float*
     }
     return ln_bwd_reduce(partials, blocks2, D, dgamma, dbeta, accumulate_param_grads, s);
   }
+  // rows wider than 1280: the kernel that produces dx AND the parameter partials keeps the whole row twice in registers and
+  // spilled 300-376 bytes per lane at D = 2048 — two launches (dx, then the partials) fit
+  if (do_dx && do_pg && nch >= 5) {
+    int rc = ln_bwd_impl(dy, x, x_is_f32, gamma, mean, rstd, dx_add, dx, nullptr, nullptr, M, D, dy_row_stride, x_row_stride,
+                         dx_row_stride, 0, nullptr, 0, stream, nullptr);
+    if (rc != CFHIP_OK) return rc;
+    return ln_bwd_impl(dy, x, x_is_f32, gamma, mean, rstd, nullptr, nullptr, dgamma, dbeta, M, D, dy_row_stride, x_row_stride,
+                       dx_row_stride, accumulate_param_grads, workspace, workspace_bytes, stream, rows_out);
+  }
   const int blocks = ln_grid(M, do_pg ? 512 : 1024);  // dx-only: fewer registers, twice the waves
   const size_t lds = do_pg ? (size_t)2 * D * sizeof(float) : 0;
 #define LN_BWD_ONE(N_, EX_, XT_, DX_, PG_)                                                               \
@@ -572,8 +581,9 @@ static int ln_bwd_impl(const void* dy, const void* x, int x_is_f32, const float*
                      (long)dx_row_stride)
 #define LN_BWD_MODE(N_, EX_, XT_)                                     \
   do {                                                                \
-    if (do_dx && do_pg) LN_BWD_ONE(N_, EX_, XT_, true, true);          \
-    else if (do_dx) LN_BWD_ONE(N_, EX_, XT_, true, false);             \
+    if (do_dx && do_pg) {                                              \
+      if constexpr (N_ < 6) LN_BWD_ONE(N_, EX_, XT_, true, true);      \
+    } else if (do_dx) LN_BWD_ONE(N_, EX_, XT_, true, false);           \
     else LN_BWD_ONE(N_, EX_, XT_, false, true);                        \
   } while (0)
 #define LN_BWD(N_, EX_)                        \
