@@ -12,7 +12,12 @@ Rank 0 prints ONE JSON line (metric = BASELINE.json's: train samples/sec + step 
 Extra fields / objects:
   host_issue_ms_per_step   wall time the host needed to ISSUE the timed steps (it never waits for the device inside): the device is
                 the bound when this is well below ms_per_step (ViT: 10.3 of 18.0 ms), the Python path when it is not.
-  step_ms       median / p10 / p90 / min / max of per-step HIP-event timings;  other_workloads: UNet 64^2 x 8 and CLIP b256 steps.
+  step_ms       median / p10 / p90 / min / max of per-step HIP-event timings;  other_workloads: UNet 64^2 x 8, UNet 256^2 x 1 (BASELINE
+                config 4 as stated) and CLIP b256 steps.
+  streams       did every helper stream (batch slices, weight-gradient lane, comm stream) get a hardware queue of its own
+                (functional.stream_report)?  `distinct: false` = a serialised step; a multi-GPU run then exits non-zero.
+  rccl          (N > 1 / --force-ddp) who launches the collectives, ncclCommCount / ncclCommUserRank of the C-ABI communicator,
+                NCCL_MAX_NCHANNELS (--nchannels), buckets, wire dtype, the all-reduce self-test.
   roofline      dominant kernel family = the MFMA GEMM (`gemm_grouped_tn_kernel<*>` / `gemm_bf16_kernel<*>`, 96 % of the step's
                 FLOPs).  `achieved` = algorithmic FLOPs of every GEMM launch of one step (2*M*N*K each, the per-sample
                 figure of SURVEY §8d x the batch) / the SUM OF THEIR IN-STEP DURATIONS: HIP-event pairs around every
@@ -21,6 +26,8 @@ Extra fields / objects:
                 streams overlap, that sum exceeds the wall time of the step; two more views are carried next to it:
                 `isolated` (each shape timed alone, random operands) and `wall` (GEMM FLOPs / measured step time — the
                 lower bound nobody can argue with).  peak = 2500 TFLOP/s dense bf16.
+                `dominant_kernel`: `by_kernel` = in-step timings summed per kernel INSTANTIATION (cfhip_gemm_kernel_name: the row a
+                rocprofv3 --stats summary lists first), `by_launch_shape` = the single launch shape with the most time.
                 `traffic` = HBM-side bytes of the family from PMC passes (tools/gpu/run.sh pmc): only reported when
                 the committed pass was taken on THIS kernel source (sha256 of the GEMM sources recorded in the JSON),
                 otherwise null with `traffic_stale`.
