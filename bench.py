@@ -888,7 +888,7 @@ def main() -> None:
             wl = name
             try:
                 r = run_other_workload(a2)
-                others[wl] = {k_: r[k_] for k_ in ("value", "unit", "ms_per_step", "steps", "warmup", "roofline", "peak_mem_gb")}
+                others[wl] = {k_: r[k_] for k_ in ("value", "unit", "ms_per_step", "host_issue_ms_per_step", "steps", "warmup", "roofline", "peak_mem_gb")}
                 others[wl]["workload"] = r["config"]["workload"]
                 others[wl]["per_gpu_batch"] = r["config"]["per_gpu_batch"]
             except Exception as e:  # the headline line must survive a failure here

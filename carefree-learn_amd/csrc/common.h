@@ -21,15 +21,18 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // pending LDS store that may alias every later ds_read and puts `s_waitcnt vmcnt(0)` in front of the next LDS read — in the
 // K loops of the GEMM kernels that drained the DMA queue once per K-step, i.e. the rings never prefetched anything (the ISA
 // of every round-1/2 GEMM loop shows it: tools/isa_waits.py).  The asm form is invisible to that pass: completion is counted
-// by hand (CFHIP_WAIT_VMCNT, then a barrier, then the ds_read — the protocol the kernels were written for anyway).  M0 is
-// written in the same statement that reads it (the compiler neither preserves nor uses it around LDS instructions on gfx950).
+// by hand (CFHIP_WAIT_VMCNT, then a barrier, then the ds_read — the protocol the kernels were written for anyway).  The LDS
+// address is bound to M0 through an "{m0}" input constraint: the COMPILER writes M0 (and so knows it is written: a value it
+// keeps there for movrel indexing / sendmsg / the builtin DMA form is rebuilt, not silently lost; an "m0" clobber is refused
+// as a reserved register); the s_nop covers the M0-write -> LDS-DMA wait state, which the hazard recogniser cannot see
+// inside an asm statement.
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, const void* lds_dst, unsigned voff) {
 #ifdef CFHIP_DMA_BUILTIN  // A/B builds only (tools/build_variant.sh dmabuiltin -DCFHIP_DMA_BUILTIN): the round-1/2 form
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(const_cast<void*>(lds_dst)), 16, voff, 0, 0, 0);
   return;
 #endif
   const unsigned la = (unsigned)(uintptr_t)LDS_PTR(const_cast<void*>(lds_dst));
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(rsrc) : "memory");
+  asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"{m0}"(la), "v"(voff), "s"(rsrc) : "memory");
 }
 
 // Every LDS-DMA this wave has issued has landed (follow with a barrier before other waves read the tile).  Needed because
@@ -40,7 +43,7 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, const voi
 // (gfx9 raw buffers: the range check covers voffset only, an out-of-range lane stays out of range whatever the soffset.)
 __device__ __forceinline__ void lds_dma16_s(__amdgpu_buffer_rsrc_t rsrc, const void* lds_dst, unsigned voff, unsigned soff) {
   const unsigned la = (unsigned)(uintptr_t)LDS_PTR(const_cast<void*>(lds_dst));
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(la), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"{m0}"(la), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

@@ -627,7 +627,7 @@ def _plan_for(x: Tensor, metas: tuple, keep_mask: Optional[Tensor], causal: bool
         return None  # gradients outside an arena / frozen weights / some slots written and others accumulated: the normal path
     key = (tuple(x.shape), x.dtype, metas, causal, None if keep_mask is None else keep_mask.data_ptr(), FWD_HALVES, BWD_HALVES,
            DW_GROUP_BLOCKS, DW_GROUP_TILES, DW_TAIL_BLOCKS, LN_REDUCE_ASIDE, DW_GROUP_ON_MAIN, FIRST_SLICE_SHARE, FUSE_BIAS_GRAD,
-           tuple(id(cb) for cb in _functional.grad_ready_callbacks), x.requires_grad, state)
+           ops.FORCE_SPLIT_K, tuple(id(cb) for cb in _functional.grad_ready_callbacks), x.requires_grad, state)
     pid = id(params[0])
     plan = _plans.get(pid)
     if plan is None or plan.key != key or (plan.params_ref and plan.params_ref[0]() is not params[0]):

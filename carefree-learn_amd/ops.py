@@ -60,8 +60,13 @@ def set_option(name: str, value: int) -> None:
 # ---------------------------------------------------------------------------------------------
 
 
+FORCE_SPLIT_K = int(os.environ.get("CFHIP_FORCE_SPLIT_K", "0"))  # A/B runs: > 0 = every weight-gradient GEMM takes this split
+
+
 def pick_split_k(m: int, n: int, k: int) -> int:
     """Split the reduction when the output has too few 128x128 tiles to fill 256 CUs."""
+    if FORCE_SPLIT_K > 0:
+        return FORCE_SPLIT_K
     tiles = ((m + 127) // 128) * ((n + 127) // 128)
     steps = (k + 63) // 64
     if tiles >= 256 or steps < 16:

@@ -25,8 +25,10 @@ img = torch.randn(BATCH, 3, 224, 224, generator=g).to(dev)
 labels = torch.randint(0, 1000, (BATCH,), generator=g).to(dev)
 
 
-def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt=-1, nn=-1, share=0.5, heuristic=8):
+def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt=-1, nn=-1, share=0.5, heuristic=8, tn=-1, split=0):
     def f():
+        ops.FORCE_SPLIT_K = split
+        ops.set_option("gemm_cfg_tn", tn)
         fused.FIRST_SLICE_SHARE = share
         ops.set_option("gemm_heuristic", heuristic)
         fused.DW_GROUP_BLOCKS = blocks
@@ -60,6 +62,21 @@ VARIANTS = {
     "nn=c0 ntw=c0 nt=c0": setv(2, nn=0, nt_wide=0, nt=0),
     "one-pass fwd, nn=c13 ntw=c13 nt=c13": setv(2, halves=1, nn=13, nt_wide=13, nt=13),
     "one-pass both, all c13": setv(2, halves=1, bhalves=1, nn=13, nt_wide=13, nt=13),
+    # round 4: weight gradients per operator on the side lane, every tile its whole reduction (no slabs, no reduce), on the
+    # 80 KB plain kernel — leaves LDS room for a forward / dX workgroup on the same CU, unlike the 160 KB grouped kernel
+    "plain grouped dW 192x128x64, 1 block / launch": setv(1, variant=64),
+    "plain grouped dW 192x128x64, 2 blocks / launch": setv(2, variant=64),
+    "plain grouped dW 192x128x64, 3 blocks / launch": setv(3, variant=64),
+    "plain grouped dW 192x128x64, 4 blocks / launch": setv(4, variant=64),
+    "plain grouped dW 192x128x64, 6 blocks / launch": setv(6, variant=64),
+    "plain grouped dW 128x128x64, 2 blocks / launch": setv(2, variant=128),
+    "plain grouped dW 128x128x64, 4 blocks / launch": setv(4, variant=128),
+    "per-op dW, whole reduction, tn=c15 (192x128x64, 4 waves)": setv(0, tn=15, split=1),
+    "per-op dW, whole reduction, tn=c14 (192x128x64, 8 waves)": setv(0, tn=14, split=1),
+    "per-op dW, whole reduction, tn=c0 (128x128x64)": setv(0, tn=0, split=1),
+    "per-op dW, split 2, tn=c15": setv(0, tn=15, split=2),
+    "per-op dW, split 2, tn=c0": setv(0, tn=0, split=2),
+    "per-op dW, r2 path (split-K heuristic, 128x128x32)": setv(0),
     # round 4: the software-pipelined 32x32x16 kernels of csrc/gemm_pp.hip (pass the configuration numbers: pp=<ntw>,<nt>,<nn>)
 }
 for a in list(sys.argv[2:]):
