@@ -37,6 +37,7 @@ SIGNATURES = {
          c_int, c_int, c_int, _P, c_size_t, _P, c_int, _P],
     ),
     "cfhip_gemm_bf16_grouped_tn": (c_int, [_P, c_int, _P]),
+    "cfhip_gemm_bf16_grouped_tn_tiles": (c_int, [_P, c_int, c_int, _P]),
     "cfhip_colsum_workspace": (c_size_t, [c_int, c_int]),
     "cfhip_colsum_bf16": (c_int, [_P, _P, c_int, c_int, c_int64, c_int, _P, c_size_t, _P]),
     "cfhip_layernorm_fwd": (
@@ -66,6 +67,19 @@ SIGNATURES = {
         c_int,
         [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
          c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, _P],
+    ),
+    "cfhip_conv2d_grouped_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 11 + [_P]),
+    "cfhip_conv2d_grouped_bwd_input": (c_int, [_P, _P, _P] + [c_int] * 11 + [_P]),
+    "cfhip_conv2d_grouped_bwd_weight": (c_int, [_P, _P, _P, c_int, _P, c_int] + [c_int] * 11 + [_P]),
+    "cfhip_attn_probs": (
+        c_int,
+        [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
+         c_float, c_int, _P],
+    ),
+    "cfhip_attn_probs_bwd": (
+        c_int,
+        [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
+         c_int64, c_float, c_int, _P],
     ),
     "cfhip_attn_bwd_dh": (
         c_int,

@@ -380,10 +380,21 @@ int cfhip_internal_set_grouped_variant(int v) {
   return CFHIP_OK;
 }
 
+static int grouped_tn(const cfhip_gemm_problem* problems, int count, int kernel, void* stream);
+
 extern "C" int cfhip_gemm_bf16_grouped_tn(const cfhip_gemm_problem* problems, int count, void* stream) {
+  return grouped_tn(problems, count, g_grouped_kernel, stream);
+}
+
+extern "C" int cfhip_gemm_bf16_grouped_tn_tiles(const cfhip_gemm_problem* problems, int count, int tile_kind, void* stream) {
+  CFHIP_REQUIRE(tile_kind >= 0 && tile_kind <= 2, "gemm_grouped: tile_kind %d (0: 256x256x32, 1: 192x128x64, 2: 128x128x64)", tile_kind);
+  return grouped_tn(problems, count, tile_kind, stream);
+}
+
+static int grouped_tn(const cfhip_gemm_problem* problems, int count, int kernel, void* stream) {
   CFHIP_REQUIRE(problems != nullptr && count > 0, "gemm_grouped: no problems");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (g_grouped_kernel != 0) {  // the 80 KB forms (gemm.hip: gemm_grouped_plain_kernel): same checks, other tiles
+  if (kernel != 0) {  // the 80 KB forms (gemm.hip: gemm_grouped_plain_kernel): same checks, other tiles
     for (int i = 0; i < count; ++i) {
       const cfhip_gemm_problem& src = problems[i];
       CFHIP_REQUIRE(src.A && src.B && src.C, "gemm_grouped: null operand in problem %d", i);
@@ -395,7 +406,7 @@ extern "C" int cfhip_gemm_bf16_grouped_tn(const cfhip_gemm_problem* problems, in
       CFHIP_REQUIRE((long)src.K * src.lda * 2 < 0x7fffffffL && (long)src.K * src.ldb * 2 < 0x7fffffffL && (long)src.M * src.ldc * 4 < 0x7fffffffL,
                     "gemm_grouped: problem %d exceeds the 2 GiB descriptor range (K=%d lda=%ld ldb=%ld)", i, src.K, (long)src.lda, (long)src.ldb);
     }
-    return cfhip_internal_gemm_grouped_plain(problems, count, g_grouped_kernel, stream);
+    return cfhip_internal_gemm_grouped_plain(problems, count, kernel, stream);
   }
   for (int base = 0; base < count; base += GROUP_MAX) {
     const int n = count - base < GROUP_MAX ? count - base : GROUP_MAX;

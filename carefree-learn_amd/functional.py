@@ -14,6 +14,8 @@ post-accumulate hooks do not fire for such parameters, `grad_ready_callbacks` is
 import os
 from typing import Any, Callable, List, Optional, Tuple
 
+import math
+
 import torch
 from torch import Tensor
 from torch.autograd import Function
@@ -707,6 +709,46 @@ class AttentionCoreFn(Function):
         return dq, dk, dv, None, None, None, None, None
 
 
+class AttentionWeightsFn(Function):
+    """(output, weights) for separately projected q / k / v — the reference's slow path `require_weights=True` /
+    `customize_sdp` (attentions.py:256-268).  The output is the fused kernels' (scale = 1 / `scaling`: the slow path is
+    the one place where the reference honours `qk_scale`); the weights f32 [B, H, Tq, Tk] are rebuilt from the saved
+    log-sum-exp (`cfhip_attn_probs`); a gradient on the weights reaches q and k through `cfhip_attn_probs_bwd`."""
+
+    @staticmethod
+    def forward(ctx: Any, q: Tensor, k: Tensor, v: Tensor, num_heads: int, keep_mask: Optional[Tensor], causal: bool,
+                head_dim: int, scale: float):
+        q, k, v = (t if t.dtype == bf16 else ops.to_bf16(t.float().contiguous()) for t in (q, k, v))
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        o, lse = ops.attn_fwd(q, k, v, num_heads, mask=keep_mask, causal=causal, head_dim=head_dim, scale=scale)
+        probs = ops.attn_probs(q, k, lse, num_heads, mask=keep_mask, causal=causal, head_dim=head_dim, scale=scale)
+        ctx.save_for_backward(q, k, v, o, lse, keep_mask)
+        ctx.num_heads, ctx.causal, ctx.head_dim, ctx.scale = num_heads, causal, head_dim, scale
+        ctx.set_materialize_grads(False)
+        return o, probs
+
+    @staticmethod
+    def backward(ctx: Any, d_o: Optional[Tensor], d_p: Optional[Tensor]):  # type: ignore
+        q, k, v, o, lse, keep_mask = ctx.saved_tensors
+        kw = dict(mask=keep_mask, causal=ctx.causal, head_dim=ctx.head_dim, scale=ctx.scale)
+        dq = dk = dv = None
+        if d_o is not None:
+            d_o = (d_o if d_o.dtype == bf16 else ops.to_bf16(d_o.float())).contiguous()
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            ops.attn_bwd(q, k, v, o, d_o, lse, ctx.num_heads, dq=dq, dk=dk, dv=dv, **kw)
+        if d_p is not None:
+            dq2, dk2 = ops.attn_probs_bwd(q, k, lse, d_p.float().contiguous(), ctx.num_heads, **kw)
+            dq = dq2 if dq is None else ops.add(dq, dq2)
+            dk = dk2 if dk is None else ops.add(dk, dk2)
+        return dq, dk, dv, None, None, None, None, None
+
+
+def attention_with_weights(q: Tensor, k: Tensor, v: Tensor, num_heads: int, keep_mask: Optional[Tensor] = None,
+                           causal: bool = False, head_dim: int = 64, scale: Optional[float] = None):
+    return AttentionWeightsFn.apply(q, k, v, num_heads, keep_mask, causal, head_dim,
+                                    1.0 / math.sqrt(float(head_dim)) if scale is None else float(scale))
+
+
 def _take_attn_dropout(dropout_p: float, b: int, num_heads: int, tq: int, tk: int) -> dict:
     """kernel arguments of one attention call with dropout on the probabilities: draws its (seed, offset) from the
     process-wide Philox stream; the backward passes get the same pair and regenerate the mask"""
@@ -1029,7 +1071,59 @@ class Conv2dFn(Function):
         return dx, gw, gb, None, None, None
 
 
-def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int, pad: int, dil: int = 1) -> Tensor:
+class GroupedConv2dFn(Function):
+    """F.conv2d with groups > 1 (reference convs/basic.py:160-177; depthwise = groups == Cin): the direct kernels of
+    csrc/conv_grouped.hip — an option outside the benchmark configurations, correct and deterministic, not tuned."""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int, pad: int, dil: int, groups: int) -> Tensor:
+        x2 = (x if x.dtype == bf16 else ops.to_bf16(x.float().contiguous())).contiguous()
+        w16 = shadow_bf16(weight).view(weight.shape)
+        bias_f = None if bias is None else bias.detach().reshape(-1).contiguous()
+        ctx.save_for_backward(x2, w16)
+        ctx.weight, ctx.bias, ctx.geom = weight, bias, (stride, pad, dil, groups)
+        return ops.conv2d_grouped_fwd(x2, w16, bias_f, stride, pad, dil, groups)
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        x2, w16 = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        stride, pad, dil, groups = ctx.geom
+        dy = (dy if dy.dtype == bf16 else ops.to_bf16(dy.float().contiguous())).contiguous()
+        want_b = bias is not None and bias.requires_grad
+        gw = gb = None
+        if weight.requires_grad or want_b:
+            direct_w, direct_b = _is_direct(weight), (want_b and _is_direct(bias))
+            dw = db = None
+            acc_w = acc_b = False
+            if weight.requires_grad and direct_w:
+                if weight.grad is None:
+                    weight.grad = grad_buffer(weight)
+                    weight._cfhip_fresh = True
+                dw, acc_w = weight.grad, not getattr(weight, "_cfhip_fresh", False)
+            else:
+                dw = gw = torch.empty(weight.shape, dtype=f32, device=dy.device)  # (also the scratch of a bias-only request)
+            if want_b and direct_b:
+                if bias.grad is None:
+                    bias.grad = grad_buffer(bias)
+                    bias._cfhip_fresh = True
+                db, acc_b = bias.grad.view(-1), not getattr(bias, "_cfhip_fresh", False)
+            elif want_b:
+                db = gb = torch.empty(bias.shape, dtype=f32, device=dy.device)
+            ops.conv2d_grouped_bwd_weight(dy, x2, dw, acc_w, db, acc_b, stride, pad, dil, groups)
+            for prm, direct in ((weight, weight.requires_grad and direct_w), (bias, direct_b)):
+                if direct:
+                    prm._cfhip_fresh = False
+                    notify_grad_ready(prm)
+            if not weight.requires_grad:
+                gw = None
+        dx = ops.conv2d_grouped_bwd_input(dy, w16, x2.shape, stride, pad, dil, groups) if ctx.needs_input_grad[0] else None
+        return dx, gw, gb, None, None, None, None
+
+
+def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int, pad: int, dil: int = 1, groups: int = 1) -> Tensor:
+    if groups != 1:
+        return GroupedConv2dFn.apply(x, weight, bias, stride, pad, dil, groups)
     return Conv2dFn.apply(x, weight, bias, stride, pad, dil)
 
 

@@ -84,6 +84,11 @@ _slice_streams: list = []  # streams of the backward's batch slices beyond the c
 # per gradient (whole-reduction 256 x 256 tiles on a handful of CUs would take longer than 128 x 128 split-K tiles on all).
 LINEAR_DW_TILES = int(os.environ.get("CFHIP_LINEAR_DW_TILES", "0"))  # (env: A/B runs)  0: LinearFn computes its weight gradient on the spot (round-1/2 behaviour)
 DW_MIN_TILES = int(os.environ.get("CFHIP_DW_MIN_TILES", "48"))
+# Round 4: the tile form of a flush that holds stand-alone Linear gradients only (ops.GROUPED_TILE_SHAPES: 0 = 256 x 256 on a
+# whole CU, 1 = 192 x 128 x 64, 2 = 128 x 128 x 64 — two workgroups per CU, for the UNet's many 9-60-tile projections); the
+# two thresholds above then count tiles of THAT shape.
+LINEAR_DW_KERNEL = int(os.environ.get("CFHIP_LINEAR_DW_KERNEL", "0"))
+_linear_items: set = set()  # id() of the queued weights that came through queue_linear_dw
 GROUP_MAX = 24  # problems per launch (gemm_grouped.hip: the by-value problem table)
 _end_flush_queued = False
 
@@ -112,8 +117,8 @@ def queue_linear_dw(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> 
     global _end_flush_queued
     if LINEAR_DW_TILES <= 0 or DW_GROUP_BLOCKS <= 0 or not w.requires_grad or not _groupable(w, dy2, x2):
         return False
-    if _functional.grad_ready_callbacks:
-        # A gradient reducer is listening.  LinearFn takes its parameters as tensor inputs, so autograd runs their
+    if any(not getattr(getattr(cb, "__self__", None), "accepts_deferred_gradients", False) for cb in _functional.grad_ready_callbacks):
+        # A gradient reducer is listening (optim.StepInBackward only acts on explicit notifications: it may stay).  LinearFn takes its parameters as tensor inputs, so autograd runs their
         # post-accumulate hooks (the reducer's per-parameter notification) when LinearFn.backward returns — before a
         # queued gradient is written: the bucket would be reduced with stale contents
         # (tests/test_ddp_gloo.py::test_gradients_queued_for_a_later_launch...).  Deferral is for single-process runs.
@@ -125,6 +130,7 @@ def queue_linear_dw(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> 
             return False
         _end_flush_queued = True
     _pending_dw.append((w, b, dy2, x2))
+    _linear_items.add(id(w))
     if _pending_tiles() >= LINEAR_DW_TILES:
         _flush_dw(tuple(_slice_streams))
     return True
@@ -146,12 +152,20 @@ def _flush_deferred() -> None:
 _functional.deferred_grad_flushes.append(_flush_deferred)
 
 
+def _tile_kind(items: list) -> int:
+    """tile form of one launch for these queued gradients: LINEAR_DW_KERNEL when all of them are stand-alone Linear layers"""
+    if LINEAR_DW_KERNEL and items and all(id(it[0]) in _linear_items for it in items):
+        return LINEAR_DW_KERNEL
+    return 0
+
+
 def _tiles_of(items: list) -> int:
-    return sum(((dy2.shape[1] + 255) // 256) * ((x2.shape[1] + 255) // 256) for _, _, dy2, x2 in items)
+    bm, bn = ops.GROUPED_TILE_SHAPES[_tile_kind(items)]
+    return sum(((dy2.shape[1] + bm - 1) // bm) * ((x2.shape[1] + bn - 1) // bn) for _, _, dy2, x2 in items)
 
 
 def _pending_tiles() -> int:
-    """256 x 256 output tiles of the queued weight gradients"""
+    """output tiles of the queued weight gradients (256 x 256, or the LINEAR_DW_KERNEL form)"""
     return _tiles_of(_pending_dw)
 
 
@@ -164,7 +178,10 @@ def _flush_dw(wait: tuple = ()) -> None:
         return
     items = list(_pending_dw)
     _pending_dw.clear()
-    if _tiles_of(items) < DW_MIN_TILES:  # too few tiles for one-tile-per-CU whole reductions: split-K GEMMs
+    kind = _tile_kind(items)
+    few = _tiles_of(items) < DW_MIN_TILES
+    _linear_items.clear()
+    if few:  # too few tiles for one-tile-per-CU whole reductions: split-K GEMMs
         for w, b, dy2, x2 in items:
             SideStream.run(lambda w=w, b=b, dy2=dy2, x2=x2: _dw_db(w, b, dy2, x2), (dy2, x2), wait=wait)
         return
@@ -194,7 +211,7 @@ def _flush_dw(wait: tuple = ()) -> None:
                 for prm in prms:
                     prm._cfhip_fresh = False
                 done.extend(prms)
-            ops.gemm_grouped_tn(probs)
+            ops.gemm_grouped_tn(probs, tiles=kind if kind else None)
             for prm in done:
                 _functional.notify_grad_ready(prm)
 
@@ -756,6 +773,7 @@ class MixingStackFn(Function):
                 SideStream.keep.append(d2)  # written by both slice streams, allocated on the caller's
         except BaseException:
             _pending_dw.clear()  #  nothing queued by a failed pass may be flushed into `.grad` by the next one
+            _linear_items.clear()
             raise
         finally:
             _slice_streams[:] = []

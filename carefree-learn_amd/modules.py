@@ -360,6 +360,13 @@ class Attention(Module):
         self.reduction = None
         self.hook = hook
 
+    # -- reference hooks of the slow path (attentions.py:151-157); overriding them is refused in forward()
+    def _get_weights(self, raw_weights: Tensor) -> Tensor:
+        return torch.softmax(raw_weights, dim=-1)
+
+    def _weights_callback(self, weights: Tensor) -> Tensor:
+        return weights
+
     # -- projections --------------------------------------------------------------------------
     def _project(self, q: Tensor, k: Tensor, v: Tensor) -> Tuple[Optional[Tensor], Tensor, Tensor, Tensor]:
         """returns (packed qkv or None, q, k, v)"""
@@ -380,9 +387,14 @@ class Attention(Module):
     def forward(self, q: Tensor, k: Tensor, v: Tensor, *, hw: Optional[Tuple[int, int]] = None,
                 mask: Optional[Tensor] = None, require_weights: bool = False,
                 deterministic: bool = False, residual: Optional[Tensor] = None) -> AttentionOutput:
-        if require_weights or self.customize_sdp:
-            raise NotImplementedError("attention weights / custom softmax need the un-fused slow path")
         drop = self.dropout if (self.training and 0.0 < self.dropout < 1.0) else 0.0  # attentions.py:254: on the probabilities
+        slow = require_weights or self.customize_sdp  # attentions.py:256-268: the weights are materialised and returned
+        if slow:
+            if type(self)._get_weights is not Attention._get_weights or type(self)._weights_callback is not Attention._weights_callback:
+                raise NotImplementedError("a custom `_get_weights` / `_weights_callback` replaces the softmax the HIP kernels fuse")
+            if drop > 0.0:
+                raise NotImplementedError("returned attention weights with dropout > 0 in training mode (the kernels' Philox mask is "
+                                          "not applied to the materialised weights yet)")
         if self.head_dim % 8 != 0 or self.head_dim > 192:
             raise NotImplementedError(f"HIP attention kernels take head_dim = a multiple of 8 up to 192, got {self.head_dim}")
         qkv_inp = q, k, v
@@ -393,6 +405,12 @@ class Attention(Module):
             qq, kk, vv = self.hook.after_forward(qkv_inp, (qq, kk, vv))
             packed = None
         keep = None if mask is None else expand_module_mask(mask, self.num_heads)
+        if slow:
+            if packed is not None:
+                d = packed.shape[-1] // 3
+                qq, kk, vv = packed[..., :d], packed[..., d:2 * d], packed[..., 2 * d:]
+            out, weights = HF.attention_with_weights(qq, kk, vv, self.num_heads, keep, False, self.head_dim, 1.0 / self.scaling)
+            return AttentionOutput(self.out_linear(out, residual=residual), weights)
         if self.head_dim != 64:
             # the general-head_dim kernels (`cfhip_attn_*_dh`, what CrossAttention uses) take separate q / k / v views
             if packed is not None:
@@ -904,10 +922,11 @@ class MixedStackedEncoder(Module):
 
 
 class Conv2d(Module):
-    """reference convs/basic.py:41-184 — parameters `weight` [out, in, k, k], `bias`.  groups = 1 only:
-    im2row + MFMA GEMM (`functional.Conv2dFn`); the stride == kernel, padding 0 form of the ViT patch
-    embedding has its own fused path (`functional.patch_tokens`).  Style modulation, kernel transform,
-    reflection padding and transposed convolution are outside the accelerated hot path."""
+    """reference convs/basic.py:41-184 — parameters `weight` [out, in / groups, k, k], `bias`.  groups = 1: implicit GEMM /
+    im2row + MFMA GEMM (`functional.Conv2dFn`); groups > 1 (depthwise included): the direct kernels of
+    `functional.GroupedConv2dFn`; the stride == kernel, padding 0 form of the ViT patch embedding has its own fused path
+    (`functional.patch_tokens`).  Style modulation, kernel transform, reflection padding and transposed convolution are
+    outside the accelerated hot path."""
 
     def __init__(self, in_channels: int, out_channels: int, *, kernel_size: int, groups: int = 1,
                  stride: int = 1, dilation: int = 1, padding: Any = "same", transform_kernel: bool = False,
@@ -916,14 +935,16 @@ class Conv2d(Module):
         super().__init__()
         if padding == "same":
             padding = kernel_size // 2
-        if groups != 1 or transform_kernel or demodulate or weight_scale is not None or not isinstance(padding, int):
-            raise NotImplementedError("grouped / kernel-transformed / demodulated / reflection-padded "
+        if transform_kernel or demodulate or weight_scale is not None or not isinstance(padding, int):
+            raise NotImplementedError("kernel-transformed / demodulated / reflection-padded "
                                       "convolutions are outside the accelerated hot path")
+        if groups < 1 or in_channels % groups or out_channels % groups:
+            raise ValueError(f"`groups` ({groups}) must divide in_channels ({in_channels}) and out_channels ({out_channels})")
         self.in_c, self.out_c, self.kernel_size = in_channels, out_channels, kernel_size
         self.groups, self.stride, self.dilation, self.padding = groups, stride, dilation, padding
         self.reflection_pad = None
         self.transform_kernel, self.demodulate, self.weight_scale = transform_kernel, demodulate, weight_scale
-        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, kernel_size, kernel_size))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         with torch.no_grad():
             nn.init.xavier_normal_(self.weight.data, gain / math.sqrt(2.0))
@@ -933,11 +954,22 @@ class Conv2d(Module):
     def forward(self, net: Tensor, style: Optional[Tensor] = None, *, transpose: bool = False) -> Tensor:
         if style is not None or transpose:
             raise NotImplementedError("stylised / transposed convolution is outside the accelerated hot path")
-        return HF.conv2d(net, self.weight, self.bias, self.stride, self.padding, self.dilation)
+        return HF.conv2d(net, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
     def extra_repr(self) -> str:
         return (f"{self.in_c}, {self.out_c}, kernel_size={self.kernel_size}, stride={self.stride}, "
                 f"padding={self.padding}, dilation={self.dilation}, bias={self.bias is not None}")
+
+
+class DepthWiseConv2d(Module):
+    """reference convs/basic.py:187-201: 3x3 / stride 1 / pad 1 convolution with one filter per channel; state key `net.*`"""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.net = Conv2d(dim, dim, kernel_size=3, stride=1, padding=1, bias=True, groups=dim)
+
+    def forward(self, net: Tensor) -> Tensor:
+        return self.net(net)
 
 
 def get_conv_blocks(in_channels: int, out_channels: int, kernel_size: int, stride: int, *, bias: bool = True,

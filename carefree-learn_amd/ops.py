@@ -196,8 +196,12 @@ def gemm(
     return out
 
 
-def gemm_grouped_tn(problems: list) -> None:
-    """Weight gradients of several Linear layers in ONE launch (cfhip_gemm_bf16_grouped_tn).
+GROUPED_TILE_SHAPES = {0: (256, 256), 1: (192, 128), 2: (128, 128)}  # tile_kind of cfhip_gemm_bf16_grouped_tn_tiles -> output tile
+
+
+def gemm_grouped_tn(problems: list, tiles: Optional[int] = None) -> None:
+    """Weight gradients of several Linear layers in ONE launch (cfhip_gemm_bf16_grouped_tn; `tiles` = 0 / 1 / 2: the tile
+    form of cfhip_gemm_bf16_grouped_tn_tiles — 256 x 256 on a whole CU, or the 80 / 64 KB forms for many small problems).
 
     `problems`: list of (dy [K, M] bf16, x [K, N] bf16, out [M, N] f32, accumulate, bias_grad f32 [M] or None,
     bias_grad_accumulate): out (+)= dy^T x, bias_grad (+)= colsum(dy).  256 x 256 tiles of all problems share the chip and
@@ -230,7 +234,10 @@ def gemm_grouped_tn(problems: list) -> None:
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = _lib.load().cfhip_gemm_bf16_grouped_tn(ctypes.cast(arr, ctypes.c_void_p), len(problems), _stream())
+    if tiles is None:
+        rc = _lib.load().cfhip_gemm_bf16_grouped_tn(ctypes.cast(arr, ctypes.c_void_p), len(problems), _stream())
+    else:
+        rc = _lib.load().cfhip_gemm_bf16_grouped_tn_tiles(ctypes.cast(arr, ctypes.c_void_p), len(problems), int(tiles), _stream())
     _lib.check(rc, "gemm_grouped_tn")
     if timer is not None:
         e1.record()
@@ -420,6 +427,45 @@ def attn_fwd(
         )
     _lib.check(rc, "attn_fwd")
     return o, lse
+
+
+def attn_probs(q: Tensor, k: Tensor, lse: Tensor, num_heads: int, *, mask: Optional[Tensor] = None, causal: bool = False,
+               scale: Optional[float] = None, head_dim: int = 64) -> Tensor:
+    """f32 [B, H, Tq, Tk]: the attention weights behind `attn_fwd`'s output, exp(scale q.k - lse) with masked slots 0
+    (cfhip_attn_probs: the reference's `require_weights` path, attentions.py:256-268)."""
+    b, tq, d, q_sb, q_st = _bth(q, "q")
+    _, tk, _, k_sb, k_st = _bth(k, "k")
+    _need(lse, f32, "lse")
+    if scale is None:
+        scale = 1.0 / math.sqrt(float(head_dim))
+    out = torch.empty((b, num_heads, tq, tk), dtype=f32, device=q.device)
+    keep, mp, ms_b, ms_h, ms_q = _mask_args(mask, b, num_heads, tq, tk)
+    rc = _lib.load().cfhip_attn_probs(q.data_ptr(), k.data_ptr(), lse.data_ptr(), mp, out.data_ptr(), b, num_heads, tq, tk,
+                                      int(head_dim), q_sb, q_st, k_sb, k_st, ms_b, ms_h, ms_q, float(scale), int(causal), _stream())
+    _lib.check(rc, "attn_probs")
+    return out
+
+
+def attn_probs_bwd(q: Tensor, k: Tensor, lse: Tensor, d_probs: Tensor, num_heads: int, *, mask: Optional[Tensor] = None,
+                   causal: bool = False, scale: Optional[float] = None, head_dim: int = 64) -> Tuple[Tensor, Tensor]:
+    """(dq, dk) bf16 [B, T, H*head_dim]: what a gradient on the returned weights adds to the input gradients"""
+    b, tq, d, q_sb, q_st = _bth(q, "q")
+    _, tk, _, k_sb, k_st = _bth(k, "k")
+    _need(lse, f32, "lse")
+    _need(d_probs, f32, "d_probs")
+    if tuple(d_probs.shape) != (b, num_heads, tq, tk) or not d_probs.is_contiguous():
+        raise ValueError("cfhip attn_probs_bwd: d_probs must be a contiguous f32 [B, H, Tq, Tk]")
+    if scale is None:
+        scale = 1.0 / math.sqrt(float(head_dim))
+    ws = torch.empty_like(d_probs)
+    dq = torch.empty((b, tq, d), dtype=bf16, device=q.device)
+    dk = torch.empty((b, tk, d), dtype=bf16, device=q.device)
+    keep, mp, ms_b, ms_h, ms_q = _mask_args(mask, b, num_heads, tq, tk)
+    rc = _lib.load().cfhip_attn_probs_bwd(q.data_ptr(), k.data_ptr(), lse.data_ptr(), mp, d_probs.data_ptr(), ws.data_ptr(),
+                                          dq.data_ptr(), dk.data_ptr(), b, num_heads, tq, tk, int(head_dim), q_sb, q_st, k_sb, k_st,
+                                          ms_b, ms_h, ms_q, float(scale), int(causal), _stream())
+    _lib.check(rc, "attn_probs_bwd")
+    return dq, dk
 
 
 def attn_dropout_blocks(b: int, num_heads: int, tq: int, tk: int) -> int:
@@ -1051,6 +1097,49 @@ def conv3x3_nhwc(x_rows: Tensor, wk: Tensor, bias: Optional[Tensor], b: int, h: 
 
 def conv3x3_wgrad_ok(b: int, h: int, w: int) -> bool:
     return h >= 2 and w >= 2 and h < 65536 and w < 65536 and b * h * w * max(h, w) < (1 << 32)
+
+
+def _gconv_args(x_shape, w: Tensor, stride: int, pad: int, dil: int, groups: int):
+    b, cin, h, wd = x_shape
+    cout, cgi, kh, kw = w.shape
+    if cin % groups or cout % groups or cgi != cin // groups:
+        raise ValueError(f"cfhip grouped conv: weight {tuple(w.shape)} does not fit Cin {cin} with groups {groups}")
+    return [b, cin, h, wd, cout, kh, kw, int(stride), int(pad), int(dil), int(groups)]
+
+
+def conv2d_grouped_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad: int, dil: int, groups: int) -> Tensor:
+    """F.conv2d(x, w, bias, stride, pad, dil, groups) for groups > 1 (cfhip_conv2d_grouped_fwd): x bf16 NCHW, w bf16
+    [Cout, Cin / groups, kh, kw], bias f32 -> y bf16 NCHW"""
+    _need(x, bf16, "x")
+    _need(w, bf16, "w")
+    args = _gconv_args(x.shape, w, stride, pad, dil, groups)
+    ho, wo = conv_out_hw(x.shape[2], x.shape[3], w.shape[2], w.shape[3], stride, pad, dil)
+    y = torch.empty((x.shape[0], w.shape[0], ho, wo), dtype=bf16, device=x.device)
+    rc = _lib.load().cfhip_conv2d_grouped_fwd(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), *args, _stream())
+    _lib.check(rc, "conv2d_grouped_fwd")
+    return y
+
+
+def conv2d_grouped_bwd_input(dy: Tensor, w: Tensor, x_shape, stride: int, pad: int, dil: int, groups: int) -> Tensor:
+    _need(dy, bf16, "dy")
+    _need(w, bf16, "w")
+    dx = torch.empty(tuple(x_shape), dtype=bf16, device=dy.device)
+    rc = _lib.load().cfhip_conv2d_grouped_bwd_input(dy.data_ptr(), w.data_ptr(), dx.data_ptr(),
+                                                    *_gconv_args(x_shape, w, stride, pad, dil, groups), _stream())
+    _lib.check(rc, "conv2d_grouped_bwd_input")
+    return dx
+
+
+def conv2d_grouped_bwd_weight(dy: Tensor, x: Tensor, dw: Tensor, accumulate: bool, bias_grad: Optional[Tensor],
+                              bias_grad_accumulate: bool, stride: int, pad: int, dil: int, groups: int) -> None:
+    """dw f32 [Cout, Cin / groups, kh, kw] (+)= the filter gradient, bias_grad f32 [Cout] (+)= dy summed over b, y, x"""
+    _need(dy, bf16, "dy")
+    _need(x, bf16, "x")
+    _need(dw, f32, "dw")
+    rc = _lib.load().cfhip_conv2d_grouped_bwd_weight(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), int(accumulate), _p(bias_grad),
+                                                     int(bias_grad_accumulate), *_gconv_args(x.shape, dw, stride, pad, dil, groups),
+                                                     _stream())
+    _lib.check(rc, "conv2d_grouped_bwd_weight")
 
 
 def conv3x3_wgrad_nhwc(dy_rows: Tensor, x_rows: Tensor, b: int, h: int, w: int, split_k: int = 1,

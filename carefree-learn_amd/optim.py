@@ -344,6 +344,8 @@ class StepInBackward:
         updated is an error (construct the step engine with `step_in_backward=False` for such models).
     Not combined with global-norm clipping (the norm needs every gradient first) — `FusedAdam.set_step_clip` refuses."""
 
+    accepts_deferred_gradients = True  # acts on explicit notifications only: weight gradients may sit in fused.queue_linear_dw
+
     def __init__(self, optimizer: FusedAdam, range_bytes: int = 32 << 20):
         from . import functional as HF
 

@@ -57,7 +57,8 @@ const char* cfhip_last_error(void);
  *                     (forward with N >= 2560, other forward, dX, dW); -1 (default): the heuristic table
  *   "grouped_variant" ring of cfhip_gemm_bf16_grouped_tn: 0 (default) 5 slots, DMA 3 K-steps ahead; 1: 4 slots, 2 ahead;
  *                     2: 5 slots, 2 ahead; 3 / 4: DMA placement variants of 0.  +16: bias gradients reduced by the first tile
- *                     column alone instead of shared by the tile row; +32: row-major tile order (both: A/B runs)
+ *                     column alone instead of shared by the tile row; +32: row-major tile order (both: A/B runs);
+ *                     +64 / +128: tile form 1 / 2 of cfhip_gemm_bf16_grouped_tn_tiles for every grouped launch (A/B runs)
  * Unknown names are an error.  (The phase-timing ablation masks "gemm_ablate" / "attn_ablate" of round 1 are
  * not part of this library any more: they exist only in the -DCFHIP_ABLATE build that tools/build_variant.sh
  * writes to tools/libcfhip_ablate.so, selected by the tools through CFHIP_LIB.) */
@@ -128,6 +129,12 @@ typedef struct cfhip_gemm_problem {
   int bias_grad_accumulate;  /* bias_grad += */
 } cfhip_gemm_problem;
 int cfhip_gemm_bf16_grouped_tn(const cfhip_gemm_problem* problems, int count, void* stream);
+/* The same launch with the tile form chosen by the caller instead of the "grouped_variant" option:
+ *   0  256 x 256 x 32, 160 KB of LDS — one workgroup owns a CU; the most FLOPs per CU-second, what the ViT block stack uses;
+ *   1  192 x 128 x 64 on four waves, 80 KB;   2  128 x 128 x 64, 64 KB — cfhip_gemm_bf16's plain kernel, two workgroups per CU,
+ *      for MANY SMALL problems (the UNet's ~10 projections per transformer block: 9-60 tiles each) whose 256 x 256 tiles would
+ *      leave most CUs idle.  Every tile still runs its whole reduction; the bias gradient is summed by the first tile column. */
+int cfhip_gemm_bf16_grouped_tn_tiles(const cfhip_gemm_problem* problems, int count, int tile_kind, void* stream);
 
 /* column sums of a bf16 matrix: out[n] (f32) (+)= sum_m X[m*ldx + n]   (bias gradients)
  * workspace: >= cfhip_colsum_workspace(M, N) bytes. */
@@ -199,6 +206,23 @@ int cfhip_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
                    int64_t kv_stride_b, int64_t kv_stride_t, int64_t o_stride_b, int64_t o_stride_t,
                    int64_t ms_b, int64_t ms_h, int64_t ms_q, float scale, int causal, int parts,
                    void* stream);
+/* Attention with RETURNED weights — the reference's slow path `Attention.forward(require_weights=True)` / `customize_sdp`
+ * (attentions.py:256-268: raw = q k^T / scaling, masked_fill(-inf), softmax, weights @ v).  The output comes from
+ * cfhip_attn_fwd_dh with scale = 1 / scaling; cfhip_attn_probs materialises what the fused kernels never store:
+ *     probs[b][h][i][j] (f32) = keep(b,h,i,j) ? exp(scale * q_i . k_j - lse[b][h][i]) : 0
+ * and cfhip_attn_probs_bwd turns a gradient on those weights into its dq / dk contribution through the softmax
+ *     t_i = sum_j dP_ij P_ij;  dS_ij = scale P_ij (dP_ij - t_i);  dq_i = sum_j dS_ij k_j;  dk_j = sum_i dS_ij q_i
+ * (written as bf16 [B][T][H*head_dim] contiguous; the caller adds them to cfhip_attn_bwd_dh's; dv gets nothing).
+ * ds_workspace: f32 [B][H][Tq][Tk].  fp32 VALU arithmetic, no atomics (deterministic); an inspection / auxiliary-loss path,
+ * not a throughput path.  Addressing, mask and causal conventions as cfhip_attn_fwd_dh; head_dim a multiple of 8 up to 192. */
+int cfhip_attn_probs(const void* q, const void* k, const float* lse, const uint8_t* mask, float* probs, int B, int H,
+                     int Tq, int Tk, int head_dim, int64_t q_stride_b, int64_t q_stride_t, int64_t k_stride_b,
+                     int64_t k_stride_t, int64_t ms_b, int64_t ms_h, int64_t ms_q, float scale, int causal, void* stream);
+int cfhip_attn_probs_bwd(const void* q, const void* k, const float* lse, const uint8_t* mask, const float* d_probs,
+                         float* ds_workspace, void* dq, void* dk, int B, int H, int Tq, int Tk, int head_dim,
+                         int64_t q_stride_b, int64_t q_stride_t, int64_t k_stride_b, int64_t k_stride_t, int64_t ms_b,
+                         int64_t ms_h, int64_t ms_q, float scale, int causal, void* stream);
+
 /* The same with an explicit head_dim (any multiple of 8 up to 192, e.g. the 40 / 80 / 160-channel heads of the UNet's
  * SpatialTransformer, mixed_stacks/api.py:766-893; attentions.py:498-569): always the chunked general kernels unless
  * head_dim == 64 and both lengths fit the resident form.  Addressing ptr[b*stride_b + t*stride_t + h*head_dim + d]. */
@@ -526,6 +550,21 @@ int cfhip_comm_allreduce(void* comm, void* buf, size_t count, int dtype, void* s
 int cfhip_comm_allgather(void* comm, const void* send, void* recv, size_t count_per_rank, int dtype, void* stream);
 int cfhip_comm_reduce_scatter(void* comm, const void* send, void* recv, size_t count_per_rank, int dtype, void* stream);
 int cfhip_comm_broadcast(void* comm, void* buf, size_t count, int dtype, int root, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouped convolution (groups > 1, depthwise included): F.conv2d(net, w, bias, stride, padding, dilation, groups) reached
+ * from Conv2d.forward (modules/core/convs/basic.py:160-177) and its two backward halves.  An option outside the named
+ * benchmark configurations: direct kernels (one thread per output / input element, one workgroup per filter plane for the
+ * weight gradient), fp32 accumulation, no atomics.  x / y / dy / dx bf16 NCHW; w bf16 [Cout][Cin / groups][kh][kw];
+ * bias, dw, bias_grad f32; kh * kw <= 49 for the weight gradient.
+ * ------------------------------------------------------------------------------------------ */
+int cfhip_conv2d_grouped_fwd(const void* x, const void* w, const float* bias, void* y, int B, int Cin, int H, int W, int Cout,
+                             int kh, int kw, int stride, int pad, int dil, int groups, void* stream);
+int cfhip_conv2d_grouped_bwd_input(const void* dy, const void* w, void* dx, int B, int Cin, int H, int W, int Cout, int kh,
+                                   int kw, int stride, int pad, int dil, int groups, void* stream);
+int cfhip_conv2d_grouped_bwd_weight(const void* dy, const void* x, float* dw, int accumulate, float* bias_grad,
+                                    int bias_grad_accumulate, int B, int Cin, int H, int W, int Cout, int kh, int kw,
+                                    int stride, int pad, int dil, int groups, void* stream);
 
 #ifdef __cplusplus
 }

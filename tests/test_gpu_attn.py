@@ -382,3 +382,113 @@ def test_attention_at_the_256px_unet_level_sampled():
     got_dv = dv[0].float().reshape(t, h, dh)[keys].permute(1, 0, 2)
     assert_close(got_dv, want_dv, 2e-2, "dv (256 sampled keys, all queries)", abs_floor=1e-6)
     assert_close(got_dk, want_dk, 2e-2, "dk (256 sampled keys, all queries)", abs_floor=1e-6)
+
+
+def _weights_reference(q, k, v, h, dh, scale, keep=None, causal=False):
+    """the reference's slow path (attentions.py:256-268) in fp32 on the same bf16 operands: raw = q k^T * scale,
+    masked_fill(-inf), softmax, weights @ v; returns leaves + (output [B, Tq, H dh], weights [B, H, Tq, Tk])"""
+    leaves = [t.float().requires_grad_(True) for t in (q, k, v)]
+    b, tq, _ = q.shape
+    tk = k.shape[1]
+    hd = lambda z, t: z.reshape(b, t, h, dh).permute(0, 2, 1, 3)  # noqa: E731
+    raw = (hd(leaves[0], tq) @ hd(leaves[1], tk).transpose(-1, -2)) * scale
+    drop = torch.zeros(b, h, tq, tk, dtype=torch.bool)
+    if keep is not None:
+        drop |= ~keep.bool().expand(b, h, tq, tk)
+    if causal:
+        drop |= torch.ones(tq, tk, dtype=torch.bool).triu(1)
+    w = torch.softmax(raw.masked_fill(drop, float("-inf")), dim=-1)
+    o = (w @ hd(leaves[2], tk)).permute(0, 2, 1, 3).reshape(b, tq, h * dh)
+    return leaves, o, w
+
+
+@pytest.mark.parametrize("dh,tq,tk,h,causal,masked,scale", [(64, 197, 197, 3, False, False, None), (40, 50, 77, 2, False, False, 0.2),
+                                                              (64, 33, 33, 4, True, False, None), (80, 70, 90, 2, False, True, None),
+                                                              (64, 300, 300, 2, False, True, 0.1), (8, 5, 3, 1, False, False, None)])
+def test_attention_with_returned_weights(dh, tq, tk, h, causal, masked, scale):
+    """`Attention.forward(require_weights=True)` at the kernel level: output AND weights against the reference's slow-path
+    formula in fp32, and the gradients of a loss that uses BOTH (the weights' share goes through cfhip_attn_probs_bwd)."""
+    from cflearn_amd import functional as HF
+
+    b = 2
+    g = torch.Generator().manual_seed(7 * tq + dh)
+    rnd = lambda *s: (torch.randn(*s, generator=g) * 1.2).to(torch.bfloat16)  # noqa: E731
+    q, k, v = rnd(b, tq, h * dh), rnd(b, tk, h * dh), rnd(b, tk, h * dh)
+    keep = None
+    if masked:
+        keep = torch.rand(b, h, tq, tk, generator=g) > 0.3
+        keep[..., 0] = True  # (a row without any key is NaN in the reference too)
+    sc = 1.0 / math.sqrt(dh) if scale is None else scale
+    leaves, want_o, want_w = _weights_reference(q, k, v, h, dh, sc, keep, causal)
+    g_o = torch.randn(b, tq, h * dh, generator=g)
+    g_w = torch.randn(b, h, tq, tk, generator=g)
+    ((want_o * g_o).sum() + (want_w * g_w).sum()).backward()
+
+    dq, dk, dv = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    o, w = HF.attention_with_weights(dq, dk, dv, h, None if keep is None else keep.to(DEV), causal, dh, scale)
+    assert w.dtype == torch.float32 and tuple(w.shape) == (b, h, tq, tk)
+    assert_close(o, want_o.detach(), 1e-2, "output")
+    assert_close(w, want_w.detach(), 2e-3, "weights")
+    assert_close(w.sum(-1), torch.ones(b, h, tq), 1e-3, "rows sum to one")
+    ((o.float() * g_o.to(DEV)).sum() + (w * g_w.to(DEV)).sum()).backward()
+    for name, got, leaf in (("dq", dq.grad, leaves[0]), ("dk", dk.grad, leaves[1]), ("dv", dv.grad, leaves[2])):
+        assert_close(got, leaf.grad, 2.5e-2, f"{name} (loss on output and weights)")
+    # a loss on the weights alone: no output gradient exists, dv is None
+    dq2, dk2, dv2 = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    _, w2 = HF.attention_with_weights(dq2, dk2, dv2, h, None if keep is None else keep.to(DEV), causal, dh, scale)
+    (w2 * g_w.to(DEV)).sum().backward()
+    l2 = [t.float().requires_grad_(True) for t in (q, k)]
+    hd = lambda z, t: z.reshape(b, t, h, dh).permute(0, 2, 1, 3)  # noqa: E731
+    raw = (hd(l2[0], tq) @ hd(l2[1], tk).transpose(-1, -2)) * sc
+    drop = torch.zeros(b, h, tq, tk, dtype=torch.bool)
+    if keep is not None:
+        drop |= ~keep
+    if causal:
+        drop |= torch.ones(tq, tk, dtype=torch.bool).triu(1)
+    (torch.softmax(raw.masked_fill(drop, float("-inf")), -1) * g_w).sum().backward()
+    assert_close(dq2.grad, l2[0].grad, 1.5e-2, "dq (weights only)")
+    assert_close(dk2.grad, l2[1].grad, 1.5e-2, "dk (weights only)")
+    assert dv2.grad is None
+
+
+def test_attention_module_returns_weights_like_the_reference_slow_path():
+    """modules.Attention(require_weights=True) — self attention with a mask and `qk_scale` (the slow path is the one place where
+    the reference applies it: attentions.py:262), and cross attention with separate k / v widths — against the reference's
+    formula on the module's own parameters; `customize_sdp = True` takes the same path; overriding `_get_weights` is refused."""
+    import cflearn_amd as C
+
+    torch.manual_seed(3)
+    att = C.modules.Attention(128, 2, is_self_attention=True, qk_scale=5.0).to(DEV).eval()
+    x = torch.randn(2, 37, 128, device=DEV)
+    mask = torch.rand(2, 37, 37, device=DEV) > 0.8  # True = zeroed (reference convention)
+    mask[..., 0] = False
+    out = att(x, x, x, mask=mask, require_weights=True)
+    assert out.weights is not None and tuple(out.weights.shape) == (2, 2, 37, 37)
+    bfr = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    qkv = bfr(torch.nn.functional.linear(bfr(x), bfr(att.in_w), att.qkv_bias))
+    q, k, v = (t.reshape(2, 37, 2, 64).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1))
+    raw = (q @ k.transpose(-1, -2)).masked_fill(C.modules.expand_module_mask(mask, 2) == 0, float("-inf")) / 5.0
+    w = torch.softmax(raw, -1)
+    o = (w @ v).permute(0, 2, 1, 3).reshape(2, 37, 128)
+    want = torch.nn.functional.linear(bfr(o), bfr(att.out_linear.linear.weight), att.out_linear.linear.bias)
+    assert_close(out.weights, w, 3e-3, "module weights")
+    assert_close(out.output, want, 1.5e-2, "module output")
+    fast = att(x, x, x, mask=mask)  # the fused path ignores qk_scale, as the reference's sdp_attn call does
+    assert fast.weights is None and not torch.allclose(fast.output.float(), out.output.float(), atol=1e-3)
+
+    class Custom(C.modules.Attention):
+        customize_sdp = True
+
+    att2 = Custom(64, 1, k_dim=48, v_dim=32).to(DEV).eval()
+    got = att2(torch.randn(2, 9, 64, device=DEV), torch.randn(2, 5, 48, device=DEV), torch.randn(2, 5, 32, device=DEV))
+    assert tuple(got.weights.shape) == (2, 1, 9, 5)
+    assert_close(got.weights.sum(-1), torch.ones(2, 1, 9), 1e-3, "cross-attention rows")
+
+    class Sparse(C.modules.Attention):
+        customize_sdp = True
+
+        def _get_weights(self, raw_weights):
+            return torch.relu(raw_weights)
+
+    with pytest.raises(NotImplementedError):
+        Sparse(64, 1, is_self_attention=True).to(DEV)(x[..., :64], x[..., :64], x[..., :64])

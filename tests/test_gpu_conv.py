@@ -319,3 +319,53 @@ def test_pointwise_convolution_route(cin, cout, dtype):
         assert_close(wd.grad, rep * wr.grad, 1e-2, "1x1 conv gw")
         assert_close(bd.grad, rep * br.grad, 6e-3, "1x1 conv gb")
     assert_close(xd.grad, 2 * xr.grad, 1e-2, "1x1 conv gx")
+
+
+@pytest.mark.parametrize("b,cin,cout,h,w,k,s,p,d,g,bias", [
+    (2, 16, 16, 14, 14, 3, 1, 1, 1, 16, True),     # depthwise (DepthWiseConv2d)
+    (3, 32, 64, 9, 11, 3, 2, 1, 1, 4, True),       # strided, 8 -> 16 channels per group
+    (2, 24, 24, 13, 10, 5, 1, 2, 1, 24, False),    # depthwise 5x5
+    (1, 12, 6, 8, 8, 3, 1, 2, 2, 3, True),         # dilated
+    (2, 8, 8, 7, 7, 7, 1, 3, 1, 2, True),          # 49 taps
+    (2, 6, 10, 5, 6, 1, 1, 0, 1, 2, True),         # 1x1
+])
+def test_grouped_convolution_vs_torch(b, cin, cout, h, w, k, s, p, d, g, bias):
+    """`Conv2d(groups > 1)` (reference convs/basic.py:160-177, `F.conv2d(..., groups=g)`): output, input gradient, filter and
+    bias gradients against fp32 torch on the same bf16-rounded operands; second backward accumulates."""
+    torch.manual_seed(b * 100 + cin + k)
+    conv = C.modules.Conv2d(cin, cout, kernel_size=k, groups=g, stride=s, dilation=d, padding=p, bias=bias).to(DEV)
+    assert tuple(conv.weight.shape) == (cout, cin // g, k, k)
+    with torch.no_grad():
+        conv.weight.mul_(3.0)
+        if bias:
+            conv.bias.normal_()
+    x = bf16_round(torch.randn(b, cin, h, w))
+    xd = x.to(DEV).requires_grad_(True)
+    y = conv(xd)
+    xr = x.clone().requires_grad_(True)
+    wr = bf16_round(conv.weight.detach().cpu()).requires_grad_(True)
+    br = conv.bias.detach().cpu().clone().requires_grad_(True) if bias else None
+    want = torch.nn.functional.conv2d(xr, wr, br, stride=s, padding=p, dilation=d, groups=g)
+    assert y.shape == want.shape
+    assert_close(y, want.detach(), 5e-3, "grouped conv forward")
+    gy = bf16_round(torch.randn(want.shape))
+    want.backward(gy)
+    y.backward(gy.to(DEV))
+    assert_close(xd.grad, xr.grad, 5e-3, "dX")
+    assert_close(conv.weight.grad, wr.grad, 1e-4, "dW")
+    if bias:
+        assert_close(conv.bias.grad, br.grad, 1e-4, "db")
+    conv(xd).backward(gy.to(DEV))  # accumulation
+    assert_close(conv.weight.grad, 2 * wr.grad, 1e-4, "dW accumulated")
+    if bias:
+        assert_close(conv.bias.grad, 2 * br.grad, 1e-4, "db accumulated")
+
+
+def test_depthwise_module_state_keys_and_eval():
+    m = C.modules.DepthWiseConv2d(32).to(DEV)
+    assert sorted(m.state_dict()) == ["net.bias", "net.weight"] and tuple(m.net.weight.shape) == (32, 1, 3, 3)
+    x = torch.randn(2, 32, 10, 10, device=DEV)
+    with torch.no_grad():
+        y = m(x)
+    want = torch.nn.functional.conv2d(bf16_round(x.cpu()), bf16_round(m.net.weight.detach().cpu()), m.net.bias.detach().cpu(), padding=1, groups=32)
+    assert_close(y, want, 5e-3, "depthwise")

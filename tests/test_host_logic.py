@@ -82,8 +82,12 @@ def test_unsupported_features_raise():
         C.Attention(128, 2, reduction_ratio=2)
     with pytest.raises(NotImplementedError):
         C.FeedForward(8, 16, 0.0, activation="glu")
+    grouped = C.Conv2d(4, 8, kernel_size=3, groups=2)  # round 4: built (csrc/conv_grouped.hip); the reference's parameter shape
+    assert tuple(grouped.weight.shape) == (8, 2, 3, 3) and grouped.groups == 2
+    with pytest.raises(ValueError):
+        C.Conv2d(6, 8, kernel_size=3, groups=4)
     with pytest.raises(NotImplementedError):
-        C.Conv2d(4, 8, kernel_size=3, groups=2)
+        C.Conv2d(4, 8, kernel_size=3, transform_kernel=True)
     with pytest.raises(NotImplementedError):
         C.Conv2d(3, 8, kernel_size=3, padding="reflection")
     # round 2: dropout / DropPath are built (csrc/random.hip): the constructors keep the reference's modules in place
