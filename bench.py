@@ -433,7 +433,8 @@ def build_other_workload(args):
 
         batch = args.batch if args.batch != 128 else 256
         m = C.build_module("clip", config={}).to(dev)
-        ts = LossTrainStep(m, lambda mod, b_: mod.contrastive_loss(b_["image"], b_["text"]), lr=1.0e-4)
+        ts = LossTrainStep(m, lambda mod, b_: mod.contrastive_loss(b_["image"], b_["text"]), lr=1.0e-4,
+                           step_in_backward=not getattr(args, "no_step_in_backward", False))
         img = torch.randn(batch, 3, 224, 224, generator=g)
         txt = torch.randint(1, 49407, (batch, 77), generator=g)
         eot = torch.randint(8, 77, (batch,), generator=g)

@@ -125,7 +125,7 @@ class LossTrainStep:
 
     def __init__(self, model: torch.nn.Module, loss_fn: Any, *, lr: float = 1.0e-4, betas: Any = (0.9, 0.999),
                  eps: float = 1.0e-8, weight_decay: float = 0.0, decoupled: bool = True, distributed: bool = False,
-                 bucket_bytes: int = 64 << 20):
+                 bucket_bytes: int = 64 << 20, step_in_backward: bool = True, range_bytes: int = 32 << 20):
         self.model, self.loss_fn = model, loss_fn
         params = [p for p in model.parameters() if p.requires_grad]
         self.arena = ParamArena(params, with_shadow=True)
@@ -136,9 +136,15 @@ class LossTrainStep:
         if params and params[0].is_cuda:
             SideStream.ensure()
         self.reducer: Optional[BucketedAllReduce] = None
+        # the update of an arena range runs inside backward once its last gradient is announced (optim.StepInBackward);
+        # parameters whose gradient comes through autograd's accumulation (logit_scale) never announce: their range waits
+        # for launch_step()
+        in_bwd = bool(step_in_backward) and bool(params) and params[0].is_cuda
         if distributed:
-            self.reducer = BucketedAllReduce(self.arena, bucket_bytes=bucket_bytes, optimizer=self.optimizer)
+            self.reducer = BucketedAllReduce(self.arena, bucket_bytes=bucket_bytes, optimizer=self.optimizer, step_in_backward=in_bwd)
             self.reducer.broadcast_parameters(0)
+        elif in_bwd:
+            self.optimizer.enable_step_in_backward(range_bytes)
         self.loss: Optional[Tensor] = None
 
     def step(self, batch: Any) -> Tensor:

@@ -196,3 +196,27 @@ def test_clip_contrastive_train_steps(golden):
     # logit_scale (a 0-d parameter whose gradient comes back through autograd) lives in the arena and moved
     assert m.logit_scale.grad is not None and m.logit_scale.grad.data_ptr() >= ts.arena.flat_g.data_ptr()
     assert abs(m.logit_scale.item() - g["sd"]["logit_scale"].item()) > 1e-4
+
+
+def test_clip_step_updates_inside_backward_like_the_end_of_step_launch(golden):
+    """LossTrainStep(step_in_backward=True) (round 4): arena ranges are updated inside backward as their last gradient is
+    announced; the parameters after three steps equal the end-of-step launch's.  CLIP's embedding-table gradients are f32
+    atomic scatter-adds (run-to-run differences in the last bits), hence a tolerance instead of torch.equal; `logit_scale`
+    (gradient through autograd's accumulation: never announced) is covered by the complement launch."""
+    from cflearn_amd.engine import LossTrainStep
+
+    g = golden("clip_small.pt")
+    batch = dict(image=g["img"].to(DEV), text=g["txt"].to(DEV))
+    outs = []
+    for in_bwd in (False, True):
+        m = _clip(g)
+        ts = LossTrainStep(m, lambda mod, b: mod.contrastive_loss(b["image"], b["text"]), lr=1e-3, step_in_backward=in_bwd,
+                           range_bytes=1 << 20)
+        losses = [ts.step(batch).item() for _ in range(3)]
+        if in_bwd:
+            assert ts.optimizer.in_backward.launched_in_backward > 0
+        torch.cuda.synchronize()
+        outs.append((losses, ts.arena.flat_p.clone()))
+    (l0, p0), (l1, p1) = outs
+    assert max(abs(a - b) for a, b in zip(l0, l1)) <= 2e-3 * abs(l0[0]), (l0, l1)
+    assert_close(p1, p0, 2e-4, "parameters after three steps")
