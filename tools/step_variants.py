@@ -64,6 +64,8 @@ VARIANTS = {
     "one-pass both, all c13": setv(2, halves=1, bhalves=1, nn=13, nt_wide=13, nt=13),
     # round 4: weight gradients per operator on the side lane, every tile its whole reduction (no slabs, no reduce), on the
     # 80 KB plain kernel — leaves LDS room for a forward / dX workgroup on the same CU, unlike the 160 KB grouped kernel
+    "grouped ring variant 1 (4 slots = 128 KB: 32 KB of LDS left per CU)": setv(2, variant=1),
+    "grouped ring variant 2 (5 slots, DMA 2 ahead)": setv(2, variant=2),
     "plain grouped dW 192x128x64, 1 block / launch": setv(1, variant=64),
     "plain grouped dW 192x128x64, 2 blocks / launch": setv(2, variant=64),
     "plain grouped dW 192x128x64, 3 blocks / launch": setv(3, variant=64),
