@@ -91,3 +91,66 @@ def test_rccl_code_path_with_one_rank():
     r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, port=_free_port())], capture_output=True, text=True,
                        timeout=300, env=env)
     assert r.returncode == 0 and "RCCL-1RANK-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+CHILD2 = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+    import torch, torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda", 0)   # both ranks on the one GPU of the box: RCCL refuses that, gloo does not care
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cflearn_amd as C
+    from cflearn_amd.engine import TrainStep
+
+    g = torch.load(os.path.join({root!r}, "tests", "golden", "vit_small.pt"))
+    def build():
+        cfg = dict(g["cfg"])
+        m = C.build_module("cv_clf", config=dict(in_channels=3, num_classes=g["num_classes"], img_size=cfg.pop("img_size"),
+                                                 latent_dim=cfg["latent_dim"], encoder="vit", encoder_config=cfg))
+        m.load_state_dict(g["sd"])
+        return m.to(dev)
+    x, y = g["img"].to(dev), g["labels"].view(-1).to(dev)
+    x, y = torch.cat([x, x.flip(0) * 0.5], 0), torch.cat([y, y.flip(0)], 0)   # 8 samples: 4 per rank
+    half = x.shape[0] // world
+    # (a) one process, whole batch, optimizer after backward — the reference's order (schema.py:977-986)
+    ts = TrainStep(build(), lr=1e-3, weight_decay=0.01, step_in_backward=False)
+    for _ in range(3):
+        ts.step(x, y)
+    torch.cuda.synchronize()
+    want = ts.arena.flat_p.clone()
+    # (b) two ranks, half the batch each, bucketed all-reduce; the update of every arena range rides behind its bucket's all-reduce
+    for in_bwd in (True, False):
+        ts = TrainStep(build(), lr=1e-3, weight_decay=0.01, distributed=True, bucket_bytes=1 << 16, step_in_backward=in_bwd, range_bytes=1 << 16)
+        assert len(ts.reducer.buckets) >= 2
+        for _ in range(3):
+            ts.step(x[rank * half:(rank + 1) * half], y[rank * half:(rank + 1) * half])
+        torch.cuda.synchronize()
+        got = ts.arena.flat_p.clone()
+        err = ((got - want).norm() / want.norm()).item()
+        upd = ((got - want).abs().max() / 1e-3).item()   # in units of the learning rate
+        other = got.clone()
+        dist.broadcast(other, 0)
+        assert torch.equal(other, got), "ranks diverged"
+        assert err < 2e-5 and upd < 0.5, (in_bwd, err, upd)
+        print("rank", rank, "in_bwd", in_bwd, "rel", err, "max / lr", upd)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print("GLOO-2RANK-GPU-OK")
+""")
+
+
+def test_two_ranks_on_one_gpu_match_one_process_on_the_whole_batch(tmp_path):
+    """The N > 1 code path of `engine.TrainStep` end to end on a 1-GPU box: two gloo ranks sharing the GPU, four samples each,
+    three AdamW steps — with the optimizer update of each arena range behind its bucket's all-reduce and with the
+    end-of-step launch — against ONE process on the eight samples with the reference's order (backward, then step).
+    Ranks stay bit-identical to each other; against the single process the parameters agree to 2e-5 (two partial
+    weight-gradient sums added in another order) and no element moves by more than half a learning rate."""
+    script = tmp_path / "child2.py"
+    script.write_text(CHILD2.format(root=ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0 and "GLOO-2RANK-GPU-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
