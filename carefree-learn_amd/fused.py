@@ -523,7 +523,7 @@ class StackPlan:
         self.x_now = self.dy_now = 0
         self.disabled = False     # a usage the plan cannot follow was seen (two forwards before a backward): normal path from then on
         self.mask_tensor: Optional[Tensor] = None
-        self.state = key[-1]      # 1: every gradient slot of the stack is written first (lazy zero), 0: every one is accumulated into
+        self.state = key[-1]      # (1, fingerprint): every gradient slot of the stack is written first (lazy zero); (0, ...): every one is accumulated into; fingerprint = where parameters and gradients live
         self.params_ref = [__import__("weakref").ref(p) for p in params if p is not None][:1]
 
     @staticmethod
@@ -618,18 +618,25 @@ class _KeepAllocations:
         torch.empty, torch.empty_like = self.empty, self.empty_like
 
 
-def _grad_state(params: tuple) -> Optional[int]:
-    """1: every parameter gradient of the stack is 'fresh' (the first kernel writes it: lazy zero-grad); 0: none is (zeroed
-    arena, kernels accumulate); None: mixed, or a gradient that does not live where the recording saw it"""
+def _grad_state(params: tuple) -> Optional[tuple]:
+    """(state, fingerprint) or None.  state 1: every parameter gradient of the stack is 'fresh' (the first kernel writes it:
+    lazy zero-grad); 0: none is (zeroed arena, kernels accumulate); None: mixed, frozen weights, or a gradient that does not
+    exist yet.  fingerprint: a checksum of where every parameter and every gradient LIVES — the recorded launches carry those
+    addresses, so a `.grad` somebody replaced, parameters re-homed into another arena or `p.data = ...` must give another plan
+    (a new recording), never a replay into the old buffers."""
     n_fresh = n = 0
+    fp = 0
     for p in params:
         if p is None:
             continue
-        if p.grad is None or not p.requires_grad:
+        g = p.grad
+        if g is None or not p.requires_grad:
             return None
         n += 1
         n_fresh += 1 if getattr(p, "_cfhip_fresh", False) else 0
-    return 1 if n_fresh == n else 0 if n_fresh == 0 else None
+        fp = (fp * 1000003 + p.data_ptr() + 31 * g.data_ptr()) & 0xFFFFFFFFFFFFFFFF
+    state = 1 if n_fresh == n else 0 if n_fresh == 0 else None
+    return None if state is None else (state, fp)
 
 
 def _plan_for(x: Tensor, metas: tuple, keep_mask: Optional[Tensor], causal: bool, params: tuple, training: bool) -> Optional[StackPlan]:

@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 
 import cflearn_amd as C  # noqa: E402
 from cflearn_amd.engine import TrainStep  # noqa: E402
+from cflearn_amd import functional as HF, ops  # noqa: E402
 
 DEV = "cuda"
 
@@ -354,3 +355,46 @@ def test_stack_launch_plans_fall_back():
         y = m(img)["predictions"]
     assert torch.isfinite(y.float()).all()
     fused._plans.clear()
+
+
+def test_stack_launch_plans_follow_replaced_gradient_buffers():
+    """the recorded launches carry the ADDRESSES of parameters and gradients: when somebody replaces a `.grad` (here: every
+    gradient of the stack gets a new zero tensor outside the arena) the plan key changes (address fingerprint) and the
+    stack records again instead of replaying into the old buffers; results equal the no-plan path bit for bit."""
+    from cflearn_amd import fused
+
+    def run(plans: bool):
+        prev = fused.STACK_PLANS
+        fused.STACK_PLANS = plans
+        fused._plans.clear()
+        try:
+            torch.manual_seed(4)
+            m = C.vit_b16_classifier(10, img_size=32, patch_size=8, latent_dim=256, num_layers=2).to(DEV)
+            gen = torch.Generator().manual_seed(6)
+            img, lab = torch.randn(8, 3, 32, 32, generator=gen).to(DEV), torch.randint(0, 10, (8,), generator=gen).to(DEV)
+            grads = []
+            for step in range(8):
+                if step == 5:  # new homes for the gradients (a user's own accumulation buffers)
+                    for p_ in m.parameters():
+                        p_.grad = torch.zeros_like(p_)
+                else:
+                    for p_ in m.parameters():
+                        if p_.grad is not None:
+                            p_.grad.zero_()
+                out = m(img)["predictions"]
+                loss_sum, dlogits = ops.softmax_xent(out, lab, 1.0 / 8)
+                out.backward(dlogits)
+                HF.SideStream.join()
+                torch.cuda.synchronize()
+                grads.append(torch.cat([p_.grad.flatten() for p_ in m.parameters()]).clone())
+            plan = next(iter(fused._plans.values())) if fused._plans else None
+            return grads, plan
+        finally:
+            fused.STACK_PLANS = prev
+            fused._plans.clear()
+
+    ref, _ = run(False)
+    got, plan = run(True)
+    assert plan is not None and plan.ready_bwd  # recorded again after the switch and replayed since
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), i
