@@ -12,3 +12,7 @@ done
 for p in "${pids[@]}"; do wait $p; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../_build/*.o -ldl
 echo "built $(realpath $OUT)"
+# the vectorcall entry module of the host path (generated from _lib.SIGNATURES)
+python3 gen_fastcall.py ../_build/fastcall_gen.c
+gcc -O2 -shared -fPIC $(python3-config --includes) ../_build/fastcall_gen.c -o ../_cfhip_fast$(python3 -c "import sysconfig; print(sysconfig.get_config_var('EXT_SUFFIX'))")
+echo "built _cfhip_fast"

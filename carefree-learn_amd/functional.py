@@ -913,6 +913,9 @@ def _conv_weight_rows(weight: Tensor, kp: int) -> Tensor:
 IMPLICIT_CONV = True
 
 
+PACK_AHEAD = os.environ.get("CFHIP_PACK_AHEAD", "0") != "0"  # rotated 3x3 filters for dX packed beside the forward (side lane); measured on the 64^2 x 8 UNet step: 62.3 vs 61.5 ms — the step is bound by the host there (53.5 of 61.4 ms is issue time) and the fork / event calls cost more than the queue gains: off
+
+
 def _implicit_ok(cin: int, cout: int, kh: int, kw: int, stride: int, pad: int, dil: int, h: int, w: int) -> bool:
     return (IMPLICIT_CONV and (kh, kw, stride, pad, dil) == (3, 3, 1, 1, 1) and cin % 32 == 0 and cout % 8 == 0
             and h < 65536 and w < 65536)
@@ -944,6 +947,19 @@ class Conv2dFn(Function):
             y_rows = ops.conv3x3_nhwc(x_rows, wk, bias_f, b, h, w)
             ctx.save_for_backward(x_rows, w16)  # the NHWC bf16 copy serves the weight gradient; x itself is not kept
             ctx.xshape = (b, cin, h, w)
+            # the input gradient wants the filters rotated by 180 degrees with the channels swapped: packed HERE, on the side
+            # lane beside the forward convolution, instead of on the backward's critical queue (47 launches, 1.65 ms of the
+            # 64^2 x 8 UNet step).  The weights' current bf16 shadow does not change before this step's backward has run.
+            ctx.wr = ctx.wr_event = None
+            if PACK_AHEAD and cout % 32 == 0 and ctx.needs_input_grad[0]:
+                side = SideStream.fork(0)
+                if side is not None:
+                    wr = torch.empty((cin, 9 * cout), dtype=bf16, device=x.device)  # (allocated on the caller's stream: freed there)
+                    with on_stream(side):
+                        ops.conv3x3_pack_filters(w16, True, out=wr)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    ctx.wr, ctx.wr_event = wr, ev
             return ops.transpose_batched(y_rows.view(b, h * w, cout)).view(b, cout, h, w)
         # 1x1 / stride 1 (the skip connections of the UNet's residual blocks): the im2row matrix IS the NHWC copy of x — one
         # batched transpose instead of the gather kernel, kept for the weight gradient (the im2row route recomputes it), and
@@ -1058,7 +1074,11 @@ class Conv2dFn(Function):
         if ctx.needs_input_grad[0]:
             if ctx.implicit and cout % 32 == 0:
                 # dX = conv3x3(dY, filters rotated by 180 degrees, channels swapped): k = (ky, kx, co)
-                wr = ops.conv3x3_pack_filters(wp, True)
+                wr = getattr(ctx, "wr", None)
+                if wr is not None:
+                    cur_stream().wait_event(ctx.wr_event)
+                else:
+                    wr = ops.conv3x3_pack_filters(wp, True)
                 dx_rows = ops.conv3x3_nhwc(dy_rows, wr, None, b, h, w)
                 dx = ops.transpose_batched(dx_rows.view(b, h * w, cin)).view(b, cin, h, w)
             else:

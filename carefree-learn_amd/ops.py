@@ -1172,14 +1172,15 @@ def conv3x3_wgrad_nhwc(dy_rows: Tensor, x_rows: Tensor, b: int, h: int, w: int, 
     return out
 
 
-def conv3x3_pack_filters(w16: Tensor, rotate: bool) -> Tensor:
+def conv3x3_pack_filters(w16: Tensor, rotate: bool, out: Optional[Tensor] = None) -> Tensor:
     """w16 bf16 [Cout, Cin, 3, 3] -> [Cout, 9*Cin] (k = (ky, kx, c)) or, rotate=True, [Cin, 9*Cout] with the taps rotated
     by 180 degrees (k = (ky, kx, co)): the filter matrices of conv3x3_nhwc for the forward / the input gradient."""
     _need(w16, bf16, "w16")
     if w16.dim() != 4 or tuple(w16.shape[2:]) != (3, 3) or not w16.is_contiguous():
         raise ValueError("cfhip conv3x3_pack_filters: contiguous bf16 [Cout, Cin, 3, 3] expected")
     cout, cin = w16.shape[0], w16.shape[1]
-    out = torch.empty((cin, 9 * cout) if rotate else (cout, 9 * cin), dtype=bf16, device=w16.device)
+    if out is None:
+        out = torch.empty((cin, 9 * cout) if rotate else (cout, 9 * cin), dtype=bf16, device=w16.device)
     _lib.check(_lib.load().cfhip_conv3x3_pack_filters(w16.data_ptr(), out.data_ptr(), cout, cin, int(rotate), _stream()),
                "conv3x3_pack_filters")
     return out

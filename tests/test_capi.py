@@ -99,3 +99,31 @@ def test_conv3x3_host_side_checks_and_split_heuristic():
         split = nbytes // (pixels * cout * 4)
         assert 2 <= split <= (9 * cin // 64) // 8
     assert lib.cfhip_conv3x3_wgrad_workspace(320, 640, 4) == 4 * 640 * (9 * 320 + 1) * 4
+
+
+def test_vectorcall_entry_module_is_the_same_library():
+    """`_cfhip_fast` (csrc/gen_fastcall.py): METH_FASTCALL wrappers of the SAME loaded libcfhip.so, generated from
+    `_lib.SIGNATURES` — every entry point whose arguments are plain numbers is served by it, the others (ctypes objects /
+    strings at their call sites) stay on ctypes; wrong argument counts / types are Python errors raised BEFORE the library
+    is entered; return codes and error strings are the library's."""
+    if not os.path.isfile(_lib.FAST_PATH) or os.environ.get("CFHIP_FASTCALL", "1") == "0":
+        pytest.skip("the vectorcall module is not built (build_lib.sh / __graft_entry__.build() builds it)")
+    lib = _lib.load()
+    assert type(lib).__name__ == "_FastLib" and _lib.fast_bound >= 75
+    cdll = lib.__dict__["_cdll"]
+    fast_names = [n for n in _lib.SIGNATURES if n in lib.__dict__]
+    slow_names = [n for n in _lib.SIGNATURES if n not in lib.__dict__]
+    assert "cfhip_gemm_bf16" in fast_names and "cfhip_adam_step_dev" in fast_names and "cfhip_attn_fwd_dh" in fast_names
+    assert all(n.startswith("cfhip_comm_") or n in ("cfhip_version", "cfhip_last_error", "cfhip_set_option", "cfhip_gemm_kernel_name",
+                                                     "cfhip_gemm_bf16_grouped_tn", "cfhip_gemm_bf16_grouped_tn_tiles",
+                                                     "cfhip_layernorm_bwd_partials") for n in slow_names), slow_names
+    args = (None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1, None, 0, None, 0, None)
+    assert lib.cfhip_gemm_bf16(*args) == cdll.cfhip_gemm_bf16(*args) == -1 and b"null" in lib.cfhip_last_error()
+    assert lib.cfhip_colsum_workspace(1000, 64) == cdll.cfhip_colsum_workspace(1000, 64) > 0
+    assert lib.cfhip_layernorm_bwd_workspace(512, 768) == cdll.cfhip_layernorm_bwd_workspace(512, 768)
+    with pytest.raises(TypeError, match="23 arguments"):
+        lib.cfhip_gemm_bf16(1, 2, 3)
+    with pytest.raises(TypeError):
+        lib.cfhip_colsum_workspace("a", 3)
+    with pytest.raises((TypeError, OverflowError)):
+        lib.cfhip_gemm_bf16(*(("x",) + args[1:]))
