@@ -913,7 +913,12 @@ def _conv_weight_rows(weight: Tensor, kp: int) -> Tensor:
 IMPLICIT_CONV = True
 
 
-PACK_AHEAD = os.environ.get("CFHIP_PACK_AHEAD", "0") != "0"  # rotated 3x3 filters for dX packed beside the forward (side lane); measured on the 64^2 x 8 UNet step: 62.3 vs 61.5 ms — the step is bound by the host there (53.5 of 61.4 ms is issue time) and the fork / event calls cost more than the queue gains: off
+# Where the rotated 3x3 filters of the input-gradient convolution are packed.  2 (default): in the FORWARD of the layer, on the
+# caller's stream — the UNet's forward is issue-bound (its queue drains faster than the host fills it) and its backward is
+# bound by the queue, so the 35 us per layer cost nothing there and 1.65 ms per step here: 64^2 x 8 step 62.4 -> 61.8 ms
+# (three alternating pairs, profiles/r04/unet_pack_ahead_ab.txt; +1 GB of packed filters alive until backward).  1: on the
+# side lane beside the forward (fork + event per layer cost the host more than the queue gains: 62.3 vs 61.5).  0: in backward.
+PACK_AHEAD = int(os.environ.get("CFHIP_PACK_AHEAD", "2"))
 
 
 def _implicit_ok(cin: int, cout: int, kh: int, kw: int, stride: int, pad: int, dil: int, h: int, w: int) -> bool:
@@ -951,7 +956,11 @@ class Conv2dFn(Function):
             # lane beside the forward convolution, instead of on the backward's critical queue (47 launches, 1.65 ms of the
             # 64^2 x 8 UNet step).  The weights' current bf16 shadow does not change before this step's backward has run.
             ctx.wr = ctx.wr_event = None
-            if PACK_AHEAD and cout % 32 == 0 and ctx.needs_input_grad[0]:
+            if PACK_AHEAD == 2 and cout % 32 == 0 and ctx.needs_input_grad[0]:
+                # on the caller's stream: the forward of the UNet is issue-bound (the queue drains faster than the host fills
+                # it), the backward is bound by its queue — the pack costs nothing here and 35 us per layer there
+                ctx.wr = ops.conv3x3_pack_filters(w16, True)
+            elif PACK_AHEAD == 1 and cout % 32 == 0 and ctx.needs_input_grad[0]:
                 side = SideStream.fork(0)
                 if side is not None:
                     wr = torch.empty((cin, 9 * cout), dtype=bf16, device=x.device)  # (allocated on the caller's stream: freed there)
@@ -1076,7 +1085,8 @@ class Conv2dFn(Function):
                 # dX = conv3x3(dY, filters rotated by 180 degrees, channels swapped): k = (ky, kx, co)
                 wr = getattr(ctx, "wr", None)
                 if wr is not None:
-                    cur_stream().wait_event(ctx.wr_event)
+                    if ctx.wr_event is not None:
+                        cur_stream().wait_event(ctx.wr_event)
                 else:
                     wr = ops.conv3x3_pack_filters(wp, True)
                 dx_rows = ops.conv3x3_nhwc(dy_rows, wr, None, b, h, w)
