@@ -492,3 +492,20 @@ def test_attention_module_returns_weights_like_the_reference_slow_path():
 
     with pytest.raises(NotImplementedError):
         Sparse(64, 1, is_self_attention=True).to(DEV)(x[..., :64], x[..., :64], x[..., :64])
+
+
+def test_returned_weights_at_a_unet_token_count_rows_sum_to_one_and_match_the_output():
+    """size-independent properties of `attention_with_weights` at T = 4 096, head_dim 40 (a UNet level): every row of the
+    returned weights sums to one, and weights @ v (fp32 on the host side of the check, a row sample) reproduces the fused
+    kernels' output — the two results come from different kernels and must describe the same softmax."""
+    from cflearn_amd import functional as HF
+
+    b, t, h, dh = 1, 4096, 2, 40
+    g = torch.Generator().manual_seed(11)
+    q, k, v = ((torch.randn(b, t, h * dh, generator=g) * 0.8).to(torch.bfloat16).to(DEV) for _ in range(3))
+    o, w = HF.attention_with_weights(q, k, v, h, None, False, dh, None)
+    assert_close(w.sum(-1), torch.ones(b, h, t), 1e-3, "rows sum to one")
+    rows = torch.randint(0, t, (64,), generator=g).to(DEV)
+    vh = v.float().view(b, t, h, dh).permute(0, 2, 1, 3)            # [B, H, T, dh]
+    want = (w[:, :, rows] @ vh).permute(0, 2, 1, 3).reshape(b, 64, h * dh)
+    assert_close(o[:, rows], want, 1e-2, "weights @ v == fused output (sampled rows)")

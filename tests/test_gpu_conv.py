@@ -369,3 +369,18 @@ def test_depthwise_module_state_keys_and_eval():
         y = m(x)
     want = torch.nn.functional.conv2d(bf16_round(x.cpu()), bf16_round(m.net.weight.detach().cpu()), m.net.bias.detach().cpu(), padding=1, groups=32)
     assert_close(y, want, 5e-3, "depthwise")
+
+
+def test_grouped_convolution_is_linear_and_block_diagonal():
+    """properties that do not need a reference: conv(a x + b y) == a conv(x) + b conv(y) without bias, and a group's output
+    channels do not see the other groups' input channels (zeroing them changes nothing)."""
+    torch.manual_seed(9)
+    conv = C.modules.Conv2d(32, 48, kernel_size=3, groups=4, padding=1, bias=False).to(DEV)
+    x, y = bf16_round(torch.randn(2, 32, 12, 12)).to(DEV), bf16_round(torch.randn(2, 32, 12, 12)).to(DEV)
+    with torch.no_grad():
+        lhs = conv(bf16_round(2.0 * x.cpu() + 0.5 * y.cpu()).to(DEV)).float()
+        rhs = 2.0 * conv(x).float() + 0.5 * conv(y).float()
+        assert_close(lhs, rhs, 1.5e-2, "linearity (bf16 rounding of the combined input and of both outputs)")
+        x2 = x.clone()
+        x2[:, 8:] = 0  # groups 1..3 of the input
+        assert torch.equal(conv(x)[:, :12], conv(x2)[:, :12])  # group 0's 12 output channels: bit-identical
