@@ -626,6 +626,188 @@ __global__ __launch_bounds__(PERS_WAVES * 64, 4) void attn_bwd_dkv_pers_kernel(A
   }
 }
 
+// The forward in the persistent form (round 4; PLAIN only — the ViT path): wave w owns query rows 16 w .. 16 w + 15 of every
+// head its workgroup visits, the next head's K / V stream into the second buffer.  The per-tile arithmetic is attn_fwd_kernel's
+// (same instruction order: outputs and log-sum-exp are bit-identical).  Option "attn_persistent" bit 2.
+template <int NB>
+__global__ __launch_bounds__(PERS_WAVES * 64, 4) void attn_fwd_pers_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TILE = 256 * 128, BUF = 2 * TILE;
+  static_assert(NB * 32 <= 256, "K / V of one head fit the 256-row tile slot");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int heads = p.B * p.H;
+  const float sl2 = p.scale * LOG2E;
+  auto issue = [&](int hh, char* buf, bool live) {
+    const int b = hh / p.H, h = hh - b * p.H;
+    dma_tile_pers(buf, p.k + (long)b * p.kv_sb + h * DH, p.kv_st, p.Tk, live, wave, lane);
+    dma_tile_pers(buf + TILE, p.v + (long)b * p.kv_sb + h * DH, p.kv_st, p.Tk, live, wave, lane);
+  };
+  int hh = blockIdx.x;
+  int cur = 0;
+  issue(hh, smem, hh < heads);
+  lds_dma_wait_all();
+  __syncthreads();
+  const int row0 = wave * 16;
+  const int qi = row0 + i;
+  for (; hh < heads; hh += gridDim.x) {
+    const int b = hh / p.H, h = hh - b * p.H;
+    const char* Ks = smem + cur * BUF;
+    const char* Vs = Ks + TILE;
+    const bf16_t* qb = p.q + (long)b * p.q_sb + h * DH;
+    const bf16x8 qf0 = frag_global(qb, p.q_st, row0, p.Tq, 0, lane);
+    const bf16x8 qf1 = frag_global(qb, p.q_st, row0, p.Tq, 1, lane);
+    const int nxt = hh + gridDim.x;
+    issue(nxt < heads ? nxt : hh, smem + (cur ^ 1) * BUF, nxt < heads);
+    if (row0 < p.Tq) {
+      f32x4 st[2 * NB];
+#pragma unroll
+      for (int jt = 0; jt < 2 * NB; ++jt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 0, lane), qf0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 1, lane), qf1, acc, 0, 0, 0);
+        st[jt] = acc;
+        if (jt & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int jt = 2 * NB - 2; jt < 2 * NB; ++jt) {
+        if (jt * 16 >= p.Tk) {
+          st[jt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        } else if (jt * 16 + 15 >= p.Tk) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[jt][r] = (jt * 16 + 4 * g + r < p.Tk) ? st[jt][r] : -INFINITY;
+        }
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < 2 * NB; ++jt) mx = fmaxf(mx, fmaxf(fmaxf(st[jt][0], st[jt][1]), fmaxf(st[jt][2], st[jt][3])));
+      mx = group_max(mx) * sl2;
+      const f32x4 sc4 = {sl2, sl2, sl2, sl2}, nm4 = {-mx, -mx, -mx, -mx};
+      f32x4 l4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jt = 0; jt < 2 * NB; ++jt) {
+        const f32x4 x = __builtin_elementwise_fma(st[jt], sc4, nm4);
+        f32x4 e;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(x[r]);
+        st[jt] = e;
+        l4 += e;
+      }
+      const float l = group_sum((l4[0] + l4[1]) + (l4[2] + l4[3]));
+      f32x4 ot[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < NB; ++a) {
+        const bf16x8 pa = pack8(st[2 * a], st[2 * a + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Vs, a * 32, dt * 16, lane), pa, ot[dt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const bool valid = qi < p.Tq;
+      const float inv = 1.0f / l;
+      store_row64(p.o + (long)b * p.o_sb + (long)qi * p.o_st + h * DH, ot, inv, g, valid);
+      if (valid && g == 0 && p.lse != nullptr) p.lse[(long)hh * p.Tq + qi] = (mx + log2f(l)) * (1.0f / LOG2E);
+    }
+    lds_dma_wait_all();
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+// The dQ pass in the same persistent form (round 4): one 16-wave workgroup per CU walks (batch, head) pairs, wave w owns query
+// rows 16 w .. 16 w + 15 of every head, K / V of the NEXT head stream into the second LDS buffer behind the current head's
+// work.  In the round-4 stream plan the persistent dK / dV pass is worth 0.12 ms of the ViT step against the one-shot form
+// (it was neutral in round 2); this is the dQ pass given the same treatment.  Option "attn_persistent" bit 1.
+template <int NB>
+__global__ __launch_bounds__(PERS_WAVES * 64, 4) void attn_bwd_dq_pers_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TILE = 256 * 128, BUF = 2 * TILE;  // K tile + V tile, 256-row slots (rows beyond Tk are zero)
+  static_assert(NB * 32 <= 256, "K / V of one head fit the 256-row tile slot");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int heads = p.B * p.H;
+  const float sl2 = p.scale * LOG2E;
+
+  auto issue = [&](int hh, char* buf, bool live) {
+    const int b = hh / p.H, h = hh - b * p.H;
+    dma_tile_pers(buf, p.k + (long)b * p.kv_sb + h * DH, p.kv_st, p.Tk, live, wave, lane);
+    dma_tile_pers(buf + TILE, p.v + (long)b * p.kv_sb + h * DH, p.kv_st, p.Tk, live, wave, lane);
+  };
+
+  int hh = blockIdx.x;
+  int cur = 0;
+  issue(hh, smem, hh < heads);
+  lds_dma_wait_all();
+  __syncthreads();
+  const int row0 = wave * 16;
+  const int qi = row0 + i;
+  const bool qvalid = qi < p.Tq;
+  for (; hh < heads; hh += gridDim.x) {
+    const int b = hh / p.H, h = hh - b * p.H;
+    const char* Ks = smem + cur * BUF;
+    const char* Vs = Ks + TILE;
+    const bf16_t* qb = p.q + (long)b * p.q_sb + h * DH;
+    const bf16_t* dob = p.d_o + (long)b * p.o_sb + h * DH;
+    const bf16_t* ob = p.o_in + (long)b * p.o_sb + h * DH;
+    // this head's own fragments first: older than the DMA below in the vmcnt order
+    const bf16x8 qf0 = frag_global(qb, p.q_st, row0, p.Tq, 0, lane);
+    const bf16x8 qf1 = frag_global(qb, p.q_st, row0, p.Tq, 1, lane);
+    const bf16x8 dof0 = frag_global(dob, p.o_st, row0, p.Tq, 0, lane);
+    const bf16x8 dof1 = frag_global(dob, p.o_st, row0, p.Tq, 1, lane);
+    const bf16x8 of0 = frag_global(ob, p.o_st, row0, p.Tq, 0, lane);
+    const bf16x8 of1 = frag_global(ob, p.o_st, row0, p.Tq, 1, lane);
+    const long stat = (long)hh * p.Tq + (qvalid ? qi : 0);
+    const float lse_raw = p.lse[stat];
+    const int nxt = hh + gridDim.x;
+    issue(nxt < heads ? nxt : hh, smem + (cur ^ 1) * BUF, nxt < heads);
+
+    float delta;
+    {
+      float sacc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sacc += bf16_to_f32((bf16_t)dof0[e]) * bf16_to_f32((bf16_t)of0[e]);
+        sacc += bf16_to_f32((bf16_t)dof1[e]) * bf16_to_f32((bf16_t)of1[e]);
+      }
+      delta = group_sum(sacc);
+    }
+    if (qvalid && g == 0) p.delta[stat] = delta;
+    const float lse2 = qvalid ? lse_raw * LOG2E : INFINITY;  // +inf -> p = 0 for padded rows
+
+    f32x4 dqt[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dqt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row0 < p.Tq) {
+      for (int a = 0; a < NB; ++a) {
+        f32x4 ds[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int jt = 2 * a + t;
+          f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 0, lane), qf0, sc, 0, 0, 0);
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 1, lane), qf1, sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vs, jt * 16, 0, lane), dof0, dp, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vs, jt * 16, 1, lane), dof1, dp, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[t][r] = __builtin_amdgcn_exp2f(sc[r] * sl2 - lse2) * (dp[r] - delta);
+        }
+        const bf16x8 dsp = pack8(ds[0], ds[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Ks, a * 32, dt * 16, lane), dsp, dqt[dt], 0, 0, 0);
+      }
+    }
+    store_row64(p.dq + (long)b * p.q_sb + (long)qi * p.q_st + h * DH, dqt, p.scale, g, qvalid);
+    lds_dma_wait_all();
+    __syncthreads();  // the next head's K / V have landed (vmcnt 0) and nobody reads this head's buffer any more
+    cur ^= 1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // General form: any sequence length, head_dim = any multiple of 8 up to 192 (UNet cross-attention heads of 40 / 80 /
 // 160 channels, convs / mixed_stacks/api.py:766-893).  The same three kernels with (1) an outer loop over CHUNKS of
@@ -1754,7 +1936,7 @@ bool set_dropout(AttnParams& p, float dropout_p, uint64_t seed, uint64_t offset)
   return true;
 }
 
-int g_attn_persistent = 1;
+int g_attn_persistent = 7;  // bit 0: dK / dV pass, bit 1: dQ pass, bit 2: forward — as persistent 16-wave workgroups when 128 < T <= 256 (the ViT shape)
 
 int check_head_dim(const char* who, int head_dim) {
   CFHIP_REQUIRE(head_dim >= 8 && head_dim <= 192 && head_dim % 8 == 0,
@@ -1832,6 +2014,25 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
       case 2: return launch_gen_fwd<2>(p, plain, s);
       default: return launch_gen_fwd<3>(p, plain, s);
     }
+  }
+  if (plain && (g_attn_persistent & 4) && Tq > 128 && Tq <= PERS_WAVES * 16 && Tk > 128 && Tk <= 256 && lse != nullptr) {
+    const size_t plds = (size_t)2 * 2 * 256 * 128;
+    const int heads = B * H;
+    dim3 pgrid(heads < 256 ? heads : 256), pblock(PERS_WAVES * 64);
+    int prc = CFHIP_OK;
+#define CFHIP_FWD_PERS(NB_)                                                                          \
+  case NB_:                                                                                          \
+    prc = set_lds(attn_fwd_pers_kernel<NB_>, plds, "attn_fwd");                                      \
+    if (prc != CFHIP_OK) return prc;                                                                 \
+    hipLaunchKernelGGL(attn_fwd_pers_kernel<NB_>, pgrid, pblock, plds, s, p);                        \
+    break;
+    switch (nb) {
+      CFHIP_FWD_PERS(5) CFHIP_FWD_PERS(6) CFHIP_FWD_PERS(7) CFHIP_FWD_PERS(8)
+      default: cfhip_set_error("attn_fwd: bad nb %d", nb); return CFHIP_ERR_INVALID;
+    }
+#undef CFHIP_FWD_PERS
+    CFHIP_CHECK_LAUNCH("attn_fwd(persistent)");
+    return CFHIP_OK;
   }
 #define CFHIP_ATTN_FWD(NB_)                                                                         \
   case NB_:                                                                                         \
@@ -1914,7 +2115,24 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
       default: return launch_gen_bwd<3>(p, plain, parts, s);
     }
   }
-  if (parts & 1) {
+  if ((parts & 1) && plain && (g_attn_persistent & 2) && Tq > 128 && Tq <= PERS_WAVES * 16 && Tk > 128 && Tk <= 256) {
+    const int nb = (Tk + 31) / 32;
+    const size_t lds = (size_t)2 * 2 * 256 * 128;
+    const int heads = B * H;
+    dim3 grid(heads < 256 ? heads : 256), block(PERS_WAVES * 64);
+#define CFHIP_DQ_PERS(NB_)                                                                                           \
+  case NB_:                                                                                                          \
+    rc = set_lds(attn_bwd_dq_pers_kernel<NB_>, lds, "attn_bwd_dq");                                                 \
+    if (rc != CFHIP_OK) return rc;                                                                                  \
+    hipLaunchKernelGGL(attn_bwd_dq_pers_kernel<NB_>, grid, block, lds, s, p);                                       \
+    break;
+    switch (nb) {
+      CFHIP_DQ_PERS(5) CFHIP_DQ_PERS(6) CFHIP_DQ_PERS(7) CFHIP_DQ_PERS(8)
+      default: cfhip_set_error("attn_bwd: bad nb %d", nb); return CFHIP_ERR_INVALID;
+    }
+#undef CFHIP_DQ_PERS
+    CFHIP_CHECK_LAUNCH("attn_bwd_dq(persistent)");
+  } else if (parts & 1) {
     const int nb = (Tk + 31) / 32;
     const int nw = pick_waves(Tq);
     const int tiles = (Tq + 15) / 16;
@@ -1925,7 +2143,7 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
     else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, block, lds, s, p, nb);
     CFHIP_CHECK_LAUNCH("attn_bwd_dq");
   }
-  if ((parts & 2) && plain && p.delta_ready && g_attn_persistent && Tq > 128 && Tk <= PERS_WAVES * 16) {
+  if ((parts & 2) && plain && p.delta_ready && (g_attn_persistent & 1) && Tq > 128 && Tk <= PERS_WAVES * 16) {
     // the ViT shape: persistent workgroups, next head's Q / dO streaming in behind the current one
     const int nbq = (Tq + 31) / 32;
     const size_t lds = 2 * ((size_t)2 * 256 * 128 + (size_t)2 * nbq * 32 * sizeof(float));

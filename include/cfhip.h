@@ -55,6 +55,10 @@ const char* cfhip_last_error(void);
  *                     (D a multiple of 256 up to 1280); 0: the round-1 one-wave-per-row kernel
  *   "gemm_cfg_nt_wide" / "gemm_cfg_nt" / "gemm_cfg_nn" / "gemm_cfg_tn"   tile configuration of one class of M >= 1024 GEMMs
  *                     (forward with N >= 2560, other forward, dX, dW); -1 (default): the heuristic table
+ *   "attn_persistent" bits: 1 dK / dV pass, 2 dQ pass, 4 forward of the head_dim-64 kernels run as persistent 16-wave
+ *                     workgroups (one per CU walking (batch, head) pairs, the next head's operands streaming into a second
+ *                     LDS buffer) when no mask / not causal and 128 < T <= 256 — the ViT shape; default 7; 0: one workgroup
+ *                     per head.  Results are bit-identical either way.
  *   "grouped_variant" ring of cfhip_gemm_bf16_grouped_tn: 0 (default) 5 slots, DMA 3 K-steps ahead; 1: 4 slots, 2 ahead;
  *                     2: 5 slots, 2 ahead; 3 / 4: DMA placement variants of 0.  +16: bias gradients reduced by the first tile
  *                     column alone instead of shared by the tile row; +32: row-major tile order (both: A/B runs);

@@ -509,3 +509,49 @@ def test_returned_weights_at_a_unet_token_count_rows_sum_to_one_and_match_the_ou
     vh = v.float().view(b, t, h, dh).permute(0, 2, 1, 3)            # [B, H, T, dh]
     want = (w[:, :, rows] @ vh).permute(0, 2, 1, 3).reshape(b, 64, h * dh)
     assert_close(o[:, rows], want, 1e-2, "weights @ v == fused output (sampled rows)")
+
+
+@pytest.mark.parametrize("b,t,h", [(2, 197, 12), (1, 256, 3), (3, 130, 2), (40, 197, 12)])
+def test_persistent_dq_pass_is_bit_identical_to_the_one_shot_kernel(b, t, h):
+    """option "attn_persistent" bit 1 (round 4): the dQ pass as one 16-wave workgroup per CU walking (batch, head) pairs with the
+    next head's K / V streaming in — the same instruction sequence per query tile as `attn_bwd_dq_kernel`, so dq (and the
+    delta it leaves for the dK / dV pass, hence dk / dv) must be BIT-identical; 40 x 12 heads = more heads than workgroups."""
+    qkv = _qkv(b, t, h, 300 + t, scale=1.3).to(DEV)
+    d = h * 64
+    d_o = torch.randn(b, t, d, generator=torch.Generator().manual_seed(t + 1)).to(torch.bfloat16).to(DEV)
+    o, lse = ops.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], h)
+    outs = []
+    try:
+        for opt in (1, 3, 2, 0):
+            ops.set_option("attn_persistent", opt)
+            g = torch.zeros_like(qkv)
+            ops.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, d_o, lse, h,
+                         dq=g[..., :d], dk=g[..., d:2 * d], dv=g[..., 2 * d:])
+            outs.append(g)
+    finally:
+        ops.set_option("attn_persistent", 7)
+    for g in outs[1:]:
+        assert torch.equal(g, outs[0])
+    if b <= 3:
+        _, want = _oracle(qkv.cpu(), h, None, d_o.cpu())
+        assert_close(outs[1], want, 2e-2, "persistent dq / dkv vs the oracle")
+
+
+@pytest.mark.parametrize("b,t,h", [(2, 197, 12), (1, 256, 3), (3, 130, 2), (40, 197, 12)])
+def test_persistent_forward_is_bit_identical_to_the_one_shot_kernel(b, t, h):
+    """option "attn_persistent" bit 2: the forward as persistent 16-wave workgroups — same per-tile instruction sequence as
+    `attn_fwd_kernel<NB, true>`: output and log-sum-exp bit-identical."""
+    qkv = _qkv(b, t, h, 500 + t, scale=1.3).to(DEV)
+    d = h * 64
+    outs = []
+    try:
+        for opt in (1, 5, 7):
+            ops.set_option("attn_persistent", opt)
+            outs.append(ops.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], h))
+    finally:
+        ops.set_option("attn_persistent", 7)
+    for o, lse in outs[1:]:
+        assert torch.equal(o, outs[0][0]) and torch.equal(lse, outs[0][1])
+    if b <= 3:
+        want_o, _ = _oracle(qkv.cpu(), h)
+        assert_close(outs[1][0], want_o, 1e-2, "persistent forward vs the oracle")

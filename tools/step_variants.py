@@ -28,7 +28,7 @@ labels = torch.randint(0, 1000, (BATCH,), generator=g).to(dev)
 def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt=-1, nn=-1, share=0.5, heuristic=8, tn=-1, split=0):
     def f():
         ops.FORCE_SPLIT_K = split
-        ops.set_option("attn_persistent", 1)
+        ops.set_option("attn_persistent", 7)
         ops.set_option("gemm_cfg_tn", tn)
         fused.FIRST_SLICE_SHARE = share
         ops.set_option("gemm_heuristic", heuristic)
@@ -66,7 +66,11 @@ VARIANTS = {
     # round 4: weight gradients per operator on the side lane, every tile its whole reduction (no slabs, no reduce), on the
     # 80 KB plain kernel — leaves LDS room for a forward / dX workgroup on the same CU, unlike the 160 KB grouped kernel
     "attention dK/dV: one workgroup per head (not the persistent 16-wave kernel)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 0))),
-    "attention dK/dV: persistent (default, restated)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 1))),
+    "attention dK/dV persistent only (attn_persistent 1: the round-3 default)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 1))),
+    "attention dQ AND dK/dV persistent (attn_persistent 3)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 3))),
+    "attention dQ persistent only (attn_persistent 2)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 2))),
+    "attention fwd + dQ + dK/dV persistent (attn_persistent 7)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 7))),
+    "attention fwd + dK/dV persistent (attn_persistent 5)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 5))),
     "grouped ring variant 1 (4 slots = 128 KB: 32 KB of LDS left per CU)": setv(2, variant=1),
     "grouped ring variant 2 (5 slots, DMA 2 ahead)": setv(2, variant=2),
     "plain grouped dW 192x128x64, 1 block / launch": setv(1, variant=64),
