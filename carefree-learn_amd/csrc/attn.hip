@@ -1936,6 +1936,7 @@ bool set_dropout(AttnParams& p, float dropout_p, uint64_t seed, uint64_t offset)
   return true;
 }
 
+int g_attn_pers_ctas = 256;  // workgroups of a persistent launch (one per CU; fewer leave CUs to the other queues)
 int g_attn_persistent = 7;  // bit 0: dK / dV pass, bit 1: dQ pass, bit 2: forward — as persistent 16-wave workgroups when 128 < T <= 256 (the ViT shape)
 
 int check_head_dim(const char* who, int head_dim) {
@@ -1953,6 +1954,11 @@ int cfhip_internal_set_attn_short_max(int v) {
 
 int cfhip_internal_set_attn_two_tiles(int v) {
   g_attn_two_tiles = v;
+  return CFHIP_OK;
+}
+
+int cfhip_internal_set_attn_pers_ctas(int v) {
+  g_attn_pers_ctas = v < 1 ? 1 : v;
   return CFHIP_OK;
 }
 
@@ -2018,7 +2024,7 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
   if (plain && (g_attn_persistent & 4) && Tq > 128 && Tq <= PERS_WAVES * 16 && Tk > 128 && Tk <= 256 && lse != nullptr) {
     const size_t plds = (size_t)2 * 2 * 256 * 128;
     const int heads = B * H;
-    dim3 pgrid(heads < 256 ? heads : 256), pblock(PERS_WAVES * 64);
+    dim3 pgrid(heads < g_attn_pers_ctas ? heads : g_attn_pers_ctas), pblock(PERS_WAVES * 64);
     int prc = CFHIP_OK;
 #define CFHIP_FWD_PERS(NB_)                                                                          \
   case NB_:                                                                                          \
@@ -2119,7 +2125,7 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
     const int nb = (Tk + 31) / 32;
     const size_t lds = (size_t)2 * 2 * 256 * 128;
     const int heads = B * H;
-    dim3 grid(heads < 256 ? heads : 256), block(PERS_WAVES * 64);
+    dim3 grid(heads < g_attn_pers_ctas ? heads : g_attn_pers_ctas), block(PERS_WAVES * 64);
 #define CFHIP_DQ_PERS(NB_)                                                                                           \
   case NB_:                                                                                                          \
     rc = set_lds(attn_bwd_dq_pers_kernel<NB_>, lds, "attn_bwd_dq");                                                 \
@@ -2148,7 +2154,7 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
     const int nbq = (Tq + 31) / 32;
     const size_t lds = 2 * ((size_t)2 * 256 * 128 + (size_t)2 * nbq * 32 * sizeof(float));
     const int heads = B * H;
-    dim3 grid(heads < 256 ? heads : 256), block(PERS_WAVES * 64);
+    dim3 grid(heads < g_attn_pers_ctas ? heads : g_attn_pers_ctas), block(PERS_WAVES * 64);
 #define CFHIP_DKV_PERS(NBQ_)                                                                                         \
   case NBQ_:                                                                                                         \
     rc = set_lds(attn_bwd_dkv_pers_kernel<NBQ_>, lds, "attn_bwd_dkv");                                              \

@@ -781,6 +781,7 @@ int cfhip_internal_gemm_pp_supported(int M, int N, int K, long ldc, int a_trans,
                                      int variant);  // gemm_pp.hip
 int cfhip_internal_gemm_pp(const void* params, int variant, int b_trans, int epilogue, void* stream);
 int cfhip_internal_set_attn_persistent(int v);  // attn.hip
+int cfhip_internal_set_attn_pers_ctas(int v);  // attn.hip
 int cfhip_internal_set_grouped_variant(int v);  // gemm_grouped.hip
 int cfhip_internal_set_attn_two_tiles(int v);  // attn.hip
 int cfhip_internal_set_attn_short_max(int v);  // attn.hip
@@ -810,6 +811,7 @@ extern "C" int cfhip_set_option(const char* name, int value) {
   }
   if (name != nullptr && strcmp(name, "ln_bwd_fused") == 0) return cfhip_internal_set_ln_fused(value);
   if (name != nullptr && strcmp(name, "attn_persistent") == 0) return cfhip_internal_set_attn_persistent(value);
+  if (name != nullptr && strcmp(name, "attn_pers_ctas") == 0) return cfhip_internal_set_attn_pers_ctas(value);
   if (name != nullptr && strcmp(name, "grouped_variant") == 0) return cfhip_internal_set_grouped_variant(value);
   if (name != nullptr && strcmp(name, "attn_two_tiles") == 0) return cfhip_internal_set_attn_two_tiles(value);
   if (name != nullptr && strcmp(name, "attn_short_max") == 0) return cfhip_internal_set_attn_short_max(value);

@@ -59,6 +59,8 @@ const char* cfhip_last_error(void);
  *                     workgroups (one per CU walking (batch, head) pairs, the next head's operands streaming into a second
  *                     LDS buffer) when no mask / not causal and 128 < T <= 256 — the ViT shape; default 7; 0: one workgroup
  *                     per head.  Results are bit-identical either way.
+ *   "attn_pers_ctas"  workgroups of a persistent attention launch (default 256 = one per CU; measured in the ViT step:
+ *                     128 / 192 / 224 / 256 / 512 -> 17.80 / 17.71 / 17.59 / 17.60 / 17.78 ms)
  *   "grouped_variant" ring of cfhip_gemm_bf16_grouped_tn: 0 (default) 5 slots, DMA 3 K-steps ahead; 1: 4 slots, 2 ahead;
  *                     2: 5 slots, 2 ahead; 3 / 4: DMA placement variants of 0.  +16: bias gradients reduced by the first tile
  *                     column alone instead of shared by the tile row; +32: row-major tile order (both: A/B runs);

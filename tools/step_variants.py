@@ -29,6 +29,7 @@ def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt
     def f():
         ops.FORCE_SPLIT_K = split
         ops.set_option("attn_persistent", 7)
+        ops.set_option("attn_pers_ctas", 256)
         ops.set_option("gemm_cfg_tn", tn)
         fused.FIRST_SLICE_SHARE = share
         ops.set_option("gemm_heuristic", heuristic)
@@ -67,6 +68,10 @@ VARIANTS = {
     # 80 KB plain kernel — leaves LDS room for a forward / dX workgroup on the same CU, unlike the 160 KB grouped kernel
     "attention dK/dV: one workgroup per head (not the persistent 16-wave kernel)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 0))),
     "attention dK/dV persistent only (attn_persistent 1: the round-3 default)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 1))),
+    "persistent attention on 192 workgroups": (lambda: (setv(2)(), ops.set_option("attn_pers_ctas", 192))),
+    "persistent attention on 128 workgroups": (lambda: (setv(2)(), ops.set_option("attn_pers_ctas", 128))),
+    "persistent attention on 224 workgroups": (lambda: (setv(2)(), ops.set_option("attn_pers_ctas", 224))),
+    "persistent attention on 512 workgroups": (lambda: (setv(2)(), ops.set_option("attn_pers_ctas", 512))),
     "attention dQ AND dK/dV persistent (attn_persistent 3)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 3))),
     "attention dQ persistent only (attn_persistent 2)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 2))),
     "attention fwd + dQ + dK/dV persistent (attn_persistent 7)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 7))),
