@@ -16,7 +16,9 @@ def main() -> None:
     # a step = from the first kernel of one forward (the patch embedding's im2row) to the next (round 4: the optimizer runs as
     # several range launches inside backward, so "the Adam kernel" no longer marks the end of a step); traces without an
     # im2row kernel fall back to the round-1..3 rule (end of one adam_dev_kernel to the end of the next)
-    marks = [r for r in rows if "im2row" in r["name"]]
+    marks = [r for r in rows if r["name"].split("<")[0].endswith("im2row_kernel") and "conv_im2row" not in r["name"]]
+    if len(marks) < back + 1:  # the UNet step: one diffusion-loss kernel per step
+        marks = [r for r in rows if "diffusion_loss" in r["name"]]
     if len(marks) >= back + 1:
         t0, t1 = marks[-back - 1]["s"], marks[-back]["s"]
     else:
