@@ -103,9 +103,17 @@ def _groupable(w: Tensor, dy2: Tensor, x2: Tensor) -> bool:
             and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0)
 
 
+# The last blocks of a backward pass (block index < DW_PEROP_TAIL) issue their weight gradients per operator (split-K GEMM +
+# reduce on the weight-gradient lane, beside the dX chain) instead of queueing them: the grouped launch of the final blocks
+# can only start when the chain has ended, and its ~0.9 ms are the tail of the step.  Measured (tools/step_variants.py
+# "weight gradients per operator (DW_PEROP"): 1 block +0.29 ms, 2 blocks +0.41 ms — the grouped launch stays; kept as a knob.
+DW_PEROP_TAIL = int(os.environ.get("CFHIP_DW_PEROP_TAIL", "0"))
+_perop_now = False
+
+
 def _queue_dw(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> None:
     """dW = dy^T x (+ db): queued for the next grouped launch, or issued now on the side stream (round-1/2 path)."""
-    if DW_GROUP_BLOCKS <= 0 or not _groupable(w, dy2, x2):
+    if DW_GROUP_BLOCKS <= 0 or _perop_now or not _groupable(w, dy2, x2):
         SideStream.run(lambda: _dw_db(w, b, dy2, x2), (dy2, x2), wait=tuple(_slice_streams))
         return
     _pending_dw.append((w, b, dy2, x2))
@@ -650,7 +658,7 @@ def _plan_for(x: Tensor, metas: tuple, keep_mask: Optional[Tensor], causal: bool
     if state is None:
         return None  # gradients outside an arena / frozen weights / some slots written and others accumulated: the normal path
     key = (tuple(x.shape), x.dtype, metas, causal, None if keep_mask is None else keep_mask.data_ptr(), FWD_HALVES, BWD_HALVES,
-           DW_GROUP_BLOCKS, DW_GROUP_TILES, DW_TAIL_BLOCKS, LN_REDUCE_ASIDE, DW_GROUP_ON_MAIN, FIRST_SLICE_SHARE, FUSE_BIAS_GRAD,
+           DW_GROUP_BLOCKS, DW_GROUP_TILES, DW_TAIL_BLOCKS, DW_PEROP_TAIL, LN_REDUCE_ASIDE, DW_GROUP_ON_MAIN, FIRST_SLICE_SHARE, FUSE_BIAS_GRAD,
            ops.FORCE_SPLIT_K, tuple(id(cb) for cb in _functional.grad_ready_callbacks), x.requires_grad, state)
     pid = id(params[0])
     plan = _plans.get(pid)
@@ -765,6 +773,10 @@ class MixingStackFn(Function):
                 saved = tuple(all_saved[N_SAVED * i:N_SAVED * (i + 1)])
                 quick = bool(metas[i][3]) if len(metas[i]) > 3 else False
                 before = _pending_tiles()
+                global _perop_now
+                if i < DW_PEROP_TAIL and not _perop_now:
+                    _flush_dw(tuple(_slice_streams))  # what the earlier blocks queued goes out first
+                    _perop_now = True
                 d2 = _block_bwd(saved, params[12 * i:12 * i + 12], metas[i][0], bsz, t, keep_mask, causal, d2, quick, streams)
                 if DW_GROUP_BLOCKS > 0 and DW_GROUP_TILES > 0:
                     now = _pending_tiles()
@@ -784,6 +796,7 @@ class MixingStackFn(Function):
             raise
         finally:
             _slice_streams[:] = []
+            _perop_now = False
         return d2
 
     @staticmethod

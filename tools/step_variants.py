@@ -35,6 +35,7 @@ def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt
         ops.set_option("gemm_heuristic", heuristic)
         fused.DW_GROUP_BLOCKS = blocks
         fused.DW_GROUP_TILES = 0  # the variants of this tool group by block count
+        fused.DW_PEROP_TAIL = 0
         fused.DW_GROUP_ON_MAIN = on_main
         fused.FWD_HALVES = halves
         fused.BWD_HALVES = bhalves
@@ -68,6 +69,9 @@ VARIANTS = {
     # 80 KB plain kernel — leaves LDS room for a forward / dX workgroup on the same CU, unlike the 160 KB grouped kernel
     "attention dK/dV: one workgroup per head (not the persistent 16-wave kernel)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 0))),
     "attention dK/dV persistent only (attn_persistent 1: the round-3 default)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 1))),
+    "last block's weight gradients per operator (DW_PEROP_TAIL 1)": (lambda: (setv(2)(), setattr(fused, "DW_PEROP_TAIL", 1), setattr(fused, "DW_GROUP_TILES", 256))),
+    "last two blocks' weight gradients per operator (DW_PEROP_TAIL 2)": (lambda: (setv(2)(), setattr(fused, "DW_PEROP_TAIL", 2), setattr(fused, "DW_GROUP_TILES", 256))),
+    "default with DW_GROUP_TILES 256 (as shipped)": (lambda: (setv(2)(), setattr(fused, "DW_GROUP_TILES", 256))),
     "persistent attention on 192 workgroups": (lambda: (setv(2)(), ops.set_option("attn_pers_ctas", 192))),
     "persistent attention on 128 workgroups": (lambda: (setv(2)(), ops.set_option("attn_pers_ctas", 128))),
     "persistent attention on 224 workgroups": (lambda: (setv(2)(), ops.set_option("attn_pers_ctas", 224))),
