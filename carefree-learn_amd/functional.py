@@ -114,12 +114,12 @@ def _overlap(streams: List["torch.cuda.Stream"]) -> bool:
     return (time.perf_counter() - t0) < 1.6e-6 * _SPIN_US
 
 
-def distinct_stream(others: List["torch.cuda.Stream"], tries: int = 12) -> "torch.cuda.Stream":
+def distinct_stream(others: List["torch.cuda.Stream"], tries: int = 12, priority: int = 0) -> "torch.cuda.Stream":
     """A new stream whose kernels run concurrently with those of every stream in `others` (and of the current one)."""
     base = [torch.cuda.current_stream()] + [st for st in others if st is not None]
     first = None
     for n in range(tries):
-        cand = torch.cuda.Stream()
+        cand = torch.cuda.Stream(priority=priority)
         first = first or cand
         # pairwise against each stream: robust to `others` that already alias one another
         if all(_overlap([st, cand]) for st in base):
@@ -195,6 +195,10 @@ class on_stream:
             torch.cuda.set_stream(self.prev)
 
 
+# HIP stream priority per side lane (A/B knob: CFHIP_LANE_PRIORITY="0:-1,1:0"; negative = higher priority)
+LANE_PRIORITY = {int(k): int(v) for k, v in (kv.split(":") for kv in os.environ.get("CFHIP_LANE_PRIORITY", "").split(",") if kv)}
+
+
 class SideStream:
     enabled = True
     # side streams: lane 0 carries the weight-gradient launches (and the forward's second batch slice), lane 1 the backward's
@@ -216,7 +220,7 @@ class SideStream:
         if cls.streams[lane] is None:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("cfhip: side streams must exist before a hipGraph capture starts (run one eager step)")
-            cls.streams[lane] = distinct_stream(cls.streams)
+            cls.streams[lane] = distinct_stream(cls.streams, priority=LANE_PRIORITY.get(lane, 0))
         return cls.streams[lane]
 
     @classmethod
