@@ -476,3 +476,75 @@ def test_round3_host_rules():
     C.ParamArena(list(b.parameters()), with_shadow=True)
     assert not HF.qkv_weights_adjacent(a.to_q.weight, b.to_k.weight, a.to_v.weight)
     assert m._plain_projections()
+
+
+def test_round4_host_rules(tmp_path):
+    """Host-side rules added in round 4, no device needed: the tile form / tile count of a weight-gradient flush, the address
+    fingerprint that keys a launch plan, the kernel-trace step marks of the ViT and the UNet, the vectorcall generator's
+    coverage rule."""
+    import gzip
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    from cflearn_amd import fused, ops
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # weight-gradient queue: 256 x 256 tiles by default, the chosen form's tiles when every queued item is a stand-alone Linear
+    dy, x = torch.empty(10, 768), torch.empty(10, 3072)
+    w = torch.empty(768, 3072)
+    items = [(w, None, dy, x)]
+    assert fused._tile_kind(items) == 0 and fused._tiles_of(items) == 3 * 12
+    keep = fused.LINEAR_DW_KERNEL
+    try:
+        fused.LINEAR_DW_KERNEL = 2
+        fused._linear_items.add(id(w))
+        assert fused._tile_kind(items) == 2 and fused._tiles_of(items) == 6 * 24  # 128 x 128 tiles
+        fused.LINEAR_DW_KERNEL = 1
+        assert fused._tiles_of(items) == 4 * 24                                    # 192 x 128 tiles
+        assert fused._tile_kind(items + [(torch.empty(8, 8), None, dy, x)]) == 0    # mixed with a block-stack item: the whole-CU form
+    finally:
+        fused.LINEAR_DW_KERNEL = keep
+        fused._linear_items.clear()
+    assert ops.GROUPED_TILE_SHAPES == {0: (256, 256), 1: (192, 128), 2: (128, 128)}
+
+    # plan key: state + where parameters and gradients live
+    p1, p2 = torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(4))
+    assert fused._grad_state((p1, None, p2)) is None  # no gradients yet
+    p1.grad, p2.grad = torch.zeros(4), torch.zeros(4)
+    s0 = fused._grad_state((p1, None, p2))
+    assert s0 is not None and s0[0] == 0
+    p1._cfhip_fresh = p2._cfhip_fresh = True
+    s1 = fused._grad_state((p1, None, p2))
+    assert s1[0] == 1 and s1[1] == s0[1]
+    p2.grad = torch.zeros(4)  # a replaced gradient buffer: another fingerprint
+    assert fused._grad_state((p1, None, p2))[1] != s1[1]
+    p2._cfhip_fresh = False
+    assert fused._grad_state((p1, None, p2)) is None  # some written first, others accumulated: no plan
+
+    # timeline step marks: the ViT's patch-embedding im2row, the UNet's diffusion-loss kernel (its conv_im2row launches are not marks)
+    def trace(names):
+        pth = tmp_path / "t.csv.gz"
+        with gzip.open(pth, "wt") as f:
+            f.write("queue,stream,start_us,dur_us,name\n")
+            for i, n in enumerate(names):
+                f.write(f"1,0,{i * 10.0:.2f},5.00,{n}\n")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "timeline_report.py"), str(pth)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return r.stdout.splitlines()[0]
+
+    vit = ["(anonymous namespace)::im2row_kernel<false>", "k1", "softmax_xent_kernel", "k2"] * 3
+    assert trace(vit).startswith("step window 40.0 us, 4 kernels")
+    unet = ["(anonymous namespace)::conv_im2row_kernel<false>", "a", "(anonymous namespace)::conv_im2row_kernel<false>", "b",
+            "diffusion_loss_kernel", "c"] * 3
+    assert trace(unet).startswith("step window 60.0 us, 6 kernels")
+
+    # vectorcall generator: every entry point whose arguments are plain numbers is wrapped, the others are named in its skip list
+    out = tmp_path / "fastcall_gen.c"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "carefree-learn_amd", "csrc", "gen_fastcall.py"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and "wrappers" in r.stdout, r.stderr
+    src = out.read_text()
+    assert "w_cfhip_gemm_bf16(" in src and "w_cfhip_adam_step_dev(" in src and "w_cfhip_comm_init(" not in src
+    assert src.count("METH_FASTCALL") >= 75 and "if (PyErr_Occurred()) return NULL;" in src
