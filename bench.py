@@ -596,7 +596,7 @@ def main() -> None:
                          "comm stream (auto with the nccl backend: measured 22.4 ms vs 23.0 ms for the torch.distributed "
                          "launch at 1 rank, 22.3 ms without any exchange — profiles/r02/rccl_1rank_comm_*.json), or "
                          "torch.distributed (auto with gloo; fallback when the communicator cannot be created)")
-    ap.add_argument("--profile-steps", type=int, default=3, help="extra (untimed) steps with event pairs around every GEMM launch")
+    ap.add_argument("--profile-steps", type=int, default=6, help="extra (untimed) steps with event pairs around every GEMM launch (an event pair spans the launch from the moment its stream is ready for it: it includes the wait for free CUs, which a profiler's kernel duration does not)")
     ap.add_argument("--watchdog", type=int, default=0, help="dump all Python stacks every N seconds")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for the "
                                                       "single-GPU dry run of the N > 1 code path)")
