@@ -500,7 +500,11 @@ class MixingBlockFn(Function):
 #   * the bf16 weight shadows alternate between two arenas when the optimizer updates inside backward: the plan carries the
 #     address map and a twin argument list;
 #   * anything the recording did not see — another shape, a mask at another address, gradient accumulation state, timers or
-#     FLOP counters attached, a hipGraph capture, a second forward before the backward of the first — takes the normal path.
+#     FLOP counters attached, a hipGraph capture, a second forward before the backward of the first — takes the normal path;
+#   * ALIASING CONTRACT (as with the static outputs of a captured graph): the output of a replayed forward and the input
+#     gradient of a replayed backward ARE the recorded buffers — valid until the next training-mode forward / backward of the
+#     same stack overwrites them.  Everything inside a step (the head, the loss, autograd) consumes them before that; code
+#     that keeps a stack's training-mode output across steps must clone it (or run with CFHIP_STACK_PLANS=0).
 STACK_PLANS = os.environ.get("CFHIP_STACK_PLANS", "1") != "0"
 _plans: dict = {}  # id(first parameter) -> StackPlan
 _PLAN_CACHE = 8
