@@ -605,7 +605,9 @@ def _replay(ops_: list) -> None:
 
 class _KeepAllocations:
     """while recording: every tensor torch.empty / empty_like hands out stays alive with the plan (its address is in the
-    recorded arguments).  The wrappers allocate with these two calls only (no fills: nothing an ATen kernel would have to redo)."""
+    recorded arguments).  The wrappers allocate with these two calls only (no fills: nothing an ATen kernel would have to redo).
+    Process-wide for the duration of ONE recorded forward / backward (two module attributes are swapped): a tensor another
+    thread allocates in that window is kept too — a few bytes held longer, never a wrong result."""
 
     def __init__(self, keep: list) -> None:
         self.keep = keep
