@@ -547,6 +547,75 @@ def self_launch(n: int, argv: list) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def sweep_launch(n: int, argv: list) -> int:
+    """`python bench.py --gpus N --sweep` from a plain shell: one set of ranks per NCCL_MAX_NCHANNELS candidate (0 = RCCL's own
+    choice), each sweeping bucket size x wire dtype in-process; the best line (by `value`) is printed with every table attached."""
+    import subprocess
+
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if "--all-on-gpu0" not in argv and visible < n:
+        print(f"[bench] --gpus {n} needs {n} visible GPUs, this node shows {visible}", file=sys.stderr)
+        return 2
+    best, tables, rc_last = None, {}, 0
+    for nch in (0, 8, 16):
+        env = dict(os.environ, CFHIP_BENCH_LAUNCHER="self", MASTER_ADDR="127.0.0.1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        env.pop("NCCL_MAX_NCHANNELS", None)
+        extra = []
+        if nch > 0:
+            env["NCCL_MAX_NCHANNELS"] = str(nch)
+            extra = ["--nchannels", str(nch)]
+        cmd = launch_command(n, list(argv) + extra + ["--no-cpu-baseline", "--no-roofline"], free_port())
+        print(f"[bench] sweep: {n} ranks with NCCL_MAX_NCHANNELS={nch or 'default'} ...", file=sys.stderr, flush=True)
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        rc_last = r.returncode
+        line = None
+        for ln in r.stdout.splitlines():
+            if ln.startswith("{"):
+                try:
+                    line = json.loads(ln)
+                except ValueError:
+                    pass
+        if r.returncode != 0 or line is None:
+            tables[str(nch)] = {"error": f"exit code {r.returncode}"}
+            continue
+        tables[str(nch)] = {"value": line["value"], "ms_per_step": line["ms_per_step"], "bucket_mb": line.get("rccl", {}).get("bucket_mb"),
+                            "sweep": line.get("rccl", {}).get("sweep")}
+        if best is None or line["value"] > best["value"]:
+            best = line
+    if best is None:
+        print("[bench] sweep: no candidate produced a line", file=sys.stderr)
+        return rc_last or 1
+    best.setdefault("rccl", {})["nchannels_sweep"] = tables
+    print(json.dumps(best))
+    return 0
+
+
+def time_exchange_settings(ts, next_batch, sync, dev, distributed: bool, bucket_mbs, wires, steps: int) -> list:
+    """Time the live job with the reducer re-cut / re-wired between passes: [{bucket_mb, wire, buckets, ms_per_step}] (max over
+    ranks).  Two untimed steps per setting first (launch plans re-record nothing: the notifications are replayed live)."""
+    rows = []
+    for wire in wires:
+        for mb in bucket_mbs:
+            ts.reducer.set_wire_bf16(wire)
+            nbk = ts.reducer.rebucket(mb << 20)
+            for _ in range(2):
+                ts.step(*next_batch())
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ts.step(*next_batch())
+            sync()
+            dt = time.perf_counter() - t0
+            if distributed:
+                tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt = tmax.item()
+            rows.append({"bucket_mb": mb, "wire": "bf16" if wire else "fp32", "buckets": nbk, "ms_per_step": round(dt / steps * 1e3, 3)})
+    return rows
+
+
 _T0 = time.perf_counter()
 
 
@@ -561,6 +630,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (weak scaling; SURVEY §8a: 64 or 128)")
+    ap.add_argument("--batches", type=int, default=8, help="HBM-resident synthetic batches the steps rotate through (1: one fixed batch, which the model memorises)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (single GPU).  Default is eager multi-stream "
                          "launches: with the parameter-gradient kernels on side streams the eager step measured "
@@ -584,6 +654,15 @@ def main() -> None:
     ap.add_argument("--nchannels", type=int, default=0,
                     help="NCCL_MAX_NCHANNELS for the ranks (RCCL's kernels take one workgroup per channel: fewer channels leave more "
                          "CUs to a step whose kernels already share the chip; 0 = RCCL's default).  Sweep on an 8-GPU node.")
+    ap.add_argument("--sweep", action="store_true",
+                    help="N > 1: tune the gradient exchange inside ONE launch — --bucket-mb {32,64,128} x --wire-bf16 {0,1} on the live "
+                         "job (the reducer is re-cut between passes; 10 steps each), and, when bench.py starts its own ranks, once per "
+                         "--nchannels {0,8,16} (RCCL reads NCCL_MAX_NCHANNELS when the communicator is created: a new set of ranks "
+                         "each).  Prints the best line (timed on the best fp32-wire setting) with the table in `rccl.sweep`")
+    ap.add_argument("--tune-buckets", default="auto", choices=["auto", "on", "off"],
+                    help="before the warm-up of an N > 1 run, time --bucket-mb {32,64,128} for a few steps each on the live job and "
+                         "keep the fastest (auto: on for N > 1 unless --bucket-mb was given); the table goes to `rccl.bucket_sweep`")
+    ap.add_argument("--sweep-steps", type=int, default=10)
     ap.add_argument("--strict-streams", action="store_true",
                     help="exit with code 3 (after printing the line) when a helper stream had to share a hardware queue on any rank; "
                          "by default the line carries `streams.distinct_on_every_rank: false` and a `warnings` entry instead")
@@ -625,6 +704,8 @@ def main() -> None:
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` from a plain shell: start the N ranks ourselves (the reference launches its own ranks
         # too: api/api.py:269-293 run_accelerate -> `accelerate launch`); rank 0's JSON line passes through
+        if args.sweep and args.nchannels == 0:
+            raise SystemExit(sweep_launch(args.gpus, sys.argv[1:]))
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -713,8 +794,15 @@ def main() -> None:
     if ts.reducer is not None:
         ts.reducer.time_exposed = True
     g = torch.Generator().manual_seed(1234 + rank)
-    img = torch.randn(args.batch, 3, 224, 224, generator=g).to(dev)
-    labels = torch.randint(0, 1000, (args.batch,), generator=g).to(dev)
+    # A RING of HBM-resident batches with fresh labels (round 5): one fixed batch is memorised within the
+    # warm-up (loss 7.1 -> 0.006), after which the backward GEMMs see the gradients of a collapsed loss; the MFMA rate of this
+    # chip depends on operand values (profiles/r04/hipblaslt_and_zero_operand_probe.log), so the timed steps must see
+    # full-entropy activations and gradients.  `--batches 1` is the old behaviour (A/B in profiles/r05/).
+    nb = max(1, args.batches)
+    ring = [(torch.randn(args.batch, 3, 224, 224, generator=g).to(dev), torch.randint(0, 1000, (args.batch,), generator=g).to(dev))
+            for _ in range(nb)]
+    img, labels = ring[0]
+    ring_pos = [0]
 
     def sync() -> None:
         if distributed:
@@ -741,15 +829,46 @@ def main() -> None:
 
     def next_batch():
         if feed is None:
-            return img, labels
+            ring_pos[0] += 1
+            return ring[ring_pos[0] % nb]
         b = next(feed)
         return b["input"], b["labels"]
 
     note(f"model + arena ready on {dev}, launch={'graph' if ts.use_graph else 'eager'}, input={args.input}")
-    first_loss = None
+    # ---- the exchange settings of a multi-GPU run, tuned on the live job BEFORE the warm-up (untimed; the timed region below is
+    # still exactly --steps steps on ONE setting).  Every rank takes the same decisions: the timings are all-reduced (MAX).
+    sweep_rows, first_loss = None, None
+    bucket_given = any(a == "--bucket-mb" or a.startswith("--bucket-mb=") for a in sys.argv[1:])
+    tune = ts.reducer is not None and not ts.use_graph and (
+        args.sweep or args.tune_buckets == "on" or (args.tune_buckets == "auto" and world > 1 and not bucket_given))
+    if tune:
+        try:
+            for i in range(3):  # lazy initialisations, launch-plan recording, allocator
+                loss = ts.step(*next_batch())
+                if i == 0:
+                    first_loss = loss.item() / args.batch
+            sync()
+            wires = (False, True) if (args.sweep and not args.wire_bf16) else (args.wire_bf16,)
+            sweep_rows = time_exchange_settings(ts, next_batch, sync, dev, distributed, (32, 64, 128), wires,
+                                                max(3, args.sweep_steps if args.sweep else 6))
+            same_wire = [r for r in sweep_rows if (r["wire"] == "bf16") == bool(args.wire_bf16)]
+            # the fastest bucket size on the wire dtype that was asked for (bf16 on the wire is a numerics trade: reported, never picked);
+            # within 0.5 % of the default the default stays
+            pick = min(same_wire, key=lambda r: r["ms_per_step"])
+            dflt = next((r for r in same_wire if r["bucket_mb"] == args.bucket_mb), None)
+            if dflt is not None and dflt["ms_per_step"] <= pick["ms_per_step"] * 1.005:
+                pick = dflt
+            args.bucket_mb = pick["bucket_mb"]
+            note("exchange sweep: " + ", ".join(f"{r['bucket_mb']} MB/{r['wire']} {r['ms_per_step']:.2f} ms" for r in sweep_rows)
+                 + f" -> {args.bucket_mb} MB buckets")
+        except Exception as e:  # the headline run must survive a failed sweep: back to the defaults
+            note(f"exchange sweep failed ({type(e).__name__}: {e}); default settings")
+            sweep_rows = [{"error": f"{type(e).__name__}: {e}"[:200]}]
+        ts.reducer.set_wire_bf16(args.wire_bf16)
+        ts.reducer.rebucket(args.bucket_mb << 20)
     for i in range(args.warmup):
         loss = ts.step(*next_batch())
-        if i == 0:
+        if first_loss is None:
             first_loss = loss.item() / args.batch
             note(f"first step done, loss {first_loss:.4f}")
     if ts.reducer is not None:
@@ -798,7 +917,8 @@ def main() -> None:
             "seq_len": 197,
             "parallelism": f"dp{world}",
             "launch": "hipGraph replay" if ts.use_graph else "eager",
-            "input": "resident in HBM" if feed is None else "host numpy -> TensorBatcher (copy stream, 1 batch ahead, device buffer ring)",
+            "batches_in_rotation": nb if feed is None else 4,
+            "input": f"resident in HBM ({nb} synthetic batches in rotation, each with its own labels)" if feed is None else "host numpy -> TensorBatcher (copy stream, 1 batch ahead, device buffer ring)",
             "grad_exchange": "none" if not distributed else (
                 f"bucketed {'RCCL' if args.backend == 'nccl' else args.backend} all-reduce {'bf16 wire' if args.wire_bf16 else 'fp32'}, "
                 f"{args.bucket_mb} MB buckets ({len(ts.reducer.buckets)}), comm stream, launched by {args.comm}"),
@@ -827,6 +947,9 @@ def main() -> None:
             "max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS", "default"),
             "self_test": comm_selftest, "buckets": len(ts.reducer.buckets) if ts.reducer is not None else 0,
             "bucket_mb": args.bucket_mb, "wire": "bf16" if args.wire_bf16 else "fp32",
+            # (round 5) bucket size x wire dtype timed on this job before the warm-up (ms per step, max over ranks); the timed region
+            # ran on `bucket_mb`.  `sweep` = the full --sweep table, `bucket_sweep` = the default short one.
+            ("sweep" if args.sweep else "bucket_sweep"): sweep_rows,
         }
     if ts.reducer is not None:
         ex = ts.reducer.exposed_ms()

@@ -579,12 +579,22 @@ int launch_pp_cfg(GemmParams p, int b_trans, int epilogue, hipStream_t s) {
 }  // namespace
 
 // gemm.hip hands over a fully checked problem (its own GemmParams: the same header, the same layout)
-int cfhip_internal_gemm_pp_supported(int M, int N, int K, long ldc, int a_trans, int epilogue, int out_dtype, int accumulate, int split_k,
-                                     int variant) {
+int cfhip_internal_gemm_pp_supported(int M, int N, int K, long ldc, int a_trans, int b_trans, int epilogue, int out_dtype, int accumulate,
+                                     int split_k, int variant) {
   if (a_trans || accumulate || split_k > 1 || variant < 0 || variant > 3) return 0;
   if ((N & 7) != 0 || (ldc & 7) != 0) return 0;   // 16-byte bf16 row segments per lane
   if (K < 3 * 64 || (K & 63) != 0) return 0;       // whole 64-deep K-steps, at least NSLOT of them
-  (void)M; (void)epilogue; (void)out_dtype;
+  // exactly the (layout, epilogue, output type) combinations launch_pp_cfg instantiates: anything else is "not supported"
+  // (the caller then takes the 16x16x32 kernels), never an error out of a forced configuration
+  const bool f32 = out_dtype != 0;
+  switch (epilogue) {
+    case CFHIP_EPI_NONE: break;
+    case CFHIP_EPI_GELU: if (b_trans || f32) return 0; break;
+    case CFHIP_EPI_RESIDUAL: if (b_trans) return 0; break;
+    case CFHIP_EPI_DGELU: if (!b_trans || f32) return 0; break;
+    default: return 0;
+  }
+  (void)M;
   return 1;
 }
 

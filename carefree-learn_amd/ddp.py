@@ -157,8 +157,9 @@ class BucketedAllReduce:
         # the fused Adam(W) update of a bucket's arena range right behind its all-reduce, on the comm stream (the arena holds
         # the rank SUM and the kernel applies 1 / W): see optim.StepInBackward for why no running kernel sees a half-updated
         # weight.  Not with bf16 on the wire (widened in finish()), not with an averaged arena (a trainer that clips).
-        self.step_in_backward = bool(step_in_backward) and optimizer is not None and not wire_bf16 and arena.flat_g.is_cuda
-        if self.step_in_backward:
+        self._want_step_in_backward = bool(step_in_backward) and optimizer is not None and arena.flat_g.is_cuda
+        self.step_in_backward = self._want_step_in_backward and not wire_bf16
+        if self._want_step_in_backward:
             arena.double_buffer_shadows()
         self.comm = comm  # None: torch.distributed launches the collectives; a Communicator: the cfhip_comm_* C-ABI
         self.is_cuda = arena.flat_g.is_cuda
@@ -172,7 +173,31 @@ class BucketedAllReduce:
         # closes LAST (the first-registered parameters: stem / positional encoding, whose gradients appear when backward
         # ends) is the one exchange nothing can hide: it is kept small (`tail_bytes`) — the parameters before the first
         # cut-off go into a bucket of their own instead of riding on up to `bucket_bytes` of earlier-finished gradients.
-        self.buckets: List[_Bucket] = []
+        self.tail_bytes = tail_bytes
+        self._index = {id(p): i for i, p in enumerate(arena.params)}
+        self._pass_open = False      # a backward pass has notified since the last finish()
+        self.rebucket(bucket_bytes)
+        self._pass_sync = True       # ... and it is a synchronising pass (sync_fn at its first notification)
+        self._wire: Optional[Tensor] = None  # bf16 staging of the gradient arena (wire_bf16)
+        self.exposed_events: List[Any] = []  # (start, end) event pairs around finish()'s waits, when timing is on
+        self.time_exposed = False
+        HF.grad_ready_callbacks.append(self._on_direct)
+        HF.backward_entered_callbacks.append(self._on_backward_entered)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_ready) for p in arena.params]
+        if optimizer is not None:
+            optimizer.grad_scale = 1.0 if self.average else 1.0 / self.world_size
+
+    def rebucket(self, bucket_bytes: int, tail_bytes: Optional[int] = None) -> int:
+        """(Re)cut the gradient arena into buckets — the same communicator, streams and hooks (`bench.py` sweeps the bucket size
+        of a live job with it: a new communicator per candidate would also re-read NCCL_* settings).  Only BETWEEN passes:
+        every rank must call it with the same sizes at the same point of its step sequence.  Returns the bucket count."""
+        if self._pass_open or any(b.launched for b in getattr(self, "buckets", [])):
+            raise RuntimeError("BucketedAllReduce.rebucket: a backward pass is open (call it after finish() / the optimizer step)")
+        arena = self.arena
+        if tail_bytes is None:
+            tail_bytes = self.tail_bytes
+        self.bucket_bytes, self.tail_bytes = int(bucket_bytes), int(tail_bytes)
+        self.buckets = []
         n = len(arena.params)
         n_tail, acc = 0, 0
         if tail_bytes > 0 and arena.total * 4 > bucket_bytes:
@@ -195,17 +220,15 @@ class BucketedAllReduce:
                 self.bucket_of[i] = bi
         self._ready = [False] * n
         self._direct = [False] * n  # notified by a HIP backward (functional.grad_ready_callbacks)
-        self._index = {id(p): i for i, p in enumerate(arena.params)}
-        self._pass_open = False      # a backward pass has notified since the last finish()
-        self._pass_sync = True       # ... and it is a synchronising pass (sync_fn at its first notification)
-        self._wire: Optional[Tensor] = None  # bf16 staging of the gradient arena (wire_bf16)
-        self.exposed_events: List[Any] = []  # (start, end) event pairs around finish()'s waits, when timing is on
-        self.time_exposed = False
-        HF.grad_ready_callbacks.append(self._on_direct)
-        HF.backward_entered_callbacks.append(self._on_backward_entered)
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_ready) for p in arena.params]
-        if optimizer is not None:
-            optimizer.grad_scale = 1.0 if self.average else 1.0 / self.world_size
+        return len(self.buckets)
+
+    def set_wire_bf16(self, on: bool) -> None:
+        """Switch the wire dtype of a live reducer (between passes; every rank alike).  bf16 on the wire keeps the optimizer at the
+        end of the step (the widened sum exists only after finish())."""
+        if self._pass_open:
+            raise RuntimeError("BucketedAllReduce.set_wire_bf16: a backward pass is open")
+        self.wire_bf16 = bool(on)
+        self.step_in_backward = self._want_step_in_backward and not self.wire_bf16
 
     # -- life cycle ---------------------------------------------------------------------------
     def close(self) -> None:
@@ -362,7 +385,7 @@ class BucketedAllReduce:
                     b.work = _StreamWork(self.comm_stream)
                 else:
                     b.work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                if self.step_in_backward and not self.average and self._pass_open:
+                if self.step_in_backward and not self.average and self._pass_open and getattr(self.optimizer, "step_armed", False):
                     if self.comm is None:
                         b.work.wait()  # the process group reduces on a stream of its own: the comm stream follows it
                     self.optimizer.launch_range(b.start, b.end, self.comm_stream)

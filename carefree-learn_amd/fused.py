@@ -507,6 +507,7 @@ class MixingBlockFn(Function):
 #     that keeps a stack's training-mode output across steps must clone it (or run with CFHIP_STACK_PLANS=0).
 STACK_PLANS = os.environ.get("CFHIP_STACK_PLANS", "1") != "0"
 _plans: dict = {}  # id(first parameter) -> StackPlan
+_plan_conflicts: dict = {}  # id(first parameter) -> times a forward found the stack's plan still in flight
 _PLAN_CACHE = 8
 
 
@@ -552,6 +553,16 @@ class StackPlan:
         sites = []
         for li, ops_ in enumerate((self.fwd, self.bwd)):
             for ei, (kind, _f, a) in enumerate(ops_):
+                if kind == 3:
+                    # the host problem table of a grouped weight-gradient launch (ops.gemm_grouped_tn): its A / B operand
+                    # addresses are not in any argument tuple.  Site = (table row, field name); the table object is shared
+                    # by the twin lists (no weight shadow is an operand of a weight gradient), so it is patched in place.
+                    for pi in range(a):
+                        for field in ("A", "B"):
+                            v = getattr(_f[pi], field) or 0
+                            if base <= v < base + nbytes:
+                                sites.append((li, ei, (pi, field), v - base))
+                    continue
                 if kind != 0:
                     continue
                 for ai, v in enumerate(a):
@@ -563,6 +574,9 @@ class StackPlan:
         """the stack's input (or incoming gradient) lives at another address this step: rewrite the few launches that read it —
         in both twin lists — instead of copying the tensor into the recorded buffer"""
         for li, ei, ai, off in sites:
+            if type(ai) is tuple:  # a row of a grouped launch's problem table (shared by both twin lists)
+                setattr((self.fwd if li == 0 else self.bwd)[ei][1][ai[0]], ai[1], new_base + off)
+                continue
             for ops_ in ((self.fwd, self.fwd_alt) if li == 0 else (self.bwd, self.bwd_alt)):
                 if ops_ is None:
                     continue
@@ -598,6 +612,8 @@ def _replay(ops_: list) -> None:
                 _lib.check(rc, "launch plan")
         elif kind == 1:
             f(*a)
+        elif kind == 3:
+            continue  # the problem table of the grouped launch that follows (kept for repoint)
         else:  # gradient notification, on the stream it fired on
             with _functional.on_stream(a):
                 _functional.notify_grad_ready(f)
@@ -606,24 +622,29 @@ def _replay(ops_: list) -> None:
 class _KeepAllocations:
     """while recording: every tensor torch.empty / empty_like hands out stays alive with the plan (its address is in the
     recorded arguments).  The wrappers allocate with these two calls only (no fills: nothing an ATen kernel would have to redo).
-    Process-wide for the duration of ONE recorded forward / backward (two module attributes are swapped): a tensor another
-    thread allocates in that window is kept too — a few bytes held longer, never a wrong result."""
+    Two module attributes are swapped for the duration of ONE recorded forward / backward; only allocations made by the
+    RECORDING thread are kept (a loader thread's pinned buffers allocated in that window pass through untouched)."""
 
     def __init__(self, keep: list) -> None:
         self.keep = keep
 
     def __enter__(self) -> None:
+        import threading
+
         self.empty, self.empty_like = torch.empty, torch.empty_like
         keep, e0, e1 = self.keep, self.empty, self.empty_like
+        me, ident = threading.get_ident(), threading.get_ident
 
         def empty(*a, **k):
             t = e0(*a, **k)
-            keep.append(t)
+            if ident() == me:
+                keep.append(t)
             return t
 
         def empty_like(*a, **k):
             t = e1(*a, **k)
-            keep.append(t)
+            if ident() == me:
+                keep.append(t)
             return t
 
         torch.empty, torch.empty_like = empty, empty_like
@@ -726,12 +747,32 @@ class MixingStackFn(Function):
         ctx.plan = None
         plan = _plan_for(x, metas, keep_mask, causal, params, any(ctx.needs_input_grad))
         if plan is not None and plan.in_flight and not plan.disabled:
-            # a second forward of this stack before the backward of the first (shared towers, evaluation between steps): the
-            # recorded buffers would be overwritten under the pending backward — this stack keeps the normal path
-            plan.disabled = True
+            # a second forward of this stack before the backward of the first: the recorded buffers would be overwritten under
+            # the pending backward.  The plan in flight is dropped from the table (the pending backward — if one ever comes —
+            # still holds it through its ctx and replays on its own buffers; a forward that never gets a backward, e.g. an
+            # exception mid-step or an evaluation with grad enabled, releases it with its graph) and the stack starts a NEW
+            # plan: this call runs the normal path, the next one records.  A stack that keeps doing it (towers shared inside
+            # one step) would re-record every other step: after the third time it keeps the normal path for good, said once.
+            pid = id(params[0])
+            n = _plan_conflicts[pid] = _plan_conflicts.get(pid, 0) + 1
+            plan = _plans[pid] = StackPlan(plan.key, params)
+            if n > 2:
+                plan.disabled = True
+                if n == 3:
+                    import warnings
+
+                    warnings.warn("cfhip: a block stack is called again before the backward of its previous call, repeatedly: "
+                                  "launch plans are off for this stack (normal launch path; results are the same)")
         if plan is not None and not plan.in_flight and not plan.disabled:
             plan.calls += 1
             plan.mask_tensor = keep_mask
+            # every weight shadow the recorded launches read is brought up to date HERE (attribute reads when the optimizer
+            # keeps them fresh; a cast on the caller's stream, before the replay forks, when a torch optimizer stepped the
+            # parameter or nobody re-cast it between two accumulation micro-batches: the recording may not hold that cast —
+            # ADVICE r4, medium)
+            for j in range(2, len(params), 12):
+                for q in (params[j], params[j + 2], params[j + 6], params[j + 8]):  # in_w, out_w, w1, w2
+                    shadow_bf16(q)
             w_now = shadow_bf16(params[2]).data_ptr()
             if plan.ready_fwd and plan.ready_bwd and w_now in (plan.w_ptr, plan.w_alt):
                 # ---- replay

@@ -234,6 +234,10 @@ def gemm_grouped_tn(problems: list, tiles: Optional[int] = None) -> None:
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    if _lib.RECORDER is not None:
+        # the operand addresses of this launch live in a host table, not in the argument tuple: a launch plan that moves its
+        # input (fused.StackPlan.repoint) must be able to find and rewrite them — kind-3 entry = the table
+        _lib.RECORDER.append((3, arr, len(problems)))
     if tiles is None:
         rc = _lib.load().cfhip_gemm_bf16_grouped_tn(ctypes.cast(arr, ctypes.c_void_p), len(problems), _stream())
     else:

@@ -184,6 +184,11 @@ class FusedAdam:
         self._done: List[Tuple[int, int]] = []  # arena ranges already updated in this step (update-in-backward)
         self._range_streams: List[Any] = []     # ... and the streams those updates were issued on
         self.in_backward: Optional["StepInBackward"] = None
+        # True between prepare_step() and launch_step(): only then does `_hyper_dev` hold THIS step's record.  Whoever launches
+        # range updates from inside backward (StepInBackward, ddp.BucketedAllReduce(step_in_backward=True)) checks it: with the
+        # public `optimizer.step()` pattern (prepare + launch after backward) an early bucket would otherwise be updated with
+        # the previous step's bias corrections — all zeros on step 1.
+        self.step_armed = False
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.arena.zero_grad(lazy=self.lazy_zero)
@@ -234,6 +239,10 @@ class FusedAdam:
         """Host side of a step: advance t and upload the 32-byte hyper-parameter record.  Kept
         separate from `launch_step()` so the launch itself can live inside a captured hipGraph."""
         self.step_count += 1
+        # ranges updated by a pass whose launch_step() never ran (an exception between the two, a skipped non-finite loss)
+        # must not count as done in THIS step (ADVICE r4)
+        self._done, self._range_streams = [], []
+        self.step_armed = True  # this step's hyper-parameter record is on its way: range updates may be launched until launch_step()
         self._fill_hyper()
         self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
         if self._hyper_dev.is_cuda:
@@ -266,6 +275,7 @@ class FusedAdam:
 
         if self.in_backward is not None:
             self.in_backward.end_step()
+        self.step_armed = False
         for st in self._range_streams:  # the caller's stream now follows every range update issued so far
             torch.cuda.current_stream().wait_stream(st)
         self._range_streams = []

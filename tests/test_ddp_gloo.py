@@ -66,8 +66,34 @@ def _worker(rank: int, world: int, port: int, out: str) -> None:
     ((model(xs[2:]) - ys[2:]) ** 2).sum().backward()
     red.finish()
     g_acc = arena.flat_g.clone()
+
+    # step 3 (round 5): the SAME reducer re-cut into other buckets between passes (bench.py's bucket sweep of a live job), and the
+    # wire dtype switched: the plain step must give the same sum again (bf16 wire: to bf16 rounding of the per-rank gradients)
+    g_rebucket = []
+    for bb in (64, 1 << 20):
+        nbk = red.rebucket(bb)
+        assert nbk == len(red.buckets) and (nbk == 1) == (bb == 1 << 20)
+        arena.zero_grad()
+        ((model(xs) - ys) ** 2).mean().backward()
+        red.finish()
+        g_rebucket.append(arena.flat_g.clone())
+    red.set_wire_bf16(True)
+    arena.zero_grad()
+    ((model(xs) - ys) ** 2).mean().backward()
+    red.finish()
+    g_wire = arena.flat_g.clone()
+    red.set_wire_bf16(False)
+    arena.zero_grad()
+    ((model(xs) - ys) ** 2).mean().backward()
+    try:
+        red.rebucket(128)
+        refused = False
+    except RuntimeError:
+        refused = True  # a pass is open: buckets may hold launched collectives
+    red.finish()
     torch.save(dict(g_sync=g_sync, g_acc=g_acc, p=arena.flat_p.clone(), offsets=arena.offsets,
-                    extra_grad=extra.grad.clone()), f"{out}.{rank}")
+                    extra_grad=extra.grad.clone(), g_rebucket=g_rebucket, g_wire=g_wire, refused=refused,
+                    g_after=arena.flat_g.clone()), f"{out}.{rank}")
     red.close()
     dist.destroy_process_group()
 
@@ -82,6 +108,11 @@ def test_bucketed_allreduce_two_ranks(tmp_path):
     assert torch.equal(r0["g_sync"], r1["g_sync"]) and torch.equal(r0["p"], r1["p"])
     assert torch.equal(r0["g_acc"], r1["g_acc"])
     assert r0["extra_grad"].abs().sum() == 0
+    for r in (r0, r1):
+        for gr in r["g_rebucket"]:
+            assert torch.equal(gr, r["g_sync"])  # other buckets, the same element-wise sums
+        assert (r["g_wire"] - r["g_sync"]).abs().max() <= 1e-2 * r["g_sync"].abs().max()
+        assert r["refused"] and torch.equal(r["g_after"], r["g_sync"])
 
     # single-process reference on the concatenated batch
     model = _model()

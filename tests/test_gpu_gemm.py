@@ -177,6 +177,26 @@ def test_fused_bias_gradient_of_dw_gemm():
             assert_close(gw, 2 * want_w, 2e-5, "dW accumulate")
 
 
+# gemm.hip: Cfg<BM, BN, WM, WN, NSTAGE, BK> of gemm_config 0 .. 16, as rocprofv3 prints the instantiation
+TILE_CONFIG_NAMES = [
+    "Cfg<128, 128, 2, 2, 2, 64>", "Cfg<128, 128, 2, 2, 2, 32>", "Cfg<128, 128, 2, 2, 3, 32>", "Cfg<128, 64, 2, 2, 2, 64>",
+    "Cfg<128, 128, 2, 2, 4, 32>", "Cfg<128, 64, 2, 2, 2, 32>", "Cfg<128, 64, 2, 2, 3, 32>", "Cfg<256, 256, 2, 4, 4, 32>",
+    "Cfg<256, 128, 2, 4, 3, 32>", "Cfg<256, 128, 2, 2, 3, 32>", "Cfg<128, 256, 2, 2, 3, 32>", "Cfg<256, 128, 2, 4, 6, 32>",
+    "Cfg<256, 256, 2, 4, 5, 32>", "Cfg<256, 256, 2, 4, 2, 64>", "Cfg<192, 128, 2, 4, 2, 64>", "Cfg<192, 128, 2, 2, 2, 64>",
+    "Cfg<128, 256, 2, 4, 2, 64>"]
+
+
+def _kernel_name(m, n, k, a_trans, b_trans, epilogue=0):
+    import ctypes
+
+    from cflearn_amd import _lib
+
+    buf = ctypes.create_string_buffer(128)
+    rc = _lib.load().cfhip_gemm_kernel_name(m, n, k, int(a_trans), int(b_trans), epilogue, buf, 128)
+    _lib.check(rc, "gemm_kernel_name")
+    return buf.value.decode()
+
+
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 def test_every_tile_config(cfg):
     """all tile configurations of the kernel on ragged shapes, all three layouts"""
@@ -194,6 +214,13 @@ def test_every_tile_config(cfg):
                 b = _mk(k, n, 41) if b_trans else _mk(n, k, 41)
                 got = ops.gemm(a.to(DEV), b.to(DEV), a_trans=a_trans, b_trans=b_trans, out_dtype=torch.float32)
                 assert_close(got, _ref(a, b, a_trans, b_trans), 2e-5, f"cfg{cfg} {layout} {m}x{n}x{k}")
+                # the kernel that ran IS the configuration this case names: the library resolves the request
+                # to an instantiation; the one documented reroute (256x128x32 phase kernel has no weight-gradient layout:
+                # 12 bytes of scratch, instantiation removed) is asserted as such instead of passing for its sibling
+                name = _kernel_name(m, n, k, a_trans, b_trans)
+                want_cfg = TILE_CONFIG_NAMES[1 if (cfg == 8 and a_trans) else cfg]
+                assert want_cfg in name, (cfg, layout, name)
+                assert ("phase_kernel" in name) == (7 <= cfg <= 12 and not (cfg == 8 and a_trans)), (cfg, layout, name)
     finally:
         ops.set_option("gemm_config", -1)
 

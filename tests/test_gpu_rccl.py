@@ -135,6 +135,29 @@ CHILD2 = textwrap.dedent("""
         assert torch.equal(other, got), "ranks diverged"
         assert err < 2e-5 and upd < 0.5, (in_bwd, err, upd)
         print("rank", rank, "in_bwd", in_bwd, "rel", err, "max / lr", upd)
+    # (c) the same reducer driven with the PUBLIC optimizer pattern: backward, reducer.finish(), optimizer.step() (prepare +
+    # launch AFTER backward).  No hyper-parameter record of this step exists while the buckets close, so no bucket may be
+    # updated inside backward (round 5, ADVICE r4: early buckets took the previous step's bias corrections — zeros on step 1)
+    from cflearn_amd import ops
+    from cflearn_amd.functional import SideStream
+    ts = TrainStep(build(), lr=1e-3, weight_decay=0.01, distributed=True, bucket_bytes=1 << 16, step_in_backward=True, range_bytes=1 << 16)
+    assert ts.reducer.step_in_backward
+    xs, ys = x[rank * half:(rank + 1) * half], y[rank * half:(rank + 1) * half]
+    for _ in range(3):
+        ts.optimizer.zero_grad()
+        logits = ts.model(xs)["predictions"]
+        _, dlogits = ops.softmax_xent(logits, ys, 1.0 / logits.shape[0])
+        logits.backward(dlogits)
+        SideStream.join()
+        ts.reducer.finish()
+        assert not ts.optimizer._done, "a bucket was updated without this step's hyper-parameter record"
+        ts.optimizer.step()
+    torch.cuda.synchronize()
+    got = ts.arena.flat_p.clone()
+    assert torch.isfinite(got).all()
+    err = ((got - want).norm() / want.norm()).item()
+    assert err < 2e-5, ("public step() pattern", err)
+    print("rank", rank, "public step() pattern rel", err)
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:

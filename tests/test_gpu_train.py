@@ -281,12 +281,16 @@ def test_optimizer_scalars_survive_a_host_that_runs_ahead(golden):
     assert_close(b, a, 2e-6, "parameters after 6 steps, stalled GPU vs step-by-step")
 
 
-def test_stack_launch_plans_replay_bit_identically():
+@pytest.mark.parametrize("width,layers,grouped", [(256, 3, False), (512, 4, True)])
+def test_stack_launch_plans_replay_bit_identically(width, layers, grouped):
     """fused.StackPlan (round 4): the second step of a block stack is recorded at the C-ABI boundary, later steps replay the
     recorded launches.  Same kernels, same arguments: the trajectory of a 256-wide ViT (LayerNorm gradients on the
     deterministic kernel, batch large enough for the two batch slices, optimizer inside backward with both shadow arenas)
     must be BIT-identical with plans on and off — parameters and moments after every step, losses — and the plan must really
-    have replayed."""
+    have replayed.  The 512-wide case (round 5) has more than DW_MIN_TILES weight-gradient tiles per flush, so
+    the stack's weight gradients go out as GROUPED launches whose operand addresses sit in a host problem table: the last
+    block's dW2 reads the stack's incoming gradient through that table, and a replay that moves the incoming gradient must
+    patch the table too (it did not: w2.grad / b2.grad of the last block came from the recorded step's gradient)."""
     from cflearn_amd import fused
 
     def run(plans: bool, steps: int = 7):
@@ -295,7 +299,7 @@ def test_stack_launch_plans_replay_bit_identically():
         fused._plans.clear()
         try:
             torch.manual_seed(3)
-            m = C.vit_b16_classifier(10, img_size=32, patch_size=8, latent_dim=256, num_layers=3).to(DEV)
+            m = C.vit_b16_classifier(10, img_size=32, patch_size=8, latent_dim=width, num_layers=layers).to(DEV)
             ts = TrainStep(m, lr=1e-3, weight_decay=0.01)
             gen = torch.Generator().manual_seed(5)
             batches = [(torch.randn(8, 3, 32, 32, generator=gen).to(DEV), torch.randint(0, 10, (8,), generator=gen).to(DEV)) for _ in range(3)]
@@ -316,6 +320,10 @@ def test_stack_launch_plans_replay_bit_identically():
     assert no_plan is None
     assert plan is not None and plan.ready_fwd and plan.ready_bwd and not plan.disabled and plan.calls == 7
     assert plan.fwd_alt is not None and len(plan.fwd) > 30 and len(plan.bwd) > 60  # both shadow arenas, real launch lists
+    tables = [e for e in plan.bwd if e[0] == 3]
+    assert bool(tables) == grouped, (len(tables), grouped)
+    if grouped:  # the incoming gradient is an operand of a grouped launch, and the plan knows where
+        assert any(type(site[2]) is tuple for site in plan.dy_sites), plan.dy_sites
     for i, ((l0, p0, v0), (l1, p1, v1)) in enumerate(zip(ref, got)):
         assert abs(l0 - l1) <= 1e-5 * abs(l0), (i, l0, l1)  # (the scalar loss is a sum of per-sample f32 atomics: not bitwise)
         assert torch.equal(p0, p1) and torch.equal(v0, v1), i
@@ -323,10 +331,12 @@ def test_stack_launch_plans_replay_bit_identically():
 
 def test_stack_launch_plans_fall_back():
     """what a plan cannot follow takes the normal path: another batch size re-records, a forward-only call between steps
-    (two forwards before a backward) switches the plan of that stack off, evaluation runs without one."""
+    (two forwards before a backward) drops the plan in flight and starts a new one — switched off for good only when it keeps
+    happening —, evaluation runs without one."""
     from cflearn_amd import fused
 
     fused._plans.clear()
+    fused._plan_conflicts.clear()
     torch.manual_seed(3)
     m = C.vit_b16_classifier(10, img_size=32, patch_size=8, latent_dim=256, num_layers=2).to(DEV)
     ts = TrainStep(m, lr=1e-3)
@@ -347,9 +357,26 @@ def test_stack_launch_plans_fall_back():
     ts.optimizer.zero_grad()
     m(img)  # forward in training mode without a backward ...
     ts.step(img, lab)  # ... then a step: the stack is asked again while the plan is in flight
-    assert plan3.disabled
-    l_after = ts.step(img, lab).item()
+    # (round 5) one abandoned forward does not cost the stack its plans: the plan in flight is dropped, a new one starts
+    plan4 = next(iter(fused._plans.values()))
+    assert plan4 is not plan3 and not plan4.disabled and not plan3.disabled and not plan4.ready_fwd
+    for _ in range(3):
+        l_after = ts.step(img, lab).item()
+    assert plan4.ready_bwd and plan4.calls >= 4  # recorded again and replaying
     assert l_after == l_after and l_after < l8 * 1.5
+    # a stack that keeps being called twice per backward ends on the normal path, with one warning
+    import warnings as _w
+
+    with _w.catch_warnings(record=True) as seen:
+        _w.simplefilter("always")
+        for _ in range(6):
+            ts.optimizer.zero_grad()
+            m(img)
+            ts.step(img, lab)
+    last = next(iter(fused._plans.values()))
+    assert last.disabled and sum("launch plans are off" in str(w.message) for w in seen) == 1
+    l_end = ts.step(img, lab).item()
+    assert l_end == l_end and l_end < l8 * 1.5
     m.eval()
     with torch.no_grad():
         y = m(img)["predictions"]
