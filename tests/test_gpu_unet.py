@@ -548,6 +548,11 @@ def test_unet_zoo_full_size_step_vs_oracle():
     cfg = dict(in_channels=3, out_channels=3, start_channels=320, num_heads=8, use_spatial_transformer=True,
                num_transformer_layers=1, num_res_blocks=2, attention_downsample_rates=(1, 2, 4),
                channel_multipliers=(1, 2, 4, 4), context_dim=None)
+    # the reference's OWN numbers for this seeded problem (oracle/gen_unet_zoo_yardstick.py, made in the build container from
+    # cflearn's UNetDiffuser): its fp32 loss / probes of its fp32 output and gradients (pins the restatement at 865 M parameters),
+    # and how far ITS bf16-autocast run sits from its fp32 run, tensor by tensor — the yardstick of the bounds below
+    ref = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "unet_zoo_yardstick.pt"), weights_only=False)
+    assert ref["cfg"] == cfg and set(ref["grad_err"]) == set(ZOO_SAMPLED)
     torch.manual_seed(0)
     m = C.build_module("unet_diffuser", config=cfg)
     assert sum(p.numel() for p in m.parameters()) == 865126723
@@ -598,24 +603,39 @@ def test_unet_zoo_full_size_step_vs_oracle():
         torch.set_num_threads(prev)
     from helpers import rel_l2
 
-    errs = {k: rel_l2(got[k], ref) for k, ref in zip(ZOO_SAMPLED, grads)}
-    ac_errs = {k: rel_l2(a.float(), ref) for k, a, ref in zip(ZOO_SAMPLED, ac_grads, grads)}
+    # (1) the restatement against the reference at FULL size: fp32 loss, 64 strided output values, 64 strided values of every
+    # sampled gradient — from the reference's own fp32 run of the same seeded problem (two fp32 CPU runs with different op
+    # decompositions: 1e-4)
+    assert abs(want_loss.item() - ref["loss_fp32"]) <= 1e-5 * abs(ref["loss_fp32"]), (want_loss.item(), ref["loss_fp32"])
+    assert rel_l2(want_y.detach().flatten()[::192][:64], ref["y_probe"]) <= 1e-4
+    for k, gr in zip(ZOO_SAMPLED, grads):
+        probe = gr.flatten()[:: max(1, gr.numel() // 64)][:64]
+        assert rel_l2(probe, ref["grad_probe"][k]) <= 2e-4, (k, rel_l2(probe, ref["grad_probe"][k]))
+        assert abs(gr.norm().item() - ref["grad_norm"][k]) <= 1e-4 * ref["grad_norm"][k], k
+    errs = {k: rel_l2(got[k], gr) for k, gr in zip(ZOO_SAMPLED, grads)}
+    ac_errs = {k: rel_l2(a.float(), gr) for k, a, gr in zip(ZOO_SAMPLED, ac_grads, grads)}
     y_err, loss_err = rel_l2(got_y, want_y.detach()), abs(got_loss - want_loss.item()) / abs(want_loss.item())
     ac_y_err = rel_l2(ac_y.detach().float(), want_y.detach())
     worst = max(errs, key=errs.get)
-    print(f"zoo UNet 64^2 x 1: output rel-L2 {y_err:.3e} (bf16-autocast oracle {ac_y_err:.3e}), loss {got_loss:.6f} vs "
-          f"{want_loss.item():.6f} (rel {loss_err:.2e}); worst sampled gradient rel-L2 {errs[worst]:.3e} ({worst})")
+    print(f"zoo UNet 64^2 x 1: output rel-L2 {y_err:.3e} (the reference under bf16 autocast {ref['y_err']:.3e}; the primitive-op oracle "
+          f"under autocast {ac_y_err:.3e}), loss {got_loss:.6f} vs {want_loss.item():.6f} (rel {loss_err:.2e}); worst sampled gradient "
+          f"rel-L2 {errs[worst]:.3e} ({worst})")
     for k in ZOO_SAMPLED:
-        print(f"    {k:55s} {errs[k]:.3e}   bf16-autocast oracle {ac_errs[k]:.3e}")
-    # Bounds.  Loss: 2e-3 relative (measured 1.7e-4).  Output and gradients: VERDICT r3 proposed 3e-2 for the
-    # gradients; the deepest tensors (8^2 x 1280, the middle block) sit at 4.5-5.2e-2 — and so does the ORACLE's own arithmetic
-    # under bf16 autocast (4.5-4.6e-2 on the same tensors: bf16 rounding through ~30 layers each way), so the bound is
-    # relative to that run: no tensor more than 1.3 x as far from fp32 as the reference's own bf16 execution (measured
-    # 0.9-1.2 x on all 21), and never beyond the small fixture's 8e-2.
+        print(f"    {k:55s} {errs[k]:.3e}   reference bf16-autocast {ref['grad_err'][k]:.3e} (x {errs[k] / ref['grad_err'][k]:.2f})   "
+              f"[primitive-op oracle under autocast {ac_errs[k]:.3e}]")
+    # Bounds.  Loss: 2e-3 relative (measured 1.7e-4).  Output and gradients: the deepest tensors (8^2 x 1280, the
+    # middle block) sit at 5e-2 from fp32 — bf16 rounding through ~30 layers each way — so the bound is relative to what the
+    # REFERENCE'S OWN bf16 execution does on the same seeded problem (the fixture: cflearn's UNetDiffuser under
+    # torch.autocast(bf16), 5.9e-2 on those tensors).  Round 4 measured the yardstick by running the primitive-op oracle under
+    # autocast; that run keeps an f32 residual stream (autocast only rounds its `@`, the bias add behind it promotes to f32) and
+    # sat BELOW the reference's real mixed-precision run (1.31e-2 vs 1.72e-2 on the output) — the "systematic 1.03-1.28 x" of
+    # VERDICT r4 weak #2 was the yardstick, not an intermediate of ours.  Against the real one every sampled tensor is CLOSER to
+    # fp32 than the reference's bf16 run (0.83-0.95 x; fp32 parameter gradients and the un-rounded time-embedding add are why):
+    # bound 1.1 x (asked: <= 1.1 x, then a 1.15 x test bound), never beyond the small fixture's 8e-2.
     assert loss_err <= 2e-3, (got_loss, want_loss.item())
-    assert y_err <= max(1e-2, 1.3 * ac_y_err) and y_err <= 2e-2, (y_err, ac_y_err)
+    assert y_err <= max(1e-2, 1.1 * ref["y_err"]) and y_err <= 2e-2, (y_err, ref["y_err"])
     for k in ZOO_SAMPLED:
-        assert errs[k] <= max(1e-2, 1.3 * ac_errs[k]) and errs[k] <= 8e-2, (k, errs[k], ac_errs[k])
+        assert errs[k] <= max(1e-2, 1.1 * ref["grad_err"][k]) and errs[k] <= 8e-2, (k, errs[k], ref["grad_err"][k])
 
 
 def test_ddpm_step_updates_inside_backward_bit_identically(golden):
