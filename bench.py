@@ -445,6 +445,7 @@ def build_other_workload(args):
         step = lambda: ts.step(data)  # noqa: E731
         name = "CLIP (ViT-B/32 + 12 x 512 causal text tower) symmetric InfoNCE step, fwd + bwd + fused AdamW"
         loss_div = 1
+    step.engine = ts  # (run_other_workload reports how many optimizer ranges were updated inside backward)
     return step, m, name, batch, loss_div
 
 
@@ -470,6 +471,8 @@ def run_other_workload(args) -> dict:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     note(f"{args.workload}: {dt * 1e3:.3f} ms/step, host issue time {host_dt * 1e3:.3f} ms/step")
+    inb = getattr(step.engine.optimizer, "in_backward", None)
+    in_bwd = None if inb is None else {"ranges": len(inb.ranges), "updated_inside_backward_last_step": int(inb.launched_in_backward)}
     counter = ops.FlopCounter()
     ops.FLOP_COUNTER = counter
     try:
@@ -489,6 +492,7 @@ def run_other_workload(args) -> dict:
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "host_issue_ms_per_step": round(host_dt * 1e3, 3),
+        "optimizer_in_backward": in_bwd,
         "config": {"workload": name, "per_gpu_batch": batch, "parameters": n_params,
                    "loss_first_step": None if first is None else round(first, 5),
                    "loss_last_step": round(loss.item() / loss_div, 5)},
@@ -630,6 +634,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (weak scaling; SURVEY §8a: 64 or 128)")
+    ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="cfhip_set_option before anything runs (A/B runs: e.g. gemm_heuristic=9); recorded in config.options")
     ap.add_argument("--batches", type=int, default=8, help="HBM-resident synthetic batches the steps rotate through (1: one fixed batch, which the model memorises)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (single GPU).  Default is eager multi-stream "
@@ -691,6 +697,12 @@ def main() -> None:
     if args.cpu_child is not None:
         _cpu_child(args.cpu_child, args.cpu_batch, args.cpu_steps, args.cpu_threads or (os.cpu_count() or 1))
         return
+    if args.set_option:
+        from cflearn_amd import ops as _ops
+
+        for item in args.set_option:
+            name, _, val = item.partition("=")
+            _ops.set_option(name, int(val))
     if args.workload != "vit":
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -917,6 +929,7 @@ def main() -> None:
             "seq_len": 197,
             "parallelism": f"dp{world}",
             "launch": "hipGraph replay" if ts.use_graph else "eager",
+            "options": list(args.set_option),
             "batches_in_rotation": nb if feed is None else 4,
             "input": f"resident in HBM ({nb} synthetic batches in rotation, each with its own labels)" if feed is None else "host numpy -> TensorBatcher (copy stream, 1 batch ahead, device buffer ring)",
             "grad_exchange": "none" if not distributed else (
@@ -1014,7 +1027,7 @@ def main() -> None:
             wl = name
             try:
                 r = run_other_workload(a2)
-                others[wl] = {k_: r[k_] for k_ in ("value", "unit", "ms_per_step", "host_issue_ms_per_step", "steps", "warmup", "roofline", "peak_mem_gb")}
+                others[wl] = {k_: r[k_] for k_ in ("value", "unit", "ms_per_step", "host_issue_ms_per_step", "optimizer_in_backward", "steps", "warmup", "roofline", "peak_mem_gb")}
                 others[wl]["workload"] = r["config"]["workload"]
                 others[wl]["per_gpu_batch"] = r["config"]["per_gpu_batch"]
             except Exception as e:  # the headline line must survive a failure here

@@ -574,7 +574,7 @@ int g_gemm_config = -1;
 #ifdef CFHIP_ABLATE
 int g_gemm_ablate = 0;
 #endif
-int g_gemm_heuristic = 8;
+int g_gemm_heuristic = 9;  // round 5: 9 (four-wave 192x128x64 for every M >= 1024 forward / dX GEMM): ViT 17.61 -> 17.47 ms, CLIP 17.89 -> 17.60, UNet neutral (profiles/r05/heuristic9_ab.txt)
 int g_gemm_group_n = 8;
 int g_pp_group_n = 0;  // tile walk of the gemm_pp kernels: 0 row-major, n > 0 column groups of n tiles
 
@@ -689,7 +689,10 @@ int pick_config(int M, int N, int a_trans, int b_trans) {
     // round 3c: the same 192x128x64 tile on FOUR waves of 96x64 for outputs up to 1 024 columns wide (2.4 MFMAs per
     // fragment read against 1.5 with eight 96x32 waves): N = 768 shapes 5-10 % faster alone (K = 2 304 dX 898 -> 992 TFLOP/s),
     // wider outputs lose (their waves' epilogues are twice as long); profiles/r03/gemm_bench_b128_c15.log
-    if (M >= 1024) return (g_gemm_heuristic >= 8 && N <= 1024) ? 15 : 14;
+    // round 5 (table 9): on the final round-4 kernels the four-wave form is ahead on EVERY step shape alone, the wide GELU / GELU'
+    // outputs included (80.7 / 81.8 us against 99.4 / 105.4, QKV 49.3 against 56.5: profiles/r05/gemm_bench_wide_tiles.log);
+    // in the step the gain is what a CU-time-bound step leaves of it (17.515 -> 17.443 ms, profiles/r05/step_variants_four_wave.log)
+    if (M >= 1024) return (g_gemm_heuristic >= 9 || (g_gemm_heuristic >= 8 && N <= 1024)) ? 15 : 14;
     if (b_trans) return 1;
     return N <= 1024 ? 3 : 0;
   }

@@ -17,7 +17,7 @@ SHAPES = [  # (layout, M, N, K, launches per step)
     ("nn", 32768, 960, 320, 1), ("nt", 8192, 640, 2560, 5), ("nn", 512, 1280, 10240, 1), ("nn", 32768, 1280, 320, 5),
     ("nn", 8192, 2560, 640, 5), ("nn", 2048, 5120, 1280, 5), ("nt", 512, 1280, 1280, 10), ("nt", 512, 1280, 5120, 1),
 ]
-CFGS = (14, 0, 1, 2, 3, 5, 6, 8)
+CFGS = (14, 15, 0, 1, 2, 3, 5, 6, 8)
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=30)
 args = ap.parse_args()

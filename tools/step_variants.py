@@ -25,7 +25,7 @@ img = torch.randn(BATCH, 3, 224, 224, generator=g).to(dev)
 labels = torch.randint(0, 1000, (BATCH,), generator=g).to(dev)
 
 
-def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt=-1, nn=-1, share=0.5, heuristic=8, tn=-1, split=0):
+def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt=-1, nn=-1, share=0.5, heuristic=9, tn=-1, split=0):
     def f():
         ops.FORCE_SPLIT_K = split
         ops.set_option("attn_persistent", 7)
@@ -47,10 +47,16 @@ def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt
 
 
 VARIANTS = {
-    "default (g2, s2, table 7)": setv(2),
+    "default (g2, s2, table 9)": setv(2),
+    "r4 table 8 (eight waves above N = 1024)": setv(2, heuristic=8),
     "heuristic 7 (192x128 on eight waves everywhere)": setv(2, heuristic=7),
     "nn=c15 (all dX on four waves)": setv(2, nn=15),
     "nn=c15 nt=c15": setv(2, nn=15, nt=15),
+    # round 5: isolated sweep of the final r4 kernels (profiles/r05/gemm_bench_wide_tiles.log) has the four-wave 192x128x64 form ahead on
+    # EVERY shape of the step, the wide GELU / GELU' outputs included (80.7 / 81.8 us against 99.4 / 105.4 on eight waves)
+    "r5 all four-wave: ntw=c15 nt=c15 nn=c15": setv(2, nt_wide=15, nt=15, nn=15),
+    "r5 ntw=c15 (FF1 + GELU on four waves)": setv(2, nt_wide=15),
+    "r5 ntw=c15 nn=c15 (FF1 + GELU and GELU' on four waves)": setv(2, nt_wide=15, nn=15),
     "first slice 60 of 128": setv(2, share=60 / 128),
     "first slice 56 of 128": setv(2, share=56 / 128),
     "first slice 52 of 128": setv(2, share=52 / 128),
