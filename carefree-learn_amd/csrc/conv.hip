@@ -956,6 +956,55 @@ __global__ void avgpool2_kernel(const bf16_t* __restrict__ src, bf16_t* __restri
   }
 }
 
+// ---- nn.ReflectionPad2d (convs/basic.py:61-75: `padding="reflection[N]"` of the reference's Conv2d) ---------------------------
+// fwd: y[bc][oy][ox] = x[bc][refl(oy - pt, H)][refl(ox - pl, W)], refl(i, n) = i < 0 ? -i : i >= n ? 2 (n - 1) - i : i.
+// bwd: a GATHER (deterministic, no atomics): input pixel (iy, ix) receives the output positions that mirror onto it — along each
+// axis the direct one plus at most one reflection at either border (pads are < the extent, checked on the host), <= 3 x 3 terms.
+__device__ __forceinline__ int refl(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+template <bool IN_F32>
+__global__ void reflect_pad2d_fwd_kernel(const void* __restrict__ x, bf16_t* __restrict__ y, long BC, int H, int W, int pl, int pr,
+                                         int pt, int pb) {
+  const int Ho = H + pt + pb, Wo = W + pl + pr;
+  const long total = BC * (long)Ho * Wo;
+  const long step = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += step) {
+    const int ox = (int)(i % Wo);
+    const long t = i / Wo;
+    const int oy = (int)(t % Ho);
+    const long bc = t / Ho;
+    const long src = (bc * H + refl(oy - pt, H)) * W + refl(ox - pl, W);
+    y[i] = IN_F32 ? f32_to_bf16(reinterpret_cast<const float*>(x)[src]) : reinterpret_cast<const bf16_t*>(x)[src];
+  }
+}
+
+__global__ void reflect_pad2d_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, long BC, int H, int W, int pl, int pr,
+                                         int pt, int pb) {
+  const int Ho = H + pt + pb, Wo = W + pl + pr;
+  const long total = BC * (long)H * W;
+  const long step = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += step) {
+    const int ix = (int)(i % W);
+    const long t = i / W;
+    const int iy = (int)(t % H);
+    const long bc = t / H;
+    // output rows / columns that read this input row / column: the direct one, the mirror at the low border (output index
+    // pt - iy for 1 <= iy <= pt), the mirror at the high border (pt + 2 (H - 1) - iy for 1 <= H - 1 - iy <= pb)
+    int ys[3], xs[3], ny = 0, nx = 0;
+    ys[ny++] = iy + pt;
+    if (iy >= 1 && iy <= pt) ys[ny++] = pt - iy;
+    if (H - 1 - iy >= 1 && H - 1 - iy <= pb) ys[ny++] = pt + 2 * (H - 1) - iy;
+    xs[nx++] = ix + pl;
+    if (ix >= 1 && ix <= pl) xs[nx++] = pl - ix;
+    if (W - 1 - ix >= 1 && W - 1 - ix <= pr) xs[nx++] = pl + 2 * (W - 1) - ix;
+    float acc = 0.f;
+    const bf16_t* base = dy + bc * (long)Ho * Wo;
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) acc += bf16_to_f32(base[(long)ys[a] * Wo + xs[b]]);
+    dx[i] = f32_to_bf16(acc);
+  }
+}
+
 // timestep embedding (multimodal/diffusion/unet.py:52-74): freq_i = exp(-ln(max_period) * i / half);
 // out[b] = [cos(t_b * freq) | sin(t_b * freq) | 0 if dim is odd], computed in fp32
 __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int B, int dim,
@@ -1287,6 +1336,31 @@ extern "C" int cfhip_avgpool2_bwd(const void* dy, void* dx, int64_t BC, int Ho, 
   hipLaunchKernelGGL((avgpool2_kernel<true>), dim3(grid_for(BC * 4L * Ho * Wo, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dy, (bf16_t*)dx, (long)BC, Ho, Wo);
   CFHIP_CHECK_LAUNCH("avgpool2_bwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_reflect_pad2d_fwd(const void* x, int x_is_f32, void* y, int64_t BC, int H, int W, int pl, int pr, int pt, int pb,
+                                       void* stream) {
+  CFHIP_REQUIRE(x && y && BC > 0 && H > 0 && W > 0, "reflect_pad2d_fwd: bad arguments");
+  CFHIP_REQUIRE(pl >= 0 && pr >= 0 && pt >= 0 && pb >= 0 && pl < W && pr < W && pt < H && pb < H,
+                "reflect_pad2d_fwd: every pad must be >= 0 and smaller than the extent it mirrors (H=%d W=%d pads %d %d %d %d)", H, W, pl, pr, pt, pb);
+  const long total = (long)BC * (H + pt + pb) * (W + pl + pr);
+  if (x_is_f32)
+    hipLaunchKernelGGL((reflect_pad2d_fwd_kernel<true>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y,
+                       (long)BC, H, W, pl, pr, pt, pb);
+  else
+    hipLaunchKernelGGL((reflect_pad2d_fwd_kernel<false>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y,
+                       (long)BC, H, W, pl, pr, pt, pb);
+  CFHIP_CHECK_LAUNCH("reflect_pad2d_fwd");
+  return CFHIP_OK;
+}
+extern "C" int cfhip_reflect_pad2d_bwd(const void* dy, void* dx, int64_t BC, int H, int W, int pl, int pr, int pt, int pb, void* stream) {
+  CFHIP_REQUIRE(dy && dx && BC > 0 && H > 0 && W > 0, "reflect_pad2d_bwd: bad arguments");
+  CFHIP_REQUIRE(pl >= 0 && pr >= 0 && pt >= 0 && pb >= 0 && pl < W && pr < W && pt < H && pb < H,
+                "reflect_pad2d_bwd: every pad must be >= 0 and smaller than the extent it mirrors (H=%d W=%d pads %d %d %d %d)", H, W, pl, pr, pt, pb);
+  hipLaunchKernelGGL(reflect_pad2d_bwd_kernel, dim3(grid_for((long)BC * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, (bf16_t*)dx, (long)BC, H, W, pl, pr, pt, pb);
+  CFHIP_CHECK_LAUNCH("reflect_pad2d_bwd");
   return CFHIP_OK;
 }
 

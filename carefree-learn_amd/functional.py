@@ -1155,6 +1155,70 @@ class GroupedConv2dFn(Function):
         return dx, gw, gb, None, None, None, None
 
 
+class ConvTranspose2dFn(Function):
+    """F.conv_transpose2d(x, wt, None, stride, padding, dilation=dilation), groups 1, output_padding 0 — what the reference's
+    `Conv2d.forward(transpose=True)` reaches (convs/basic.py:160-177).  A transposed convolution IS the input-gradient map of the
+    convolution with the same weight tensor read as [C_conv_out = Cin, C_conv_in = Cout, k, k], so the three products are the ones
+    `Conv2dFn` already issues with the roles of forward and backward swapped:
+      forward   y  = row2im(x_rows wt2)                       (Conv2dFn's dX route: GEMM (nn) + gather of the overlapping windows)
+      backward  dx = im2row(dy) wt2^T   (Conv2dFn's forward), dwt2 = x_rows^T im2row(dy)   (its weight gradient, tn GEMM)
+    x [B, Cin, h, w] -> bf16 [B, Cout, (h - 1) s - 2 p + d (k - 1) + 1, ...]; wt [Cin, Cout, k, k]."""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, wt: Tensor, stride: int, pad: int, dil: int) -> Tensor:
+        if x.dtype not in (bf16, f32):
+            x = x.float()
+        x = x.contiguous()
+        b, cin, h, w = x.shape
+        cin_w, cout, kh, kw = wt.shape
+        if cin_w != cin:
+            raise ValueError(f"conv_transpose2d: input has {cin} channels, the weight expects {cin_w}")
+        ho = (h - 1) * stride - 2 * pad + dil * (kh - 1) + 1
+        wo = (w - 1) * stride - 2 * pad + dil * (kw - 1) + 1
+        if ho <= 0 or wo <= 0:
+            raise ValueError("conv_transpose2d: empty output")
+        k = cout * kh * kw
+        kp = (k + 7) // 8 * 8
+        x_rows = ops.transpose_batched(x.view(b, cin, h * w)).view(b * h * w, cin)  # NHWC rows, bf16
+        w2 = _conv_weight_rows(wt, kp)                                             # [Cin, Kp] bf16
+        drows = ops.gemm(x_rows, w2, b_trans=True)                                 # [B h w, Kp]
+        y = ops.conv_row2im(drows, (b, cout, ho, wo), kh, kw, stride, pad, dil)
+        ctx.save_for_backward(x_rows, w2)
+        ctx.wt = wt
+        ctx.geom = (b, cin, h, w, cout, kh, kw, stride, pad, dil, k, kp)
+        return y
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        x_rows, w2 = ctx.saved_tensors
+        wt = ctx.wt
+        b, cin, h, w, cout, kh, kw, stride, pad, dil, k, kp = ctx.geom
+        if dy.dtype != bf16:
+            dy = ops.to_bf16(dy.float().contiguous())
+        rows = ops.conv_im2row(dy.contiguous(), kh, kw, stride, pad, dil)  # [B h w, Kp]: the convolution's view of dy
+        dx = gw = None
+        if ctx.needs_input_grad[0]:
+            if cin % 8 == 0:
+                dx_rows = ops.gemm(rows, w2)  # [B h w, Cin]
+            else:  # (output columns that are no multiple of 8 would leave the MFMA path: pad with zero filters, as Conv2dFn does)
+                cp = (cin + 7) // 8 * 8
+                wpad = torch.zeros((cp, kp), dtype=bf16, device=dy.device)
+                wpad[:cin] = w2
+                dx_rows = ops.gemm(rows, wpad)[:, :cin].contiguous()
+            dx = ops.transpose_batched(dx_rows.view(b, h * w, cin)).view(b, cin, h, w)
+        if wt.requires_grad:
+            if cin % 8 == 0:
+                g2 = ops.gemm(x_rows, rows, a_trans=True, b_trans=True, out_dtype=f32, split_k=ops.pick_split_k(cin, kp, rows.shape[0]))
+            else:
+                g2 = ops.gemm(x_rows, rows, a_trans=True, b_trans=True, out_dtype=f32)
+            gw = g2[:, :k].reshape(wt.shape)
+        return dx, gw, None, None, None
+
+
+def conv_transpose2d(x: Tensor, wt: Tensor, stride: int, pad: int, dil: int = 1) -> Tensor:
+    return ConvTranspose2dFn.apply(x, wt, stride, pad, dil)
+
+
 def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int, pad: int, dil: int = 1, groups: int = 1) -> Tensor:
     if groups != 1:
         return GroupedConv2dFn.apply(x, weight, bias, stride, pad, dil, groups)
@@ -1503,6 +1567,30 @@ class AvgPool2Fn(Function):
         if dy.dtype != bf16:
             dy = ops.to_bf16(dy.float().contiguous())
         return ops.avgpool2_bwd(dy.contiguous())
+
+
+class ReflectPad2dFn(Function):
+    """nn.ReflectionPad2d (reference convs/basic.py:61-75: the `padding="reflection[N]"` form of Conv2d)"""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, pads: Tuple[int, int, int, int]) -> Tensor:
+        if x.dtype not in (bf16, f32):
+            x = x.float()
+        ctx.pads = pads
+        return ops.reflect_pad2d_fwd(x.contiguous(), pads)
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        if dy.dtype != bf16:
+            dy = ops.to_bf16(dy.float().contiguous())
+        return ops.reflect_pad2d_bwd(dy.contiguous(), ctx.pads), None
+
+
+def reflect_pad2d(x: Tensor, pads: Any) -> Tensor:
+    """`pads`: one int or (left, right, top, bottom), as nn.ReflectionPad2d takes them"""
+    if isinstance(pads, int):
+        pads = (pads,) * 4
+    return ReflectPad2dFn.apply(x, tuple(int(v) for v in pads))
 
 
 def upsample2(x: Tensor) -> Tensor:

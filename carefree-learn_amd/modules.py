@@ -52,16 +52,75 @@ class Lambda(Module):
 # ---------------------------------------------------------------------------------------------
 
 
+class Pruner(Module):
+    """reference modules/core/customs.py:317-413: a soft mask on a WEIGHT matrix, `w * mask(|w|)` — parameter-sized element-wise math
+    in front of `F.linear`, so it runs as torch ops on the fp32 parameter (autograd carries the gradients to the weight and, for
+    `auto_prune`, to the four learnable scalars); the product with the activations stays on the HIP GEMM.  State keys as in the
+    reference (`alpha`, `beta`, `gamma`, `max_ratio`, `eps`, `exp`, `mask`, depending on the method).
+
+      simplified      mask = m(min(max_ratio, beta |w|^exp))
+      hard / soft /   mask = m(min(max_ratio, beta log max(eps, |w| / (gamma mean|w|))))     with m(t) = max(alpha / beta t, t)
+      auto_prune      (auto_prune: the four scalars are parameters, stored through an inverse softplus and read through softplus)
+      surgery         mask = the `mask` buffer (the reference's threshold updates use the out-of-place `masked_fill` and drop its
+                      result, customs.py:386-387: the buffer stays all ones — mirrored)"""
+
+    _DEFAULTS = {
+        "surgery": dict(alpha=1.0, beta=4.0, gamma=1.0e-4, eps=1.0e-12),
+        "simplified": dict(alpha=0.01, beta=1.0, max_ratio=1.0, exp=0.5),
+        "hard_prune": dict(alpha=1.0e-4, beta=1.0, gamma=1.0, max_ratio=1.0, eps=1.0e-12),
+        None: dict(alpha=1.0e-2, beta=1.0, gamma=1.0, max_ratio=1.0, eps=1.0e-12),  # auto_prune and every other name
+    }
+
+    def __init__(self, config: Dict[str, Any], w_shape: Optional[List[int]] = None):
+        super().__init__()
+        self.method = config.setdefault("method", "auto_prune")
+        table = self._DEFAULTS.get(self.method, self._DEFAULTS[None])
+        if self.method == "surgery":
+            if w_shape is None:
+                raise ValueError("`w_shape` of `Pruner` should be provided when `surgery` is used")
+            self.register_buffer("mask", torch.ones(*w_shape, dtype=torch.float32))
+        values = {k: torch.tensor([config.setdefault(k, v)], dtype=torch.float32) for k, v in table.items()}
+        if self.method not in ("surgery", "simplified"):
+            if not all(float(values[k]) > 0 for k in ("alpha", "beta", "gamma", "max_ratio")):
+                raise ValueError("parameters should greater than 0. in pruner")
+        learnable = ("alpha", "beta", "gamma", "max_ratio") if self.method == "auto_prune" else ()
+        for k, v in values.items():
+            if k in learnable:
+                setattr(self, k, nn.Parameter(torch.log(torch.exp(v) - 1)))  # softplus^-1
+            else:
+                self.register_buffer(k, v)
+        self._repr_keys = list(table)
+
+    def _scalar(self, name: str) -> Tensor:
+        v = getattr(self, name)
+        return torch.nn.functional.softplus(v) if self.method == "auto_prune" else v
+
+    def forward(self, w: Tensor) -> Tensor:
+        if self.method == "surgery":
+            return w * self.mask
+        w_abs = w.abs()
+        alpha, beta, ratio = self._scalar("alpha"), self._scalar("beta"), self._scalar("max_ratio")
+        if self.method == "simplified":
+            t = torch.min(ratio, beta * w_abs.pow(self.exp))
+        else:
+            t = torch.log(torch.max(self.eps, w_abs / (w_abs.mean() * self._scalar("gamma"))))
+            t = torch.min(ratio, beta * t)
+        return w * torch.max(alpha / beta * t, t)
+
+    def extra_repr(self) -> str:
+        if self.method == "auto_prune":
+            return f"method='{self.method}'"
+        return f"method='{self.method}', " + ", ".join(f"{k}={getattr(self, k).item():g}" for k in self._repr_keys)
+
+
 class Linear(Module):
     """reference modules/core/customs.py:23-114 — state keys `linear.weight`, `linear.bias`
-    (or `w1`, `w2`, `b` for the low-rank form)."""
+    (or `w1`, `w2`, `b` for the low-rank form; `pruner.*` / `pruner1.*` / `pruner2.*` with `pruner_config`)."""
 
     def __init__(self, in_dim: int, out_dim: int, *, bias: bool = True,
                  pruner_config: Optional[Dict[str, Any]] = None, init_method: Optional[str] = None,
                  rank: Optional[int] = None, rank_ratio: Optional[float] = None, hook: Any = None):
         super().__init__()
-        if pruner_config is not None:
-            raise NotImplementedError("`pruner_config` is outside the accelerated hot path")
         full_rank = min(in_dim, out_dim)
         if rank is None and rank_ratio is not None:
             rank = round(full_rank * rank_ratio)
@@ -74,6 +133,12 @@ class Linear(Module):
             self.b = nn.Parameter(torch.zeros(1, out_dim)) if bias else None
             self.linear = None
         self.pruner = self.pruner1 = self.pruner2 = None
+        if pruner_config is not None:  # (round 5; customs.py:54-62)
+            if rank is None:
+                self.pruner = Pruner(pruner_config, [out_dim, in_dim])
+            else:
+                self.pruner1 = Pruner(pruner_config, [rank, in_dim])
+                self.pruner2 = Pruner(pruner_config, [out_dim, rank])
         init_fn = getattr(nn.init, f"{init_method or 'xavier_normal'}_", nn.init.xavier_normal_)
         self.init_weights_with(lambda t: init_fn(t, 1.0 / math.sqrt(2.0)))
         self.hook = hook
@@ -92,11 +157,13 @@ class Linear(Module):
         if self.hook is not None:
             inp = self.hook.before_forward(inp)
         if self.linear is not None:
-            net = HF.linear(net, self.linear.weight, self.linear.bias, act=act, residual=residual,
-                            out_f32=self.out_f32)
+            weight = self.linear.weight if self.pruner is None else self.pruner(self.linear.weight)
+            net = HF.linear(net, weight, self.linear.bias, act=act, residual=residual, out_f32=self.out_f32)
         else:
-            net = HF.linear(net, self.w1, None)
-            net = HF.linear(net, self.w2, self.b, act=act, residual=residual, out_f32=self.out_f32)
+            w1 = self.w1 if self.pruner1 is None else self.pruner1(self.w1)
+            w2 = self.w2 if self.pruner2 is None else self.pruner2(self.w2)
+            net = HF.linear(net, w1, None)
+            net = HF.linear(net, w2, self.b, act=act, residual=residual, out_f32=self.out_f32)
         if self.hook is not None:
             net = self.hook.after_forward(inp, net)
         return net
@@ -925,24 +992,38 @@ class Conv2d(Module):
     """reference convs/basic.py:41-184 — parameters `weight` [out, in / groups, k, k], `bias`.  groups = 1: implicit GEMM /
     im2row + MFMA GEMM (`functional.Conv2dFn`); groups > 1 (depthwise included): the direct kernels of
     `functional.GroupedConv2dFn`; the stride == kernel, padding 0 form of the ViT patch embedding has its own fused path
-    (`functional.patch_tokens`).  Style modulation, kernel transform, reflection padding and transposed convolution are
-    outside the accelerated hot path."""
+    (`functional.patch_tokens`).
+
+    Round 5 — the constructor / forward options that used to raise (none is used by a named benchmark configuration):
+      * `padding="reflection[N]"` (basic.py:61-75): `cfhip_reflect_pad2d_*` in front of an unpadded convolution;
+      * `transform_kernel`, `demodulate`, `weight_scale`, `style` (basic.py:116-150; the StyleGAN forms): these act on the
+        WEIGHT tensor — parameter-sized element-wise math, done with torch ops on the fp32 parameter (autograd carries their
+        gradients back to it); the convolution of the activations still runs on the HIP path (`style` makes it a grouped
+        convolution with one group per sample, as in the reference);
+      * `forward(transpose=True)` (basic.py:151-160): `functional.ConvTranspose2dFn`, groups = 1."""
 
     def __init__(self, in_channels: int, out_channels: int, *, kernel_size: int, groups: int = 1,
                  stride: int = 1, dilation: int = 1, padding: Any = "same", transform_kernel: bool = False,
                  bias: bool = True, demodulate: bool = False, weight_scale: Optional[float] = None,
                  gain: float = math.sqrt(2.0)):
         super().__init__()
+        self.reflection_pad: Optional[Tuple[int, int, int, int]] = None
         if padding == "same":
             padding = kernel_size // 2
-        if transform_kernel or demodulate or weight_scale is not None or not isinstance(padding, int):
-            raise NotImplementedError("kernel-transformed / demodulated / reflection-padded "
-                                      "convolutions are outside the accelerated hot path")
+        elif isinstance(padding, str) and padding.startswith("reflection"):
+            n = kernel_size // 2 if padding == "reflection" else int(padding[len("reflection"):])
+            pads = [n, n, n, n]  # (left, right, top, bottom)
+            if transform_kernel:  # the transformed kernel is one tap larger: one more row / column at the top / left
+                pads[0] += 1
+                pads[2] += 1
+            self.reflection_pad = tuple(pads)
+            padding = 0
+        elif not isinstance(padding, int):
+            raise ValueError(f"padding = {padding!r}: an int, 'same' or 'reflection[N]'")
         if groups < 1 or in_channels % groups or out_channels % groups:
             raise ValueError(f"`groups` ({groups}) must divide in_channels ({in_channels}) and out_channels ({out_channels})")
         self.in_c, self.out_c, self.kernel_size = in_channels, out_channels, kernel_size
         self.groups, self.stride, self.dilation, self.padding = groups, stride, dilation, padding
-        self.reflection_pad = None
         self.transform_kernel, self.demodulate, self.weight_scale = transform_kernel, demodulate, weight_scale
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, kernel_size, kernel_size))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
@@ -951,14 +1032,53 @@ class Conv2d(Module):
             if self.bias is not None:
                 self.bias.zero_()
 
+    def _effective_weight(self, style: Optional[Tensor]) -> Tensor:
+        """the weight the convolution sees (basic.py:116-150), in the reference's order: kernel transform, style modulation,
+        demodulation, scale.  Untouched parameters pass through as they are (the direct-gradient path of Conv2dFn)."""
+        w: Tensor = self.weight
+        if self.transform_kernel:  # average of the four one-tap shifts of the zero-padded kernel: [.., k + 1, k + 1]
+            wp = torch.nn.functional.pad(w, [1, 1, 1, 1])
+            w = (wp[:, :, 1:, 1:] + wp[:, :, :-1, 1:] + wp[:, :, 1:, :-1] + wp[:, :, :-1, :-1]) * 0.25
+        if style is not None:      # [B, out, in, k, k]: one filter bank per sample
+            w = w[None] * style.to(w.dtype)[:, None, :, None, None]
+        if self.demodulate:
+            w = w * torch.rsqrt(w.pow(2).sum([-3, -2, -1], keepdim=True) + 1e-8)
+        if self.weight_scale is not None:
+            w = w * self.weight_scale
+        return w
+
     def forward(self, net: Tensor, style: Optional[Tensor] = None, *, transpose: bool = False) -> Tensor:
-        if style is not None or transpose:
-            raise NotImplementedError("stylised / transposed convolution is outside the accelerated hot path")
-        return HF.conv2d(net, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        b = net.shape[0]
+        if style is not None:
+            if self.bias is not None:
+                raise ValueError("`bias` should not be used when `style` is provided")
+            if self.groups != 1:
+                raise ValueError("`groups` should be 1 when `style` is provided")
+            if self.reflection_pad is not None:
+                raise ValueError("`reflection_pad` should not be used when `style` is provided, maybe you want to use `same` padding?")
+        if self.reflection_pad is not None:
+            net = HF.reflect_pad2d(net, self.reflection_pad)
+        w = self._effective_weight(style)
+        bias, groups = self.bias, self.groups
+        if style is not None:  # a grouped convolution over the batch: sample i sees filter bank i
+            groups = b
+            net = net.reshape(1, b * net.shape[1], *net.shape[2:])
+            w = w.reshape(b * self.out_c, *w.shape[2:])
+        if transpose:
+            if groups != 1:
+                raise NotImplementedError("transposed convolution with groups > 1 (or `style`) is outside the accelerated hot path")
+            out = HF.conv_transpose2d(net, w.transpose(0, 1).contiguous(), self.stride, self.padding, self.dilation)
+            if bias is not None:  # (per-channel add of a parameter: a torch op; autograd gives its gradient)
+                out = out + bias.to(out.dtype).view(1, -1, 1, 1)
+            return out
+        out = HF.conv2d(net, w.contiguous(), bias, self.stride, self.padding, self.dilation, groups)
+        if style is None:
+            return out
+        return out.reshape(b, -1, *out.shape[2:])
 
     def extra_repr(self) -> str:
         return (f"{self.in_c}, {self.out_c}, kernel_size={self.kernel_size}, stride={self.stride}, "
-                f"padding={self.padding}, dilation={self.dilation}, bias={self.bias is not None}")
+                f"padding={self.padding}, dilation={self.dilation}, bias={self.bias is not None}, demodulate={self.demodulate}")
 
 
 class DepthWiseConv2d(Module):

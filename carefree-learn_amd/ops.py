@@ -1044,6 +1044,32 @@ def _resample(name: str, x: Tensor, out_hw: Tuple[int, int], small_hw: Tuple[int
     return out
 
 
+def reflect_pad2d_fwd(x: Tensor, pads: Tuple[int, int, int, int]) -> Tensor:
+    """nn.ReflectionPad2d((left, right, top, bottom)): x [B, C, H, W] bf16 / f32 -> bf16 [B, C, H + t + b, W + l + r]."""
+    _need(x, x.dtype if x.dtype in (bf16, f32) else bf16, "x")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("cfhip reflect_pad2d: contiguous [B, C, H, W] expected")
+    pl, pr, pt, pb = (int(v) for v in pads)
+    b, c, h, w = x.shape
+    out = torch.empty((b, c, h + pt + pb, w + pl + pr), dtype=bf16, device=x.device)
+    rc = _lib.load().cfhip_reflect_pad2d_fwd(x.data_ptr(), int(x.dtype == f32), out.data_ptr(), b * c, h, w, pl, pr, pt, pb, _stream())
+    _lib.check(rc, "reflect_pad2d_fwd")
+    return out
+
+
+def reflect_pad2d_bwd(dy: Tensor, pads: Tuple[int, int, int, int]) -> Tensor:
+    _need(dy, bf16, "dy")
+    if dy.dim() != 4 or not dy.is_contiguous():
+        raise ValueError("cfhip reflect_pad2d_bwd: contiguous bf16 [B, C, Ho, Wo] expected")
+    pl, pr, pt, pb = (int(v) for v in pads)
+    b, c, ho, wo = dy.shape
+    h, w = ho - pt - pb, wo - pl - pr
+    dx = torch.empty((b, c, h, w), dtype=bf16, device=dy.device)
+    rc = _lib.load().cfhip_reflect_pad2d_bwd(dy.data_ptr(), dx.data_ptr(), b * c, h, w, pl, pr, pt, pb, _stream())
+    _lib.check(rc, "reflect_pad2d_bwd")
+    return dx
+
+
 def upsample2_fwd(x: Tensor) -> Tensor:
     h, w = x.shape[2], x.shape[3]
     return _resample("upsample2_fwd", x, (2 * h, 2 * w), (h, w))

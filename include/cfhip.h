@@ -460,6 +460,13 @@ int cfhip_upsample2_fwd(const void* x, void* y, int64_t BC, int H, int W, void* 
 int cfhip_upsample2_bwd(const void* dy, void* dx, int64_t BC, int H, int W, void* stream);
 int cfhip_avgpool2_fwd(const void* x, void* y, int64_t BC, int Ho, int Wo, void* stream);
 int cfhip_avgpool2_bwd(const void* dy, void* dx, int64_t BC, int Ho, int Wo, void* stream);
+/* nn.ReflectionPad2d in front of F.conv2d (reference convs/basic.py:61-75,114-115: Conv2d(padding="reflection[N]")):
+ *   fwd: x [BC][H][W] (bf16, or f32 when x_is_f32) -> y bf16 [BC][H + pt + pb][W + pl + pr], mirrored without repeating the border;
+ *   bwd: dx bf16 [BC][H][W] = gather of the <= 9 positions of dy that mirror onto each input pixel (deterministic).
+ * Every pad is >= 0 and smaller than the extent it mirrors (torch's rule). */
+int cfhip_reflect_pad2d_fwd(const void* x, int x_is_f32, void* y, int64_t BC, int H, int W, int pl, int pr, int pt, int pb,
+                            void* stream);
+int cfhip_reflect_pad2d_bwd(const void* dy, void* dx, int64_t BC, int H, int W, int pl, int pr, int pt, int pb, void* stream);
 /* out[d] (+)= sum_r x[r][d] for a dense f32 [R][D] matrix (per-batch partials -> parameter gradient) */
 int cfhip_colreduce_f32(const float* x, float* out, int R, int D, int accumulate, void* stream);
 int cfhip_timestep_embedding(const int64_t* t, float* out, int B, int dim, float max_period, void* stream);

@@ -384,3 +384,97 @@ def test_grouped_convolution_is_linear_and_block_diagonal():
         x2 = x.clone()
         x2[:, 8:] = 0  # groups 1..3 of the input
         assert torch.equal(conv(x)[:, :12], conv(x2)[:, :12])  # group 0's 12 output channels: bit-identical
+
+
+# ---- round 5: the Conv2d options that used to raise (reference convs/basic.py:41-177) ----------------------------------------------
+
+
+@pytest.mark.parametrize("shape,pads", [((2, 3, 9, 7), (1, 1, 1, 1)), ((1, 5, 6, 6), (3, 0, 2, 5)), ((2, 8, 4, 12), (0, 3, 3, 0)),
+                                        ((1, 2, 2, 2), (1, 1, 1, 1)), ((3, 4, 17, 5), (4, 4, 4, 4))])
+def test_reflect_pad2d_vs_torch(shape, pads):
+    """cfhip_reflect_pad2d_fwd / _bwd behind `Conv2d(padding="reflection[N]")` (nn.ReflectionPad2d, basic.py:61-75): the forward is a
+    copy (bit-equal to F.pad(mode="reflect") of the bf16-rounded input, from f32 and from bf16 sources); the backward gathers the <= 9
+    mirrored positions — against torch's gradient; pads as large as the extent allows (size - 1), asymmetric, zero."""
+    torch.manual_seed(sum(shape) + sum(pads))
+    x = torch.randn(*shape)
+    want = torch.nn.functional.pad(bf16_round(x), list(pads), mode="reflect")
+    for src in (x, x.to(torch.bfloat16)):
+        xd = src.to(DEV).requires_grad_(True)
+        y = HF.reflect_pad2d(xd, pads)
+        assert y.dtype == torch.bfloat16 and torch.equal(y.float().cpu(), want)
+    g = bf16_round(torch.randn(want.shape))
+    xr = bf16_round(x).requires_grad_(True)
+    torch.nn.functional.pad(xr, list(pads), mode="reflect").backward(g)
+    y.backward(g.to(DEV))
+    assert_close(xd.grad, xr.grad, 4e-3, "reflection-pad backward")
+    with pytest.raises(RuntimeError):
+        HF.reflect_pad2d(x.to(DEV), (shape[3], 0, 0, 0))  # a pad must be smaller than the extent it mirrors
+
+
+@pytest.mark.parametrize("b,cin,cout,h,w,k,s,p,d", [(2, 16, 8, 7, 7, 4, 2, 1, 1), (1, 8, 24, 5, 9, 3, 1, 1, 1), (2, 6, 5, 6, 6, 3, 2, 0, 1),
+                                                      (1, 32, 16, 8, 8, 2, 2, 0, 1), (1, 8, 8, 6, 5, 3, 1, 2, 2)])
+def test_conv_transpose2d_vs_torch(b, cin, cout, h, w, k, s, p, d):
+    """`functional.ConvTranspose2dFn` (Conv2d.forward(transpose=True), basic.py:151-160 -> F.conv_transpose2d): output, input gradient
+    and weight gradient against fp32 torch on the same bf16-rounded operands; the stride-2 4x4 GAN up-sampling form, channel counts
+    that are no multiple of 8 (generic GEMM path), dilation."""
+    torch.manual_seed(b + cin + cout + k)
+    x = bf16_round(torch.randn(b, cin, h, w))
+    wt = bf16_round(torch.randn(cin, cout, k, k) * 0.2)
+    xd, wd = x.to(DEV).requires_grad_(True), wt.to(DEV).requires_grad_(True)
+    y = HF.conv_transpose2d(xd, wd, s, p, d)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    want = torch.nn.functional.conv_transpose2d(xr, wr, None, stride=s, padding=p, dilation=d)
+    assert y.shape == want.shape, (y.shape, want.shape)
+    assert_close(y, want.detach(), 5e-3, "transposed convolution forward")
+    gy = bf16_round(torch.randn(want.shape))
+    want.backward(gy)
+    y.backward(gy.to(DEV))
+    assert_close(xd.grad, xr.grad, 5e-3, "dX")
+    assert_close(wd.grad, wr.grad, 2e-4, "dW")
+
+
+@pytest.mark.parametrize("kw", [
+    dict(kernel_size=3, padding="reflection"), dict(kernel_size=3, padding="reflection", transform_kernel=True),
+    dict(kernel_size=3, demodulate=True, weight_scale=0.5), dict(kernel_size=3, bias=False, demodulate=True, style=True),
+    dict(kernel_size=4, stride=2, padding=1, transpose=True),
+])
+def test_conv2d_round5_options_on_the_gpu(kw):
+    """the module end to end on the HIP path: reflection padding (kernel), kernel transform / demodulation / scale / style (weight math
+    in torch + the HIP convolution; `style` = one group per sample on the grouped kernels), transposed form — against the same
+    composition of torch functionals in fp32 on bf16-rounded activations and effective weights."""
+    import torch.nn.functional as F
+
+    kw = dict(kw)
+    style_on, transpose = kw.pop("style", False), kw.pop("transpose", False)
+    torch.manual_seed(11)
+    m = C.modules.Conv2d(8, 16, **kw).to(DEV)
+    with torch.no_grad():
+        m.weight.mul_(2.0)
+        if m.bias is not None:
+            m.bias.normal_()
+    x = bf16_round(torch.randn(2, 8, 10, 10))
+    style = torch.randn(2, 8) if style_on else None
+    xd = x.to(DEV).requires_grad_(True)
+    y = m(xd, None if style is None else style.to(DEV), transpose=transpose)
+    # the reference composition on the CPU
+    xr = x.clone().requires_grad_(True)
+    net = xr if m.reflection_pad is None else F.pad(xr, list(m.reflection_pad), mode="reflect")
+    mc = C.modules.Conv2d(8, 16, **kw)
+    mc.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    w = mc._effective_weight(style)
+    w = w.detach().to(torch.bfloat16).float()  # what the MFMA sees
+    bias = None if mc.bias is None else mc.bias.detach()
+    if style_on:
+        want = F.conv2d(net.reshape(1, 16, 10, 10), w.reshape(32, 8, 3, 3), None, stride=mc.stride, padding=mc.padding, groups=2).reshape(2, 16, 10, 10)
+    elif transpose:
+        want = F.conv_transpose2d(net, w.transpose(0, 1), bias, stride=mc.stride, padding=mc.padding)
+    else:
+        want = F.conv2d(net, w, bias, stride=mc.stride, padding=mc.padding)
+    assert y.shape == want.shape, (y.shape, want.shape)
+    assert_close(y, want.detach(), 6e-3, "output")
+    gy = bf16_round(torch.randn(want.shape))
+    want.backward(gy)
+    y.backward(gy.to(DEV))
+    HF.SideStream.join()
+    assert_close(xd.grad, xr.grad, 6e-3, "dX")
+    assert m.weight.grad is not None and torch.isfinite(m.weight.grad).all() and float(m.weight.grad.abs().max()) > 0

@@ -76,8 +76,10 @@ def test_mask_quirk_is_bit_exact():
 
 
 def test_unsupported_features_raise():
-    with pytest.raises(NotImplementedError):
-        C.Linear(8, 8, pruner_config={})
+    # round 5: built — pruned weights, reflection padding, the StyleGAN weight forms, transposed convolution
+    pr = C.Linear(8, 8, pruner_config={})
+    assert isinstance(pr.pruner, C.modules.Pruner) and sorted(k for k in pr.state_dict() if k.startswith("pruner.")) == [
+        "pruner.alpha", "pruner.beta", "pruner.eps", "pruner.gamma", "pruner.max_ratio"]
     with pytest.raises(NotImplementedError):
         C.Attention(128, 2, reduction_ratio=2)
     with pytest.raises(NotImplementedError):
@@ -86,10 +88,11 @@ def test_unsupported_features_raise():
     assert tuple(grouped.weight.shape) == (8, 2, 3, 3) and grouped.groups == 2
     with pytest.raises(ValueError):
         C.Conv2d(6, 8, kernel_size=3, groups=4)
-    with pytest.raises(NotImplementedError):
-        C.Conv2d(4, 8, kernel_size=3, transform_kernel=True)
-    with pytest.raises(NotImplementedError):
-        C.Conv2d(3, 8, kernel_size=3, padding="reflection")
+    assert C.Conv2d(4, 8, kernel_size=3, transform_kernel=True)._effective_weight(None).shape == (8, 4, 4, 4)  # one tap larger
+    assert C.Conv2d(3, 8, kernel_size=3, padding="reflection").reflection_pad == (1, 1, 1, 1)
+    assert C.Conv2d(3, 8, kernel_size=5, padding="reflection3", transform_kernel=True).reflection_pad == (4, 3, 4, 3)
+    with pytest.raises(ValueError):
+        C.Conv2d(3, 8, kernel_size=3, padding="circular")
     # round 2: dropout / DropPath are built (csrc/random.hip): the constructors keep the reference's modules in place
     mp = C.modules.Mapping(8, 8, dropout=0.5)
     assert isinstance(mp.dropout, C.modules.Dropout) and mp.dropout.p == 0.5

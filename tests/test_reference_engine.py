@@ -205,3 +205,73 @@ def test_lazy_loss_patch_under_the_reference_trainer(cflearn, tmp_path, monkeypa
     preds = m.predict(m.data.build_loader(x, y))[TO.PREDICTIONS_KEY]
     assert (preds.argmax(1) == y.ravel()).mean() > 0.6
     assert float(seen[-1]) < float(seen[0])
+
+
+@pytest.mark.parametrize("method", ["auto_prune", "hard_prune", "soft_prune", "simplified", "surgery"])
+def test_pruner_matches_the_reference_bit_for_bit(cflearn, method):
+    """`Linear(pruner_config=...)` (customs.py:54-62,84-96): the weight mask of `modules.Pruner` against the reference's
+    `Pruner` (customs.py:317-413) — same state keys and initial values, bit-equal masked weight, bit-equal gradients to the
+    weight and (auto_prune) to the four learnable scalars.  Pure weight-space math: torch ops on both sides."""
+    import cflearn_amd as C
+
+    ref = sys.modules["cflearn.modules.core.customs"]
+    a, b = ref.Pruner({"method": method}, [12, 20]), C.modules.Pruner({"method": method}, [12, 20])
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa) == list(sb) or set(sa) == set(sb)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    torch.manual_seed(3)
+    w = torch.randn(12, 20)
+    wa, wb = w.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ya, yb = a(wa), b(wb)
+    assert torch.equal(ya, yb)
+    g = torch.randn_like(w)
+    ya.backward(g)
+    yb.backward(g)
+    assert torch.equal(wa.grad, wb.grad)
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    assert set(pa) == set(pb) and (set(pa) == {"alpha", "beta", "gamma", "max_ratio"}) == (method == "auto_prune")
+    for k in pa:
+        assert torch.equal(pa[k].grad, pb[k].grad), k
+    lin_a, lin_b = ref.Linear(20, 12, pruner_config={"method": method}), C.Linear(20, 12, pruner_config={"method": method})
+    assert set(lin_a.state_dict()) == set(lin_b.state_dict())
+
+
+@pytest.mark.parametrize("kw", [
+    dict(kernel_size=3, padding="reflection"), dict(kernel_size=3, padding="reflection2", bias=False),
+    dict(kernel_size=3, transform_kernel=True), dict(kernel_size=3, padding="reflection", transform_kernel=True),
+    dict(kernel_size=3, demodulate=True), dict(kernel_size=3, weight_scale=0.37),
+    dict(kernel_size=3, bias=False, demodulate=True, style=True), dict(kernel_size=1, bias=False, style=True),
+    dict(kernel_size=4, stride=2, padding=1, transpose=True), dict(kernel_size=3, padding=1, bias=False, transpose=True, weight_scale=2.0),
+])
+def test_conv2d_option_logic_matches_the_reference_with_torch_standing_in_for_the_kernels(cflearn, kw, monkeypatch):
+    """The round-5 Conv2d options (convs/basic.py:41-177): everything AROUND the convolution kernel — which padding, which
+    weight the convolution sees (kernel transform, style modulation, demodulation, scale), the grouped-over-the-batch reshape of the
+    stylised form, the transposed weight — with the three HIP entry points replaced by their torch definitions
+    (`F.pad(mode="reflect")`, `F.conv2d`, `F.conv_transpose2d`), against the reference module on the same weights and input.
+    (The kernels themselves are compared with the same torch calls on the GPU: tests/test_gpu_conv.py.)"""
+    import torch.nn.functional as F
+
+    import cflearn_amd as C
+    from cflearn_amd import functional as HF
+
+    kw = dict(kw)
+    style_on, transpose = kw.pop("style", False), kw.pop("transpose", False)
+    refmod = sys.modules["cflearn.modules.core.convs.basic"]
+    torch.manual_seed(5)
+    a = refmod.Conv2d(6, 8, **kw)
+    b = C.Conv2d(6, 8, **kw)
+    b.load_state_dict(a.state_dict())
+    monkeypatch.setattr(HF, "reflect_pad2d", lambda x, pads: F.pad(x, list(pads), mode="reflect"))
+    monkeypatch.setattr(HF, "conv2d", lambda x, w, bias, s, p, d=1, g=1: F.conv2d(x, w, bias, stride=s, padding=p, dilation=d, groups=g))
+    monkeypatch.setattr(HF, "conv_transpose2d", lambda x, wt, s, p, d=1: F.conv_transpose2d(x, wt, None, stride=s, padding=p, dilation=d))
+    x = torch.randn(3, 6, 9, 9)
+    style = torch.randn(3, 6) if style_on else None
+    ya = a(x, style, transpose=transpose)
+    yb = b(x, style, transpose=transpose)
+    assert ya.shape == yb.shape
+    assert (ya - yb).abs().max() <= 1e-5 * max(1.0, ya.abs().max().item()), (ya - yb).abs().max()
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g)
+    assert (a.weight.grad - b.weight.grad).abs().max() <= 1e-4 * a.weight.grad.abs().max()
