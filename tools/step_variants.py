@@ -40,6 +40,7 @@ def setv(blocks=2, on_main=False, variant=0, halves=2, bhalves=2, nt_wide=-1, nt
         fused.FWD_HALVES = halves
         fused.BWD_HALVES = bhalves
         ops.set_option("grouped_variant", variant)
+        ops.set_option("gemm_group_n", 8)
         ops.set_option("gemm_cfg_nt_wide", nt_wide)
         ops.set_option("gemm_cfg_nt", nt)
         ops.set_option("gemm_cfg_nn", nn)
@@ -71,6 +72,11 @@ VARIANTS = {
     "nn=c0 ntw=c0 nt=c0": setv(2, nn=0, nt_wide=0, nt=0),
     "one-pass fwd, nn=c13 ntw=c13 nt=c13": setv(2, halves=1, nn=13, nt_wide=13, nt=13),
     "one-pass both, all c13": setv(2, halves=1, bhalves=1, nn=13, nt_wide=13, nt=13),
+    "r5 tile walk: groups of 4 tile columns": (lambda: (setv(2)(), ops.set_option("gemm_group_n", 4))),
+    "r5 tile walk: groups of 12 tile columns": (lambda: (setv(2)(), ops.set_option("gemm_group_n", 12))),
+    "r5 tile walk: row-major (no groups)": (lambda: (setv(2)(), ops.set_option("gemm_group_n", 0))),
+    "r5 grouped dW: 1 block per launch": setv(1),
+    "r5 grouped dW: 3 blocks per launch": setv(3),
     # round 4: weight gradients per operator on the side lane, every tile its whole reduction (no slabs, no reduce), on the
     # 80 KB plain kernel — leaves LDS room for a forward / dX workgroup on the same CU, unlike the 160 KB grouped kernel
     "attention dK/dV: one workgroup per head (not the persistent 16-wave kernel)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 0))),
