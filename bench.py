@@ -994,8 +994,8 @@ def main() -> None:
             "traffic": traffic,
             "traffic_unit": "HBM-side bytes per step over all GEMM launches (PMC FETCH_SIZE x2 + WRITE_SIZE)",
             "traffic_source": traffic_src, "traffic_stale": stale, "algorithmic_bytes": round(algo_bytes),
-            "kernel": "gemm_bf16_kernel<AT,BT,EPI,Cfg<192,128,2,4,2,64>> (forward, dX) + gemm_grouped_tn_kernel<Cfg<256,256,2,4,5,32>,3,BG> "
-                      "(weight gradients): all GEMM launches of one step",
+            "kernel": "gemm_bf16_kernel<AT,BT,EPI,Cfg<192,128,2,2,2,64>> (forward, dX: four waves of 96x64, gemm_heuristic 9) + "
+                      "gemm_grouped_tn_kernel<Cfg<256,256,2,4,5,32>,3,BG> (weight gradients): all GEMM launches of one step",
             "dominant_kernel": _dominant(in_step_rows),
             "gemm_ms_per_step": round(gemm_sec * 1e3, 3), "gemm_flops_per_step": flops_step,
             "shapes": in_step_rows, "shapes_isolated": iso_rows,
