@@ -719,6 +719,13 @@ def main() -> None:
         if args.sweep and args.nchannels == 0:
             raise SystemExit(sweep_launch(args.gpus, sys.argv[1:]))
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    # The result line must be the ONLY thing on stdout (the driver reads it from there): RCCL prints a version banner to the C-level
+    # stdout of every rank when its first communicator is created (seen in the 1-rank RCCL runs: it lands AFTER the JSON line because C
+    # stdio flushes at exit).  So file descriptor 1 is pointed at stderr for the whole run — Python's and every library's stdout text
+    # goes there — and rank 0 writes the JSON line to the saved descriptor at the very end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if "--all-on-gpu0" in sys.argv else int(os.environ.get("LOCAL_RANK", "0"))
@@ -1052,11 +1059,13 @@ def main() -> None:
         result.setdefault("warnings", []).append(
             "a helper stream (batch slice / weight-gradient lane / comm) shares a hardware queue with a stream it should overlap "
             "with on at least one rank: this step ran partly serialised (GPU_MAX_HW_QUEUES, --nchannels)")
-    if rank == 0:
-        print(json.dumps(result))
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:  # after everything that could still print: the one line on the real stdout
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
+    os.close(result_fd)
     if aliased:
         print("[bench] WARNING: a helper stream had to share a hardware queue (see `streams` / `warnings` in the line): the step ran "
               "partly serialised", file=sys.stderr)
