@@ -142,6 +142,11 @@ SIGNATURES = {
     "cfhip_silu_f32_bwd": (c_int, [_P, _P, _P, c_int64, _P]),
     "cfhip_upsample2_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
     "cfhip_upsample2_bwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    "cfhip_groupnorm_nhwc_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "cfhip_groupnorm_nhwc_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, _P, _P]),
+    "cfhip_groupnorm_nhwc_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "cfhip_upsample2_nhwc_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, _P]),
+    "cfhip_upsample2_nhwc_bwd": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, _P]),
     "cfhip_reflect_pad2d_fwd": (c_int, [_P, c_int, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cfhip_reflect_pad2d_bwd": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cfhip_avgpool2_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),

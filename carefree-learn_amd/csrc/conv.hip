@@ -866,6 +866,366 @@ __global__ __launch_bounds__(128) void gn_split_dadd_kernel(const float* __restr
   }
 }
 
+// ---- GroupNorm on NHWC rows (round 5) ------------------------------------------------------------------------------------------
+// x, y, dy, dx: bf16 [B][inner = H * W][C] — the layout the implicit-GEMM convolutions read and write, so a residual block that keeps
+// its activations in it needs no NCHW <-> NHWC hop around every convolution (318 transposes per 64^2 x 8 UNet step).  Same
+// arithmetic as the split NCHW kernels above (two-pass statistics per slice in fp32, Chan's merge in slice order, the additive
+// per-(b, c) term in front, SiLU behind, per-sample partial sums of dgamma / dbeta, deterministic: no atomics), other indexing:
+// a workgroup owns a slice of ROWS of one sample and all C channels; a thread owns KC slots of 8 consecutive channels (one
+// 16-byte access per row and slot: rows are read and written as whole contiguous lines) and walks the rows rl, rl + RPP, ...;
+// per-channel partial sums of the RPP row lanes meet in LDS in a fixed order, 32 threads fold channels into groups.
+struct GnNhwcMap {
+  int cg8, rpp, rl, nslot;  // 8-channel slots per row, row lanes, this thread's row lane, its number of slots (0: idle)
+  int slot[2];              // its slots (channel = slot * 8)
+};
+__device__ __forceinline__ GnNhwcMap gn_nhwc_map(int C) {
+  GnNhwcMap m;
+  m.cg8 = C >> 3;
+  const int t = threadIdx.x;
+  if (m.cg8 >= 256) {
+    m.rpp = 1; m.rl = 0;
+    m.slot[0] = t; m.slot[1] = t + 256;
+    m.nslot = (t < m.cg8 ? 1 : 0) + (t + 256 < m.cg8 ? 1 : 0);
+  } else {
+    m.rpp = 256 / m.cg8;
+    m.rl = t / m.cg8;
+    m.slot[0] = t - m.rl * m.cg8; m.slot[1] = 0;
+    m.nslot = m.rl < m.rpp ? 1 : 0;
+  }
+  return m;
+}
+// rows [r0, r1) of slice sl of S over `inner` rows
+__device__ __forceinline__ void gn_nhwc_rows(int inner, int S, int sl, int& r0, int& r1) {
+  r0 = (int)((long)sl * inner / S);
+  r1 = (int)((long)(sl + 1) * inner / S);
+}
+// per-channel values of all row lanes (acc[k][e] of every thread) -> chan[c] in LDS, summed over the row lanes in lane order
+template <int KC>
+__device__ __forceinline__ void gn_nhwc_fold(const GnNhwcMap& m, const float (&acc)[KC][8], float* lanes, float* chan, int C) {
+  __syncthreads();  // (the buffers may still be read from a previous use)
+#pragma unroll
+  for (int k = 0; k < KC; ++k)
+    if (k < m.nslot) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) lanes[m.rl * C + m.slot[k] * 8 + e] = acc[k][e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int l = 0; l < m.rpp; ++l) s += lanes[l * C + c];
+    chan[c] = s;
+  }
+  __syncthreads();
+}
+
+// LDS: lanes [rpp][C] + chan [C] + grp [2 G] floats (rpp * C <= 2048 + C: at most 4 C floats)
+template <int KC>
+__global__ __launch_bounds__(256) void gn_nhwc_stats_kernel(const bf16_t* __restrict__ x, const float* __restrict__ add,
+                                                            float* __restrict__ part, int C, int G, int inner, int S) {
+  extern __shared__ float gsm[];
+  const int b = blockIdx.x / S, sl = blockIdx.x - b * S;
+  const GnNhwcMap m = gn_nhwc_map(C);
+  float* lanes = gsm;
+  float* chan = gsm + m.rpp * C;
+  float* grp = chan + C;
+  const int cpg = C / G;
+  int r0, r1;
+  gn_nhwc_rows(inner, S, sl, r0, r1);
+  const bf16_t* xb = x + (long)b * inner * C;
+  float ad[KC][8], acc[KC][8];
+#pragma unroll
+  for (int k = 0; k < KC; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ad[k][e] = (add != nullptr && k < m.nslot) ? add[(long)b * C + m.slot[k] * 8 + e] : 0.f;
+      acc[k][e] = 0.f;
+    }
+  for (int r = r0 + m.rl; r < r1; r += m.rpp) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+      if (k < m.nslot) {
+        float v[8];
+        gn_load8<false>(xb, (long)r * C + m.slot[k] * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[k][e] += v[e] + ad[k][e];
+      }
+  }
+  gn_nhwc_fold<KC>(m, acc, lanes, chan, C);
+  const float cnt = (float)cpg * (float)(r1 - r0);
+  if ((int)threadIdx.x < G) {
+    float s = 0.f;
+    for (int c = threadIdx.x * cpg; c < (int)(threadIdx.x + 1) * cpg; ++c) s += chan[c];
+    grp[threadIdx.x] = cnt > 0.f ? s / cnt : 0.f;
+  }
+  __syncthreads();
+  float mu[KC][8];
+#pragma unroll
+  for (int k = 0; k < KC; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      mu[k][e] = k < m.nslot ? ad[k][e] - grp[(m.slot[k] * 8 + e) / cpg] : 0.f;  // v + add - mean
+      acc[k][e] = 0.f;
+    }
+  for (int r = r0 + m.rl; r < r1; r += m.rpp) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+      if (k < m.nslot) {
+        float v[8];
+        gn_load8<false>(xb, (long)r * C + m.slot[k] * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[e] + mu[k][e];
+          acc[k][e] += d * d;
+        }
+      }
+  }
+  gn_nhwc_fold<KC>(m, acc, lanes, chan, C);
+  if ((int)threadIdx.x < G) {
+    float q = 0.f;
+    for (int c = threadIdx.x * cpg; c < (int)(threadIdx.x + 1) * cpg; ++c) q += chan[c];
+    float* o = part + (((long)b * S + sl) * G + threadIdx.x) * 2;
+    o[0] = grp[threadIdx.x];
+    o[1] = q;
+  }
+}
+
+// (mean, rstd) of every group of sample b from the S slice pairs, by threads 0 .. G - 1, into grp[0 .. G) / grp[G .. 2 G)
+__device__ __forceinline__ void gn_nhwc_merge(const float* __restrict__ part, int b, int S, int G, int cpg, int inner, float eps,
+                                              float* grp) {
+  if ((int)threadIdx.x < G) {
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int sl = 0; sl < S; ++sl) {
+      int r0, r1;
+      gn_nhwc_rows(inner, S, sl, r0, r1);
+      const float nb = (float)cpg * (float)(r1 - r0);
+      if (nb <= 0.f) continue;
+      const float* o = part + (((long)b * S + sl) * G + threadIdx.x) * 2;
+      const float nt = n + nb, d = o[0] - mean;
+      mean += d * (nb / nt);
+      m2 += o[1] + d * d * (n * nb / nt);
+      n = nt;
+    }
+    grp[threadIdx.x] = mean;
+    grp[G + threadIdx.x] = rsqrtf(m2 / n + eps);
+  }
+  __syncthreads();
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ add,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ part, bf16_t* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int C, int G,
+                                                            int inner, float eps, int silu, int affine_bs, int S) {
+  __shared__ float grp[2 * 64];
+  const int b = blockIdx.x / S, sl = blockIdx.x - b * S;
+  const GnNhwcMap m = gn_nhwc_map(C);
+  const int cpg = C / G;
+  gamma += (long)b * affine_bs;
+  beta += (long)b * affine_bs;
+  gn_nhwc_merge(part, b, S, G, cpg, inner, eps, grp);
+  if (sl == 0 && (int)threadIdx.x < G) {
+    mean_out[b * G + threadIdx.x] = grp[threadIdx.x];
+    rstd_out[b * G + threadIdx.x] = grp[G + threadIdx.x];
+  }
+  float a[KC][8], bb[KC][8];
+#pragma unroll
+  for (int k = 0; k < KC; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a[k][e] = bb[k][e] = 0.f;
+      if (k < m.nslot) {
+        const int c = m.slot[k] * 8 + e, g = c / cpg;
+        const float ad = add != nullptr ? add[(long)b * C + c] : 0.f;
+        a[k][e] = grp[G + g] * gamma[c];
+        bb[k][e] = beta[c] + (ad - grp[g]) * a[k][e];
+      }
+    }
+  int r0, r1;
+  gn_nhwc_rows(inner, S, sl, r0, r1);
+  const bf16_t* xb = x + (long)b * inner * C;
+  bf16_t* yb = y + (long)b * inner * C;
+  for (int r = r0 + m.rl; r < r1; r += m.rpp) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+      if (k < m.nslot) {
+        float v[8];
+        const long off = (long)r * C + m.slot[k] * 8;
+        gn_load8<false>(xb, off, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float o = fmaf(v[e], a[k][e], bb[k][e]);
+          v[e] = silu ? silu_f(o) : o;
+        }
+        gn_store8(yb, off, v);
+      }
+  }
+}
+
+// backward, statistics: per slice and channel  A_c = sum dn * xhat,  B_c = sum dn  (dn = dy [* SiLU'(xhat gamma + beta)])
+// part: [B][S][2][C]
+template <int KC>
+__global__ __launch_bounds__(256) void gn_nhwc_bwd_stats_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                const float* __restrict__ add, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, float* __restrict__ part, int C, int G,
+                                                                int inner, int silu, int affine_bs, int S) {
+  extern __shared__ float gsm[];
+  const int b = blockIdx.x / S, sl = blockIdx.x - b * S;
+  const GnNhwcMap m = gn_nhwc_map(C);
+  float* lanes = gsm;
+  float* chan = gsm + m.rpp * C;
+  const int cpg = C / G;
+  gamma += (long)b * affine_bs;
+  beta += (long)b * affine_bs;
+  float sh[KC][8], rs[KC][8], ga[KC][8], be[KC][8], accA[KC][8], accB[KC][8];
+#pragma unroll
+  for (int k = 0; k < KC; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sh[k][e] = rs[k][e] = ga[k][e] = be[k][e] = accA[k][e] = accB[k][e] = 0.f;
+      if (k < m.nslot) {
+        const int c = m.slot[k] * 8 + e, g = c / cpg;
+        rs[k][e] = rstd[b * G + g];
+        sh[k][e] = (add != nullptr ? add[(long)b * C + c] : 0.f) - mean[b * G + g];  // xhat = (x + sh) * rs
+        ga[k][e] = gamma[c];
+        be[k][e] = beta[c];
+      }
+    }
+  int r0, r1;
+  gn_nhwc_rows(inner, S, sl, r0, r1);
+  const bf16_t* xb = x + (long)b * inner * C;
+  const bf16_t* dyb = dy + (long)b * inner * C;
+  for (int r = r0 + m.rl; r < r1; r += m.rpp) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+      if (k < m.nslot) {
+        float v[8], d[8];
+        const long off = (long)r * C + m.slot[k] * 8;
+        gn_load8<false>(xb, off, v);
+        gn_load8<false>(dyb, off, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (v[e] + sh[k][e]) * rs[k][e];
+          float dn = d[e];
+          if (silu) dn *= silu_grad_f(fmaf(xh, ga[k][e], be[k][e]));
+          accA[k][e] += dn * xh;
+          accB[k][e] += dn;
+        }
+      }
+  }
+  float* o = part + ((long)b * S + sl) * 2 * C;
+  gn_nhwc_fold<KC>(m, accA, lanes, chan, C);
+  for (int c = threadIdx.x; c < C; c += 256) o[c] = chan[c];
+  gn_nhwc_fold<KC>(m, accB, lanes, chan, C);
+  for (int c = threadIdx.x; c < C; c += 256) o[C + c] = chan[c];
+}
+
+// backward, apply: merges the slices per channel (slice order), writes the per-sample dgamma / dbeta partial rows (slice 0's
+// workgroup), dx = rstd (dn gamma - s1 / n - xhat s2 / n), and per slice and channel sum(dx) for the time-embedding gradient
+// LDS: lanes [rpp][C] + chA [C] + chB [C] + grp [2 G]
+template <int KC>
+__global__ __launch_bounds__(256) void gn_nhwc_bwd_apply_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                const float* __restrict__ add, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ part,
+                                                                bf16_t* __restrict__ dx, float* __restrict__ dgamma_part,
+                                                                float* __restrict__ dbeta_part, float* __restrict__ dadd_part, int C,
+                                                                int G, int inner, int silu, int affine_bs, int S) {
+  extern __shared__ float gsm[];
+  const int b = blockIdx.x / S, sl = blockIdx.x - b * S;
+  const GnNhwcMap m = gn_nhwc_map(C);
+  float* lanes = gsm;
+  float* chA = gsm + m.rpp * C;
+  float* chB = chA + C;
+  float* grp = chB + C;
+  const int cpg = C / G;
+  gamma += (long)b * affine_bs;
+  beta += (long)b * affine_bs;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float sa = 0.f, sb = 0.f;
+    for (int s2 = 0; s2 < S; ++s2) {
+      const float* o = part + ((long)b * S + s2) * 2 * C;
+      sa += o[c];
+      sb += o[C + c];
+    }
+    chA[c] = sa;
+    chB[c] = sb;
+    if (sl == 0) {
+      dgamma_part[(long)b * C + c] = sa;
+      dbeta_part[(long)b * C + c] = sb;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    float s1 = 0.f, s2 = 0.f;  // sum dn gamma, sum dn gamma xhat
+    for (int c = threadIdx.x * cpg; c < (int)(threadIdx.x + 1) * cpg; ++c) {
+      s1 += chB[c] * gamma[c];
+      s2 += chA[c] * gamma[c];
+    }
+    const float inv_n = 1.f / ((float)cpg * (float)inner);
+    grp[threadIdx.x] = s1 * inv_n;
+    grp[G + threadIdx.x] = s2 * inv_n;
+  }
+  __syncthreads();
+  float sh[KC][8], rs[KC][8], ga[KC][8], be[KC][8], m1[KC][8], m2[KC][8], accD[KC][8];
+#pragma unroll
+  for (int k = 0; k < KC; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sh[k][e] = rs[k][e] = ga[k][e] = be[k][e] = m1[k][e] = m2[k][e] = accD[k][e] = 0.f;
+      if (k < m.nslot) {
+        const int c = m.slot[k] * 8 + e, g = c / cpg;
+        rs[k][e] = rstd[b * G + g];
+        sh[k][e] = (add != nullptr ? add[(long)b * C + c] : 0.f) - mean[b * G + g];
+        ga[k][e] = gamma[c];
+        be[k][e] = beta[c];
+        m1[k][e] = grp[g];
+        m2[k][e] = grp[G + g];
+      }
+    }
+  int r0, r1;
+  gn_nhwc_rows(inner, S, sl, r0, r1);
+  const bf16_t* xb = x + (long)b * inner * C;
+  const bf16_t* dyb = dy + (long)b * inner * C;
+  bf16_t* dxb = dx + (long)b * inner * C;
+  for (int r = r0 + m.rl; r < r1; r += m.rpp) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+      if (k < m.nslot) {
+        float v[8], d[8];
+        const long off = (long)r * C + m.slot[k] * 8;
+        gn_load8<false>(xb, off, v);
+        gn_load8<false>(dyb, off, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (v[e] + sh[k][e]) * rs[k][e];
+          float dn = d[e];
+          if (silu) dn *= silu_grad_f(fmaf(xh, ga[k][e], be[k][e]));
+          const float o = rs[k][e] * (dn * ga[k][e] - m1[k][e] - xh * m2[k][e]);
+          v[e] = o;
+          accD[k][e] += o;
+        }
+        gn_store8(dxb, off, v);
+      }
+  }
+  if (dadd_part != nullptr) {
+    gn_nhwc_fold<KC>(m, accD, lanes, chA, C);  // (chA / chB are no longer needed: every thread holds its coefficients in registers)
+    float* o = dadd_part + ((long)b * S + sl) * C;
+    for (int c = threadIdx.x; c < C; c += 256) o[c] = chA[c];
+  }
+}
+
+// dadd[b][c] = sum over the slices of sum(dx), slice order
+__global__ void gn_nhwc_dadd_kernel(const float* __restrict__ part, float* __restrict__ dadd, int C, int S) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int sl = 0; sl < S; ++sl) s += part[((long)b * S + sl) * C + c];
+  dadd[(long)b * C + c] = s;
+}
+
 // ---- 3x3 filter repacking for the implicit-GEMM convolution -----------------------------------------------------------
 // w bf16 [Cout][Cin][3][3] (the reference's layout, arena-backed shadow of the fp32 master) ->
 //   FWD: wk[co][tap][c]        = w[co][c][tap]         (tap = ky*3 + kx; a K-step of the GEMM = 32 channels of one tap)
@@ -1002,6 +1362,41 @@ __global__ void reflect_pad2d_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* 
     for (int a = 0; a < ny; ++a)
       for (int b = 0; b < nx; ++b) acc += bf16_to_f32(base[(long)ys[a] * Wo + xs[b]]);
     dx[i] = f32_to_bf16(acc);
+  }
+}
+
+// nearest x2 up-sampling on NHWC rows, 8 channels (16 bytes) per thread.  fwd: y[b][2h + i][2w + j][c] = x[b][h][w][c];
+// bwd: dx[b][h][w][c] = the sum of the four dy (H, W = the SMALL size, C % 8 == 0)
+template <bool BWD>
+__global__ void upsample2_nhwc_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, long B, int H, int W, int C) {
+  const int c8 = C >> 3;
+  const long total = (BWD ? B * H * W : B * 4L * H * W) * c8;
+  const long step = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += step) {
+    const int cc = (int)(i % c8);
+    long t = i / c8;
+    if (!BWD) {
+      const int ox = (int)(t % (2 * W));
+      t /= 2 * W;
+      const int oy = (int)(t % (2 * H));
+      const long b = t / (2 * H);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(src + (((b * H + oy / 2) * W + ox / 2) * (long)C) + cc * 8);
+      *reinterpret_cast<u32x4*>(dst + (((b * 2 * H + oy) * 2 * W + ox) * (long)C) + cc * 8) = v;
+    } else {
+      const int xw = (int)(t % W);
+      t /= W;
+      const int yh = (int)(t % H);
+      const long b = t / H;
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[8];
+        gn_load8<false>(src, (((b * 2 * H + 2 * yh + (q >> 1)) * 2 * W + 2 * xw + (q & 1)) * (long)C) + cc * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      }
+      gn_store8(dst, (((b * H + yh) * W + xw) * (long)C) + cc * 8, acc);
+    }
   }
 }
 
@@ -1297,6 +1692,77 @@ extern "C" int cfhip_groupnorm_bwd(const void* dy, const void* x, int x_is_f32, 
                                     G, inner, silu, 0, stream);
 }
 
+// ---- GroupNorm on NHWC rows: entry points ---------------------------------------------------------------------------------------
+static int gn_nhwc_check(const char* who, int B, int C, int G, int inner, int splits) {
+  CFHIP_REQUIRE(B > 0 && C > 0 && G > 0 && inner > 0, "%s: empty problem (B=%d C=%d G=%d inner=%d)", who, B, C, G, inner);
+  CFHIP_REQUIRE(C % 8 == 0 && C % G == 0 && G <= 64 && C <= 4096, "%s: C = %d must be a multiple of 8 and of G = %d (<= 64), at most 4096", who, C, G);
+  CFHIP_REQUIRE(splits >= 1 && splits <= inner && splits <= 4096, "%s: splits = %d outside 1 .. min(inner, 4096)", who, splits);
+  return CFHIP_OK;
+}
+static inline int gn_nhwc_rpp(int C) { return (C >> 3) >= 256 ? 1 : 256 / (C >> 3); }
+
+extern "C" size_t cfhip_groupnorm_nhwc_workspace(int B, int C, int G, int splits, int backward, int with_add) {
+  if (B <= 0 || C <= 0 || G <= 0 || splits <= 0) return 0;
+  if (!backward) return (size_t)B * splits * G * 2 * sizeof(float);
+  return ((size_t)B * splits * 2 * C + (with_add ? (size_t)B * splits * C : 0)) * sizeof(float);
+}
+
+extern "C" int cfhip_groupnorm_nhwc_fwd(const void* x, const float* add, const float* gamma, const float* beta, void* y, float* mean,
+                                        float* rstd, int B, int C, int G, int inner, float eps, int silu, int affine_batch_stride,
+                                        int splits, float* workspace, void* stream) {
+  CFHIP_REQUIRE(x && gamma && beta && y && mean && rstd && workspace, "groupnorm_nhwc_fwd: null argument");
+  const int rc = gn_nhwc_check("groupnorm_nhwc_fwd", B, C, G, inner, splits);
+  if (rc != CFHIP_OK) return rc;
+  CFHIP_REQUIRE(affine_batch_stride == 0 || affine_batch_stride == C, "groupnorm_nhwc_fwd: affine_batch_stride must be 0 or C");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = ((size_t)gn_nhwc_rpp(C) * C + C + 2 * 64) * sizeof(float);
+  const bf16_t* xp = (const bf16_t*)x;
+  if ((C >> 3) > 256) {
+    hipLaunchKernelGGL((gn_nhwc_stats_kernel<2>), dim3(B * splits), dim3(256), lds, s, xp, add, workspace, C, G, inner, splits);
+    hipLaunchKernelGGL((gn_nhwc_apply_kernel<2>), dim3(B * splits), dim3(256), 0, s, xp, add, gamma, beta, workspace, (bf16_t*)y, mean, rstd,
+                       C, G, inner, eps, silu, affine_batch_stride, splits);
+  } else {
+    hipLaunchKernelGGL((gn_nhwc_stats_kernel<1>), dim3(B * splits), dim3(256), lds, s, xp, add, workspace, C, G, inner, splits);
+    hipLaunchKernelGGL((gn_nhwc_apply_kernel<1>), dim3(B * splits), dim3(256), 0, s, xp, add, gamma, beta, workspace, (bf16_t*)y, mean, rstd,
+                       C, G, inner, eps, silu, affine_batch_stride, splits);
+  }
+  CFHIP_CHECK_LAUNCH("groupnorm_nhwc_fwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_groupnorm_nhwc_bwd(const void* dy, const void* x, const float* add, const float* gamma, const float* beta,
+                                        const float* mean, const float* rstd, void* dx, float* dgamma_part, float* dbeta_part, float* dadd,
+                                        int B, int C, int G, int inner, int silu, int affine_batch_stride, int splits, float* workspace,
+                                        void* stream) {
+  CFHIP_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma_part && dbeta_part && workspace, "groupnorm_nhwc_bwd: null argument");
+  const int rc = gn_nhwc_check("groupnorm_nhwc_bwd", B, C, G, inner, splits);
+  if (rc != CFHIP_OK) return rc;
+  CFHIP_REQUIRE(affine_batch_stride == 0 || affine_batch_stride == C, "groupnorm_nhwc_bwd: affine_batch_stride must be 0 or C");
+  CFHIP_REQUIRE((dadd != nullptr) == (add != nullptr), "groupnorm_nhwc_bwd: dadd goes with add");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds_a = ((size_t)gn_nhwc_rpp(C) * C + C) * sizeof(float);
+  const size_t lds_b = ((size_t)gn_nhwc_rpp(C) * C + 2 * C + 2 * 64) * sizeof(float);
+  float* part = workspace;
+  float* dpart = dadd != nullptr ? workspace + (size_t)B * splits * 2 * C : nullptr;
+  const bf16_t* dyp = (const bf16_t*)dy;
+  const bf16_t* xp = (const bf16_t*)x;
+  if ((C >> 3) > 256) {
+    hipLaunchKernelGGL((gn_nhwc_bwd_stats_kernel<2>), dim3(B * splits), dim3(256), lds_a, s, dyp, xp, add, gamma, beta, mean, rstd, part, C, G,
+                       inner, silu, affine_batch_stride, splits);
+    hipLaunchKernelGGL((gn_nhwc_bwd_apply_kernel<2>), dim3(B * splits), dim3(256), lds_b, s, dyp, xp, add, gamma, beta, mean, rstd, part,
+                       (bf16_t*)dx, dgamma_part, dbeta_part, dpart, C, G, inner, silu, affine_batch_stride, splits);
+  } else {
+    hipLaunchKernelGGL((gn_nhwc_bwd_stats_kernel<1>), dim3(B * splits), dim3(256), lds_a, s, dyp, xp, add, gamma, beta, mean, rstd, part, C, G,
+                       inner, silu, affine_batch_stride, splits);
+    hipLaunchKernelGGL((gn_nhwc_bwd_apply_kernel<1>), dim3(B * splits), dim3(256), lds_b, s, dyp, xp, add, gamma, beta, mean, rstd, part,
+                       (bf16_t*)dx, dgamma_part, dbeta_part, dpart, C, G, inner, silu, affine_batch_stride, splits);
+  }
+  if (dadd != nullptr)
+    hipLaunchKernelGGL(gn_nhwc_dadd_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, dpart, dadd, C, splits);
+  CFHIP_CHECK_LAUNCH("groupnorm_nhwc_bwd");
+  return CFHIP_OK;
+}
+
 extern "C" int cfhip_silu_f32_fwd(const float* x, float* y, int64_t n, void* stream) {
   CFHIP_REQUIRE(x && y && n > 0, "silu_f32_fwd: bad arguments");
   hipLaunchKernelGGL((silu_f32_kernel<false>), dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, x, y, (long)n);
@@ -1322,6 +1788,20 @@ extern "C" int cfhip_upsample2_bwd(const void* dy, void* dx, int64_t BC, int H, 
   hipLaunchKernelGGL((upsample2_kernel<true>), dim3(grid_for(BC * (long)H * W, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dy, (bf16_t*)dx, (long)BC, H, W);
   CFHIP_CHECK_LAUNCH("upsample2_bwd");
+  return CFHIP_OK;
+}
+extern "C" int cfhip_upsample2_nhwc_fwd(const void* x, void* y, int64_t B, int H, int W, int C, void* stream) {
+  CFHIP_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "upsample2_nhwc_fwd: bad arguments (C must be a multiple of 8)");
+  hipLaunchKernelGGL((upsample2_nhwc_kernel<false>), dim3(grid_for(B * 4L * H * W * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (bf16_t*)y, (long)B, H, W, C);
+  CFHIP_CHECK_LAUNCH("upsample2_nhwc_fwd");
+  return CFHIP_OK;
+}
+extern "C" int cfhip_upsample2_nhwc_bwd(const void* dy, void* dx, int64_t B, int H, int W, int C, void* stream) {
+  CFHIP_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "upsample2_nhwc_bwd: bad arguments (C must be a multiple of 8)");
+  hipLaunchKernelGGL((upsample2_nhwc_kernel<true>), dim3(grid_for(B * (long)H * W * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, (bf16_t*)dx, (long)B, H, W, C);
+  CFHIP_CHECK_LAUNCH("upsample2_nhwc_bwd");
   return CFHIP_OK;
 }
 extern "C" int cfhip_avgpool2_fwd(const void* x, void* y, int64_t BC, int Ho, int Wo, void* stream) {

@@ -780,6 +780,10 @@ def attention_core(q: Tensor, k: Tensor, v: Tensor, num_heads: int, keep_mask: O
 class AddFn(Function):
     @staticmethod
     def forward(ctx: Any, a: Tensor, b: Tensor) -> Tensor:
+        if a.dim() == 4 and (is_nhwc(a) or is_nhwc(b)):  # the residual adds of the UNet on NHWC rows (a layout mismatch: one transpose)
+            a2, b2 = to_nhwc(a), to_nhwc(b)
+            n, c, h, w = a2.shape
+            return rows_to_nhwc(ops.add(nhwc_rows(a2), nhwc_rows(b2)), n, c, h, w)
         a2 = a if a.dtype == bf16 else ops.to_bf16(a.float().contiguous())
         b2 = b if b.dtype == bf16 else ops.to_bf16(b.float().contiguous())
         return ops.add(a2.contiguous(), b2.contiguous())
@@ -899,6 +903,66 @@ def patch_tokens(img: Tensor, conv_w: Tensor, conv_b: Optional[Tensor], head_tok
 # ---------------------------------------------------------------------------------------------
 
 
+# ---- NHWC activations (round 5) ------------------------------------------------------------------------------------------------
+# The implicit-GEMM convolutions read and write NHWC ROWS ([B * H * W, C] bf16); modules exchange [B, C, H, W] tensors like the
+# reference.  With `NHWC[0]` set (modules.UNetDiffuser.forward does it for the duration of a forward) a convolution hands its
+# rows on as a channels_last VIEW — logical shape [B, C, H, W], strides (H W C, 1, W C, C), no copy — and every Function of the
+# UNet path (GroupNorm, up-sampling, skip concatenation, residual add, the token <-> image hops of the SpatialTransformer)
+# works on the rows behind such a view: the 318 NCHW <-> NHWC transposes of a 64^2 x 8 step are gone.  A Function that meets a
+# layout it has no kernel for converts EXPLICITLY with the transpose kernel (`to_nchw` / `to_nhwc`) — never through
+# `.contiguous()`, which would be a silent ATen copy.  CFHIP_UNET_NHWC=0 keeps the round-4 NCHW hand-over.
+NHWC = [False]
+NHWC_ENABLED = os.environ.get("CFHIP_UNET_NHWC", "1") != "0"
+
+
+def is_nhwc(x: Tensor) -> bool:
+    if x.dim() != 4:
+        return False
+    b, c, h, w = x.shape
+    return c > 1 and h * w > 1 and x.stride() == (h * w * c, 1, w * c, c)
+
+
+def nhwc_rows(x: Tensor) -> Tensor:
+    """the [B * H * W, C] rows behind a channels_last view (no copy)"""
+    b, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(b * h * w, c)
+
+
+def rows_to_nhwc(rows: Tensor, b: int, c: int, h: int, w: int) -> Tensor:
+    """[B * H * W, C] rows as a [B, C, H, W] channels_last view (no copy)"""
+    return rows.view(b, h, w, c).permute(0, 3, 1, 2)
+
+
+def to_nchw(x: Tensor) -> Tensor:
+    """dense NCHW of a 4-D activation: the transpose kernel for a channels_last view, `.contiguous()` otherwise (no-op when dense)"""
+    if not is_nhwc(x):
+        return x.contiguous()
+    b, c, h, w = x.shape
+    return ops.transpose_batched(nhwc_rows(x).view(b, h * w, c)).view(b, c, h, w)
+
+
+def to_nhwc(x: Tensor) -> Tensor:
+    """bf16 channels_last view of a 4-D activation (the transpose kernel when it arrives NCHW)"""
+    if is_nhwc(x) and x.dtype == bf16:
+        return x
+    if x.dtype not in (bf16, f32):
+        x = x.float()
+    x = to_nchw(x)
+    b, c, h, w = x.shape
+    return rows_to_nhwc(ops.transpose_batched(x.view(b, c, h * w)).view(b * h * w, c), b, c, h, w)
+
+
+def as_bf16_act(t: Tensor) -> Tensor:
+    """a 4-D activation / gradient as bf16 in the layout it arrived in (NHWC rows stay NHWC rows)"""
+    if t.dtype == bf16:
+        return t
+    t = t.float()
+    if is_nhwc(t):
+        b, c, h, w = t.shape
+        return rows_to_nhwc(ops.to_bf16(nhwc_rows(t)), b, c, h, w)
+    return ops.to_bf16(t.contiguous())
+
+
 def _conv_weight_rows(weight: Tensor, kp: int) -> Tensor:
     """bf16 [Cout, Kp] view / zero-padded copy of the [Cout, Cin, kh, kw] weight (k = (c, ky, kx))."""
     cout = weight.shape[0]
@@ -941,7 +1005,10 @@ class Conv2dFn(Function):
                 dil: int) -> Tensor:
         if x.dtype not in (bf16, f32):
             x = x.float()
-        x = x.contiguous()
+        nhwc_in = is_nhwc(x) and x.dtype == bf16  # the producer handed its NHWC rows on: no transpose on the way in
+        ctx.nhwc_in = nhwc_in
+        if not nhwc_in:
+            x = to_nchw(x)
         b, cin, h, w = x.shape
         cout, _, kh, kw = weight.shape
         ho, wo = ops.conv_out_hw(h, w, kh, kw, stride, pad, dil)
@@ -949,8 +1016,9 @@ class Conv2dFn(Function):
         ctx.weight, ctx.bias = weight, bias
         ctx.geom = (kh, kw, stride, pad, dil, ho, wo)
         ctx.implicit = _implicit_ok(cin, cout, kh, kw, stride, pad, dil, h, w)
+        nhwc_out = NHWC[0] and cout % 8 == 0  # hand the output rows on as a channels_last view
         if ctx.implicit:
-            x_rows = ops.transpose_batched(x.view(b, cin, h * w)).view(b * h * w, cin)  # NHWC bf16
+            x_rows = nhwc_rows(x) if nhwc_in else ops.transpose_batched(x.view(b, cin, h * w)).view(b * h * w, cin)  # NHWC bf16
             w16 = shadow_bf16(weight).view(cout, cin, 3, 3)
             wk = ops.conv3x3_pack_filters(w16, False)  # k = (ky, kx, c): a K-step = 32 channels of a tap
             y_rows = ops.conv3x3_nhwc(x_rows, wk, bias_f, b, h, w)
@@ -973,14 +1041,18 @@ class Conv2dFn(Function):
                     ev = torch.cuda.Event()
                     ev.record(side)
                     ctx.wr, ctx.wr_event = wr, ev
+            if nhwc_out:
+                return rows_to_nhwc(y_rows, b, cout, h, w)
             return ops.transpose_batched(y_rows.view(b, h * w, cout)).view(b, cout, h, w)
         # 1x1 / stride 1 (the skip connections of the UNet's residual blocks): the im2row matrix IS the NHWC copy of x — one
         # batched transpose instead of the gather kernel, kept for the weight gradient (the im2row route recomputes it), and
         # dX comes back through a transpose instead of row2im (UNet 64^2 x 8: 38 im2row + 18 row2im launches, 3.7 ms)
         ctx.pointwise = (kh, kw, stride, pad, dil) == (1, 1, 1, 0, 1) and cin % 8 == 0
         if ctx.pointwise:
-            rows = ops.transpose_batched(x.view(b, cin, h * w)).view(b * h * w, cin)
+            rows = nhwc_rows(x) if nhwc_in else ops.transpose_batched(x.view(b, cin, h * w)).view(b * h * w, cin)
         else:
+            if nhwc_in:  # strided / odd-shaped convolutions gather from NCHW (3 down-sampling layers per UNet): one transpose
+                x = to_nchw(x)
             rows = ops.conv_im2row(x, kh, kw, stride, pad, dil)
         wp = _conv_weight_rows(weight, rows.shape[1])
         # Cout that is not a multiple of 8 (the 3-channel head of the UNet) would fall off the MFMA path onto the
@@ -995,7 +1067,10 @@ class Conv2dFn(Function):
                 bpad[:cout] = bias_f
                 bias_f = bpad
         y_rows = ops.gemm(rows, wp, bias=bias_f)  # [B*Ho*Wo, Cp] bf16
-        y = ops.transpose_batched(y_rows.view(b, ho * wo, cp)).view(b, cp, ho, wo)
+        if nhwc_out and cp == cout:
+            y = rows_to_nhwc(y_rows, b, cout, ho, wo)
+        else:
+            y = ops.transpose_batched(y_rows.view(b, ho * wo, cp)).view(b, cp, ho, wo)
         if cp != cout:
             y = y[:, :cout].contiguous()
         ctx.save_for_backward(rows if ctx.pointwise else x, wp)
@@ -1010,15 +1085,18 @@ class Conv2dFn(Function):
         b, cin, h, w = ctx.xshape
         cout = weight.shape[0]
         k = cin * kh * kw
-        if dy.dtype != bf16:
-            dy = ops.to_bf16(dy.float().contiguous())
+        dy = as_bf16_act(dy)
         # implicit forward: wp is the [Cout, Cin, 3, 3] bf16 shadow, the dW GEMM still reads an im2row matrix
         cp = cout if ctx.implicit else wp.shape[0]  # output channels incl. the zero filters padding Cout to 8
         if cp != cout:
             dyp = torch.zeros((b, cp, ho * wo), dtype=bf16, device=dy.device)
-            dyp[:, :cout] = dy.reshape(b, cout, ho * wo)
+            dyp[:, :cout] = to_nchw(dy).reshape(b, cout, ho * wo)
             dy = dyp
-        dy_rows = ops.transpose_batched(dy.contiguous().view(b, cp, ho * wo)).view(b * ho * wo, cp)
+        if is_nhwc(dy):
+            dy_rows = nhwc_rows(dy)  # the consumer's gradient arrives as NHWC rows: no transpose
+        else:
+            dy_rows = ops.transpose_batched(dy.contiguous().view(b, cp, ho * wo)).view(b * ho * wo, cp)
+        nhwc_dx = getattr(ctx, "nhwc_in", False)  # the input came as NHWC rows: its gradient goes back the same way
         wgrad_implicit = ctx.implicit and ops.conv3x3_wgrad_ok(b, h, w)
 
         def param_grads(x: Tensor = x) -> Tuple[Optional[Tensor], Optional[Tensor]]:
@@ -1094,14 +1172,16 @@ class Conv2dFn(Function):
                 else:
                     wr = ops.conv3x3_pack_filters(wp, True)
                 dx_rows = ops.conv3x3_nhwc(dy_rows, wr, None, b, h, w)
-                dx = ops.transpose_batched(dx_rows.view(b, h * w, cin)).view(b, cin, h, w)
+                dx = rows_to_nhwc(dx_rows, b, cin, h, w) if nhwc_dx else ops.transpose_batched(dx_rows.view(b, h * w, cin)).view(b, cin, h, w)
             else:
                 w2 = wp.reshape(cout, k) if ctx.implicit else wp
                 drows = ops.gemm(dy_rows, w2, b_trans=True)  # [M, Kp] bf16
                 if getattr(ctx, "pointwise", False):
-                    dx = ops.transpose_batched(drows.view(b, h * w, cin)).view(b, cin, h, w)
+                    dx = rows_to_nhwc(drows, b, cin, h, w) if nhwc_dx else ops.transpose_batched(drows.view(b, h * w, cin)).view(b, cin, h, w)
                 else:
                     dx = ops.conv_row2im(drows, (b, cin, h, w), kh, kw, stride, pad, dil)
+                    if nhwc_dx:
+                        dx = to_nhwc(dx)
         return dx, gw, gb, None, None, None
 
 
@@ -1111,7 +1191,7 @@ class GroupedConv2dFn(Function):
 
     @staticmethod
     def forward(ctx: Any, x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int, pad: int, dil: int, groups: int) -> Tensor:
-        x2 = (x if x.dtype == bf16 else ops.to_bf16(x.float().contiguous())).contiguous()
+        x2 = to_nchw(as_bf16_act(x))
         w16 = shadow_bf16(weight).view(weight.shape)
         bias_f = None if bias is None else bias.detach().reshape(-1).contiguous()
         ctx.save_for_backward(x2, w16)
@@ -1123,7 +1203,7 @@ class GroupedConv2dFn(Function):
         x2, w16 = ctx.saved_tensors
         weight, bias = ctx.weight, ctx.bias
         stride, pad, dil, groups = ctx.geom
-        dy = (dy if dy.dtype == bf16 else ops.to_bf16(dy.float().contiguous())).contiguous()
+        dy = to_nchw(as_bf16_act(dy))
         want_b = bias is not None and bias.requires_grad
         gw = gb = None
         if weight.requires_grad or want_b:
@@ -1168,7 +1248,7 @@ class ConvTranspose2dFn(Function):
     def forward(ctx: Any, x: Tensor, wt: Tensor, stride: int, pad: int, dil: int) -> Tensor:
         if x.dtype not in (bf16, f32):
             x = x.float()
-        x = x.contiguous()
+        x = to_nchw(x)
         b, cin, h, w = x.shape
         cin_w, cout, kh, kw = wt.shape
         if cin_w != cin:
@@ -1193,9 +1273,7 @@ class ConvTranspose2dFn(Function):
         x_rows, w2 = ctx.saved_tensors
         wt = ctx.wt
         b, cin, h, w, cout, kh, kw, stride, pad, dil, k, kp = ctx.geom
-        if dy.dtype != bf16:
-            dy = ops.to_bf16(dy.float().contiguous())
-        rows = ops.conv_im2row(dy.contiguous(), kh, kw, stride, pad, dil)  # [B h w, Kp]: the convolution's view of dy
+        rows = ops.conv_im2row(to_nchw(as_bf16_act(dy)), kh, kw, stride, pad, dil)  # [B h w, Kp]: the convolution's view of dy
         dx = gw = None
         if ctx.needs_input_grad[0]:
             if cin % 8 == 0:
@@ -1234,7 +1312,7 @@ class BatchNormFn(Function):
                 training: bool) -> Tensor:
         if x.dtype not in (bf16, f32):
             x = x.float()
-        x = x.contiguous()
+        x = to_nchw(x)
         gamma = None if weight is None else weight.detach().contiguous()
         beta = None if bias is None else bias.detach().contiguous()
         y, mean, rstd = ops.batchnorm_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training)
@@ -1246,8 +1324,7 @@ class BatchNormFn(Function):
     def backward(ctx: Any, dy: Tensor):  # type: ignore
         x, gamma, mean, rstd = ctx.saved_tensors
         weight, bias = ctx.weight, ctx.bias
-        if dy.dtype != bf16:
-            dy = ops.to_bf16(dy.float().contiguous())
+        dy = to_nchw(as_bf16_act(dy)) if dy.dim() == 4 else (dy if dy.dtype == bf16 else ops.to_bf16(dy.float().contiguous()))
         dx, dg, db = ops.batchnorm_bwd(dy, x, gamma, mean, rstd, training=ctx.training,
                                        want_dx=ctx.needs_input_grad[0])
         gw = gb = None
@@ -1438,22 +1515,36 @@ class GroupNormFn(Function):
                 silu: bool) -> Tensor:
         if x.dtype not in (bf16, f32):
             x = x.float()
-        x = x.contiguous()
         gamma, beta = weight.detach().contiguous(), bias.detach().contiguous()
         addc = None if add is None else add.detach().float().contiguous()
+        ctx.weight, ctx.bias, ctx.groups, ctx.silu = weight, bias, groups, silu
+        ctx.nhwc = None
+        if is_nhwc(x) and x.dtype == bf16 and x.shape[1] % 8 == 0 and x.shape[1] <= 4096 and groups <= 64:
+            # NHWC rows in, NHWC rows out (cfhip_groupnorm_nhwc_*): what sits between two implicit-GEMM convolutions
+            b, c, h, w = x.shape
+            rows = nhwc_rows(x)
+            y_rows, mean, rstd = ops.groupnorm_nhwc_fwd(rows, b, gamma, beta, groups, eps, add=addc, silu=silu)
+            ctx.save_for_backward(rows, gamma, beta, mean, rstd, addc)
+            ctx.nhwc = (b, c, h, w)
+            return rows_to_nhwc(y_rows, b, c, h, w)
+        x = to_nchw(x)
         y, mean, rstd = ops.groupnorm_fwd(x, gamma, beta, groups, eps, add=addc, silu=silu)
         ctx.save_for_backward(x, gamma, beta, mean, rstd, addc)
-        ctx.weight, ctx.bias, ctx.groups, ctx.silu = weight, bias, groups, silu
         return y
 
     @staticmethod
     def backward(ctx: Any, dy: Tensor):  # type: ignore
         x, gamma, beta, mean, rstd, addc = ctx.saved_tensors
-        if dy.dtype != bf16:
-            dy = ops.to_bf16(dy.float().contiguous())
+        dy = as_bf16_act(dy)
         per_sample = gamma.dim() == 2  # one affine per sample: dgamma / dbeta stay [B, C] (ScaleShiftAffineFn reduces them)
-        dx, dg, db, dadd = ops.groupnorm_bwd(dy, x, gamma, beta, mean, rstd, ctx.groups, add=addc, silu=ctx.silu,
-                                             reduce=per_sample)
+        if ctx.nhwc is not None:
+            b, c, h, w = ctx.nhwc
+            dx_rows, dg, db, dadd = ops.groupnorm_nhwc_bwd(nhwc_rows(to_nhwc(dy)), x, b, gamma, beta, mean, rstd, ctx.groups, add=addc,
+                                                           silu=ctx.silu)
+            dx = rows_to_nhwc(dx_rows, b, c, h, w)
+        else:
+            dx, dg, db, dadd = ops.groupnorm_bwd(to_nchw(dy), x, gamma, beta, mean, rstd, ctx.groups, add=addc, silu=ctx.silu,
+                                                 reduce=per_sample)
         gw = gb = None
         for prm, g, which in ((ctx.weight, dg, 0), (ctx.bias, db, 1)):
             if not prm.requires_grad:
@@ -1542,15 +1633,20 @@ class Upsample2Fn(Function):
 
     @staticmethod
     def forward(ctx: Any, x: Tensor) -> Tensor:
-        if x.dtype != bf16:
-            x = ops.to_bf16(x.float().contiguous())
-        return ops.upsample2_fwd(x.contiguous())
+        x = as_bf16_act(x)
+        ctx.nhwc = is_nhwc(x) and x.shape[1] % 8 == 0
+        if ctx.nhwc:
+            b, c, h, w = x.shape
+            return rows_to_nhwc(ops.upsample2_nhwc(nhwc_rows(x), b, h, w), b, c, 2 * h, 2 * w)
+        return ops.upsample2_fwd(to_nchw(x))
 
     @staticmethod
     def backward(ctx: Any, dy: Tensor):  # type: ignore
-        if dy.dtype != bf16:
-            dy = ops.to_bf16(dy.float().contiguous())
-        return ops.upsample2_bwd(dy.contiguous())
+        dy = as_bf16_act(dy)
+        if ctx.nhwc:
+            b, c, h2, w2 = dy.shape
+            return rows_to_nhwc(ops.upsample2_nhwc(nhwc_rows(to_nhwc(dy)), b, h2 // 2, w2 // 2, backward=True), b, c, h2 // 2, w2 // 2)
+        return ops.upsample2_bwd(to_nchw(dy))
 
 
 class AvgPool2Fn(Function):
@@ -1558,15 +1654,15 @@ class AvgPool2Fn(Function):
 
     @staticmethod
     def forward(ctx: Any, x: Tensor) -> Tensor:
-        if x.dtype != bf16:
-            x = ops.to_bf16(x.float().contiguous())
-        return ops.avgpool2_fwd(x.contiguous())
+        x = as_bf16_act(x)
+        ctx.nhwc = is_nhwc(x)  # (no NHWC pooling kernel: the zoo UNet down-samples with strided convolutions; one explicit hop each way)
+        y = ops.avgpool2_fwd(to_nchw(x))
+        return to_nhwc(y) if ctx.nhwc else y
 
     @staticmethod
     def backward(ctx: Any, dy: Tensor):  # type: ignore
-        if dy.dtype != bf16:
-            dy = ops.to_bf16(dy.float().contiguous())
-        return ops.avgpool2_bwd(dy.contiguous())
+        dx = ops.avgpool2_bwd(to_nchw(as_bf16_act(dy)))
+        return to_nhwc(dx) if ctx.nhwc else dx
 
 
 class ReflectPad2dFn(Function):
@@ -1577,13 +1673,11 @@ class ReflectPad2dFn(Function):
         if x.dtype not in (bf16, f32):
             x = x.float()
         ctx.pads = pads
-        return ops.reflect_pad2d_fwd(x.contiguous(), pads)
+        return ops.reflect_pad2d_fwd(to_nchw(x), pads)
 
     @staticmethod
     def backward(ctx: Any, dy: Tensor):  # type: ignore
-        if dy.dtype != bf16:
-            dy = ops.to_bf16(dy.float().contiguous())
-        return ops.reflect_pad2d_bwd(dy.contiguous(), ctx.pads), None
+        return ops.reflect_pad2d_bwd(to_nchw(as_bf16_act(dy)), ctx.pads), None
 
 
 def reflect_pad2d(x: Tensor, pads: Any) -> Tensor:
@@ -1635,11 +1729,17 @@ class NchwToTokensFn(Function):
             x = x.float()
         b, c, h, w = x.shape
         ctx.hw = (h, w)
-        return ops.transpose_batched(x.contiguous().view(b, c, h * w))
+        ctx.nhwc = is_nhwc(x) and x.dtype == bf16
+        if ctx.nhwc:  # NHWC rows ARE the token-major matrix
+            return nhwc_rows(x).view(b, h * w, c)
+        return ops.transpose_batched(to_nchw(x).view(b, c, h * w))
 
     @staticmethod
     def backward(ctx: Any, dy: Tensor):  # type: ignore
         b, t, c = dy.shape
+        if ctx.nhwc:
+            dy = dy if dy.dtype == bf16 else ops.to_bf16(dy.float().contiguous())
+            return rows_to_nhwc(dy.contiguous().view(b * t, c), b, c, *ctx.hw)
         return ops.transpose_batched(dy.contiguous()).view(b, c, *ctx.hw)
 
 
@@ -1651,11 +1751,17 @@ class TokensToNchwFn(Function):
         if x.dtype not in (bf16, f32):
             x = x.float()
         b, t, c = x.shape
+        if NHWC[0] and c % 8 == 0 and c > 1 and t > 1:  # the token-major matrix IS the image's NHWC rows: a view
+            x = x if x.dtype == bf16 else ops.to_bf16(x.contiguous())
+            return rows_to_nhwc(x.contiguous().view(b * t, c), b, c, h, w)
         return ops.transpose_batched(x.contiguous()).view(b, c, h, w)
 
     @staticmethod
     def backward(ctx: Any, dy: Tensor):  # type: ignore
         b, c, h, w = dy.shape
+        dy = as_bf16_act(dy)
+        if is_nhwc(dy):
+            return nhwc_rows(dy).view(b, h * w, c), None, None
         return ops.transpose_batched(dy.contiguous().view(b, c, h * w)), None, None
 
 
@@ -1672,6 +1778,17 @@ class ConcatChannelsFn(Function):
 
     @staticmethod
     def forward(ctx: Any, a: Tensor, b: Tensor) -> Tensor:
+        ctx.nhwc = None
+        if a.dim() == 4 and (is_nhwc(a) or is_nhwc(b)) and a.shape[1] > 1 and b.shape[1] > 1:
+            # NHWC rows: every pixel row of the output is [a's channels | b's channels] — two strided row copies
+            a, b = to_nhwc(a), to_nhwc(b)
+            n, ca, h, w = a.shape
+            cb = b.shape[1]
+            out = torch.empty((n * h * w, ca + cb), dtype=bf16, device=a.device)
+            ops.copy_strided(nhwc_rows(a), out, n * h * w, ca, ca, ca + cb)
+            ops.copy_strided(nhwc_rows(b), out, n * h * w, cb, cb, ca + cb, dst_off=ca)
+            ctx.nhwc = (n, ca, cb, h, w)
+            return rows_to_nhwc(out, n, ca + cb, h, w)
         a = (a if a.dtype == bf16 else ops.to_bf16(a.float().contiguous())).contiguous()
         b = (b if b.dtype == bf16 else ops.to_bf16(b.float().contiguous())).contiguous()
         n, ca, cb = a.shape[0], a.shape[1], b.shape[1]
@@ -1685,8 +1802,16 @@ class ConcatChannelsFn(Function):
 
     @staticmethod
     def backward(ctx: Any, dy: Tensor):  # type: ignore
+        if ctx.nhwc is not None:
+            n, ca, cb, h, w = ctx.nhwc
+            rows = nhwc_rows(to_nhwc(as_bf16_act(dy)))
+            da = torch.empty((n * h * w, ca), dtype=bf16, device=dy.device)
+            db = torch.empty((n * h * w, cb), dtype=bf16, device=dy.device)
+            ops.copy_strided(rows, da, n * h * w, ca, ca + cb, ca)
+            ops.copy_strided(rows, db, n * h * w, cb, ca + cb, cb, src_off=ca)
+            return rows_to_nhwc(da, n, ca, h, w), rows_to_nhwc(db, n, cb, h, w)
         ca, cb, inner = ctx.split
-        dy = (dy if dy.dtype == bf16 else ops.to_bf16(dy.float().contiguous())).contiguous()
+        dy = to_nchw(dy if dy.dtype == bf16 else ops.to_bf16(to_nchw(dy.float())))
         n = dy.shape[0]
         da = torch.empty((n, ca, *dy.shape[2:]), dtype=bf16, device=dy.device)
         db = torch.empty((n, cb, *dy.shape[2:]), dtype=bf16, device=dy.device)
@@ -1761,13 +1886,15 @@ class DropoutFn(Function):
     def forward(ctx: Any, x: Tensor, p: float, mask: Optional[Tensor]) -> Tensor:  # type: ignore
         ctx.p, ctx.mask = float(p), mask
         ctx.seed, ctx.offset = (0, 0) if mask is not None else ops.PhiloxState.take((x.numel() + 3) // 4)
-        y, _ = ops.dropout(x, ctx.p, seed=ctx.seed, offset=ctx.offset, mask=mask)
-        return y
+        # the mask is indexed in the LOGICAL (NCHW) element order — what an injected mask and torch's own use: NHWC rows hop over
+        ctx.nhwc = x.dim() == 4 and is_nhwc(x)
+        y, _ = ops.dropout(to_nchw(x) if ctx.nhwc else x, ctx.p, seed=ctx.seed, offset=ctx.offset, mask=mask)
+        return to_nhwc(y) if ctx.nhwc else y
 
     @staticmethod
     def backward(ctx: Any, dy: Tensor) -> Any:  # type: ignore
-        dx, _ = ops.dropout(dy.contiguous(), ctx.p, seed=ctx.seed, offset=ctx.offset, mask=ctx.mask)
-        return dx, None, None
+        dx, _ = ops.dropout(to_nchw(dy) if dy.dim() == 4 else dy.contiguous(), ctx.p, seed=ctx.seed, offset=ctx.offset, mask=ctx.mask)
+        return (to_nhwc(dx) if ctx.nhwc else dx), None, None
 
 
 def dropout(x: Tensor, p: float, training: bool, mask: Optional[Tensor] = None) -> Tensor:

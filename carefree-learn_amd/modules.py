@@ -1999,19 +1999,28 @@ class UNetDiffuser(Module):
             time_net = time_net + HF.embedding(labels.reshape(-1).to(torch.int64), self.label_embedding.weight)
         control = None if control is None else list(control)
         nets: List[Tensor] = []
-        for block in self.input_blocks:
-            net = block(net, time_net, context)
-            nets.append(net)
-        net = self.residual(net, time_net, context)
-        if control is not None:  # unet.py:311-318
-            net = HF.add(net, control.pop())
-        for block in self.output_blocks:
-            skip = nets.pop()
-            if control is not None and not only_mid_control:
-                skip = HF.add(skip, control.pop())
-            net = block(HF.concat_channels(net, skip), time_net, context)
-        net = self.head[0](net, silu=True)  # GroupNorm + SiLU in one kernel
-        return self.head[2](net)
+        # Round 5: between the stem and the head every activation travels as the NHWC rows the implicit-GEMM convolutions read and
+        # write (channels_last views of logical [B, C, H, W] tensors, `functional.NHWC`): no NCHW <-> NHWC hop around the
+        # convolutions, GroupNorm on the rows, token matrices of the transformers as views.  The head (3 output channels)
+        # returns NCHW like the reference.
+        prev = HF.NHWC[0]
+        HF.NHWC[0] = HF.NHWC_ENABLED and net.is_cuda
+        try:
+            for block in self.input_blocks:
+                net = block(net, time_net, context)
+                nets.append(net)
+            net = self.residual(net, time_net, context)
+            if control is not None:  # unet.py:311-318
+                net = HF.add(net, control.pop())
+            for block in self.output_blocks:
+                skip = nets.pop()
+                if control is not None and not only_mid_control:
+                    skip = HF.add(skip, control.pop())
+                net = block(HF.concat_channels(net, skip), time_net, context)
+            net = self.head[0](net, silu=True)  # GroupNorm + SiLU in one kernel
+            return self.head[2](net)
+        finally:
+            HF.NHWC[0] = prev
 
 
 # ---------------------------------------------------------------------------------------------

@@ -946,6 +946,83 @@ def gn_splits(b: int, c: int, groups: int, inner: int) -> int:
     return max(1, min(64, want, inner // GN_MIN_SLICE))
 
 
+GN_NHWC_TARGET_WORKGROUPS = int(os.environ.get("CFHIP_GN_NHWC_TARGET", "1024"))
+GN_NHWC_MIN_ROWS = int(os.environ.get("CFHIP_GN_NHWC_MIN_ROWS", "16"))
+
+
+def gn_nhwc_splits(b: int, inner: int) -> int:
+    """row slices per sample of the NHWC GroupNorm kernels (one workgroup each): ~4 workgroups per CU, at least GN_NHWC_MIN_ROWS rows each"""
+    want = -(-GN_NHWC_TARGET_WORKGROUPS // b)
+    return max(1, min(want, inner // GN_NHWC_MIN_ROWS, 4096))
+
+
+def groupnorm_nhwc_fwd(rows: Tensor, b: int, gamma: Tensor, beta: Tensor, groups: int, eps: float, *, add: Optional[Tensor] = None,
+                       silu: bool = False):
+    """rows bf16 [B * inner, C] (NHWC) -> (y rows bf16, mean f32 [B * G], rstd f32 [B * G]); y = [SiLU](GN(x + add[b, c])).
+    gamma / beta: f32 [C], or [B, C] = one affine per sample."""
+    _need(rows, bf16, "rows")
+    _need(gamma, f32, "gamma")
+    _need(beta, f32, "beta")
+    if rows.dim() != 2 or not rows.is_contiguous() or rows.shape[0] % b:
+        raise ValueError("cfhip groupnorm_nhwc_fwd: contiguous bf16 [B * inner, C] rows expected")
+    c = rows.shape[1]
+    inner = rows.shape[0] // b
+    affine_bs = _gn_affine_stride(gamma, beta, b, c)
+    if add is not None:
+        _need(add, f32, "add")
+        if tuple(add.shape) != (b, c) or not add.is_contiguous():
+            raise ValueError("cfhip groupnorm_nhwc_fwd: add must be contiguous f32 [B, C]")
+    lib = _lib.load()
+    splits = gn_nhwc_splits(b, inner)
+    y = torch.empty_like(rows)
+    mean = torch.empty((b * groups,), dtype=f32, device=rows.device)
+    rstd = torch.empty((b * groups,), dtype=f32, device=rows.device)
+    ws = torch.empty((max(4, lib.cfhip_groupnorm_nhwc_workspace(b, c, groups, splits, 0, 0)) // 4,), dtype=f32, device=rows.device)
+    rc = lib.cfhip_groupnorm_nhwc_fwd(rows.data_ptr(), _p(add), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                      rstd.data_ptr(), b, c, groups, inner, float(eps), int(silu), affine_bs, splits, ws.data_ptr(), _stream())
+    _lib.check(rc, "groupnorm_nhwc_fwd")
+    return y, mean, rstd
+
+
+def groupnorm_nhwc_bwd(dy: Tensor, rows: Tensor, b: int, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tensor, groups: int, *,
+                       add: Optional[Tensor] = None, silu: bool = False):
+    """Returns (dx rows bf16, dgamma_part f32 [B, C], dbeta_part f32 [B, C], dadd f32 [B, C] | None): the per-sample partial sums are
+    reduced over B by the caller (`colreduce_f32(part, out=param.grad)`), or ARE the gradient of a per-sample affine."""
+    _need(dy, bf16, "dy")
+    _need(rows, bf16, "rows")
+    if dy.shape != rows.shape or not dy.is_contiguous() or not rows.is_contiguous():
+        raise ValueError("cfhip groupnorm_nhwc_bwd: dy and x must be contiguous bf16 rows of one shape")
+    c = rows.shape[1]
+    inner = rows.shape[0] // b
+    affine_bs = _gn_affine_stride(gamma, beta, b, c)
+    lib = _lib.load()
+    splits = gn_nhwc_splits(b, inner)
+    dx = torch.empty_like(rows)
+    dg = torch.empty((b, c), dtype=f32, device=rows.device)
+    db = torch.empty((b, c), dtype=f32, device=rows.device)
+    dadd = torch.empty((b, c), dtype=f32, device=rows.device) if add is not None else None
+    ws = torch.empty((max(4, lib.cfhip_groupnorm_nhwc_workspace(b, c, groups, splits, 1, int(add is not None))) // 4,), dtype=f32,
+                     device=rows.device)
+    rc = lib.cfhip_groupnorm_nhwc_bwd(dy.data_ptr(), rows.data_ptr(), _p(add), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                                      rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), _p(dadd), b, c, groups, inner,
+                                      int(silu), affine_bs, splits, ws.data_ptr(), _stream())
+    _lib.check(rc, "groupnorm_nhwc_bwd")
+    return dx, dg, db, dadd
+
+
+def upsample2_nhwc(rows: Tensor, b: int, h: int, w: int, backward: bool = False) -> Tensor:
+    """nearest x2 on NHWC rows [B * H * W, C] (h, w = the SMALL size): forward -> [B * 4 H W, C]; backward: dy rows [B * 4 H W, C] -> dx"""
+    _need(rows, bf16, "rows")
+    c = rows.shape[1]
+    n_in = b * h * w * (4 if backward else 1)
+    if rows.dim() != 2 or not rows.is_contiguous() or rows.shape[0] != n_in:
+        raise ValueError("cfhip upsample2_nhwc: contiguous bf16 rows of the stated geometry expected")
+    out = torch.empty((b * h * w * (1 if backward else 4), c), dtype=bf16, device=rows.device)
+    fn = _lib.load().cfhip_upsample2_nhwc_bwd if backward else _lib.load().cfhip_upsample2_nhwc_fwd
+    _lib.check(fn(rows.data_ptr(), out.data_ptr(), b, h, w, c, _stream()), "upsample2_nhwc")
+    return out
+
+
 def groupnorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, *, add: Optional[Tensor] = None,
                   silu: bool = False):
     """x [B, C, ...] f32 / bf16 -> (y bf16, mean f32 [B*G], rstd f32 [B*G]); y = [SiLU](GN(x + add[b, c])).

@@ -460,6 +460,22 @@ int cfhip_upsample2_fwd(const void* x, void* y, int64_t BC, int H, int W, void* 
 int cfhip_upsample2_bwd(const void* dy, void* dx, int64_t BC, int H, int W, void* stream);
 int cfhip_avgpool2_fwd(const void* x, void* y, int64_t BC, int Ho, int Wo, void* stream);
 int cfhip_avgpool2_bwd(const void* dy, void* dx, int64_t BC, int Ho, int Wo, void* stream);
+/* NHWC forms (round 5): the UNet keeps its activations as the rows the implicit-GEMM convolutions read and write — bf16 [B][H * W][C],
+ * C % 8 == 0 — instead of hopping NCHW <-> NHWC around every convolution.
+ *   groupnorm_nhwc: nn.GroupNorm (+ the per-(b, c) additive term in front, + SiLU behind) of convs/residual.py:194,226-247 on such rows;
+ *     `splits` slices of rows per sample (one workgroup each), workspace = cfhip_groupnorm_nhwc_workspace(...) bytes;
+ *     mean / rstd f32 [B * G]; bwd: dgamma_part / dbeta_part f32 [B][C] (per-sample sums: the caller reduces over B), dadd f32 [B][C]
+ *     (with `add`); gamma / beta [C], or [B][C] with affine_batch_stride == C (the scale-shift norm); deterministic, no atomics.
+ *   upsample2_nhwc: F.interpolate(scale_factor=2, mode="nearest") (residual.py:147) and its gradient; H, W = the small size. */
+size_t cfhip_groupnorm_nhwc_workspace(int B, int C, int G, int splits, int backward, int with_add);
+int cfhip_groupnorm_nhwc_fwd(const void* x, const float* add, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                             int B, int C, int G, int inner, float eps, int silu, int affine_batch_stride, int splits, float* workspace,
+                             void* stream);
+int cfhip_groupnorm_nhwc_bwd(const void* dy, const void* x, const float* add, const float* gamma, const float* beta, const float* mean,
+                             const float* rstd, void* dx, float* dgamma_part, float* dbeta_part, float* dadd, int B, int C, int G, int inner,
+                             int silu, int affine_batch_stride, int splits, float* workspace, void* stream);
+int cfhip_upsample2_nhwc_fwd(const void* x, void* y, int64_t B, int H, int W, int C, void* stream);
+int cfhip_upsample2_nhwc_bwd(const void* dy, void* dx, int64_t B, int H, int W, int C, void* stream);
 /* nn.ReflectionPad2d in front of F.conv2d (reference convs/basic.py:61-75,114-115: Conv2d(padding="reflection[N]")):
  *   fwd: x [BC][H][W] (bf16, or f32 when x_is_f32) -> y bf16 [BC][H + pt + pb][W + pl + pr], mirrored without repeating the border;
  *   bwd: dx bf16 [BC][H][W] = gather of the <= 9 positions of dy that mirror onto each input pixel (deterministic).

@@ -667,3 +667,103 @@ def test_ddpm_step_updates_inside_backward_bit_identically(golden):
         assert torch.equal(p16, ar.flat_p16), step
         assert opt.in_backward.launched_in_backward >= 4, opt.in_backward.launched_in_backward
     assert losses[-1] < losses[0], losses
+
+
+# ---- round 5: NHWC activations between the convolutions (functional.NHWC; cfhip_groupnorm_nhwc_*, cfhip_upsample2_nhwc_*) -----------
+
+
+@pytest.mark.parametrize("b,c,h,w,groups,silu,with_add,per_sample", [
+    (2, 320, 16, 16, 32, True, True, False), (1, 640, 8, 8, 32, True, False, False), (3, 64, 5, 7, 32, False, True, False),
+    (1, 2560, 8, 8, 32, True, True, False), (2, 96, 12, 12, 32, True, False, True), (1, 1920, 4, 4, 32, False, False, False)])
+def test_groupnorm_on_nhwc_rows_vs_torch(b, c, h, w, groups, silu, with_add, per_sample):
+    """cfhip_groupnorm_nhwc_fwd / _bwd (nn.GroupNorm(32) [+ the time-embedding add in front, + SiLU behind] on the NHWC rows the
+    implicit-GEMM convolutions exchange): output, input gradient, dgamma / dbeta and the add's gradient against fp32 torch on the same
+    bf16-rounded input; 2 560 channels (two 8-channel slots per thread), 10 / 20 / 60 / 80 channels per group (groups that straddle the
+    8-channel slots), row counts that do not divide into the slices, one affine per sample (the scale-shift form)."""
+    torch.manual_seed(b * 1000 + c + h)
+    x = bf16_round(torch.randn(b, c, h, w) * 1.5 + 0.3)
+    gamma = torch.randn(b, c) if per_sample else torch.randn(c)
+    beta = torch.randn(b, c) if per_sample else torch.randn(c)
+    add = torch.randn(b, c) * 0.5 if with_add else None
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ar = None if add is None else add.clone().requires_grad_(True)
+    z = xr if ar is None else xr + ar[:, :, None, None]
+    zn = torch.nn.functional.group_norm(z, groups, None, None, 1e-5)
+    want = zn * (gr[:, :, None, None] if per_sample else gr[None, :, None, None]) + (br[:, :, None, None] if per_sample else br[None, :, None, None])
+    if silu:
+        want = torch.nn.functional.silu(want)
+    rows = x.permute(0, 2, 3, 1).reshape(b * h * w, c).to(torch.bfloat16).to(DEV).contiguous()
+    y, mean, rstd = ops.groupnorm_nhwc_fwd(rows, b, gamma.to(DEV), beta.to(DEV), groups, 1e-5, add=None if add is None else add.to(DEV), silu=silu)
+    got = y.float().cpu().view(b, h, w, c).permute(0, 3, 1, 2)
+    assert_close(got, want.detach(), 6e-3, "NHWC GroupNorm forward")
+    gy = bf16_round(torch.randn(want.shape))
+    want.backward(gy)
+    dy_rows = gy.permute(0, 2, 3, 1).reshape(b * h * w, c).to(torch.bfloat16).to(DEV).contiguous()
+    dx, dg, db, dadd = ops.groupnorm_nhwc_bwd(dy_rows, rows, b, gamma.to(DEV), beta.to(DEV), mean, rstd, groups,
+                                              add=None if add is None else add.to(DEV), silu=silu)
+    assert_close(dx.float().cpu().view(b, h, w, c).permute(0, 3, 1, 2), xr.grad, 8e-3, "dx")
+    if per_sample:
+        assert_close(dg, gr.grad, 2e-4, "dgamma [B, C]")
+        assert_close(db, br.grad, 2e-4, "dbeta [B, C]")
+    else:
+        assert_close(dg.sum(0), gr.grad, 2e-4, "dgamma")
+        assert_close(db.sum(0), br.grad, 2e-4, "dbeta")
+    if add is not None:
+        assert_close(dadd, ar.grad, 1e-2, "dadd")  # (a sum of bf16-rounded dx values on our side)
+    # deterministic: a second launch gives the same bits
+    y2, _, _ = ops.groupnorm_nhwc_fwd(rows, b, gamma.to(DEV), beta.to(DEV), groups, 1e-5, add=None if add is None else add.to(DEV), silu=silu)
+    assert torch.equal(y, y2)
+
+
+def test_upsample2_on_nhwc_rows_bit_exact():
+    torch.manual_seed(3)
+    for (b, c, h, w) in ((2, 320, 8, 8), (1, 8, 3, 5), (3, 64, 1, 4)):
+        x = bf16_round(torch.randn(b, c, h, w))
+        rows = x.permute(0, 2, 3, 1).reshape(b * h * w, c).to(torch.bfloat16).to(DEV).contiguous()
+        up = ops.upsample2_nhwc(rows, b, h, w)
+        assert torch.equal(up.float().cpu().view(b, 2 * h, 2 * w, c).permute(0, 3, 1, 2), UO.upsample2(x))
+        g = bf16_round(torch.randn(b, c, 2 * h, 2 * w))
+        grows = g.permute(0, 2, 3, 1).reshape(b * 4 * h * w, c).to(torch.bfloat16).to(DEV).contiguous()
+        dx = ops.upsample2_nhwc(grows, b, h, w, backward=True)
+        want = g.view(b, c, h, 2, w, 2).sum(dim=(3, 5))
+        assert_close(dx.float().cpu().view(b, h, w, c).permute(0, 3, 1, 2), want, 4e-3, "upsample2 nhwc bwd")
+
+
+def test_unet_nhwc_handover_matches_the_nchw_path(golden):
+    """functional.NHWC on (the default inside UNetDiffuser.forward) against off (the round-4 NCHW hand-over with its transposes) on the
+    small zoo-structured UNet: the same kernels for the convolutions and attention, the NHWC GroupNorm / up-sampling / concatenation /
+    residual-add forms in between — output and every parameter gradient agree to bf16 accumulation-order noise, and the NHWC run
+    launches no NCHW <-> NHWC transpose except around the stem, the strided down-sampling convolutions and the 3-channel head."""
+    from cflearn_amd import _lib
+
+    u = golden("unet_small.pt")
+    outs = []
+    for enabled in (False, True):
+        keep = HF.NHWC_ENABLED
+        HF.NHWC_ENABLED = enabled
+        try:
+            m = C.build_module("unet_diffuser", config=dict(u["cfg"]))
+            m.load_state_dict(u["sd"])
+            m = m.to(DEV)
+            calls = []
+            _lib.RECORDER = calls
+            try:
+                y = m(u["x"].to(DEV), timesteps=u["timesteps"].to(DEV), context=u["context"].to(DEV))
+                loss = torch.nn.functional.mse_loss(y.float(), u["noise"].to(DEV))
+                loss.backward()
+                HF.SideStream.join()
+            finally:
+                _lib.RECORDER = None
+            torch.cuda.synchronize()
+            n_t = sum(1 for e in calls if e[0] == 0 and getattr(e[1], "__name__", "") == "cfhip_transpose_batched")
+            outs.append((y.detach().float().cpu(), {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters()}, n_t, len(calls)))
+        finally:
+            HF.NHWC_ENABLED = keep
+    (y0, g0, t0, n0), (y1, g1, t1, n1) = outs
+    assert y1.shape == y0.shape and y1.is_contiguous()
+    assert_close(y1, y0, 1.5e-2, "output, NHWC vs NCHW hand-over")
+    for k in g0:
+        assert_close(g1[k], g0[k], 4e-2, f"gradient {k}")
+    print(f"transposes per forward + backward: NCHW hand-over {t0} of {n0} launches, NHWC {t1} of {n1}")
+    assert t1 <= t0 // 4 and n1 < n0, (t0, t1, n0, n1)
