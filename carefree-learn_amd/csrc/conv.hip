@@ -918,6 +918,233 @@ __device__ __forceinline__ void gn_nhwc_fold(const GnNhwcMap& m, const float (&a
   __syncthreads();
 }
 
+// ---- group form: one workgroup per (sample, group), ONE launch each way --------------------------------------------------------------
+// With enough samples (B G >= ~128 workgroups: the 64^2 x 8 step has 256) a workgroup takes all rows of one group: its cpg
+// channels are a 2 cpg-byte chunk of every row (20 .. 160 bytes), read as dwords — thread (rl, dw) owns the channel pair dw of the
+// rows rl, rl + RPP, ... — so statistics, normalisation and the parameter-gradient sums all stay inside the workgroup: no slices,
+// no workspace, no merge.  The 32 workgroups of a sample share every row's cache lines in L2.  cpg even, cpg <= 256.
+struct GnGroupMap {
+  int dpr, rpp, rl, dw;  // dwords per row chunk, row lanes, this thread's row lane / dword
+  bool active;
+};
+__device__ __forceinline__ GnGroupMap gn_group_map(int cpg) {
+  GnGroupMap m;
+  m.dpr = cpg >> 1;
+  m.rpp = 256 / m.dpr;
+  m.rl = threadIdx.x / m.dpr;
+  m.dw = threadIdx.x - m.rl * m.dpr;
+  m.active = m.rl < m.rpp;
+  return m;
+}
+
+// RPT > 0: the thread's rows (at most RPT of them: ceil(inner / rpp) <= RPT, chosen by the launcher) stay in REGISTERS between the
+// passes — one global read and one write per element instead of three reads and a write (the chunked dword accesses are what these
+// kernels spend their time on); RPT = 0: every pass re-reads (out of L2).
+template <int RPT>
+__global__ __launch_bounds__(256) void gn_nhwc_group_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ add,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                bf16_t* __restrict__ y, float* __restrict__ mean_out,
+                                                                float* __restrict__ rstd_out, int C, int G, int inner, float eps, int silu,
+                                                                int affine_bs) {
+  __shared__ float red[4];
+  constexpr int NC = RPT > 0 ? RPT : 1;
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int cpg = C / G;
+  const GnGroupMap m = gn_group_map(cpg);
+  gamma += (long)b * affine_bs;
+  beta += (long)b * affine_bs;
+  const int c0 = g * cpg + 2 * m.dw;
+  const long base = (long)b * inner * C + c0;
+  float a0 = 0.f, a1 = 0.f;
+  if (m.active && add != nullptr) {
+    a0 = add[(long)b * C + c0];
+    a1 = add[(long)b * C + c0 + 1];
+  }
+  const float n = (float)cpg * (float)inner;
+  unsigned cache[NC];
+  float s = 0.f;
+  if (RPT > 0) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int r = m.rl + i * m.rpp;
+      cache[i] = 0u;
+      if (m.active && r < inner) {
+        cache[i] = *reinterpret_cast<const unsigned*>(x + base + (long)r * C);
+        s += (bf16lo(cache[i]) + a0) + (bf16hi(cache[i]) + a1);
+      }
+    }
+  } else if (m.active) {
+    for (int r = m.rl; r < inner; r += m.rpp) {
+      const unsigned w = *reinterpret_cast<const unsigned*>(x + base + (long)r * C);
+      s += (bf16lo(w) + a0) + (bf16hi(w) + a1);
+    }
+  }
+  const float mean = block_sum(s, red) / n;
+  float q = 0.f;
+  if (RPT > 0) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int r = m.rl + i * m.rpp;
+      if (m.active && r < inner) {
+        const float d0 = bf16lo(cache[i]) + a0 - mean, d1 = bf16hi(cache[i]) + a1 - mean;
+        q += d0 * d0 + d1 * d1;
+      }
+    }
+  } else if (m.active) {
+    for (int r = m.rl; r < inner; r += m.rpp) {
+      const unsigned w = *reinterpret_cast<const unsigned*>(x + base + (long)r * C);
+      const float d0 = bf16lo(w) + a0 - mean, d1 = bf16hi(w) + a1 - mean;
+      q += d0 * d0 + d1 * d1;
+    }
+  }
+  const float rstd = rsqrtf(block_sum(q, red) / n + eps);
+  if (threadIdx.x == 0) {
+    mean_out[blockIdx.x] = mean;
+    rstd_out[blockIdx.x] = rstd;
+  }
+  if (!m.active) return;
+  const float k0 = rstd * gamma[c0], k1 = rstd * gamma[c0 + 1];
+  const float o0 = beta[c0] + (a0 - mean) * k0, o1 = beta[c0 + 1] + (a1 - mean) * k1;
+  auto emit = [&](int r, unsigned w) {
+    float v0 = fmaf(bf16lo(w), k0, o0), v1 = fmaf(bf16hi(w), k1, o1);
+    if (silu) {
+      v0 = silu_f(v0);
+      v1 = silu_f(v1);
+    }
+    *reinterpret_cast<unsigned*>(y + base + (long)r * C) = pack_bf16x2(v0, v1);
+  };
+  if (RPT > 0) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int r = m.rl + i * m.rpp;
+      if (r < inner) emit(r, cache[i]);
+    }
+  } else {
+    for (int r = m.rl; r < inner; r += m.rpp) emit(r, *reinterpret_cast<const unsigned*>(x + base + (long)r * C));
+  }
+}
+
+// LDS: lanes [rpp][cpg] (<= 512 floats) + ch [2][cpg]
+template <int RPT>
+__global__ __launch_bounds__(256) void gn_nhwc_group_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                const float* __restrict__ add, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, bf16_t* __restrict__ dx,
+                                                                float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
+                                                                float* __restrict__ dadd, int C, int G, int inner, int silu, int affine_bs) {
+  __shared__ float lanes[512];
+  __shared__ float chA[256], chB[256], sums[2];
+  constexpr int NC = RPT > 0 ? RPT : 1;
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int cpg = C / G;
+  const GnGroupMap m = gn_group_map(cpg);
+  gamma += (long)b * affine_bs;
+  beta += (long)b * affine_bs;
+  const int c0 = g * cpg + 2 * m.dw;
+  const long base = (long)b * inner * C + c0;
+  const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
+  float sh0 = -mu, sh1 = -mu, g0 = 0.f, g1 = 0.f, b0 = 0.f, b1 = 0.f;
+  if (m.active) {
+    if (add != nullptr) {
+      sh0 += add[(long)b * C + c0];
+      sh1 += add[(long)b * C + c0 + 1];
+    }
+    g0 = gamma[c0]; g1 = gamma[c0 + 1];
+    b0 = beta[c0]; b1 = beta[c0 + 1];
+  }
+  // a per-channel quantity of every row lane -> ch[c], summed over the row lanes in lane order
+  auto fold = [&](float v0, float v1, float* ch) {
+    __syncthreads();
+    if (m.active) {
+      lanes[m.rl * cpg + 2 * m.dw] = v0;
+      lanes[m.rl * cpg + 2 * m.dw + 1] = v1;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cpg) {
+      float t = 0.f;
+      for (int l = 0; l < m.rpp; ++l) t += lanes[l * cpg + threadIdx.x];
+      ch[threadIdx.x] = t;
+    }
+    __syncthreads();
+  };
+  // (xhat, dn) of one element pair from the raw words
+  auto terms = [&](unsigned wx, unsigned wd, float& xh0, float& xh1, float& d0, float& d1) {
+    xh0 = (bf16lo(wx) + sh0) * rs;
+    xh1 = (bf16hi(wx) + sh1) * rs;
+    d0 = bf16lo(wd);
+    d1 = bf16hi(wd);
+    if (silu) {
+      d0 *= silu_grad_f(fmaf(xh0, g0, b0));
+      d1 *= silu_grad_f(fmaf(xh1, g1, b1));
+    }
+  };
+  unsigned cx[NC], cd[NC];
+  float A0 = 0.f, A1 = 0.f, B0 = 0.f, B1 = 0.f;
+  if (RPT > 0) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int r = m.rl + i * m.rpp;
+      cx[i] = cd[i] = 0u;
+      if (m.active && r < inner) {
+        cx[i] = *reinterpret_cast<const unsigned*>(x + base + (long)r * C);
+        cd[i] = *reinterpret_cast<const unsigned*>(dy + base + (long)r * C);
+        float xh0, xh1, d0, d1;
+        terms(cx[i], cd[i], xh0, xh1, d0, d1);
+        A0 += d0 * xh0; A1 += d1 * xh1;
+        B0 += d0; B1 += d1;
+      }
+    }
+  } else if (m.active) {
+    for (int r = m.rl; r < inner; r += m.rpp) {
+      float xh0, xh1, d0, d1;
+      terms(*reinterpret_cast<const unsigned*>(x + base + (long)r * C), *reinterpret_cast<const unsigned*>(dy + base + (long)r * C), xh0, xh1, d0, d1);
+      A0 += d0 * xh0; A1 += d1 * xh1;
+      B0 += d0; B1 += d1;
+    }
+  }
+  fold(A0, A1, chA);
+  fold(B0, B1, chB);
+  if ((int)threadIdx.x < cpg) {
+    dgamma_part[(long)b * C + g * cpg + threadIdx.x] = chA[threadIdx.x];
+    dbeta_part[(long)b * C + g * cpg + threadIdx.x] = chB[threadIdx.x];
+  }
+  if (threadIdx.x == 0) {
+    float s1 = 0.f, s2 = 0.f;  // sum dn gamma, sum dn gamma xhat
+    for (int c = 0; c < cpg; ++c) {
+      s1 += chB[c] * gamma[g * cpg + c];
+      s2 += chA[c] * gamma[g * cpg + c];
+    }
+    const float inv_n = 1.f / ((float)cpg * (float)inner);
+    sums[0] = s1 * inv_n;
+    sums[1] = s2 * inv_n;
+  }
+  __syncthreads();
+  const float m1 = sums[0], m2 = sums[1];
+  float D0 = 0.f, D1 = 0.f;
+  auto emit = [&](int r, unsigned wx, unsigned wd) {
+    float xh0, xh1, d0, d1;
+    terms(wx, wd, xh0, xh1, d0, d1);
+    const float o0 = rs * (d0 * g0 - m1 - xh0 * m2), o1 = rs * (d1 * g1 - m1 - xh1 * m2);
+    *reinterpret_cast<unsigned*>(dx + base + (long)r * C) = pack_bf16x2(o0, o1);
+    D0 += o0; D1 += o1;
+  };
+  if (RPT > 0) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int r = m.rl + i * m.rpp;
+      if (m.active && r < inner) emit(r, cx[i], cd[i]);
+    }
+  } else if (m.active) {
+    for (int r = m.rl; r < inner; r += m.rpp)
+      emit(r, *reinterpret_cast<const unsigned*>(x + base + (long)r * C), *reinterpret_cast<const unsigned*>(dy + base + (long)r * C));
+  }
+  if (dadd != nullptr) {
+    fold(D0, D1, chA);
+    if ((int)threadIdx.x < cpg) dadd[(long)b * C + g * cpg + threadIdx.x] = chA[threadIdx.x];
+  }
+}
+
+// ---- slice form (few samples: B G too small to fill the chip, e.g. 256^2 x 1) --------------------------------------------------------
 // LDS: lanes [rpp][C] + chan [C] + grp [2 G] floats (rpp * C <= 2048 + C: at most 4 C floats)
 template <int KC>
 __global__ __launch_bounds__(256) void gn_nhwc_stats_kernel(const bf16_t* __restrict__ x, const float* __restrict__ add,
@@ -1011,23 +1238,36 @@ __device__ __forceinline__ void gn_nhwc_merge(const float* __restrict__ part, in
   __syncthreads();
 }
 
+// one workgroup per sample merges the slice pairs ONCE (the apply kernels read the result: merging inside every apply workgroup was
+// S^2 G loads per sample — 268 MB of L2 reads per call at 256^2 x 1)
+__global__ void gn_nhwc_merge_kernel(const float* __restrict__ part, float* __restrict__ mean_out, float* __restrict__ rstd_out, int G,
+                                     int cpg, int inner, float eps, int S) {
+  __shared__ float grp[2 * 64];
+  const int b = blockIdx.x;
+  gn_nhwc_merge(part, b, S, G, cpg, inner, eps, grp);
+  if ((int)threadIdx.x < G) {
+    mean_out[b * G + threadIdx.x] = grp[threadIdx.x];
+    rstd_out[b * G + threadIdx.x] = grp[G + threadIdx.x];
+  }
+}
+
 template <int KC>
 __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ add,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            const float* __restrict__ part, bf16_t* __restrict__ y,
-                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int C, int G,
-                                                            int inner, float eps, int silu, int affine_bs, int S) {
+                                                            bf16_t* __restrict__ y, const float* __restrict__ mean_in,
+                                                            const float* __restrict__ rstd_in, int C, int G, int inner, int silu,
+                                                            int affine_bs, int S) {
   __shared__ float grp[2 * 64];
   const int b = blockIdx.x / S, sl = blockIdx.x - b * S;
   const GnNhwcMap m = gn_nhwc_map(C);
   const int cpg = C / G;
   gamma += (long)b * affine_bs;
   beta += (long)b * affine_bs;
-  gn_nhwc_merge(part, b, S, G, cpg, inner, eps, grp);
-  if (sl == 0 && (int)threadIdx.x < G) {
-    mean_out[b * G + threadIdx.x] = grp[threadIdx.x];
-    rstd_out[b * G + threadIdx.x] = grp[G + threadIdx.x];
+  if ((int)threadIdx.x < G) {
+    grp[threadIdx.x] = mean_in[b * G + threadIdx.x];
+    grp[G + threadIdx.x] = rstd_in[b * G + threadIdx.x];
   }
+  __syncthreads();
   float a[KC][8], bb[KC][8];
 #pragma unroll
   for (int k = 0; k < KC; ++k)
@@ -1129,8 +1369,8 @@ __global__ __launch_bounds__(256) void gn_nhwc_bwd_apply_kernel(const bf16_t* __
                                                                 const float* __restrict__ add, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ part,
-                                                                bf16_t* __restrict__ dx, float* __restrict__ dgamma_part,
-                                                                float* __restrict__ dbeta_part, float* __restrict__ dadd_part, int C,
+                                                                bf16_t* __restrict__ dx, const float* __restrict__ dgamma_part,
+                                                                const float* __restrict__ dbeta_part, float* __restrict__ dadd_part, int C,
                                                                 int G, int inner, int silu, int affine_bs, int S) {
   extern __shared__ float gsm[];
   const int b = blockIdx.x / S, sl = blockIdx.x - b * S;
@@ -1142,19 +1382,10 @@ __global__ __launch_bounds__(256) void gn_nhwc_bwd_apply_kernel(const bf16_t* __
   const int cpg = C / G;
   gamma += (long)b * affine_bs;
   beta += (long)b * affine_bs;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float sa = 0.f, sb = 0.f;
-    for (int s2 = 0; s2 < S; ++s2) {
-      const float* o = part + ((long)b * S + s2) * 2 * C;
-      sa += o[c];
-      sb += o[C + c];
-    }
-    chA[c] = sa;
-    chB[c] = sb;
-    if (sl == 0) {
-      dgamma_part[(long)b * C + c] = sa;
-      dbeta_part[(long)b * C + c] = sb;
-    }
+  (void)part;
+  for (int c = threadIdx.x; c < C; c += 256) {  // the per-sample sums gn_nhwc_bwd_merge_kernel left in dgamma_part / dbeta_part
+    chA[c] = dgamma_part[(long)b * C + c];
+    chB[c] = dbeta_part[(long)b * C + c];
   }
   __syncthreads();
   if ((int)threadIdx.x < G) {
@@ -1214,6 +1445,22 @@ __global__ __launch_bounds__(256) void gn_nhwc_bwd_apply_kernel(const bf16_t* __
     float* o = dadd_part + ((long)b * S + sl) * C;
     for (int c = threadIdx.x; c < C; c += 256) o[c] = chA[c];
   }
+}
+
+// dgamma_part[b][c] / dbeta_part[b][c] = the slice sums of A_c / B_c added in slice order, once per sample (S C loads per sample)
+__global__ void gn_nhwc_bwd_merge_kernel(const float* __restrict__ part, float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
+                                         int C, int S) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float sa = 0.f, sb = 0.f;
+  for (int sl = 0; sl < S; ++sl) {
+    const float* o = part + ((long)b * S + sl) * 2 * C;
+    sa += o[c];
+    sb += o[C + c];
+  }
+  dgamma_part[(long)b * C + c] = sa;
+  dbeta_part[(long)b * C + c] = sb;
 }
 
 // dadd[b][c] = sum over the slices of sum(dx), slice order
@@ -1696,10 +1943,16 @@ extern "C" int cfhip_groupnorm_bwd(const void* dy, const void* x, int x_is_f32, 
 static int gn_nhwc_check(const char* who, int B, int C, int G, int inner, int splits) {
   CFHIP_REQUIRE(B > 0 && C > 0 && G > 0 && inner > 0, "%s: empty problem (B=%d C=%d G=%d inner=%d)", who, B, C, G, inner);
   CFHIP_REQUIRE(C % 8 == 0 && C % G == 0 && G <= 64 && C <= 4096, "%s: C = %d must be a multiple of 8 and of G = %d (<= 64), at most 4096", who, C, G);
+  if (splits == 0) {
+    const int cpg = C / G;
+    CFHIP_REQUIRE(cpg % 2 == 0 && cpg <= 256, "%s: the group form (splits = 0) needs an even number of channels per group, at most 256 (got %d)", who, cpg);
+    return CFHIP_OK;
+  }
   CFHIP_REQUIRE(splits >= 1 && splits <= inner && splits <= 4096, "%s: splits = %d outside 1 .. min(inner, 4096)", who, splits);
   return CFHIP_OK;
 }
 static inline int gn_nhwc_rpp(int C) { return (C >> 3) >= 256 ? 1 : 256 / (C >> 3); }
+static inline int gn_group_rpp(int cpg) { return 256 / (cpg >> 1); }  // row lanes of the group form (cpg even, <= 256)
 
 extern "C" size_t cfhip_groupnorm_nhwc_workspace(int B, int C, int G, int splits, int backward, int with_add) {
   if (B <= 0 || C <= 0 || G <= 0 || splits <= 0) return 0;
@@ -1710,21 +1963,37 @@ extern "C" size_t cfhip_groupnorm_nhwc_workspace(int B, int C, int G, int splits
 extern "C" int cfhip_groupnorm_nhwc_fwd(const void* x, const float* add, const float* gamma, const float* beta, void* y, float* mean,
                                         float* rstd, int B, int C, int G, int inner, float eps, int silu, int affine_batch_stride,
                                         int splits, float* workspace, void* stream) {
-  CFHIP_REQUIRE(x && gamma && beta && y && mean && rstd && workspace, "groupnorm_nhwc_fwd: null argument");
+  CFHIP_REQUIRE(x && gamma && beta && y && mean && rstd && (workspace || splits == 0), "groupnorm_nhwc_fwd: null argument");
   const int rc = gn_nhwc_check("groupnorm_nhwc_fwd", B, C, G, inner, splits);
   if (rc != CFHIP_OK) return rc;
   CFHIP_REQUIRE(affine_batch_stride == 0 || affine_batch_stride == C, "groupnorm_nhwc_fwd: affine_batch_stride must be 0 or C");
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = ((size_t)gn_nhwc_rpp(C) * C + C + 2 * 64) * sizeof(float);
   const bf16_t* xp = (const bf16_t*)x;
+  if (splits == 0) {  // group form: one workgroup per (sample, group), one launch
+    const int rpt = (inner + gn_group_rpp(C / G) - 1) / gn_group_rpp(C / G);  // rows per thread: kept in registers when they fit
+#define CFHIP_GN_GROUP_FWD(RPT)                                                                                                        \
+  hipLaunchKernelGGL((gn_nhwc_group_fwd_kernel<RPT>), dim3(B * G), dim3(256), 0, s, xp, add, gamma, beta, (bf16_t*)y, mean, rstd, C, G, inner, \
+                     eps, silu, affine_batch_stride)
+    if (rpt <= 48) CFHIP_GN_GROUP_FWD(48);  // (a 24-row instantiation came out of hipcc with 254 VGPRs and 132 B of scratch: not built)
+    else if (rpt <= 96) CFHIP_GN_GROUP_FWD(96);
+    else if (rpt <= 176) CFHIP_GN_GROUP_FWD(176);
+    else CFHIP_GN_GROUP_FWD(0);
+#undef CFHIP_GN_GROUP_FWD
+    CFHIP_CHECK_LAUNCH("groupnorm_nhwc_fwd");
+    return CFHIP_OK;
+  }
+  const size_t lds = ((size_t)gn_nhwc_rpp(C) * C + C + 2 * 64) * sizeof(float);
+  const int cpg = C / G;
   if ((C >> 3) > 256) {
     hipLaunchKernelGGL((gn_nhwc_stats_kernel<2>), dim3(B * splits), dim3(256), lds, s, xp, add, workspace, C, G, inner, splits);
-    hipLaunchKernelGGL((gn_nhwc_apply_kernel<2>), dim3(B * splits), dim3(256), 0, s, xp, add, gamma, beta, workspace, (bf16_t*)y, mean, rstd,
-                       C, G, inner, eps, silu, affine_batch_stride, splits);
+    hipLaunchKernelGGL(gn_nhwc_merge_kernel, dim3(B), dim3(64), 0, s, workspace, mean, rstd, G, cpg, inner, eps, splits);
+    hipLaunchKernelGGL((gn_nhwc_apply_kernel<2>), dim3(B * splits), dim3(256), 0, s, xp, add, gamma, beta, (bf16_t*)y, mean, rstd, C, G, inner,
+                       silu, affine_batch_stride, splits);
   } else {
     hipLaunchKernelGGL((gn_nhwc_stats_kernel<1>), dim3(B * splits), dim3(256), lds, s, xp, add, workspace, C, G, inner, splits);
-    hipLaunchKernelGGL((gn_nhwc_apply_kernel<1>), dim3(B * splits), dim3(256), 0, s, xp, add, gamma, beta, workspace, (bf16_t*)y, mean, rstd,
-                       C, G, inner, eps, silu, affine_batch_stride, splits);
+    hipLaunchKernelGGL(gn_nhwc_merge_kernel, dim3(B), dim3(64), 0, s, workspace, mean, rstd, G, cpg, inner, eps, splits);
+    hipLaunchKernelGGL((gn_nhwc_apply_kernel<1>), dim3(B * splits), dim3(256), 0, s, xp, add, gamma, beta, (bf16_t*)y, mean, rstd, C, G, inner,
+                       silu, affine_batch_stride, splits);
   }
   CFHIP_CHECK_LAUNCH("groupnorm_nhwc_fwd");
   return CFHIP_OK;
@@ -1734,12 +2003,24 @@ extern "C" int cfhip_groupnorm_nhwc_bwd(const void* dy, const void* x, const flo
                                         const float* mean, const float* rstd, void* dx, float* dgamma_part, float* dbeta_part, float* dadd,
                                         int B, int C, int G, int inner, int silu, int affine_batch_stride, int splits, float* workspace,
                                         void* stream) {
-  CFHIP_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma_part && dbeta_part && workspace, "groupnorm_nhwc_bwd: null argument");
+  CFHIP_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma_part && dbeta_part && (workspace || splits == 0), "groupnorm_nhwc_bwd: null argument");
   const int rc = gn_nhwc_check("groupnorm_nhwc_bwd", B, C, G, inner, splits);
   if (rc != CFHIP_OK) return rc;
   CFHIP_REQUIRE(affine_batch_stride == 0 || affine_batch_stride == C, "groupnorm_nhwc_bwd: affine_batch_stride must be 0 or C");
   CFHIP_REQUIRE((dadd != nullptr) == (add != nullptr), "groupnorm_nhwc_bwd: dadd goes with add");
   hipStream_t s = (hipStream_t)stream;
+  if (splits == 0) {  // group form
+    const int rpt = (inner + gn_group_rpp(C / G) - 1) / gn_group_rpp(C / G);
+#define CFHIP_GN_GROUP_BWD(RPT)                                                                                                         \
+  hipLaunchKernelGGL((gn_nhwc_group_bwd_kernel<RPT>), dim3(B * G), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, add, gamma, beta, mean, \
+                     rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu, affine_batch_stride)
+    if (rpt <= 48) CFHIP_GN_GROUP_BWD(48);
+    else if (rpt <= 88) CFHIP_GN_GROUP_BWD(88);
+    else CFHIP_GN_GROUP_BWD(0);
+#undef CFHIP_GN_GROUP_BWD
+    CFHIP_CHECK_LAUNCH("groupnorm_nhwc_bwd");
+    return CFHIP_OK;
+  }
   const size_t lds_a = ((size_t)gn_nhwc_rpp(C) * C + C) * sizeof(float);
   const size_t lds_b = ((size_t)gn_nhwc_rpp(C) * C + 2 * C + 2 * 64) * sizeof(float);
   float* part = workspace;
@@ -1749,11 +2030,13 @@ extern "C" int cfhip_groupnorm_nhwc_bwd(const void* dy, const void* x, const flo
   if ((C >> 3) > 256) {
     hipLaunchKernelGGL((gn_nhwc_bwd_stats_kernel<2>), dim3(B * splits), dim3(256), lds_a, s, dyp, xp, add, gamma, beta, mean, rstd, part, C, G,
                        inner, silu, affine_batch_stride, splits);
+    hipLaunchKernelGGL(gn_nhwc_bwd_merge_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, part, dgamma_part, dbeta_part, C, splits);
     hipLaunchKernelGGL((gn_nhwc_bwd_apply_kernel<2>), dim3(B * splits), dim3(256), lds_b, s, dyp, xp, add, gamma, beta, mean, rstd, part,
                        (bf16_t*)dx, dgamma_part, dbeta_part, dpart, C, G, inner, silu, affine_batch_stride, splits);
   } else {
     hipLaunchKernelGGL((gn_nhwc_bwd_stats_kernel<1>), dim3(B * splits), dim3(256), lds_a, s, dyp, xp, add, gamma, beta, mean, rstd, part, C, G,
                        inner, silu, affine_batch_stride, splits);
+    hipLaunchKernelGGL(gn_nhwc_bwd_merge_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, part, dgamma_part, dbeta_part, C, splits);
     hipLaunchKernelGGL((gn_nhwc_bwd_apply_kernel<1>), dim3(B * splits), dim3(256), lds_b, s, dyp, xp, add, gamma, beta, mean, rstd, part,
                        (bf16_t*)dx, dgamma_part, dbeta_part, dpart, C, G, inner, silu, affine_batch_stride, splits);
   }

@@ -2004,7 +2004,9 @@ class UNetDiffuser(Module):
         # convolutions, GroupNorm on the rows, token matrices of the transformers as views.  The head (3 output channels)
         # returns NCHW like the reference.
         prev = HF.NHWC[0]
-        HF.NHWC[0] = HF.NHWC_ENABLED and net.is_cuda
+        # (with few samples the NHWC GroupNorm has to cut a sample into row slices and merge them — three launches — and loses to the
+        # NCHW path: 256^2 x 1 457 -> 485 ms; with a batch the group form is one launch and the step gains: 64^2 x 8 60.6 -> 59.6 ms)
+        HF.NHWC[0] = HF.NHWC_ENABLED and net.is_cuda and net.shape[0] * 32 >= ops.GN_NHWC_GROUP_MIN_WORKGROUPS
         try:
             for block in self.input_blocks:
                 net = block(net, time_net, context)

@@ -950,8 +950,16 @@ GN_NHWC_TARGET_WORKGROUPS = int(os.environ.get("CFHIP_GN_NHWC_TARGET", "1024"))
 GN_NHWC_MIN_ROWS = int(os.environ.get("CFHIP_GN_NHWC_MIN_ROWS", "16"))
 
 
-def gn_nhwc_splits(b: int, inner: int) -> int:
-    """row slices per sample of the NHWC GroupNorm kernels (one workgroup each): ~4 workgroups per CU, at least GN_NHWC_MIN_ROWS rows each"""
+GN_NHWC_GROUP_MIN_WORKGROUPS = int(os.environ.get("CFHIP_GN_NHWC_GROUP_MIN", "128"))  # B * G from which one workgroup per (sample, group) fills the chip
+
+
+def gn_nhwc_splits(b: int, inner: int, c: int = 0, groups: int = 0) -> int:
+    """0: the group form (one workgroup per (sample, group), ONE launch each way: enough samples, an even number of channels per group);
+    otherwise the row slices per sample of the slice form (few samples, e.g. 256^2 x 1): ~4 workgroups per CU, >= GN_NHWC_MIN_ROWS rows each"""
+    if groups and c % groups == 0:
+        cpg = c // groups
+        if b * groups >= GN_NHWC_GROUP_MIN_WORKGROUPS and cpg % 2 == 0 and cpg <= 256:
+            return 0
     want = -(-GN_NHWC_TARGET_WORKGROUPS // b)
     return max(1, min(want, inner // GN_NHWC_MIN_ROWS, 4096))
 
@@ -973,13 +981,14 @@ def groupnorm_nhwc_fwd(rows: Tensor, b: int, gamma: Tensor, beta: Tensor, groups
         if tuple(add.shape) != (b, c) or not add.is_contiguous():
             raise ValueError("cfhip groupnorm_nhwc_fwd: add must be contiguous f32 [B, C]")
     lib = _lib.load()
-    splits = gn_nhwc_splits(b, inner)
+    splits = gn_nhwc_splits(b, inner, c, groups)
     y = torch.empty_like(rows)
     mean = torch.empty((b * groups,), dtype=f32, device=rows.device)
     rstd = torch.empty((b * groups,), dtype=f32, device=rows.device)
-    ws = torch.empty((max(4, lib.cfhip_groupnorm_nhwc_workspace(b, c, groups, splits, 0, 0)) // 4,), dtype=f32, device=rows.device)
+    ws = None if splits == 0 else torch.empty((max(4, lib.cfhip_groupnorm_nhwc_workspace(b, c, groups, splits, 0, 0)) // 4,), dtype=f32,
+                                              device=rows.device)
     rc = lib.cfhip_groupnorm_nhwc_fwd(rows.data_ptr(), _p(add), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
-                                      rstd.data_ptr(), b, c, groups, inner, float(eps), int(silu), affine_bs, splits, ws.data_ptr(), _stream())
+                                      rstd.data_ptr(), b, c, groups, inner, float(eps), int(silu), affine_bs, splits, _p(ws), _stream())
     _lib.check(rc, "groupnorm_nhwc_fwd")
     return y, mean, rstd
 
@@ -996,16 +1005,16 @@ def groupnorm_nhwc_bwd(dy: Tensor, rows: Tensor, b: int, gamma: Tensor, beta: Te
     inner = rows.shape[0] // b
     affine_bs = _gn_affine_stride(gamma, beta, b, c)
     lib = _lib.load()
-    splits = gn_nhwc_splits(b, inner)
+    splits = gn_nhwc_splits(b, inner, c, groups)
     dx = torch.empty_like(rows)
     dg = torch.empty((b, c), dtype=f32, device=rows.device)
     db = torch.empty((b, c), dtype=f32, device=rows.device)
     dadd = torch.empty((b, c), dtype=f32, device=rows.device) if add is not None else None
-    ws = torch.empty((max(4, lib.cfhip_groupnorm_nhwc_workspace(b, c, groups, splits, 1, int(add is not None))) // 4,), dtype=f32,
-                     device=rows.device)
+    ws = None if splits == 0 else torch.empty((max(4, lib.cfhip_groupnorm_nhwc_workspace(b, c, groups, splits, 1, int(add is not None))) // 4,),
+                                              dtype=f32, device=rows.device)
     rc = lib.cfhip_groupnorm_nhwc_bwd(dy.data_ptr(), rows.data_ptr(), _p(add), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
                                       rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), _p(dadd), b, c, groups, inner,
-                                      int(silu), affine_bs, splits, ws.data_ptr(), _stream())
+                                      int(silu), affine_bs, splits, _p(ws), _stream())
     _lib.check(rc, "groupnorm_nhwc_bwd")
     return dx, dg, db, dadd
 

@@ -672,14 +672,19 @@ def test_ddpm_step_updates_inside_backward_bit_identically(golden):
 # ---- round 5: NHWC activations between the convolutions (functional.NHWC; cfhip_groupnorm_nhwc_*, cfhip_upsample2_nhwc_*) -----------
 
 
+@pytest.mark.parametrize("form", ["slices", "groups"])
 @pytest.mark.parametrize("b,c,h,w,groups,silu,with_add,per_sample", [
     (2, 320, 16, 16, 32, True, True, False), (1, 640, 8, 8, 32, True, False, False), (3, 64, 5, 7, 32, False, True, False),
     (1, 2560, 8, 8, 32, True, True, False), (2, 96, 12, 12, 32, True, False, True), (1, 1920, 4, 4, 32, False, False, False)])
-def test_groupnorm_on_nhwc_rows_vs_torch(b, c, h, w, groups, silu, with_add, per_sample):
+def test_groupnorm_on_nhwc_rows_vs_torch(b, c, h, w, groups, silu, with_add, per_sample, form, monkeypatch):
     """cfhip_groupnorm_nhwc_fwd / _bwd (nn.GroupNorm(32) [+ the time-embedding add in front, + SiLU behind] on the NHWC rows the
     implicit-GEMM convolutions exchange): output, input gradient, dgamma / dbeta and the add's gradient against fp32 torch on the same
     bf16-rounded input; 2 560 channels (two 8-channel slots per thread), 10 / 20 / 60 / 80 channels per group (groups that straddle the
     8-channel slots), row counts that do not divide into the slices, one affine per sample (the scale-shift form)."""
+    # both kernel families on every case: "groups" = one workgroup per (sample, group), one launch each way (what a batch of 8 takes);
+    # "slices" = row slices of a sample + merge (what 256^2 x 1 takes)
+    monkeypatch.setattr(ops, "GN_NHWC_GROUP_MIN_WORKGROUPS", 1 if form == "groups" else 1 << 30)
+    assert (ops.gn_nhwc_splits(b, h * w, c, groups) == 0) == (form == "groups" and (c // groups) % 2 == 0)  # (3 channels per group: slices)
     torch.manual_seed(b * 1000 + c + h)
     x = bf16_round(torch.randn(b, c, h, w) * 1.5 + 0.3)
     gamma = torch.randn(b, c) if per_sample else torch.randn(c)
@@ -717,6 +722,8 @@ def test_groupnorm_on_nhwc_rows_vs_torch(b, c, h, w, groups, silu, with_add, per
 
 
 def test_upsample2_on_nhwc_rows_bit_exact():
+    import unet_oracle as UO
+
     torch.manual_seed(3)
     for (b, c, h, w) in ((2, 320, 8, 8), (1, 8, 3, 5), (3, 64, 1, 4)):
         x = bf16_round(torch.randn(b, c, h, w))
@@ -730,13 +737,14 @@ def test_upsample2_on_nhwc_rows_bit_exact():
         assert_close(dx.float().cpu().view(b, h, w, c).permute(0, 3, 1, 2), want, 4e-3, "upsample2 nhwc bwd")
 
 
-def test_unet_nhwc_handover_matches_the_nchw_path(golden):
+def test_unet_nhwc_handover_matches_the_nchw_path(golden, monkeypatch):
     """functional.NHWC on (the default inside UNetDiffuser.forward) against off (the round-4 NCHW hand-over with its transposes) on the
     small zoo-structured UNet: the same kernels for the convolutions and attention, the NHWC GroupNorm / up-sampling / concatenation /
     residual-add forms in between — output and every parameter gradient agree to bf16 accumulation-order noise, and the NHWC run
     launches no NCHW <-> NHWC transpose except around the stem, the strided down-sampling convolutions and the 3-channel head."""
     from cflearn_amd import _lib
 
+    monkeypatch.setattr(ops, "GN_NHWC_GROUP_MIN_WORKGROUPS", 1)  # (the fixture's batch of 2 would otherwise keep the NCHW hand-over)
     u = golden("unet_small.pt")
     outs = []
     for enabled in (False, True):
@@ -763,7 +771,8 @@ def test_unet_nhwc_handover_matches_the_nchw_path(golden):
     (y0, g0, t0, n0), (y1, g1, t1, n1) = outs
     assert y1.shape == y0.shape and y1.is_contiguous()
     assert_close(y1, y0, 1.5e-2, "output, NHWC vs NCHW hand-over")
-    for k in g0:
-        assert_close(g1[k], g0[k], 4e-2, f"gradient {k}")
+    scale = max(float(v.abs().max()) for v in g0.values())
+    for k in g0:  # (a convolution bias in front of a GroupNorm has a gradient of rounding noise: absolute floor)
+        assert_close(g1[k], g0[k], 4e-2, f"gradient {k}", abs_floor=2e-3 * scale)
     print(f"transposes per forward + backward: NCHW hand-over {t0} of {n0} launches, NHWC {t1} of {n1}")
     assert t1 <= t0 // 4 and n1 < n0, (t0, t1, n0, n1)
