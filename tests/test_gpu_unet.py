@@ -12,6 +12,24 @@ from helpers import assert_close, bf16_round
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda")
 
+# Tests that run a whole UNetDiffuser run twice (round 5): with the NCHW hand-over between modules (what a batch below 4 takes, e.g.
+# 256^2 x 1) and with the NHWC hand-over + group-form GroupNorm forced on (what 64^2 x 8 takes; the fixtures' batches of 1-2 would
+# not select it by themselves).
+_WHOLE_UNET = ("test_unet_diffuser_golden", "test_unet_variants_golden", "test_q_sample_bit_exact_mse_and_ddpm_train_step",
+               "test_gradient_checkpoint_matches_plain_backward", "test_ddpm_train_step_learned_log_var_and_labels",
+               "test_unet_zoo_full_size_step_vs_oracle", "test_ddpm_step_updates_inside_backward_bit_identically")
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.function.__name__ in _WHOLE_UNET:
+        metafunc.parametrize("handover", ["nchw", "nhwc"], indirect=True)
+
+
+@pytest.fixture
+def handover(request, monkeypatch):
+    monkeypatch.setattr(ops, "GN_NHWC_GROUP_MIN_WORKGROUPS", 1 if request.param == "nhwc" else 1 << 30)
+    return request.param
+
 
 @pytest.mark.parametrize("silu,with_add", [(False, False), (True, False), (True, True)])
 def test_groupnorm_kernel(silu, with_add):
@@ -200,7 +218,7 @@ def test_spatial_transformer_golden(golden):
         assert_close(p.grad, g["grads"][k], 4e-2, f"spatial transformer grad {k}", abs_floor=3e-3)
 
 
-def test_unet_diffuser_golden(golden):
+def test_unet_diffuser_golden(golden, handover):
     """The whole UNet (time embedding MLP, res blocks, spatial transformers with 8 / 16-channel heads and a context,
     strided-conv down-sampling, nearest up-sampling, skip concatenation, GroupNorm-SiLU-conv head) and the DDPM
     epsilon-prediction MSE step vs the reference's fp32 CPU run."""
@@ -225,7 +243,7 @@ def test_unet_diffuser_golden(golden):
     print(f"unet worst grad rel-L2 vs fp32 reference {worst:.3e}")
 
 
-def test_q_sample_bit_exact_mse_and_ddpm_train_step(golden):
+def test_q_sample_bit_exact_mse_and_ddpm_train_step(golden, handover):
     """DDPM forward process (bit-exact vs the reference's DDPMQSampler on fp32), the epsilon-prediction MSE kernel, and
     a few optimisation steps of the small UNet: the loss of a fixed (x, t, eps) goes down."""
     from cflearn_amd.diffusion import DDPMTrainStep, NoiseSchedule
@@ -282,7 +300,7 @@ def test_ddpm_train_step_as_a_hipgraph_matches_the_eager_step(golden):
         assert abs(a - b) <= 2e-3 * abs(b) + 1e-5, (losses[True], losses[False])
 
 
-def test_gradient_checkpoint_matches_plain_backward(golden):
+def test_gradient_checkpoint_matches_plain_backward(golden, handover):
     """Row U6 (reference toolkit.py:2535-2647, switched on by `use_checkpoint=True` in the zoo diffusion/ddpm config):
     the block is recomputed inside backward, i.e. every HIP Function in it is entered a second time under a
     re-entrant `torch.autograd.grad`, with parameter gradients written straight into `.grad`.  Same kernels on the
@@ -376,7 +394,7 @@ def test_scale_shift_residual_block_golden(golden):
 
 
 @pytest.mark.parametrize("case", [0, 1])
-def test_unet_variants_golden(golden, case):
+def test_unet_variants_golden(golden, case, handover):
     """(0) pixel self attention + ResBlock resampling + scale-shift norm + class labels; (1) spatial transformers with
     Linear projections + ControlNet residuals — output, DDPM loss and every parameter gradient vs the reference"""
     g = golden("unet_variants.pt")["unets"][case]
@@ -435,7 +453,7 @@ def test_ddpm_objectives_golden(golden):
             assert_close(v, want_v, 1e-6, "v target")
 
 
-def test_ddpm_train_step_learned_log_var_and_labels(golden):
+def test_ddpm_train_step_learned_log_var_and_labels(golden, handover):
     """a few steps of the class-conditional scale-shift UNet with the v objective, l1 loss and a trained log-variance:
     the loss goes down, log_var moves only at the drawn timesteps, every parameter stays finite"""
     from cflearn_amd.diffusion import DDPMTrainStep, NoiseSchedule
@@ -533,7 +551,7 @@ ZOO_SAMPLED = [
 ]
 
 
-def test_unet_zoo_full_size_step_vs_oracle():
+def test_unet_zoo_full_size_step_vs_oracle(handover):
     """The 865 M-parameter zoo UNet (zoo/configs/diffusion/ddpm/default.json: start 320, multipliers 1/2/4/4, SpatialTransformer at
     rates 1/2/4; multimodal/diffusion/unet.py:97-322, mixed_stacks/api.py:766-893, models/cv/diffusion.py:44-94) — the model
     bench.py times — at 64^2 x 1 from a seeded initialisation: output, epsilon-prediction MSE loss and 21 sampled parameter
@@ -638,7 +656,7 @@ def test_unet_zoo_full_size_step_vs_oracle():
         assert errs[k] <= max(1e-2, 1.1 * ref["grad_err"][k]) and errs[k] <= 8e-2, (k, errs[k], ref["grad_err"][k])
 
 
-def test_ddpm_step_updates_inside_backward_bit_identically(golden):
+def test_ddpm_step_updates_inside_backward_bit_identically(golden, handover):
     """DDPMTrainStep with the optimizer inside backward (optim.StepInBackward over the UNet's Conv2dFn / LinearFn / GroupNorm
     gradient notifications): after every step the parameters, moments and bf16 shadows equal ONE launch of the Adam kernel on
     the pre-step state and the gradients this backward left in the arena; ranges were launched from inside backward."""
