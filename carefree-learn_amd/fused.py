@@ -703,10 +703,23 @@ class MixingStackFn(Function):
     kernels per step), and the engine walks 1 node instead of 12."""
 
     @staticmethod
+    def _slices(metas: tuple, default: int) -> int:
+        """batch slices of this stack: the 5th meta entry when the owner set one (modules.MixedStackedEncoder.stack_slices — CLIP runs
+        its two towers side by side on two streams instead of two slices of one tower after the other), else the module default"""
+        m0 = metas[0]
+        return int(m0[4]) if len(m0) > 4 and m0[4] else default
+
+    @staticmethod
+    def _slices_bwd(metas: tuple, default: int) -> int:
+        m0 = metas[0]
+        return int(m0[5]) if len(m0) > 5 and m0[5] else MixingStackFn._slices(metas, default)
+
+    @staticmethod
     def _forward_body(cur: Tensor, bsz: int, t: int, metas: tuple, keep_mask: Optional[Tensor], causal: bool, params: tuple):
         nblk = len(metas)
         all_saved = []
         streams = None
+        FWD_HALVES = MixingStackFn._slices(metas, globals()["FWD_HALVES"])
         if FWD_HALVES > 1 and cur.is_cuda and bsz >= 2 * FWD_HALVES:
             # every bf16 weight shadow a slice will read is (re)cast HERE, on the caller's stream, BEFORE the side streams
             # fork: a stale shadow (weights stepped by a torch optimizer, first forward without a ParamArena) would
@@ -808,6 +821,7 @@ class MixingStackFn(Function):
     def _backward_body(all_saved: list, keep_mask: Optional[Tensor], bsz: int, t: int, metas: tuple, causal: bool, d2: Tensor,
                        params: tuple) -> Tensor:
         streams = None
+        BWD_HALVES = MixingStackFn._slices_bwd(metas, globals()["BWD_HALVES"])
         if BWD_HALVES > 1 and d2.is_cuda and bsz >= 2 * BWD_HALVES:
             main = _functional.cur_stream()
             # lane 1, 2, ...: lane 0 is the stream of the weight-gradient launches

@@ -968,8 +968,9 @@ class MixedStackedEncoder(Module):
                 and all(b.use_fused and b._fusable() for b in blocks)):
             # one autograd node for the whole stack (fused.MixingStackFn)
             metas, params = [], []
+            slices = getattr(self, "stack_slices", None)
             for b in blocks:
-                metas.append(b.fused_meta())
+                metas.append(b.fused_meta() + ((slices,) if isinstance(slices, int) and slices else tuple(slices) if slices else ()))
                 params.extend(b.fused_params())
             net = fused.mixing_stack(net, tuple(metas), None, causal, params)
         else:
@@ -1523,12 +1524,41 @@ class CLIP(Module):
 
         return similarity_logits(self.encode_image(image), self.encode_text(text), self.logit_scale)
 
+    # Round 5: the two towers are independent until the similarity matrix, and their kernels are small (ViT-B/32: 50 tokens, the text
+    # tower: 77 tokens x 512 channels — a half-batch GEMM is ~200 tiles for 512 slots).  `towers_side_by_side` runs the text tower on
+    # lane 1 while the image tower runs on the caller's stream, each as ONE batch pipeline (`stack_slices` = 1): two different kernel
+    # streams in flight instead of two slices of one tower after the other, half as many launches (profiles/r05/clip_towers_ab.txt).
+    towers_side_by_side = os.environ.get("CFHIP_CLIP_TOWERS", "1") != "0"
+
+    def _encode_both(self, image: Tensor, text: Tensor) -> Tuple[Tensor, Tensor]:
+        side = HF.SideStream.fork(1) if (self.towers_side_by_side and image.is_cuda and self.vit is not None
+                                         and self.text_transformer is not None and torch.is_grad_enabled()) else None
+        if side is None or side == HF.cur_stream():
+            return self.encode_image(image), self.encode_text(text)
+        main = HF.cur_stream()
+        keep = (self.vit.encoder.stack_slices if hasattr(self.vit.encoder, "stack_slices") else None,
+                getattr(self.text_transformer.encoder, "stack_slices", None))
+        # (forward slices, backward slices): in the forward the weight-gradient lane is idle, so the image tower may still take it for a
+        # second batch slice (CFHIP_CLIP_TOWERS=2: three forward pipelines); the backward keeps one pipeline per tower + the dW lane
+        self.vit.encoder.stack_slices = (2, 1) if os.environ.get("CFHIP_CLIP_TOWERS", "1") == "2" else 1
+        self.text_transformer.encoder.stack_slices = 1
+        try:
+            with HF.on_stream(side):
+                txt = self.encode_text(text)
+            img = self.encode_image(image)
+        finally:
+            self.vit.encoder.stack_slices, self.text_transformer.encoder.stack_slices = keep
+        HF.rec_wait_stream(main, side)
+        txt.record_stream(main)  # allocated under lane 1, consumed on the caller's stream
+        return img, txt
+
     def contrastive_loss(self, image: Tensor, text: Tensor, group: Any = None) -> Tensor:
         """Symmetric InfoNCE over the local batch against the embeddings of every rank (contrastive.py; the
         reference has no training loss for CLIP: new design, parity unpinned)."""
         from .contrastive import clip_contrastive_loss
 
-        return clip_contrastive_loss(self.encode_image(image), self.encode_text(text), self.logit_scale, group)
+        img, txt = self._encode_both(image, text)
+        return clip_contrastive_loss(img, txt, self.logit_scale, group)
 
 
 # ---------------------------------------------------------------------------------------------
