@@ -1308,8 +1308,11 @@ constexpr int A2_TILE = A2_CH * 128;
 // is then that of the bf16-rounded probabilities, i.e. of exactly what multiplied V.
 // Both forms skip the rescale of O when no row of the wave raised its running maximum in this block (alpha == 1 for all 32
 // rows — the common case after the first few blocks of a long sequence): a wave-uniform branch around 12-16 v_pk_mul_f32.
+#ifndef CFHIP_ATTN_NDT4_WAVES
+#define CFHIP_ATTN_NDT4_WAVES 4  // waves per SIMD of the head_dim-64 (NDT = 4) long-sequence forms: 4 keeps 12-36 B of scratch, 3 has none (A/B: profiles/r05)
+#endif
 template <bool PLAIN, int NDT, bool SUMCOL = false>
-__global__ __launch_bounds__(512, 4) void attn_fwd2_kernel(AttnParams p) {
+__global__ __launch_bounds__(512, NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4) void attn_fwd2_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + A2_TILE;
@@ -1475,7 +1478,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd2_kernel(AttnParams p) {
 // (masked / causal instantiations: the predicate registers do not fit beside two 16-row tiles at 128 registers — two waves per
 // SIMD for them, no scratch; PLAIN, the UNet's and the ViT's path, keeps four)
 template <bool PLAIN, int NDT>
-__global__ __launch_bounds__(512, PLAIN ? 4 : 2) void attn_bwd_dq2_kernel(AttnParams p) {
+__global__ __launch_bounds__(512, PLAIN ? (NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4) : 2) void attn_bwd_dq2_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + A2_TILE;
