@@ -12,6 +12,7 @@ read-modify-write pass per parameter and lets the gradient arena / DDP bucket vi
 post-accumulate hooks do not fire for such parameters, `grad_ready_callbacks` is invoked instead.
 """
 import os
+import threading
 from typing import Any, Callable, List, Optional, Tuple
 
 import math
@@ -293,6 +294,176 @@ class SideStream:
 
 
 # ---------------------------------------------------------------------------------------------
+# Taped composite nodes (round 5): a whole sub-module as ONE autograd node
+# ---------------------------------------------------------------------------------------------
+# The composed module paths (the UNet's residual block and spatial transformer: residual.py:154-253, mixed_stacks/api.py:766-893)
+# are chains of the Functions of this file.  Through autograd each link costs a `Function.apply` on the way in and an engine
+# dispatch on the way back (8-9 us of host time each, ~600 links per zoo-UNet step whose forward is bound by the host's issue
+# rate) and every fan-in is an ATen add.  Inside a taped node the SAME static `forward` / `backward` of every Function run
+# against a plain context object: `TapedFn.forward` records (Function, context, argument slots) while the module's own forward
+# code runs, `TapedFn.backward` walks the record in reverse, sums fan-ins with `cfhip_add_bf16` and lets LayerNorm's backward
+# kernel take the gradient its input has already received as its `dx_add` operand.  Nothing is re-implemented per module.
+# What the tape cannot see is a plain torch op BETWEEN two Functions (its result would silently drop out of the gradient):
+# views of taped tensors are detected and end the attempt (`TapeBreak`: the module runs its composed path from then on); the
+# modules that use the tape only do so for configurations whose op sequence is known to consist of Functions
+# (tests/test_gpu_unet.py compares every gradient of both node types with the composed path).
+# MEASURED (profiles/r05/unet_taped_nodes.txt): the zoo UNet's graph shrinks from 1 201 to 751 autograd nodes, the host's backward
+# from ~28 to ~24-29 ms, its forward GROWS from 14.5 to 17-18 ms (collecting a node's parameters and slots costs more than the
+# `apply` calls it saves) — and neither matters: the GPU needs 19.1 ms for the forward and 39.8 ms for the backward either way
+# (events around the phases), so the step is bound by the queues in BOTH phases, 59.7 vs 59.6-60.0 ms.  Off by default.
+
+TAPED_NODES = [os.environ.get("CFHIP_TAPED_NODES", "0") == "1"]  # built, measured, not selected: see the note below
+_TAPE = threading.local()  # `.tape`: the tape that records on THIS thread (a forward on another thread is none of its business)
+
+
+class TapeBreak(RuntimeError):
+    """the sub-module's forward did something the tape cannot differentiate"""
+
+
+class _TapeCtx:
+    """what a Function's static `forward` / `backward` get in place of autograd's context while a tape records"""
+
+    def __init__(self, needs: Tuple[bool, ...]):
+        self.needs_input_grad = needs
+        self.saved_tensors: Tuple[Any, ...] = ()
+
+    def save_for_backward(self, *tensors: Any) -> None:
+        self.saved_tensors = tensors
+
+    def set_materialize_grads(self, value: bool) -> None:
+        pass
+
+    def mark_non_differentiable(self, *tensors: Any) -> None:
+        pass
+
+
+class _Tape:
+    def __init__(self, inputs: Tuple[Any, ...]):
+        self.n_inputs = len(inputs)
+        self.by_id = {id(t): i for i, t in enumerate(inputs) if isinstance(t, Tensor) and t.requires_grad}
+        self.inputs = inputs  # keeps the ids stable
+        self.entries: List[Tuple[Any, _TapeCtx, Tuple[Any, ...], int]] = []
+        self.next_slot = len(inputs)
+        self.out_slot = -1
+        self.used = False
+        self.token = object()  # what taped results carry (not the tape itself: a result saved by its own link would close a cycle)
+
+    def slot(self, t: Tensor) -> Optional[Tuple[int, Optional[torch.Size]]]:
+        """(slot, None) of a node input or a taped result; (slot, parameter shape) of a contiguous view of a whole parameter;
+        None for a constant"""
+        s = getattr(t, "_cfhip_slot", None)
+        if s is not None and s[0] is self.token:
+            return s[1], None
+        i = self.by_id.get(id(t))
+        if i is not None:
+            return i, None
+        if t._is_view():
+            base = t._base
+            i = None if base is None else self.by_id.get(id(base))
+            if (i is not None and base.is_leaf and base.numel() == t.numel() and t.is_contiguous() and base.is_contiguous()
+                    and t.data_ptr() == base.data_ptr()):
+                return i, base.shape  # e.g. a [Cout, Cin, 1, 1] filter seen as the matrix of its GEMM (cf. whole_param)
+            if base is not None and (i is not None or (getattr(base, "_cfhip_slot", None) or (None,))[0] is self.token):
+                raise TapeBreak("a view of a taped tensor reached a Function: the tape has no gradient rule for the view")
+        return None
+
+    def record(self, fn: Any, args: Tuple[Any, ...]) -> Any:
+        slots = tuple(self.slot(a) if isinstance(a, Tensor) else None for a in args)
+        ctx = _TapeCtx(tuple(sl is not None for sl in slots))
+        out = fn.forward(ctx, *args)
+        if any(sl is not None for sl in slots):
+            if not isinstance(out, Tensor):
+                raise TapeBreak(f"{fn.__name__} returns {type(out).__name__}: only single-tensor Functions are taped")
+            if any(out is a for a in args):  # an identity link: its result needs an identity of its own
+                out = out.view_as(out)
+            out._cfhip_slot = (self.token, self.next_slot)
+            metas = tuple(None if sl is None else (sl[0], sl[1], a.dtype, a.shape) for sl, a in zip(slots, args))
+            self.entries.append((fn, ctx, metas, self.next_slot))
+            self.next_slot += 1
+        return out
+
+    def backward(self, dy: Tensor) -> List[Optional[Tensor]]:
+        if self.used:
+            raise RuntimeError("cfhip: a taped node was differentiated twice (retain_graph / double backward); set "
+                               "CFHIP_TAPED_NODES=0 or functional.TAPED_NODES[0] = False for such a graph")
+        self.used = True
+        grads: dict = {self.out_slot: dy}
+        entries = self.entries
+        while entries:
+            fn, ctx, metas, out_slot = entries.pop()  # popped: what the link saved is freed as the walk passes it
+            g = grads.pop(out_slot, None)
+            if g is None:
+                continue
+            first = metas[0]
+            if getattr(fn, "folds_dx_add", False) and first is not None and first[1] is None:
+                pending = grads.get(first[0])
+                if pending is not None and pending.dtype == bf16 and pending.shape == first[3] and pending.is_contiguous():
+                    ctx.dx_add = grads.pop(first[0])  # the kernel adds it: the link's dx then IS the sum so far
+            gin = fn.backward(ctx, g)
+            if not isinstance(gin, tuple):
+                gin = (gin,)
+            for meta, ga in zip(metas, gin):
+                if meta is None or ga is None:
+                    continue
+                slot, param_shape, dtype, shape = meta
+                if ga.shape != shape:
+                    raise RuntimeError(f"cfhip taped node: {fn.__name__}.backward returned {tuple(ga.shape)} for an input of {tuple(shape)}")
+                if ga.dtype != dtype:
+                    ga = ga.to(dtype)  # what autograd's engine does between two nodes
+                if param_shape is not None:
+                    ga = ga.reshape(param_shape)
+                prev = grads.get(slot)
+                grads[slot] = ga if prev is None else _sum_grads(prev, ga)
+        self.inputs = ()
+        return [grads.get(i) for i in range(self.n_inputs)]
+
+
+def _sum_grads(a: Tensor, b: Tensor) -> Tensor:
+    if a.dtype == bf16 and b.dtype == bf16 and a.is_cuda and a.shape == b.shape:
+        return AddFn.forward(None, a, b)  # a new tensor: either operand may be somebody else's gradient too
+    return a + b
+
+
+def _apply(fn: Any, *args: Any) -> Any:
+    """`fn.apply(*args)`, or — inside a taped node — the Function's forward run directly and put on the tape"""
+    tape = getattr(_TAPE, "tape", None)
+    if tape is None:
+        return fn.apply(*args)
+    if not getattr(fn, "tapeable", True):
+        raise TapeBreak(f"{fn.__name__} cannot run inside a taped node")
+    return tape.record(fn, args)
+
+
+class TapedFn(Function):
+    @staticmethod
+    def forward(ctx: Any, run: Callable[[], Tensor], *tensors: Any) -> Tensor:
+        tape = _Tape(tensors)
+        _TAPE.tape = tape
+        try:
+            out = run()
+        finally:
+            _TAPE.tape = None
+        s = getattr(out, "_cfhip_slot", None)
+        if s is None or s[0] is not tape.token:
+            raise TapeBreak("the sub-module's result is not the result of a taped Function")
+        tape.out_slot = s[1]
+        ctx.tape = tape
+        return out
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        return (None,) + tuple(ctx.tape.backward(dy))
+
+
+def run_taped(run: Callable[[], Tensor], tensors: Tuple[Any, ...]) -> Tensor:
+    """`run()` as one autograd node over `tensors` (the activations it reads and every parameter it uses); plainly when a tape is
+    already recording (nested sub-modules join the outer node), without grad mode, or when nothing asks for a gradient."""
+    if getattr(_TAPE, "tape", None) is not None or not torch.is_grad_enabled():
+        return run()
+    return TapedFn.apply(run, *tensors)
+
+
+# ---------------------------------------------------------------------------------------------
 # bf16 shadows of fp32 master parameters
 # ---------------------------------------------------------------------------------------------
 
@@ -329,7 +500,7 @@ def whole_param(t: Optional[Tensor]) -> Optional[Tensor]:
     """`t` itself, or — when `t` is a contiguous view of a WHOLE leaf parameter (a [Cout, Cin, 1, 1] filter seen as the
     [Cout, Cin] matrix of the GEMM it is) — that parameter: its gradient can then be written straight into `.grad` (and
     run on the side stream) instead of travelling back through autograd's view chain."""
-    if t is None or t.is_leaf or not t._is_view():
+    if t is None or not t._is_view():  # (a view taken without grad mode, e.g. inside a taped node, IS a leaf)
         return t
     base = t._base
     if (base is not None and base.is_leaf and base.requires_grad and base.dtype == f32 and base.numel() == t.numel()
@@ -519,7 +690,7 @@ class LinearFn(Function):
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,
            residual: Optional[Tensor] = None, out_f32: bool = False) -> Tensor:
-    return LinearFn.apply(x, weight, bias, act, residual, out_f32)
+    return _apply(LinearFn, x, weight, bias, act, residual, out_f32)
 
 
 def qkv_weights_adjacent(wq: Tensor, wk: Tensor, wv: Tensor) -> bool:
@@ -592,7 +763,7 @@ class QKVLinearFn(Function):
 
 
 def qkv_linear(x: Tensor, wq: Tensor, wk: Tensor, wv: Tensor) -> Tensor:
-    return QKVLinearFn.apply(x, wq, wk, wv)
+    return _apply(QKVLinearFn, x, wq, wk, wv)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -602,6 +773,8 @@ def qkv_linear(x: Tensor, wq: Tensor, wk: Tensor, wv: Tensor) -> Tensor:
 
 class LayerNormFn(Function):
     """Replaces nn.LayerNorm.forward (reference norms.py:88-89 via NormFactory)."""
+
+    folds_dx_add = True  # a taped node hands the backward kernel the gradient x already has (`ctx.dx_add`, bf16, x's shape)
 
     @staticmethod
     def forward(ctx: Any, x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
@@ -622,12 +795,15 @@ class LayerNormFn(Function):
         wd, bd = _is_direct(weight), _is_direct(bias)
         gw = gb = None
         res: list = []
+        dx_add = getattr(ctx, "dx_add", None)  # inside a taped node: the gradient x has already received from its other readers
+        if dx_add is not None:
+            dx_add = dx_add.view(-1, dx_add.shape[-1])
         if wd and bd and write_param_grad_pair(
                 weight, bias, lambda ga, gb_, acc: res.append(ops.layernorm_bwd(
-                    dy2, x2, gamma, mean, rstd, dgamma=ga.view(-1), dbeta=gb_.view(-1), accumulate=acc)[0])):
+                    dy2, x2, gamma, mean, rstd, dx_add=dx_add, dgamma=ga.view(-1), dbeta=gb_.view(-1), accumulate=acc)[0])):
             dx = res[0]  # the kernel reduced dgamma / dbeta straight into `.grad` (round 1-2: two device copies per call)
         else:
-            dx, dg, db = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd)
+            dx, dg, db = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dx_add=dx_add)
             if wd:
                 write_param_grad(weight, lambda out, acc: out.add_(dg.view(out.shape)) if acc else out.copy_(dg.view(out.shape)))
             elif weight.requires_grad:
@@ -641,7 +817,7 @@ class LayerNormFn(Function):
 
 
 def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
-    return LayerNormFn.apply(x, weight, bias, eps)
+    return _apply(LayerNormFn, x, weight, bias, eps)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -749,7 +925,7 @@ class AttentionWeightsFn(Function):
 
 def attention_with_weights(q: Tensor, k: Tensor, v: Tensor, num_heads: int, keep_mask: Optional[Tensor] = None,
                            causal: bool = False, head_dim: int = 64, scale: Optional[float] = None):
-    return AttentionWeightsFn.apply(q, k, v, num_heads, keep_mask, causal, head_dim,
+    return _apply(AttentionWeightsFn, q, k, v, num_heads, keep_mask, causal, head_dim,
                                     1.0 / math.sqrt(float(head_dim)) if scale is None else float(scale))
 
 
@@ -764,12 +940,12 @@ def _take_attn_dropout(dropout_p: float, b: int, num_heads: int, tq: int, tk: in
 
 def packed_self_attention(qkv: Tensor, num_heads: int, keep_mask: Optional[Tensor] = None,
                           causal: bool = False, dropout_p: float = 0.0, head_dim: int = 64) -> Tensor:
-    return PackedSelfAttentionFn.apply(qkv, num_heads, keep_mask, causal, dropout_p, head_dim)
+    return _apply(PackedSelfAttentionFn, qkv, num_heads, keep_mask, causal, dropout_p, head_dim)
 
 
 def attention_core(q: Tensor, k: Tensor, v: Tensor, num_heads: int, keep_mask: Optional[Tensor] = None,
                    causal: bool = False, head_dim: int = 64, dropout_p: float = 0.0) -> Tensor:
-    return AttentionCoreFn.apply(q, k, v, num_heads, keep_mask, causal, head_dim, dropout_p)
+    return _apply(AttentionCoreFn, q, k, v, num_heads, keep_mask, causal, head_dim, dropout_p)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -808,11 +984,11 @@ class GeluFn(Function):
 
 
 def add(a: Tensor, b: Tensor) -> Tensor:
-    return AddFn.apply(a, b)
+    return _apply(AddFn, a, b)
 
 
 def gelu(x: Tensor) -> Tensor:
-    return GeluFn.apply(x)
+    return _apply(GeluFn, x)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -895,7 +1071,7 @@ class PatchTokensFn(Function):
 
 def patch_tokens(img: Tensor, conv_w: Tensor, conv_b: Optional[Tensor], head_token: Tensor,
                  pos: Tensor) -> Tensor:
-    return PatchTokensFn.apply(img, conv_w, conv_b, head_token, pos)
+    return _apply(PatchTokensFn, img, conv_w, conv_b, head_token, pos)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1294,13 +1470,13 @@ class ConvTranspose2dFn(Function):
 
 
 def conv_transpose2d(x: Tensor, wt: Tensor, stride: int, pad: int, dil: int = 1) -> Tensor:
-    return ConvTranspose2dFn.apply(x, wt, stride, pad, dil)
+    return _apply(ConvTranspose2dFn, x, wt, stride, pad, dil)
 
 
 def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int, pad: int, dil: int = 1, groups: int = 1) -> Tensor:
     if groups != 1:
-        return GroupedConv2dFn.apply(x, weight, bias, stride, pad, dil, groups)
-    return Conv2dFn.apply(x, weight, bias, stride, pad, dil)
+        return _apply(GroupedConv2dFn, x, weight, bias, stride, pad, dil, groups)
+    return _apply(Conv2dFn, x, weight, bias, stride, pad, dil)
 
 
 class BatchNormFn(Function):
@@ -1342,7 +1518,7 @@ class BatchNormFn(Function):
 
 def batch_norm(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], running_mean: Optional[Tensor],
                running_var: Optional[Tensor], eps: float, momentum: float, training: bool) -> Tensor:
-    return BatchNormFn.apply(x, weight, bias, running_mean, running_var, eps, momentum, training)
+    return _apply(BatchNormFn, x, weight, bias, running_mean, running_var, eps, momentum, training)
 
 
 class LeakyReLUFn(Function):
@@ -1366,7 +1542,7 @@ class LeakyReLUFn(Function):
 
 
 def leaky_relu(x: Tensor, slope: float) -> Tensor:
-    return LeakyReLUFn.apply(x, slope)
+    return _apply(LeakyReLUFn, x, slope)
 
 
 class GlobalAvgPoolFn(Function):
@@ -1387,7 +1563,7 @@ class GlobalAvgPoolFn(Function):
 
 
 def global_avg_pool(x: Tensor) -> Tensor:
-    return GlobalAvgPoolFn.apply(x)
+    return _apply(GlobalAvgPoolFn, x)
 
 
 class FocalLossFn(Function):
@@ -1407,7 +1583,7 @@ class FocalLossFn(Function):
 
 
 def focal_loss(logits: Tensor, labels: Tensor, gamma: float = 2.0, eps: float = 1.0e-6) -> Tensor:
-    return FocalLossFn.apply(logits, labels, gamma, eps)
+    return _apply(FocalLossFn, logits, labels, gamma, eps)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1454,7 +1630,7 @@ class EmbeddingFn(Function):
 
 
 def embedding(indices: Tensor, weight: Tensor, pos: Optional[Tensor] = None, padding_idx: int = -1) -> Tensor:
-    return EmbeddingFn.apply(indices, weight, pos, padding_idx)
+    return _apply(EmbeddingFn, indices, weight, pos, padding_idx)
 
 
 class GatherRowsFn(Function):
@@ -1479,7 +1655,7 @@ class GatherRowsFn(Function):
 
 
 def gather_rows(x: Tensor, index: Tensor) -> Tensor:
-    return GatherRowsFn.apply(x, index)
+    return _apply(GatherRowsFn, x, index)
 
 
 class L2NormalizeFn(Function):
@@ -1498,7 +1674,7 @@ class L2NormalizeFn(Function):
 
 
 def l2_normalize(x: Tensor) -> Tensor:
-    return L2NormalizeFn.apply(x)
+    return _apply(L2NormalizeFn, x)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1568,7 +1744,7 @@ class GroupNormFn(Function):
 def group_norm(x: Tensor, weight: Tensor, bias: Tensor, groups: int, eps: float, add: Optional[Tensor] = None,
                silu: bool = False) -> Tensor:
     """`weight` / `bias`: [C], or [B, C] for one affine per sample (see `scale_shift_affine`)."""
-    return GroupNormFn.apply(x, weight, bias, groups, eps, add, silu)
+    return _apply(GroupNormFn, x, weight, bias, groups, eps, add, silu)
 
 
 class ScaleShiftAffineFn(Function):
@@ -1606,7 +1782,7 @@ class ScaleShiftAffineFn(Function):
 
 
 def scale_shift_affine(weight: Tensor, bias: Tensor, scale: Tensor, shift: Tensor):
-    return ScaleShiftAffineFn.apply(weight, bias, scale, shift)
+    return _apply(ScaleShiftAffineFn, weight, bias, scale, shift)
 
 
 class SiLUF32Fn(Function):
@@ -1625,7 +1801,7 @@ class SiLUF32Fn(Function):
 
 
 def silu_f32(x: Tensor) -> Tensor:
-    return SiLUF32Fn.apply(x)
+    return _apply(SiLUF32Fn, x)
 
 
 class Upsample2Fn(Function):
@@ -1684,15 +1860,15 @@ def reflect_pad2d(x: Tensor, pads: Any) -> Tensor:
     """`pads`: one int or (left, right, top, bottom), as nn.ReflectionPad2d takes them"""
     if isinstance(pads, int):
         pads = (pads,) * 4
-    return ReflectPad2dFn.apply(x, tuple(int(v) for v in pads))
+    return _apply(ReflectPad2dFn, x, tuple(int(v) for v in pads))
 
 
 def upsample2(x: Tensor) -> Tensor:
-    return Upsample2Fn.apply(x)
+    return _apply(Upsample2Fn, x)
 
 
 def avg_pool2(x: Tensor) -> Tensor:
-    return AvgPool2Fn.apply(x)
+    return _apply(AvgPool2Fn, x)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1717,7 +1893,7 @@ class GegluFn(Function):
 
 
 def geglu(vg: Tensor) -> Tensor:
-    return GegluFn.apply(vg)
+    return _apply(GegluFn, vg)
 
 
 class NchwToTokensFn(Function):
@@ -1766,11 +1942,11 @@ class TokensToNchwFn(Function):
 
 
 def nchw_to_tokens(x: Tensor) -> Tensor:
-    return NchwToTokensFn.apply(x)
+    return _apply(NchwToTokensFn, x)
 
 
 def tokens_to_nchw(x: Tensor, h: int, w: int) -> Tensor:
-    return TokensToNchwFn.apply(x, h, w)
+    return _apply(TokensToNchwFn, x, h, w)
 
 
 class ConcatChannelsFn(Function):
@@ -1822,7 +1998,7 @@ class ConcatChannelsFn(Function):
 
 
 def concat_channels(a: Tensor, b: Tensor) -> Tensor:
-    return ConcatChannelsFn.apply(a, b)
+    return _apply(ConcatChannelsFn, a, b)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1837,6 +2013,8 @@ class _CheckpointFn(Function):
     `torch.autograd.grad`: their parameter gradients are written straight into `.grad` (arena) during the inner
     backward and returned as None, so this node returns None for every parameter as well — nothing is counted twice.
     With 288 GB of HBM per GPU the default stays OFF; the switch is for the configurations that set it."""
+
+    tapeable = False  # re-enters autograd: not inside a taped node
 
     @staticmethod
     def forward(ctx: Any, fn: Callable, n_inputs: int, *args: Any) -> Any:  # type: ignore
@@ -1872,7 +2050,7 @@ def gradient_checkpoint(fn: Callable, inputs: Any, params: Any, enabled: bool) -
     if not enabled or not torch.is_grad_enabled():
         return fn(*inputs)
     inputs = tuple(inputs)
-    return _CheckpointFn.apply(fn, len(inputs), *(inputs + tuple(params)))
+    return _apply(_CheckpointFn, fn, len(inputs), *(inputs + tuple(params)))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1901,7 +2079,7 @@ def dropout(x: Tensor, p: float, training: bool, mask: Optional[Tensor] = None) 
     """nn.Dropout semantics (identity unless training and 0 < p < 1); `mask` (uint8, 1 = keep) injects the mask."""
     if not training or not 0.0 < p < 1.0:
         return x
-    return DropoutFn.apply(x, p, mask)
+    return _apply(DropoutFn, x, p, mask)
 
 
 class DropPathFn(Function):
@@ -1926,7 +2104,7 @@ def drop_path(x: Tensor, rate: float, training: bool, mask: Optional[Tensor] = N
         b = x.shape[0]
         seed, offset = ops.PhiloxState.take((b + 3) // 4)
         mask = ops.drop_path_mask(b, keep_prob, x.device, seed=seed, offset=offset)
-    return DropPathFn.apply(x, keep_prob, mask)
+    return _apply(DropPathFn, x, keep_prob, mask)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -8,6 +8,7 @@ softmax callbacks...) raise NotImplementedError instead of silently doing someth
 """
 import math
 import os
+import sys
 from typing import Any, Callable, Dict, List, NamedTuple, Optional, Tuple
 
 import torch
@@ -1598,6 +1599,27 @@ class GroupNorm(nn.GroupNorm):
         return HF.group_norm(net, weight, bias, self.num_groups, self.eps, add, silu)
 
 
+def _plain_children(mod: Module) -> bool:
+    """No user hook anywhere under `mod` (the `hook=` of the Hijack layers, nn.Module forward hooks, pruners): what a taped node
+    (functional.run_taped) requires, because a hook's torch ops would fall out of the node's gradient."""
+    for m in mod.modules():
+        if m._forward_hooks or m._forward_pre_hooks or getattr(m, "hook", None) is not None:
+            return False
+        if getattr(m, "pruner", None) is not None or getattr(m, "pruner1", None) is not None:
+            return False
+    return True
+
+
+_tape_break_warned = [False]
+
+
+def _tape_broke(mod: Module, err: Exception) -> None:
+    mod._tape_ok = False
+    if not _tape_break_warned[0]:
+        _tape_break_warned[0] = True
+        print(f"cfhip: {type(mod).__name__} runs as separate autograd nodes from now on ({err})", file=sys.stderr)
+
+
 class ResDownsample(Module):
     """reference residual.py:86-117: conv3x3 stride 2 (`use_conv`) or 2x2 average pooling"""
 
@@ -1687,7 +1709,21 @@ class ResidualBlockWithTimeEmbedding(Module):
             if time_net is None:
                 return HF.gradient_checkpoint(lambda n: self._forward(n, None), (net,), self.parameters(), True)
             return HF.gradient_checkpoint(self._forward, (net, time_net), self.parameters(), True)
+        if self._taped(net):  # the whole block as ONE autograd node (functional.run_taped)
+            tensors = (net,) + (() if time_net is None else (time_net,)) + tuple(self.parameters())
+            try:
+                return HF.run_taped(lambda: self._forward(net, time_net), tensors)
+            except HF.TapeBreak as err:
+                _tape_broke(self, err)
         return self._forward(net, time_net)
+
+    _tape_ok = True
+
+    def _taped(self, net: Tensor) -> bool:
+        """the configurations whose op sequence is Functions only: no scale-shift modulation (torch.chunk), no active dropout
+        (its Philox draws would repeat on a fall-back), no hooks"""
+        return (HF.TAPED_NODES[0] and self._tape_ok and net.is_cuda and torch.is_grad_enabled() and not self.use_scale_shift_norm
+                and not (self.training and 0.0 < self.dropout.p < 1.0) and _plain_children(self))
 
     def _forward(self, net: Tensor, time_net: Optional[Tensor] = None) -> Tensor:
         inp = net
@@ -1885,7 +1921,27 @@ class SpatialTransformer(Module):
             for p in self.from_latent.parameters():
                 p.zero_()
 
+    _tape_ok = True
+
+    def _taped(self, net: Tensor, context: Optional[Tensor]) -> bool:
+        """Functions only: Linear-free of hooks, no recomputed blocks, no active dropout, no mask (CrossAttention is called without)"""
+        if not (HF.TAPED_NODES[0] and self._tape_ok and net.is_cuda and torch.is_grad_enabled()):
+            return False
+        for block in self.blocks:
+            if block.use_checkpoint or (self.training and (0.0 < block.ff.dropout < 1.0 or 0.0 < block.attn1.out_linear[1].p < 1.0)):
+                return False
+        return _plain_children(self)
+
     def forward(self, net: Tensor, context: Optional[Tensor]) -> Tensor:
+        if self._taped(net, context):  # norm, projections, every block and the residual add as ONE autograd node
+            tensors = (net,) + (() if context is None else (context,)) + tuple(self.parameters())
+            try:
+                return HF.run_taped(lambda: self._forward(net, context), tensors)
+            except HF.TapeBreak as err:
+                _tape_broke(self, err)
+        return self._forward(net, context)
+
+    def _forward(self, net: Tensor, context: Optional[Tensor]) -> Tensor:
         inp = net
         b, c, h, w = net.shape
         tokens = HF.nchw_to_tokens(self.norm(net))  # [B, HW, C]

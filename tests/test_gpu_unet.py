@@ -17,7 +17,8 @@ DEV = torch.device("cuda")
 # not select it by themselves).
 _WHOLE_UNET = ("test_unet_diffuser_golden", "test_unet_variants_golden", "test_q_sample_bit_exact_mse_and_ddpm_train_step",
                "test_gradient_checkpoint_matches_plain_backward", "test_ddpm_train_step_learned_log_var_and_labels",
-               "test_unet_zoo_full_size_step_vs_oracle", "test_ddpm_step_updates_inside_backward_bit_identically")
+               "test_unet_zoo_full_size_step_vs_oracle", "test_ddpm_step_updates_inside_backward_bit_identically",
+               "test_taped_nodes_match_the_composed_path")
 
 
 def pytest_generate_tests(metafunc):
@@ -300,13 +301,16 @@ def test_ddpm_train_step_as_a_hipgraph_matches_the_eager_step(golden):
         assert abs(a - b) <= 2e-3 * abs(b) + 1e-5, (losses[True], losses[False])
 
 
-def test_gradient_checkpoint_matches_plain_backward(golden, handover):
+def test_gradient_checkpoint_matches_plain_backward(golden, handover, monkeypatch):
     """Row U6 (reference toolkit.py:2535-2647, switched on by `use_checkpoint=True` in the zoo diffusion/ddpm config):
     the block is recomputed inside backward, i.e. every HIP Function in it is entered a second time under a
     re-entrant `torch.autograd.grad`, with parameter gradients written straight into `.grad`.  Same kernels on the
     same data: outputs bit-equal, every gradient equal to the plain run."""
     from cflearn_amd.modules import SpatialTransformer
 
+    # (both runs as one autograd node per Function: a taped node — what the plain run would otherwise be — rounds the fan-in in
+    # front of a LayerNorm once instead of twice, test_taped_nodes_match_the_composed_path)
+    monkeypatch.setattr(HF, "TAPED_NODES", [False])
     g = golden("resblock.pt")
     case = g["blocks"][0]
     cfg = case["cfg"]
@@ -794,3 +798,96 @@ def test_unet_nhwc_handover_matches_the_nchw_path(golden, monkeypatch):
         assert_close(g1[k], g0[k], 4e-2, f"gradient {k}", abs_floor=2e-3 * scale)
     print(f"transposes per forward + backward: NCHW hand-over {t0} of {n0} launches, NHWC {t1} of {n1}")
     assert t1 <= t0 // 4 and n1 < n0, (t0, t1, n0, n1)
+
+
+# ---- round 5: residual blocks and spatial transformers as ONE autograd node each (functional.run_taped) -----------------------
+
+
+def _graph_nodes(t):
+    seen, stack, names = set(), [t.grad_fn], []
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        names.append(type(fn).__name__)
+        stack.extend(nf for nf, _ in fn.next_functions)
+    return names
+
+
+def test_taped_nodes_match_the_composed_path(golden, handover, monkeypatch):
+    """functional.TAPED_NODES on (every ResidualBlockWithTimeEmbedding and SpatialTransformer — blocks, cross attention on a context,
+    GEGLU feed-forward included — is ONE autograd node whose backward walks the tape of the same Functions) against off (one node per
+    Function, fan-ins summed by autograd) on the small zoo-structured UNet.  The forward is the same launches: equal bit for bit.
+    The gradients differ only where the tape hands LayerNorm's backward kernel the gradient its input already has (one rounding
+    instead of two).  Without an arena the parameter gradients travel back through the node's outputs; with one
+    (DDPMTrainStep) they are written where the optimizer reads them — both are compared."""
+    from cflearn_amd.diffusion import DDPMTrainStep, NoiseSchedule
+    from cflearn_amd.modules import SpatialTransformer
+
+    u = golden("unet_small.pt")
+    x, ctx, t, eps = u["x"].to(DEV), u["context"].to(DEV), u["timesteps"].to(DEV), u["noise"].to(DEV)
+    outs, flats = [], []
+    for taped in (False, True):
+        monkeypatch.setattr(HF, "TAPED_NODES", [taped])
+        m = C.build_module("unet_diffuser", config=dict(u["cfg"]))
+        m.load_state_dict(u["sd"])
+        m = m.to(DEV)
+        y = m(x, timesteps=t, context=ctx)
+        names = _graph_nodes(y)
+        torch.nn.functional.mse_loss(y.float(), eps).backward()
+        HF.SideStream.join()
+        torch.cuda.synchronize()
+        nodes = [b for b in m.modules() if isinstance(b, (ResidualBlockWithTimeEmbedding, SpatialTransformer))]
+        assert nodes and all(b._tape_ok for b in nodes)
+        outs.append((y.detach().clone(), {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters()}, names, len(nodes)))
+        m2 = C.build_module("unet_diffuser", config=dict(u["cfg"]))
+        m2.load_state_dict(u["sd"])
+        ts = DDPMTrainStep(m2.to(DEV), NoiseSchedule(device=DEV), lr=1e-3)
+        loss = ts.step(x, ctx, timesteps=t, noise=eps).item()
+        torch.cuda.synchronize()
+        flats.append((loss, ts.arena.flat_g.detach().float().cpu().clone()))
+    (y0, g0, n0, _), (y1, g1, n1, k) = outs
+    assert n1.count("TapedFnBackward") == k and "TapedFnBackward" not in n0, (k, n1.count("TapedFnBackward"))
+    print(f"autograd nodes per forward: composed {len(n0)}, taped {len(n1)} ({k} taped nodes)")
+    f0, f1 = (sum(1 for n in names if n.endswith("FnBackward")) for names in (n0, n1))
+    assert f1 * 3 < f0, (f0, f1)  # (what remains: the stem, the resampling convolutions, the skip concatenations, the head)
+    assert torch.equal(y0, y1), "the forward of a taped node is the composed forward"
+    scale = max(float(v.abs().max()) for v in g0.values())
+    for name in g0:
+        assert_close(g1[name], g0[name], 2e-2, f"gradient {name}, taped vs composed", abs_floor=1e-3 * scale)
+    assert flats[0][0] == flats[1][0], flats
+    assert_close(flats[1][1], flats[0][1], 2e-2, "arena gradients, taped vs composed", abs_floor=1e-3 * float(flats[0][1].abs().max()))
+
+
+@pytest.mark.parametrize("kind", ["plain", "up", "down", "wider"])
+def test_taped_residual_block_is_bit_equal(kind):
+    """a residual block has no LayerNorm: its taped node reproduces the composed path's input / time / parameter gradients bit for
+    bit (two-operand fan-ins commute), with and without resampling and with the 1x1 shortcut"""
+    torch.manual_seed(3)
+    cin, cout = (64, 128) if kind == "wider" else (64, 64)
+    blk = ResidualBlockWithTimeEmbedding(cin, cout, integrate_upsample=kind == "up", integrate_downsample=kind == "down",
+                                         time_embedding_channels=96)
+    with torch.no_grad():
+        for p in blk.conv2.parameters():
+            p.normal_(0.0, 0.05)
+    blk = blk.to(DEV)
+    x = torch.randn(2, cin, 16, 16, device=DEV).bfloat16()
+    tn = torch.randn(2, 96, device=DEV)
+    res, before = [], HF.TAPED_NODES[0]
+    for taped in (False, True):
+        HF.TAPED_NODES[0] = taped
+        try:
+            blk.zero_grad(set_to_none=True)
+            xr, tr = x.clone().requires_grad_(True), tn.clone().requires_grad_(True)
+            y = blk(xr, tr)
+            assert ("TapedFnBackward" in _graph_nodes(y)) == taped
+            y.float().square().mean().backward()
+            HF.SideStream.join()
+            torch.cuda.synchronize()
+            res.append([y.detach().clone(), xr.grad.clone(), tr.grad.clone()] + [p.grad.clone() for p in blk.parameters()])
+        finally:
+            HF.TAPED_NODES[0] = before
+    assert blk._tape_ok
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b), (kind, i, float((a.float() - b.float()).abs().max()))

@@ -551,3 +551,117 @@ def test_round4_host_rules(tmp_path):
     src = out.read_text()
     assert "w_cfhip_gemm_bf16(" in src and "w_cfhip_adam_step_dev(" in src and "w_cfhip_comm_init(" not in src
     assert src.count("METH_FASTCALL") >= 75 and "if (PyErr_Occurred()) return NULL;" in src
+
+
+def test_taped_node_engine_against_autograd():
+    """functional.run_taped (round 5: a sub-module as ONE autograd node) with Functions whose arithmetic runs on the CPU: the walk
+    over the tape gives autograd's gradients — fan-in, a frozen parameter, a contiguous view of a whole parameter, a gradient
+    returned in another dtype, the `dx_add` fold of a pending gradient — and says so when it cannot (a view of a taped tensor
+    between two Functions, a plain torch op behind the last one, a second backward, a Function that re-enters autograd)."""
+    from torch.autograd import Function
+    import cflearn_amd.functional as HF
+
+    class Scale(Function):
+        @staticmethod
+        def forward(ctx, x, w, k):
+            ctx.save_for_backward(x, w)
+            ctx.k = k
+            return x * w * k
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            return ((g * w * ctx.k if ctx.needs_input_grad[0] else None),
+                    ((g * x * ctx.k).sum(0) if ctx.needs_input_grad[1] else None), None)
+
+    seen = []
+
+    class Squash(Function):
+        folds_dx_add = True
+
+        @staticmethod
+        def forward(ctx, x):
+            ctx.save_for_backward(x)
+            return x.tanh()
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            dx = g * (1 - x.tanh() ** 2)
+            add = getattr(ctx, "dx_add", None)
+            seen.append(add is not None)
+            return dx if add is None else dx + add
+
+    class Mat(Function):
+        @staticmethod
+        def forward(ctx, x, w2d):
+            ctx.save_for_backward(x, w2d)
+            return x @ w2d.t()
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            return g @ w, (g.t() @ x).double()  # the engine casts it like autograd's
+
+    class Add2(Function):
+        @staticmethod
+        def forward(ctx, a, b):
+            return a + b
+
+        @staticmethod
+        def backward(ctx, g):
+            return g, g
+
+    def body(x, t, w1, w2, w4):
+        h = HF._apply(Scale, x, w1, 2.0)
+        r = HF._apply(Scale, HF._apply(Squash, h), w2, 0.5)
+        m = HF._apply(Mat, HF._apply(Add2, h, r), w4.view(4, 4))  # h fans out; w4 is a [4, 4, 1, 1] filter seen as its matrix
+        return HF._apply(Add2, m, HF._apply(Scale, t, w1, 1.0))
+
+    def leaves(dtype=torch.float32):
+        torch.manual_seed(0)
+        return [torch.randn(3, 4).to(dtype).requires_grad_(True), torch.randn(3, 4).to(dtype).requires_grad_(True),
+                torch.randn(4).to(dtype).requires_grad_(True), torch.randn(4).to(dtype).requires_grad_(True),
+                torch.randn(4, 4, 1, 1).to(dtype).requires_grad_(True)]
+
+    a = leaves()
+    ya = body(*a)
+    ya.square().sum().backward()
+    b = leaves()
+    yb = HF.run_taped(lambda: body(*b), tuple(b))
+    assert type(yb.grad_fn).__name__ == "TapedFnBackward" and torch.equal(ya, yb)
+    yb.square().sum().backward()
+    for p, q in zip(a, b):
+        assert q.grad is not None and q.grad.dtype == q.dtype and torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-6)
+    assert seen == [False, False]  # f32 gradients are not folded (the kernel operand is bf16)
+    # bf16: the gradient h already has from the residual add rides into Squash's backward
+    del seen[:]
+    a, b = leaves(torch.bfloat16), leaves(torch.bfloat16)
+    body(*a).float().sum().backward()
+    HF.run_taped(lambda: body(*b), tuple(b)).float().sum().backward()
+    assert seen == [False, True]
+    for p, q in zip(a, b):
+        assert torch.allclose(p.grad.float(), q.grad.float(), rtol=3e-2, atol=3e-2)
+    # a frozen parameter
+    c = leaves()
+    c[3].requires_grad_(False)
+    HF.run_taped(lambda: body(*c), tuple(c)).sum().backward()
+    assert c[3].grad is None and c[2].grad is not None and c[4].grad is not None
+    # a view of a taped tensor between two Functions
+    d = leaves()
+    with pytest.raises(HF.TapeBreak, match="view of a taped tensor"):
+        HF.run_taped(lambda: HF._apply(Squash, HF._apply(Scale, d[0], d[2], 2.0).t()), tuple(d))
+    assert getattr(HF._TAPE, "tape", None) is None
+    with pytest.raises(HF.TapeBreak, match="not the result of a taped Function"):
+        HF.run_taped(lambda: HF._apply(Squash, d[0]) * 2, tuple(d))  # a plain torch op at the end
+    with pytest.raises(HF.TapeBreak, match="cannot run inside"):
+        HF.run_taped(lambda: HF._apply(HF._CheckpointFn, lambda v: v * 2, 1, d[0]), tuple(d))
+    # differentiated twice
+    e = leaves()
+    loss = HF.run_taped(lambda: body(*e), tuple(e)).sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="differentiated twice"):
+        loss.backward()
+    # without grad mode: nothing is taped
+    with torch.no_grad():
+        assert HF.run_taped(lambda: body(*a), tuple(a)).grad_fn is None
