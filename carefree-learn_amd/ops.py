@@ -950,6 +950,7 @@ GN_NHWC_TARGET_WORKGROUPS = int(os.environ.get("CFHIP_GN_NHWC_TARGET", "1024"))
 GN_NHWC_MIN_ROWS = int(os.environ.get("CFHIP_GN_NHWC_MIN_ROWS", "16"))
 
 
+GN_NHWC_GROUP_MAX_ROWS = int(os.environ.get("CFHIP_GN_NHWC_GROUP_MAX_ROWS", "48"))  # rows per thread up to which the group form is used
 GN_NHWC_GROUP_MIN_WORKGROUPS = int(os.environ.get("CFHIP_GN_NHWC_GROUP_MIN", "128"))  # B * G from which one workgroup per (sample, group) fills the chip
 
 
@@ -959,7 +960,16 @@ def gn_nhwc_splits(b: int, inner: int, c: int = 0, groups: int = 0) -> int:
     if groups and c % groups == 0:
         cpg = c // groups
         if b * groups >= GN_NHWC_GROUP_MIN_WORKGROUPS and cpg % 2 == 0 and cpg <= 256:
-            return 0
+            # a thread of the group form owns ceil(inner / row lanes) rows as 2 cpg-byte chunks (20-60 bytes of every 640-3 840-byte
+            # row on the UNet's upper levels): fine while there are few, but with many rows per thread the slice form's whole-row
+            # 16-byte accesses win although it is three launches — alone only beyond the 88 rows the group form can keep in
+            # registers (64^2 x 8 x 960: 281 / 246 us forward / backward against 94 / 126, `tools/gn_nhwc_bench.py`), inside the
+            # step, beside the weight-gradient GEMMs of the other queue, already from ~50 (64^2 x 8 step: threshold none / 88 / 48 /
+            # 32 / 16 / 0 = 59.3 / 58.8 / 58.3 / +0.4 / +1.4 / +3.0 ms, `profiles/r05/gn_nhwc_form_rule_ab.txt`)
+            row_lanes = 256 // (cpg // 2)
+            if -(-inner // row_lanes) <= GN_NHWC_GROUP_MAX_ROWS:
+                return 0
+            return max(1, min(64, inner // 32))
     want = -(-GN_NHWC_TARGET_WORKGROUPS // b)
     return max(1, min(want, inner // GN_NHWC_MIN_ROWS, 4096))
 

@@ -665,3 +665,17 @@ def test_taped_node_engine_against_autograd():
     # without grad mode: nothing is taped
     with torch.no_grad():
         assert HF.run_taped(lambda: body(*a), tuple(a)).grad_fn is None
+
+
+def test_groupnorm_nhwc_form_rule():
+    """ops.gn_nhwc_splits: the group form (0) while B * G workgroups fill the chip AND a thread's rows fit the registers it caches them
+    in; the slice form beyond that (the zoo UNet's 64^2 x 960 / 640 and 32^2 x 1920 levels) and for few samples (256^2 x 1)"""
+    from cflearn_amd import ops
+
+    assert ops.gn_nhwc_splits(8, 1024, 640, 32) == 0 and ops.gn_nhwc_splits(8, 1024, 320, 32) == 0  # 41 / 21 rows per thread
+    assert ops.gn_nhwc_splits(8, 256, 2560, 32) == 0 and ops.gn_nhwc_splits(8, 64, 1280, 32) == 0
+    assert ops.gn_nhwc_splits(8, 4096, 960, 32) == 64 and ops.gn_nhwc_splits(8, 4096, 640, 32) == 64  # 241 / 164
+    assert ops.gn_nhwc_splits(8, 4096, 320, 32) == 64 and ops.gn_nhwc_splits(8, 1024, 1920, 32) == 32  # 81 / 128
+    assert ops.gn_nhwc_splits(8, 1024, 1280, 32) == 32 and ops.gn_nhwc_splits(8, 1024, 960, 32) == 32  # 86 / 61
+    assert ops.gn_nhwc_splits(1, 65536, 320, 32) == 1024  # one sample: slices over the whole chip
+    assert ops.gn_nhwc_splits(8, 4096, 96, 32) > 0  # 3 channels per group: no dword pairs
