@@ -899,6 +899,10 @@ __device__ __forceinline__ void gn_nhwc_rows(int inner, int S, int sl, int& r0, 
   r0 = (int)((long)sl * inner / S);
   r1 = (int)((long)(sl + 1) * inner / S);
 }
+// The row walk of a thread: rows r0 + rl, r0 + rl + rpp, ... of the slice.  An idle thread (no slot) gets an EMPTY range instead of a
+// branch around the body, and the loop is unrolled by 4: the four 16-byte loads of an unrolled body are independent and issue back
+// to back (one load in flight per thread left these kernels at ~1.3 TB/s).
+#define GN_NHWC_ROW_LOOP(r) _Pragma("unroll 4") for (int r = (m.nslot > 0 ? r0 + m.rl : r1); r < r1; r += m.rpp)
 // per-channel values of all row lanes (acc[k][e] of every thread) -> chan[c] in LDS, summed over the row lanes in lane order
 template <int KC>
 __device__ __forceinline__ void gn_nhwc_fold(const GnNhwcMap& m, const float (&acc)[KC][8], float* lanes, float* chan, int C) {
@@ -1167,10 +1171,10 @@ __global__ __launch_bounds__(256) void gn_nhwc_stats_kernel(const bf16_t* __rest
       ad[k][e] = (add != nullptr && k < m.nslot) ? add[(long)b * C + m.slot[k] * 8 + e] : 0.f;
       acc[k][e] = 0.f;
     }
-  for (int r = r0 + m.rl; r < r1; r += m.rpp) {
+  GN_NHWC_ROW_LOOP(r) {
 #pragma unroll
     for (int k = 0; k < KC; ++k)
-      if (k < m.nslot) {
+      if (k == 0 || k < m.nslot) {
         float v[8];
         gn_load8<false>(xb, (long)r * C + m.slot[k] * 8, v);
 #pragma unroll
@@ -1193,10 +1197,10 @@ __global__ __launch_bounds__(256) void gn_nhwc_stats_kernel(const bf16_t* __rest
       mu[k][e] = k < m.nslot ? ad[k][e] - grp[(m.slot[k] * 8 + e) / cpg] : 0.f;  // v + add - mean
       acc[k][e] = 0.f;
     }
-  for (int r = r0 + m.rl; r < r1; r += m.rpp) {
+  GN_NHWC_ROW_LOOP(r) {
 #pragma unroll
     for (int k = 0; k < KC; ++k)
-      if (k < m.nslot) {
+      if (k == 0 || k < m.nslot) {
         float v[8];
         gn_load8<false>(xb, (long)r * C + m.slot[k] * 8, v);
 #pragma unroll
@@ -1285,10 +1289,10 @@ __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(const bf16_t* __rest
   gn_nhwc_rows(inner, S, sl, r0, r1);
   const bf16_t* xb = x + (long)b * inner * C;
   bf16_t* yb = y + (long)b * inner * C;
-  for (int r = r0 + m.rl; r < r1; r += m.rpp) {
+  GN_NHWC_ROW_LOOP(r) {
 #pragma unroll
     for (int k = 0; k < KC; ++k)
-      if (k < m.nslot) {
+      if (k == 0 || k < m.nslot) {
         float v[8];
         const long off = (long)r * C + m.slot[k] * 8;
         gn_load8<false>(xb, off, v);
@@ -1336,10 +1340,10 @@ __global__ __launch_bounds__(256) void gn_nhwc_bwd_stats_kernel(const bf16_t* __
   gn_nhwc_rows(inner, S, sl, r0, r1);
   const bf16_t* xb = x + (long)b * inner * C;
   const bf16_t* dyb = dy + (long)b * inner * C;
-  for (int r = r0 + m.rl; r < r1; r += m.rpp) {
+  GN_NHWC_ROW_LOOP(r) {
 #pragma unroll
     for (int k = 0; k < KC; ++k)
-      if (k < m.nslot) {
+      if (k == 0 || k < m.nslot) {
         float v[8], d[8];
         const long off = (long)r * C + m.slot[k] * 8;
         gn_load8<false>(xb, off, v);
@@ -1420,10 +1424,10 @@ __global__ __launch_bounds__(256) void gn_nhwc_bwd_apply_kernel(const bf16_t* __
   const bf16_t* xb = x + (long)b * inner * C;
   const bf16_t* dyb = dy + (long)b * inner * C;
   bf16_t* dxb = dx + (long)b * inner * C;
-  for (int r = r0 + m.rl; r < r1; r += m.rpp) {
+  GN_NHWC_ROW_LOOP(r) {
 #pragma unroll
     for (int k = 0; k < KC; ++k)
-      if (k < m.nslot) {
+      if (k == 0 || k < m.nslot) {
         float v[8], d[8];
         const long off = (long)r * C + m.slot[k] * 8;
         gn_load8<false>(xb, off, v);

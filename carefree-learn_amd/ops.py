@@ -954,7 +954,7 @@ GN_NHWC_GROUP_MAX_ROWS = int(os.environ.get("CFHIP_GN_NHWC_GROUP_MAX_ROWS", "48"
 GN_NHWC_GROUP_MIN_WORKGROUPS = int(os.environ.get("CFHIP_GN_NHWC_GROUP_MIN", "128"))  # B * G from which one workgroup per (sample, group) fills the chip
 
 
-def gn_nhwc_splits(b: int, inner: int, c: int = 0, groups: int = 0) -> int:
+def gn_nhwc_splits(b: int, inner: int, c: int = 0, groups: int = 0, backward: bool = False) -> int:
     """0: the group form (one workgroup per (sample, group), ONE launch each way: enough samples, an even number of channels per group);
     otherwise the row slices per sample of the slice form (few samples, e.g. 256^2 x 1): ~4 workgroups per CU, >= GN_NHWC_MIN_ROWS rows each"""
     if groups and c % groups == 0:
@@ -969,7 +969,8 @@ def gn_nhwc_splits(b: int, inner: int, c: int = 0, groups: int = 0) -> int:
             row_lanes = 256 // (cpg // 2)
             if -(-inner // row_lanes) <= GN_NHWC_GROUP_MAX_ROWS:
                 return 0
-            return max(1, min(64, inner // 32))
+            # (forward: 32 slices — its statistics kernel reads the slice twice, the second time out of L2; backward: 64)
+            return max(1, min(64 if backward else 32, inner // 32))
     want = -(-GN_NHWC_TARGET_WORKGROUPS // b)
     return max(1, min(want, inner // GN_NHWC_MIN_ROWS, 4096))
 
@@ -1015,7 +1016,7 @@ def groupnorm_nhwc_bwd(dy: Tensor, rows: Tensor, b: int, gamma: Tensor, beta: Te
     inner = rows.shape[0] // b
     affine_bs = _gn_affine_stride(gamma, beta, b, c)
     lib = _lib.load()
-    splits = gn_nhwc_splits(b, inner, c, groups)
+    splits = gn_nhwc_splits(b, inner, c, groups, True)
     dx = torch.empty_like(rows)
     dg = torch.empty((b, c), dtype=f32, device=rows.device)
     db = torch.empty((b, c), dtype=f32, device=rows.device)

@@ -44,14 +44,14 @@ for inner, c in SHAPES:
     cells = []
     for name, sp in FORMS:
         if sp is None:
-            ops.gn_nhwc_splits = lambda b, i, cc=0, g=0: 0
+            ops.gn_nhwc_splits = lambda b, i, cc=0, g=0, bw=False: 0
         elif sp == "default":
-            ops.gn_nhwc_splits = lambda b, i, cc=0, g=0: max(1, min(-(-ops.GN_NHWC_TARGET_WORKGROUPS // b), i // ops.GN_NHWC_MIN_ROWS, 4096))
+            ops.gn_nhwc_splits = lambda b, i, cc=0, g=0, bw=False: max(1, min(-(-ops.GN_NHWC_TARGET_WORKGROUPS // b), i // ops.GN_NHWC_MIN_ROWS, 4096))
         else:
             if inner // sp < 4:
                 cells.append(f"{name}: -")
                 continue
-            ops.gn_nhwc_splits = lambda b, i, cc=0, g=0, sp=sp: sp
+            ops.gn_nhwc_splits = lambda b, i, cc=0, g=0, bw=False, sp=sp: sp
         try:
             stats = ops.groupnorm_nhwc_fwd(sets[0][0], B, gamma, beta, 32, 1e-6, add=add, silu=True)
             tf = timed(lambda i: ops.groupnorm_nhwc_fwd(sets[i % 4][0], B, gamma, beta, 32, 1e-6, add=add, silu=True))
