@@ -927,79 +927,104 @@ __device__ __forceinline__ void gn_nhwc_fold(const GnNhwcMap& m, const float (&a
 // channels are a 2 cpg-byte chunk of every row (20 .. 160 bytes), read as dwords — thread (rl, dw) owns the channel pair dw of the
 // rows rl, rl + RPP, ... — so statistics, normalisation and the parameter-gradient sums all stay inside the workgroup: no slices,
 // no workspace, no merge.  The 32 workgroups of a sample share every row's cache lines in L2.  cpg even, cpg <= 256.
+// VW (round 5): a thread owns VW consecutive dwords (2 VW channels) of the chunk and reads them with ONE 4 VW-byte access — 4 when the
+// chunk is a multiple of 16 bytes (cpg = 40, 80: C = 1 280, 2 560), 2 for multiples of 8 (cpg = 20, 60), else 1: a quarter / half of
+// the memory instructions for the same bytes (the chunked accesses are what these kernels spend their time on, twice as much
+// inside the step as alone).
+template <int VW> struct GnVecT;
+template <> struct GnVecT<1> { typedef unsigned T; };
+template <> struct GnVecT<2> { typedef u32x2 T; };
+template <> struct GnVecT<4> { typedef u32x4 T; };
+template <int VW> struct GnWords {
+  unsigned w[VW];
+};
+template <int VW> __device__ __forceinline__ GnWords<VW> gn_ldw(const bf16_t* p) {
+  union { typename GnVecT<VW>::T v; GnWords<VW> w; } u;
+  u.v = *reinterpret_cast<const typename GnVecT<VW>::T*>(p);
+  return u.w;
+}
+template <int VW> __device__ __forceinline__ void gn_stw(bf16_t* p, const GnWords<VW>& w) {
+  union { typename GnVecT<VW>::T v; GnWords<VW> w; } u;
+  u.w = w;
+  *reinterpret_cast<typename GnVecT<VW>::T*>(p) = u.v;
+}
 struct GnGroupMap {
-  int dpr, rpp, rl, dw;  // dwords per row chunk, row lanes, this thread's row lane / dword
+  int vpr, rpp, rl, vs;  // vector slots per row chunk, row lanes, this thread's row lane / slot
   bool active;
 };
-__device__ __forceinline__ GnGroupMap gn_group_map(int cpg) {
+template <int VW> __device__ __forceinline__ GnGroupMap gn_group_map(int cpg) {
   GnGroupMap m;
-  m.dpr = cpg >> 1;
-  m.rpp = 256 / m.dpr;
-  m.rl = threadIdx.x / m.dpr;
-  m.dw = threadIdx.x - m.rl * m.dpr;
+  m.vpr = (cpg >> 1) / VW;
+  m.rpp = 256 / m.vpr;
+  m.rl = threadIdx.x / m.vpr;
+  m.vs = threadIdx.x - m.rl * m.vpr;
   m.active = m.rl < m.rpp;
   return m;
 }
 
-// RPT > 0: the thread's rows (at most RPT of them: ceil(inner / rpp) <= RPT, chosen by the launcher) stay in REGISTERS between the
-// passes — one global read and one write per element instead of three reads and a write (the chunked dword accesses are what these
-// kernels spend their time on); RPT = 0: every pass re-reads (out of L2).
-template <int RPT>
+// RPT > 0: the thread's rows (at most RPT / VW of them, chosen by the launcher) stay in REGISTERS between the passes — one global read
+// and one write per element instead of three reads and a write; RPT = 0: every pass re-reads (out of L2).
+template <int RPT, int VW>
 __global__ __launch_bounds__(256) void gn_nhwc_group_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ add,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 bf16_t* __restrict__ y, float* __restrict__ mean_out,
                                                                 float* __restrict__ rstd_out, int C, int G, int inner, float eps, int silu,
                                                                 int affine_bs) {
   __shared__ float red[4];
-  constexpr int NC = RPT > 0 ? RPT : 1;
+  constexpr int NC = RPT > 0 ? RPT / VW : 1;
+  constexpr int CH = 2 * VW;  // channels per thread
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
   const int cpg = C / G;
-  const GnGroupMap m = gn_group_map(cpg);
+  const GnGroupMap m = gn_group_map<VW>(cpg);
   gamma += (long)b * affine_bs;
   beta += (long)b * affine_bs;
-  const int c0 = g * cpg + 2 * m.dw;
+  const int c0 = g * cpg + CH * m.vs;
   const long base = (long)b * inner * C + c0;
-  float a0 = 0.f, a1 = 0.f;
-  if (m.active && add != nullptr) {
-    a0 = add[(long)b * C + c0];
-    a1 = add[(long)b * C + c0 + 1];
-  }
+  float a[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) a[e] = (m.active && add != nullptr) ? add[(long)b * C + c0 + e] : 0.f;
   const float n = (float)cpg * (float)inner;
-  unsigned cache[NC];
+  auto row_sum = [&](const GnWords<VW>& w) {
+    float t = 0.f;
+#pragma unroll
+    for (int v = 0; v < VW; ++v) t += (bf16lo(w.w[v]) + a[2 * v]) + (bf16hi(w.w[v]) + a[2 * v + 1]);
+    return t;
+  };
+  GnWords<VW> cache[NC];
   float s = 0.f;
   if (RPT > 0) {
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int r = m.rl + i * m.rpp;
-      cache[i] = 0u;
+#pragma unroll
+      for (int v = 0; v < VW; ++v) cache[i].w[v] = 0u;
       if (m.active && r < inner) {
-        cache[i] = *reinterpret_cast<const unsigned*>(x + base + (long)r * C);
-        s += (bf16lo(cache[i]) + a0) + (bf16hi(cache[i]) + a1);
+        cache[i] = gn_ldw<VW>(x + base + (long)r * C);
+        s += row_sum(cache[i]);
       }
     }
   } else if (m.active) {
-    for (int r = m.rl; r < inner; r += m.rpp) {
-      const unsigned w = *reinterpret_cast<const unsigned*>(x + base + (long)r * C);
-      s += (bf16lo(w) + a0) + (bf16hi(w) + a1);
-    }
+    for (int r = m.rl; r < inner; r += m.rpp) s += row_sum(gn_ldw<VW>(x + base + (long)r * C));
   }
   const float mean = block_sum(s, red) / n;
+  auto row_sq = [&](const GnWords<VW>& w) {
+    float t = 0.f;
+#pragma unroll
+    for (int v = 0; v < VW; ++v) {
+      const float d0 = bf16lo(w.w[v]) + a[2 * v] - mean, d1 = bf16hi(w.w[v]) + a[2 * v + 1] - mean;
+      t += d0 * d0 + d1 * d1;
+    }
+    return t;
+  };
   float q = 0.f;
   if (RPT > 0) {
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int r = m.rl + i * m.rpp;
-      if (m.active && r < inner) {
-        const float d0 = bf16lo(cache[i]) + a0 - mean, d1 = bf16hi(cache[i]) + a1 - mean;
-        q += d0 * d0 + d1 * d1;
-      }
+      if (m.active && r < inner) q += row_sq(cache[i]);
     }
   } else if (m.active) {
-    for (int r = m.rl; r < inner; r += m.rpp) {
-      const unsigned w = *reinterpret_cast<const unsigned*>(x + base + (long)r * C);
-      const float d0 = bf16lo(w) + a0 - mean, d1 = bf16hi(w) + a1 - mean;
-      q += d0 * d0 + d1 * d1;
-    }
+    for (int r = m.rl; r < inner; r += m.rpp) q += row_sq(gn_ldw<VW>(x + base + (long)r * C));
   }
   const float rstd = rsqrtf(block_sum(q, red) / n + eps);
   if (threadIdx.x == 0) {
@@ -1007,15 +1032,24 @@ __global__ __launch_bounds__(256) void gn_nhwc_group_fwd_kernel(const bf16_t* __
     rstd_out[blockIdx.x] = rstd;
   }
   if (!m.active) return;
-  const float k0 = rstd * gamma[c0], k1 = rstd * gamma[c0 + 1];
-  const float o0 = beta[c0] + (a0 - mean) * k0, o1 = beta[c0 + 1] + (a1 - mean) * k1;
-  auto emit = [&](int r, unsigned w) {
-    float v0 = fmaf(bf16lo(w), k0, o0), v1 = fmaf(bf16hi(w), k1, o1);
-    if (silu) {
-      v0 = silu_f(v0);
-      v1 = silu_f(v1);
+  float k[CH], o[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) {
+    k[e] = rstd * gamma[c0 + e];
+    o[e] = beta[c0 + e] + (a[e] - mean) * k[e];
+  }
+  auto emit = [&](int r, const GnWords<VW>& w) {
+    GnWords<VW> out;
+#pragma unroll
+    for (int v = 0; v < VW; ++v) {
+      float v0 = fmaf(bf16lo(w.w[v]), k[2 * v], o[2 * v]), v1 = fmaf(bf16hi(w.w[v]), k[2 * v + 1], o[2 * v + 1]);
+      if (silu) {
+        v0 = silu_f(v0);
+        v1 = silu_f(v1);
+      }
+      out.w[v] = pack_bf16x2(v0, v1);
     }
-    *reinterpret_cast<unsigned*>(y + base + (long)r * C) = pack_bf16x2(v0, v1);
+    gn_stw<VW>(y + base + (long)r * C, out);
   };
   if (RPT > 0) {
 #pragma unroll
@@ -1024,44 +1058,47 @@ __global__ __launch_bounds__(256) void gn_nhwc_group_fwd_kernel(const bf16_t* __
       if (r < inner) emit(r, cache[i]);
     }
   } else {
-    for (int r = m.rl; r < inner; r += m.rpp) emit(r, *reinterpret_cast<const unsigned*>(x + base + (long)r * C));
+    for (int r = m.rl; r < inner; r += m.rpp) emit(r, gn_ldw<VW>(x + base + (long)r * C));
   }
 }
 
-// LDS: lanes [rpp][cpg] (<= 512 floats) + ch [2][cpg]
-template <int RPT>
+// LDS: lanes [rpp][cpg] (<= 512 VW floats) + ch [2][cpg]
+template <int RPT, int VW>
 __global__ __launch_bounds__(256) void gn_nhwc_group_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                                 const float* __restrict__ add, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, bf16_t* __restrict__ dx,
                                                                 float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
                                                                 float* __restrict__ dadd, int C, int G, int inner, int silu, int affine_bs) {
-  __shared__ float lanes[512];
+  __shared__ float lanes[512 * VW];
   __shared__ float chA[256], chB[256], sums[2];
-  constexpr int NC = RPT > 0 ? RPT : 1;
+  constexpr int NC = RPT > 0 ? RPT / VW : 1;
+  constexpr int CH = 2 * VW;
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
   const int cpg = C / G;
-  const GnGroupMap m = gn_group_map(cpg);
+  const GnGroupMap m = gn_group_map<VW>(cpg);
   gamma += (long)b * affine_bs;
   beta += (long)b * affine_bs;
-  const int c0 = g * cpg + 2 * m.dw;
+  const int c0 = g * cpg + CH * m.vs;
   const long base = (long)b * inner * C + c0;
   const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
-  float sh0 = -mu, sh1 = -mu, g0 = 0.f, g1 = 0.f, b0 = 0.f, b1 = 0.f;
-  if (m.active) {
-    if (add != nullptr) {
-      sh0 += add[(long)b * C + c0];
-      sh1 += add[(long)b * C + c0 + 1];
+  float sh[CH], ga[CH], be[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) {
+    sh[e] = -mu;
+    ga[e] = be[e] = 0.f;
+    if (m.active) {
+      if (add != nullptr) sh[e] += add[(long)b * C + c0 + e];
+      ga[e] = gamma[c0 + e];
+      be[e] = beta[c0 + e];
     }
-    g0 = gamma[c0]; g1 = gamma[c0 + 1];
-    b0 = beta[c0]; b1 = beta[c0 + 1];
   }
   // a per-channel quantity of every row lane -> ch[c], summed over the row lanes in lane order
-  auto fold = [&](float v0, float v1, float* ch) {
+  auto fold = [&](const float (&v)[CH], float* ch) {
     __syncthreads();
     if (m.active) {
-      lanes[m.rl * cpg + 2 * m.dw] = v0;
-      lanes[m.rl * cpg + 2 * m.dw + 1] = v1;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) lanes[m.rl * cpg + CH * m.vs + e] = v[e];
     }
     __syncthreads();
     if ((int)threadIdx.x < cpg) {
@@ -1071,43 +1108,50 @@ __global__ __launch_bounds__(256) void gn_nhwc_group_bwd_kernel(const bf16_t* __
     }
     __syncthreads();
   };
-  // (xhat, dn) of one element pair from the raw words
-  auto terms = [&](unsigned wx, unsigned wd, float& xh0, float& xh1, float& d0, float& d1) {
-    xh0 = (bf16lo(wx) + sh0) * rs;
-    xh1 = (bf16hi(wx) + sh1) * rs;
-    d0 = bf16lo(wd);
-    d1 = bf16hi(wd);
+  // (xhat, dn) of the thread's 2 VW elements of a row from the raw words
+  auto terms = [&](const GnWords<VW>& wx, const GnWords<VW>& wd, float (&xh)[CH], float (&d)[CH]) {
+#pragma unroll
+    for (int v = 0; v < VW; ++v) {
+      xh[2 * v] = (bf16lo(wx.w[v]) + sh[2 * v]) * rs;
+      xh[2 * v + 1] = (bf16hi(wx.w[v]) + sh[2 * v + 1]) * rs;
+      d[2 * v] = bf16lo(wd.w[v]);
+      d[2 * v + 1] = bf16hi(wd.w[v]);
+    }
     if (silu) {
-      d0 *= silu_grad_f(fmaf(xh0, g0, b0));
-      d1 *= silu_grad_f(fmaf(xh1, g1, b1));
+#pragma unroll
+      for (int e = 0; e < CH; ++e) d[e] *= silu_grad_f(fmaf(xh[e], ga[e], be[e]));
     }
   };
-  unsigned cx[NC], cd[NC];
-  float A0 = 0.f, A1 = 0.f, B0 = 0.f, B1 = 0.f;
+  GnWords<VW> cx[NC], cd[NC];
+  float A[CH], Bs[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) A[e] = Bs[e] = 0.f;
+  auto accumulate = [&](const GnWords<VW>& wx, const GnWords<VW>& wd) {
+    float xh[CH], d[CH];
+    terms(wx, wd, xh, d);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      A[e] += d[e] * xh[e];
+      Bs[e] += d[e];
+    }
+  };
   if (RPT > 0) {
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int r = m.rl + i * m.rpp;
-      cx[i] = cd[i] = 0u;
+#pragma unroll
+      for (int v = 0; v < VW; ++v) cx[i].w[v] = cd[i].w[v] = 0u;
       if (m.active && r < inner) {
-        cx[i] = *reinterpret_cast<const unsigned*>(x + base + (long)r * C);
-        cd[i] = *reinterpret_cast<const unsigned*>(dy + base + (long)r * C);
-        float xh0, xh1, d0, d1;
-        terms(cx[i], cd[i], xh0, xh1, d0, d1);
-        A0 += d0 * xh0; A1 += d1 * xh1;
-        B0 += d0; B1 += d1;
+        cx[i] = gn_ldw<VW>(x + base + (long)r * C);
+        cd[i] = gn_ldw<VW>(dy + base + (long)r * C);
+        accumulate(cx[i], cd[i]);
       }
     }
   } else if (m.active) {
-    for (int r = m.rl; r < inner; r += m.rpp) {
-      float xh0, xh1, d0, d1;
-      terms(*reinterpret_cast<const unsigned*>(x + base + (long)r * C), *reinterpret_cast<const unsigned*>(dy + base + (long)r * C), xh0, xh1, d0, d1);
-      A0 += d0 * xh0; A1 += d1 * xh1;
-      B0 += d0; B1 += d1;
-    }
+    for (int r = m.rl; r < inner; r += m.rpp) accumulate(gn_ldw<VW>(x + base + (long)r * C), gn_ldw<VW>(dy + base + (long)r * C));
   }
-  fold(A0, A1, chA);
-  fold(B0, B1, chB);
+  fold(A, chA);
+  fold(Bs, chB);
   if ((int)threadIdx.x < cpg) {
     dgamma_part[(long)b * C + g * cpg + threadIdx.x] = chA[threadIdx.x];
     dbeta_part[(long)b * C + g * cpg + threadIdx.x] = chB[threadIdx.x];
@@ -1124,13 +1168,22 @@ __global__ __launch_bounds__(256) void gn_nhwc_group_bwd_kernel(const bf16_t* __
   }
   __syncthreads();
   const float m1 = sums[0], m2 = sums[1];
-  float D0 = 0.f, D1 = 0.f;
-  auto emit = [&](int r, unsigned wx, unsigned wd) {
-    float xh0, xh1, d0, d1;
-    terms(wx, wd, xh0, xh1, d0, d1);
-    const float o0 = rs * (d0 * g0 - m1 - xh0 * m2), o1 = rs * (d1 * g1 - m1 - xh1 * m2);
-    *reinterpret_cast<unsigned*>(dx + base + (long)r * C) = pack_bf16x2(o0, o1);
-    D0 += o0; D1 += o1;
+  float D[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) D[e] = 0.f;
+  auto emit = [&](int r, const GnWords<VW>& wx, const GnWords<VW>& wd) {
+    float xh[CH], d[CH];
+    terms(wx, wd, xh, d);
+    GnWords<VW> out;
+#pragma unroll
+    for (int v = 0; v < VW; ++v) {
+      const float o0 = rs * (d[2 * v] * ga[2 * v] - m1 - xh[2 * v] * m2);
+      const float o1 = rs * (d[2 * v + 1] * ga[2 * v + 1] - m1 - xh[2 * v + 1] * m2);
+      out.w[v] = pack_bf16x2(o0, o1);
+      D[2 * v] += o0;
+      D[2 * v + 1] += o1;
+    }
+    gn_stw<VW>(dx + base + (long)r * C, out);
   };
   if (RPT > 0) {
 #pragma unroll
@@ -1139,11 +1192,10 @@ __global__ __launch_bounds__(256) void gn_nhwc_group_bwd_kernel(const bf16_t* __
       if (m.active && r < inner) emit(r, cx[i], cd[i]);
     }
   } else if (m.active) {
-    for (int r = m.rl; r < inner; r += m.rpp)
-      emit(r, *reinterpret_cast<const unsigned*>(x + base + (long)r * C), *reinterpret_cast<const unsigned*>(dy + base + (long)r * C));
+    for (int r = m.rl; r < inner; r += m.rpp) emit(r, gn_ldw<VW>(x + base + (long)r * C), gn_ldw<VW>(dy + base + (long)r * C));
   }
   if (dadd != nullptr) {
-    fold(D0, D1, chA);
+    fold(D, chA);
     if ((int)threadIdx.x < cpg) dadd[(long)b * C + g * cpg + threadIdx.x] = chA[threadIdx.x];
   }
 }
@@ -1956,7 +2008,9 @@ static int gn_nhwc_check(const char* who, int B, int C, int G, int inner, int sp
   return CFHIP_OK;
 }
 static inline int gn_nhwc_rpp(int C) { return (C >> 3) >= 256 ? 1 : 256 / (C >> 3); }
-static inline int gn_group_rpp(int cpg) { return 256 / (cpg >> 1); }  // row lanes of the group form (cpg even, <= 256)
+// dwords a thread of the group form reads with one access: the largest of 4 / 2 / 1 that divides the chunk's cpg / 2 dwords
+// (the chunk then starts on a 4 VW-byte boundary in every row: C * 2 is a multiple of 16)
+static inline int gn_group_vw(int cpg) { const int d = cpg >> 1; return d % 4 == 0 ? 4 : d % 2 == 0 ? 2 : 1; }
 
 extern "C" size_t cfhip_groupnorm_nhwc_workspace(int B, int C, int G, int splits, int backward, int with_add) {
   if (B <= 0 || C <= 0 || G <= 0 || splits <= 0) return 0;
@@ -1974,15 +2028,25 @@ extern "C" int cfhip_groupnorm_nhwc_fwd(const void* x, const float* add, const f
   hipStream_t s = (hipStream_t)stream;
   const bf16_t* xp = (const bf16_t*)x;
   if (splits == 0) {  // group form: one workgroup per (sample, group), one launch
-    const int rpt = (inner + gn_group_rpp(C / G) - 1) / gn_group_rpp(C / G);  // rows per thread: kept in registers when they fit
-#define CFHIP_GN_GROUP_FWD(RPT)                                                                                                        \
-  hipLaunchKernelGGL((gn_nhwc_group_fwd_kernel<RPT>), dim3(B * G), dim3(256), 0, s, xp, add, gamma, beta, (bf16_t*)y, mean, rstd, C, G, inner, \
-                     eps, silu, affine_batch_stride)
+    // dwords per thread (rows x vector width): kept in registers when they fit
+    const int vw = (((uintptr_t)x | (uintptr_t)y) & 15) == 0 ? gn_group_vw(C / G) : 1;  // (rows of an odd view: dword accesses)
+    const int rpp = 256 / ((C / G / 2) / vw);
+    const int rpt = ((inner + rpp - 1) / rpp) * vw;
+#define CFHIP_GN_GROUP_FWD_V(RPT, VW)                                                                                                  \
+  hipLaunchKernelGGL((gn_nhwc_group_fwd_kernel<RPT, VW>), dim3(B * G), dim3(256), 0, s, xp, add, gamma, beta, (bf16_t*)y, mean, rstd, C, G, \
+                     inner, eps, silu, affine_batch_stride)
+#define CFHIP_GN_GROUP_FWD(RPT)                  \
+  do {                                           \
+    if (vw == 4) CFHIP_GN_GROUP_FWD_V(RPT, 4);   \
+    else if (vw == 2) CFHIP_GN_GROUP_FWD_V(RPT, 2); \
+    else CFHIP_GN_GROUP_FWD_V(RPT, 1);           \
+  } while (0)
     if (rpt <= 48) CFHIP_GN_GROUP_FWD(48);  // (a 24-row instantiation came out of hipcc with 254 VGPRs and 132 B of scratch: not built)
     else if (rpt <= 96) CFHIP_GN_GROUP_FWD(96);
     else if (rpt <= 176) CFHIP_GN_GROUP_FWD(176);
     else CFHIP_GN_GROUP_FWD(0);
 #undef CFHIP_GN_GROUP_FWD
+#undef CFHIP_GN_GROUP_FWD_V
     CFHIP_CHECK_LAUNCH("groupnorm_nhwc_fwd");
     return CFHIP_OK;
   }
@@ -2014,14 +2078,23 @@ extern "C" int cfhip_groupnorm_nhwc_bwd(const void* dy, const void* x, const flo
   CFHIP_REQUIRE((dadd != nullptr) == (add != nullptr), "groupnorm_nhwc_bwd: dadd goes with add");
   hipStream_t s = (hipStream_t)stream;
   if (splits == 0) {  // group form
-    const int rpt = (inner + gn_group_rpp(C / G) - 1) / gn_group_rpp(C / G);
-#define CFHIP_GN_GROUP_BWD(RPT)                                                                                                         \
-  hipLaunchKernelGGL((gn_nhwc_group_bwd_kernel<RPT>), dim3(B * G), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, add, gamma, beta, mean, \
-                     rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu, affine_batch_stride)
+    const int vw = (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0 ? gn_group_vw(C / G) : 1;
+    const int rpp = 256 / ((C / G / 2) / vw);
+    const int rpt = ((inner + rpp - 1) / rpp) * vw;
+#define CFHIP_GN_GROUP_BWD_V(RPT, VW)                                                                                                   \
+  hipLaunchKernelGGL((gn_nhwc_group_bwd_kernel<RPT, VW>), dim3(B * G), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, add, gamma, beta, \
+                     mean, rstd, (bf16_t*)dx, dgamma_part, dbeta_part, dadd, C, G, inner, silu, affine_batch_stride)
+#define CFHIP_GN_GROUP_BWD(RPT)                  \
+  do {                                           \
+    if (vw == 4) CFHIP_GN_GROUP_BWD_V(RPT, 4);   \
+    else if (vw == 2) CFHIP_GN_GROUP_BWD_V(RPT, 2); \
+    else CFHIP_GN_GROUP_BWD_V(RPT, 1);           \
+  } while (0)
     if (rpt <= 48) CFHIP_GN_GROUP_BWD(48);
     else if (rpt <= 88) CFHIP_GN_GROUP_BWD(88);
     else CFHIP_GN_GROUP_BWD(0);
 #undef CFHIP_GN_GROUP_BWD
+#undef CFHIP_GN_GROUP_BWD_V
     CFHIP_CHECK_LAUNCH("groupnorm_nhwc_bwd");
     return CFHIP_OK;
   }

@@ -966,7 +966,9 @@ def gn_nhwc_splits(b: int, inner: int, c: int = 0, groups: int = 0, backward: bo
             # registers (64^2 x 8 x 960: 281 / 246 us forward / backward against 94 / 126, `tools/gn_nhwc_bench.py`), inside the
             # step, beside the weight-gradient GEMMs of the other queue, already from ~50 (64^2 x 8 step: threshold none / 88 / 48 /
             # 32 / 16 / 0 = 59.3 / 58.8 / 58.3 / +0.4 / +1.4 / +3.0 ms, `profiles/r05/gn_nhwc_form_rule_ab.txt`)
-            row_lanes = 256 // (cpg // 2)
+            d = cpg // 2  # dwords per row chunk; a thread reads 4 / 2 / 1 of them with one access (conv.hip: gn_group_vw)
+            vw = 4 if d % 4 == 0 else 2 if d % 2 == 0 else 1
+            row_lanes = 256 // (d // vw)
             if -(-inner // row_lanes) <= GN_NHWC_GROUP_MAX_ROWS:
                 return 0
             # (forward: 32 slices — its statistics kernel reads the slice twice, the second time out of L2; backward: 64)

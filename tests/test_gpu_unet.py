@@ -697,7 +697,8 @@ def test_ddpm_step_updates_inside_backward_bit_identically(golden, handover):
 @pytest.mark.parametrize("form", ["slices", "groups"])
 @pytest.mark.parametrize("b,c,h,w,groups,silu,with_add,per_sample", [
     (2, 320, 16, 16, 32, True, True, False), (1, 640, 8, 8, 32, True, False, False), (3, 64, 5, 7, 32, False, True, False),
-    (1, 2560, 8, 8, 32, True, True, False), (2, 96, 12, 12, 32, True, False, True), (1, 1920, 4, 4, 32, False, False, False)])
+    (1, 2560, 8, 8, 32, True, True, False), (2, 96, 12, 12, 32, True, False, True), (1, 1920, 4, 4, 32, False, False, False),
+    (2, 1280, 40, 40, 32, True, True, False), (1, 640, 48, 48, 32, True, False, False)])
 def test_groupnorm_on_nhwc_rows_vs_torch(b, c, h, w, groups, silu, with_add, per_sample, form, monkeypatch):
     """cfhip_groupnorm_nhwc_fwd / _bwd (nn.GroupNorm(32) [+ the time-embedding add in front, + SiLU behind] on the NHWC rows the
     implicit-GEMM convolutions exchange): output, input gradient, dgamma / dbeta and the add's gradient against fp32 torch on the same
@@ -705,7 +706,10 @@ def test_groupnorm_on_nhwc_rows_vs_torch(b, c, h, w, groups, silu, with_add, per
     8-channel slots), row counts that do not divide into the slices, one affine per sample (the scale-shift form)."""
     # both kernel families on every case: "groups" = one workgroup per (sample, group), one launch each way (what a batch of 8 takes);
     # "slices" = row slices of a sample + merge (what 256^2 x 1 takes)
+    # (the last two cases: 16- and 8-byte accesses of the group form with more rows per thread than its register cache holds one way
+    # or both — the form rule itself would hand them to the slices)
     monkeypatch.setattr(ops, "GN_NHWC_GROUP_MIN_WORKGROUPS", 1 if form == "groups" else 1 << 30)
+    monkeypatch.setattr(ops, "GN_NHWC_GROUP_MAX_ROWS", 1 << 30)
     assert (ops.gn_nhwc_splits(b, h * w, c, groups) == 0) == (form == "groups" and (c // groups) % 2 == 0)  # (3 channels per group: slices)
     torch.manual_seed(b * 1000 + c + h)
     x = bf16_round(torch.randn(b, c, h, w) * 1.5 + 0.3)
