@@ -308,20 +308,24 @@ template <> struct Row8<float> {
   }
 };
 
-template <int G, typename XT>
+// EXACT: D = G * 256.  Otherwise (round 5: the UNet's 320- and 640-wide token rows, which the one-wave-per-row kernel above served at
+// ~1 TB/s inside the step) the row is D_real < G * 256 columns wide, a multiple of 8: the lanes of the last group whose 8 columns lie
+// beyond it load zeros, store nothing and keep zero sums — everything else, LDS layout included, works on the padded width.
+template <int G, typename XT, bool EXACT>
 __global__ __launch_bounds__(LN2_THREADS) void layernorm_bwd_fused_kernel(
     const bf16_t* __restrict__ dy, const XT* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     const bf16_t* __restrict__ dx_add, bf16_t* __restrict__ dx, float* __restrict__ partials, int M,
-    long dys, long xs, long dxs) {
+    long dys, long xs, long dxs, int D_real) {
   constexpr int D = G * 256;
+  const int Dr = EXACT ? D : D_real;
   extern __shared__ __attribute__((aligned(16))) float lds[];  // gamma [D] | red [LN2_WAVES][2][D]
   float* gs = lds;
   float* red = lds + D;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int hl = lane & 31, half = lane >> 5;
-  for (int i = threadIdx.x; i < D; i += LN2_THREADS) gs[i] = gamma[i];
+  for (int i = threadIdx.x; i < D; i += LN2_THREADS) gs[i] = (EXACT || i < Dr) ? gamma[i] : 0.f;
   __syncthreads();
 
   float dg[G][8], db[G][8];
@@ -330,9 +334,10 @@ __global__ __launch_bounds__(LN2_THREADS) void layernorm_bwd_fused_kernel(
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dg[g][e] = 0.f; db[g][e] = 0.f; }
 
-  const float inv_d = 1.0f / (float)D;
+  const float inv_d = 1.0f / (float)Dr;
   const int npairs = (M + 1) >> 1;
   const int nw = gridDim.x * LN2_WAVES;
+  const bool tail_in = EXACT || (G - 1) * 256 + hl * 8 < Dr;  // this lane's columns of the last group exist
   for (int pair = blockIdx.x * LN2_WAVES + wave; pair < npairs; pair += nw) {
     const int row = 2 * pair + half;
     const bool ok = row < M;
@@ -343,9 +348,15 @@ __global__ __launch_bounds__(LN2_THREADS) void layernorm_bwd_fused_kernel(
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const int col = g * 256 + hl * 8;
-        rx[g].load(x + (long)row * xs + col);
-        ry[g] = *reinterpret_cast<const u32x4*>(dy + (long)row * dys + col);
-        ra[g] = dx_add != nullptr ? *reinterpret_cast<const u32x4*>(dx_add + (long)row * dxs + col) : u32x4{0u, 0u, 0u, 0u};
+        if (EXACT || g < G - 1 || tail_in) {
+          rx[g].load(x + (long)row * xs + col);
+          ry[g] = *reinterpret_cast<const u32x4*>(dy + (long)row * dys + col);
+          ra[g] = dx_add != nullptr ? *reinterpret_cast<const u32x4*>(dx_add + (long)row * dxs + col) : u32x4{0u, 0u, 0u, 0u};
+        } else {
+          rx[g].zero();
+          ry[g] = u32x4{0u, 0u, 0u, 0u};
+          ra[g] = ry[g];
+        }
       }
       mean = mean_in[row];
       rstd = rstd_in[row];
@@ -376,6 +387,7 @@ __global__ __launch_bounds__(LN2_THREADS) void layernorm_bwd_fused_kernel(
     if (ok) {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
+        if (!EXACT && g == G - 1 && !tail_in) continue;
         float xv[8], o[8];
         rx[g].get(xv);
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(gs + g * 256 + hl * 8);
@@ -412,12 +424,17 @@ __global__ __launch_bounds__(LN2_THREADS) void layernorm_bwd_fused_kernel(
     }
   }
   __syncthreads();
-  float* out = partials + (long)blockIdx.x * 2 * D;
+  float* out = partials + (long)blockIdx.x * 2 * Dr;
   for (int i = threadIdx.x; i < 2 * D; i += LN2_THREADS) {
     float v = red[i];  // wave 0: [dgamma | dbeta]
 #pragma unroll
     for (int w = 1; w < LN2_WAVES; ++w) v += red[w * 2 * D + i];
-    out[i] = v;
+    if (EXACT) {
+      out[i] = v;
+    } else {
+      const int which = i >= D ? 1 : 0, c = i - which * D;
+      if (c < Dr) out[which * Dr + c] = v;  // the partial rows are [dgamma | dbeta] of the REAL width
+    }
   }
 }
 
@@ -482,7 +499,7 @@ extern "C" size_t cfhip_layernorm_bwd_workspace(int M, int D) {
   return (size_t)rows * 2 * (size_t)D * sizeof(float);
 }
 
-static int g_ln_fused = 1;  // "ln_bwd_fused" option: 1 = the one-launch kernel when both outputs are asked for (default)
+static int g_ln_fused = 1;  // "ln_bwd_fused" option: 1 = the one-launch kernel when both outputs are asked for (default); 2 = only for D % 256 == 0 (rounds 3-4); 0 = never
 int cfhip_internal_set_ln_fused(int v) {
   g_ln_fused = v;
   return CFHIP_OK;
@@ -530,23 +547,24 @@ static int ln_bwd_impl(const void* dy, const void* x, int x_is_f32, const float*
   const int nch = (D + 255) / 256;
   const bool exact = (D % 256) == 0;
   float* partials = reinterpret_cast<float*>(workspace);
-  // one launch for both outputs: D a multiple of 256 up to 1280, 16-byte aligned rows
-  const bool fused_ok = g_ln_fused && do_dx && do_pg && exact && nch <= 5 && dy_row_stride % 8 == 0 && dx_row_stride % 8 == 0 &&
+  // one launch for both outputs: D a multiple of 8 up to 1280 (round 5: not only multiples of 256), 16-byte aligned rows
+  const bool fused_ok = g_ln_fused && (exact || g_ln_fused == 1) && do_dx && do_pg && D % 8 == 0 && nch <= 5 && dy_row_stride % 8 == 0 && dx_row_stride % 8 == 0 &&
                         x_row_stride % (x_is_f32 ? 4 : 8) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0 &&
                         ((uintptr_t)dx & 15) == 0 && ((uintptr_t)dx_add & 15) == 0;
   if (fused_ok) {
     const int blocks2 = ln2_grid(M);
-    const size_t lds2 = (size_t)(1 + 2 * LN2_WAVES) * D * sizeof(float);
+    const size_t lds2 = (size_t)(1 + 2 * LN2_WAVES) * nch * 256 * sizeof(float);
+#define LN_BWD2_T(G_, XT_, EX_)                                                                                      \
+  hipLaunchKernelGGL((layernorm_bwd_fused_kernel<G_, XT_, EX_>), dim3(blocks2), dim3(LN2_THREADS), lds2, s,          \
+                     (const bf16_t*)dy, (const XT_*)x, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx,        \
+                     partials, M, (long)dy_row_stride, (long)x_row_stride, (long)dx_row_stride, D)
 #define LN_BWD2(G_)                                                                                                  \
   do {                                                                                                               \
-    if (x_is_f32)                                                                                                    \
-      hipLaunchKernelGGL((layernorm_bwd_fused_kernel<G_, float>), dim3(blocks2), dim3(LN2_THREADS), lds2, s,         \
-                         (const bf16_t*)dy, (const float*)x, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx,  \
-                         partials, M, (long)dy_row_stride, (long)x_row_stride, (long)dx_row_stride);                 \
-    else                                                                                                             \
-      hipLaunchKernelGGL((layernorm_bwd_fused_kernel<G_, bf16_t>), dim3(blocks2), dim3(LN2_THREADS), lds2, s,        \
-                         (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, \
-                         partials, M, (long)dy_row_stride, (long)x_row_stride, (long)dx_row_stride);                 \
+    if (x_is_f32) {                                                                                                  \
+      if (exact) LN_BWD2_T(G_, float, true); else LN_BWD2_T(G_, float, false);                                       \
+    } else {                                                                                                         \
+      if (exact) LN_BWD2_T(G_, bf16_t, true); else LN_BWD2_T(G_, bf16_t, false);                                     \
+    }                                                                                                                \
   } while (0)
     switch (nch) {
       case 1: LN_BWD2(1); break;
@@ -556,6 +574,7 @@ static int ln_bwd_impl(const void* dy, const void* x, int x_is_f32, const float*
       default: LN_BWD2(5); break;
     }
 #undef LN_BWD2
+#undef LN_BWD2_T
     CFHIP_CHECK_LAUNCH("layernorm_bwd_fused");
     if (rows_out != nullptr) {
       *rows_out = blocks2;

@@ -154,7 +154,10 @@ def test_layernorm_bwd_split_modes():
 
 
 @pytest.mark.parametrize("m,d,xf32", [(25216, 768, True), (1001, 768, False), (7, 256, True), (130, 512, False),
-                                      (999, 1024, True), (513, 1280, True), (1, 768, True)])
+                                      (999, 1024, True), (513, 1280, True), (1, 768, True),
+                                      # round 5: widths that are not multiples of 256 (the UNet's 320 / 640-wide token rows; a last group of
+                                      # one lane; a single lane at all; the widest padded form)
+                                      (4096, 320, False), (1000, 640, False), (77, 520, True), (9, 8, False), (513, 1272, False)])
 def test_layernorm_bwd_one_launch(m, d, xf32):
     """The one-launch backward (dx + dgamma / dbeta, dy and x read once; reference norms.py:88-119 = nn.LayerNorm):
     vs torch autograd in fp32, vs the round-1 kernels (option ln_bwd_fused = 0), and bitwise run-to-run."""
