@@ -1277,15 +1277,19 @@ __device__ __forceinline__ void gn_nhwc_merge(const float* __restrict__ part, in
                                               float* grp) {
   if ((int)threadIdx.x < G) {
     float n = 0.f, mean = 0.f, m2 = 0.f;
+    // (no branch in the body and unrolled: the S pair loads of a thread are independent and issue ahead of the serial merge)
+#pragma unroll 8
     for (int sl = 0; sl < S; ++sl) {
       int r0, r1;
       gn_nhwc_rows(inner, S, sl, r0, r1);
       const float nb = (float)cpg * (float)(r1 - r0);
-      if (nb <= 0.f) continue;
       const float* o = part + (((long)b * S + sl) * G + threadIdx.x) * 2;
-      const float nt = n + nb, d = o[0] - mean;
-      mean += d * (nb / nt);
-      m2 += o[1] + d * d * (n * nb / nt);
+      const float o0 = o[0], o1 = o[1];
+      const bool some = nb > 0.f;  // (an empty slice wrote (0, 0))
+      const float nt = n + nb, d = o0 - mean;
+      const float w = some ? nb / nt : 0.f;
+      mean += d * w;
+      m2 += some ? o1 + d * d * (n * w) : 0.f;
       n = nt;
     }
     grp[threadIdx.x] = mean;
@@ -1510,7 +1514,8 @@ __global__ void gn_nhwc_bwd_merge_kernel(const float* __restrict__ part, float* 
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float sa = 0.f, sb = 0.f;
-  for (int sl = 0; sl < S; ++sl) {
+#pragma unroll 8
+  for (int sl = 0; sl < S; ++sl) {  // (same order of additions; unrolled so that the loads run ahead of them)
     const float* o = part + ((long)b * S + sl) * 2 * C;
     sa += o[c];
     sb += o[C + c];
@@ -1525,6 +1530,7 @@ __global__ void gn_nhwc_dadd_kernel(const float* __restrict__ part, float* __res
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float s = 0.f;
+#pragma unroll 8
   for (int sl = 0; sl < S; ++sl) s += part[((long)b * S + sl) * C + c];
   dadd[(long)b * C + c] = s;
 }
