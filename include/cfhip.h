@@ -52,7 +52,8 @@ const char* cfhip_last_error(void);
  *                     groups of n columns, all rows of a group first (an XCD's resident workgroups then share n B panels
  *                     that stay in its L2); n < 0: row groups of -n panels, columns outer; 0: rows outer, every column inner
  *   "ln_bwd_fused"    1 (default): cfhip_layernorm_bwd asked for dx AND dgamma / dbeta runs the one-launch kernel
- *                     (D a multiple of 256 up to 1280); 0: the round-1 one-wave-per-row kernel
+ *                     (D a multiple of 8 up to 1280; round 5: not only multiples of 256); 2: only for D a multiple of 256
+ *                     (rounds 3-4); 0: the round-1 one-wave-per-row kernel
  *   "gemm_cfg_nt_wide" / "gemm_cfg_nt" / "gemm_cfg_nn" / "gemm_cfg_tn"   tile configuration of one class of M >= 1024 GEMMs
  *                     (forward with N >= 2560, other forward, dX, dW); -1 (default): the heuristic table
  *   "attn_persistent" bits: 1 dK / dV pass, 2 dQ pass, 4 forward of the head_dim-64 kernels run as persistent 16-wave
