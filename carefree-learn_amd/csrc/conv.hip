@@ -1507,6 +1507,8 @@ __global__ __launch_bounds__(256) void gn_nhwc_bwd_apply_kernel(const bf16_t* __
   }
 }
 
+#undef GN_NHWC_ROW_LOOP
+
 // dgamma_part[b][c] / dbeta_part[b][c] = the slice sums of A_c / B_c added in slice order, once per sample (S C loads per sample)
 __global__ void gn_nhwc_bwd_merge_kernel(const float* __restrict__ part, float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
                                          int C, int S) {
