@@ -1170,6 +1170,20 @@ def _implicit_ok(cin: int, cout: int, kh: int, kw: int, stride: int, pad: int, d
             and h < 65536 and w < 65536)
 
 
+# A 3x3 / stride 1 / pad 1 convolution onto a FEW channels that are not a multiple of 8 (the UNet's 3-channel head at full
+# resolution) runs the implicit route on filters padded with zeros to 32 output channels: the im2row route materialises the
+# [B H W, 9 Cin] matrix (189 MB at 64^2 x 8 x 320) in the forward, again for the weight gradient, and once more as the gradient
+# matrix that row2im folds back; the padded implicit convolution reads the 21 MB activation.  32, not 8: the input-gradient
+# convolution takes dY as its input and wants a multiple of 32 channels there.
+THIN_HEAD_IMPLICIT = os.environ.get("CFHIP_CONV_THIN_HEAD", "1") != "0"
+THIN_HEAD_PAD = 32
+
+
+def _thin_head_ok(cin: int, cout: int, kh: int, kw: int, stride: int, pad: int, dil: int, h: int, w: int) -> bool:
+    return (THIN_HEAD_IMPLICIT and cout % 8 != 0 and cout < THIN_HEAD_PAD
+            and _implicit_ok(cin, THIN_HEAD_PAD, kh, kw, stride, pad, dil, h, w))
+
+
 class Conv2dFn(Function):
     """Replaces F.conv2d reached from Conv2d.forward (reference convs/basic.py:160-177), groups = 1:
     NCHW in (f32 / bf16), NCHW bf16 out.  Two routes: implicit GEMM on an NHWC copy (3x3 / stride 1 / pad 1,
@@ -1192,10 +1206,22 @@ class Conv2dFn(Function):
         ctx.weight, ctx.bias = weight, bias
         ctx.geom = (kh, kw, stride, pad, dil, ho, wo)
         ctx.implicit = _implicit_ok(cin, cout, kh, kw, stride, pad, dil, h, w)
+        thin = not ctx.implicit and _thin_head_ok(cin, cout, kh, kw, stride, pad, dil, h, w)
         nhwc_out = NHWC[0] and cout % 8 == 0  # hand the output rows on as a channels_last view
-        if ctx.implicit:
+        if ctx.implicit or thin:
+            ctx.implicit = True
             x_rows = nhwc_rows(x) if nhwc_in else ops.transpose_batched(x.view(b, cin, h * w)).view(b * h * w, cin)  # NHWC bf16
             w16 = shadow_bf16(weight).view(cout, cin, 3, 3)
+            cop = cout
+            if thin:  # zero filters up to THIN_HEAD_PAD output channels (see _thin_head_ok); backward reads the padded copy
+                cop = THIN_HEAD_PAD
+                w16p = torch.zeros((cop, cin, 3, 3), dtype=bf16, device=x.device)
+                w16p[:cout] = w16
+                w16 = w16p
+                if bias_f is not None:
+                    bpad = torch.zeros((cop,), dtype=f32, device=x.device)
+                    bpad[:cout] = bias_f
+                    bias_f = bpad
             wk = ops.conv3x3_pack_filters(w16, False)  # k = (ky, kx, c): a K-step = 32 channels of a tap
             y_rows = ops.conv3x3_nhwc(x_rows, wk, bias_f, b, h, w)
             ctx.save_for_backward(x_rows, w16)  # the NHWC bf16 copy serves the weight gradient; x itself is not kept
@@ -1204,14 +1230,14 @@ class Conv2dFn(Function):
             # lane beside the forward convolution, instead of on the backward's critical queue (47 launches, 1.65 ms of the
             # 64^2 x 8 UNet step).  The weights' current bf16 shadow does not change before this step's backward has run.
             ctx.wr = ctx.wr_event = None
-            if PACK_AHEAD == 2 and cout % 32 == 0 and ctx.needs_input_grad[0]:
+            if PACK_AHEAD == 2 and cop % 32 == 0 and ctx.needs_input_grad[0]:
                 # on the caller's stream: the forward of the UNet is issue-bound (the queue drains faster than the host fills
                 # it), the backward is bound by its queue — the pack costs nothing here and 35 us per layer there
                 ctx.wr = ops.conv3x3_pack_filters(w16, True)
-            elif PACK_AHEAD == 1 and cout % 32 == 0 and ctx.needs_input_grad[0]:
+            elif PACK_AHEAD == 1 and cop % 32 == 0 and ctx.needs_input_grad[0]:
                 side = SideStream.fork(0)
                 if side is not None:
-                    wr = torch.empty((cin, 9 * cout), dtype=bf16, device=x.device)  # (allocated on the caller's stream: freed there)
+                    wr = torch.empty((cin, 9 * cop), dtype=bf16, device=x.device)  # (allocated on the caller's stream: freed there)
                     with on_stream(side):
                         ops.conv3x3_pack_filters(w16, True, out=wr)
                     ev = torch.cuda.Event()
@@ -1219,7 +1245,8 @@ class Conv2dFn(Function):
                     ctx.wr, ctx.wr_event = wr, ev
             if nhwc_out:
                 return rows_to_nhwc(y_rows, b, cout, h, w)
-            return ops.transpose_batched(y_rows.view(b, h * w, cout)).view(b, cout, h, w)
+            y = ops.transpose_batched(y_rows.view(b, h * w, cop)).view(b, cop, h, w)
+            return y[:, :cout].contiguous() if cop != cout else y
         # 1x1 / stride 1 (the skip connections of the UNet's residual blocks): the im2row matrix IS the NHWC copy of x — one
         # batched transpose instead of the gather kernel, kept for the weight gradient (the im2row route recomputes it), and
         # dX comes back through a transpose instead of row2im (UNet 64^2 x 8: 38 im2row + 18 row2im launches, 3.7 ms)
@@ -1263,7 +1290,7 @@ class Conv2dFn(Function):
         k = cin * kh * kw
         dy = as_bf16_act(dy)
         # implicit forward: wp is the [Cout, Cin, 3, 3] bf16 shadow, the dW GEMM still reads an im2row matrix
-        cp = cout if ctx.implicit else wp.shape[0]  # output channels incl. the zero filters padding Cout to 8
+        cp = wp.shape[0]  # output channels incl. the zero filters padding Cout (to 8 on the im2row route, to 32 for a thin implicit head)
         if cp != cout:
             dyp = torch.zeros((b, cp, ho * wo), dtype=bf16, device=dy.device)
             dyp[:, :cout] = to_nchw(dy).reshape(b, cout, ho * wo)
@@ -1280,10 +1307,17 @@ class Conv2dFn(Function):
             if ctx.implicit and not wgrad_implicit and weight.requires_grad:
                 x = ops.transpose_batched(x.view(b, h * w, cin)).view(b, cin, h, w)  # back to NCHW for the im2row route
             if weight.requires_grad and wgrad_implicit:
-                split = ops.pick_split_k(cout, 9 * cin, b * h * w)
+                split = ops.pick_split_k(cp, 9 * cin, b * h * w)
 
                 def dw_implicit(out: Tensor, acc: bool) -> None:
-                    ops.conv3x3_wgrad_nhwc(dy_rows, x, b, h, w, split, out=out.view(cout, cin, 3, 3), accumulate=acc)
+                    if cp == cout:
+                        ops.conv3x3_wgrad_nhwc(dy_rows, x, b, h, w, split, out=out.view(cout, cin, 3, 3), accumulate=acc)
+                        return
+                    tmp = ops.conv3x3_wgrad_nhwc(dy_rows, x, b, h, w, split)[:cout]  # (the zero filters' rows are dropped)
+                    if acc:
+                        out.view(cout, cin, 3, 3).add_(tmp)
+                    else:
+                        out.view(cout, cin, 3, 3).copy_(tmp)
 
                 if _is_direct(weight):
                     write_param_grad(weight, dw_implicit)
@@ -1339,7 +1373,7 @@ class Conv2dFn(Function):
             gw, gb = param_grads()
         dx = None
         if ctx.needs_input_grad[0]:
-            if ctx.implicit and cout % 32 == 0:
+            if ctx.implicit and cp % 32 == 0:
                 # dX = conv3x3(dY, filters rotated by 180 degrees, channels swapped): k = (ky, kx, co)
                 wr = getattr(ctx, "wr", None)
                 if wr is not None:
@@ -1350,7 +1384,7 @@ class Conv2dFn(Function):
                 dx_rows = ops.conv3x3_nhwc(dy_rows, wr, None, b, h, w)
                 dx = rows_to_nhwc(dx_rows, b, cin, h, w) if nhwc_dx else ops.transpose_batched(dx_rows.view(b, h * w, cin)).view(b, cin, h, w)
             else:
-                w2 = wp.reshape(cout, k) if ctx.implicit else wp
+                w2 = wp.reshape(cp, k) if ctx.implicit else wp
                 drows = ops.gemm(dy_rows, w2, b_trans=True)  # [M, Kp] bf16
                 if getattr(ctx, "pointwise", False):
                     dx = rows_to_nhwc(drows, b, cin, h, w) if nhwc_dx else ops.transpose_batched(drows.view(b, h * w, cin)).view(b, cin, h, w)

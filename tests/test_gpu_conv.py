@@ -236,12 +236,15 @@ def test_conv_classifier_and_fcnn_train_steps(golden):
     (2, 320, 320, 32, 32),  # UNet level (K = 2880 = 90 K-steps, 10 per tap); 24 tiles: the reduction is split 5 ways
     (1, 96, 64, 5, 7),      # image smaller than a tile row: every tile crosses image rows
     (2, 256, 128, 8, 8),    # the UNet's deepest level: one output tile, the reduction is split 4 ways (base kernel)
+    (2, 64, 3, 20, 24),     # a thin head (the UNet's 3 output channels): zero filters up to 32 channels, all three passes implicit
+    (3, 320, 5, 16, 16),    # the same from 320 channels, M = 768 (base kernel)
 ])
 def test_implicit_conv3x3_matches_fp32_reference_and_im2row_route(shape):
     """cfhip_conv3x3_nhwc_bf16 / cfhip_conv3x3_wgrad_nhwc_bf16 (taps gathered inside the GEMM K loop, zero padding by per-lane range checks) against
     torch's fp32 conv2d on the bf16-rounded operands (CPU), forward / input gradient / weight + bias gradients, and
     against the im2row route of the same Function."""
     b, cin, cout, h, w = shape
+    assert HF._thin_head_ok(cin, cout, 3, 3, 1, 1, 1, h, w) == (cout % 8 != 0)
     g = torch.Generator().manual_seed(b * 1000 + cin + h)
     x = bf16_round(torch.randn(b, cin, h, w, generator=g))
     wt = bf16_round(torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5))
