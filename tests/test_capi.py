@@ -127,3 +127,41 @@ def test_vectorcall_entry_module_is_the_same_library():
         lib.cfhip_colsum_workspace("a", 3)
     with pytest.raises((TypeError, OverflowError)):
         lib.cfhip_gemm_bf16(*(("x",) + args[1:]))
+
+
+def test_kernels_spill_only_where_documented(tmp_path):
+    """The code objects inside the built libcfhip.so: no kernel uses scratch memory except the three head_dim-64 long-sequence attention
+    instantiations DESIGN.md §3.5 names (12-36 bytes; built without scratch they are 6-16 % slower, profiles/r05/attn_ndt4_scratch_ab.txt).
+    Read from the kernels' metadata notes with the ROCm LLVM tools — a compiler flag or an edit that makes a kernel spill shows up here,
+    on the CPU, before it costs anything on the GPU."""
+    import re
+    import shutil
+    import subprocess
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in tools) or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("ROCm LLVM tools or the built library are missing")
+    fat = tmp_path / "fat.bin"
+    subprocess.run([tools[0], f"--dump-section=.hip_fatbin={fat}", _lib.LIB_PATH, str(tmp_path / "stripped.so")], check=True)
+    data = fat.read_bytes()
+    starts = [m.start() for m in re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), data)]  # one bundle per translation unit
+    assert len(starts) >= 10, len(starts)
+    kernels, spilling = 0, {}
+    for i, off in enumerate(starts):
+        blob = tmp_path / f"bundle{i}.bin"
+        blob.write_bytes(data[off:starts[i + 1] if i + 1 < len(starts) else len(data)])
+        elf = tmp_path / f"code{i}.elf"
+        subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={blob}",
+                        f"--output={elf}"], check=True, capture_output=True)
+        notes = subprocess.run([tools[2], "--notes", str(elf)], check=True, capture_output=True, text=True).stdout
+        for name, scratch in re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", notes):
+            kernels += 1
+            if int(scratch) > 0:
+                spilling[name] = int(scratch)
+    shutil.rmtree(tmp_path, ignore_errors=True)
+    assert kernels > 400, kernels
+    allowed = ("attn_fwd2_kernelILb1ELi4ELb0E", "attn_fwd2_kernelILb0ELi4ELb0E", "attn_bwd_dq2_kernelILb1ELi4E")
+    unexpected = {k: v for k, v in spilling.items() if not any(a in k for a in allowed)}
+    assert not unexpected, unexpected
+    assert all(v <= 64 for v in spilling.values()), spilling
