@@ -1,0 +1,158 @@
+"""How far does the REFERENCE'S OWN bf16 execution of the full-size CLIP (ViT-B/32 + 12 x 512 causal text tower) sit from its
+fp32 execution?  — TEST INFRASTRUCTURE ONLY.
+
+Build container only (imports the reference from /root/reference through oracle/refharness).  Writes the small fixture
+tests/golden/clip_b32_yardstick.pt that `tests/test_gpu_clip.py::test_clip_b32_step_vs_oracle` uses as its bound (VERDICT r5 #1:
+the benchmarked CLIP step was only compared with the oracle on a 2-layer / 128-wide / 16-token fixture).
+
+The model is cflearn's `CLIP` with its default constructor arguments (multimodal/clip.py:22-256: ViT-B/32 at 224^2 -> 50 tokens x
+768, 12 layers x 12 heads; text tower `TeTEncoder`, nlp/encoder/transformer.py:17-99: 77 tokens x 512, 12 layers x 8 heads, triu
+mask, vocabulary 49 408; 151 277 825 parameters) — the model `bench.py --workload clip` times.  The reference has no CLIP training
+loss; the symmetric InfoNCE over `logits_per_image` (multimodal/schema.py:25-30) gives the backward pass something to
+differentiate, as in `gen_golden.py::gen_clip`.
+
+The state dict (600 MB) cannot be committed, so the problem is SEEDED: `seeded_problem()` builds this repo's module on the CPU
+(parameter creation only, no kernel) exactly as the GPU test does, and the reference module loads that state dict (strict).
+What travels is numbers: the fp32 loss / probes of the fp32 features, logits and sampled gradients (pins `oracle/clip_oracle.py`
+at full size), and per tensor the rel-L2 distance of the reference's `torch.autocast("cpu", bfloat16)` run from its fp32 run —
+what `mixed_precision="bf16"` executes (trainer.py:264-273).
+
+    python oracle/gen_clip_b32_yardstick.py        # ~2 min on 8 cores
+"""
+import importlib
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from refharness import load_reference  # noqa: E402
+
+BATCH = 16
+
+# one tensor per layer type and depth of both towers + everything outside the block stacks
+CLIP_SAMPLED = [
+    "logit_scale",
+    "vit.output_projection",
+    "vit.to_patches.projection.weight",
+    "vit.encoder.head_token",
+    "vit.encoder.pos_encoding.pos_encoding",
+    "vit.encoder.embedding_norm.weight",
+    "vit.encoder.mixing_blocks.0.token_mixing.net.in_w",
+    "vit.encoder.mixing_blocks.0.channel_mixing.net.0.linear.weight",
+    "vit.encoder.mixing_blocks.5.token_mixing.net.out_linear.linear.weight",
+    "vit.encoder.mixing_blocks.5.channel_mixing.net.3.linear.weight",
+    "vit.encoder.mixing_blocks.5.token_norm.weight",
+    "vit.encoder.mixing_blocks.11.token_mixing.net.qkv_bias",
+    "vit.encoder.mixing_blocks.11.channel_mixing.net.0.linear.bias",
+    "vit.encoder.mixing_blocks.11.channel_mixing.net.3.linear.weight",
+    "vit.encoder.head_norm.weight",
+    "token_embedding.weight",
+    "text_transformer.encoder.pos_encoding.pos_encoding",
+    "text_transformer.encoder.mixing_blocks.0.token_mixing.net.in_w",
+    "text_transformer.encoder.mixing_blocks.0.channel_mixing.net.0.linear.weight",
+    "text_transformer.encoder.mixing_blocks.6.token_mixing.net.out_linear.linear.weight",
+    "text_transformer.encoder.mixing_blocks.6.channel_mixing.net.3.linear.weight",
+    "text_transformer.encoder.mixing_blocks.6.channel_norm.bias",
+    "text_transformer.encoder.mixing_blocks.11.token_mixing.net.in_w",
+    "text_transformer.encoder.mixing_blocks.11.channel_mixing.net.3.linear.bias",
+    "text_transformer.encoder.head.norms.0.weight",
+    "text_projection.weight",
+    "text_projection.bias",
+]
+
+
+def seeded_problem(batch: int = BATCH):
+    """state dict + inputs exactly as tests/test_gpu_clip.py::test_clip_b32_step_vs_oracle builds them (this repo's module is
+    only used for its seeded initialisation on the CPU).  1-D parameters (biases, LayerNorm affines) are moved off their trivial
+    initial values so that their gradients are not taken at a symmetric point; captions are ragged: the end-of-text token (the
+    largest id, which `indices.argmax` finds: clip.py:251) sits at a different place in each row, padding id 0 behind it — the
+    layout SURVEY §8(d) states and bench.py generates."""
+    import cflearn_amd as C
+
+    torch.manual_seed(0)
+    m = C.build_module("clip", config={})
+    g = torch.Generator().manual_seed(97)
+    with torch.no_grad():
+        for prm in m.parameters():
+            if prm.dim() == 1:
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.05)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(2468)
+    img = torch.randn(batch, 3, 224, 224, generator=g)
+    txt = torch.randint(1, 49407, (batch, 77), generator=g)
+    eot = torch.randint(8, 77, (batch,), generator=g)
+    for i in range(batch):
+        txt[i, eot[i]] = 49407
+        txt[i, eot[i] + 1:] = 0
+    return sd, img, txt
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-30)).item()
+
+
+def probe(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach().flatten()
+    return t[:: max(1, t.numel() // 64)][:64].clone()
+
+
+def info_nce(logits: torch.Tensor) -> torch.Tensor:
+    target = torch.arange(logits.shape[0])
+    ce = torch.nn.functional.cross_entropy
+    return 0.5 * (ce(logits, target) + ce(logits.t(), target))
+
+
+def main() -> None:
+    load_reference()
+    clip = importlib.import_module("cflearn.modules.multimodal.clip")
+    sd, img, txt = seeded_problem()
+    m = clip.CLIP()
+    print("reference CLIP:", sum(p.numel() for p in m.parameters()), "parameters;", m.load_state_dict(sd, strict=True))
+    params = dict(m.named_parameters())
+    leaves = [params[k] for k in CLIP_SAMPLED]
+
+    t0 = time.time()
+    fi32, ft32 = m.encode_image(img), m.encode_text(txt)
+    lg32 = m.logit_scale.exp() * fi32 @ ft32.t()  # IPerceptor.forward, schema.py:25-30
+    loss32 = info_nce(lg32)
+    g32 = torch.autograd.grad(loss32, leaves)
+    print(f"fp32 forward + backward: {time.time() - t0:.1f} s, loss {loss32.item():.6f}", flush=True)
+
+    t0 = time.time()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        fi16, ft16 = m.encode_image(img), m.encode_text(txt)
+        lg16 = m(img, txt)
+        loss16 = info_nce(lg16.float())
+    g16 = torch.autograd.grad(loss16, leaves)
+    print(f"bf16-autocast forward + backward: {time.time() - t0:.1f} s, loss {loss16.item():.6f}, "
+          f"feature dtypes {fi16.dtype} / {ft16.dtype}, logits {lg16.dtype}", flush=True)
+
+    out = dict(
+        batch=BATCH, torch_version=torch.__version__, threads=torch.get_num_threads(),
+        n_params=sum(p.numel() for p in m.parameters()),
+        loss_fp32=loss32.item(), loss_autocast=loss16.item(),
+        image_features_err=rel_l2(fi16.detach(), fi32.detach()), text_features_err=rel_l2(ft16.detach(), ft32.detach()),
+        logits_err=rel_l2(lg16.detach(), lg32.detach()),
+        image_features_probe=probe(fi32), text_features_probe=probe(ft32), logits_probe=probe(lg32),
+        grad_err={k: rel_l2(a, b) for k, a, b in zip(CLIP_SAMPLED, g16, g32)},
+        grad_norm={k: b.norm().item() for k, b in zip(CLIP_SAMPLED, g32)},
+        grad_probe={k: probe(b) for k, b in zip(CLIP_SAMPLED, g32)},
+    )
+    print(f"autocast vs fp32 rel-L2: image features {out['image_features_err']:.3e}, text features {out['text_features_err']:.3e}, "
+          f"logits {out['logits_err']:.3e}, loss {abs(loss16.item() - loss32.item()) / abs(loss32.item()):.3e}")
+    for k in CLIP_SAMPLED:
+        print(f"    {k:80s} {out['grad_err'][k]:.3e}   |g| {out['grad_norm'][k]:.3e}")
+    dst = os.path.join(ROOT, "tests", "golden", "clip_b32_yardstick.pt")
+    torch.save(out, dst)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -6,7 +6,7 @@ import torch
 import cflearn_amd as C
 from cflearn_amd import functional as HF
 from cflearn_amd import ops
-from helpers import assert_close, bf16_round
+from helpers import assert_close, bf16_round, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda")
@@ -220,3 +220,102 @@ def test_clip_step_updates_inside_backward_like_the_end_of_step_launch(golden):
     (l0, p0), (l1, p1) = outs
     assert max(abs(a - b) for a, b in zip(l0, l1)) <= 2e-3 * abs(l0[0]), (l0, l1)
     assert_close(p1, p0, 2e-4, "parameters after three steps")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Full size (round 6): the model bench.py --workload clip times, against the fp32 oracle on the host cores and
+# against the REFERENCE'S OWN bf16-autocast distance from fp32 (tests/golden/clip_b32_yardstick.pt, made in the build container
+# from cflearn's CLIP by oracle/gen_clip_b32_yardstick.py).
+# ---------------------------------------------------------------------------------------------------------------------
+_B32 = {}
+
+
+def _clip_b32_oracle():
+    """seeded problem + fp32 oracle (features, logits, loss, sampled gradients) on the host cores, once per session"""
+    if _B32:
+        return _B32
+    import os
+    import time
+
+    import clip_oracle as CL
+    from gen_clip_b32_yardstick import BATCH, CLIP_SAMPLED, info_nce, probe, seeded_problem
+
+    ref = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clip_b32_yardstick.pt"), weights_only=False)
+    assert ref["batch"] == BATCH and list(ref["grad_err"]) == CLIP_SAMPLED
+    sd, img, txt = seeded_problem()
+    assert ref["n_params"] == 151277825  # BASELINE.md: ViT-B/32 + 12 x 512 text tower
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    try:
+        t0 = time.time()
+        osd = {k: v.clone() for k, v in sd.items()}
+        leaves = [osd[k].requires_grad_(True) for k in CLIP_SAMPLED]
+        fi = CL.encode_image(img, osd, 12, 12)
+        ft = CL.encode_text(txt, osd, 8, 12)
+        logits = osd["logit_scale"].exp() * fi @ ft.t()
+        loss = info_nce(logits)
+        grads = torch.autograd.grad(loss, leaves)
+        print(f"CLIP ViT-B/32 + text oracle, batch {BATCH}: fp32 forward + backward on the host {time.time() - t0:.1f} s")
+    finally:
+        torch.set_num_threads(prev)
+    # (1) the restatement against the reference's own fp32 run at FULL size (two fp32 CPU runs with different op decompositions)
+    assert abs(loss.item() - ref["loss_fp32"]) <= 1e-5 * abs(ref["loss_fp32"]), (loss.item(), ref["loss_fp32"])
+    assert rel_l2(probe(fi), ref["image_features_probe"]) <= 1e-4
+    assert rel_l2(probe(ft), ref["text_features_probe"]) <= 1e-4
+    assert rel_l2(probe(logits), ref["logits_probe"]) <= 1e-4
+    for k, gr in zip(CLIP_SAMPLED, grads):
+        assert rel_l2(probe(gr), ref["grad_probe"][k]) <= 5e-4, (k, rel_l2(probe(gr), ref["grad_probe"][k]))
+        assert abs(gr.norm().item() - ref["grad_norm"][k]) <= 2e-4 * ref["grad_norm"][k], k
+    _B32.update(ref=ref, sd=sd, img=img, txt=txt, fi=fi.detach(), ft=ft.detach(), logits=logits.detach(), loss=loss.item(),
+                grads=dict(zip(CLIP_SAMPLED, (g_.detach() for g_ in grads))), names=CLIP_SAMPLED)
+    return _B32
+
+
+@pytest.mark.parametrize("towers", [True, False], ids=["towers_side_by_side", "one_tower_after_the_other"])
+def test_clip_b32_step_vs_oracle(towers):
+    """BASELINE config 5 at the benchmarked model size (multimodal/clip.py:209-256, nlp/encoder/transformer.py:17-99: ViT-B/32 at
+    224^2 = 50 tokens x 768 + 12 x 512 causal text tower at 77 tokens, vocabulary 49 408, ragged captions with the end token
+    placed as SURVEY §8(d) says), batch 16, through the path bench.py times: `LossTrainStep` over `CLIP.contrastive_loss` ->
+    `_encode_both` (arena + bf16 shadows, in-backward optimizer, the recorded AND the replayed launch plan), with the two towers
+    side by side on two streams and one after the other (`CFHIP_CLIP_TOWERS=0`).  lr = 0 keeps the problem fixed over the three
+    steps, so step 1 (composed launch), step 2 (plan recording) and step 3 (plan replay) must all reproduce the oracle."""
+    from cflearn_amd.engine import LossTrainStep
+
+    o = _clip_b32_oracle()
+    ref, names = o["ref"], o["names"]
+    torch.manual_seed(0)
+    m = C.build_module("clip", config={})
+    m.load_state_dict(o["sd"])
+    m = m.to(DEV)
+    m.towers_side_by_side = towers
+    img, txt = o["img"].to(DEV), o["txt"].to(DEV)
+    with torch.no_grad():
+        fi, ft = m.encode_image(img), m.encode_text(txt)
+        logits = m(img, txt)
+    e_fi, e_ft, e_lg = rel_l2(fi, o["fi"]), rel_l2(ft, o["ft"]), rel_l2(logits, o["logits"])
+    print(f"CLIP b32 (towers side by side: {towers}): image features {e_fi:.3e} (reference bf16-autocast {ref['image_features_err']:.3e}), "
+          f"text features {e_ft:.3e} ({ref['text_features_err']:.3e}), logits {e_lg:.3e} ({ref['logits_err']:.3e})")
+    assert e_fi <= 1.1 * ref["image_features_err"], (e_fi, ref["image_features_err"])
+    assert e_ft <= 1.1 * ref["text_features_err"], (e_ft, ref["text_features_err"])
+    assert e_lg <= 1.1 * ref["logits_err"], (e_lg, ref["logits_err"])
+
+    ts = LossTrainStep(m, lambda mod, b: mod.contrastive_loss(b["image"], b["text"]), lr=0.0)
+    batch = dict(image=img, text=txt)
+    params = dict(m.named_parameters())
+    before = ts.arena.flat_p.clone()
+    for step in (1, 2, 3):
+        loss = ts.step(batch).item()
+        torch.cuda.synchronize()
+        loss_err = abs(loss - o["loss"]) / abs(o["loss"])
+        errs = {k: rel_l2(params[k].grad, o["grads"][k]) for k in names}
+        worst = max(errs, key=lambda k: errs[k] / ref["grad_err"][k])
+        print(f"  step {step}: loss {loss:.6f} vs {o['loss']:.6f} (rel {loss_err:.2e}); worst sampled gradient {errs[worst]:.3e} = "
+              f"{errs[worst] / ref['grad_err'][worst]:.2f} x the reference's bf16-autocast distance ({worst})")
+        if step == 3:
+            for k in names:
+                print(f"    {k:82s} {errs[k]:.3e}   reference bf16-autocast {ref['grad_err'][k]:.3e} (x {errs[k] / ref['grad_err'][k]:.2f})")
+        assert loss_err <= 1e-3, (loss, o["loss"])
+        for k in names:
+            assert errs[k] <= max(1e-2, 1.1 * ref["grad_err"][k]), (step, k, errs[k], ref["grad_err"][k])
+    assert torch.equal(ts.arena.flat_p, before)  # lr = 0: the three steps really were the same problem
+    assert ts.optimizer.in_backward is None or ts.optimizer.in_backward.launched_in_backward > 0

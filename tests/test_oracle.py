@@ -322,3 +322,17 @@ def test_ddpm_objective_oracle_and_noise_schedule_tables(golden):
         s = NoiseSchedule(1000, c["schedule"], parameterization=c["parameterization"], v_posterior=c["v_posterior"])
         for name in ("betas", "lvlb_weights", "posterior_variance", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod"):
             assert torch.equal(getattr(s, name), c[name]), (c["schedule"], c["parameterization"], name)
+
+
+def test_clip_oracle_at_full_size_matches_the_reference_probes():
+    """oracle/clip_oracle.py at the benchmarked model size (ViT-B/32 + 12 x 512 text tower, 151 M parameters, batch 16, seeded)
+    against the numbers the reference's own CLIP produced for the same seeded problem in fp32
+    (tests/golden/clip_b32_yardstick.pt, oracle/gen_clip_b32_yardstick.py): loss, feature / logit probes, 27 sampled gradients.
+    The same check runs on the GPU box inside tests/test_gpu_clip.py::test_clip_b32_step_vs_oracle."""
+    import test_gpu_clip as T
+
+    o = T._clip_b32_oracle()  # (asserts the probes)
+    ref = o["ref"]
+    assert len(o["names"]) >= 20 and {"token_embedding.weight", "logit_scale", "vit.output_projection", "text_projection.weight"} <= set(o["names"])
+    # the yardstick itself: the reference's bf16-autocast run is a real distance away from its fp32 run, and a small one
+    assert 1e-3 < ref["logits_err"] < 2e-2 and all(5e-3 < v < 6e-2 for v in ref["grad_err"].values())
