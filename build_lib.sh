@@ -5,7 +5,7 @@ cd "$(dirname "$0")/carefree-learn_amd/csrc"
 OUT=../libcfhip.so
 mkdir -p ../_build
 pids=()
-for f in errors gemm gemm_pp gemm_grouped attn attn_probs norm elementwise conv conv_grouped embed random tabular comm; do
+for f in errors gemm gemm_grouped attn attn_probs norm elementwise conv conv_grouped embed random tabular comm; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -c $f.hip -o ../_build/$f.o &
   pids+=($!)
 done

@@ -566,8 +566,7 @@ using CfgW = Cfg<256, 256, 2, 4, 2, 64>;  // 128 KiB LDS, 8 waves (128x64 each),
 using CfgY = Cfg<192, 128, 2, 4, 2, 64>;  //  80 KiB LDS, 8 waves (96x32 each), 2 WG / CU, BK = 64 (plain kernel)
 using CfgZ = Cfg<192, 128, 2, 2, 2, 64>;  //  80 KiB LDS, 4 waves (96x64 each: 2.4 MFMAs per fragment read against 1.5), 2 WG / CU
 using CfgV = Cfg<128, 256, 2, 4, 2, 64>;  //  96 KiB LDS, 8 waves (64x64 each), 1 WG / CU
-constexpr int PP_BASE = 17, PP_COUNT = 4;  // 17 .. 20: the software-pipelined 32x32x16 kernels of gemm_pp.hip
-constexpr int NUM_CFG = PP_BASE + PP_COUNT;  // 7 .. 12 = CfgP / CfgQ / CfgR / CfgS / CfgT / CfgU on the phase kernel; 13 / 14 = CfgW / CfgY; 15 / 16 = CfgZ / CfgV
+constexpr int NUM_CFG = 17;  // (17 .. 20 were the software-pipelined 32x32x16 kernels of round 4: measured, never selected, removed in round 6 — profiles/r04/gemm_pp_*.log, docs/DESIGN_HISTORY.md)  7 .. 12 = CfgP / CfgQ / CfgR / CfgS / CfgT / CfgU on the phase kernel; 13 / 14 = CfgW / CfgY; 15 / 16 = CfgZ / CfgV
 constexpr int BK_MAX = 64;
 
 int g_gemm_config = -1;
@@ -576,7 +575,6 @@ int g_gemm_ablate = 0;
 #endif
 int g_gemm_heuristic = 9;  // round 5: 9 (four-wave 192x128x64 for every M >= 1024 forward / dX GEMM): ViT 17.61 -> 17.47 ms, CLIP 17.89 -> 17.60, UNet neutral (profiles/r05/heuristic9_ab.txt)
 int g_gemm_group_n = 8;
-int g_pp_group_n = 0;  // tile walk of the gemm_pp kernels: 0 row-major, n > 0 column groups of n tiles
 
 template <bool AT, bool BT, int EPI, class C, bool PIPE, int CONV = 0>
 int launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
@@ -780,9 +778,6 @@ int cfhip_internal_gemm_grouped_plain(const cfhip_gemm_problem* problems, int co
 int cfhip_internal_set_attn_ablate(int v);  // attn.hip
 #endif
 int cfhip_internal_set_ln_fused(int v);  // norm.hip
-int cfhip_internal_gemm_pp_supported(int M, int N, int K, long ldc, int a_trans, int b_trans, int epilogue, int out_dtype, int accumulate,
-                                     int split_k, int variant);  // gemm_pp.hip
-int cfhip_internal_gemm_pp(const void* params, int variant, int b_trans, int epilogue, void* stream);
 int cfhip_internal_set_attn_persistent(int v);  // attn.hip
 int cfhip_internal_set_attn_pers_ctas(int v);  // attn.hip
 int cfhip_internal_set_grouped_variant(int v);  // gemm_grouped.hip
@@ -808,10 +803,6 @@ extern "C" int cfhip_set_option(const char* name, int value) {
     g_gemm_group_n = value;
     return CFHIP_OK;
   }
-  if (name != nullptr && strcmp(name, "gemm_pp_group_n") == 0) {
-    g_pp_group_n = value;
-    return CFHIP_OK;
-  }
   if (name != nullptr && strcmp(name, "ln_bwd_fused") == 0) return cfhip_internal_set_ln_fused(value);
   if (name != nullptr && strcmp(name, "attn_persistent") == 0) return cfhip_internal_set_attn_persistent(value);
   if (name != nullptr && strcmp(name, "attn_pers_ctas") == 0) return cfhip_internal_set_attn_pers_ctas(value);
@@ -834,9 +825,12 @@ extern "C" int cfhip_set_option(const char* name, int value) {
 // of the plain kernel only: every phase-kernel configuration (7 .. 12) and the 256x256 / 128x256 plain tiles (13, 16) go to 1
 // (round 5, ADVICE r4: 9 / 10 / 11 used to return CFHIP_ERR_INVALID under a forced gemm_config).
 static int resolve_config(int cfg, int a_trans, int epilogue, bool bias_grad) {
-  if (cfg == 1 && (epilogue == CFHIP_EPI_RESIDUAL || epilogue == CFHIP_EPI_DGELU)) cfg = 3;
   if (cfg == 8 && a_trans) cfg = 1;
   if (bias_grad && ((cfg >= 7 && cfg <= 13) || cfg == 16)) cfg = 1;
+  // LAST (round 6): CfgB (128x128x32 on two stages) has no RESIDUAL / DGELU epilogue; a forced big-tile configuration
+  // with a fused bias gradient used to arrive here AFTER this rule had been applied and ended in CFHIP_ERR_INVALID.  CfgD
+  // (128x64x64) has both the epilogues and the bias gradient (kHasEpilogues, kHasBiasGrad in launch_cfg).
+  if (cfg == 1 && (epilogue == CFHIP_EPI_RESIDUAL || epilogue == CFHIP_EPI_DGELU)) cfg = 3;
   return cfg;
 }
 
@@ -849,14 +843,12 @@ extern "C" int cfhip_gemm_kernel_name(int M, int N, int K, int a_trans, int b_tr
       "Cfg<128, 128, 2, 2, 4, 32>", "Cfg<128, 64, 2, 2, 2, 32>", "Cfg<128, 64, 2, 2, 3, 32>", "Cfg<256, 256, 2, 4, 4, 32>",
       "Cfg<256, 128, 2, 4, 3, 32>", "Cfg<256, 128, 2, 2, 3, 32>", "Cfg<128, 256, 2, 2, 3, 32>", "Cfg<256, 128, 2, 4, 6, 32>",
       "Cfg<256, 256, 2, 4, 5, 32>", "Cfg<256, 256, 2, 4, 2, 64>", "Cfg<192, 128, 2, 4, 2, 64>", "Cfg<192, 128, 2, 2, 2, 64>",
-      "Cfg<128, 256, 2, 4, 2, 64>", "PCfg<256, 256, 2, 2, 2, true, 0>", "PCfg<256, 256, 2, 4, 2, false, 0>",
-      "PCfg<256, 128, 2, 2, 3, false, 4>", "PCfg<192, 128, 2, 2, 2, false, 0>"};
+      "Cfg<128, 256, 2, 4, 2, 64>"};
   int epi = epilogue == CFHIP_EPI_QGELU ? CFHIP_EPI_GELU : epilogue == CFHIP_EPI_DQGELU ? CFHIP_EPI_DGELU : epilogue;
   int cfg = pick_config(M, N, a_trans, b_trans);
-  if (cfg >= PP_BASE && !cfhip_internal_gemm_pp_supported(M, N, K, 8, a_trans, b_trans, epi, 0, 0, 1, cfg - PP_BASE)) cfg = a_trans ? 1 : 15;
   cfg = resolve_config(cfg, a_trans, epi, false);  // the reroutes of instantiations that do not exist: the name is the kernel that RUNS
   const bool phase = cfg >= 7 && cfg <= 12;
-  snprintf(out, out_bytes, "%s<%s, %s, %d, %s>", cfg >= PP_BASE ? "gemm_pp_kernel" : phase ? "gemm_bf16_phase_kernel" : "gemm_bf16_kernel",
+  snprintf(out, out_bytes, "%s<%s, %s, %d, %s>", phase ? "gemm_bf16_phase_kernel" : "gemm_bf16_kernel",
            a_trans ? "true" : "false", b_trans ? "true" : "false", epi, cfg_names[cfg]);
   return CFHIP_OK;
 }
@@ -945,17 +937,6 @@ extern "C" int cfhip_gemm_bf16(const void* A, const void* B, void* C, const floa
 
   int rc;
   int cfg = pick_config(M, N, a_trans, b_trans);
-  if (cfg >= PP_BASE) {
-    if (cfhip_internal_gemm_pp_supported(M, N, K, ldc, a_trans, b_trans, epilogue, out_dtype, accumulate, split_k, cfg - PP_BASE)) {
-      // tile walk of the persistent kernels: an XCD's 32 resident tiles should form a compact block of the tile grid
-      p.group_n = g_pp_group_n;
-      rc = cfhip_internal_gemm_pp(&p, cfg - PP_BASE, b_trans, epilogue, stream);
-      if (rc != CFHIP_OK) return rc;
-      CFHIP_CHECK_LAUNCH("gemm_pp");
-      return CFHIP_OK;
-    }
-    cfg = a_trans ? 1 : 15;  // shapes the pipelined kernels do not take
-  }
   cfg = resolve_config(cfg, a_trans, epilogue, bias_grad != nullptr);
   switch (cfg) {
     case 1: rc = launch_layout<CfgB>(p, a_trans, b_trans, epilogue, split_k, s); break;

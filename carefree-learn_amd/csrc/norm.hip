@@ -25,6 +25,9 @@ __device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
   const u32x2 w = *reinterpret_cast<const u32x2*>(p);
   v[0] = bf16lo(w[0]); v[1] = bf16hi(w[0]); v[2] = bf16lo(w[1]); v[3] = bf16hi(w[1]);
 }
+__device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+}
 __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
   *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
 }
@@ -66,10 +69,10 @@ template <> struct Row4<float> {
   __device__ __forceinline__ void get(float (&v)[4]) const { v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3]; }
 };
 
-template <int NCH, bool EXACT, typename XT>
+template <int NCH, bool EXACT, typename XT, typename YT = bf16_t>
 __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
     const XT* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-    bf16_t* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int D,
+    YT* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int D,
     long xs, long ys, float eps) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
       }
     }
     const float rstd = rsqrtf(wave_sum_dpp(sq) * inv_d + eps);
-    bf16_t* yr = y + (long)row * ys;
+    YT* yr = y + (long)row * ys;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
@@ -464,14 +467,17 @@ inline int ln_grid(int M, int cap = 512) {
     default: if (exact && nch == 8) { KERNEL(8, true); } else { KERNEL(8, false); } break;        \
   }
 
-extern "C" int cfhip_layernorm_fwd(const void* x, int x_is_f32, const float* gamma, const float* beta,
+extern "C" int cfhip_layernorm_fwd(const void* x, int dtype_flags, const float* gamma, const float* beta,
                                    void* y, float* mean, float* rstd, int M, int D,
                                    int64_t x_row_stride, int64_t y_row_stride, float eps, void* stream) {
+  const int x_is_f32 = dtype_flags & 1, y_is_f32 = (dtype_flags >> 1) & 1;
   CFHIP_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
+  CFHIP_REQUIRE((dtype_flags & ~3) == 0, "layernorm_fwd: dtype_flags = %d (bit 0: x is f32, bit 1: y is f32)", dtype_flags);
+  CFHIP_REQUIRE(!y_is_f32 || x_is_f32, "layernorm_fwd: an f32 output is built for f32 rows only");
   CFHIP_REQUIRE(M > 0 && D > 0, "layernorm_fwd: empty problem");
   CFHIP_REQUIRE(D % 4 == 0 && D <= 2048, "layernorm_fwd: D=%d must be a multiple of 4 and <= 2048", D);
   CFHIP_REQUIRE(x_row_stride % 4 == 0 && y_row_stride % 4 == 0, "layernorm_fwd: row strides must be multiples of 4");
-  CFHIP_REQUIRE(((uintptr_t)x & (x_is_f32 ? 15 : 7)) == 0 && ((uintptr_t)y & 7) == 0,
+  CFHIP_REQUIRE(((uintptr_t)x & (x_is_f32 ? 15 : 7)) == 0 && ((uintptr_t)y & (y_is_f32 ? 15 : 7)) == 0,
                 "layernorm_fwd: x / y must be 8-byte (bf16) / 16-byte (f32) aligned");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int nch = (D + 255) / 256;
@@ -479,7 +485,11 @@ extern "C" int cfhip_layernorm_fwd(const void* x, int x_is_f32, const float* gam
   const int blocks = ln_grid(M, 1024);
 #define LN_FWD(N_, EX_)                                                                           \
   do {                                                                                             \
-    if (x_is_f32)                                                                                  \
+    if (y_is_f32)                                                                                  \
+      hipLaunchKernelGGL((layernorm_fwd_kernel<N_, EX_, float, float>), dim3(blocks), dim3(LN_THREADS), 0, s, \
+                         (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D,                 \
+                         (long)x_row_stride, (long)y_row_stride, eps);                              \
+    else if (x_is_f32)                                                                             \
       hipLaunchKernelGGL((layernorm_fwd_kernel<N_, EX_, float>), dim3(blocks), dim3(LN_THREADS), 0, s, \
                          (const float*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D,                \
                          (long)x_row_stride, (long)y_row_stride, eps);                              \

@@ -500,7 +500,13 @@ def whole_param(t: Optional[Tensor]) -> Optional[Tensor]:
     """`t` itself, or — when `t` is a contiguous view of a WHOLE leaf parameter (a [Cout, Cin, 1, 1] filter seen as the
     [Cout, Cin] matrix of the GEMM it is) — that parameter: its gradient can then be written straight into `.grad` (and
     run on the side stream) instead of travelling back through autograd's view chain."""
-    if t is None or not t._is_view():  # (a view taken without grad mode, e.g. inside a taped node, IS a leaf)
+    if t is None or not t._is_view():
+        return t
+    # A view taken WITHOUT grad mode is a leaf that does not require grad.  Inside a taped node (TapedFn.forward runs without grad
+    # mode) that is the normal case and the view stands for its parameter; anywhere else it is a weight somebody froze on purpose
+    # (a view cached under torch.no_grad()): it must not resolve to its base and silently receive gradients / optimizer updates
+    # (ADVICE r5).
+    if t.is_leaf and getattr(_TAPE, "tape", None) is None:
         return t
     base = t._base
     if (base is not None and base.is_leaf and base.requires_grad and base.dtype == f32 and base.numel() == t.numel()
@@ -777,11 +783,11 @@ class LayerNormFn(Function):
     folds_dx_add = True  # a taped node hands the backward kernel the gradient x already has (`ctx.dx_add`, bf16, x's shape)
 
     @staticmethod
-    def forward(ctx: Any, x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
+    def forward(ctx: Any, x: Tensor, weight: Tensor, bias: Tensor, eps: float, out_f32: bool = False) -> Tensor:
         x2 = _as_rows(x)
         gamma = weight.detach().contiguous()
         beta = bias.detach().contiguous()
-        y, mean, rstd = ops.layernorm_fwd(x2, gamma, beta, eps)
+        y, mean, rstd = ops.layernorm_fwd(x2, gamma, beta, eps, out_f32=bool(out_f32) and x2.dtype == f32)
         ctx.save_for_backward(x2, gamma, mean, rstd)
         ctx.weight, ctx.bias = weight, bias
         ctx.x_shape, ctx.in_dtype = x.shape, x.dtype
@@ -813,10 +819,14 @@ class LayerNormFn(Function):
             elif bias.requires_grad:
                 gb = db.view(bias.shape)
         dx = dx.view(ctx.x_shape) if ctx.needs_input_grad[0] else None  # bf16; autograd casts if needed
-        return dx, gw, gb, None
+        return dx, gw, gb, None, None
 
 
-def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
+def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float, out_f32: bool = False) -> Tensor:
+    """`out_f32`: an f32 input gives an f32 output — for a LayerNorm whose output is the RESIDUAL STREAM of the blocks behind it
+    (nn.LayerNorm keeps its input's dtype under the reference's autocast; a bf16 copy is what a matrix product wants)."""
+    if out_f32:
+        return _apply(LayerNormFn, x, weight, bias, eps, True)
     return _apply(LayerNormFn, x, weight, bias, eps)
 
 
@@ -1087,7 +1097,22 @@ def patch_tokens(img: Tensor, conv_w: Tensor, conv_b: Optional[Tensor], head_tok
 # works on the rows behind such a view: the 318 NCHW <-> NHWC transposes of a 64^2 x 8 step are gone.  A Function that meets a
 # layout it has no kernel for converts EXPLICITLY with the transpose kernel (`to_nchw` / `to_nhwc`) — never through
 # `.contiguous()`, which would be a silent ATen copy.  CFHIP_UNET_NHWC=0 keeps the round-4 NCHW hand-over.
-NHWC = [False]
+
+
+class _ThreadFlag:
+    """`flag[0]` per thread: a forward on another thread (EMA evaluation, a second model) keeps its own setting."""
+
+    def __init__(self) -> None:
+        self._local = threading.local()
+
+    def __getitem__(self, i: int) -> bool:
+        return getattr(self._local, "value", False)
+
+    def __setitem__(self, i: int, value: Any) -> None:
+        self._local.value = bool(value)
+
+
+NHWC = _ThreadFlag()
 NHWC_ENABLED = os.environ.get("CFHIP_UNET_NHWC", "1") != "0"
 
 
@@ -2056,6 +2081,7 @@ class _CheckpointFn(Function):
         ctx.inputs = list(args[:n_inputs])
         ctx.params = list(args[n_inputs:])
         ctx.requires = [isinstance(x, Tensor) and x.requires_grad for x in ctx.inputs]
+        ctx.nhwc = NHWC[0]  # the recomputation runs inside backward, after UNetDiffuser.forward has restored the flag: same hand-over
         with torch.no_grad():
             return fn(*ctx.inputs)
 
@@ -2064,8 +2090,13 @@ class _CheckpointFn(Function):
         for cb in backward_entered_callbacks:  # outer graph task: see the note at the list's definition
             cb()
         inputs = [x.detach().requires_grad_(r) if isinstance(x, Tensor) else x for x, r in zip(ctx.inputs, ctx.requires)]
-        with torch.enable_grad():
-            outputs = ctx.fn(*[x.view_as(x) if isinstance(x, Tensor) else x for x in inputs])
+        keep = NHWC[0]
+        NHWC[0] = ctx.nhwc
+        try:
+            with torch.enable_grad():
+                outputs = ctx.fn(*[x.view_as(x) if isinstance(x, Tensor) else x for x in inputs])
+        finally:
+            NHWC[0] = keep
         if isinstance(outputs, Tensor):
             outputs = (outputs,)
         wrt = [x for x, r in zip(inputs, ctx.requires) if r]

@@ -691,7 +691,10 @@ def _plan_for(x: Tensor, metas: tuple, keep_mask: Optional[Tensor], causal: bool
     plan = _plans.get(pid)
     if plan is None or plan.key != key or (plan.params_ref and plan.params_ref[0]() is not params[0]):
         if len(_plans) >= _PLAN_CACHE:
+            _plan_conflicts.pop(next(iter(_plans)), None)  # (the conflict count lives and dies with its plan: ids are reused)
             _plans.pop(next(iter(_plans)))
+        if plan is not None and plan.params_ref and plan.params_ref[0]() is not params[0]:
+            _plan_conflicts.pop(pid, None)  # another model now owns this id
         plan = _plans[pid] = StackPlan(key, params)
     return plan
 
@@ -874,6 +877,10 @@ class MixingStackFn(Function):
             d2 = MixingStackFn._backward_body(list(all_saved), keep_mask, bsz, t, metas, causal, d2, params)
             return (d2.view(bsz, t, d),) + nret
         plan.in_flight = False
+        if _plan_conflicts:
+            # a clean forward / backward pair: an occasional forward-without-backward (a periodic evaluation with grad enabled)
+            # must not add up to "this stack keeps doing it" over a long run
+            _plan_conflicts.pop(id(params[0]), None)
         km = plan.mask_tensor
         fresh = _grad_state(params) == plan.state  # the write / accumulate flags in the recorded arguments still apply
         if plan.ready_bwd and fresh and _lib.RECORDER is None and ops.GEMM_TIMER is None and ops.FLOP_COUNTER is None:

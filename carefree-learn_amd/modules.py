@@ -216,7 +216,7 @@ class LayerNorm(nn.LayerNorm):
     def forward(self, net: Tensor) -> Tensor:  # type: ignore
         if not self.elementwise_affine or len(self.normalized_shape) != 1:
             raise NotImplementedError("only affine LayerNorm over the last dim is on the hot path")
-        return HF.layer_norm(net, self.weight, self.bias, self.eps)
+        return HF.layer_norm(net, self.weight, self.bias, self.eps, getattr(self, "out_f32", False))
 
 
 class _BatchNormMixin:
@@ -865,6 +865,8 @@ class MixedStackedEncoder(Module):
                                                is_vision=bool(is_vision_positional_encoding),
                                                enable=use_positional_encoding)
         self.embedding_norm = embedding_norm
+        if isinstance(embedding_norm, LayerNorm):
+            embedding_norm.out_f32 = True  # its output is the residual stream of the blocks: f32 in, f32 out (see ViTEncoder.forward)
         self.embedding_dropout = None if embedding_dropout is None else Dropout(embedding_dropout)  # api.py:330-333
         if dpr_list is None:
             dpr_list = [x.item() for x in torch.linspace(0, drop_path_rate, num_layers)]
@@ -1312,7 +1314,11 @@ class ViTEncoder(Module):
             pos = enc.pos_encoding.interpolate_pos_encoding(gh * gw + enc.pos_encoding.num_head_tokens, hwp)
         tokens = HF.patch_tokens(net, conv.weight, conv.bias, enc.head_token, pos)
         if enc.embedding_norm is not None:
-            tokens = enc.embedding_norm(tokens)  # CLIP vision tower: LayerNorm before the blocks (bf16 stream)
+            # CLIP vision tower: LayerNorm before the blocks.  Its output IS the residual stream: f32 like its input, as under the
+            # reference's autocast (cv/encoder/transformer.py:60-64).  Rounds 2-5 handed a bf16 copy on and the whole tower ran a
+            # bf16 stream: image features 9.2e-3 from fp32 where the reference's own bf16 run sits at 5.7e-3 — found by
+            # test_clip_b32_step_vs_oracle (round 6); the small fixture's 2 layers hid it.
+            tokens = enc.embedding_norm(tokens)  # (`out_f32`, set by MixedStackedEncoder.__init__)
         if enc.embedding_dropout is not None:
             tokens = enc.embedding_dropout(tokens)
         out = enc.forward_tokens(tokens, hw=(gh, gw), deterministic=deterministic)

@@ -272,19 +272,23 @@ def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) ->
 
 def layernorm_fwd(
     x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out: Optional[Tensor] = None,
-    mean: Optional[Tensor] = None, rstd: Optional[Tensor] = None,
+    mean: Optional[Tensor] = None, rstd: Optional[Tensor] = None, out_f32: bool = False,
 ) -> Tuple[Tensor, Tensor, Tensor]:
-    """x: bf16 or f32 [M, D] (row stride free) -> y bf16 [M, D], mean f32 [M], rstd f32 [M] (`out` / `mean` / `rstd`:
-    caller-owned destinations, e.g. row slices of larger tensors)."""
+    """x: bf16 or f32 [M, D] (row stride free) -> y bf16 (f32 with `out_f32`, f32 rows only) [M, D], mean f32 [M], rstd f32 [M]
+    (`out` / `mean` / `rstd`: caller-owned destinations, e.g. row slices of larger tensors)."""
     _need(x, x.dtype if x.dtype in (bf16, f32) else bf16, "x")
     _need(gamma, f32, "gamma")
     _need(beta, f32, "beta")
     m, d, xs = _mat(x, "x")
-    y = torch.empty((m, d), dtype=bf16, device=x.device) if out is None else out
+    if out is not None:
+        out_f32 = out.dtype == f32
+    if out_f32 and x.dtype != f32:
+        raise ValueError("cfhip layernorm_fwd: an f32 output is built for f32 rows only")
+    y = torch.empty((m, d), dtype=f32 if out_f32 else bf16, device=x.device) if out is None else out
     mean = torch.empty((m,), dtype=f32, device=x.device) if mean is None else mean
     rstd = torch.empty((m,), dtype=f32, device=x.device) if rstd is None else rstd
     rc = _lib.load().cfhip_layernorm_fwd(
-        x.data_ptr(), int(x.dtype == f32), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+        x.data_ptr(), int(x.dtype == f32) | (2 if out_f32 else 0), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
         rstd.data_ptr(), m, d, xs, y.stride(0), float(eps), _stream(),
     )
     _lib.check(rc, "layernorm_fwd")

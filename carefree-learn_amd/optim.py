@@ -241,6 +241,14 @@ class FusedAdam:
         self.step_count += 1
         # ranges updated by a pass whose launch_step() never ran (an exception between the two, a skipped non-finite loss)
         # must not count as done in THIS step
+        # — and their launches may still be queued on the comm / side stream, writing the masters, moments and shadows the next
+        # full-arena launch on the current stream writes: order them first.  Such a pass leaves a PARTIAL update
+        # behind (its launched ranges were stepped once with its gradients); nothing here can take that back.
+        if self._range_streams and self._hyper_dev.is_cuda:
+            cur = torch.cuda.current_stream()
+            for st in self._range_streams:
+                if st is not None and st != cur:
+                    cur.wait_stream(st)
         self._done, self._range_streams = [], []
         self.step_armed = True  # this step's hyper-parameter record is on its way: range updates may be launched until launch_step()
         self._fill_hyper()

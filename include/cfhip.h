@@ -38,12 +38,10 @@ extern "C" {
 int cfhip_version(void);
 const char* cfhip_last_error(void);
 /* tuning knobs (process-wide, used by the benchmarks' A/B runs; defaults are the shipped behaviour):
- *   "gemm_config"     -1 (shape heuristic, default) or 0..20 to force one tile configuration
+ *   "gemm_config"     -1 (shape heuristic, default) or 0..16 to force one tile configuration
  *                     (0: 128x128x64, 1: 128x128x32, 3: 128x64x64, 7: 256x256x32 two-group kernel,
  *                      8: 256x128x32 two-group kernel, 13: 256x256x64, 14 / 15: 192x128x64 on eight / four waves, 16: 128x256x64;
- *                      17..20: the software-pipelined 32x32x16 kernels of csrc/gemm_pp.hip — persistent 256x256 on four waves,
- *                      256x256 on eight waves, 256x128 with loader waves, 192x128; see csrc/gemm.hip, csrc/gemm_pp.hip)
- *   "gemm_pp_group_n" tile walk of the gemm_pp kernels: 0 (default) row-major, n > 0 column groups of n tiles
+ *                      see csrc/gemm.hip)
  *   "gemm_heuristic"  1..8, which shape -> configuration table pick_config() uses (default 8: every M >= 1024 forward and
  *                     dX GEMM on 192x128x64 — four waves for outputs up to 1 024 columns wide, eight otherwise —, single dW GEMMs
  *                     on 128x128x32; 7: eight waves everywhere; 6: the round-2 table — forward on the BK = 64 configurations, dX on
@@ -152,9 +150,11 @@ int cfhip_colsum_bf16(const void* X, float* out, int M, int N, int64_t ldx, int 
 /* ------------------------------------------------------------------------------------------
  * K5  LayerNorm over the last dim (replaces nn.LayerNorm built by NormFactory("layer"),
  *     modules/core/norms.py:88-89,118-119; call sites mixed_stacks/api.py:141,155,397-402)
- *   biased variance, eps inside the sqrt, fp32 statistics; y is bf16, gamma / beta fp32; x is bf16 or
- *   (x_is_f32 != 0) f32 — the residual stream is kept in f32, as it is in the reference's autocast run
- *   (head_token / pos_encoding are f32 parameters, so `x + f(LN(x))` type-promotes to f32).
+ *   biased variance, eps inside the sqrt, fp32 statistics; gamma / beta fp32; dtype_flags bit 0: x is f32 (else bf16) —
+ *   the residual stream is kept in f32, as it is in the reference's autocast run (head_token / pos_encoding are f32
+ *   parameters, so `x + f(LN(x))` type-promotes to f32); bit 1: y is f32 (else bf16; f32 rows only) — a LayerNorm whose
+ *   output IS the residual stream (the `embedding_norm` in front of CLIP's vision blocks, cv/encoder/transformer.py:60-64:
+ *   nn.LayerNorm on an f32 input returns f32 under autocast; round 6, found by the full-size CLIP parity test).
  *   D % 4 == 0 and D <= 2048 (a row lives in the registers of one wave).
  *   x_row_stride / y_row_stride in elements (lets the head LN read token 0 of every sample).
  *   fwd saves mean / rstd (f32 [M]) for bwd.
@@ -163,7 +163,7 @@ int cfhip_colsum_bf16(const void* X, float* out, int M, int N, int64_t ldx, int 
  *        only; dgamma == dbeta == NULL: input gradient only (two launches that can run on two
  *        streams: dx is the critical path of backward, the parameter gradients are not).
  * ------------------------------------------------------------------------------------------ */
-int cfhip_layernorm_fwd(const void* x, int x_is_f32, const float* gamma, const float* beta, void* y,
+int cfhip_layernorm_fwd(const void* x, int dtype_flags, const float* gamma, const float* beta, void* y,
                         float* mean, float* rstd, int M, int D, int64_t x_row_stride,
                         int64_t y_row_stride, float eps, void* stream);
 size_t cfhip_layernorm_bwd_workspace(int M, int D);

@@ -225,78 +225,6 @@ def test_every_tile_config(cfg):
         ops.set_option("gemm_config", -1)
 
 
-PP_CONFIGS = [17, 18, 19, 20]  # csrc/gemm_pp.hip: persistent 256x256 on 4 waves, 256x256 on 8 waves, 256x128 with loader waves, 192x128
-
-
-def _gpu_ref(a, b, b_trans):
-    B = b.float() if b_trans else b.float().t()
-    return a.float() @ B
-
-
-@pytest.mark.parametrize("cfg", PP_CONFIGS)
-def test_pipelined_gemm_configs(cfg):
-    """the software-pipelined 32x32x16 kernels (gemm_config 17 .. 21): forward (nt) and dX (nn) layouts, every epilogue of the
-    block stack, ragged M and N, few tiles and more tiles than a persistent grid holds (tile-to-tile hand-over), f32 and bf16
-    outputs — against an fp32 matmul of the same bf16 operands (full tensors, not samples)."""
-    torch.backends.cuda.matmul.allow_tf32 = False
-    try:
-        ops.set_option("gemm_config", cfg)
-        g = torch.Generator(device=DEV).manual_seed(100 + cfg)
-        rnd = lambda *s: (torch.randn(*s, generator=g, device=DEV) * 0.5).to(torch.bfloat16)  # noqa: E731
-        # (M, N, K): K a multiple of 64 and >= 192 (other K fall back to gemm_config 15: covered by the last shape)
-        shapes = ((333, 264, 192), (1032, 776, 320), (256, 256, 256), (130, 136, 1024), (12608, 768, 768), (9000, 2304, 256),
-                  (520, 1000, 72))
-        for (m, n, k) in shapes:
-            for b_trans in (False, True):
-                a = rnd(m, k)
-                b = rnd(k, n) if b_trans else rnd(n, k)
-                want = _gpu_ref(a, b, b_trans)
-                tag = f"cfg{cfg} {'nn' if b_trans else 'nt'} {m}x{n}x{k}"
-                assert_close(ops.gemm(a, b, b_trans=b_trans, out_dtype=torch.float32), want, 2e-5, tag + " f32")
-                assert_close(ops.gemm(a, b, b_trans=b_trans), want, 4e-3, tag + " bf16")
-                bias = torch.randn(n, generator=g, device=DEV)
-                assert_close(ops.gemm(a, b, b_trans=b_trans, bias=bias, out_dtype=torch.float32), want + bias, 2e-5, tag + " bias f32")
-                if b_trans:
-                    pre = rnd(m, n)
-                    x = pre.float().requires_grad_(True)
-                    torch.nn.functional.gelu(x).backward(torch.ones_like(x))
-                    got = ops.gemm(a, b, b_trans=True, epilogue=ops.EPI_DGELU, aux_in=pre)
-                    assert_close(got, want * x.grad, 5e-3, tag + " dgelu")
-                else:
-                    res16, res32 = rnd(m, n), torch.randn(m, n, generator=g, device=DEV)
-                    got = ops.gemm(a, b, bias=bias, epilogue=ops.EPI_RESIDUAL, aux_in=res16)
-                    assert_close(got, want + bias + res16.float(), 4e-3, tag + " residual bf16")
-                    got = ops.gemm(a, b, bias=bias, epilogue=ops.EPI_RESIDUAL, aux_in=res32, out_dtype=torch.float32)
-                    assert_close(got, want + bias + res32, 2e-5, tag + " residual f32")
-                    pre = torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
-                    got = ops.gemm(a, b, bias=bias, epilogue=ops.EPI_GELU, aux_out=pre)
-                    assert_close(pre, want + bias, 4e-3, tag + " pre-activation")
-                    assert_close(got, torch.nn.functional.gelu(pre.float()), 5e-3, tag + " gelu")
-                    got = ops.gemm(a, b, bias=bias, epilogue=ops.EPI_QGELU, aux_out=pre)
-                    assert_close(got, pre.float() * torch.sigmoid(1.702 * pre.float()), 5e-3, tag + " quick gelu")
-    finally:
-        ops.set_option("gemm_config", -1)
-
-
-def test_pipelined_gemm_is_deterministic_and_walk_independent():
-    """the persistent kernel's tile walk only decides which workgroup computes which tile"""
-    m, n, k = 12608, 3072, 256
-    g = torch.Generator(device=DEV).manual_seed(7)
-    a = (torch.randn(m, k, generator=g, device=DEV) * 0.5).to(torch.bfloat16)
-    w = (torch.randn(n, k, generator=g, device=DEV) * 0.5).to(torch.bfloat16)
-    try:
-        ops.set_option("gemm_config", 17)
-        outs = []
-        for gn in (0, 6, 4, 0):
-            ops.set_option("gemm_pp_group_n", gn)
-            outs.append(ops.gemm(a, w, out_dtype=torch.float32))
-        for o in outs[1:]:
-            assert torch.equal(o, outs[0])
-    finally:
-        ops.set_option("gemm_pp_group_n", 0)
-        ops.set_option("gemm_config", -1)
-
-
 def test_dw_layout_with_unaligned_token_count():
     """dW = dY^T X where the token count (the GEMM's K) is not a multiple of 8 — e.g. batch 3 x 197 tokens = 591 —
     must stay on the MFMA path (split-K included): K is the row index of both operands in this layout."""

@@ -42,6 +42,37 @@ def test_layernorm_fwd_bwd(m, d):
     assert_close(pg[d:], bf.grad + 1, 2e-4, "dbeta acc")
 
 
+@pytest.mark.parametrize("m,d", [(800, 768), (33, 2048), (300, 520), (17, 4)])
+def test_layernorm_f32_rows_to_f32_rows(m, d):
+    """A LayerNorm whose output is the residual stream (CLIP's `embedding_norm`, cv/encoder/transformer.py:60-64): f32 in, f32 out —
+    against fp32 math to fp32 accuracy; the same statistics as the bf16-output launch; the autograd Function's backward; refused for bf16 rows."""
+    from cflearn_amd import functional as HF
+
+    g = torch.Generator().manual_seed(3 * m + d)
+    x = torch.randn(m, d, generator=g) * 2 + 0.5
+    w = torch.randn(d, generator=g) * 0.2 + 1
+    b = torch.randn(d, generator=g) * 0.2
+    xf, wf, bf = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    want = O.layer_norm(xf, wf, bf, 1e-5)
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, out_f32=True)
+    assert y.dtype == torch.float32
+    assert_close(y, want, 2e-6, "ln f32 y")
+    y16, mean16, rstd16 = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5)
+    assert y16.dtype == torch.bfloat16 and torch.equal(mean, mean16) and torch.equal(rstd, rstd16)
+    assert torch.equal(y16, y.to(torch.bfloat16))  # the same arithmetic, one rounding apart
+    with pytest.raises(ValueError):
+        ops.layernorm_fwd(x.to(DEV).bfloat16(), w.to(DEV), b.to(DEV), 1e-5, out_f32=True)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    yd = HF.layer_norm(xd, wd, bd, 1e-5, True)
+    assert yd.dtype == torch.float32 and torch.equal(yd.detach(), y)
+    gy = torch.randn(m, d, generator=g).to(torch.bfloat16).float()
+    want.backward(gy)
+    yd.backward(gy.to(DEV))
+    assert_close(xd.grad, xf.grad, 5e-3, "ln f32 dx")
+    assert_close(wd.grad, wf.grad, 2e-4, "ln f32 dgamma")
+    assert_close(bd.grad, bf.grad, 2e-4, "ln f32 dbeta")
+
+
 def test_layernorm_strided_rows():
     """head LN reads token 0 of every sample: row stride T*D."""
     b, t, d = 16, 197, 768

@@ -9,7 +9,7 @@ ROOT="$(dirname "$(readlink -f "$0")")/.."
 cd "$ROOT/carefree-learn_amd/csrc"
 mkdir -p /tmp/cfhip_build_$NAME
 pids=()
-for f in errors gemm gemm_pp gemm_grouped attn attn_probs norm elementwise conv conv_grouped embed random tabular comm; do
+for f in errors gemm gemm_grouped attn attn_probs norm elementwise conv conv_grouped embed random tabular comm; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics "$@" -c $f.hip -o /tmp/cfhip_build_$NAME/$f.o &
   pids+=($!)
 done

@@ -1,5 +1,5 @@
 """Where are a translation unit's scratch (spill) accesses: inside a loop or around it?
-    python tools/spill_sites.py attn|gemm|norm|gemm_pp ...
+    python tools/spill_sites.py attn|gemm|norm ...
 Compiles carefree-learn_amd/csrc/<name>.hip to gfx950 assembly and lists, per kernel with scratch instructions, how many of
 them sit between a loop header and its backward branch."""
 import os

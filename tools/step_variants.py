@@ -107,14 +107,7 @@ VARIANTS = {
     "per-op dW, split 2, tn=c15": setv(0, tn=15, split=2),
     "per-op dW, split 2, tn=c0": setv(0, tn=0, split=2),
     "per-op dW, r2 path (split-K heuristic, 128x128x32)": setv(0),
-    # round 4: the software-pipelined 32x32x16 kernels of csrc/gemm_pp.hip (pass the configuration numbers: pp=<ntw>,<nt>,<nn>)
 }
-for a in list(sys.argv[2:]):
-    if a.startswith("pp="):
-        w, t, n = (int(x) for x in a[3:].split(","))
-        VARIANTS[f"pp ntw={w} nt={t} nn={n}"] = setv(2, nt_wide=w, nt=t, nn=n)
-        sys.argv.remove(a)
-        sys.argv.append(f"pp ntw={w} nt={t} nn={n}")
 if len(sys.argv) > 2:
     sel = sys.argv[2:]
     VARIANTS = {k: v for k, v in VARIANTS.items() if any(s in k for s in sel)}
