@@ -53,6 +53,12 @@ SIGNATURES = {
         c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int64, c_int64, c_int64, _P, c_size_t, _P, _P]
     ),
     "cfhip_layernorm_bwd_reduce": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P]),
+    "cfhip_layernorm_bwd2": (
+        c_int,
+        [_P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int64, c_int64, c_int64, c_int, _P, c_size_t, _P, _P],
+    ),
+    "cfhip_split_f32_bf16x2": (c_int, [_P, _P, _P, c_int64, _P]),
+    "cfhip_join_bf16x2_f32": (c_int, [_P, _P, _P, c_int64, _P]),
     "cfhip_attn_fwd": (
         c_int,
         [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,

@@ -121,6 +121,34 @@ __global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __re
   for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride)
     dst[i] = bf16_to_f32(src[i]);
 }
+// f32 <-> two bf16 words (hi = bf16(v), lo = bf16(v - hi)): the ends of the two-word residual-gradient stream (norm.hip, LO)
+__global__ void split_f32_bf16x2_kernel(const float* __restrict__ src, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long n) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+    const u32x2 h = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    reinterpret_cast<u32x2*>(hi)[i] = h;
+    reinterpret_cast<u32x2*>(lo)[i] = u32x2{pack_bf16x2(v[0] - bf16lo(h[0]), v[1] - bf16hi(h[0])),
+                                            pack_bf16x2(v[2] - bf16lo(h[1]), v[3] - bf16hi(h[1]))};
+  }
+  for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bf16_t h = f32_to_bf16(src[i]);
+    hi[i] = h;
+    lo[i] = f32_to_bf16(src[i] - bf16_to_f32(h));
+  }
+}
+__global__ void join_bf16x2_f32_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo, float* __restrict__ dst, long n) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const u32x2 h = reinterpret_cast<const u32x2*>(hi)[i], l = reinterpret_cast<const u32x2*>(lo)[i];
+    reinterpret_cast<f32x4*>(dst)[i] = f32x4{bf16lo(h[0]) + bf16lo(l[0]), bf16hi(h[0]) + bf16hi(l[0]),
+                                             bf16lo(h[1]) + bf16lo(l[1]), bf16hi(h[1]) + bf16hi(l[1])};
+  }
+  for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = bf16_to_f32(hi[i]) + bf16_to_f32(lo[i]);
+}
 // MODE 0: y = gelu(x); 1: dx = dy * gelu'(x); 2: out = a + b; 3 / 4: MODE 0 / 1 with quick GELU
 template <int MODE>
 __global__ void ew_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
@@ -492,6 +520,25 @@ extern "C" int cfhip_cast_bf16_to_f32(const void* src, float* dst, int64_t n, vo
   hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const bf16_t*)src, dst, (long)n);
   CFHIP_CHECK_LAUNCH("cast_bf16_to_f32");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_split_f32_bf16x2(const float* src, void* hi, void* lo, int64_t n, void* stream) {
+  CFHIP_REQUIRE(src && hi && lo && n >= 0, "split_f32_bf16x2: bad arguments");
+  if (n == 0) return CFHIP_OK;
+  CFHIP_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)hi & 7) == 0 && ((uintptr_t)lo & 7) == 0, "split_f32_bf16x2: misaligned");
+  hipLaunchKernelGGL(split_f32_bf16x2_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)hi,
+                     (bf16_t*)lo, (long)n);
+  CFHIP_CHECK_LAUNCH("split_f32_bf16x2");
+  return CFHIP_OK;
+}
+extern "C" int cfhip_join_bf16x2_f32(const void* hi, const void* lo, float* dst, int64_t n, void* stream) {
+  CFHIP_REQUIRE(hi && lo && dst && n >= 0, "join_bf16x2_f32: bad arguments");
+  if (n == 0) return CFHIP_OK;
+  CFHIP_REQUIRE(((uintptr_t)dst & 15) == 0 && ((uintptr_t)hi & 7) == 0 && ((uintptr_t)lo & 7) == 0, "join_bf16x2_f32: misaligned");
+  hipLaunchKernelGGL(join_bf16x2_f32_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hi,
+                     (const bf16_t*)lo, dst, (long)n);
+  CFHIP_CHECK_LAUNCH("join_bf16x2_f32");
   return CFHIP_OK;
 }
 

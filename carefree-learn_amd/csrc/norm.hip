@@ -149,7 +149,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
     const bf16_t* __restrict__ dy, const XT* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     const bf16_t* __restrict__ dx_add, bf16_t* __restrict__ dx, float* __restrict__ partials, int M,
-    int D, long dys, long xs, long dxs) {
+    int D, long dys, long xs, long dxs, const bf16_t* __restrict__ dx_add_lo, bf16_t* __restrict__ dx_lo) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [2][D]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -210,12 +210,14 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
       }
     }
     // residual-gradient rows of THIS row and the operands of the NEXT row: all in flight together
-    u32x2 addv[NCH];
+    u32x2 addv[NCH], addl[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
       addv[c] = (DO_DX && dx_add != nullptr && (EXACT || col < D))
                     ? *reinterpret_cast<const u32x2*>(dx_add + (long)row * dxs + col) : u32x2{0u, 0u};
+      addl[c] = (DO_DX && dx_add_lo != nullptr && (EXACT || col < D))
+                    ? *reinterpret_cast<const u32x2*>(dx_add_lo + (long)row * dxs + col) : u32x2{0u, 0u};
     }
     if (row + nw < M) {
 #pragma unroll
@@ -239,9 +241,14 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = rstd * (g[c][e] - s1 - xh[c][e] * s2);
-          o[0] += bf16lo(addv[c][0]); o[1] += bf16hi(addv[c][0]);
-          o[2] += bf16lo(addv[c][1]); o[3] += bf16hi(addv[c][1]);
-          store4(dxr + col, o);
+          o[0] += bf16lo(addv[c][0]) + bf16lo(addl[c][0]); o[1] += bf16hi(addv[c][0]) + bf16hi(addl[c][0]);
+          o[2] += bf16lo(addv[c][1]) + bf16lo(addl[c][1]); o[3] += bf16hi(addv[c][1]) + bf16hi(addl[c][1]);
+          const u32x2 hw = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+          *reinterpret_cast<u32x2*>(dxr + col) = hw;
+          if (dx_lo != nullptr) {  // second word of the gradient stream: what the bf16 rounding of `o` dropped
+            const float r[4] = {o[0] - bf16lo(hw[0]), o[1] - bf16hi(hw[0]), o[2] - bf16lo(hw[1]), o[3] - bf16hi(hw[1])};
+            store4(dx_lo + (long)row * dxs + col, r);
+          }
         }
       }
     }
@@ -314,12 +321,17 @@ template <> struct Row8<float> {
 // EXACT: D = G * 256.  Otherwise (round 5: the UNet's 320- and 640-wide token rows, which the one-wave-per-row kernel above served at
 // ~1 TB/s inside the step) the row is D_real < G * 256 columns wide, a multiple of 8: the lanes of the last group whose 8 columns lie
 // beyond it load zeros, store nothing and keep zero sums — everything else, LDS layout included, works on the padded width.
-template <int G, typename XT, bool EXACT>
+// LO (round 6): the residual-gradient stream as TWO bf16 words per element (hi = bf16(g), lo = bf16(g - hi): 16 mantissa bits).  The
+// reference's residual stream is f32 under autocast, so its gradient is f32 and only the matrix products see bf16(g); a one-word
+// stream rounds the running sum twice per block, and where per-sample gradients cancel in a shared parameter (CLIP's contrastive
+// loss: head token, positional encoding) that drift was 1.5 x the reference's own bf16 distance from fp32 (test_clip_b32_step_vs_oracle).
+// `dx_add_lo` / `dx_lo`: the second words of dx_add / dx, same strides; the GEMMs keep reading the first word.
+template <int G, typename XT, bool EXACT, bool LO = false>
 __global__ __launch_bounds__(LN2_THREADS) void layernorm_bwd_fused_kernel(
     const bf16_t* __restrict__ dy, const XT* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     const bf16_t* __restrict__ dx_add, bf16_t* __restrict__ dx, float* __restrict__ partials, int M,
-    long dys, long xs, long dxs, int D_real) {
+    long dys, long xs, long dxs, int D_real, const bf16_t* __restrict__ dx_add_lo = nullptr, bf16_t* __restrict__ dx_lo = nullptr) {
   constexpr int D = G * 256;
   const int Dr = EXACT ? D : D_real;
   extern __shared__ __attribute__((aligned(16))) float lds[];  // gamma [D] | red [LN2_WAVES][2][D]
@@ -345,7 +357,7 @@ __global__ __launch_bounds__(LN2_THREADS) void layernorm_bwd_fused_kernel(
     const int row = 2 * pair + half;
     const bool ok = row < M;
     Row8<XT> rx[G];
-    u32x4 ry[G], ra[G];
+    u32x4 ry[G], ra[G], rl[LO ? G : 1];
     float mean = 0.f, rstd = 0.f;
     if (ok) {
 #pragma unroll
@@ -355,17 +367,19 @@ __global__ __launch_bounds__(LN2_THREADS) void layernorm_bwd_fused_kernel(
           rx[g].load(x + (long)row * xs + col);
           ry[g] = *reinterpret_cast<const u32x4*>(dy + (long)row * dys + col);
           ra[g] = dx_add != nullptr ? *reinterpret_cast<const u32x4*>(dx_add + (long)row * dxs + col) : u32x4{0u, 0u, 0u, 0u};
+          if (LO) rl[g] = dx_add_lo != nullptr ? *reinterpret_cast<const u32x4*>(dx_add_lo + (long)row * dxs + col) : u32x4{0u, 0u, 0u, 0u};
         } else {
           rx[g].zero();
           ry[g] = u32x4{0u, 0u, 0u, 0u};
           ra[g] = ry[g];
+          if (LO) rl[g] = ry[g];
         }
       }
       mean = mean_in[row];
       rstd = rstd_in[row];
     } else {
 #pragma unroll
-      for (int g = 0; g < G; ++g) { rx[g].zero(); ry[g] = u32x4{0u, 0u, 0u, 0u}; ra[g] = ry[g]; }
+      for (int g = 0; g < G; ++g) { rx[g].zero(); ry[g] = u32x4{0u, 0u, 0u, 0u}; ra[g] = ry[g]; if (LO) rl[g] = ry[g]; }
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -401,9 +415,17 @@ __global__ __launch_bounds__(LN2_THREADS) void layernorm_bwd_fused_kernel(
           const float av = (e & 1) ? bf16hi(ra[g][e >> 1]) : bf16lo(ra[g][e >> 1]);
           const float xh = (xv[e] - mean) * rstd;
           o[e] = rstd * (dv * (e < 4 ? g0[e] : g1[e - 4]) - s1 - xh * s2) + av;
+          if (LO) o[e] += (e & 1) ? bf16hi(rl[g][e >> 1]) : bf16lo(rl[g][e >> 1]);
         }
-        *reinterpret_cast<u32x4*>(dx + (long)row * dxs + g * 256 + hl * 8) =
-            u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        const u32x4 hw = u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        *reinterpret_cast<u32x4*>(dx + (long)row * dxs + g * 256 + hl * 8) = hw;
+        if (LO) {
+          float r[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r[e] = o[e] - ((e & 1) ? bf16hi(hw[e >> 1]) : bf16lo(hw[e >> 1]));
+          *reinterpret_cast<u32x4*>(dx_lo + (long)row * dxs + g * 256 + hl * 8) =
+              u32x4{pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]), pack_bf16x2(r[4], r[5]), pack_bf16x2(r[6], r[7])};
+        }
       }
     }
   }
@@ -537,7 +559,12 @@ static int ln_bwd_impl(const void* dy, const void* x, int x_is_f32, const float*
                        float* dgamma, float* dbeta, int M, int D, int64_t dy_row_stride,
                        int64_t x_row_stride, int64_t dx_row_stride,
                        int accumulate_param_grads, void* workspace,
-                       size_t workspace_bytes, void* stream, int* rows_out) {
+                       size_t workspace_bytes, void* stream, int* rows_out,
+                       const void* dx_add_lo = nullptr, void* dx_lo = nullptr) {
+  CFHIP_REQUIRE((dx_add_lo == nullptr || dx_add != nullptr) && (dx_lo == nullptr || dx != nullptr),
+                "layernorm_bwd: a second gradient word needs its first (dx_add_lo without dx_add / dx_lo without dx)");
+  CFHIP_REQUIRE(((uintptr_t)dx_add_lo & 7) == 0 && ((uintptr_t)dx_lo & 7) == 0, "layernorm_bwd: tensors must be 8-byte aligned");
+  const bool lo = dx_lo != nullptr || dx_add_lo != nullptr;
   CFHIP_REQUIRE(dy && x && gamma && mean && rstd, "layernorm_bwd: null pointer");
   const bool do_dx = dx != nullptr, do_pg = dgamma != nullptr || dbeta != nullptr;
   CFHIP_REQUIRE(do_dx || do_pg, "layernorm_bwd: nothing to compute (dx, dgamma and dbeta are all NULL)");
@@ -560,14 +587,24 @@ static int ln_bwd_impl(const void* dy, const void* x, int x_is_f32, const float*
   // one launch for both outputs: D a multiple of 8 up to 1280 (round 5: not only multiples of 256), 16-byte aligned rows
   const bool fused_ok = g_ln_fused && (exact || g_ln_fused == 1) && do_dx && do_pg && D % 8 == 0 && nch <= 5 && dy_row_stride % 8 == 0 && dx_row_stride % 8 == 0 &&
                         x_row_stride % (x_is_f32 ? 4 : 8) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0 &&
-                        ((uintptr_t)dx & 15) == 0 && ((uintptr_t)dx_add & 15) == 0;
+                        ((uintptr_t)dx & 15) == 0 && ((uintptr_t)dx_add & 15) == 0 && ((uintptr_t)dx_lo & 15) == 0 &&
+                        ((uintptr_t)dx_add_lo & 15) == 0 && (!lo || dx_lo != nullptr);
   if (fused_ok) {
     const int blocks2 = ln2_grid(M);
     const size_t lds2 = (size_t)(1 + 2 * LN2_WAVES) * nch * 256 * sizeof(float);
 #define LN_BWD2_T(G_, XT_, EX_)                                                                                      \
-  hipLaunchKernelGGL((layernorm_bwd_fused_kernel<G_, XT_, EX_>), dim3(blocks2), dim3(LN2_THREADS), lds2, s,          \
-                     (const bf16_t*)dy, (const XT_*)x, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx,        \
-                     partials, M, (long)dy_row_stride, (long)x_row_stride, (long)dx_row_stride, D)
+  do {                                                                                                               \
+    if (lo)                                                                                                          \
+      hipLaunchKernelGGL((layernorm_bwd_fused_kernel<G_, XT_, EX_, true>), dim3(blocks2), dim3(LN2_THREADS), lds2, s, \
+                         (const bf16_t*)dy, (const XT_*)x, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx,    \
+                         partials, M, (long)dy_row_stride, (long)x_row_stride, (long)dx_row_stride, D,               \
+                         (const bf16_t*)dx_add_lo, (bf16_t*)dx_lo);                                                  \
+    else                                                                                                             \
+      hipLaunchKernelGGL((layernorm_bwd_fused_kernel<G_, XT_, EX_>), dim3(blocks2), dim3(LN2_THREADS), lds2, s,      \
+                         (const bf16_t*)dy, (const XT_*)x, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx,    \
+                         partials, M, (long)dy_row_stride, (long)x_row_stride, (long)dx_row_stride, D,               \
+                         (const bf16_t*)nullptr, (bf16_t*)nullptr);                                                  \
+  } while (0)
 #define LN_BWD2(G_)                                                                                                  \
   do {                                                                                                               \
     if (x_is_f32) {                                                                                                  \
@@ -596,7 +633,7 @@ static int ln_bwd_impl(const void* dy, const void* x, int x_is_f32, const float*
   // spilled 300-376 bytes per lane at D = 2048 — two launches (dx, then the partials) fit
   if (do_dx && do_pg && nch >= 5) {
     int rc = ln_bwd_impl(dy, x, x_is_f32, gamma, mean, rstd, dx_add, dx, nullptr, nullptr, M, D, dy_row_stride, x_row_stride,
-                         dx_row_stride, 0, nullptr, 0, stream, nullptr);
+                         dx_row_stride, 0, nullptr, 0, stream, nullptr, dx_add_lo, dx_lo);
     if (rc != CFHIP_OK) return rc;
     return ln_bwd_impl(dy, x, x_is_f32, gamma, mean, rstd, nullptr, nullptr, dgamma, dbeta, M, D, dy_row_stride, x_row_stride,
                        dx_row_stride, accumulate_param_grads, workspace, workspace_bytes, stream, rows_out);
@@ -607,7 +644,7 @@ static int ln_bwd_impl(const void* dy, const void* x, int x_is_f32, const float*
   hipLaunchKernelGGL((layernorm_bwd_kernel<N_, EX_, XT_, DX_, PG_>), dim3(blocks), dim3(LN_THREADS), lds, \
                      s, (const bf16_t*)dy, (const XT_*)x, gamma, mean, rstd, (const bf16_t*)dx_add,       \
                      (bf16_t*)dx, partials, M, D, (long)dy_row_stride, (long)x_row_stride,                \
-                     (long)dx_row_stride)
+                     (long)dx_row_stride, (const bf16_t*)dx_add_lo, (bf16_t*)dx_lo)
 #define LN_BWD_MODE(N_, EX_, XT_)                                     \
   do {                                                                \
     if (do_dx && do_pg) {                                              \
@@ -641,6 +678,23 @@ extern "C" int cfhip_layernorm_bwd(const void* dy, const void* x, int x_is_f32, 
                                    size_t workspace_bytes, void* stream) {
   return ln_bwd_impl(dy, x, x_is_f32, gamma, mean, rstd, dx_add, dx, dgamma, dbeta, M, D, dy_row_stride, x_row_stride, dx_row_stride,
                      accumulate_param_grads, workspace, workspace_bytes, stream, nullptr);
+}
+
+// The same with the residual-gradient stream in TWO bf16 words (see layernorm_bwd_fused_kernel): dx_add_lo / dx_lo are the second
+// words of dx_add / dx (either may be NULL: a one-word incoming gradient, a one-word result), same row strides as the first.
+extern "C" int cfhip_layernorm_bwd2(const void* dy, const void* x, int x_is_f32, const float* gamma,
+                                    const float* mean, const float* rstd, const void* dx_add, const void* dx_add_lo, void* dx,
+                                    void* dx_lo, float* dgamma, float* dbeta, int M, int D, int64_t dy_row_stride,
+                                    int64_t x_row_stride, int64_t dx_row_stride, int accumulate_param_grads, void* workspace,
+                                    size_t workspace_bytes, int* rows_out, void* stream) {
+  if (rows_out != nullptr) {  // the `_partials` form: row kernel only, the partial rows stay in the workspace
+    CFHIP_REQUIRE(workspace != nullptr, "layernorm_bwd2: null workspace");
+    float* marker = reinterpret_cast<float*>(workspace);
+    return ln_bwd_impl(dy, x, x_is_f32, gamma, mean, rstd, dx_add, dx, marker, marker + D, M, D, dy_row_stride, x_row_stride,
+                       dx_row_stride, 0, workspace, workspace_bytes, stream, rows_out, dx_add_lo, dx_lo);
+  }
+  return ln_bwd_impl(dy, x, x_is_f32, gamma, mean, rstd, dx_add, dx, dgamma, dbeta, M, D, dy_row_stride, x_row_stride, dx_row_stride,
+                     accumulate_param_grads, workspace, workspace_bytes, stream, nullptr, dx_add_lo, dx_lo);
 }
 
 // The same in two calls: `_partials` runs the row kernel (dx, and the per-workgroup partial sums of dgamma / dbeta into

@@ -247,7 +247,8 @@ def _ln_defers(w: Tensor, b: Tensor, dy2: Tensor) -> bool:
 
 
 def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: Tensor,
-            dx_add: Optional[Tensor], dx_out: Optional[Tensor] = None, notify: bool = True) -> Tensor:
+            dx_add: Optional[Tensor], dx_out: Optional[Tensor] = None, notify: bool = True,
+            dx_add_lo: Optional[Tensor] = None, dx_lo_out: Optional[Tensor] = None) -> Tensor:
     """LayerNorm backward, split in two launches: the input gradient (with the residual-gradient add
     fused) on the main stream — it is the critical path — and dgamma / dbeta (a streaming column
     reduction straight into `.grad`) on the side stream."""
@@ -255,7 +256,8 @@ def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: T
 
     gamma = w.detach()
     if _ln_defers(w, b, dy2):
-        dx, ws, rows = ops.layernorm_bwd_partials(dy2, x2, gamma, mean, rstd, dx_add=dx_add, dx_out=dx_out)
+        dx, ws, rows = ops.layernorm_bwd_partials(dy2, x2, gamma, mean, rstd, dx_add=dx_add, dx_out=dx_out, dx_add_lo=dx_add_lo,
+                                                  dx_lo_out=dx_lo_out)
         acc = not getattr(w, "_cfhip_fresh", False)
         if acc != (not getattr(b, "_cfhip_fresh", False)):
             for prm in (w, b):
@@ -288,7 +290,8 @@ def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: T
             acc_w = True
         dx, _, _ = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dgamma=w.grad.view(-1), dbeta=b.grad.view(-1),
                                      accumulate=acc_w, want_dx=with_dx, dx_add=dx_add if with_dx else None,
-                                     dx_out=dx_out if with_dx else None)
+                                     dx_out=dx_out if with_dx else None, dx_add_lo=dx_add_lo if with_dx else None,
+                                     dx_lo_out=dx_lo_out if with_dx else None)
         for prm in (w, b):
             if notify:  # (a batch-sliced backward notifies once, after the LAST slice has added its rows)
                 _functional.notify_grad_ready(prm)
@@ -299,7 +302,8 @@ def _ln_bwd(dy2: Tensor, x2: Tensor, w: Tensor, b: Tensor, mean: Tensor, rstd: T
     if not SPLIT_LN_BWD:
         return param_grads(True)
     SideStream.run(param_grads, (dy2, x2, mean, rstd), lane=1)
-    dx, _, _ = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dx_add=dx_add, want_param_grads=False)
+    dx, _, _ = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dx_add=dx_add, want_param_grads=False, dx_out=dx_out,
+                                 dx_add_lo=dx_add_lo, dx_lo_out=dx_lo_out)
     return dx
 
 
@@ -388,15 +392,28 @@ def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_
     """Backward of one block: d2 = dL/dy as bf16 [B*T, D]; returns dL/dx as bf16 [B*T, D]; parameter
     gradients go straight into `.grad`.  `streams`: None = one pass over all rows on the current stream; a list = the
     batch is cut into len(streams) contiguous slices, slice i runs on streams[i] (row slices of the same full-size
-    tensors)."""
+    tensors).  TWO-WORD gradient stream (round 6): d2 = bf16 [2, B*T, D] — plane 0 the first word bf16(g), which every
+    matrix product reads (as the reference's do: autocast rounds the f32 stream gradient where a linear layer consumes it),
+    plane 1 the second word bf16(g - hi), which only the residual path carries from LayerNorm backward to LayerNorm backward
+    (`cfhip_layernorm_bwd2`); the result has the same form."""
     x2, mean1, rstd1, ln1, qkv, o2, lse, x1, mean2, rstd2, ln2, pre, h, in_w16, out_w16, w1_16, w2_16 = saved
     ln1_w, ln1_b, in_w, qkv_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2 = prm
+    two = d2.dim() == 3
+    d2_full = d2
+    d2, d2_lo = (d2[0], d2[1]) if two else (d2, None)
     d = d2.shape[1]
     m = bsz * t
     E = lambda cols: torch.empty((m, cols), dtype=bf16, device=d2.device)  # noqa: E731
     # tensors that cross streams (operands of the grouped weight-gradient launch, the next block's input) are allocated
     # here, on the caller's stream, and stay alive until the end-of-backward join (_pending_dw / SideStream.keep)
-    dpre, dx1, dqkv, dx = E(pre.shape[1]), E(d), E(3 * d), E(d)
+    dpre, dqkv = E(pre.shape[1]), E(3 * d)
+    if two:
+        dx1_full, dx_full = (torch.empty((2, m, d), dtype=bf16, device=d2.device) for _ in range(2))
+        (dx1, dx1_lo), (dx, dx_lo) = (dx1_full[0], dx1_full[1]), (dx_full[0], dx_full[1])
+    else:
+        dx1, dx = E(d), E(d)
+        dx1_lo = dx_lo = None
+        dx_full = dx
     qkv3, dqkv3, o3 = qkv.view(bsz, t, 3 * d), dqkv.view(bsz, t, 3 * d), o2.view(bsz, t, d)
     dact = ops.EPI_DQGELU if quick else ops.EPI_DGELU
     nsl = len(streams) if streams else 1
@@ -413,13 +430,13 @@ def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_
         km = None if keep_mask is None else keep_mask[b0:b1_] if keep_mask.shape[0] == bsz else keep_mask
         cur = _functional.cur_stream() if d2.is_cuda else None
 
-        def ln(which: int, dy_, x_, w_, b_, mean_, rstd_, add_, out_) -> None:
+        def ln(which: int, dy_, x_, w_, b_, mean_, rstd_, add_, out_, add_lo_=None, out_lo_=None) -> None:
             if _ln_defers(w_, b_, dy_):  # (the reduces of both slices queue up on ONE lane, in order: no event between the slices)
-                _ln_bwd(dy_, x_, w_, b_, mean_, rstd_, dx_add=add_, dx_out=out_, notify=last)
+                _ln_bwd(dy_, x_, w_, b_, mean_, rstd_, dx_add=add_, dx_out=out_, notify=last, dx_add_lo=add_lo_, dx_lo_out=out_lo_)
                 return
             if ln_done[which] is not None:
                 _functional.rec_wait_event(cur, ln_done[which])
-            _ln_bwd(dy_, x_, w_, b_, mean_, rstd_, dx_add=add_, dx_out=out_, notify=last)
+            _ln_bwd(dy_, x_, w_, b_, mean_, rstd_, dx_add=add_, dx_out=out_, notify=last, dx_add_lo=add_lo_, dx_lo_out=out_lo_)
             if nsl > 1 and not last:
                 ev = torch.cuda.Event()
                 _functional.rec_record_event(ev, cur)
@@ -428,7 +445,8 @@ def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_
         # channel mixing
         ops.gemm(d2[r], w2_16, b_trans=True, epilogue=dact, aux_in=pre[r], out=dpre[r])
         dln2 = ops.gemm(dpre[r], w1_16, b_trans=True)
-        ln(0, dln2, x1[r], ln2_w, ln2_b, mean2[r], rstd2[r], d2[r], dx1[r])
+        ln(0, dln2, x1[r], ln2_w, ln2_b, mean2[r], rstd2[r], d2[r], dx1[r], None if d2_lo is None else d2_lo[r],
+           None if dx1_lo is None else dx1_lo[r])
         # token mixing
         d_o = ops.gemm(dx1[r], out_w16, b_trans=True)
         q3, dq3 = qkv3[b0:b1_], dqkv3[b0:b1_]
@@ -437,7 +455,8 @@ def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_
         ops.attn_bwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], o3[b0:b1_], d_o.view(nb, t, d), lse[b0:b1_], num_heads,
                      dq=dq3[..., :d], dk=dq3[..., d:2 * d], dv=dq3[..., 2 * d:], mask=km, causal=causal)
         dln1 = ops.gemm(dqkv[r], in_w16, b_trans=True)
-        ln(1, dln1, x2[r], ln1_w, ln1_b, mean1[r], rstd1[r], dx1[r], dx[r])
+        ln(1, dln1, x2[r], ln1_w, ln1_b, mean1[r], rstd1[r], dx1[r], dx[r], None if dx1_lo is None else dx1_lo[r],
+           None if dx_lo is None else dx_lo[r])
 
     if nsl == 1:
         run(0)
@@ -451,10 +470,29 @@ def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_
     _queue_dw(w1, b1, dpre, ln2)
     _queue_dw(out_w, out_b, dx1, o2)
     _queue_dw(in_w, qkv_b, dqkv, ln1)
-    return dx
+    if two:
+        SideStream.keep.append(d2_full)  # (its planes are views: the whole tensor stays until the end-of-backward join)
+    return dx_full
 
 
-def _as_bf16_rows(dy: Tensor, rows: int, d: int) -> Tensor:
+# The residual-gradient stream of a block stack whose residual stream is f32: 1 = one bf16 word (rounds 1-5), 2 = two bf16 words
+# ~ f32, the reference's autocast semantics (the gradient of an f32 tensor is f32; `cfhip_layernorm_bwd2`).  A stack asks for two
+# words through its metas (modules.MixedStackedEncoder.grad_stream_words; CLIP's towers do), or everything gets them with
+# GRAD_STREAM_WORDS = 2.  Measured cost / what it buys: DESIGN §3.6b.
+GRAD_STREAM_WORDS = 1
+
+
+def _as_bf16_rows(dy: Tensor, rows: int, d: int, words: int = 1) -> Tensor:
+    """the incoming gradient as bf16 rows [rows, d]; `words` = 2: [2, rows, d] — first and second word (an f32 gradient is split
+    exactly into hi + lo; a bf16 one has no second word: zeros)"""
+    if words == 2:
+        out = torch.empty((2, rows, d), dtype=bf16, device=dy.device)
+        if dy.dtype == bf16:
+            out[0].copy_(dy.contiguous().view(rows, d))
+            out[1].zero_()
+        else:
+            ops.split_f32(dy.float().contiguous().view(rows, d), out[0], out[1])
+        return out
     if dy.dtype != bf16:
         dy = ops.to_bf16(dy.float().contiguous())
     return dy.contiguous().view(rows, d)
@@ -686,7 +724,7 @@ def _plan_for(x: Tensor, metas: tuple, keep_mask: Optional[Tensor], causal: bool
         return None  # gradients outside an arena / frozen weights / some slots written and others accumulated: the normal path
     key = (tuple(x.shape), x.dtype, metas, causal, None if keep_mask is None else keep_mask.data_ptr(), FWD_HALVES, BWD_HALVES,
            DW_GROUP_BLOCKS, DW_GROUP_TILES, DW_TAIL_BLOCKS, DW_PEROP_TAIL, LN_REDUCE_ASIDE, DW_GROUP_ON_MAIN, FIRST_SLICE_SHARE, FUSE_BIAS_GRAD,
-           ops.FORCE_SPLIT_K, tuple(id(cb) for cb in _functional.grad_ready_callbacks), x.requires_grad, state)
+           ops.FORCE_SPLIT_K, tuple(id(cb) for cb in _functional.grad_ready_callbacks), x.requires_grad, GRAD_STREAM_WORDS, state)
     pid = id(params[0])
     plan = _plans.get(pid)
     if plan is None or plan.key != key or (plan.params_ref and plan.params_ref[0]() is not params[0]):
@@ -716,6 +754,13 @@ class MixingStackFn(Function):
     def _slices_bwd(metas: tuple, default: int) -> int:
         m0 = metas[0]
         return int(m0[5]) if len(m0) > 5 and m0[5] else MixingStackFn._slices(metas, default)
+
+    @staticmethod
+    def _words(metas: tuple, x_is_f32: bool) -> int:
+        """words of the residual-gradient stream (7th meta entry, else the module default); two only under an f32 stream"""
+        m0 = metas[0]
+        w = int(m0[6]) if len(m0) > 6 and m0[6] else GRAD_STREAM_WORDS
+        return 2 if (w == 2 and x_is_f32) else 1
 
     @staticmethod
     def _forward_body(cur: Tensor, bsz: int, t: int, metas: tuple, keep_mask: Optional[Tensor], causal: bool, params: tuple):
@@ -760,6 +805,7 @@ class MixingStackFn(Function):
         assert len(params) == 12 * len(metas)
         ctx.params = params
         ctx.meta = (bsz, t, d, metas, causal)
+        ctx.words = MixingStackFn._words(metas, x.dtype == f32)
         ctx.plan = None
         plan = _plan_for(x, metas, keep_mask, causal, params, any(ctx.needs_input_grad))
         if plan is not None and plan.in_flight and not plan.disabled:
@@ -854,6 +900,8 @@ class MixingStackFn(Function):
                 for st in streams[1:]:
                     _functional.rec_wait_stream(_functional.cur_stream(), st)
                 SideStream.keep.append(d2)  # written by both slice streams, allocated on the caller's
+            if d2.dim() == 3:  # two-word stream: what leaves the stack is the f32 gradient of its f32 input, hi + lo
+                d2 = ops.join_bf16x2(d2[0], d2[1])
         except BaseException:
             _pending_dw.clear()  #  nothing queued by a failed pass may be flushed into `.grad` by the next one
             _linear_items.clear()
@@ -873,7 +921,7 @@ class MixingStackFn(Function):
         nret = (None, None, None) + (None,) * len(params)
         if plan is None:
             *all_saved, keep_mask = ctx.saved_tensors
-            d2 = _as_bf16_rows(dy, bsz * t, d)
+            d2 = _as_bf16_rows(dy, bsz * t, d, ctx.words)
             d2 = MixingStackFn._backward_body(list(all_saved), keep_mask, bsz, t, metas, causal, d2, params)
             return (d2.view(bsz, t, d),) + nret
         plan.in_flight = False
@@ -885,7 +933,7 @@ class MixingStackFn(Function):
         fresh = _grad_state(params) == plan.state  # the write / accumulate flags in the recorded arguments still apply
         if plan.ready_bwd and fresh and _lib.RECORDER is None and ops.GEMM_TIMER is None and ops.FLOP_COUNTER is None:
             # ---- replay
-            d2 = _as_bf16_rows(dy, bsz * t, d)
+            d2 = _as_bf16_rows(dy, bsz * t, d, ctx.words)
             if d2.data_ptr() != plan.dy_now:
                 plan.repoint(plan.dy_sites, d2.data_ptr())
                 plan.dy_now = d2.data_ptr()
@@ -897,7 +945,7 @@ class MixingStackFn(Function):
         if not plan.ready_bwd and fresh and _lib.RECORDER is None:
             # ---- record the backward of the recorded forward (the incoming gradient is converted BEFORE the recording
             # starts: that launch reads this pass's autograd buffer, which no later pass will see at that address)
-            d2 = _as_bf16_rows(dy, bsz * t, d)
+            d2 = _as_bf16_rows(dy, bsz * t, d, ctx.words)
             plan.dy_in = d2
             _lib.RECORDER = plan.bwd
             try:
@@ -911,7 +959,7 @@ class MixingStackFn(Function):
             plan.ready_bwd = True
             return (dx.detach().view(bsz, t, d),) + nret
         # the plan cannot serve this backward (gradient accumulation state, timers attached): the normal path on its buffers
-        d2 = _as_bf16_rows(dy, bsz * t, d)
+        d2 = _as_bf16_rows(dy, bsz * t, d, ctx.words)
         saved = list(plan.all_saved)
         if plan.x_live is not None:
             saved[0] = plan.x_live  # (a replayed forward read the caller's input in place, not the recorded buffer)

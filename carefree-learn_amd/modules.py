@@ -972,8 +972,10 @@ class MixedStackedEncoder(Module):
             # one autograd node for the whole stack (fused.MixingStackFn)
             metas, params = [], []
             slices = getattr(self, "stack_slices", None)
+            sf, sb = (slices, 0) if isinstance(slices, int) else (tuple(slices) + (0, 0))[:2] if slices else (0, 0)
+            extra = (int(sf or 0), int(sb or 0), int(getattr(self, "grad_stream_words", 0) or 0))  # (0 = the module default of fused.py)
             for b in blocks:
-                metas.append(b.fused_meta() + ((slices,) if isinstance(slices, int) and slices else tuple(slices) if slices else ()))
+                metas.append(b.fused_meta() + extra)
                 params.extend(b.fused_params())
             net = fused.mixing_stack(net, tuple(metas), None, causal, params)
         else:
@@ -1479,6 +1481,13 @@ class CLIP(Module):
             self.text_head_pooler = text_head_pooler
             self.text_latent_dropout = nn.Dropout(text_dropout)
             self.text_projection = HijackLinear(text_latent_dim, latent_dim)
+        # The contrastive loss makes the per-sample gradients of the SHARED parameters (head token, positional encodings, the
+        # embedding LayerNorm) nearly cancel in the batch sum; with the residual-gradient stream rounded to one bf16 word twice per
+        # block they came out 1.3-1.5 x further from fp32 than the reference's own bf16 run (its stream gradient is f32):
+        # tests/test_gpu_clip.py::test_clip_b32_step_vs_oracle.  Both towers carry the second word (fused.GRAD_STREAM_WORDS).
+        for tower in (self.vit, self.text_transformer):
+            if tower is not None:
+                tower.encoder.grad_stream_words = 2
         self.reset_parameters()
 
     def reset_parameters(self) -> None:

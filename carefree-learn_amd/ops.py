@@ -309,9 +309,12 @@ def layernorm_bwd(
     want_dx: bool = True,
     want_param_grads: bool = True,
     dx_out: Optional[Tensor] = None,
+    dx_add_lo: Optional[Tensor] = None,
+    dx_lo_out: Optional[Tensor] = None,
 ) -> Tuple[Optional[Tensor], Optional[Tensor], Optional[Tensor]]:
     """x bf16 or f32.  Returns (dx bf16 [M, D] (+ dx_add), dgamma f32 [D], dbeta f32 [D]).  `dx_out`: dense bf16 [M, D]
-    destination for dx (e.g. a row slice of a full-batch tensor)."""
+    destination for dx (e.g. a row slice of a full-batch tensor).  `dx_add_lo` / `dx_lo_out`: the SECOND bf16 words of dx_add / dx
+    when the residual-gradient stream is carried in two words (cfhip_layernorm_bwd2), dense [M, D] like the first."""
     _need(dy, bf16, "dy")
     _need(x, x.dtype if x.dtype in (bf16, f32) else bf16, "x")
     m, d, xs = _mat(x, "x")
@@ -336,6 +339,14 @@ def layernorm_bwd(
     lib = _lib.load()
     nbytes = lib.cfhip_layernorm_bwd_workspace(m, d) if want_param_grads else 0
     ws = torch.empty((max(nbytes, 4) // 4,), dtype=f32, device=x.device)
+    if want_dx and (dx_add_lo is not None or dx_lo_out is not None):
+        _check_lo(dx_add_lo, dx_lo_out, m, d)
+        rc = lib.cfhip_layernorm_bwd2(
+            dy.data_ptr(), x.data_ptr(), int(x.dtype == f32), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add),
+            _p(dx_add_lo), _p(dx), _p(dx_lo_out), _p(dgamma), _p(dbeta), m, d, dys, xs, d, int(accumulate), ws.data_ptr(), nbytes,
+            None, _stream())
+        _lib.check(rc, "layernorm_bwd2")
+        return dx, dgamma, dbeta
     rc = lib.cfhip_layernorm_bwd(
         dy.data_ptr(), x.data_ptr(), int(x.dtype == f32), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
         _p(dx_add),
@@ -346,8 +357,38 @@ def layernorm_bwd(
     return dx, dgamma, dbeta
 
 
+def _check_lo(dx_add_lo: Optional[Tensor], dx_lo_out: Optional[Tensor], m: int, d: int) -> None:
+    for t, name in ((dx_add_lo, "dx_add_lo"), (dx_lo_out, "dx_lo_out")):
+        if t is not None:
+            _need(t, bf16, name)
+            if tuple(t.shape) != (m, d) or t.stride(0) != d or t.stride(1) != 1:
+                raise ValueError(f"cfhip layernorm_bwd: {name} must be a dense [M, D] bf16 tensor")
+
+
+def split_f32(src: Tensor, hi: Optional[Tensor] = None, lo: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """f32 -> (hi, lo) bf16 with hi = bf16(v), lo = bf16(v - hi): the two words of the residual-gradient stream (cfhip_split_f32_bf16x2)"""
+    _need(src, f32, "src")
+    src = src.contiguous()
+    hi = torch.empty(src.shape, dtype=bf16, device=src.device) if hi is None else hi
+    lo = torch.empty(src.shape, dtype=bf16, device=src.device) if lo is None else lo
+    _lib.check(_lib.load().cfhip_split_f32_bf16x2(src.data_ptr(), hi.data_ptr(), lo.data_ptr(), src.numel(), _stream()), "split_f32_bf16x2")
+    return hi, lo
+
+
+def join_bf16x2(hi: Tensor, lo: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """(hi, lo) bf16 -> f32 hi + lo (exact) (cfhip_join_bf16x2_f32)"""
+    _need(hi, bf16, "hi")
+    _need(lo, bf16, "lo")
+    if not (hi.is_contiguous() and lo.is_contiguous() and hi.shape == lo.shape):
+        raise ValueError("cfhip join_bf16x2: two dense bf16 tensors of one shape expected")
+    out = torch.empty(hi.shape, dtype=f32, device=hi.device) if out is None else out
+    _lib.check(_lib.load().cfhip_join_bf16x2_f32(hi.data_ptr(), lo.data_ptr(), out.data_ptr(), hi.numel(), _stream()), "join_bf16x2_f32")
+    return out
+
+
 def layernorm_bwd_partials(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, *, dx_add: Optional[Tensor] = None,
-                           dx_out: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, int]:
+                           dx_out: Optional[Tensor] = None, dx_add_lo: Optional[Tensor] = None,
+                           dx_lo_out: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, int]:
     """The row kernel of `layernorm_bwd` alone: dx (+ dx_add) and the per-workgroup partial sums of dgamma | dbeta.  Returns
     (dx, workspace, rows) for `layernorm_bwd_reduce` — which may run on another stream (cfhip_layernorm_bwd_partials / _reduce)."""
     _need(dy, bf16, "dy")
@@ -358,6 +399,13 @@ def layernorm_bwd_partials(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, r
     nbytes = lib.cfhip_layernorm_bwd_workspace(m, d)
     ws = torch.empty((max(nbytes, 4) // 4,), dtype=f32, device=x.device)
     rows = ctypes.c_int(0)
+    if dx_add_lo is not None or dx_lo_out is not None:
+        _check_lo(dx_add_lo, dx_lo_out, m, d)
+        rc = lib.cfhip_layernorm_bwd2(dy.data_ptr(), x.data_ptr(), int(x.dtype == f32), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                      _p(dx_add), _p(dx_add_lo), dx.data_ptr(), _p(dx_lo_out), None, None, m, d, dys, xs, dx.stride(0), 0,
+                                      ws.data_ptr(), nbytes, ctypes.byref(rows), _stream())
+        _lib.check(rc, "layernorm_bwd2 (partials)")
+        return dx, ws, rows.value
     rc = lib.cfhip_layernorm_bwd_partials(dy.data_ptr(), x.data_ptr(), int(x.dtype == f32), gamma.data_ptr(), mean.data_ptr(),
                                           rstd.data_ptr(), _p(dx_add), dx.data_ptr(), m, d, dys, xs, dx.stride(0), ws.data_ptr(),
                                           nbytes, ctypes.byref(rows), _stream())

@@ -180,6 +180,21 @@ int cfhip_layernorm_bwd_partials(const void* dy, const void* x, int x_is_f32, co
                                  int64_t x_row_stride, int64_t dx_row_stride, void* workspace, size_t workspace_bytes,
                                  int* rows_out, void* stream);
 int cfhip_layernorm_bwd_reduce(void* workspace, int rows, int D, float* dgamma, float* dbeta, int accumulate, void* stream);
+/* cfhip_layernorm_bwd / _partials with the residual-gradient stream carried in TWO bf16 words per element (round 6): hi = bf16(g),
+ * lo = bf16(g - hi), i.e. 16 mantissa bits.  The reference's residual stream is f32 under autocast (x + f(LN(x)) with f32 x), so the
+ * gradient that flows along it is f32 and only the matrix products see it rounded to bf16; with one bf16 word the running sum is
+ * rounded twice per block, and parameters whose per-sample gradients cancel (CLIP's head token / positional encoding under the
+ * contrastive loss) came out 1.5 x further from fp32 than the reference's own bf16 run.  dx_add_lo / dx_lo: the second words of
+ * dx_add / dx (same strides; either may be NULL); the GEMMs of the block keep reading the first word = bf16(g), as the reference's
+ * do.  rows_out != NULL selects the `_partials` form (row kernel only; reduce with cfhip_layernorm_bwd_reduce). */
+int cfhip_layernorm_bwd2(const void* dy, const void* x, int x_is_f32, const float* gamma, const float* mean,
+                         const float* rstd, const void* dx_add, const void* dx_add_lo, void* dx, void* dx_lo,
+                         float* dgamma, float* dbeta, int M, int D, int64_t dy_row_stride, int64_t x_row_stride,
+                         int64_t dx_row_stride, int accumulate_param_grads, void* workspace, size_t workspace_bytes,
+                         int* rows_out, void* stream);
+/* the two ends of that stream: f32 -> (hi, lo) and (hi, lo) -> f32 = hi + lo (exact in f32) */
+int cfhip_split_f32_bf16x2(const float* src, void* hi, void* lo, int64_t n, void* stream);
+int cfhip_join_bf16x2_f32(const void* hi, const void* lo, float* dst, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K3/K4  fused scaled-dot-product attention (replaces F.scaled_dot_product_attention reached

@@ -140,13 +140,19 @@ def main() -> None:
         loss_fp32=loss32.item(), loss_autocast=loss16.item(),
         image_features_err=rel_l2(fi16.detach(), fi32.detach()), text_features_err=rel_l2(ft16.detach(), ft32.detach()),
         logits_err=rel_l2(lg16.detach(), lg32.detach()),
+        # the same distance on the four 8 x 8 quadrants: how noisy this statistic is.  At a random initialisation the 16 image features
+        # have cosine 0.98 with each other, so the error of the 16 x 16 logits is essentially one number per caption — the
+        # quadrants of the reference's OWN run spread 0.77 .. 1.15 x around the whole-matrix value; the GPU test bounds the logits
+        # by 1.1 x the largest of them (features and gradients, which have thousands of degrees of freedom, by 1.1 x their own value)
+        logits_err_quadrants=[rel_l2(lg16.detach()[a:a + BATCH // 2, b:b + BATCH // 2], lg32.detach()[a:a + BATCH // 2, b:b + BATCH // 2])
+                              for a in (0, BATCH // 2) for b in (0, BATCH // 2)],
         image_features_probe=probe(fi32), text_features_probe=probe(ft32), logits_probe=probe(lg32),
         grad_err={k: rel_l2(a, b) for k, a, b in zip(CLIP_SAMPLED, g16, g32)},
         grad_norm={k: b.norm().item() for k, b in zip(CLIP_SAMPLED, g32)},
         grad_probe={k: probe(b) for k, b in zip(CLIP_SAMPLED, g32)},
     )
     print(f"autocast vs fp32 rel-L2: image features {out['image_features_err']:.3e}, text features {out['text_features_err']:.3e}, "
-          f"logits {out['logits_err']:.3e}, loss {abs(loss16.item() - loss32.item()) / abs(loss32.item()):.3e}")
+          f"logits {out['logits_err']:.3e} (quadrants {', '.join(f'{v:.3e}' for v in out['logits_err_quadrants'])}), loss {abs(loss16.item() - loss32.item()) / abs(loss32.item()):.3e}")
     for k in CLIP_SAMPLED:
         print(f"    {k:80s} {out['grad_err'][k]:.3e}   |g| {out['grad_norm'][k]:.3e}")
     dst = os.path.join(ROOT, "tests", "golden", "clip_b32_yardstick.pt")

@@ -294,10 +294,14 @@ def test_clip_b32_step_vs_oracle(towers):
         logits = m(img, txt)
     e_fi, e_ft, e_lg = rel_l2(fi, o["fi"]), rel_l2(ft, o["ft"]), rel_l2(logits, o["logits"])
     print(f"CLIP b32 (towers side by side: {towers}): image features {e_fi:.3e} (reference bf16-autocast {ref['image_features_err']:.3e}), "
-          f"text features {e_ft:.3e} ({ref['text_features_err']:.3e}), logits {e_lg:.3e} ({ref['logits_err']:.3e})")
+          f"text features {e_ft:.3e} ({ref['text_features_err']:.3e}), logits {e_lg:.3e} ({ref['logits_err']:.3e}, its quadrants up to {max(ref['logits_err_quadrants']):.3e})")
     assert e_fi <= 1.1 * ref["image_features_err"], (e_fi, ref["image_features_err"])
     assert e_ft <= 1.1 * ref["text_features_err"], (e_ft, ref["text_features_err"])
-    assert e_lg <= 1.1 * ref["logits_err"], (e_lg, ref["logits_err"])
+    # (the logits of 16 near-identical image features against 16 captions are ~16 numbers: the reference's own quadrants spread
+    # 0.77 .. 1.15 x around its whole-matrix distance — oracle/gen_clip_b32_yardstick.py; bound = 1.1 x the largest of them)
+    assert e_lg <= 1.1 * max(ref["logits_err_quadrants"]), (e_lg, ref["logits_err"], ref["logits_err_quadrants"])
+    want_lg = (m.logit_scale.detach().exp() * fi @ ft.t()).float().cpu()
+    assert rel_l2(logits, want_lg) <= 1e-5  # ... and the similarity kernel itself is exact fp32 on OUR features
 
     ts = LossTrainStep(m, lambda mod, b: mod.contrastive_loss(b["image"], b["text"]), lr=0.0)
     batch = dict(image=img, text=txt)
@@ -311,7 +315,7 @@ def test_clip_b32_step_vs_oracle(towers):
         worst = max(errs, key=lambda k: errs[k] / ref["grad_err"][k])
         print(f"  step {step}: loss {loss:.6f} vs {o['loss']:.6f} (rel {loss_err:.2e}); worst sampled gradient {errs[worst]:.3e} = "
               f"{errs[worst] / ref['grad_err'][worst]:.2f} x the reference's bf16-autocast distance ({worst})")
-        if step == 3:
+        if step in (1, 3):
             for k in names:
                 print(f"    {k:82s} {errs[k]:.3e}   reference bf16-autocast {ref['grad_err'][k]:.3e} (x {errs[k] / ref['grad_err'][k]:.2f})")
         assert loss_err <= 1e-3, (loss, o["loss"])

@@ -73,6 +73,50 @@ def test_layernorm_f32_rows_to_f32_rows(m, d):
     assert_close(bd.grad, bf.grad, 2e-4, "ln f32 dbeta")
 
 
+def test_two_word_gradient_stream_split_join_and_layernorm_bwd2():
+    """The residual-gradient stream in two bf16 words (round 6): f32 -> (hi, lo) is hi = bf16(v), lo = bf16(v - hi) bit for bit, the
+    join hi + lo is within 2^-16 of v; `cfhip_layernorm_bwd2` adds BOTH words of dx_add in f32 and returns both words of dx: the
+    pair is as close to the fp32 result as an f32 store would be (1e-5), the first word alone is the one-word kernel's result
+    whenever no second word comes in, and the parameter gradients are those of the one-word call; the `_partials` form too."""
+    g = torch.Generator().manual_seed(11)
+    v = torch.randn(1000003, generator=g) * 3
+    hi, lo = ops.split_f32(v.to(DEV))
+    assert torch.equal(hi.cpu(), v.to(torch.bfloat16))
+    assert torch.equal(lo.cpu(), (v - v.to(torch.bfloat16).float()).to(torch.bfloat16))
+    back = ops.join_bf16x2(hi, lo)
+    assert torch.equal(back.cpu(), hi.float().cpu() + lo.float().cpu())
+    assert ((back.cpu() - v).abs() <= v.abs() * 2.0 ** -16).all()
+    for m, d in ((800, 768), (1232, 512), (64, 320), (33, 2048), (17, 4)):
+        x = torch.randn(m, d, generator=g) * 2 + 0.5
+        w = torch.randn(d, generator=g) * 0.2 + 1
+        b = torch.randn(d, generator=g) * 0.2
+        dy = torch.randn(m, d, generator=g).to(torch.bfloat16)
+        add = torch.randn(m, d, generator=g) * 4  # the incoming stream gradient, f32
+        xf, wf, bf = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        O.layer_norm(xf, wf, bf, 1e-5).backward(dy.float())
+        want = xf.grad + add
+        xd, wd = x.to(DEV), w.to(DEV)
+        _, mean, rstd = ops.layernorm_fwd(xd, wd, b.to(DEV), 1e-5)
+        ahi, alo = ops.split_f32(add.to(DEV))
+        dhi, dlo = torch.empty(m, d, dtype=torch.bfloat16, device=DEV), torch.empty(m, d, dtype=torch.bfloat16, device=DEV)
+        dx, dg, db = ops.layernorm_bwd(dy.to(DEV), xd, wd, mean, rstd, dx_add=ahi, dx_add_lo=alo, dx_out=dhi, dx_lo_out=dlo)
+        assert dx.data_ptr() == dhi.data_ptr()
+        assert_close(ops.join_bf16x2(dhi, dlo), want, 2e-5, f"two-word dx {m}x{d}")
+        assert_close(dg, wf.grad, 2e-4, "dgamma")
+        assert_close(db, bf.grad, 2e-4, "dbeta")
+        # one-word in, two words out == the one-word kernel on the first word (+ a residual); no second word out: the old result
+        one, dg1, db1 = ops.layernorm_bwd(dy.to(DEV), xd, wd, mean, rstd, dx_add=ahi)
+        two, _, _ = ops.layernorm_bwd(dy.to(DEV), xd, wd, mean, rstd, dx_add=ahi, dx_lo_out=dlo)
+        assert torch.equal(one, two) and torch.equal(dg1, dg) and torch.equal(db1, db)
+        # the `_partials` form (row kernel now, column reduce later)
+        dhi2, dlo2 = torch.empty_like(dhi), torch.empty_like(dlo)
+        _, ws, rows = ops.layernorm_bwd_partials(dy.to(DEV), xd, wd, mean, rstd, dx_add=ahi, dx_add_lo=alo, dx_out=dhi2, dx_lo_out=dlo2)
+        assert torch.equal(dhi2, dhi) and torch.equal(dlo2, dlo)
+        pg = torch.zeros(2 * d, device=DEV)
+        ops.layernorm_bwd_reduce(ws, rows, d, pg[:d], pg[d:], False)
+        assert_close(pg[:d], wf.grad, 2e-4, "partials dgamma")
+
+
 def test_layernorm_strided_rows():
     """head LN reads token 0 of every sample: row stride T*D."""
     b, t, d = 16, 197, 768
