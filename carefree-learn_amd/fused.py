@@ -475,11 +475,15 @@ def _block_bwd(saved: tuple, prm: tuple, num_heads: int, bsz: int, t: int, keep_
     return dx_full
 
 
-# The residual-gradient stream of a block stack whose residual stream is f32: 1 = one bf16 word (rounds 1-5), 2 = two bf16 words
-# ~ f32, the reference's autocast semantics (the gradient of an f32 tensor is f32; `cfhip_layernorm_bwd2`).  A stack asks for two
-# words through its metas (modules.MixedStackedEncoder.grad_stream_words; CLIP's towers do), or everything gets them with
-# GRAD_STREAM_WORDS = 2.  Measured cost / what it buys: DESIGN §3.6b.
-GRAD_STREAM_WORDS = 1
+# The residual-gradient stream of a block stack whose residual stream is f32: 2 (default since round 6) = two bf16 words ~ f32, the
+# reference's autocast semantics (the gradient of an f32 tensor is f32, only the matrix products see it rounded;
+# `cfhip_layernorm_bwd2`); 1 = one bf16 word (rounds 1-5).  A bf16 residual stream (the UNet's transformer tokens: bf16 in the
+# reference too) always has a one-word gradient.  A stack can ask for either through its metas
+# (modules.MixedStackedEncoder.grad_stream_words).  What it buys, measured against the reference's OWN bf16-autocast distance from
+# fp32 (tests/golden/*_yardstick.pt): ViT-B/16 x 8, 152 gradients: one word max 1.31 x / median 1.10 x, two words max 1.09 x /
+# median 0.96 x; CLIP b32 head token 1.51 x -> 0.6 x.  What it costs: 4 B / element more in each LayerNorm backward,
+# ViT-B/16 b128 17.45 -> 17.79 ms (tools/grad_words_ab.py, profiles/r06/grad_words_ab.txt).  DESIGN §3.6b.
+GRAD_STREAM_WORDS = int(os.environ.get("CFHIP_GRAD_STREAM_WORDS", "2"))
 
 
 def _as_bf16_rows(dy: Tensor, rows: int, d: int, words: int = 1) -> Tensor:

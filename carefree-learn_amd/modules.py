@@ -1481,13 +1481,10 @@ class CLIP(Module):
             self.text_head_pooler = text_head_pooler
             self.text_latent_dropout = nn.Dropout(text_dropout)
             self.text_projection = HijackLinear(text_latent_dim, latent_dim)
-        # The contrastive loss makes the per-sample gradients of the SHARED parameters (head token, positional encodings, the
-        # embedding LayerNorm) nearly cancel in the batch sum; with the residual-gradient stream rounded to one bf16 word twice per
-        # block they came out 1.3-1.5 x further from fp32 than the reference's own bf16 run (its stream gradient is f32):
-        # tests/test_gpu_clip.py::test_clip_b32_step_vs_oracle.  Both towers carry the second word (fused.GRAD_STREAM_WORDS).
-        for tower in (self.vit, self.text_transformer):
-            if tower is not None:
-                tower.encoder.grad_stream_words = 2
+        # (The contrastive loss makes the per-sample gradients of the SHARED parameters — head token, positional encodings, the
+        # embedding LayerNorm — nearly cancel in the batch sum; with the residual-gradient stream rounded to one bf16 word twice per
+        # block they came out 1.3-1.5 x further from fp32 than the reference's own bf16 run, whose stream gradient is f32:
+        # tests/test_gpu_clip.py::test_clip_b32_step_vs_oracle.  That test is why fused.GRAD_STREAM_WORDS is 2 for every f32 stream.)
         self.reset_parameters()
 
     def reset_parameters(self) -> None:

@@ -474,3 +474,58 @@ def test_two_word_gradient_stream_through_a_block_stack():
     assert bottom
     print({k: (round(errs[1][k], 5), round(errs[2][k], 5)) for k in bottom})
     assert all(errs[2][k] <= errs[1][k] for k in bottom)
+
+
+@pytest.mark.parametrize("words", [1, 2], ids=["one_word_gradient_stream", "two_word_gradient_stream"])
+def test_vit_b16_gradients_vs_the_reference_bf16_yardstick(words):
+    """ViT-B/16 224^2 x 8 (the headline model) through `TrainStep`: all 152 parameter gradients against the fp32 oracle, bounded
+    TENSOR BY TENSOR by the distance of the reference's own bf16-autocast run from its fp32 run (tests/golden/vit_b16_yardstick.pt,
+    made from cflearn's ViTEncoder + Linear by oracle/gen_vit_b16_yardstick.py) instead of rounds 1-5's flat 2.5e-2; the same
+    fixture pins oracle/vit_oracle.py at full size (loss, logits probe, gradient probes and norms of all 152 tensors)."""
+    import os
+
+    from gen_vit_b16_yardstick import BATCH, probe, seeded_problem
+
+    from cflearn_amd import fused
+    from cflearn_amd.engine import TrainStep
+
+    ref = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vit_b16_yardstick.pt"), weights_only=False)
+    sd, img, labels = seeded_problem()
+    assert ref["batch"] == BATCH and ref["n_params"] == 86567656
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    try:
+        want_loss, want_logits, want_grads = O.loss_and_grads(img, labels, sd, 12, 12)
+    finally:
+        torch.set_num_threads(prev)
+    assert abs(want_loss.item() - ref["loss_fp32"]) <= 1e-5 * ref["loss_fp32"]
+    assert rel_l2(probe(want_logits, 64), ref["logits_probe"]) <= 1e-4
+    for k, gr in want_grads.items():
+        assert rel_l2(probe(gr), ref["grad_probe"][k]) <= 5e-4, k
+        assert abs(gr.norm().item() - ref["grad_norm"][k]) <= 2e-4 * ref["grad_norm"][k], k
+    keep = fused.GRAD_STREAM_WORDS
+    fused.GRAD_STREAM_WORDS = words
+    try:
+        torch.manual_seed(0)
+        m = C.vit_b16_classifier(num_classes=1000)
+        m.load_state_dict(sd)
+        m = m.to(DEV)
+        ts = TrainStep(m, lr=0.0)
+        for _ in range(3):  # composed launch, plan recording, plan replay (lr = 0: the same problem three times)
+            loss = ts.step(img.to(DEV), labels.view(-1).to(DEV)).item() / BATCH
+        torch.cuda.synchronize()
+        errs = {k: rel_l2(p.grad, want_grads[k]) for k, p in m.named_parameters()}
+    finally:
+        fused.GRAD_STREAM_WORDS = keep
+    assert abs(loss - want_loss.item()) <= 1e-3 * want_loss.item(), (loss, want_loss.item())
+    ratio = {k: errs[k] / ref["grad_err"][k] for k in errs}
+    order = sorted(ratio, key=ratio.get, reverse=True)
+    print(f"ViT-B/16 x {BATCH}, {words}-word gradient stream: loss {loss:.6f} vs {want_loss.item():.6f}; gradients vs fp32 oracle: worst "
+          f"{max(errs.values()):.3e}; against the reference's own bf16 distance: max x {ratio[order[0]]:.2f}, median x {ratio[order[len(order) // 2]]:.2f}")
+    for k in order[:12]:
+        print(f"    {k:74s} {errs[k]:.3e}   reference bf16-autocast {ref['grad_err'][k]:.3e} (x {ratio[k]:.2f})")
+    # two words (the default): every tensor within 1.1 x the reference's own bf16 distance (measured max 1.09 x, median 0.96 x).
+    # one word (rounds 1-5, CFHIP_GRAD_STREAM_WORDS=1): measured max 1.31 x, median 1.10 x — kept as a regression bound only
+    bound = 1.1 if words == 2 else 1.45
+    for k in errs:
+        assert errs[k] <= max(5e-3, bound * ref["grad_err"][k]), (k, errs[k], ref["grad_err"][k])

@@ -106,7 +106,7 @@ def test_two_word_gradient_stream_split_join_and_layernorm_bwd2():
         assert_close(db, bf.grad, 2e-4, "dbeta")
         # one-word in, two words out == the one-word kernel on the first word (+ a residual); no second word out: the old result
         one, dg1, db1 = ops.layernorm_bwd(dy.to(DEV), xd, wd, mean, rstd, dx_add=ahi)
-        two, _, _ = ops.layernorm_bwd(dy.to(DEV), xd, wd, mean, rstd, dx_add=ahi, dx_lo_out=dlo)
+        two, _, _ = ops.layernorm_bwd(dy.to(DEV), xd, wd, mean, rstd, dx_add=ahi, dx_lo_out=torch.empty_like(dlo))
         assert torch.equal(one, two) and torch.equal(dg1, dg) and torch.equal(db1, db)
         # the `_partials` form (row kernel now, column reduce later)
         dhi2, dlo2 = torch.empty_like(dhi), torch.empty_like(dlo)
