@@ -99,36 +99,24 @@ def _dw_rows(L: int, d: int, dff: int, m: int, nb: int):
     return rows
 
 
-def time_gemms(batch: int, reps: int):
-    """Event-timed duration of every GEMM shape of the step (steady state, same stream)."""
+def gemm_launchers(batch: int):
+    """Every GEMM launch shape of the step as (row description, launch closure, count per step, FLOPs, algorithmic bytes): seeded
+    random operands resident in HBM, the epilogue operands of the model (f32 residual stream, saved pre-activation).  Shared by
+    `time_gemms` (isolated timings) and tools/energy_table.py (joules per launch)."""
     from cflearn_amd import ops
 
     dev = torch.device("cuda", torch.cuda.current_device())
-    rows = []
-    tot_flops = tot_time = tot_bytes = 0.0
+    bf = torch.bfloat16
     for count, layout, m, n, k, epi in gemm_shapes(batch):
-        bf = torch.bfloat16
         if layout == "tn-grouped":
             g = torch.Generator(device=dev).manual_seed(len(m))
             rnd = lambda *s: (torch.randn(*s, generator=g, device=dev) * 0.5).to(bf)  # noqa: E731
             probs = [(rnd(kk, mm), rnd(kk, nn), torch.empty(mm, nn, dtype=torch.float32, device=dev), False,
                       torch.empty(mm, dtype=torch.float32, device=dev), False) for mm, nn, kk in m]
-            for _ in range(2):
-                ops.gemm_grouped_tn(probs)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                ops.gemm_grouped_tn(probs)
-            e1.record()
-            e1.synchronize()
-            dur = e0.elapsed_time(e1) * 1e-3 / reps
             flops = sum(2.0 * mm * nn * kk for mm, nn, kk in m)
             nbytes = sum(2.0 * (mm * kk + nn * kk) + 4.0 * mm * nn for mm, nn, kk in m)
-            rows.append(dict(layout=layout, problems=[list(x) for x in m], count=count, us=round(dur * 1e6, 1),
-                             tflops=round(flops / dur / 1e12, 1), algorithmic_mb=round(nbytes / 1e6, 1)))
-            tot_flops += count * flops
-            tot_time += count * dur
-            tot_bytes += count * nbytes
+            yield (dict(layout=layout, problems=[list(x) for x in m], count=count), (lambda probs=probs: ops.gemm_grouped_tn(probs)),
+                   count, flops, nbytes)
             del probs
             continue
         g = torch.Generator(device=dev).manual_seed(m + n + k)
@@ -155,18 +143,25 @@ def time_gemms(batch: int, reps: int):
         if layout == "tn":
             nbytes += 2.0 * m * n  # f32 gradient output
         out = torch.empty(m, n, dtype=kw.pop("out_dtype", bf), device=dev)
+        yield (dict(layout=layout, M=m, N=n, K=k, epilogue=epi, count=count),
+               (lambda a=a, b=b, bias=bias, out=out, kw=kw: ops.gemm(a, b, bias=bias, out=out, **kw)), count, 2.0 * m * n * k, nbytes)
+
+
+def time_gemms(batch: int, reps: int):
+    """Event-timed duration of every GEMM shape of the step (steady state, same stream)."""
+    rows = []
+    tot_flops = tot_time = tot_bytes = 0.0
+    for desc, fn, count, flops, nbytes in gemm_launchers(batch):
         for _ in range(2):
-            ops.gemm(a, b, bias=bias, out=out, **kw)
+            fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            ops.gemm(a, b, bias=bias, out=out, **kw)
+            fn()
         e1.record()
         e1.synchronize()
         dur = e0.elapsed_time(e1) * 1e-3 / reps
-        flops = 2.0 * m * n * k
-        rows.append(dict(layout=layout, M=m, N=n, K=k, epilogue=epi, count=count, us=round(dur * 1e6, 1),
-                         tflops=round(flops / dur / 1e12, 1), algorithmic_mb=round(nbytes / 1e6, 1)))
+        rows.append(dict(desc, us=round(dur * 1e6, 1), tflops=round(flops / dur / 1e12, 1), algorithmic_mb=round(nbytes / 1e6, 1)))
         tot_flops += count * flops
         tot_time += count * dur
         tot_bytes += count * nbytes
@@ -468,12 +463,15 @@ def run_other_workload(args) -> dict:
 
     gc.collect()
     gc.freeze()  # model, arena and warm-up survivors leave the collector's generations: its passes inside the timed steps stay short
+    start_telemetry(torch.cuda.current_device())
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     host_dt = (time.perf_counter() - t0) / args.steps  # the host's share: all launches of a step issued (no device wait inside)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    t_end = time.perf_counter()
+    dt = (t_end - t0) / args.steps
+    tel = telemetry_summary(t0, t_end)
     note(f"{args.workload}: {dt * 1e3:.3f} ms/step, host issue time {host_dt * 1e3:.3f} ms/step")
     inb = getattr(step.engine.optimizer, "in_backward", None)
     in_bwd = None if inb is None else {"ranges": len(inb.ranges), "updated_inside_backward_last_step": int(inb.launched_in_backward)}
@@ -497,16 +495,29 @@ def run_other_workload(args) -> dict:
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "host_issue_ms_per_step": round(host_dt * 1e3, 3),
+        "telemetry": tel,
         "optimizer_in_backward": in_bwd,
         "config": {"workload": name, "per_gpu_batch": batch, "parameters": n_params,
                    "loss_first_step": None if first is None else round(first, 5),
                    "loss_last_step": round(loss.item() / loss_div, 5)},
         "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                     "frac_at_sustained_clock": _frac_at_clock(tf, tel),
                      "definition": "algorithmic MFMA-class FLOPs of one step (ops.FlopCounter) / measured wall time of the step",
                      "flops_per_step": {k: v for k, v in counter.flops.items()}, "gemm_table": gemm_rows},
         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
     }
+
+
+NOMINAL_SCLK_MHZ = 2400.0  # the shader clock PEAK_BF16_TFLOPS is quoted at (MI355X_MICROARCH.md)
+
+
+def _frac_at_clock(tflops: float, tel: dict):
+    """fraction of the MFMA peak AT THE CLOCK THE CHIP SUSTAINED in the window: peak x sclk / 2400 MHz (null without a clock sample)"""
+    sclk = (tel or {}).get("sclk_mhz_avg")
+    if not sclk:
+        return None
+    return round(tflops / (PEAK_BF16_TFLOPS * sclk / NOMINAL_SCLK_MHZ), 4)
 
 
 def _pct(sorted_vals: list, q: float) -> float:
@@ -633,6 +644,74 @@ def note(msg: str) -> None:
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+TELEMETRY = None  # tools.gpu_telemetry.GpuTelemetry of this rank's GPU (started in main / bench_other_workload)
+
+
+def start_telemetry(device_index: int):
+    """sclk / socket power / junction temperature of this rank's GPU at 10 Hz from a side thread (tools/gpu_telemetry.py: amdsmi
+    in-process, rocm-smi as fallback).  A line without clock and power cannot be compared with a line from another box: the step
+    runs against the socket's power cap (DESIGN §9) and boxes differ by +-3 % in the clock they sustain (VERDICT r5 #2)."""
+    global TELEMETRY
+    if TELEMETRY is None:
+        try:
+            from tools.gpu_telemetry import GpuTelemetry
+
+            TELEMETRY = GpuTelemetry(device_index, hz=10.0).start()
+            if not TELEMETRY.available:
+                note(f"telemetry: no source ({TELEMETRY.error})")
+        except Exception as e:  # never fatal
+            note(f"telemetry unavailable: {type(e).__name__}: {e}")
+            TELEMETRY = None
+    return TELEMETRY
+
+
+def telemetry_summary(t0: float, t1: float) -> dict:
+    if TELEMETRY is None or not TELEMETRY.available:
+        return {"sclk_mhz_avg": None, "power_w_avg": None, "power_cap_w": None, "samples": 0,
+                "source": None if TELEMETRY is None else TELEMETRY.error}
+    return TELEMETRY.summary(t0, t1)
+
+
+def calibration_launch(min_seconds: float = 0.25) -> dict:
+    """ONE fixed launch, the same on every box and in every round, timed right AFTER the timed region (the chip is hot and at the
+    clock it sustains): the grouped weight-gradient kernel of two ViT-B/16 blocks at batch 128 (8 problems, K = 25 216, 216 tiles of
+    256 x 256, 1.43 TFLOP per launch) on seeded random operands, back to back for >= `min_seconds`.  Its TFLOP/s is this box's
+    yardstick: `ms_per_step x calibration rate` compares steps across boxes (VERDICT r5 #2)."""
+    from cflearn_amd import ops
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    k = 128 * 197
+    g = torch.Generator(device=dev).manual_seed(20260930)
+    rnd = lambda r, c: (torch.randn(r, c, generator=g, device=dev) * 0.5).to(torch.bfloat16)  # noqa: E731
+    shapes = ((768, 3072), (3072, 768), (768, 768), (2304, 768))
+    probs = [(rnd(k, m), rnd(k, n), torch.empty(m, n, dtype=torch.float32, device=dev), False,
+              torch.empty(m, dtype=torch.float32, device=dev), False) for _ in range(2) for m, n in shapes]
+    flops = 2.0 * sum(2.0 * m * n * k for m, n in shapes)
+    for _ in range(3):
+        ops.gemm_grouped_tn(probs)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    launches, t0 = 0, time.perf_counter()
+    e0.record()
+    while True:
+        for _ in range(40):
+            ops.gemm_grouped_tn(probs)
+        launches += 40
+        torch.cuda.synchronize()
+        if time.perf_counter() - t0 >= min_seconds:
+            break
+    e1.record()
+    e1.synchronize()
+    t1 = time.perf_counter()
+    us = e0.elapsed_time(e1) * 1e3 / launches
+    tel = telemetry_summary(t0, t1)
+    return {"kernel": "gemm_grouped_tn_kernel<Cfg<256,256,2,4,5,32>>: the weight gradients of two ViT-B/16 blocks at batch 128 "
+                      "(8 problems, K = 25 216, 216 tiles), seeded random bf16 operands",
+            "launches": launches, "us_per_launch": round(us, 2), "tflops": round(flops / us / 1e6, 1),
+            "frac_of_peak": round(flops / us / 1e6 / PEAK_BF16_TFLOPS, 4), "sclk_mhz_avg": tel.get("sclk_mhz_avg"),
+            "power_w_avg": tel.get("power_w_avg"), "when": "right after the timed region"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -650,6 +729,7 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true", help="(default now) kept for compatibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the fixed calibration launch behind the timed region")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the bounded UNet 64^2 x 8 / CLIP b256 runs (BASELINE configs 3 / 4) appended to the default N = 1 line")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -738,6 +818,7 @@ def main() -> None:
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    start_telemetry(local_rank)  # every rank samples its own GPU (RCCL's kernels draw from the same power cap: VERDICT r5 #8)
     distributed = world > 1 or args.force_ddp
     if args.nchannels > 0:  # (also when an external launcher started the ranks; RCCL reads it at communicator creation)
         os.environ["NCCL_MAX_NCHANNELS"] = str(args.nchannels)
@@ -909,7 +990,14 @@ def main() -> None:
         marks[i + 1].record()
     host_dt = time.perf_counter() - t0  # every launch of the timed steps issued (the host never waits for the device inside)
     sync()
-    dt = time.perf_counter() - t0
+    t_end = time.perf_counter()
+    dt = t_end - t0
+    tel = telemetry_summary(t0, t_end)
+    # the fixed calibration launch, on every rank at the same time (the ranks share nothing but the node's power delivery)
+    try:
+        calib = calibration_launch() if not args.no_calibration else None
+    except Exception as e:  # the headline line must survive
+        calib = {"error": f"{type(e).__name__}: {e}"[:200]}
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if distributed:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -954,6 +1042,12 @@ def main() -> None:
             "loss_last_step": round(last_loss, 4),
         },
         "mfma_frac_whole_step": round(samples_per_s * FLOP_PER_SAMPLE / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+        "mfma_frac_whole_step_at_sustained_clock": _frac_at_clock(samples_per_s * FLOP_PER_SAMPLE / world / 1e12, tel),
+        # this rank's GPU over the timed region (10 Hz side thread) and the fixed calibration launch right behind it: what makes
+        # this line comparable with a line from another box or round (`ms_per_step x calibration.tflops` is box-independent to
+        # first order)
+        "telemetry": tel,
+        "calibration": calib,
         "step_ms": {"median": round(_pct(per_step, 0.5), 3), "p10": round(_pct(per_step, 0.1), 3),
                     "p90": round(_pct(per_step, 0.9), 3), "min": round(per_step[0], 3), "max": round(per_step[-1], 3),
                     "n": len(per_step), "definition": "HIP events between consecutive steps on the issuing stream (this rank)"},
@@ -964,6 +1058,14 @@ def main() -> None:
 
     result["streams"] = stream_report()  # helper streams on hardware queues of their own? (False = a serialised step)
     if distributed:
+        # clock / power / calibration of EVERY rank (rank order): the first multi-GPU line shows what RCCL's kernels cost the cap
+        mine = torch.tensor([tel.get("sclk_mhz_avg") or 0.0, tel.get("power_w_avg") or 0.0, tel.get("junction_c_avg") or 0.0,
+                             (calib or {}).get("tflops") or 0.0], device=dev, dtype=torch.float32)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        result["telemetry"]["per_rank"] = [{"rank": r, "sclk_mhz_avg": round(v[0].item(), 1), "power_w_avg": round(v[1].item(), 1),
+                                            "junction_c_avg": round(v[2].item(), 1), "calibration_tflops": round(v[3].item(), 1)}
+                                           for r, v in enumerate(allr)]
         result["rccl"] = {
             "ranks": dist.get_world_size(), "backend": args.backend, "collectives_launched_by": args.comm,
             # what RCCL itself reports for the C-ABI communicator (ncclCommCount / ncclCommUserRank), not this script's bookkeeping
@@ -996,9 +1098,10 @@ def main() -> None:
         result["roofline"] = {
             "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+            "frac_at_sustained_clock": _frac_at_clock(achieved, tel),
             "definition": "GEMM FLOPs of one step / sum of the in-step durations of its GEMM launches (HIP events on the "
                           "launch streams, 3 overlapping streams: the sum exceeds the wall step)",
-            "wall": {"achieved": round(wall, 1), "frac": round(wall / PEAK_BF16_TFLOPS, 4),
+            "wall": {"achieved": round(wall, 1), "frac": round(wall / PEAK_BF16_TFLOPS, 4), "frac_at_sustained_clock": _frac_at_clock(wall, tel),
                      "definition": "GEMM FLOPs of one step / measured wall time of the step"},
             "isolated": {"achieved": round(isolated, 1), "frac": round(isolated / PEAK_BF16_TFLOPS, 4),
                          "gemm_ms_per_step": round(iso_sec * 1e3, 3),
@@ -1042,7 +1145,7 @@ def main() -> None:
             wl = name
             try:
                 r = run_other_workload(a2)
-                others[wl] = {k_: r[k_] for k_ in ("value", "unit", "ms_per_step", "host_issue_ms_per_step", "optimizer_in_backward", "steps", "warmup", "roofline", "peak_mem_gb")}
+                others[wl] = {k_: r[k_] for k_ in ("value", "unit", "ms_per_step", "host_issue_ms_per_step", "telemetry", "optimizer_in_backward", "steps", "warmup", "roofline", "peak_mem_gb")}
                 others[wl]["workload"] = r["config"]["workload"]
                 others[wl]["per_gpu_batch"] = r["config"]["per_gpu_batch"]
             except Exception as e:  # the headline line must survive a failure here
@@ -1071,6 +1174,8 @@ def main() -> None:
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if TELEMETRY is not None:
+        TELEMETRY.stop()
     sys.stdout.flush()
     if rank == 0:  # after everything that could still print: the one line on the real stdout
         os.write(result_fd, (json.dumps(result) + "\n").encode())

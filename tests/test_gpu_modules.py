@@ -155,17 +155,26 @@ def test_fused_equals_composed(golden):
 
 
 def test_stack_node_equals_block_nodes(golden):
-    """one autograd node for the whole stack (bf16 gradient stream) == one node per block: same kernels,
-    the only difference is a lossless bf16 -> f32 -> bf16 round trip of the inter-block gradient."""
+    """one autograd node for the whole stack with a ONE-word bf16 gradient stream (fused.GRAD_STREAM_WORDS = 1, rounds 1-5) == one
+    node per block: same kernels, the only difference is a lossless bf16 -> f32 -> bf16 round trip of the inter-block gradient.
+    (The default two-word stream keeps the second word from block to block, which per-block nodes cannot: compared with the oracle
+    in test_two_word_gradient_stream_through_a_block_stack.)"""
+    from cflearn_amd import fused
+
     g = golden("vit_small.pt")
     outs = []
-    for stack in (True, False):
-        m = _small_vit(g)
-        m.encoder.encoder.fuse_stack = stack
-        assert len(m.encoder.encoder.mixing_blocks) > 1
-        logits = m(g["img"].to(DEV))["predictions"]
-        torch.nn.functional.cross_entropy(logits, g["labels"].view(-1).to(DEV)).backward()
-        outs.append((logits.detach(), _grads(m)))
+    keep = fused.GRAD_STREAM_WORDS
+    fused.GRAD_STREAM_WORDS = 1
+    try:
+        for stack in (True, False):
+            m = _small_vit(g)
+            m.encoder.encoder.fuse_stack = stack
+            assert len(m.encoder.encoder.mixing_blocks) > 1
+            logits = m(g["img"].to(DEV))["predictions"]
+            torch.nn.functional.cross_entropy(logits, g["labels"].view(-1).to(DEV)).backward()
+            outs.append((logits.detach(), _grads(m)))
+    finally:
+        fused.GRAD_STREAM_WORDS = keep
     assert torch.equal(outs[0][0], outs[1][0])
     for k in outs[0][1]:
         if "norm" in k:  # dgamma / dbeta fold a workgroup's waves through LDS float atomics: order not fixed

@@ -107,7 +107,9 @@ def test_two_word_gradient_stream_split_join_and_layernorm_bwd2():
         # one-word in, two words out == the one-word kernel on the first word (+ a residual); no second word out: the old result
         one, dg1, db1 = ops.layernorm_bwd(dy.to(DEV), xd, wd, mean, rstd, dx_add=ahi)
         two, _, _ = ops.layernorm_bwd(dy.to(DEV), xd, wd, mean, rstd, dx_add=ahi, dx_lo_out=torch.empty_like(dlo))
-        assert torch.equal(one, two) and torch.equal(dg1, dg) and torch.equal(db1, db)
+        assert torch.equal(one, two)
+        assert_close(dg1, dg, 1e-6, "dgamma, two instantiations")  # (same sums; the compiler contracts the two kernels differently)
+        assert_close(db1, db, 1e-6, "dbeta, two instantiations")
         # the `_partials` form (row kernel now, column reduce later)
         dhi2, dlo2 = torch.empty_like(dhi), torch.empty_like(dlo)
         _, ws, rows = ops.layernorm_bwd_partials(dy.to(DEV), xd, wd, mean, rstd, dx_add=ahi, dx_add_lo=alo, dx_out=dhi2, dx_lo_out=dlo2)
