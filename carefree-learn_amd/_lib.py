@@ -37,7 +37,6 @@ SIGNATURES = {
          c_int, c_int, c_int, _P, c_size_t, _P, c_int, _P],
     ),
     "cfhip_gemm_bf16_grouped_tn": (c_int, [_P, c_int, _P]),
-    "cfhip_gemm_bf16_grouped_tn_tiles": (c_int, [_P, c_int, c_int, _P]),
     "cfhip_colsum_workspace": (c_size_t, [c_int, c_int]),
     "cfhip_colsum_bf16": (c_int, [_P, _P, c_int, c_int, c_int64, c_int, _P, c_size_t, _P]),
     "cfhip_layernorm_fwd": (

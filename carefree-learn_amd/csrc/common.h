@@ -90,6 +90,11 @@ __device__ __forceinline__ float bf16hi(unsigned w) { return __uint_as_float(w &
 // evaluations per lane per output tile, so this is what keeps them off the GEMM's critical path.
 // exp(-z^2) with z = |x|/sqrt(2) is exp(-x^2/2): the same value the derivative's pdf term needs.
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+#ifdef CFHIP_GELU_PROBE  // benchmarking only (tools/build_variant.sh): what the epilogue GEMMs cost WITHOUT the erf arithmetic
+  cdf = 0.5f;
+  e = 1.0f;
+  return;
+#endif
   // raw v_rcp_f32 / v_exp_f32 (1 ulp): `__frcp_rn` / a plain division expand to the IEEE sequence
   // (2 v_div_scale + v_rcp + 5 fma + v_div_fmas + v_div_fixup per element) — measured: the GELU
   // epilogue's VALU work was 55-60 us of a 210 us FF1 GEMM launch with it.

@@ -199,7 +199,7 @@ __device__ __forceinline__ int xcd_item() {
   return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
 }
 
-// One work item of problem `p` on this workgroup (the body of gemm_bf16_kernel and of gemm_grouped_plain_kernel).
+// One work item of problem `p` on this workgroup (the body of gemm_bf16_kernel).
 template <bool AT, bool BT, int EPI, class C, int CONV = 0, bool BG = false>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int item, char* smem) {
   constexpr int D = C::NSTAGE - 1;  // prefetch distance
@@ -279,58 +279,6 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD)
 void gemm_bf16_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   gemm_tile<AT, BT, EPI, C, CONV, BG>(p, xcd_item(), smem);
-}
-
-// ---- weight gradients of several Linear layers in ONE launch on the plain kernel above (round 4) ------------------------
-// The 256x256x32 grouped kernel (gemm_grouped.hip) takes 160 KB of LDS: a whole CU per workgroup, so while its 216 tiles
-// run (~0.9 ms, six times per ViT-B/16 step) the forward / dX kernels of the two batch slices share the 40 CUs it leaves
-// (profiles/r04/step_timeline_report.txt: N = 768 dX launches of 65 us take 500-600 us there).  This form runs the same
-// problems on 192x128x64 (or 128x128x64) tiles of 80 KB: a weight-gradient workgroup and a forward / dX workgroup share a
-// CU, as the workgroups of the two batch slices already do.  Every tile still runs its whole K = batch x tokens reduction
-// (no slabs, no reduce launch, deterministic); what makes that work on a 2-slot ring is occupancy: one launch carries the
-// tiles of ALL problems (288 per ViT block), where the same kernel launched per problem (24-96 tiles) is latency-bound
-// (whole step 35 ms: profiles/r04/dw_per_operator_ab.log).
-struct PlainGroupProblem {
-  const bf16_t* A;
-  const bf16_t* B;
-  float* C;
-  float* bgrad;
-  int M, N, K, lda, ldb, ldc;
-  int tiles_m, tiles_n, tile_end, flags;  // flags: 1 accumulate, 2 bias-gradient accumulate
-};
-constexpr int PLAIN_GROUP_MAX = 24;
-struct PlainGroupParams {
-  PlainGroupProblem pr[PLAIN_GROUP_MAX];
-  int count, group_n;
-};
-
-template <class C, bool BG>
-__global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD)
-void gemm_grouped_plain_kernel(PlainGroupParams tab) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int item = xcd_item();
-  int g = 0;
-  while (g + 1 < tab.count && item >= tab.pr[g].tile_end) ++g;  // (scalar: item is workgroup-uniform)
-  const PlainGroupProblem& q = tab.pr[g];
-  GemmParams p;
-  p.A = q.A; p.B = q.B; p.C = q.C;
-  p.bias = nullptr; p.aux_in = nullptr; p.aux_out = nullptr;
-  p.M = q.M; p.N = q.N; p.K = q.K;
-  p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
-  p.epilogue = CFHIP_EPI_NONE; p.out_f32 = 1; p.accumulate = q.flags & 1;
-  p.k_chunk = ((q.K + 63) / 64) * 64;  // (BK_MAX: the rounding cfhip_gemm_bf16 applies without a split)
-  p.slabs = nullptr;
-  p.tiles_m = q.tiles_m; p.tiles_n = q.tiles_n; p.splits = 1;
-  p.bgrad = q.bgrad; p.bgrad_slabs = nullptr; p.bgrad_acc = (q.flags >> 1) & 1;
-  p.quick = 0;
-  p.conv_h = p.conv_w = p.conv_c = p.conv_kpt = 0;
-  p.conv_inv_kpt = 0.f;
-  p.conv_magic_w = p.conv_magic_h = 0u;
-  p.group_n = tab.group_n > 0 && tab.group_n < q.tiles_n ? tab.group_n : 0;
-#ifdef CFHIP_ABLATE
-  p.ablate = 0;
-#endif
-  gemm_tile<true, true, CFHIP_EPI_NONE, C, 0, BG>(p, item - (g > 0 ? tab.pr[g - 1].tile_end : 0), smem);
 }
 
 // ---- big-tile, two-group "ping-pong" variant -----------------------------------------------------------
@@ -724,55 +672,6 @@ int pick_config(int M, int N, int a_trans, int b_trans) {
 }
 
 }  // namespace
-
-template <class C>
-static int launch_grouped_plain(const cfhip_gemm_problem* problems, int count, hipStream_t s) {
-  for (int base = 0; base < count; base += PLAIN_GROUP_MAX) {
-    const int n = count - base < PLAIN_GROUP_MAX ? count - base : PLAIN_GROUP_MAX;
-    PlainGroupParams t;
-    memset(&t, 0, sizeof(t));
-    t.count = n;
-    t.group_n = g_gemm_group_n;
-    int tiles = 0;
-    bool any_bg = false;
-    for (int i = 0; i < n; ++i) {
-      const cfhip_gemm_problem& src = problems[base + i];
-      PlainGroupProblem& d = t.pr[i];
-      d.A = reinterpret_cast<const bf16_t*>(src.A);
-      d.B = reinterpret_cast<const bf16_t*>(src.B);
-      d.C = reinterpret_cast<float*>(src.C);
-      d.bgrad = src.bias_grad;
-      d.M = src.M; d.N = src.N; d.K = src.K;
-      d.lda = (int)src.lda; d.ldb = (int)src.ldb; d.ldc = (int)src.ldc;
-      d.tiles_m = (src.M + C::BM - 1) / C::BM;
-      d.tiles_n = (src.N + C::BN - 1) / C::BN;
-      tiles += d.tiles_m * d.tiles_n;
-      d.tile_end = tiles;
-      d.flags = (src.accumulate ? 1 : 0) | (src.bias_grad_accumulate ? 2 : 0);
-      any_bg = any_bg || src.bias_grad != nullptr;
-    }
-    void (*kern)(PlainGroupParams) = any_bg ? gemm_grouped_plain_kernel<C, true> : gemm_grouped_plain_kernel<C, false>;
-    static bool attr_done[2] = {false, false};
-    if (!attr_done[any_bg ? 1 : 0] && C::LDS_BYTES > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-      if (e != hipSuccess) {
-        cfhip_set_error("gemm_grouped (plain): cannot reserve %d bytes of LDS: %s", C::LDS_BYTES, hipGetErrorString(e));
-        return CFHIP_ERR_LAUNCH;
-      }
-      attr_done[any_bg ? 1 : 0] = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(C::NT), C::LDS_BYTES, s, t);
-    CFHIP_CHECK_LAUNCH("gemm_grouped_plain");
-  }
-  return CFHIP_OK;
-}
-
-// gemm_grouped.hip: cfhip_gemm_bf16_grouped_tn with the option "grouped_kernel" = 1 (192x128x64 on four waves) / 2 (128x128x64);
-// the problems have passed that entry point's checks (M, N, lda, ldb multiples of 8, 16-byte aligned operands, < 2 GiB spans)
-int cfhip_internal_gemm_grouped_plain(const cfhip_gemm_problem* problems, int count, int kind, void* stream) {
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return kind == 2 ? launch_grouped_plain<CfgA>(problems, count, s) : launch_grouped_plain<CfgZ>(problems, count, s);
-}
 
 #ifdef CFHIP_ABLATE
 int cfhip_internal_set_attn_ablate(int v);  // attn.hip

@@ -320,7 +320,6 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) 
 
 int g_grouped_bias_shared = 1;  // 1: a tile row shares the bias-gradient reduction; 0: its first tile alone (round-3a behaviour)
 int g_grouped_short_fastest = 1;  // 1: tiles of a problem numbered with the shorter tile dimension fastest; 0: row-major
-int g_grouped_kernel = 0;  // 0: the 256x256x32 kernel of this file (160 KB of LDS); 1 / 2: gemm.hip's plain kernel on 192x128x64 / 128x128x64 tiles (80 / 64 KB)
 
 // Bias-gradient workspace: one per stream (launches on one stream run one after the other; a different stream gets its own
 // partial sums and counters), grown on demand.  Allocation is illegal inside a hipGraph capture: run one eager step first.
@@ -367,47 +366,19 @@ int bias_workspace(hipStream_t s, size_t floats, size_t counters, float** ws, in
 
 }  // namespace
 
-int cfhip_internal_gemm_grouped_plain(const cfhip_gemm_problem* problems, int count, int kind, void* stream);  // gemm.hip
-
 int cfhip_internal_set_grouped_variant(int v) {
-  // 0 .. 4: ring / DMA placement; +16: bias gradients by the first tile column alone; +32: row-major tile order (A/B runs);
-  // +64 / +128: the problems run on gemm.hip's plain kernel, 192x128x64 on four waves / 128x128x64 (80 / 64 KB of LDS: a
-  // weight-gradient workgroup shares its CU with a forward / dX workgroup)
+  // 0 .. 4: ring / DMA placement; +16: bias gradients by the first tile column alone; +32: row-major tile order (A/B runs)
+  // (+64 / +128 selected the 80 / 64 KB plain-tile forms of round 4: measured 1.0-1.6 ms slower per ViT step and flat on the UNet,
+  // removed in round 6 — profiles/r04/dw_plain_grouped_ab.log, profiles/r06/unet_variants_ab.txt)
   g_grouped_variant = v & 15;
   g_grouped_bias_shared = (v & 16) ? 0 : 1;
   g_grouped_short_fastest = (v & 32) ? 0 : 1;
-  g_grouped_kernel = (v & 64) ? 1 : (v & 128) ? 2 : 0;
   return CFHIP_OK;
 }
 
-static int grouped_tn(const cfhip_gemm_problem* problems, int count, int kernel, void* stream);
-
 extern "C" int cfhip_gemm_bf16_grouped_tn(const cfhip_gemm_problem* problems, int count, void* stream) {
-  return grouped_tn(problems, count, g_grouped_kernel, stream);
-}
-
-extern "C" int cfhip_gemm_bf16_grouped_tn_tiles(const cfhip_gemm_problem* problems, int count, int tile_kind, void* stream) {
-  CFHIP_REQUIRE(tile_kind >= 0 && tile_kind <= 2, "gemm_grouped: tile_kind %d (0: 256x256x32, 1: 192x128x64, 2: 128x128x64)", tile_kind);
-  return grouped_tn(problems, count, tile_kind, stream);
-}
-
-static int grouped_tn(const cfhip_gemm_problem* problems, int count, int kernel, void* stream) {
   CFHIP_REQUIRE(problems != nullptr && count > 0, "gemm_grouped: no problems");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (kernel != 0) {  // the 80 KB forms (gemm.hip: gemm_grouped_plain_kernel): same checks, other tiles
-    for (int i = 0; i < count; ++i) {
-      const cfhip_gemm_problem& src = problems[i];
-      CFHIP_REQUIRE(src.A && src.B && src.C, "gemm_grouped: null operand in problem %d", i);
-      CFHIP_REQUIRE(src.M > 0 && src.N > 0 && src.K > 0, "gemm_grouped: empty problem %d (M=%d N=%d K=%d)", i, src.M, src.N, src.K);
-      CFHIP_REQUIRE(src.M % 8 == 0 && src.N % 8 == 0 && src.lda % 8 == 0 && src.ldb % 8 == 0 && src.ldc % 4 == 0,
-                    "gemm_grouped: problem %d: M, N, lda, ldb must be multiples of 8 and ldc of 4 (M=%d N=%d lda=%ld ldb=%ld ldc=%ld)",
-                    i, src.M, src.N, (long)src.lda, (long)src.ldb, (long)src.ldc);
-      CFHIP_REQUIRE(al16(src.A) && al16(src.B) && al16(src.C), "gemm_grouped: problem %d: operands must be 16-byte aligned", i);
-      CFHIP_REQUIRE((long)src.K * src.lda * 2 < 0x7fffffffL && (long)src.K * src.ldb * 2 < 0x7fffffffL && (long)src.M * src.ldc * 4 < 0x7fffffffL,
-                    "gemm_grouped: problem %d exceeds the 2 GiB descriptor range (K=%d lda=%ld ldb=%ld)", i, src.K, (long)src.lda, (long)src.ldb);
-    }
-    return cfhip_internal_gemm_grouped_plain(problems, count, kernel, stream);
-  }
   for (int base = 0; base < count; base += GROUP_MAX) {
     const int n = count - base < GROUP_MAX ? count - base : GROUP_MAX;
     GroupedParams p;

@@ -197,7 +197,7 @@ class on_stream:
 
 
 # HIP stream priority per side lane (A/B knob: CFHIP_LANE_PRIORITY="0:-1,1:0"; negative = higher priority)
-LANE_PRIORITY = {int(k): int(v) for k, v in (kv.split(":") for kv in os.environ.get("CFHIP_LANE_PRIORITY", "").split(",") if kv)}
+LANE_PRIORITY: dict = {}  # lane -> HIP stream priority; measured flat (profiles/r05, tools/gpu/lane_priority_ab.sh): a variable for A/B scripts, no environment switch since round 6
 
 
 class SideStream:
@@ -1187,7 +1187,7 @@ IMPLICIT_CONV = True
 # bound by the queue, so the 35 us per layer cost nothing there and 1.65 ms per step here: 64^2 x 8 step 62.4 -> 61.8 ms
 # (three alternating pairs, profiles/r04/unet_pack_ahead_ab.txt; +1 GB of packed filters alive until backward).  1: on the
 # side lane beside the forward (fork + event per layer cost the host more than the queue gains: 62.3 vs 61.5).  0: in backward.
-PACK_AHEAD = int(os.environ.get("CFHIP_PACK_AHEAD", "2"))
+PACK_AHEAD = 2  # (A/B closed in round 4: profiles/r04/unet_pack_ahead_ab.txt; tests set the variable)
 
 
 def _implicit_ok(cin: int, cout: int, kh: int, kw: int, stride: int, pad: int, dil: int, h: int, w: int) -> bool:
@@ -1200,7 +1200,7 @@ def _implicit_ok(cin: int, cout: int, kh: int, kw: int, stride: int, pad: int, d
 # [B H W, 9 Cin] matrix (189 MB at 64^2 x 8 x 320) in the forward, again for the weight gradient, and once more as the gradient
 # matrix that row2im folds back; the padded implicit convolution reads the 21 MB activation.  32, not 8: the input-gradient
 # convolution takes dY as its input and wants a multiple of 32 channels there.
-THIN_HEAD_IMPLICIT = os.environ.get("CFHIP_CONV_THIN_HEAD", "1") != "0"
+THIN_HEAD_IMPLICIT = True  # (A/B closed in round 5: profiles/r05/conv_thin_head_ab.txt)
 THIN_HEAD_PAD = 32
 
 

@@ -72,7 +72,7 @@ DW_GROUP_TILES = 256
 # The LAST blocks of a backward pass (block indices below this) are flushed one by one: when the dX chain ends, what is left on
 # the weight-gradient lane is then one block's launch (108 tiles) instead of two blocks' (216) — nothing else is left to
 # share the chip with at that point, so the tail of the step is that launch's duration.
-DW_TAIL_BLOCKS = int(os.environ.get("CFHIP_DW_TAIL_BLOCKS", "0"))  # measured (profiles/r04/dw_tail_ab.txt): 1 .. 3 cost 0.3 ms per step — whole-reduction tiles on 108 of 256 CUs; kept as a knob
+DW_TAIL_BLOCKS = 0  # measured (profiles/r04/dw_tail_ab.txt): 1 .. 3 cost 0.3 ms per step — whole-reduction tiles on 108 of 256 CUs; kept as a knob
 DW_GROUP_ON_MAIN = False  # True: the grouped launch runs on the caller's stream (after the blocks' dX chain) instead of the side stream
 _pending_dw: list = []
 _slice_streams: list = []  # streams of the backward's batch slices beyond the caller's (what a dW launch has to wait for)
@@ -82,13 +82,8 @@ _slice_streams: list = []  # streams of the backward's batch slices beyond the c
 # patch embedding) queue their weight gradients here too: flushed when LINEAR_DW_TILES tiles are waiting, together with the next
 # block-stack flush, or when the backward pass ends.  A flush of fewer than DW_MIN_TILES tiles falls back to one split-K GEMM
 # per gradient (whole-reduction 256 x 256 tiles on a handful of CUs would take longer than 128 x 128 split-K tiles on all).
-LINEAR_DW_TILES = int(os.environ.get("CFHIP_LINEAR_DW_TILES", "0"))  # (env: A/B runs)  0: LinearFn computes its weight gradient on the spot (round-1/2 behaviour)
-DW_MIN_TILES = int(os.environ.get("CFHIP_DW_MIN_TILES", "48"))
-# Round 4: the tile form of a flush that holds stand-alone Linear gradients only (ops.GROUPED_TILE_SHAPES: 0 = 256 x 256 on a
-# whole CU, 1 = 192 x 128 x 64, 2 = 128 x 128 x 64 — two workgroups per CU, for the UNet's many 9-60-tile projections); the
-# two thresholds above then count tiles of THAT shape.
-LINEAR_DW_KERNEL = int(os.environ.get("CFHIP_LINEAR_DW_KERNEL", "0"))
-_linear_items: set = set()  # id() of the queued weights that came through queue_linear_dw
+LINEAR_DW_TILES = 0  # (A/B closed: flat in rounds 3, 4 and 6 — profiles/r06/unet_variants_ab.txt; tools set the variable)  0: LinearFn computes its weight gradient on the spot (round-1/2 behaviour)
+DW_MIN_TILES = 48
 GROUP_MAX = 24  # problems per launch (gemm_grouped.hip: the by-value problem table)
 _end_flush_queued = False
 
@@ -107,7 +102,7 @@ def _groupable(w: Tensor, dy2: Tensor, x2: Tensor) -> bool:
 # reduce on the weight-gradient lane, beside the dX chain) instead of queueing them: the grouped launch of the final blocks
 # can only start when the chain has ended, and its ~0.9 ms are the tail of the step.  Measured (tools/step_variants.py
 # "weight gradients per operator (DW_PEROP"): 1 block +0.29 ms, 2 blocks +0.41 ms — the grouped launch stays; kept as a knob.
-DW_PEROP_TAIL = int(os.environ.get("CFHIP_DW_PEROP_TAIL", "0"))
+DW_PEROP_TAIL = 0
 _perop_now = False
 
 
@@ -138,7 +133,6 @@ def queue_linear_dw(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> 
             return False
         _end_flush_queued = True
     _pending_dw.append((w, b, dy2, x2))
-    _linear_items.add(id(w))
     if _pending_tiles() >= LINEAR_DW_TILES:
         _flush_dw(tuple(_slice_streams))
     return True
@@ -160,20 +154,12 @@ def _flush_deferred() -> None:
 _functional.deferred_grad_flushes.append(_flush_deferred)
 
 
-def _tile_kind(items: list) -> int:
-    """tile form of one launch for these queued gradients: LINEAR_DW_KERNEL when all of them are stand-alone Linear layers"""
-    if LINEAR_DW_KERNEL and items and all(id(it[0]) in _linear_items for it in items):
-        return LINEAR_DW_KERNEL
-    return 0
-
-
 def _tiles_of(items: list) -> int:
-    bm, bn = ops.GROUPED_TILE_SHAPES[_tile_kind(items)]
-    return sum(((dy2.shape[1] + bm - 1) // bm) * ((x2.shape[1] + bn - 1) // bn) for _, _, dy2, x2 in items)
+    return sum(((dy2.shape[1] + 255) // 256) * ((x2.shape[1] + 255) // 256) for _, _, dy2, x2 in items)
 
 
 def _pending_tiles() -> int:
-    """output tiles of the queued weight gradients (256 x 256, or the LINEAR_DW_KERNEL form)"""
+    """256 x 256 output tiles of the queued weight gradients"""
     return _tiles_of(_pending_dw)
 
 
@@ -186,9 +172,7 @@ def _flush_dw(wait: tuple = ()) -> None:
         return
     items = list(_pending_dw)
     _pending_dw.clear()
-    kind = _tile_kind(items)
     few = _tiles_of(items) < DW_MIN_TILES
-    _linear_items.clear()
     if few:  # too few tiles for one-tile-per-CU whole reductions: split-K GEMMs
         for w, b, dy2, x2 in items:
             SideStream.run(lambda w=w, b=b, dy2=dy2, x2=x2: _dw_db(w, b, dy2, x2), (dy2, x2), wait=wait)
@@ -219,7 +203,7 @@ def _flush_dw(wait: tuple = ()) -> None:
                 for prm in prms:
                     prm._cfhip_fresh = False
                 done.extend(prms)
-            ops.gemm_grouped_tn(probs, tiles=kind if kind else None)
+            ops.gemm_grouped_tn(probs)
             for prm in done:
                 _functional.notify_grad_ready(prm)
 
@@ -234,7 +218,7 @@ def _flush_dw(wait: tuple = ()) -> None:
 # Round 4: the column reduce of the LayerNorm parameter gradients (13 us in the step, twice per block and batch slice: 0.35 ms
 # of each slice's dX chain) runs on the weight-gradient lane instead: only the optimizer needs its result.  The row kernels of
 # the two batch slices then write separate partial buffers and no longer wait for each other.
-LN_REDUCE_ASIDE = os.environ.get("CFHIP_LN_REDUCE_ASIDE", "1") != "0"
+LN_REDUCE_ASIDE = True
 SPLIT_LN_BWD = False  # round 2: ONE launch (half-wave-per-row kernel, dy and x read once) beats dx on the main stream + dgamma/dbeta on the side stream by 0.5 ms / step (profiles/r02/step_ab_ln_b128.log)
 
 
@@ -908,7 +892,6 @@ class MixingStackFn(Function):
                 d2 = ops.join_bf16x2(d2[0], d2[1])
         except BaseException:
             _pending_dw.clear()  #  nothing queued by a failed pass may be flushed into `.grad` by the next one
-            _linear_items.clear()
             raise
         finally:
             _slice_streams[:] = []

@@ -1825,7 +1825,7 @@ class MultiHeadSpatialAttention(Module):
 # ---------------------------------------------------------------------------------------------
 
 
-FUSE_SELF_ATTENTION_QKV = os.environ.get("CFHIP_FUSE_QKV", "1") != "0"  # CrossAttention without a context: to_q | to_k | to_v as one GEMM when their weights are adjacent
+FUSE_SELF_ATTENTION_QKV = True  # CrossAttention without a context: to_q | to_k | to_v as one GEMM when their weights are adjacent
 
 
 class CrossAttention(Module):

@@ -60,7 +60,7 @@ def set_option(name: str, value: int) -> None:
 # ---------------------------------------------------------------------------------------------
 
 
-FORCE_SPLIT_K = int(os.environ.get("CFHIP_FORCE_SPLIT_K", "0"))  # A/B runs: > 0 = every weight-gradient GEMM takes this split
+FORCE_SPLIT_K = 0  # A/B runs: > 0 = every weight-gradient GEMM takes this split
 
 
 def pick_split_k(m: int, n: int, k: int) -> int:
@@ -196,12 +196,8 @@ def gemm(
     return out
 
 
-GROUPED_TILE_SHAPES = {0: (256, 256), 1: (192, 128), 2: (128, 128)}  # tile_kind of cfhip_gemm_bf16_grouped_tn_tiles -> output tile
-
-
-def gemm_grouped_tn(problems: list, tiles: Optional[int] = None) -> None:
-    """Weight gradients of several Linear layers in ONE launch (cfhip_gemm_bf16_grouped_tn; `tiles` = 0 / 1 / 2: the tile
-    form of cfhip_gemm_bf16_grouped_tn_tiles — 256 x 256 on a whole CU, or the 80 / 64 KB forms for many small problems).
+def gemm_grouped_tn(problems: list) -> None:
+    """Weight gradients of several Linear layers in ONE launch (cfhip_gemm_bf16_grouped_tn).
 
     `problems`: list of (dy [K, M] bf16, x [K, N] bf16, out [M, N] f32, accumulate, bias_grad f32 [M] or None,
     bias_grad_accumulate): out (+)= dy^T x, bias_grad (+)= colsum(dy).  256 x 256 tiles of all problems share the chip and
@@ -238,10 +234,7 @@ def gemm_grouped_tn(problems: list, tiles: Optional[int] = None) -> None:
         # the operand addresses of this launch live in a host table, not in the argument tuple: a launch plan that moves its
         # input (fused.StackPlan.repoint) must be able to find and rewrite them — kind-3 entry = the table
         _lib.RECORDER.append((3, arr, len(problems)))
-    if tiles is None:
-        rc = _lib.load().cfhip_gemm_bf16_grouped_tn(ctypes.cast(arr, ctypes.c_void_p), len(problems), _stream())
-    else:
-        rc = _lib.load().cfhip_gemm_bf16_grouped_tn_tiles(ctypes.cast(arr, ctypes.c_void_p), len(problems), int(tiles), _stream())
+    rc = _lib.load().cfhip_gemm_bf16_grouped_tn(ctypes.cast(arr, ctypes.c_void_p), len(problems), _stream())
     _lib.check(rc, "gemm_grouped_tn")
     if timer is not None:
         e1.record()
@@ -985,8 +978,8 @@ def _gn_affine_stride(gamma: Tensor, beta: Tensor, b: int, c: int) -> int:
     raise ValueError(f"cfhip groupnorm: gamma must be [C] or [B, C], got {tuple(gamma.shape)}")
 
 
-GN_TARGET_WORKGROUPS = int(os.environ.get("CFHIP_GN_TARGET", "1024"))  # four 4-wave workgroups per CU; 0: never split
-GN_MIN_SLICE = int(os.environ.get("CFHIP_GN_MIN_SLICE", "2048"))  # elements of `inner` per slice and channel below which splitting stops paying
+GN_TARGET_WORKGROUPS = 1024  # four 4-wave workgroups per CU; 0: never split
+GN_MIN_SLICE = 2048  # elements of `inner` per slice and channel below which splitting stops paying
 
 
 def gn_splits(b: int, c: int, groups: int, inner: int) -> int:
@@ -998,12 +991,12 @@ def gn_splits(b: int, c: int, groups: int, inner: int) -> int:
     return max(1, min(64, want, inner // GN_MIN_SLICE))
 
 
-GN_NHWC_TARGET_WORKGROUPS = int(os.environ.get("CFHIP_GN_NHWC_TARGET", "1024"))
-GN_NHWC_MIN_ROWS = int(os.environ.get("CFHIP_GN_NHWC_MIN_ROWS", "16"))
+GN_NHWC_TARGET_WORKGROUPS = 1024
+GN_NHWC_MIN_ROWS = 16
 
 
-GN_NHWC_GROUP_MAX_ROWS = int(os.environ.get("CFHIP_GN_NHWC_GROUP_MAX_ROWS", "48"))  # rows per thread up to which the group form is used
-GN_NHWC_GROUP_MIN_WORKGROUPS = int(os.environ.get("CFHIP_GN_NHWC_GROUP_MIN", "128"))  # B * G from which one workgroup per (sample, group) fills the chip
+GN_NHWC_GROUP_MAX_ROWS = 48  # rows per thread up to which the group form is used
+GN_NHWC_GROUP_MIN_WORKGROUPS = 128  # B * G from which one workgroup per (sample, group) fills the chip
 
 
 def gn_nhwc_splits(b: int, inner: int, c: int = 0, groups: int = 0, backward: bool = False) -> int:

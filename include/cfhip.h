@@ -63,7 +63,6 @@ const char* cfhip_last_error(void);
  *   "grouped_variant" ring of cfhip_gemm_bf16_grouped_tn: 0 (default) 5 slots, DMA 3 K-steps ahead; 1: 4 slots, 2 ahead;
  *                     2: 5 slots, 2 ahead; 3 / 4: DMA placement variants of 0.  +16: bias gradients reduced by the first tile
  *                     column alone instead of shared by the tile row; +32: row-major tile order (both: A/B runs);
- *                     +64 / +128: tile form 1 / 2 of cfhip_gemm_bf16_grouped_tn_tiles for every grouped launch (A/B runs)
  * Unknown names are an error.  (The phase-timing ablation masks "gemm_ablate" / "attn_ablate" of round 1 are
  * not part of this library any more: they exist only in the -DCFHIP_ABLATE build that tools/build_variant.sh
  * writes to tools/libcfhip_ablate.so, selected by the tools through CFHIP_LIB.) */
@@ -134,12 +133,6 @@ typedef struct cfhip_gemm_problem {
   int bias_grad_accumulate;  /* bias_grad += */
 } cfhip_gemm_problem;
 int cfhip_gemm_bf16_grouped_tn(const cfhip_gemm_problem* problems, int count, void* stream);
-/* The same launch with the tile form chosen by the caller instead of the "grouped_variant" option:
- *   0  256 x 256 x 32, 160 KB of LDS — one workgroup owns a CU; the most FLOPs per CU-second, what the ViT block stack uses;
- *   1  192 x 128 x 64 on four waves, 80 KB;   2  128 x 128 x 64, 64 KB — cfhip_gemm_bf16's plain kernel, two workgroups per CU,
- *      for MANY SMALL problems (the UNet's ~10 projections per transformer block: 9-60 tiles each) whose 256 x 256 tiles would
- *      leave most CUs idle.  Every tile still runs its whole reduction; the bias gradient is summed by the first tile column. */
-int cfhip_gemm_bf16_grouped_tn_tiles(const cfhip_gemm_problem* problems, int count, int tile_kind, void* stream);
 
 /* column sums of a bf16 matrix: out[n] (f32) (+)= sum_m X[m*ldx + n]   (bias gradients)
  * workspace: >= cfhip_colsum_workspace(M, N) bytes. */

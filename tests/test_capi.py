@@ -115,7 +115,7 @@ def test_vectorcall_entry_module_is_the_same_library():
     slow_names = [n for n in _lib.SIGNATURES if n not in lib.__dict__]
     assert "cfhip_gemm_bf16" in fast_names and "cfhip_adam_step_dev" in fast_names and "cfhip_attn_fwd_dh" in fast_names
     assert all(n.startswith("cfhip_comm_") or n in ("cfhip_version", "cfhip_last_error", "cfhip_set_option", "cfhip_gemm_kernel_name",
-                                                     "cfhip_gemm_bf16_grouped_tn", "cfhip_gemm_bf16_grouped_tn_tiles",
+                                                     "cfhip_gemm_bf16_grouped_tn",
                                                      "cfhip_layernorm_bwd_partials", "cfhip_layernorm_bwd2") for n in slow_names), slow_names
     args = (None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1, None, 0, None, 0, None)
     assert lib.cfhip_gemm_bf16(*args) == cdll.cfhip_gemm_bf16(*args) == -1 and b"null" in lib.cfhip_last_error()

@@ -495,23 +495,10 @@ def test_round4_host_rules(tmp_path):
     from cflearn_amd import fused, ops
 
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # weight-gradient queue: 256 x 256 tiles by default, the chosen form's tiles when every queued item is a stand-alone Linear
+    # weight-gradient queue: counted in 256 x 256 output tiles
     dy, x = torch.empty(10, 768), torch.empty(10, 3072)
     w = torch.empty(768, 3072)
-    items = [(w, None, dy, x)]
-    assert fused._tile_kind(items) == 0 and fused._tiles_of(items) == 3 * 12
-    keep = fused.LINEAR_DW_KERNEL
-    try:
-        fused.LINEAR_DW_KERNEL = 2
-        fused._linear_items.add(id(w))
-        assert fused._tile_kind(items) == 2 and fused._tiles_of(items) == 6 * 24  # 128 x 128 tiles
-        fused.LINEAR_DW_KERNEL = 1
-        assert fused._tiles_of(items) == 4 * 24                                    # 192 x 128 tiles
-        assert fused._tile_kind(items + [(torch.empty(8, 8), None, dy, x)]) == 0    # mixed with a block-stack item: the whole-CU form
-    finally:
-        fused.LINEAR_DW_KERNEL = keep
-        fused._linear_items.clear()
-    assert ops.GROUPED_TILE_SHAPES == {0: (256, 256), 1: (192, 128), 2: (128, 128)}
+    assert fused._tiles_of([(w, None, dy, x)]) == 3 * 12
 
     # plan key: state + where parameters and gradients live
     p1, p2 = torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(4))

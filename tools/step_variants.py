@@ -94,13 +94,6 @@ VARIANTS = {
     "attention fwd + dK/dV persistent (attn_persistent 5)": (lambda: (setv(2)(), ops.set_option("attn_persistent", 5))),
     "grouped ring variant 1 (4 slots = 128 KB: 32 KB of LDS left per CU)": setv(2, variant=1),
     "grouped ring variant 2 (5 slots, DMA 2 ahead)": setv(2, variant=2),
-    "plain grouped dW 192x128x64, 1 block / launch": setv(1, variant=64),
-    "plain grouped dW 192x128x64, 2 blocks / launch": setv(2, variant=64),
-    "plain grouped dW 192x128x64, 3 blocks / launch": setv(3, variant=64),
-    "plain grouped dW 192x128x64, 4 blocks / launch": setv(4, variant=64),
-    "plain grouped dW 192x128x64, 6 blocks / launch": setv(6, variant=64),
-    "plain grouped dW 128x128x64, 2 blocks / launch": setv(2, variant=128),
-    "plain grouped dW 128x128x64, 4 blocks / launch": setv(4, variant=128),
     "per-op dW, whole reduction, tn=c15 (192x128x64, 4 waves)": setv(0, tn=15, split=1),
     "per-op dW, whole reduction, tn=c14 (192x128x64, 8 waves)": setv(0, tn=14, split=1),
     "per-op dW, whole reduction, tn=c0 (128x128x64)": setv(0, tn=0, split=1),
