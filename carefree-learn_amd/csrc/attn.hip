@@ -156,6 +156,19 @@ __device__ __forceinline__ void store_row64(bf16_t* row, const f32x4 (&t)[4], fl
   }
 }
 
+// the same for ONE pair of 16-column tiles (2 pr, 2 pr + 1) of the row: one 16-byte store per lane
+__device__ __forceinline__ void store_row32(bf16_t* row, const f32x4& ta, const f32x4& tb, float mul, int g, bool valid, int pr) {
+  const f32x4 a = ta * mul, b = tb * mul;
+  const unsigned a0 = pack_bf16x2(a[0], a[1]), a1 = pack_bf16x2(a[2], a[3]);
+  const unsigned b0 = pack_bf16x2(b[0], b[1]), b1 = pack_bf16x2(b[2], b[3]);
+  const bool odd = (g & 1) != 0;
+  const unsigned r0 = (unsigned)__shfl_xor((int)(odd ? a0 : b0), 16, 64);
+  const unsigned r1 = (unsigned)__shfl_xor((int)(odd ? a1 : b1), 16, 64);
+  const u32x4 w = odd ? u32x4{r0, r1, b0, b1} : u32x4{a0, a1, r0, r1};
+  const int col = (2 * pr + (odd ? 1 : 0)) * 16 + 4 * (g & 2);
+  if (valid) *reinterpret_cast<u32x4*>(row + col) = w;
+}
+
 __device__ __forceinline__ bool keep_at(const AttnParams& p, int b, int h, int i, int j) {
   if (j >= p.Tk) return false;
   if (p.causal && j > i) return false;
@@ -805,6 +818,179 @@ __global__ __launch_bounds__(PERS_WAVES * 64, 4) void attn_bwd_dq_pers_kernel(At
     lds_dma_wait_all();
     __syncthreads();  // the next head's K / V have landed (vmcnt 0) and nobody reads this head's buffer any more
     cur ^= 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ONE-PASS backward for the ViT shape (round 6; PLAIN, self-attention, 128 < T <= 224, head_dim 64): dQ, dK and dV of a head from
+// ONE evaluation of S and dP.  The two-pass form above recomputes S = Q K^T and dP = dO V^T in both passes (2 548 MFMAs per head at
+// T = 197); the energy table of round 6 ranks attention first in joules per FLOP (2.4-2.9 J/TFLOP against 1.04-1.16 for the GEMMs,
+// profiles/r06/energy_table.txt), which is what decided that this experiment gets built.
+//   * a 16-wave workgroup owns a CU and walks (batch, head) pairs; Q, dO and K of the head sit in LDS (K / V fragments of a wave's own
+//     key tile come from global memory into registers, as in the persistent dK / dV kernel);
+//   * phase 1 (waves own KEY tiles): for every query tile of the current half — S, P = exp2(S - lse), dP, dS = P (dP - delta);
+//     dV += P^T dO and dK += dS^T Q accumulate in registers over both halves; dS (bf16, the rounding the MFMAs of both passes of the
+//     two-pass form use) goes to an LDS buffer [query][key];
+//   * barrier; phase 2 (waves own (QUERY tile, half of the 64 columns)): dQ = dS K with the whole key range as the reduction, the
+//     dS operand read back from LDS in exactly the k-slot order a packed register operand has; barrier;
+//   * queries in two halves so that Q + dO + K + dS + statistics fit 160 KB (T <= 224: 147 KB); delta = rowsum(dO o O) is computed in
+//     the prologue (four lanes per row) and also written to p.delta for callers that read it.
+// 1 716 MFMAs per head (-33 %), one launch instead of two; what it gives up: the next head's operands no longer stream in behind
+// the current head (the LDS is full), and two more barriers per head.
+// ------------------------------------------------------------------------------------------------
+template <int NB, int PW>  // NB pairs of 16-row tiles (T <= 32 NB); PW waves per workgroup (>= 2 NB key tiles, >= 4 ceil(NB / 2) phase-2 items)
+__global__ __launch_bounds__(PW * 64, 4) void attn_bwd_one_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWS = NB * 32, TILE = ROWS * 128;
+  constexpr int HA = (NB + 1) / 2;          // query pair-tiles per half
+  constexpr int DSROW = ROWS * 2 + 16;      // bytes per dS row (ROWS keys, bf16) + 16: rows 4 apart start 16 banks apart
+  static_assert(3 * TILE + 2 * ROWS * 4 + HA * 32 * DSROW <= 160 * 1024, "Q + dO + K + statistics + dS must fit the LDS");
+  static_assert(2 * NB <= PW && 4 * HA <= PW && ROWS * 4 <= PW * 64, "a wave per key tile; a wave per (query tile, column half); four lanes per row");
+  char* Qs = smem;
+  char* dOs = Qs + TILE;
+  char* Ks = dOs + TILE;
+  float* lse_s = reinterpret_cast<float*>(Ks + TILE);
+  float* delta_s = lse_s + ROWS;
+  char* dSs = reinterpret_cast<char*>(delta_s + ROWS);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int heads = p.B * p.H;
+  const float sl2 = p.scale * LOG2E;
+  const int row0 = wave * 16;  // phase 1: this wave's key tile
+  const int qt = wave >> 1, ch = wave & 1;  // phase 2: query tile of the half, column half
+
+  // Q and dO of head `hx` into the LDS (DMA: no registers) ...
+  auto stage_q = [&](int hx) {
+    const int b = hx / p.H, h = hx - b * p.H;
+    dma_tile(Qs, p.q + (long)b * p.q_sb + h * DH, p.q_st, p.Tq, ROWS, wave, PW, lane);
+    dma_tile(dOs, p.d_o + (long)b * p.o_sb + h * DH, p.o_st, p.Tq, ROWS, wave, PW, lane);
+  };
+  // ... and its statistics (log-sum-exp in the log2 domain, delta = rowsum(dO o O)): four lanes per row, 16 columns each
+  auto stage_stats = [&](int hx) {
+    const int b = hx / p.H, h = hx - b * p.H;
+    const bf16_t* dob = p.d_o + (long)b * p.o_sb + h * DH;
+    const bf16_t* ob = p.o_in + (long)b * p.o_sb + h * DH;
+    const int t = (int)threadIdx.x >> 2, part = (int)threadIdx.x & 3;
+    float sacc = 0.f;
+    if (t < p.Tq) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dob + (long)t * p.o_st + part * 16 + j * 8);
+        const bf16x8 c = *reinterpret_cast<const bf16x8*>(ob + (long)t * p.o_st + part * 16 + j * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sacc += bf16_to_f32((bf16_t)a[e]) * bf16_to_f32((bf16_t)c[e]);
+      }
+    }
+    sacc += __shfl_xor(sacc, 1, 64);
+    sacc += __shfl_xor(sacc, 2, 64);
+    if (part == 0 && t < ROWS) {
+      const bool ok = t < p.Tq;
+      lse_s[t] = ok ? p.lse[(long)hx * p.Tq + t] * LOG2E : INFINITY;  // +inf -> p = 0 for padded query rows
+      delta_s[t] = ok ? sacc : 0.f;
+      if (ok && p.delta != nullptr) p.delta[(long)hx * p.Tq + t] = sacc;
+    }
+  };
+  auto stage_k = [&](int hx) {
+    const int b = hx / p.H, h = hx - b * p.H;
+    dma_tile(Ks, p.k + (long)b * p.kv_sb + h * DH, p.kv_st, p.Tk, ROWS, wave, PW, lane);
+  };
+
+  int hh = blockIdx.x;
+  if (hh < heads) {
+    stage_q(hh);
+    stage_k(hh);
+    stage_stats(hh);
+  }
+  for (; hh < heads; hh += gridDim.x) {
+    const int b = hh / p.H, h = hh - b * p.H;
+    const bf16_t* kb = p.k + (long)b * p.kv_sb + h * DH;
+    const bf16_t* vb = p.v + (long)b * p.kv_sb + h * DH;
+    // this wave's key tile: K / V fragments in registers (rows beyond Tk are zero)
+    const bf16x8 kf0 = frag_global(kb, p.kv_st, row0, p.Tk, 0, lane);
+    const bf16x8 kf1 = frag_global(kb, p.kv_st, row0, p.Tk, 1, lane);
+    const bf16x8 vf0 = frag_global(vb, p.kv_st, row0, p.Tk, 0, lane);
+    const bf16x8 vf1 = frag_global(vb, p.kv_st, row0, p.Tk, 1, lane);
+    lds_dma_wait_all();
+    __syncthreads();
+    const int nxt = hh + gridDim.x;
+
+    f32x4 dkt[4], dvt[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dkt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+    for (int hf = 0; hf < 2; ++hf) {
+      const int a0 = hf * HA, a1 = hf == 0 ? HA : NB;
+      // ---- phase 1: key tile x the query tiles of this half
+      if (row0 < ROWS) {
+        for (int a = a0; a < a1; ++a) {
+          f32x4 pp[2], ds[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int it = 2 * a + t;
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs, it * 16, 0, lane), kf0, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs, it * 16, 1, lane), kf1, sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dOs, it * 16, 0, lane), vf0, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dOs, it * 16, 1, lane), vf1, dp, 0, 0, 0);
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + it * 16 + 4 * g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + it * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pr = __builtin_amdgcn_exp2f(sc[r] * sl2 - l4[r]);
+              pp[t][r] = pr;
+              ds[t][r] = pr * (dp[r] - d4[r]);
+            }
+          }
+          const bf16x8 ppk = pack8(pp[0], pp[1]);
+          const bf16x8 dsk = pack8(ds[0], ds[1]);
+          // dS[query 16 (2a + t) + 4g + r][key row0 + n] -> LDS [query][key]
+          {
+            char* col = dSs + (row0 + n) * 2;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<short*>(col + ((2 * (a - a0) + t) * 16 + 4 * g + r) * DSROW) = dsk[4 * t + r];
+          }
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(dOs, a * 32, dt * 16, lane), ppk, dvt[dt], 0, 0, 0);
+            dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Qs, a * 32, dt * 16, lane), dsk, dkt[dt], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+      // Q and dO of this head are done with after the second half's phase 1: the NEXT head's stream in behind the last dQ phase
+      // (which reads K and dS only); its statistics follow at the end of the head, when the dK / dV accumulators are dead
+      if (hf == 1 && nxt < heads) stage_q(nxt);
+      // ---- phase 2: dQ of the query tiles of this half, 32 columns per wave, reduction over every key
+      if (qt < 2 * (a1 - a0)) {
+        f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+        const char* drow = dSs + (qt * 16 + n) * DSROW + 8 * g;
+#pragma unroll 1
+        for (int a = 0; a < NB; ++a) {
+          const s16x4 lo = *reinterpret_cast<const s16x4*>(drow + a * 64);
+          const s16x4 hi = *reinterpret_cast<const s16x4*>(drow + a * 64 + 32);
+          bf16x8 dsp;
+          dsp[0] = lo[0]; dsp[1] = lo[1]; dsp[2] = lo[2]; dsp[3] = lo[3];
+          dsp[4] = hi[0]; dsp[5] = hi[1]; dsp[6] = hi[2]; dsp[7] = hi[3];
+          dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Ks, a * 32, (2 * ch) * 16, lane), dsp, dq0, 0, 0, 0);
+          dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Ks, a * 32, (2 * ch + 1) * 16, lane), dsp, dq1, 0, 0, 0);
+        }
+        const int qi = (2 * a0 + qt) * 16 + n;
+        store_row32(p.dq + (long)b * p.q_sb + (long)qi * p.q_st + h * DH, dq0, dq1, p.scale, g, qi < p.Tq, ch);
+      }
+      __syncthreads();  // the dS buffer (and, after the second half, K) may be overwritten
+    }
+    if (nxt < heads) stage_k(nxt);
+    {
+      const int kj = row0 + n;
+      const bool valid = kj < p.Tk;
+      store_row64(p.dk + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH, dkt, p.scale, g, valid);
+      store_row64(p.dv + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH, dvt, 1.0f, g, valid);
+    }
+    if (nxt < heads) stage_stats(nxt);
   }
 }
 
@@ -1940,6 +2126,7 @@ bool set_dropout(AttnParams& p, float dropout_p, uint64_t seed, uint64_t offset)
 }
 
 int g_attn_pers_ctas = 256;  // workgroups of a persistent launch (one per CU; fewer leave CUs to the other queues)
+int g_attn_one_pass = 1;  // option "attn_one_pass": 1 (default, round 6) = attn_bwd_one_kernel when both passes are asked for in one call (PLAIN, self-attention, 32 < T <= 224); 0: the two-pass kernels
 int g_attn_persistent = 7;  // bit 0: dK / dV pass, bit 1: dQ pass, bit 2: forward — as persistent 16-wave workgroups when 128 < T <= 256 (the ViT shape)
 
 int check_head_dim(const char* who, int head_dim) {
@@ -1965,6 +2152,10 @@ int cfhip_internal_set_attn_pers_ctas(int v) {
   return CFHIP_OK;
 }
 
+int cfhip_internal_set_attn_one_pass(int v) {
+  g_attn_one_pass = v;
+  return CFHIP_OK;
+}
 int cfhip_internal_set_attn_persistent(int v) {
   g_attn_persistent = v;
   return CFHIP_OK;
@@ -2123,6 +2314,29 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
       case 2: return launch_gen_bwd<2>(p, plain, parts, s);
       default: return launch_gen_bwd<3>(p, plain, parts, s);
     }
+  }
+  if ((parts & 3) == 3 && plain && g_attn_one_pass && Tq == Tk && Tq > 32 && Tq <= 224 && o != nullptr) {
+    // dQ, dK and dV of a head from one evaluation of S and dP (attn_bwd_one_kernel): 16-wave workgroups, one per CU, for the ViT
+    // lengths; 4 / 8 waves and several workgroups per CU for the short sequences (ViT-B/32 in CLIP: T = 50)
+    const int nb = (Tq + 31) / 32;
+    const int heads = B * H;
+#define CFHIP_ONE_PASS(NB_, PW_, PER_CU_)                                                                                        \
+  case NB_: {                                                                                                                    \
+    const size_t lds1 = (size_t)3 * NB_ * 32 * 128 + (size_t)2 * NB_ * 32 * 4 + (size_t)((NB_ + 1) / 2) * 32 * (NB_ * 64 + 16); \
+    const int ctas = g_attn_pers_ctas * PER_CU_;                                                                                 \
+    rc = set_lds(attn_bwd_one_kernel<NB_, PW_>, lds1, "attn_bwd_one");                                                           \
+    if (rc != CFHIP_OK) return rc;                                                                                               \
+    hipLaunchKernelGGL((attn_bwd_one_kernel<NB_, PW_>), dim3(heads < ctas ? heads : ctas), dim3(PW_ * 64), lds1, s, p);          \
+    break;                                                                                                                       \
+  }
+    switch (nb) {
+      CFHIP_ONE_PASS(2, 4, 4) CFHIP_ONE_PASS(3, 8, 2) CFHIP_ONE_PASS(4, 8, 2)
+      CFHIP_ONE_PASS(5, 16, 1) CFHIP_ONE_PASS(6, 16, 1) CFHIP_ONE_PASS(7, 16, 1)
+      default: cfhip_set_error("attn_bwd: bad nb %d", nb); return CFHIP_ERR_INVALID;
+    }
+#undef CFHIP_ONE_PASS
+    CFHIP_CHECK_LAUNCH("attn_bwd(one pass)");
+    return CFHIP_OK;
   }
   if ((parts & 1) && plain && (g_attn_persistent & 2) && Tq > 128 && Tq <= PERS_WAVES * 16 && Tk > 128 && Tk <= 256) {
     const int nb = (Tk + 31) / 32;

@@ -678,6 +678,7 @@ int cfhip_internal_set_attn_ablate(int v);  // attn.hip
 #endif
 int cfhip_internal_set_ln_fused(int v);  // norm.hip
 int cfhip_internal_set_attn_persistent(int v);  // attn.hip
+int cfhip_internal_set_attn_one_pass(int v);  // attn.hip
 int cfhip_internal_set_attn_pers_ctas(int v);  // attn.hip
 int cfhip_internal_set_grouped_variant(int v);  // gemm_grouped.hip
 int cfhip_internal_set_attn_two_tiles(int v);  // attn.hip
@@ -704,6 +705,7 @@ extern "C" int cfhip_set_option(const char* name, int value) {
   }
   if (name != nullptr && strcmp(name, "ln_bwd_fused") == 0) return cfhip_internal_set_ln_fused(value);
   if (name != nullptr && strcmp(name, "attn_persistent") == 0) return cfhip_internal_set_attn_persistent(value);
+  if (name != nullptr && strcmp(name, "attn_one_pass") == 0) return cfhip_internal_set_attn_one_pass(value);
   if (name != nullptr && strcmp(name, "attn_pers_ctas") == 0) return cfhip_internal_set_attn_pers_ctas(value);
   if (name != nullptr && strcmp(name, "grouped_variant") == 0) return cfhip_internal_set_grouped_variant(value);
   if (name != nullptr && strcmp(name, "attn_two_tiles") == 0) return cfhip_internal_set_attn_two_tiles(value);

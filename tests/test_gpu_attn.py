@@ -555,3 +555,38 @@ def test_persistent_forward_is_bit_identical_to_the_one_shot_kernel(b, t, h):
     if b <= 3:
         want_o, _ = _oracle(qkv.cpu(), h)
         assert_close(outs[1][0], want_o, 1e-2, "persistent forward vs the oracle")
+
+
+@pytest.mark.parametrize("b,t,h", [(2, 197, 12), (1, 129, 3), (3, 160, 2), (2, 224, 4), (70, 197, 12), (3, 50, 12), (2, 33, 2), (2, 77, 8), (2, 96, 3),
+                                   (2, 128, 2), (100, 50, 12)])
+def test_one_pass_backward_matches_the_two_pass_kernels_and_the_oracle(b, t, h):
+    """`attn_bwd_one_kernel` (round 6, option "attn_one_pass"): dQ, dK, dV of a head from ONE evaluation of S and dP (the dS tile goes
+    through LDS once, in the bf16 rounding both passes of the two-pass form use) — against the two-pass kernels (same operands, same
+    roundings: agreement to a few bf16 ulps of the accumulated sums) and, for the small cases, against fp32 math; `delta` is written
+    as by the dQ pass; ragged last tiles (197 = 12 x 16 + 5), the largest supported length (224), and more heads than one round of
+    persistent workgroups (70 x 12 = 840 heads on 256 workgroups: the walk over heads, the next head's Q / dO streaming in behind the
+    last dQ phase); the short forms on 4 / 8 waves (T = 50: ViT-B/32 in CLIP; 33 .. 128)."""
+    qkv = _qkv(b, t, h, 300 + t, scale=1.5).to(DEV)
+    d = h * 64
+    d_o = torch.randn(b, t, d, generator=torch.Generator().manual_seed(t + 1)).to(torch.bfloat16).to(DEV)
+    q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    o, lse = ops.attn_fwd(q, k, v, h)
+    outs = []
+    for one in (0, 1, 1):
+        ops.set_option("attn_one_pass", one)
+        try:
+            dqkv = torch.zeros_like(qkv)
+            delta = torch.zeros(b, h, t, device=DEV)
+            ops.attn_bwd(q, k, v, o, d_o, lse, h, dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], delta=delta)
+            outs.append((dqkv, delta))
+        finally:
+            ops.set_option("attn_one_pass", 0)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[1][0], outs[2][0])  # run-to-run bitwise (no atomics)
+    for nm, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        assert_close(outs[1][0][..., sl], outs[0][0][..., sl].float(), 4e-3, f"one-pass {nm} vs two-pass {b}x{t}x{h}", abs_floor=1e-6)
+    assert_close(outs[1][1], outs[0][1], 1e-5, "delta")
+    if b <= 3:
+        _, want_g = _oracle(qkv.cpu(), h, None, d_o.cpu())
+        for nm, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+            assert_close(outs[1][0][..., sl], want_g[..., sl], 2e-2, f"one-pass {nm} vs fp32 {b}x{t}x{h}", abs_floor=1e-6)
