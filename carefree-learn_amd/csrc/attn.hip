@@ -838,7 +838,10 @@ __global__ __launch_bounds__(PERS_WAVES * 64, 4) void attn_bwd_dq_pers_kernel(At
 // 1 716 MFMAs per head (-33 %), one launch instead of two; what it gives up: the next head's operands no longer stream in behind
 // the current head (the LDS is full), and two more barriers per head.
 // ------------------------------------------------------------------------------------------------
-template <int NB, int PW>  // NB pairs of 16-row tiles (T <= 32 NB); PW waves per workgroup (>= 2 NB key tiles, >= 4 ceil(NB / 2) phase-2 items)
+// CAUSAL: key j attends only to queries i >= j (the CLIP text tower's triu(1) mask as a flag): P = 0 above the diagonal (a predicate on
+// the probability; skipping the tiles above the diagonal costs more registers than it saves at T = 77), their zero dS is not read in
+// phase 2.
+template <int NB, int PW, bool CAUSAL = false>  // NB pairs of 16-row tiles (T <= 32 NB); PW waves per workgroup (>= 2 NB key tiles, >= 4 ceil(NB / 2) phase-2 items)
 __global__ __launch_bounds__(PW * 64, 4) void attn_bwd_one_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROWS = NB * 32, TILE = ROWS * 128;
@@ -859,6 +862,7 @@ __global__ __launch_bounds__(PW * 64, 4) void attn_bwd_one_kernel(AttnParams p) 
   const float sl2 = p.scale * LOG2E;
   const int row0 = wave * 16;  // phase 1: this wave's key tile
   const int qt = wave >> 1, ch = wave & 1;  // phase 2: query tile of the half, column half
+  const int kq = row0 + n - 4 * g;  // CAUSAL: key (row0 + n) is masked for query (16 it + 4 g + r) when kq > 16 it + r
 
   // Q and dO of head `hx` into the LDS (DMA: no registers) ...
   auto stage_q = [&](int hx) {
@@ -937,7 +941,8 @@ __global__ __launch_bounds__(PW * 64, 4) void attn_bwd_one_kernel(AttnParams p) 
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + it * 16 + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float pr = __builtin_amdgcn_exp2f(sc[r] * sl2 - l4[r]);
+              float pr = __builtin_amdgcn_exp2f(sc[r] * sl2 - l4[r]);
+              if (CAUSAL && kq > it * 16 + r) pr = 0.f;
               pp[t][r] = pr;
               ds[t][r] = pr * (dp[r] - d4[r]);
             }
@@ -968,8 +973,9 @@ __global__ __launch_bounds__(PW * 64, 4) void attn_bwd_one_kernel(AttnParams p) 
       if (qt < 2 * (a1 - a0)) {
         f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
         const char* drow = dSs + (qt * 16 + n) * DSROW + 8 * g;
+        const int a_end = CAUSAL ? min(NB, ((2 * a0 + qt) * 16 + 15) / 32 + 1) : NB;  // keys beyond the tile's last query: dS = 0
 #pragma unroll 1
-        for (int a = 0; a < NB; ++a) {
+        for (int a = 0; a < a_end; ++a) {
           const s16x4 lo = *reinterpret_cast<const s16x4*>(drow + a * 64);
           const s16x4 hi = *reinterpret_cast<const s16x4*>(drow + a * 64 + 32);
           bf16x8 dsp;
@@ -2267,6 +2273,25 @@ extern "C" int cfhip_attn_fwd_dh(const void* q, const void* k, const void* v, vo
                        kv_stride_t, o_stride_b, o_stride_t, ms_b, ms_h, ms_q, scale, causal, stream);
 }
 
+template <int NB, int PW, int PER_CU>
+static int launch_one_pass(const AttnParams& p, bool causal, hipStream_t s) {
+  const size_t lds = (size_t)3 * NB * 32 * 128 + (size_t)2 * NB * 32 * 4 + (size_t)((NB + 1) / 2) * 32 * (NB * 64 + 16);
+  const int heads = p.B * p.H, ctas = g_attn_pers_ctas * PER_CU;
+  const dim3 grid(heads < ctas ? heads : ctas), block(PW * 64);
+  if constexpr (NB >= 3 && NB <= 5) {
+    if (causal) {
+      const int rc = set_lds(attn_bwd_one_kernel<NB, PW, true>, lds, "attn_bwd_one");
+      if (rc != CFHIP_OK) return rc;
+      hipLaunchKernelGGL((attn_bwd_one_kernel<NB, PW, true>), grid, block, lds, s, p);
+      return CFHIP_OK;
+    }
+  }
+  const int rc = set_lds(attn_bwd_one_kernel<NB, PW, false>, lds, "attn_bwd_one");
+  if (rc != CFHIP_OK) return rc;
+  hipLaunchKernelGGL((attn_bwd_one_kernel<NB, PW, false>), grid, block, lds, s, p);
+  return CFHIP_OK;
+}
+
 static int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                          const float* lse, float* delta, const uint8_t* mask, void* dq, void* dk,
                          void* dv, int B, int H, int Tq, int Tk, int head_dim, int64_t q_stride_b,
@@ -2315,26 +2340,22 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
       default: return launch_gen_bwd<3>(p, plain, parts, s);
     }
   }
-  if ((parts & 3) == 3 && plain && g_attn_one_pass && Tq == Tk && Tq > 32 && Tq <= 224 && o != nullptr) {
+  const int nb1 = (Tq + 31) / 32;
+  if ((parts & 3) == 3 && mask == nullptr && dropout_p == 0.f && g_attn_one_pass && Tq == Tk && Tq > 32 && Tq <= 224 && o != nullptr &&
+      (!causal || (nb1 >= 3 && nb1 <= 5))) {
     // dQ, dK and dV of a head from one evaluation of S and dP (attn_bwd_one_kernel): 16-wave workgroups, one per CU, for the ViT
-    // lengths; 4 / 8 waves and several workgroups per CU for the short sequences (ViT-B/32 in CLIP: T = 50)
-    const int nb = (Tq + 31) / 32;
-    const int heads = B * H;
-#define CFHIP_ONE_PASS(NB_, PW_, PER_CU_)                                                                                        \
-  case NB_: {                                                                                                                    \
-    const size_t lds1 = (size_t)3 * NB_ * 32 * 128 + (size_t)2 * NB_ * 32 * 4 + (size_t)((NB_ + 1) / 2) * 32 * (NB_ * 64 + 16); \
-    const int ctas = g_attn_pers_ctas * PER_CU_;                                                                                 \
-    rc = set_lds(attn_bwd_one_kernel<NB_, PW_>, lds1, "attn_bwd_one");                                                           \
-    if (rc != CFHIP_OK) return rc;                                                                                               \
-    hipLaunchKernelGGL((attn_bwd_one_kernel<NB_, PW_>), dim3(heads < ctas ? heads : ctas), dim3(PW_ * 64), lds1, s, p);          \
-    break;                                                                                                                       \
-  }
-    switch (nb) {
-      CFHIP_ONE_PASS(2, 4, 4) CFHIP_ONE_PASS(3, 8, 2) CFHIP_ONE_PASS(4, 8, 2)
-      CFHIP_ONE_PASS(5, 16, 1) CFHIP_ONE_PASS(6, 16, 1) CFHIP_ONE_PASS(7, 16, 1)
-      default: cfhip_set_error("attn_bwd: bad nb %d", nb); return CFHIP_ERR_INVALID;
+    // lengths; 4 / 8 waves and several workgroups per CU for the short sequences (ViT-B/32 in CLIP: T = 50; its causal text tower:
+    // T = 77).  Causal instantiations exist for 64 < T <= 160 (the others would spill two registers: the two-pass kernels take them).
+    switch (nb1) {
+      case 2: rc = launch_one_pass<2, 4, 4>(p, causal != 0, s); break;
+      case 3: rc = launch_one_pass<3, 8, 2>(p, causal != 0, s); break;
+      case 4: rc = launch_one_pass<4, 8, 2>(p, causal != 0, s); break;
+      case 5: rc = launch_one_pass<5, 16, 1>(p, causal != 0, s); break;
+      case 6: rc = launch_one_pass<6, 16, 1>(p, causal != 0, s); break;
+      case 7: rc = launch_one_pass<7, 16, 1>(p, causal != 0, s); break;
+      default: cfhip_set_error("attn_bwd: bad nb %d", nb1); return CFHIP_ERR_INVALID;
     }
-#undef CFHIP_ONE_PASS
+    if (rc != CFHIP_OK) return rc;
     CFHIP_CHECK_LAUNCH("attn_bwd(one pass)");
     return CFHIP_OK;
   }

@@ -580,7 +580,7 @@ def test_one_pass_backward_matches_the_two_pass_kernels_and_the_oracle(b, t, h):
             ops.attn_bwd(q, k, v, o, d_o, lse, h, dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], delta=delta)
             outs.append((dqkv, delta))
         finally:
-            ops.set_option("attn_one_pass", 0)
+            ops.set_option("attn_one_pass", 1)
     torch.cuda.synchronize()
     assert torch.equal(outs[1][0], outs[2][0])  # run-to-run bitwise (no atomics)
     for nm, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
@@ -590,3 +590,30 @@ def test_one_pass_backward_matches_the_two_pass_kernels_and_the_oracle(b, t, h):
         _, want_g = _oracle(qkv.cpu(), h, None, d_o.cpu())
         for nm, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
             assert_close(outs[1][0][..., sl], want_g[..., sl], 2e-2, f"one-pass {nm} vs fp32 {b}x{t}x{h}", abs_floor=1e-6)
+
+
+@pytest.mark.parametrize("b,t,h", [(3, 77, 8), (2, 65, 2), (2, 128, 3), (2, 160, 2), (64, 77, 8)])
+def test_one_pass_backward_causal(b, t, h):
+    """the CAUSAL instantiations of `attn_bwd_one_kernel` (64 < T <= 160: the CLIP text tower's T = 77 with the triu(1) mask as a
+    flag) against the two-pass kernels with the same flag and, for the small cases, against fp32 math with the explicit mask"""
+    qkv = _qkv(b, t, h, 500 + t, scale=1.5).to(DEV)
+    d = h * 64
+    d_o = torch.randn(b, t, d, generator=torch.Generator().manual_seed(t + 2)).to(torch.bfloat16).to(DEV)
+    q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    o, lse = ops.attn_fwd(q, k, v, h, causal=True)
+    outs = []
+    for one in (0, 1):
+        ops.set_option("attn_one_pass", one)
+        try:
+            dqkv = torch.zeros_like(qkv)
+            ops.attn_bwd(q, k, v, o, d_o, lse, h, dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], causal=True)
+            outs.append(dqkv)
+        finally:
+            ops.set_option("attn_one_pass", 1)
+    for nm, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        assert_close(outs[1][..., sl], outs[0][..., sl].float(), 4e-3, f"causal one-pass {nm} vs two-pass {b}x{t}x{h}", abs_floor=1e-6)
+    if b <= 3:
+        keep = ~torch.triu(torch.ones(t, t, dtype=torch.bool), diagonal=1)
+        _, want_g = _oracle(qkv.cpu(), h, keep, d_o.cpu())
+        for nm, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+            assert_close(outs[1][..., sl], want_g[..., sl], 2e-2, f"causal one-pass {nm} vs fp32 {b}x{t}x{h}", abs_floor=1e-6)
