@@ -27,7 +27,7 @@ case "$recipe" in
     echo "== bench $tag exit $?"; tail -n 1 gpurun_out/$tag/bench.json | cut -c1-600; tail -n 3 gpurun_out/$tag/bench.err | cut -c1-300 ;;
   prof)
     tag=$1; shift; OUT=gpurun_out/$tag; mkdir -p $OUT
-    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/prof" -o step -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-other-workloads "$@" ) > $OUT/prof.log 2>&1
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/prof" -o step -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-other-workloads --no-calibration "$@" ) > $OUT/prof.log 2>&1
     f=$(ls $OUT/prof/*kernel_stats.csv 2>/dev/null | head -1)
     [ -n "$f" ] && python tools/prof_summary.py "$f" 7 > $OUT/prof_summary.txt && cp "$f" $OUT/kernel_stats.csv
     head -40 $OUT/prof_summary.txt | cut -c1-150; rm -rf $OUT/prof ;;
@@ -40,7 +40,7 @@ case "$recipe" in
   pmc)
     tag=$1; shift; OUT=gpurun_out/$tag; mkdir -p $OUT
     for ctr in FETCH_SIZE WRITE_SIZE; do
-      ( cd /tmp && timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $R/$OUT/$ctr -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-other-workloads "$@" ) > $OUT/$ctr.log 2>&1
+      ( cd /tmp && timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $R/$OUT/$ctr -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-other-workloads --no-calibration "$@" ) > $OUT/$ctr.log 2>&1
       echo "== $ctr exit $?"; tail -n 2 $OUT/$ctr.log | cut -c1-300
     done
     f=$(ls $OUT/FETCH_SIZE/*counter_collection.csv | head -1); w=$(ls $OUT/WRITE_SIZE/*counter_collection.csv | head -1)
@@ -48,7 +48,7 @@ case "$recipe" in
     rm -rf $OUT/FETCH_SIZE $OUT/WRITE_SIZE ;;
   trace)
     tag=$1; shift; OUT=gpurun_out/$tag; mkdir -p $OUT
-    ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d "$R/$OUT/prof" -o step -- python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-other-workloads "$@" ) > $OUT/prof.log 2>&1
+    ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d "$R/$OUT/prof" -o step -- python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-other-workloads --no-calibration "$@" ) > $OUT/prof.log 2>&1
     f=$(ls $OUT/prof/*kernel_trace.csv 2>/dev/null | head -1); [ -n "$f" ] && python tools/trace_reduce.py "$f" $OUT/timeline.csv && gzip -f $OUT/timeline.csv
     rm -rf $OUT/prof; tail -3 $OUT/prof.log ;;
   py)
@@ -58,7 +58,7 @@ case "$recipe" in
     echo "== $script exit $?"; tail -n ${PY_TAIL:-40} $log | cut -c1-400 ;;
   ddp)
     tag=$1; n=$2; shift 2; mkdir -p gpurun_out/$tag
-    timeout 600 python bench.py --gpus $n --no-cpu-baseline --no-roofline --no-other-workloads "$@" > gpurun_out/$tag/bench_ddp$n.json 2> gpurun_out/$tag/bench_ddp$n.err
+    timeout 600 python bench.py --gpus $n --no-cpu-baseline --no-roofline --no-other-workloads --no-calibration "$@" > gpurun_out/$tag/bench_ddp$n.json 2> gpurun_out/$tag/bench_ddp$n.err
     echo "== ddp $n exit $?"; tail -n 1 gpurun_out/$tag/bench_ddp$n.json | cut -c1-600; tail -n 4 gpurun_out/$tag/bench_ddp$n.err | cut -c1-300 ;;
   *) echo "unknown recipe $recipe"; exit 2 ;;
 esac

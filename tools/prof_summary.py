@@ -13,6 +13,6 @@ for r in rows:
     tot += ms
     out.append((ms, name, int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3))
 print(f"{'kernel':86s} {'ms/step':>8s} {'calls':>6s} {'avg us':>8s}")
-for ms, name, calls, avg in out[:26]:
+for ms, name, calls, avg in out:  # (every row: round 5's files were cut at 26 and hid the kernels a round was about)
     print(f"{name:86s} {ms:8.3f} {calls:6.1f} {avg:8.1f}")
-print(f"{'TOTAL (all kernels)':86s} {tot:8.3f}")
+print(f"{'TOTAL (all kernels)':86s} {tot:8.3f} {sum(c for _, _, c, _ in out):6.0f} launches per step")
