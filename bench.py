@@ -648,7 +648,7 @@ TELEMETRY = None  # tools.gpu_telemetry.GpuTelemetry of this rank's GPU (started
 
 
 def start_telemetry(device_index: int):
-    """sclk / socket power / junction temperature of this rank's GPU at 10 Hz from a side thread (tools/gpu_telemetry.py: amdsmi
+    """sclk / socket power / junction temperature of this rank's GPU at 25 Hz from a side thread (tools/gpu_telemetry.py: amdsmi
     in-process, rocm-smi as fallback).  A line without clock and power cannot be compared with a line from another box: the step
     runs against the socket's power cap (DESIGN §9) and boxes differ by +-3 % in the clock they sustain (VERDICT r5 #2)."""
     global TELEMETRY
@@ -656,7 +656,7 @@ def start_telemetry(device_index: int):
         try:
             from tools.gpu_telemetry import GpuTelemetry
 
-            TELEMETRY = GpuTelemetry(device_index, hz=10.0).start()
+            TELEMETRY = GpuTelemetry(device_index, hz=25.0).start()
             if not TELEMETRY.available:
                 note(f"telemetry: no source ({TELEMETRY.error})")
         except Exception as e:  # never fatal

