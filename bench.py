@@ -1059,13 +1059,14 @@ def main() -> None:
     result["streams"] = stream_report()  # helper streams on hardware queues of their own? (False = a serialised step)
     if distributed:
         # clock / power / calibration of EVERY rank (rank order): the first multi-GPU line shows what RCCL's kernels cost the cap
-        mine = torch.tensor([tel.get("sclk_mhz_avg") or 0.0, tel.get("power_w_avg") or 0.0, tel.get("junction_c_avg") or 0.0,
-                             (calib or {}).get("tflops") or 0.0], device=dev, dtype=torch.float32)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        result["telemetry"]["per_rank"] = [{"rank": r, "sclk_mhz_avg": round(v[0].item(), 1), "power_w_avg": round(v[1].item(), 1),
-                                            "junction_c_avg": round(v[2].item(), 1), "calibration_tflops": round(v[3].item(), 1)}
-                                           for r, v in enumerate(allr)]
+        mine = {"rank": rank, "sclk_mhz_avg": tel.get("sclk_mhz_avg"), "power_w_avg": tel.get("power_w_avg"),
+                "junction_c_avg": tel.get("junction_c_avg"), "calibration_tflops": (calib or {}).get("tflops")}
+        allr = [None] * world
+        try:
+            dist.all_gather_object(allr, mine)  # (object form: the same call under nccl and gloo)
+        except Exception as e:  # never fatal: the line keeps rank 0's figures
+            allr = [mine, {"error": f"{type(e).__name__}: {e}"[:120]}]
+        result["telemetry"]["per_rank"] = allr
         result["rccl"] = {
             "ranks": dist.get_world_size(), "backend": args.backend, "collectives_launched_by": args.comm,
             # what RCCL itself reports for the C-ABI communicator (ncclCommCount / ncclCommUserRank), not this script's bookkeeping
