@@ -991,7 +991,7 @@ def test_unet_zoo_256px_forward_vs_oracle_and_gradients_vs_finite_differences(mo
 
     monkeypatch.setattr(UO.O, "sdp_attention", sdp)
     prev = torch.get_num_threads()
-    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    torch.set_num_threads(min(128, os.cpu_count() or 8))
     try:
         t0 = time.time()
         with torch.no_grad():
