@@ -78,7 +78,7 @@ __device__ __forceinline__ ItemCtx<AT, BT, C> setup_item(const GemmParams& p, in
   const long a_bytes = AT ? ((long)(c.klen - 1) * p.lda + rows_a) * 2 : ((long)(rows_a - 1) * p.lda + c.klen) * 2;
   const long b_bytes = BT ? ((long)(c.klen - 1) * p.ldb + rows_b) * 2 : ((long)(rows_b - 1) * p.ldb + c.klen) * 2;
   if constexpr (CONV == 2) {
-    static_assert(CONV != 2 || (AT && BT && C::BK == 32), "implicit weight gradient: layout (1,1), 32-pixel K-steps");
+    static_assert(CONV != 2 || (AT && BT), "implicit weight gradient: layout (1,1), a K-step = BK pixels");
     const int back = min(kb, p.conv_w + 1);
     const long span = min((long)p.K - (kb - back), (long)back + c.klen + p.conv_w + 1);
     c.b_rsrc = make_rsrc(p.B + (long)(kb - back) * p.conv_c, span * p.conv_c * 2);
@@ -101,10 +101,10 @@ __device__ __forceinline__ ItemCtx<AT, BT, C> setup_item(const GemmParams& p, in
     }
   } else {
     c.b_rsrc = make_rsrc(b_base, b_bytes);
-    c.pb = make_plan<BT, C::BN, C::B_INSTR, C::BK>(wave, lane, p.ldb, rows_b);
+    c.pb = make_plan<BT, C::BN, C::B_INSTR, C::BK>(wave, lane, p.ldb, C::B_PADDED ? min(rows_b, C::BN) : rows_b);
   }
   if constexpr (CONV == 1) {
-    static_assert(!AT && C::BK == 32, "implicit convolution: k-major A, 32-channel K-steps");
+    static_assert(!AT, "implicit convolution: k-major A, a K-step = BK channels of one tap");
     // The descriptor starts W+1 pixels BEFORE the tile (clamped at pixel 0) so that the (-1,-1) tap is a
     // non-negative offset; it ends W+1 pixels after it.  Taps outside the image are sent out of range per lane.
     const int back = min(c.m0, p.conv_w + 1);
@@ -113,8 +113,9 @@ __device__ __forceinline__ ItemCtx<AT, BT, C> setup_item(const GemmParams& p, in
 #pragma unroll
     for (int j = 0; j < C::A_INSTR; ++j) {
       const int inst = wave * C::A_INSTR + j;
-      const int row = inst * 16 + (lane >> 2);
-      const int chunk = (lane & 3) ^ kswz<32>(row);
+      constexpr int SPR = C::BK / 8;  // 16-byte slots per tile row
+      const int row = inst * (64 / SPR) + lane / SPR;
+      const int chunk = (lane % SPR) ^ kswz<C::BK>(row);
       c.pa.kpos[j] = chunk * 8;
       c.pa.voff[j] = (row < rows_a) ? (unsigned)(((back + row) * p.conv_c + chunk * 8) * 2) : OOB;
       const int m = c.m0 + row;
@@ -128,13 +129,13 @@ __device__ __forceinline__ ItemCtx<AT, BT, C> setup_item(const GemmParams& p, in
   return c;
 }
 
-// CONV: K-step `kstep` of the A operand = 32 channels (c0..) of tap (ky, kx) for the tile's BM pixels
+// CONV: K-step `kstep` of the A operand = BK channels (c0..) of tap (ky, kx) for the tile's BM pixels
 template <class C>
 __device__ __forceinline__ void stage_tile_conv(const __amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int wave,
                                                 const StagePlan<C::A_INSTR>& pl, const unsigned (&yx)[C::A_INSTR],
                                                 const GemmParams& p, int kstep) {
   const int tap = (int)(((float)kstep + 0.5f) * p.conv_inv_kpt);  // kstep / conv_kpt (exact: kstep < 2^16)
-  const int c0 = (kstep - tap * p.conv_kpt) * 32;
+  const int c0 = (kstep - tap * p.conv_kpt) * C::BK;
   const int ky = (tap * 11) >> 5;  // tap / 3 for tap in 0..8
   const int dy = ky - 1, dx = tap - 3 * ky - 1;
   const int shift = ((dy * p.conv_w + dx) * p.conv_c + c0) * 2;
@@ -147,10 +148,10 @@ __device__ __forceinline__ void stage_tile_conv(const __amdgpu_buffer_rsrc_t rsr
   }
 }
 
-// CONV 2: K-step `kstep` of the B operand = 32 pixels x the tile's BN (tap, channel) columns of the shifted activation
+// CONV 2: K-step `kstep` of the B operand = BK pixels x the tile's BN (tap, channel) columns of the shifted activation
 template <class C, class Ctx>
 __device__ __forceinline__ void stage_tile_wgrad(const Ctx& c, char* lds_tile, int wave, const GemmParams& p, int kstep) {
-  const int k0 = kstep * 32;
+  const int k0 = kstep * C::BK;
 #pragma unroll
   for (int j = 0; j < C::B_INSTR; ++j) {
     const int kl = k0 + (int)c.pb.kpos[j];
@@ -168,7 +169,7 @@ template <bool AT, bool BT, class C, int CONV = 0>
 __device__ __forceinline__ void stage_step(const ItemCtx<AT, BT, C>& c, const GemmParams& p, char* smem,
                                            int slot, int wave, int kstep) {
   char* st = smem + slot * C::STAGE_BYTES;
-  if constexpr (CONV == 1) stage_tile_conv<C>(c.a_rsrc, st, wave, c.pa, c.yx, p, kstep + (c.kb >> 5));
+  if constexpr (CONV == 1) stage_tile_conv<C>(c.a_rsrc, st, wave, c.pa, c.yx, p, kstep + c.kb / C::BK);
   else stage_tile<AT, C::A_INSTR, C::BK>(c.a_rsrc, st, wave, c.pa, p.lda, kstep * C::BK, c.klen);
   if constexpr (CONV == 2) {
     stage_tile_wgrad<C>(c, st + C::A_BYTES, wave, p, kstep);
@@ -203,7 +204,8 @@ __device__ __forceinline__ int xcd_item() {
 template <bool AT, bool BT, int EPI, class C, int CONV = 0, bool BG = false>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int item, char* smem) {
   constexpr int D = C::NSTAGE - 1;  // prefetch distance
-  static_assert(C::NW * 16 * (C::FN * 16) * 4 <= C::STAGE_BYTES, "epilogue staging must fit in one ring slot");
+  static_assert(kFlatEpilogue<C> ? C::NW * 16 * (C::FN * 16 + 4) * 4 <= C::LDS_BYTES : C::NW * 16 * (C::FN * 16) * 4 <= C::STAGE_BYTES,
+                "epilogue staging must fit in one ring slot (80-column wave tiles: in the ring)");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -271,7 +273,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int item, c
   __builtin_amdgcn_s_barrier();
   int eslot = rd - 1;
   if (eslot < 0) eslot += C::NSTAGE;
-  epilogue<EPI, C>(p, acc, smem + eslot * C::STAGE_BYTES, m0, n0, z, wm, wn, wave, lane);
+  // (every wave is past its last compute_tile at that barrier: the WHOLE ring is free — the 80-column tiles' strips start at slot 0)
+  epilogue<EPI, C>(p, acc, kFlatEpilogue<C> ? smem : smem + eslot * C::STAGE_BYTES, m0, n0, z, wm, wn, wave, lane);
 }
 
 template <bool AT, bool BT, int EPI, class C, int CONV = 0, bool BG = false>
@@ -312,7 +315,7 @@ void gemm_bf16_phase_kernel(GemmParams p) {
   static_assert(C::BK == 32 && C::NSTAGE >= 3 && C::NSTAGE <= 7 && C::WM == 2, "phase kernel: BK = 32, 3-7 ring slots, 2 wave rows");
   static_assert(5 * C::LPS < 64, "vmcnt is a 6-bit counter");
   constexpr int D = C::NSTAGE - 1;  // prefetch distance (K-steps)
-  static_assert(C::NW * 16 * (C::FN * 16) * 4 <= C::LDS_BYTES, "epilogue staging must fit in the (free) ring");
+  static_assert(C::NW * 16 * (C::FN * 16 + 4) * 4 <= C::LDS_BYTES, "epilogue staging must fit in the (free) ring");
   // phases per K-step: two (upper / lower half of the wave's rows) when a half still carries 16 MFMAs,
   // otherwise one — a barrier pair per 8 MFMAs costs more than the overlap buys
   constexpr int PH = (C::FM / 2) * C::FN >= 16 ? 2 : 1;
@@ -514,6 +517,14 @@ using CfgW = Cfg<256, 256, 2, 4, 2, 64>;  // 128 KiB LDS, 8 waves (128x64 each),
 using CfgY = Cfg<192, 128, 2, 4, 2, 64>;  //  80 KiB LDS, 8 waves (96x32 each), 2 WG / CU, BK = 64 (plain kernel)
 using CfgZ = Cfg<192, 128, 2, 2, 2, 64>;  //  80 KiB LDS, 4 waves (96x64 each: 2.4 MFMAs per fragment read against 1.5), 2 WG / CU
 using CfgV = Cfg<128, 256, 2, 4, 2, 64>;  //  96 KiB LDS, 8 waves (64x64 each), 1 WG / CU
+// The UNet's convolutions (N = 320 .. 2560: multiples of 160, of no power-of-two tile width; M = 65 536 .. 512 pixels): four waves of
+// 64 x 80 (20 MFMAs per 9 fragment reads; the 128x32 waves of CfgQ: 16 per 10).  Convolution launcher only (conv_plan), not in the
+// gemm_config table.  Round 6, tools/conv_bench.py over the 26 (pixels, Cin, Cout) of the zoo UNet at 64^2 x 8, launches x isolated time:
+// 9.45 ms with the round-3 table (CfgQ / CfgB), 8.08 with CfgH, 6.41 with CfgI (profiles/r06/conv_forms_bench.txt): the 64-channel
+// K-step is worth more than the tile shape.  (Measured and not kept: 128x320 on the eight-wave phase kernel 8.17, CfgH on the phase
+// kernel 8.17, a two-stage 128x160x32 at 4 WG / CU 9.05.)
+using CfgH = Cfg<128, 160, 2, 2, 4, 32>;  //  80 KiB LDS (B image padded to 192 rows), 4 waves, 2 WG / CU, prefetch 3
+using CfgI = Cfg<128, 160, 2, 2, 2, 64>;  //  72 KiB LDS, 4 waves, 2 WG / CU, prefetch 1, 64-channel K-steps (Cin % 64 == 0)
 constexpr int NUM_CFG = 17;  // (17 .. 20 were the software-pipelined 32x32x16 kernels of round 4: measured, never selected, removed in round 6 — profiles/r04/gemm_pp_*.log, docs/DESIGN_HISTORY.md)  7 .. 12 = CfgP / CfgQ / CfgR / CfgS / CfgT / CfgU on the phase kernel; 13 / 14 = CfgW / CfgY; 15 / 16 = CfgZ / CfgV
 constexpr int BK_MAX = 64;
 
@@ -523,6 +534,8 @@ int g_gemm_ablate = 0;
 #endif
 int g_gemm_heuristic = 9;  // round 5: 9 (four-wave 192x128x64 for every M >= 1024 forward / dX GEMM): ViT 17.61 -> 17.47 ms, CLIP 17.89 -> 17.60, UNet neutral (profiles/r05/heuristic9_ab.txt)
 int g_gemm_group_n = 8;
+int g_conv_form = -1;   // "conv_form" option: -1 = conv_plan's choice
+int g_conv_split = -1;  // "conv_split" option: -1 = conv_plan's choice (tools/conv_bench.py sweeps both)
 
 template <bool AT, bool BT, int EPI, class C, bool PIPE, int CONV = 0>
 int launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
@@ -703,6 +716,14 @@ extern "C" int cfhip_set_option(const char* name, int value) {
     g_gemm_group_n = value;
     return CFHIP_OK;
   }
+  if (name != nullptr && strcmp(name, "conv_form") == 0) {
+    g_conv_form = value;
+    return CFHIP_OK;
+  }
+  if (name != nullptr && strcmp(name, "conv_split") == 0) {
+    g_conv_split = value;
+    return CFHIP_OK;
+  }
   if (name != nullptr && strcmp(name, "ln_bwd_fused") == 0) return cfhip_internal_set_ln_fused(value);
   if (name != nullptr && strcmp(name, "attn_persistent") == 0) return cfhip_internal_set_attn_persistent(value);
   if (name != nullptr && strcmp(name, "attn_one_pass") == 0) return cfhip_internal_set_attn_one_pass(value);
@@ -881,13 +902,14 @@ static int launch_conv(GemmParams p, int split_k, hipStream_t s) {
   return launch_cfg<false, false, CFHIP_EPI_NONE, C, PIPE, 1>(p, dim3(p.tiles_m * p.tiles_n * split_k), s);
 }
 
-// The UNet's deeper levels have few output tiles (32^2 x 8 x 640: 160 tiles of 256x128, 8^2 x 8 x 1280: 40 of 128x128)
+// Tile form and K split of one convolution.  Forms: 0 = 256x128x32 phase kernel (CfgQ, 2 WG / CU), 1 = 128x128x32 plain (CfgB, 4 WG / CU)
+// — the round-3 table: form 0 from 1 024 pixels on; 2 = 128x160x32 on four waves (CfgH, 2 WG / CU), 3 = 128x160x64 (CfgI, 2 WG / CU).
+// Round 6: outputs that 160-column tiles cover with at most 1/8 of waste (the UNet: none) take form 3 when Cin % 64 == 0, else form 2.
+// The UNet's deeper levels have few output tiles (32^2 x 8 x 640: 256 tiles of 128x160, 8^2 x 8 x 1280: 32)
 // under a deep reduction (K = 9 * Cin = 5 760 .. 23 040): split K until the grid covers the resident slots.
-static int conv_pick_split(long pixels, int Cin, int Cout) {
-  const bool phase = pixels >= 1024;
-  const int bm = phase ? 256 : 128;
-  const long tiles = ((pixels + bm - 1) / bm) * ((Cout + 127) / 128);
-  const long slots = phase ? 512 : 1024;
+struct ConvPlan { int form, split; };
+
+static int conv_split_for(long tiles, long slots, int Cin) {
   const int steps = (9 * Cin + BK_MAX - 1) / BK_MAX;
   if (tiles * 2 > slots || steps < 16) return 1;
   long split = (slots + tiles - 1) / tiles;
@@ -897,9 +919,27 @@ static int conv_pick_split(long pixels, int Cin, int Cout) {
   return (steps + per - 1) / per;
 }
 
+static ConvPlan conv_plan(long pixels, int Cin, int Cout) {
+  ConvPlan pl;
+  pl.form = pixels >= 1024 ? 0 : 1;
+  if (g_conv_form != -2 && (long)((Cout + 159) / 160) * 160 * 8 <= 9L * Cout) pl.form = 3;  // (-2: the round-3 table, A/B runs)
+  if (g_conv_form >= 0 && g_conv_form <= 3) pl.form = g_conv_form;
+  static const int bm[4] = {256, 128, 128, 128}, bn[4] = {128, 128, 160, 160}, slots[4] = {512, 1024, 512, 512};
+  if (pl.form == 3 && Cin % 64 != 0) pl.form = 2;
+  const long tiles = ((pixels + bm[pl.form] - 1) / bm[pl.form]) * ((Cout + bn[pl.form] - 1) / bn[pl.form]);
+  pl.split = conv_split_for(tiles, slots[pl.form], Cin);
+  if (g_conv_split >= 1) {
+    const int steps = (9 * Cin + BK_MAX - 1) / BK_MAX;
+    int split = g_conv_split > steps ? steps : g_conv_split;
+    const int per = (steps + split - 1) / split;
+    pl.split = (steps + per - 1) / per;
+  }
+  return pl;
+}
+
 extern "C" size_t cfhip_conv3x3_workspace(int B, int H, int W, int Cin, int Cout) {
   const long pixels = (long)B * H * W;
-  const int split = conv_pick_split(pixels, Cin, Cout);
+  const int split = conv_plan(pixels, Cin, Cout).split;
   return split > 1 ? (size_t)split * pixels * Cout * sizeof(float) : 0;
 }
 
@@ -934,7 +974,8 @@ extern "C" int cfhip_conv3x3_nhwc_bf16(const void* X, const void* Wk, const floa
   p.conv_h = H; p.conv_w = W; p.conv_c = Cin; p.conv_kpt = Cin / 32;
   p.conv_inv_kpt = 1.0f / (float)p.conv_kpt;
   p.conv_magic_w = p.conv_magic_h = 0u;
-  const int split = conv_pick_split(pixels, Cin, Cout);
+  const ConvPlan plan = conv_plan(pixels, Cin, Cout);
+  const int split = plan.split;
   if (split > 1) {
     const size_t need = (size_t)split * pixels * Cout * sizeof(float);
     if (workspace == nullptr || workspace_bytes < need) {
@@ -946,7 +987,17 @@ extern "C" int cfhip_conv3x3_nhwc_bf16(const void* X, const void* Wk, const floa
     p.slabs = reinterpret_cast<float*>(workspace);
   }
   hipStream_t s = (hipStream_t)stream;
-  const int rc = p.M >= 1024 ? launch_conv<CfgQ, true>(p, split, s) : launch_conv<CfgB, false>(p, split, s);
+  int rc;
+  switch (plan.form) {
+    case 0: rc = launch_conv<CfgQ, true>(p, split, s); break;
+    case 2: rc = launch_conv<CfgH, false>(p, split, s); break;
+    case 3:
+      p.conv_kpt = Cin / 64;
+      p.conv_inv_kpt = 1.0f / (float)p.conv_kpt;
+      rc = launch_conv<CfgI, false>(p, split, s);
+      break;
+    default: rc = launch_conv<CfgB, false>(p, split, s); break;
+  }
   if (rc != CFHIP_OK) return rc;
   CFHIP_CHECK_LAUNCH("conv3x3_nhwc");
   if (split > 1) {
@@ -1006,10 +1057,13 @@ extern "C" int cfhip_conv3x3_wgrad_nhwc_bf16(const void* dY, const void* X, floa
   }
   p.slabs = reinterpret_cast<float*>(workspace);
   if (bias_grad) p.bgrad_slabs = p.slabs + (size_t)split_k * p.M * p.N;
-  p.tiles_m = (p.M + CfgC::BM - 1) / CfgC::BM;
-  p.tiles_n = (p.N + CfgC::BN - 1) / CfgC::BN;
   p.splits = split_k;
   hipStream_t s = (hipStream_t)stream;
+  // (round 6: the same launch on 128x128x64 / two stages — the 64-deep K-step that is worth 21 % on the forward / dX tiles — came out
+  // level over the UNet's 16 filter-gradient shapes: 5.54 vs 5.57 ms per step alone, profiles/r06/conv_wgrad_bk64_not_kept.txt;
+  // both operands are m-major here, every staged line is used whole at either depth)
+  p.tiles_m = (p.M + CfgC::BM - 1) / CfgC::BM;
+  p.tiles_n = (p.N + CfgC::BN - 1) / CfgC::BN;
   const int rc = launch_cfg<true, true, CFHIP_EPI_NONE, CfgC, false, 2>(p, dim3(p.tiles_m * p.tiles_n * split_k), s);
   if (rc != CFHIP_OK) return rc;
   CFHIP_CHECK_LAUNCH("conv3x3_wgrad");

@@ -46,7 +46,12 @@ struct Cfg {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_, BK = BK_;
   static constexpr int NW = WM * WN, NT = NW * 64;
   static constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
-  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  // B_BYTES: the staged B image, rounded up to whole LDS-DMA instructions per wave.  Only the 80-column-per-wave tiles of the
+  // UNet's convolutions (BN = 320 on eight waves, 160 on four: N = 320 / 640 / 960 / 1280 / 1920 / 2560 are all multiples of 160
+  // and of none of the power-of-two widths) round: their extra rows are statically out of range (zero-filled, never read).
+  static constexpr int A_BYTES = BM * BK * 2, B_RAW = BN * BK * 2;
+  static constexpr int B_BYTES = (B_RAW + 1024 * WM_ * WN_ - 1) / (1024 * WM_ * WN_) * (1024 * WM_ * WN_), STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr bool B_PADDED = B_BYTES != B_RAW;
   static constexpr int LDS_BYTES = STAGE_BYTES * NSTAGE;
   static constexpr int A_INSTR = A_BYTES / 1024 / NW, B_INSTR = B_BYTES / 1024 / NW;  // LDS-DMA instr / wave / K-step
   static constexpr int LPS = A_INSTR + B_INSTR;                        // "loads per stage" for vmcnt
@@ -81,7 +86,6 @@ __device__ __forceinline__ int kswz(int row) { return BK == 64 ? ((row >> 1) & 7
 // group of four, so the key never leaves a 12-chunk row).  mkey(krow) == mkey(krow + 4) for krow % 8 < 4.
 template <int R>
 __device__ __forceinline__ int mkey(int krow) {
-  static_assert(R % 64 == 0, "m-major tiles: whole 128-byte lines per k-row");
   return R % 128 == 0 ? ((krow & 3) | (((krow >> 3) & 1) << 2)) : (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1));
 }
 
@@ -91,7 +95,6 @@ __device__ __forceinline__ int mkey(int krow) {
 // pitch = 128 mod 256 (R = 64, 192): odd k-rows already sit on the other bank half, key = krow & 2.
 template <int R>
 __device__ __forceinline__ int mkey32(int krow) {
-  static_assert(R % 64 == 0, "m-major tiles: whole 128-byte lines per k-row");
   return R % 128 == 0 ? ((krow & 3) << 1) : (krow & 2);
 }
 
@@ -101,7 +104,7 @@ __device__ __forceinline__ StagePlan<NI> make_plan(int wave, int lane, long ld, 
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int inst = wave * NI + j;
-    if (!TRANS) {
+    if constexpr (!TRANS) {
       // k-major tile [R rows][BK k]: SPR 16-B slots per row; slot s of row r holds source chunk
       // s ^ kswz(r)
       constexpr int SPR = BK / 8;
@@ -112,6 +115,7 @@ __device__ __forceinline__ StagePlan<NI> make_plan(int wave, int lane, long ld, 
     } else {
       // m-major tile [BK k][R cols]: one k-row = R/8 slots of 16 B; 32-B chunk c of k-row kr holds
       // source chunk c ^ mkey(kr)
+      static_assert(R % 64 == 0, "m-major tiles: whole 128-byte lines per k-row (mkey / mkey32)");
       constexpr int SLOTS = R / 8;
       const int slot = inst * 64 + lane;  // 16-byte slot of the tile image (SLOTS need not divide 64: R = 192)
       const int krow = slot / SLOTS;
@@ -523,9 +527,82 @@ __device__ __forceinline__ void epilogue_slab(const GemmParams& p, f32x4 (&acc)[
   }
 }
 
+// Wave sub-tiles whose width does not divide a wave's 64 lanes into whole rows (80 columns per wave: the convolution tiles
+// Cfg<128, 320, 2, 4, ..> / Cfg<128, 160, 2, 2, ..>).  The 16 x WCOLS strip of a row fragment is handed out as a flat list of
+// 16-byte pieces (8 bf16 columns, or 4 f32 columns of a split-K slab), 64 per pass; rows are padded by 4 floats instead of the
+// XOR swizzle (20 chunks per row are not a power of two).  Bias + bf16 output or split-K slabs: what the convolutions need.
+template <class C>
+__device__ __forceinline__ void epilogue_flat(const GemmParams& p, f32x4 (&acc)[C::FM][C::FN], char* stage,
+                                              int m0, int n0, int z, int wm, int wn, int wave, int lane) {
+  constexpr int WCOLS = C::FN * 16, PITCH = WCOLS + 4;
+  float* stg = reinterpret_cast<float*>(stage) + wave * (16 * PITCH);
+  const int i = lane & 15, g = lane >> 4;
+  if (p.slabs != nullptr) {
+    constexpr int CPR = WCOLS / 4, NCH = 16 * CPR, NP = (NCH + 63) / 64;
+    const __amdgpu_buffer_rsrc_t s_rsrc = tile_rsrc(p.slabs + (long)z * p.M * p.N, p.N, 4, m0, n0, p.M, p.N);
+    int srow[NP], scol[NP];
+    bool sok[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int c = ps * 64 + lane;
+      srow[ps] = c / CPR;
+      scol[ps] = (c - srow[ps] * CPR) * 4;
+      sok[ps] = c < NCH && n0 + wn * WCOLS + scol[ps] < p.N;
+    }
+#pragma unroll
+    for (int mi = 0; mi < C::FM; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < C::FN; ++ni) *reinterpret_cast<f32x4*>(stg + i * PITCH + ni * 16 + g * 4) = acc[mi][ni];
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        const int r = sok[ps] ? srow[ps] : 0;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * PITCH + (sok[ps] ? scol[ps] : 0));
+        const unsigned e = (unsigned)((wm * (C::FM * 16) + mi * 16 + srow[ps]) * p.N + wn * WCOLS + scol[ps]);
+        bstore16(s_rsrc, sok[ps] ? e * 4u : OOB, __builtin_bit_cast(u32x4, v));
+      }
+    }
+    return;
+  }
+  constexpr int CPR = WCOLS / 8, NCH = 16 * CPR, NP = (NCH + 63) / 64;
+  const __amdgpu_buffer_rsrc_t c_rsrc = tile_rsrc(p.C, p.ldc, 2, m0, n0, p.M, p.N);
+  int srow[NP], scol[NP];
+  bool sok[NP];
+  f32x4 b_lo[NP], b_hi[NP];
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int c = ps * 64 + lane;
+    srow[ps] = c / CPR;
+    scol[ps] = (c - srow[ps] * CPR) * 8;
+    const int col = n0 + wn * WCOLS + scol[ps];
+    sok[ps] = c < NCH && col < p.N;  // N % 8 == 0 on this path: the 8 columns are all inside or all outside
+    b_lo[ps] = b_hi[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr && sok[ps]) {
+      b_lo[ps] = *reinterpret_cast<const f32x4*>(p.bias + col);
+      b_hi[ps] = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < C::FM; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < C::FN; ++ni) *reinterpret_cast<f32x4*>(stg + i * PITCH + ni * 16 + g * 4) = acc[mi][ni];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int r = sok[ps] ? srow[ps] : 0, cc = sok[ps] ? scol[ps] : 0;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + r * PITCH + cc) + b_lo[ps];
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + r * PITCH + cc + 4) + b_hi[ps];
+      const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+      const unsigned e = (unsigned)((wm * (C::FM * 16) + mi * 16 + srow[ps]) * (int)p.ldc + wn * WCOLS + scol[ps]);
+      bstore16(c_rsrc, sok[ps] ? e * 2u : OOB, w);
+    }
+  }
+}
+
+template <class C>
+constexpr bool kFlatEpilogue = 64 % (C::FN * 2) != 0;
+
 template <int EPI, class C>
-__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[C::FM][C::FN], char* stage,
-                                         int m0, int n0, int z, int wm, int wn, int wave, int lane) {
+__device__ __forceinline__ void epilogue_std(const GemmParams& p, f32x4 (&acc)[C::FM][C::FN], char* stage,
+                                             int m0, int n0, int z, int wm, int wn, int wave, int lane) {
   if constexpr (EPI == CFHIP_EPI_NONE) {  // split-K (host-checked: epilogue NONE only)
     if (p.slabs != nullptr) {
       epilogue_slab<C>(p, acc, stage, m0, n0, z, wm, wn, wave, lane);
@@ -544,6 +621,17 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[C::FM
     if (p.out_f32) epilogue_f32<EPI, C>(p, acc, stage, m0, n0, wm, wn, wave, lane);
     else if ((p.N & 7) == 0) epilogue_impl<EPI, C, false, true, false>(p, acc, stage, m0, n0, wm, wn, wave, lane);
     else epilogue_impl<EPI, C, false, false, false>(p, acc, stage, m0, n0, wm, wn, wave, lane);
+  }
+}
+
+template <int EPI, class C>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[C::FM][C::FN], char* stage,
+                                         int m0, int n0, int z, int wm, int wn, int wave, int lane) {
+  if constexpr (kFlatEpilogue<C>) {
+    static_assert(!kFlatEpilogue<C> || EPI == CFHIP_EPI_NONE, "80-column wave tiles: bias / bf16 output / split-K slabs only");
+    epilogue_flat<C>(p, acc, stage, m0, n0, z, wm, wn, wave, lane);
+  } else {
+    epilogue_std<EPI, C>(p, acc, stage, m0, n0, z, wm, wn, wave, lane);
   }
 }
 

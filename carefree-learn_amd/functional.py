@@ -903,19 +903,32 @@ class AttentionWeightsFn(Function):
     """(output, weights) for separately projected q / k / v — the reference's slow path `require_weights=True` /
     `customize_sdp` (attentions.py:256-268).  The output is the fused kernels' (scale = 1 / `scaling`: the slow path is
     the one place where the reference honours `qk_scale`); the weights f32 [B, H, Tq, Tk] are rebuilt from the saved
-    log-sum-exp (`cfhip_attn_probs`); a gradient on the weights reaches q and k through `cfhip_attn_probs_bwd`."""
+    log-sum-exp (`cfhip_attn_probs`); a gradient on the weights reaches q and k through `cfhip_attn_probs_bwd`.
+    `dropout_p` > 0 (training, attentions.py:263-264: `F.dropout(weights)` BEFORE `_weights_callback` and the product with
+    v): the output comes from the dropout forms of the fused kernels and the returned weights are the softmax times the SAME
+    Philox keep-mask (`cfhip_attn_dropout_mask` of the call's (seed, offset)) / (1 - p): what multiplied v, as in the reference."""
 
     @staticmethod
     def forward(ctx: Any, q: Tensor, k: Tensor, v: Tensor, num_heads: int, keep_mask: Optional[Tensor], causal: bool,
-                head_dim: int, scale: float):
+                head_dim: int, scale: float, dropout_p: float = 0.0):
         q, k, v = (t if t.dtype == bf16 else ops.to_bf16(t.float().contiguous()) for t in (q, k, v))
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        o, lse = ops.attn_fwd(q, k, v, num_heads, mask=keep_mask, causal=causal, head_dim=head_dim, scale=scale)
+        ctx.drop = _take_attn_dropout(dropout_p, q.shape[0], num_heads, q.shape[1], k.shape[1])
+        o, lse = ops.attn_fwd(q, k, v, num_heads, mask=keep_mask, causal=causal, head_dim=head_dim, scale=scale, **ctx.drop)
         probs = ops.attn_probs(q, k, lse, num_heads, mask=keep_mask, causal=causal, head_dim=head_dim, scale=scale)
+        if ctx.drop:
+            probs.mul_(AttentionWeightsFn._drop_factor(ctx.drop, probs))
         ctx.save_for_backward(q, k, v, o, lse, keep_mask)
         ctx.num_heads, ctx.causal, ctx.head_dim, ctx.scale = num_heads, causal, head_dim, scale
         ctx.set_materialize_grads(False)
         return o, probs
+
+    @staticmethod
+    def _drop_factor(drop: dict, like: Tensor) -> Tensor:
+        """keep-mask / (1 - p) of the call, f32 [B, H, Tq, Tk]; p is quantised to 1 / 256 by the kernels (ops.attn_dropout_p)"""
+        b, h, tq, tk = like.shape
+        keep = ops.attn_dropout_mask(b, h, tq, tk, drop["dropout_p"], drop["seed"], drop["offset"], device=like.device)
+        return keep.to(f32).mul_(1.0 / (1.0 - ops.attn_dropout_p(drop["dropout_p"])))
 
     @staticmethod
     def backward(ctx: Any, d_o: Optional[Tensor], d_p: Optional[Tensor]):  # type: ignore
@@ -925,18 +938,21 @@ class AttentionWeightsFn(Function):
         if d_o is not None:
             d_o = (d_o if d_o.dtype == bf16 else ops.to_bf16(d_o.float())).contiguous()
             dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-            ops.attn_bwd(q, k, v, o, d_o, lse, ctx.num_heads, dq=dq, dk=dk, dv=dv, **kw)
+            ops.attn_bwd(q, k, v, o, d_o, lse, ctx.num_heads, dq=dq, dk=dk, dv=dv, **kw, **ctx.drop)
         if d_p is not None:
-            dq2, dk2 = ops.attn_probs_bwd(q, k, lse, d_p.float().contiguous(), ctx.num_heads, **kw)
+            d_p = d_p.float().contiguous()
+            if ctx.drop:  # weights = softmax * keep / (1 - p): the gradient on the softmax is the gradient on the weights times the same factor
+                d_p = d_p * AttentionWeightsFn._drop_factor(ctx.drop, d_p)
+            dq2, dk2 = ops.attn_probs_bwd(q, k, lse, d_p, ctx.num_heads, **kw)
             dq = dq2 if dq is None else ops.add(dq, dq2)
             dk = dk2 if dk is None else ops.add(dk, dk2)
-        return dq, dk, dv, None, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None, None
 
 
 def attention_with_weights(q: Tensor, k: Tensor, v: Tensor, num_heads: int, keep_mask: Optional[Tensor] = None,
-                           causal: bool = False, head_dim: int = 64, scale: Optional[float] = None):
+                           causal: bool = False, head_dim: int = 64, scale: Optional[float] = None, dropout_p: float = 0.0):
     return _apply(AttentionWeightsFn, q, k, v, num_heads, keep_mask, causal, head_dim,
-                                    1.0 / math.sqrt(float(head_dim)) if scale is None else float(scale))
+                                    1.0 / math.sqrt(float(head_dim)) if scale is None else float(scale), float(dropout_p))
 
 
 def _take_attn_dropout(dropout_p: float, b: int, num_heads: int, tq: int, tk: int) -> dict:

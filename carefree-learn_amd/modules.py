@@ -460,9 +460,6 @@ class Attention(Module):
         if slow:
             if type(self)._get_weights is not Attention._get_weights or type(self)._weights_callback is not Attention._weights_callback:
                 raise NotImplementedError("a custom `_get_weights` / `_weights_callback` replaces the softmax the HIP kernels fuse")
-            if drop > 0.0:
-                raise NotImplementedError("returned attention weights with dropout > 0 in training mode (the kernels' Philox mask is "
-                                          "not applied to the materialised weights yet)")
         if self.head_dim % 8 != 0 or self.head_dim > 192:
             raise NotImplementedError(f"HIP attention kernels take head_dim = a multiple of 8 up to 192, got {self.head_dim}")
         qkv_inp = q, k, v
@@ -477,7 +474,8 @@ class Attention(Module):
             if packed is not None:
                 d = packed.shape[-1] // 3
                 qq, kk, vv = packed[..., :d], packed[..., d:2 * d], packed[..., 2 * d:]
-            out, weights = HF.attention_with_weights(qq, kk, vv, self.num_heads, keep, False, self.head_dim, 1.0 / self.scaling)
+            # training dropout (attentions.py:263-264) acts on the weights that are returned AND multiply v: same Philox mask in both
+            out, weights = HF.attention_with_weights(qq, kk, vv, self.num_heads, keep, False, self.head_dim, 1.0 / self.scaling, drop)
             return AttentionOutput(self.out_linear(out, residual=residual), weights)
         if self.head_dim != 64:
             # the general-head_dim kernels (`cfhip_attn_*_dh`, what CrossAttention uses) take separate q / k / v views

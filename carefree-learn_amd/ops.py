@@ -522,6 +522,11 @@ def attn_dropout_blocks(b: int, num_heads: int, tq: int, tk: int) -> int:
     return b * num_heads * ((tq + 3) // 4) * ((tk + 3) // 4)
 
 
+def attn_dropout_p(dropout_p: float) -> float:
+    """the probability the kernels apply: p quantised to 1 / 256 (csrc/attn.hip set_dropout: thresh = lrintf(256 p), clamped to 1 .. 255)"""
+    return min(max(int(round(float(dropout_p) * 256.0)), 1), 255) / 256.0
+
+
 def attn_dropout_mask(b: int, num_heads: int, tq: int, tk: int, dropout_p: float, seed: int, offset: int,
                       device: object = "cuda") -> Tensor:
     """uint8 [B, H, Tq, Tk] (1 = keep): the mask `attn_fwd(..., dropout_p, seed, offset)` applies"""

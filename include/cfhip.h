@@ -63,6 +63,11 @@ const char* cfhip_last_error(void);
  *   "grouped_variant" ring of cfhip_gemm_bf16_grouped_tn: 0 (default) 5 slots, DMA 3 K-steps ahead; 1: 4 slots, 2 ahead;
  *                     2: 5 slots, 2 ahead; 3 / 4: DMA placement variants of 0.  +16: bias gradients reduced by the first tile
  *                     column alone instead of shared by the tile row; +32: row-major tile order (both: A/B runs);
+ *   "conv_form"       tile form of cfhip_conv3x3_nhwc_bf16: -1 (default) = by shape (128x160x64 on four waves where 160-column tiles cover
+ *                     Cout with at most 1/8 of waste — the UNet's 320 / 640 / 960 / 1280 / 1920 / 2560 — and Cin % 64 == 0; otherwise
+ *                     the round-3 table); -2: the round-3 table everywhere; 0: 256x128x32 two-group kernel, 1: 128x128x32, 2: 128x160x32, 3: 128x160x64
+ *   "conv_split"      -1 (default): the K split cfhip_conv3x3_workspace sizes for; n >= 1 forces n (A/B runs; size the workspace
+ *                     with the option already set)
  * Unknown names are an error.  (The phase-timing ablation masks "gemm_ablate" / "attn_ablate" of round 1 are
  * not part of this library any more: they exist only in the -DCFHIP_ABLATE build that tools/build_variant.sh
  * writes to tools/libcfhip_ablate.so, selected by the tools through CFHIP_LIB.) */

@@ -494,6 +494,73 @@ def test_attention_module_returns_weights_like_the_reference_slow_path():
         Sparse(64, 1, is_self_attention=True).to(DEV)(x[..., :64], x[..., :64], x[..., :64])
 
 
+@pytest.mark.parametrize("dh,tq,tk,h", [(64, 37, 37, 2), (40, 130, 77, 2), (64, 300, 280, 1)])
+def test_returned_weights_with_training_dropout(dh, tq, tk, h):
+    """The reference's slow path in training mode (attentions.py:263-267): `weights = F.dropout(softmax)`, `output = weights @ v`,
+    and the DROPPED weights are what is returned.  Here the output comes from the fused dropout kernels and the weights from
+    cfhip_attn_probs times the same Philox keep-mask: checked against fp32 autograd given that mask (exported by
+    cfhip_attn_dropout_mask for the (seed, offset) the call drew) — output, weights, and the gradients of a loss on BOTH."""
+    from cflearn_amd import functional as HF
+
+    b, p = 2, 0.3
+    p_eff = ops.attn_dropout_p(p)
+    assert p_eff == 77 / 256
+    g = torch.Generator().manual_seed(dh + tq)
+    q, k, v = (torch.randn(b, t, h * dh, generator=g).to(torch.bfloat16) for t in (tq, tk, tk))
+    d_o = torch.randn(b, tq, h * dh, generator=g).to(torch.bfloat16)
+    d_w = torch.randn(b, h, tq, tk, generator=g)
+    ops.PhiloxState.manual_seed(99)
+    seed, off0 = ops.PhiloxState.seed, ops.PhiloxState.offset
+    leaves = [t.to(DEV).requires_grad_(True) for t in (q, k, v)]
+    o, w = HF.attention_with_weights(*leaves, h, None, False, dh, None, p)
+    assert ops.PhiloxState.offset - off0 == ops.attn_dropout_blocks(b, h, tq, tk)
+    keep = ops.attn_dropout_mask(b, h, tq, tk, p, seed, off0).cpu()
+    (o.float() * d_o.to(DEV).float()).sum().add((w * d_w.to(DEV)).sum()).backward()
+    # fp32 reference with the same mask
+    ref = [t.float().clone().requires_grad_(True) for t in (q, k, v)]
+    hd = lambda t, n: t.reshape(b, n, h, dh).permute(0, 2, 1, 3)  # noqa: E731
+    sm = torch.softmax(hd(ref[0], tq) @ hd(ref[1], tk).transpose(-1, -2) / math.sqrt(dh), -1)
+    w_ref = sm * (keep.float() / (1.0 - p_eff))
+    o_ref = (w_ref @ hd(ref[2], tk)).permute(0, 2, 1, 3).reshape(b, tq, h * dh)
+    ((o_ref * d_o.float()).sum() + (w_ref * d_w).sum()).backward()
+    assert torch.count_nonzero(w[(keep == 0).to(DEV)]) == 0
+    assert_close(w, w_ref.detach(), 3e-3, "dropped weights")
+    assert_close(o, o_ref.detach(), 1e-2, "output of the dropped weights")
+    for name, got, want in zip("qkv", leaves, ref):
+        assert_close(got.grad, want.grad, 2e-2, f"d{name} (loss on output + weights, dropout)")
+    # eval mode / p = 0: no counters drawn, plain weights
+    off1 = ops.PhiloxState.offset
+    _, w0 = HF.attention_with_weights(*(t.detach() for t in leaves), h, None, False, dh, None, 0.0)
+    assert ops.PhiloxState.offset == off1
+    assert_close(w0.sum(-1), torch.ones(b, h, tq), 1e-3, "undropped rows sum to one")
+
+
+def test_attention_module_returns_dropped_weights_in_training_mode():
+    """modules.Attention(dropout > 0).train()(…, require_weights=True) no longer raises: the module's weights are
+    zero exactly where its own mask dropped them, rows average to one over masks, and eval mode returns the plain softmax."""
+    import cflearn_amd as C
+
+    torch.manual_seed(4)
+    att = C.modules.Attention(128, 2, is_self_attention=True, dropout=0.25).to(DEV)
+    x = torch.randn(2, 41, 128, device=DEV)
+    att.eval()
+    w_eval = att(x, x, x, require_weights=True).weights
+    assert_close(w_eval.sum(-1), torch.ones(2, 2, 41), 1e-3, "eval rows")
+    att.train()
+    ops.PhiloxState.manual_seed(7)
+    seed, off0 = ops.PhiloxState.seed, ops.PhiloxState.offset
+    xr = x.clone().requires_grad_(True)
+    out = att(xr, xr, xr, require_weights=True)
+    keep = ops.attn_dropout_mask(2, 2, 41, 41, 0.25, seed, off0)
+    assert torch.count_nonzero(out.weights[keep == 0]) == 0
+    assert_close(out.weights, w_eval * keep.float() / (1.0 - ops.attn_dropout_p(0.25)), 3e-3, "train weights = eval weights x mask / (1 - p)")
+    (out.output.float().sum() + out.weights.square().sum()).backward()
+    assert torch.isfinite(xr.grad).all() and all(p.grad is not None and torch.isfinite(p.grad).all() for p in att.parameters())
+    ops.PhiloxState.manual_seed(7)
+    again = att(x, x, x, require_weights=True)
+    assert torch.equal(again.weights, out.weights) and torch.equal(again.output, out.output)
+
+
 def test_returned_weights_at_a_unet_token_count_rows_sum_to_one_and_match_the_output():
     """size-independent properties of `attention_with_weights` at T = 4 096, head_dim 40 (a UNet level): every row of the
     returned weights sums to one, and weights @ v (fp32 on the host side of the check, a row sample) reproduces the fused

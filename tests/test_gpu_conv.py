@@ -288,6 +288,42 @@ def test_implicit_conv3x3_matches_fp32_reference_and_im2row_route(shape):
     assert_close(yi, ref, 4e-3, "corner impulse")
 
 
+@pytest.mark.parametrize("form", [0, 1, 2, 3])
+def test_conv3x3_every_tile_form_and_split_vs_fp32(form):
+    """Every tile form of cfhip_conv3x3_nhwc_bf16 (csrc/gemm.hip conv_plan: 256x128x32 / 128x128x32 / the 80-column-per-wave 128x160
+    tiles of round 6 with 32- and 64-channel K-steps — B image padded to whole DMA instructions, 16 x 80 epilogue strips handed out
+    as a flat list of 16-byte pieces; form 3 falls back to 2 where Cin % 64 != 0),
+    forced through the `conv_form` / `conv_split` options, against torch's fp32 conv2d on the same bf16 operands: ragged pixel counts,
+    channel counts that end inside a tile / inside a wave's 80 columns, with and without bias, whole-K and split reductions (the
+    split path writes f32 slabs through the same flat epilogue)."""
+    shapes = [(1, 32, 320, 20, 24), (2, 64, 168, 13, 9), (1, 96, 488, 37, 21), (3, 32, 24, 5, 7), (1, 320, 640, 16, 16)]
+    g = torch.Generator().manual_seed(form + 11)
+    try:
+        for b, cin, cout, h, w in shapes:
+            x = bf16_round(torch.randn(b, cin, h, w, generator=g))
+            wt = bf16_round(torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5))
+            bias = torch.randn(cout, generator=g)
+            ref = torch.nn.functional.conv2d(x, wt, bias, stride=1, padding=1).permute(0, 2, 3, 1).reshape(b * h * w, cout)
+            x_rows = x.permute(0, 2, 3, 1).reshape(b * h * w, cin).contiguous().to(DEV).to(torch.bfloat16)
+            wk = ops.conv3x3_pack_filters(wt.to(DEV).to(torch.bfloat16), False)
+            ops.set_option("conv_form", form)
+            outs = {}
+            for split in (1, 3, -1):
+                ops.set_option("conv_split", split)
+                for bi in (bias.to(DEV), None):
+                    y = ops.conv3x3_nhwc(x_rows, wk, bi, b, h, w)
+                    want = ref if bi is not None else ref - bias
+                    assert_close(y, want, 4e-3, f"form {form} split {split} {(b, cin, cout, h, w)} bias {bi is not None}")
+                    outs[(split, bi is not None)] = y
+            # whole-K results do not depend on the tile form: the K order inside a tile is the same in every form
+            ops.set_option("conv_form", 1)
+            ops.set_option("conv_split", 1)
+            assert torch.equal(ops.conv3x3_nhwc(x_rows, wk, bias.to(DEV), b, h, w), outs[(1, True)])
+    finally:
+        ops.set_option("conv_form", -1)
+        ops.set_option("conv_split", -1)
+
+
 def test_conv3x3_filter_packing_bit_exact():
     """cfhip_conv3x3_pack_filters: pure data movement, compared bit for bit with the permutes it replaces."""
     g = torch.Generator().manual_seed(5)
