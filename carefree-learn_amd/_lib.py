@@ -56,6 +56,9 @@ SIGNATURES = {
         c_int,
         [_P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int64, c_int64, c_int64, c_int, _P, c_size_t, _P, _P],
     ),
+    "cfhip_layernorm4d_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "cfhip_layernorm4d_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
+    "cfhip_layernorm4d_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
     "cfhip_split_f32_bf16x2": (c_int, [_P, _P, _P, c_int64, _P]),
     "cfhip_join_bf16x2_f32": (c_int, [_P, _P, _P, c_int64, _P]),
     "cfhip_attn_fwd": (

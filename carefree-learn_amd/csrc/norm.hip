@@ -715,3 +715,211 @@ extern "C" int cfhip_layernorm_bwd_reduce(void* workspace, int rows, int D, floa
   CFHIP_REQUIRE(workspace != nullptr && rows > 0 && D > 0 && (dgamma != nullptr || dbeta != nullptr), "layernorm_bwd_reduce: bad arguments");
   return ln_bwd_reduce(reinterpret_cast<float*>(workspace), rows, D, dgamma, dbeta, accumulate, reinterpret_cast<hipStream_t>(stream));
 }
+
+// ---- the reference's 4-D `LN` (norms.py:30-46; NormFactory("layer_norm") inside conv blocks) ----------------------------------------
+// y = (x - mean_b) / (std_b + eps) * w[c] + b[c] on [B, C, H, W]: ONE mean and one UNBIASED standard deviation per sample over all
+// C*H*W elements, eps added to the standard deviation (not inside a square root), per-channel affine.  Not a GroupNorm with one group
+// (biased variance, eps under the root) — its own kernels.  Off every benchmarked path (no named configuration uses it): written for
+// clarity and a fixed summation order (slice partials in double, block tree reduces), not for the last GB/s.
+//   forward:  ln4d_partial (sum, sum of squares per slice) -> ln4d_finish (mean, std per sample) -> ln4d_apply
+//   backward: g = dy * w[c];  dx = inv g - inv S1 / n - (x - mean) inv^2 S2 / ((n - 1) std),  S1 = sum g, S2 = sum g (x - mean),
+//             inv = 1 / (std + eps);  dw[c] = sum_{b, hw} dy (x - mean_b) inv_b,  db[c] = sum dy   (one workgroup per channel)
+namespace {
+
+constexpr int LN4_THREADS = 256;
+constexpr int LN4_MAX_SLICES = 64;
+
+__device__ __forceinline__ double block_sum_f64(double v, double* sh) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int off = LN4_THREADS / 2; off > 0; off >>= 1) {
+    if (t < off) sh[t] += sh[t + off];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// MODE 0: (sum x, sum x^2);  MODE 1: (sum g, sum g (x - mean)) with g = dy * w[c]
+template <int MODE>
+__global__ __launch_bounds__(LN4_THREADS) void ln4d_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                     const float* __restrict__ w, const float* __restrict__ mean,
+                                                                     double* __restrict__ partial, long n, int HW, int slices) {
+  __shared__ double sh[LN4_THREADS];
+  const int b = blockIdx.y, s = blockIdx.x;
+  const long per = (n + slices - 1) / slices;
+  const long lo = (long)s * per, hi = min(n, lo + per);
+  const bf16_t* xb = x + (long)b * n;
+  const bf16_t* gb = MODE == 1 ? dy + (long)b * n : nullptr;
+  const float m = MODE == 1 ? mean[b] : 0.f;
+  double a0 = 0.0, a1 = 0.0;
+  for (long base = lo; base < hi; base += (long)LN4_THREADS * 64) {  // f32 inside a 64-element run, double across runs
+    float f0 = 0.f, f1 = 0.f;
+    for (int r = 0; r < 64; ++r) {
+      const long i = base + (long)r * LN4_THREADS + threadIdx.x;
+      if (i >= hi) break;
+      const float xv = bf16_to_f32(xb[i]);
+      if (MODE == 0) {
+        f0 += xv;
+        f1 = fmaf(xv, xv, f1);
+      } else {
+        float g = bf16_to_f32(gb[i]);
+        if (w != nullptr) g *= w[(int)(i / HW)];
+        f0 += g;
+        f1 = fmaf(g, xv - m, f1);
+      }
+    }
+    a0 += (double)f0;
+    a1 += (double)f1;
+  }
+  const double s0 = block_sum_f64(a0, sh), s1 = block_sum_f64(a1, sh);
+  if (threadIdx.x == 0) {
+    partial[((long)b * slices + s) * 2] = s0;
+    partial[((long)b * slices + s) * 2 + 1] = s1;
+  }
+}
+
+// MODE 0: partials -> mean[b], std[b] (unbiased);  MODE 1: partials -> coef[b] = (inv S1 / n, inv^2 S2 / ((n - 1) std))
+template <int MODE>
+__global__ void ln4d_finish_kernel(const double* __restrict__ partial, float* __restrict__ out0, float* __restrict__ out1,
+                                   const float* __restrict__ stdv, long n, int slices, int B, float eps) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int s = 0; s < slices; ++s) {
+    s0 += partial[((long)b * slices + s) * 2];
+    s1 += partial[((long)b * slices + s) * 2 + 1];
+  }
+  if (MODE == 0) {
+    const double mean = s0 / (double)n;
+    const double var = (s1 - (double)n * mean * mean) / (double)(n - 1);  // torch.std: Bessel's correction (n = 1: NaN, as there)
+    out0[b] = (float)mean;
+    out1[b] = (float)sqrt(var > 0.0 ? var : (n > 1 ? 0.0 : var));
+  } else {
+    const double sd = (double)stdv[b], inv = 1.0 / (sd + (double)eps);
+    out0[b] = (float)(inv * s0 / (double)n);
+    out1[b] = sd > 0.0 ? (float)(inv * inv * s1 / ((double)(n - 1) * sd)) : 0.f;
+  }
+}
+
+// forward: y = (x - mean) inv w[c] + b[c];  backward (BWD): dx = inv g - c1 - (x - mean) c2
+template <bool BWD>
+__global__ __launch_bounds__(LN4_THREADS) void ln4d_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                                                   const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                                   const float* __restrict__ c1, const float* __restrict__ c2,
+                                                                   bf16_t* __restrict__ out, long n, int HW, long total, float eps) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / n);
+    const int c = (int)((i - (long)b * n) / HW);
+    const float m = mean[b], inv = 1.0f / (stdv[b] + eps);
+    const float xv = bf16_to_f32(x[i]);
+    float r;
+    if (!BWD) {
+      r = (xv - m) * inv;
+      if (w != nullptr) r = fmaf(r, w[c], bias[c]);
+    } else {
+      float g = bf16_to_f32(dy[i]);
+      if (w != nullptr) g *= w[c];
+      r = fmaf(inv, g, -c1[b]) - (xv - m) * c2[b];
+    }
+    out[i] = f32_to_bf16(r);
+  }
+}
+
+// one workgroup per channel: dw[c] (+)= sum_{b, hw} dy xhat, db[c] (+)= sum dy
+__global__ __launch_bounds__(LN4_THREADS) void ln4d_param_grad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                        const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                                        float* __restrict__ dw, float* __restrict__ db, int B, int C,
+                                                                        int HW, float eps, int accumulate) {
+  __shared__ double sh[LN4_THREADS];
+  const int c = blockIdx.x;
+  double a0 = 0.0, a1 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float m = mean[b], inv = 1.0f / (stdv[b] + eps);
+    const long base = ((long)b * C + c) * HW;
+    float f0 = 0.f, f1 = 0.f;
+    for (int i = threadIdx.x; i < HW; i += LN4_THREADS) {
+      const float g = bf16_to_f32(dy[base + i]);
+      f0 = fmaf(g, (bf16_to_f32(x[base + i]) - m) * inv, f0);
+      f1 += g;
+    }
+    a0 += (double)f0;
+    a1 += (double)f1;
+  }
+  const double s0 = block_sum_f64(a0, sh), s1 = block_sum_f64(a1, sh);
+  if (threadIdx.x == 0) {
+    dw[c] = accumulate ? dw[c] + (float)s0 : (float)s0;
+    db[c] = accumulate ? db[c] + (float)s1 : (float)s1;
+  }
+}
+
+int ln4d_slices(long n) {
+  long s = (n + 16383) / 16384;
+  return (int)(s < 1 ? 1 : (s > LN4_MAX_SLICES ? LN4_MAX_SLICES : s));
+}
+
+}  // namespace
+
+extern "C" size_t cfhip_layernorm4d_workspace(int B, int C, int HW) {
+  const long n = (long)C * HW;
+  return (size_t)B * ln4d_slices(n) * 2 * sizeof(double) + (size_t)B * 2 * sizeof(float);
+}
+
+extern "C" int cfhip_layernorm4d_fwd(const void* x, const float* weight, const float* bias, void* y, float* mean, float* stdv,
+                                     int B, int C, int HW, float eps, void* workspace, size_t workspace_bytes, void* stream) {
+  CFHIP_REQUIRE(x && y && mean && stdv, "layernorm4d_fwd: null operand");
+  CFHIP_REQUIRE(B > 0 && C > 0 && HW > 0, "layernorm4d_fwd: bad shape %d x %d x %d", B, C, HW);
+  CFHIP_REQUIRE((weight == nullptr) == (bias == nullptr), "layernorm4d_fwd: weight and bias come together");
+  CFHIP_REQUIRE(workspace != nullptr && workspace_bytes >= cfhip_layernorm4d_workspace(B, C, HW),
+                "layernorm4d_fwd: workspace of %zu bytes needed (cfhip_layernorm4d_workspace)", cfhip_layernorm4d_workspace(B, C, HW));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long n = (long)C * HW;
+  const int slices = ln4d_slices(n);
+  double* partial = reinterpret_cast<double*>(workspace);
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(x);
+  hipLaunchKernelGGL(ln4d_partial_kernel<0>, dim3(slices, B), dim3(LN4_THREADS), 0, s, xb, (const bf16_t*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, partial, n, HW, slices);
+  hipLaunchKernelGGL(ln4d_finish_kernel<0>, dim3((B + 63) / 64), dim3(64), 0, s, partial, mean, stdv, (const float*)nullptr, n, slices, B, eps);
+  const long total = (long)B * n;
+  int blocks = (int)((total + LN4_THREADS * 8L - 1) / (LN4_THREADS * 8L));
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(ln4d_apply_kernel<false>, dim3(blocks), dim3(LN4_THREADS), 0, s, xb, (const bf16_t*)nullptr, weight, bias, mean, stdv,
+                     (const float*)nullptr, (const float*)nullptr, reinterpret_cast<bf16_t*>(y), n, HW, total, eps);
+  CFHIP_CHECK_LAUNCH("layernorm4d_fwd");
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_layernorm4d_bwd(const void* dy, const void* x, const float* weight, const float* mean, const float* stdv, void* dx,
+                                     float* dweight, float* dbias, int accumulate_param_grads, int B, int C, int HW, float eps,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  CFHIP_REQUIRE(dy && x && mean && stdv, "layernorm4d_bwd: null operand");
+  CFHIP_REQUIRE(B > 0 && C > 0 && HW > 0, "layernorm4d_bwd: bad shape %d x %d x %d", B, C, HW);
+  CFHIP_REQUIRE((dweight == nullptr) == (dbias == nullptr), "layernorm4d_bwd: dweight and dbias come together");
+  CFHIP_REQUIRE(dx != nullptr || dweight != nullptr, "layernorm4d_bwd: nothing asked for");
+  CFHIP_REQUIRE(workspace != nullptr && workspace_bytes >= cfhip_layernorm4d_workspace(B, C, HW),
+                "layernorm4d_bwd: workspace of %zu bytes needed (cfhip_layernorm4d_workspace)", cfhip_layernorm4d_workspace(B, C, HW));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long n = (long)C * HW;
+  const int slices = ln4d_slices(n);
+  double* partial = reinterpret_cast<double*>(workspace);
+  float* coef = reinterpret_cast<float*>(partial + (size_t)B * slices * 2);
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(x);
+  const bf16_t* gb = reinterpret_cast<const bf16_t*>(dy);
+  if (dx != nullptr) {
+    hipLaunchKernelGGL(ln4d_partial_kernel<1>, dim3(slices, B), dim3(LN4_THREADS), 0, s, xb, gb, weight, mean, partial, n, HW, slices);
+    hipLaunchKernelGGL(ln4d_finish_kernel<1>, dim3((B + 63) / 64), dim3(64), 0, s, partial, coef, coef + B, stdv, n, slices, B, eps);
+    const long total = (long)B * n;
+    int blocks = (int)((total + LN4_THREADS * 8L - 1) / (LN4_THREADS * 8L));
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(ln4d_apply_kernel<true>, dim3(blocks), dim3(LN4_THREADS), 0, s, xb, gb, weight, (const float*)nullptr, mean, stdv,
+                       coef, coef + B, reinterpret_cast<bf16_t*>(dx), n, HW, total, eps);
+  }
+  if (dweight != nullptr)
+    hipLaunchKernelGGL(ln4d_param_grad_kernel, dim3(C), dim3(LN4_THREADS), 0, s, xb, gb, mean, stdv, dweight, dbias, B, C, HW, eps,
+                       accumulate_param_grads);
+  CFHIP_CHECK_LAUNCH("layernorm4d_bwd");
+  return CFHIP_OK;
+}

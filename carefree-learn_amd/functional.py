@@ -822,6 +822,40 @@ class LayerNormFn(Function):
         return dx, gw, gb, None, None
 
 
+class LayerNorm4dFn(Function):
+    """The reference's custom `LN.forward` on 4-D inputs (norms.py:30-46): per-sample mean / unbiased std over C*H*W, eps added to the
+    standard deviation, per-channel affine — cfhip_layernorm4d_fwd / _bwd (csrc/norm.hip)."""
+
+    @staticmethod
+    def forward(ctx: Any, x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], eps: float) -> Tensor:
+        x2 = to_nchw(x if x.dtype == bf16 else ops.to_bf16(x.float().contiguous())).contiguous()
+        w = None if weight is None else weight.detach().float().contiguous().view(-1)
+        b = None if bias is None else bias.detach().float().contiguous().view(-1)
+        y, mean, std = ops.layernorm4d_fwd(x2, w, b, eps)
+        ctx.save_for_backward(x2, mean, std)
+        ctx.w, ctx.eps, ctx.affine = w, float(eps), weight is not None
+        ctx.shapes = (None if weight is None else weight.shape, None if bias is None else bias.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        x2, mean, std = ctx.saved_tensors
+        dy2 = to_nchw(dy if dy.dtype == bf16 else ops.to_bf16(dy.float().contiguous())).contiguous()
+        dw = db = None
+        want_pg = ctx.affine and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        if want_pg:
+            dw = torch.empty((x2.shape[1],), dtype=f32, device=x2.device)
+            db = torch.empty_like(dw)
+        dx = ops.layernorm4d_bwd(dy2, x2, ctx.w, mean, std, ctx.eps, want_dx=ctx.needs_input_grad[0], dweight=dw, dbias=db)
+        if want_pg:
+            dw, db = dw.view(ctx.shapes[0]), db.view(ctx.shapes[1])
+        return dx, dw if ctx.affine and ctx.needs_input_grad[1] else None, db if ctx.affine and ctx.needs_input_grad[2] else None, None
+
+
+def layer_norm_4d(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], eps: float) -> Tensor:
+    return _apply(LayerNorm4dFn, x, weight, bias, eps)
+
+
 def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float, out_f32: bool = False) -> Tensor:
     """`out_f32`: an f32 input gives an f32 output — for a LayerNorm whose output is the RESIDUAL STREAM of the blocks behind it
     (nn.LayerNorm keeps its input's dtype under the reference's autocast; a bf16 copy is what a matrix product wants)."""

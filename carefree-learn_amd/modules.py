@@ -219,6 +219,19 @@ class LayerNorm(nn.LayerNorm):
         return HF.layer_norm(net, self.weight, self.bias, self.eps, getattr(self, "out_f32", False))
 
 
+class LN(LayerNorm):
+    """`NormFactory("layer_norm").make(dim)` (reference norms.py:30-46, 84-85): nn.LayerNorm over the last dim for everything but a 4-D
+    input with a 1-D `normalized_shape`, where it is the reference's own per-sample normalisation — ONE mean and one UNBIASED standard
+    deviation over C*H*W, `(x - mean) / (std + eps)`, per-channel affine (`cfhip_layernorm4d_*`).  State keys `weight`, `bias`."""
+
+    def forward(self, net: Tensor) -> Tensor:  # type: ignore
+        if net.dim() != 4 or len(self.normalized_shape) != 1:
+            return super().forward(net)
+        if self.elementwise_affine:
+            return HF.layer_norm_4d(net, self.weight, self.bias, self.eps)
+        return HF.layer_norm_4d(net, None, None, self.eps)
+
+
 class _BatchNormMixin:
     """nn.BatchNorm{1,2}d semantics (reference norms.py:20-27,90-93) on `cfhip_batchnorm_fwd/bwd`: training
     mode normalises with the batch statistics and updates running_mean / running_var (unbiased) /
@@ -317,6 +330,9 @@ class NormFactory:
         if self.norm_type == "layer":
             kw = update_dict(kwargs, {"eps": 1.0e-6})
             return LayerNorm(*args, **kw)
+        if self.norm_type == "layer_norm":
+            kw = update_dict(kwargs, {"eps": 1.0e-6})
+            return LN(*args, **kw)
         if self.norm_type == "batch":
             kw = update_dict(kwargs, {"affine": True, "track_running_stats": True})
             return BatchNorm2d(*args, **kw)

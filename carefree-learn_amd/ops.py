@@ -288,6 +288,44 @@ def layernorm_fwd(
     return y, mean, rstd
 
 
+def layernorm4d_fwd(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], eps: float) -> Tuple[Tensor, Tensor, Tensor]:
+    """The reference's 4-D `LN` (norms.py:30-46) on a contiguous bf16 [B, C, H, W]: per-sample mean / UNBIASED std over C*H*W,
+    y = (x - mean) / (std + eps) * weight[c] + bias[c].  Returns (y bf16, mean f32 [B], std f32 [B])."""
+    _need(x, bf16, "x")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("cfhip layernorm4d_fwd: a contiguous [B, C, H, W] tensor is expected")
+    if (weight is None) != (bias is None):
+        raise ValueError("cfhip layernorm4d_fwd: weight and bias come together")
+    b, c, h, w = x.shape
+    lib = _lib.load()
+    nbytes = lib.cfhip_layernorm4d_workspace(b, c, h * w)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    y = torch.empty_like(x)
+    mean = torch.empty((b,), dtype=f32, device=x.device)
+    std = torch.empty((b,), dtype=f32, device=x.device)
+    _lib.check(lib.cfhip_layernorm4d_fwd(x.data_ptr(), _p(weight), _p(bias), y.data_ptr(), mean.data_ptr(), std.data_ptr(), b, c, h * w,
+                                         float(eps), ws.data_ptr(), nbytes, _stream()), "layernorm4d_fwd")
+    return y, mean, std
+
+
+def layernorm4d_bwd(dy: Tensor, x: Tensor, weight: Optional[Tensor], mean: Tensor, std: Tensor, eps: float, *, want_dx: bool = True,
+                    dweight: Optional[Tensor] = None, dbias: Optional[Tensor] = None, accumulate: bool = False) -> Optional[Tensor]:
+    """dx bf16 (or None), dweight / dbias f32 [C] (+)= in place when given"""
+    _need(dy, bf16, "dy")
+    _need(x, bf16, "x")
+    if dy.shape != x.shape or not dy.is_contiguous() or not x.is_contiguous():
+        raise ValueError("cfhip layernorm4d_bwd: dy and x must be contiguous [B, C, H, W] of one shape")
+    b, c, h, w = x.shape
+    lib = _lib.load()
+    nbytes = lib.cfhip_layernorm4d_workspace(b, c, h * w)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    dx = torch.empty_like(x) if want_dx else None
+    _lib.check(lib.cfhip_layernorm4d_bwd(dy.data_ptr(), x.data_ptr(), _p(weight), mean.data_ptr(), std.data_ptr(), _p(dx), _p(dweight),
+                                         _p(dbias), int(accumulate), b, c, h * w, float(eps), ws.data_ptr(), nbytes, _stream()),
+               "layernorm4d_bwd")
+    return dx
+
+
 def layernorm_bwd(
     dy: Tensor,
     x: Tensor,

@@ -190,6 +190,17 @@ int cfhip_layernorm_bwd2(const void* dy, const void* x, int x_is_f32, const floa
                          float* dgamma, float* dbeta, int M, int D, int64_t dy_row_stride, int64_t x_row_stride,
                          int64_t dx_row_stride, int accumulate_param_grads, void* workspace, size_t workspace_bytes,
                          int* rows_out, void* stream);
+/* The reference's 4-D `LN` (modules/core/norms.py:30-46: NormFactory("layer_norm") on [B, C, H, W]): y = (x - mean_b) / (std_b + eps) *
+ * weight[c] + bias[c], ONE mean and one UNBIASED standard deviation per sample over all C*H*W elements, eps added to the standard
+ * deviation.  x / y / dy / dx bf16 NCHW (contiguous); weight / bias f32 [C] or both NULL (elementwise_affine = False); mean / std f32 [B]
+ * written by the forward, read by the backward.  dx == NULL: parameter gradients only; dweight == dbias == NULL: dx only.
+ * workspace >= cfhip_layernorm4d_workspace(B, C, HW) bytes.  Fixed summation order: results are reproducible bit for bit. */
+size_t cfhip_layernorm4d_workspace(int B, int C, int HW);
+int cfhip_layernorm4d_fwd(const void* x, const float* weight, const float* bias, void* y, float* mean, float* std, int B, int C,
+                          int HW, float eps, void* workspace, size_t workspace_bytes, void* stream);
+int cfhip_layernorm4d_bwd(const void* dy, const void* x, const float* weight, const float* mean, const float* std, void* dx,
+                          float* dweight, float* dbias, int accumulate_param_grads, int B, int C, int HW, float eps, void* workspace,
+                          size_t workspace_bytes, void* stream);
 /* the two ends of that stream: f32 -> (hi, lo) and (hi, lo) -> f32 = hi + lo (exact in f32) */
 int cfhip_split_f32_bf16x2(const float* src, void* hi, void* lo, int64_t n, void* stream);
 int cfhip_join_bf16x2_f32(const void* hi, const void* lo, float* dst, int64_t n, void* stream);

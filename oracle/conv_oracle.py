@@ -5,7 +5,7 @@ oracle/gen_golden.py; nothing under carefree-learn_amd/ may import it).
 Each function cites the reference lines it restates (relative to /root/reference/cflearn/).  The
 restatement is pinned: `oracle/gen_golden.py` checks every function against the reference's own
 modules (imported through oracle/refharness) before it writes the fixtures under tests/golden/
-(conv2d.pt, batchnorm.pt, mnist_clf.pt, fcnn.pt).
+(conv2d.pt, batchnorm.pt, mnist_clf.pt, fcnn.pt, layernorm4d.pt).
 """
 from typing import Dict, Optional, Tuple
 
@@ -24,6 +24,23 @@ def bf16_round(t: Tensor) -> Tensor:
 
 def _id(t: Tensor) -> Tensor:
     return t
+
+
+def layer_norm_4d(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], eps: float = 1.0e-6) -> Tensor:
+    """The reference's `LN.forward` on a 4-D input (modules/core/norms.py:30-46; built by NormFactory("layer_norm"), whose default
+    config injects eps = 1e-6, norms.py:118-119): ONE mean and one UNBIASED standard deviation per sample over all C*H*W elements
+    (torch.std's default Bessel correction), eps added to the standard deviation, then the per-channel affine.  Sums written out
+    so that no torch reduction shortcut stands between the formula and the result."""
+    b = x.shape[0]
+    flat = x.reshape(b, -1)
+    n = flat.shape[1]
+    mean = flat.sum(1) / n
+    centred = flat - mean[:, None]
+    std = torch.sqrt((centred * centred).sum(1) / (n - 1))
+    y = (x - mean.view(b, 1, 1, 1)) / (std.view(b, 1, 1, 1) + eps)
+    if weight is not None:
+        y = y * weight.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    return y
 
 
 def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int = 1, padding: int = 0,

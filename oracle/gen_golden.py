@@ -75,6 +75,29 @@ def gen_layernorm(ref) -> None:
     )
 
 
+def gen_layernorm4d(ref) -> None:
+    """the reference's own `LN` on [B, C, H, W] (norms.py:30-46), batch 3 and batch 1 (its `batch_size == 1` branch), affine and not"""
+    torch.manual_seed(21)
+    cases = []
+    for (b, c, h, w), affine in (((3, 16, 9, 7), True), ((1, 32, 8, 8), True), ((2, 8, 5, 6), False)):
+        m = ref.NormFactory("layer_norm").make(c, elementwise_affine=affine)
+        assert type(m).__name__ == "LN" and m.eps == 1.0e-6
+        if affine:
+            with torch.no_grad():
+                m.weight.normal_(1.0, 0.3)
+                m.bias.normal_(0.0, 0.3)
+        x = (torch.randn(b, c, h, w) * 1.7 + 0.4).requires_grad_(True)
+        y = m(x)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        wt = m.weight.detach().clone() if affine else None
+        bs = m.bias.detach().clone() if affine else None
+        _check(f"layer_norm_4d {b}x{c}x{h}x{w}", CO.layer_norm_4d(x.detach(), wt, bs, m.eps), y.detach())
+        cases.append(dict(eps=m.eps, w=wt, b=bs, x=x.detach().clone(), y=y.detach().clone(), gy=gy, gx=x.grad.clone(),
+                          gw=m.weight.grad.clone() if affine else None, gb=m.bias.grad.clone() if affine else None))
+    torch.save(cases, os.path.join(OUT, "layernorm4d.pt"))
+
+
 def gen_attention(ref) -> None:
     """Self-attention with and without the 3-D bool mask (mask quirk, attentions.py:246-253)."""
     torch.manual_seed(13)
@@ -733,7 +756,7 @@ def main() -> None:
     ref = load_reference()
     torch.set_num_threads(4)
     only = sys.argv[1:]
-    for fn in (gen_linear, gen_layernorm, gen_sdp, gen_attention, gen_feedforward, gen_vit, gen_conv2d,
+    for fn in (gen_linear, gen_layernorm, gen_layernorm4d, gen_sdp, gen_attention, gen_feedforward, gen_vit, gen_conv2d,
                gen_batchnorm, gen_mnist_clf, gen_fcnn, gen_clip, gen_resblock, gen_spatial_transformer, gen_unet, gen_ddpm_schedule,
                gen_ml_encoder, gen_stochastic, gen_postnorm_interp, gen_unet_variants, gen_ddpm_objectives):
         if only and fn.__name__ not in only:

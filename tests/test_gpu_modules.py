@@ -54,6 +54,59 @@ def test_layernorm_golden(golden):
     assert_close(m.bias.grad, g["gb"], 1e-2, "ln gb")
 
 
+def test_layernorm_4d_golden(golden):
+    """`NormFactory("layer_norm")` on [B, C, H, W] — the reference's own per-sample `LN` (norms.py:30-46: unbiased std over C*H*W, eps
+    added to it), cfhip_layernorm4d_fwd / _bwd — against vectors generated from the reference's class (oracle/gen_golden.py
+    gen_layernorm4d): batch 3, its batch-1 branch, and the non-affine form; NCHW and channels_last inputs; bit-reproducible."""
+    for g in golden("layernorm4d.pt"):
+        affine = g["w"] is not None
+        c = g["x"].shape[1]
+        m = C.NormFactory("layer_norm").make(c, elementwise_affine=affine).to(DEV)
+        assert type(m).__name__ == "LN" and m.eps == g["eps"] and sorted(m.state_dict()) == (["bias", "weight"] if affine else [])
+        if affine:
+            with torch.no_grad():
+                m.weight.copy_(g["w"]); m.bias.copy_(g["b"])
+        x = g["x"].to(DEV).requires_grad_(True)
+        y = m(x)
+        assert y.dtype == torch.bfloat16 and y.shape == x.shape
+        assert_close(y, g["y"], 6e-3, "ln4d y")
+        y.backward(g["gy"].to(DEV).to(torch.bfloat16))
+        assert_close(x.grad, g["gx"], 2e-2, "ln4d gx")
+        if affine:
+            assert_close(m.weight.grad, g["gw"], 1e-2, "ln4d gw")
+            assert_close(m.bias.grad, g["gb"], 1e-2, "ln4d gb")
+        x2 = g["x"].to(DEV).to(memory_format=torch.channels_last)
+        with torch.no_grad():
+            assert torch.equal(m(x2), y.detach()) and torch.equal(m(g["x"].to(DEV)), y.detach())
+    # a 3-D input of the same module is the plain last-dim LayerNorm (norms.py:32-33)
+    m = C.NormFactory("layer_norm").make(64).to(DEV)
+    t = torch.randn(2, 5, 64, device=DEV)
+    assert_close(m(t), torch.nn.functional.layer_norm(t, (64,), m.weight, m.bias, m.eps), 6e-3, "LN on tokens")
+
+
+def test_layernorm_4d_at_a_unet_level_vs_oracle():
+    """[2, 320, 32, 32] (655 360 elements per sample: 40 slices) with an offset far from zero — the sums run in double across slices — against
+    the fp64 evaluation of the oracle's formula, forward and all three gradients"""
+    import conv_oracle as CO
+    from cflearn_amd import functional as HF
+
+    g = torch.Generator().manual_seed(8)
+    x = (torch.randn(2, 320, 32, 32, generator=g) * 0.7 + 3.0).to(torch.bfloat16)
+    w, b = torch.randn(320, generator=g) * 0.3 + 1.0, torch.randn(320, generator=g) * 0.3
+    gy = torch.randn(2, 320, 32, 32, generator=g).to(torch.bfloat16)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = CO.layer_norm_4d(xr, wr, br, 1.0e-6)
+    yr.backward(gy.double())
+    xd = x.to(DEV).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = HF.layer_norm_4d(xd, wd, bd, 1.0e-6)
+    y.backward(gy.to(DEV))
+    assert_close(y, yr.detach().float(), 4e-3, "ln4d y")
+    assert_close(xd.grad, xr.grad.float(), 6e-3, "ln4d gx")
+    assert_close(wd.grad, wr.grad.float(), 2e-3, "ln4d gw")
+    assert_close(bd.grad, br.grad.float(), 1e-4, "ln4d gb")
+
+
 @pytest.mark.parametrize("tag", ["r_nomask", "r_mask"])
 def test_attention_golden(golden, tag):
     """incl. the reference's 3-D mask layout quirk (attentions.py:246-253)."""

@@ -20,6 +20,24 @@ def test_layernorm(golden):
     assert max_abs(O.layer_norm(g["x"], g["w"], g["b"], g["eps"]), g["y"]) < TOL
 
 
+def test_layernorm_4d(golden):
+    """the reference's own 4-D `LN` (norms.py:30-46) incl. its batch-1 branch and the non-affine form: forward, and the gradients of the
+    restated formula under autograd against the reference's"""
+    import conv_oracle as CO
+
+    for g in golden("layernorm4d.pt"):
+        assert g["eps"] == 1.0e-6  # NormFactory("layer_norm") default (norms.py:118-119)
+        x = g["x"].clone().requires_grad_(True)
+        w = None if g["w"] is None else g["w"].clone().requires_grad_(True)
+        b = None if g["b"] is None else g["b"].clone().requires_grad_(True)
+        y = CO.layer_norm_4d(x, w, b, g["eps"])
+        assert max_abs(y.detach(), g["y"]) < TOL
+        y.backward(g["gy"])
+        assert max_abs(x.grad, g["gx"]) < 5 * TOL
+        if w is not None:
+            assert max_abs(w.grad, g["gw"]) < 20 * TOL and max_abs(b.grad, g["gb"]) < 20 * TOL
+
+
 def test_sdp(golden):
     g = golden("sdp.pt")
     assert max_abs(O.sdp_attention(g["q"], g["k"], g["v"]), g["y_nomask"]) < TOL
