@@ -11,8 +11,10 @@ read-modify-write pass per parameter and lets the gradient arena / DDP bucket vi
 (`optim.ParamArena`, `ddp.BucketedAllReduce`) be the kernels' destination.  Because autograd's own
 post-accumulate hooks do not fire for such parameters, `grad_ready_callbacks` is invoked instead.
 """
+import contextlib
 import os
 import threading
+import weakref
 from typing import Any, Callable, List, Optional, Tuple
 
 import math
@@ -632,6 +634,67 @@ def _linear_param_grads(dy2: Tensor, x2: Tensor, weight: Tensor, bias: Optional[
     return gw, gb
 
 
+# ---- fan-in links (round 6; VERDICT r5 #3b "fan-in adds inside the consumer") -----------------------------------------------------------
+# `net = f(LN(net)) + net` with the add riding in the last GEMM's epilogue (the UNet's SpatialTransformerBlock, three times per block):
+# in backward the GEMM's Function returns dY for the residual operand, the LayerNorm's returns dx, and autograd's engine sums the two with an
+# ATen add (45 launches and 1.7 GB of traffic per 64^2 x 8 step).  Inside a `fanin_links()` scope a LayerNormFn that sees a bf16 input
+# requiring a gradient leaves a link behind; a LinearFn whose `residual` operand IS that tensor takes the link, and in backward hands its dY
+# to the link instead of to autograd (None for the residual); the LayerNorm backward — which runs later, it sits upstream of that GEMM —
+# passes it to its kernel as `dx_add`: one rounding instead of two, no add launch.  The scope is the module's promise that the GEMM consumes
+# (a function of) that LayerNorm's output, i.e. that the LayerNorm backward runs after, and whenever, the GEMM's does.
+FANIN_LINKS = True  # (A/B: tools set the attribute)
+
+
+class FanInLink:
+    __slots__ = ("pending", "__weakref__")
+
+    def __init__(self) -> None:
+        self.pending: Optional[Tensor] = None
+
+
+class _FanInState(threading.local):
+    def __init__(self) -> None:
+        self.active = 0
+        self.entries: List[Tuple[Any, FanInLink]] = []
+
+
+_FANIN = _FanInState()
+
+
+@contextlib.contextmanager
+def fanin_links():
+    if not FANIN_LINKS:
+        yield
+        return
+    _FANIN.active += 1
+    try:
+        yield
+    finally:
+        _FANIN.active -= 1
+        if _FANIN.active == 0:
+            _FANIN.entries.clear()
+
+
+def _fanin_offer(ctx: Any, x: Tensor) -> None:
+    """LayerNormFn.forward: leave a link for the GEMM that will add `x` back"""
+    ctx.link = None
+    if _FANIN.active and x.dtype == bf16 and getattr(_TAPE, "tape", None) is None and ctx.needs_input_grad[0]:
+        ctx.link = FanInLink()
+        _FANIN.entries.append((weakref.ref(x), ctx.link))
+        del _FANIN.entries[:-4]
+
+
+def _fanin_take(residual: Optional[Tensor]) -> Optional[FanInLink]:
+    """LinearFn.forward: the link of the LayerNorm that read this very tensor, if one is waiting"""
+    if residual is None or not _FANIN.active or residual.dtype != bf16:
+        return None
+    for i, (ref, link) in enumerate(_FANIN.entries):
+        if ref() is residual:
+            del _FANIN.entries[i]
+            return link
+    return None
+
+
 class LinearFn(Function):
     """Replaces F.linear (reference customs.py:89, attentions.py:214) incl. backward."""
 
@@ -661,6 +724,7 @@ class LinearFn(Function):
         ctx.weight, ctx.bias = weight, bias
         ctx.n = n
         ctx.has_residual = residual is not None
+        ctx.link = _fanin_take(residual) if residual is not None and y.dtype == bf16 else None
         ctx.x_shape = x.shape
         ctx.in_dtype = x.dtype
         ctx.act = act
@@ -675,6 +739,9 @@ class LinearFn(Function):
             dy2 = dy2.contiguous()
         d_res = dy2.view(*ctx.x_shape[:-1], ctx.n) if ctx.has_residual and ctx.needs_input_grad[4] else None
         # (autograd casts d_res to the residual's dtype; the gradient stream itself stays bf16)
+        link = getattr(ctx, "link", None)
+        if link is not None and d_res is not None:  # the LayerNorm that read the residual operand adds it inside its backward kernel
+            link.pending, d_res = dy2, None
         if pre is not None:
             dy2 = ops.gelu_bwd(dy2, pre) if ctx.act == ACT_GELU else ops.quick_gelu_bwd(dy2, pre)
         gw = gb = None
@@ -791,6 +858,7 @@ class LayerNormFn(Function):
         ctx.save_for_backward(x2, gamma, mean, rstd)
         ctx.weight, ctx.bias = weight, bias
         ctx.x_shape, ctx.in_dtype = x.shape, x.dtype
+        _fanin_offer(ctx, x)
         return y.view(x.shape)
 
     @staticmethod
@@ -802,6 +870,13 @@ class LayerNormFn(Function):
         gw = gb = None
         res: list = []
         dx_add = getattr(ctx, "dx_add", None)  # inside a taped node: the gradient x has already received from its other readers
+        link = getattr(ctx, "link", None)
+        if link is not None and link.pending is not None:  # fan-in link: the dY of the GEMM that added x back (see fanin_links)
+            if dx_add is None and link.pending.shape == x2.shape:
+                dx_add, link.pending = link.pending, None
+            else:
+                raise RuntimeError("cfhip: a fan-in link delivered a gradient the LayerNorm backward cannot take "
+                                   f"({tuple(link.pending.shape)} for rows {tuple(x2.shape)})")
         if dx_add is not None:
             dx_add = dx_add.view(-1, dx_add.shape[-1])
         if wd and bd and write_param_grad_pair(
@@ -1382,7 +1457,7 @@ class Conv2dFn(Function):
             if ctx.implicit and not wgrad_implicit and weight.requires_grad:
                 x = ops.transpose_batched(x.view(b, h * w, cin)).view(b, cin, h, w)  # back to NCHW for the im2row route
             if weight.requires_grad and wgrad_implicit:
-                split = ops.pick_split_k(cp, 9 * cin, b * h * w)
+                split = ops.pick_split_k(cp, 9 * cin, b * h * w, conv=True)
 
                 def dw_implicit(out: Tensor, acc: bool) -> None:
                     if cp == cout:

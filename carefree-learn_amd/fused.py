@@ -82,7 +82,13 @@ _slice_streams: list = []  # streams of the backward's batch slices beyond the c
 # patch embedding) queue their weight gradients here too: flushed when LINEAR_DW_TILES tiles are waiting, together with the next
 # block-stack flush, or when the backward pass ends.  A flush of fewer than DW_MIN_TILES tiles falls back to one split-K GEMM
 # per gradient (whole-reduction 256 x 256 tiles on a handful of CUs would take longer than 128 x 128 split-K tiles on all).
-LINEAR_DW_TILES = 0  # (A/B closed: flat in rounds 3, 4 and 6 — profiles/r06/unet_variants_ab.txt; tools set the variable)  0: LinearFn computes its weight gradient on the spot (round-1/2 behaviour)
+# Measured flat on the 64^2 x 8 UNet in rounds 3, 4 and 6 (profiles/r06/unet_variants_ab.txt; 55.7 vs 55.4 ms again at the end of round 6) and
+# worth 4-5 ms of the 256^2 x 1 step (460.9 vs 464.8 ms with the level-0 layers alone, 459.6 vs 465.0 with every layer from 12 288 rows on:
+# profiles/r06/unet256_linear_dw_grouped_ab.txt): there the token-level projections reduce 65 536 rows into 320 x 320 outputs, and a
+# whole-reduction 256 x 256 tile streams its operands once where the split form writes and re-reads 57-114 slabs per gradient.  So: on for
+# reductions of at least LINEAR_DW_MIN_ROWS rows.  LINEAR_DW_TILES = 0: LinearFn computes every weight gradient on the spot (rounds 1-2).
+LINEAR_DW_TILES = 256
+LINEAR_DW_MIN_ROWS = 49152
 DW_MIN_TILES = 48
 GROUP_MAX = 24  # problems per launch (gemm_grouped.hip: the by-value problem table)
 _end_flush_queued = False
@@ -118,7 +124,7 @@ def queue_linear_dw(w: Tensor, b: Optional[Tensor], dy2: Tensor, x2: Tensor) -> 
     """`functional.LinearFn.backward`: take over dW (+ db) of a stand-alone Linear whose gradients go straight into `.grad`.
     False = not taken (grouping off, shapes the grouped kernel does not accept, not inside a backward pass)."""
     global _end_flush_queued
-    if LINEAR_DW_TILES <= 0 or DW_GROUP_BLOCKS <= 0 or not w.requires_grad or not _groupable(w, dy2, x2):
+    if LINEAR_DW_TILES <= 0 or DW_GROUP_BLOCKS <= 0 or not w.requires_grad or x2.shape[0] < LINEAR_DW_MIN_ROWS or not _groupable(w, dy2, x2):
         return False
     if any(not getattr(getattr(cb, "__self__", None), "accepts_deferred_gradients", False) for cb in _functional.grad_ready_callbacks):
         # A gradient reducer is listening (optim.StepInBackward only acts on explicit notifications: it may stay).  LinearFn takes its parameters as tensor inputs, so autograd runs their

@@ -1915,9 +1915,12 @@ class SpatialTransformerBlock(Module):
         return self._forward(net, context)
 
     def _forward(self, net: Tensor, context: Optional[Tensor] = None) -> Tensor:
-        net = self.attn1(self.norm1(net), residual=net)
-        net = self.attn2(self.norm2(net), context=context, residual=net)
-        return self.ff(self.norm3(net), residual=net)
+        # every `residual=net` below is the tensor the LayerNorm in the same line has just read, and the GEMM that adds it back consumes
+        # that LayerNorm's output: the three gradient fan-ins of a block ride in the LayerNorm backward kernels (functional.fanin_links)
+        with HF.fanin_links():
+            net = self.attn1(self.norm1(net), residual=net)
+            net = self.attn2(self.norm2(net), context=context, residual=net)
+            return self.ff(self.norm3(net), residual=net)
 
 
 class SpatialTransformer(Module):

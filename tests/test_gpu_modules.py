@@ -444,6 +444,7 @@ def test_stand_alone_linear_weight_gradients_join_the_grouped_launches():
     dims = [512, 768, 768, 512, 1024, 512]
     x = torch.randn(384, dims[0], device=DEV)
     keep = fused.LINEAR_DW_TILES, fused.DW_MIN_TILES
+    keep_rows, fused.LINEAR_DW_MIN_ROWS = fused.LINEAR_DW_MIN_ROWS, 0  # (the default queues only reductions of >= 49 152 rows: the 256^2 UNet's)
     try:
         res = {}
         for name, (tiles, floor) in (("grouped", (12, 1)), ("end of pass", (10 ** 6, 1)), ("few tiles", (10 ** 6, 10 ** 6)), ("on the spot", (0, 1))):
@@ -484,6 +485,7 @@ def test_stand_alone_linear_weight_gradients_join_the_grouped_launches():
         assert not fused._pending_dw
     finally:
         fused.LINEAR_DW_TILES, fused.DW_MIN_TILES = keep
+        fused.LINEAR_DW_MIN_ROWS = keep_rows
 
 
 def test_two_word_gradient_stream_through_a_block_stack():
