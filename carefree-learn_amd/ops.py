@@ -82,7 +82,9 @@ def pick_split_k(m: int, n: int, k: int, conv: bool = False) -> int:
         # kernel (82 TFLOP/s, 8 x the time the operands take to stream once).  A slice keeps at least 8 K-steps, the grid aims at the
         # 1 024 resident slots: 114 slices there.  256^2 x 1 step 459.5 -> 450.4 ms; 64^2 x 8 (64 slices for the same layers) level
         # (profiles/r06/unet_split_deep_ab.txt)
-        split = max(split, min(steps // 8, (1024 + tiles - 1) // tiles, 128))
+        # (only where the 32-slice cap was what bound the rule above: outputs of at most 16 tiles under >= 128 K-steps)
+        if split == 32:
+            split = max(split, min(steps // 8, (1024 + tiles - 1) // tiles, 128))
     return max(1, split)
 
 
