@@ -1457,7 +1457,7 @@ class Conv2dFn(Function):
             if ctx.implicit and not wgrad_implicit and weight.requires_grad:
                 x = ops.transpose_batched(x.view(b, h * w, cin)).view(b, cin, h, w)  # back to NCHW for the im2row route
             if weight.requires_grad and wgrad_implicit:
-                split = ops.pick_split_k(cp, 9 * cin, b * h * w, conv=True)
+                split = ops.pick_split_k(cp, 9 * cin, b * h * w)
 
                 def dw_implicit(out: Tensor, acc: bool) -> None:
                     if cp == cout:

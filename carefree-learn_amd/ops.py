@@ -61,13 +61,9 @@ def set_option(name: str, value: int) -> None:
 
 
 FORCE_SPLIT_K = 0  # A/B runs: > 0 = every weight-gradient GEMM takes this split
-SPLIT_K_DEEP = True  # round 6: long reductions over few tiles may split deeper than 32 (A/B: tools/attr_ab.py ops.SPLIT_K_DEEP=False)
 
 
-SPLIT_K_DEEP_CONV = False  # the same rule for the implicit filter gradients (A/B)
-
-
-def pick_split_k(m: int, n: int, k: int, conv: bool = False) -> int:
+def pick_split_k(m: int, n: int, k: int) -> int:
     """Split the reduction when the output has too few 128x128 tiles to fill 256 CUs."""
     if FORCE_SPLIT_K > 0:
         return FORCE_SPLIT_K
@@ -75,16 +71,10 @@ def pick_split_k(m: int, n: int, k: int, conv: bool = False) -> int:
     steps = (k + 63) // 64
     if tiles >= 256 or steps < 16:
         return 1
+    # (deeper than 32: the reduce pass costs more than it fills.  Round 6 tried 64-128 slices aimed at 1 024 workgroups for long reductions
+    # over <= 16 tiles: 256^2 x 1 UNet step -5 ms, level at 64^2 x 8 — and nothing once such reductions of >= 49 152 rows go to the grouped
+    # whole-K launches (fused.LINEAR_DW_MIN_ROWS), which is worth as much: profiles/r06/unet_split_deep_ab.txt; removed)
     split = min(steps // 4, (512 + tiles - 1) // tiles, 32)
-    if SPLIT_K_DEEP_CONV if conv else SPLIT_K_DEEP:
-        # Round 6: the rule above stops at 32 slices aimed at 512 workgroups; the zoo UNet's token-level Linear layers at 256^2 x 1 reduce
-        # 65 536 rows into 320 x 320 outputs: 9 tiles x 32 slices = 288 workgroups of 32 K-steps each on a chip that holds 1 024 of this
-        # kernel (82 TFLOP/s, 8 x the time the operands take to stream once).  A slice keeps at least 8 K-steps, the grid aims at the
-        # 1 024 resident slots: 114 slices there.  256^2 x 1 step 459.5 -> 450.4 ms; 64^2 x 8 (64 slices for the same layers) level
-        # (profiles/r06/unet_split_deep_ab.txt)
-        # (only where the 32-slice cap was what bound the rule above: outputs of at most 16 tiles under >= 128 K-steps)
-        if split == 32:
-            split = max(split, min(steps // 8, (1024 + tiles - 1) // tiles, 128))
     return max(1, split)
 
 

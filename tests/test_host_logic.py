@@ -144,9 +144,7 @@ def test_split_k_policy():
     s = pick_split_k(2304, 768, 12608)
     assert 2 <= s <= 8
     assert pick_split_k(1000, 768, 64) == 1
-    # round 6: long reductions over at most 16 tiles go deeper than 32 slices (>= 8 K-steps each, aimed at 1 024 workgroups)
-    assert pick_split_k(320, 320, 65536) == 114 and pick_split_k(320, 320, 32768) == 64 and pick_split_k(320, 320, 8192) == 32
-    assert pick_split_k(640, 640, 16384) == 21 and pick_split_k(320, 2880, 32768, conv=True) == 8
+    assert pick_split_k(320, 320, 65536) == 32 and pick_split_k(640, 640, 16384) == 21 and pick_split_k(320, 2880, 32768) == 8
 
 
 def test_conv_classifier_and_fcnn_state_dict_keys_match_reference(golden):
@@ -463,9 +461,8 @@ def test_round3_host_rules():
         assert fused._slice_cuts(128, 2) == [0, 1, 128]
     finally:
         fused.FIRST_SLICE_SHARE = keep
-    # split-K: capped at 32 slices (round 6: 64-128 where that cap bound a long reduction over <= 16 tiles), none for short
-    # reductions or outputs that fill the chip
-    assert ops.pick_split_k(320, 320, 32768) == 64 and ops.pick_split_k(320, 320, 16384) == 32 and ops.pick_split_k(1280, 1280, 512) == 1
+    # split-K: capped at 32 slices, none for short reductions or outputs that fill the chip
+    assert ops.pick_split_k(320, 320, 32768) == 32 and ops.pick_split_k(1280, 1280, 512) == 1
     assert ops.pick_split_k(4096, 4096, 100000) == 1 and 1 < ops.pick_split_k(768, 768, 25088) <= 32
     # adjacency of the three projection weights: true inside one arena in registration order, false without an arena, across
     # arenas, or when the shapes differ (a cross attention with its own context width)
