@@ -1910,6 +1910,169 @@ __global__ __launch_bounds__(256, (NDT == 3 && PLAIN) ? 3 : 2) void attn_bwd_dkv
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 6: the backward passes of head_dim <= 48 (the UNet's 40-channel heads: 333 of the 256^2 step's 474 ms of kernel time) with the
+// two reductions over head_dim — S = Q K^T and dP = dO V^T — on v_mfma_f32_32x32x16_bf16.  The kernels above run them on 16x16x32
+// MFMAs: head_dim 40 is padded to 64 there (two 32-deep steps, the second three quarters empty) and the passes sit at their MFMA-issue
+// bound (dK / dV: 1.6 + 1.6 + 1.2 + 1.2 = 5.6 padded units, 1 166 TFLOP/s issued).  A 32x32 tile takes the reduction in 16-deep steps:
+// three of them (48) instead of 64 — 3.6 units instead of 4.4 for dQ.  (The 16-deep 16x16 MFMA costs what the 32-deep one does on gfx950
+// — measured, profiles/r06/attn_k48_mfma16_rejected.txt — the 32x32x16 one is the double-rate instruction of its shape.)
+// MEASURED (profiles/r06/attn_s32x32_ab.txt): dQ at T = 65 536 10.38 -> 9.79 ms (-5.6 %), at T = 4 096 x 8 410 -> 391 us: a quarter of
+// what the MFMA count promised — the passes turn out to sit at ~50 % of the matrix pipe with the VALU (exp2, two multiplies, a subtract
+// and the packing per score) about as busy, so removing matrix cycles returns a fraction.  The same form of the dK / dV pass (eight
+// statistics loads and two swaps per block instead of four and none) was 1.8 % SLOWER (13.60 -> 13.84 ms) and is not in the tree.
+// The price is the result layout: lane l holds ONE column (l & 31) and the 16 rows 8 j + 4 (l >> 5) + r, where the products that consume
+// dS as an operand (dQ: output width head_dim, 48 on 16-column tiles — a 32-wide tile would pad it to 64 again) want 8
+// reduction slots of one of 16 columns per lane.  v_permlane16_swap does that conversion: with X = the packed rows of j in {0, 1} and
+// Y = those of j in {2, 3}, swapping X's odd 16-lane rows with Y's even ones leaves in X the complete 16x16x32 operand of columns 0..15
+// and in Y that of columns 16..31, k-slot group g = lane >> 4 holding rows base(g) + {0..3, 8..11}, base = {0, 16, 4, 20}: the
+// transposing LDS reads of the other operand take their four-row runs from exactly those rows (frag_cols32).  tools/micro/mfma32_swap.hip
+// checks the chain bit for bit.  No mask / causal / dropout forms: the UNet's path (PLAIN); everything else stays on the kernels above.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// A operand of a 32x32x16 MFMA from a swizzled tile: lane (rho = l & 31, hk = l >> 5) <- tile[row0 + rho][ks*16 + 8 hk .. +8]
+__device__ __forceinline__ bf16x8 frag_rows32(const char* tile, int row0, int ks, int lane) {
+  const int row = row0 + (lane & 31);
+  const int slot = ks * 2 + (lane >> 5);
+  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((slot ^ swz(row)) << 4));
+}
+
+// the same straight from global memory for the wave's own 32 rows, zero beyond dh / rows_valid
+__device__ __forceinline__ bf16x8 frag_global32_dh(const bf16_t* base, long stride_t, int row0, int rows_valid, int ks, int lane, int dh) {
+  const int row = row0 + (lane & 31);
+  const int col = ks * 16 + (lane >> 5) * 8;
+  bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (row < rows_valid && col < dh) r = *reinterpret_cast<const bf16x8*>(base + (long)row * stride_t + col);
+  return r;
+}
+
+// column-operand fragment over the 32-row block at `r32`, columns c0..c0+15, in the k-slot order of swap32_operands' results
+__device__ __forceinline__ bf16x8 frag_cols32(const char* tile, int r32, int c0, int lane) {
+  const int g = lane >> 4, s = lane & 15;
+  const int r_lo = r32 + (g & 1) * 16 + (g >> 1) * 4 + (s >> 2);
+  const int col = c0 + 4 * (s & 3);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)LDS_PTR(tile + tile_off(r_lo, col)));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)LDS_PTR(tile + tile_off(r_lo + 8, col)));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+// 32x32 MFMA result (16 f32 per lane: column l & 31, rows 8 j + 4 (l >> 5) + r) -> the bf16 B operands of two 16x16x32 MFMAs:
+// `lo` for columns 0..15, `hi` for columns 16..31 (lane n = l & 15 in both), 32 reduction slots in frag_cols32's order
+__device__ __forceinline__ void swap32_operands(const f32x16& t, bf16x8& lo, bf16x8& hi) {
+  union { bf16x8 v; unsigned w[4]; } x, y;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    x.w[w] = pack_bf16x2(t[2 * w], t[2 * w + 1]);
+    y.w[w] = pack_bf16x2(t[8 + 2 * w], t[8 + 2 * w + 1]);
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const auto r = __builtin_amdgcn_permlane16_swap(x.w[w], y.w[w], false, false);
+    x.w[w] = r[0];
+    y.w[w] = r[1];
+  }
+  lo = x.v;
+  hi = y.v;
+}
+
+template <int NDT>
+__global__ __launch_bounds__(512, 4) void attn_bwd_dq3_kernel(AttnParams p) {
+  static_assert(NDT == 3, "head_dim <= 48: three 16-deep reduction steps, three 16-column output tiles");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + A2_TILE;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int dh = p.dh;
+  const int row0 = (blockIdx.x * 8 + wave) * 32;
+  const bool active = row0 < p.Tq;
+  const bf16_t* qb = p.q + (long)b * p.q_sb + h * dh;
+  const bf16_t* dob = p.d_o + (long)b * p.o_sb + h * dh;
+  const bf16_t* ob = p.o_in + (long)b * p.o_sb + h * dh;
+  bf16x8 qf[3], dof[3];
+  float sacc = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    qf[ks] = frag_global32_dh(qb, p.q_st, row0, active ? p.Tq : 0, ks, lane, dh);
+    dof[ks] = frag_global32_dh(dob, p.o_st, row0, active ? p.Tq : 0, ks, lane, dh);
+    const bf16x8 of = frag_global32_dh(ob, p.o_st, row0, active ? p.Tq : 0, ks, lane, dh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sacc += bf16_to_f32((bf16_t)dof[ks][e]) * bf16_to_f32((bf16_t)of[e]);
+  }
+  const float delta = sacc + __shfl_xor(sacc, 32, 64);  // the two halves of a row's reduction sit in lanes l and l ^ 32
+  const int qrow = row0 + (lane & 31);
+  const bool qvalid = active && qrow < p.Tq;
+  const long stat = ((long)b * p.H + h) * p.Tq + qrow;
+  if (qvalid && lane < 32) p.delta[stat] = delta;
+  const float lse2 = qvalid ? p.lse[stat] * LOG2E : INFINITY;
+  const float sl2 = p.scale * LOG2E;
+  f32x4 dqt[2][NDT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) dqt[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kv0 = 0; kv0 < p.Tk; kv0 += A2_CH) {
+    const int rows = min(A2_CH, p.Tk - kv0);
+    __syncthreads();
+    {
+      int ln = lane;  // opaque copy: see attn_fwd2_kernel
+      asm volatile("" : "+v"(ln));
+      dma_oper<1>(Ks, p.k + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * dh, p.kv_st, rows, dh, wave, 8, ln);
+      dma_oper<1>(Vs, p.v + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * dh, p.kv_st, rows, dh, wave, 8, ln);
+    }
+    lds_dma_wait_all();
+    __syncthreads();
+    if (!active) continue;
+    const int nbl = (rows + 31) / 32;
+#pragma unroll 1
+    for (int a = 0; a < nbl; ++a) {
+      f32x16 sc, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { sc[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows32(Ks, a * 32, ks, lane), qf[ks], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows32(Vs, a * 32, ks, lane), dof[ks], dp, 0, 0, 0);
+      }
+      // lane: query row0 + (l & 31), keys a*32 + 8 j + 4 (l >> 5) + r.  Key rows beyond Tk are zero rows of the chunk: p finite, dP = 0
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sc[e] = __builtin_amdgcn_exp2f(fmaf(sc[e], sl2, -lse2)) * (dp[e] - delta);
+      bf16x8 ds0, ds1;
+      swap32_operands(sc, ds0, ds1);
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const bf16x8 kc = frag_cols32(Ks, a * 32, dt * 16, lane);
+        dqt[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc, ds0, dqt[0][dt], 0, 0, 0);
+        dqt[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc, ds1, dqt[1][dt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int qi = row0 + 16 * t + i;
+    if (active && qi < p.Tq) {
+      bf16_t* dqrow = p.dq + (long)b * p.q_sb + (long)qi * p.q_st + h * dh;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int col = dt * 16 + 4 * g;
+        if (col >= dh) continue;
+        const f32x4 v = dqt[t][dt] * p.scale;
+        *reinterpret_cast<u32x2*>(dqrow + col) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      }
+    }
+  }
+}
+
 // waves per workgroup: ONE workgroup per (batch, head) (the resident K / V — or Q / dO — tiles are
 // loaded once), its waves walk the 16-row tiles in rounds; pick the wave count that leaves the
 // fewest idle slots in the last round (at most 8 waves).
@@ -2013,7 +2176,7 @@ int launch_gen_bwd_drop(const AttnParams& p, bool plain, int parts, hipStream_t 
 }
 
 int g_attn_short_max = CFHIP_ATTN_MAX_T;  // "attn_short_max" option: head_dim-64 sequences up to this length take the LDS-resident kernels
-int g_attn_two_tiles = 63;  // "attn_two_tiles" option (bits): 1 forward, 2 dQ pass (4: also head_dim > 48), 8 dK / dV pass of head_dim <= 64 on the two-tiles-per-wave kernels; 16: forward row sums through the ones column when head_dim = 8 mod 16; 32: dK / dV pass of head_dim 72 .. 96 on the two-tile kernel
+int g_attn_two_tiles = 127;  // "attn_two_tiles" option (bits): 1 forward, 2 dQ pass (4: also head_dim > 48), 8 dK / dV pass of head_dim <= 64 on the two-tiles-per-wave kernels; 16: forward row sums through the ones column when head_dim = 8 mod 16; 32: dK / dV pass of head_dim 72 .. 96 on the two-tile kernel; 64 (round 6): the plain head_dim <= 48 dQ pass with S / dP on 32x32x16 MFMAs (attn_bwd_dq3_kernel)
 
 extern int g_attn_two_tiles;
 template <int NDT>
@@ -2060,6 +2223,16 @@ int launch_dq2(const AttnParams& p, bool plain, hipStream_t s) {
   return CFHIP_OK;
 }
 
+int launch_dq3(const AttnParams& p, hipStream_t s) {
+  dim3 grid((p.Tq + A2_ROWS - 1) / A2_ROWS, p.H, p.B);
+  const size_t lds = (size_t)2 * A2_TILE;
+  const int rc = set_lds(attn_bwd_dq3_kernel<3>, lds, "attn_bwd_dq");
+  if (rc != CFHIP_OK) return rc;
+  hipLaunchKernelGGL((attn_bwd_dq3_kernel<3>), grid, dim3(512), lds, s, p);
+  CFHIP_CHECK_LAUNCH("attn_bwd_dq3");
+  return CFHIP_OK;
+}
+
 template <int NDT>
 int launch_dkv2(const AttnParams& p, bool plain, hipStream_t s) {
   dim3 grid((p.Tk + 127) / 128, p.H, p.B);
@@ -2077,7 +2250,7 @@ int launch_dkv2(const AttnParams& p, bool plain, hipStream_t s) {
 template <int NH>
 int launch_gen_bwd(const AttnParams& p, bool plain, int parts, hipStream_t s) {
   if ((parts & 1) && NH == 1 && (g_attn_two_tiles & 2) && (p.dh <= 48 || (g_attn_two_tiles & 4))) {  // (the 4-column-tile form spills: bit 4 to try it)
-    const int rc = p.dh <= 48 ? launch_dq2<3>(p, plain, s) : launch_dq2<4>(p, plain, s);
+    const int rc = p.dh <= 48 ? ((plain && (g_attn_two_tiles & 64)) ? launch_dq3(p, s) : launch_dq2<3>(p, plain, s)) : launch_dq2<4>(p, plain, s);
     if (rc != CFHIP_OK) return rc;
   } else if (parts & 1) {
     dim3 grid((p.Tq + 127) / 128, p.H, p.B);
