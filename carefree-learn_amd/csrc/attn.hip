@@ -1788,8 +1788,12 @@ constexpr int A2D_TILE = A2D_CH * 128;
 // NDT = 5 / 6 (head_dim 72 .. 96, the UNet's 80-channel heads; round 3b): the same loop over KS = 3 reduction steps and two
 // 64-column halves of the staged operands (66 KB of LDS, ~215 registers: two workgroups per CU) — the general one-tile kernel
 // ran this head_dim at 342 TFLOP/s against 800 for head_dim 40 here.
-template <bool PLAIN, int NDT>
+// FOLD (round 6; plain, head_dim 40): dP - delta from the matrix pipe, as in attn_bwd_dq3_kernel — ones in columns 40 / 41 of the V
+// fragments, -bf16(delta) / -bf16(delta - hi) in columns 40 / 41 of the staged dO rows (written by the thread that owns the row's
+// statistics; the dO DMAs skip the pad columns).
+template <bool PLAIN, int NDT, bool FOLD = false>
 __global__ __launch_bounds__(256, (NDT == 3 && PLAIN) ? 3 : 2) void attn_bwd_dkv2_kernel(AttnParams p) {
+  static_assert(!FOLD || (PLAIN && NDT == 3), "the folded delta: plain head_dim-40 form only");
   constexpr int KS = (NDT + 1) / 2;     // 32-deep steps of the reductions over head_dim
   constexpr int NHALF = (NDT + 3) / 4;  // 64-column halves of a staged operand
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1814,6 +1818,16 @@ __global__ __launch_bounds__(256, (NDT == 3 && PLAIN) ? 3 : 2) void attn_bwd_dkv
       kf[u][ks] = frag_global_dh(kb, p.kv_st, row0 + 16 * u, active ? p.Tk : 0, ks, lane, dh);
       vf[u][ks] = frag_global_dh(vb, p.kv_st, row0 + 16 * u, active ? p.Tk : 0, ks, lane, dh);
     }
+  if (FOLD) {
+    if (g == 1) {  // dh == 40: the (ks = 1, g = 1) fragment is columns 40 .. 47
+      vf[0][KS - 1][0] = vf[0][KS - 1][1] = (short)0x3F80;
+      vf[1][KS - 1][0] = vf[1][KS - 1][1] = (short)0x3F80;
+    }
+    for (int idx = threadIdx.x; idx < A2D_CH * 8; idx += 256) {  // the pad chunks of the dO tile, once (columns 40 / 41 are rewritten per chunk)
+      const int row = idx >> 3, chunk = idx & 7;
+      if (chunk * 8 >= dh) *reinterpret_cast<u32x4*>(dOs + row * 128 + ((chunk ^ swz(row)) << 4)) = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
   const float sl2 = p.scale * LOG2E;
   f32x4 dkt[2][NDT], dvt[2][NDT];
 #pragma unroll
@@ -1830,14 +1844,21 @@ __global__ __launch_bounds__(256, (NDT == 3 && PLAIN) ? 3 : 2) void attn_bwd_dkv
 #pragma unroll
       for (int hf = 0; hf < NHALF; ++hf) {
         dma_half(Qs + hf * A2D_TILE, p.q + (long)b * p.q_sb + (long)q0 * p.q_st + h * dh, p.q_st, rows, A2D_CH, hf, dh, wave, 4, ln);
-        dma_half(dOs + hf * A2D_TILE, p.d_o + (long)b * p.o_sb + (long)q0 * p.o_st + h * dh, p.o_st, rows, A2D_CH, hf, dh, wave, 4, ln);
+        dma_half<FOLD>(dOs + hf * A2D_TILE, p.d_o + (long)b * p.o_sb + (long)q0 * p.o_st + h * dh, p.o_st, rows, A2D_CH, hf, dh, wave, 4, ln);
       }
     }
     if ((int)threadIdx.x < A2D_CH) {  // thread t owns the statistics of row t of the chunk
       const int tq = q0 + (int)threadIdx.x;
       const long at = ((long)b * p.H + h) * p.Tq + tq;
       lse_s[threadIdx.x] = tq < p.Tq ? p.lse[at] * LOG2E : INFINITY;
-      delta_s[threadIdx.x] = tq < p.Tq ? p.delta[at] : 0.f;
+      const float dl = tq < p.Tq ? p.delta[at] : 0.f;
+      if (FOLD) {
+        const bf16_t hi = f32_to_bf16(-dl);
+        const bf16_t lo = f32_to_bf16(-dl - bf16_to_f32(hi));
+        *reinterpret_cast<unsigned*>(dOs + tile_off((int)threadIdx.x, 40)) = (unsigned)hi | ((unsigned)lo << 16);
+      } else {
+        delta_s[threadIdx.x] = dl;
+      }
     }
     lds_dma_wait_all();
     __syncthreads();
@@ -1857,7 +1878,8 @@ __global__ __launch_bounds__(256, (NDT == 3 && PLAIN) ? 3 : 2) void attn_bwd_dkv
           of[ks] = frag_rows(dOs + (ks >> 1) * A2D_TILE, r16, ks & 1, lane);
         }
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + r16 + 4 * g);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + r16 + 4 * g);
+        f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+        if (!FOLD) d4 = *reinterpret_cast<const f32x4*>(delta_s + r16 + 4 * g);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -1874,7 +1896,7 @@ __global__ __launch_bounds__(256, (NDT == 3 && PLAIN) ? 3 : 2) void attn_bwd_dkv
               pr = (qi < p.Tq && keep_at(p, b, h, qi, row0 + 16 * u + n)) ? pr : 0.f;
             }
             pp[u][it][r] = pr;
-            ds[u][it][r] = pr * (dp[r] - d4[r]);
+            ds[u][it][r] = pr * (FOLD ? dp[r] : dp[r] - d4[r]);
           }
         }
       }
@@ -1982,7 +2004,10 @@ __device__ __forceinline__ void swap32_operands(const f32x16& t, bf16x8& lo, bf1
   hi = y.v;
 }
 
-template <int NDT>
+// FOLD (head_dim 40: the reduction is padded to 48, columns 40 / 41 are free): dP - delta comes out of the matrix pipe.  The staged V tile
+// carries ones in columns 40 and 41 (written once; the chunk DMAs skip the pad columns), the dO fragment -bf16(delta) and -bf16(delta - hi)
+// (16 mantissa bits of delta): 16 subtractions per lane and 32 x 32 block leave a loop whose VALU is as busy as its matrix pipe.
+template <int NDT, bool FOLD>
 __global__ __launch_bounds__(512, 4) void attn_bwd_dq3_kernel(AttnParams p) {
   static_assert(NDT == 3, "head_dim <= 48: three 16-deep reduction steps, three 16-column output tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2009,6 +2034,16 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq3_kernel(AttnParams p) {
     for (int e = 0; e < 8; ++e) sacc += bf16_to_f32((bf16_t)dof[ks][e]) * bf16_to_f32((bf16_t)of[e]);
   }
   const float delta = sacc + __shfl_xor(sacc, 32, 64);  // the two halves of a row's reduction sit in lanes l and l ^ 32
+  if (FOLD) {  // dh == 40: element 0 / 1 of the (ks = 2, hk = 1) fragment are columns 40 / 41
+    const bf16_t hi = f32_to_bf16(-delta);
+    const bf16_t lo = f32_to_bf16(-delta - bf16_to_f32(hi));
+    if (lane >= 32) { dof[2][0] = (short)hi; dof[2][1] = (short)lo; }
+    for (int idx = threadIdx.x; idx < A2_CH * 8; idx += 512) {  // the pad chunks of the V tile, once: ones in columns 40 / 41
+      const int row = idx >> 3, chunk = idx & 7;
+      if (chunk * 8 >= dh)
+        *reinterpret_cast<u32x4*>(Vs + row * 128 + ((chunk ^ swz(row)) << 4)) = u32x4{chunk * 8 == dh ? 0x3F803F80u : 0u, 0u, 0u, 0u};
+    }
+  }
   const int qrow = row0 + (lane & 31);
   const bool qvalid = active && qrow < p.Tq;
   const long stat = ((long)b * p.H + h) * p.Tq + qrow;
@@ -2028,7 +2063,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq3_kernel(AttnParams p) {
       int ln = lane;  // opaque copy: see attn_fwd2_kernel
       asm volatile("" : "+v"(ln));
       dma_oper<1>(Ks, p.k + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * dh, p.kv_st, rows, dh, wave, 8, ln);
-      dma_oper<1>(Vs, p.v + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * dh, p.kv_st, rows, dh, wave, 8, ln);
+      dma_oper<1, FOLD>(Vs, p.v + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * dh, p.kv_st, rows, dh, wave, 8, ln);
     }
     lds_dma_wait_all();
     __syncthreads();
@@ -2046,7 +2081,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq3_kernel(AttnParams p) {
       }
       // lane: query row0 + (l & 31), keys a*32 + 8 j + 4 (l >> 5) + r.  Key rows beyond Tk are zero rows of the chunk: p finite, dP = 0
 #pragma unroll
-      for (int e = 0; e < 16; ++e) sc[e] = __builtin_amdgcn_exp2f(fmaf(sc[e], sl2, -lse2)) * (dp[e] - delta);
+      for (int e = 0; e < 16; ++e) sc[e] = __builtin_amdgcn_exp2f(fmaf(sc[e], sl2, -lse2)) * (FOLD ? dp[e] : dp[e] - delta);
       bf16x8 ds0, ds1;
       swap32_operands(sc, ds0, ds1);
 #pragma unroll
@@ -2176,7 +2211,7 @@ int launch_gen_bwd_drop(const AttnParams& p, bool plain, int parts, hipStream_t 
 }
 
 int g_attn_short_max = CFHIP_ATTN_MAX_T;  // "attn_short_max" option: head_dim-64 sequences up to this length take the LDS-resident kernels
-int g_attn_two_tiles = 127;  // "attn_two_tiles" option (bits): 1 forward, 2 dQ pass (4: also head_dim > 48), 8 dK / dV pass of head_dim <= 64 on the two-tiles-per-wave kernels; 16: forward row sums through the ones column when head_dim = 8 mod 16; 32: dK / dV pass of head_dim 72 .. 96 on the two-tile kernel; 64 (round 6): the plain head_dim <= 48 dQ pass with S / dP on 32x32x16 MFMAs (attn_bwd_dq3_kernel)
+int g_attn_two_tiles = 255;  // "attn_two_tiles" option (bits): 1 forward, 2 dQ pass (4: also head_dim > 48), 8 dK / dV pass of head_dim <= 64 on the two-tiles-per-wave kernels; 16: forward row sums through the ones column when head_dim = 8 mod 16; 32: dK / dV pass of head_dim 72 .. 96 on the two-tile kernel; 64 (round 6): the plain head_dim <= 48 dQ pass with S / dP on 32x32x16 MFMAs (attn_bwd_dq3_kernel); 128 (round 6): head_dim 40, plain: dP - delta out of the matrix pipe (two spare reduction columns) in that dQ pass and in the dK / dV pass
 
 extern int g_attn_two_tiles;
 template <int NDT>
@@ -2226,9 +2261,11 @@ int launch_dq2(const AttnParams& p, bool plain, hipStream_t s) {
 int launch_dq3(const AttnParams& p, hipStream_t s) {
   dim3 grid((p.Tq + A2_ROWS - 1) / A2_ROWS, p.H, p.B);
   const size_t lds = (size_t)2 * A2_TILE;
-  const int rc = set_lds(attn_bwd_dq3_kernel<3>, lds, "attn_bwd_dq");
+  const bool fold = p.dh == 40 && (g_attn_two_tiles & 128);
+  const int rc = fold ? set_lds(attn_bwd_dq3_kernel<3, true>, lds, "attn_bwd_dq") : set_lds(attn_bwd_dq3_kernel<3, false>, lds, "attn_bwd_dq");
   if (rc != CFHIP_OK) return rc;
-  hipLaunchKernelGGL((attn_bwd_dq3_kernel<3>), grid, dim3(512), lds, s, p);
+  if (fold) hipLaunchKernelGGL((attn_bwd_dq3_kernel<3, true>), grid, dim3(512), lds, s, p);
+  else hipLaunchKernelGGL((attn_bwd_dq3_kernel<3, false>), grid, dim3(512), lds, s, p);
   CFHIP_CHECK_LAUNCH("attn_bwd_dq3");
   return CFHIP_OK;
 }
@@ -2240,6 +2277,13 @@ int launch_dkv2(const AttnParams& p, bool plain, hipStream_t s) {
   if (lds > 64 * 1024) {
     const int rc = plain ? set_lds(attn_bwd_dkv2_kernel<true, NDT>, lds, "attn_bwd_dkv") : set_lds(attn_bwd_dkv2_kernel<false, NDT>, lds, "attn_bwd_dkv");
     if (rc != CFHIP_OK) return rc;
+  }
+  if constexpr (NDT == 3) {
+    if (plain && p.dh == 40 && (g_attn_two_tiles & 128)) {
+      hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true, 3, true>), grid, dim3(256), lds, s, p);
+      CFHIP_CHECK_LAUNCH("attn_bwd_dkv2");
+      return CFHIP_OK;
+    }
   }
   if (plain) hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true, NDT>), grid, dim3(256), lds, s, p);
   else hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false, NDT>), grid, dim3(256), lds, s, p);
