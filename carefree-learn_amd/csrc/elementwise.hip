@@ -286,10 +286,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   const long stride = (long)gridDim.x * blockDim.x;
   const float step_size = lr / bc1;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
-    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
-    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
-    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
-    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+    f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p) + i);  // (non-temporal: see adam_dev_kernel)
+    f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+    f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m) + i);
+    f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v) + i);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float gg = gv[e] * gscale;
@@ -304,11 +304,11 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
       pp -= step_size * (mm / denom);
       pv[e] = pp; mv[e] = mm; vv[e] = v2;
     }
-    reinterpret_cast<f32x4*>(p)[i] = pv;
-    reinterpret_cast<f32x4*>(m)[i] = mv;
-    reinterpret_cast<f32x4*>(v)[i] = vv;
+    __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(p) + i);  // (see adam_dev_kernel)
+    __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(m) + i);
+    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v) + i);
     if (pb != nullptr)
-      reinterpret_cast<u32x2*>(pb)[i] = u32x2{pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+      __builtin_nontemporal_store(u32x2{pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])}, reinterpret_cast<u32x2*>(pb) + i);
   }
   for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
     float gg = g[i] * gscale, pp = p[i];
@@ -336,10 +336,14 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
   const long stride = (long)gridDim.x * blockDim.x;
   const float step_size = lr / bc1;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
-    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
-    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
-    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
-    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+    // Non-temporal accesses (round 6): every stream of the update is touched ONCE per step and is far larger than the caches (the zoo
+    // UNet: 26 GB per step), and the update runs on a side lane beside the backward pass — without the hint its lines push the main
+    // queue's operands out of L2 / MALL.  UNet 64^2 x 8 step 54.05 -> 53.39 ms, ViT-B/16 18.07 -> 18.03 (three alternating pairs on one
+    // box, profiles/r06/adam_nontemporal_ab.txt).
+    f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p) + i);
+    f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+    f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m) + i);
+    f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v) + i);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float gg = gv[e] * gscale;
@@ -353,11 +357,11 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
       pp -= step_size * (mm / (sqrtf(v2) * bc2_rsqrt + eps));
       pv[e] = pp; mv[e] = mm; vv[e] = v2;
     }
-    reinterpret_cast<f32x4*>(p)[i] = pv;
-    reinterpret_cast<f32x4*>(m)[i] = mv;
-    reinterpret_cast<f32x4*>(v)[i] = vv;
+    __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(p) + i);
+    __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(m) + i);
+    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v) + i);
     if (pb != nullptr)
-      reinterpret_cast<u32x2*>(pb)[i] = u32x2{pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+      __builtin_nontemporal_store(u32x2{pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])}, reinterpret_cast<u32x2*>(pb) + i);
   }
   for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
     float gg = g[i] * gscale, pp = p[i];

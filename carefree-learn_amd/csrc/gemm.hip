@@ -394,7 +394,9 @@ void gemm_bf16_phase_kernel(GemmParams p) {
   epilogue<EPI, C>(p, acc, smem, cur.m0, cur.n0, cur.z, wm, wn, wave, lane);
 }
 
-// split-K second pass: C = sum_z slab[z] (+ bias) (+ C)
+// split-K second pass: C = sum_z slab[z] (+ bias) (+ C).  (Round 6: non-temporal slab loads / gradient stores — what helps the optimizer
+// kernel, elementwise.hip — cost the UNet steps 3-4 ms, and the stores alone as much: a range's gradients are read by its optimizer launch
+// inside the same backward pass, out of L2 / MALL unless the hint sent them past it; profiles/r06/adam_nontemporal_ab.txt.)
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, void* C, const float* bias,
                                      int M, int N, long ldc, int splits, int out_f32, int accumulate,
                                      const float* __restrict__ bgrad_slabs, float* bgrad, int bgrad_acc) {
