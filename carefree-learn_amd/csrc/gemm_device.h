@@ -302,6 +302,25 @@ __device__ __forceinline__ void bstore16(__amdgpu_buffer_rsrc_t r, unsigned off,
 __device__ __forceinline__ void bstore8(__amdgpu_buffer_rsrc_t r, unsigned off, u32x2 v) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, v), r, (int)off, 0, CFHIP_ST_AUX);
 }
+// The saved pre-activation of the GELU epilogues is written in the forward and read once, a whole backward later (ViT-B/16 at batch 128:
+// 77 MB per block): non-temporal on both sides (aux bit 2), so that it does not push the next GEMM's operands out of L2 / MALL.
+#ifdef CFHIP_EPI_AUX_TEMPORAL  // A/B builds: the plain accesses of rounds 1-5
+#define CFHIP_PRE_AUX 0
+#else
+#define CFHIP_PRE_AUX 2
+#endif
+__device__ __forceinline__ u32x4 bload16_pre(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, CFHIP_PRE_AUX));
+}
+__device__ __forceinline__ u32x2 bload8_pre(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, CFHIP_PRE_AUX));
+}
+__device__ __forceinline__ void bstore16_pre(__amdgpu_buffer_rsrc_t r, unsigned off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v), r, (int)off, 0, CFHIP_PRE_AUX);
+}
+__device__ __forceinline__ void bstore8_pre(__amdgpu_buffer_rsrc_t r, unsigned off, u32x2 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, v), r, (int)off, 0, CFHIP_PRE_AUX);
+}
 // descriptor of an [M][ld] matrix of ES-byte elements, anchored at (m0, n0); valid bytes end with element (M-1, N-1)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, long ld, int es, int m0, int n0, int M, int N) {
   const char* origin = reinterpret_cast<const char*>(base) + ((long)m0 * ld + n0) * es;
@@ -348,6 +367,13 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
     if constexpr (AUX_F32) {
       r.a = bload16(x_rsrc, c_lo ? e * 4u : OOB);
       r.b = bload16(x_rsrc, c_hi ? e * 4u + 16u : OOB);
+    } else if constexpr (EPI == CFHIP_EPI_DGELU) {  // the saved pre-activation: read once
+      if constexpr (N8) {
+        r.a = bload16_pre(x_rsrc, c_lo ? e * 2u : OOB);
+      } else {
+        const u32x2 h0 = bload8_pre(x_rsrc, c_lo ? e * 2u : OOB), h1 = bload8_pre(x_rsrc, c_hi ? e * 2u + 8u : OOB);
+        r.a = u32x4{h0[0], h0[1], h1[0], h1[1]};
+      }
     } else if constexpr (N8) {
       r.a = bload16(x_rsrc, c_lo ? e * 2u : OOB);
     } else {
@@ -385,10 +411,10 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
       const u32x4 w = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
                        pack_bf16x2(hi[2], hi[3])};
       if constexpr (N8) {
-        bstore16(o_rsrc, (has_pre && c_lo) ? e * 2u : OOB, w);
+        bstore16_pre(o_rsrc, (has_pre && c_lo) ? e * 2u : OOB, w);
       } else {
-        bstore8(o_rsrc, (has_pre && c_lo) ? e * 2u : OOB, u32x2{w[0], w[1]});
-        bstore8(o_rsrc, (has_pre && c_hi) ? e * 2u + 8u : OOB, u32x2{w[2], w[3]});
+        bstore8_pre(o_rsrc, (has_pre && c_lo) ? e * 2u : OOB, u32x2{w[0], w[1]});
+        bstore8_pre(o_rsrc, (has_pre && c_hi) ? e * 2u + 8u : OOB, u32x2{w[2], w[3]});
       }
       if constexpr (QUICK) {
         lo = f32x4{quick_gelu_f(bf16lo(w[0])), quick_gelu_f(bf16hi(w[0])), quick_gelu_f(bf16lo(w[1])), quick_gelu_f(bf16hi(w[1]))};
