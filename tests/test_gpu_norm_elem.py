@@ -175,6 +175,21 @@ def test_assemble_tokens():
     assert torch.equal(dp.cpu(), dx0[:, 1:].reshape(b * np_, d))
     assert_close(dpos, dx0.float().sum(0).reshape(-1), 1e-5, "dpos")
     assert_close(dhead, dx0.float()[:, 0].sum(0), 1e-5, "dhead")
+    # round 6: the batch-parallel vector kernel (one workgroup per token and 256-column block, eight batch groups) at the ViT / CLIP step's
+    # shapes, a width that is no multiple of 256, a batch that is no multiple of 8, accumulation onto existing gradients, the scalar form (D % 8 != 0)
+    for b2, np2, d2 in ((128, 196, 768), (13, 7, 328), (3, 2, 20)):
+        dx = torch.randn(b2, np2 + 1, d2, generator=g).to(torch.bfloat16)
+        dh0, dp0 = torch.randn(d2, generator=g), torch.randn((np2 + 1) * d2, generator=g)
+        dh, dq = dh0.to(DEV), dp0.to(DEV)
+        out = ops.assemble_tokens_bwd(dx.to(DEV), dh, dq, True)
+        assert torch.equal(out.cpu(), dx[:, 1:].reshape(b2 * np2, d2))
+        assert_close(dq, dp0 + dx.float().sum(0).reshape(-1), 2e-6, f"dpos {b2}x{np2}x{d2} (+=)")
+        assert_close(dh, dh0 + dx.float()[:, 0].sum(0), 2e-6, f"dhead {b2}x{np2}x{d2} (+=)")
+        dq2 = torch.empty_like(dq)
+        ops.assemble_tokens_bwd(dx.to(DEV), None, dq2, False, want_dpatches=False)
+        dq3 = torch.empty_like(dq)
+        ops.assemble_tokens_bwd(dx.to(DEV), None, dq3, False, want_dpatches=False)
+        assert torch.equal(dq2, dq3)  # fixed summation order
 
 
 def test_adam_matches_oracle():
