@@ -63,6 +63,12 @@ const char* cfhip_last_error(void);
  *   "grouped_variant" ring of cfhip_gemm_bf16_grouped_tn: 0 (default) 5 slots, DMA 3 K-steps ahead; 1: 4 slots, 2 ahead;
  *                     2: 5 slots, 2 ahead; 3 / 4: DMA placement variants of 0.  +16: bias gradients reduced by the first tile
  *                     column alone instead of shared by the tile row; +32: row-major tile order (both: A/B runs);
+ *   "attn_two_tiles"  bits (default 255) selecting the long-sequence attention forms (csrc/attn.hip): 1 forward, 2 dQ pass (4: also head_dim
+ *                     > 48), 8 dK / dV pass of head_dim <= 64 on the two-tiles-per-wave kernels; 16: forward row sums through a ones column
+ *                     when head_dim = 8 mod 16; 32: dK / dV pass of head_dim 72 .. 96 on the two-tile kernel; 64 (round 6): the plain
+ *                     head_dim <= 48 dQ pass with S / dP on 32x32x16 MFMAs; 128 (round 6): head_dim 40, plain: dP - delta out of the matrix
+ *                     pipe (two spare reduction columns) in the dQ and dK / dV passes.  "attn_one_pass" (default 1): dQ, dK, dV of a short
+ *                     self-attention from one evaluation of S and dP.  "attn_short_max": longest head_dim-64 sequence on the LDS-resident kernels
  *   "conv_form"       tile form of cfhip_conv3x3_nhwc_bf16: -1 (default) = by shape (128x160x64 on four waves where 160-column tiles cover
  *                     Cout with at most 1/8 of waste — the UNet's 320 / 640 / 960 / 1280 / 1920 / 2560 — and Cin % 64 == 0; otherwise
  *                     the round-3 table); -2: the round-3 table everywhere; 0: 256x128x32 two-group kernel, 1: 128x128x32, 2: 128x160x32, 3: 128x160x64
