@@ -190,6 +190,18 @@ __device__ __forceinline__ float group_max(float v) {  // across the 4 lanes sha
   v = fmaxf(v, __shfl_xor(v, 16, 64));
   return fmaxf(v, __shfl_xor(v, 32, 64));
 }
+// The same through gfx950's lane swaps (round 6): `__shfl_xor` is a ds_bpermute — an LDS round trip behind ~6 VALU of address arithmetic,
+// twice in a row on the critical path of every 64-key block of the long-sequence forward.  v_permlane16_swap(v, v) leaves the two halves of
+// every 32-lane pair of rows side by side (result 0: the even rows' values in both rows, result 1: the odd rows'), v_permlane32_swap(v, v)
+// the two 32-lane halves: one max each.
+__device__ __forceinline__ float group_max_swap(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float m1 = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const unsigned w = __float_as_uint(m1);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 __device__ __forceinline__ float group_sum(float v) {
   v += __shfl_xor(v, 16, 64);
   return v + __shfl_xor(v, 32, 64);
@@ -1607,7 +1619,7 @@ __global__ __launch_bounds__(512, NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4) void att
             mx = fmaxf(mx, x);
           }
         }
-        mx = group_max(mx) * sl2;
+        mx = group_max_swap(mx) * sl2;
         const float m_new = fmaxf(m[t], mx);
         // rows whose every position so far is masked (m_new = -inf) must not produce NaN from (-inf) - (-inf): use 0
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
