@@ -2068,6 +2068,26 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq3_kernel(AttnParams p) {
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) dqt[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Lane-constant parts of the twelve LDS addresses of a block (the swizzle key of row a*32 + r is that of r; the V tile sits A2_TILE
+  // bytes behind the K tile, the second transposing read 8 rows = 1 024 bytes behind the first): a block adds its a * 4 096 bytes to SIX
+  // of them — the compiler's own form added it to all twelve, 12 of the loop's 72 VALU instructions.
+  // (kept as LDS-space pointers: through generic pointers every load paid a `v_add_u32 v, 0, v` for the address-space cast)
+  typedef __attribute__((address_space(3))) const char* lds_cp;
+  lds_cp kr[3], kc[NDT];
+  {
+    const lds_cp ks3 = (lds_cp)LDS_PTR(Ks);
+    const int r = lane & 31;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) kr[ks] = ks3 + r * 128 + (((ks * 2 + (lane >> 5)) ^ swz(r)) << 4);
+    const int s16 = lane & 15;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) kc[dt] = ks3 + tile_off((g & 1) * 16 + (g >> 1) * 4 + (s16 >> 2), dt * 16 + 4 * (s16 & 3));
+    // opaque: the tile's base is a link-time constant that hipcc otherwise adds at every USE (`v_add_u32 v, 0, v`) beside the loop's increments
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) { unsigned u = (unsigned)(uintptr_t)kr[ks]; asm volatile("" : "+v"(u)); kr[ks] = (lds_cp)(uintptr_t)u; }
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) { unsigned u = (unsigned)(uintptr_t)kc[dt]; asm volatile("" : "+v"(u)); kc[dt] = (lds_cp)(uintptr_t)u; }
+  }
   for (int kv0 = 0; kv0 < p.Tk; kv0 += A2_CH) {
     const int rows = min(A2_CH, p.Tk - kv0);
     __syncthreads();
@@ -2086,10 +2106,13 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq3_kernel(AttnParams p) {
       f32x16 sc, dp;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { sc[e] = 0.f; dp[e] = 0.f; }
+      const int aoff = a * (32 * 128);
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows32(Ks, a * 32, ks, lane), qf[ks], sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows32(Vs, a * 32, ks, lane), dof[ks], dp, 0, 0, 0);
+        const lds_cp kp = kr[ks] + aoff;
+        typedef __attribute__((address_space(3))) const bf16x8* lds_v8;
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(lds_v8)kp, qf[ks], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(lds_v8)(kp + A2_TILE), dof[ks], dp, 0, 0, 0);
       }
       // lane: query row0 + (l & 31), keys a*32 + 8 j + 4 (l >> 5) + r.  Key rows beyond Tk are zero rows of the chunk: p finite, dP = 0
 #pragma unroll
@@ -2098,9 +2121,12 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq3_kernel(AttnParams p) {
       swap32_operands(sc, ds0, ds1);
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        const bf16x8 kc = frag_cols32(Ks, a * 32, dt * 16, lane);
-        dqt[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc, ds0, dqt[0][dt], 0, 0, 0);
-        dqt[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc, ds1, dqt[1][dt], 0, 0, 0);
+        const lds_cp cp = kc[dt] + aoff;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)cp);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(cp + 8 * 128));
+        const bf16x8 kcf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        dqt[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kcf, ds0, dqt[0][dt], 0, 0, 0);
+        dqt[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kcf, ds1, dqt[1][dt], 0, 0, 0);
       }
     }
   }
