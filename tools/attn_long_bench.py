@@ -37,6 +37,10 @@ for a in sys.argv[1:]:
 if "--quick" in sys.argv:
     cases = [c for c in cases if c[2] <= 16384]
 g = torch.Generator(device=dev).manual_seed(0)
+_w = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+for _ in range(200):  # ~0.2 s of matmuls: the first timed case of a cold process is 20 % slow otherwise (clocks ramping)
+    _w @ _w
+torch.cuda.synchronize()
 for b, h, t, dh, reps in cases:
     d = h * dh
     rnd = lambda: (torch.randn(b, t, d, device=dev, generator=g) * 0.5).to(torch.bfloat16)  # noqa: E731
