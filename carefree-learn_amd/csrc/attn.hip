@@ -855,7 +855,7 @@ __global__ __launch_bounds__(PERS_WAVES * 64, 4) void attn_bwd_dq_pers_kernel(At
 // phase 2.
 template <int NB, int PW, bool CAUSAL = false>  // NB pairs of 16-row tiles (T <= 32 NB); PW waves per workgroup (>= 2 NB key tiles, >= 4 ceil(NB / 2) phase-2 items)
 __global__ __launch_bounds__(PW * 64, 4) void attn_bwd_one_kernel(AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(128))) char smem[];  // 128: the XOR-derived addresses below need whole tile rows
   constexpr int ROWS = NB * 32, TILE = ROWS * 128;
   constexpr int HA = (NB + 1) / 2;          // query pair-tiles per half
   constexpr int DSROW = ROWS * 2 + 16;      // bytes per dS row (ROWS keys, bf16) + 16: rows 4 apart start 16 banks apart
@@ -912,6 +912,32 @@ __global__ __launch_bounds__(PW * 64, 4) void attn_bwd_one_kernel(AttnParams p) 
     dma_tile(Ks, p.k + (long)b * p.kv_sb + h * DH, p.kv_st, p.Tk, ROWS, wave, PW, lane);
   };
 
+  // Lane-constant parts of the LDS addresses of both phases, kept as LDS-space pointers and made opaque once (see attn_bwd_dq3_kernel):
+  // through generic pointers every access paid a `v_add_u32 v, 0, v` for the link-time base, and the statistics / dS regions sit beyond
+  // the 64 KB an instruction's offset field reaches, so each of their twelve accesses per block paid an add of its own — 28 of the 65
+  // VALU instructions of the phase-1 block.  With the region's base inside the pointer the rest are immediates: 8 adds per block.
+  typedef __attribute__((address_space(3))) const char* lds_cp;
+  typedef __attribute__((address_space(3))) char* lds_p;
+  typedef __attribute__((address_space(3))) const bf16x8* lds_v8;
+  typedef __attribute__((address_space(3))) const f32x4* lds_f4;
+  typedef __attribute__((address_space(3))) s16x4* lds_s4;
+  lds_cp qr0, qc0, sp;
+  lds_p dsw;
+  {
+    // (the tiles start on 128-byte boundaries — the first one at the dynamic LDS base — so the other reduction half of a row fragment and
+    // the other column tiles are one XOR of bits 5..6 away: slot ^ key with the key in bits 1..2 of the slot)
+    const lds_cp q3 = (lds_cp)LDS_PTR(Qs);
+    qr0 = q3 + n * 128 + ((g ^ swz(n)) << 4);
+    qc0 = q3 + tile_off(4 * g + (n >> 2), 4 * (n & 3));
+    sp = (lds_cp)LDS_PTR(lse_s) + 16 * g;
+    dsw = (lds_p)LDS_PTR(dSs) + (row0 + n) * 2 + 4 * g * DSROW;
+#define CFHIP_OPAQUE_LDS(ptr, T) { unsigned u_ = (unsigned)(uintptr_t)(ptr); asm volatile("" : "+v"(u_)); (ptr) = (T)(uintptr_t)u_; }
+#define CFHIP_LDS_XOR(ptr, bits) ((lds_cp)(uintptr_t)((unsigned)(uintptr_t)(ptr) ^ (unsigned)(bits)))
+    CFHIP_OPAQUE_LDS(qr0, lds_cp)
+    CFHIP_OPAQUE_LDS(qc0, lds_cp)
+    CFHIP_OPAQUE_LDS(sp, lds_cp)
+    CFHIP_OPAQUE_LDS(dsw, lds_p)
+  }
   int hh = blockIdx.x;
   if (hh < heads) {
     stage_q(hh);
@@ -941,16 +967,19 @@ __global__ __launch_bounds__(PW * 64, 4) void attn_bwd_one_kernel(AttnParams p) 
       if (row0 < ROWS) {
         for (int a = a0; a < a1; ++a) {
           f32x4 pp[2], ds[2];
+          const int aoff = a * (32 * 128);
+          const lds_cp spa = sp + a * 128;
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             const int it = 2 * a + t;
             f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs, it * 16, 0, lane), kf0, sc, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs, it * 16, 1, lane), kf1, sc, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dOs, it * 16, 0, lane), vf0, dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dOs, it * 16, 1, lane), vf1, dp, 0, 0, 0);
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + it * 16 + 4 * g);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + it * 16 + 4 * g);
+            const lds_cp r0 = qr0 + aoff + t * 2048, r1 = CFHIP_LDS_XOR(qr0 + aoff, 64) + t * 2048;  // rows 16 it + n of Q; dO sits TILE bytes behind
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(lds_v8)r0, kf0, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(lds_v8)r1, kf1, sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(lds_v8)(r0 + TILE), vf0, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(lds_v8)(r1 + TILE), vf1, dp, 0, 0, 0);
+            const f32x4 l4 = *(lds_f4)(spa + t * 64);
+            const f32x4 d4 = *(lds_f4)(spa + t * 64 + ROWS * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float pr = __builtin_amdgcn_exp2f(sc[r] * sl2 - l4[r]);
@@ -963,17 +992,24 @@ __global__ __launch_bounds__(PW * 64, 4) void attn_bwd_one_kernel(AttnParams p) 
           const bf16x8 dsk = pack8(ds[0], ds[1]);
           // dS[query 16 (2a + t) + 4g + r][key row0 + n] -> LDS [query][key]
           {
-            char* col = dSs + (row0 + n) * 2;
+            const lds_p col = dsw + (a - a0) * (32 * DSROW);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
               for (int r = 0; r < 4; ++r)
-                *reinterpret_cast<short*>(col + ((2 * (a - a0) + t) * 16 + 4 * g + r) * DSROW) = dsk[4 * t + r];
+                *(__attribute__((address_space(3))) short*)(col + (t * 16 + r) * DSROW) = dsk[4 * t + r];
           }
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
-            dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(dOs, a * 32, dt * 16, lane), ppk, dvt[dt], 0, 0, 0);
-            dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Qs, a * 32, dt * 16, lane), dsk, dkt[dt], 0, 0, 0);
+            const lds_cp cp = CFHIP_LDS_XOR(qc0 + aoff, dt * 32);  // rows 32 a + 4 g + (n >> 2) of Q (+16: 2 048 bytes on); dO TILE bytes behind
+            const s16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)cp);
+            const s16x4 qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(cp + 2048));
+            const s16x4 olo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(cp + TILE));
+            const s16x4 ohi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(cp + TILE + 2048));
+            const bf16x8 dof = {olo[0], olo[1], olo[2], olo[3], ohi[0], ohi[1], ohi[2], ohi[3]};
+            const bf16x8 qf = {qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+            dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, ppk, dvt[dt], 0, 0, 0);
+            dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsk, dkt[dt], 0, 0, 0);
           }
         }
       }
@@ -984,17 +1020,30 @@ __global__ __launch_bounds__(PW * 64, 4) void attn_bwd_one_kernel(AttnParams p) 
       // ---- phase 2: dQ of the query tiles of this half, 32 columns per wave, reduction over every key
       if (qt < 2 * (a1 - a0)) {
         f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
-        const char* drow = dSs + (qt * 16 + n) * DSROW + 8 * g;
         const int a_end = CAUSAL ? min(NB, ((2 * a0 + qt) * 16 + 15) / 32 + 1) : NB;  // keys beyond the tile's last query: dS = 0
+        // (phase 2's three pointers are rebuilt per half: kept across phase 1 they push the CAUSAL forms into scratch)
+        lds_cp kc2[2], drow = (lds_cp)LDS_PTR(dSs) + (qt * 16 + n) * DSROW + 8 * g;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          kc2[j] = (lds_cp)LDS_PTR(Ks) + tile_off(4 * g + (n >> 2), (2 * ch + j) * 16 + 4 * (n & 3));
+          CFHIP_OPAQUE_LDS(kc2[j], lds_cp)
+        }
+        CFHIP_OPAQUE_LDS(drow, lds_cp)
 #pragma unroll 1
         for (int a = 0; a < a_end; ++a) {
-          const s16x4 lo = *reinterpret_cast<const s16x4*>(drow + a * 64);
-          const s16x4 hi = *reinterpret_cast<const s16x4*>(drow + a * 64 + 32);
+          typedef __attribute__((address_space(3))) const s16x4* lds_cs4;
+          const s16x4 lo = *(lds_cs4)(drow + a * 64);
+          const s16x4 hi = *(lds_cs4)(drow + a * 64 + 32);
           bf16x8 dsp;
           dsp[0] = lo[0]; dsp[1] = lo[1]; dsp[2] = lo[2]; dsp[3] = lo[3];
           dsp[4] = hi[0]; dsp[5] = hi[1]; dsp[6] = hi[2]; dsp[7] = hi[3];
-          dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Ks, a * 32, (2 * ch) * 16, lane), dsp, dq0, 0, 0, 0);
-          dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Ks, a * 32, (2 * ch + 1) * 16, lane), dsp, dq1, 0, 0, 0);
+          const lds_cp c0 = kc2[0] + a * (32 * 128), c1 = kc2[1] + a * (32 * 128);
+          const s16x4 k0l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)c0), k0h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(c0 + 2048));
+          const s16x4 k1l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)c1), k1h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(c1 + 2048));
+          const bf16x8 kf0c = {k0l[0], k0l[1], k0l[2], k0l[3], k0h[0], k0h[1], k0h[2], k0h[3]};
+          const bf16x8 kf1c = {k1l[0], k1l[1], k1l[2], k1l[3], k1h[0], k1h[1], k1h[2], k1h[3]};
+          dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0c, dsp, dq0, 0, 0, 0);
+          dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1c, dsp, dq1, 0, 0, 0);
         }
         const int qi = (2 * a0 + qt) * 16 + n;
         store_row32(p.dq + (long)b * p.q_sb + (long)qi * p.q_st + h * DH, dq0, dq1, p.scale, g, qi < p.Tq, ch);
@@ -1011,6 +1060,9 @@ __global__ __launch_bounds__(PW * 64, 4) void attn_bwd_one_kernel(AttnParams p) 
     if (nxt < heads) stage_stats(nxt);
   }
 }
+
+#undef CFHIP_OPAQUE_LDS
+#undef CFHIP_LDS_XOR
 
 // ------------------------------------------------------------------------------------------------
 // General form: any sequence length, head_dim = any multiple of 8 up to 192 (UNet cross-attention heads of 40 / 80 /
