@@ -48,7 +48,7 @@ struct AttnParams {
   unsigned drop_thresh;
   float drop_scale;
 #ifdef CFHIP_ABLATE
-  int ablate;       // benchmarking only (forward): bit0 skip the K/V DMA, bit1 skip the tile loop, bit2 skip stores
+  int ablate;       // benchmarking only (forward): bit0 skip the K/V DMA, bit1 skip the tile loop, bit2 skip stores; attn_bwd_one2_kernel: 8 no phase 1, 16 no phase 2, 32 no statistics, 64 no dK / dV stores, 128 no K / V fragments, 256 no staging of the next head
 #endif
 };
 
@@ -1058,6 +1058,263 @@ __global__ __launch_bounds__(PW * 64, 4) void attn_bwd_one_kernel(AttnParams p) 
       store_row64(p.dv + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH, dvt, 1.0f, g, valid);
     }
     if (nxt < heads) stage_stats(nxt);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The one-pass backward with TWO key tiles per wave (round 6, late; non-causal, 128 < T <= 224).  The 16-wave form above sits at 13 %
+// of the matrix pipe and 26 % of the LDS: at 128 registers per wave hipcc issues the LDS reads of a block two at a time and waits for
+// each pair (twelve exposed LDS latencies per 16 MFMAs).  Here a workgroup is 8 waves at 256 registers: a wave owns 32 keys, so every
+// Q / dO fragment read from LDS (row form for S and dP, column form for dV and dK) feeds two MFMAs — half the LDS reads per FLOP,
+// 32 MFMAs per block — and all fragments of a block are in flight before the first MFMA needs one.  Phase 2: a wave per 16-query tile
+// of the half, all 64 columns (four accumulators per dS operand read instead of two).  Same LDS layout, same arithmetic per element
+// (the reduction order over queries / keys inside an accumulator is unchanged): results are bit-identical to the 16-wave form.
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(512, 2) void attn_bwd_one2_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(128))) char smem[];  // 128: the XOR-derived addresses below need whole tile rows
+  constexpr int PW = 8;
+  constexpr int ROWS = NB * 32, TILE = ROWS * 128;
+  constexpr int HA = (NB + 1) / 2;          // query pair-tiles per half
+  constexpr int DSROW = ROWS * 2 + 16;      // bytes per dS row (ROWS keys, bf16) + 16: rows 4 apart start 16 banks apart
+  static_assert(3 * TILE + 2 * ROWS * 4 + HA * 32 * DSROW <= 160 * 1024, "Q + dO + K + statistics + dS must fit the LDS");
+  static_assert(NB <= PW && 2 * HA <= PW, "a wave per 32 keys; a wave per query tile of a half");
+  char* Qs = smem;
+  char* dOs = Qs + TILE;
+  char* Ks = dOs + TILE;
+  float* lse_s = reinterpret_cast<float*>(Ks + TILE);
+  float* delta_s = lse_s + ROWS;
+  char* dSs = reinterpret_cast<char*>(delta_s + ROWS);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int heads = p.B * p.H;
+  const float sl2 = p.scale * LOG2E;
+  const int row0 = wave * 32;  // phase 1: this wave's keys
+  const int qt = wave;         // phase 2: query tile of the half
+
+  auto stage_q = [&](int hx) {
+    const int b = hx / p.H, h = hx - b * p.H;
+    dma_tile(Qs, p.q + (long)b * p.q_sb + h * DH, p.q_st, p.Tq, ROWS, wave, PW, lane);
+    dma_tile(dOs, p.d_o + (long)b * p.o_sb + h * DH, p.o_st, p.Tq, ROWS, wave, PW, lane);
+  };
+  // statistics of a head (log-sum-exp in the log2 domain, delta = rowsum(dO o O)): four lanes per row, two sweeps of 128 rows.  The
+  // global loads (load_stats) are issued a whole dQ phase before their values are folded and written to the LDS (finish_stats).
+  bf16x8 st_a[2][2], st_c[2][2];
+  float st_l[2];
+  auto load_stats = [&](int hx) {
+    const int b = hx / p.H, h = hx - b * p.H;
+    const bf16_t* dob = p.d_o + (long)b * p.o_sb + h * DH;
+    const bf16_t* ob = p.o_in + (long)b * p.o_sb + h * DH;
+    const int part = (int)threadIdx.x & 3;
+#pragma unroll
+    for (int sw = 0; sw < 2; ++sw) {
+      const int t = ((int)threadIdx.x >> 2) + sw * (PW * 16);
+      const bool ok = t < p.Tq && !ATTN_ABL(32);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        st_a[sw][j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        st_c[sw][j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) {
+          st_a[sw][j] = *reinterpret_cast<const bf16x8*>(dob + (long)t * p.o_st + part * 16 + j * 8);
+          st_c[sw][j] = *reinterpret_cast<const bf16x8*>(ob + (long)t * p.o_st + part * 16 + j * 8);
+        }
+      }
+      st_l[sw] = (ok && part == 0) ? p.lse[(long)hx * p.Tq + t] * LOG2E : INFINITY;  // +inf -> p = 0 for padded query rows
+    }
+  };
+  auto finish_stats = [&](int hx) {
+    const int part = (int)threadIdx.x & 3;
+#pragma unroll
+    for (int sw = 0; sw < 2; ++sw) {
+      const int t = ((int)threadIdx.x >> 2) + sw * (PW * 16);
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sacc += bf16_to_f32((bf16_t)st_a[sw][j][e]) * bf16_to_f32((bf16_t)st_c[sw][j][e]);
+      sacc += __shfl_xor(sacc, 1, 64);
+      sacc += __shfl_xor(sacc, 2, 64);
+      if (part == 0 && t < ROWS) {
+        lse_s[t] = st_l[sw];
+        delta_s[t] = sacc;  // (rows beyond Tq: zero operands)
+        if (t < p.Tq && p.delta != nullptr) p.delta[(long)hx * p.Tq + t] = sacc;
+      }
+    }
+  };
+  auto stage_k = [&](int hx) {
+    const int b = hx / p.H, h = hx - b * p.H;
+    dma_tile(Ks, p.k + (long)b * p.kv_sb + h * DH, p.kv_st, p.Tk, ROWS, wave, PW, lane);
+  };
+
+  typedef __attribute__((address_space(3))) const char* lds_cp;
+  typedef __attribute__((address_space(3))) char* lds_p;
+  typedef __attribute__((address_space(3))) const bf16x8* lds_v8;
+  typedef __attribute__((address_space(3))) const f32x4* lds_f4;
+  typedef __attribute__((address_space(3))) s16x4* lds_s4;
+  typedef __attribute__((address_space(3))) const s16x4* lds_cs4;
+  lds_cp qr0, qc0, sp, drow, kc0;
+  lds_p dsw;
+  {
+    const lds_cp q3 = (lds_cp)LDS_PTR(Qs);
+    qr0 = q3 + n * 128 + ((g ^ swz(n)) << 4);
+    qc0 = q3 + tile_off(4 * g + (n >> 2), 4 * (n & 3));
+    kc0 = qc0 + 2 * TILE;
+    sp = (lds_cp)LDS_PTR(lse_s) + 16 * g;
+    dsw = (lds_p)LDS_PTR(dSs) + (row0 + n) * 2 + 4 * g * DSROW;
+    drow = (lds_cp)LDS_PTR(dSs) + (qt * 16 + n) * DSROW + 8 * g;
+    CFHIP_OPAQUE_LDS(qr0, lds_cp)
+    CFHIP_OPAQUE_LDS(qc0, lds_cp)
+    CFHIP_OPAQUE_LDS(kc0, lds_cp)
+    CFHIP_OPAQUE_LDS(sp, lds_cp)
+    CFHIP_OPAQUE_LDS(dsw, lds_p)
+    CFHIP_OPAQUE_LDS(drow, lds_cp)
+  }
+  // K / V fragments of this wave's two key tiles (rows beyond Tk are zero): loaded for the NEXT head behind the last phase 1 of a head
+  bf16x8 kf[2][2], vf[2][2];
+  auto load_kv = [&](int hx) {
+    const int b = hx / p.H, h = hx - b * p.H;
+    const bf16_t* kb = p.k + (long)b * p.kv_sb + h * DH;
+    const bf16_t* vb = p.v + (long)b * p.kv_sb + h * DH;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        kf[kt][ks] = frag_global(kb, p.kv_st, row0 + 16 * kt, ATTN_ABL(128) ? 0 : p.Tk, ks, lane);
+        vf[kt][ks] = frag_global(vb, p.kv_st, row0 + 16 * kt, ATTN_ABL(128) ? 0 : p.Tk, ks, lane);
+      }
+  };
+  int hh = blockIdx.x;
+  if (hh < heads) {
+    stage_q(hh);
+    load_kv(hh);
+    load_stats(hh);
+    finish_stats(hh);
+  }
+  for (; hh < heads; hh += gridDim.x) {
+    const int b = hh / p.H, h = hh - b * p.H;
+    const int nxt = hh + gridDim.x;
+    // Q, dO and the statistics of this head are in the LDS (staged behind the previous head's last phase 1); the previous head's last
+    // dQ phase is over, so its K tile may go: this head's K streams in under phase 1, which takes K from registers
+    lds_dma_wait_all();
+    __syncthreads();
+    if (!ATTN_ABL(256)) stage_k(hh);
+
+    f32x4 dkt[2][4], dvt[2][4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { dkt[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int a0 = hf * HA, a1 = hf == 0 ? HA : NB;
+      // ---- phase 1: 32 keys x the query tiles of this half
+      if (row0 < ROWS && !ATTN_ABL(8)) {
+#pragma unroll 1
+        for (int a = a0; a < a1; ++a) {
+          const int aoff = a * (32 * 128);
+          const lds_cp spa = sp + a * 128;
+          bf16x8 qf[2][2], dof[2][2];
+          f32x4 l4[2], d4[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const lds_cp r0 = qr0 + aoff + t * 2048, r1 = CFHIP_LDS_XOR(qr0 + aoff, 64) + t * 2048;  // rows 32 a + 16 t + n of Q; dO TILE bytes behind
+            qf[t][0] = *(lds_v8)r0;
+            qf[t][1] = *(lds_v8)r1;
+            dof[t][0] = *(lds_v8)(r0 + TILE);
+            dof[t][1] = *(lds_v8)(r1 + TILE);
+            l4[t] = *(lds_f4)(spa + t * 64);
+            d4[t] = *(lds_f4)(spa + t * 64 + ROWS * 4);
+          }
+          bf16x8 ppk[2], dsk[2];
+          const lds_p col = dsw + (a - a0) * (32 * DSROW);
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            f32x4 pp[2], ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+              sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[t][0], kf[kt][0], sc, 0, 0, 0);
+              sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[t][1], kf[kt][1], sc, 0, 0, 0);
+              dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[t][0], vf[kt][0], dp, 0, 0, 0);
+              dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[t][1], vf[kt][1], dp, 0, 0, 0);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float pr = __builtin_amdgcn_exp2f(sc[r] * sl2 - l4[t][r]);
+                pp[t][r] = pr;
+                ds[t][r] = pr * (dp[r] - d4[t][r]);
+              }
+            }
+            ppk[kt] = pack8(pp[0], pp[1]);
+            dsk[kt] = pack8(ds[0], ds[1]);
+            // dS[query 16 (2 (a - a0) + t) + 4g + r][key row0 + 16 kt + n] -> LDS [query][key]
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                *(__attribute__((address_space(3))) short*)(col + kt * 32 + (t * 16 + r) * DSROW) = dsk[kt][4 * t + r];
+          }
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const lds_cp cp = CFHIP_LDS_XOR(qc0 + aoff, dt * 32);  // rows 32 a + 4 g + (n >> 2) of Q (+16: 2 048 bytes on); dO TILE bytes behind
+            const s16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)cp);
+            const s16x4 qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(cp + 2048));
+            const s16x4 olo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(cp + TILE));
+            const s16x4 ohi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(cp + TILE + 2048));
+            const bf16x8 doc = {olo[0], olo[1], olo[2], olo[3], ohi[0], ohi[1], ohi[2], ohi[3]};
+            const bf16x8 qcf = {qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+              dvt[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doc, ppk[kt], dvt[kt][dt], 0, 0, 0);
+              dkt[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qcf, dsk[kt], dkt[kt][dt], 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (hf == 0) {
+        lds_dma_wait_all();  // this head's K tile (issued a phase ago)
+      } else {
+        // dK / dV are complete: out now, behind the dQ phase, not at the end of the head
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          const int kj = row0 + 16 * kt + n;
+          const bool valid = kj < p.Tk && !ATTN_ABL(64);
+          store_row64(p.dk + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH, dkt[kt], p.scale, g, valid);
+          store_row64(p.dv + (long)b * p.kv_sb + (long)kj * p.kv_st + h * DH, dvt[kt], 1.0f, g, valid);
+        }
+      }
+      __syncthreads();
+      // Q, dO and the statistics of this head are done with after the second half's phase 1: the NEXT head's stream in behind the last
+      // dQ phase — tiles by DMA, the wave's K / V fragments and the statistics' inputs into registers
+      if (hf == 1 && nxt < heads) {
+        if (!ATTN_ABL(256)) stage_q(nxt);
+        load_kv(nxt);
+        load_stats(nxt);
+      }
+      // ---- phase 2: dQ of the query tiles of this half, reduction over every key
+      if (qt < 2 * (a1 - a0) && !ATTN_ABL(16)) {
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int a = 0; a < NB; ++a) {
+          const s16x4 lo = *(lds_cs4)(drow + a * 64);
+          const s16x4 hi = *(lds_cs4)(drow + a * 64 + 32);
+          const bf16x8 dsp = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const lds_cp cp = CFHIP_LDS_XOR(kc0 + a * (32 * 128), dt * 32);
+            const s16x4 kl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)cp), kh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(cp + 2048));
+            const bf16x8 kcf = {kl[0], kl[1], kl[2], kl[3], kh[0], kh[1], kh[2], kh[3]};
+            dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kcf, dsp, dq[dt], 0, 0, 0);
+          }
+        }
+        const int qi = (2 * a0 + qt) * 16 + n;
+        store_row64(p.dq + (long)b * p.q_sb + (long)qi * p.q_st + h * DH, dq, p.scale, g, qi < p.Tq);
+      }
+      if (hf == 0) __syncthreads();  // the dS buffer may be overwritten (after the second half: the barrier at the top of the next head)
+    }
+    if (nxt < heads) finish_stats(nxt);
   }
 }
 
@@ -2439,7 +2696,7 @@ bool set_dropout(AttnParams& p, float dropout_p, uint64_t seed, uint64_t offset)
 }
 
 int g_attn_pers_ctas = 256;  // workgroups of a persistent launch (one per CU; fewer leave CUs to the other queues)
-int g_attn_one_pass = 1;  // option "attn_one_pass": 1 (default, round 6) = attn_bwd_one_kernel when both passes are asked for in one call (PLAIN, self-attention, 32 < T <= 224); 0: the two-pass kernels
+int g_attn_one_pass = 2;  // option "attn_one_pass": 0 = the two-pass kernels; 1 (round 6) = attn_bwd_one_kernel when both passes are asked for in one call (PLAIN or causal self-attention, 32 < T <= 224); 2 (default) = that, with 128 < T <= 224 without a mask on attn_bwd_one2_kernel (8 waves, two key tiles per wave; bit-identical results)
 int g_attn_persistent = 7;  // bit 0: dK / dV pass, bit 1: dQ pass, bit 2: forward — as persistent 16-wave workgroups when 128 < T <= 256 (the ViT shape)
 
 int check_head_dim(const char* who, int head_dim) {
@@ -2590,6 +2847,14 @@ static int launch_one_pass(const AttnParams& p, bool causal, hipStream_t s) {
       const int rc = set_lds(attn_bwd_one_kernel<NB, PW, true>, lds, "attn_bwd_one");
       if (rc != CFHIP_OK) return rc;
       hipLaunchKernelGGL((attn_bwd_one_kernel<NB, PW, true>), grid, block, lds, s, p);
+      return CFHIP_OK;
+    }
+  }
+  if constexpr (NB >= 5) {
+    if (!causal && g_attn_one_pass >= 2) {  // two key tiles per wave: 8 waves
+      const int rc = set_lds(attn_bwd_one2_kernel<NB>, lds, "attn_bwd_one");
+      if (rc != CFHIP_OK) return rc;
+      hipLaunchKernelGGL((attn_bwd_one2_kernel<NB>), grid, dim3(512), lds, s, p);
       return CFHIP_OK;
     }
   }

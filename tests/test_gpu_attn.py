@@ -632,14 +632,15 @@ def test_one_pass_backward_matches_the_two_pass_kernels_and_the_oracle(b, t, h):
     roundings: agreement to a few bf16 ulps of the accumulated sums) and, for the small cases, against fp32 math; `delta` is written
     as by the dQ pass; ragged last tiles (197 = 12 x 16 + 5), the largest supported length (224), and more heads than one round of
     persistent workgroups (70 x 12 = 840 heads on 256 workgroups: the walk over heads, the next head's Q / dO streaming in behind the
-    last dQ phase); the short forms on 4 / 8 waves (T = 50: ViT-B/32 in CLIP; 33 .. 128)."""
+    last dQ phase); the short forms on 4 / 8 waves (T = 50: ViT-B/32 in CLIP; 33 .. 128); the 8-wave two-key-tile form of
+    128 < T <= 224 (`attn_bwd_one2_kernel`, option value 2, the default) bit for bit against the 16-wave form."""
     qkv = _qkv(b, t, h, 300 + t, scale=1.5).to(DEV)
     d = h * 64
     d_o = torch.randn(b, t, d, generator=torch.Generator().manual_seed(t + 1)).to(torch.bfloat16).to(DEV)
     q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
     o, lse = ops.attn_fwd(q, k, v, h)
     outs = []
-    for one in (0, 1, 1):
+    for one in (0, 1, 1, 2):
         ops.set_option("attn_one_pass", one)
         try:
             dqkv = torch.zeros_like(qkv)
@@ -647,9 +648,11 @@ def test_one_pass_backward_matches_the_two_pass_kernels_and_the_oracle(b, t, h):
             ops.attn_bwd(q, k, v, o, d_o, lse, h, dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], delta=delta)
             outs.append((dqkv, delta))
         finally:
-            ops.set_option("attn_one_pass", 1)
+            ops.set_option("attn_one_pass", 2)
     torch.cuda.synchronize()
     assert torch.equal(outs[1][0], outs[2][0])  # run-to-run bitwise (no atomics)
+    # option 2 (the default): 128 < T <= 224 on the 8-wave form with two key tiles per wave — the same sums in the same order
+    assert torch.equal(outs[3][0], outs[1][0]) and torch.equal(outs[3][1], outs[1][1])
     for nm, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
         assert_close(outs[1][0][..., sl], outs[0][0][..., sl].float(), 4e-3, f"one-pass {nm} vs two-pass {b}x{t}x{h}", abs_floor=1e-6)
     assert_close(outs[1][1], outs[0][1], 1e-5, "delta")
@@ -676,7 +679,7 @@ def test_one_pass_backward_causal(b, t, h):
             ops.attn_bwd(q, k, v, o, d_o, lse, h, dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], causal=True)
             outs.append(dqkv)
         finally:
-            ops.set_option("attn_one_pass", 1)
+            ops.set_option("attn_one_pass", 2)
     for nm, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
         assert_close(outs[1][..., sl], outs[0][..., sl].float(), 4e-3, f"causal one-pass {nm} vs two-pass {b}x{t}x{h}", abs_floor=1e-6)
     if b <= 3:

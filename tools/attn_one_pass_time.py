@@ -32,10 +32,10 @@ time.sleep(2.0)
 idle = tel.summary(t0, time.perf_counter())["power_w_avg"]
 print(f"batch {B}: {B * H} heads; idle {idle} W")
 for rnd in range(2):
-    for one in (0, 1):
+    for one in (0, 1, 2):
         ops.set_option("attn_one_pass", one)
         n, sec, s = loop(lambda: ops.attn_bwd(q, k, v, o, d_o, lse, H, dq=dq, dk=dk, dv=dv, parts=3, delta=delta), 1.5, tel)
-        print(f"  {'one pass ' if one else 'two passes'}: {sec * 1e6:7.1f} us per backward  {flops / sec / 1e12:6.1f} TFLOP/s (two-pass FLOP count)  "
+        print(f"  {('two passes', 'one pass (16 waves)', 'one pass (8 waves, 2 key tiles)')[one]:31s}: {sec * 1e6:7.1f} us per backward  {flops / sec / 1e12:6.1f} TFLOP/s (two-pass FLOP count)  "
               f"{s['power_w_avg']} W  {s['sclk_mhz_avg']} MHz  {(s['power_w_avg'] - idle) * sec * 1e3:7.2f} mJ", flush=True)
-ops.set_option("attn_one_pass", 1)
+ops.set_option("attn_one_pass", 2)
 tel.stop()
