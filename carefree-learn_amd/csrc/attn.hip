@@ -676,13 +676,19 @@ __global__ __launch_bounds__(PERS_WAVES * 64, 4) void attn_fwd_pers_kernel(AttnP
   __syncthreads();
   const int row0 = wave * 16;
   const int qi = row0 + i;
+  // this wave's Q fragments: of the first head here, of every later head right behind the S products of the head before (their
+  // global-memory latency used to sit in front of the first MFMA of every head)
+  bf16x8 qf0 = {0, 0, 0, 0, 0, 0, 0, 0}, qf1 = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hh < heads) {
+    const int b = hh / p.H, h = hh - b * p.H;
+    const bf16_t* qb = p.q + (long)b * p.q_sb + h * DH;
+    qf0 = frag_global(qb, p.q_st, row0, p.Tq, 0, lane);
+    qf1 = frag_global(qb, p.q_st, row0, p.Tq, 1, lane);
+  }
   for (; hh < heads; hh += gridDim.x) {
     const int b = hh / p.H, h = hh - b * p.H;
     const char* Ks = smem + cur * BUF;
     const char* Vs = Ks + TILE;
-    const bf16_t* qb = p.q + (long)b * p.q_sb + h * DH;
-    const bf16x8 qf0 = frag_global(qb, p.q_st, row0, p.Tq, 0, lane);
-    const bf16x8 qf1 = frag_global(qb, p.q_st, row0, p.Tq, 1, lane);
     const int nxt = hh + gridDim.x;
     issue(nxt < heads ? nxt : hh, smem + (cur ^ 1) * BUF, nxt < heads);
     if (row0 < p.Tq) {
@@ -694,6 +700,12 @@ __global__ __launch_bounds__(PERS_WAVES * 64, 4) void attn_fwd_pers_kernel(AttnP
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, jt * 16, 1, lane), qf1, acc, 0, 0, 0);
         st[jt] = acc;
         if (jt & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (nxt < heads) {
+        const int bn = nxt / p.H, hn = nxt - bn * p.H;
+        const bf16_t* qn = p.q + (long)bn * p.q_sb + hn * DH;
+        qf0 = frag_global(qn, p.q_st, row0, p.Tq, 0, lane);
+        qf1 = frag_global(qn, p.q_st, row0, p.Tq, 1, lane);
       }
 #pragma unroll
       for (int jt = 2 * NB - 2; jt < 2 * NB; ++jt) {
