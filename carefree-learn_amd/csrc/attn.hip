@@ -2129,7 +2129,7 @@ __global__ __launch_bounds__(256, (NDT == 3 && PLAIN) ? 3 : 2) void attn_bwd_dkv
   static_assert(!FOLD || (PLAIN && NDT == 3), "the folded delta: plain head_dim-40 form only");
   constexpr int KS = (NDT + 1) / 2;     // 32-deep steps of the reductions over head_dim
   constexpr int NHALF = (NDT + 3) / 4;  // 64-column halves of a staged operand
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(128))) char smem[];  // 128: the XOR-derived addresses below need whole tile rows
   char* Qs = smem;
   char* dOs = smem + NHALF * A2D_TILE;
   float* lse_s = reinterpret_cast<float*>(smem + 2 * NHALF * A2D_TILE);
@@ -2168,6 +2168,26 @@ __global__ __launch_bounds__(256, (NDT == 3 && PLAIN) ? 3 : 2) void attn_bwd_dkv
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) { dkt[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+  // Lane-constant parts of the LDS addresses of a block as opaque LDS-space pointers (see attn_bwd_dq3_kernel / attn_bwd_one_kernel):
+  // the other reduction half of a row fragment and the other column tiles are an XOR of bits 5..6 away, halves / dO / the second
+  // transposing read / the second 16-row tile are immediates; a block adds its a * 4 096 (statistics: a * 128) bytes to three of them.
+  typedef __attribute__((address_space(3))) const char* lds_cp;
+  typedef __attribute__((address_space(3))) const bf16x8* lds_v8;
+  typedef __attribute__((address_space(3))) const f32x4* lds_f4;
+  typedef __attribute__((address_space(3))) s16x4* lds_s4;
+  lds_cp qr0, qc0, sp;
+  {
+    const lds_cp q3 = (lds_cp)LDS_PTR(Qs);
+    qr0 = q3 + n * 128 + ((g ^ swz(n)) << 4);
+    qc0 = q3 + tile_off(4 * g + (n >> 2), 4 * (n & 3));
+    sp = (lds_cp)LDS_PTR(lse_s) + 16 * g;
+#define CFHIP_OPAQUE_LDS(ptr, T) { unsigned u_ = (unsigned)(uintptr_t)(ptr); asm volatile("" : "+v"(u_)); (ptr) = (T)(uintptr_t)u_; }
+#define CFHIP_LDS_XOR(ptr, bits) ((lds_cp)(uintptr_t)((unsigned)(uintptr_t)(ptr) ^ (unsigned)(bits)))
+    CFHIP_OPAQUE_LDS(qr0, lds_cp)
+    CFHIP_OPAQUE_LDS(qc0, lds_cp)
+    CFHIP_OPAQUE_LDS(sp, lds_cp)
+  }
+  constexpr int DO_OFF = NHALF * A2D_TILE;  // the dO tile(s) behind the Q tile(s)
   for (int q0 = 0; q0 < p.Tq; q0 += A2D_CH) {
     const int rows = min(A2D_CH, p.Tq - q0);
     __syncthreads();
@@ -2201,18 +2221,21 @@ __global__ __launch_bounds__(256, (NDT == 3 && PLAIN) ? 3 : 2) void attn_bwd_dkv
 #pragma unroll 1
     for (int a = 0; a < nbl; ++a) {
       f32x4 pp[2][2], ds[2][2];  // [kv tile][query 16-row tile]
+      const int aoff = a * (32 * 128);
+      const lds_cp ra = qr0 + aoff, rb = CFHIP_LDS_XOR(qr0 + aoff, 64), spa = sp + a * 128;
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int r16 = a * 32 + it * 16;
         bf16x8 qf[KS], of[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          qf[ks] = frag_rows(Qs + (ks >> 1) * A2D_TILE, r16, ks & 1, lane);
-          of[ks] = frag_rows(dOs + (ks >> 1) * A2D_TILE, r16, ks & 1, lane);
+          const lds_cp rp = ((ks & 1) ? rb : ra) + (ks >> 1) * A2D_TILE + it * 2048;  // rows r16 + n, reduction half ks
+          qf[ks] = *(lds_v8)rp;
+          of[ks] = *(lds_v8)(rp + DO_OFF);
         }
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + r16 + 4 * g);
+        const f32x4 l4 = *(lds_f4)(spa + it * 64);
         f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
-        if (!FOLD) d4 = *reinterpret_cast<const f32x4*>(delta_s + r16 + 4 * g);
+        if (!FOLD) d4 = *(lds_f4)(spa + it * 64 + A2D_CH * 4);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -2237,10 +2260,15 @@ __global__ __launch_bounds__(256, (NDT == 3 && PLAIN) ? 3 : 2) void attn_bwd_dkv
       const bf16x8 dsk0 = pack8(ds[0][0], ds[0][1]), dsk1 = pack8(ds[1][0], ds[1][1]);
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        const bf16x8 oc = frag_cols(dOs + (dt >> 2) * A2D_TILE, a * 32, (dt & 3) * 16, lane);
+        const lds_cp cp = CFHIP_LDS_XOR(qc0 + aoff, (dt & 3) * 32) + (dt >> 2) * A2D_TILE;  // rows 32 a + 4 g + (n >> 2) (+16: 2 048 bytes on)
+        const s16x4 olo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(cp + DO_OFF));
+        const s16x4 ohi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(cp + DO_OFF + 2048));
+        const bf16x8 oc = {olo[0], olo[1], olo[2], olo[3], ohi[0], ohi[1], ohi[2], ohi[3]};
         dvt[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oc, ppk0, dvt[0][dt], 0, 0, 0);
         dvt[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oc, ppk1, dvt[1][dt], 0, 0, 0);
-        const bf16x8 qc = frag_cols(Qs + (dt >> 2) * A2D_TILE, a * 32, (dt & 3) * 16, lane);
+        const s16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)cp);
+        const s16x4 qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(cp + 2048));
+        const bf16x8 qc = {qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
         dkt[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qc, dsk0, dkt[0][dt], 0, 0, 0);
         dkt[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qc, dsk1, dkt[1][dt], 0, 0, 0);
       }
@@ -2264,6 +2292,8 @@ __global__ __launch_bounds__(256, (NDT == 3 && PLAIN) ? 3 : 2) void attn_bwd_dkv
     }
   }
 }
+#undef CFHIP_OPAQUE_LDS
+#undef CFHIP_LDS_XOR
 
 
 // ------------------------------------------------------------------------------------------------
