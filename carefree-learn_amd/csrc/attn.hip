@@ -127,6 +127,14 @@ __device__ __forceinline__ bf16x8 frag_global(const bf16_t* base, long stride_t,
   return r;
 }
 
+// Packed f32 VALU, measured twice in round 6 (profiles/r06/attn_packed_f32_rejected.txt): (1) the softmax math of the long-sequence backward
+// passes written on vectors (16 fma + 16 mul -> 8 v_pk_fma_f32 + 8 v_pk_mul_f32 per block) made dQ 2.5 % and dK / dV 4-5 % SLOWER — the
+// packed instructions are no bargain beside MFMAs (MI355X_MICROARCH.md prices one v_pk_fma_f32 at +22 cycles against two v_fma_f32);
+// (2) the other direction — the v_pk_mul_f32 hipcc's SLP pass makes of the one-pass backward's `pr * (dP - delta)` pinned to single
+// v_mul_f32 through inline asm — was 3.4 % slower too (12 more conversions).  And inline asm must never READ an MFMA result: hipcc's
+// hazard recogniser does not see the asm as a VALU consumer and omits the wait states (the persistent forward with asm fma / max3
+// on the scores returned NaN).  So: scalar source, the compiler's own choice of packing, asm only on VALU results (max_nn).
+
 __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   union { bf16x8 v; unsigned w[4]; } u;
   u.w[0] = pack_bf16x2(a[0], a[1]); u.w[1] = pack_bf16x2(a[2], a[3]);
@@ -194,13 +202,21 @@ __device__ __forceinline__ float group_max(float v) {  // across the 4 lanes sha
 // twice in a row on the critical path of every 64-key block of the long-sequence forward.  v_permlane16_swap(v, v) leaves the two halves of
 // every 32-lane pair of rows side by side (result 0: the even rows' values in both rows, result 1: the odd rows'), v_permlane32_swap(v, v)
 // the two 32-lane halves: one max each.
+// max of two values that are never NaN (scores, running maxima: finite or -inf): fmaxf() on values that come out of a lane swap
+// (integers to the compiler) is preceded by a quieting v_max_f32 v, v, v per operand — three instructions for one; the med3(x, y, +inf)
+// builtin is folded back into the same maxnum.  The instruction itself, then.
+__device__ __forceinline__ float max_nn(float x, float y) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
 __device__ __forceinline__ float group_max_swap(float v) {
   const unsigned u = __float_as_uint(v);
   const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  const float m1 = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const float m1 = max_nn(__uint_as_float(a[0]), __uint_as_float(a[1]));
   const unsigned w = __float_as_uint(m1);
   const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+  return max_nn(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 __device__ __forceinline__ float group_sum(float v) {
   v += __shfl_xor(v, 16, 64);
@@ -1941,7 +1957,7 @@ __global__ __launch_bounds__(512, NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4) void att
           }
         }
         mx = group_max_swap(mx) * sl2;
-        const float m_new = fmaxf(m[t], mx);
+        const float m_new = max_nn(m[t], mx);
         // rows whose every position so far is masked (m_new = -inf) must not produce NaN from (-inf) - (-inf): use 0
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
         alpha[t] = __builtin_amdgcn_exp2f(m[t] - m_use);  // m = -inf on the first block: 0; unchanged maximum: exactly 1
