@@ -1852,11 +1852,26 @@ constexpr int A2_TILE = A2_CH * 128;
 #ifndef CFHIP_ATTN_NDT4_WAVES
 #define CFHIP_ATTN_NDT4_WAVES 4  // waves per SIMD of the head_dim-64 (NDT = 4) long-sequence forms: 4 keeps 12-36 B of scratch, 3 has none (A/B: profiles/r05)
 #endif
+// NDT = 5 / 6 (head_dim 72 .. 96: the UNet's 80-channel heads; round 6, late): the same loop over KS = 3 reduction steps and two
+// 64-column halves of the staged K / V — as attn_bwd_dkv2_kernel does it: 4 waves, 128-key chunks (64 KB of LDS), two workgroups per CU
+// at 256 registers.  The one-tile general kernel ran this head_dim's forward at 527 TFLOP/s against 1 020 for its dK / dV pass.
+template <int NDT>
+struct Fwd2 {
+  static constexpr int NH = (NDT + 3) / 4;  // 64-column halves of a staged operand
+  static constexpr int KS = (NDT + 1) / 2;  // 32-deep steps of the reduction over head_dim
+  static constexpr int NW = NH == 1 ? 8 : 4;
+  static constexpr int CH = Gen<NH>::CH;    // keys per staged chunk: 256 / 128
+  static constexpr int HB = Gen<NH>::HALF_BYTES;
+  static constexpr int WAVES_PER_SIMD = NH == 1 ? (NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4) : 2;
+};
 template <bool PLAIN, int NDT, bool SUMCOL = false>
-__global__ __launch_bounds__(512, NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4) void attn_fwd2_kernel(AttnParams p) {
+__global__ __launch_bounds__(Fwd2<NDT>::NW * 64, Fwd2<NDT>::WAVES_PER_SIMD) void attn_fwd2_kernel(AttnParams p) {
+  using F = Fwd2<NDT>;
+  constexpr int NH = F::NH, KS = F::KS, NW = F::NW, CH = F::CH, HB = F::HB;
+  static_assert(!SUMCOL || NH == 1, "the ones column: single-half forms only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
-  char* Vs = smem + A2_TILE;
+  char* Vs = smem + NH * HB;
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1864,7 +1879,7 @@ __global__ __launch_bounds__(512, NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4) void att
   const int dh = p.dh;
   if (SUMCOL) {
     // pad chunks of both tiles, once: zeros, and 1.0 in column dh of V (dh % 16 == 8: element 0 of its 16-byte chunk)
-    for (int idx = threadIdx.x; idx < A2_CH * 8; idx += 512) {
+    for (int idx = threadIdx.x; idx < CH * 8; idx += NW * 64) {
       const int row = idx >> 3, chunk = idx & 7;
       if (chunk * 8 >= dh) {
         const int off = row * 128 + ((chunk ^ swz(row)) << 4);
@@ -1876,13 +1891,13 @@ __global__ __launch_bounds__(512, NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4) void att
   const bf16_t* kb = p.k + (long)b * p.kv_sb + h * dh;
   const bf16_t* vb = p.v + (long)b * p.kv_sb + h * dh;
   const bf16_t* qb = p.q + (long)b * p.q_sb + h * dh;
-  const int row0 = (blockIdx.x * 8 + wave) * 32;
+  const int row0 = (blockIdx.x * NW + wave) * 32;
   const bool active = row0 < p.Tq;  // inactive waves still stage and hit the barriers
-  bf16x8 qf[2][2];
+  bf16x8 qf[2][KS];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[t][ks] = frag_global_dh(qb, p.q_st, row0 + 16 * t, active ? p.Tq : 0, ks, lane, dh);
+    for (int ks = 0; ks < KS; ++ks) qf[t][ks] = frag_global_dh(qb, p.q_st, row0 + 16 * t, active ? p.Tq : 0, ks, lane, dh);
   const float sl2 = p.scale * LOG2E;
   float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};  // l: this LANE's share of the row sum
   f32x4 ot[2][NDT];
@@ -1891,14 +1906,14 @@ __global__ __launch_bounds__(512, NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4) void att
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) ot[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int kv0 = 0; kv0 < p.Tk; kv0 += A2_CH) {
-    const int rows = min(A2_CH, p.Tk - kv0);
+  for (int kv0 = 0; kv0 < p.Tk; kv0 += CH) {
+    const int rows = min(CH, p.Tk - kv0);
     __syncthreads();  // every wave is done with the previous chunk
     {
       int ln = lane;  // opaque copy: the per-lane DMA offsets are recomputed per chunk instead of hoisted and spilled
       asm volatile("" : "+v"(ln));
-      dma_oper<1, SUMCOL>(Ks, kb + (long)kv0 * p.kv_st, p.kv_st, rows, dh, wave, 8, ln);
-      dma_oper<1, SUMCOL>(Vs, vb + (long)kv0 * p.kv_st, p.kv_st, rows, dh, wave, 8, ln);
+      dma_oper<NH, SUMCOL>(Ks, kb + (long)kv0 * p.kv_st, p.kv_st, rows, dh, wave, NW, ln);
+      dma_oper<NH, SUMCOL>(Vs, vb + (long)kv0 * p.kv_st, p.kv_st, rows, dh, wave, NW, ln);
     }
     lds_dma_wait_all();
     __syncthreads();
@@ -1912,13 +1927,14 @@ __global__ __launch_bounds__(512, NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4) void att
       f32x4 st[2][4];
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
-        const bf16x8 kf0 = frag_rows(Ks, k0 + jt * 16, 0, lane);
-        const bf16x8 kf1 = frag_rows(Ks, k0 + jt * 16, 1, lane);
+        bf16x8 kf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = frag_rows(Ks + (ks >> 1) * HB, k0 + jt * 16, ks & 1, lane);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[t][0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[t][1], acc, 0, 0, 0);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[t][ks], acc, 0, 0, 0);
           st[t][jt] = acc;
         }
       }
@@ -1986,7 +2002,7 @@ __global__ __launch_bounds__(512, NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4) void att
         const bf16x8 pa1 = pack8(st[1][2 * a], st[1][2 * a + 1]);
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-          const bf16x8 vf = frag_cols(Vs, k0 + a * 32, dt * 16, lane);
+          const bf16x8 vf = frag_cols(Vs + (dt >> 2) * HB, k0 + a * 32, (dt & 3) * 16, lane);
           ot[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pa0, ot[0][dt], 0, 0, 0);
           ot[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pa1, ot[1][dt], 0, 0, 0);
         }
@@ -2018,28 +2034,32 @@ __global__ __launch_bounds__(512, NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4) void att
 // Key rows beyond Tk are zero rows of the staged chunk: their p is finite, their dP and their K are zero, they add nothing.
 // (masked / causal instantiations: the predicate registers do not fit beside two 16-row tiles at 128 registers — two waves per
 // SIMD for them, no scratch; PLAIN, the UNet's and the ViT's path, keeps four)
+// NDT = 5 / 6 (head_dim 72 .. 96; round 6, late): KS = 3 reduction steps and two 64-column halves per staged operand, 4 waves, 128-key
+// chunks, two workgroups per CU — the geometry of Fwd2<NDT> (the general one-tile kernel ran the UNet's 80-channel dQ at 746 TFLOP/s).
 template <bool PLAIN, int NDT>
-__global__ __launch_bounds__(512, PLAIN ? (NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4) : 2) void attn_bwd_dq2_kernel(AttnParams p) {
+__global__ __launch_bounds__(Fwd2<NDT>::NW * 64, PLAIN ? Fwd2<NDT>::WAVES_PER_SIMD : 2) void attn_bwd_dq2_kernel(AttnParams p) {
+  using F = Fwd2<NDT>;
+  constexpr int NH = F::NH, KS = F::KS, NW = F::NW, CH = F::CH, HB = F::HB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
-  char* Vs = smem + A2_TILE;
+  char* Vs = smem + NH * HB;
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int dh = p.dh;
-  const int row0 = (blockIdx.x * 8 + wave) * 32;
+  const int row0 = (blockIdx.x * NW + wave) * 32;
   const bool active = row0 < p.Tq;
   const bf16_t* qb = p.q + (long)b * p.q_sb + h * dh;
   const bf16_t* dob = p.d_o + (long)b * p.o_sb + h * dh;
   const bf16_t* ob = p.o_in + (long)b * p.o_sb + h * dh;
-  bf16x8 qf[2][2], dof[2][2];
+  bf16x8 qf[2][KS], dof[2][KS];
   float delta[2], lse2[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     float sacc = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       qf[t][ks] = frag_global_dh(qb, p.q_st, row0 + 16 * t, active ? p.Tq : 0, ks, lane, dh);
       dof[t][ks] = frag_global_dh(dob, p.o_st, row0 + 16 * t, active ? p.Tq : 0, ks, lane, dh);
       const bf16x8 of = frag_global_dh(ob, p.o_st, row0 + 16 * t, active ? p.Tq : 0, ks, lane, dh);
@@ -2060,14 +2080,14 @@ __global__ __launch_bounds__(512, PLAIN ? (NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4)
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) dqt[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int kv0 = 0; kv0 < p.Tk; kv0 += A2_CH) {
-    const int rows = min(A2_CH, p.Tk - kv0);
+  for (int kv0 = 0; kv0 < p.Tk; kv0 += CH) {
+    const int rows = min(CH, p.Tk - kv0);
     __syncthreads();
     {
       int ln = lane;  // opaque copy: see attn_fwd2_kernel
       asm volatile("" : "+v"(ln));
-      dma_oper<1>(Ks, p.k + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * dh, p.kv_st, rows, dh, wave, 8, ln);
-      dma_oper<1>(Vs, p.v + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * dh, p.kv_st, rows, dh, wave, 8, ln);
+      dma_oper<NH>(Ks, p.k + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * dh, p.kv_st, rows, dh, wave, NW, ln);
+      dma_oper<NH>(Vs, p.v + (long)b * p.kv_sb + (long)kv0 * p.kv_st + h * dh, p.kv_st, rows, dh, wave, NW, ln);
     }
     lds_dma_wait_all();
     __syncthreads();
@@ -2080,15 +2100,20 @@ __global__ __launch_bounds__(512, PLAIN ? (NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4)
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
         const int r16 = a * 32 + jt * 16;
-        const bf16x8 kf0 = frag_rows(Ks, r16, 0, lane), kf1 = frag_rows(Ks, r16, 1, lane);
-        const bf16x8 vf0 = frag_rows(Vs, r16, 0, lane), vf1 = frag_rows(Vs, r16, 1, lane);
+        bf16x8 kf[KS], vf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          kf[ks] = frag_rows(Ks + (ks >> 1) * HB, r16, ks & 1, lane);
+          vf[ks] = frag_rows(Vs + (ks >> 1) * HB, r16, ks & 1, lane);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[t][0], sc, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, dof[t][0], dp, 0, 0, 0);
-          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[t][1], sc, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, dof[t][1], dp, 0, 0, 0);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[t][ks], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ks], dof[t][ks], dp, 0, 0, 0);
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float pr = __builtin_amdgcn_exp2f(fmaf(sc[r], sl2, -lse2[t]));
@@ -2104,7 +2129,7 @@ __global__ __launch_bounds__(512, PLAIN ? (NDT == 4 ? CFHIP_ATTN_NDT4_WAVES : 4)
       const bf16x8 dsp1 = pack8(ds[1][0], ds[1][1]);
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        const bf16x8 kc = frag_cols(Ks, a * 32, dt * 16, lane);
+        const bf16x8 kc = frag_cols(Ks + (dt >> 2) * HB, a * 32, (dt & 3) * 16, lane);
         dqt[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc, dsp0, dqt[0][dt], 0, 0, 0);
         dqt[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc, dsp1, dqt[1][dt], 0, 0, 0);
       }
@@ -2616,31 +2641,43 @@ int launch_gen_bwd_drop(const AttnParams& p, bool plain, int parts, hipStream_t 
 }
 
 int g_attn_short_max = CFHIP_ATTN_MAX_T;  // "attn_short_max" option: head_dim-64 sequences up to this length take the LDS-resident kernels
-int g_attn_two_tiles = 255;  // "attn_two_tiles" option (bits): 1 forward, 2 dQ pass (4: also head_dim > 48), 8 dK / dV pass of head_dim <= 64 on the two-tiles-per-wave kernels; 16: forward row sums through the ones column when head_dim = 8 mod 16; 32: dK / dV pass of head_dim 72 .. 96 on the two-tile kernel; 64 (round 6): the plain head_dim <= 48 dQ pass with S / dP on 32x32x16 MFMAs (attn_bwd_dq3_kernel); 128 (round 6): head_dim 40, plain: dP - delta out of the matrix pipe (two spare reduction columns) in that dQ pass and in the dK / dV pass
+int g_attn_two_tiles = 511;  // "attn_two_tiles" option (bits): 1 forward, 2 dQ pass (4: also head_dim > 48), 8 dK / dV pass of head_dim <= 64 on the two-tiles-per-wave kernels; 16: forward row sums through the ones column when head_dim = 8 mod 16; 32: dK / dV pass of head_dim 72 .. 96 on the two-tile kernel; 64 (round 6): the plain head_dim <= 48 dQ pass with S / dP on 32x32x16 MFMAs (attn_bwd_dq3_kernel); 128 (round 6): head_dim 40, plain: dP - delta out of the matrix pipe (two spare reduction columns) in that dQ pass and in the dK / dV pass; 256 (round 6, late): head_dim 72 .. 96 without a mask: forward and dQ pass on the two-tile kernels (Fwd2<5 / 6>: two 64-column halves, 4 waves, 128-key chunks)
 
 extern int g_attn_two_tiles;
 template <int NDT>
 int launch_fwd2(const AttnParams& p, bool plain, hipStream_t s) {
-  dim3 grid((p.Tq + A2_ROWS - 1) / A2_ROWS, p.H, p.B);
-  const size_t lds = (size_t)2 * A2_TILE;
+  using F = Fwd2<NDT>;
+  constexpr int ROWS = F::NW * 32;
+  dim3 grid((p.Tq + ROWS - 1) / ROWS, p.H, p.B);
+  const size_t lds = (size_t)2 * F::NH * F::HB;
+  const dim3 block(F::NW * 64);
+  if constexpr (F::NH == 2) {  // head_dim 72 .. 96: the plain form only (masked / causal sequences of that width stay on the general kernel)
+    const int rc = set_lds(attn_fwd2_kernel<true, NDT>, lds, "attn_fwd");
+    if (rc != CFHIP_OK) return rc;
+    hipLaunchKernelGGL((attn_fwd2_kernel<true, NDT>), grid, block, lds, s, p);
+    CFHIP_CHECK_LAUNCH("attn_fwd2");
+    return CFHIP_OK;
+  } else {
   if (plain && p.dh == (NDT - 1) * 16 + 8 && (g_attn_two_tiles & 16)) {  // a free column in the last tile: row sums by MFMA
     const int rc = set_lds(attn_fwd2_kernel<true, NDT, true>, lds, "attn_fwd");
     if (rc != CFHIP_OK) return rc;
-    hipLaunchKernelGGL((attn_fwd2_kernel<true, NDT, true>), grid, dim3(512), lds, s, p);
+    hipLaunchKernelGGL((attn_fwd2_kernel<true, NDT, true>), grid, block, lds, s, p);
     CFHIP_CHECK_LAUNCH("attn_fwd2");
     return CFHIP_OK;
   }
   int rc = plain ? set_lds(attn_fwd2_kernel<true, NDT>, lds, "attn_fwd") : set_lds(attn_fwd2_kernel<false, NDT>, lds, "attn_fwd");
   if (rc != CFHIP_OK) return rc;
-  if (plain) hipLaunchKernelGGL((attn_fwd2_kernel<true, NDT>), grid, dim3(512), lds, s, p);
-  else hipLaunchKernelGGL((attn_fwd2_kernel<false, NDT>), grid, dim3(512), lds, s, p);
+  if (plain) hipLaunchKernelGGL((attn_fwd2_kernel<true, NDT>), grid, block, lds, s, p);
+  else hipLaunchKernelGGL((attn_fwd2_kernel<false, NDT>), grid, block, lds, s, p);
   CFHIP_CHECK_LAUNCH("attn_fwd2");
   return CFHIP_OK;
+  }
 }
 
 template <int NH>
 int launch_gen_fwd(const AttnParams& p, bool plain, hipStream_t s) {
   if (NH == 1 && (g_attn_two_tiles & 1)) return p.dh <= 48 ? launch_fwd2<3>(p, plain, s) : launch_fwd2<4>(p, plain, s);
+  if (NH == 2 && plain && p.dh <= 96 && (g_attn_two_tiles & 256)) return p.dh <= 80 ? launch_fwd2<5>(p, true, s) : launch_fwd2<6>(p, true, s);
   dim3 grid((p.Tq + 127) / 128, p.H, p.B);
   const size_t lds = (size_t)Gen<NH>::NSLOT * Gen<NH>::SLOT_BYTES;
   int rc = plain ? set_lds(attn_gen_fwd_kernel<NH, true>, lds, "attn_fwd") : set_lds(attn_gen_fwd_kernel<NH, false>, lds, "attn_fwd");
@@ -2653,12 +2690,21 @@ int launch_gen_fwd(const AttnParams& p, bool plain, hipStream_t s) {
 
 template <int NDT>
 int launch_dq2(const AttnParams& p, bool plain, hipStream_t s) {
-  dim3 grid((p.Tq + A2_ROWS - 1) / A2_ROWS, p.H, p.B);
-  const size_t lds = (size_t)2 * A2_TILE;
-  int rc = plain ? set_lds(attn_bwd_dq2_kernel<true, NDT>, lds, "attn_bwd_dq") : set_lds(attn_bwd_dq2_kernel<false, NDT>, lds, "attn_bwd_dq");
-  if (rc != CFHIP_OK) return rc;
-  if (plain) hipLaunchKernelGGL((attn_bwd_dq2_kernel<true, NDT>), grid, dim3(512), lds, s, p);
-  else hipLaunchKernelGGL((attn_bwd_dq2_kernel<false, NDT>), grid, dim3(512), lds, s, p);
+  using F = Fwd2<NDT>;
+  constexpr int ROWS = F::NW * 32;
+  dim3 grid((p.Tq + ROWS - 1) / ROWS, p.H, p.B);
+  const size_t lds = (size_t)2 * F::NH * F::HB;
+  const dim3 block(F::NW * 64);
+  if constexpr (F::NH == 2) {  // head_dim 72 .. 96: the plain form only
+    const int rc = set_lds(attn_bwd_dq2_kernel<true, NDT>, lds, "attn_bwd_dq");
+    if (rc != CFHIP_OK) return rc;
+    hipLaunchKernelGGL((attn_bwd_dq2_kernel<true, NDT>), grid, block, lds, s, p);
+  } else {
+    int rc = plain ? set_lds(attn_bwd_dq2_kernel<true, NDT>, lds, "attn_bwd_dq") : set_lds(attn_bwd_dq2_kernel<false, NDT>, lds, "attn_bwd_dq");
+    if (rc != CFHIP_OK) return rc;
+    if (plain) hipLaunchKernelGGL((attn_bwd_dq2_kernel<true, NDT>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((attn_bwd_dq2_kernel<false, NDT>), grid, block, lds, s, p);
+  }
   CFHIP_CHECK_LAUNCH("attn_bwd_dq2");
   return CFHIP_OK;
 }
@@ -2700,6 +2746,9 @@ template <int NH>
 int launch_gen_bwd(const AttnParams& p, bool plain, int parts, hipStream_t s) {
   if ((parts & 1) && NH == 1 && (g_attn_two_tiles & 2) && (p.dh <= 48 || (g_attn_two_tiles & 4))) {  // (the 4-column-tile form spills: bit 4 to try it)
     const int rc = p.dh <= 48 ? ((plain && (g_attn_two_tiles & 64)) ? launch_dq3(p, s) : launch_dq2<3>(p, plain, s)) : launch_dq2<4>(p, plain, s);
+    if (rc != CFHIP_OK) return rc;
+  } else if ((parts & 1) && NH == 2 && plain && p.dh <= 96 && (g_attn_two_tiles & 256)) {  // head_dim 72 .. 96 on the two-tile form (round 6, late)
+    const int rc = p.dh <= 80 ? launch_dq2<5>(p, true, s) : launch_dq2<6>(p, true, s);
     if (rc != CFHIP_OK) return rc;
   } else if (parts & 1) {
     dim3 grid((p.Tq + 127) / 128, p.H, p.B);

@@ -63,11 +63,12 @@ const char* cfhip_last_error(void);
  *   "grouped_variant" ring of cfhip_gemm_bf16_grouped_tn: 0 (default) 5 slots, DMA 3 K-steps ahead; 1: 4 slots, 2 ahead;
  *                     2: 5 slots, 2 ahead; 3 / 4: DMA placement variants of 0.  +16: bias gradients reduced by the first tile
  *                     column alone instead of shared by the tile row; +32: row-major tile order (both: A/B runs);
- *   "attn_two_tiles"  bits (default 255) selecting the long-sequence attention forms (csrc/attn.hip): 1 forward, 2 dQ pass (4: also head_dim
+ *   "attn_two_tiles"  bits (default 511) selecting the long-sequence attention forms (csrc/attn.hip): 1 forward, 2 dQ pass (4: also head_dim
  *                     > 48), 8 dK / dV pass of head_dim <= 64 on the two-tiles-per-wave kernels; 16: forward row sums through a ones column
  *                     when head_dim = 8 mod 16; 32: dK / dV pass of head_dim 72 .. 96 on the two-tile kernel; 64 (round 6): the plain
  *                     head_dim <= 48 dQ pass with S / dP on 32x32x16 MFMAs; 128 (round 6): head_dim 40, plain: dP - delta out of the matrix
- *                     pipe (two spare reduction columns) in the dQ and dK / dV passes.  "attn_one_pass" (default 2; 0 = two passes, 1 = the 16-wave
+ *                     pipe (two spare reduction columns) in the dQ and dK / dV passes; 256 (round 6): head_dim 72 .. 96 without a mask: forward and dQ
+ *                     pass on the two-tile kernels.  "attn_one_pass" (default 2; 0 = two passes, 1 = the 16-wave
  *                     kernel at every length, 2 = 128 < T <= 224 on 8 waves with two key tiles each, bit-identical): dQ, dK, dV of a short
  *                     self-attention from one evaluation of S and dP.  "attn_short_max": longest head_dim-64 sequence on the LDS-resident kernels
  *   "conv_form"       tile form of cfhip_conv3x3_nhwc_bf16: -1 (default) = by shape (128x160x64 on four waves where 160-column tiles cover

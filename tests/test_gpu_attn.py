@@ -305,6 +305,42 @@ def test_attention_module_dropout_trains_and_is_off_in_eval():
     assert_close(acc / 600, y_eval.float(), 6e-2, "mean over dropout masks")
 
 
+@pytest.mark.parametrize("dh,t,h", [(80, 1024, 3), (72, 300, 2), (96, 1000, 2), (88, 777, 1), (80, 129, 2)])
+def test_two_tile_forms_of_head_dim_72_to_96(dh, t, h):
+    """`attn_fwd2_kernel<true, 5 / 6>` and `attn_bwd_dq2_kernel<true, 5 / 6>` (round 6: option "attn_two_tiles" bit 256, on by default — the
+    UNet's 80-channel heads) against the one-tile general kernels they replace (bit off) and against fp32 autograd: ragged lengths, a
+    length just beyond one chunk, the widest head_dim of the form; delta as the dQ pass writes it."""
+    b = 2
+    d = h * dh
+    g = torch.Generator(device=DEV).manual_seed(dh * 7 + t)
+    rnd = lambda *s: (torch.randn(*s, generator=g, device=DEV) * 0.8).to(torch.bfloat16)  # noqa: E731
+    q, k, v, d_o = rnd(b, t, d), rnd(b, t, d), rnd(b, t, d), rnd(b, t, d)
+    leaves = [z.float().requires_grad_(True) for z in (q, k, v)]
+    hd = lambda z: z.reshape(b, t, h, dh).permute(0, 2, 1, 3)  # noqa: E731
+    s = (hd(leaves[0]) @ hd(leaves[1]).transpose(-1, -2)) * (1.0 / math.sqrt(dh))
+    want_lse = torch.logsumexp(s.detach(), -1)
+    want = (torch.softmax(s, -1) @ hd(leaves[2])).permute(0, 2, 1, 3).reshape(b, t, d)
+    want.backward(d_o.float())
+    outs = []
+    for bits in (255, 511):
+        ops.set_option("attn_two_tiles", bits)
+        try:
+            o, lse = ops.attn_fwd(q, k, v, h, head_dim=dh)
+            dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+            delta = torch.zeros(b, h, t, device=DEV)
+            ops.attn_bwd(q, k, v, o, d_o, lse, h, dq=dq, dk=dk, dv=dv, delta=delta, head_dim=dh)
+            outs.append((o, lse, dq, dk, dv, delta))
+        finally:
+            ops.set_option("attn_two_tiles", 511)
+    for tag, (o, lse, dq, dk, dv, delta) in zip(("one tile", "two tiles"), outs):
+        assert_close(o, want.detach(), 1e-2, f"{tag}: fwd dh={dh}")
+        assert_close(lse, want_lse, 1e-4, f"{tag}: lse dh={dh}")
+        for nm, got, leaf in (("dq", dq, leaves[0]), ("dk", dk, leaves[1]), ("dv", dv, leaves[2])):
+            assert_close(got, leaf.grad, 2e-2, f"{tag}: {nm} dh={dh}", abs_floor=1e-6)
+    assert_close(outs[1][5], outs[0][5], 2e-3, "delta of the two dQ passes", abs_floor=1e-4)
+    assert_close(outs[1][0], outs[0][0].float(), 4e-3, "forward of the two forms", abs_floor=1e-6)
+
+
 @pytest.mark.parametrize("t,dh", [(4096, 40), (4096, 80), (16384, 40), (16384, 80), (4096, 160), (4096, 64), (5000, 48)])
 def test_attention_at_the_unet_token_counts(t, dh):
     """The general-length kernels at the sizes the DDPM UNet runs them (BASELINE config 4: `SpatialTransformer` self
