@@ -148,6 +148,8 @@ SIGNATURES = {
     "cfhip_diffusion_loss": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int, _P]),
     "cfhip_silu_f32_fwd": (c_int, [_P, _P, c_int64, _P]),
     "cfhip_silu_f32_bwd": (c_int, [_P, _P, _P, c_int64, _P]),
+    "cfhip_time_proj_fwd": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P]),
+    "cfhip_time_proj_bwd": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P, _P]),
     "cfhip_upsample2_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
     "cfhip_upsample2_bwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
     "cfhip_groupnorm_nhwc_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),

@@ -1582,6 +1582,136 @@ __global__ void silu_f32_kernel(const float* __restrict__ a, const float* __rest
     out[i] = BWD ? a[i] * silu_grad_f(x[i]) : silu_f(a[i]);
 }
 
+
+// ---- the UNet's per-block time-embedding projections, ALL blocks in one launch each way (round 6, late) ------------------------------
+// Every ResidualBlock computes Linear_i(SiLU(time_net)) from the SAME [B, K] time embedding (residual.py:226-239): per block and per step
+// that was a SiLU launch, a cast, an M = B GEMM (a 128-row tile for 8 rows), and in backward a cast, a GEMM, a copy and a SiLU' launch
+// plus autograd's add into the shared gradient — ~160 launches on the critical queue of the 64^2 x 8 step for 0.05 ms of arithmetic.
+// Here: ONE forward launch (problem table in the kernel arguments: up to 32 weight matrices), TWO backward launches (per-column-block
+// partial sums of dY_i W_i in a fixed order, then their sum times SiLU': no atomics).  Arithmetic as the per-block path has it: bf16
+// SiLU(emb) and bf16 weights, f32 accumulation, f32 output; dY rounded to bf16 before it multiplies (what the GEMMs did).
+// Layout: a workgroup = 64 output columns (one per lane: no cross-lane reduction) x the reduction split over its 4 waves.
+constexpr int TP_MAX = 32;
+struct TimeProjArgs {
+  const bf16_t* w[TP_MAX];   // [N_i, K] bf16
+  const float* vec[TP_MAX];  // forward: bias [N_i] or null; backward: dY_i [B, N_i] f32 or null (no gradient for this output)
+  float* out[TP_MAX];        // forward: out_i [B, N_i] f32
+  bf16_t* aux[TP_MAX];       // backward: dY_i as bf16 [B, N_i] (for the weight-gradient GEMMs) or null
+  int n[TP_MAX];
+  int blk0[TP_MAX + 1];      // first 64-column block of problem i; blk0[count] = number of blocks
+  int count;
+};
+
+__device__ __forceinline__ int tp_problem(const TimeProjArgs& a, int blk) {
+  int p = 0;
+  while (p + 1 < a.count && blk >= a.blk0[p + 1]) ++p;
+  return p;
+}
+
+__global__ __launch_bounds__(256) void time_proj_fwd_kernel(const float* __restrict__ emb, int B, int K, TimeProjArgs a,
+                                                            bf16_t* __restrict__ t_out) {
+  extern __shared__ __attribute__((aligned(16))) char tp_smem[];
+  bf16_t* ts = reinterpret_cast<bf16_t*>(tp_smem);                        // [8][K] bf16: SiLU(emb) of this batch chunk
+  float* red = reinterpret_cast<float*>(tp_smem + (size_t)8 * K * 2);     // [4][8][64] partial sums of the four K quarters
+  const int b0 = blockIdx.y * 8;
+  for (int idx = threadIdx.x; idx < 8 * K; idx += 256) {
+    const int r = idx / K, k = idx - r * K;
+    const bool ok = b0 + r < B;
+    const bf16_t h = f32_to_bf16(ok ? silu_f(emb[(long)(b0 + r) * K + k]) : 0.f);
+    ts[idx] = h;
+    if (blockIdx.x == 0 && ok) t_out[(long)(b0 + r) * K + k] = h;
+  }
+  __syncthreads();
+  const int p = tp_problem(a, blockIdx.x);
+  const int N = a.n[p];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = (blockIdx.x - a.blk0[p]) * 64 + lane;
+  float acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+  if (col < N) {
+    const bf16_t* wrow = a.w[p] + (long)col * K;
+    const int kq = K / 4;
+#pragma unroll 2
+    for (int k = wave * kq; k < (wave + 1) * kq; k += 8) {
+      const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wrow + k);
+      float wf[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wf[e] = bf16_to_f32((bf16_t)wv[e]);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const bf16x8 tv = *reinterpret_cast<const bf16x8*>(ts + r * K + k);  // the same address in every lane: a broadcast
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[r] = fmaf(wf[e], bf16_to_f32((bf16_t)tv[e]), acc[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) red[(wave * 8 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (wave == 0 && col < N) {
+    const float bias = a.vec[p] != nullptr ? a.vec[p][col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (b0 + r >= B) break;
+      const float s = ((red[(0 * 8 + r) * 64 + lane] + red[(1 * 8 + r) * 64 + lane]) + red[(2 * 8 + r) * 64 + lane]) + red[(3 * 8 + r) * 64 + lane];
+      a.out[p][(long)(b0 + r) * N + col] = s + bias;
+    }
+  }
+}
+
+// backward, stage 1: partial[blk][b][k] = sum over the 64 columns n of block blk of bf16(dY[b][n]) * W[n][k]   (thread = one k)
+__global__ __launch_bounds__(256) void time_proj_bwd_part_kernel(int B, int K, TimeProjArgs a, float* __restrict__ partial, int Bpad) {
+  __shared__ float dys[8][64];
+  const int blk = blockIdx.x;
+  const int p = tp_problem(a, blk);
+  const int N = a.n[p];
+  const int c0 = (blk - a.blk0[p]) * 64;
+  const int k = blockIdx.y * 256 + threadIdx.x;
+  const float* dy = a.vec[p];
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 8 * 64; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      float v = 0.f;
+      if (dy != nullptr && b0 + r < B && c0 + c < N) {
+        const bf16_t h = f32_to_bf16(dy[(long)(b0 + r) * N + c0 + c]);
+        v = bf16_to_f32(h);
+        if (blockIdx.y == 0 && a.aux[p] != nullptr) a.aux[p][(long)(b0 + r) * N + c0 + c] = h;
+      }
+      dys[r][c] = v;
+    }
+    __syncthreads();
+    if (k < K) {
+      float acc[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+      if (dy != nullptr) {
+        const int cn = min(64, N - c0);
+        const bf16_t* wp = a.w[p] + (long)c0 * K + k;
+        for (int c = 0; c < cn; ++c) {
+          const float wv = bf16_to_f32(wp[(long)c * K]);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) acc[r] = fmaf(dys[r][c], wv, acc[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) partial[((long)blk * Bpad + b0 + r) * K + k] = acc[r];
+    }
+  }
+}
+
+// backward, stage 2: d_emb[b][k] = SiLU'(emb[b][k]) * sum over blocks (in block order) of partial[blk][b][k]
+__global__ void time_proj_bwd_sum_kernel(const float* __restrict__ emb, const float* __restrict__ partial, float* __restrict__ d_emb,
+                                         int B, int K, int Bpad, int nblk) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)B * K) return;
+  const int b = (int)(i / K), k = (int)(i - (long)b * K);
+  float s = 0.f;
+  for (int blk = 0; blk < nblk; ++blk) s += partial[((long)blk * Bpad + b) * K + k];
+  d_emb[i] = s * silu_grad_f(emb[i]);
+}
+
 // fwd: y[b,c,2h+dy,2w+dx] = x[b,c,h,w]; bwd: dx[b,c,h,w] = sum of the 4 dy
 template <bool BWD>
 __global__ void upsample2_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, long BC, int H, int W) {
@@ -2141,6 +2271,61 @@ extern "C" int cfhip_silu_f32_bwd(const float* dy, const float* x, float* dx, in
   CFHIP_REQUIRE(dy && x && dx && n > 0, "silu_f32_bwd: bad arguments");
   hipLaunchKernelGGL((silu_f32_kernel<true>), dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, (long)n);
   CFHIP_CHECK_LAUNCH("silu_f32_bwd");
+  return CFHIP_OK;
+}
+
+// table: 4 int64 per problem.  Forward: {weight bf16 [N, K], bias f32 [N] or 0, out f32 [B, N], N}; backward: {weight, dY f32 [B, N] or 0
+// (no gradient for that output), dY as bf16 [B, N] out or 0, N}.  A HOST array (the pointers travel in the kernel arguments).
+static int time_proj_args(const int64_t* table, int count, bool fwd, TimeProjArgs* a, const char* who) {
+  CFHIP_REQUIRE(table && count > 0 && count <= TP_MAX, "%s: 1 .. %d problems per call (got %d)", who, TP_MAX, count);
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const int64_t* e = table + 4 * i;
+    CFHIP_REQUIRE(e[0] != 0 && e[3] > 0 && (e[0] & 15) == 0, "%s: problem %d: weight pointer (16-byte aligned) and N > 0", who, i);
+    a->w[i] = reinterpret_cast<const bf16_t*>(e[0]);
+    a->vec[i] = reinterpret_cast<const float*>(e[1]);
+    if (fwd) {
+      CFHIP_REQUIRE(e[2] != 0, "%s: problem %d: output pointer", who, i);
+      a->out[i] = reinterpret_cast<float*>(e[2]);
+      a->aux[i] = nullptr;
+    } else {
+      a->out[i] = nullptr;
+      a->aux[i] = reinterpret_cast<bf16_t*>(e[2]);
+    }
+    a->n[i] = (int)e[3];
+    a->blk0[i] = blocks;
+    blocks += ((int)e[3] + 63) / 64;
+  }
+  a->blk0[count] = blocks;
+  a->count = count;
+  return CFHIP_OK;
+}
+
+extern "C" int cfhip_time_proj_fwd(const float* emb, int B, int K, const int64_t* table, int count, void* t_bf16, void* stream) {
+  CFHIP_REQUIRE(emb && t_bf16 && B > 0 && K > 0 && K % 32 == 0 && K <= 4096, "time_proj_fwd: emb [B, K] f32 with K %% 32 == 0, K <= 4096 (got B=%d K=%d)", B, K);
+  TimeProjArgs a;
+  const int rc = time_proj_args(table, count, true, &a, "time_proj_fwd");
+  if (rc != CFHIP_OK) return rc;
+  const size_t lds = (size_t)8 * K * 2 + (size_t)4 * 8 * 64 * 4;
+  hipLaunchKernelGGL(time_proj_fwd_kernel, dim3(a.blk0[count], (B + 7) / 8), dim3(256), lds, (hipStream_t)stream, emb, B, K, a,
+                     (bf16_t*)t_bf16);
+  CFHIP_CHECK_LAUNCH("time_proj_fwd");
+  return CFHIP_OK;
+}
+
+// partial: f32 workspace of (sum over problems of ceil(N_i / 64)) * ceil8(B) * K elements, owned by the caller
+extern "C" int cfhip_time_proj_bwd(const float* emb, int B, int K, const int64_t* table, int count, float* partial, float* d_emb,
+                                   void* stream) {
+  CFHIP_REQUIRE(emb && partial && d_emb && B > 0 && K > 0 && K % 32 == 0 && K <= 4096, "time_proj_bwd: bad arguments (B=%d K=%d)", B, K);
+  TimeProjArgs a;
+  const int rc = time_proj_args(table, count, false, &a, "time_proj_bwd");
+  if (rc != CFHIP_OK) return rc;
+  const int Bpad = (B + 7) / 8 * 8, nblk = a.blk0[count];
+  hipLaunchKernelGGL(time_proj_bwd_part_kernel, dim3(nblk, (K + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, K, a, partial, Bpad);
+  CFHIP_CHECK_LAUNCH("time_proj_bwd(partial sums)");
+  hipLaunchKernelGGL(time_proj_bwd_sum_kernel, dim3((unsigned)(((long)B * K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, emb,
+                     (const float*)partial, d_emb, B, K, Bpad, nblk);
+  CFHIP_CHECK_LAUNCH("time_proj_bwd(sum)");
   return CFHIP_OK;
 }
 

@@ -15,7 +15,7 @@ import contextlib
 import os
 import threading
 import weakref
-from typing import Any, Callable, List, Optional, Tuple
+from typing import Any, Callable, List, Optional, Sequence, Tuple
 
 import math
 
@@ -1986,6 +1986,118 @@ class SiLUF32Fn(Function):
 
 def silu_f32(x: Tensor) -> Tensor:
     return _apply(SiLUF32Fn, x)
+
+
+# ---- the residual blocks' time-embedding projections, every block of a UNet forward in one launch (round 6) ------------------------------
+# Each ResidualBlock computes Linear_i(SiLU(time_net)) from the same [B, K] embedding: per block a SiLU, a cast and an M = B GEMM on the
+# critical queue, and in backward a cast, a GEMM, a copy, a SiLU' and autograd's add into the shared gradient (~160 launches per 64^2 x 8
+# UNet step for 0.05 ms of arithmetic).  `time_proj_all` computes all of them at the top of the forward (cfhip_time_proj_fwd / _bwd); a
+# block picks its own output up with `time_pre_lookup`.  The weight / bias gradients keep their path (one dW + db launch per block, on the
+# side stream or in a grouped launch).
+TIME_PROJ_GROUPED = True  # (A/B: tools set the attribute)
+
+
+class _TimePre(threading.local):
+    def __init__(self) -> None:
+        self.src: Optional[Tensor] = None
+        self.outs: dict = {}
+
+
+_TIME_PRE = _TimePre()
+
+
+class TimeProjAllFn(Function):
+    """(emb, weights..., biases...) -> (Linear_i(SiLU(emb)) ..., bf16 SiLU(emb)).  Its backward is the EMBEDDING's gradient only (two
+    launches when every block's dY is there, i.e. at the end of the UNet's backward); the weights' gradients are computed by each block's
+    `TimeProjTapFn` when ITS dY arrives — an arena range of the in-backward optimizer must not wait for the end of the pass."""
+    tapeable = False
+
+    @staticmethod
+    def forward(ctx: Any, emb: Tensor, count: int, *wb: Any):  # wb: count weights, then count biases (None allowed)
+        weights = [whole_param(w) for w in wb[:count]]
+        biases = [whole_param(b) for b in wb[count:]]
+        w16 = [shadow_bf16(w).view(w.shape[0], -1) for w in weights]
+        bias_f = [None if b is None else b.detach().reshape(-1).contiguous() for b in biases]
+        emb = emb.contiguous()
+        t16 = torch.empty(emb.shape, dtype=bf16, device=emb.device)
+        outs = ops.time_proj_fwd(emb, w16, bias_f, t16)
+        ctx.save_for_backward(emb, *w16)
+        ctx.count = count
+        ctx.mark_non_differentiable(t16)
+        return tuple(outs) + (t16,)
+
+    @staticmethod
+    def backward(ctx: Any, *dys: Any):  # type: ignore
+        emb = ctx.saved_tensors[0]
+        w16 = ctx.saved_tensors[1:]
+        count = ctx.count
+        if not ctx.needs_input_grad[0]:
+            return (None,) * (2 + 2 * count)
+        dys = [None if dy is None else dy.float().contiguous() for dy in dys[:count]]
+        d_emb = ops.time_proj_bwd(emb, w16, dys, [None] * count)
+        return (d_emb, None) + (None,) * (2 * count)
+
+
+class TimeProjTapFn(Function):
+    """identity on one block's precomputed projection; in backward the block's weight / bias gradient (dW = dY^T SiLU(emb), db = colsum dY:
+    on the side stream when they land straight in `.grad`) and dY handed on to `TimeProjAllFn`"""
+    tapeable = False
+
+    @staticmethod
+    def forward(ctx: Any, pre: Tensor, t16: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+        ctx.weight, ctx.bias = whole_param(weight), whole_param(bias)
+        ctx.save_for_backward(t16)
+        return pre.view_as(pre)
+
+    @staticmethod
+    def backward(ctx: Any, dy: Tensor):  # type: ignore
+        (t16,) = ctx.saved_tensors
+        w, b = ctx.weight, ctx.bias
+        gw = gb = None
+        if w.requires_grad or (b is not None and b.requires_grad):
+            dyf = dy.float().contiguous()
+            if _all_direct(w, b):
+                SideStream.run(lambda: _linear_param_grads(ops.to_bf16(dyf), t16, w, b, True, True), (dyf, t16))
+            else:
+                gw, gb = _linear_param_grads(ops.to_bf16(dyf), t16, w, b, _is_direct(w), _is_direct(b))
+        return dy, None, gw, gb
+
+
+def time_proj_all(time_net: Tensor, blocks: Sequence[Any]) -> bool:
+    """Linear_i(SiLU(time_net)) of every block in `blocks` (modules with a plain `time_embedding` Linear) in one launch, kept for
+    `time_pre_lookup` until `time_pre_clear`.  False (nothing done) when the grouped kernel does not take this input."""
+    time_pre_clear()
+    # (taped nodes — one autograd node per block, off by default — run each block's Functions on a tape of their own: per-block path)
+    if (not TIME_PROJ_GROUPED or TAPED_NODES[0] or not blocks or getattr(_TAPE, "tape", None) is not None or not time_net.is_cuda or time_net.dtype != f32
+            or time_net.dim() != 2 or time_net.shape[1] % 32 != 0 or time_net.shape[1] > 4096):
+        return False
+    pres: dict = {}
+    for i in range(0, len(blocks), ops.TIME_PROJ_MAX):
+        chunk = blocks[i:i + ops.TIME_PROJ_MAX]
+        ws = [blk.time_embedding.weight for blk in chunk]
+        bs = [blk.time_embedding.bias for blk in chunk]
+        res = TimeProjAllFn.apply(time_net, len(chunk), *ws, *bs)
+        for blk, out in zip(chunk, res[:-1]):
+            pres[id(blk)] = (out, res[-1])
+    _TIME_PRE.src = time_net
+    _TIME_PRE.outs = pres
+    return True
+
+
+def time_pre_lookup(block: Any, time_net: Tensor) -> Optional[Tensor]:
+    """`block.time_embedding(SiLU(time_net))` out of the grouped launch for exactly this `time_net` tensor, else None"""
+    if _TIME_PRE.src is not time_net or getattr(_TAPE, "tape", None) is not None:
+        return None
+    hit = _TIME_PRE.outs.get(id(block))
+    if hit is None:
+        return None
+    lin = block.time_embedding
+    return TimeProjTapFn.apply(hit[0], hit[1], lin.weight, lin.bias)
+
+
+def time_pre_clear() -> None:
+    _TIME_PRE.src = None
+    _TIME_PRE.outs = {}
 
 
 class Upsample2Fn(Function):

@@ -1762,8 +1762,10 @@ class ResidualBlockWithTimeEmbedding(Module):
             inp = self.shortcut(inp)
         add = scale_shift = None
         if time_net is not None:
-            t = HF.silu_f32(time_net)
-            t = HF.linear(t, self.time_embedding.weight, self.time_embedding.bias, out_f32=True)  # [B, Cout] / [B, 2 Cout]
+            t = HF.time_pre_lookup(self, time_net)  # all blocks' projections in one launch at the top of the UNet's forward
+            if t is None:
+                t = HF.silu_f32(time_net)
+                t = HF.linear(t, self.time_embedding.weight, self.time_embedding.bias, out_f32=True)  # [B, Cout] / [B, 2 Cout]
             if self.use_scale_shift_norm:
                 scale_shift = tuple(torch.chunk(t, 2, dim=1))  # residual.py:236-239
             else:
@@ -2118,6 +2120,9 @@ class UNetDiffuser(Module):
         # write (channels_last views of logical [B, C, H, W] tensors, `functional.NHWC`): no NCHW <-> NHWC hop around the
         # convolutions, GroupNorm on the rows, token matrices of the transformers as views.  The head (3 output channels)
         # returns NCHW like the reference.
+        # every residual block's Linear(SiLU(time_net)) in one launch (functional.time_proj_all); blocks that recompute themselves in
+        # backward, use the scale-shift modulation's 2C projection all the same, or carry hooks / low-rank weights fall out of the list
+        HF.time_proj_all(time_net, self._time_projection_blocks())
         prev = HF.NHWC[0]
         # (with few samples the NHWC GroupNorm has to cut a sample into row slices and merge them — three launches — and loses to the
         # NCHW path: 256^2 x 1 457 -> 485 ms; with a batch the group form is one launch and the step gains: 64^2 x 8 60.6 -> 59.6 ms)
@@ -2138,6 +2143,15 @@ class UNetDiffuser(Module):
             return self.head[2](net)
         finally:
             HF.NHWC[0] = prev
+            HF.time_pre_clear()
+
+    def _time_projection_blocks(self) -> List[Module]:
+        blocks = getattr(self, "_time_blocks", None)
+        if blocks is None:
+            blocks = [m for m in self.modules()
+                      if isinstance(m, ResidualBlockWithTimeEmbedding) and type(getattr(m, "time_embedding", None)) in (HijackLinear, nn.Linear)]
+            object.__setattr__(self, "_time_blocks", blocks)  # (a plain list: not a registered sub-module container)
+        return [m for m in blocks if not m.use_checkpoint and getattr(m.time_embedding, "hook", None) is None]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1206,6 +1206,52 @@ def groupnorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, beta: Tensor, mean: Tens
     return dx, colreduce_f32(dg_part), colreduce_f32(db_part), dadd
 
 
+TIME_PROJ_MAX = 32  # problems per launch of the grouped time-embedding projection (csrc/conv.hip: TP_MAX)
+
+
+def _time_proj_table(rows) -> "ctypes.Array":
+    """4 int64 per problem, a HOST array that lives until the call returns (the pointers travel in the kernel arguments)"""
+    flat = [int(v) for row in rows for v in row]
+    return (ctypes.c_int64 * len(flat))(*flat)
+
+
+def time_proj_fwd(emb: Tensor, weights16, biases, t16: Tensor):
+    """out_i = Linear_i(SiLU(emb)) for every (weight bf16 [N_i, K], bias f32 [N_i] or None) in ONE launch; returns the list of f32
+    [B, N_i] outputs and fills t16 = bf16 SiLU(emb) [B, K] (cfhip_time_proj_fwd; reference residual.py:226-239 per block)"""
+    _need(emb, f32, "emb")
+    b, k = emb.shape
+    outs = [torch.empty((b, w.shape[0]), dtype=f32, device=emb.device) for w in weights16]
+    rows = []
+    for w, bias, out in zip(weights16, biases, outs):
+        _need(w, bf16, "weight")
+        if w.shape[1] != k or not w.is_contiguous() or (bias is not None and (bias.dtype != f32 or not bias.is_contiguous())):
+            raise ValueError("cfhip time_proj_fwd: contiguous bf16 [N, K] weights and f32 [N] biases expected")
+        rows.append((w.data_ptr(), 0 if bias is None else bias.data_ptr(), out.data_ptr(), w.shape[0]))
+    table = _time_proj_table(rows)
+    _lib.check(_lib.load().cfhip_time_proj_fwd(emb.data_ptr(), b, k, ctypes.addressof(table), len(rows), t16.data_ptr(), _stream()),
+               "time_proj_fwd")
+    return outs
+
+
+def time_proj_bwd(emb: Tensor, weights16, dys, dys16) -> Tensor:
+    """d_emb = SiLU'(emb) * sum_i bf16(dY_i) W_i in two launches (partial sums per 64 columns, then their sum in a fixed order);
+    dys[i] None = no gradient for output i; dys16[i]: bf16 [B, N_i] buffers that receive the rounded dY_i (or None)"""
+    b, k = emb.shape
+    rows = []
+    nblk = 0
+    for w, dy, dy16 in zip(weights16, dys, dys16):
+        if dy is not None and (dy.dtype != f32 or not dy.is_contiguous() or dy.shape != (b, w.shape[0])):
+            raise ValueError("cfhip time_proj_bwd: contiguous f32 [B, N] gradients expected")
+        rows.append((w.data_ptr(), 0 if dy is None else dy.data_ptr(), 0 if dy16 is None else dy16.data_ptr(), w.shape[0]))
+        nblk += (w.shape[0] + 63) // 64
+    table = _time_proj_table(rows)
+    partial = torch.empty((nblk, (b + 7) // 8 * 8, k), dtype=f32, device=emb.device)
+    d_emb = torch.empty_like(emb)
+    _lib.check(_lib.load().cfhip_time_proj_bwd(emb.data_ptr(), b, k, ctypes.addressof(table), len(rows), partial.data_ptr(),
+                                               d_emb.data_ptr(), _stream()), "time_proj_bwd")
+    return d_emb
+
+
 def silu_f32_fwd(x: Tensor) -> Tensor:
     _need(x, f32, "x")
     x = x.contiguous()

@@ -489,6 +489,16 @@ int cfhip_groupnorm_split_bwd(const void* dy, const void* x, int x_is_f32, const
                               int affine_batch_stride, int splits, float* workspace, void* stream);
 int cfhip_silu_f32_fwd(const float* x, float* y, int64_t n, void* stream);
 int cfhip_silu_f32_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+/* The per-block time-embedding projections of the UNet's residual blocks, every block in ONE launch (replaces `self.time_embedding`
+ * = Sequential(SiLU, Linear) of each ResidualBlockWithTimeEmbedding: reference convs/residual.py:185-191,226-239, unet.py:154-190).
+ *   out_i[b, :] = Linear_i(SiLU(emb[b, :])), i < count <= 32, emb f32 [B, K] (K % 32 == 0, K <= 4096) shared by all problems; bf16 SiLU(emb)
+ *   and bf16 weights, f32 accumulation and output (what the per-block GEMMs computed).  `table`: a HOST array of 4 int64 per problem —
+ *   forward {weight bf16 [N, K] (16-byte aligned), bias f32 [N] or 0, out f32 [B, N], N}; backward {weight, dY f32 [B, N] or 0 (no gradient
+ *   for that output), bf16 copy of dY [B, N] to write or 0, N}.  t_bf16: SiLU(emb) as bf16 [B, K] (out; the weight-gradient GEMMs' operand).
+ *   backward: d_emb[b, k] = SiLU'(emb) * sum_i sum_n bf16(dY_i[b, n]) W_i[n, k]: per-64-column partial sums in `partial` (f32,
+ *   (sum_i ceil(N_i / 64)) * ceil8(B) * K elements, caller-owned), summed in block order: deterministic, no atomics. */
+int cfhip_time_proj_fwd(const float* emb, int B, int K, const int64_t* table, int count, void* t_bf16, void* stream);
+int cfhip_time_proj_bwd(const float* emb, int B, int K, const int64_t* table, int count, float* partial, float* d_emb, void* stream);
 int cfhip_upsample2_fwd(const void* x, void* y, int64_t BC, int H, int W, void* stream);
 int cfhip_upsample2_bwd(const void* dy, void* dx, int64_t BC, int H, int W, void* stream);
 int cfhip_avgpool2_fwd(const void* x, void* y, int64_t BC, int Ho, int Wo, void* stream);

@@ -860,6 +860,98 @@ def test_unet_nhwc_handover_matches_the_nchw_path(golden, monkeypatch):
     assert t1 <= t0 // 4 and n1 < n0, (t0, t1, n0, n1)
 
 
+# ---- round 6: the residual blocks' time-embedding projections in one launch (functional.time_proj_all) --------------------------------
+
+
+@pytest.mark.parametrize("b,k,ns,no_bias", [(8, 1280, (320, 320, 640, 1280, 1280, 77), ()), (3, 128, (64, 130), (1,)), (17, 512, (256,) * 5, ()),
+                                            (1, 1280, (320,) * 33, (0, 7))])
+def test_time_projection_kernels_vs_fp32(b, k, ns, no_bias):
+    """`cfhip_time_proj_fwd` / `_bwd`: out_i = Linear_i(SiLU(emb)) for up to 32 weight matrices per launch (33: two launches) against fp32
+    torch on the same bf16-rounded operands; a batch that is not a multiple of 8 and one beyond 8 (two batch chunks), an N that is not a
+    multiple of 64, missing biases, a missing output gradient; backward: d_emb and, through `TimeProjTapFn`, every dW / db."""
+    g = torch.Generator().manual_seed(b * 1000 + k)
+    emb = torch.randn(b, k, generator=g)
+    ws = [torch.randn(n, k, generator=g) * 0.05 for n in ns]
+    bs = [None if i in no_bias else torch.randn(n, generator=g) * 0.1 for i, n in enumerate(ns)]
+    dys = [torch.randn(b, n, generator=g) for n in ns]
+    skip = len(ns) - 1 if len(ns) > 2 else None  # this output gets no gradient
+    # fp32 reference on the roundings the kernels apply: bf16 SiLU(emb), bf16 W, bf16 dY
+    er = emb.clone().requires_grad_(True)
+    t_ref = bf16_round(torch.nn.functional.silu(er))  # (the rounding's own autograd is the identity: a straight-through estimate)
+    wr = [bf16_round(w).requires_grad_(True) for w in ws]
+    br = [None if x is None else x.clone().requires_grad_(True) for x in bs]
+    outs_r = [t_ref @ w.t() + (0 if x is None else x) for w, x in zip(wr, br)]
+    total = sum((o * bf16_round(dy)).sum() for i, (o, dy) in enumerate(zip(outs_r, dys)) if i != skip)
+    total.backward()
+
+    class Blk(torch.nn.Module):
+        def __init__(self, w, x):
+            super().__init__()
+            self.time_embedding = torch.nn.Linear(w.shape[1], w.shape[0], bias=x is not None)
+            with torch.no_grad():
+                self.time_embedding.weight.copy_(w)
+                if x is not None:
+                    self.time_embedding.bias.copy_(x)
+
+    blocks = [Blk(w, x).to(DEV) for w, x in zip(ws, bs)]
+    ed = emb.to(DEV).requires_grad_(True)
+    assert HF.time_proj_all(ed, blocks)
+    try:
+        outs = [HF.time_pre_lookup(blk, ed) for blk in blocks]
+    finally:
+        HF.time_pre_clear()
+    for i, (o, r) in enumerate(zip(outs, outs_r)):
+        assert o.dtype == torch.float32 and o.shape == r.shape
+        assert_close(o, r.detach(), 2e-4, f"projection {i} (N = {ns[i]})", abs_floor=1e-5)
+    sum((o * dy.to(DEV)).sum() for i, (o, dy) in enumerate(zip(outs, dys)) if i != skip).backward()
+    HF.SideStream.join()
+    torch.cuda.synchronize()
+    assert_close(ed.grad, er.grad, 2e-3, "d_emb", abs_floor=1e-4)
+    for i, blk in enumerate(blocks):
+        lin = blk.time_embedding
+        if i == skip:
+            assert lin.weight.grad is None or float(lin.weight.grad.abs().max()) == 0.0
+            continue
+        assert_close(lin.weight.grad, wr[i].grad, 6e-3, f"dW {i}", abs_floor=1e-4)  # (the dW GEMM reads bf16 SiLU(emb): the reference's t_ref)
+        if lin.bias is not None:
+            assert_close(lin.bias.grad, br[i].grad, 6e-3, f"db {i}", abs_floor=1e-4)
+
+
+def test_grouped_time_projection_matches_the_per_block_path(golden, monkeypatch):
+    """`functional.TIME_PROJ_GROUPED` on (the default: one launch for every block's Linear(SiLU(time_net)) at the top of
+    UNetDiffuser.forward, two for the embedding's gradient) against off (per block: SiLU, cast, GEMM; cast, GEMM, copy, SiLU', add) on the
+    small zoo-structured UNet: output and every parameter gradient — the time-embedding MLP's above all — and fewer launches."""
+    from cflearn_amd import _lib
+
+    u = golden("unet_small.pt")
+    outs = []
+    for grouped in (False, True):
+        monkeypatch.setattr(HF, "TIME_PROJ_GROUPED", grouped)
+        m = C.build_module("unet_diffuser", config=dict(u["cfg"]))
+        m.load_state_dict(u["sd"])
+        m = m.to(DEV)
+        calls = []
+        _lib.RECORDER = calls
+        try:
+            y = m(u["x"].to(DEV), timesteps=u["timesteps"].to(DEV), context=u["context"].to(DEV))
+            torch.nn.functional.mse_loss(y.float(), u["noise"].to(DEV)).backward()
+            HF.SideStream.join()
+        finally:
+            _lib.RECORDER = None
+        torch.cuda.synchronize()
+        names = [getattr(e[1], "__name__", "") for e in calls if e[0] == 0]
+        outs.append((y.detach().float().cpu(), {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters()}, names))
+    (y0, g0, n0), (y1, g1, n1) = outs
+    assert "cfhip_time_proj_fwd" in n1 and "cfhip_time_proj_bwd" in n1 and "cfhip_time_proj_fwd" not in n0
+    assert n1.count("cfhip_silu_f32_fwd") == 1 and n0.count("cfhip_silu_f32_fwd") > 4  # (the one left: inside the time-embedding MLP itself)
+    assert len(n1) < len(n0)
+    assert_close(y1, y0, 2e-3, "output, grouped vs per-block time projections")
+    scale = max(float(v.abs().max()) for v in g0.values())
+    for k in g0:
+        assert_close(g1[k], g0[k], 2e-2, f"gradient {k}", abs_floor=1e-3 * scale)
+    print(f"launches per forward + backward: per block {len(n0)}, grouped {len(n1)}")
+
+
 # ---- round 5: residual blocks and spatial transformers as ONE autograd node each (functional.run_taped) -----------------------
 
 
@@ -888,6 +980,9 @@ def test_taped_nodes_match_the_composed_path(golden, handover, monkeypatch):
     u = golden("unet_small.pt")
     x, ctx, t, eps = u["x"].to(DEV), u["context"].to(DEV), u["timesteps"].to(DEV), u["noise"].to(DEV)
     outs, flats = [], []
+    # (a taped block computes its own time projection — the grouped launch of round 6 is off under taped nodes — so the composed run takes
+    # the per-block path too: only then are the two forwards the same launches)
+    monkeypatch.setattr(HF, "TIME_PROJ_GROUPED", False)
     for taped in (False, True):
         monkeypatch.setattr(HF, "TAPED_NODES", [taped])
         m = C.build_module("unet_diffuser", config=dict(u["cfg"]))
