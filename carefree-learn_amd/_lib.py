@@ -172,6 +172,7 @@ SIGNATURES = {
     "cfhip_conv3x3_wgrad_nhwc_bf16": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                               c_size_t, _P]),
     "cfhip_conv3x3_pack_filters": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "cfhip_conv3x3_pack_filters_grouped": (c_int, [_P, c_int, _P]),
     "cfhip_colreduce_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "cfhip_q_sample": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int64, _P]),
     "cfhip_mse_loss": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_float, _P]),

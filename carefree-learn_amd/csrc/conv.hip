@@ -1543,35 +1543,59 @@ __global__ void gn_nhwc_dadd_kernel(const float* __restrict__ part, float* __res
 //   BWD: wr[c][tap][co]        = w[co][c][8 - tap]     (rotated by 180 degrees, channels swapped: the dX convolution)
 // One lane owns 8 channels of one filter: 72 consecutive bf16 (144 B, nine 16-byte loads), transposed in registers.
 template <bool BWD>
+__device__ __forceinline__ void conv3x3_pack_item(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, long idx) {
+  const int c8n = Cin >> 3;
+  // FWD: adjacent lanes take adjacent channel blocks (16-byte stores, contiguous over c);
+  // BWD: adjacent lanes take adjacent filters (2-byte stores, contiguous over co)
+  const int co = BWD ? (int)(idx % Cout) : (int)(idx / c8n);
+  const int c0 = (BWD ? (int)(idx / Cout) : (int)(idx % c8n)) << 3;
+  union { u32x4 v[9]; bf16_t e[72]; } u;
+  const u32x4* src = reinterpret_cast<const u32x4*>(w + ((long)co * Cin + c0) * 9);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) u.v[i] = src[i];
+  if (!BWD) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      union { u32x4 v; bf16_t e[8]; } o;
+#pragma unroll
+      for (int cl = 0; cl < 8; ++cl) o.e[cl] = u.e[cl * 9 + tap];
+      *reinterpret_cast<u32x4*>(out + ((long)co * 9 + tap) * Cin + c0) = o.v;
+    }
+  } else {
+#pragma unroll
+    for (int cl = 0; cl < 8; ++cl)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+        out[((long)(c0 + cl) * 9 + tap) * Cout + co] = u.e[cl * 9 + (8 - tap)];
+  }
+}
+
+template <bool BWD>
 __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out,
                                                            int Cout, int Cin) {
-  const int c8n = Cin >> 3;
-  const long total = (long)Cout * c8n;
-  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    // FWD: adjacent lanes take adjacent channel blocks (16-byte stores, contiguous over c);
-    // BWD: adjacent lanes take adjacent filters (2-byte stores, contiguous over co)
-    const int co = BWD ? (int)(idx % Cout) : (int)(idx / c8n);
-    const int c0 = (BWD ? (int)(idx / Cout) : (int)(idx % c8n)) << 3;
-    union { u32x4 v[9]; bf16_t e[72]; } u;
-    const u32x4* src = reinterpret_cast<const u32x4*>(w + ((long)co * Cin + c0) * 9);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) u.v[i] = src[i];
-    if (!BWD) {
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        union { u32x4 v; bf16_t e[8]; } o;
-#pragma unroll
-        for (int cl = 0; cl < 8; ++cl) o.e[cl] = u.e[cl * 9 + tap];
-        *reinterpret_cast<u32x4*>(out + ((long)co * 9 + tap) * Cin + c0) = o.v;
-      }
-    } else {
-#pragma unroll
-      for (int cl = 0; cl < 8; ++cl)
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-          out[((long)(c0 + cl) * 9 + tap) * Cout + co] = u.e[cl * 9 + (8 - tap)];
-    }
-  }
+  const long total = (long)Cout * (Cin >> 3);
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
+    conv3x3_pack_item<BWD>(w, out, Cout, Cin, idx);
+}
+
+// The filter matrices of MANY convolutions in one launch (round 6, late: the UNet packed both forms of its 48 3x3 convolutions with 96
+// launches of 12-15 us on the critical queue of every step): the problem table travels in the kernel arguments.
+constexpr int PK_MAX = 64;
+struct PackArgs {
+  const bf16_t* w[PK_MAX];
+  bf16_t* out[PK_MAX];
+  int cout[PK_MAX], cin[PK_MAX], rot[PK_MAX];
+  int blk0[PK_MAX + 1];  // first 256-item block of problem i; blk0[count] = number of blocks
+  int count;
+};
+__global__ __launch_bounds__(256) void conv3x3_pack_grouped_kernel(PackArgs a) {
+  int p = 0;
+  while (p + 1 < a.count && (int)blockIdx.x >= a.blk0[p + 1]) ++p;
+  const long idx = (long)((int)blockIdx.x - a.blk0[p]) * 256 + threadIdx.x;
+  const int Cout = a.cout[p], Cin = a.cin[p];
+  if (idx >= (long)Cout * (Cin >> 3)) return;
+  if (a.rot[p]) conv3x3_pack_item<true>(a.w[p], a.out[p], Cout, Cin, idx);
+  else conv3x3_pack_item<false>(a.w[p], a.out[p], Cout, Cin, idx);
 }
 
 // ---- SiLU on small f32 vectors (the time embedding), nearest x2 up-sampling, 2x2 average pooling ------------------
@@ -2416,5 +2440,30 @@ extern "C" int cfhip_conv3x3_pack_filters(const void* w, void* out, int Cout, in
     hipLaunchKernelGGL((conv3x3_pack_kernel<false>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)w, (bf16_t*)out, Cout, Cin);
   CFHIP_CHECK_LAUNCH("conv3x3_pack_filters");
+  return CFHIP_OK;
+}
+
+// table: a HOST array of 5 int64 per problem {w bf16 [Cout, Cin, 3, 3], out, Cout, Cin, rotate}; 1 .. 64 problems per call
+extern "C" int cfhip_conv3x3_pack_filters_grouped(const int64_t* table, int count, void* stream) {
+  CFHIP_REQUIRE(table && count > 0 && count <= PK_MAX, "conv3x3_pack_filters_grouped: 1 .. %d problems per call (got %d)", PK_MAX, count);
+  PackArgs a;
+  long blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const int64_t* e = table + 5 * i;
+    CFHIP_REQUIRE(e[0] != 0 && e[1] != 0 && e[2] > 0 && e[3] > 0 && e[3] % 8 == 0 && (e[0] & 15) == 0 && (e[1] & 15) == 0,
+                  "conv3x3_pack_filters_grouped: problem %d: 16-byte aligned pointers, Cout > 0, Cin %% 8 == 0", i);
+    a.w[i] = reinterpret_cast<const bf16_t*>(e[0]);
+    a.out[i] = reinterpret_cast<bf16_t*>(e[1]);
+    a.cout[i] = (int)e[2];
+    a.cin[i] = (int)e[3];
+    a.rot[i] = e[4] != 0;
+    a.blk0[i] = (int)blocks;
+    blocks += (e[2] * (e[3] / 8) + 255) / 256;
+  }
+  CFHIP_REQUIRE(blocks < (1L << 30), "conv3x3_pack_filters_grouped: too many items");
+  a.blk0[count] = (int)blocks;
+  a.count = count;
+  hipLaunchKernelGGL(conv3x3_pack_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  CFHIP_CHECK_LAUNCH("conv3x3_pack_filters_grouped");
   return CFHIP_OK;
 }

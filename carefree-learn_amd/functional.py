@@ -1334,6 +1334,57 @@ def _thin_head_ok(cin: int, cout: int, kh: int, kw: int, stride: int, pad: int, 
             and _implicit_ok(cin, THIN_HEAD_PAD, kh, kw, stride, pad, dil, h, w))
 
 
+# ---- the filter matrices of a model's 3x3 convolutions packed in one launch at the top of its forward (round 6, late) -------------------
+# Conv2dFn packs its filters into the two layouts of the implicit-GEMM kernel (forward; rotated for dX) on every call: the weights change
+# every step.  For the zoo UNet that is 96 launches of 12-15 us on the critical queue.  `prepack_convs` does all of them in two launches
+# (cfhip_conv3x3_pack_filters_grouped) into buffers that live with the model; Conv2dFn.forward picks its pair up with `pack_pre_lookup`
+# while the scope of that forward lasts.  The buffers of a step are overwritten by the next forward's launch, i.e. after the backward that
+# read them was issued on the same stream.
+PACK_GROUPED = True  # (A/B: tools set the attribute)
+
+
+class _PackPre(threading.local):
+    def __init__(self) -> None:
+        self.packed: dict = {}
+
+
+_PACK_PRE = _PackPre()
+
+
+def prepack_convs(owner: Any, convs: Sequence[Any]) -> bool:
+    """pack the filters of `convs` (modules with a [Cout, Cin, 3, 3] `weight` that reach Conv2dFn's implicit route untransformed) now"""
+    pack_pre_clear()
+    if not PACK_GROUPED or not convs or not convs[0].weight.is_cuda:
+        return False
+    bufs = owner.__dict__.setdefault("_cfhip_pack_bufs", {})
+    items, packed = [], {}
+    for conv in convs:
+        w = conv.weight
+        cout, cin = w.shape[0], w.shape[1]
+        w16 = shadow_bf16(w).view(cout, cin, 3, 3)
+        ent = bufs.get(id(w))
+        if ent is None or ent[0].device != w16.device:
+            ent = (torch.empty((cout, 9 * cin), dtype=bf16, device=w16.device),
+                   torch.empty((cin, 9 * cout), dtype=bf16, device=w16.device) if cout % 32 == 0 else None)
+            bufs[id(w)] = ent
+        items.append((w16, ent[0], False))
+        if ent[1] is not None:
+            items.append((w16, ent[1], True))
+        packed[id(w)] = ent
+    ops.conv3x3_pack_grouped(items)
+    _PACK_PRE.packed = packed
+    return True
+
+
+def pack_pre_lookup(weight: Tensor):
+    """(forward filter matrix, rotated one or None) of `weight` out of this forward's grouped launch, else None"""
+    return _PACK_PRE.packed.get(id(weight))
+
+
+def pack_pre_clear() -> None:
+    _PACK_PRE.packed = {}
+
+
 class Conv2dFn(Function):
     """Replaces F.conv2d reached from Conv2d.forward (reference convs/basic.py:160-177), groups = 1:
     NCHW in (f32 / bf16), NCHW bf16 out.  Two routes: implicit GEMM on an NHWC copy (3x3 / stride 1 / pad 1,
@@ -1372,7 +1423,8 @@ class Conv2dFn(Function):
                     bpad = torch.zeros((cop,), dtype=f32, device=x.device)
                     bpad[:cout] = bias_f
                     bias_f = bpad
-            wk = ops.conv3x3_pack_filters(w16, False)  # k = (ky, kx, c): a K-step = 32 channels of a tap
+            pre = None if thin else pack_pre_lookup(weight)  # both filter matrices out of the model's one launch (prepack_convs)
+            wk = pre[0] if pre is not None else ops.conv3x3_pack_filters(w16, False)  # k = (ky, kx, c): a K-step = 32 channels of a tap
             y_rows = ops.conv3x3_nhwc(x_rows, wk, bias_f, b, h, w)
             ctx.save_for_backward(x_rows, w16)  # the NHWC bf16 copy serves the weight gradient; x itself is not kept
             ctx.xshape = (b, cin, h, w)
@@ -1380,7 +1432,9 @@ class Conv2dFn(Function):
             # lane beside the forward convolution, instead of on the backward's critical queue (47 launches, 1.65 ms of the
             # 64^2 x 8 UNet step).  The weights' current bf16 shadow does not change before this step's backward has run.
             ctx.wr = ctx.wr_event = None
-            if PACK_AHEAD == 2 and cop % 32 == 0 and ctx.needs_input_grad[0]:
+            if pre is not None and pre[1] is not None and ctx.needs_input_grad[0]:
+                ctx.wr = pre[1]
+            elif PACK_AHEAD == 2 and cop % 32 == 0 and ctx.needs_input_grad[0]:
                 # on the caller's stream: the forward of the UNet is issue-bound (the queue drains faster than the host fills
                 # it), the backward is bound by its queue — the pack costs nothing here and 35 us per layer there
                 ctx.wr = ops.conv3x3_pack_filters(w16, True)

@@ -2123,6 +2123,9 @@ class UNetDiffuser(Module):
         # every residual block's Linear(SiLU(time_net)) in one launch (functional.time_proj_all); blocks that recompute themselves in
         # backward, use the scale-shift modulation's 2C projection all the same, or carry hooks / low-rank weights fall out of the list
         HF.time_proj_all(time_net, self._time_projection_blocks())
+        # ... and both filter matrices of every plain 3x3 convolution (functional.prepack_convs: two launches instead of two per convolution)
+        if net.is_cuda:
+            HF.prepack_convs(self, self._packable_convs())
         prev = HF.NHWC[0]
         # (with few samples the NHWC GroupNorm has to cut a sample into row slices and merge them — three launches — and loses to the
         # NCHW path: 256^2 x 1 457 -> 485 ms; with a batch the group form is one launch and the step gains: 64^2 x 8 60.6 -> 59.6 ms)
@@ -2144,6 +2147,16 @@ class UNetDiffuser(Module):
         finally:
             HF.NHWC[0] = prev
             HF.time_pre_clear()
+            HF.pack_pre_clear()
+
+    def _packable_convs(self) -> List[Module]:
+        convs = getattr(self, "_pack_convs", None)
+        if convs is None:  # 3x3 / stride 1 / pad 1 convolutions whose weight goes to Conv2dFn as it is, on the implicit route (Cin % 32, Cout % 8)
+            convs = [m for m in self.modules()
+                     if type(m) is HijackConv2d and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1)
+                     and m.groups == 1 and m.padding_mode == "zeros" and m.in_channels % 32 == 0 and m.out_channels % 8 == 0]
+            object.__setattr__(self, "_pack_convs", convs)
+        return [m for m in convs if getattr(m, "hook", None) is None]
 
     def _time_projection_blocks(self) -> List[Module]:
         blocks = getattr(self, "_time_blocks", None)

@@ -1453,6 +1453,23 @@ def conv3x3_pack_filters(w16: Tensor, rotate: bool, out: Optional[Tensor] = None
     return out
 
 
+PACK_GROUP_MAX = 64  # problems per launch of conv3x3_pack_grouped (csrc/conv.hip: PK_MAX)
+
+
+def conv3x3_pack_grouped(items) -> None:
+    """items: (w16 bf16 [Cout, Cin, 3, 3], out, rotate) — `conv3x3_pack_filters` for all of them in ceil(len / 64) launches"""
+    lib = _lib.load()
+    for i in range(0, len(items), PACK_GROUP_MAX):
+        flat = []
+        for w16, out, rotate in items[i:i + PACK_GROUP_MAX]:
+            if w16.dtype != bf16 or w16.dim() != 4 or tuple(w16.shape[2:]) != (3, 3) or not w16.is_contiguous() or out.dtype != bf16 \
+                    or out.numel() != w16.numel():
+                raise ValueError("cfhip conv3x3_pack_grouped: contiguous bf16 [Cout, Cin, 3, 3] filters and bf16 outputs of the same size expected")
+            flat += [w16.data_ptr(), out.data_ptr(), w16.shape[0], w16.shape[1], int(bool(rotate))]
+        table = (ctypes.c_int64 * len(flat))(*flat)
+        _lib.check(lib.cfhip_conv3x3_pack_filters_grouped(ctypes.addressof(table), len(flat) // 5, _stream()), "conv3x3_pack_filters_grouped")
+
+
 def sgemm_f32(a: Tensor, b: Tensor, *, a_trans: bool = False, b_trans: bool = False,
               alpha_dev: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
     """fp32 C[m,n] = alpha * alpha_dev[0] * sum_k A(m,k) B(n,k) on dense f32 matrices (a: [M,K] or, a_trans, [K,M];

@@ -396,6 +396,10 @@ int cfhip_conv3x3_wgrad_nhwc_bf16(const void* dY, const void* X, float* dW, int 
  *   rotate == 0: out[co][(ky*3+kx)*Cin + c]        = w[co][c][ky][kx]       ([Cout][9*Cin], the forward's Wk)
  *   rotate != 0: out[c][(ky*3+kx)*Cout + co]       = w[co][c][2-ky][2-kx]   ([Cin][9*Cout], the input gradient's Wk') */
 int cfhip_conv3x3_pack_filters(const void* w, void* out, int Cout, int Cin, int rotate, void* stream);
+/* The same for 1 .. 64 filter banks in one launch: `table` is a HOST array of 5 int64 per problem {w, out, Cout, Cin, rotate} (the pointers
+ * travel in the kernel arguments).  What a model calls once at the top of its forward instead of two packs per convolution
+ * (functional.prepack_convs; reference: every `conv_nd(2, ..., 3, padding=1)` of unet.py / residual.py reaches F.conv2d with its own weight). */
+int cfhip_conv3x3_pack_filters_grouped(const int64_t* table, int count, void* stream);
 /* One idle wavefront for `microseconds` (1..100000) on `stream`.  Host-side stream self-check only (two streams
  * that share a ROCclr hardware queue run it back to back; the side streams of the backward pass and the RCCL
  * stream must not share the compute stream's queue -- reference counterpart: none, torch DDP owns its streams). */

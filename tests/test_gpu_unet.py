@@ -1159,3 +1159,49 @@ def test_unet_zoo_256px_forward_vs_oracle_and_gradients_vs_finite_differences(mo
     y_err = rel_l2(got_y, want_y)
     print(f"zoo UNet 256^2 x 1: output rel-L2 vs the fp32 oracle {y_err:.3e}")
     assert y_err <= 2e-2, y_err
+
+
+def test_grouped_filter_packing_matches_the_per_convolution_packs(golden, monkeypatch):
+    """`functional.PACK_GROUPED` on (the default: both filter matrices of every plain 3x3 convolution packed by one grouped launch at the top
+    of UNetDiffuser.forward, `cfhip_conv3x3_pack_filters_grouped`) against off (two `cfhip_conv3x3_pack_filters` launches per convolution):
+    the packed bytes are the same, so output and gradients are equal bit for bit; and the kernel alone against the single-problem one."""
+    from cflearn_amd import _lib
+
+    g = torch.Generator().manual_seed(5)
+    items, want = [], []
+    for cout, cin in ((64, 32), (320, 640), (8, 96), (96, 64)):
+        w16 = torch.randn(cout, cin, 3, 3, generator=g).to(torch.bfloat16).to(DEV)
+        for rot in (False, True):
+            items.append((w16, torch.empty((cin, 9 * cout) if rot else (cout, 9 * cin), dtype=torch.bfloat16, device=DEV), rot))
+            want.append(ops.conv3x3_pack_filters(w16, rot))
+    ops.conv3x3_pack_grouped(items * 9)  # 72 problems: two launches
+    for (w16, out, rot), ref in zip(items, want):
+        assert torch.equal(out, ref), (tuple(w16.shape), rot)
+
+    u = golden("unet_small.pt")
+    outs = []
+    for grouped in (False, True):
+        monkeypatch.setattr(HF, "PACK_GROUPED", grouped)
+        m = C.build_module("unet_diffuser", config=dict(u["cfg"]))
+        m.load_state_dict(u["sd"])
+        m = m.to(DEV)
+        calls = []
+        _lib.RECORDER = calls
+        try:
+            for _ in range(2):  # (twice: the second forward overwrites the buffers the first backward read)
+                for p in m.parameters():
+                    p.grad = None
+                y = m(u["x"].to(DEV), timesteps=u["timesteps"].to(DEV), context=u["context"].to(DEV))
+                torch.nn.functional.mse_loss(y.float(), u["noise"].to(DEV)).backward()
+                HF.SideStream.join()
+        finally:
+            _lib.RECORDER = None
+        torch.cuda.synchronize()
+        names = [getattr(e[1], "__name__", "") for e in calls if e[0] == 0]
+        outs.append((y.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}, names))
+    (y0, g0, n0), (y1, g1, n1) = outs
+    assert n1.count("cfhip_conv3x3_pack_filters_grouped") == 2 and n0.count("cfhip_conv3x3_pack_filters_grouped") == 0
+    assert n1.count("cfhip_conv3x3_pack_filters") < n0.count("cfhip_conv3x3_pack_filters") // 4  # (what is left: the padded thin head)
+    assert torch.equal(y0, y1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
