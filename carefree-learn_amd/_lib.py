@@ -177,6 +177,7 @@ SIGNATURES = {
     "cfhip_q_sample": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int64, _P]),
     "cfhip_mse_loss": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_float, _P]),
     "cfhip_copy_strided_bf16": (c_int, [_P, _P, c_int64, c_int64, c_int64, c_int64, _P]),
+    "cfhip_copy_strided2_bf16": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, c_int64, c_int64, c_int64, c_int64, _P]),
     "cfhip_geglu_fwd": (c_int, [_P, _P, c_int64, c_int, _P]),
     "cfhip_geglu_bwd": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "cfhip_quick_gelu_fwd": (c_int, [_P, _P, c_int64, _P]),

@@ -726,6 +726,35 @@ extern "C" int cfhip_copy_strided_bf16(const void* src, void* dst, int64_t batch
   return CFHIP_OK;
 }
 
+// Two such copies with the same batch count in ONE launch: both halves of a channel concatenation, or both halves of its backward split
+// (the UNet's twelve skip connections: 48 launches of 6-7 us on the critical queue of a step became 24).
+__global__ void copy_strided2_bf16_kernel(const bf16_t* __restrict__ sa, bf16_t* __restrict__ da, long na, long sa_bs, long da_bs,
+                                          const bf16_t* __restrict__ sb, bf16_t* __restrict__ db, long nb, long sb_bs, long db_bs,
+                                          long batch) {
+  const long na4 = na >> 2, n4 = na4 + (nb >> 2);
+  const long total = batch * n4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long b = i / n4, r = i - b * n4;
+    if (r < na4) *reinterpret_cast<u32x2*>(da + b * da_bs + r * 4) = *reinterpret_cast<const u32x2*>(sa + b * sa_bs + r * 4);
+    else *reinterpret_cast<u32x2*>(db + b * db_bs + (r - na4) * 4) = *reinterpret_cast<const u32x2*>(sb + b * sb_bs + (r - na4) * 4);
+  }
+}
+
+extern "C" int cfhip_copy_strided2_bf16(const void* src_a, void* dst_a, int64_t n_a, int64_t src_a_batch_stride, int64_t dst_a_batch_stride,
+                                        const void* src_b, void* dst_b, int64_t n_b, int64_t src_b_batch_stride, int64_t dst_b_batch_stride,
+                                        int64_t batch, void* stream) {
+  CFHIP_REQUIRE(src_a && dst_a && src_b && dst_b && batch > 0 && n_a > 0 && n_b > 0, "copy_strided2_bf16: bad arguments");
+  CFHIP_REQUIRE(n_a % 4 == 0 && n_b % 4 == 0 && src_a_batch_stride % 4 == 0 && dst_a_batch_stride % 4 == 0 && src_b_batch_stride % 4 == 0 &&
+                    dst_b_batch_stride % 4 == 0 && (((uintptr_t)src_a | (uintptr_t)dst_a | (uintptr_t)src_b | (uintptr_t)dst_b) & 7) == 0,
+                "copy_strided2_bf16: lengths / strides must be multiples of 4 elements, pointers 8-byte aligned");
+  hipLaunchKernelGGL(copy_strided2_bf16_kernel, dim3(grid_for(batch * ((n_a + n_b) / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src_a, (bf16_t*)dst_a, (long)n_a, (long)src_a_batch_stride, (long)dst_a_batch_stride,
+                     (const bf16_t*)src_b, (bf16_t*)dst_b, (long)n_b, (long)src_b_batch_stride, (long)dst_b_batch_stride, (long)batch);
+  CFHIP_CHECK_LAUNCH("copy_strided2_bf16");
+  return CFHIP_OK;
+}
+
 // ---- GEGLU (activations.py:150-158): out[m][c] = vg[m][c] * gelu(vg[m][L + c]); 4 bf16 per thread ------------------
 template <bool BWD>
 __global__ void geglu_kernel(const bf16_t* __restrict__ vg, const bf16_t* __restrict__ dy, bf16_t* __restrict__ out,

@@ -2311,8 +2311,7 @@ class ConcatChannelsFn(Function):
             n, ca, h, w = a.shape
             cb = b.shape[1]
             out = torch.empty((n * h * w, ca + cb), dtype=bf16, device=a.device)
-            ops.copy_strided(nhwc_rows(a), out, n * h * w, ca, ca, ca + cb)
-            ops.copy_strided(nhwc_rows(b), out, n * h * w, cb, cb, ca + cb, dst_off=ca)
+            ops.copy_strided2(nhwc_rows(a), out, ca, ca, ca + cb, nhwc_rows(b), out, cb, cb, ca + cb, n * h * w, dst_b_off=ca)
             ctx.nhwc = (n, ca, cb, h, w)
             return rows_to_nhwc(out, n, ca + cb, h, w)
         a = (a if a.dtype == bf16 else ops.to_bf16(a.float().contiguous())).contiguous()
@@ -2321,8 +2320,7 @@ class ConcatChannelsFn(Function):
         inner = a.numel() // (n * ca)
         out = torch.empty((n, ca + cb, *a.shape[2:]), dtype=bf16, device=a.device)
         tot = (ca + cb) * inner
-        ops.copy_strided(a, out, n, ca * inner, ca * inner, tot)
-        ops.copy_strided(b, out, n, cb * inner, cb * inner, tot, dst_off=ca * inner)
+        ops.copy_strided2(a, out, ca * inner, ca * inner, tot, b, out, cb * inner, cb * inner, tot, n, dst_b_off=ca * inner)
         ctx.split = (ca, cb, inner)
         return out
 
@@ -2333,8 +2331,7 @@ class ConcatChannelsFn(Function):
             rows = nhwc_rows(to_nhwc(as_bf16_act(dy)))
             da = torch.empty((n * h * w, ca), dtype=bf16, device=dy.device)
             db = torch.empty((n * h * w, cb), dtype=bf16, device=dy.device)
-            ops.copy_strided(rows, da, n * h * w, ca, ca + cb, ca)
-            ops.copy_strided(rows, db, n * h * w, cb, ca + cb, cb, src_off=ca)
+            ops.copy_strided2(rows, da, ca, ca + cb, ca, rows, db, cb, ca + cb, cb, n * h * w, src_b_off=ca)
             return rows_to_nhwc(da, n, ca, h, w), rows_to_nhwc(db, n, cb, h, w)
         ca, cb, inner = ctx.split
         dy = to_nchw(dy if dy.dtype == bf16 else ops.to_bf16(to_nchw(dy.float())))
@@ -2342,8 +2339,7 @@ class ConcatChannelsFn(Function):
         da = torch.empty((n, ca, *dy.shape[2:]), dtype=bf16, device=dy.device)
         db = torch.empty((n, cb, *dy.shape[2:]), dtype=bf16, device=dy.device)
         tot = (ca + cb) * inner
-        ops.copy_strided(dy, da, n, ca * inner, tot, ca * inner)
-        ops.copy_strided(dy, db, n, cb * inner, tot, cb * inner, src_off=ca * inner)
+        ops.copy_strided2(dy, da, ca * inner, tot, ca * inner, dy, db, cb * inner, tot, cb * inner, n, src_b_off=ca * inner)
         return da, db
 
 

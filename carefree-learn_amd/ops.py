@@ -1547,6 +1547,17 @@ def copy_strided(src: Tensor, dst: Tensor, batch: int, n: int, src_bs: int, dst_
     _lib.check(rc, "copy_strided_bf16")
 
 
+def copy_strided2(src_a: Tensor, dst_a: Tensor, n_a: int, sa_bs: int, da_bs: int, src_b: Tensor, dst_b: Tensor, n_b: int, sb_bs: int,
+                  db_bs: int, batch: int, *, src_a_off: int = 0, dst_a_off: int = 0, src_b_off: int = 0, dst_b_off: int = 0) -> None:
+    """two `copy_strided` with the same batch count in one launch (a channel concatenation, or its backward split)"""
+    for t, nm in ((src_a, "src_a"), (dst_a, "dst_a"), (src_b, "src_b"), (dst_b, "dst_b")):
+        _need(t, bf16, nm)
+    rc = _lib.load().cfhip_copy_strided2_bf16(src_a.data_ptr() + 2 * src_a_off, dst_a.data_ptr() + 2 * dst_a_off, n_a, sa_bs, da_bs,
+                                              src_b.data_ptr() + 2 * src_b_off, dst_b.data_ptr() + 2 * dst_b_off, n_b, sb_bs, db_bs,
+                                              batch, _stream())
+    _lib.check(rc, "copy_strided2_bf16")
+
+
 def q_sample(x: Tensor, noise: Tensor, t: Tensor, sqrt_ac: Tensor, sqrt_1mac: Tensor, out_dtype: torch.dtype = f32) -> Tensor:
     """x_t = sqrt_ac[t] * x + sqrt_1mac[t] * noise per sample (reference samplers/schema.py:94-108)"""
     for tt, nm in ((x, "x"), (noise, "noise"), (sqrt_ac, "sqrt_ac"), (sqrt_1mac, "sqrt_1mac")):

@@ -343,6 +343,10 @@ int cfhip_diffusion_loss(const void* pred, const float* target, const float* wei
  * split of NCHW tensors — torch.cat(dim=1) of the UNet skip connections (multimodal/diffusion/unet.py:311-316) */
 int cfhip_copy_strided_bf16(const void* src, void* dst, int64_t batch, int64_t n, int64_t src_batch_stride,
                             int64_t dst_batch_stride, void* stream);
+/* two of them (same batch count) in one launch: both halves of torch.cat([a, b], dim=1) or of its backward split (unet.py:311-316) */
+int cfhip_copy_strided2_bf16(const void* src_a, void* dst_a, int64_t n_a, int64_t src_a_batch_stride, int64_t dst_a_batch_stride,
+                             const void* src_b, void* dst_b, int64_t n_b, int64_t src_b_batch_stride, int64_t dst_b_batch_stride,
+                             int64_t batch, void* stream);
 /* GEGLU (activations.py:150-158): out[m][c] = vg[m][c] * gelu_erf(vg[m][L + c]) for vg bf16 [M][2L]; bwd writes dvg */
 int cfhip_geglu_fwd(const void* vg, void* out, int64_t M, int L, void* stream);
 int cfhip_geglu_bwd(const void* dy, const void* vg, void* dvg, int64_t M, int L, void* stream);
