@@ -174,6 +174,7 @@ SIGNATURES = {
     "cfhip_conv3x3_pack_filters": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "cfhip_conv3x3_pack_filters_grouped": (c_int, [_P, c_int, _P]),
     "cfhip_colreduce_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "cfhip_colreduce2_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "cfhip_q_sample": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int64, _P]),
     "cfhip_mse_loss": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_float, _P]),
     "cfhip_copy_strided_bf16": (c_int, [_P, _P, c_int64, c_int64, c_int64, c_int64, _P]),

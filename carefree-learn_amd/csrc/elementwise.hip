@@ -21,9 +21,12 @@ inline int grid_for(long work_items, int per_block, int cap = 2048) {
 // workgroup = 32 columns x 32 row-lanes (1024 threads): every thread owns R/32 rows of one column and
 // keeps its loads independent, so the kernel is one short burst of parallel loads instead of a long
 // dependent chain (the 8-row-lane version spent 13 us on a 3 MB input).
+// (blockIdx.y = 1: the second matrix / output of a pair — GroupNorm's dgamma and dbeta partial sums in one launch)
 __global__ __launch_bounds__(1024) void colreduce_f32_kernel(const float* __restrict__ p, int R, int D,
-                                                             float* __restrict__ out, int accumulate) {
+                                                             float* __restrict__ out, int accumulate,
+                                                             const float* __restrict__ p2 = nullptr, float* __restrict__ out2 = nullptr) {
   __shared__ float red[32][33];
+  if (blockIdx.y == 1) { p = p2; out = out2; }
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + cx;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -456,7 +459,7 @@ __global__ void softmax_xent_kernel(const float* __restrict__ logits, const long
 int cfhip_internal_colreduce_f32(const float* partials, int R, int D, float* out, int accumulate,
                                  hipStream_t s) {
   hipLaunchKernelGGL(colreduce_f32_kernel, dim3((D + 31) / 32), dim3(1024), 0, s, partials, R, D, out,
-                     accumulate);
+                     accumulate, (const float*)nullptr, (float*)nullptr);
   CFHIP_CHECK_LAUNCH("colreduce_f32");
   return CFHIP_OK;
 }
@@ -514,6 +517,13 @@ extern "C" int cfhip_spin(int microseconds, void* stream) {
 extern "C" int cfhip_colreduce_f32(const float* x, float* out, int R, int D, int accumulate, void* stream) {
   CFHIP_REQUIRE(x && out && R > 0 && D > 0, "colreduce_f32: bad arguments");
   return cfhip_internal_colreduce_f32(x, R, D, out, accumulate, (hipStream_t)stream);
+}
+
+extern "C" int cfhip_colreduce2_f32(const float* x_a, float* out_a, const float* x_b, float* out_b, int R, int D, int accumulate, void* stream) {
+  CFHIP_REQUIRE(x_a && out_a && x_b && out_b && R > 0 && D > 0, "colreduce2_f32: bad arguments");
+  hipLaunchKernelGGL(colreduce_f32_kernel, dim3((D + 31) / 32, 2), dim3(1024), 0, (hipStream_t)stream, x_a, R, D, out_a, accumulate, x_b, out_b);
+  CFHIP_CHECK_LAUNCH("colreduce2_f32");
+  return CFHIP_OK;
 }
 
 extern "C" size_t cfhip_colsum_workspace(int M, int N) {

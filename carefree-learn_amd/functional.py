@@ -1960,6 +1960,12 @@ class GroupNormFn(Function):
             dx, dg, db, dadd = ops.groupnorm_bwd(to_nchw(dy), x, gamma, beta, mean, rstd, ctx.groups, add=addc, silu=ctx.silu,
                                                  reduce=per_sample)
         gw = gb = None
+        # both [B, C] partial sums reduced over B straight into `.grad` by ONE launch when the two parameters take the same kind of write
+        if (not per_sample and ctx.weight.requires_grad and ctx.bias.requires_grad and _is_direct(ctx.weight) and _is_direct(ctx.bias)
+                and dg.shape == db.shape and dg.dim() == 2
+                and write_param_grad_pair(ctx.weight, ctx.bias,
+                                          lambda ga, gb_, acc: ops.colreduce2_f32(dg, db, ga.view(-1), gb_.view(-1), acc))):
+            return (dx if ctx.needs_input_grad[0] else None), None, None, None, None, dadd, None
         for prm, g, which in ((ctx.weight, dg, 0), (ctx.bias, db, 1)):
             if not prm.requires_grad:
                 continue

@@ -1015,6 +1015,16 @@ def colreduce_f32(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = Fa
     return out
 
 
+def colreduce2_f32(xa: Tensor, xb: Tensor, out_a: Tensor, out_b: Tensor, accumulate: bool) -> None:
+    """out_a[d] (+)= sum_r xa[r][d] and the same for (xb, out_b) — two contiguous f32 [R, D] matrices of one shape — in one launch"""
+    _need(xa, f32, "xa")
+    _need(xb, f32, "xb")
+    if xa.dim() != 2 or xa.shape != xb.shape or not xa.is_contiguous() or not xb.is_contiguous():
+        raise ValueError("cfhip colreduce2_f32: two contiguous [R, D] matrices of one shape expected")
+    _lib.check(_lib.load().cfhip_colreduce2_f32(xa.data_ptr(), out_a.data_ptr(), xb.data_ptr(), out_b.data_ptr(), xa.shape[0], xa.shape[1],
+                                                int(accumulate), _stream()), "colreduce2_f32")
+
+
 def _gn_affine_stride(gamma: Tensor, beta: Tensor, b: int, c: int) -> int:
     if gamma.shape != beta.shape or not gamma.is_contiguous() or not beta.is_contiguous():
         raise ValueError("cfhip groupnorm: gamma / beta must be contiguous and of one shape")

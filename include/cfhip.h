@@ -536,6 +536,8 @@ int cfhip_reflect_pad2d_fwd(const void* x, int x_is_f32, void* y, int64_t BC, in
 int cfhip_reflect_pad2d_bwd(const void* dy, void* dx, int64_t BC, int H, int W, int pl, int pr, int pt, int pb, void* stream);
 /* out[d] (+)= sum_r x[r][d] for a dense f32 [R][D] matrix (per-batch partials -> parameter gradient) */
 int cfhip_colreduce_f32(const float* x, float* out, int R, int D, int accumulate, void* stream);
+/* two [R, D] matrices into two outputs in one launch (GroupNorm's dgamma / dbeta partial sums: norms.py nn.GroupNorm's weight / bias gradients) */
+int cfhip_colreduce2_f32(const float* x_a, float* out_a, const float* x_b, float* out_b, int R, int D, int accumulate, void* stream);
 int cfhip_timestep_embedding(const int64_t* t, float* out, int B, int dim, float max_period, void* stream);
 
 
