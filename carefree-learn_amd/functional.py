@@ -1337,7 +1337,7 @@ def _thin_head_ok(cin: int, cout: int, kh: int, kw: int, stride: int, pad: int, 
 # ---- the filter matrices of a model's 3x3 convolutions packed in one launch at the top of its forward (round 6, late) -------------------
 # Conv2dFn packs its filters into the two layouts of the implicit-GEMM kernel (forward; rotated for dX) on every call: the weights change
 # every step.  For the zoo UNet that is 96 launches of 12-15 us on the critical queue.  `prepack_convs` does all of them in two launches
-# (cfhip_conv3x3_pack_filters_grouped) into buffers that live with the model; Conv2dFn.forward picks its pair up with `pack_pre_lookup`
+# (cfhip_conv3x3_pack_filters_grouped) into buffers that live with the parameters; Conv2dFn.forward picks its pair up with `pack_pre_lookup`
 # while the scope of that forward lasts.  The buffers of a step are overwritten by the next forward's launch, i.e. after the backward that
 # read them was issued on the same stream.
 PACK_GROUPED = True  # (A/B: tools set the attribute)
@@ -1351,22 +1351,21 @@ class _PackPre(threading.local):
 _PACK_PRE = _PackPre()
 
 
-def prepack_convs(owner: Any, convs: Sequence[Any]) -> bool:
+def prepack_convs(convs: Sequence[Any]) -> bool:
     """pack the filters of `convs` (modules with a [Cout, Cin, 3, 3] `weight` that reach Conv2dFn's implicit route untransformed) now"""
     pack_pre_clear()
     if not PACK_GROUPED or not convs or not convs[0].weight.is_cuda:
         return False
-    bufs = owner.__dict__.setdefault("_cfhip_pack_bufs", {})
     items, packed = [], {}
     for conv in convs:
         w = conv.weight
         cout, cin = w.shape[0], w.shape[1]
         w16 = shadow_bf16(w).view(cout, cin, 3, 3)
-        ent = bufs.get(id(w))
+        ent = getattr(w, "_cfhip_packed", None)  # (the buffers live on the parameter object: a deep copy of the model starts without them)
         if ent is None or ent[0].device != w16.device:
             ent = (torch.empty((cout, 9 * cin), dtype=bf16, device=w16.device),
                    torch.empty((cin, 9 * cout), dtype=bf16, device=w16.device) if cout % 32 == 0 else None)
-            bufs[id(w)] = ent
+            w._cfhip_packed = ent
         items.append((w16, ent[0], False))
         if ent[1] is not None:
             items.append((w16, ent[1], True))

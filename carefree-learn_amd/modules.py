@@ -2125,7 +2125,7 @@ class UNetDiffuser(Module):
         HF.time_proj_all(time_net, self._time_projection_blocks())
         # ... and both filter matrices of every plain 3x3 convolution (functional.prepack_convs: two launches instead of two per convolution)
         if net.is_cuda:
-            HF.prepack_convs(self, self._packable_convs())
+            HF.prepack_convs(self._packable_convs())
         prev = HF.NHWC[0]
         # (with few samples the NHWC GroupNorm has to cut a sample into row slices and merge them — three launches — and loses to the
         # NCHW path: 256^2 x 1 457 -> 485 ms; with a batch the group form is one launch and the step gains: 64^2 x 8 60.6 -> 59.6 ms)
