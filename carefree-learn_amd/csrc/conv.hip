@@ -2326,7 +2326,7 @@ static int time_proj_args(const int64_t* table, int count, bool fwd, TimeProjArg
 }
 
 extern "C" int cfhip_time_proj_fwd(const float* emb, int B, int K, const int64_t* table, int count, void* t_bf16, void* stream) {
-  CFHIP_REQUIRE(emb && t_bf16 && B > 0 && K > 0 && K % 32 == 0 && K <= 4096, "time_proj_fwd: emb [B, K] f32 with K %% 32 == 0, K <= 4096 (got B=%d K=%d)", B, K);
+  CFHIP_REQUIRE(emb && t_bf16 && B > 0 && K > 0 && K % 32 == 0 && K <= 2048, "time_proj_fwd: emb [B, K] f32 with K %% 32 == 0, K <= 2048 — 8 bf16 rows of it sit in 32 KB of LDS (got B=%d K=%d)", B, K);
   TimeProjArgs a;
   const int rc = time_proj_args(table, count, true, &a, "time_proj_fwd");
   if (rc != CFHIP_OK) return rc;
@@ -2340,7 +2340,7 @@ extern "C" int cfhip_time_proj_fwd(const float* emb, int B, int K, const int64_t
 // partial: f32 workspace of (sum over problems of ceil(N_i / 64)) * ceil8(B) * K elements, owned by the caller
 extern "C" int cfhip_time_proj_bwd(const float* emb, int B, int K, const int64_t* table, int count, float* partial, float* d_emb,
                                    void* stream) {
-  CFHIP_REQUIRE(emb && partial && d_emb && B > 0 && K > 0 && K % 32 == 0 && K <= 4096, "time_proj_bwd: bad arguments (B=%d K=%d)", B, K);
+  CFHIP_REQUIRE(emb && partial && d_emb && B > 0 && K > 0 && K % 32 == 0 && K <= 2048, "time_proj_bwd: bad arguments (B=%d K=%d)", B, K);
   TimeProjArgs a;
   const int rc = time_proj_args(table, count, false, &a, "time_proj_bwd");
   if (rc != CFHIP_OK) return rc;

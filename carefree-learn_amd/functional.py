@@ -2128,7 +2128,7 @@ def time_proj_all(time_net: Tensor, blocks: Sequence[Any]) -> bool:
     time_pre_clear()
     # (taped nodes — one autograd node per block, off by default — run each block's Functions on a tape of their own: per-block path)
     if (not TIME_PROJ_GROUPED or TAPED_NODES[0] or not blocks or getattr(_TAPE, "tape", None) is not None or not time_net.is_cuda or time_net.dtype != f32
-            or time_net.dim() != 2 or time_net.shape[1] % 32 != 0 or time_net.shape[1] > 4096):
+            or time_net.dim() != 2 or time_net.shape[1] % 32 != 0 or time_net.shape[1] > 2048):
         return False
     pres: dict = {}
     for i in range(0, len(blocks), ops.TIME_PROJ_MAX):

@@ -499,7 +499,7 @@ int cfhip_silu_f32_fwd(const float* x, float* y, int64_t n, void* stream);
 int cfhip_silu_f32_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
 /* The per-block time-embedding projections of the UNet's residual blocks, every block in ONE launch (replaces `self.time_embedding`
  * = Sequential(SiLU, Linear) of each ResidualBlockWithTimeEmbedding: reference convs/residual.py:185-191,226-239, unet.py:154-190).
- *   out_i[b, :] = Linear_i(SiLU(emb[b, :])), i < count <= 32, emb f32 [B, K] (K % 32 == 0, K <= 4096) shared by all problems; bf16 SiLU(emb)
+ *   out_i[b, :] = Linear_i(SiLU(emb[b, :])), i < count <= 32, emb f32 [B, K] (K % 32 == 0, K <= 2048) shared by all problems; bf16 SiLU(emb)
  *   and bf16 weights, f32 accumulation and output (what the per-block GEMMs computed).  `table`: a HOST array of 4 int64 per problem —
  *   forward {weight bf16 [N, K] (16-byte aligned), bias f32 [N] or 0, out f32 [B, N], N}; backward {weight, dY f32 [B, N] or 0 (no gradient
  *   for that output), bf16 copy of dY [B, N] to write or 0, N}.  t_bf16: SiLU(emb) as bf16 [B, K] (out; the weight-gradient GEMMs' operand).
